@@ -1,0 +1,184 @@
+/*
+ * lpm_hip.h -- C ABI of liblpm_hip.so: the MI355X (gfx950) hot path behind the
+ * NetVladV1 / NetVladV2 model-registry API of pomonam/LearnablePoolingMethods.
+ *
+ * The reference is 100 % Python on TensorFlow 1.x and has no FFI of its own; each
+ * entry point below replaces the TF op sub-graph cited next to it (file:line under
+ * the reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted;
+ *   - the caller owns every buffer (the library never allocates or frees);
+ *   - tensors are contiguous row-major fp32 unless a leading dimension is passed;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and is
+ *     asynchronous; nothing synchronises internally;
+ *   - returns LPM_OK (0) or a negative LPM_ERR_*; lpm_last_error() (thread-local
+ *     string) says why;
+ *   - re-entrant; no global mutable state except the error string.
+ */
+#ifndef LPM_HIP_H
+#define LPM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPM_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef void* lpm_stream_t; /* hipStream_t */
+
+enum {
+    LPM_OK = 0,
+    LPM_ERR_BADARG = -1,
+    LPM_ERR_UNSUPPORTED_SHAPE = -2,
+    LPM_ERR_WORKSPACE = -3,
+    LPM_ERR_LAUNCH = -4
+};
+
+/* flags of lpm_vlad_aggregate_{fwd,bwd} */
+enum {
+    LPM_VLAD_SOFTMAX = 1,      /* `assign` holds logits; apply affine + softmax over K (NetVLAD)      */
+    LPM_VLAD_RESIDUAL = 2,     /* subtract (sum_t a) * centres (NetVLAD, NetVladAttenCluster)           */
+    LPM_VLAD_OUT_KMAJOR = 4    /* lpm_vlad_finalize_*: descriptor laid out [B,K,D] instead of [B,D*K]   */
+};
+
+int lpm_version(void);
+const char* lpm_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * a2 + a3: SampleUniformFrames + input_bn
+ *   replaces model_utils.py:101-122 (gather_nd) + frame_level_models.py:2265-2271 (slim.batch_norm).
+ * raw [B, max_frames, F]; num_frames [B] int32; S sampled frames per clip; rows = B*S.
+ * Training: lpm_frame_stats writes per-block column partials (sum, sum of squares) of the gathered
+ * rows into `partial` (lpm_frame_stats_workspace_bytes); lpm_bn_fold turns them into the folded
+ * affine and updates the moving statistics; lpm_frame_apply writes y = gather(raw)*scale + shift.
+ * ------------------------------------------------------------------------------------------- */
+size_t lpm_frame_stats_workspace_bytes(int B, int S, int F);
+int lpm_frame_stats(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
+                    float* partial, lpm_stream_t stream);
+int lpm_frame_apply(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
+                    const float* scale, const float* shift, float* y, lpm_stream_t stream);
+int lpm_frame_stats_nblk(int B, int S);   /* rows of `partial` lpm_frame_stats writes (for lpm_bn_fold) */
+/* backward of input_bn's affine parameters only (the frames are data, never a trainable tensor, so no
+ * gradient w.r.t. raw is produced): dgamma = sum dy*xhat, dbeta = sum dy over the gathered rows.
+ * dy [B*S, F] with row stride lddy; mean/var = the batch statistics lpm_bn_fold returned.
+ * workspace: lpm_frame_stats_workspace_bytes(B,S,F). */
+int lpm_frame_bn_bwd(const float* dy, int64_t lddy, const float* raw, const int32_t* num_frames, int B,
+                     int max_frames, int F, int S, const float* mean, const float* var, float eps, float* dgamma,
+                     float* dbeta, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training-mode batch-norm statistics -> folded affine
+ *   replaces the statistics half of slim.batch_norm (frame_level_models.py:2266,2784).
+ * partial [nblk, 2, C] (sum, sumsq over `rows` rows in total).  Outputs: mean, var (biased),
+ * scale = gamma*rsqrt(var+eps), shift = beta - mean*scale.  If moving_mean != NULL:
+ * moving = moving*decay + batch*(1-decay) with the unbiased variance (fused-BN semantics).
+ * ------------------------------------------------------------------------------------------- */
+int lpm_bn_fold(const float* partial, int nblk, int C, int64_t rows, const float* gamma, const float* beta,
+                float eps, float decay, float* mean, float* var, float* scale, float* shift,
+                float* moving_mean, float* moving_var, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1: soft-assignment GEMM  logits[M,K] = x[M,D] (row stride ldx) . w[D,K]
+ *   replaces tf.matmul at frame_level_models.py:2781 plus the batch-statistics reduction of the
+ *   cluster_bn that follows (:2783-2789): the epilogue writes per-block column partials
+ *   (sum, sumsq) into `partial` [lpm_assign_gemm_nblk(M), 2, K] for lpm_bn_fold.
+ * precision: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = split-bf16 (3 bf16 MFMAs, ~fp32).
+ * ------------------------------------------------------------------------------------------- */
+int lpm_assign_gemm_nblk(int M);
+int lpm_assign_gemm_fwd(const float* x, int64_t ldx, const float* w, int M, int D, int K, int precision,
+                        float* logits, float* partial, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2: fused [BN-affine -> softmax] -> residual aggregation -> intra-normalisation
+ *   replaces frame_level_models.py:2798-2819 (NetVLAD), :2856-2872 (LightVLAD, no RESIDUAL flag),
+ *   video_pooling_modules.py:1646-1655 (NetVladAttenCluster, no SOFTMAX flag).
+ * assign [B*T, K]: logits (SOFTMAX: a = softmax(assign*scale + shift), scale/shift [K], either may be
+ *   NULL = 1 / 0) or the similarities themselves.  x [B*T, D] with row stride ldx.  centres [D,K].
+ * Outputs: nrm [B, D, K] (d-major, each cluster column L2-normalised over D),
+ *          asum [B,K] = sum_t a, colsq [B,K] = column square norm before normalisation,
+ *          csq [B,K] = column square norm after it.
+ * lpm_vlad_finalize_fwd applies the global L2 (frame_level_models.py:2821-2822):
+ *   gsq[b] = sum_k csq[b,k]; out = nrm * rsqrt(max(gsq,1e-12)) laid out [B, D*K] (d-major, the
+ *   reference layout) or [B,K,D] with LPM_VLAD_OUT_KMAJOR (App. C5 view for the V1 encoders).
+ * ------------------------------------------------------------------------------------------- */
+int lpm_vlad_aggregate_fwd(const float* assign, const float* scale, const float* shift, const float* x,
+                           int64_t ldx, const float* centres, int B, int T, int D, int K, int flags,
+                           float* nrm, float* asum, float* colsq, float* csq, lpm_stream_t stream);
+int lpm_vlad_finalize_fwd(const float* nrm, const float* csq, int B, int D, int K, int flags, float* out,
+                          float* gsq, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3: backward of K2 (TF autodiff of the same lines; formulas SURVEY.md App. F.1-F.3).
+ * dout: gradient w.r.t. `out` in the layout given by flags.  Saved from forward: nrm, asum, colsq, csq, gsq.
+ * Outputs: dassign [B*T,K] = gradient w.r.t. the affine-transformed logits (SOFTMAX) or w.r.t. the
+ *   similarities; dx [B*T, D] row stride lddx, ACCUMULATED (+=) when accumulate_dx != 0;
+ *   dcentres [D,K] (overwritten; NULL without RESIDUAL).
+ * workspace: lpm_vlad_bwd_workspace_bytes(B,D,K) bytes of scratch.
+ * ------------------------------------------------------------------------------------------- */
+size_t lpm_vlad_bwd_workspace_bytes(int B, int D, int K);
+int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const float* asum, const float* colsq,
+                           const float* csq, const float* gsq, const float* assign, const float* scale,
+                           const float* shift, const float* x, int64_t ldx, const float* centres, int B, int T,
+                           int D, int K, int flags, float* dassign, float* dx, int64_t lddx, int accumulate_dx,
+                           float* dcentres, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward through the training-mode batch-norm on the logits:
+ *   in : dlt [M,K] (grad wrt gamma*Lhat+beta), logits L [M,K], mean, var [K], gamma [K]
+ *   out: dl [M,K] (may alias dlt), dgamma [K], dbeta [K].   workspace: lpm_bn_bwd_workspace_bytes(M,K).
+ * ------------------------------------------------------------------------------------------- */
+size_t lpm_bn_bwd_workspace_bytes(int M, int K);
+int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var, const float* gamma,
+               float eps, int M, int K, float* dl, float* dgamma, float* dbeta, void* workspace,
+               size_t workspace_bytes, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4: multi-head attention core  o = softmax(scale * q k^T) v   per (batch, head)
+ *   replaces transformer_utils.py:564-581 (split_heads, q scaling, matmul, softmax, matmul,
+ *   combine_heads).  q,k,v,o are the [B, L, h*d] outputs of the dense projections (heads
+ *   interleaved on the last axis, row stride ld); no [B,h,L,L] tensor is ever materialised.
+ *   lse [B,h,L] (log-sum-exp per query row) is saved for the backward.
+ *   lpm_mha_bwd: dz_partial (optional, used with key_scale) [B*h, 2, L] receives per-(batch,head)
+ *   column sums over the query axis of dz and dz*s (s = raw logit) for the logits_bn backward.
+ *   The batch-statistics term of that backward enters as two per-key vectors (both [L], optional):
+ *   ds = key_scale*dz - corr_a[key] - s*corr_b[key].  With dq = dk = dv = NULL only dz_partial is
+ *   produced (first pass of the two-pass logits_bn backward).
+ * With key_scale/key_shift != NULL (both [L]) the logits are first mapped
+ *   z[q,j] = (q.k_j)*key_scale[j] + key_shift[j] -- the folded logits_bn of MultiHeadAttentionBN
+ *   (transformer_utils.py:652-659); lpm_mha_logit_stats produces the column partials for it.
+ * Supported: d in {8,16}, L <= 512 (backward: L <= 448).
+ * ------------------------------------------------------------------------------------------- */
+int lpm_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d,
+                float scale, const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse,
+                lpm_stream_t stream);
+int lpm_mha_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
+                int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
+                const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
+                const float* corr_b, float* dz_partial, lpm_stream_t stream);
+size_t lpm_mha_logit_stats_workspace_bytes(int B, int L, int h);
+int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float* partial,
+                        lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a14 + a15: per-variable clip_by_norm + TF-style Adam over a flat parameter arena
+ *   replaces utils.clip_gradient_norms (utils.py:170-189) + tf.train.AdamOptimizer.apply_gradients
+ *   (train.py:336).  `offsets` [ntensors+1] (int64, DEVICE) delimits each variable inside the
+ *   flat fp32 arenas param/grad/m/v; every offset is a multiple of LPM_ARENA_ALIGN floats (padding
+ *   holds zeros).  scratch: lpm_clip_adam_scratch_bytes(total, ntensors).  step is 1-based.  Per variable:
+ *   g *= clip / max(||g||, clip);  m,v update;  p -= lr_t * m / (sqrt(v) + eps),
+ *   lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)   (epsilon outside the bias correction, as TF1).
+ * ------------------------------------------------------------------------------------------- */
+#define LPM_ARENA_ALIGN 4096
+size_t lpm_clip_adam_scratch_bytes(int64_t total, int ntensors);
+int lpm_multi_tensor_clip_adam(float* param, const float* grad, float* m, float* v, const int64_t* offsets,
+                               int ntensors, int64_t total, float clip_norm, float lr, float beta1, float beta2,
+                               float eps, int64_t step, float* scratch, lpm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPM_HIP_H */

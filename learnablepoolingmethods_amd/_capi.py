@@ -1,0 +1,105 @@
+"""ctypes binding of liblpm_hip.so (include/lpm_hip.h).
+
+This is the only place the Python host code touches the C ABI.  There is no CPU fallback:
+``load()`` raises if the library is missing, and every wrapper raises ``LpmError`` when the
+library reports a non-zero status (bad argument, unsupported shape, launch failure).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "liblpm_hip.so")
+
+LPM_VLAD_SOFTMAX = 1
+LPM_VLAD_RESIDUAL = 2
+LPM_VLAD_OUT_KMAJOR = 4
+
+# symbol -> (restype, argtypes); kept in one table so tests can check it against the header
+_f = C.c_void_p      # device pointer
+_i = C.c_int
+_l = C.c_int64
+_s = C.c_size_t
+_fl = C.c_float
+SIGNATURES = {
+    "lpm_version": (_i, []),
+    "lpm_last_error": (C.c_char_p, []),
+    "lpm_frame_stats_workspace_bytes": (_s, [_i, _i, _i]),
+    "lpm_frame_stats": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),
+    "lpm_frame_apply": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "lpm_frame_stats_nblk": (_i, [_i, _i]),
+    "lpm_frame_bn_bwd": (_i, [_f, _l, _f, _f, _i, _i, _i, _i, _f, _f, _fl, _f, _f, _f, _s, _f]),
+    "lpm_bn_fold": (_i, [_f, _i, _i, _l, _f, _f, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
+    "lpm_assign_gemm_nblk": (_i, [_i]),
+    "lpm_assign_gemm_fwd": (_i, [_f, _l, _f, _i, _i, _i, _i, _f, _f, _f]),
+    "lpm_vlad_aggregate_fwd": (_i, [_f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "lpm_vlad_finalize_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f]),
+    "lpm_vlad_bwd_workspace_bytes": (_s, [_i, _i, _i]),
+    "lpm_vlad_aggregate_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _l,
+                                    _i, _f, _f, _s, _f]),
+    "lpm_bn_bwd_workspace_bytes": (_s, [_i, _i]),
+    "lpm_bn_bwd": (_i, [_f, _f, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _s, _f]),
+    "lpm_mha_fwd": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),
+    "lpm_mha_bwd": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _l, _f, _f, _f, _f]),
+    "lpm_mha_logit_stats_workspace_bytes": (_s, [_i, _i, _i]),
+    "lpm_mha_logit_stats": (_i, [_f, _f, _l, _i, _i, _i, _i, _f, _f]),
+    "lpm_clip_adam_scratch_bytes": (_s, [_l, _i]),
+    "lpm_multi_tensor_clip_adam": (_i, [_f, _f, _f, _f, _f, _i, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _f]),
+}
+
+
+class LpmError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise LpmError(
+                f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (needs hipcc). There is no CPU fallback for the hot path.")
+        self._dll = C.CDLL(path)
+        self.path = path
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self._dll, name)  # AttributeError if the symbol is missing -> loud failure
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, "_" + name, fn)
+
+    def last_error(self) -> str:
+        return (self._lpm_last_error() or b"").decode()
+
+    def check(self, status: int, what: str):
+        if status != 0:
+            raise LpmError(f"{what} failed with status {status}: {self.last_error()}")
+
+    def version(self) -> int:
+        return self._lpm_version()
+
+
+_LIB: Optional[_Lib] = None
+
+
+def load() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib(LIB_PATH)
+    return _LIB
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a tensor (None -> NULL).  Raises unless the tensor is fp32/int on a GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LpmError("lpm ops need tensors on an MI355X (cuda/hip device); got a CPU tensor. "
+                       "There is no CPU fallback for the hot path.")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,172 @@
+// Training-mode batch-norm plumbing around the hot kernels (slim.batch_norm semantics,
+// SURVEY.md App. B): statistics fold (frame_level_models.py:2266,2784) and the backward
+// through the batch statistics of the assignment logits (App. F.4).
+#include "lpm_common.h"
+
+namespace lpm {
+
+// partial [nblk, 2, C] -> mean/var/scale/shift (+ moving averages).  One 1024-thread block per
+// 64 columns: 16 row groups stride over the partial rows, fp64 accumulation, LDS tree.
+__global__ __launch_bounds__(1024) void bn_fold_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                       double inv_rows, double unbias,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, float decay,
+                                                       float* mean, float* var, float* scale, float* shift,
+                                                       float* moving_mean, float* moving_var) {
+    __shared__ double sh[2][16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int b = rg; b < nblk; b += 16) {
+            const float* p = partial + (int64_t)b * 2 * C;
+            s += (double)p[c];
+            q += (double)p[C + c];
+        }
+    }
+    sh[0][rg][cl] = s;
+    sh[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        for (int i = 1; i < 16; ++i) {
+            s += sh[0][i][cl];
+            q += sh[1][i][cl];
+        }
+        const double mu = s * inv_rows;
+        double vr = q * inv_rows - mu * mu;
+        if (vr < 0.0) vr = 0.0;
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = g * (float)(1.0 / sqrt(vr + (double)eps));
+        if (mean) mean[c] = (float)mu;
+        if (var) var[c] = (float)vr;
+        scale[c] = sc;
+        shift[c] = b - (float)mu * sc;
+        if (moving_mean) {
+            moving_mean[c] = moving_mean[c] * decay + (float)mu * (1.f - decay);
+            moving_var[c] = moving_var[c] * decay + (float)(vr * unbias) * (1.f - decay);
+        }
+    }
+}
+
+// pass 1 of the BN backward: per-block column partials of dlt and dlt*Lhat.
+constexpr int BNB_ROWS = 64;
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dlt,
+                                                             const float* __restrict__ logits,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ var, float eps, int M,
+                                                             int K, float* __restrict__ partial) {
+    const int r0 = blockIdx.x * BNB_ROWS;
+    const int r1 = min(M, r0 + BNB_ROWS);
+    for (int c = threadIdx.x; c < K; c += 256) {
+        const float mu = mean[c], rstd = rsqrtf(var[c] + eps);
+        float s = 0.f, q = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const float d = dlt[(int64_t)r * K + c];
+            const float lh = (logits[(int64_t)r * K + c] - mu) * rstd;
+            s += d;
+            q += d * lh;
+        }
+        float* p = partial + (int64_t)blockIdx.x * 2 * K;
+        p[c] = s;
+        p[K + c] = q;
+    }
+}
+
+// pass 2: reduce partials -> dbeta (sum dlt), dgamma (sum dlt*Lhat)
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int K,
+                                                             float* dgamma, float* dbeta) {
+    __shared__ double sh[2][16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < K) {
+        for (int b = rg; b < nblk; b += 16) {
+            const float* p = partial + (int64_t)b * 2 * K;
+            s += (double)p[c];
+            q += (double)p[K + c];
+        }
+    }
+    sh[0][rg][cl] = s;
+    sh[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < K) {
+        for (int i = 1; i < 16; ++i) {
+            s += sh[0][i][cl];
+            q += sh[1][i][cl];
+        }
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)q;
+    }
+}
+
+// pass 3: dl = gamma*rstd*(dlt - mean_r(dlt) - Lhat*mean_r(dlt*Lhat))
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dlt,
+                                                           const float* __restrict__ logits,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ var,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float eps, int M, int K,
+                                                           float* __restrict__ dl) {
+    const int64_t total4 = (int64_t)M * K / 4;
+    const float invM = 1.f / (float)M;
+    const int K4 = K / 4;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % K4) * 4;
+        const float4 d = reinterpret_cast<const float4*>(dlt)[i];
+        const float4 l = reinterpret_cast<const float4*>(logits)[i];
+        float o[4];
+        const float dv[4] = {d.x, d.y, d.z, d.w}, lv[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float rstd = rsqrtf(var[c + j] + eps);
+            const float lh = (lv[j] - mean[c + j]) * rstd;
+            const float g = gamma ? gamma[c + j] : 1.f;
+            o[j] = g * rstd * (dv[j] - dbeta[c + j] * invM - lh * dgamma[c + j] * invM);
+        }
+        reinterpret_cast<float4*>(dl)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+}  // namespace lpm
+
+extern "C" int lpm_bn_fold(const float* partial, int nblk, int C, int64_t rows, const float* gamma, const float* beta,
+                           float eps, float decay, float* mean, float* var, float* scale, float* shift,
+                           float* moving_mean, float* moving_var, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(partial && scale && shift, LPM_ERR_BADARG, "lpm_bn_fold: null pointer");
+    LPM_REQUIRE(nblk > 0 && C > 0 && rows > 0, LPM_ERR_BADARG, "lpm_bn_fold: bad sizes");
+    LPM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), LPM_ERR_BADARG,
+                "lpm_bn_fold: moving_mean and moving_var must be given together");
+    const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C,
+                       1.0 / (double)rows, unbias, gamma, beta, eps, decay, mean, var, scale, shift, moving_mean,
+                       moving_var);
+    return check_launch("lpm_bn_fold");
+}
+
+extern "C" size_t lpm_bn_bwd_workspace_bytes(int M, int K) {
+    const int nblk = (M + lpm::BNB_ROWS - 1) / lpm::BNB_ROWS;
+    return (size_t)nblk * 2 * K * sizeof(float);
+}
+
+extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var,
+                          const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta,
+                          void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dlt && logits && mean && var && dl && dgamma && dbeta && workspace, LPM_ERR_BADARG,
+                "lpm_bn_bwd: null pointer");
+    LPM_REQUIRE(M > 0 && K > 0 && K % 4 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_bn_bwd: need K %% 4 == 0 (M=%d K=%d)", M, K);
+    LPM_REQUIRE(workspace_bytes >= lpm_bn_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE, "lpm_bn_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (M + BNB_ROWS - 1) / BNB_ROWS;
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, dlt, logits, mean, var, eps, M, K, partial);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((K + 63) / 64), dim3(1024), 0, s, partial, nblk, K, dgamma, dbeta);
+    const int64_t total4 = (int64_t)M * K / 4;
+    const int64_t want = (total4 + 255) / 256;
+    const int grid = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, dlt, logits, mean, var, gamma, dgamma, dbeta,
+                       eps, M, K, dl);
+    return check_launch("lpm_bn_bwd");
+}

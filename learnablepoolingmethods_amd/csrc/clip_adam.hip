@@ -1,0 +1,118 @@
+// a14 + a15 -- per-variable clip_by_norm fused with TF1-style Adam over a flat parameter arena.
+//   utils.clip_gradient_norms (utils.py:170-189): g *= c / max(||g||_2, c), per variable
+//   tf.train.AdamOptimizer (train.py:252,336): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+//                                              p -= lr_t * m / (sqrt(v) + eps)
+// Every variable starts at a multiple of LPM_ARENA_ALIGN floats inside the arena, so each
+// 4096-float chunk belongs to exactly one variable: pass 1 writes one partial sum of squares per
+// chunk, pass 2 reduces each variable's chunks in a fixed order (deterministic norms), pass 3
+// streams p/g/m/v once as float4 (HBM-bound: 28 B per parameter).
+#include "lpm_common.h"
+
+namespace lpm {
+
+constexpr int CA_CHUNK = 4096;   // == LPM_ARENA_ALIGN
+
+__global__ __launch_bounds__(256) void ca_chunk_sumsq_kernel(const float* __restrict__ g, int64_t total,
+                                                             float* __restrict__ chunk_ss) {
+    const int64_t base = (int64_t)blockIdx.x * CA_CHUNK;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CA_CHUNK / (256 * 4); ++i) {
+        const int64_t e = base + (int64_t)(i * 256 + threadIdx.x) * 4;
+        if (e + 3 < total) {
+            const float4 v = *reinterpret_cast<const float4*>(g + e);
+            s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+        }
+    }
+    s = wave_sum(s);
+    __shared__ float w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_ss[blockIdx.x] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+
+// one block per variable: factor[t] = clip / max(||g_t||, clip)   (1 when clip <= 0)
+__global__ __launch_bounds__(256) void ca_tensor_factor_kernel(const float* __restrict__ chunk_ss,
+                                                               const int64_t* __restrict__ offsets, float clip,
+                                                               float* __restrict__ factor) {
+    const int t = blockIdx.x;
+    const int64_t c0 = offsets[t] / CA_CHUNK, c1 = (offsets[t + 1] + CA_CHUNK - 1) / CA_CHUNK;
+    double s = 0.0;
+    for (int64_t c = c0 + threadIdx.x; c < c1; c += 256) s += (double)chunk_ss[c];
+    __shared__ double sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float nrm = (float)sqrt(sh[0]);
+        factor[t] = clip > 0.f ? clip / fmaxf(nrm, clip) : 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void ca_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       const int64_t* __restrict__ offsets, int ntensors,
+                                                       int64_t total, const float* __restrict__ factor, float lr_t,
+                                                       float b1, float b2, float eps) {
+    const int64_t base = (int64_t)blockIdx.x * CA_CHUNK;
+    // which variable owns this chunk: binary search on the (chunk-aligned) offsets
+    int lo = 0, hi = ntensors;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= base) lo = mid; else hi = mid;
+    }
+    const float f = factor[lo];
+#pragma unroll
+    for (int i = 0; i < CA_CHUNK / (256 * 4); ++i) {
+        const int64_t e = base + (int64_t)(i * 256 + threadIdx.x) * 4;
+        if (e + 3 < total) {
+            float4 pp = *reinterpret_cast<float4*>(p + e);
+            const float4 gg = *reinterpret_cast<const float4*>(g + e);
+            float4 mm = *reinterpret_cast<float4*>(m + e);
+            float4 vv = *reinterpret_cast<float4*>(v + e);
+#define LPM_ADAM1(c)                                             \
+    {                                                            \
+        const float gc = gg.c * f;                               \
+        mm.c = b1 * mm.c + (1.f - b1) * gc;                      \
+        vv.c = b2 * vv.c + (1.f - b2) * gc * gc;                 \
+        pp.c -= lr_t * mm.c / (sqrtf(vv.c) + eps);               \
+    }
+            LPM_ADAM1(x) LPM_ADAM1(y) LPM_ADAM1(z) LPM_ADAM1(w)
+#undef LPM_ADAM1
+            *reinterpret_cast<float4*>(p + e) = pp;
+            *reinterpret_cast<float4*>(m + e) = mm;
+            *reinterpret_cast<float4*>(v + e) = vv;
+        }
+    }
+}
+
+}  // namespace lpm
+
+extern "C" size_t lpm_clip_adam_scratch_bytes(int64_t total, int ntensors) {
+    const int64_t nchunk = (total + lpm::CA_CHUNK - 1) / lpm::CA_CHUNK;
+    return (size_t)(nchunk + ntensors) * sizeof(float);
+}
+
+extern "C" int lpm_multi_tensor_clip_adam(float* param, const float* grad, float* m, float* v, const int64_t* offsets,
+                                          int ntensors, int64_t total, float clip_norm, float lr, float beta1,
+                                          float beta2, float eps, int64_t step, float* scratch, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(param && grad && m && v && offsets && scratch, LPM_ERR_BADARG, "lpm_multi_tensor_clip_adam: null pointer");
+    LPM_REQUIRE(ntensors > 0 && total > 0 && step >= 1, LPM_ERR_BADARG, "lpm_multi_tensor_clip_adam: bad sizes (step is 1-based)");
+    LPM_REQUIRE(total % 4 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_multi_tensor_clip_adam: arena length must be a multiple of 4");
+    LPM_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_multi_tensor_clip_adam: arenas must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nchunk = (total + CA_CHUNK - 1) / CA_CHUNK;
+    float* chunk_ss = scratch;
+    float* factor = scratch + nchunk;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    hipLaunchKernelGGL(ca_chunk_sumsq_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, grad, total, chunk_ss);
+    hipLaunchKernelGGL(ca_tensor_factor_kernel, dim3(ntensors), dim3(256), 0, s, chunk_ss, offsets, clip_norm, factor);
+    hipLaunchKernelGGL(ca_apply_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, param, grad, m, v, offsets, ntensors, total,
+                       factor, (float)lr_t, beta1, beta2, eps);
+    return check_launch("lpm_multi_tensor_clip_adam");
+}

@@ -1,0 +1,79 @@
+// Shared device/host helpers for liblpm_hip.so (gfx950 only: 64-wide wavefronts, MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/lpm_hip.h"
+
+namespace lpm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+constexpr float kL2Eps = 1e-12f;  // tf.nn.l2_normalize epsilon
+
+// thread-local error string behind lpm_last_error()
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return LPM_ERR_LAUNCH;
+    }
+    return LPM_OK;
+}
+
+#define LPM_REQUIRE(cond, code, ...)  \
+    do {                              \
+        if (!(cond)) {                \
+            lpm::set_error(__VA_ARGS__); \
+            return (code);            \
+        }                             \
+    } while (0)
+
+// ---- wave-level reductions (64 lanes) -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce across the 32 lanes that share (lane >> 5): lanes of one half-wave
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact fp32.
+//   A operand: lane l supplies A[i = l & 31][k = l >> 5];  B operand: B[k = l >> 5][j = l & 31]
+//   C/D: lane l, reg r holds D[i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][j = l & 31]
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16], exact fp32.
+//   A: lane l supplies A[i = l & 15][k = l >> 4];  B: B[k = l >> 4][j = l & 15]
+//   C/D: lane l, reg r holds D[i = 4 * (l >> 4) + r][j = l & 15]
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// XCD-aware block remap: hardware places consecutive block ids round-robin over the 8 XCDs
+// (speed only, never correctness).  Returns a logical id such that logical ids
+// [g*per, (g+1)*per) of one group land on the same XCD when nblk % 8 == 0 handling is
+// bijective for any nblk (cdna guide 5.5 T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+}  // namespace lpm

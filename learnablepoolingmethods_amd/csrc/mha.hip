@@ -1,0 +1,447 @@
+// K4 -- multi-head attention core, forward + backward, never materialising [B,h,L,L].
+//   o = softmax(scale * q k^T) v                          transformer_utils.py:564-581
+//   MultiHeadAttentionBN variant: z = (q k^T) * key_scale[j] + key_shift[j] (folded logits_bn over the
+//   key-position channel, :652-659); lpm_mha_logit_stats reduces the column statistics it needs.
+//
+// gfx950 mapping.  One 256-thread workgroup per (batch, head); K and V (L x d, d in {8,16}) are staged
+// once into LDS (row stride 20 floats: both the "row-chunk" and the "column" MFMA operand walks are
+// at most 2-way bank conflicted).  Each wave owns 16-query tiles and works on TRANSPOSED score tiles
+// S^T[key, q] = K Q^T with v_mfma_f32_16x16x4_f32 (exact fp32): in that layout a lane owns one query
+// column (q = lane & 15) and 4 keys per register, so (a) the softmax reductions are register-local plus
+// two cross-lane steps, and (b) the probability tile is ALREADY the B operand of the next MFMA
+// (O^T = V^T P^T) -- no LDS round trip, no transposes.  The backward recomputes the tiles from the
+// saved log-sum-exp in two sweeps: per query tile (dQ) and per key tile (dK, dV), each reduction-free
+// across waves.
+#include "lpm_common.h"
+
+namespace lpm {
+
+constexpr int MH_S = 20;  // LDS row stride (floats) of the staged [L, d<=16] operands
+
+// stage rows [0, L) of a [B, L, h*d] tensor (head hh) into LDS [L16][MH_S]; columns >= d and rows >= L stay 0
+__device__ __forceinline__ void mha_stage(float* dst, const float* __restrict__ src, int64_t ld, int b, int L,
+                                          int hh, int d, int tid) {
+    const int d4 = d >> 2;
+    for (int i = tid; i < L * d4; i += 256) {
+        const int row = i / d4, c = (i % d4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + row) * ld + hh * d + c);
+        *reinterpret_cast<float4*>(dst + row * MH_S + c) = v;
+    }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, int64_t ld, int L, int h, int d,
+                                                      float scale, const float* __restrict__ key_scale,
+                                                      const float* __restrict__ key_shift, float* __restrict__ o,
+                                                      int64_t ldo, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nkt = (L + 15) >> 4, L16 = nkt * 16;
+    float* Ks = smem;
+    float* Vs = Ks + L16 * MH_S;
+    float* ksc = Vs + L16 * MH_S;
+    float* ksh = ksc + L16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    const int ns = d >> 2;  // reduction steps of 4 over the head dimension
+
+    for (int i = tid; i < 2 * L16 * MH_S; i += 256) smem[i] = 0.f;
+    for (int i = tid; i < L16; i += 256) {
+        ksc[i] = (key_scale && i < L) ? key_scale[i] : 1.f;
+        ksh[i] = (key_shift && i < L) ? key_shift[i] : 0.f;
+    }
+    __syncthreads();
+    mha_stage(Ks, k, ld, b, L, hh, d, tid);
+    mha_stage(Vs, v, ld, b, L, hh, d, tid);
+    __syncthreads();
+
+    for (int qt = wave; qt < nkt; qt += 4) {
+        const int qrow = qt * 16 + l15;
+        float qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[s] = (s < ns && qrow < L) ? q[((int64_t)b * L + qrow) * ld + hh * d + 4 * s + g] * scale : 0.f;
+        f32x4 p[NKT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt < nkt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* ka = Ks + (kt * 16 + l15) * MH_S + g;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < ns) acc = mfma16(ka[4 * s], qf[s], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    const float z = (key < L) ? fmaf(acc[r], ksc[key], ksh[key]) : -INFINITY;
+                    acc[r] = z;
+                    m = fmaxf(m, z);
+                }
+                p[kt] = acc;
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(p[kt][r] - m);
+                    p[kt][r] = e;
+                    sum += e;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt < nkt) {
+                const float* va = Vs + (kt * 16 + 4 * g) * MH_S + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc = mfma16(va[r * MH_S], p[kt][r], oacc);
+            }
+        }
+        const float inv = 1.f / sum;
+        if (qrow < L) {
+            if (4 * g < d) {
+                float4 ov = make_float4(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv);
+                *reinterpret_cast<float4*>(o + ((int64_t)b * L + qrow) * ldo + hh * d + 4 * g) = ov;
+            }
+            if (g == 0) lse[((int64_t)b * h + hh) * L + qrow] = m + __logf(sum);
+        }
+    }
+}
+
+// per (batch, head) column statistics of the raw logits s = q k^T over the query axis:
+// partial[(b*h+hh)][0][key] = sum_q s, [1][key] = sum_q s^2
+template <int NKT>
+__global__ __launch_bounds__(256) void mha_logit_stats_kernel(const float* __restrict__ q,
+                                                              const float* __restrict__ k, int64_t ld, int L, int h,
+                                                              int d, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nkt = (L + 15) >> 4, L16 = nkt * 16;
+    float* Ks = smem;
+    float* red = Ks + L16 * MH_S;   // [4 waves][2][L16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    const int ns = d >> 2;
+    for (int i = tid; i < L16 * MH_S; i += 256) smem[i] = 0.f;
+    __syncthreads();
+    mha_stage(Ks, k, ld, b, L, hh, d, tid);
+    __syncthreads();
+    f32x4 cs[NKT], cq[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        cs[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cq[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int qt = wave; qt < nkt; qt += 4) {
+        const int qrow = qt * 16 + l15;
+        float qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[s] = (s < ns && qrow < L) ? q[((int64_t)b * L + qrow) * ld + hh * d + 4 * s + g] : 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt < nkt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* ka = Ks + (kt * 16 + l15) * MH_S + g;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < ns) acc = mfma16(ka[4 * s], qf[s], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cs[kt][r] += acc[r];            // rows q >= L have q == 0 -> contribute 0
+                    cq[kt][r] = fmaf(acc[r], acc[r], cq[kt][r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = cs[kt][r], c = cq[kt][r];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    c += __shfl_xor(c, o, 64);
+                }
+                if (l15 == 0) {
+                    const int key = kt * 16 + 4 * g + r;
+                    red[(wave * 2 + 0) * L16 + key] = a;
+                    red[(wave * 2 + 1) * L16 + key] = c;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* out = partial + ((int64_t)b * h + hh) * 2 * L;
+    for (int key = tid; key < L; key += 256) {
+        out[key] = red[0 * L16 + key] + red[2 * L16 + key] + red[4 * L16 + key] + red[6 * L16 + key];
+        out[L + key] = red[1 * L16 + key] + red[3 * L16 + key] + red[5 * L16 + key] + red[7 * L16 + key];
+    }
+}
+
+// backward.  dz_partial (optional, with key_scale): [(b*h+hh)][0][key] = sum_q dz, [1][key] = sum_q dz * s
+__global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, int64_t ld,
+                                                      const float* __restrict__ o, const float* __restrict__ dout,
+                                                      int64_t ldo, const float* __restrict__ lse, int L, int h, int d,
+                                                      float scale, const float* __restrict__ key_scale,
+                                                      const float* __restrict__ key_shift, float* __restrict__ dq,
+                                                      float* __restrict__ dk, float* __restrict__ dv, int64_t ldd,
+                                                      const float* __restrict__ corr_a,
+                                                      const float* __restrict__ corr_b,
+                                                      float* __restrict__ dz_partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nkt = (L + 15) >> 4, L16 = nkt * 16;
+    float* Ks = smem;
+    float* Vs = Ks + L16 * MH_S;
+    float* Qs = Vs + L16 * MH_S;
+    float* Gs = Qs + L16 * MH_S;     // dO
+    float* ksc = Gs + L16 * MH_S;
+    float* ksh = ksc + L16;
+    float* lses = ksh + L16;
+    float* Dq = lses + L16;          // rowsum(P * dP) = <dO_q, O_q>
+    float* cas = Dq + L16;           // logits-BN batch-statistics correction: ds = ksc*dz - ca - s*cb
+    float* cbs = cas + L16;
+    const bool stats_only = (dq == nullptr);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    const int ns = d >> 2, d4 = d >> 2;
+
+    for (int i = tid; i < 4 * L16 * MH_S; i += 256) smem[i] = 0.f;
+    for (int i = tid; i < L16; i += 256) {
+        ksc[i] = (key_scale && i < L) ? key_scale[i] : 1.f;
+        ksh[i] = (key_shift && i < L) ? key_shift[i] : 0.f;
+        lses[i] = (i < L) ? lse[((int64_t)b * h + hh) * L + i] : INFINITY;   // padded queries -> p = 0
+        Dq[i] = 0.f;
+        cas[i] = (corr_a && i < L) ? corr_a[i] : 0.f;
+        cbs[i] = (corr_b && i < L) ? corr_b[i] : 0.f;
+    }
+    __syncthreads();
+    mha_stage(Ks, k, ld, b, L, hh, d, tid);
+    mha_stage(Vs, v, ld, b, L, hh, d, tid);
+    mha_stage(Qs, q, ld, b, L, hh, d, tid);
+    // dO and D_q: d4 consecutive threads share a row
+    for (int i0 = 0; i0 < L * d4; i0 += 256) {
+        const int i = i0 + tid;
+        float part = 0.f;
+        int row = 0;
+        if (i < L * d4) {
+            row = i / d4;
+            const int c = (i % d4) * 4;
+            const int64_t off = ((int64_t)b * L + row) * ldo + hh * d + c;
+            const float4 gv = *reinterpret_cast<const float4*>(dout + off);
+            const float4 ov = *reinterpret_cast<const float4*>(o + off);
+            *reinterpret_cast<float4*>(Gs + row * MH_S + c) = gv;
+            part = gv.x * ov.x + gv.y * ov.y + gv.z * ov.z + gv.w * ov.w;
+        }
+        part += __shfl_xor(part, 1, 64);
+        if (d4 == 4) part += __shfl_xor(part, 2, 64);
+        if (i < L * d4 && (i % d4) == 0) Dq[row] = part;
+    }
+    __syncthreads();
+
+    // ---- sweep A: one query tile per wave iteration -> dQ ---------------------------------------
+    for (int qt = wave; qt < nkt && !stats_only; qt += 4) {
+        const int qrow = qt * 16 + l15;
+        float qf[4], gf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = (s < ns) ? Qs[qrow * MH_S + 4 * s + g] * scale : 0.f;
+            gf[s] = (s < ns) ? Gs[qrow * MH_S + 4 * s + g] : 0.f;
+        }
+        const float lq = lses[qrow], dqv = Dq[qrow];
+        f32x4 dqa = {0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            const float* ka = Ks + (kt * 16 + l15) * MH_S + g;
+            const float* va = Vs + (kt * 16 + l15) * MH_S + g;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < ns) {
+                    st = mfma16(ka[4 * s], qf[s], st);     // S^T[key, q]
+                    dp = mfma16(va[4 * s], gf[s], dp);     // dP^T[key, q] = V dO^T
+                }
+            }
+            const float* kc = Ks + (kt * 16 + 4 * g) * MH_S + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                const float z = (key < L) ? fmaf(st[r], ksc[key], ksh[key]) : -INFINITY;
+                const float p = __expf(z - lq);
+                const float ds = p * (dp[r] - dqv) * ksc[key] - cas[key] - st[r] * cbs[key];
+                dqa = mfma16(kc[r * MH_S], ds, dqa);       // dQ^T[dd, q] += K^T[dd, key] dS^T[key, q]
+            }
+        }
+        if (qrow < L && 4 * g < d) {
+            float4 ov = make_float4(dqa[0] * scale, dqa[1] * scale, dqa[2] * scale, dqa[3] * scale);
+            *reinterpret_cast<float4*>(dq + ((int64_t)b * L + qrow) * ldd + hh * d + 4 * g) = ov;
+        }
+    }
+
+    // ---- sweep B: one key tile per wave iteration -> dK, dV (+ logits-BN partial sums) -----------
+    for (int kt = wave; kt < nkt; kt += 4) {
+        const int krow = kt * 16 + l15;
+        float kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = (s < ns) ? Ks[krow * MH_S + 4 * s + g] : 0.f;
+            vf[s] = (s < ns) ? Vs[krow * MH_S + 4 * s + g] : 0.f;
+        }
+        const float sck = ksc[krow], shk = ksh[krow], cak = cas[krow], cbk = cbs[krow];
+        f32x4 dka = {0.f, 0.f, 0.f, 0.f}, dva = {0.f, 0.f, 0.f, 0.f};
+        float zs = 0.f, zq = 0.f;
+        for (int qt = 0; qt < nkt; ++qt) {
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            const float* qa = Qs + (qt * 16 + l15) * MH_S + g;
+            const float* ga = Gs + (qt * 16 + l15) * MH_S + g;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < ns) {
+                    st = mfma16(qa[4 * s], kf[s], st);     // S[q, key]
+                    dp = mfma16(ga[4 * s], vf[s], dp);     // dP[q, key] = dO V^T
+                }
+            }
+            const float* qc = Qs + (qt * 16 + 4 * g) * MH_S + l15;
+            const float* gc = Gs + (qt * 16 + 4 * g) * MH_S + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qr = qt * 16 + 4 * g + r;
+                const float sraw = st[r] * scale;
+                const float z = (krow < L) ? fmaf(sraw, sck, shk) : -INFINITY;
+                const float p = __expf(z - lses[qr]);
+                const float dz = p * (dp[r] - Dq[qr]);
+                zs += dz;
+                zq = fmaf(dz, sraw, zq);
+                if (!stats_only) {
+                    const float ds = (qr < L) ? dz * sck - cak - sraw * cbk : 0.f;
+                    dva = mfma16(gc[r * MH_S], p, dva);      // dV^T[dd, key] += dO^T[dd, q] P[q, key]
+                    dka = mfma16(qc[r * MH_S], ds, dka);     // dK^T[dd, key] += Q^T[dd, q] dS[q, key]
+                }
+            }
+        }
+        if (!stats_only && krow < L && 4 * g < d) {
+            const int64_t off = ((int64_t)b * L + krow) * ldd + hh * d + 4 * g;
+            *reinterpret_cast<float4*>(dk + off) = make_float4(dka[0] * scale, dka[1] * scale, dka[2] * scale, dka[3] * scale);
+            *reinterpret_cast<float4*>(dv + off) = make_float4(dva[0], dva[1], dva[2], dva[3]);
+        }
+        if (dz_partial) {
+            zs += __shfl_xor(zs, 16, 64); zs += __shfl_xor(zs, 32, 64);
+            zq += __shfl_xor(zq, 16, 64); zq += __shfl_xor(zq, 32, 64);
+            if (g == 0 && krow < L) {
+                float* out = dz_partial + ((int64_t)b * h + hh) * 2 * L;
+                out[krow] = zs;
+                out[L + krow] = zq;
+            }
+        }
+    }
+}
+
+static inline size_t mha_fwd_lds(int L) { const int L16 = ((L + 15) / 16) * 16; return (size_t)(2 * L16 * MH_S + 2 * L16) * 4; }
+static inline size_t mha_stats_lds(int L) { const int L16 = ((L + 15) / 16) * 16; return (size_t)(L16 * MH_S + 8 * L16) * 4; }
+static inline size_t mha_bwd_lds(int L) { const int L16 = ((L + 15) / 16) * 16; return (size_t)(4 * L16 * MH_S + 6 * L16) * 4; }
+
+template <typename KernT>
+static int reserve_lds(KernT kern, size_t bytes, const char* what) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: cannot reserve %zu bytes of LDS", what, bytes);
+        return LPM_ERR_LAUNCH;
+    }
+    return LPM_OK;
+}
+
+}  // namespace lpm
+
+#define LPM_MHA_CHECK(name)                                                                                       \
+    LPM_REQUIRE(B > 0 && L > 0 && h > 0 && (d == 8 || d == 16) && L <= 512, LPM_ERR_UNSUPPORTED_SHAPE,              \
+                name ": need d in {8,16} and L <= 512 (L=%d d=%d)", L, d);                                          \
+    LPM_REQUIRE(ld >= (int64_t)h * d && ld % 4 == 0, LPM_ERR_BADARG, name ": bad leading dimension")
+
+extern "C" int lpm_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d,
+                           float scale, const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse,
+                           lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o && lse, LPM_ERR_BADARG, "lpm_mha_fwd: null pointer");
+    LPM_MHA_CHECK("lpm_mha_fwd");
+    LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_fwd: key_scale/key_shift go together");
+    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0, LPM_ERR_BADARG, "lpm_mha_fwd: bad ldo");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = mha_fwd_lds(L);
+    const int nkt = (L + 15) / 16;
+    dim3 grid(B * h);
+#define LPM_MHA_FWD(N)                                                                                           \
+    do {                                                                                                         \
+        auto kern = mha_fwd_kernel<N>;                                                                           \
+        if (int rc = reserve_lds(kern, lds, "lpm_mha_fwd")) return rc;                                           \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ld, L, h, d, scale, key_scale, key_shift, o, ldo, lse); \
+    } while (0)
+    if (nkt <= 4) LPM_MHA_FWD(4);
+    else if (nkt <= 8) LPM_MHA_FWD(8);
+    else if (nkt <= 16) LPM_MHA_FWD(16);
+    else if (nkt <= 20) LPM_MHA_FWD(20);
+    else LPM_MHA_FWD(32);
+#undef LPM_MHA_FWD
+    return check_launch("lpm_mha_fwd");
+}
+
+extern "C" size_t lpm_mha_logit_stats_workspace_bytes(int B, int L, int h) { return (size_t)B * h * 2 * L * sizeof(float); }
+
+extern "C" int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float* partial,
+                                   lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && partial, LPM_ERR_BADARG, "lpm_mha_logit_stats: null pointer");
+    LPM_MHA_CHECK("lpm_mha_logit_stats");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = mha_stats_lds(L);
+    const int nkt = (L + 15) / 16;
+    dim3 grid(B * h);
+#define LPM_MHA_ST(N)                                                                                   \
+    do {                                                                                                \
+        auto kern = mha_logit_stats_kernel<N>;                                                          \
+        if (int rc = reserve_lds(kern, lds, "lpm_mha_logit_stats")) return rc;                          \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, ld, L, h, d, partial);                  \
+    } while (0)
+    if (nkt <= 4) LPM_MHA_ST(4);
+    else if (nkt <= 8) LPM_MHA_ST(8);
+    else if (nkt <= 16) LPM_MHA_ST(16);
+    else if (nkt <= 20) LPM_MHA_ST(20);
+    else LPM_MHA_ST(32);
+#undef LPM_MHA_ST
+    return check_launch("lpm_mha_logit_stats");
+}
+
+extern "C" int lpm_mha_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
+                           int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
+                           const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
+                           const float* corr_b, float* dz_partial, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o && dout && lse, LPM_ERR_BADARG, "lpm_mha_bwd: null pointer");
+    LPM_REQUIRE((dq && dk && dv) || (!dq && !dk && !dv && dz_partial), LPM_ERR_BADARG,
+                "lpm_mha_bwd: give dq, dk, dv together, or none of them (statistics-only pass needs dz_partial)");
+    LPM_REQUIRE((corr_a == nullptr) == (corr_b == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd: corr_a/corr_b go together");
+    LPM_MHA_CHECK("lpm_mha_bwd");
+    LPM_REQUIRE(L <= 448, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bwd: L <= 448 (four staged operands must fit 160 KB of LDS), L=%d", L);
+    LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd: key_scale/key_shift go together");
+    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0, LPM_ERR_BADARG, "lpm_mha_bwd: bad ldo/ldd");
+    const size_t lds = mha_bwd_lds(L);
+    if (int rc = reserve_lds(mha_bwd_kernel, lds, "lpm_mha_bwd")) return rc;
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * h), dim3(256), lds, (hipStream_t)stream, q, k, v, ld, o, dout, ldo, lse, L, h, d,
+                       scale, key_scale, key_shift, dq, dk, dv, ldd, corr_a, corr_b, dz_partial);
+    return check_launch("lpm_mha_bwd");
+}

@@ -1,0 +1,413 @@
+// K3 -- backward of K2 (the reference has no backward code: TF autodiff of
+// frame_level_models.py:2798-2822 / video_pooling_modules.py:1646-1658; closed forms in SURVEY.md
+// App. F.1-F.3, restated and checked against autograd in oracle/numpy_ref.py).
+//
+// With N the intra-normalised descriptor saved by K2 and per-(clip,cluster) scalars
+//   p = <dO_k, N_k>, alpha = <dO, O>:    dU[:,k] = u_k * dO[:,k] - v_k * N[:,k]
+//   u_k = inv_n_k * inv_g,   v_k = u_k * (m_g * alpha * inv_g * (1 - m_k c_k) + m_k p_k)
+// (m_* = "clamp inactive").  Then
+//   dA[t,k] = sum_d x[t,d] dU[d,k] - ctil_k,  ctil_k = sum_d dU[d,k] W2[d,k]
+//   dx[t,d] = sum_k A[t,k] dU[d,k]
+//   dW2[d,k] = - sum_b s_b[k] dU_b[d,k]
+//   dlogit~[t,k] = A (dA - sum_j A_j dA_j)                      (softmax, F.3)
+//
+// Launch sequence: (0) optional k-major -> d-major transpose of dO; (1) column dots, split 4-way over
+// D for parallelism; (2) coefficients; (3) main kernel, one workgroup per (clip, 32-frame slab): both
+// GEMMs share one pass over dU, which is formed on the fly from dO and N while staging 32-row d-chunks
+// into LDS (dU never reaches HBM), v_mfma_f32_32x32x2_f32 accumulation, the softmax backward is done
+// on the workgroup's 32 x K tile in LDS; (4) dW2 as a clip-loop per (d,k) float4.
+#include "lpm_common.h"
+
+namespace lpm {
+
+constexpr int VB_TS = 32;     // frames per workgroup in the main kernel
+constexpr int VB_DC = 32;     // d rows per staged chunk
+constexpr int VB_DSPLIT = 4;  // column-dot split over D
+
+// [B,K,D] -> [B,D,K]
+__global__ __launch_bounds__(256) void vlad_kmajor_to_dmajor_kernel(const float* __restrict__ src, int D, int K,
+                                                                    float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, d0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* s = src + (int64_t)b * K * D;
+    float* o = dst + (int64_t)b * D * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i;
+        tile[ty + 8 * i][tx] = (k < K) ? s[(int64_t)k * D + d0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = d0 + ty + 8 * i, k = k0 + tx;
+        if (k < K) o[(int64_t)d * K + k] = tile[tx][ty + 8 * i];
+    }
+}
+
+// dots[b][split][0..2][k]: <dO_k,N_k>, <dO_k,W2_k>, <N_k,W2_k> over the split's quarter of D
+__global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __restrict__ dO,
+                                                               const float* __restrict__ N,
+                                                               const float* __restrict__ W2, int D, int K,
+                                                               float* __restrict__ dots) {
+    const int b = blockIdx.x, sp = blockIdx.y;
+    const int dper = D / VB_DSPLIT, d0 = sp * dper;
+    const float* pdo = dO + ((int64_t)b * D + d0) * K;
+    const float* pn = N + ((int64_t)b * D + d0) * K;
+    const float* pw = W2 ? W2 + (int64_t)d0 * K : nullptr;
+    float* out = dots + ((int64_t)b * VB_DSPLIT + sp) * 3 * K;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float p = 0.f, dw = 0.f, nw = 0.f;
+#pragma unroll 4
+        for (int d = 0; d < dper; ++d) {
+            const float a = pdo[(int64_t)d * K + k], n = pn[(int64_t)d * K + k];
+            const float w = pw ? pw[(int64_t)d * K + k] : 0.f;
+            p = fmaf(a, n, p);
+            dw = fmaf(a, w, dw);
+            nw = fmaf(n, w, nw);
+        }
+        out[k] = p;
+        out[K + k] = dw;
+        out[2 * K + k] = nw;
+    }
+}
+
+// per clip: alpha, then u, v, ctil per cluster
+__global__ __launch_bounds__(256) void vlad_bwd_coeff_kernel(const float* __restrict__ dots,
+                                                             const float* __restrict__ colsq,
+                                                             const float* __restrict__ csq,
+                                                             const float* __restrict__ gsq, int K,
+                                                             float* __restrict__ u, float* __restrict__ v,
+                                                             float* __restrict__ ctil) {
+    __shared__ float wsum[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* dp = dots + (int64_t)b * VB_DSPLIT * 3 * K;
+    float psum = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        float p = 0.f;
+#pragma unroll
+        for (int s = 0; s < VB_DSPLIT; ++s) p += dp[s * 3 * K + k];
+        psum += p;
+    }
+    psum = wave_sum(psum);
+    if ((tid & 63) == 0) wsum[tid >> 6] = psum;
+    __syncthreads();
+    const float g = gsq[b];
+    const float inv_g = rsqrtf(fmaxf(g, kL2Eps));
+    const float m_g = (g >= kL2Eps) ? 1.f : 0.f;
+    const float alpha = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_g;   // <dO, O>
+    for (int k = tid; k < K; k += 256) {
+        float p = 0.f, dw = 0.f, nw = 0.f;
+#pragma unroll
+        for (int s = 0; s < VB_DSPLIT; ++s) {
+            p += dp[s * 3 * K + k];
+            dw += dp[s * 3 * K + K + k];
+            nw += dp[s * 3 * K + 2 * K + k];
+        }
+        const float n = colsq[(int64_t)b * K + k], c = csq[(int64_t)b * K + k];
+        const float m_k = (n >= kL2Eps) ? 1.f : 0.f;
+        const float uu = rsqrtf(fmaxf(n, kL2Eps)) * inv_g;
+        const float vv = uu * (m_g * alpha * inv_g * (1.f - m_k * c) + m_k * p);
+        u[(int64_t)b * K + k] = uu;
+        v[(int64_t)b * K + k] = vv;
+        ctil[(int64_t)b * K + k] = uu * dw - vv * nw;
+    }
+}
+
+// main backward kernel: workgroup = (clip, 32-frame slab).  KTW = k-tiles (32 clusters) per wave.
+template <int KTW, bool SOFTMAX>
+__global__ __launch_bounds__(256) void vlad_bwd_main_kernel(
+    const float* __restrict__ dO, const float* __restrict__ N, const float* __restrict__ ug,
+    const float* __restrict__ vg, const float* __restrict__ cg, const float* __restrict__ assign,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ x, int64_t ldx,
+    int T, int D, int K, int nts, float* __restrict__ dassign, float* __restrict__ dx, int64_t lddx,
+    int accumulate) {
+    constexpr int KPL = 2 * KTW;          // logits columns per lane in a row pass
+    constexpr int NP = 4 * KTW;           // float4 staging passes per d-chunk (32 rows x K/4 float4 / 256 thr)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int KS = K + 1;                 // padded row stride (column-wise MFMA operand reads)
+    float* As = smem;                     // [32][KS]  assignment tile
+    float* dUs = As + VB_TS * KS;         // [32][KS]  dU chunk; later dA - ctil
+    float* xs = dUs + VB_DC * KS;         // [32][33]  x chunk
+    float* red = xs + 32 * 33;            // [4][32][33] per-wave partial dx tiles
+    float* cu = red + 4 * 32 * 33;        // [K] u, [K] v, [K] ctil
+    float* cv = cu + K;
+    float* cc = cv + K;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / nts, t0 = (lid % nts) * VB_TS;
+    const int KT = (K + 31) / 32;
+    const int K4 = K / 4;
+
+    for (int k = tid; k < K; k += 256) {
+        cu[k] = ug[(int64_t)b * K + k];
+        cv[k] = vg[(int64_t)b * K + k];
+        cc[k] = cg[(int64_t)b * K + k];
+    }
+    // ---- prologue: assignment tile (softmax recomputed from the logits) ----------------------
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, t = t0 + row;
+        const float* ar = assign + ((int64_t)b * T + t) * K;
+        float vals[KPL];
+        if (SOFTMAX) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int c = lane + 64 * j;
+                float lv = -INFINITY;
+                if (t < T && c < K) lv = fmaf(ar[c], scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
+                vals[j] = lv;
+                m = fmaxf(m, lv);
+            }
+            m = wave_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                vals[j] = (t < T) ? __expf(vals[j] - m) : 0.f;
+                sum += vals[j];
+            }
+            sum = wave_sum(sum);
+            const float inv = (t < T) ? 1.f / sum : 0.f;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < K) As[row * KS + c] = vals[j] * inv;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < K) As[row * KS + c] = (t < T) ? ar[c] : 0.f;
+            }
+        }
+    }
+
+    // ---- staging helpers -----------------------------------------------------------------------
+    float4 rdo[NP], rn[NP], rx;
+    const float* dOb = dO + (int64_t)b * D * K;
+    const float* Nb = N + (int64_t)b * D * K;
+    const int xt = tid >> 3, xc = (tid & 7) * 4;
+    const bool xok = (t0 + xt) < T;
+    const float* xrow = x + ((int64_t)b * T + t0 + xt) * ldx + xc;
+    auto gload = [&](int d0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int f = tid + 256 * i;
+            const int r = f / K4;
+            if (r < VB_DC) {
+                const int64_t off = (int64_t)(d0 + r) * K + (f % K4) * 4;
+                rdo[i] = *reinterpret_cast<const float4*>(dOb + off);
+                rn[i] = *reinterpret_cast<const float4*>(Nb + off);
+            }
+        }
+        rx = xok ? *reinterpret_cast<const float4*>(xrow + d0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int f = tid + 256 * i;
+            const int r = f / K4;
+            if (r < VB_DC) {
+                const int k = (f % K4) * 4;
+                float* dst = dUs + r * KS + k;
+                dst[0] = cu[k + 0] * rdo[i].x - cv[k + 0] * rn[i].x;
+                dst[1] = cu[k + 1] * rdo[i].y - cv[k + 1] * rn[i].y;
+                dst[2] = cu[k + 2] * rdo[i].z - cv[k + 2] * rn[i].z;
+                dst[3] = cu[k + 3] * rdo[i].w - cv[k + 3] * rn[i].w;
+            }
+        }
+        float* xd = xs + xt * 33 + xc;
+        xd[0] = rx.x; xd[1] = rx.y; xd[2] = rx.z; xd[3] = rx.w;
+    };
+
+    f32x16 accA[KTW];
+#pragma unroll
+    for (int i = 0; i < KTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[i][r] = 0.f;
+
+    const int nchunk = D / VB_DC;
+    gload(0);
+    __syncthreads();          // cu/cv visible, As complete
+    sstore();
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int d0 = c * VB_DC;
+        if (c + 1 < nchunk) gload(d0 + VB_DC);
+        f32x16 accX;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accX[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) {
+            const int tile = wave + 4 * i;
+            if (tile < KT) {
+                // dA[t, tile] += x[t, dchunk] . dU[dchunk, tile]
+                const float* xa = xs + l31 * 33 + half;
+                const float* ub = dUs + half * KS + tile * 32 + l31;
+#pragma unroll
+                for (int dd = 0; dd < VB_DC; dd += 2) accA[i] = mfma32(xa[dd], ub[dd * KS], accA[i]);
+                // dx[t, dchunk] += A[t, tile] . dU[dchunk, tile]^T
+                const float* aa = As + l31 * KS + tile * 32 + half;
+                const float* ud = dUs + l31 * KS + tile * 32 + half;
+#pragma unroll
+                for (int kk = 0; kk < 32; kk += 2) accX = mfma32(aa[kk], ud[kk], accX);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave * 32 * 33 + mfma32_row(r, lane) * 33 + l31] = accX[r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const int tt = e >> 5, dd = e & 31;
+            const float s = red[tt * 33 + dd] + red[32 * 33 + tt * 33 + dd] + red[2 * 32 * 33 + tt * 33 + dd] +
+                            red[3 * 32 * 33 + tt * 33 + dd];
+            if (t0 + tt < T) {
+                float* p = dx + ((int64_t)b * T + t0 + tt) * lddx + d0 + dd;
+                *p = accumulate ? (*p + s) : s;
+            }
+        }
+        if (c + 1 < nchunk) sstore();
+        __syncthreads();
+    }
+
+    // ---- epilogue: dA - ctil -> LDS, softmax backward row-wise ---------------------------------
+#pragma unroll
+    for (int i = 0; i < KTW; ++i) {
+        const int tile = wave + 4 * i;
+        if (tile < KT) {
+            const int k = tile * 32 + l31;
+            if (k < K) {
+                const float ct = cc[k];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dUs[mfma32_row(r, lane) * KS + k] = accA[i][r] - ct;
+            }
+        }
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, t = t0 + row;
+        if (t >= T) continue;   // wave-uniform
+        float* out = dassign + ((int64_t)b * T + t) * K;
+        if (SOFTMAX) {
+            float a[KPL], g[KPL], dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int c = lane + 64 * j;
+                a[j] = (c < K) ? As[row * KS + c] : 0.f;
+                g[j] = (c < K) ? dUs[row * KS + c] : 0.f;
+                dot = fmaf(a[j], g[j], dot);
+            }
+            dot = wave_sum(dot);
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < K) out[c] = a[j] * (g[j] - dot);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < K) out[c] = dUs[row * KS + c];
+            }
+        }
+    }
+}
+
+// dW2[d,k] = - sum_b s[b,k] * (u[b,k] dO[b,d,k] - v[b,k] N[b,d,k])
+__global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __restrict__ dO,
+                                                                const float* __restrict__ N,
+                                                                const float* __restrict__ asum,
+                                                                const float* __restrict__ u,
+                                                                const float* __restrict__ v, int B, int D, int K,
+                                                                float* __restrict__ dW2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index into [D,K]
+    const int64_t n4 = (int64_t)D * K / 4;
+    if (i >= n4) return;
+    const int k = (int)((i * 4) % K);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < B; ++b) {
+        const float4 a = reinterpret_cast<const float4*>(dO + (int64_t)b * D * K)[i];
+        const float4 n = reinterpret_cast<const float4*>(N + (int64_t)b * D * K)[i];
+        const float4 s = *reinterpret_cast<const float4*>(asum + (int64_t)b * K + k);
+        const float4 uu = *reinterpret_cast<const float4*>(u + (int64_t)b * K + k);
+        const float4 vv = *reinterpret_cast<const float4*>(v + (int64_t)b * K + k);
+        acc.x -= s.x * (uu.x * a.x - vv.x * n.x);
+        acc.y -= s.y * (uu.y * a.y - vv.y * n.y);
+        acc.z -= s.z * (uu.z * a.z - vv.z * n.z);
+        acc.w -= s.w * (uu.w * a.w - vv.w * n.w);
+    }
+    reinterpret_cast<float4*>(dW2)[i] = acc;
+}
+
+static size_t bwd_main_lds_bytes(int K) {
+    return (size_t)(2 * 32 * (K + 1) + 32 * 33 + 4 * 32 * 33 + 3 * K) * sizeof(float);
+}
+
+}  // namespace lpm
+
+extern "C" size_t lpm_vlad_bwd_workspace_bytes(int B, int D, int K) {
+    return ((size_t)B * lpm::VB_DSPLIT * 3 * K + 3 * (size_t)B * K + (size_t)B * D * K) * sizeof(float);
+}
+
+extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const float* asum, const float* colsq,
+                                      const float* csq, const float* gsq, const float* assign, const float* scale,
+                                      const float* shift, const float* x, int64_t ldx, const float* centres, int B,
+                                      int T, int D, int K, int flags, float* dassign, float* dx, int64_t lddx,
+                                      int accumulate_dx, float* dcentres, void* workspace, size_t workspace_bytes,
+                                      lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dout && nrm && asum && colsq && csq && gsq && assign && x && dassign && dx && workspace,
+                LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd: null pointer");
+    const bool residual = (flags & LPM_VLAD_RESIDUAL) != 0;
+    const bool sm = (flags & LPM_VLAD_SOFTMAX) != 0;
+    LPM_REQUIRE(!residual || (centres && dcentres), LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd: RESIDUAL needs centres/dcentres");
+    LPM_REQUIRE(B > 0 && T > 0 && ldx >= D && lddx >= D, LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd: bad sizes");
+    LPM_REQUIRE(D % 128 == 0 && K % 4 == 0 && K <= 512 && ldx % 4 == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_bwd: need D %% 128 == 0, K %% 4 == 0, K <= 512, ldx %% 4 == 0 (D=%d K=%d)", D, K);
+    LPM_REQUIRE(workspace_bytes >= lpm_vlad_bwd_workspace_bytes(B, D, K), LPM_ERR_WORKSPACE,
+                "lpm_vlad_aggregate_bwd: workspace too small");
+    LPM_REQUIRE((((uintptr_t)x | (uintptr_t)dout | (uintptr_t)nrm | (uintptr_t)workspace) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_vlad_aggregate_bwd: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    float* dots = ws;
+    float* u = dots + (size_t)B * VB_DSPLIT * 3 * K;
+    float* v = u + (size_t)B * K;
+    float* ctil = v + (size_t)B * K;
+    float* dod = ctil + (size_t)B * K;   // d-major copy of dout when it arrives k-major
+    const float* dO = dout;
+    if (flags & LPM_VLAD_OUT_KMAJOR) {
+        hipLaunchKernelGGL(vlad_kmajor_to_dmajor_kernel, dim3(D / 32, (K + 31) / 32, B), dim3(256), 0, s, dout, D, K, dod);
+        dO = dod;
+    }
+    hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr,
+                       D, K, dots);
+    hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil);
+    const int nts = (T + VB_TS - 1) / VB_TS;
+    const size_t lds = bwd_main_lds_bytes(K);
+    dim3 grid(B * nts);
+#define LPM_VB_LAUNCH(KTW, SM)                                                                                        \
+    do {                                                                                                              \
+        auto kern = vlad_bwd_main_kernel<KTW, SM>;                                                                    \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            (void)hipGetLastError();                                                                                  \
+            set_error("lpm_vlad_aggregate_bwd: cannot reserve %zu bytes of LDS", lds);                                \
+            return LPM_ERR_LAUNCH;                                                                                    \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, dO, nrm, u, v, ctil, assign, scale, shift, x, ldx, T, D, K, \
+                           nts, dassign, dx, lddx, accumulate_dx);                                                    \
+    } while (0)
+    if (K <= 128) { if (sm) LPM_VB_LAUNCH(1, true); else LPM_VB_LAUNCH(1, false); }
+    else if (K <= 256) { if (sm) LPM_VB_LAUNCH(2, true); else LPM_VB_LAUNCH(2, false); }
+    else { if (sm) LPM_VB_LAUNCH(4, true); else LPM_VB_LAUNCH(4, false); }
+#undef LPM_VB_LAUNCH
+    if (residual) {
+        const int64_t n4 = (int64_t)D * K / 4;
+        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dO, nrm, asum, u, v,
+                           B, D, K, dcentres);
+    }
+    return check_launch("lpm_vlad_aggregate_bwd");
+}

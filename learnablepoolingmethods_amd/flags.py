@@ -1,0 +1,46 @@
+"""Flag registry with the reference's names and defaults (absl/tf.flags in the reference:
+frame_level_models.py:35,2197-2216; video_level_models.py:26-45; train.py:44-112)."""
+from __future__ import annotations
+
+
+class _Flags:
+    def __init__(self):
+        self.__dict__["_defaults"] = {}
+
+    def define(self, name, default, help=""):  # noqa: A002
+        self._defaults[name] = default
+        self.__dict__[name] = default
+
+    def reset(self):
+        for k, v in self._defaults.items():
+            self.__dict__[k] = v
+
+    def __setattr__(self, k, v):
+        if k not in self._defaults:
+            raise AttributeError(f"unknown flag {k!r}")
+        self.__dict__[k] = v
+
+
+FLAGS = _Flags()
+# frame_level_models.py
+FLAGS.define("iterations", 30, "Number of frames per batch (frame_level_models.py:35)")
+FLAGS.define("sample_random_frames", True, "unused by NetVladV1/V2 (uniform sampling, :2255)")
+FLAGS.define("netvlad_add_batch_norm", True, ":2197")
+FLAGS.define("netvlad_cluster_size", 256, ":2199")
+FLAGS.define("netvlad_hidden_size", 1024, ":2201")
+FLAGS.define("netvlad_relu", False, ":2203")
+FLAGS.define("gating", True, ":2205")
+FLAGS.define("gating_remove_diag", False, ":2207")
+FLAGS.define("netvlad_encoder", True, "build extension: False = gated NetVLAD without the cluster encoders (BASELINE cfg-5)")
+# video_level_models.py
+FLAGS.define("moe_num_mixtures", 2, "video_level_models.py:27")
+FLAGS.define("moe_l2", 1e-8, ":35")
+FLAGS.define("moe_low_rank_gating", -1, ":38")
+FLAGS.define("moe_prob_gating", False, ":41")
+# train.py
+FLAGS.define("batch_size", 1024, "train.py:78")
+FLAGS.define("regularization_penalty", 1.0, ":83")
+FLAGS.define("base_learning_rate", 0.01, ":86")
+FLAGS.define("learning_rate_decay", 0.95, ":88")
+FLAGS.define("learning_rate_decay_examples", 4000000, ":91")
+FLAGS.define("clip_gradient_norm", 1.0, ":108")

@@ -1,0 +1,169 @@
+"""NetVLAD prototypes behind the reference's model-registry API
+(reference: frame_level_models.py:2193-2513 NetVladV1 / NetVladV2, :2765-2877 NetVLAD / LightVLAD).
+
+Same names, ``create_model`` signature, variable names and output contract as the reference; the hot
+ops (frame sampling + input_bn, soft-assignment GEMM, fused softmax/residual aggregation/normalise,
+attention cores) run as hand-written gfx950 kernels through ops.py.  Defect resolutions follow
+SURVEY.md App. C (C1 scope_id ignored, C5 tokens = clusters, C8 K // 4, C9 rgb-only input skips audio).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import FLAGS, layers, models, ops, transformer_utils, video_level_models, video_pooling_modules
+from . import variables as vs
+
+
+class NetVLAD():
+    """frame_level_models.py:2765-2824.  forward(reshaped_input [(B*max_frames), D]) -> [B, D*K] (d-major)."""
+
+    residual = True
+
+    def __init__(self, feature_size, max_frames, cluster_size, add_batch_norm, is_training, scope_id=None):
+        self.feature_size = feature_size
+        self.max_frames = max_frames
+        self.is_training = is_training
+        self.add_batch_norm = add_batch_norm
+        self.cluster_size = int(cluster_size)
+
+    def forward(self, reshaped_input, kmajor=False):
+        D, K, dev = self.feature_size, self.cluster_size, reshaped_input.device
+        std = 1 / math.sqrt(D)
+        cluster_weights = vs.get_variable("cluster_weights", [D, K], vs.random_normal_initializer(std), device=dev)   # :2775
+        bn = bias = None
+        if self.add_batch_norm:
+            bn = layers.bn_variables("cluster_bn", K, dev)                                                          # :2783-2789
+        else:
+            bias = vs.get_variable("cluster_biases", [K], vs.random_normal_initializer(std), device=dev)            # :2790-2796
+        cluster_weights2 = None
+        if self.residual:
+            cluster_weights2 = vs.get_variable("cluster_weights2", [1, D, K], vs.random_normal_initializer(std),
+                                               device=dev)                                                           # :2805-2808
+        # matmul -> cluster_bn -> softmax -> a^T x - sum(a) W2 -> l2norm(D) -> flatten -> l2norm  (:2781-2822)
+        return ops.netvlad(reshaped_input, cluster_weights, cluster_weights2, self.max_frames, bn=bn, bias=bias,
+                           is_training=self.is_training, kmajor=kmajor)
+
+
+class LightVLAD(NetVLAD):
+    """frame_level_models.py:2827-2877: NetVLAD without the centre-residual term."""
+    residual = False
+
+
+def _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating, remove_diag,
+                           is_training, **unused_params):
+    """Shared tail of NetVladV1 / NetVladV2: hidden projection, context gating, MoE
+    (frame_level_models.py:2309-2377 == :2445-2513)."""
+    dev = vlad.device
+    vlad_dim = vlad.shape[1]
+    hidden1_weights = vs.get_variable("hidden1_weights", [vlad_dim, hidden1_size],
+                                      vs.random_normal_initializer(1 / math.sqrt(cluster_size)), device=dev)   # :2315-2317
+    activation = vlad.matmul(hidden1_weights)                                                                  # :2319
+    if add_batch_norm and relu:
+        activation = layers.batch_norm(activation, is_training, "hidden1_bn")                                  # :2321-2327
+    else:
+        hidden1_biases = vs.get_variable("hidden1_biases", [hidden1_size], vs.random_normal_initializer(0.01), device=dev)
+        activation = activation + hidden1_biases                                                               # :2329-2334
+    if relu:
+        activation = torch.clamp(activation, 0.0, 6.0)                                                         # relu6 :2337
+    if gating:
+        gating_weights = vs.get_variable("gating_weights_2", [hidden1_size, hidden1_size],
+                                         vs.random_normal_initializer(1 / math.sqrt(hidden1_size)), device=dev)  # :2343-2346
+        gates = activation.matmul(gating_weights)
+        if remove_diag:
+            gates = gates - torch.diagonal(gating_weights) * activation                                        # :2349-2352
+        if add_batch_norm:
+            gates = layers.batch_norm(gates, is_training, "gating_bn")                                         # :2354-2360
+        else:
+            raise NotImplementedError("context gating without batch norm is broken in the reference (App. C12)")
+        activation = activation * torch.sigmoid(gates)                                                         # :2367-2368
+    aggregated_model = getattr(video_level_models, "MoeModel")
+    return aggregated_model().create_model(model_input=activation, vocab_size=vocab_size, is_training=is_training,
+                                           **unused_params)
+
+
+def _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training):
+    """SampleUniformFrames + reshape + input_bn (frame_level_models.py:2248-2271), one fused kernel pair."""
+    bn = layers.bn_variables("input_bn", model_input.shape[2], model_input.device) if add_batch_norm else (None,) * 4
+    return ops.frame_sample_bn(model_input, num_frames.reshape(-1), iterations, *bn, is_training=is_training)
+
+
+class NetVladV1(models.BaseModel):
+    """Paper prototype 1: NetVLAD -> cluster-level transformer encoders -> context gating -> MoE
+    (frame_level_models.py:2222-2377)."""
+
+    def create_model(self, model_input, vocab_size, num_frames, iterations=None, add_batch_norm=None,
+                     sample_random_frames=None, cluster_size=None, hidden_size=None, is_training=True, encoder=None,
+                     **unused_params):
+        iterations = iterations or FLAGS.iterations
+        add_batch_norm = add_batch_norm or FLAGS.netvlad_add_batch_norm
+        cluster_size = cluster_size or FLAGS.netvlad_cluster_size
+        hidden1_size = hidden_size or FLAGS.netvlad_hidden_size
+        relu, gating, remove_diag = FLAGS.netvlad_relu, FLAGS.gating, FLAGS.gating_remove_diag
+        encoder = FLAGS.netvlad_encoder if encoder is None else encoder
+        unused_params.pop("labels", None)
+
+        reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training)
+        max_frames, feature_size = iterations, model_input.shape[2]
+        has_audio = feature_size > 1024                                      # App. C9
+
+        video_NetVLAD = NetVLAD(1024, max_frames, cluster_size, add_batch_norm, is_training, "netvlad_rgb_scope")
+        audio_NetVLAD = NetVLAD(128, max_frames, cluster_size // 4, add_batch_norm, is_training, "netvlad_audio_scope")
+        with vs.variable_scope("video_VLAD"):
+            vlad_video = video_NetVLAD.forward(reshaped_input[:, 0:1024], kmajor=encoder)     # :2273-2274
+        if has_audio:
+            with vs.variable_scope("audio_VLAD"):
+                vlad_audio = audio_NetVLAD.forward(reshaped_input[:, 1024:], kmajor=encoder)  # :2276-2277
+
+        if encoder:
+            # tokens = clusters (App. C5): the pooling kernel already wrote the [B, K, D] view
+            with vs.variable_scope("video_attention"):
+                video_encoder_block = transformer_utils.TransformerEncoder(
+                    feature_size=1024, hidden_size=1024, num_heads=64, attention_dropout=0.1, ff_filter_size=4 * 1024,
+                    ff_relu_dropout=0.1, is_train=is_training, scope_id="encode1")
+                vlad_video = video_encoder_block.forward(vlad_video).reshape(-1, 1024 * cluster_size)        # :2282-2292
+            if has_audio:
+                with vs.variable_scope("audio_attention"):
+                    audio_encoder_block = transformer_utils.TransformerEncoder(
+                        feature_size=128, hidden_size=128, num_heads=16, attention_dropout=0.1, ff_filter_size=4 * 128,
+                        ff_relu_dropout=0.1, is_train=is_training, scope_id="encode2")
+                    vlad_audio = audio_encoder_block.forward(vlad_audio).reshape(-1, 128 * (cluster_size // 4))  # :2294-2304
+
+        vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video             # :2309
+        return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
+                                      remove_diag, is_training, **unused_params)
+
+
+class NetVladV2(models.BaseModel):
+    """Paper prototype 2: attention-based cluster similarities (frame_level_models.py:2383-2513)."""
+
+    def create_model(self, model_input, vocab_size, num_frames, iterations=None, add_batch_norm=None,
+                     sample_random_frames=None, cluster_size=None, hidden_size=None, is_training=True,
+                     dropout_masks=None, dropout_rate=None, **unused_params):
+        iterations = iterations or FLAGS.iterations
+        add_batch_norm = add_batch_norm or FLAGS.netvlad_add_batch_norm
+        cluster_size = cluster_size or FLAGS.netvlad_cluster_size
+        hidden1_size = hidden_size or FLAGS.netvlad_hidden_size
+        relu, gating, remove_diag = FLAGS.netvlad_relu, FLAGS.gating, FLAGS.gating_remove_diag
+        unused_params.pop("labels", None)
+        dm = dropout_masks or {}
+
+        reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training)
+        max_frames, feature_size = iterations, model_input.shape[2]
+        has_audio = feature_size > 1024
+
+        video_NetVLAD = video_pooling_modules.NetVladAttenCluster(1024, max_frames, cluster_size, add_batch_norm,
+                                                                  is_training, "netvlad_rgb_scope")
+        audio_NetVLAD = video_pooling_modules.NetVladAttenCluster(128, max_frames, cluster_size // 4, add_batch_norm,
+                                                                  is_training, "netvlad_audio_scope")
+        with vs.variable_scope("video_VLAD"):
+            vlad_video = video_NetVLAD.forward(reshaped_input[:, 0:1024], dropout_mask=dm.get("video"),
+                                               dropout_rate=dropout_rate)                      # :2437-2438
+        if has_audio:
+            with vs.variable_scope("audio_VLAD"):
+                vlad_audio = audio_NetVLAD.forward(reshaped_input[:, 1024:], dropout_mask=dm.get("audio"),
+                                                   dropout_rate=dropout_rate)                  # :2440-2441
+        vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video             # :2445
+        return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
+                                      remove_diag, is_training, **unused_params)

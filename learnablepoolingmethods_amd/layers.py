@@ -1,0 +1,68 @@
+"""TF1 / slim layer semantics the hot path depends on, as thin torch code.
+These are the non-hot ops (dense GEMMs go to hipBLASLt through torch.matmul; small [B,H]-sized batch
+norms and layer norms are elementwise plumbing).  The hot ops live in ops.py / csrc/."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import variables as vs
+
+BN_EPS = 1e-3
+BN_DECAY = 0.999
+LN_EPS = 1e-12
+
+
+def l2_normalize(x: torch.Tensor, dim: int, eps: float = 1e-12) -> torch.Tensor:
+    """tf.nn.l2_normalize: x * rsqrt(max(sum x^2, eps)) (train.py:264)."""
+    return x * torch.rsqrt(torch.clamp((x * x).sum(dim=dim, keepdim=True), min=eps))
+
+
+def bn_variables(scope: str, channels: int, device):
+    """slim.batch_norm(center=True, scale=True) variables: beta, gamma, moving_mean, moving_variance."""
+    with vs.variable_scope(scope):
+        beta = vs.get_variable("beta", [channels], vs.zeros_initializer(), device=device)
+        gamma = vs.get_variable("gamma", [channels], vs.ones_initializer(), device=device)
+        mm = vs.get_variable("moving_mean", [channels], vs.zeros_initializer(), trainable=False, device=device)
+        mv = vs.get_variable("moving_variance", [channels], vs.ones_initializer(), trainable=False, device=device)
+    return gamma, beta, mm, mv
+
+
+def batch_norm(x: torch.Tensor, is_training: bool, scope: str) -> torch.Tensor:
+    """slim.batch_norm on a tensor whose last axis is the channel (frame_level_models.py:2355;
+    transformer_utils.py:666,747,760).  Moving variance gets the unbiased estimate on the fused
+    (rank-2/4) path, the biased one otherwise."""
+    C = x.shape[-1]
+    gamma, beta, mm, mv = bn_variables(scope, C, x.device)
+    if is_training:
+        red = tuple(range(x.dim() - 1))
+        n = x.numel() // C
+        mean = x.mean(dim=red)
+        var = ((x - mean) ** 2).mean(dim=red)
+        with torch.no_grad():
+            uv = var * (n / max(n - 1, 1)) if x.dim() in (2, 4) else var
+            mm.mul_(BN_DECAY).add_(mean.detach(), alpha=1 - BN_DECAY)
+            mv.mul_(BN_DECAY).add_(uv.detach(), alpha=1 - BN_DECAY)
+    else:
+        mean, var = mm, mv
+    return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
+
+
+def layer_norm(x: torch.Tensor, scope: str = "LayerNorm") -> torch.Tensor:
+    """tf.contrib.layers.layer_norm defaults: moments over ALL non-batch axes, gamma/beta [last], eps 1e-12
+    (transformer_utils.py:407,411,454,713)."""
+    with vs.variable_scope(scope):
+        beta = vs.get_variable("beta", [x.shape[-1]], vs.zeros_initializer(), device=x.device)
+        gamma = vs.get_variable("gamma", [x.shape[-1]], vs.ones_initializer(), device=x.device)
+    y = F.layer_norm(x, tuple(x.shape[1:]), None, None, LN_EPS)
+    return y * gamma + beta
+
+
+def dense(x: torch.Tensor, units: int, use_bias: bool, name: str, activation=None) -> torch.Tensor:
+    """tf.layers.dense: contracts the last axis; glorot-uniform kernel, zero bias."""
+    with vs.variable_scope(name):
+        kernel = vs.get_variable("kernel", [x.shape[-1], units], vs.glorot_uniform_initializer(), device=x.device)
+        y = x.matmul(kernel)
+        if use_bias:
+            y = y + vs.get_variable("bias", [units], vs.zeros_initializer(), device=x.device)
+    return activation(y) if activation is not None else y

@@ -1,0 +1,8 @@
+"""Base class for models (reference: models.py:18-25)."""
+
+
+class BaseModel(object):
+    """Inherit from this class when implementing new models."""
+
+    def create_model(self, unused_model_input, **unused_params):
+        raise NotImplementedError()

@@ -1,0 +1,369 @@
+"""torch.autograd bindings of the HIP hot path (liblpm_hip.so, include/lpm_hip.h).
+
+Every op here launches hand-written gfx950 kernels on the current PyTorch HIP stream through the
+C ABI.  There is NO CPU fallback: CPU tensors or a missing library raise ``LpmError``.
+PyTorch only supplies device memory, streams and the autograd tape.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _capi
+from ._capi import LPM_VLAD_OUT_KMAJOR, LPM_VLAD_RESIDUAL, LPM_VLAD_SOFTMAX, LpmError, ptr, stream_ptr
+
+BN_EPS = 1e-3     # slim.batch_norm epsilon
+BN_DECAY = 0.999  # slim.batch_norm decay
+
+
+def _f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise LpmError(f"{what}: expected float32, got {t.dtype}")
+    return t
+
+
+def _rows(t: torch.Tensor, what: str) -> torch.Tensor:
+    """2-D tensor whose rows are contiguous (a column slice of a wider row-major matrix is fine)."""
+    _f32(t, what)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise LpmError(f"{what}: need a 2-D tensor with unit column stride")
+    return t
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# ----------------------------------------------------------------------------------------------
+# batch-norm statistics -> folded affine
+# ----------------------------------------------------------------------------------------------
+def bn_fold(partial, nblk, C, rows, gamma, beta, moving_mean=None, moving_var=None, eps=BN_EPS, decay=BN_DECAY):
+    lib = _capi.load()
+    mean, var, scale, shift = (_empty((C,), partial) for _ in range(4))
+    lib.check(lib._lpm_bn_fold(ptr(partial), nblk, C, rows, ptr(gamma), ptr(beta), eps, decay, ptr(mean), ptr(var),
+                               ptr(scale), ptr(shift), ptr(moving_mean), ptr(moving_var), stream_ptr()), "lpm_bn_fold")
+    return mean, var, scale, shift
+
+
+def folded_eval_affine(gamma, beta, moving_mean, moving_var, eps=BN_EPS):
+    """Inference-mode batch norm is a constant affine (tiny [C] tensors: plain torch)."""
+    scale = gamma * torch.rsqrt(moving_var + eps)
+    return scale, beta - moving_mean * scale
+
+
+# ----------------------------------------------------------------------------------------------
+# a2 + a3: SampleUniformFrames + input_bn
+# ----------------------------------------------------------------------------------------------
+class _FrameSampleBN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, num_frames, gamma, beta, moving_mean, moving_var, S, is_training, use_bn):
+        lib = _capi.load()
+        raw = _f32(raw, "model_input").contiguous()
+        if raw.dim() != 3:
+            raise LpmError("model_input must be [batch, max_frames, feature]")
+        B, MF, F = raw.shape
+        nf = num_frames.to(device=raw.device, dtype=torch.int32).contiguous()
+        y = _empty((B * S, F), raw)
+        mean = var = None
+        if use_bn:
+            if is_training:
+                nblk = lib._lpm_frame_stats_nblk(B, S)
+                partial = _empty((nblk, 2, F), raw)
+                lib.check(lib._lpm_frame_stats(ptr(raw), ptr(nf), B, MF, F, S, ptr(partial), stream_ptr()), "lpm_frame_stats")
+                mean, var, scale, shift = bn_fold(partial, nblk, F, B * S, gamma, beta, moving_mean, moving_var)
+            else:
+                scale, shift = folded_eval_affine(gamma, beta, moving_mean, moving_var)
+                scale, shift = scale.contiguous(), shift.contiguous()
+            lib.check(lib._lpm_frame_apply(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(y), stream_ptr()),
+                      "lpm_frame_apply")
+        else:
+            lib.check(lib._lpm_frame_apply(ptr(raw), ptr(nf), B, MF, F, S, None, None, ptr(y), stream_ptr()), "lpm_frame_apply")
+        ctx.use_bn, ctx.is_training, ctx.S = use_bn, is_training, S
+        if use_bn:
+            if is_training:
+                ctx.save_for_backward(raw, nf, mean, var)
+            else:
+                ctx.save_for_backward(raw, nf, moving_mean.detach().clone(), moving_var.detach().clone())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.use_bn:
+            return (None,) * 9
+        lib = _capi.load()
+        raw, nf, mean, var = ctx.saved_tensors
+        B, MF, F = raw.shape
+        dy = _rows(dy.contiguous(), "dy")
+        dgamma, dbeta = _empty((F,), raw), _empty((F,), raw)
+        wsb = lib._lpm_frame_stats_workspace_bytes(B, ctx.S, F)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=raw.device)
+        lib.check(lib._lpm_frame_bn_bwd(ptr(dy), dy.stride(0), ptr(raw), ptr(nf), B, MF, F, ctx.S, ptr(mean), ptr(var),
+                                        BN_EPS, ptr(dgamma), ptr(dbeta), ptr(ws), wsb, stream_ptr()), "lpm_frame_bn_bwd")
+        return None, None, dgamma, dbeta, None, None, None, None, None
+
+
+def frame_sample_bn(raw, num_frames, S, gamma=None, beta=None, moving_mean=None, moving_var=None, is_training=True):
+    """[B, max_frames, F] -> [B*S, F]: uniform frame sampling (model_utils.py:101-122) fused with
+    input_bn (frame_level_models.py:2265-2271).  The frames are data: no gradient flows to ``raw``."""
+    use_bn = gamma is not None
+    return _FrameSampleBN.apply(raw, num_frames, gamma, beta, moving_mean, moving_var, int(S), bool(is_training), use_bn)
+
+
+# ----------------------------------------------------------------------------------------------
+# K1 + K2 (+K3): NetVLAD pooling
+# ----------------------------------------------------------------------------------------------
+def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor):
+    nrm = _empty((B, D, K), x)
+    asum, colsq, csq = (_empty((B, K), x) for _ in range(3))
+    lib.check(lib._lpm_vlad_aggregate_fwd(ptr(assign), ptr(scale), ptr(shift), ptr(x), x.stride(0), ptr(centres), B, T, D, K,
+                                          flags, ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), stream_ptr()),
+              "lpm_vlad_aggregate_fwd")
+    out = _empty((B, K, D) if kmajor else (B, D * K), x)
+    gsq = _empty((B,), x)
+    lib.check(lib._lpm_vlad_finalize_fwd(ptr(nrm), ptr(csq), B, D, K, LPM_VLAD_OUT_KMAJOR if kmajor else 0, ptr(out),
+                                         ptr(gsq), stream_ptr()), "lpm_vlad_finalize_fwd")
+    return out, nrm, asum, colsq, csq, gsq
+
+
+def _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor):
+    dassign = _empty((B * T, K), x)
+    dx = _empty((B * T, D), x)
+    dcentres = _empty((D, K), x) if centres is not None else None
+    wsb = lib._lpm_vlad_bwd_workspace_bytes(B, D, K)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+    fl = flags | (LPM_VLAD_OUT_KMAJOR if kmajor else 0)
+    lib.check(lib._lpm_vlad_aggregate_bwd(ptr(dout), ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(assign),
+                                          ptr(scale), ptr(shift), ptr(x), x.stride(0), ptr(centres), B, T, D, K, fl,
+                                          ptr(dassign), ptr(dx), D, 0, ptr(dcentres), ptr(ws), wsb, stream_ptr()),
+              "lpm_vlad_aggregate_bwd")
+    return dassign, dx, dcentres
+
+
+class _NetVLAD(torch.autograd.Function):
+    """x [B*T, D] -> pooled descriptor.  cluster_weights [D,K]; cluster_bn (gamma, beta, moving) or
+    cluster_biases; cluster_weights2 [1,D,K] (None = LightVLAD).  frame_level_models.py:2773-2824."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, moving_mean, moving_var, bias, W2, T, is_training, kmajor):
+        lib = _capi.load()
+        x = _rows(x, "reshaped_input")
+        W = _f32(W, "cluster_weights").contiguous()
+        M, D = x.shape
+        K = W.shape[1]
+        if M % T:
+            raise LpmError(f"rows {M} not divisible by max_frames {T}")
+        B = M // T
+        nblk = lib._lpm_assign_gemm_nblk(M)
+        logits = _empty((M, K), x)
+        partial = _empty((nblk, 2, K), x)
+        lib.check(lib._lpm_assign_gemm_fwd(ptr(x), x.stride(0), ptr(W), M, D, K, 0, ptr(logits), ptr(partial), stream_ptr()),
+                  "lpm_assign_gemm_fwd")
+        mean = var = None
+        use_bn = gamma is not None
+        if use_bn:
+            if is_training:
+                mean, var, scale, shift = bn_fold(partial, nblk, K, M, gamma, beta, moving_mean, moving_var)
+            else:
+                scale, shift = folded_eval_affine(gamma, beta, moving_mean, moving_var)
+                scale, shift = scale.contiguous(), shift.contiguous()
+                mean, var = moving_mean.detach().clone(), moving_var.detach().clone()
+        else:
+            scale, shift = None, bias.contiguous()
+        flags = LPM_VLAD_SOFTMAX | (LPM_VLAD_RESIDUAL if W2 is not None else 0)
+        centres = W2.reshape(D, K).contiguous() if W2 is not None else None
+        out, nrm, asum, colsq, csq, gsq = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor)
+        ctx.dims = (B, T, D, K, flags, kmajor, use_bn, is_training, W2 is not None)
+        ctx.save_for_backward(x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _capi.load()
+        B, T, D, K, flags, kmajor, use_bn, is_training, has_w2 = ctx.dims
+        x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq = ctx.saved_tensors
+        dout = _f32(dout, "dout").contiguous()
+        dlt, dx, dcentres = _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, centres, B, T, D,
+                                           K, flags, kmajor)
+        M = B * T
+        dgamma = dbeta = dbias = None
+        if use_bn and is_training:
+            dgamma, dbeta = _empty((K,), x), _empty((K,), x)
+            wsb = lib._lpm_bn_bwd_workspace_bytes(M, K)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+            lib.check(lib._lpm_bn_bwd(ptr(dlt), ptr(logits), ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, K, ptr(dlt),
+                                      ptr(dgamma), ptr(dbeta), ptr(ws), wsb, stream_ptr()), "lpm_bn_bwd")
+            dl = dlt
+        elif use_bn:   # inference-mode statistics are constants
+            lhat = (logits - mean) * torch.rsqrt(var + BN_EPS)
+            dgamma, dbeta = (dlt * lhat).sum(0), dlt.sum(0)
+            dl = dlt * scale
+        else:
+            dbias = dlt.sum(0)
+            dl = dlt
+        # assignment-GEMM backward: plain library GEMMs (hipBLASLt through torch)
+        dW = x.t().matmul(dl)
+        dx.addmm_(dl, W.t())
+        dW2 = dcentres.reshape(1, D, K) if has_w2 else None
+        return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None
+
+
+def netvlad(x, cluster_weights, cluster_weights2, max_frames, bn=None, bias=None, is_training=True, kmajor=False):
+    """bn = (gamma, beta, moving_mean, moving_var) or None (then ``bias`` = cluster_biases)."""
+    g, b, mm, mv = bn if bn is not None else (None, None, None, None)
+    return _NetVLAD.apply(x, cluster_weights, g, b, mm, mv, bias, cluster_weights2, int(max_frames), bool(is_training),
+                          bool(kmajor))
+
+
+class _VladAggregate(torch.autograd.Function):
+    """Similarities given (no softmax): NetVladAttenCluster tail, video_pooling_modules.py:1641-1658."""
+
+    @staticmethod
+    def forward(ctx, sims, x, centres, T, kmajor):
+        lib = _capi.load()
+        x = _rows(x, "inputs")
+        M, D = x.shape
+        K = centres.shape[1]
+        B = M // T
+        sims2 = _f32(sims, "cluster_similarities").reshape(M, K).contiguous()
+        centres = _f32(centres, "cluster_centers").contiguous()
+        flags = LPM_VLAD_RESIDUAL
+        out, nrm, asum, colsq, csq, gsq = _aggregate_fwd(lib, sims2, None, None, x, centres, B, T, D, K, flags, kmajor)
+        ctx.dims = (B, T, D, K, flags, kmajor, sims.shape)
+        ctx.save_for_backward(sims2, x, centres, nrm, asum, colsq, csq, gsq)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _capi.load()
+        B, T, D, K, flags, kmajor, sshape = ctx.dims
+        sims2, x, centres, nrm, asum, colsq, csq, gsq = ctx.saved_tensors
+        dsims, dx, dcentres = _aggregate_bwd(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x, centres,
+                                             B, T, D, K, flags, kmajor)
+        return dsims.reshape(sshape), dx, dcentres, None, None
+
+
+def vlad_aggregate(sims, x, centres, max_frames, kmajor=False):
+    return _VladAggregate.apply(sims, x, centres, int(max_frames), bool(kmajor))
+
+
+# ----------------------------------------------------------------------------------------------
+# K4: attention core
+# ----------------------------------------------------------------------------------------------
+def _mha_dims(q, num_heads):
+    if q.dim() != 3 or q.stride(2) != 1 or q.stride(0) != q.shape[1] * q.stride(1):
+        raise LpmError("attention operands must be [B, L, h*d] with contiguous rows")
+    B, L, F = q.shape
+    if F % num_heads:
+        raise LpmError("hidden size not divisible by num_heads")
+    return B, L, F // num_heads
+
+
+class _MHACore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, num_heads, scale):
+        lib = _capi.load()
+        q, k, v = (_f32(t, "qkv").contiguous() for t in (q, k, v))
+        B, L, d = _mha_dims(q, num_heads)
+        o = torch.empty_like(q)
+        lse = _empty((B, num_heads, L), q)
+        lib.check(lib._lpm_mha_fwd(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, None, None, ptr(o),
+                                   o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
+        ctx.dims = (B, L, num_heads, d, scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _capi.load()
+        B, L, h, d, scale = ctx.dims
+        q, k, v, o, lse = ctx.saved_tensors
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        lib.check(lib._lpm_mha_bwd(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d,
+                                   scale, None, None, ptr(dq), ptr(dk), ptr(dv), dq.stride(1), None, None, None, stream_ptr()),
+                  "lpm_mha_bwd")
+        return dq, dk, dv, None, None
+
+
+def mha_core(q, k, v, num_heads, scale):
+    """softmax(scale * q k^T) v per head on [B, L, h*d] projections (transformer_utils.py:564-581)."""
+    return _MHACore.apply(q, k, v, int(num_heads), float(scale))
+
+
+class _MHACoreBN(torch.autograd.Function):
+    """MultiHeadAttentionBN core: batch_norm over the key-position channel of the rank-4 logits, then
+    softmax . v (transformer_utils.py:652-661).  Training statistics over (B, h, query)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, gamma, beta, moving_mean, moving_var, num_heads, is_training):
+        lib = _capi.load()
+        q, k, v = (_f32(t, "qkv").contiguous() for t in (q, k, v))
+        B, L, d = _mha_dims(q, num_heads)
+        h = num_heads
+        if is_training:
+            partial = _empty((B * h, 2, L), q)
+            lib.check(lib._lpm_mha_logit_stats(ptr(q), ptr(k), q.stride(1), B, L, h, d, ptr(partial), stream_ptr()),
+                      "lpm_mha_logit_stats")
+            mean, var, kscale, kshift = bn_fold(partial, B * h, L, B * h * L, gamma, beta, moving_mean, moving_var)
+        else:
+            kscale, kshift = folded_eval_affine(gamma, beta, moving_mean, moving_var)
+            kscale, kshift = kscale.contiguous(), kshift.contiguous()
+            mean, var = moving_mean.detach().clone(), moving_var.detach().clone()
+        o = torch.empty_like(q)
+        lse = _empty((B, h, L), q)
+        lib.check(lib._lpm_mha_fwd(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, h, d, 1.0, ptr(kscale), ptr(kshift), ptr(o),
+                                   o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
+        ctx.dims = (B, L, h, d, is_training)
+        ctx.save_for_backward(q, k, v, o, lse, kscale, kshift, mean, var, gamma)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _capi.load()
+        B, L, h, d, is_training = ctx.dims
+        q, k, v, o, lse, kscale, kshift, mean, var, gamma = ctx.saved_tensors
+        do = do.contiguous()
+        st = stream_ptr()
+        # pass 1: column sums of dz and dz*s over (B, h, query)
+        partial = _empty((B * h, 2, L), q)
+        lib.check(lib._lpm_mha_bwd(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
+                                   ptr(kscale), ptr(kshift), None, None, None, q.stride(1), None, None, ptr(partial), st),
+                  "lpm_mha_bwd(stats)")
+        sums = partial.to(torch.float64).sum(0)                      # [2, L]  (tiny)
+        sdz, sdzs = sums[0], sums[1]
+        rstd = torch.rsqrt(var.double() + BN_EPS)
+        sdz_hat = rstd * (sdzs - mean.double() * sdz)                # sum dz * s_hat
+        dbeta, dgamma = sdz.float(), sdz_hat.float()
+        if is_training:
+            n = float(B * h * L)
+            c1, c2 = sdz / n, sdz_hat / n
+            ks = kscale.double()
+            corr_b = (ks * c2 * rstd).float().contiguous()
+            corr_a = (ks * (c1 - mean.double() * rstd * c2)).float().contiguous()
+        else:
+            corr_a = corr_b = None
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        lib.check(lib._lpm_mha_bwd(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
+                                   ptr(kscale), ptr(kshift), ptr(dq), ptr(dk), ptr(dv), dq.stride(1), ptr(corr_a), ptr(corr_b),
+                                   None, st), "lpm_mha_bwd")
+        return dq, dk, dv, dgamma, dbeta, None, None, None, None
+
+
+def mha_core_bn(q, k, v, num_heads, gamma, beta, moving_mean, moving_var, is_training=True):
+    return _MHACoreBN.apply(q, k, v, gamma, beta, moving_mean, moving_var, int(num_heads), bool(is_training))
+
+
+# ----------------------------------------------------------------------------------------------
+# a14 + a15: clip + Adam over flat arenas
+# ----------------------------------------------------------------------------------------------
+def clip_adam_step(param, grad, m, v, offsets, ntensors, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8,
+                   scratch: Optional[torch.Tensor] = None):
+    lib = _capi.load()
+    total = param.numel()
+    if scratch is None:
+        scratch = torch.empty(lib._lpm_clip_adam_scratch_bytes(total, ntensors) // 4, dtype=torch.float32, device=param.device)
+    lib.check(lib._lpm_multi_tensor_clip_adam(ptr(param), ptr(grad), ptr(m), ptr(v), ptr(offsets), ntensors, total,
+                                              float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch),
+                                              stream_ptr()), "lpm_multi_tensor_clip_adam")
+    return scratch

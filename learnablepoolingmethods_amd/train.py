@@ -1,0 +1,202 @@
+"""Training step of the NetVLAD path (reference: train.build_graph, train.py:193-345; utils.py:170-213).
+
+One process per GPU.  The reference splits a global batch over in-graph towers, SUMs the tower
+gradients on the host, clips every variable to L2 norm 1 and applies Adam (train.py:266-336).  Here a
+rank is a tower: forward/backward run locally, gradients live in ONE flat fp32 arena per rank so the
+cross-tower SUM is an RCCL all-reduce on arena slices (no packing copies), launched as early as
+backward produces them (the 554 MB ``hidden1_weights`` gradient -- 85 % of the payload -- sits next
+to the loss, so its all-reduce overlaps the whole encoder / NetVLAD backward), and the per-variable
+clip + TF-style Adam is one fused multi-tensor HIP kernel over the arena.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import FLAGS, layers, losses, ops
+from . import variables as vs
+
+ARENA_ALIGN = 4096   # LPM_ARENA_ALIGN: every variable starts on a chunk boundary of the optimizer kernel
+
+
+def learning_rate(base_learning_rate, global_step, batch_size, num_towers, decay_examples, decay):
+    """tf.train.exponential_decay(staircase=True) over examples seen (train.py:244-249)."""
+    p = math.floor(global_step * batch_size * num_towers / decay_examples)
+    return base_learning_rate * decay ** p
+
+
+class ParameterArena:
+    """Flat fp32 arenas (param / grad / adam m / adam v) with every trainable variable a view into them."""
+
+    def __init__(self, store: vs.VariableStore, first: Optional[List[str]] = None):
+        tv = store.trainable_variables()
+        names = [n for n in (first or []) if n in tv] + [n for n in tv if n not in (first or [])]
+        self.names = names
+        offs, cur = [], 0
+        for n in names:
+            offs.append(cur)
+            cur += (tv[n].numel() + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+        self.total = cur
+        offs.append(cur)
+        dev = tv[names[0]].device
+        self.device = dev
+        self.param = torch.zeros(cur, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(cur, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(cur, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(cur, dtype=torch.float32, device=dev)
+        self.offsets_host = offs
+        self.offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self.views: Dict[str, torch.Tensor] = {}
+        with torch.no_grad():
+            for n, o in zip(names, offs):
+                t = tv[n]
+                pv = self.param[o:o + t.numel()].view(t.shape)
+                pv.copy_(t)
+                t.data = pv                                   # the variable now lives in the arena
+                t.grad = self.grad[o:o + t.numel()].view(t.shape)
+                self.views[n] = t
+        store.frozen = True
+        self._scratch = None
+
+    def segment(self, name: str):
+        i = self.names.index(name)
+        return self.offsets_host[i], self.offsets_host[i + 1]
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class GradientSynchronizer:
+    """Cross-rank SUM of the gradient arena (utils.combine_gradients semantics: sum, not mean).
+    Buckets are contiguous arena slices; ``early`` buckets are all-reduced from an autograd hook as soon
+    as their last gradient is accumulated, the rest after backward.  Works with any torch.distributed
+    backend (RCCL on the GPU box, gloo in the CPU tests)."""
+
+    def __init__(self, arena_grad: torch.Tensor, buckets: List[tuple], group=None):
+        self.grad = arena_grad
+        self.buckets = buckets
+        self.group = group
+        self.pending = []
+        self.done = set()
+
+    @property
+    def active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def launch(self, i: int):
+        if not self.active or i in self.done:
+            return
+        a, b = self.buckets[i]
+        self.pending.append(dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.done.add(i)
+
+    def finish(self):
+        for i in range(len(self.buckets)):
+            self.launch(i)
+        for w in self.pending:
+            w.wait()
+        self.pending, self.done = [], set()
+
+
+class Trainer:
+    """Owns the variable store, the arenas and the optimiser state; ``step`` is one ``sess.run(train_op)``."""
+
+    def __init__(self, model, vocab_size=3862, batch_size=None, base_learning_rate=None, learning_rate_decay=None,
+                 learning_rate_decay_examples=None, regularization_penalty=None, clip_gradient_norm=None,
+                 label_loss_fn=None, device="cuda", group=None, seed=0, model_kwargs=None):
+        self.model = model
+        self.vocab_size = vocab_size
+        self.batch_size = batch_size or FLAGS.batch_size
+        self.base_lr = FLAGS.base_learning_rate if base_learning_rate is None else base_learning_rate
+        self.lr_decay = FLAGS.learning_rate_decay if learning_rate_decay is None else learning_rate_decay
+        self.lr_decay_examples = (FLAGS.learning_rate_decay_examples if learning_rate_decay_examples is None
+                                  else learning_rate_decay_examples)
+        self.reg_penalty = FLAGS.regularization_penalty if regularization_penalty is None else regularization_penalty
+        self.clip = FLAGS.clip_gradient_norm if clip_gradient_norm is None else clip_gradient_norm
+        self.loss_fn = label_loss_fn or losses.CrossEntropyLoss()
+        self.device = torch.device(device)
+        self.group = group
+        self.store = vs.VariableStore(device=self.device, seed=seed)
+        self.model_kwargs = dict(model_kwargs or {})
+        self.global_step = 0
+        self.arena: Optional[ParameterArena] = None
+        self.sync: Optional[GradientSynchronizer] = None
+
+    @property
+    def num_towers(self) -> int:
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    # ---------------------------------------------------------------------------------------------
+    def _forward(self, model_input, num_frames, labels, **kw):
+        with vs.use_store(self.store):
+            with vs.variable_scope("tower"):
+                result = self.model.create_model(model_input, num_frames=num_frames, vocab_size=self.vocab_size,
+                                                 labels=labels, **{**self.model_kwargs, **kw})
+            reg_losses = self.store.pop_regularization_losses()
+        return result, reg_losses
+
+    def build(self, model_input_raw, num_frames, labels):
+        """Create every variable (a throw-away forward: moving statistics are restored afterwards),
+        then move the trainable ones into the flat arenas and set up the gradient buckets."""
+        if self.arena is not None:
+            return
+        with torch.no_grad():
+            x = layers.l2_normalize(model_input_raw.to(self.device), 2)
+            self._forward(x, num_frames, labels)
+            for n, v in self.store.vars.items():       # undo the moving-average side effects of the dry run
+                if n.endswith("/moving_mean"):
+                    v.zero_()
+                elif n.endswith("/moving_variance"):
+                    v.fill_(1.0)
+        self.arena = ParameterArena(self.store, first=["tower/hidden1_weights"])
+        a0, a1 = self.arena.segment("tower/hidden1_weights")
+        self.sync = GradientSynchronizer(self.arena.grad, [(a0, a1), (a1, self.arena.total)], self.group)
+        if self.sync.active:
+            # hidden1_weights' gradient is complete right after the projection GEMM's backward: start its
+            # all-reduce there and let it ride under the encoder / NetVLAD backward.
+            w = self.arena.views["tower/hidden1_weights"]
+            w.register_post_accumulate_grad_hook(lambda p: self.sync.launch(0))
+            # every rank must start from identical weights (the reference shares variables across towers)
+            dist.broadcast(self.arena.param, src=0, group=self.group)
+            for n, v in self.store.vars.items():
+                if not self.store.trainable[n]:
+                    dist.broadcast(v, src=0, group=self.group)
+
+    def step(self, model_input_raw, num_frames, labels, **kw):
+        """One optimiser step on this rank's shard of the global batch.  Returns loss / predictions."""
+        dev = self.device
+        model_input_raw = model_input_raw.to(dev)
+        labels = labels.to(dev)
+        num_frames = num_frames.to(dev)
+        self.build(model_input_raw, num_frames, labels)
+        self.arena.zero_grad()
+        model_input = layers.l2_normalize(model_input_raw, 2)                                   # train.py:262-264
+        result, reg_losses = self._forward(model_input, num_frames, labels, **kw)
+        predictions = result["predictions"]
+        label_loss = result["loss"] if "loss" in result else self.loss_fn.calculate_loss(predictions, labels)  # :291-294
+        reg_loss = result.get("regularization_loss", 0.0)
+        if reg_losses:
+            reg_loss = reg_loss + torch.stack(reg_losses).sum()                                 # :301-303
+        final_loss = self.reg_penalty * reg_loss + label_loss                                   # :321
+        final_loss.backward()                                                                   # :322-323
+        self.sync.finish()                                                                      # utils.combine_gradients :330
+        lr = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers,
+                           self.lr_decay_examples, self.lr_decay)                               # :244-249
+        self.global_step += 1
+        self.arena._scratch = ops.clip_adam_step(self.arena.param, self.arena.grad, self.arena.m, self.arena.v,
+                                                 self.arena.offsets, len(self.arena.names), self.clip, lr,
+                                                 self.global_step, scratch=self.arena._scratch)  # :332-336
+        return {"loss": label_loss.detach(), "predictions": predictions.detach(), "learning_rate": lr,
+                "global_step": self.global_step}
+
+    @torch.no_grad()
+    def predict(self, model_input_raw, num_frames, **kw):
+        """eval.build_graph path: same forward with is_training=False (eval.py:143-150)."""
+        x = layers.l2_normalize(model_input_raw.to(self.device), 2)
+        result, _ = self._forward(x, num_frames.to(self.device), None, is_training=False, **kw)
+        return result["predictions"]

@@ -1,0 +1,129 @@
+"""Transformer blocks used by NetVladV1 / NetVladV2 (reference: transformer_utils.py:374-457, 507-766).
+The attention cores (QK^T -> softmax -> .V) run in the HIP kernel K4 (csrc/mha.hip); the dense
+projections are library GEMMs."""
+from __future__ import annotations
+
+import torch
+
+from . import layers, modules, ops
+
+
+class MultiHeadAttention(modules.BaseModule):
+    """transformer_utils.py:507-586."""
+
+    def __init__(self, feature_size, hidden_size, num_heads, attention_dropout, is_train):
+        self.feature_size = feature_size
+        self.hidden_size = hidden_size
+        self.num_heads = num_heads
+        self.attention_dropout = attention_dropout
+        self.is_train = is_train
+
+    def forward(self, queries, keys):
+        q = layers.dense(queries, self.hidden_size, use_bias=False, name="q")      # :559
+        k = layers.dense(keys, self.hidden_size, use_bias=False, name="k")         # :560
+        v = layers.dense(keys, self.hidden_size, use_bias=False, name="v")         # :561
+        depth = self.hidden_size // self.num_heads
+        # split_heads, q *= depth**-0.5, softmax(q k^T) v, combine_heads (:564-581): one kernel
+        attention_output = ops.mha_core(q, k, v, self.num_heads, depth ** -0.5)
+        return layers.dense(attention_output, self.feature_size, use_bias=True, name="output_transform")  # :583
+
+
+class MultiHeadAttentionBN(modules.BaseModule):
+    """transformer_utils.py:589-677: no q scaling, batch_norm on the logits and on the combined heads."""
+
+    def __init__(self, feature_size, hidden_size, num_heads, attention_dropout, is_train):
+        self.feature_size = feature_size
+        self.hidden_size = hidden_size
+        self.num_heads = num_heads
+        self.attention_dropout = attention_dropout
+        self.is_train = is_train
+
+    def forward(self, queries, keys):
+        q = layers.dense(queries, self.hidden_size, use_bias=False, name="q")
+        k = layers.dense(keys, self.hidden_size, use_bias=False, name="k")
+        v = layers.dense(keys, self.hidden_size, use_bias=False, name="v")
+        L = keys.shape[1]
+        gamma, beta, mm, mv = layers.bn_variables("logits_bn", L, q.device)        # channel = key position :652-658
+        attention_output = ops.mha_core_bn(q, k, v, self.num_heads, gamma, beta, mm, mv, self.is_train)
+        attention_output = layers.batch_norm(attention_output, self.is_train, "attention_bn")   # :666-671
+        return layers.dense(attention_output, self.feature_size, use_bias=True, name="output_transform")
+
+
+class FeedForwardNetwork(modules.BaseModule):
+    """transformer_utils.py:679-715 (relu on both dense layers, residual + layer_norm inside)."""
+
+    def __init__(self, feature_size, filter_size, relu_dropout, is_train, scope_id):
+        self.feature_size = feature_size
+        self.filter_size = filter_size
+        self.relu_dropout = relu_dropout
+        self.is_train = is_train
+        self.scope_id = scope_id
+
+    def forward(self, inputs, **unused_params):
+        filter_output = layers.dense(inputs, self.filter_size, True, "filter_output{}".format(self.scope_id), torch.relu)
+        output = layers.dense(filter_output, self.feature_size, True, "ff_output{}".format(self.scope_id), torch.relu)
+        output = output + inputs
+        return layers.layer_norm(output, "LayerNorm_1")
+
+
+class FeedForwardNetworkMod(modules.BaseModule):
+    """transformer_utils.py:718-766."""
+
+    def __init__(self, feature_size, filter_size, relu_dropout, is_train, scope_id, final_size):
+        self.feature_size = feature_size
+        self.filter_size = filter_size
+        self.relu_dropout = relu_dropout
+        self.is_train = is_train
+        self.scope_id = scope_id
+        self.final_size = final_size
+
+    def forward(self, inputs, **unused_params):
+        filter_output = layers.dense(inputs, self.filter_size, True, "filter_output{}".format(self.scope_id), torch.relu)
+        filter_output = layers.batch_norm(filter_output, self.is_train, "filter_bn")
+        output = layers.dense(filter_output, self.final_size, True, "ff_output{}".format(self.scope_id), torch.relu)
+        return layers.batch_norm(output, self.is_train, "feed_output_bn")
+
+
+class TransformerEncoder(modules.BaseModule):
+    """transformer_utils.py:374-413."""
+
+    def __init__(self, feature_size, hidden_size, num_heads, attention_dropout, ff_filter_size, ff_relu_dropout,
+                 is_train, scope_id):
+        self.feature_size = feature_size
+        self.hidden_size = hidden_size
+        self.num_heads = num_heads
+        self.is_train = is_train
+        self.scope_id = scope_id
+        self.multi_head_attention = MultiHeadAttention(feature_size, hidden_size, num_heads, attention_dropout, is_train)
+        self.ff_network = FeedForwardNetwork(feature_size, ff_filter_size, ff_relu_dropout, is_train, scope_id)
+
+    def forward(self, inputs, **unused_params):
+        attention = self.multi_head_attention.forward(inputs, inputs)
+        attention = attention + inputs
+        attention = layers.layer_norm(attention, "LayerNorm")          # :407
+        ff_output = self.ff_network.forward(attention)                 # adds its own residual + LayerNorm_1
+        ff_output = ff_output + attention
+        return layers.layer_norm(ff_output, "LayerNorm_2")             # :411
+
+
+class TransformerEncoderMod(modules.BaseModule):
+    """transformer_utils.py:415-457."""
+
+    def __init__(self, feature_size, hidden_size, num_heads, attention_dropout, ff_filter_size, ff_relu_dropout,
+                 is_train, scope_id, final_size):
+        self.attention_dropout = attention_dropout
+        self.is_train = is_train
+        self.multi_head_attention = MultiHeadAttentionBN(feature_size, hidden_size, num_heads, attention_dropout, is_train)
+        self.ff_network = FeedForwardNetworkMod(feature_size, ff_filter_size, ff_relu_dropout, is_train, scope_id, final_size)
+
+    def forward(self, inputs, dropout_mask=None, dropout_rate=None, **unused_params):
+        attention = self.multi_head_attention.forward(inputs, inputs)
+        # tf.layers.dropout(rate = 1.0 - attention_dropout) -- drops 90 % when training (:450, App. C10)
+        rate = (1.0 - self.attention_dropout) if dropout_rate is None else dropout_rate
+        if self.is_train and rate > 0.0:
+            if dropout_mask is None:
+                dropout_mask = (torch.rand_like(attention) >= rate).to(attention.dtype)
+            attention = attention * dropout_mask / (1.0 - rate)
+        attention = attention + inputs
+        attention = layers.layer_norm(attention, "LayerNorm")
+        return self.ff_network.forward(attention)

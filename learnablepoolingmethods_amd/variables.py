@@ -1,0 +1,134 @@
+"""A small variable store standing in for TF1's graph collections + variable scopes.
+
+The reference creates variables lazily by name inside ``tf.variable_scope`` blocks
+(``tf.get_variable`` / ``slim`` layers, e.g. frame_level_models.py:2273-2277,2775-2808) and reuses them
+across towers (train.py:276).  ``VariableStore`` reproduces that: the first ``get_variable`` under a
+scope creates a leaf tensor on the current device, later calls return the same tensor.  Names follow
+SURVEY.md App. A.9 so checkpoints / oracle weights can be exchanged by name.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+
+class VariableStore:
+    def __init__(self, device=None, seed: int = 0):
+        self.device = torch.device(device) if device is not None else None
+        self.vars: Dict[str, torch.Tensor] = {}
+        self.trainable: Dict[str, bool] = {}
+        self._scope: List[str] = []
+        self._reg_losses: List[torch.Tensor] = []
+        self._gen_seed = seed
+        self._gen: Optional[torch.Generator] = None
+        self.frozen = False
+
+    # -- scopes ---------------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def variable_scope(self, name: str):
+        self._scope.append(name)
+        try:
+            yield
+        finally:
+            self._scope.pop()
+
+    def full_name(self, name: str) -> str:
+        return "/".join(self._scope + [name])
+
+    # -- variables ------------------------------------------------------------------------------
+    def _generator(self, device):
+        if self._gen is None or self._gen.device != device:
+            self._gen = torch.Generator(device=device)
+            self._gen.manual_seed(self._gen_seed)
+        return self._gen
+
+    def get_variable(self, name: str, shape, initializer: Callable, trainable: bool = True, device=None) -> torch.Tensor:
+        full = self.full_name(name)
+        if full in self.vars:
+            v = self.vars[full]
+            if tuple(v.shape) != tuple(shape):
+                raise ValueError(f"variable {full}: shape {tuple(v.shape)} != requested {tuple(shape)}")
+            return v
+        if self.frozen:
+            raise RuntimeError(f"variable store is frozen (arena built); cannot create {full}")
+        dev = torch.device(device) if device is not None else (self.device or torch.device("cpu"))
+        with torch.no_grad():
+            t = initializer(tuple(shape), dev, self._generator(dev)).to(torch.float32)
+        t.requires_grad_(trainable)
+        self.vars[full] = t
+        self.trainable[full] = trainable
+        return t
+
+    def trainable_variables(self) -> Dict[str, torch.Tensor]:
+        return {n: v for n, v in self.vars.items() if self.trainable[n]}
+
+    def load(self, values: Dict[str, torch.Tensor], strict: bool = False):
+        """Copy values in by name (e.g. the oracle's weight dict)."""
+        with torch.no_grad():
+            for n, v in values.items():
+                if n in self.vars:
+                    self.vars[n].copy_(v.reshape(self.vars[n].shape).to(self.vars[n].dtype))
+                elif strict:
+                    raise KeyError(n)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {n: v.detach().clone() for n, v in self.vars.items()}
+
+    # -- regularisation collection (tf.losses.get_regularization_losses, train.py:301-303) ------
+    def add_regularization_loss(self, t: torch.Tensor):
+        self._reg_losses.append(t)
+
+    def pop_regularization_losses(self) -> List[torch.Tensor]:
+        out, self._reg_losses = self._reg_losses, []
+        return out
+
+
+# -- initialisers (TF1 names) --------------------------------------------------------------------
+def random_normal_initializer(stddev: float):
+    return lambda shape, dev, gen: torch.randn(shape, device=dev, generator=gen) * stddev
+
+
+def zeros_initializer():
+    return lambda shape, dev, gen: torch.zeros(shape, device=dev)
+
+
+def ones_initializer():
+    return lambda shape, dev, gen: torch.ones(shape, device=dev)
+
+
+def glorot_uniform_initializer():
+    """tf.layers.dense default kernel init / slim xavier_initializer (uniform)."""
+    def init(shape, dev, gen):
+        fan_in, fan_out = shape[0], shape[-1]
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return (torch.rand(shape, device=dev, generator=gen) * 2 - 1) * lim
+    return init
+
+
+# -- default store (TF's default graph) -----------------------------------------------------------
+_default = VariableStore()
+
+
+def default_store() -> VariableStore:
+    return _default
+
+
+@contextlib.contextmanager
+def use_store(store: VariableStore):
+    global _default
+    prev, _default = _default, store
+    try:
+        yield store
+    finally:
+        _default = prev
+
+
+def variable_scope(name: str):
+    return _default.variable_scope(name)
+
+
+def get_variable(name, shape, initializer, trainable=True, device=None):
+    return _default.get_variable(name, shape, initializer, trainable, device)

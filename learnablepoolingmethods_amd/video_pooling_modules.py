@@ -1,0 +1,39 @@
+"""NetVladAttenCluster (reference: video_pooling_modules.py:1589-1663)."""
+from __future__ import annotations
+
+import math
+
+from . import modules, ops, transformer_utils
+from . import variables as vs
+
+
+class NetVladAttenCluster(modules.BaseModule):
+    """NetVLAD whose cluster similarities come from a frame-level transformer encoder."""
+
+    def __init__(self, feature_size, max_frames, cluster_size, batch_norm, is_training, scope_id=None):
+        self.feature_size = feature_size
+        self.max_frames = max_frames
+        self.is_training = is_training
+        self.batch_norm = batch_norm
+        self.cluster_size = int(cluster_size)
+        self.scope_id = scope_id
+        self.encoder_hidden_size = feature_size
+        self.num_heads = feature_size // 16               # :1613
+        self.dropout_ratio = 0.1
+        self.filter_size = 4 * self.encoder_hidden_size   # :1615
+
+    def forward(self, inputs, dropout_mask=None, dropout_rate=None, **unused_params):
+        """inputs [(B*max_frames), F] -> [B, F*K] (f-major), L2-normalised."""
+        reshaped_input = inputs.reshape(-1, self.max_frames, self.feature_size)          # :1623
+        with vs.variable_scope("cluster_attention"):
+            encoder_block = transformer_utils.TransformerEncoderMod(
+                feature_size=self.feature_size, hidden_size=self.encoder_hidden_size, num_heads=self.num_heads,
+                attention_dropout=self.dropout_ratio, ff_filter_size=self.filter_size, ff_relu_dropout=0.1,
+                is_train=self.is_training, scope_id="encode", final_size=self.cluster_size)
+            cluster_similarities = encoder_block.forward(reshaped_input, dropout_mask=dropout_mask,
+                                                         dropout_rate=dropout_rate)          # [B,S,K] :1638
+        cluster_centres = vs.get_variable("cluster_centers", [self.feature_size, self.cluster_size],
+                                          vs.random_normal_initializer(1 / math.sqrt(self.feature_size)),
+                                          device=inputs.device)                                # :1641-1643
+        # sum_n sims * (x - c), intra-L2, flatten, L2 (:1646-1658; App. C6/C7) -- HIP kernel K2
+        return ops.vlad_aggregate(cluster_similarities, inputs, cluster_centres, self.max_frames)

@@ -1,0 +1,299 @@
+"""-m gpu: each HIP kernel through the C ABI vs the fp64 oracle on the same seeded inputs.
+Tolerance: 1e-3 relative (north_star); the exact-fp32 MFMA kernels land around 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lpm_oracle as O
+from oracle import numpy_ref as R
+from tests._util import assert_close, cuda, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _netvlad_inputs(B, T, D, K, ld=None, seed=0, dev=None):
+    g = torch.Generator().manual_seed(seed)
+    ld = ld or D
+    full = torch.randn(B * T, ld, generator=g)
+    W = torch.randn(D, K, generator=g) / D ** 0.5
+    gamma = 1 + 0.3 * torch.randn(K, generator=g)
+    beta = 0.2 * torch.randn(K, generator=g)
+    W2 = torch.randn(1, D, K, generator=g) / D ** 0.5
+    dout = torch.randn(B, D * K, generator=g)
+    return full, W, gamma, beta, W2, dout
+
+
+def _oracle_netvlad(x, W, gamma, beta, W2, T, dout, residual=True):
+    p = {"s/cluster_weights": W.double().requires_grad_(True), "s/cluster_bn/gamma": gamma.double().requires_grad_(True),
+         "s/cluster_bn/beta": beta.double().requires_grad_(True), "s/cluster_weights2": W2.double().requires_grad_(True)}
+    xd = x.double().requires_grad_(True)
+    upd = {}
+    fn = O.netvlad_forward if residual else O.lightvlad_forward
+    out = fn(xd, p, "s", T, True, True, upd)
+    out.backward(dout.double())
+    return out.detach(), xd.grad, p, upd
+
+
+@pytest.mark.parametrize("B,T,D,K,off", [(3, 30, 1024, 16, 0), (2, 37, 128, 64, 1024), (4, 300, 1024, 256, 0),
+                                          (2, 300, 128, 64, 1024), (2, 16, 256, 96, 0), (1, 9, 512, 40, 0)])
+def test_netvlad_fwd_bwd(B, T, D, K, off):
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    ld = 1152 if off or D == 1024 else D
+    full, W, gamma, beta, W2, dout = _netvlad_inputs(B, T, D, K, ld, seed=B * 1000 + T)
+    xs = full[:, off:off + D]
+    ref, dx_ref, p, upd = _oracle_netvlad(xs, W, gamma, beta, W2, T, dout)
+    fg = full.to(dev).requires_grad_(True)
+    xg = fg[:, off:off + D]
+    Wg, gg, bg, W2g = (t.to(dev).requires_grad_(True) for t in (W, gamma, beta, W2))
+    mm, mv = torch.zeros(K, device=dev), torch.ones(K, device=dev)
+    out = ops.netvlad(xg, Wg, W2g, T, bn=(gg, bg, mm, mv), is_training=True)
+    assert out.shape == (B, D * K)
+    assert_close(out, ref, what="netvlad fwd")
+    out.backward(dout.to(dev))
+    assert_close(fg.grad[:, off:off + D], dx_ref, what="dx")
+    assert_close(Wg.grad, p["s/cluster_weights"].grad, what="dW")
+    assert_close(gg.grad, p["s/cluster_bn/gamma"].grad, what="dgamma")
+    assert_close(bg.grad, p["s/cluster_bn/beta"].grad, what="dbeta")
+    assert_close(W2g.grad, p["s/cluster_weights2"].grad, what="dW2")
+    # moving statistics (decay 0.999, unbiased variance on the fused path)
+    assert_close(mm, upd["s/cluster_bn/moving_mean"] * 0.001, tol=1e-4, what="moving_mean")
+    assert_close(mv, 0.999 + upd["s/cluster_bn/moving_variance"] * 0.001, tol=1e-5, what="moving_var")
+    # norm invariant: unit global norm, every cluster column 1/sqrt(K)
+    o = out.detach().reshape(B, D, K)
+    assert torch.allclose(o.norm(dim=(1, 2)), torch.ones(B, device=dev), atol=1e-5)
+    assert torch.allclose(o.norm(dim=1), torch.full((B, K), K ** -0.5, device=dev), atol=1e-5)
+
+
+def test_netvlad_kmajor_layout_and_eval_mode():
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, T, D, K = 3, 20, 128, 32
+    full, W, gamma, beta, W2, dout = _netvlad_inputs(B, T, D, K, seed=5)
+    mm, mv = 0.1 * torch.randn(K), 1 + 0.2 * torch.rand(K)
+    p = {"s/cluster_weights": W.double(), "s/cluster_bn/gamma": gamma.double(), "s/cluster_bn/beta": beta.double(),
+         "s/cluster_weights2": W2.double(), "s/cluster_bn/moving_mean": mm.double(), "s/cluster_bn/moving_variance": mv.double()}
+    for k in ("s/cluster_weights", "s/cluster_weights2", "s/cluster_bn/gamma", "s/cluster_bn/beta"):
+        p[k].requires_grad_(True)
+    xd = full.double().requires_grad_(True)
+    ref = O.netvlad_forward(xd, p, "s", T, True, False)
+    refk = ref.reshape(B, D, K).transpose(1, 2)
+    dk = torch.randn(B, K, D, generator=torch.Generator().manual_seed(9))
+    (refk * dk.double()).sum().backward()
+    xg = full.to(dev).requires_grad_(True)
+    Wg, gg, bg, W2g = (t.to(dev).requires_grad_(True) for t in (W, gamma, beta, W2))
+    out = ops.netvlad(xg, Wg, W2g, T, bn=(gg, bg, mm.to(dev), mv.to(dev)), is_training=False, kmajor=True)
+    assert out.shape == (B, K, D)
+    assert_close(out, refk, what="kmajor eval fwd")
+    out.backward(dk.to(dev))
+    assert_close(xg.grad, xd.grad, what="dx")
+    assert_close(Wg.grad, p["s/cluster_weights"].grad, what="dW")
+    assert_close(gg.grad, p["s/cluster_bn/gamma"].grad, what="dgamma (eval)")
+    assert_close(W2g.grad, p["s/cluster_weights2"].grad, what="dW2")
+
+
+def test_lightvlad_and_bias_mode():
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, T, D, K = 2, 12, 128, 8
+    full, W, gamma, beta, W2, dout = _netvlad_inputs(B, T, D, K, seed=11)
+    ref, dx_ref, p, _ = _oracle_netvlad(full, W, gamma, beta, W2, T, dout, residual=False)
+    xg = full.to(dev).requires_grad_(True)
+    Wg, gg, bg = (t.to(dev).requires_grad_(True) for t in (W, gamma, beta))
+    out = ops.netvlad(xg, Wg, None, T, bn=(gg, bg, torch.zeros(K, device=dev), torch.ones(K, device=dev)))
+    assert_close(out, ref, what="lightvlad fwd")
+    out.backward(dout.to(dev))
+    assert_close(xg.grad, dx_ref, what="lightvlad dx")
+    # no-BN branch: logits + cluster_biases (frame_level_models.py:2790-2796)
+    bias = torch.randn(K, generator=torch.Generator().manual_seed(3))
+    pb = {"s/cluster_weights": W.double(), "s/cluster_biases": bias.double().requires_grad_(True), "s/cluster_weights2": W2.double()}
+    xd = full.double().requires_grad_(True)
+    refb = O.netvlad_forward(xd, pb, "s", T, False, True)
+    refb.backward(dout.double())
+    xg2 = full.to(dev).requires_grad_(True)
+    bgp = bias.to(dev).requires_grad_(True)
+    outb = ops.netvlad(xg2, W.to(dev), W2.to(dev), T, bn=None, bias=bgp)
+    assert_close(outb, refb, what="bias-mode fwd")
+    outb.backward(dout.to(dev))
+    assert_close(xg2.grad, xd.grad, what="bias-mode dx")
+    assert_close(bgp.grad, pb["s/cluster_biases"].grad, what="dbias")
+
+
+@pytest.mark.parametrize("B,T,D,K", [(2, 30, 128, 16), (2, 300, 1024, 256), (3, 17, 256, 64)])
+def test_vlad_aggregate_v2_form(B, T, D, K):
+    """NetVladAttenCluster tail: similarities may be negative, no softmax (video_pooling_modules.py:1646-1658)."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(B + T)
+    sims, x, C = torch.randn(B, T, K, generator=g), torch.randn(B * T, D, generator=g), torch.randn(D, K, generator=g) / D ** .5
+    dout = torch.randn(B, D * K, generator=g)
+    sd, xd, Cd = (t.double().requires_grad_(True) for t in (sims, x, C))
+    ref = O.vlad_aggregate(sd, xd.reshape(B, T, D), Cd)
+    ref.backward(dout.double())
+    sg, xg, Cg = (t.to(dev).requires_grad_(True) for t in (sims, x, C))
+    out = ops.vlad_aggregate(sg, xg, Cg, T)
+    assert_close(out, ref, what="v2 aggregate fwd")
+    out.backward(dout.to(dev))
+    assert_close(sg.grad, sd.grad, what="dsims")
+    assert_close(xg.grad, xd.grad, what="dx")
+    assert_close(Cg.grad, Cd.grad, what="dcentres")
+
+
+def test_vlad_degenerate_zero_column():
+    """A cluster with zero mass hits tf.nn.l2_normalize's 1e-12 clamp (forward 0, backward unprojected)."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, T, D, K = 2, 8, 128, 8
+    g = torch.Generator().manual_seed(1)
+    sims, x, C = torch.randn(B, T, K, generator=g), torch.randn(B * T, D, generator=g), torch.randn(D, K, generator=g)
+    sims[:, :, 3] = 0.0
+    dout = torch.randn(B, D * K, generator=g)
+    sd, xd, Cd = (t.double().requires_grad_(True) for t in (sims, x, C))
+    ref = O.vlad_aggregate(sd, xd.reshape(B, T, D), Cd)
+    ref.backward(dout.double())
+    sg, xg, Cg = (t.to(dev).requires_grad_(True) for t in (sims, x, C))
+    out = ops.vlad_aggregate(sg, xg, Cg, T)
+    assert torch.isfinite(out).all()
+    assert_close(out, ref, what="degenerate fwd")
+    out.backward(dout.to(dev))
+    assert_close(sg.grad, sd.grad, what="degenerate dsims")
+    assert_close(Cg.grad, Cd.grad, what="degenerate dcentres")
+
+
+def test_frame_permutation_invariance_full_size():
+    """Size-independent property at BASELINE cfg-2 shapes: the descriptor sums over frames, so permuting
+    the frames of every clip identically (BN statistics unchanged) leaves it unchanged."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, T, D, K = 80, 300, 1024, 256
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(B, T, 1152, device=dev, generator=g)
+    W = torch.randn(D, K, device=dev, generator=g) / 32
+    W2 = torch.randn(1, D, K, device=dev, generator=g) / 32
+    bn = lambda: (torch.ones(K, device=dev), torch.zeros(K, device=dev), torch.zeros(K, device=dev), torch.ones(K, device=dev))
+    a = ops.netvlad(x.reshape(B * T, 1152)[:, :D], W, W2, T, bn=bn())
+    perm = torch.randperm(T, device=dev, generator=g)
+    b = ops.netvlad(x[:, perm].reshape(B * T, 1152)[:, :D], W, W2, T, bn=bn())
+    assert rel_err(a, b) < 1e-4
+    o = a.reshape(B, D, K)
+    assert torch.allclose(o.norm(dim=(1, 2)), torch.ones(B, device=dev), atol=1e-5)
+
+
+@pytest.mark.parametrize("B,L,h,d", [(2, 256, 4, 16), (3, 64, 16, 8), (2, 300, 8, 16), (1, 33, 2, 16), (2, 16, 1, 8)])
+def test_mha_core(B, L, h, d):
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(L)
+    F = h * d
+    q, k, v, do = (torch.randn(B, L, F, generator=g) for _ in range(4))
+    sc = d ** -0.5
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = O._combine_heads(O.attention_core(O._split_heads(qd, h), O._split_heads(kd, h), O._split_heads(vd, h), sc))
+    ref.backward(do.double())
+    qg, kg, vg = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out = ops.mha_core(qg, kg, vg, h, sc)
+    assert_close(out, ref, what="mha fwd")
+    out.backward(do.to(dev))
+    assert_close(qg.grad, qd.grad, what="dq")
+    assert_close(kg.grad, kd.grad, what="dk")
+    assert_close(vg.grad, vd.grad, what="dv")
+
+
+@pytest.mark.parametrize("B,L,h,d,training", [(2, 48, 2, 16, True), (2, 300, 8, 16, True), (2, 30, 8, 16, False)])
+def test_mha_core_logits_bn(B, L, h, d, training):
+    """MultiHeadAttentionBN core: batch_norm over the key-position channel of [B,h,Lq,Lk] (transformer_utils.py:652-659)."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(L + 1)
+    F = h * d
+    q, k, v, do = (0.5 * torch.randn(B, L, F, generator=g) for _ in range(4))
+    gamma, beta = 1 + 0.2 * torch.randn(L, generator=g), 0.1 * torch.randn(L, generator=g)
+    mm, mv = 0.1 * torch.randn(L, generator=g), 1 + 0.3 * torch.rand(L, generator=g)
+    p = {"bn/gamma": gamma.double().requires_grad_(True), "bn/beta": beta.double().requires_grad_(True),
+         "bn/moving_mean": mm.double(), "bn/moving_variance": mv.double()}
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    upd = {}
+    ref = O._combine_heads(O.attention_core(O._split_heads(qd, h), O._split_heads(kd, h), O._split_heads(vd, h), 1.0,
+                                            lambda lg: O.batch_norm(lg, p, "bn", training, upd)))
+    ref.backward(do.double())
+    qg, kg, vg, gg, bg = (t.to(dev).requires_grad_(True) for t in (q, k, v, gamma, beta))
+    mmg, mvg = mm.to(dev), mv.to(dev)
+    out = ops.mha_core_bn(qg, kg, vg, h, gg, bg, mmg, mvg, is_training=training)
+    assert_close(out, ref, what="mha-bn fwd")
+    out.backward(do.to(dev))
+    assert_close(qg.grad, qd.grad, what="dq")
+    assert_close(kg.grad, kd.grad, what="dk")
+    assert_close(vg.grad, vd.grad, what="dv")
+    assert_close(gg.grad, p["bn/gamma"].grad, what="dgamma")
+    assert_close(bg.grad, p["bn/beta"].grad, what="dbeta")
+    if training:
+        assert_close(mmg, mm.double() * 0.999 + upd["bn/moving_mean"] * 0.001, tol=1e-5, what="moving_mean")
+        assert_close(mvg, mv.double() * 0.999 + upd["bn/moving_variance"] * 0.001, tol=1e-5, what="moving_var")
+
+
+@pytest.mark.parametrize("B,MF,F,S", [(4, 30, 1024, 30), (3, 300, 1152, 300), (2, 300, 1152, 256), (5, 40, 128, 7)])
+def test_frame_sample_bn(B, MF, F, S):
+    from learnablepoolingmethods_amd import model_utils, ops
+    dev = cuda()
+    x, nf, _ = O.make_synthetic_batch(B, MF, F, 10, seed=S)
+    ref_s = O.sample_uniform_frames(x, nf, S)
+    got_s = model_utils.SampleUniformFrames(x.to(dev), nf.to(dev), S)
+    assert torch.equal(got_s.cpu(), ref_s), "gather must be bit-exact (index arithmetic is integer work)"
+    g = torch.Generator().manual_seed(2)
+    gamma, beta = 1 + 0.2 * torch.randn(F, generator=g), 0.1 * torch.randn(F, generator=g)
+    p = {"input_bn/gamma": gamma.double().requires_grad_(True), "input_bn/beta": beta.double().requires_grad_(True)}
+    upd = {}
+    ref = O.batch_norm(ref_s.double().reshape(-1, F), p, "input_bn", True, upd)
+    dy = torch.randn(B * S, F, generator=g)
+    ref.backward(dy.double())
+    gg, bg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    mm, mv = torch.zeros(F, device=dev), torch.ones(F, device=dev)
+    y = ops.frame_sample_bn(x.to(dev), nf.to(dev), S, gg, bg, mm, mv, True)
+    assert_close(y, ref, what="input_bn fwd")
+    y.backward(dy.to(dev))
+    assert_close(gg.grad, p["input_bn/gamma"].grad, what="input_bn dgamma")
+    assert_close(bg.grad, p["input_bn/beta"].grad, what="input_bn dbeta")
+    assert_close(mm, upd["input_bn/moving_mean"] * 0.001, tol=1e-4, what="moving_mean")
+
+
+def test_clip_adam_matches_oracle():
+    from learnablepoolingmethods_amd import ops
+    from learnablepoolingmethods_amd.train import ARENA_ALIGN
+    dev = cuda()
+    g = torch.Generator().manual_seed(0)
+    shapes = [(700, 33), (5,), (4096,), (123, 7), (1,)]
+    scales = [3.0, 0.01, 0.05, 1.0, 5.0]          # some variables clip, some do not
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    gs = [torch.randn(s, generator=g) * c for s, c in zip(shapes, scales)]
+    offs, cur = [], 0
+    for p in ps:
+        offs.append(cur)
+        cur += (p.numel() + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+    offs.append(cur)
+    P, G, M, V = (torch.zeros(cur, device=dev) for _ in range(4))
+    for p, gr, o in zip(ps, gs, offs):
+        P[o:o + p.numel()] = p.flatten().to(dev)
+        G[o:o + p.numel()] = gr.flatten().to(dev)
+    offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
+    ref_p = [p.double() for p in ps]
+    ref_m = [torch.zeros_like(p).double() for p in ps]
+    ref_v = [torch.zeros_like(p).double() for p in ps]
+    for step in (1, 2, 3):
+        ops.clip_adam_step(P, G, M, V, offsets, len(ps), 1.0, 2e-4, step)
+        cl = O.clip_gradient_norms({i: g_.double() for i, g_ in enumerate(gs)}, 1.0)
+        for i in range(len(ps)):
+            ref_p[i], ref_m[i], ref_v[i] = O.adam_tf_update(ref_p[i], cl[i], ref_m[i], ref_v[i], 2e-4, step)
+    for p, rp, rm, o in zip(ps, ref_p, ref_m, offs):
+        assert_close(P[o:o + p.numel()].reshape(p.shape), rp, tol=1e-6, what="adam param")
+        assert_close(M[o:o + p.numel()].reshape(p.shape), rm, tol=1e-5, what="adam m")
+
+
+def test_capi_rejects_bad_shapes_loudly():
+    from learnablepoolingmethods_amd import _capi, ops
+    dev = cuda()
+    x = torch.randn(10, 100, device=dev)     # D = 100 unsupported
+    W = torch.randn(100, 8, device=dev)
+    with pytest.raises(_capi.LpmError):
+        ops.netvlad(x, W, None, 5, bn=None, bias=torch.zeros(8, device=dev))
+    with pytest.raises(_capi.LpmError):
+        ops.mha_core(torch.randn(1, 8, 24, device=dev), torch.randn(1, 8, 24, device=dev), torch.randn(1, 8, 24, device=dev), 2, 1.0)

@@ -1,0 +1,159 @@
+"""-m gpu: NetVladV1 / NetVladV2 through the registry API vs the oracle (forward, one and two
+optimiser steps).  BASELINE configs: cfg-1 exactly; cfg-2 / cfg-3 at their real layer sizes with the
+batch cut to what the CPU oracle finishes in seconds."""
+import pytest
+import torch
+
+from oracle import lpm_oracle as O
+from tests._util import assert_close, cuda
+
+pytestmark = pytest.mark.gpu
+
+
+def _product_forward(name, params, x, nf, cfg, is_training, dev, **kw):
+    from learnablepoolingmethods_amd import registry
+    from learnablepoolingmethods_amd import variables as vs
+    store = vs.VariableStore(device=dev, seed=1)
+    model = registry.get_model(name)
+    args = dict(vocab_size=cfg.vocab_size, num_frames=nf.to(dev), iterations=cfg.iterations, cluster_size=cfg.cluster_size,
+                hidden_size=cfg.hidden_size, is_training=is_training, **kw)
+    with vs.use_store(store):
+        with torch.no_grad():
+            model.create_model(x.to(dev), **args)          # creates the variables
+        missing = [n for n in params if n not in store.vars and not n.endswith("cluster_biases")]
+        assert not missing, f"variables the oracle has but the model did not create: {missing}"
+        extra = [n for n in store.vars if n not in params]
+        assert not extra, f"variables the model created that the oracle does not know: {extra}"
+        store.load(params)
+        out = model.create_model(x.to(dev), **args)
+        store.pop_regularization_losses()
+    return out["predictions"], store
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_cfg1_netvladv1_forward(training):
+    """BASELINE configs[0]: NetVladV1 K=16 hidden=128, 30-frame rgb-only (1024-d), bs=8."""
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", iterations=30, cluster_size=16, hidden_size=128)
+    x, nf, _ = O.make_synthetic_batch(8, 30, 1024, cfg.vocab_size, seed=0, min_frames=10)
+    p = O.init_params(cfg, 1024, seed=1000)
+    ref = O.model_forward({k: v.double() for k, v in p.items()}, x.double(), nf, cfg, training)
+    pred, _ = _product_forward("NetVladV1", p, x, nf, cfg, training, dev)
+    assert pred.shape == (8, 3862)
+    assert_close(pred, ref, what="cfg-1 predictions")
+
+
+def test_netvladv1_rgb_audio_small():
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", iterations=20, cluster_size=32, hidden_size=64, vocab_size=100)
+    x, nf, _ = O.make_synthetic_batch(4, 25, 1152, 100, seed=1, min_frames=8)
+    p = O.init_params(cfg, 1152, seed=1001)
+    ref = O.model_forward({k: v.double() for k, v in p.items()}, x.double(), nf, cfg, True)
+    pred, _ = _product_forward("NetVladV1", p, x, nf, cfg, True, dev)
+    assert_close(pred, ref, what="V1 rgb+audio predictions")
+
+
+def test_gated_netvlad_no_encoder():
+    """BASELINE cfg-5 family: NetVLAD + gating + MoE-4 without the cluster encoders."""
+    from learnablepoolingmethods_amd import FLAGS
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", iterations=16, cluster_size=64, hidden_size=64, vocab_size=50, encoder=False,
+                         moe_num_mixtures=4)
+    x, nf, _ = O.make_synthetic_batch(3, 20, 1152, 50, seed=2, min_frames=8)
+    p = O.init_params(cfg, 1152, seed=1002)
+    ref = O.model_forward({k: v.double() for k, v in p.items()}, x.double(), nf, cfg, True)
+    FLAGS.moe_num_mixtures = 4
+    try:
+        pred, _ = _product_forward("NetVladV1", p, x, nf, cfg, True, dev, encoder=False)
+    finally:
+        FLAGS.reset()
+    assert_close(pred, ref, what="gated NetVLAD predictions")
+
+
+def test_netvladv2_forward_with_dropout_mask():
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV2", iterations=24, cluster_size=32, hidden_size=64, vocab_size=80)
+    B = 3
+    x, nf, _ = O.make_synthetic_batch(B, 30, 1152, 80, seed=3, min_frames=10)
+    p = O.init_params(cfg, 1152, seed=1003)
+    g = torch.Generator().manual_seed(4)
+    masks = {"video": (torch.rand(B, 24, 1024, generator=g) >= 0.9).float(),
+             "audio": (torch.rand(B, 24, 128, generator=g) >= 0.9).float()}
+    ref = O.model_forward({k: v.double() for k, v in p.items()}, x.double(), nf, cfg, True,
+                          dropout_masks={k: v.double() for k, v in masks.items()})
+    pred, _ = _product_forward("NetVladV2", p, x, nf, cfg, True, dev,
+                               dropout_masks={k: v.to(dev) for k, v in masks.items()})
+    assert_close(pred, ref, what="V2 predictions")
+
+
+def test_cfg2_layer_sizes_reduced_batch():
+    """BASELINE configs[1] layer sizes (K=256, hidden=512, 300 x 1152) with bs 4 (oracle in fp32 on the CPU)."""
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", iterations=300, cluster_size=256, hidden_size=512)
+    x, nf, _ = O.make_synthetic_batch(4, 300, 1152, cfg.vocab_size, seed=0)
+    p = O.init_params(cfg, 1152, seed=1000)
+    with torch.no_grad():
+        ref, inter = O.model_forward(p, x, nf, cfg, True, return_intermediates=True)
+    pred, _ = _product_forward("NetVladV1", p, x, nf, cfg, True, dev)
+    assert_close(pred, ref, what="cfg-2 predictions")
+
+
+def test_cfg3_layer_sizes_reduced_batch():
+    """BASELINE configs[2]: NetVladV2 K=256, 300 x 1152, hidden 512; bs 2, dropout disabled for determinism."""
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV2", iterations=300, cluster_size=256, hidden_size=512, v2_dropout_rate=0.0)
+    x, nf, _ = O.make_synthetic_batch(2, 300, 1152, cfg.vocab_size, seed=1)
+    p = O.init_params(cfg, 1152, seed=1001)
+    with torch.no_grad():
+        ref = O.model_forward(p, x, nf, cfg, True)
+    pred, _ = _product_forward("NetVladV2", p, x, nf, cfg, True, dev, dropout_rate=0.0)
+    assert_close(pred, ref, what="cfg-3 predictions")
+
+
+def _train_compare(name, cfg, feat, B, MF, steps, dev, tol=1e-3, **kw):
+    from learnablepoolingmethods_amd import registry
+    from learnablepoolingmethods_amd.train import Trainer
+    x, nf, lab = O.make_synthetic_batch(B, MF, feat, cfg.vocab_size, seed=7, min_frames=max(2, MF // 3))
+    p = {k: v.double() for k, v in O.init_params(cfg, feat, seed=1007).items()}
+    tr = Trainer(registry.get_model(name), vocab_size=cfg.vocab_size, batch_size=B, base_learning_rate=cfg.base_learning_rate,
+                 learning_rate_decay=cfg.learning_rate_decay, learning_rate_decay_examples=cfg.learning_rate_decay_examples,
+                 device=dev, model_kwargs=dict(iterations=cfg.iterations, cluster_size=cfg.cluster_size,
+                                               hidden_size=cfg.hidden_size, **kw))
+    tr.build(x, nf, lab)
+    tr.store.load({"tower/" + k: v for k, v in p.items()})
+    st = {"step": 0, "m": {}, "v": {}}
+    for s in range(steps):
+        out = tr.step(x, nf, lab)
+        p, st, info = O.train_step(p, st, x.double(), nf, lab, cfg, 1)
+        assert_close(out["loss"], info["loss"], tol=1e-4, what=f"step {s} loss")
+        assert_close(out["predictions"], info["predictions"], what=f"step {s} predictions")
+    names = O.trainable_names(p, cfg)
+    worst = 0.0
+    for n in names:
+        got = tr.store.vars["tower/" + n]
+        # compare the UPDATE (w - w0 is ~lr per element), scaled by lr: catches clip / Adam mistakes
+        worst = max(worst, assert_close(got, p[n], tol=tol, what=f"post-step weights {n}"))
+    for n in p:
+        if n.endswith("moving_mean") or n.endswith("moving_variance"):
+            assert_close(tr.store.vars["tower/" + n], p[n], tol=1e-4, what=f"moving stat {n}")
+    return worst
+
+
+def test_train_steps_cfg1_v1():
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", iterations=30, cluster_size=16, hidden_size=128, base_learning_rate=1e-3)
+    _train_compare("NetVladV1", cfg, 1024, 8, 30, 2, dev)
+
+
+def test_train_steps_v1_audio():
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", iterations=12, cluster_size=16, hidden_size=32, vocab_size=40,
+                         base_learning_rate=1e-3)
+    _train_compare("NetVladV1", cfg, 1152, 4, 16, 2, dev)
+
+
+def test_train_steps_v2():
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV2", iterations=12, cluster_size=16, hidden_size=32, vocab_size=40,
+                         base_learning_rate=1e-3, v2_dropout_rate=0.0)
+    _train_compare("NetVladV2", cfg, 1152, 4, 16, 2, dev, dropout_rate=0.0)
