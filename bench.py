@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/sec of one full NetVladV1 training step (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = fwd + bwd + gradient SUM all-reduce (RCCL) + per-variable clip + TF-Adam on one synthetic batch
+already resident in HBM (the reference's `Examples/sec`, train.py:450-451).  Workload = BASELINE configs[1]:
+NetVladV1 K=256 hidden=512, rgb+audio 1152-d, 300 frames, bs 80 per GPU (weak scaling: cfg-4 at 8 GPUs).
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` for the residual-aggregation kernel (K2, video
+stream) timed with HIP events on the launch stream inside the timed region, and `cpu_baseline` = the CPU
+oracle (fp32 torch restatement, oracle/) timed on this box's host cores on a bounded sample (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+METRIC = "clips/sec training step, NetVladV1 K=256 300-frame 1152-d, bs=80, 1/2/4/8 GPU"
+CFG = dict(iterations=300, cluster_size=256, hidden_size=512)           # README.md:12-18 with 300 frames (BASELINE)
+PER_GPU_BATCH, MAX_FRAMES, FEATURE, VOCAB = 80, 300, 1152, 3862
+TRAIN = dict(base_learning_rate=0.0002, learning_rate_decay=0.85, learning_rate_decay_examples=4000000)
+HBM_PEAK_GBS = 8000.0                                                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def synthetic_batch(batch, device, seed):
+    """Reader-faithful synthetic input generated on the device: uint8 -> Dequantize
+    (utils.py:28-43) -> zero the frames past num_frames (readers.py:189-193); 1-5 positive labels."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    q = torch.randint(0, 256, (batch, MAX_FRAMES, FEATURE), device=device, generator=g, dtype=torch.uint8)
+    nf = torch.randint(120, MAX_FRAMES + 1, (batch,), device=device, generator=g, dtype=torch.int32)
+    raw = q.float() * (4.0 / 255.0) + (4.0 / 512.0 - 2.0)
+    raw = raw * (torch.arange(MAX_FRAMES, device=device)[None, :, None] < nf[:, None, None])
+    labels = torch.zeros(batch, VOCAB, dtype=torch.bool, device=device)
+    npos = torch.randint(1, 6, (batch,), device=device, generator=g)
+    idx = torch.randint(0, VOCAB, (batch, 5), device=device, generator=g)
+    labels.scatter_(1, idx, torch.arange(5, device=device)[None, :] < npos[:, None])
+    return raw, nf, labels
+
+
+def k2_algorithmic_bytes(B, T, D, K, elt=4):
+    """read assignment logits + frames once, W2 once per batch, write the descriptor once."""
+    return elt * (B * T * K + B * T * D + D * K + B * D * K)
+
+
+def cpu_baseline(budget_s):
+    """The oracle's train_step (fp32, torch CPU) on a bounded sample of the same workload."""
+    from oracle import lpm_oracle as O
+    cfg = O.OracleConfig(model="NetVladV1", **CFG, **TRAIN)
+    b = 4
+    torch.set_num_threads(os.cpu_count() or 1)
+    x, nf, lab = O.make_synthetic_batch(b, MAX_FRAMES, FEATURE, VOCAB, seed=0)
+    p = O.init_params(cfg, FEATURE, seed=1000)
+    st = {"step": 0, "m": {}, "v": {}}
+    t0 = time.perf_counter()
+    p, st, _ = O.train_step(p, st, x, nf, lab, cfg, 1)            # warm-up (page-in, thread pools)
+    warm = time.perf_counter() - t0
+    times = []
+    while len(times) < 5 and (sum(times) + warm) < budget_s:
+        t0 = time.perf_counter()
+        p, st, _ = O.train_step(p, st, x, nf, lab, cfg, 1)
+        times.append(time.perf_counter() - t0)
+    if not times:
+        times = [warm]
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(b / med, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/lpm_oracle.train_step fp32 torch-CPU, same NetVladV1 cfg-2 layer sizes, batch {b} "
+                      f"(1 warm-up + {len(times)} timed steps, median {med:.2f} s/step); stand-in for the TF1 "
+                      f"reference, which cannot run here (SURVEY F2)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)       # nccl == RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from learnablepoolingmethods_amd import ops, registry
+    from learnablepoolingmethods_amd.train import Trainer
+
+    model = registry.get_model("NetVladV1")
+    trainer = Trainer(model, vocab_size=VOCAB, batch_size=PER_GPU_BATCH, device=device, seed=1234, model_kwargs=CFG, **TRAIN)
+    raw, nf, labels = synthetic_batch(PER_GPU_BATCH, device, seed=rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(raw, nf, labels)
+    ops.KERNEL_TIMELINE = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(raw, nf, labels)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timeline, ops.KERNEL_TIMELINE = ops.KERNEL_TIMELINE, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(out["loss"])
+
+    if rank == 0:
+        global_batch = PER_GPU_BATCH * world
+        ms = 1000.0 * elapsed / args.steps
+        value = global_batch * args.steps / elapsed
+        # dominant north-star kernel: K2 residual aggregation on the video stream (D=1024)
+        k2 = [(d, a.elapsed_time(b)) for (n, d, a, b) in timeline if n == "vlad_aggregate_fwd" and d[2] == 1024]
+        k1 = [(d, a.elapsed_time(b)) for (n, d, a, b) in timeline if n == "assign_gemm_fwd" and d[1] == 1024]
+        roof = None
+        if k2:
+            B, T, D, K = k2[0][0]
+            avg_ms = sum(t for _, t in k2) / len(k2)
+            bytes_ = k2_algorithmic_bytes(B, T, D, K)
+            ach = bytes_ / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": "vlad_aggregate_kernel<8,4,true> (K2, video stream)", "bound": "hbm", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes": bytes_, "avg_kernel_ms": round(avg_ms, 4), "launches": len(k2),
+                    "flops_per_launch": 2.0 * B * T * D * K,
+                    "achieved_tflops_fp32_mfma": round(2.0 * B * T * D * K / (avg_ms * 1e-3) / 1e12, 2)}
+            pmc = os.path.join(ROOT, "profiles", "k2_hbm_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    roof["traffic"] = json.load(open(pmc)).get("bytes_per_launch")
+                except Exception:
+                    pass
+        line = {"metric": METRIC, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "NetVladV1 K=256 hidden=512 rgb+audio 1152-d 300 frames, bs 80 per GPU "
+                                       "(BASELINE configs[1]; configs[3] at 8 GPUs), full training step",
+                           "global_batch": global_batch, "seq_len": MAX_FRAMES, "parallelism": f"dp{world}"},
+                "final_loss": round(loss, 4)}
+        if roof:
+            line["roofline"] = roof
+        if k1:
+            M, D, K = k1[0][0]
+            avg_ms = sum(t for _, t in k1) / len(k1)
+            line["assign_gemm"] = {"avg_kernel_ms": round(avg_ms, 4), "tflops": round(2.0 * M * D * K / (avg_ms * 1e-3) / 1e12, 2),
+                                   "mfma": "v_mfma_f32_32x32x2_f32 (exact fp32, peak 157.3 TFLOP/s)"}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) void vlad_bwd_main_kernel(
     constexpr int KPL = 2 * KTW;          // logits columns per lane in a row pass
     constexpr int NP = 4 * KTW;           // float4 staging passes per d-chunk (32 rows x K/4 float4 / 256 thr)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int KS = K + 1;                 // padded row stride (column-wise MFMA operand reads)
+    const int KT = (K + 31) / 32;
+    const int KS = KT * 32 + 1;           // row stride: K rounded up to whole 32-cluster tiles (+1: column-wise
+                                          // MFMA operand reads hit distinct banks); pad columns hold zeros
     float* As = smem;                     // [32][KS]  assignment tile
     float* dUs = As + VB_TS * KS;         // [32][KS]  dU chunk; later dA - ctil
     float* xs = dUs + VB_DC * KS;         // [32][33]  x chunk
@@ -138,8 +140,10 @@ __global__ __launch_bounds__(256) void vlad_bwd_main_kernel(
     const int half = lane >> 5, l31 = lane & 31;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = lid / nts, t0 = (lid % nts) * VB_TS;
-    const int KT = (K + 31) / 32;
     const int K4 = K / 4;
+
+    for (int i = tid; i < 2 * VB_TS * KS; i += 256) smem[i] = 0.f;   // As and dUs, including the pad columns
+    __syncthreads();
 
     for (int k = tid; k < K; k += 256) {
         cu[k] = ug[(int64_t)b * K + k];
@@ -343,7 +347,8 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
 }
 
 static size_t bwd_main_lds_bytes(int K) {
-    return (size_t)(2 * 32 * (K + 1) + 32 * 33 + 4 * 32 * 33 + 3 * K) * sizeof(float);
+    const int KS = (K + 31) / 32 * 32 + 1;
+    return (size_t)(2 * 32 * KS + 32 * 33 + 4 * 32 * 33 + 3 * K) * sizeof(float);
 }
 
 }  // namespace lpm

@@ -16,6 +16,28 @@ from ._capi import LPM_VLAD_OUT_KMAJOR, LPM_VLAD_RESIDUAL, LPM_VLAD_SOFTMAX, Lpm
 BN_EPS = 1e-3     # slim.batch_norm epsilon
 BN_DECAY = 0.999  # slim.batch_norm decay
 
+# bench.py sets this to a list to collect (name, dims, start_event, end_event) around hot-kernel launches
+# on the current stream (HIP events; nothing is recorded or synchronised when it is None).
+KERNEL_TIMELINE = None
+
+
+class _timed:
+    def __init__(self, name, dims):
+        self.name, self.dims = name, dims
+
+    def __enter__(self):
+        if KERNEL_TIMELINE is not None:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t1 = torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if KERNEL_TIMELINE is not None:
+            self.t1.record()
+            KERNEL_TIMELINE.append((self.name, self.dims, self.t0, self.t1))
+        return False
+
 
 def _f32(t: torch.Tensor, what: str) -> torch.Tensor:
     if t.dtype != torch.float32:
@@ -116,9 +138,10 @@ def frame_sample_bn(raw, num_frames, S, gamma=None, beta=None, moving_mean=None,
 def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor):
     nrm = _empty((B, D, K), x)
     asum, colsq, csq = (_empty((B, K), x) for _ in range(3))
-    lib.check(lib._lpm_vlad_aggregate_fwd(ptr(assign), ptr(scale), ptr(shift), ptr(x), x.stride(0), ptr(centres), B, T, D, K,
-                                          flags, ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), stream_ptr()),
-              "lpm_vlad_aggregate_fwd")
+    with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+        lib.check(lib._lpm_vlad_aggregate_fwd(ptr(assign), ptr(scale), ptr(shift), ptr(x), x.stride(0), ptr(centres), B, T, D,
+                                              K, flags, ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), stream_ptr()),
+                  "lpm_vlad_aggregate_fwd")
     out = _empty((B, K, D) if kmajor else (B, D * K), x)
     gsq = _empty((B,), x)
     lib.check(lib._lpm_vlad_finalize_fwd(ptr(nrm), ptr(csq), B, D, K, LPM_VLAD_OUT_KMAJOR if kmajor else 0, ptr(out),
@@ -157,8 +180,9 @@ class _NetVLAD(torch.autograd.Function):
         nblk = lib._lpm_assign_gemm_nblk(M)
         logits = _empty((M, K), x)
         partial = _empty((nblk, 2, K), x)
-        lib.check(lib._lpm_assign_gemm_fwd(ptr(x), x.stride(0), ptr(W), M, D, K, 0, ptr(logits), ptr(partial), stream_ptr()),
-                  "lpm_assign_gemm_fwd")
+        with _timed("assign_gemm_fwd", (M, D, K)):
+            lib.check(lib._lpm_assign_gemm_fwd(ptr(x), x.stride(0), ptr(W), M, D, K, 0, ptr(logits), ptr(partial),
+                                               stream_ptr()), "lpm_assign_gemm_fwd")
         mean = var = None
         use_bn = gamma is not None
         if use_bn:
