@@ -57,7 +57,7 @@ def cpu_baseline(budget_s):
     from oracle import lpm_oracle as O
     cfg = O.OracleConfig(model="NetVladV1", **CFG, **TRAIN)
     b = 4
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_flush_denormal(True)   # as TF's CPU kernels do; g*g underflows to denormals in Adam otherwise (100x slower)
     x, nf, lab = O.make_synthetic_batch(b, MAX_FRAMES, FEATURE, VOCAB, seed=0)
     p = O.init_params(cfg, FEATURE, seed=1000)
     st = {"step": 0, "m": {}, "v": {}}

@@ -515,7 +515,8 @@ def train_step(params, opt_state, model_input, num_frames, labels, cfg: OracleCo
         m0 = opt_state["m"].get(n, torch.zeros_like(params[n]))
         v0 = opt_state["v"].get(n, torch.zeros_like(params[n]))
         new_params[n], new_m[n], new_v[n] = adam_tf_update(params[n], g, m0, v0, lr, t)
-    info = {"loss": torch.stack(losses).mean(), "predictions": torch.cat(preds, 0), "clipped_grads": merged, "lr": lr}
+    info = {"loss": torch.stack(losses).mean(), "predictions": torch.cat(preds, 0), "clipped_grads": merged, "lr": lr,
+            "adam_m": new_m, "adam_v": new_v}
     return new_params, {"step": t, "m": new_m, "v": new_v}, info
 
 
