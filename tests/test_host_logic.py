@@ -1,0 +1,97 @@
+"""-m "not gpu": host-side logic that mirrors the reference's registry / flags / variable scoping /
+training-loop arithmetic (no kernels)."""
+import pytest
+import torch
+
+from learnablepoolingmethods_amd import FLAGS, registry, train, utils
+from learnablepoolingmethods_amd import models as lp_models
+from learnablepoolingmethods_amd import variables as vs
+from oracle import lpm_oracle as O
+
+
+def test_registry_finds_reference_class_names():
+    for name in ("NetVladV1", "NetVladV2", "MoeModel"):
+        cls = registry.find_class_by_name(name)
+        assert cls.__name__ == name and issubclass(cls, lp_models.BaseModel)
+        cls()                                   # no-arg constructible, as train.py:680-681 needs
+        assert registry.validate_class_name(name)
+    with pytest.raises(ValueError):
+        registry.find_class_by_name("NoSuchModel")
+    with pytest.raises(NotImplementedError):
+        lp_models.BaseModel().create_model(None)
+
+
+def test_flag_defaults_match_reference():
+    assert FLAGS.netvlad_cluster_size == 256 and FLAGS.netvlad_hidden_size == 1024 and FLAGS.iterations == 30
+    assert FLAGS.netvlad_add_batch_norm and FLAGS.gating and not FLAGS.netvlad_relu and not FLAGS.gating_remove_diag
+    assert FLAGS.moe_num_mixtures == 2 and FLAGS.moe_l2 == 1e-8
+    assert FLAGS.clip_gradient_norm == 1.0 and FLAGS.regularization_penalty == 1.0
+    FLAGS.moe_num_mixtures = 4
+    FLAGS.reset()
+    assert FLAGS.moe_num_mixtures == 2
+    with pytest.raises(AttributeError):
+        FLAGS.no_such_flag = 1
+
+
+def test_variable_store_scoping_and_reuse():
+    store = vs.VariableStore(device="cpu", seed=3)
+    with vs.use_store(store):
+        with vs.variable_scope("tower"):
+            with vs.variable_scope("video_VLAD"):
+                a = vs.get_variable("cluster_weights", [4, 2], vs.random_normal_initializer(0.5))
+                b = vs.get_variable("cluster_weights", [4, 2], vs.random_normal_initializer(0.5))   # reuse
+            mm = vs.get_variable("moving_mean", [2], vs.zeros_initializer(), trainable=False)
+        assert a is b and "tower/video_VLAD/cluster_weights" in store.vars
+        assert a.requires_grad and not mm.requires_grad
+        assert list(store.trainable_variables()) == ["tower/video_VLAD/cluster_weights"]
+        with pytest.raises(ValueError):
+            with vs.variable_scope("tower"), vs.variable_scope("video_VLAD"):
+                vs.get_variable("cluster_weights", [5, 2], vs.zeros_initializer())
+    store.load({"tower/video_VLAD/cluster_weights": torch.ones(4, 2)})
+    assert torch.equal(a.detach(), torch.ones(4, 2))
+
+
+def test_learning_rate_matches_oracle():
+    cfg = O.OracleConfig(base_learning_rate=2e-4, learning_rate_decay=0.85, learning_rate_decay_examples=4000000)
+    for step in (0, 1, 6249, 6250, 12500, 100000):
+        assert train.learning_rate(2e-4, step, 80, 8, 4000000, 0.85) == O.learning_rate(cfg, step, 80, 8)
+
+
+def test_utils_combine_and_clip_match_oracle():
+    g = torch.Generator().manual_seed(0)
+    towers = [{"a": torch.randn(5, 3, generator=g) * s, "b": torch.randn(7, generator=g) * 0.01} for s in (1.0, 3.0)]
+    got = utils.clip_gradient_norms(utils.combine_gradients(towers), 1.0)
+    ref = O.clip_gradient_norms(O.combine_gradients(towers), 1.0)
+    for n in ref:
+        assert torch.equal(got[n], ref[n])
+    assert abs(float(got["a"].norm()) - 1.0) < 1e-6            # clipped
+    assert float(got["b"].norm()) < 1.0                         # left alone
+
+
+def test_dequantize_matches_reference_formula():
+    q = torch.arange(256, dtype=torch.float32)
+    d = utils.Dequantize(q)
+    assert abs(float(d[0]) - (4 / 512 - 2)) < 1e-7 and abs(float(d[255]) - (4 + 4 / 512 - 2)) < 1e-6
+
+
+def test_parameter_arena_layout_and_views():
+    store = vs.VariableStore(device="cpu", seed=0)
+    with vs.use_store(store):
+        w = vs.get_variable("hidden1_weights", [300, 7], vs.random_normal_initializer(1.0))
+        b = vs.get_variable("b", [5], vs.ones_initializer())
+        vs.get_variable("moving_mean", [5], vs.zeros_initializer(), trainable=False)
+    w0 = w.detach().clone()
+    arena = train.ParameterArena(store, first=["b"])
+    assert arena.names == ["b", "hidden1_weights"]
+    assert all(o % train.ARENA_ALIGN == 0 for o in arena.offsets_host)
+    assert arena.total == 2 * train.ARENA_ALIGN
+    assert torch.equal(w.detach(), w0) and w.data_ptr() == arena.param[train.ARENA_ALIGN:].data_ptr()
+    (w.sum() * 2 + b.sum()).backward()
+    a0, _ = arena.segment("hidden1_weights")
+    assert torch.equal(arena.grad[a0:a0 + 2100], torch.full((2100,), 2.0))
+    assert float(arena.grad[a0 + 2100:].abs().sum()) == 0.0      # padding stays zero
+    arena.zero_grad()
+    assert float(arena.grad.abs().sum()) == 0.0
+    with pytest.raises(RuntimeError):
+        with vs.use_store(store):
+            vs.get_variable("late", [1], vs.zeros_initializer())
