@@ -140,11 +140,18 @@ def main():
             avg_ms = sum(t for _, t in k2) / len(k2)
             bytes_ = k2_algorithmic_bytes(B, T, D, K)
             ach = bytes_ / (avg_ms * 1e-3) / 1e9
-            roof = {"kernel": "vlad_aggregate_kernel<8,4,true> (K2, video stream)", "bound": "hbm", "achieved": round(ach, 1),
+            prec = ops.VLAD_PRECISION
+            kname = ("vlad_aggregate_tiles_kernel<8> (K2, video stream, split-bf16 MFMA)" if prec == "bf16x3"
+                     else "vlad_aggregate_kernel<8,4,true> (K2, video stream, exact-fp32 MFMA)")
+            roof = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes": bytes_, "avg_kernel_ms": round(avg_ms, 4), "launches": len(k2),
                     "flops_per_launch": 2.0 * B * T * D * K,
-                    "achieved_tflops_fp32_mfma": round(2.0 * B * T * D * K / (avg_ms * 1e-3) / 1e12, 2)}
+                    "achieved_tflops": round(2.0 * B * T * D * K / (avg_ms * 1e-3) / 1e12, 2)}
+            for nm in ("split_frames", "assign_tiles"):
+                tt = [a.elapsed_time(b) for (n, d, a, b) in timeline if n == nm and d[2] in (1024, 256)]
+                if tt:
+                    roof[nm + "_avg_ms"] = round(sum(tt) / len(tt), 4)
             pmc = os.path.join(ROOT, "profiles", "k2_hbm_traffic.json")
             if os.path.exists(pmc):
                 try:

@@ -61,6 +61,11 @@ int lpm_frame_stats(const float* raw, const int32_t* num_frames, int B, int max_
                     float* partial, lpm_stream_t stream);
 int lpm_frame_apply(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
                     const float* scale, const float* shift, float* y, lpm_stream_t stream);
+/* lpm_frame_apply that also emits the split-bf16 tile copies K2 reads (see lpm_split_frames): columns [0,Dv) -> xt_video,
+ * [Dv, Dv+Da) -> xt_audio (either may be NULL); Dv + Da == F. */
+int lpm_frame_apply_tiles(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
+                          const float* scale, const float* shift, float* y, void* xt_video, int Dv, void* xt_audio, int Da,
+                          lpm_stream_t stream);
 int lpm_frame_stats_nblk(int B, int S);   /* rows of `partial` lpm_frame_stats writes (for lpm_bn_fold) */
 /* backward of input_bn's affine parameters only (the frames are data, never a trainable tensor, so no
  * gradient w.r.t. raw is produced): dgamma = sum dy*xhat, dbeta = sum dy over the gathered rows.
@@ -110,6 +115,25 @@ int lpm_vlad_aggregate_fwd(const float* assign, const float* scale, const float*
                            float* nrm, float* asum, float* colsq, float* csq, lpm_stream_t stream);
 int lpm_vlad_finalize_fwd(const float* nrm, const float* csq, int B, int D, int K, int flags, float* out,
                           float* gsq, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2 on the bf16 matrix pipe (split-bf16, "bf16x3": each fp32 operand is carried as hi/lo bf16 planes and a
+ * product is accumulated as ah*xh + ah*xl + al*xh in fp32 -- ~1e-5 relative error, inside the 1e-3 parity bar,
+ * at 5.3x less matrix-pipe time than the exact-fp32 MFMA).  Same reference lines and outputs as
+ * lpm_vlad_aggregate_fwd; operands arrive in MFMA-fragment ("tile") order produced by:
+ *   lpm_split_frames : x [B*T, D] (row stride ldx) -> xt (lpm_xt_bytes(B,T,D) bytes)
+ *   lpm_assign_tiles : assign [B*T, K] (logits with LPM_VLAD_SOFTMAX: softmax(assign*scale+shift); else the
+ *                      similarities themselves) -> at (lpm_at_bytes(B,T,K) bytes)
+ * Layouts (16-byte units): xt[b][s][d/32][plane][lane], at[b][k/32][s][plane][lane]; lane l holds the 8 frames
+ * t = 16 s + 8 (l>>5) + 0..7 of column d (or cluster k) = 32*tile + (l&31); plane 0 = hi, 1 = lo.
+ * ------------------------------------------------------------------------------------------- */
+size_t lpm_xt_bytes(int B, int T, int D);
+size_t lpm_at_bytes(int B, int T, int K);
+int lpm_split_frames(const float* x, int64_t ldx, int B, int T, int D, void* xt, lpm_stream_t stream);
+int lpm_assign_tiles(const float* assign, const float* scale, const float* shift, int B, int T, int K, int flags,
+                     void* at, lpm_stream_t stream);
+int lpm_vlad_aggregate_tiles_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,
+                                 int flags, float* nrm, float* asum, float* colsq, float* csq, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3: backward of K2 (TF autodiff of the same lines; formulas SURVEY.md App. F.1-F.3).

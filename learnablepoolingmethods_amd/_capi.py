@@ -31,6 +31,7 @@ SIGNATURES = {
     "lpm_frame_stats_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_frame_stats": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),
     "lpm_frame_apply": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "lpm_frame_apply_tiles": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _i, _f]),
     "lpm_frame_stats_nblk": (_i, [_i, _i]),
     "lpm_frame_bn_bwd": (_i, [_f, _l, _f, _f, _i, _i, _i, _i, _f, _f, _fl, _f, _f, _f, _s, _f]),
     "lpm_bn_fold": (_i, [_f, _i, _i, _l, _f, _f, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
@@ -38,6 +39,11 @@ SIGNATURES = {
     "lpm_assign_gemm_fwd": (_i, [_f, _l, _f, _i, _i, _i, _i, _f, _f, _f]),
     "lpm_vlad_aggregate_fwd": (_i, [_f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_vlad_finalize_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f]),
+    "lpm_xt_bytes": (_s, [_i, _i, _i]),
+    "lpm_at_bytes": (_s, [_i, _i, _i]),
+    "lpm_split_frames": (_i, [_f, _l, _i, _i, _i, _f, _f]),
+    "lpm_assign_tiles": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),
+    "lpm_vlad_aggregate_tiles_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_vlad_bwd_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_vlad_aggregate_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _l,
                                     _i, _f, _f, _s, _f]),

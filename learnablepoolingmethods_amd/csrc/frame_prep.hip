@@ -72,6 +72,70 @@ __global__ __launch_bounds__(256) void frame_apply_kernel(const float* __restric
     }
 }
 
+// Same as frame_apply_kernel, but one work item owns 8 consecutive sampled frames of 4 columns so that it can
+// ALSO emit the split-bf16 MFMA-fragment tiles K2 consumes (vlad_tiles.hip: XT[b][s][d/32][plane][lane][8]) for
+// the rgb columns [0, Dv) and the audio columns [Dv, Dv+Da) -- the normalised frames are then written once in
+// fp32 (for K1 / the backward GEMMs) and once in tile order, with no separate re-read for the split.
+__device__ __forceinline__ unsigned fp_bf16_rne(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__global__ __launch_bounds__(256) void frame_apply_tiles_kernel(const float* __restrict__ raw,
+                                                                const int32_t* __restrict__ num_frames, int B,
+                                                                int max_frames, int F, int S, float step,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, float* __restrict__ y,
+                                                                uint4* __restrict__ xtv, int Dv,
+                                                                uint4* __restrict__ xta, int Da) {
+    const int F4 = F / 4, NS = (S + 15) / 16;
+    const int64_t total = (int64_t)B * NS * 2 * F4;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(w % F4);
+        const int64_t r = w / F4;
+        const int kh = (int)(r & 1), st = (int)((r >> 1) % NS), b = (int)((r >> 1) / NS);
+        const int c = 4 * c4;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) {
+            sc = *reinterpret_cast<const float4*>(scale + c);
+            sh = *reinterpret_cast<const float4*>(shift + c);
+        }
+        const int nf = num_frames[b];
+        float v[4][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 16 * st + 8 * kh + e;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < S) {
+                int idx = sample_index(j, step, nf);
+                idx = max(0, min(idx, max_frames - 1));
+                f = *reinterpret_cast<const float4*>(raw + ((int64_t)b * max_frames + idx) * F + c);
+                f.x = fmaf(f.x, sc.x, sh.x); f.y = fmaf(f.y, sc.y, sh.y);
+                f.z = fmaf(f.z, sc.z, sh.z); f.w = fmaf(f.w, sc.w, sh.w);
+                *reinterpret_cast<float4*>(y + ((int64_t)b * S + j) * F + c) = f;
+            }
+            v[0][e] = f.x; v[1][e] = f.y; v[2][e] = f.z; v[3][e] = f.w;
+        }
+        uint4* xt = (c < Dv) ? xtv : xta;
+        const int DT = ((c < Dv) ? Dv : Da) / 32;
+        const int cb = (c < Dv) ? c : c - Dv;
+        if (xt == nullptr) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[e] = fp_bf16_rne(v[q][e]);
+                l[e] = fp_bf16_rne(v[q][e] - __uint_as_float(h[e] << 16));
+            }
+            const int d = cb + q, dt = d >> 5, jj = d & 31;
+            const int64_t base = ((((int64_t)b * NS + st) * DT + dt) * 2) * 64 + kh * 32 + jj;
+            xt[base] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            xt[base + 64] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+        }
+    }
+}
+
 // column partials of (sum dy, sum dy * x) over the gathered rows, for dgamma/dbeta of input_bn
 __global__ __launch_bounds__(256) void frame_bn_bwd_partial_kernel(const float* __restrict__ dy, int64_t lddy,
                                                                    const float* __restrict__ raw,
@@ -171,6 +235,22 @@ extern "C" int lpm_frame_apply(const float* raw, const int32_t* num_frames, int 
     hipLaunchKernelGGL(frame_apply_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, raw,
                        num_frames, B, max_frames, F, S, step, scale, shift, y);
     return check_launch("lpm_frame_apply");
+}
+
+extern "C" int lpm_frame_apply_tiles(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
+                                     const float* scale, const float* shift, float* y, void* xt_video, int Dv,
+                                     void* xt_audio, int Da, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_FRAME_CHECK("lpm_frame_apply_tiles");
+    LPM_REQUIRE(y && ((scale == nullptr) == (shift == nullptr)), LPM_ERR_BADARG, "lpm_frame_apply_tiles: bad pointers");
+    LPM_REQUIRE(Dv > 0 && Da >= 0 && Dv + Da == F && Dv % 32 == 0 && Da % 32 == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_frame_apply_tiles: need Dv + Da == F, both multiples of 32 (F=%d Dv=%d Da=%d)", F, Dv, Da);
+    const float step = 1.0f / (float)S;
+    const int64_t total = (int64_t)B * ((S + 15) / 16) * 2 * (F / 4);
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(frame_apply_tiles_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, raw,
+                       num_frames, B, max_frames, F, S, step, scale, shift, y, (uint4*)xt_video, Dv, (uint4*)xt_audio, Da);
+    return check_launch("lpm_frame_apply_tiles");
 }
 
 extern "C" int lpm_frame_bn_bwd(const float* dy, int64_t lddy, const float* raw, const int32_t* num_frames, int B,

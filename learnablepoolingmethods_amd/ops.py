@@ -6,6 +6,8 @@ PyTorch only supplies device memory, streams and the autograd tape.
 """
 from __future__ import annotations
 
+import os
+import weakref
 from typing import Optional
 
 import torch
@@ -15,6 +17,16 @@ from ._capi import LPM_VLAD_OUT_KMAJOR, LPM_VLAD_RESIDUAL, LPM_VLAD_SOFTMAX, Lpm
 
 BN_EPS = 1e-3     # slim.batch_norm epsilon
 BN_DECAY = 0.999  # slim.batch_norm decay
+
+# Matrix-core arithmetic of the aggregation kernel K2:
+#   "bf16x3": split-bf16 (hi/lo planes, 3 bf16 MFMAs per product, ~1e-5 relative error)  [default]
+#   "f32":    exact fp32 MFMA (v_mfma_f32_32x32x2_f32, ~1e-7), 5.3x more matrix-pipe time
+VLAD_PRECISION = os.environ.get("LPM_VLAD_PRECISION", "bf16x3")
+
+# Split-bf16 tile copies of the most recent frame_sample_bn output (produced by the same kernel that writes the fp32
+# frames): {"base": weakref to y, "F": F, "Dv": .., "video": tensor, "audio": tensor|None}.  ops.netvlad / vlad_aggregate
+# look a column-slice view of y up here instead of re-reading it through lpm_split_frames.
+_XT_CACHE = {}
 
 # bench.py sets this to a list to collect (name, dims, start_event, end_event) around hot-kernel launches
 # on the current stream (HIP events; nothing is recorded or synchronised when it is None).
@@ -97,10 +109,20 @@ class _FrameSampleBN(torch.autograd.Function):
             else:
                 scale, shift = folded_eval_affine(gamma, beta, moving_mean, moving_var)
                 scale, shift = scale.contiguous(), shift.contiguous()
+        else:
+            scale = shift = None
+        tiles = VLAD_PRECISION == "bf16x3" and F in (1024, 1152)
+        if tiles:
+            Dv, Da = 1024, F - 1024
+            xtv = torch.empty(lib._lpm_xt_bytes(B, S, Dv) // 4, dtype=torch.int32, device=raw.device)
+            xta = torch.empty(lib._lpm_xt_bytes(B, S, Da) // 4, dtype=torch.int32, device=raw.device) if Da else None
+            lib.check(lib._lpm_frame_apply_tiles(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(y), ptr(xtv), Dv,
+                                                 ptr(xta), Da, stream_ptr()), "lpm_frame_apply_tiles")
+            _XT_CACHE.clear()
+            _XT_CACHE.update(base=weakref.ref(y), F=F, Dv=Dv, S=S, B=B, video=xtv, audio=xta)
+        else:
             lib.check(lib._lpm_frame_apply(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(y), stream_ptr()),
                       "lpm_frame_apply")
-        else:
-            lib.check(lib._lpm_frame_apply(ptr(raw), ptr(nf), B, MF, F, S, None, None, ptr(y), stream_ptr()), "lpm_frame_apply")
         ctx.use_bn, ctx.is_training, ctx.S = use_bn, is_training, S
         if use_bn:
             if is_training:
@@ -135,13 +157,44 @@ def frame_sample_bn(raw, num_frames, S, gamma=None, beta=None, moving_mean=None,
 # ----------------------------------------------------------------------------------------------
 # K1 + K2 (+K3): NetVLAD pooling
 # ----------------------------------------------------------------------------------------------
+def _cached_tiles(x, B, T, D):
+    """The tile copy written by frame_sample_bn, if ``x`` is the rgb / audio column slice of its latest output."""
+    c = _XT_CACHE
+    if not c or c["B"] != B or c["S"] != T:
+        return None
+    base = c["base"]()
+    if base is None or x._base is not base or x.stride(0) != c["F"]:
+        return None
+    if x.storage_offset() == 0 and D == c["Dv"]:
+        return c["video"]
+    if x.storage_offset() == c["Dv"] and D == c["F"] - c["Dv"] and c["audio"] is not None:
+        return c["audio"]
+    return None
+
+
 def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor):
     nrm = _empty((B, D, K), x)
     asum, colsq, csq = (_empty((B, K), x) for _ in range(3))
-    with _timed("vlad_aggregate_fwd", (B, T, D, K)):
-        lib.check(lib._lpm_vlad_aggregate_fwd(ptr(assign), ptr(scale), ptr(shift), ptr(x), x.stride(0), ptr(centres), B, T, D,
-                                              K, flags, ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), stream_ptr()),
-                  "lpm_vlad_aggregate_fwd")
+    if VLAD_PRECISION == "bf16x3":
+        st = stream_ptr()
+        xt = _cached_tiles(x, B, T, D)
+        if xt is None:
+            xt = torch.empty(lib._lpm_xt_bytes(B, T, D) // 4, dtype=torch.int32, device=x.device)
+            with _timed("split_frames", (B, T, D)):
+                lib.check(lib._lpm_split_frames(ptr(x), x.stride(0), B, T, D, ptr(xt), st), "lpm_split_frames")
+        at = torch.empty(lib._lpm_at_bytes(B, T, K) // 4, dtype=torch.int32, device=x.device)
+        with _timed("assign_tiles", (B, T, K)):
+            lib.check(lib._lpm_assign_tiles(ptr(assign), ptr(scale), ptr(shift), B, T, K, flags, ptr(at), st), "lpm_assign_tiles")
+        with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+            lib.check(lib._lpm_vlad_aggregate_tiles_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
+                                                        ptr(colsq), ptr(csq), st), "lpm_vlad_aggregate_tiles_fwd")
+    elif VLAD_PRECISION == "f32":
+        with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+            lib.check(lib._lpm_vlad_aggregate_fwd(ptr(assign), ptr(scale), ptr(shift), ptr(x), x.stride(0), ptr(centres), B, T,
+                                                  D, K, flags, ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), stream_ptr()),
+                      "lpm_vlad_aggregate_fwd")
+    else:
+        raise LpmError(f"unknown LPM_VLAD_PRECISION {VLAD_PRECISION!r} (bf16x3 | f32)")
     out = _empty((B, K, D) if kmajor else (B, D * K), x)
     gsq = _empty((B,), x)
     lib.check(lib._lpm_vlad_finalize_fwd(ptr(nrm), ptr(csq), B, D, K, LPM_VLAD_OUT_KMAJOR if kmajor else 0, ptr(out),

@@ -11,6 +11,16 @@ from tests._util import assert_close, cuda, rel_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["bf16x3", "f32"])
+def vlad_precision(request):
+    """Both matrix-core arithmetics of K2: split-bf16 (default) and exact fp32."""
+    from learnablepoolingmethods_amd import ops
+    old = ops.VLAD_PRECISION
+    ops.VLAD_PRECISION = request.param
+    yield request.param
+    ops.VLAD_PRECISION = old
+
+
 def _netvlad_inputs(B, T, D, K, ld=None, seed=0, dev=None):
     g = torch.Generator().manual_seed(seed)
     ld = ld or D
@@ -36,7 +46,7 @@ def _oracle_netvlad(x, W, gamma, beta, W2, T, dout, residual=True):
 
 @pytest.mark.parametrize("B,T,D,K,off", [(3, 30, 1024, 16, 0), (2, 37, 128, 64, 1024), (4, 300, 1024, 256, 0),
                                           (2, 300, 128, 64, 1024), (2, 16, 256, 96, 0), (1, 9, 512, 40, 0)])
-def test_netvlad_fwd_bwd(B, T, D, K, off):
+def test_netvlad_fwd_bwd(B, T, D, K, off, vlad_precision):
     from learnablepoolingmethods_amd import ops
     dev = cuda()
     ld = 1152 if off or D == 1024 else D
@@ -65,7 +75,7 @@ def test_netvlad_fwd_bwd(B, T, D, K, off):
     assert torch.allclose(o.norm(dim=1), torch.full((B, K), K ** -0.5, device=dev), atol=1e-5)
 
 
-def test_netvlad_kmajor_layout_and_eval_mode():
+def test_netvlad_kmajor_layout_and_eval_mode(vlad_precision):
     from learnablepoolingmethods_amd import ops
     dev = cuda()
     B, T, D, K = 3, 20, 128, 32
@@ -92,7 +102,7 @@ def test_netvlad_kmajor_layout_and_eval_mode():
     assert_close(W2g.grad, p["s/cluster_weights2"].grad, what="dW2")
 
 
-def test_lightvlad_and_bias_mode():
+def test_lightvlad_and_bias_mode(vlad_precision):
     from learnablepoolingmethods_amd import ops
     dev = cuda()
     B, T, D, K = 2, 12, 128, 8
@@ -120,7 +130,7 @@ def test_lightvlad_and_bias_mode():
 
 
 @pytest.mark.parametrize("B,T,D,K", [(2, 30, 128, 16), (2, 300, 1024, 256), (3, 17, 256, 64)])
-def test_vlad_aggregate_v2_form(B, T, D, K):
+def test_vlad_aggregate_v2_form(B, T, D, K, vlad_precision):
     """NetVladAttenCluster tail: similarities may be negative, no softmax (video_pooling_modules.py:1646-1658)."""
     from learnablepoolingmethods_amd import ops
     dev = cuda()
@@ -139,7 +149,7 @@ def test_vlad_aggregate_v2_form(B, T, D, K):
     assert_close(Cg.grad, Cd.grad, what="dcentres")
 
 
-def test_vlad_degenerate_zero_column():
+def test_vlad_degenerate_zero_column(vlad_precision):
     """A cluster with zero mass hits tf.nn.l2_normalize's 1e-12 clamp (forward 0, backward unprojected)."""
     from learnablepoolingmethods_amd import ops
     dev = cuda()

@@ -162,7 +162,7 @@ def _train_compare(name, cfg, feat, B, MF, steps, dev, tol=5e-3, **kw):
                 assert e <= 1e-2, f"step {s} update {n}: relative L2 error {e:.3e}"
     for n in p:
         if n.endswith("moving_mean") or n.endswith("moving_variance"):
-            assert_close(tr.store.vars["tower/" + n], p[n], tol=1e-4, what=f"moving stat {n}")
+            assert_close(tr.store.vars["tower/" + n], p[n], tol=1e-3, what=f"moving stat {n}")
 
 
 def test_train_steps_cfg1_v1():
