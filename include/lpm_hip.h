@@ -161,6 +161,18 @@ int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const f
                size_t workspace_bytes, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Split-bf16 operand preparation for the encoder's dense layers (tf.layers.dense at
+ * transformer_utils.py:559-561,583,701,708).  The GEMMs stay library GEMMs (hipBLASLt); these kernels produce the
+ * operand format that runs them on the bf16 matrix pipe at fp32-grade accuracy:
+ *   x W ~= xh Wh + xl Wh + xh Wl = [xh | xl | xh] . [Wh ; Wh ; Wl]   (one bf16 GEMM, fp32 accumulation)
+ * lpm_split_rows:   x [M,K] fp32 (row stride ldx; optional fused relu(x + bias)) -> out3 [M,3K] bf16 = [hi|lo|hi]
+ * lpm_split_weight: W [K,N] fp32 -> w3 [3K,N] bf16 = [Wh;Wh;Wl], w3t [3N,K] bf16 = [Wh^T;Wh^T;Wl^T] (w3t may be NULL)
+ * ------------------------------------------------------------------------------------------- */
+int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, void* out3,
+                   lpm_stream_t stream);
+int lpm_split_weight(const float* W, int K, int N, void* w3, void* w3t, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K4: multi-head attention core  o = softmax(scale * q k^T) v   per (batch, head)
  *   replaces transformer_utils.py:564-581 (split_heads, q scaling, matmul, softmax, matmul,
  *   combine_heads).  q,k,v,o are the [B, L, h*d] outputs of the dense projections (heads

@@ -49,6 +49,8 @@ SIGNATURES = {
                                     _i, _f, _f, _s, _f]),
     "lpm_bn_bwd_workspace_bytes": (_s, [_i, _i]),
     "lpm_bn_bwd": (_i, [_f, _f, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _s, _f]),
+    "lpm_split_rows": (_i, [_f, _l, _l, _i, _f, _i, _f, _f]),
+    "lpm_split_weight": (_i, [_f, _i, _i, _f, _f, _f]),
     "lpm_mha_fwd": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),
     "lpm_mha_bwd": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _l, _f, _f, _f, _f]),
     "lpm_mha_logit_stats_workspace_bytes": (_s, [_i, _i, _i]),

@@ -32,6 +32,7 @@ FLAGS.define("netvlad_relu", False, ":2203")
 FLAGS.define("gating", True, ":2205")
 FLAGS.define("gating_remove_diag", False, ":2207")
 FLAGS.define("netvlad_encoder", True, "build extension: False = gated NetVLAD without the cluster encoders (BASELINE cfg-5)")
+FLAGS.define("dense_precision", "bf16x3", "build extension: encoder dense GEMMs as split-bf16 ('bf16x3', ~4e-6) or 'f32'")
 # video_level_models.py
 FLAGS.define("moe_num_mixtures", 2, "video_level_models.py:27")
 FLAGS.define("moe_l2", 1e-8, ":35")

@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from . import FLAGS, ops
 from . import variables as vs
 
 BN_EPS = 1e-3
@@ -62,7 +63,12 @@ def dense(x: torch.Tensor, units: int, use_bias: bool, name: str, activation=Non
     """tf.layers.dense: contracts the last axis; glorot-uniform kernel, zero bias."""
     with vs.variable_scope(name):
         kernel = vs.get_variable("kernel", [x.shape[-1], units], vs.glorot_uniform_initializer(), device=x.device)
-        y = x.matmul(kernel)
+        rows = x.numel() // x.shape[-1]
+        if (FLAGS.dense_precision == "bf16x3" and x.is_cuda and rows >= 1024 and x.shape[-1] % 8 == 0 and units % 8 == 0):
+            # split-bf16 operands -> bf16 matrix pipe at fp32-grade accuracy (ops._DenseX3)
+            y = ops.dense_x3(x.reshape(rows, x.shape[-1]), kernel).reshape(*x.shape[:-1], units)
+        else:
+            y = x.matmul(kernel)
         if use_bias:
             y = y + vs.get_variable("bias", [units], vs.zeros_initializer(), device=x.device)
     return activation(y) if activation is not None else y

@@ -325,6 +325,63 @@ def vlad_aggregate(sims, x, centres, max_frames, kmajor=False):
 
 
 # ----------------------------------------------------------------------------------------------
+# dense layers of the encoders on the bf16 matrix pipe at fp32-grade accuracy (split-bf16 operands)
+# ----------------------------------------------------------------------------------------------
+def _split_rows(x2d, bias=None, relu=False):
+    """[M,K] fp32 -> [M,3K] bf16 = [hi | lo | hi] (optionally of relu(x + bias))."""
+    lib = _capi.load()
+    M, K = x2d.shape
+    out = torch.empty((M, 3 * K), dtype=torch.bfloat16, device=x2d.device)
+    lib.check(lib._lpm_split_rows(ptr(x2d), x2d.stride(0), M, K, ptr(bias), 1 if relu else 0, ptr(out), stream_ptr()),
+              "lpm_split_rows")
+    return out
+
+
+def _split_weight(W, need_t=True):
+    """[K,N] fp32 -> W3 [3K,N] = [Wh;Wh;Wl] and W3T [3N,K] = [Wh^T;Wh^T;Wl^T] (bf16)."""
+    lib = _capi.load()
+    K, N = W.shape
+    w3 = torch.empty((3 * K, N), dtype=torch.bfloat16, device=W.device)
+    w3t = torch.empty((3 * N, K), dtype=torch.bfloat16, device=W.device) if need_t else None
+    lib.check(lib._lpm_split_weight(ptr(W), K, N, ptr(w3), ptr(w3t), stream_ptr()), "lpm_split_weight")
+    return w3, w3t
+
+
+class _DenseX3(torch.autograd.Function):
+    """y = x W with x W ~= [xh|xl|xh].[Wh;Wh;Wl]: library bf16 GEMMs (hipBLASLt), fp32 accumulation, ~4e-6 relative
+    error (a plain bf16 GEMM: 2.5e-3, outside the parity bar; the fp32 GEMM: 1.5e-6 at 2-3x the time)."""
+
+    @staticmethod
+    def forward(ctx, x2d, W):
+        x2d = _rows(x2d, "dense input")
+        W = _f32(W, "dense kernel").contiguous()
+        x3 = _split_rows(x2d)
+        w3, w3t = _split_weight(W, need_t=ctx.needs_input_grad[0])
+        ctx.save_for_backward(x3, w3t)
+        ctx.dims = (x2d.shape[1], W.shape[1])
+        return torch.mm(x3, w3, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, w3t = ctx.saved_tensors
+        K, N = ctx.dims
+        dy3 = _split_rows(dy.contiguous())
+        dx = torch.mm(dy3, w3t, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            xh, xl = x3[:, :K], x3[:, K:2 * K]
+            dyh, dyl = dy3[:, :N], dy3[:, N:2 * N]
+            dW = torch.mm(xh.t(), dyh, out_dtype=torch.float32)
+            dW += torch.mm(xl.t(), dyh, out_dtype=torch.float32)
+            dW += torch.mm(xh.t(), dyl, out_dtype=torch.float32)
+        return dx, dW
+
+
+def dense_x3(x2d, W):
+    return _DenseX3.apply(x2d, W)
+
+
+# ----------------------------------------------------------------------------------------------
 # K4: attention core
 # ----------------------------------------------------------------------------------------------
 def _mha_dims(q, num_heads):

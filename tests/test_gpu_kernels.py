@@ -307,3 +307,20 @@ def test_capi_rejects_bad_shapes_loudly():
         ops.netvlad(x, W, None, 5, bn=None, bias=torch.zeros(8, device=dev))
     with pytest.raises(_capi.LpmError):
         ops.mha_core(torch.randn(1, 8, 24, device=dev), torch.randn(1, 8, 24, device=dev), torch.randn(1, 8, 24, device=dev), 2, 1.0)
+
+
+@pytest.mark.parametrize("M,K,N", [(2048, 1024, 1024), (4096, 128, 512), (1536, 4096, 1024)])
+def test_dense_split_bf16(M, K, N):
+    """Encoder dense layers on the bf16 pipe with split operands: fp32-grade accuracy forward and backward."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(M)
+    x, W, dy = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / K ** 0.5, torch.randn(M, N, generator=g)
+    xd, Wd = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    (xd @ Wd).backward(dy.double())
+    xg, Wg = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    y = ops.dense_x3(xg, Wg)
+    assert_close(y, (xd @ Wd).detach(), tol=5e-5, what="dense_x3 fwd")
+    y.backward(dy.to(dev))
+    assert_close(xg.grad, xd.grad, tol=5e-5, what="dense_x3 dx")
+    assert_close(Wg.grad, Wd.grad, tol=5e-5, what="dense_x3 dW")
