@@ -186,7 +186,7 @@ int lpm_split_weight(const float* W, int K, int N, void* w3, void* w3t, lpm_stre
  * With key_scale/key_shift != NULL (both [L]) the logits are first mapped
  *   z[q,j] = (q.k_j)*key_scale[j] + key_shift[j] -- the folded logits_bn of MultiHeadAttentionBN
  *   (transformer_utils.py:652-659); lpm_mha_logit_stats produces the column partials for it.
- * Supported: d in {8,16}, L <= 512 (backward: L <= 448).
+ * Supported: d in {8,16}, L <= 512.
  * ------------------------------------------------------------------------------------------- */
 int lpm_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d,
                 float scale, const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse,

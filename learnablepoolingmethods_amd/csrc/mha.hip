@@ -193,79 +193,64 @@ __global__ __launch_bounds__(256) void mha_logit_stats_kernel(const float* __res
     }
 }
 
-// backward.  dz_partial (optional, with key_scale): [(b*h+hh)][0][key] = sum_q dz, [1][key] = sum_q dz * s
-__global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, int64_t ld,
-                                                      const float* __restrict__ o, const float* __restrict__ dout,
-                                                      int64_t ldo, const float* __restrict__ lse, int L, int h, int d,
-                                                      float scale, const float* __restrict__ key_scale,
-                                                      const float* __restrict__ key_shift, float* __restrict__ dq,
-                                                      float* __restrict__ dk, float* __restrict__ dv, int64_t ldd,
-                                                      const float* __restrict__ corr_a,
-                                                      const float* __restrict__ corr_b,
-                                                      float* __restrict__ dz_partial) {
+// backward, two kernels so that each stages only TWO operands (L16 x 20 floats each: 41 KB at L = 256, three
+// workgroups per CU instead of one with all four staged):
+//   mha_bwd_dq_kernel : K, V in LDS; one query tile per wave iteration; Q / dO / O fragments and lse from global
+//   mha_bwd_dkv_kernel: Q, dO (+ lse, D_q) in LDS; one key tile per wave iteration; K / V fragments from global;
+//                       also the per-(batch, head) column sums of dz and dz*s for the logits_bn backward
+//                       (dz_partial [(b*h+hh)][0][key] = sum_q dz, [1][key] = sum_q dz * s).
+// D_q = rowsum(P * dP) = <dO_q, O_q>.  corr_a / corr_b: ds = key_scale*dz - corr_a[key] - s*corr_b[key].
+__global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, int64_t ld,
+                                                         const float* __restrict__ o, const float* __restrict__ dout,
+                                                         int64_t ldo, const float* __restrict__ lse, int L, int h, int d,
+                                                         float scale, const float* __restrict__ key_scale,
+                                                         const float* __restrict__ key_shift, float* __restrict__ dq,
+                                                         int64_t ldd, const float* __restrict__ corr_a,
+                                                         const float* __restrict__ corr_b) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nkt = (L + 15) >> 4, L16 = nkt * 16;
     float* Ks = smem;
     float* Vs = Ks + L16 * MH_S;
-    float* Qs = Vs + L16 * MH_S;
-    float* Gs = Qs + L16 * MH_S;     // dO
-    float* ksc = Gs + L16 * MH_S;
+    float* ksc = Vs + L16 * MH_S;
     float* ksh = ksc + L16;
-    float* lses = ksh + L16;
-    float* Dq = lses + L16;          // rowsum(P * dP) = <dO_q, O_q>
-    float* cas = Dq + L16;           // logits-BN batch-statistics correction: ds = ksc*dz - ca - s*cb
+    float* cas = ksh + L16;
     float* cbs = cas + L16;
-    const bool stats_only = (dq == nullptr);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = lid / h, hh = lid % h;
-    const int ns = d >> 2, d4 = d >> 2;
+    const int ns = d >> 2;
 
-    for (int i = tid; i < 4 * L16 * MH_S; i += 256) smem[i] = 0.f;
+    for (int i = tid; i < 2 * L16 * MH_S; i += 256) smem[i] = 0.f;
     for (int i = tid; i < L16; i += 256) {
         ksc[i] = (key_scale && i < L) ? key_scale[i] : 1.f;
         ksh[i] = (key_shift && i < L) ? key_shift[i] : 0.f;
-        lses[i] = (i < L) ? lse[((int64_t)b * h + hh) * L + i] : INFINITY;   // padded queries -> p = 0
-        Dq[i] = 0.f;
         cas[i] = (corr_a && i < L) ? corr_a[i] : 0.f;
         cbs[i] = (corr_b && i < L) ? corr_b[i] : 0.f;
     }
     __syncthreads();
     mha_stage(Ks, k, ld, b, L, hh, d, tid);
     mha_stage(Vs, v, ld, b, L, hh, d, tid);
-    mha_stage(Qs, q, ld, b, L, hh, d, tid);
-    // dO and D_q: d4 consecutive threads share a row
-    for (int i0 = 0; i0 < L * d4; i0 += 256) {
-        const int i = i0 + tid;
-        float part = 0.f;
-        int row = 0;
-        if (i < L * d4) {
-            row = i / d4;
-            const int c = (i % d4) * 4;
-            const int64_t off = ((int64_t)b * L + row) * ldo + hh * d + c;
-            const float4 gv = *reinterpret_cast<const float4*>(dout + off);
-            const float4 ov = *reinterpret_cast<const float4*>(o + off);
-            *reinterpret_cast<float4*>(Gs + row * MH_S + c) = gv;
-            part = gv.x * ov.x + gv.y * ov.y + gv.z * ov.z + gv.w * ov.w;
-        }
-        part += __shfl_xor(part, 1, 64);
-        if (d4 == 4) part += __shfl_xor(part, 2, 64);
-        if (i < L * d4 && (i % d4) == 0) Dq[row] = part;
-    }
     __syncthreads();
 
-    // ---- sweep A: one query tile per wave iteration -> dQ ---------------------------------------
-    for (int qt = wave; qt < nkt && !stats_only; qt += 4) {
+    for (int qt = wave; qt < nkt; qt += 4) {
         const int qrow = qt * 16 + l15;
-        float qf[4], gf[4];
+        const bool qok = qrow < L;
+        float qf[4], gf[4], dpart = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            qf[s] = (s < ns) ? Qs[qrow * MH_S + 4 * s + g] * scale : 0.f;
-            gf[s] = (s < ns) ? Gs[qrow * MH_S + 4 * s + g] : 0.f;
+            qf[s] = gf[s] = 0.f;
+            if (s < ns && qok) {
+                qf[s] = q[((int64_t)b * L + qrow) * ld + hh * d + 4 * s + g] * scale;
+                const int64_t off = ((int64_t)b * L + qrow) * ldo + hh * d + 4 * s + g;
+                gf[s] = dout[off];
+                dpart = fmaf(gf[s], o[off], dpart);
+            }
         }
-        const float lq = lses[qrow], dqv = Dq[qrow];
+        dpart += __shfl_xor(dpart, 16, 64);
+        dpart += __shfl_xor(dpart, 32, 64);          // D_q for q = l15
+        const float lq = qok ? lse[((int64_t)b * h + hh) * L + qrow] : INFINITY, dqv = dpart;
         f32x4 dqa = {0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nkt; ++kt) {
             f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -288,22 +273,77 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
                 dqa = mfma16(kc[r * MH_S], ds, dqa);       // dQ^T[dd, q] += K^T[dd, key] dS^T[key, q]
             }
         }
-        if (qrow < L && 4 * g < d) {
+        if (qok && 4 * g < d) {
             float4 ov = make_float4(dqa[0] * scale, dqa[1] * scale, dqa[2] * scale, dqa[3] * scale);
             *reinterpret_cast<float4*>(dq + ((int64_t)b * L + qrow) * ldd + hh * d + 4 * g) = ov;
         }
     }
+}
 
-    // ---- sweep B: one key tile per wave iteration -> dK, dV (+ logits-BN partial sums) -----------
+__global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, int64_t ld,
+                                                          const float* __restrict__ o, const float* __restrict__ dout,
+                                                          int64_t ldo, const float* __restrict__ lse, int L, int h, int d,
+                                                          float scale, const float* __restrict__ key_scale,
+                                                          const float* __restrict__ key_shift, float* __restrict__ dk,
+                                                          float* __restrict__ dv, int64_t ldd,
+                                                          const float* __restrict__ corr_a,
+                                                          const float* __restrict__ corr_b,
+                                                          float* __restrict__ dz_partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nkt = (L + 15) >> 4, L16 = nkt * 16;
+    float* Qs = smem;
+    float* Gs = Qs + L16 * MH_S;     // dO
+    float* lses = Gs + L16 * MH_S;
+    float* Dq = lses + L16;
+    const bool stats_only = (dk == nullptr);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    const int ns = d >> 2, d4 = d >> 2;
+
+    for (int i = tid; i < 2 * L16 * MH_S; i += 256) smem[i] = 0.f;
+    for (int i = tid; i < L16; i += 256) {
+        lses[i] = (i < L) ? lse[((int64_t)b * h + hh) * L + i] : INFINITY;   // padded queries -> p = 0
+        Dq[i] = 0.f;
+    }
+    __syncthreads();
+    mha_stage(Qs, q, ld, b, L, hh, d, tid);
+    for (int i0 = 0; i0 < L * d4; i0 += 256) {     // dO and D_q: d4 consecutive threads share a row
+        const int i = i0 + tid;
+        float part = 0.f;
+        int row = 0;
+        if (i < L * d4) {
+            row = i / d4;
+            const int c = (i % d4) * 4;
+            const int64_t off = ((int64_t)b * L + row) * ldo + hh * d + c;
+            const float4 gv = *reinterpret_cast<const float4*>(dout + off);
+            const float4 ov = *reinterpret_cast<const float4*>(o + off);
+            *reinterpret_cast<float4*>(Gs + row * MH_S + c) = gv;
+            part = gv.x * ov.x + gv.y * ov.y + gv.z * ov.z + gv.w * ov.w;
+        }
+        part += __shfl_xor(part, 1, 64);
+        if (d4 == 4) part += __shfl_xor(part, 2, 64);
+        if (i < L * d4 && (i % d4) == 0) Dq[row] = part;
+    }
+    __syncthreads();
+
     for (int kt = wave; kt < nkt; kt += 4) {
         const int krow = kt * 16 + l15;
+        const bool kok = krow < L;
         float kf[4], vf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            kf[s] = (s < ns) ? Ks[krow * MH_S + 4 * s + g] : 0.f;
-            vf[s] = (s < ns) ? Vs[krow * MH_S + 4 * s + g] : 0.f;
+            kf[s] = vf[s] = 0.f;
+            if (s < ns && kok) {
+                const int64_t off = ((int64_t)b * L + krow) * ld + hh * d + 4 * s + g;
+                kf[s] = k[off];
+                vf[s] = v[off];
+            }
         }
-        const float sck = ksc[krow], shk = ksh[krow], cak = cas[krow], cbk = cbs[krow];
+        const float sck = (key_scale && kok) ? key_scale[krow] : 1.f, shk = (key_shift && kok) ? key_shift[krow] : 0.f;
+        const float cak = (corr_a && kok) ? corr_a[krow] : 0.f, cbk = (corr_b && kok) ? corr_b[krow] : 0.f;
         f32x4 dka = {0.f, 0.f, 0.f, 0.f}, dva = {0.f, 0.f, 0.f, 0.f};
         float zs = 0.f, zq = 0.f;
         for (int qt = 0; qt < nkt; ++qt) {
@@ -323,7 +363,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
             for (int r = 0; r < 4; ++r) {
                 const int qr = qt * 16 + 4 * g + r;
                 const float sraw = st[r] * scale;
-                const float z = (krow < L) ? fmaf(sraw, sck, shk) : -INFINITY;
+                const float z = kok ? fmaf(sraw, sck, shk) : -INFINITY;
                 const float p = __expf(z - lses[qr]);
                 const float dz = p * (dp[r] - Dq[qr]);
                 zs += dz;
@@ -335,7 +375,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
                 }
             }
         }
-        if (!stats_only && krow < L && 4 * g < d) {
+        if (!stats_only && kok && 4 * g < d) {
             const int64_t off = ((int64_t)b * L + krow) * ldd + hh * d + 4 * g;
             *reinterpret_cast<float4*>(dk + off) = make_float4(dka[0] * scale, dka[1] * scale, dka[2] * scale, dka[3] * scale);
             *reinterpret_cast<float4*>(dv + off) = make_float4(dva[0], dva[1], dva[2], dva[3]);
@@ -343,7 +383,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
         if (dz_partial) {
             zs += __shfl_xor(zs, 16, 64); zs += __shfl_xor(zs, 32, 64);
             zq += __shfl_xor(zq, 16, 64); zq += __shfl_xor(zq, 32, 64);
-            if (g == 0 && krow < L) {
+            if (g == 0 && kok) {
                 float* out = dz_partial + ((int64_t)b * h + hh) * 2 * L;
                 out[krow] = zs;
                 out[L + krow] = zq;
@@ -354,7 +394,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
 
 static inline size_t mha_fwd_lds(int L) { const int L16 = ((L + 15) / 16) * 16; return (size_t)(2 * L16 * MH_S + 2 * L16) * 4; }
 static inline size_t mha_stats_lds(int L) { const int L16 = ((L + 15) / 16) * 16; return (size_t)(L16 * MH_S + 8 * L16) * 4; }
-static inline size_t mha_bwd_lds(int L) { const int L16 = ((L + 15) / 16) * 16; return (size_t)(4 * L16 * MH_S + 6 * L16) * 4; }
+static inline size_t mha_bwd_lds(int L) { const int L16 = ((L + 15) / 16) * 16; return (size_t)(2 * L16 * MH_S + 4 * L16) * 4; }
 
 template <typename KernT>
 static int reserve_lds(KernT kern, size_t bytes, const char* what) {
@@ -436,12 +476,17 @@ extern "C" int lpm_mha_bwd(const float* q, const float* k, const float* v, int64
                 "lpm_mha_bwd: give dq, dk, dv together, or none of them (statistics-only pass needs dz_partial)");
     LPM_REQUIRE((corr_a == nullptr) == (corr_b == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd: corr_a/corr_b go together");
     LPM_MHA_CHECK("lpm_mha_bwd");
-    LPM_REQUIRE(L <= 448, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bwd: L <= 448 (four staged operands must fit 160 KB of LDS), L=%d", L);
     LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd: key_scale/key_shift go together");
     LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0, LPM_ERR_BADARG, "lpm_mha_bwd: bad ldo/ldd");
     const size_t lds = mha_bwd_lds(L);
-    if (int rc = reserve_lds(mha_bwd_kernel, lds, "lpm_mha_bwd")) return rc;
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * h), dim3(256), lds, (hipStream_t)stream, q, k, v, ld, o, dout, ldo, lse, L, h, d,
-                       scale, key_scale, key_shift, dq, dk, dv, ldd, corr_a, corr_b, dz_partial);
+    hipStream_t s = (hipStream_t)stream;
+    if (dq) {
+        if (int rc = reserve_lds(mha_bwd_dq_kernel, lds, "lpm_mha_bwd")) return rc;
+        hipLaunchKernelGGL(mha_bwd_dq_kernel, dim3(B * h), dim3(256), lds, s, q, k, v, ld, o, dout, ldo, lse, L, h, d, scale,
+                           key_scale, key_shift, dq, ldd, corr_a, corr_b);
+    }
+    if (int rc = reserve_lds(mha_bwd_dkv_kernel, lds, "lpm_mha_bwd")) return rc;
+    hipLaunchKernelGGL(mha_bwd_dkv_kernel, dim3(B * h), dim3(256), lds, s, q, k, v, ld, o, dout, ldo, lse, L, h, d, scale,
+                       key_scale, key_shift, dk, dv, ldd, corr_a, corr_b, dz_partial);
     return check_launch("lpm_mha_bwd");
 }
