@@ -173,6 +173,21 @@ int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* b
 int lpm_split_weight(const float* W, int K, int N, void* w3, void* w3t, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Residual add + tf.contrib.layers.layer_norm with TF1 defaults (transformer_utils.py:405-411,451-454,712-713):
+ * one mean/variance per example over all L*F non-batch elements, gamma/beta [F], eps inside the sqrt.
+ *   fwd: z = a + r (r may be NULL: then z is not written and a plays its role); y = (z-mean)*rstd*gamma + beta;
+ *        stats [B,2] = (mean, rstd).   bwd: dz (gradient w.r.t. z, i.e. w.r.t. both a and r), dgamma, dbeta.
+ * a, r, y, z, dy, dz: [B, L, F] contiguous.  workspace: lpm_layer_norm_workspace_bytes(B, F).
+ * ------------------------------------------------------------------------------------------- */
+size_t lpm_layer_norm_workspace_bytes(int B, int F);
+int lpm_layer_norm_fwd(const float* a, const float* r, const float* gamma, const float* beta, int B, int L, int F,
+                       float eps, float* y, float* z, float* stats, void* workspace, size_t workspace_bytes,
+                       lpm_stream_t stream);
+int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, const float* gamma, int B, int L, int F,
+                       float* dz, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                       lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K4: multi-head attention core  o = softmax(scale * q k^T) v   per (batch, head)
  *   replaces transformer_utils.py:564-581 (split_heads, q scaling, matmul, softmax, matmul,
  *   combine_heads).  q,k,v,o are the [B, L, h*d] outputs of the dense projections (heads

@@ -1,0 +1,242 @@
+// Residual add + tf.contrib.layers.layer_norm (transformer_utils.py:405-411, 451-454, 712-713).
+// TF1 defaults: ONE mean/variance per example over all non-batch axes (L*F = 262144 elements for the video
+// encoder), gamma/beta over the last axis, variance epsilon 1e-12.  A per-row LayerNorm kernel gets 80 rows of
+// 1 MB each -- 80 workgroups on 256 CUs; here each example is cut into row chunks (grid = B x NB) with a
+// partial-sum hand-off between two light HBM-bound passes, and the residual add is fused into pass 1.
+//   fwd : z = a (+ r);  y = (z - mean) * rstd * gamma + beta        saves z, stats[b] = (mean, rstd)
+//   bwd : g = dy*gamma; dz = rstd * (g - mean_e(g) - zhat * mean_e(g*zhat));  dgamma = sum dy*zhat; dbeta = sum dy
+#include "lpm_common.h"
+
+namespace lpm {
+
+constexpr int LN_NB = 16;   // chunks per example
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {   // 256 threads; result in every thread
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// pass 1: z = a + r (written when r != NULL), partial[b][chunk] = (sum z, sum z^2)
+__global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                           int64_t n_per, float* __restrict__ z,
+                                                           float* __restrict__ partial) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x, ch = blockIdx.y;
+    const int64_t n4 = n_per / 4, per = (n4 + LN_NB - 1) / LN_NB;
+    const int64_t i0 = ch * per, i1 = min(n4, i0 + per);
+    const float4* ap = reinterpret_cast<const float4*>(a + (int64_t)b * n_per);
+    const float4* rp = r ? reinterpret_cast<const float4*>(r + (int64_t)b * n_per) : nullptr;
+    float4* zp = reinterpret_cast<float4*>(z + (int64_t)b * n_per);
+    float s = 0.f, q = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        float4 v = ap[i];
+        if (rp) {
+            const float4 w = rp[i];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            zp[i] = v;
+        }
+        s += (v.x + v.y) + (v.z + v.w);
+        q = fmaf(v.x, v.x, q); q = fmaf(v.y, v.y, q); q = fmaf(v.z, v.z, q); q = fmaf(v.w, v.w, q);
+    }
+    s = block_sum(s, sh);
+    q = block_sum(q, sh);
+    if (threadIdx.x == 0) {
+        partial[((int64_t)b * LN_NB + ch) * 2] = s;
+        partial[((int64_t)b * LN_NB + ch) * 2 + 1] = q;
+    }
+}
+
+// pass 2: y = (z - mean) * rstd * gamma + beta
+__global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ partial,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int64_t n_per, int F,
+                                                           float eps, float* __restrict__ y, float* __restrict__ stats) {
+    const int b = blockIdx.x, ch = blockIdx.y;
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int i = 0; i < LN_NB; ++i) {
+        s += (double)partial[((int64_t)b * LN_NB + i) * 2];
+        q += (double)partial[((int64_t)b * LN_NB + i) * 2 + 1];
+    }
+    const double mu = s / (double)n_per;
+    double var = q / (double)n_per - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (ch == 0 && threadIdx.x == 0) {
+        stats[2 * b] = mean;
+        stats[2 * b + 1] = rstd;
+    }
+    const int64_t n4 = n_per / 4, per = (n4 + LN_NB - 1) / LN_NB;
+    const int64_t i0 = ch * per, i1 = min(n4, i0 + per);
+    const int F4 = F / 4;
+    const float4* zp = reinterpret_cast<const float4*>(z + (int64_t)b * n_per);
+    float4* yp = reinterpret_cast<float4*>(y + (int64_t)b * n_per);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int c = (int)(i % F4) * 4;
+        const float4 v = zp[i];
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;
+        o.x = fmaf((v.x - mean) * rstd, g.x, bt.x);
+        o.y = fmaf((v.y - mean) * rstd, g.y, bt.y);
+        o.z = fmaf((v.z - mean) * rstd, g.z, bt.z);
+        o.w = fmaf((v.w - mean) * rstd, g.w, bt.w);
+        yp[i] = o;
+    }
+}
+
+// backward pass 1: per (example, chunk): sums of g and g*zhat (g = dy*gamma) and the column partials of
+// dy*zhat / dy for dgamma / dbeta.  Threads are laid out (row group, float4 column) with F4 = F/4 dividing 256,
+// and chunks are whole rows, so a thread always sees the same 4 columns.
+__global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, int L, int F,
+                                                           float* __restrict__ partial, float* __restrict__ colpart) {
+    __shared__ float sh[4];
+    __shared__ float4 cs[2][256];
+    const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    const int F4 = F / 4, RG = 256 / F4;
+    const int c4 = tid % F4, rg = tid / F4;
+    const int rows_per = (L + LN_NB - 1) / LN_NB;
+    const int l0 = ch * rows_per, l1 = min(L, l0 + rows_per);
+    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+    const float4 g4 = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+    float s1 = 0.f, s2 = 0.f;
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = l0 + rg; l < l1; l += RG) {
+        const int64_t off = ((int64_t)b * L + l) * F + 4 * c4;
+        const float4 d = *reinterpret_cast<const float4*>(dy + off);
+        const float4 v = *reinterpret_cast<const float4*>(z + off);
+        const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
+        const float gx = d.x * g4.x, gy = d.y * g4.y, gz = d.z * g4.z, gw = d.w * g4.w;
+        s1 += (gx + gy) + (gz + gw);
+        s2 = fmaf(gx, hx, s2); s2 = fmaf(gy, hy, s2); s2 = fmaf(gz, hz, s2); s2 = fmaf(gw, hw, s2);
+        dg.x = fmaf(d.x, hx, dg.x); dg.y = fmaf(d.y, hy, dg.y); dg.z = fmaf(d.z, hz, dg.z); dg.w = fmaf(d.w, hw, dg.w);
+        db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
+    }
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (tid == 0) {
+        partial[((int64_t)b * LN_NB + ch) * 2] = s1;
+        partial[((int64_t)b * LN_NB + ch) * 2 + 1] = s2;
+    }
+    cs[0][tid] = dg;
+    cs[1][tid] = db;
+    __syncthreads();
+    if (rg == 0) {
+        for (int i = 1; i < RG; ++i) {
+            const float4 a = cs[0][i * F4 + c4], c = cs[1][i * F4 + c4];
+            dg.x += a.x; dg.y += a.y; dg.z += a.z; dg.w += a.w;
+            db.x += c.x; db.y += c.y; db.z += c.z; db.w += c.w;
+        }
+        float* cp = colpart + ((int64_t)b * LN_NB + ch) * 2 * F;
+        *reinterpret_cast<float4*>(cp + 4 * c4) = dg;
+        *reinterpret_cast<float4*>(cp + F + 4 * c4) = db;
+    }
+}
+
+// backward pass 2: dz = rstd * (g - S1/N - zhat * S2/N)
+__global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ partial, int64_t n_per, int F,
+                                                           float* __restrict__ dz) {
+    const int b = blockIdx.x, ch = blockIdx.y;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < LN_NB; ++i) {
+        s1 += (double)partial[((int64_t)b * LN_NB + i) * 2];
+        s2 += (double)partial[((int64_t)b * LN_NB + i) * 2 + 1];
+    }
+    const float m1 = (float)(s1 / (double)n_per), m2 = (float)(s2 / (double)n_per);
+    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+    const int64_t n4 = n_per / 4, per = (n4 + LN_NB - 1) / LN_NB;
+    const int64_t i0 = ch * per, i1 = min(n4, i0 + per);
+    const int F4 = F / 4;
+    const float4* dp = reinterpret_cast<const float4*>(dy + (int64_t)b * n_per);
+    const float4* zp = reinterpret_cast<const float4*>(z + (int64_t)b * n_per);
+    float4* op = reinterpret_cast<float4*>(dz + (int64_t)b * n_per);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int c = (int)(i % F4) * 4;
+        const float4 d = dp[i], v = zp[i];
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        float4 o;
+        o.x = rstd * (d.x * g.x - m1 - (v.x - mean) * rstd * m2);
+        o.y = rstd * (d.y * g.y - m1 - (v.y - mean) * rstd * m2);
+        o.z = rstd * (d.z * g.z - m1 - (v.z - mean) * rstd * m2);
+        o.w = rstd * (d.w * g.w - m1 - (v.w - mean) * rstd * m2);
+        op[i] = o;
+    }
+}
+
+// column partials [nblk][2][F] -> dgamma, dbeta
+__global__ __launch_bounds__(1024) void ln_bwd_colreduce_kernel(const float* __restrict__ colpart, int nblk, int F,
+                                                                float* dgamma, float* dbeta) {
+    __shared__ double sh[2][16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < F) {
+        for (int b = rg; b < nblk; b += 16) {
+            const float* p = colpart + (int64_t)b * 2 * F;
+            s += (double)p[c];
+            q += (double)p[F + c];
+        }
+    }
+    sh[0][rg][cl] = s;
+    sh[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < F) {
+        for (int i = 1; i < 16; ++i) {
+            s += sh[0][i][cl];
+            q += sh[1][i][cl];
+        }
+        dgamma[c] = (float)s;
+        dbeta[c] = (float)q;
+    }
+}
+
+}  // namespace lpm
+
+extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
+    return ((size_t)B * lpm::LN_NB * 2 + (size_t)B * lpm::LN_NB * 2 * F) * sizeof(float);
+}
+
+#define LPM_LN_CHECK(name)                                                                                              \
+    LPM_REQUIRE(B > 0 && L > 0 && (F == 128 || F == 256 || F == 512 || F == 1024), LPM_ERR_UNSUPPORTED_SHAPE,             \
+                name ": need F in {128,256,512,1024} (F=%d)", F);                                                        \
+    LPM_REQUIRE(workspace && workspace_bytes >= lpm_layer_norm_workspace_bytes(B, F), LPM_ERR_WORKSPACE, name ": workspace too small")
+
+extern "C" int lpm_layer_norm_fwd(const float* a, const float* r, const float* gamma, const float* beta, int B, int L, int F,
+                                  float eps, float* y, float* z, float* stats, void* workspace, size_t workspace_bytes,
+                                  lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(a && gamma && beta && y && stats && (z || !r), LPM_ERR_BADARG, "lpm_layer_norm_fwd: null pointer (z is required with a residual)");
+    LPM_LN_CHECK("lpm_layer_norm_fwd");
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const int64_t n_per = (int64_t)L * F;
+    dim3 grid(B, LN_NB);
+    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, n_per, z, partial);
+    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, r ? z : a, partial, gamma, beta, n_per, F, eps, y, stats);
+    return check_launch("lpm_layer_norm_fwd");
+}
+
+extern "C" int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, const float* gamma, int B, int L, int F,
+                                  float* dz, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                  lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dy && z && stats && gamma && dz && dgamma && dbeta, LPM_ERR_BADARG, "lpm_layer_norm_bwd: null pointer");
+    LPM_LN_CHECK("lpm_layer_norm_bwd");
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* colpart = partial + (size_t)B * LN_NB * 2;
+    const int64_t n_per = (int64_t)L * F;
+    dim3 grid(B, LN_NB);
+    hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart);
+    hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, n_per, F, dz);
+    hipLaunchKernelGGL(ln_bwd_colreduce_kernel, dim3((F + 63) / 64), dim3(1024), 0, s, colpart, B * LN_NB, F, dgamma, dbeta);
+    return check_launch("lpm_layer_norm_bwd");
+}

@@ -49,12 +49,17 @@ def batch_norm(x: torch.Tensor, is_training: bool, scope: str) -> torch.Tensor:
     return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
 
 
-def layer_norm(x: torch.Tensor, scope: str = "LayerNorm") -> torch.Tensor:
-    """tf.contrib.layers.layer_norm defaults: moments over ALL non-batch axes, gamma/beta [last], eps 1e-12
-    (transformer_utils.py:407,411,454,713)."""
+def layer_norm(x: torch.Tensor, scope: str = "LayerNorm", residual: torch.Tensor = None) -> torch.Tensor:
+    """tf.contrib.layers.layer_norm(x [+ residual]) with TF1 defaults: moments over ALL non-batch axes, gamma/beta
+    [last], eps 1e-12 (transformer_utils.py:407,411,454,713).  [B,L,F] tensors on the GPU take the fused
+    residual + layer-norm HIP kernels (csrc/layer_norm.hip)."""
     with vs.variable_scope(scope):
         beta = vs.get_variable("beta", [x.shape[-1]], vs.zeros_initializer(), device=x.device)
         gamma = vs.get_variable("gamma", [x.shape[-1]], vs.ones_initializer(), device=x.device)
+    if x.is_cuda and x.dim() == 3 and x.shape[-1] in ops.LN_FEATURES:
+        return ops.residual_layer_norm(x, residual, gamma, beta)
+    if residual is not None:
+        x = x + residual
     y = F.layer_norm(x, tuple(x.shape[1:]), None, None, LN_EPS)
     return y * gamma + beta
 

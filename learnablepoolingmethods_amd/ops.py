@@ -382,6 +382,52 @@ def dense_x3(x2d, W):
 
 
 # ----------------------------------------------------------------------------------------------
+# residual add + layer_norm (TF1 defaults: moments over all non-batch axes)
+# ----------------------------------------------------------------------------------------------
+LN_EPS = 1e-12
+LN_FEATURES = (128, 256, 512, 1024)
+
+
+class _ResidualLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, r, gamma, beta):
+        lib = _capi.load()
+        a = _f32(a, "layer_norm input").contiguous()
+        B, L, F = a.shape
+        r = r.contiguous() if r is not None else None
+        y = torch.empty_like(a)
+        z = torch.empty_like(a) if r is not None else a
+        stats = _empty((B, 2), a)
+        wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
+        lib.check(lib._lpm_layer_norm_fwd(ptr(a), ptr(r), ptr(gamma), ptr(beta), B, L, F, LN_EPS, ptr(y),
+                                          ptr(z) if r is not None else None, ptr(stats), ptr(ws), wsb, stream_ptr()),
+                  "lpm_layer_norm_fwd")
+        ctx.has_r = r is not None
+        ctx.save_for_backward(z, stats, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _capi.load()
+        z, stats, gamma = ctx.saved_tensors
+        B, L, F = z.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(z)
+        dgamma, dbeta = _empty((F,), z), _empty((F,), z)
+        wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=z.device)
+        lib.check(lib._lpm_layer_norm_bwd(ptr(dy), ptr(z), ptr(stats), ptr(gamma), B, L, F, ptr(dz), ptr(dgamma), ptr(dbeta),
+                                          ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_bwd")
+        return dz, (dz if ctx.has_r else None), dgamma, dbeta
+
+
+def residual_layer_norm(a, r, gamma, beta):
+    """layer_norm(a + r) with TF1 joint moments; a, r: [B, L, F]."""
+    return _ResidualLayerNorm.apply(a, r, gamma, beta)
+
+
+# ----------------------------------------------------------------------------------------------
 # K4: attention core
 # ----------------------------------------------------------------------------------------------
 def _mha_dims(q, num_heads):

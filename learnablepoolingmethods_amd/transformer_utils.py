@@ -62,8 +62,7 @@ class FeedForwardNetwork(modules.BaseModule):
     def forward(self, inputs, **unused_params):
         filter_output = layers.dense(inputs, self.filter_size, True, "filter_output{}".format(self.scope_id), torch.relu)
         output = layers.dense(filter_output, self.feature_size, True, "ff_output{}".format(self.scope_id), torch.relu)
-        output = output + inputs
-        return layers.layer_norm(output, "LayerNorm_1")
+        return layers.layer_norm(output, "LayerNorm_1", residual=inputs)      # output + inputs, then layer_norm :712-713
 
 
 class FeedForwardNetworkMod(modules.BaseModule):
@@ -99,11 +98,9 @@ class TransformerEncoder(modules.BaseModule):
 
     def forward(self, inputs, **unused_params):
         attention = self.multi_head_attention.forward(inputs, inputs)
-        attention = attention + inputs
-        attention = layers.layer_norm(attention, "LayerNorm")          # :407
-        ff_output = self.ff_network.forward(attention)                 # adds its own residual + LayerNorm_1
-        ff_output = ff_output + attention
-        return layers.layer_norm(ff_output, "LayerNorm_2")             # :411
+        attention = layers.layer_norm(attention, "LayerNorm", residual=inputs)         # attention + inputs :405-407
+        ff_output = self.ff_network.forward(attention)                                 # adds its own residual + LayerNorm_1
+        return layers.layer_norm(ff_output, "LayerNorm_2", residual=attention)         # ff_output + attention :409-411
 
 
 class TransformerEncoderMod(modules.BaseModule):
@@ -124,6 +121,5 @@ class TransformerEncoderMod(modules.BaseModule):
             if dropout_mask is None:
                 dropout_mask = (torch.rand_like(attention) >= rate).to(attention.dtype)
             attention = attention * dropout_mask / (1.0 - rate)
-        attention = attention + inputs
-        attention = layers.layer_norm(attention, "LayerNorm")
+        attention = layers.layer_norm(attention, "LayerNorm", residual=inputs)         # :451-454
         return self.ff_network.forward(attention)

@@ -324,3 +324,26 @@ def test_dense_split_bf16(M, K, N):
     y.backward(dy.to(dev))
     assert_close(xg.grad, xd.grad, tol=5e-5, what="dense_x3 dx")
     assert_close(Wg.grad, Wd.grad, tol=5e-5, what="dense_x3 dW")
+
+
+@pytest.mark.parametrize("B,L,F,res", [(3, 256, 1024, True), (2, 64, 128, True), (4, 300, 128, False), (2, 7, 256, True)])
+def test_residual_layer_norm(B, L, F, res):
+    """tf.contrib.layers.layer_norm defaults (joint moments over L*F) with the residual add fused."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(L)
+    a, r, dy = (torch.randn(B, L, F, generator=g) for _ in range(3))
+    gamma, beta = 1 + 0.2 * torch.randn(F, generator=g), 0.1 * torch.randn(F, generator=g)
+    p = {"ln/gamma": gamma.double().requires_grad_(True), "ln/beta": beta.double().requires_grad_(True)}
+    ad, rd = a.double().requires_grad_(True), r.double().requires_grad_(True)
+    ref = O.layer_norm(ad + rd if res else ad, p, "ln")
+    ref.backward(dy.double())
+    ag, rg, gg, bg = (t.to(dev).requires_grad_(True) for t in (a, r, gamma, beta))
+    y = ops.residual_layer_norm(ag, rg if res else None, gg, bg)
+    assert_close(y, ref, tol=1e-5, what="layer_norm fwd")
+    y.backward(dy.to(dev))
+    assert_close(ag.grad, ad.grad, tol=1e-4, what="layer_norm da")
+    if res:
+        assert_close(rg.grad, rd.grad, tol=1e-4, what="layer_norm dr")
+    assert_close(gg.grad, p["ln/gamma"].grad, tol=1e-4, what="layer_norm dgamma")
+    assert_close(bg.grad, p["ln/beta"].grad, tol=1e-4, what="layer_norm dbeta")
