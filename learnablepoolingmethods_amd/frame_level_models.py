@@ -59,7 +59,7 @@ def _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_bat
     vlad_dim = vlad.shape[1]
     hidden1_weights = vs.get_variable("hidden1_weights", [vlad_dim, hidden1_size],
                                       vs.random_normal_initializer(1 / math.sqrt(cluster_size)), device=dev)   # :2315-2317
-    activation = vlad.matmul(hidden1_weights)                                                                  # :2319
+    activation = ops.projection(vlad, hidden1_weights) if vlad.is_cuda else vlad.matmul(hidden1_weights)      # :2319
     if add_batch_norm and relu:
         activation = layers.batch_norm(activation, is_training, "hidden1_bn")                                  # :2321-2327
     else:

@@ -382,6 +382,44 @@ def dense_x3(x2d, W):
 
 
 # ----------------------------------------------------------------------------------------------
+# a9: VLAD -> hidden projection (frame_level_models.py:2314-2319): [B, 270336] x [270336, H], weight-stream bound
+# ----------------------------------------------------------------------------------------------
+class _Projection(torch.autograd.Function):
+    """Plain library GEMMs, arranged for a skinny-M / huge-K problem: the forward is split-K (a batched GEMM over
+    K-slices + a tiny reduction: 0.21 ms instead of 0.77 ms for the one-shot GEMM hipBLASLt picks at M = 80), and the
+    weight gradient (554 MB at cfg-2, 85 % of all gradient bytes) is written straight into the trainer's gradient
+    arena when the weight carries ``_lpm_grad_view`` -- no autograd accumulate pass over it."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        M, K = x.shape
+        N = W.shape[1]
+        S = next((s for s in (132, 128, 96, 64, 48, 32, 16, 8) if K % s == 0 and K // s >= 512), 1)
+        ctx.save_for_backward(x, W)
+        if S == 1 or M > 512:
+            return x.matmul(W)
+        return torch.bmm(x.view(M, S, K // S).transpose(0, 1), W.view(S, K // S, N)).sum(0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy.matmul(W.t()) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            view = getattr(W, "_lpm_grad_view", None)
+            if view is not None and W.grad is None:
+                dW = torch.mm(x.t(), dy, out=view)      # AccumulateGrad adopts this tensor: the arena IS the gradient
+            else:
+                dW = x.t().matmul(dy)
+        return dx, dW
+
+
+def projection(x, W):
+    return _Projection.apply(x, W)
+
+
+# ----------------------------------------------------------------------------------------------
 # residual add + layer_norm (TF1 defaults: moments over all non-batch axes)
 # ----------------------------------------------------------------------------------------------
 LN_EPS = 1e-12

@@ -60,13 +60,32 @@ class ParameterArena:
                 self.views[n] = t
         store.frozen = True
         self._scratch = None
+        self.direct = []          # (name, offset, numel): gradients their producer writes straight into the arena
+
+    def mark_direct(self, name: str):
+        """The op producing this variable's gradient writes it into the arena itself (ops._Projection): skip its
+        memset and let autograd adopt the arena view instead of running an accumulate pass over it."""
+        t = self.views[name]
+        a0, _ = self.segment(name)
+        t._lpm_grad_view = self.grad[a0:a0 + t.numel()].view(t.shape)
+        self.direct.append((name, a0, t.numel()))
 
     def segment(self, name: str):
         i = self.names.index(name)
         return self.offsets_host[i], self.offsets_host[i + 1]
 
     def zero_grad(self):
-        self.grad.zero_()
+        if not self.direct:
+            self.grad.zero_()
+            return
+        cur = 0
+        for name, a0, n in sorted(self.direct, key=lambda d: d[1]):
+            if a0 > cur:
+                self.grad[cur:a0].zero_()
+            cur = a0 + n                      # (alignment padding after a direct segment stays zero forever)
+            self.views[name].grad = None      # autograd will adopt the arena view the producer returns
+        if cur < self.total:
+            self.grad[cur:].zero_()
 
 
 class GradientSynchronizer:
@@ -154,6 +173,8 @@ class Trainer:
                 elif n.endswith("/moving_variance"):
                     v.fill_(1.0)
         self.arena = ParameterArena(self.store, first=["tower/hidden1_weights"])
+        if self.device.type == "cuda":
+            self.arena.mark_direct("tower/hidden1_weights")
         a0, a1 = self.arena.segment("tower/hidden1_weights")
         self.sync = GradientSynchronizer(self.arena.grad, [(a0, a1), (a1, self.arena.total)], self.group)
         if self.sync.active:
