@@ -141,8 +141,11 @@ def main():
             bytes_ = k2_algorithmic_bytes(B, T, D, K)
             ach = bytes_ / (avg_ms * 1e-3) / 1e9
             prec = ops.VLAD_PRECISION
-            kname = ("vlad_aggregate_tiles_kernel<8> (K2, video stream, split-bf16 MFMA)" if prec == "bf16x3"
-                     else "vlad_aggregate_kernel<8,4,true> (K2, video stream, exact-fp32 MFMA)")
+            if prec == "bf16x3":
+                kname = ("vlad_aggregate_tiles3_kernel (K2, video stream, split-bf16 MFMA, LDS-DMA tiles)" if ops.VLAD_TILES3
+                         else "vlad_aggregate_tiles_kernel<8> (K2, video stream, split-bf16 MFMA, register streaming)")
+            else:
+                kname = "vlad_aggregate_kernel<8,4,true> (K2, video stream, exact-fp32 MFMA)"
             roof = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes": bytes_, "avg_kernel_ms": round(avg_ms, 4), "launches": len(k2),
@@ -152,7 +155,7 @@ def main():
                 tt = [a.elapsed_time(b) for (n, d, a, b) in timeline if n == nm and d[2] in (1024, 256)]
                 if tt:
                     roof[nm + "_avg_ms"] = round(sum(tt) / len(tt), 4)
-            pmc = os.path.join(ROOT, "profiles", "k2_hbm_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "k2_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             if os.path.exists(pmc):
                 try:
                     roof["traffic"] = json.load(open(pmc)).get("bytes_per_launch")

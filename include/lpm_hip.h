@@ -135,6 +135,18 @@ int lpm_assign_tiles(const float* assign, const float* scale, const float* shift
 int lpm_vlad_aggregate_tiles_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,
                                  int flags, float* nrm, float* asum, float* colsq, float* csq, lpm_stream_t stream);
 
+/* K2, LDS-shared form (csrc/vlad_tiles3.hip): 512-thread workgroups own 128 clusters x 128 columns of a clip, tiles
+ * arrive by LDS-DMA and are shared by 8 waves (2.8x less L2 -> CU traffic than the streaming form).  Needs
+ * D %% 128 == 0 and K %% 128 == 0 (lpm_vlad_tiles3_supported).  It writes the UN-normalised residual sums into nrm and
+ * per-column-slab partial square norms colsq_part [B, D/128, K]; lpm_vlad_finalize2_fwd then applies BOTH normalisations:
+ * nrm <- intra-normalised (in place, what lpm_vlad_aggregate_bwd reads), out = globally normalised in the flagged
+ * layout, plus colsq, csq [B,K] and gsq [B].  P = number of partial slabs (D/128). */
+int lpm_vlad_tiles3_supported(int D, int K);
+int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,
+                                  int flags, float* nrm, float* asum, float* colsq_part, lpm_stream_t stream);
+int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out,
+                           float* colsq, float* csq, float* gsq, lpm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K3: backward of K2 (TF autodiff of the same lines; formulas SURVEY.md App. F.1-F.3).
  * dout: gradient w.r.t. `out` in the layout given by flags.  Saved from forward: nrm, asum, colsq, csq, gsq.

@@ -44,6 +44,9 @@ SIGNATURES = {
     "lpm_split_frames": (_i, [_f, _l, _i, _i, _i, _f, _f]),
     "lpm_assign_tiles": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),
     "lpm_vlad_aggregate_tiles_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "lpm_vlad_tiles3_supported": (_i, [_i, _i]),
+    "lpm_vlad_aggregate_tiles3_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "lpm_vlad_finalize2_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_vlad_bwd_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_vlad_aggregate_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _l,
                                     _i, _f, _f, _s, _f]),

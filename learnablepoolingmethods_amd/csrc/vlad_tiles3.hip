@@ -1,0 +1,272 @@
+// K2, third form: LDS-shared split-bf16 tiles fed by LDS-DMA (global_load_lds), 128 clusters x 128 columns per
+// workgroup.
+//
+// vlad_tiles.hip streams every fragment from L2 straight into registers with (clip, 32-cluster slab) workgroups:
+// HBM traffic is algorithmic, but each clip's frames are re-read by its K/32 = 8 slab workgroups, 1.09 GB of
+// L2 -> CU traffic per launch, and that delivery path (not HBM, not the matrix pipe) bounds it at ~100 us.
+// Here a 512-thread workgroup owns 128 clusters x 128 columns of one clip: per 16-frame step it brings 4 cluster
+// tiles + 4 column tiles (hi and lo planes, 16 KB) into LDS ONCE with LDS-DMA -- the tile format is lane-linear,
+// so a 1 KB fragment is exactly one wave-wide global_load_lds_dwordx4 -- and its 8 waves (2 cluster pairs x 4
+// column tiles, 64 x 32 accumulator tile each) read their fragments from LDS with conflict-free ds_read_b128.
+// L2 -> CU traffic drops to A x D/128 + x x K/128 = 394 MB at cfg-2.  A 4-stage ring keeps three steps of DMA in
+// flight across ONE raw s_barrier per step with hand-counted vmcnt (cdna guide: never __syncthreads with glds in
+// flight).  Because a workgroup no longer sees all D columns of a cluster, the intra-normalisation moves to the
+// finalize pass: this kernel writes the un-normalised residual sums U and per-column-slab partial square norms.
+#include "lpm_common.h"
+
+namespace lpm {
+
+typedef __bf16 t3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned t3_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 t3_mfma(t3_u32x4 a, t3_u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(t3_bf16x8, a), __builtin_bit_cast(t3_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float t3_bf(unsigned h) { return __uint_as_float(h << 16); }
+
+constexpr int T3_NS = 4;                  // ring stages
+constexpr int T3_STAGE = 16 * 1024;       // bytes per stage: 4 A tiles + 4 x tiles, 2 planes, 1 KB each
+constexpr int T3_WS = 68;                 // epilogue per-wave tile row stride (floats): 272 B, 16-B aligned, conflict-free
+constexpr int T3_EPI = 8 * 32 * T3_WS * 4;  // epilogue bytes (8 waves x [32 d][64 k + pad])
+
+__global__ __launch_bounds__(512, 4) void vlad_aggregate_tiles3_kernel(
+    const uint4* __restrict__ at, const uint4* __restrict__ xt, const float* __restrict__ centres, int T, int D, int K,
+    int S, int KT, int residual, float* __restrict__ nrm, float* __restrict__ asum, float* __restrict__ colsq_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object (guide 5, trap (a))
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int kw = wave >> 2, dw = wave & 3;
+    const int DT = D >> 5, P = D >> 7, KB = K >> 7;      // column tiles, column slabs, cluster slabs
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / (KB * P), rem = lid % (KB * P);
+    const int kb = rem / P, ds = rem % P;                 // consecutive workgroups: same clip, same cluster slab
+
+    // DMA role of this wave: piece (tile = wave >> 1, plane = wave & 1) of the A block and of the x block
+    const int ptile = wave >> 1, pplane = wave & 1;
+    const uint4* asrc = at + ((((int64_t)b * KT + kb * 4 + ptile) * S) * 2 + pplane) * 64 + lane;       // + s * 128
+    const uint4* xsrc = xt + ((((int64_t)b * S) * DT + ds * 4 + ptile) * 2 + pplane) * 64 + lane;        // + s * DT * 128
+    const int adst = (ptile * 2 + pplane) * 1024, xdst = 8192 + (ptile * 2 + pplane) * 1024;
+
+    auto issue = [&](int s) {
+        unsigned char* st = smem + (s % T3_NS) * T3_STAGE;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)s * 128),
+                                         (__attribute__((address_space(3))) void*)(st + adst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (int64_t)s * DT * 128),
+                                         (__attribute__((address_space(3))) void*)(st + xdst), 16, 0, 0);
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    float asum_l[2] = {0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < T3_NS - 1; ++s)
+        if (s < S) issue(s);
+
+    for (int s = 0; s < S; ++s) {
+        // this wave's two pieces of step s have landed when at most 2 * (younger steps in flight) remain
+        const int behind = min(T3_NS - 2, S - 1 - s);
+        if (behind >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everyone's pieces of step s are in LDS; stage (s-1) % NS is free
+        asm volatile("" ::: "memory");
+        if (s + T3_NS - 1 < S) issue(s + T3_NS - 1);
+        const unsigned char* st = smem + (s % T3_NS) * T3_STAGE;
+        const t3_u32x4* af = reinterpret_cast<const t3_u32x4*>(st) + lane;                 // A tile c, plane p: + (c*2+p)*64
+        const t3_u32x4* xf = reinterpret_cast<const t3_u32x4*>(st + 8192) + lane;
+        const t3_u32x4 xh = xf[(dw * 2 + 0) * 64], xl = xf[(dw * 2 + 1) * 64];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const t3_u32x4 ah = af[((kw * 2 + c) * 2 + 0) * 64], al = af[((kw * 2 + c) * 2 + 1) * 64];
+            acc[c] = t3_mfma(ah, xh, acc[c]);
+            acc[c] = t3_mfma(ah, xl, acc[c]);
+            acc[c] = t3_mfma(al, xh, acc[c]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                asum_l[c] += (t3_bf(ah[q] & 0xffffu) + t3_bf(al[q] & 0xffffu)) + (t3_bf(ah[q] >> 16) + t3_bf(al[q] >> 16));
+        }
+    }
+    __syncthreads();     // no DMA in flight any more: the ring is reused by the epilogue
+
+    // ---- epilogue: residual, partial column square norms, coalesced d-major store of U -----------------
+    float* wl = reinterpret_cast<float*>(smem) + wave * (32 * T3_WS);
+    float* red = reinterpret_cast<float*>(smem + T3_EPI);        // [4 dw][128 k]
+    float* ssum = red + 4 * 128;                                 // [128 k]
+    const int k0 = kb * 128, d0 = ds * 128 + dw * 32;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        asum_l[c] += __shfl_xor(asum_l[c], 32, 64);
+        if (dw == 0 && half == 0) ssum[(kw * 2 + c) * 32 + l31] = asum_l[c];
+    }
+    if (residual) {
+        // centres rows d0..d0+31, columns k0 + kw*64 .. +63 -> wave-private LDS tile (coalesced 256-byte rows)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            const float4 w = *reinterpret_cast<const float4*>(centres + (int64_t)(d0 + row) * K + k0 + kw * 64 + c4);
+            *reinterpret_cast<float4*>(wl + row * T3_WS + c4) = w;
+        }
+    }
+    __syncthreads();
+    float part[2][16];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (residual) w = *reinterpret_cast<const float4*>(wl + l31 * T3_WS + c * 32 + 8 * q + 4 * half);
+            const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * q + j;
+                const float u = acc[c][r] - ssum[(kw * 2 + c) * 32 + 8 * q + 4 * half + j] * wv[j];
+                acc[c][r] = u;
+                part[c][r] = u * u;
+            }
+        }
+    }
+    __syncthreads();     // all reads of the centres tile done before it is overwritten with U
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(wl + l31 * T3_WS + c * 32 + 8 * q + 4 * half) =
+                make_float4(acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = half_sum(part[c][r]);
+            if (l31 == 0) red[dw * 128 + (kw * 2 + c) * 32 + mfma32_row(r, lane)] = v;
+        }
+    }
+    __syncthreads();
+    float* ob = nrm + ((int64_t)b * D + d0) * K + k0 + kw * 64;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+        *reinterpret_cast<float4*>(ob + (int64_t)row * K + c4) = *reinterpret_cast<const float4*>(wl + row * T3_WS + c4);
+    }
+    if (tid < 128) {
+        colsq_part[((int64_t)b * P + ds) * K + k0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+        if (ds == 0) asum[(int64_t)b * K + k0 + tid] = ssum[tid];
+    }
+}
+
+// finalize for the un-normalised form: per clip n_k = sum_p colsq_part, inv_n = rsqrt(max(n,eps)), c_k = n inv_n^2,
+// g = sum_k c_k;  nrm <- U * inv_n (in place, d-major: what the backward reads);  out = nrm * rsqrt(max(g,eps)) laid out
+// d-major [B, D*K] or k-major [B,K,D].   grid (B, D/32).
+template <bool KMAJOR>
+__global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
+                                                             int P, int D, int K, float* __restrict__ out,
+                                                             float* __restrict__ colsq, float* __restrict__ csq,
+                                                             float* __restrict__ gsq) {
+    extern __shared__ float fs[];            // [K] inv_n, then [32][33] transpose tile, [4] partial sums
+    float* invn = fs;
+    float* tile = fs + K;
+    float* wg = tile + 32 * 33;
+    const int b = blockIdx.x, d0 = blockIdx.y * 32, tid = threadIdx.x;
+    float g = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        float n = 0.f;
+        for (int p = 0; p < P; ++p) n += colsq_part[((int64_t)b * P + p) * K + k];
+        const float iv = rsqrtf(fmaxf(n, kL2Eps));
+        const float c = n * iv * iv;
+        invn[k] = iv;
+        g += c;
+        if (blockIdx.y == 0) {
+            colsq[(int64_t)b * K + k] = n;
+            csq[(int64_t)b * K + k] = c;
+        }
+    }
+    g = wave_sum(g);
+    if ((tid & 63) == 0) wg[tid >> 6] = g;
+    __syncthreads();
+    const float tot = (wg[0] + wg[1]) + (wg[2] + wg[3]);
+    const float ig = rsqrtf(fmaxf(tot, kL2Eps));
+    if (blockIdx.y == 0 && tid == 0) gsq[b] = tot;
+    float* src = nrm + ((int64_t)b * D + d0) * K;
+    if (!KMAJOR) {
+        float* dst = out + ((int64_t)b * D + d0) * K;
+        const int n4 = 32 * K / 4, K4 = K / 4;
+        for (int i = tid; i < n4; i += 256) {
+            const int k = (i % K4) * 4;
+            float4 v = reinterpret_cast<const float4*>(src)[i];
+            v.x *= invn[k]; v.y *= invn[k + 1]; v.z *= invn[k + 2]; v.w *= invn[k + 3];
+            reinterpret_cast<float4*>(src)[i] = v;
+            v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
+            reinterpret_cast<float4*>(dst)[i] = v;
+        }
+    } else {
+        float* dst = out + (int64_t)b * K * D;
+        const int tx = tid & 31, ty = tid >> 5;
+        for (int kb = 0; kb < K; kb += 32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int dl = ty + 8 * i, k = kb + tx;
+                float v = 0.f;
+                if (k < K) {
+                    v = src[(int64_t)dl * K + k] * invn[k];
+                    src[(int64_t)dl * K + k] = v;
+                }
+                tile[dl * 33 + tx] = v * ig;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kl = ty + 8 * i, k = kb + kl;
+                if (k < K) dst[(int64_t)k * D + d0 + tx] = tile[tx * 33 + kl];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace lpm
+
+extern "C" int lpm_vlad_tiles3_supported(int D, int K) { return (D % 128 == 0 && K % 128 == 0 && D >= 128 && K >= 128) ? 1 : 0; }
+
+extern "C" int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,
+                                             int flags, float* nrm, float* asum, float* colsq_part, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(at && xt && nrm && asum && colsq_part, LPM_ERR_BADARG, "lpm_vlad_aggregate_tiles3_fwd: null pointer");
+    const int residual = (flags & LPM_VLAD_RESIDUAL) ? 1 : 0;
+    LPM_REQUIRE(!residual || centres, LPM_ERR_BADARG, "lpm_vlad_aggregate_tiles3_fwd: RESIDUAL needs centres");
+    LPM_REQUIRE(B > 0 && T > 0 && lpm_vlad_tiles3_supported(D, K), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_tiles3_fwd: need D %% 128 == 0 and K %% 128 == 0 (D=%d K=%d)", D, K);
+    LPM_REQUIRE((((uintptr_t)at | (uintptr_t)xt | (uintptr_t)centres | (uintptr_t)nrm) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_vlad_aggregate_tiles3_fwd: pointers must be 16-byte aligned");
+    const int S = (T + 15) / 16, KT = K / 32;
+    const size_t lds = (size_t)T3_EPI + (4 * 128 + 128) * sizeof(float);
+    static_assert(T3_EPI >= T3_NS * T3_STAGE, "epilogue region must cover the DMA ring");
+    auto kern = vlad_aggregate_tiles3_kernel;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("lpm_vlad_aggregate_tiles3_fwd: cannot reserve %zu bytes of LDS", lds);
+        return LPM_ERR_LAUNCH;
+    }
+    dim3 grid(B * (K / 128) * (D / 128));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
+                       residual, nrm, asum, colsq_part);
+    return check_launch("lpm_vlad_aggregate_tiles3_fwd");
+}
+
+extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out,
+                                      float* colsq, float* csq, float* gsq, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(nrm && colsq_part && out && colsq && csq && gsq, LPM_ERR_BADARG, "lpm_vlad_finalize2_fwd: null pointer");
+    LPM_REQUIRE(B > 0 && P > 0 && D % 32 == 0 && K % 4 == 0 && K <= 4096, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_finalize2_fwd: need D %% 32 == 0, K %% 4 == 0 (D=%d K=%d)", D, K);
+    dim3 grid(B, D / 32);
+    const size_t lds = (size_t)(K + 32 * 33 + 4) * sizeof(float);
+    if (flags & LPM_VLAD_OUT_KMAJOR)
+        hipLaunchKernelGGL(vlad_finalize2_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq,
+                           csq, gsq);
+    else
+        hipLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out,
+                           colsq, csq, gsq);
+    return check_launch("lpm_vlad_finalize2_fwd");
+}

@@ -22,6 +22,9 @@ BN_DECAY = 0.999  # slim.batch_norm decay
 #   "bf16x3": split-bf16 (hi/lo planes, 3 bf16 MFMAs per product, ~1e-5 relative error)  [default]
 #   "f32":    exact fp32 MFMA (v_mfma_f32_32x32x2_f32, ~1e-7), 5.3x more matrix-pipe time
 VLAD_PRECISION = os.environ.get("LPM_VLAD_PRECISION", "bf16x3")
+# bf16x3 only: use the LDS-shared 128x128 workgroup form (vlad_tiles3.hip) where the shape allows (D, K multiples of
+# 128); otherwise / when off, the register-streaming form (vlad_tiles.hip).
+VLAD_TILES3 = os.environ.get("LPM_VLAD_TILES3", "1") != "0"
 
 # Split-bf16 tile copies of the most recent frame_sample_bn output (produced by the same kernel that writes the fp32
 # frames): {"base": weakref to y, "F": F, "Dv": .., "video": tensor, "audio": tensor|None}.  ops.netvlad / vlad_aggregate
@@ -185,6 +188,18 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
         at = torch.empty(lib._lpm_at_bytes(B, T, K) // 4, dtype=torch.int32, device=x.device)
         with _timed("assign_tiles", (B, T, K)):
             lib.check(lib._lpm_assign_tiles(ptr(assign), ptr(scale), ptr(shift), B, T, K, flags, ptr(at), st), "lpm_assign_tiles")
+        if VLAD_TILES3 and lib._lpm_vlad_tiles3_supported(D, K):
+            # LDS-shared form: un-normalised sums + partial square norms; finalize2 applies both normalisations
+            P = D // 128
+            part = _empty((B, P, K), x)
+            with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+                lib.check(lib._lpm_vlad_aggregate_tiles3_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm),
+                                                             ptr(asum), ptr(part), st), "lpm_vlad_aggregate_tiles3_fwd")
+            out = _empty((B, K, D) if kmajor else (B, D * K), x)
+            gsq = _empty((B,), x)
+            lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, LPM_VLAD_OUT_KMAJOR if kmajor else 0,
+                                                  ptr(out), ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_finalize2_fwd")
+            return out, nrm, asum, colsq, csq, gsq
         with _timed("vlad_aggregate_fwd", (B, T, D, K)):
             lib.check(lib._lpm_vlad_aggregate_tiles_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
                                                         ptr(colsq), ptr(csq), st), "lpm_vlad_aggregate_tiles_fwd")
