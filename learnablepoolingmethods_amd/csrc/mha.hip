@@ -29,13 +29,18 @@ __device__ __forceinline__ void mha_stage(float* dst, const float* __restrict__ 
     }
 }
 
-template <int NKT>
+// One workgroup per (batch, head).  Measured alternatives at the V1 video shape (B=80, L=256, h=64, d=16):
+// first form 429 us; + query fragments prefetched ahead of the K/V staging, two PV accumulator chains, affine /
+// ragged handling compiled out -> 334 us (this form); persistent workgroups with the next item's K/V/Q fetched
+// into registers during compute -> 400-456 us (the register ring costs a wave per SIMD or spills).
+template <int NKT, bool AFFINE>
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, int64_t ld, int L, int h, int d,
                                                       float scale, const float* __restrict__ key_scale,
                                                       const float* __restrict__ key_shift, float* __restrict__ o,
                                                       int64_t ldo, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NQ = (NKT + 3) / 4;    // query tiles per wave
     const int nkt = (L + 15) >> 4, L16 = nkt * 16;
     float* Ks = smem;
     float* Vs = Ks + L16 * MH_S;
@@ -46,23 +51,39 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = lid / h, hh = lid % h;
     const int ns = d >> 2;  // reduction steps of 4 over the head dimension
+    const bool ragged = (L != L16);
 
-    for (int i = tid; i < 2 * L16 * MH_S; i += 256) smem[i] = 0.f;
-    for (int i = tid; i < L16; i += 256) {
-        ksc[i] = (key_scale && i < L) ? key_scale[i] : 1.f;
-        ksh[i] = (key_shift && i < L) ? key_shift[i] : 0.f;
+    // every query fragment this wave will need, issued before the K/V staging so the loads overlap it
+    float qf[NQ][4];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int qrow = (wave + 4 * i) * 16 + l15;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[i][s] = (s < ns && qrow < L) ? q[((int64_t)b * L + qrow) * ld + hh * d + 4 * s + g] : 0.f;
     }
-    __syncthreads();
+    if (ragged || d < 16) {               // pad rows / columns must read as zero; otherwise every word is overwritten
+        for (int i = tid; i < 2 * L16 * MH_S; i += 256) smem[i] = 0.f;
+        __syncthreads();
+    }
+    if (AFFINE) {
+        for (int i = tid; i < L16; i += 256) {
+            ksc[i] = (i < L) ? key_scale[i] : 1.f;
+            ksh[i] = (i < L) ? key_shift[i] : 0.f;
+        }
+    }
     mha_stage(Ks, k, ld, b, L, hh, d, tid);
     mha_stage(Vs, v, ld, b, L, hh, d, tid);
     __syncthreads();
 
-    for (int qt = wave; qt < nkt; qt += 4) {
-        const int qrow = qt * 16 + l15;
-        float qf[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            qf[s] = (s < ns && qrow < L) ? q[((int64_t)b * L + qrow) * ld + hh * d + 4 * s + g] * scale : 0.f;
+    for (int i = 0; i < NQ; ++i) {
+        const int qt = wave + 4 * i;
+        if (qt >= nkt) break;
+        const int qrow = qt * 16 + l15;
+        float qs[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qs[s] = qf[i][s] * scale;
         f32x4 p[NKT];
         float m = -INFINITY;
 #pragma unroll
@@ -72,11 +93,13 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
                 const float* ka = Ks + (kt * 16 + l15) * MH_S + g;
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    if (s < ns) acc = mfma16(ka[4 * s], qf[s], acc);
+                    if (s < ns) acc = mfma16(ka[4 * s], qs[s], acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + 4 * g + r;
-                    const float z = (key < L) ? fmaf(acc[r], ksc[key], ksh[key]) : -INFINITY;
+                    float z = acc[r];
+                    if (AFFINE) z = fmaf(z, ksc[key], ksh[key]);
+                    if (ragged && key >= L) z = -INFINITY;
                     acc[r] = z;
                     m = fmaxf(m, z);
                 }
@@ -99,19 +122,21 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};   // two chains: the 40-cycle dependent latency hides
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt < nkt) {
                 const float* va = Vs + (kt * 16 + 4 * g) * MH_S + l15;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oacc = mfma16(va[r * MH_S], p[kt][r], oacc);
+                oa = mfma16(va[0], p[kt][0], oa);
+                ob = mfma16(va[MH_S], p[kt][1], ob);
+                oa = mfma16(va[2 * MH_S], p[kt][2], oa);
+                ob = mfma16(va[3 * MH_S], p[kt][3], ob);
             }
         }
         const float inv = 1.f / sum;
         if (qrow < L) {
             if (4 * g < d) {
-                float4 ov = make_float4(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv);
+                float4 ov = make_float4((oa[0] + ob[0]) * inv, (oa[1] + ob[1]) * inv, (oa[2] + ob[2]) * inv, (oa[3] + ob[3]) * inv);
                 *reinterpret_cast<float4*>(o + ((int64_t)b * L + qrow) * ldo + hh * d + 4 * g) = ov;
             }
             if (g == 0) lse[((int64_t)b * h + hh) * L + qrow] = m + __logf(sum);
@@ -200,6 +225,7 @@ __global__ __launch_bounds__(256) void mha_logit_stats_kernel(const float* __res
 //                       also the per-(batch, head) column sums of dz and dz*s for the logits_bn backward
 //                       (dz_partial [(b*h+hh)][0][key] = sum_q dz, [1][key] = sum_q dz * s).
 // D_q = rowsum(P * dP) = <dO_q, O_q>.  corr_a / corr_b: ds = key_scale*dz - corr_a[key] - s*corr_b[key].
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, int64_t ld,
                                                          const float* __restrict__ o, const float* __restrict__ dout,
@@ -222,14 +248,19 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
     const int b = lid / h, hh = lid % h;
     const int ns = d >> 2;
 
-    for (int i = tid; i < 2 * L16 * MH_S; i += 256) smem[i] = 0.f;
-    for (int i = tid; i < L16; i += 256) {
-        ksc[i] = (key_scale && i < L) ? key_scale[i] : 1.f;
-        ksh[i] = (key_shift && i < L) ? key_shift[i] : 0.f;
-        cas[i] = (corr_a && i < L) ? corr_a[i] : 0.f;
-        cbs[i] = (corr_b && i < L) ? corr_b[i] : 0.f;
+    const bool ragged = (L != L16);
+    if (ragged || d < 16) {               // pad rows / columns must read as zero; otherwise every word is overwritten
+        for (int i = tid; i < 2 * L16 * MH_S; i += 256) smem[i] = 0.f;
+        __syncthreads();
     }
-    __syncthreads();
+    if (AFFINE) {
+        for (int i = tid; i < L16; i += 256) {
+            ksc[i] = (i < L) ? key_scale[i] : 1.f;
+            ksh[i] = (i < L) ? key_shift[i] : 0.f;
+            cas[i] = (corr_a && i < L) ? corr_a[i] : 0.f;
+            cbs[i] = (corr_b && i < L) ? corr_b[i] : 0.f;
+        }
+    }
     mha_stage(Ks, k, ld, b, L, hh, d, tid);
     mha_stage(Vs, v, ld, b, L, hh, d, tid);
     __syncthreads();
@@ -251,7 +282,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
         dpart += __shfl_xor(dpart, 16, 64);
         dpart += __shfl_xor(dpart, 32, 64);          // D_q for q = l15
         const float lq = qok ? lse[((int64_t)b * h + hh) * L + qrow] : INFINITY, dqv = dpart;
-        f32x4 dqa = {0.f, 0.f, 0.f, 0.f};
+        f32x4 dqa = {0.f, 0.f, 0.f, 0.f}, dqb = {0.f, 0.f, 0.f, 0.f};   // two accumulation chains
         for (int kt = 0; kt < nkt; ++kt) {
             f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
             const float* ka = Ks + (kt * 16 + l15) * MH_S + g;
@@ -264,15 +295,24 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
                 }
             }
             const float* kc = Ks + (kt * 16 + 4 * g) * MH_S + l15;
+            float ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + 4 * g + r;
-                const float z = (key < L) ? fmaf(st[r], ksc[key], ksh[key]) : -INFINITY;
+                float z = st[r];
+                if (AFFINE) z = fmaf(z, ksc[key], ksh[key]);
+                if (ragged && key >= L) z = -INFINITY;
                 const float p = __expf(z - lq);
-                const float ds = p * (dp[r] - dqv) * ksc[key] - cas[key] - st[r] * cbs[key];
-                dqa = mfma16(kc[r * MH_S], ds, dqa);       // dQ^T[dd, q] += K^T[dd, key] dS^T[key, q]
+                ds[r] = p * (dp[r] - dqv);
+                if (AFFINE) ds[r] = ds[r] * ksc[key] - cas[key] - st[r] * cbs[key];
             }
+            dqa = mfma16(kc[0], ds[0], dqa);               // dQ^T[dd, q] += K^T[dd, key] dS^T[key, q]
+            dqb = mfma16(kc[MH_S], ds[1], dqb);
+            dqa = mfma16(kc[2 * MH_S], ds[2], dqa);
+            dqb = mfma16(kc[3 * MH_S], ds[3], dqb);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dqa[r] += dqb[r];
         if (qok && 4 * g < d) {
             float4 ov = make_float4(dqa[0] * scale, dqa[1] * scale, dqa[2] * scale, dqa[3] * scale);
             *reinterpret_cast<float4*>(dq + ((int64_t)b * L + qrow) * ldd + hh * d + 4 * g) = ov;
@@ -280,6 +320,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
     }
 }
 
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ v, int64_t ld,
                                                           const float* __restrict__ o, const float* __restrict__ dout,
@@ -359,17 +400,25 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
             }
             const float* qc = Qs + (qt * 16 + 4 * g) * MH_S + l15;
             const float* gc = Gs + (qt * 16 + 4 * g) * MH_S + l15;
+            const float4 lq4v = *reinterpret_cast<const float4*>(lses + qt * 16 + 4 * g);    // this lane's 4 query rows
+            const float4 dq4v = *reinterpret_cast<const float4*>(Dq + qt * 16 + 4 * g);
+            const float lq4[4] = {lq4v.x, lq4v.y, lq4v.z, lq4v.w}, dq4[4] = {dq4v.x, dq4v.y, dq4v.z, dq4v.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qr = qt * 16 + 4 * g + r;
                 const float sraw = st[r] * scale;
-                const float z = kok ? fmaf(sraw, sck, shk) : -INFINITY;
-                const float p = __expf(z - lses[qr]);
-                const float dz = p * (dp[r] - Dq[qr]);
-                zs += dz;
-                zq = fmaf(dz, sraw, zq);
+                float z = sraw;
+                if (AFFINE) z = fmaf(sraw, sck, shk);
+                if (!kok) z = -INFINITY;
+                const float p = __expf(z - lq4[r]);
+                const float dz = p * (dp[r] - dq4[r]);
+                if (AFFINE) {
+                    zs += dz;
+                    zq = fmaf(dz, sraw, zq);
+                }
                 if (!stats_only) {
-                    const float ds = (qr < L) ? dz * sck - cak - sraw * cbk : 0.f;
+                    float ds = dz;
+                    if (AFFINE) ds = (qr < L) ? dz * sck - cak - sraw * cbk : 0.f;
                     dva = mfma16(gc[r * MH_S], p, dva);      // dV^T[dd, key] += dO^T[dd, q] P[q, key]
                     dka = mfma16(qc[r * MH_S], ds, dka);     // dK^T[dd, key] += Q^T[dd, q] dS[q, key]
                 }
@@ -425,11 +474,16 @@ extern "C" int lpm_mha_fwd(const float* q, const float* k, const float* v, int64
     const size_t lds = mha_fwd_lds(L);
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
-#define LPM_MHA_FWD(N)                                                                                           \
+#define LPM_MHA_FWD1(N, AFF)                                                                                     \
     do {                                                                                                         \
-        auto kern = mha_fwd_kernel<N>;                                                                           \
+        auto kern = mha_fwd_kernel<N, AFF>;                                                                      \
         if (int rc = reserve_lds(kern, lds, "lpm_mha_fwd")) return rc;                                           \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ld, L, h, d, scale, key_scale, key_shift, o, ldo, lse); \
+    } while (0)
+#define LPM_MHA_FWD(N)                 \
+    do {                               \
+        if (key_scale) LPM_MHA_FWD1(N, true); \
+        else LPM_MHA_FWD1(N, false);   \
     } while (0)
     if (nkt <= 4) LPM_MHA_FWD(4);
     else if (nkt <= 8) LPM_MHA_FWD(8);
@@ -437,6 +491,7 @@ extern "C" int lpm_mha_fwd(const float* q, const float* k, const float* v, int64
     else if (nkt <= 20) LPM_MHA_FWD(20);
     else LPM_MHA_FWD(32);
 #undef LPM_MHA_FWD
+#undef LPM_MHA_FWD1
     return check_launch("lpm_mha_fwd");
 }
 
@@ -480,13 +535,19 @@ extern "C" int lpm_mha_bwd(const float* q, const float* k, const float* v, int64
     LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0, LPM_ERR_BADARG, "lpm_mha_bwd: bad ldo/ldd");
     const size_t lds = mha_bwd_lds(L);
     hipStream_t s = (hipStream_t)stream;
-    if (dq) {
-        if (int rc = reserve_lds(mha_bwd_dq_kernel, lds, "lpm_mha_bwd")) return rc;
-        hipLaunchKernelGGL(mha_bwd_dq_kernel, dim3(B * h), dim3(256), lds, s, q, k, v, ld, o, dout, ldo, lse, L, h, d, scale,
-                           key_scale, key_shift, dq, ldd, corr_a, corr_b);
-    }
-    if (int rc = reserve_lds(mha_bwd_dkv_kernel, lds, "lpm_mha_bwd")) return rc;
-    hipLaunchKernelGGL(mha_bwd_dkv_kernel, dim3(B * h), dim3(256), lds, s, q, k, v, ld, o, dout, ldo, lse, L, h, d, scale,
-                       key_scale, key_shift, dk, dv, ldd, corr_a, corr_b, dz_partial);
+#define LPM_MHA_BWD(AFF)                                                                                                  \
+    do {                                                                                                                  \
+        if (dq) {                                                                                                         \
+            if (int rc = reserve_lds(mha_bwd_dq_kernel<AFF>, lds, "lpm_mha_bwd")) return rc;                              \
+            hipLaunchKernelGGL(mha_bwd_dq_kernel<AFF>, dim3(B * h), dim3(256), lds, s, q, k, v, ld, o, dout, ldo, lse, L, h, d, \
+                               scale, key_scale, key_shift, dq, ldd, corr_a, corr_b);                                     \
+        }                                                                                                                 \
+        if (int rc = reserve_lds(mha_bwd_dkv_kernel<AFF>, lds, "lpm_mha_bwd")) return rc;                                 \
+        hipLaunchKernelGGL(mha_bwd_dkv_kernel<AFF>, dim3(B * h), dim3(256), lds, s, q, k, v, ld, o, dout, ldo, lse, L, h, d,   \
+                           scale, key_scale, key_shift, dk, dv, ldd, corr_a, corr_b, dz_partial);                         \
+    } while (0)
+    if (key_scale) LPM_MHA_BWD(true);
+    else LPM_MHA_BWD(false);
+#undef LPM_MHA_BWD
     return check_launch("lpm_mha_bwd");
 }
