@@ -183,6 +183,12 @@ int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const f
 int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, void* out3,
                    lpm_stream_t stream);
 int lpm_split_weight(const float* W, int K, int N, void* w3, void* w3t, lpm_stream_t stream);
+/* backward of the fused relu(x + bias) split (FeedForwardNetwork, transformer_utils.py:701-711): g = df * [act > 0]
+ * (act3 = the forward's [M,3K] split image of the activation), out3 = split image of g, dbias [K] = column sums of g.
+ * workspace: lpm_split_rows_relu_bwd_workspace_bytes(M, K). */
+size_t lpm_split_rows_relu_bwd_workspace_bytes(int64_t M, int K);
+int lpm_split_rows_relu_bwd(const float* df, int64_t M, int K, const void* act3, void* out3, float* dbias, void* workspace,
+                            size_t workspace_bytes, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Residual add + tf.contrib.layers.layer_norm with TF1 defaults (transformer_utils.py:405-411,451-454,712-713):

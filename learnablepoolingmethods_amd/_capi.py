@@ -54,6 +54,8 @@ SIGNATURES = {
     "lpm_bn_bwd": (_i, [_f, _f, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _s, _f]),
     "lpm_split_rows": (_i, [_f, _l, _l, _i, _f, _i, _f, _f]),
     "lpm_split_weight": (_i, [_f, _i, _i, _f, _f, _f]),
+    "lpm_split_rows_relu_bwd_workspace_bytes": (_s, [_l, _i]),
+    "lpm_split_rows_relu_bwd": (_i, [_f, _l, _i, _f, _f, _f, _f, _s, _f]),
     "lpm_layer_norm_workspace_bytes": (_s, [_i, _i]),
     "lpm_layer_norm_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _f, _f, _f, _s, _f]),
     "lpm_layer_norm_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _s, _f]),

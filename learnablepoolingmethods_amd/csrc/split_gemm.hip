@@ -51,6 +51,65 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
+// Backward companion of the fused relu(x + bias) split: g = df * [act > 0] where `act3` is the [M,3K] split image of
+// the forward activation (its hi plane is > 0 exactly where the activation was), out3 = split(g), and per-block
+// column partial sums of g (the bias gradient) -> colpart [gridDim.x][K].  One workgroup = SR_ROWS rows, all columns.
+constexpr int SR_ROWS = 32;
+__global__ __launch_bounds__(256) void split_rows_relu_bwd_kernel(const float* __restrict__ df, int64_t M, int K,
+                                                                  const unsigned short* __restrict__ act3,
+                                                                  unsigned short* __restrict__ out3,
+                                                                  float* __restrict__ colpart) {
+    const int K8 = K / 8;
+    const int64_t r0 = (int64_t)blockIdx.x * SR_ROWS, r1 = min(M, r0 + SR_ROWS);
+    for (int cg = threadIdx.x; cg < K8; cg += 256) {
+        const int c = cg * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int64_t m = r0; m < r1; ++m) {
+            const float4 a = *reinterpret_cast<const float4*>(df + m * K + c);
+            const float4 b = *reinterpret_cast<const float4*>(df + m * K + c + 4);
+            const uint4 hm = *reinterpret_cast<const uint4*>(act3 + m * 3 * (int64_t)K + c);   // hi plane of the activation
+            float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const unsigned mw[4] = {hm.x, hm.y, hm.z, hm.w};
+            unsigned h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned ah = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                const bool on = (ah != 0u) && !(ah & 0x8000u);                 // activation > 0
+                v[e] = on ? v[e] : 0.f;
+                acc[e] += v[e];
+                h[e] = sg_bf16_rne(v[e]);
+                l[e] = sg_bf16_rne(v[e] - sg_bf16_f32(h[e]));
+            }
+            const uint4 hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            const uint4 lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+            unsigned short* row = out3 + m * 3 * (int64_t)K;
+            *reinterpret_cast<uint4*>(row + c) = hi;
+            *reinterpret_cast<uint4*>(row + K + c) = lo;
+            *reinterpret_cast<uint4*>(row + 2 * (int64_t)K + c) = hi;
+        }
+        float* cp = colpart + (int64_t)blockIdx.x * K + c;
+        *reinterpret_cast<float4*>(cp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(cp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+// colpart [nblk][K] -> out [K]  (fp64 accumulation, 16 row groups x 64 columns per workgroup)
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ colpart, int nblk, int K,
+                                                             float* __restrict__ out) {
+    __shared__ double sh[16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0;
+    if (c < K)
+        for (int b = rg; b < nblk; b += 16) s += (double)colpart[(int64_t)b * K + c];
+    sh[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < K) {
+        for (int i = 1; i < 16; ++i) s += sh[i][cl];
+        out[c] = (float)s;
+    }
+}
+
 // grid (K/32, N/32); 32x32 tile through LDS for the transposed copy
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int K, int N,
                                                            unsigned short* __restrict__ w3,
@@ -102,6 +161,25 @@ extern "C" int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, con
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                        M, K, bias, relu, (unsigned short*)out3);
     return check_launch("lpm_split_rows");
+}
+
+extern "C" size_t lpm_split_rows_relu_bwd_workspace_bytes(int64_t M, int K) {
+    return (size_t)((M + lpm::SR_ROWS - 1) / lpm::SR_ROWS) * K * sizeof(float);
+}
+
+extern "C" int lpm_split_rows_relu_bwd(const float* df, int64_t M, int K, const void* act3, void* out3, float* dbias,
+                                       void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(df && act3 && out3 && dbias && workspace, LPM_ERR_BADARG, "lpm_split_rows_relu_bwd: null pointer");
+    LPM_REQUIRE(M > 0 && K > 0 && K % 8 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_split_rows_relu_bwd: need K %% 8 == 0 (K=%d)", K);
+    LPM_REQUIRE(workspace_bytes >= lpm_split_rows_relu_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE,
+                "lpm_split_rows_relu_bwd: workspace too small");
+    const int nblk = (int)((M + SR_ROWS - 1) / SR_ROWS);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(split_rows_relu_bwd_kernel, dim3(nblk), dim3(256), 0, s, df, M, K, (const unsigned short*)act3,
+                       (unsigned short*)out3, (float*)workspace);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((K + 63) / 64), dim3(1024), 0, s, (const float*)workspace, nblk, K, dbias);
+    return check_launch("lpm_split_rows_relu_bwd");
 }
 
 extern "C" int lpm_split_weight(const float* W, int K, int N, void* w3, void* w3t, lpm_stream_t stream) {

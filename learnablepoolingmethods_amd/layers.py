@@ -64,16 +64,27 @@ def layer_norm(x: torch.Tensor, scope: str = "LayerNorm", residual: torch.Tensor
     return y * gamma + beta
 
 
+def use_split_gemm(x: torch.Tensor, rows: int, units: int) -> bool:
+    """Dense layers big enough to pay for the operand split run as split-bf16 library GEMMs (ops._DenseX3)."""
+    return (FLAGS.dense_precision == "bf16x3" and x.is_cuda and rows >= 1024 and x.shape[-1] % 8 == 0 and units % 8 == 0)
+
+
+def dense_variables(name: str, fan_in: int, units: int, use_bias: bool, device):
+    """tf.layers.dense variables: <name>/kernel (glorot uniform), <name>/bias (zeros)."""
+    with vs.variable_scope(name):
+        kernel = vs.get_variable("kernel", [fan_in, units], vs.glorot_uniform_initializer(), device=device)
+        bias = vs.get_variable("bias", [units], vs.zeros_initializer(), device=device) if use_bias else None
+    return kernel, bias
+
+
 def dense(x: torch.Tensor, units: int, use_bias: bool, name: str, activation=None) -> torch.Tensor:
     """tf.layers.dense: contracts the last axis; glorot-uniform kernel, zero bias."""
-    with vs.variable_scope(name):
-        kernel = vs.get_variable("kernel", [x.shape[-1], units], vs.glorot_uniform_initializer(), device=x.device)
-        rows = x.numel() // x.shape[-1]
-        if (FLAGS.dense_precision == "bf16x3" and x.is_cuda and rows >= 1024 and x.shape[-1] % 8 == 0 and units % 8 == 0):
-            # split-bf16 operands -> bf16 matrix pipe at fp32-grade accuracy (ops._DenseX3)
-            y = ops.dense_x3(x.reshape(rows, x.shape[-1]), kernel).reshape(*x.shape[:-1], units)
-        else:
-            y = x.matmul(kernel)
-        if use_bias:
-            y = y + vs.get_variable("bias", [units], vs.zeros_initializer(), device=x.device)
+    kernel, bias = dense_variables(name, x.shape[-1], units, use_bias, x.device)
+    rows = x.numel() // x.shape[-1]
+    if use_split_gemm(x, rows, units):
+        y = ops.dense_x3(x.reshape(rows, x.shape[-1]), kernel).reshape(*x.shape[:-1], units)
+    else:
+        y = x.matmul(kernel)
+    if use_bias:
+        y = y + bias
     return activation(y) if activation is not None else y

@@ -396,6 +396,60 @@ def dense_x3(x2d, W):
     return _DenseX3.apply(x2d, W)
 
 
+def _dw_x3(x3, dy3, K, N):
+    """dW = x^T dy from the split images (three small-output bf16 GEMMs, fp32 accumulation)."""
+    xh, xl = x3[:, :K], x3[:, K:2 * K]
+    dyh, dyl = dy3[:, :N], dy3[:, N:2 * N]
+    dW = torch.mm(xh.t(), dyh, out_dtype=torch.float32)
+    dW += torch.mm(xl.t(), dyh, out_dtype=torch.float32)
+    dW += torch.mm(xh.t(), dyl, out_dtype=torch.float32)
+    return dW
+
+
+class _FFNX3(torch.autograd.Function):
+    """relu(y W1 + b1) W2 of FeedForwardNetwork (transformer_utils.py:701-708) on split-bf16 operands with the first
+    layer's bias + ReLU fused into the operand split of the second: the [M,4F] activation exists only as its bf16
+    hi/lo image, and the backward's ReLU mask, bias gradient and operand split are one pass as well."""
+
+    @staticmethod
+    def forward(ctx, y2d, W1, b1, W2):
+        y2d = _rows(y2d, "ffn input")
+        W1, W2 = _f32(W1, "W1").contiguous(), _f32(W2, "W2").contiguous()
+        y3 = _split_rows(y2d)
+        w13, w13t = _split_weight(W1)
+        pre1 = torch.mm(y3, w13, out_dtype=torch.float32)
+        f3 = _split_rows(pre1, bias=b1.contiguous(), relu=True)
+        del pre1
+        w23, w23t = _split_weight(W2)
+        ctx.save_for_backward(y3, f3, w13t, w23t)
+        ctx.dims = (W1.shape[0], W1.shape[1], W2.shape[1])
+        return torch.mm(f3, w23, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _capi.load()
+        y3, f3, w13t, w23t = ctx.saved_tensors
+        F, H, N = ctx.dims
+        M = y3.shape[0]
+        do3 = _split_rows(dout.contiguous())
+        df = torch.mm(do3, w23t, out_dtype=torch.float32)                 # [M, H]
+        dW2 = _dw_x3(f3, do3, H, N)
+        dp3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=df.device)
+        db1 = _empty((H,), df)
+        wsb = lib._lpm_split_rows_relu_bwd_workspace_bytes(M, H)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=df.device)
+        lib.check(lib._lpm_split_rows_relu_bwd(ptr(df), M, H, ptr(f3), ptr(dp3), ptr(db1), ptr(ws), wsb, stream_ptr()),
+                  "lpm_split_rows_relu_bwd")
+        del df
+        dy = torch.mm(dp3, w13t, out_dtype=torch.float32)
+        dW1 = _dw_x3(y3, dp3, F, H)
+        return dy, dW1, db1, dW2
+
+
+def ffn_x3(y2d, W1, b1, W2):
+    return _FFNX3.apply(y2d, W1, b1, W2)
+
+
 # ----------------------------------------------------------------------------------------------
 # a9: VLAD -> hidden projection (frame_level_models.py:2314-2319): [B, 270336] x [270336, H], weight-stream bound
 # ----------------------------------------------------------------------------------------------

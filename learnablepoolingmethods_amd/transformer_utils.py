@@ -60,8 +60,17 @@ class FeedForwardNetwork(modules.BaseModule):
         self.scope_id = scope_id
 
     def forward(self, inputs, **unused_params):
-        filter_output = layers.dense(inputs, self.filter_size, True, "filter_output{}".format(self.scope_id), torch.relu)
-        output = layers.dense(filter_output, self.feature_size, True, "ff_output{}".format(self.scope_id), torch.relu)
+        n1, n2 = "filter_output{}".format(self.scope_id), "ff_output{}".format(self.scope_id)
+        rows = inputs.numel() // inputs.shape[-1]
+        if layers.use_split_gemm(inputs, rows, self.filter_size) and self.feature_size % 8 == 0:
+            # both dense layers as split-bf16 library GEMMs with the inner bias + ReLU fused into the operand split
+            w1, b1 = layers.dense_variables(n1, inputs.shape[-1], self.filter_size, True, inputs.device)
+            w2, b2 = layers.dense_variables(n2, self.filter_size, self.feature_size, True, inputs.device)
+            output = ops.ffn_x3(inputs.reshape(rows, inputs.shape[-1]), w1, b1, w2).reshape(*inputs.shape[:-1], self.feature_size)
+            output = torch.relu(output + b2)
+        else:
+            filter_output = layers.dense(inputs, self.filter_size, True, n1, torch.relu)                       # :701-704
+            output = layers.dense(filter_output, self.feature_size, True, n2, torch.relu)                      # :708-711
         return layers.layer_norm(output, "LayerNorm_1", residual=inputs)      # output + inputs, then layer_norm :712-713
 
 

@@ -347,3 +347,29 @@ def test_residual_layer_norm(B, L, F, res):
         assert_close(rg.grad, rd.grad, tol=1e-4, what="layer_norm dr")
     assert_close(gg.grad, p["ln/gamma"].grad, tol=1e-4, what="layer_norm dgamma")
     assert_close(bg.grad, p["ln/beta"].grad, tol=1e-4, what="layer_norm dbeta")
+
+
+def test_ffn_split_bf16_fused_bias_relu():
+    """FeedForwardNetwork core relu(y W1 + b1) W2 with the inner bias + ReLU fused into the operand split."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(3)
+    M, F, H = 2048, 128, 512
+    y, W1, b1, W2, dout = (torch.randn(M, F, generator=g), torch.randn(F, H, generator=g) / F ** .5, 0.3 * torch.randn(H, generator=g),
+                           torch.randn(H, F, generator=g) / H ** .5, torch.randn(M, F, generator=g))
+    yd, W1d, b1d, W2d = (t.double().requires_grad_(True) for t in (y, W1, b1, W2))
+    ref = torch.relu(yd @ W1d + b1d) @ W2d
+    ref.backward(dout.double())
+    yg, W1g, b1g, W2g = (t.to(dev).requires_grad_(True) for t in (y, W1, b1, W2))
+    out = ops.ffn_x3(yg, W1g, b1g, W2g)
+    assert_close(out, ref, tol=5e-5, what="ffn fwd")
+    out.backward(dout.to(dev))
+    # Frobenius norm: a pre-activation within the GEMM's rounding of zero flips its ReLU mask (a handful of the 1M
+    # units here), which moves single gradient entries by O(1) in max-norm without being an error of either side
+    from tests._util import rel_l2
+    for got, want, nm in ((yg, yd, "dy"), (W1g, W1d, "dW1"), (b1g, b1d, "db1"), (W2g, W2d, "dW2")):
+        e = rel_l2(got.grad, want.grad)
+        assert e <= 5e-3, f"ffn {nm}: relative L2 error {e:.3e}"
+    # and the flips must be isolated: all but a few rows of dy agree to 1e-4 of the tensor scale
+    err = (yg.grad.double().cpu() - yd.grad).abs().amax(dim=1) / yd.grad.abs().max()
+    assert int((err > 1e-4).sum()) <= 20, f"{int((err > 1e-4).sum())} of {M} dy rows differ: not ReLU-flip noise"
