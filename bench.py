@@ -92,11 +92,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # LPM_SHARE_GPU=1 (debug only): several ranks on ONE GPU over gloo, to exercise the data-parallel code path on a
+    # single-GPU box; the measured configuration is always one rank per GPU over RCCL.
+    share = os.environ.get("LPM_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)       # nccl == RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)       # nccl == RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from learnablepoolingmethods_amd import ops, registry
