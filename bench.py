@@ -171,8 +171,9 @@ def main():
         line = {"metric": METRIC, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "dtype_detail": "fp32 storage and accumulation everywhere; K2 and the encoder dense GEMMs feed the bf16 MFMA pipe "
-                                "with split-bf16 (hi+lo) operands (~5e-6 relative error), K1/K3/K4 use the exact-fp32 MFMA",
+                "dtype_detail": "fp32 storage and accumulation everywhere; K1, K2, K3 and the encoder dense GEMMs feed the bf16 MFMA "
+                                "pipe with split-bf16 (hi+lo) operands, 3 MFMAs per product (~5e-6 relative error); K4 (attention) "
+                                "uses the exact-fp32 MFMA",
                 "config": {"workload": "NetVladV1 K=256 hidden=512 rgb+audio 1152-d 300 frames, bs 80 per GPU "
                                        "(BASELINE configs[1]; configs[3] at 8 GPUs), full training step",
                            "global_batch": global_batch, "seq_len": MAX_FRAMES, "parallelism": f"dp{world}"},
@@ -182,8 +183,16 @@ def main():
         if k1:
             M, D, K = k1[0][0]
             avg_ms = sum(t for _, t in k1) / len(k1)
-            line["assign_gemm"] = {"avg_kernel_ms": round(avg_ms, 4), "tflops": round(2.0 * M * D * K / (avg_ms * 1e-3) / 1e12, 2),
-                                   "mfma": "v_mfma_f32_32x32x2_f32 (exact fp32, peak 157.3 TFLOP/s)"}
+            fl = 2.0 * M * D * K
+            if ops.ASSIGN_PRECISION == "bf16x3":
+                # split-bf16: 3 bf16 MFMAs per product -> matrix-pipe utilisation = 3 x useful flops / dense bf16 peak
+                line["assign_gemm"] = {"avg_kernel_ms": round(avg_ms, 4), "tflops": round(fl / (avg_ms * 1e-3) / 1e12, 2),
+                                       "mfma": "v_mfma_f32_32x32x16_bf16 x3 (split-bf16 operands, fp32 accumulate)",
+                                       "executed_bf16_tflops": round(3 * fl / (avg_ms * 1e-3) / 1e12, 1),
+                                       "mfma_util_vs_bf16_peak": round(3 * fl / (avg_ms * 1e-3) / 2.5e15, 3)}
+            else:
+                line["assign_gemm"] = {"avg_kernel_ms": round(avg_ms, 4), "tflops": round(fl / (avg_ms * 1e-3) / 1e12, 2),
+                                       "mfma": "v_mfma_f32_32x32x2_f32 (exact fp32, peak 157.3 TFLOP/s)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)

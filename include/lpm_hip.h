@@ -97,6 +97,31 @@ int lpm_assign_gemm_nblk(int M);
 int lpm_assign_gemm_fwd(const float* x, int64_t ldx, const float* w, int M, int D, int K, int precision,
                         float* logits, float* partial, lpm_stream_t stream);
 
+/* K1 and its backward on the bf16 matrix pipe (csrc/tile_gemm.hip, csrc/tile_gemm.h): split-bf16 operands (a = hi + lo
+ * bf16 planes; ah*bh + ah*bl + al*bh accumulated in fp32, ~5e-6 relative error) stored as MFMA-fragment tiles:
+ *   tile[plane][lane][e] = M[outer = 32*tile + (lane&31)][reduction = 16*step + 8*(lane>>5) + e],  16 bytes per lane.
+ *   row tiles    [b][mt][cs]  of a [B*T, C] matrix, per clip, mt < 2*ceil(T/64) (rows >= T zero)     lpm_split_rows_tiles
+ *   weight tiles [rs][nt]     of M[R, N] (reduction R); `transposed`: the source is stored [N, R]     lpm_split_weight_tiles
+ *   frame tiles  [b][s][ct]   reduction along the frame axis                                          lpm_split_frames
+ * Needs D %% 32 == 0, K %% 32 == 0, K <= 512 (lpm_assign_gemm_tiles_supported).
+ *   fwd:    logits[B*T,K] = x . w  + per-workgroup column statistics `partial` [lpm_assign_gemm_tiles_nblk(B,T), 2, K]
+ *           (replaces tf.matmul + cluster_bn statistics, frame_level_models.py:2781-2789)
+ *   bwd_dx: dx[B*T, D] (row stride lddx) += dlogits . w^T     dlr = row tiles of dlogits, wtt = weight tiles of w^T
+ *   bwd_dw: dw[D,K] = x^T . dlogits                           xt / dlt = frame tiles of x and dlogits */
+size_t lpm_row_tiles_bytes(int B, int T, int C);
+size_t lpm_weight_tiles_bytes(int R, int N);
+int lpm_assign_gemm_tiles_supported(int T, int D, int K);
+int lpm_assign_gemm_tiles_nblk(int B, int T);
+int lpm_split_rows_tiles(const float* x, int64_t ldx, int B, int T, int C, void* out, lpm_stream_t stream);
+int lpm_split_weight_tiles(const float* w, int R, int N, int transposed, void* wt, lpm_stream_t stream);
+int lpm_assign_gemm_tiles_fwd(const void* xr, const void* wt, int B, int T, int D, int K, float* logits, float* partial,
+                              lpm_stream_t stream);
+int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T, int D, int K, float* dx, int64_t lddx,
+                                 lpm_stream_t stream);
+size_t lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(int B, int T, int D, int K);
+int lpm_assign_gemm_tiles_bwd_dw(const void* xt, const void* dlt, int B, int T, int D, int K, float* dw, void* workspace,
+                                 size_t workspace_bytes, lpm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2: fused [BN-affine -> softmax] -> residual aggregation -> intra-normalisation
  *   replaces frame_level_models.py:2798-2819 (NetVLAD), :2856-2872 (LightVLAD, no RESIDUAL flag),
@@ -161,6 +186,22 @@ int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const float* asu
                            const float* shift, const float* x, int64_t ldx, const float* centres, int B, int T,
                            int D, int K, int flags, float* dassign, float* dx, int64_t lddx, int accumulate_dx,
                            float* dcentres, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+
+/* K3 on the bf16 matrix pipe (tile form; needs D %% 32 == 0, K %% 32 == 0, K <= 512).  dU = u dO - v N is written once per
+ * clip as split-bf16 fragment tiles and both GEMMs of the backward run through the tile GEMM (csrc/tile_gemm.h):
+ *   lpm_vlad_aggregate_bwd_tiles:    dassign (softmax backward fused in the epilogue) and dcentres; xr = row tiles of x
+ *                                    (lpm_split_rows_tiles).  Leaves the dU and assignment tiles in `workspace`.
+ *   lpm_vlad_aggregate_bwd_tiles_dx: dx[B*T, D] (=, or += when accumulate_dx) sum_k a dU  [+ dl . w^T when dlr / wtt, the row
+ *                                    tiles of the assignment GEMM's dlogits and the weight tiles of w^T, are given: the
+ *                                    soft-assignment GEMM's input gradient rides in the same pass].  Same workspace. */
+size_t lpm_vlad_bwd_tiles_workspace_bytes(int B, int T, int D, int K);
+int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm, const float* asum, const float* colsq,
+                                 const float* csq, const float* gsq, const float* assign, const float* scale,
+                                 const float* shift, const void* xr, const float* centres, int B, int T, int D, int K,
+                                 int flags, float* dassign, float* dcentres, void* workspace, size_t workspace_bytes,
+                                 lpm_stream_t stream);
+int lpm_vlad_aggregate_bwd_tiles_dx(const void* workspace, size_t workspace_bytes, const void* dlr, const void* wtt, int B,
+                                    int T, int D, int K, float* dx, int64_t lddx, int accumulate_dx, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward through the training-mode batch-norm on the logits:

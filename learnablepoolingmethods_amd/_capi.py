@@ -37,6 +37,16 @@ SIGNATURES = {
     "lpm_bn_fold": (_i, [_f, _i, _i, _l, _f, _f, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
     "lpm_assign_gemm_nblk": (_i, [_i]),
     "lpm_assign_gemm_fwd": (_i, [_f, _l, _f, _i, _i, _i, _i, _f, _f, _f]),
+    "lpm_row_tiles_bytes": (_s, [_i, _i, _i]),
+    "lpm_weight_tiles_bytes": (_s, [_i, _i]),
+    "lpm_assign_gemm_tiles_supported": (_i, [_i, _i, _i]),
+    "lpm_assign_gemm_tiles_nblk": (_i, [_i, _i]),
+    "lpm_split_rows_tiles": (_i, [_f, _l, _i, _i, _i, _f, _f]),
+    "lpm_split_weight_tiles": (_i, [_f, _i, _i, _i, _f, _f]),
+    "lpm_assign_gemm_tiles_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f]),
+    "lpm_assign_gemm_tiles_bwd_dx": (_i, [_f, _f, _i, _i, _i, _i, _f, _l, _f]),
+    "lpm_assign_gemm_tiles_bwd_dw_workspace_bytes": (_s, [_i, _i, _i, _i]),
+    "lpm_assign_gemm_tiles_bwd_dw": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _s, _f]),
     "lpm_vlad_aggregate_fwd": (_i, [_f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_vlad_finalize_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f]),
     "lpm_xt_bytes": (_s, [_i, _i, _i]),
@@ -50,6 +60,9 @@ SIGNATURES = {
     "lpm_vlad_bwd_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_vlad_aggregate_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _l,
                                     _i, _f, _f, _s, _f]),
+    "lpm_vlad_bwd_tiles_workspace_bytes": (_s, [_i, _i, _i, _i]),
+    "lpm_vlad_aggregate_bwd_tiles": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _s, _f]),
+    "lpm_vlad_aggregate_bwd_tiles_dx": (_i, [_f, _s, _f, _f, _i, _i, _i, _i, _f, _l, _i, _f]),
     "lpm_bn_bwd_workspace_bytes": (_s, [_i, _i]),
     "lpm_bn_bwd": (_i, [_f, _f, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _s, _f]),
     "lpm_split_rows": (_i, [_f, _l, _l, _i, _f, _i, _f, _f]),
@@ -118,4 +131,6 @@ def ptr(t: Optional[torch.Tensor]):
 
 
 def stream_ptr():
+    if not torch.cuda.is_available():
+        raise LpmError("lpm ops need an MI355X (no HIP device is visible). There is no CPU fallback for the hot path.")
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,80 @@
+// Split-bf16 tile GEMM on the bf16 matrix pipe: C[rows, cols] (+)= A . B with both operands stored as MFMA-fragment
+// tiles in HBM.  A fragment tile is 32 outer indices (rows of A / columns of B) x 16 reduction elements, hi and lo bf16
+// planes, 16 bytes per lane and lane-linear:
+//     tile[plane][lane][e] = M[outer = 32 * tile_index + (lane & 31)][red = 16 * step + 8 * (lane >> 5) + e]
+// so one 1 KB plane is exactly one wave-wide LDS-DMA (global_load_lds_dwordx4) and one conflict-free ds_read_b128.
+// The (tile, step, batch) -> address map is three strides per operand, which lets the same kernel read
+//   row tiles     [b][mt][cs]  (lpm_split_rows_tiles: frames x features, reduction along the feature axis),
+//   weight tiles  [rs][nt]     (lpm_split_weight_tiles),
+//   frame tiles   [b][s][ct]   (lpm_split_frames: reduction along the frame axis, clips folded into the step index),
+//   per-clip dU tiles          (vlad_backward_tiles.hip).
+// a * b = ah*bh + ah*bl + al*bh with fp32 accumulation: ~5e-6 relative error (the 1e-3 parity bar with room to spare).
+//
+// Workgroup = 256 threads = 64 rows x (128 * NTW) columns: wave w owns the 32*NTW-column slice w, both row tiles.
+// Per reduction step the workgroup brings 2 row tiles + 4*NTW column tiles (hi, lo) into a 3-stage LDS ring by LDS-DMA
+// with ONE raw s_barrier per step and hand-counted vmcnt (cdna guide 5: no __syncthreads with glds in flight, a single
+// extern LDS object); 6*NTW MFMAs per wave per step.
+#pragma once
+#include "lpm_common.h"
+
+namespace lpm {
+
+typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned tg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 tg_mfma(tg_u32x4 a, tg_u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tg_bf16x8, a), __builtin_bit_cast(tg_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned tg_rne(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void tg_split8(const float* v, uint4& hi, uint4& lo) {
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = tg_rne(v[e]);
+        l[e] = tg_rne(v[e] - __uint_as_float(h[e] << 16));
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+constexpr int TG_NS = 3;     // LDS ring stages
+enum { TG_EPI_STORE = 0, TG_EPI_SOFTMAX_BWD = 1 };
+
+struct TileGemmArgs {
+    const uint4* a;            // strides below are in 16-byte units; a (tile, step) pair is 128 units (hi plane, lo plane)
+    const uint4* b;
+    int64_t a_tile, a_step, a_batch;
+    int64_t b_tile, b_step, b_batch;
+    int a_tiles, b_tiles;      // valid tile counts per batch (indices beyond are clamped; their results are masked)
+    // optional second operand pair, reduced after the first into the same accumulators (C = A.B + A2.B2; splits == 1):
+    const uint4* a2;
+    const uint4* b2;
+    int64_t a2_tile, a2_step, a2_batch;
+    int64_t b2_tile, b2_step, b2_batch;
+    int b2_tiles, steps2;      // (the row tiling of A2 is A's)
+    int rb_per_batch;          // 64-row blocks per batch: blockIdx.x = batch * rb_per_batch + rb
+    int steps_per_split;       // blockIdx.z = split: reduction steps [z * steps_per_split, ...) clipped to total_steps
+    int total_steps;
+    float* out;                // STORE: out[batch * out_batch + split * out_split + row * ldo + col]
+    int64_t ldo, out_batch, out_split;
+    int rows_valid, cols_valid;
+    int accumulate;            // STORE: out += result
+    float* stats;              // STORE, optional: [gridDim.x][2][cols_valid] per-workgroup column (sum, sum of squares)
+    // SOFTMAX_BWD (needs gridDim.y == gridDim.z == 1): out = dlogit~ with a = softmax(logits*scale + shift) recomputed
+    const float* logits;       // [batch * rows_valid + row][cols_valid]
+    const float* scale;        // [cols] or null
+    const float* shift;        // [cols] or null
+    const float* ctil;         // [batch][cols]
+    int softmax;               // 0: out = result - ctil (similarities given, NetVLAD-V2 form)
+};
+
+// Launchers (defined in tile_gemm.hip, the only translation unit that instantiates the kernel).  nbatch * rb_per_batch
+// workgroup rows, ceil(cols / (128 NTW)) column blocks, `splits` reduction splits.
+int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what);
+int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what);
+int tile_gemm_ntw(int cols);
+
+}  // namespace lpm

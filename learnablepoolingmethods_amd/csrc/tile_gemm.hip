@@ -1,0 +1,404 @@
+// K1 (soft-assignment GEMM) and its backward on the bf16 matrix pipe, as instances of the split-bf16 tile GEMM
+// (tile_gemm.h).  Reference: frame_level_models.py:2781-2789 (tf.matmul + the batch statistics of cluster_bn); the
+// backward is TF autodiff of that matmul.
+//   forward   logits[B*T, K] = x . W           A = row tiles of x (per clip), B = weight tiles of W, + BN-stat epilogue
+//   dx       += dlogits . W^T                   A = row tiles of dlogits,      B = weight tiles of W^T (reduction over K)
+//   dW        = x^T . dlogits                   A = frame tiles of x,          B = frame tiles of dlogits: the reduction
+//                                               runs over every frame of every clip, split over workgroups + a reduce pass
+#include "tile_gemm.h"
+
+namespace lpm {
+
+__host__ __device__ constexpr int tg_ring_bytes(int ntw) { return TG_NS * (4 + 8 * ntw) * 1024; }
+__host__ __device__ constexpr int tg_epi_stride(int ntw) { return 128 * ntw + 1; }
+static size_t tg_lds_bytes(int ntw, int epi) {
+    const size_t ring = tg_ring_bytes(ntw);
+    const size_t e = epi == TG_EPI_SOFTMAX_BWD ? (size_t)64 * tg_epi_stride(ntw) * sizeof(float) : 0;
+    return ring > e ? ring : e;
+}
+
+template <int NTW, int EPI>
+__global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g) {
+    constexpr int NTB = 4 * NTW;                   // column tiles per workgroup
+    constexpr int NP = 4 + 2 * NTB;                // 1 KB pieces per stage
+    constexpr int PW = NP / 4;                     // pieces per wave per stage
+    constexpr int STAGE = NP * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int batch = lid / g.rb_per_batch, rb = lid % g.rb_per_batch;
+    const int cb = blockIdx.y, split = blockIdx.z;
+    const int step0 = split * g.steps_per_split;
+    const int nstep1 = min(g.steps_per_split, g.total_steps - step0);
+    const int nstep = nstep1 + g.steps2;
+
+    // this wave's PW pieces of a stage: piece p < 4: row tile p>>1, plane p&1;  else column tile (p-4)>>1, plane (p-4)&1
+    const uint4* src[PW];
+    const uint4* src2[PW];
+    int64_t sstep[PW], sstep2[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int p = wave + 4 * j;
+        if (p < 4) {
+            const int t = min(rb * 2 + (p >> 1), g.a_tiles - 1);
+            src[j] = g.a + batch * g.a_batch + t * g.a_tile + step0 * g.a_step + (p & 1) * 64 + lane;
+            sstep[j] = g.a_step;
+            src2[j] = g.a2 + batch * g.a2_batch + t * g.a2_tile + (p & 1) * 64 + lane;
+            sstep2[j] = g.a2_step;
+        } else {
+            const int ct = cb * NTB + ((p - 4) >> 1);
+            src[j] = g.b + batch * g.b_batch + min(ct, g.b_tiles - 1) * g.b_tile + step0 * g.b_step + ((p - 4) & 1) * 64 + lane;
+            sstep[j] = g.b_step;
+            src2[j] = g.b2 + batch * g.b2_batch + min(ct, g.b2_tiles - 1) * g.b2_tile + ((p - 4) & 1) * 64 + lane;
+            sstep2[j] = g.b2_step;
+        }
+    }
+    auto issue = [&](int s) {
+        unsigned char* st = smem + (s % TG_NS) * STAGE;
+        const bool second = s >= nstep1;       // wave-uniform
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const uint4* q = second ? src2[j] + (s - nstep1) * sstep2[j] : src[j] + s * sstep[j];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
+                                             (__attribute__((address_space(3))) void*)(st + (wave + 4 * j) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][NTW];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < TG_NS - 1; ++s)
+        if (s < nstep) issue(s);
+    for (int s = 0; s < nstep; ++s) {
+        if (s + 1 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // one younger step in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // step s is in LDS for everyone; stage (s-1) % NS is free again
+        asm volatile("" ::: "memory");
+        if (s + TG_NS - 1 < nstep) issue(s + TG_NS - 1);
+        const tg_u32x4* f = reinterpret_cast<const tg_u32x4*>(smem + (s % TG_NS) * STAGE) + lane;
+        tg_u32x4 ah[2], al[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ah[m] = f[(m * 2 + 0) * 64];
+            al[m] = f[(m * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int nt = wave * NTW + n;
+            const tg_u32x4 bh = f[(4 + nt * 2 + 0) * 64], bl = f[(4 + nt * 2 + 1) * 64];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m][n] = tg_mfma(ah[m], bh, acc[m][n]);
+                acc[m][n] = tg_mfma(ah[m], bl, acc[m][n]);
+                acc[m][n] = tg_mfma(al[m], bh, acc[m][n]);
+            }
+        }
+    }
+
+    const int N = g.cols_valid;
+    if (EPI == TG_EPI_STORE) {
+        float* ob = g.out + batch * g.out_batch + split * g.out_split;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int col = (cb * NTB + wave * NTW + n) * 32 + l31;
+            float cs = 0.f, cq = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb * 64 + m * 32 + mfma32_row(r, lane);
+                    const float v = acc[m][n][r];
+                    if (row < g.rows_valid && col < N) {
+                        float* p = ob + (int64_t)row * g.ldo + col;
+                        *p = g.accumulate ? (*p + v) : v;
+                    }
+                    cs += v;                   // statistics callers pad with zero row tiles: rows >= rows_valid add nothing
+                    cq = fmaf(v, v, cq);
+                }
+            }
+            if (g.stats) {
+                cs += __shfl_xor(cs, 32, 64);
+                cq += __shfl_xor(cq, 32, 64);
+                if (lane < 32 && col < N) {
+                    float* p = g.stats + (int64_t)lid * 2 * N;
+                    p[col] = cs;
+                    p[N + col] = cq;
+                }
+            }
+        }
+    } else {
+        // dA - ctil -> LDS [64][128 NTW + 1]; then the softmax backward row by row:
+        //   dlogit~[t,k] = a[t,k] (g[t,k] - sum_j a[t,j] g[t,j]),  g = dA - ctil
+        constexpr int ES = tg_epi_stride(NTW);
+        constexpr int KPL = 2 * NTW;
+        float* ds = reinterpret_cast<float*>(smem);
+        __syncthreads();                       // nothing in flight (the last step waited for vmcnt(0)): the ring is free
+        const float* ct = g.ctil + (int64_t)batch * N;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int col = (wave * NTW + n) * 32 + l31;
+            const float c = (col < N) ? ct[col] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[(m * 32 + mfma32_row(r, lane)) * ES + col] = acc[m][n][r] - c;
+        }
+        __syncthreads();
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = wave * 16 + rr, t = rb * 64 + row;
+            if (t >= g.rows_valid) continue;   // wave-uniform
+            const int64_t grow = (int64_t)batch * g.rows_valid + t;
+            float* out = g.out + grow * N;
+            if (g.softmax) {
+                const float* lr = g.logits + grow * N;
+                float a[KPL], gg[KPL];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int c = lane + 64 * j;
+                    a[j] = (c < N) ? fmaf(lr[c], g.scale ? g.scale[c] : 1.f, g.shift ? g.shift[c] : 0.f) : -INFINITY;
+                    mx = fmaxf(mx, a[j]);
+                }
+                mx = wave_max(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    a[j] = __expf(a[j] - mx);
+                    sum += a[j];
+                }
+                sum = wave_sum(sum);
+                const float inv = 1.f / sum;
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int c = lane + 64 * j;
+                    a[j] *= inv;
+                    gg[j] = (c < N) ? ds[row * ES + c] : 0.f;
+                    dot = fmaf(a[j], gg[j], dot);
+                }
+                dot = wave_sum(dot);
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int c = lane + 64 * j;
+                    if (c < N) out[c] = a[j] * (gg[j] - dot);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int c = lane + 64 * j;
+                    if (c < N) out[c] = ds[row * ES + c];
+                }
+            }
+        }
+    }
+}
+
+// NTW for a problem with `cols` output columns: one column block when cols <= 512 (the row-wise epilogues need that),
+// 256-column blocks beyond.
+int tg_ntw(int cols) { const int nt = (cols + 31) / 32; return nt <= 4 ? 1 : (nt <= 8 ? 2 : (nt <= 16 ? 4 : 2)); }
+
+template <int EPI>
+static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what) {
+    const int ntw = tg_ntw(g.cols_valid);
+    const int nt = (g.cols_valid + 31) / 32;
+    dim3 grid((unsigned)(nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)), (unsigned)splits);
+    const size_t lds = tg_lds_bytes(ntw, EPI);
+#define LPM_TG_LAUNCH(NTW)                                                                                             \
+    do {                                                                                                               \
+        auto kern = tile_gemm_kernel<NTW, EPI>;                                                                        \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            (void)hipGetLastError();                                                                                   \
+            set_error("%s: cannot reserve %zu bytes of LDS", what, lds);                                               \
+            return LPM_ERR_LAUNCH;                                                                                     \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);                                                     \
+    } while (0)
+    if (ntw == 1) LPM_TG_LAUNCH(1);
+    else if (ntw == 2) LPM_TG_LAUNCH(2);
+    else LPM_TG_LAUNCH(4);
+#undef LPM_TG_LAUNCH
+    return check_launch(what);
+}
+
+
+int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what) {
+    return tg_launch<TG_EPI_STORE>(g, nbatch, splits, stream, what);
+}
+int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what) {
+    return tg_launch<TG_EPI_SOFTMAX_BWD>(g, nbatch, 1, stream, what);
+}
+int tile_gemm_ntw(int cols) { return tg_ntw(cols); }
+
+// [B*T, C] fp32 (row stride ldx) -> row tiles [b][mt][cs][plane][lane]; mt < 2*ceil(T/64), rows >= T are zero.
+__global__ __launch_bounds__(256) void split_rows_tiles_kernel(const float* __restrict__ x, int64_t ldx, int B, int T, int C, int MT,
+                                                               uint4* __restrict__ out) {
+    const int CS = C / 16;
+    const int64_t total = (int64_t)B * MT * CS * 64;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(w & 63);
+        int64_t t = w >> 6;
+        const int cs = (int)(t % CS);
+        t /= CS;
+        const int mt = (int)(t % MT), b = (int)(t / MT);
+        const int row = mt * 32 + (lane & 31), c = cs * 16 + 8 * (lane >> 5);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (row < T) {
+            const float* p = x + ((int64_t)b * T + row) * ldx + c;
+            const float4 a = *reinterpret_cast<const float4*>(p);
+            const float4 q = *reinterpret_cast<const float4*>(p + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+        }
+        uint4 hi, lo;
+        tg_split8(v, hi, lo);
+        const int64_t base = (w >> 6) * 128 + lane;
+        out[base] = hi;
+        out[base + 64] = lo;
+    }
+}
+
+// B operand of M[R, N] (reduction R, columns N): [rs][nt][plane][lane].  transposed: the source is stored [N, R].
+__global__ __launch_bounds__(256) void split_weight_tiles_kernel(const float* __restrict__ W, int R, int N, int transposed,
+                                                                 uint4* __restrict__ wt) {
+    const int RS = R / 16, NT = (N + 31) / 32;
+    const int64_t total = (int64_t)RS * NT * 64;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(w & 63);
+        const int64_t t = w >> 6;
+        const int nt = (int)(t % NT), rs = (int)(t / NT);
+        const int col = nt * 32 + (lane & 31), r = rs * 16 + 8 * (lane >> 5);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = (col < N) ? (transposed ? W[(int64_t)col * R + r + e] : W[(int64_t)(r + e) * N + col]) : 0.f;
+        uint4 hi, lo;
+        tg_split8(v, hi, lo);
+        const int64_t base = t * 128 + lane;
+        wt[base] = hi;
+        wt[base + 64] = lo;
+    }
+}
+
+// out[i] = sum_z part[z][i]   (float4 granularity)
+__global__ __launch_bounds__(256) void tg_reduce_splits_kernel(const float4* __restrict__ part, int Z, int64_t n4,
+                                                               float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = part[i];
+    for (int z = 1; z < Z; ++z) {
+        const float4 p = part[(int64_t)z * n4 + i];
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    out[i] = s;
+}
+
+static inline int row_tiles_per_clip(int T) { return 2 * ((T + 63) / 64); }
+static inline int dw_splits(int B, int T, int D, int K) {
+    const int blocks = ((D + 63) / 64) * (((K + 31) / 32 + 4 * tg_ntw(K) - 1) / (4 * tg_ntw(K)));
+    const int steps = B * ((T + 15) / 16);
+    int z = (512 + blocks - 1) / blocks;
+    if (z > steps / 8) z = steps / 8;
+    return z < 1 ? 1 : z;
+}
+
+}  // namespace lpm
+
+extern "C" size_t lpm_row_tiles_bytes(int B, int T, int C) {
+    return (size_t)B * lpm::row_tiles_per_clip(T) * (C / 16) * 2048;
+}
+extern "C" size_t lpm_weight_tiles_bytes(int R, int N) { return (size_t)(R / 16) * ((N + 31) / 32) * 2048; }
+extern "C" int lpm_assign_gemm_tiles_nblk(int B, int T) { return B * ((T + 63) / 64); }
+extern "C" int lpm_assign_gemm_tiles_supported(int T, int D, int K) {
+    return (D % 32 == 0 && K % 32 == 0 && K <= 512 && D > 0 && K > 0 && T > 0) ? 1 : 0;
+}
+
+extern "C" int lpm_split_rows_tiles(const float* x, int64_t ldx, int B, int T, int C, void* out, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x && out, LPM_ERR_BADARG, "lpm_split_rows_tiles: null pointer");
+    LPM_REQUIRE(B > 0 && T > 0 && C > 0 && C % 16 == 0 && ldx >= C && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0,
+                LPM_ERR_UNSUPPORTED_SHAPE, "lpm_split_rows_tiles: need C %% 16 == 0, ldx %% 4 == 0, aligned pointers (C=%d)", C);
+    const int MT = row_tiles_per_clip(T);
+    const int64_t total = (int64_t)B * MT * (C / 16) * 64;
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(split_rows_tiles_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       B, T, C, MT, (uint4*)out);
+    return check_launch("lpm_split_rows_tiles");
+}
+
+extern "C" int lpm_split_weight_tiles(const float* w, int R, int N, int transposed, void* wt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(w && wt, LPM_ERR_BADARG, "lpm_split_weight_tiles: null pointer");
+    LPM_REQUIRE(R > 0 && N > 0 && R % 16 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_split_weight_tiles: need R %% 16 == 0 (R=%d N=%d)", R, N);
+    const int64_t total = (int64_t)(R / 16) * ((N + 31) / 32) * 64;
+    hipLaunchKernelGGL(split_weight_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, R, N,
+                       transposed, (uint4*)wt);
+    return check_launch("lpm_split_weight_tiles");
+}
+
+extern "C" int lpm_assign_gemm_tiles_fwd(const void* xr, const void* wt, int B, int T, int D, int K, float* logits, float* partial,
+                                         lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(xr && wt && logits && partial, LPM_ERR_BADARG, "lpm_assign_gemm_tiles_fwd: null pointer");
+    LPM_REQUIRE(B > 0 && lpm_assign_gemm_tiles_supported(T, D, K), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_assign_gemm_tiles_fwd: need D %% 32 == 0, K %% 32 == 0, K <= 512 (D=%d K=%d)", D, K);
+    const int MT = row_tiles_per_clip(T), DS = D / 16, NT = K / 32;
+    TileGemmArgs g{};
+    g.a = (const uint4*)xr; g.a_tile = (int64_t)DS * 128; g.a_step = 128; g.a_batch = (int64_t)MT * DS * 128; g.a_tiles = MT;
+    g.b = (const uint4*)wt; g.b_tile = 128; g.b_step = (int64_t)NT * 128; g.b_batch = 0; g.b_tiles = NT;
+    g.rb_per_batch = MT / 2; g.steps_per_split = DS; g.total_steps = DS;
+    g.out = logits; g.ldo = K; g.out_batch = (int64_t)T * K; g.out_split = 0;
+    g.rows_valid = T; g.cols_valid = K; g.accumulate = 0; g.stats = partial;
+    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd");
+}
+
+extern "C" int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T, int D, int K, float* dx, int64_t lddx,
+                                            lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dlr && wtt && dx, LPM_ERR_BADARG, "lpm_assign_gemm_tiles_bwd_dx: null pointer");
+    LPM_REQUIRE(B > 0 && lpm_assign_gemm_tiles_supported(T, D, K) && lddx >= D, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_assign_gemm_tiles_bwd_dx: need D %% 32 == 0, K %% 32 == 0, K <= 512 (D=%d K=%d)", D, K);
+    const int MT = row_tiles_per_clip(T), KS = K / 16, NT = D / 32;
+    TileGemmArgs g{};
+    g.a = (const uint4*)dlr; g.a_tile = (int64_t)KS * 128; g.a_step = 128; g.a_batch = (int64_t)MT * KS * 128; g.a_tiles = MT;
+    g.b = (const uint4*)wtt; g.b_tile = 128; g.b_step = (int64_t)NT * 128; g.b_batch = 0; g.b_tiles = NT;
+    g.rb_per_batch = MT / 2; g.steps_per_split = KS; g.total_steps = KS;
+    g.out = dx; g.ldo = lddx; g.out_batch = (int64_t)T * lddx; g.out_split = 0;
+    g.rows_valid = T; g.cols_valid = D; g.accumulate = 1; g.stats = nullptr;
+    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_bwd_dx");
+}
+
+extern "C" size_t lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(int B, int T, int D, int K) {
+    return (size_t)lpm::dw_splits(B, T, D, K) * D * K * sizeof(float);
+}
+
+extern "C" int lpm_assign_gemm_tiles_bwd_dw(const void* xt, const void* dlt, int B, int T, int D, int K, float* dW, void* workspace,
+                                            size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(xt && dlt && dW && workspace, LPM_ERR_BADARG, "lpm_assign_gemm_tiles_bwd_dw: null pointer");
+    LPM_REQUIRE(B > 0 && lpm_assign_gemm_tiles_supported(T, D, K), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_assign_gemm_tiles_bwd_dw: need D %% 32 == 0, K %% 32 == 0, K <= 512 (D=%d K=%d)", D, K);
+    LPM_REQUIRE(workspace_bytes >= lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(B, T, D, K), LPM_ERR_BADARG,
+                "lpm_assign_gemm_tiles_bwd_dw: workspace too small");
+    const int S = (T + 15) / 16, DT = D / 32, KT = K / 32;
+    const int Z = dw_splits(B, T, D, K), steps = B * S;
+    TileGemmArgs g{};
+    g.a = (const uint4*)xt; g.a_tile = 128; g.a_step = (int64_t)DT * 128; g.a_batch = 0; g.a_tiles = DT;
+    g.b = (const uint4*)dlt; g.b_tile = 128; g.b_step = (int64_t)KT * 128; g.b_batch = 0; g.b_tiles = KT;
+    g.rb_per_batch = (D + 63) / 64; g.steps_per_split = (steps + Z - 1) / Z; g.total_steps = steps;
+    g.out = Z > 1 ? (float*)workspace : dW; g.ldo = K; g.out_batch = 0; g.out_split = (int64_t)D * K;
+    g.rows_valid = D; g.cols_valid = K; g.accumulate = 0; g.stats = nullptr;
+    const int Zeff = (steps + g.steps_per_split - 1) / g.steps_per_split;     // every launched split has >= 1 step
+    const int rc = tg_launch<TG_EPI_STORE>(g, 1, Zeff, (hipStream_t)stream, "lpm_assign_gemm_tiles_bwd_dw");
+    if (rc != LPM_OK || Z == 1) return rc;
+    const int64_t n4 = (int64_t)D * K / 4;
+    hipLaunchKernelGGL(tg_reduce_splits_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)workspace, Zeff, n4, (float4*)dW);
+    return check_launch("lpm_assign_gemm_tiles_bwd_dw");
+}

@@ -16,7 +16,7 @@
 // GEMMs share one pass over dU, which is formed on the fly from dO and N while staging 32-row d-chunks
 // into LDS (dU never reaches HBM), v_mfma_f32_32x32x2_f32 accumulation, the softmax backward is done
 // on the workgroup's 32 x K tile in LDS; (4) dW2 as a clip-loop per (d,k) float4.
-#include "lpm_common.h"
+#include "tile_gemm.h"
 
 namespace lpm {
 
@@ -346,6 +346,126 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
     reinterpret_cast<float4*>(dW2)[i] = acc;
 }
 
+// ---- split-bf16 tile form of the main step (VLAD_PRECISION bf16x3) --------------------------------------------------
+// dU = u dO - v N is formed ONCE per clip and written as B-operand fragment tiles in both orientations; the two GEMMs
+// of the backward then run on the bf16 pipe through the tile GEMM (tile_gemm.h):
+//   dA[t,k] = sum_d x[t,d] dU[d,k]      A = row tiles of x,            B = ub1[b][d-step][k-tile]   + softmax backward epilogue
+//   dx[t,d] = sum_k a[t,k] dU[d,k]      A = row tiles of the assignment, B = ub2[b][k-step][d-tile]  (+ dl . W^T as a second
+//                                       reduction segment when the caller chains the assignment GEMM's backward)
+// grid (D/32, B): one workgroup stages a [32 d][K] chunk of dU in LDS and emits both tile forms from it.
+__global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __restrict__ dO, const float* __restrict__ N,
+                                                                const float* __restrict__ ug, const float* __restrict__ vg,
+                                                                int D, int K, uint4* __restrict__ ub1, uint4* __restrict__ ub2) {
+    extern __shared__ float dus[];           // [32][K+1], then u[K], v[K]
+    const int KS = K + 1;
+    float* cu = dus + 32 * KS;
+    float* cv = cu + K;
+    const int tid = threadIdx.x, b = blockIdx.y, d0 = blockIdx.x * 32;
+    for (int k = tid; k < K; k += 256) {
+        cu[k] = ug[(int64_t)b * K + k];
+        cv[k] = vg[(int64_t)b * K + k];
+    }
+    __syncthreads();
+    const int K4 = K / 4;
+    const float* ob = dO + ((int64_t)b * D + d0) * K;
+    const float* nb = N + ((int64_t)b * D + d0) * K;
+    for (int i = tid; i < 32 * K4; i += 256) {
+        const int r = i / K4, k = (i % K4) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(ob + (int64_t)r * K + k);
+        const float4 n = *reinterpret_cast<const float4*>(nb + (int64_t)r * K + k);
+        float* dst = dus + r * KS + k;
+        dst[0] = cu[k + 0] * a.x - cv[k + 0] * n.x;
+        dst[1] = cu[k + 1] * a.y - cv[k + 1] * n.y;
+        dst[2] = cu[k + 2] * a.z - cv[k + 2] * n.z;
+        dst[3] = cu[k + 3] * a.w - cv[k + 3] * n.w;
+    }
+    __syncthreads();
+    const int KT = K / 32, DS = D / 16, KS16 = K / 16, DT = D / 32;
+    for (int it = tid; it < 2 * KT * 64; it += 256) {            // reduction over d, columns k
+        const int lane = it & 63, kt = (it >> 6) % KT, dsl = (it >> 6) / KT;
+        const int k = kt * 32 + (lane & 31), dl = dsl * 16 + 8 * (lane >> 5);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = dus[(dl + e) * KS + k];
+        uint4 hi, lo;
+        tg_split8(v, hi, lo);
+        const int64_t base = ((((int64_t)b * DS + d0 / 16 + dsl) * KT + kt) * 2) * 64 + lane;
+        ub1[base] = hi;
+        ub1[base + 64] = lo;
+    }
+    for (int it = tid; it < KS16 * 64; it += 256) {              // reduction over k, columns d
+        const int lane = it & 63, ks = it >> 6;
+        const int dl = lane & 31, k = ks * 16 + 8 * (lane >> 5);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = dus[dl * KS + k + e];
+        uint4 hi, lo;
+        tg_split8(v, hi, lo);
+        const int64_t base = ((((int64_t)b * KS16 + ks) * DT + d0 / 32) * 2) * 64 + lane;
+        ub2[base] = hi;
+        ub2[base + 64] = lo;
+    }
+}
+
+// assignment (softmax recomputed from the logits, or the similarities themselves) -> row tiles [b][mt][ks][plane][lane].
+// grid (MT, B), one workgroup per 32-frame row tile; K <= 512.
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256) void vlad_bwd_assign_rows_kernel(const float* __restrict__ assign, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, int T, int K, int MT,
+                                                                   uint4* __restrict__ ar) {
+    extern __shared__ float as[];            // [32][K+1]
+    const int KS = K + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = blockIdx.x, b = blockIdx.y;
+    for (int i = tid; i < 32 * KS; i += 256) as[i] = 0.f;
+    __syncthreads();
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, t = mt * 32 + row;
+        if (t >= T) continue;                // wave-uniform
+        const float* arow = assign + ((int64_t)b * T + t) * K;
+        if (SOFTMAX) {
+            float v[8];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = lane + 64 * j;
+                v[j] = (c < K) ? fmaf(arow[c], scale ? scale[c] : 1.f, shift ? shift[c] : 0.f) : -INFINITY;
+                m = fmaxf(m, v[j]);
+            }
+            m = wave_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = __expf(v[j] - m);
+                sum += v[j];
+            }
+            sum = wave_sum(sum);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = lane + 64 * j;
+                if (c < K) as[row * KS + c] = v[j] * inv;
+            }
+        } else {
+            for (int c = lane; c < K; c += 64) as[row * KS + c] = arow[c];
+        }
+    }
+    __syncthreads();
+    const int KS16 = K / 16;
+    for (int it = tid; it < KS16 * 64; it += 256) {
+        const int ln = it & 63, ks = it >> 6;
+        const int row = ln & 31, k = ks * 16 + 8 * (ln >> 5);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = as[row * KS + k + e];
+        uint4 hi, lo;
+        tg_split8(v, hi, lo);
+        const int64_t base = ((((int64_t)b * MT + mt) * KS16 + ks) * 2) * 64 + ln;
+        ar[base] = hi;
+        ar[base + 64] = lo;
+    }
+}
+
 static size_t bwd_main_lds_bytes(int K) {
     const int KS = (K + 31) / 32 * 32 + 1;
     return (size_t)(2 * 32 * KS + 32 * 33 + 4 * 32 * 33 + 3 * K) * sizeof(float);
@@ -415,4 +535,129 @@ extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const
                            B, D, K, dcentres);
     }
     return check_launch("lpm_vlad_aggregate_bwd");
+}
+
+// ---- tile form: workspace = [dots | u | v | ctil | d-major dout copy | ub1 | ub2 | ar] ------------------------------
+namespace lpm {
+struct BwdTilesLayout {
+    size_t dots, u, v, ctil, dod, ub1, ub2, ar, total;     // byte offsets
+    int MT;
+};
+static BwdTilesLayout bwd_tiles_layout(int B, int T, int D, int K) {
+    BwdTilesLayout L;
+    size_t o = 0;
+    L.dots = o; o += (size_t)B * VB_DSPLIT * 3 * K * 4;
+    L.u = o; o += (size_t)B * K * 4;
+    L.v = o; o += (size_t)B * K * 4;
+    L.ctil = o; o += (size_t)B * K * 4;
+    o = (o + 255) / 256 * 256;
+    L.dod = o; o += (size_t)B * D * K * 4;
+    L.ub1 = o; o += (size_t)B * D * K * 4;             // D/16 steps x K/32 tiles x 2 KB = 4 bytes per element
+    L.ub2 = o; o += (size_t)B * D * K * 4;
+    L.MT = 2 * ((T + 63) / 64);
+    L.ar = o; o += (size_t)B * L.MT * (K / 16) * 2048;
+    L.total = o;
+    return L;
+}
+}  // namespace lpm
+
+extern "C" size_t lpm_vlad_bwd_tiles_workspace_bytes(int B, int T, int D, int K) { return lpm::bwd_tiles_layout(B, T, D, K).total; }
+
+extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm, const float* asum, const float* colsq,
+                                            const float* csq, const float* gsq, const float* assign, const float* scale,
+                                            const float* shift, const void* xr, const float* centres, int B, int T, int D,
+                                            int K, int flags, float* dassign, float* dcentres, void* workspace,
+                                            size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dout && nrm && asum && colsq && csq && gsq && assign && xr && dassign && workspace, LPM_ERR_BADARG,
+                "lpm_vlad_aggregate_bwd_tiles: null pointer");
+    const bool residual = (flags & LPM_VLAD_RESIDUAL) != 0;
+    const bool sm = (flags & LPM_VLAD_SOFTMAX) != 0;
+    LPM_REQUIRE(!residual || (centres && dcentres), LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd_tiles: RESIDUAL needs centres/dcentres");
+    LPM_REQUIRE(B > 0 && T > 0 && D > 0 && D % 32 == 0 && K > 0 && K % 32 == 0 && K <= 512, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_bwd_tiles: need D %% 32 == 0, K %% 32 == 0, K <= 512 (D=%d K=%d)", D, K);
+    const BwdTilesLayout L = bwd_tiles_layout(B, T, D, K);
+    LPM_REQUIRE(workspace_bytes >= L.total, LPM_ERR_WORKSPACE, "lpm_vlad_aggregate_bwd_tiles: workspace too small");
+    LPM_REQUIRE((((uintptr_t)xr | (uintptr_t)dout | (uintptr_t)nrm | (uintptr_t)workspace) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_vlad_aggregate_bwd_tiles: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* dots = (float*)(ws + L.dots);
+    float* u = (float*)(ws + L.u);
+    float* v = (float*)(ws + L.v);
+    float* ctil = (float*)(ws + L.ctil);
+    float* dod = (float*)(ws + L.dod);
+    uint4* ub1 = (uint4*)(ws + L.ub1);
+    uint4* ub2 = (uint4*)(ws + L.ub2);
+    uint4* ar = (uint4*)(ws + L.ar);
+    const float* dO = dout;
+    if (flags & LPM_VLAD_OUT_KMAJOR) {
+        hipLaunchKernelGGL(vlad_kmajor_to_dmajor_kernel, dim3(D / 32, (K + 31) / 32, B), dim3(256), 0, s, dout, D, K, dod);
+        dO = dod;
+    }
+    hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr, D, K, dots);
+    hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil);
+    {
+        const size_t lds = (size_t)(32 * (K + 1) + 2 * K) * sizeof(float);
+        auto kern = vlad_bwd_du_tiles_kernel;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("lpm_vlad_aggregate_bwd_tiles: cannot reserve %zu bytes of LDS", lds);
+            return LPM_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(256), lds, s, dO, nrm, u, v, D, K, ub1, ub2);
+    }
+    {
+        const size_t lds = (size_t)32 * (K + 1) * sizeof(float);
+        if (sm) {
+            auto kern = vlad_bwd_assign_rows_kernel<true>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(L.MT, B), dim3(256), lds, s, assign, scale, shift, T, K, L.MT, ar);
+        } else {
+            auto kern = vlad_bwd_assign_rows_kernel<false>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(L.MT, B), dim3(256), lds, s, assign, scale, shift, T, K, L.MT, ar);
+        }
+    }
+    const int DS = D / 16, KT = K / 32;
+    TileGemmArgs g{};
+    g.a = (const uint4*)xr; g.a_tile = (int64_t)DS * 128; g.a_step = 128; g.a_batch = (int64_t)L.MT * DS * 128; g.a_tiles = L.MT;
+    g.b = ub1; g.b_tile = 128; g.b_step = (int64_t)KT * 128; g.b_batch = (int64_t)DS * KT * 128; g.b_tiles = KT;
+    g.rb_per_batch = L.MT / 2; g.steps_per_split = DS; g.total_steps = DS;
+    g.out = dassign; g.rows_valid = T; g.cols_valid = K;
+    g.logits = assign; g.scale = scale; g.shift = shift; g.ctil = ctil; g.softmax = sm ? 1 : 0;
+    const int rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles");
+    if (rc != LPM_OK) return rc;
+    if (residual) {
+        const int64_t n4 = (int64_t)D * K / 4;
+        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dO, nrm, asum, u, v, B, D, K,
+                           dcentres);
+    }
+    return check_launch("lpm_vlad_aggregate_bwd_tiles");
+}
+
+extern "C" int lpm_vlad_aggregate_bwd_tiles_dx(const void* workspace, size_t workspace_bytes, const void* dlr, const void* wtt, int B,
+                                               int T, int D, int K, float* dx, int64_t lddx, int accumulate_dx,
+                                               lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(workspace && dx, LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd_tiles_dx: null pointer");
+    LPM_REQUIRE((dlr == nullptr) == (wtt == nullptr), LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd_tiles_dx: dlr and wtt go together");
+    LPM_REQUIRE(B > 0 && T > 0 && D > 0 && D % 32 == 0 && K > 0 && K % 32 == 0 && K <= 512 && lddx >= D, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_bwd_tiles_dx: need D %% 32 == 0, K %% 32 == 0, K <= 512 (D=%d K=%d)", D, K);
+    const BwdTilesLayout L = bwd_tiles_layout(B, T, D, K);
+    LPM_REQUIRE(workspace_bytes >= L.total, LPM_ERR_WORKSPACE, "lpm_vlad_aggregate_bwd_tiles_dx: workspace too small");
+    const char* ws = (const char*)workspace;
+    const int KS16 = K / 16, DT = D / 32;
+    TileGemmArgs g{};
+    g.a = (const uint4*)(ws + L.ar); g.a_tile = (int64_t)KS16 * 128; g.a_step = 128; g.a_batch = (int64_t)L.MT * KS16 * 128;
+    g.a_tiles = L.MT;
+    g.b = (const uint4*)(ws + L.ub2); g.b_tile = 128; g.b_step = (int64_t)DT * 128; g.b_batch = (int64_t)KS16 * DT * 128; g.b_tiles = DT;
+    g.rb_per_batch = L.MT / 2; g.steps_per_split = KS16; g.total_steps = KS16;
+    if (dlr) {
+        g.a2 = (const uint4*)dlr; g.a2_tile = g.a_tile; g.a2_step = 128; g.a2_batch = g.a_batch;
+        g.b2 = (const uint4*)wtt; g.b2_tile = 128; g.b2_step = (int64_t)DT * 128; g.b2_batch = 0; g.b2_tiles = DT;
+        g.steps2 = KS16;
+    }
+    g.out = dx; g.ldo = lddx; g.out_batch = (int64_t)T * lddx; g.rows_valid = T; g.cols_valid = D; g.accumulate = accumulate_dx ? 1 : 0;
+    return tile_gemm_store(g, B, 1, (hipStream_t)stream, "lpm_vlad_aggregate_bwd_tiles_dx");
 }

@@ -26,6 +26,10 @@ VLAD_PRECISION = os.environ.get("LPM_VLAD_PRECISION", "bf16x3")
 # 128); otherwise / when off, the register-streaming form (vlad_tiles.hip).
 VLAD_TILES3 = os.environ.get("LPM_VLAD_TILES3", "1") != "0"
 
+# Matrix-core arithmetic of the soft-assignment GEMM K1: "bf16x3" (split-bf16 tiles on the bf16 pipe, default where
+# D %% 16 == 0 and K <= 512) or "f32" (exact fp32 MFMA).
+ASSIGN_PRECISION = os.environ.get("LPM_ASSIGN_PRECISION", "bf16x3")
+
 # Split-bf16 tile copies of the most recent frame_sample_bn output (produced by the same kernel that writes the fp32
 # frames): {"base": weakref to y, "F": F, "Dv": .., "video": tensor, "audio": tensor|None}.  ops.netvlad / vlad_aggregate
 # look a column-slice view of y up here instead of re-reading it through lpm_split_frames.
@@ -176,6 +180,8 @@ def _cached_tiles(x, B, T, D):
 
 
 def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor):
+    """-> out, nrm, asum, colsq, csq, gsq, xt (the split-bf16 frame tiles of x, or None on the fp32 path)."""
+    xt = None
     nrm = _empty((B, D, K), x)
     asum, colsq, csq = (_empty((B, K), x) for _ in range(3))
     if VLAD_PRECISION == "bf16x3":
@@ -199,7 +205,7 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
             gsq = _empty((B,), x)
             lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, LPM_VLAD_OUT_KMAJOR if kmajor else 0,
                                                   ptr(out), ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_finalize2_fwd")
-            return out, nrm, asum, colsq, csq, gsq
+            return out, nrm, asum, colsq, csq, gsq, xt
         with _timed("vlad_aggregate_fwd", (B, T, D, K)):
             lib.check(lib._lpm_vlad_aggregate_tiles_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
                                                         ptr(colsq), ptr(csq), st), "lpm_vlad_aggregate_tiles_fwd")
@@ -214,7 +220,7 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
     gsq = _empty((B,), x)
     lib.check(lib._lpm_vlad_finalize_fwd(ptr(nrm), ptr(csq), B, D, K, LPM_VLAD_OUT_KMAJOR if kmajor else 0, ptr(out),
                                          ptr(gsq), stream_ptr()), "lpm_vlad_finalize_fwd")
-    return out, nrm, asum, colsq, csq, gsq
+    return out, nrm, asum, colsq, csq, gsq, xt
 
 
 def _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor):
@@ -231,6 +237,70 @@ def _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, shift, 
     return dassign, dx, dcentres
 
 
+def _tile_buffer(nbytes, like):
+    return torch.empty(nbytes // 4, dtype=torch.int32, device=like.device)
+
+
+def _bwd_tiles_ok(lib, T, D, K):
+    """K3 on the bf16 pipe (tile form) is available for this shape and arithmetic."""
+    return VLAD_PRECISION == "bf16x3" and bool(lib._lpm_assign_gemm_tiles_supported(T, D, K))
+
+
+def _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, shift, x, xr, centres, B, T, D, K, flags, kmajor):
+    """First half of K3's tile form: -> dassign, dcentres, (workspace, bytes) for _aggregate_bwd_tiles_dx."""
+    st = stream_ptr()
+    if xr is None:
+        xr = _tile_buffer(lib._lpm_row_tiles_bytes(B, T, D), x)
+        lib.check(lib._lpm_split_rows_tiles(ptr(x), x.stride(0), B, T, D, ptr(xr), st), "lpm_split_rows_tiles")
+    dassign = _empty((B * T, K), x)
+    dcentres = _empty((D, K), x) if centres is not None else None
+    wsb = lib._lpm_vlad_bwd_tiles_workspace_bytes(B, T, D, K)
+    ws = _tile_buffer(wsb, x)
+    fl = flags | (LPM_VLAD_OUT_KMAJOR if kmajor else 0)
+    with _timed("vlad_aggregate_bwd", (B, T, D, K)):
+        lib.check(lib._lpm_vlad_aggregate_bwd_tiles(ptr(dout), ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(assign),
+                                                    ptr(scale), ptr(shift), ptr(xr), ptr(centres), B, T, D, K, fl, ptr(dassign),
+                                                    ptr(dcentres), ptr(ws), wsb, st), "lpm_vlad_aggregate_bwd_tiles")
+    return dassign, dcentres, (ws, wsb)
+
+
+def _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, like, B, T, D, K):
+    """Second half: dx = sum_k a dU (+ dl . W^T when the assignment GEMM's tiles are given)."""
+    ws, wsb = wspace
+    dx = _empty((B * T, D), like)
+    with _timed("vlad_aggregate_bwd_dx", (B, T, D, K)):
+        lib.check(lib._lpm_vlad_aggregate_bwd_tiles_dx(ptr(ws), wsb, ptr(dlr), ptr(wtt), B, T, D, K, ptr(dx), D, 0, stream_ptr()),
+                  "lpm_vlad_aggregate_bwd_tiles_dx")
+    return dx
+
+
+def _assign_gemm_dw_tiles(lib, x, xt, dl, B, T, D, K):
+    """dW = x^T . dl on the bf16 pipe (frame tiles of both operands, reduction over every frame of every clip)."""
+    st = stream_ptr()
+    if xt is None:
+        xt = _tile_buffer(lib._lpm_xt_bytes(B, T, D), x)
+        lib.check(lib._lpm_split_frames(ptr(x), x.stride(0), B, T, D, ptr(xt), st), "lpm_split_frames")
+    dlt = _tile_buffer(lib._lpm_xt_bytes(B, T, K), x)
+    lib.check(lib._lpm_split_frames(ptr(dl), dl.stride(0), B, T, K, ptr(dlt), st), "lpm_split_frames")
+    dW = _empty((D, K), x)
+    wsb = lib._lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(B, T, D, K)
+    ws = _tile_buffer(max(wsb, 16), x)
+    with _timed("assign_gemm_bwd_dw", (B * T, D, K)):
+        lib.check(lib._lpm_assign_gemm_tiles_bwd_dw(ptr(xt), ptr(dlt), B, T, D, K, ptr(dW), ptr(ws), wsb, st),
+                  "lpm_assign_gemm_tiles_bwd_dw")
+    return dW
+
+
+def _assign_gemm_dx_operands(lib, W, dl, B, T, D, K):
+    """Row tiles of dl and weight tiles of W^T: the operands of dx += dl . W^T."""
+    st = stream_ptr()
+    dlr = _tile_buffer(lib._lpm_row_tiles_bytes(B, T, K), dl)
+    wtt = _tile_buffer(lib._lpm_weight_tiles_bytes(K, D), dl)
+    lib.check(lib._lpm_split_rows_tiles(ptr(dl), dl.stride(0), B, T, K, ptr(dlr), st), "lpm_split_rows_tiles")
+    lib.check(lib._lpm_split_weight_tiles(ptr(W), K, D, 1, ptr(wtt), st), "lpm_split_weight_tiles")
+    return dlr, wtt
+
+
 class _NetVLAD(torch.autograd.Function):
     """x [B*T, D] -> pooled descriptor.  cluster_weights [D,K]; cluster_bn (gamma, beta, moving) or
     cluster_biases; cluster_weights2 [1,D,K] (None = LightVLAD).  frame_level_models.py:2773-2824."""
@@ -245,12 +315,29 @@ class _NetVLAD(torch.autograd.Function):
         if M % T:
             raise LpmError(f"rows {M} not divisible by max_frames {T}")
         B = M // T
-        nblk = lib._lpm_assign_gemm_nblk(M)
         logits = _empty((M, K), x)
-        partial = _empty((nblk, 2, K), x)
-        with _timed("assign_gemm_fwd", (M, D, K)):
-            lib.check(lib._lpm_assign_gemm_fwd(ptr(x), x.stride(0), ptr(W), M, D, K, 0, ptr(logits), ptr(partial),
-                                               stream_ptr()), "lpm_assign_gemm_fwd")
+        if ASSIGN_PRECISION not in ("bf16x3", "f32"):
+            raise LpmError(f"unknown LPM_ASSIGN_PRECISION {ASSIGN_PRECISION!r} (bf16x3 | f32)")
+        tiles = ASSIGN_PRECISION == "bf16x3" and bool(lib._lpm_assign_gemm_tiles_supported(T, D, K))
+        xr = None
+        if tiles:
+            st = stream_ptr()
+            nblk = lib._lpm_assign_gemm_tiles_nblk(B, T)
+            partial = _empty((nblk, 2, K), x)
+            xr = _tile_buffer(lib._lpm_row_tiles_bytes(B, T, D), x)
+            wt = _tile_buffer(lib._lpm_weight_tiles_bytes(D, K), x)
+            with _timed("split_rows_tiles", (M, D)):
+                lib.check(lib._lpm_split_rows_tiles(ptr(x), x.stride(0), B, T, D, ptr(xr), st), "lpm_split_rows_tiles")
+            lib.check(lib._lpm_split_weight_tiles(ptr(W), D, K, 0, ptr(wt), st), "lpm_split_weight_tiles")
+            with _timed("assign_gemm_fwd", (M, D, K)):
+                lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st),
+                          "lpm_assign_gemm_tiles_fwd")
+        else:
+            nblk = lib._lpm_assign_gemm_nblk(M)
+            partial = _empty((nblk, 2, K), x)
+            with _timed("assign_gemm_fwd", (M, D, K)):
+                lib.check(lib._lpm_assign_gemm_fwd(ptr(x), x.stride(0), ptr(W), M, D, K, 0, ptr(logits), ptr(partial),
+                                                   stream_ptr()), "lpm_assign_gemm_fwd")
         mean = var = None
         use_bn = gamma is not None
         if use_bn:
@@ -264,19 +351,25 @@ class _NetVLAD(torch.autograd.Function):
             scale, shift = None, bias.contiguous()
         flags = LPM_VLAD_SOFTMAX | (LPM_VLAD_RESIDUAL if W2 is not None else 0)
         centres = W2.reshape(D, K).contiguous() if W2 is not None else None
-        out, nrm, asum, colsq, csq, gsq = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor)
-        ctx.dims = (B, T, D, K, flags, kmajor, use_bn, is_training, W2 is not None)
-        ctx.save_for_backward(x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq)
+        out, nrm, asum, colsq, csq, gsq, xt = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor)
+        ctx.dims = (B, T, D, K, flags, kmajor, use_bn, is_training, W2 is not None, tiles)
+        ctx.save_for_backward(x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _capi.load()
-        B, T, D, K, flags, kmajor, use_bn, is_training, has_w2 = ctx.dims
-        x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq = ctx.saved_tensors
+        B, T, D, K, flags, kmajor, use_bn, is_training, has_w2, tiles = ctx.dims
+        x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr = ctx.saved_tensors
         dout = _f32(dout, "dout").contiguous()
-        dlt, dx, dcentres = _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, centres, B, T, D,
-                                           K, flags, kmajor)
+        k3_tiles = _bwd_tiles_ok(lib, T, D, K)
+        if k3_tiles:
+            dlt, dcentres, wspace = _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, xr,
+                                                         centres, B, T, D, K, flags, kmajor)
+            dx = None
+        else:
+            dlt, dx, dcentres = _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, centres, B, T, D,
+                                               K, flags, kmajor)
         M = B * T
         dgamma = dbeta = dbias = None
         if use_bn and is_training:
@@ -293,9 +386,22 @@ class _NetVLAD(torch.autograd.Function):
         else:
             dbias = dlt.sum(0)
             dl = dlt
-        # assignment-GEMM backward: plain library GEMMs (hipBLASLt through torch)
-        dW = x.t().matmul(dl)
-        dx.addmm_(dl, W.t())
+        # backward of the soft-assignment GEMM; with K3 in tile form its dx term rides in K3's dx pass
+        dlr = wtt = None
+        if tiles:
+            dW = _assign_gemm_dw_tiles(lib, x, xt, dl, B, T, D, K)
+            dlr, wtt = _assign_gemm_dx_operands(lib, W, dl, B, T, D, K)
+        else:   # plain fp32 library GEMM (hipBLASLt through torch)
+            dW = x.t().matmul(dl)
+        if k3_tiles:
+            dx = _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, x, B, T, D, K)
+            if not tiles:
+                dx.addmm_(dl, W.t())
+        elif tiles:
+            lib.check(lib._lpm_assign_gemm_tiles_bwd_dx(ptr(dlr), ptr(wtt), B, T, D, K, ptr(dx), dx.stride(0), stream_ptr()),
+                      "lpm_assign_gemm_tiles_bwd_dx")
+        else:
+            dx.addmm_(dl, W.t())
         dW2 = dcentres.reshape(1, D, K) if has_w2 else None
         return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None
 
@@ -320,7 +426,7 @@ class _VladAggregate(torch.autograd.Function):
         sims2 = _f32(sims, "cluster_similarities").reshape(M, K).contiguous()
         centres = _f32(centres, "cluster_centers").contiguous()
         flags = LPM_VLAD_RESIDUAL
-        out, nrm, asum, colsq, csq, gsq = _aggregate_fwd(lib, sims2, None, None, x, centres, B, T, D, K, flags, kmajor)
+        out, nrm, asum, colsq, csq, gsq, _ = _aggregate_fwd(lib, sims2, None, None, x, centres, B, T, D, K, flags, kmajor)
         ctx.dims = (B, T, D, K, flags, kmajor, sims.shape)
         ctx.save_for_backward(sims2, x, centres, nrm, asum, colsq, csq, gsq)
         return out
@@ -330,8 +436,13 @@ class _VladAggregate(torch.autograd.Function):
         lib = _capi.load()
         B, T, D, K, flags, kmajor, sshape = ctx.dims
         sims2, x, centres, nrm, asum, colsq, csq, gsq = ctx.saved_tensors
-        dsims, dx, dcentres = _aggregate_bwd(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x, centres,
-                                             B, T, D, K, flags, kmajor)
+        if _bwd_tiles_ok(lib, T, D, K):
+            dsims, dcentres, wspace = _aggregate_bwd_tiles(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x,
+                                                           None, centres, B, T, D, K, flags, kmajor)
+            dx = _aggregate_bwd_tiles_dx(lib, wspace, None, None, x, B, T, D, K)
+        else:
+            dsims, dx, dcentres = _aggregate_bwd(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x, centres,
+                                                 B, T, D, K, flags, kmajor)
         return dsims.reshape(sshape), dx, dcentres, None, None
 
 

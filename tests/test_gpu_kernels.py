@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["bf16x3", "f32"])
 def vlad_precision(request):
-    """Both matrix-core arithmetics of K2: split-bf16 (default) and exact fp32."""
+    """Both matrix-core arithmetics of K1 / K2: split-bf16 (default) and exact fp32."""
     from learnablepoolingmethods_amd import ops
-    old = ops.VLAD_PRECISION
-    ops.VLAD_PRECISION = request.param
+    old = ops.VLAD_PRECISION, ops.ASSIGN_PRECISION
+    ops.VLAD_PRECISION = ops.ASSIGN_PRECISION = request.param
     yield request.param
-    ops.VLAD_PRECISION = old
+    ops.VLAD_PRECISION, ops.ASSIGN_PRECISION = old
 
 
 def _netvlad_inputs(B, T, D, K, ld=None, seed=0, dev=None):
@@ -127,6 +127,57 @@ def test_lightvlad_and_bias_mode(vlad_precision):
     outb.backward(dout.to(dev))
     assert_close(xg2.grad, xd.grad, what="bias-mode dx")
     assert_close(bgp.grad, pb["s/cluster_biases"].grad, what="dbias")
+
+
+@pytest.mark.parametrize("B,T,D,K,ld,off", [(3, 30, 1024, 32, 1024, 0), (2, 300, 128, 64, 1152, 1024), (20, 300, 1024, 256, 1152, 0),
+                                              (1, 77, 256, 512, 256, 0), (1, 1, 32, 32, 32, 0), (5, 129, 1024, 288, 1024, 0)])
+def test_assign_gemm_tiles(B, T, D, K, ld, off):
+    """K1 and its backward on the bf16 pipe through the C ABI (frame_level_models.py:2781-2789 and TF autodiff of it):
+    logits + per-workgroup column statistics, dx += dl . W^T, dW = x^T . dl.  Ragged frame counts (zero-padded tail
+    tiles), strided inputs, K below / across / at the column-block limits."""
+    from learnablepoolingmethods_amd import _capi
+    from learnablepoolingmethods_amd._capi import ptr, stream_ptr
+    lib = _capi.load()
+    dev = cuda()
+    M = B * T
+    g = torch.Generator().manual_seed(M + K)
+    full = torch.randn(M, ld, generator=g).to(dev)
+    W = (torch.randn(D, K, generator=g) / D ** 0.5).to(dev)
+    dl = torch.randn(M, K, generator=g).to(dev)
+    dx0 = torch.randn(M, D, generator=g).to(dev)
+    x = full[:, off:off + D]
+    assert lib._lpm_assign_gemm_tiles_supported(T, D, K)
+
+    def buf(n):
+        return torch.empty(n // 4, dtype=torch.int32, device=dev)
+    st = stream_ptr()
+    xr, wt = buf(lib._lpm_row_tiles_bytes(B, T, D)), buf(lib._lpm_weight_tiles_bytes(D, K))
+    nblk = lib._lpm_assign_gemm_tiles_nblk(B, T)
+    logits = torch.full((M, K), float("nan"), device=dev)
+    partial = torch.full((nblk, 2, K), float("nan"), device=dev)
+    lib.check(lib._lpm_split_rows_tiles(ptr(x), x.stride(0), B, T, D, ptr(xr), st), "split_rows_tiles")
+    lib.check(lib._lpm_split_weight_tiles(ptr(W), D, K, 0, ptr(wt), st), "split_weight_tiles")
+    lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st), "assign_gemm_tiles_fwd")
+    x64, W64, dl64 = x.double().cpu(), W.double().cpu(), dl.double().cpu()
+    ref = x64 @ W64
+    assert_close(logits, ref, 2e-5, "logits")
+    assert_close(partial[:, 0].sum(0), ref.sum(0), 1e-4, "column sums", floor=1e-3 * float(ref.abs().sum(0).max()))
+    assert_close(partial[:, 1].sum(0), (ref * ref).sum(0), 1e-4, "column square sums")
+    # backward
+    dlr, wtt = buf(lib._lpm_row_tiles_bytes(B, T, K)), buf(lib._lpm_weight_tiles_bytes(K, D))
+    lib.check(lib._lpm_split_rows_tiles(ptr(dl), K, B, T, K, ptr(dlr), st), "split_rows_tiles")
+    lib.check(lib._lpm_split_weight_tiles(ptr(W), K, D, 1, ptr(wtt), st), "split_weight_tiles")
+    dx = dx0.clone()
+    lib.check(lib._lpm_assign_gemm_tiles_bwd_dx(ptr(dlr), ptr(wtt), B, T, D, K, ptr(dx), D, st), "assign_gemm_tiles_bwd_dx")
+    assert_close(dx, dx0.double().cpu() + dl64 @ W64.t(), 2e-5, "dx")
+    xt, dlt = buf(lib._lpm_xt_bytes(B, T, D)), buf(lib._lpm_xt_bytes(B, T, K))
+    lib.check(lib._lpm_split_frames(ptr(x), x.stride(0), B, T, D, ptr(xt), st), "split_frames")
+    lib.check(lib._lpm_split_frames(ptr(dl), K, B, T, K, ptr(dlt), st), "split_frames")
+    wsb = lib._lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(B, T, D, K)
+    ws = buf(max(wsb, 4))
+    dW = torch.full((D, K), float("nan"), device=dev)
+    lib.check(lib._lpm_assign_gemm_tiles_bwd_dw(ptr(xt), ptr(dlt), B, T, D, K, ptr(dW), ptr(ws), wsb, st), "assign_gemm_tiles_bwd_dw")
+    assert_close(dW, x64.t() @ dl64, 2e-5, "dW")
 
 
 @pytest.mark.parametrize("B,T,D,K", [(2, 30, 128, 16), (2, 300, 1024, 256), (3, 17, 256, 64)])
