@@ -118,6 +118,9 @@ int lpm_assign_gemm_tiles_fwd(const void* xr, const void* wt, int B, int T, int 
                               lpm_stream_t stream);
 int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T, int D, int K, float* dx, int64_t lddx,
                                  lpm_stream_t stream);
+/* dw[N1,N2] = x^T . dy for a skinny batch R (multiple of 16): xt / dyt = weight tiles of x [R,N1] and dy [R,N2]
+ * (lpm_split_weight_tiles, not transposed).  The hidden1 weight gradient (frame_level_models.py:2314-2319 backward). */
+int lpm_skinny_weight_grad_tiles(const void* xt, const void* dyt, int R, int N1, int N2, float* dw, lpm_stream_t stream);
 size_t lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(int B, int T, int D, int K);
 int lpm_assign_gemm_tiles_bwd_dw(const void* xt, const void* dlt, int B, int T, int D, int K, float* dw, void* workspace,
                                  size_t workspace_bytes, lpm_stream_t stream);

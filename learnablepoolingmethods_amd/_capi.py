@@ -45,6 +45,7 @@ SIGNATURES = {
     "lpm_split_weight_tiles": (_i, [_f, _i, _i, _i, _f, _f]),
     "lpm_assign_gemm_tiles_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f]),
     "lpm_assign_gemm_tiles_bwd_dx": (_i, [_f, _f, _i, _i, _i, _i, _f, _l, _f]),
+    "lpm_skinny_weight_grad_tiles": (_i, [_f, _f, _i, _i, _i, _f, _f]),
     "lpm_assign_gemm_tiles_bwd_dw_workspace_bytes": (_s, [_i, _i, _i, _i]),
     "lpm_assign_gemm_tiles_bwd_dw": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _s, _f]),
     "lpm_vlad_aggregate_fwd": (_i, [_f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),

@@ -73,7 +73,7 @@ struct TileGemmArgs {
 
 // Launchers (defined in tile_gemm.hip, the only translation unit that instantiates the kernel).  nbatch * rb_per_batch
 // workgroup rows, ceil(cols / (128 NTW)) column blocks, `splits` reduction splits.
-int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what);
+int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw = 0);   // ntw 0 = by column count
 int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what);
 int tile_gemm_ntw(int cols);
 

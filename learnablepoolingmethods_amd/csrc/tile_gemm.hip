@@ -105,32 +105,54 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g)
 
     const int N = g.cols_valid;
     if (EPI == TG_EPI_STORE) {
+        // column statistics from the registers; the tile itself goes through LDS (the ring is free) so that every global
+        // access is a 16-byte piece of a contiguous row segment: 32 rows x 128*NTW columns per pass
+        constexpr int ESTR = 128 * NTW + 4;
+        constexpr int C4 = 32 * NTW;
+        float* es = reinterpret_cast<float*>(smem);
         float* ob = g.out + batch * g.out_batch + split * g.out_split;
+        if (g.stats) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const int col = (cb * NTB + wave * NTW + n) * 32 + l31;
-            float cs = 0.f, cq = 0.f;
+            for (int n = 0; n < NTW; ++n) {
+                const int col = (cb * NTB + wave * NTW + n) * 32 + l31;
+                float cs = 0.f, cq = 0.f;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rb * 64 + m * 32 + mfma32_row(r, lane);
-                    const float v = acc[m][n][r];
-                    if (row < g.rows_valid && col < N) {
-                        float* p = ob + (int64_t)row * g.ldo + col;
-                        *p = g.accumulate ? (*p + v) : v;
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[m][n][r];
+                        cs += v;               // statistics callers pad with zero row tiles: rows >= rows_valid add nothing
+                        cq = fmaf(v, v, cq);
                     }
-                    cs += v;                   // statistics callers pad with zero row tiles: rows >= rows_valid add nothing
-                    cq = fmaf(v, v, cq);
-                }
-            }
-            if (g.stats) {
                 cs += __shfl_xor(cs, 32, 64);
                 cq += __shfl_xor(cq, 32, 64);
                 if (lane < 32 && col < N) {
                     float* p = g.stats + (int64_t)lid * 2 * N;
                     p[col] = cs;
                     p[N + col] = cq;
+                }
+            }
+        }
+        __syncthreads();                       // nothing in flight (the last step waited for vmcnt(0)): the ring is free
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (m) __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) es[mfma32_row(r, lane) * ESTR + (wave * NTW + n) * 32 + l31] = acc[m][n][r];
+            __syncthreads();
+            for (int i = tid; i < 32 * C4; i += 256) {
+                const int row = i / C4, c4 = (i % C4) * 4;
+                const int grow = rb * 64 + m * 32 + row, gcol = cb * NTB * 32 + c4;
+                if (grow < g.rows_valid && gcol < N) {
+                    float4 v = *reinterpret_cast<const float4*>(es + row * ESTR + c4);
+                    float4* p = reinterpret_cast<float4*>(ob + (int64_t)grow * g.ldo + gcol);
+                    if (g.accumulate) {
+                        const float4 o = *p;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *p = v;
                 }
             }
         }
@@ -206,8 +228,13 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g)
 int tg_ntw(int cols) { const int nt = (cols + 31) / 32; return nt <= 4 ? 1 : (nt <= 8 ? 2 : (nt <= 16 ? 4 : 2)); }
 
 template <int EPI>
-static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what) {
-    const int ntw = tg_ntw(g.cols_valid);
+static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override = 0) {
+    if (EPI == TG_EPI_STORE && (g.cols_valid % 4 != 0 || g.ldo % 4 != 0 || g.out_batch % 4 != 0 || g.out_split % 4 != 0 ||
+                                ((uintptr_t)g.out & 15) != 0)) {
+        set_error("%s: the output needs 16-byte aligned rows (columns and leading dimension multiples of 4)", what);
+        return LPM_ERR_BADARG;
+    }
+    const int ntw = ntw_override ? ntw_override : tg_ntw(g.cols_valid);
     const int nt = (g.cols_valid + 31) / 32;
     dim3 grid((unsigned)(nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)), (unsigned)splits);
     const size_t lds = tg_lds_bytes(ntw, EPI);
@@ -229,8 +256,8 @@ static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t 
 }
 
 
-int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what) {
-    return tg_launch<TG_EPI_STORE>(g, nbatch, splits, stream, what);
+int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw) {
+    return tg_launch<TG_EPI_STORE>(g, nbatch, splits, stream, what, ntw);
 }
 int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what) {
     return tg_launch<TG_EPI_SOFTMAX_BWD>(g, nbatch, 1, stream, what);
@@ -401,4 +428,24 @@ extern "C" int lpm_assign_gemm_tiles_bwd_dw(const void* xt, const void* dlt, int
     hipLaunchKernelGGL(tg_reduce_splits_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)workspace, Zeff, n4, (float4*)dW);
     return check_launch("lpm_assign_gemm_tiles_bwd_dw");
+}
+
+// dW[N1, N2] = X^T . DY for a skinny batch: X [R, N1], DY [R, N2] fp32, R (the batch, a multiple of 16) is the whole
+// reduction.  Both operands are weight tiles (lpm_split_weight_tiles of X and DY, not transposed): xt [R/16][N1/32],
+// dyt [R/16][N2/32].  The hidden1 weight gradient of the NetVLAD models (frame_level_models.py:2314-2319 backward) at
+// cfg-2 is N1 = 270336, N2 = 512, R = 80: write-bound (554 MB), written once, straight into the caller's buffer.
+extern "C" int lpm_skinny_weight_grad_tiles(const void* xt, const void* dyt, int R, int N1, int N2, float* dW, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(xt && dyt && dW, LPM_ERR_BADARG, "lpm_skinny_weight_grad_tiles: null pointer");
+    LPM_REQUIRE(R > 0 && R % 16 == 0 && N1 > 0 && N2 > 0 && N2 % 32 == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_skinny_weight_grad_tiles: need R %% 16 == 0 and N2 %% 32 == 0 (R=%d N2=%d)", R, N2);
+    const int NT1 = (N1 + 31) / 32, NT2 = N2 / 32;
+    TileGemmArgs g{};
+    g.a = (const uint4*)xt; g.a_tile = 128; g.a_step = (int64_t)NT1 * 128; g.a_batch = 0; g.a_tiles = NT1;
+    g.b = (const uint4*)dyt; g.b_tile = 128; g.b_step = (int64_t)NT2 * 128; g.b_batch = 0; g.b_tiles = NT2;
+    g.rb_per_batch = (N1 + 63) / 64; g.steps_per_split = R / 16; g.total_steps = R / 16;
+    g.out = dW; g.ldo = N2; g.rows_valid = N1; g.cols_valid = N2;
+    // 5 reduction steps and a 554 MB store: narrow column blocks (36 KB of LDS, 4 workgroups per CU) so that one workgroup's
+    // store overlaps its neighbours' loads (measured at cfg-2: 145 us with 128-column blocks, 215 us with 512)
+    return tile_gemm_store(g, 1, 1, (hipStream_t)stream, "lpm_skinny_weight_grad_tiles", 1);
 }

@@ -564,11 +564,30 @@ def ffn_x3(y2d, W1, b1, W2):
 # ----------------------------------------------------------------------------------------------
 # a9: VLAD -> hidden projection (frame_level_models.py:2314-2319): [B, 270336] x [270336, H], weight-stream bound
 # ----------------------------------------------------------------------------------------------
+def skinny_weight_grad(x, dy, out=None):
+    """dW [N1,N2] = x^T dy for a skinny batch (x [R,N1], dy [R,N2], R %% 16 == 0, N2 %% 32 == 0) on the bf16 pipe with
+    split-bf16 operands: one pass, written straight into ``out``."""
+    lib = _capi.load()
+    R, N1 = x.shape
+    N2 = dy.shape[1]
+    st = stream_ptr()
+    xt = _tile_buffer(lib._lpm_weight_tiles_bytes(R, N1), x)
+    dyt = _tile_buffer(lib._lpm_weight_tiles_bytes(R, N2), x)
+    lib.check(lib._lpm_split_weight_tiles(ptr(x), R, N1, 0, ptr(xt), st), "lpm_split_weight_tiles")
+    lib.check(lib._lpm_split_weight_tiles(ptr(dy), R, N2, 0, ptr(dyt), st), "lpm_split_weight_tiles")
+    if out is None:
+        out = _empty((N1, N2), x)
+    with _timed("skinny_weight_grad", (R, N1, N2)):
+        lib.check(lib._lpm_skinny_weight_grad_tiles(ptr(xt), ptr(dyt), R, N1, N2, ptr(out), st), "lpm_skinny_weight_grad_tiles")
+    return out
+
+
 class _Projection(torch.autograd.Function):
     """Plain library GEMMs, arranged for a skinny-M / huge-K problem: the forward is split-K (a batched GEMM over
     K-slices + a tiny reduction: 0.21 ms instead of 0.77 ms for the one-shot GEMM hipBLASLt picks at M = 80), and the
     weight gradient (554 MB at cfg-2, 85 % of all gradient bytes) is written straight into the trainer's gradient
-    arena when the weight carries ``_lpm_grad_view`` -- no autograd accumulate pass over it."""
+    arena when the weight carries ``_lpm_grad_view`` -- autograd never sees it (``_lpm_grad_ready`` is called instead
+    of a post-accumulate hook)."""
 
     @staticmethod
     def forward(ctx, x, W):
@@ -585,14 +604,25 @@ class _Projection(torch.autograd.Function):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dy.matmul(W.t()) if ctx.needs_input_grad[0] else None
-        dW = None
-        if ctx.needs_input_grad[1]:
-            view = getattr(W, "_lpm_grad_view", None)
-            if view is not None and W.grad is None:
-                dW = torch.mm(x.t(), dy, out=view)      # AccumulateGrad adopts this tensor: the arena IS the gradient
-            else:
-                dW = x.t().matmul(dy)
-        return dx, dW
+        if not ctx.needs_input_grad[1]:
+            return dx, None
+        skinny = x.shape[0] % 16 == 0 and dy.shape[1] % 32 == 0 and x.is_contiguous()
+        view = getattr(W, "_lpm_grad_view", None)
+        if view is None:
+            return dx, (skinny_weight_grad(x, dy) if skinny else x.t().matmul(dy))
+        # The trainer owns this gradient's storage (a slice of the flat gradient arena): write it there and hand autograd
+        # nothing -- returning the tensor would make AccumulateGrad copy all 554 MB of it into a fresh .grad.
+        if getattr(W, "_lpm_grad_written", False):          # second use of the weight in one step: accumulate
+            view += skinny_weight_grad(x, dy) if skinny else x.t().matmul(dy)
+        elif skinny:
+            skinny_weight_grad(x, dy, out=view)             # bf16 pipe, split-bf16 operands, one 554 MB pass
+        else:
+            torch.mm(x.t(), dy, out=view)
+        W._lpm_grad_written = True
+        ready = getattr(W, "_lpm_grad_ready", None)
+        if ready is not None:
+            ready()                                         # e.g. start this bucket's all-reduce under the rest of backward
+        return dx, None
 
 
 def projection(x, W):

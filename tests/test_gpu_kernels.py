@@ -424,3 +424,27 @@ def test_ffn_split_bf16_fused_bias_relu():
     # and the flips must be isolated: all but a few rows of dy agree to 1e-4 of the tensor scale
     err = (yg.grad.double().cpu() - yd.grad).abs().amax(dim=1) / yd.grad.abs().max()
     assert int((err > 1e-4).sum()) <= 20, f"{int((err > 1e-4).sum())} of {M} dy rows differ: not ReLU-flip noise"
+
+
+@pytest.mark.parametrize("B,KV,H", [(80, 33792, 512), (16, 4224, 64), (6, 2048, 96)])
+def test_projection_skinny_gemms(B, KV, H):
+    """VLAD -> hidden1 projection (frame_level_models.py:2314-2319): split-K forward, dx, and the weight gradient written
+    by the tile GEMM straight into a caller-owned buffer (the trainer's gradient arena).  B = 6 takes the library path."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn(B, KV, generator=g).to(dev).requires_grad_(True)
+    W = (torch.randn(KV, H, generator=g) / KV ** 0.5).to(dev).requires_grad_(True)
+    dy = torch.randn(B, H, generator=g).to(dev)
+    view = torch.full((KV, H), float("nan"), device=dev)
+    W._lpm_grad_view = view
+    y = ops.projection(x, W)
+    y.backward(dy)
+    x64, W64, dy64 = x.detach().double().cpu(), W.detach().double().cpu(), dy.double().cpu()
+    assert_close(y, x64 @ W64, 2e-5, "y")
+    assert_close(x.grad, dy64 @ W64.t(), 2e-5, "dx")
+    assert_close(view, x64.t() @ dy64, 2e-5, "dW")
+    assert W.grad is None and W._lpm_grad_written, "the weight gradient lives in the caller's buffer only"
+    del W._lpm_grad_view                       # without a caller-owned buffer the gradient goes through autograd
+    ops.projection(x, W).backward(dy)
+    assert_close(W.grad, x64.t() @ dy64, 2e-5, "dW (autograd path)")
