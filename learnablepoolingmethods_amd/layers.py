@@ -77,6 +77,21 @@ def dense_variables(name: str, fan_in: int, units: int, use_bias: bool, device):
     return kernel, bias
 
 
+def qkv_projections(queries: torch.Tensor, keys: torch.Tensor, units: int):
+    """The bias-free q / k / v projections of an attention block (transformer_utils.py:559-561).  Self-attention on the
+    split-bf16 path runs them as one fused GEMM (ops.qkv_x3); variable names and values are those of three tf.layers.dense."""
+    rows = queries.numel() // queries.shape[-1]
+    if queries is keys and use_split_gemm(queries, rows, units):
+        wq, _ = dense_variables("q", queries.shape[-1], units, False, queries.device)
+        wk, _ = dense_variables("k", queries.shape[-1], units, False, queries.device)
+        wv, _ = dense_variables("v", queries.shape[-1], units, False, queries.device)
+        q, k, v = ops.qkv_x3(queries.reshape(rows, queries.shape[-1]), wq, wk, wv)
+        shape = (*queries.shape[:-1], units)
+        return q.view(shape), k.view(shape), v.view(shape)
+    return (dense(queries, units, use_bias=False, name="q"), dense(keys, units, use_bias=False, name="k"),
+            dense(keys, units, use_bias=False, name="v"))
+
+
 def dense(x: torch.Tensor, units: int, use_bias: bool, name: str, activation=None) -> torch.Tensor:
     """tf.layers.dense: contracts the last axis; glorot-uniform kernel, zero bias."""
     kernel, bias = dense_variables(name, x.shape[-1], units, use_bias, x.device)

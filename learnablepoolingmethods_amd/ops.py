@@ -507,6 +507,46 @@ def dense_x3(x2d, W):
     return _DenseX3.apply(x2d, W)
 
 
+class _QKVX3(torch.autograd.Function):
+    """q, k, v = x Wq, x Wk, x Wv of a self-attention block as ONE split-bf16 library GEMM against [Wq|Wk|Wv]: the input is
+    split once, the GEMM has 3x the columns (1024-column GEMMs fill the chip badly: 0.70 vs 1.2 PFLOP/s executed), and in
+    the backward dx comes out of a single GEMM over the concatenated reduction instead of three GEMMs + two adds.
+    q, k, v are returned as column views of one [M, 3N] buffer (the attention kernels take a row stride)."""
+
+    @staticmethod
+    def forward(ctx, x2d, Wq, Wk, Wv):
+        x2d = _rows(x2d, "dense input")
+        K, N = Wq.shape
+        Wcat = torch.cat([_f32(Wq, "q kernel"), _f32(Wk, "k kernel"), _f32(Wv, "v kernel")], dim=1)
+        x3 = _split_rows(x2d)
+        w3, w3t = _split_weight(Wcat, need_t=ctx.needs_input_grad[0])
+        ctx.save_for_backward(x3, w3t)
+        ctx.dims = (K, N)
+        qkv = torch.mm(x3, w3, out_dtype=torch.float32)
+        return qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x3, w3t = ctx.saved_tensors
+        K, N = ctx.dims
+        M = x3.shape[0]
+        esz = dq.element_size()
+        adjacent = (dq.stride() == (3 * N, 1) and dk.stride() == (3 * N, 1) and dv.stride() == (3 * N, 1)
+                    and dk.data_ptr() == dq.data_ptr() + N * esz and dv.data_ptr() == dq.data_ptr() + 2 * N * esz)
+        if adjacent:      # the attention backward wrote all three into one buffer
+            dqkv = torch.as_strided(dq, (M, 3 * N), (3 * N, 1))
+        else:
+            dqkv = torch.cat([dq, dk, dv], dim=1)
+        dy3 = _split_rows(dqkv)
+        dx = torch.mm(dy3, w3t, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dW = _dw_x3(x3, dy3, K, 3 * N)
+        return dx, dW[:, :N], dW[:, N:2 * N], dW[:, 2 * N:]
+
+
+def qkv_x3(x2d, Wq, Wk, Wv):
+    return _QKVX3.apply(x2d, Wq, Wk, Wv)
+
+
 def _dw_x3(x3, dy3, K, N):
     """dW = x^T dy from the split images (three small-output bf16 GEMMs, fp32 accumulation)."""
     xh, xl = x3[:, :K], x3[:, K:2 * K]
@@ -687,13 +727,33 @@ def _mha_dims(q, num_heads):
     return B, L, F // num_heads
 
 
+def _qkv_operands(q, k, v):
+    """q, k, v as the kernels take them: [B, L, h*d] with unit column stride and ONE common row stride (column views of a
+    fused [B, L, 3*h*d] projection qualify); anything else is made contiguous."""
+    q, k, v = (_f32(t, "qkv") for t in (q, k, v))
+
+    def ok(t):
+        return t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 4 == 0 \
+            and t.data_ptr() % 16 == 0
+    if ok(q) and ok(k) and ok(v) and q.stride(1) == k.stride(1) == v.stride(1):
+        return q, k, v
+    return q.contiguous(), k.contiguous(), v.contiguous()
+
+
+def _dqkv_buffers(q):
+    """dq, dk, dv as column views of one [B, L, 3*h*d] buffer (what ops._QKVX3.backward consumes without a copy)."""
+    B, L, F = q.shape
+    buf = torch.empty((B, L, 3 * F), dtype=torch.float32, device=q.device)
+    return buf[..., :F], buf[..., F:2 * F], buf[..., 2 * F:]
+
+
 class _MHACore(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, num_heads, scale):
         lib = _capi.load()
-        q, k, v = (_f32(t, "qkv").contiguous() for t in (q, k, v))
+        q, k, v = _qkv_operands(q, k, v)
         B, L, d = _mha_dims(q, num_heads)
-        o = torch.empty_like(q)
+        o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
         lse = _empty((B, num_heads, L), q)
         lib.check(lib._lpm_mha_fwd(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, None, None, ptr(o),
                                    o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
@@ -707,7 +767,7 @@ class _MHACore(torch.autograd.Function):
         B, L, h, d, scale = ctx.dims
         q, k, v, o, lse = ctx.saved_tensors
         do = do.contiguous()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        dq, dk, dv = _dqkv_buffers(q)
         lib.check(lib._lpm_mha_bwd(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d,
                                    scale, None, None, ptr(dq), ptr(dk), ptr(dv), dq.stride(1), None, None, None, stream_ptr()),
                   "lpm_mha_bwd")
@@ -726,7 +786,7 @@ class _MHACoreBN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, gamma, beta, moving_mean, moving_var, num_heads, is_training):
         lib = _capi.load()
-        q, k, v = (_f32(t, "qkv").contiguous() for t in (q, k, v))
+        q, k, v = _qkv_operands(q, k, v)
         B, L, d = _mha_dims(q, num_heads)
         h = num_heads
         if is_training:
@@ -738,7 +798,7 @@ class _MHACoreBN(torch.autograd.Function):
             kscale, kshift = folded_eval_affine(gamma, beta, moving_mean, moving_var)
             kscale, kshift = kscale.contiguous(), kshift.contiguous()
             mean, var = moving_mean.detach().clone(), moving_var.detach().clone()
-        o = torch.empty_like(q)
+        o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
         lse = _empty((B, h, L), q)
         lib.check(lib._lpm_mha_fwd(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, h, d, 1.0, ptr(kscale), ptr(kshift), ptr(o),
                                    o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
@@ -771,7 +831,7 @@ class _MHACoreBN(torch.autograd.Function):
             corr_a = (ks * (c1 - mean.double() * rstd * c2)).float().contiguous()
         else:
             corr_a = corr_b = None
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        dq, dk, dv = _dqkv_buffers(q)
         lib.check(lib._lpm_mha_bwd(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
                                    ptr(kscale), ptr(kshift), ptr(dq), ptr(dk), ptr(dv), dq.stride(1), ptr(corr_a), ptr(corr_b),
                                    None, st), "lpm_mha_bwd")

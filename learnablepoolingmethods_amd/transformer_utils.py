@@ -19,9 +19,7 @@ class MultiHeadAttention(modules.BaseModule):
         self.is_train = is_train
 
     def forward(self, queries, keys):
-        q = layers.dense(queries, self.hidden_size, use_bias=False, name="q")      # :559
-        k = layers.dense(keys, self.hidden_size, use_bias=False, name="k")         # :560
-        v = layers.dense(keys, self.hidden_size, use_bias=False, name="v")         # :561
+        q, k, v = layers.qkv_projections(queries, keys, self.hidden_size)          # :559-561
         depth = self.hidden_size // self.num_heads
         # split_heads, q *= depth**-0.5, softmax(q k^T) v, combine_heads (:564-581): one kernel
         attention_output = ops.mha_core(q, k, v, self.num_heads, depth ** -0.5)
@@ -39,9 +37,7 @@ class MultiHeadAttentionBN(modules.BaseModule):
         self.is_train = is_train
 
     def forward(self, queries, keys):
-        q = layers.dense(queries, self.hidden_size, use_bias=False, name="q")
-        k = layers.dense(keys, self.hidden_size, use_bias=False, name="k")
-        v = layers.dense(keys, self.hidden_size, use_bias=False, name="v")
+        q, k, v = layers.qkv_projections(queries, keys, self.hidden_size)
         L = keys.shape[1]
         gamma, beta, mm, mv = layers.bn_variables("logits_bn", L, q.device)        # channel = key position :652-658
         attention_output = ops.mha_core_bn(q, k, v, self.num_heads, gamma, beta, mm, mv, self.is_train)

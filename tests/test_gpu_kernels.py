@@ -448,3 +448,31 @@ def test_projection_skinny_gemms(B, KV, H):
     del W._lpm_grad_view                       # without a caller-owned buffer the gradient goes through autograd
     ops.projection(x, W).backward(dy)
     assert_close(W.grad, x64.t() @ dy64, 2e-5, "dW (autograd path)")
+
+
+def test_fused_qkv_projection_through_attention():
+    """q, k, v projections as one split-bf16 GEMM (transformer_utils.py:559-561) feeding the attention kernel through
+    column views, and the backward consuming dq|dk|dv from one buffer: against fp64 autograd of the unfused maths."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, L, F, h = 5, 256, 128, 8
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B * L, F, generator=g)
+    Ws = [torch.randn(F, F, generator=g) / F ** 0.5 for _ in range(3)]
+    do = torch.randn(B, L, F, generator=g)
+    xg = x.to(dev).requires_grad_(True)
+    Wg = [w.to(dev).requires_grad_(True) for w in Ws]
+    q, k, v = ops.qkv_x3(xg, *Wg)
+    assert q.data_ptr() + 4 * F == k.data_ptr(), "q, k, v must be column views of one buffer"
+    o = ops.mha_core(q.view(B, L, F), k.view(B, L, F), v.view(B, L, F), h, (F // h) ** -0.5)
+    o.backward(do.to(dev))
+    x64 = x.double().requires_grad_(True)
+    W64 = [w.double().requires_grad_(True) for w in Ws]
+    q64, k64, v64 = ((x64 @ w).view(B, L, h, F // h).transpose(1, 2) for w in W64)
+    p = torch.softmax(q64 @ k64.transpose(-1, -2) * (F // h) ** -0.5, dim=-1)
+    o64 = (p @ v64).transpose(1, 2).reshape(B, L, F)
+    o64.backward(do.double())
+    assert_close(o, o64, 1e-4, "attention output")
+    assert_close(xg.grad, x64.grad, 1e-4, "dx")
+    for name, a, b in zip("qkv", Wg, W64):
+        assert_close(a.grad, b.grad, 1e-4, f"dW{name}")
