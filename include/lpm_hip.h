@@ -221,10 +221,13 @@ int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const f
  * transformer_utils.py:559-561,583,701,708).  The GEMMs stay library GEMMs (hipBLASLt); these kernels produce the
  * operand format that runs them on the bf16 matrix pipe at fp32-grade accuracy:
  *   x W ~= xh Wh + xl Wh + xh Wl = [xh | xl | xh] . [Wh ; Wh ; Wl]   (one bf16 GEMM, fp32 accumulation)
- * lpm_split_rows:   x [M,K] fp32 (row stride ldx; optional fused relu(x + bias)) -> out3 [M,3K] bf16 = [hi|lo|hi]
- * lpm_split_weight: W [K,N] fp32 -> w3 [3K,N] bf16 = [Wh;Wh;Wl], w3t [3N,K] bf16 = [Wh^T;Wh^T;Wl^T] (w3t may be NULL)
+ * lpm_split_rows:   x [M,K] fp32 (row stride ldx; optional fused relu(x + bias)) -> out3 [M,3K] bf16, plane order
+ *                   [hi|lo|hi] (order 0: activations) or [hi|hi|lo] (order 1: gradients; what lpm_split_rows_relu_bwd emits)
+ * lpm_split_weight: W [K,N] fp32 -> w3 [3K,N] bf16 = [Wh;Wh;Wl], w3t [3N,K] bf16 = [Wh^T;Wl^T;Wh^T] (w3t may be NULL)
+ *   forward  y = X3 . w3;   dx = DY3 . w3t (DY3 in gradient order);   dW = X3[3M,K]^T . DY3[3M,N] -- the two plane orders
+ *   pair up row by row, so the weight gradient is ONE long-reduction GEMM over the [3M, .] views of the two images.
  * ------------------------------------------------------------------------------------------- */
-int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, void* out3,
+int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, int order, void* out3,
                    lpm_stream_t stream);
 int lpm_split_weight(const float* W, int K, int N, void* w3, void* w3t, lpm_stream_t stream);
 /* backward of the fused relu(x + bias) split (FeedForwardNetwork, transformer_utils.py:701-711): g = df * [act > 0]

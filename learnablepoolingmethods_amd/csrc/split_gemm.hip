@@ -5,8 +5,13 @@
 // parity bar: x = xh + xl, W = Wh + Wl (bf16 planes, 2^-17 residual) and
 //     x W  ~=  xh Wh + xl Wh + xh Wl  =  [xh | xl | xh] . [Wh ; Wh ; Wl]
 // i.e. ONE bf16 GEMM with a 3x longer reduction and fp32 accumulation inside the GEMM (no partial-sum passes).
-//   lpm_split_rows    x [M,K] fp32 (optionally relu(x + bias) fused)  -> X3 [M,3K] bf16 = [hi | lo | hi]
-//   lpm_split_weight  W [K,N] fp32 -> W3 [3K,N] = [Wh;Wh;Wl]  and  W3T [3N,K] = [Wh^T;Wh^T;Wl^T] (for dX = dY W^T)
+//   lpm_split_rows    x [M,K] fp32 (optionally relu(x + bias) fused)  -> X3 [M,3K] bf16 = [hi | lo | hi]   (activations)
+//                                                                      or  [hi | hi | lo]   (gradients, order = 1)
+//   lpm_split_weight  W [K,N] fp32 -> W3 [3K,N] = [Wh;Wh;Wl]  and  W3T [3N,K] = [Wh^T;Wl^T;Wh^T] (for dX = dY3 W3T)
+// The two plane orders pair up row by row: seen as [3M, K] and [3M, N] matrices (row 3m+p = plane p of row m), an
+// activation image and a gradient image give the weight gradient as ONE long-reduction GEMM
+//     dW = X3[3M,K]^T . DY3[3M,N] = xh^T dyh + xl^T dyh + xh^T dyl
+// (a 61440-deep reduction at cfg-2: hipBLASLt runs it at ~2x the rate of three separate 20480-deep GEMMs).
 #include "lpm_common.h"
 
 namespace lpm {
@@ -20,7 +25,7 @@ __device__ __forceinline__ float sg_bf16_f32(unsigned h) { return __uint_as_floa
 
 // one thread = 8 consecutive columns of one row
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int K,
-                                                         const float* __restrict__ bias, int relu,
+                                                         const float* __restrict__ bias, int relu, int order,
                                                          unsigned short* __restrict__ out3) {
     const int K8 = K / 8;
     const int64_t total = M * K8;
@@ -46,13 +51,14 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         const uint4 lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
         unsigned short* row = out3 + m * 3 * (int64_t)K;
         *reinterpret_cast<uint4*>(row + c) = hi;
-        *reinterpret_cast<uint4*>(row + K + c) = lo;
-        *reinterpret_cast<uint4*>(row + 2 * (int64_t)K + c) = hi;
+        *reinterpret_cast<uint4*>(row + K + c) = order ? hi : lo;
+        *reinterpret_cast<uint4*>(row + 2 * (int64_t)K + c) = order ? lo : hi;
     }
 }
 
 // Backward companion of the fused relu(x + bias) split: g = df * [act > 0] where `act3` is the [M,3K] split image of
-// the forward activation (its hi plane is > 0 exactly where the activation was), out3 = split(g), and per-block
+// the forward activation (its hi plane is > 0 exactly where the activation was), out3 = split(g) in the gradient plane
+// order [hi | hi | lo], and per-block
 // column partial sums of g (the bias gradient) -> colpart [gridDim.x][K].  One workgroup = SR_ROWS rows, all columns.
 constexpr int SR_ROWS = 32;
 __global__ __launch_bounds__(256) void split_rows_relu_bwd_kernel(const float* __restrict__ df, int64_t M, int K,
@@ -82,10 +88,10 @@ __global__ __launch_bounds__(256) void split_rows_relu_bwd_kernel(const float* _
             }
             const uint4 hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             const uint4 lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-            unsigned short* row = out3 + m * 3 * (int64_t)K;
+            unsigned short* row = out3 + m * 3 * (int64_t)K;     // gradient plane order [hi | hi | lo]
             *reinterpret_cast<uint4*>(row + c) = hi;
-            *reinterpret_cast<uint4*>(row + K + c) = lo;
-            *reinterpret_cast<uint4*>(row + 2 * (int64_t)K + c) = hi;
+            *reinterpret_cast<uint4*>(row + K + c) = hi;
+            *reinterpret_cast<uint4*>(row + 2 * (int64_t)K + c) = lo;
         }
         float* cp = colpart + (int64_t)blockIdx.x * K + c;
         *reinterpret_cast<float4*>(cp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -140,8 +146,8 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
             if (k < K && n < N) {
                 const unsigned short h = th[tx][ty + 8 * i], l = tl[tx][ty + 8 * i];
                 w3t[(int64_t)n * K + k] = h;
-                w3t[((int64_t)N + n) * K + k] = h;
-                w3t[(2 * (int64_t)N + n) * K + k] = l;
+                w3t[((int64_t)N + n) * K + k] = l;
+                w3t[(2 * (int64_t)N + n) * K + k] = h;
             }
         }
     }
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
 
 }  // namespace lpm
 
-extern "C" int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, void* out3,
+extern "C" int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, int order, void* out3,
                               lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(x && out3, LPM_ERR_BADARG, "lpm_split_rows: null pointer");
@@ -159,7 +165,7 @@ extern "C" int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, con
     const int64_t total = M * (K / 8);
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       M, K, bias, relu, (unsigned short*)out3);
+                       M, K, bias, relu, order ? 1 : 0, (unsigned short*)out3);
     return check_launch("lpm_split_rows");
 }
 

@@ -453,18 +453,19 @@ def vlad_aggregate(sims, x, centres, max_frames, kmajor=False):
 # ----------------------------------------------------------------------------------------------
 # dense layers of the encoders on the bf16 matrix pipe at fp32-grade accuracy (split-bf16 operands)
 # ----------------------------------------------------------------------------------------------
-def _split_rows(x2d, bias=None, relu=False):
-    """[M,K] fp32 -> [M,3K] bf16 = [hi | lo | hi] (optionally of relu(x + bias))."""
+def _split_rows(x2d, bias=None, relu=False, grad=False):
+    """[M,K] fp32 -> [M,3K] bf16 = [hi | lo | hi] (optionally of relu(x + bias)); grad=True: the gradient plane order
+    [hi | hi | lo] that pairs with w3t = [Wh^T; Wl^T; Wh^T] and, row by row, with an activation image (see _dw_x3)."""
     lib = _capi.load()
     M, K = x2d.shape
     out = torch.empty((M, 3 * K), dtype=torch.bfloat16, device=x2d.device)
-    lib.check(lib._lpm_split_rows(ptr(x2d), x2d.stride(0), M, K, ptr(bias), 1 if relu else 0, ptr(out), stream_ptr()),
-              "lpm_split_rows")
+    lib.check(lib._lpm_split_rows(ptr(x2d), x2d.stride(0), M, K, ptr(bias), 1 if relu else 0, 1 if grad else 0, ptr(out),
+                                  stream_ptr()), "lpm_split_rows")
     return out
 
 
 def _split_weight(W, need_t=True):
-    """[K,N] fp32 -> W3 [3K,N] = [Wh;Wh;Wl] and W3T [3N,K] = [Wh^T;Wh^T;Wl^T] (bf16)."""
+    """[K,N] fp32 -> W3 [3K,N] = [Wh;Wh;Wl] and W3T [3N,K] = [Wh^T;Wl^T;Wh^T] (bf16)."""
     lib = _capi.load()
     K, N = W.shape
     w3 = torch.empty((3 * K, N), dtype=torch.bfloat16, device=W.device)
@@ -491,15 +492,9 @@ class _DenseX3(torch.autograd.Function):
     def backward(ctx, dy):
         x3, w3t = ctx.saved_tensors
         K, N = ctx.dims
-        dy3 = _split_rows(dy.contiguous())
+        dy3 = _split_rows(dy.contiguous(), grad=True)
         dx = torch.mm(dy3, w3t, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dW = None
-        if ctx.needs_input_grad[1]:
-            xh, xl = x3[:, :K], x3[:, K:2 * K]
-            dyh, dyl = dy3[:, :N], dy3[:, N:2 * N]
-            dW = torch.mm(xh.t(), dyh, out_dtype=torch.float32)
-            dW += torch.mm(xl.t(), dyh, out_dtype=torch.float32)
-            dW += torch.mm(xh.t(), dyl, out_dtype=torch.float32)
+        dW = _dw_x3(x3, dy3, K, N) if ctx.needs_input_grad[1] else None
         return dx, dW
 
 
@@ -537,7 +532,7 @@ class _QKVX3(torch.autograd.Function):
             dqkv = torch.as_strided(dq, (M, 3 * N), (3 * N, 1))
         else:
             dqkv = torch.cat([dq, dk, dv], dim=1)
-        dy3 = _split_rows(dqkv)
+        dy3 = _split_rows(dqkv, grad=True)
         dx = torch.mm(dy3, w3t, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
         dW = _dw_x3(x3, dy3, K, 3 * N)
         return dx, dW[:, :N], dW[:, N:2 * N], dW[:, 2 * N:]
@@ -548,13 +543,11 @@ def qkv_x3(x2d, Wq, Wk, Wv):
 
 
 def _dw_x3(x3, dy3, K, N):
-    """dW = x^T dy from the split images (three small-output bf16 GEMMs, fp32 accumulation)."""
-    xh, xl = x3[:, :K], x3[:, K:2 * K]
-    dyh, dyl = dy3[:, :N], dy3[:, N:2 * N]
-    dW = torch.mm(xh.t(), dyh, out_dtype=torch.float32)
-    dW += torch.mm(xl.t(), dyh, out_dtype=torch.float32)
-    dW += torch.mm(xh.t(), dyl, out_dtype=torch.float32)
-    return dW
+    """dW = x^T dy from an activation image x3 [M,3K] = [hi|lo|hi] and a gradient image dy3 [M,3N] = [hi|hi|lo]: seen as
+    [3M,K] and [3M,N] their rows pair up plane by plane, so dW = xh^T dyh + xl^T dyh + xh^T dyl is ONE bf16 GEMM with a
+    3M-deep reduction and fp32 accumulation."""
+    M = x3.shape[0]
+    return torch.mm(x3.view(3 * M, K).t(), dy3.view(3 * M, N), out_dtype=torch.float32)
 
 
 class _FFNX3(torch.autograd.Function):
@@ -582,7 +575,7 @@ class _FFNX3(torch.autograd.Function):
         y3, f3, w13t, w23t = ctx.saved_tensors
         F, H, N = ctx.dims
         M = y3.shape[0]
-        do3 = _split_rows(dout.contiguous())
+        do3 = _split_rows(dout.contiguous(), grad=True)
         df = torch.mm(do3, w23t, out_dtype=torch.float32)                 # [M, H]
         dW2 = _dw_x3(f3, do3, H, N)
         dp3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=df.device)
