@@ -223,13 +223,15 @@ int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const f
  *   x W ~= xh Wh + xl Wh + xh Wl = [xh | xl | xh] . [Wh ; Wh ; Wl]   (one bf16 GEMM, fp32 accumulation)
  * lpm_split_rows:   x [M,K] fp32 (row stride ldx; optional fused relu(x + bias)) -> out3 [M,3K] bf16, plane order
  *                   [hi|lo|hi] (order 0: activations) or [hi|hi|lo] (order 1: gradients; what lpm_split_rows_relu_bwd emits)
- * lpm_split_weight: W [K,N] fp32 -> w3 [3K,N] bf16 = [Wh;Wh;Wl], w3t [3N,K] bf16 = [Wh^T;Wl^T;Wh^T] (w3t may be NULL)
- *   forward  y = X3 . w3;   dx = DY3 . w3t (DY3 in gradient order);   dW = X3[3M,K]^T . DY3[3M,N] -- the two plane orders
- *   pair up row by row, so the weight gradient is ONE long-reduction GEMM over the [3M, .] views of the two images.
+ * lpm_split_weight: W [K,N] fp32 -> w3n [N,3K] bf16, row n = [Wh[:,n] | Wh[:,n] | Wl[:,n]], and
+ *                                     w3k [K,3N] bf16, row k = [Wh[k,:] | Wl[k,:] | Wh[k,:]]  (w3k may be NULL)
+ *   forward  y = X3 . w3n^T;   dx = DY3 . w3k^T (DY3 in gradient order): "B stored transposed", the layout hipBLASLt runs
+ *   fastest;   dW = X3[3M,K]^T . DY3[3M,N] -- the two plane orders pair up row by row, so the weight gradient is a GEMM
+ *   over the [3M, .] views of the two images (split over the reduction as a batched GEMM by the host code).
  * ------------------------------------------------------------------------------------------- */
 int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, int order, void* out3,
                    lpm_stream_t stream);
-int lpm_split_weight(const float* W, int K, int N, void* w3, void* w3t, lpm_stream_t stream);
+int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w3k, lpm_stream_t stream);
 /* backward of the fused relu(x + bias) split (FeedForwardNetwork, transformer_utils.py:701-711): g = df * [act > 0]
  * (act3 = the forward's [M,3K] split image of the activation), out3 = split image of g, dbias [K] = column sums of g.
  * workspace: lpm_split_rows_relu_bwd_workspace_bytes(M, K). */

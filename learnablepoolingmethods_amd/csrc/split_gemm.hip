@@ -3,11 +3,12 @@
 // The dense GEMMs themselves are plain library GEMMs (hipBLASLt through torch.mm, as the brief prescribes); what
 // is hand-written here is the operand format that lets them run on the bf16 matrix pipe WITHOUT leaving the fp32
 // parity bar: x = xh + xl, W = Wh + Wl (bf16 planes, 2^-17 residual) and
-//     x W  ~=  xh Wh + xl Wh + xh Wl  =  [xh | xl | xh] . [Wh ; Wh ; Wl]
+//     x W  ~=  xh Wh + xl Wh + xh Wl  =  [xh | xl | xh] . [Wh ; Wh ; Wl]      (the weight image is stored transposed)
 // i.e. ONE bf16 GEMM with a 3x longer reduction and fp32 accumulation inside the GEMM (no partial-sum passes).
 //   lpm_split_rows    x [M,K] fp32 (optionally relu(x + bias) fused)  -> X3 [M,3K] bf16 = [hi | lo | hi]   (activations)
 //                                                                      or  [hi | hi | lo]   (gradients, order = 1)
-//   lpm_split_weight  W [K,N] fp32 -> W3 [3K,N] = [Wh;Wh;Wl]  and  W3T [3N,K] = [Wh^T;Wl^T;Wh^T] (for dX = dY3 W3T)
+//   lpm_split_weight  W [K,N] fp32 -> w3n [N,3K] (rows [Wh^T|Wh^T|Wl^T]: y = X3 w3n^T)  and
+//                                      w3k [K,3N] (rows [Wh|Wl|Wh]:       dx = DY3 w3k^T)
 // The two plane orders pair up row by row: seen as [3M, K] and [3M, N] matrices (row 3m+p = plane p of row m), an
 // activation image and a gradient image give the weight gradient as ONE long-reduction GEMM
 //     dW = X3[3M,K]^T . DY3[3M,N] = xh^T dyh + xl^T dyh + xh^T dyl
@@ -116,10 +117,13 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
     }
 }
 
-// grid (K/32, N/32); 32x32 tile through LDS for the transposed copy
+// grid (K/32, N/32); 32x32 tile through LDS for the transposed image.
+//   w3n [N, 3K]: row n = [Wh[:,n] | Wh[:,n] | Wl[:,n]]   (forward: y = X3 . w3n^T, X3 = [xh|xl|xh])
+//   w3k [K, 3N]: row k = [Wh[k,:] | Wl[k,:] | Wh[k,:]]   (input gradient: dx = DY3 . w3k^T, DY3 = [dyh|dyh|dyl])
+// Both are "B stored transposed" (NT) operands: hipBLASLt runs that layout 8-10 % faster than NN at these shapes.
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int K, int N,
-                                                           unsigned short* __restrict__ w3,
-                                                           unsigned short* __restrict__ w3t) {
+                                                           unsigned short* __restrict__ w3n,
+                                                           unsigned short* __restrict__ w3k) {
     __shared__ unsigned short th[32][33], tl[32][33];
     const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -131,24 +135,26 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
             const float v = W[(int64_t)k * N + n];
             h = sg_bf16_rne(v);
             l = sg_bf16_rne(v - sg_bf16_f32(h));
-            w3[(int64_t)k * N + n] = (unsigned short)h;
-            w3[((int64_t)K + k) * N + n] = (unsigned short)h;
-            w3[(2 * (int64_t)K + k) * N + n] = (unsigned short)l;
+            if (w3k) {
+                unsigned short* row = w3k + (int64_t)k * 3 * N;
+                row[n] = (unsigned short)h;
+                row[N + n] = (unsigned short)l;
+                row[2 * N + n] = (unsigned short)h;
+            }
         }
         th[ty + 8 * i][tx] = (unsigned short)h;
         tl[ty + 8 * i][tx] = (unsigned short)l;
     }
     __syncthreads();
-    if (w3t) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + ty + 8 * i, k = k0 + tx;
-            if (k < K && n < N) {
-                const unsigned short h = th[tx][ty + 8 * i], l = tl[tx][ty + 8 * i];
-                w3t[(int64_t)n * K + k] = h;
-                w3t[((int64_t)N + n) * K + k] = l;
-                w3t[(2 * (int64_t)N + n) * K + k] = h;
-            }
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, k = k0 + tx;
+        if (k < K && n < N) {
+            const unsigned short h = th[tx][ty + 8 * i], l = tl[tx][ty + 8 * i];
+            unsigned short* row = w3n + (int64_t)n * 3 * K;
+            row[k] = h;
+            row[K + k] = h;
+            row[2 * K + k] = l;
         }
     }
 }
@@ -188,11 +194,11 @@ extern "C" int lpm_split_rows_relu_bwd(const float* df, int64_t M, int K, const 
     return check_launch("lpm_split_rows_relu_bwd");
 }
 
-extern "C" int lpm_split_weight(const float* W, int K, int N, void* w3, void* w3t, lpm_stream_t stream) {
+extern "C" int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w3k, lpm_stream_t stream) {
     using namespace lpm;
-    LPM_REQUIRE(W && w3, LPM_ERR_BADARG, "lpm_split_weight: null pointer");
+    LPM_REQUIRE(W && w3n, LPM_ERR_BADARG, "lpm_split_weight: null pointer");
     LPM_REQUIRE(K > 0 && N > 0, LPM_ERR_BADARG, "lpm_split_weight: bad sizes");
     hipLaunchKernelGGL(split_weight_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, (hipStream_t)stream, W, K, N,
-                       (unsigned short*)w3, (unsigned short*)w3t);
+                       (unsigned short*)w3n, (unsigned short*)w3k);
     return check_launch("lpm_split_weight");
 }

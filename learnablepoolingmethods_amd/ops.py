@@ -455,7 +455,7 @@ def vlad_aggregate(sims, x, centres, max_frames, kmajor=False):
 # ----------------------------------------------------------------------------------------------
 def _split_rows(x2d, bias=None, relu=False, grad=False):
     """[M,K] fp32 -> [M,3K] bf16 = [hi | lo | hi] (optionally of relu(x + bias)); grad=True: the gradient plane order
-    [hi | hi | lo] that pairs with w3t = [Wh^T; Wl^T; Wh^T] and, row by row, with an activation image (see _dw_x3)."""
+    [hi | hi | lo] that pairs with w3k (rows [Wh|Wl|Wh]) and, row by row, with an activation image (see _dw_x3)."""
     lib = _capi.load()
     M, K = x2d.shape
     out = torch.empty((M, 3 * K), dtype=torch.bfloat16, device=x2d.device)
@@ -465,13 +465,18 @@ def _split_rows(x2d, bias=None, relu=False, grad=False):
 
 
 def _split_weight(W, need_t=True):
-    """[K,N] fp32 -> W3 [3K,N] = [Wh;Wh;Wl] and W3T [3N,K] = [Wh^T;Wl^T;Wh^T] (bf16)."""
+    """[K,N] fp32 -> w3n [N,3K] (rows [Wh^T|Wh^T|Wl^T]: y = X3 w3n^T) and w3k [K,3N] (rows [Wh|Wl|Wh]: dx = DY3 w3k^T), bf16."""
     lib = _capi.load()
     K, N = W.shape
-    w3 = torch.empty((3 * K, N), dtype=torch.bfloat16, device=W.device)
-    w3t = torch.empty((3 * N, K), dtype=torch.bfloat16, device=W.device) if need_t else None
-    lib.check(lib._lpm_split_weight(ptr(W), K, N, ptr(w3), ptr(w3t), stream_ptr()), "lpm_split_weight")
-    return w3, w3t
+    w3n = torch.empty((N, 3 * K), dtype=torch.bfloat16, device=W.device)
+    w3k = torch.empty((K, 3 * N), dtype=torch.bfloat16, device=W.device) if need_t else None
+    lib.check(lib._lpm_split_weight(ptr(W), K, N, ptr(w3n), ptr(w3k), stream_ptr()), "lpm_split_weight")
+    return w3n, w3k
+
+
+def _mm3(a3, w3):
+    """a3 [M,3K] . w3 [N,3K]^T with fp32 accumulation and output (the weight image is stored transposed)."""
+    return torch.mm(a3, w3.t(), out_dtype=torch.float32)
 
 
 class _DenseX3(torch.autograd.Function):
@@ -483,17 +488,17 @@ class _DenseX3(torch.autograd.Function):
         x2d = _rows(x2d, "dense input")
         W = _f32(W, "dense kernel").contiguous()
         x3 = _split_rows(x2d)
-        w3, w3t = _split_weight(W, need_t=ctx.needs_input_grad[0])
-        ctx.save_for_backward(x3, w3t)
+        w3n, w3k = _split_weight(W, need_t=ctx.needs_input_grad[0])
+        ctx.save_for_backward(x3, w3k)
         ctx.dims = (x2d.shape[1], W.shape[1])
-        return torch.mm(x3, w3, out_dtype=torch.float32)
+        return _mm3(x3, w3n)
 
     @staticmethod
     def backward(ctx, dy):
-        x3, w3t = ctx.saved_tensors
+        x3, w3k = ctx.saved_tensors
         K, N = ctx.dims
         dy3 = _split_rows(dy.contiguous(), grad=True)
-        dx = torch.mm(dy3, w3t, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dx = _mm3(dy3, w3k) if ctx.needs_input_grad[0] else None
         dW = _dw_x3(x3, dy3, K, N) if ctx.needs_input_grad[1] else None
         return dx, dW
 
@@ -514,15 +519,15 @@ class _QKVX3(torch.autograd.Function):
         K, N = Wq.shape
         Wcat = torch.cat([_f32(Wq, "q kernel"), _f32(Wk, "k kernel"), _f32(Wv, "v kernel")], dim=1)
         x3 = _split_rows(x2d)
-        w3, w3t = _split_weight(Wcat, need_t=ctx.needs_input_grad[0])
-        ctx.save_for_backward(x3, w3t)
+        w3n, w3k = _split_weight(Wcat, need_t=ctx.needs_input_grad[0])
+        ctx.save_for_backward(x3, w3k)
         ctx.dims = (K, N)
-        qkv = torch.mm(x3, w3, out_dtype=torch.float32)
+        qkv = _mm3(x3, w3n)
         return qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
 
     @staticmethod
     def backward(ctx, dq, dk, dv):
-        x3, w3t = ctx.saved_tensors
+        x3, w3k = ctx.saved_tensors
         K, N = ctx.dims
         M = x3.shape[0]
         esz = dq.element_size()
@@ -533,7 +538,7 @@ class _QKVX3(torch.autograd.Function):
         else:
             dqkv = torch.cat([dq, dk, dv], dim=1)
         dy3 = _split_rows(dqkv, grad=True)
-        dx = torch.mm(dy3, w3t, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dx = _mm3(dy3, w3k) if ctx.needs_input_grad[0] else None
         dW = _dw_x3(x3, dy3, K, 3 * N)
         return dx, dW[:, :N], dW[:, N:2 * N], dW[:, 2 * N:]
 
@@ -544,10 +549,19 @@ def qkv_x3(x2d, Wq, Wk, Wv):
 
 def _dw_x3(x3, dy3, K, N):
     """dW = x^T dy from an activation image x3 [M,3K] = [hi|lo|hi] and a gradient image dy3 [M,3N] = [hi|hi|lo]: seen as
-    [3M,K] and [3M,N] their rows pair up plane by plane, so dW = xh^T dyh + xl^T dyh + xh^T dyl is ONE bf16 GEMM with a
-    3M-deep reduction and fp32 accumulation."""
-    M = x3.shape[0]
-    return torch.mm(x3.view(3 * M, K).t(), dy3.view(3 * M, N), out_dtype=torch.float32)
+    [3M,K] and [3M,N] their rows pair up plane by plane, so dW = xh^T dyh + xl^T dyh + xh^T dyl is one bf16 GEMM with a
+    3M-deep reduction and fp32 accumulation.  hipBLASLt does not split a long reduction with a small output by itself
+    (one 61440-deep GEMM: 0.45-0.94 PFLOP/s executed at cfg-2), so it is handed over as a batched GEMM over S slices of the
+    reduction plus a sum, computing dW^T when the output is large (measured best: 0.93-1.1 PFLOP/s, tools/bench_dw_gemms.py)."""
+    M3 = 3 * x3.shape[0]
+    small = K * N <= (1 << 20)
+    S = 8 if small else 4
+    if M3 % S or M3 // S < 512:
+        return torch.mm(x3.view(M3, K).t(), dy3.view(M3, N), out_dtype=torch.float32)
+    xb, db = x3.view(S, M3 // S, K), dy3.view(S, M3 // S, N)
+    if small:
+        return torch.bmm(xb.transpose(1, 2), db, out_dtype=torch.float32).sum(0)
+    return torch.bmm(db.transpose(1, 2), xb, out_dtype=torch.float32).sum(0).t()
 
 
 class _FFNX3(torch.autograd.Function):
@@ -560,23 +574,23 @@ class _FFNX3(torch.autograd.Function):
         y2d = _rows(y2d, "ffn input")
         W1, W2 = _f32(W1, "W1").contiguous(), _f32(W2, "W2").contiguous()
         y3 = _split_rows(y2d)
-        w13, w13t = _split_weight(W1)
-        pre1 = torch.mm(y3, w13, out_dtype=torch.float32)
+        w13n, w13k = _split_weight(W1)
+        pre1 = _mm3(y3, w13n)
         f3 = _split_rows(pre1, bias=b1.contiguous(), relu=True)
         del pre1
-        w23, w23t = _split_weight(W2)
-        ctx.save_for_backward(y3, f3, w13t, w23t)
+        w23n, w23k = _split_weight(W2)
+        ctx.save_for_backward(y3, f3, w13k, w23k)
         ctx.dims = (W1.shape[0], W1.shape[1], W2.shape[1])
-        return torch.mm(f3, w23, out_dtype=torch.float32)
+        return _mm3(f3, w23n)
 
     @staticmethod
     def backward(ctx, dout):
         lib = _capi.load()
-        y3, f3, w13t, w23t = ctx.saved_tensors
+        y3, f3, w13k, w23k = ctx.saved_tensors
         F, H, N = ctx.dims
         M = y3.shape[0]
         do3 = _split_rows(dout.contiguous(), grad=True)
-        df = torch.mm(do3, w23t, out_dtype=torch.float32)                 # [M, H]
+        df = _mm3(do3, w23k)                                              # [M, H]
         dW2 = _dw_x3(f3, do3, H, N)
         dp3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=df.device)
         db1 = _empty((H,), df)
@@ -585,7 +599,7 @@ class _FFNX3(torch.autograd.Function):
         lib.check(lib._lpm_split_rows_relu_bwd(ptr(df), M, H, ptr(f3), ptr(dp3), ptr(db1), ptr(ws), wsb, stream_ptr()),
                   "lpm_split_rows_relu_bwd")
         del df
-        dy = torch.mm(dp3, w13t, out_dtype=torch.float32)
+        dy = _mm3(dp3, w13k)
         dW1 = _dw_x3(y3, dp3, F, H)
         return dy, dW1, db1, dW2
 
