@@ -171,9 +171,8 @@ def main():
         line = {"metric": METRIC, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "dtype_detail": "fp32 storage and accumulation everywhere; K1, K2, K3 and the encoder dense GEMMs feed the bf16 MFMA "
-                                "pipe with split-bf16 (hi+lo) operands, 3 MFMAs per product (~5e-6 relative error); K4 (attention) "
-                                "uses the exact-fp32 MFMA",
+                "dtype_detail": "fp32 storage and accumulation everywhere; K1, K2, K3, K4 and the encoder dense GEMMs feed the bf16 "
+                                "MFMA pipe with split-bf16 (hi+lo) operands, 3 MFMAs per product (~5e-6 relative error)",
                 "config": {"workload": "NetVladV1 K=256 hidden=512 rgb+audio 1152-d 300 frames, bs 80 per GPU "
                                        "(BASELINE configs[1]; configs[3] at 8 GPUs), full training step",
                            "global_batch": global_batch, "seq_len": MAX_FRAMES, "parallelism": f"dp{world}"},

@@ -273,7 +273,17 @@ int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, cons
 int lpm_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d,
                 float scale, const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse,
                 lpm_stream_t stream);
+/* The same contract on the bf16 matrix pipe (csrc/mha_x3.hip): split-bf16 operands (3 bf16 MFMAs per product, fp32
+ * accumulation, ~1e-5 relative error on the logits), v_mfma_f32_16x16x32_bf16.  Pointers 16-byte aligned. */
+int lpm_mha_fwd_x3(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d,
+                float scale, const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse,
+                lpm_stream_t stream);
 int lpm_mha_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
+                int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
+                const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
+                const float* corr_b, float* dz_partial, lpm_stream_t stream);
+/* lpm_mha_bwd on the bf16 matrix pipe (split-bf16 operands, csrc/mha_x3.hip); same contract, 16-byte aligned pointers. */
+int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
                 int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
                 const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
                 const float* corr_b, float* dz_partial, lpm_stream_t stream);

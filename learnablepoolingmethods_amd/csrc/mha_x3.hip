@@ -1,0 +1,596 @@
+// K4 on the bf16 matrix pipe -- the attention core of mha.hip with split-bf16 operands (v = hi + lo bf16 planes,
+// a*b = ah*bh + ah*bl + al*bh accumulated in fp32: ~1e-5 relative error on the logits, inside the 1e-3 parity bar) and
+// v_mfma_f32_16x16x32_bf16.  Same structure as the fp32 form: one 256-thread workgroup per (batch, head), TRANSPOSED score
+// tiles S^T[key, q] so that a lane owns one query column and the probability tile is already the B operand of the PV
+// product -- no LDS round trip for P.  What changes:
+//   * K is staged once per workgroup as bf16 hi/lo planes in fragment order (16 bytes per key per 8-column half): one
+//     conflict-free ds_read_b128 per key tile.  The 32-deep reduction of the 16x16x32 MFMA holds [Kh | Kl] against
+//     [Qh | Qh], so a score tile costs 2 MFMAs (1 for d = 8) instead of 4 fp32 ones at half the rate each.
+//   * V is staged TRANSPOSED (Vt[d][key], hi and lo planes) with the keys of every 32-key block permuted to the order in
+//     which the score-tile accumulators hold them (lane group g owns keys 4g..4g+3 of both 16-key tiles): the A operand
+//     of O^T += V^T P^T is one ds_read_b128 per plane, the B operand is the lane's own 8 probabilities.
+//   * fp32 -> (hi, lo) splits use v_cvt_pk_bf16_f32 (2.5 VALU ops per element).
+// transformer_utils.py:564-581 (MultiHeadAttention) and :652-659 (logits_bn variant: key_scale / key_shift).
+#include "lpm_common.h"
+
+namespace lpm {
+
+typedef __bf16 mx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mx_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned mx_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mx_mfma(mx_u32x4 a, mx_u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mx_bf16x8, a), __builtin_bit_cast(mx_bf16x8, b), c, 0, 0, 0);
+}
+// (a, b) -> packed bf16 hi pair and lo pair (RNE both)
+__device__ __forceinline__ void mx_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const mx_f32x2 v = {a, b};
+    const mx_bf16x2 h = __builtin_convertvector(v, mx_bf16x2);
+    const mx_f32x2 hf = __builtin_convertvector(h, mx_f32x2);
+    const mx_bf16x2 l = __builtin_convertvector(v - hf, mx_bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void mx_split8(const float* v, mx_u32x4& hi, mx_u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h, l;
+        mx_split2(v[2 * i], v[2 * i + 1], h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+// position of key (or query) `i` inside its 32-block in the permuted order: i = 16 t + 4 g + e  ->  8 g + 4 t + e
+__device__ __forceinline__ int mx_perm(int i) { return (i & ~31) | (((i >> 2) & 3) << 3) | (((i >> 4) & 1) << 2) | (i & 3); }
+
+// LDS geometry for a sequence padded to LP (a multiple of 32) positions
+//   row planes of an [L, D] operand: (D/8)*2 arrays of LP x 16 bytes, array index = plane * (D/8) + half
+//   transposed planes:               2 planes x 16 rows x (LP*2 + 16) bytes
+__host__ __device__ constexpr int mx_rowplanes_bytes(int LP, int D) { return (D / 8) * 2 * LP * 16; }
+__host__ __device__ constexpr int mx_tstride(int LP) { return LP * 2 + 16; }
+__host__ __device__ constexpr int mx_tplanes_bytes(int LP) { return 2 * 16 * mx_tstride(LP); }
+
+// stage rows [0, L) of head hh of a [B, L, ld] tensor as row planes (optionally scaled)
+template <int D>
+__device__ __forceinline__ void mx_stage_rows(unsigned char* dst, const float* __restrict__ src, int64_t ld, int b, int L, int LP,
+                                              int hh, float mul, int tid) {
+    constexpr int NH = D / 8;
+    for (int i = tid; i < L * NH; i += 256) {
+        const int row = i / NH, hf = i % NH;
+        const float* p = src + ((int64_t)b * L + row) * ld + hh * D + 8 * hf;
+        const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+        const float v[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, c.x * mul, c.y * mul, c.z * mul, c.w * mul};
+        mx_u32x4 hi, lo;
+        mx_split8(v, hi, lo);
+        *reinterpret_cast<mx_u32x4*>(dst + ((0 * NH + hf) * LP + row) * 16) = hi;
+        *reinterpret_cast<mx_u32x4*>(dst + ((1 * NH + hf) * LP + row) * 16) = lo;
+    }
+}
+// stage the same rows transposed and permuted: T[plane][d][perm(row)]
+template <int D>
+__device__ __forceinline__ void mx_stage_transposed(unsigned char* dst, const float* __restrict__ src, int64_t ld, int b, int L,
+                                                    int LP, int hh, int tid) {
+    constexpr int NH = D / 8;
+    const int TS = mx_tstride(LP);
+    for (int i = tid; i < L * NH; i += 256) {
+        const int row = i / NH, hf = i % NH;
+        const float* p = src + ((int64_t)b * L + row) * ld + hh * D + 8 * hf;
+        const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        mx_u32x4 hi, lo;
+        mx_split8(v, hi, lo);
+        const int pos = mx_perm(row);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int dd = 8 * hf + e;
+            const unsigned short h16 = (unsigned short)(hi[e >> 1] >> ((e & 1) * 16)), l16 = (unsigned short)(lo[e >> 1] >> ((e & 1) * 16));
+            *reinterpret_cast<unsigned short*>(dst + dd * TS + pos * 2) = h16;
+            *reinterpret_cast<unsigned short*>(dst + 16 * TS + dd * TS + pos * 2) = l16;
+        }
+    }
+}
+
+// A fragment of a row-plane operand for tile `t` (16 rows): lane group g picks array g (D = 16: Kh0, Kh1, Kl0, Kl1;
+// D = 8: Kh0, Kl0, Kh0, Kh0) -- one ds_read_b128.
+template <int D>
+__device__ __forceinline__ mx_u32x4 mx_row_frag(const unsigned char* planes, int LP, int t, int l15, int g) {
+    const int arr = (D == 16) ? g : ((g == 1) ? 1 : 0);
+    return *reinterpret_cast<const mx_u32x4*>(planes + (arr * LP + t * 16 + l15) * 16);
+}
+// B fragments of this lane's own row (8 values already split): first MFMA pairs [h|h] with the planes [Xh|Xl] (D = 16) or
+// [h|h|l|0] with [Xh|Xl|Xh|.] (D = 8); the second MFMA (D = 16 only) pairs [l|0] with [Xh|.].
+template <int D>
+__device__ __forceinline__ void mx_col_frags(const mx_u32x4& hi, const mx_u32x4& lo, int g, mx_u32x4& b1, mx_u32x4& b2) {
+    const mx_u32x4 z = {0u, 0u, 0u, 0u};
+    if (D == 16) {
+        b1 = hi;
+        b2 = (g < 2) ? lo : z;
+    } else {
+        b1 = (g < 2) ? hi : ((g == 2) ? lo : z);
+        b2 = z;
+    }
+}
+
+template <int NKT, bool AFFINE, int D>
+__global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, int64_t ld, int L, int h, float scale,
+                                                         const float* __restrict__ key_scale, const float* __restrict__ key_shift,
+                                                         float* __restrict__ o, int64_t ldo, float* __restrict__ lse) {
+    static_assert(NKT % 2 == 0, "key tiles come in pairs (32-deep PV reduction)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LP = NKT * 16;
+    constexpr int NQ = (NKT + 3) / 4;
+    const int nkt = (L + 15) >> 4;
+    unsigned char* Kp = smem;
+    unsigned char* Vt = Kp + mx_rowplanes_bytes(LP, D);
+    float* ksc = reinterpret_cast<float*>(Vt + mx_tplanes_bytes(LP));
+    float* ksh = ksc + LP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    const int TS = mx_tstride(LP);
+
+    if (L != LP || D < 16) {                // padded keys and (d = 8) the unused rows of V^T must read as zero
+        for (int i = tid; i < (mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP)) / 16; i += 256)
+            reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+    if (AFFINE) {
+        for (int i = tid; i < LP; i += 256) {
+            ksc[i] = (i < L) ? key_scale[i] : 1.f;
+            ksh[i] = (i < L) ? key_shift[i] : 0.f;
+        }
+    }
+    mx_stage_rows<D>(Kp, k, ld, b, L, LP, hh, 1.f, tid);
+    mx_stage_transposed<D>(Vt, v, ld, b, L, LP, hh, tid);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = 0; i < NQ; ++i) {
+        const int qt = wave + 4 * i;
+        if (qt >= nkt) break;
+        const int qrow = qt * 16 + l15;
+        // this lane's query fragment: columns 8*(g&1).. of head hh (D = 16) or all 8 (D = 8), scaled, split
+        mx_u32x4 qh = {0u, 0u, 0u, 0u}, ql = {0u, 0u, 0u, 0u};
+        if (qrow < L) {
+            const float* p = q + ((int64_t)b * L + qrow) * ld + hh * D + ((D == 16) ? 8 * (g & 1) : 0);
+            const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+            const float qv[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+            mx_split8(qv, qh, ql);
+        }
+        mx_u32x4 b1, b2;
+        mx_col_frags<D>(qh, ql, g, b1, b2);
+        f32x4 p[NKT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const mx_u32x4 a = mx_row_frag<D>(Kp, LP, kt, l15, g);
+            acc = mx_mfma(a, b1, acc);
+            if (D == 16) acc = mx_mfma(a, b2, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                float z = acc[r];
+                if (AFFINE) z = fmaf(z, ksc[key], ksh[key]);
+                if (L != LP && key >= L) z = -INFINITY;
+                acc[r] = z;
+                m = fmaxf(m, z);
+            }
+            p[kt] = acc;
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+        f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NKT / 2; ++j) {
+            float e8[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e8[r] = __expf(p[2 * j][r] - m);
+                e8[4 + r] = __expf(p[2 * j + 1][r] - m);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sum += e8[r];
+            mx_u32x4 ph, pl;
+            mx_split8(e8, ph, pl);
+            const unsigned char* va = Vt + l15 * TS + (32 * j + 8 * g) * 2;
+            const mx_u32x4 vh = *reinterpret_cast<const mx_u32x4*>(va), vl = *reinterpret_cast<const mx_u32x4*>(va + 16 * TS);
+            oa = mx_mfma(vh, ph, oa);
+            ob = mx_mfma(vh, pl, ob);
+            oa = mx_mfma(vl, ph, oa);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        if (qrow < L) {
+            if (4 * g < D) {
+                const float4 ov = make_float4((oa[0] + ob[0]) * inv, (oa[1] + ob[1]) * inv, (oa[2] + ob[2]) * inv, (oa[3] + ob[3]) * inv);
+                *reinterpret_cast<float4*>(o + ((int64_t)b * L + qrow) * ldo + hh * D + 4 * g) = ov;
+            }
+            if (g == 0) lse[((int64_t)b * h + hh) * L + qrow] = m + __logf(sum);
+        }
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------
+// Two kernels as in the fp32 form (each stages what ITS sweep re-reads; tiles are recomputed from the saved log-sum-exp):
+//   mha_bwd_dq_x3_kernel : K and V row planes + K^T planes in LDS; a wave owns query tiles:
+//       S^T = K Q^T, dP^T = V dO^T (2 MFMAs each), dS^T in registers, dQ^T += K^T dS^T (3 MFMAs per 32 keys)
+//   mha_bwd_dkv_x3_kernel: Q (pre-scaled) and dO row planes + their transposes in LDS; a wave owns key tiles:
+//       S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS; also the logits_bn column sums (dz_partial).
+template <int NKT, bool AFFINE, int D>
+__global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
+                                                            const float* __restrict__ dout, int64_t ldo,
+                                                            const float* __restrict__ lse, int L, int h, float scale,
+                                                            const float* __restrict__ key_scale, const float* __restrict__ key_shift,
+                                                            float* __restrict__ dq, int64_t ldd, const float* __restrict__ corr_a,
+                                                            const float* __restrict__ corr_b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LP = NKT * 16;
+    const int nkt = (L + 15) >> 4;
+    unsigned char* Kp = smem;
+    unsigned char* Vp = Kp + mx_rowplanes_bytes(LP, D);
+    unsigned char* Kt = Vp + mx_rowplanes_bytes(LP, D);
+    float* ksc = reinterpret_cast<float*>(Kt + mx_tplanes_bytes(LP));
+    float* ksh = ksc + LP;
+    float* cas = ksh + LP;
+    float* cbs = cas + LP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    const int TS = mx_tstride(LP);
+
+    if (L != LP || D < 16) {
+        for (int i = tid; i < (2 * mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP)) / 16; i += 256)
+            reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+    if (AFFINE) {
+        for (int i = tid; i < LP; i += 256) {
+            ksc[i] = (i < L) ? key_scale[i] : 1.f;
+            ksh[i] = (i < L) ? key_shift[i] : 0.f;
+            cas[i] = (corr_a && i < L) ? corr_a[i] : 0.f;
+            cbs[i] = (corr_b && i < L) ? corr_b[i] : 0.f;
+        }
+    }
+    mx_stage_rows<D>(Kp, k, ld, b, L, LP, hh, 1.f, tid);
+    mx_stage_rows<D>(Vp, v, ld, b, L, LP, hh, 1.f, tid);
+    mx_stage_transposed<D>(Kt, k, ld, b, L, LP, hh, tid);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int qt = wave; qt < nkt; qt += 4) {
+        const int qrow = qt * 16 + l15;
+        const bool qok = qrow < L;
+        mx_u32x4 qh = {0u, 0u, 0u, 0u}, ql = qh, gh = qh, gl = qh;
+        float dpart = 0.f;
+        if (qok) {
+            const int c0 = hh * D + ((D == 16) ? 8 * (g & 1) : 0);
+            const float* qp = q + ((int64_t)b * L + qrow) * ld + c0;
+            const float4 a = *reinterpret_cast<const float4*>(qp), c = *reinterpret_cast<const float4*>(qp + 4);
+            const float qv[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+            mx_split8(qv, qh, ql);
+            const int64_t off = ((int64_t)b * L + qrow) * ldo + c0;
+            const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
+            const float4 oa = *reinterpret_cast<const float4*>(o + off), oc = *reinterpret_cast<const float4*>(o + off + 4);
+            const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
+            mx_split8(gv, gh, gl);
+            dpart = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
+        }
+        if (D == 16) dpart += __shfl_xor(dpart, 16, 64);       // the two 8-column halves live in lane groups g and g^1
+        const float dqv = dpart;                               // D_q = <dO_q, O_q>
+        const float lq = qok ? lse[((int64_t)b * h + hh) * L + qrow] : INFINITY;
+        mx_u32x4 qb1, qb2, gb1, gb2;
+        mx_col_frags<D>(qh, ql, g, qb1, qb2);
+        mx_col_frags<D>(gh, gl, g, gb1, gb2);
+        f32x4 dqa = {0.f, 0.f, 0.f, 0.f}, dqb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int j = 0; j < NKT / 2; ++j) {
+            float ds8[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = 2 * j + t;
+                const mx_u32x4 ka = mx_row_frag<D>(Kp, LP, kt, l15, g), va = mx_row_frag<D>(Vp, LP, kt, l15, g);
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                st = mx_mfma(ka, qb1, st);
+                dp = mx_mfma(va, gb1, dp);
+                if (D == 16) {
+                    st = mx_mfma(ka, qb2, st);
+                    dp = mx_mfma(va, gb2, dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    float z = st[r];
+                    if (AFFINE) z = fmaf(z, ksc[key], ksh[key]);
+                    if (L != LP && key >= L) z = -INFINITY;
+                    const float pr = __expf(z - lq);
+                    float dsv = pr * (dp[r] - dqv);
+                    if (AFFINE) dsv = dsv * ksc[key] - cas[key] - st[r] * cbs[key];
+                    ds8[4 * t + r] = dsv;
+                }
+            }
+            mx_u32x4 dh, dl;
+            mx_split8(ds8, dh, dl);
+            const unsigned char* kc = Kt + l15 * TS + (32 * j + 8 * g) * 2;
+            const mx_u32x4 kh = *reinterpret_cast<const mx_u32x4*>(kc), kl = *reinterpret_cast<const mx_u32x4*>(kc + 16 * TS);
+            dqa = mx_mfma(kh, dh, dqa);          // dQ^T[dd, q] += K^T[dd, keys] dS^T[keys, q]
+            dqb = mx_mfma(kh, dl, dqb);
+            dqa = mx_mfma(kl, dh, dqa);
+        }
+        if (qok && 4 * g < D) {
+            const float4 ov = make_float4((dqa[0] + dqb[0]) * scale, (dqa[1] + dqb[1]) * scale, (dqa[2] + dqb[2]) * scale,
+                                          (dqa[3] + dqb[3]) * scale);
+            *reinterpret_cast<float4*>(dq + ((int64_t)b * L + qrow) * ldd + hh * D + 4 * g) = ov;
+        }
+    }
+}
+
+template <int NKT, bool AFFINE, int D>
+__global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
+                                                             const float* __restrict__ dout, int64_t ldo,
+                                                             const float* __restrict__ lse, int L, int h, float scale,
+                                                             const float* __restrict__ key_scale, const float* __restrict__ key_shift,
+                                                             float* __restrict__ dk, float* __restrict__ dv, int64_t ldd,
+                                                             const float* __restrict__ corr_a, const float* __restrict__ corr_b,
+                                                             float* __restrict__ dz_partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LP = NKT * 16;
+    constexpr int NH = D / 8;
+    const int nkt = (L + 15) >> 4;
+    unsigned char* Qp = smem;                                   // scale * Q
+    unsigned char* Gp = Qp + mx_rowplanes_bytes(LP, D);         // dO
+    unsigned char* Qt = Gp + mx_rowplanes_bytes(LP, D);
+    unsigned char* Gt = Qt + mx_tplanes_bytes(LP);
+    float* lses = reinterpret_cast<float*>(Gt + mx_tplanes_bytes(LP));
+    float* Dq = lses + LP;
+    const bool stats_only = (dk == nullptr);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    const int TS = mx_tstride(LP);
+
+    if (L != LP || D < 16) {
+        for (int i = tid; i < (2 * mx_rowplanes_bytes(LP, D) + 2 * mx_tplanes_bytes(LP)) / 16; i += 256)
+            reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
+    }
+    for (int i = tid; i < LP; i += 256) {
+        lses[i] = (i < L) ? lse[((int64_t)b * h + hh) * L + i] : INFINITY;     // padded queries -> p = 0
+        Dq[i] = 0.f;
+    }
+    __syncthreads();
+    // Q (scaled) and dO: row planes and transposed planes from ONE pass over global memory; D_q = <dO_q, O_q>
+    for (int i0 = 0; i0 < L * NH; i0 += 256) {
+        const int i = i0 + tid;
+        float part = 0.f;
+        int row = 0;
+        if (i < L * NH) {
+            row = i / NH;
+            const int hf = i % NH;
+            const float* qp = q + ((int64_t)b * L + row) * ld + hh * D + 8 * hf;
+            const int64_t off = ((int64_t)b * L + row) * ldo + hh * D + 8 * hf;
+            const float4 qa = *reinterpret_cast<const float4*>(qp), qc = *reinterpret_cast<const float4*>(qp + 4);
+            const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
+            const float4 oa = *reinterpret_cast<const float4*>(o + off), oc = *reinterpret_cast<const float4*>(o + off + 4);
+            part = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
+            const float qv[8] = {qa.x * scale, qa.y * scale, qa.z * scale, qa.w * scale, qc.x * scale, qc.y * scale, qc.z * scale, qc.w * scale};
+            const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
+            mx_u32x4 qh, ql, gh, gl;
+            mx_split8(qv, qh, ql);
+            mx_split8(gv, gh, gl);
+            *reinterpret_cast<mx_u32x4*>(Qp + ((0 * NH + hf) * LP + row) * 16) = qh;
+            *reinterpret_cast<mx_u32x4*>(Qp + ((1 * NH + hf) * LP + row) * 16) = ql;
+            *reinterpret_cast<mx_u32x4*>(Gp + ((0 * NH + hf) * LP + row) * 16) = gh;
+            *reinterpret_cast<mx_u32x4*>(Gp + ((1 * NH + hf) * LP + row) * 16) = gl;
+            const int pos = mx_perm(row);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int dd = 8 * hf + e, sh = (e & 1) * 16;
+                *reinterpret_cast<unsigned short*>(Qt + dd * TS + pos * 2) = (unsigned short)(qh[e >> 1] >> sh);
+                *reinterpret_cast<unsigned short*>(Qt + 16 * TS + dd * TS + pos * 2) = (unsigned short)(ql[e >> 1] >> sh);
+                *reinterpret_cast<unsigned short*>(Gt + dd * TS + pos * 2) = (unsigned short)(gh[e >> 1] >> sh);
+                *reinterpret_cast<unsigned short*>(Gt + 16 * TS + dd * TS + pos * 2) = (unsigned short)(gl[e >> 1] >> sh);
+            }
+        }
+        if (NH == 2) part += __shfl_xor(part, 1, 64);          // the two halves of a row sit in adjacent threads
+        if (i < L * NH && (i % NH) == 0) Dq[row] = part;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int kt = wave; kt < nkt; kt += 4) {
+        const int krow = kt * 16 + l15;
+        const bool kok = krow < L;
+        mx_u32x4 kh = {0u, 0u, 0u, 0u}, kl = kh, vh = kh, vl = kh;
+        if (kok) {
+            const int64_t off = ((int64_t)b * L + krow) * ld + hh * D + ((D == 16) ? 8 * (g & 1) : 0);
+            const float4 ka = *reinterpret_cast<const float4*>(k + off), kc = *reinterpret_cast<const float4*>(k + off + 4);
+            const float4 va = *reinterpret_cast<const float4*>(v + off), vc = *reinterpret_cast<const float4*>(v + off + 4);
+            const float kv[8] = {ka.x, ka.y, ka.z, ka.w, kc.x, kc.y, kc.z, kc.w};
+            const float vv[8] = {va.x, va.y, va.z, va.w, vc.x, vc.y, vc.z, vc.w};
+            mx_split8(kv, kh, kl);
+            mx_split8(vv, vh, vl);
+        }
+        mx_u32x4 kb1, kb2, vb1, vb2;
+        mx_col_frags<D>(kh, kl, g, kb1, kb2);
+        mx_col_frags<D>(vh, vl, g, vb1, vb2);
+        const float sck = (key_scale && kok) ? key_scale[krow] : 1.f, shk = (key_shift && kok) ? key_shift[krow] : 0.f;
+        const float cak = (corr_a && kok) ? corr_a[krow] : 0.f, cbk = (corr_b && kok) ? corr_b[krow] : 0.f;
+        f32x4 dka = {0.f, 0.f, 0.f, 0.f}, dkb = dka, dva = dka, dvb = dka;
+        float zs = 0.f, zq = 0.f;
+#pragma unroll 2
+        for (int j = 0; j < NKT / 2; ++j) {
+            float p8[8], ds8[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qt = 2 * j + t;
+                const mx_u32x4 qa = mx_row_frag<D>(Qp, LP, qt, l15, g), ga = mx_row_frag<D>(Gp, LP, qt, l15, g);
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                st = mx_mfma(qa, kb1, st);                 // S[q, key] (scale folded into Q)
+                dp = mx_mfma(ga, vb1, dp);                 // dP[q, key] = dO V^T
+                if (D == 16) {
+                    st = mx_mfma(qa, kb2, st);
+                    dp = mx_mfma(ga, vb2, dp);
+                }
+                const float4 lq4v = *reinterpret_cast<const float4*>(lses + qt * 16 + 4 * g);
+                const float4 dq4v = *reinterpret_cast<const float4*>(Dq + qt * 16 + 4 * g);
+                const float lq4[4] = {lq4v.x, lq4v.y, lq4v.z, lq4v.w}, dq4[4] = {dq4v.x, dq4v.y, dq4v.z, dq4v.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qr = qt * 16 + 4 * g + r;
+                    const float sraw = st[r];
+                    float z = sraw;
+                    if (AFFINE) z = fmaf(sraw, sck, shk);
+                    if (!kok) z = -INFINITY;
+                    const float pr = __expf(z - lq4[r]);
+                    const float dz = pr * (dp[r] - dq4[r]);
+                    float dsv = dz;
+                    if (AFFINE) {
+                        zs += dz;
+                        zq = fmaf(dz, sraw, zq);
+                        dsv = (qr < L) ? dz * sck - cak - sraw * cbk : 0.f;
+                    }
+                    p8[4 * t + r] = pr;
+                    ds8[4 * t + r] = dsv;
+                }
+            }
+            if (!stats_only) {
+                mx_u32x4 ph, pl, dh, dl;
+                mx_split8(p8, ph, pl);
+                mx_split8(ds8, dh, dl);
+                const int offt = l15 * TS + (32 * j + 8 * g) * 2;
+                const mx_u32x4 gth = *reinterpret_cast<const mx_u32x4*>(Gt + offt), gtl = *reinterpret_cast<const mx_u32x4*>(Gt + 16 * TS + offt);
+                const mx_u32x4 qth = *reinterpret_cast<const mx_u32x4*>(Qt + offt), qtl = *reinterpret_cast<const mx_u32x4*>(Qt + 16 * TS + offt);
+                dva = mx_mfma(gth, ph, dva);               // dV^T[dd, key] += dO^T[dd, q] P[q, key]
+                dvb = mx_mfma(gth, pl, dvb);
+                dva = mx_mfma(gtl, ph, dva);
+                dka = mx_mfma(qth, dh, dka);               // dK^T[dd, key] += (scale Q)^T[dd, q] dS[q, key]
+                dkb = mx_mfma(qth, dl, dkb);
+                dka = mx_mfma(qtl, dh, dka);
+            }
+        }
+        if (!stats_only && kok && 4 * g < D) {
+            const int64_t off = ((int64_t)b * L + krow) * ldd + hh * D + 4 * g;
+            *reinterpret_cast<float4*>(dk + off) = make_float4(dka[0] + dkb[0], dka[1] + dkb[1], dka[2] + dkb[2], dka[3] + dkb[3]);
+            *reinterpret_cast<float4*>(dv + off) = make_float4(dva[0] + dvb[0], dva[1] + dvb[1], dva[2] + dvb[2], dva[3] + dvb[3]);
+        }
+        if (dz_partial) {
+            zs += __shfl_xor(zs, 16, 64); zs += __shfl_xor(zs, 32, 64);
+            zq += __shfl_xor(zq, 16, 64); zq += __shfl_xor(zq, 32, 64);
+            if (g == 0 && kok) {
+                float* out = dz_partial + ((int64_t)b * h + hh) * 2 * L;
+                out[krow] = zs;
+                out[L + krow] = zq;
+            }
+        }
+    }
+}
+
+static inline size_t mx_bwd_dq_lds(int LP, int D) { return (size_t)2 * mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP) + 4 * LP * 4; }
+static inline size_t mx_bwd_dkv_lds(int LP, int D) { return (size_t)2 * mx_rowplanes_bytes(LP, D) + 2 * mx_tplanes_bytes(LP) + 2 * LP * 4; }
+static inline size_t mx_fwd_lds(int LP, int D) { return (size_t)mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP) + 2 * LP * 4; }
+
+template <typename KernT>
+static int mx_reserve(KernT kern, size_t bytes, const char* what) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: cannot reserve %zu bytes of LDS", what, bytes);
+        return LPM_ERR_LAUNCH;
+    }
+    return LPM_OK;
+}
+
+}  // namespace lpm
+
+#define LPM_MX_CHECK(name)                                                                                        \
+    LPM_REQUIRE(B > 0 && L > 0 && h > 0 && (d == 8 || d == 16) && L <= 512, LPM_ERR_UNSUPPORTED_SHAPE,              \
+                name ": need d in {8,16} and L <= 512 (L=%d d=%d)", L, d);                                          \
+    LPM_REQUIRE(ld >= (int64_t)h * d && ld % 4 == 0, LPM_ERR_BADARG, name ": bad leading dimension")
+
+extern "C" int lpm_mha_fwd_x3(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d, float scale,
+                              const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse,
+                              lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o && lse, LPM_ERR_BADARG, "lpm_mha_fwd_x3: null pointer");
+    LPM_MX_CHECK("lpm_mha_fwd_x3");
+    LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_fwd_x3: key_scale/key_shift go together");
+    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0, LPM_ERR_BADARG, "lpm_mha_fwd_x3: bad ldo");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_mha_fwd_x3: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int nkt = (L + 15) / 16;
+    dim3 grid(B * h);
+#define LPM_MX_FWD2(N, AFF, DD)                                                                                  \
+    do {                                                                                                         \
+        auto kern = mha_fwd_x3_kernel<N, AFF, DD>;                                                               \
+        const size_t lds = mx_fwd_lds(N * 16, DD);                                                               \
+        if (int rc = mx_reserve(kern, lds, "lpm_mha_fwd_x3")) return rc;                                         \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ld, L, h, scale, key_scale, key_shift, o, ldo, lse); \
+    } while (0)
+#define LPM_MX_FWD1(N, AFF)            \
+    do {                               \
+        if (d == 16) LPM_MX_FWD2(N, AFF, 16); \
+        else LPM_MX_FWD2(N, AFF, 8);   \
+    } while (0)
+#define LPM_MX_FWD(N)                  \
+    do {                               \
+        if (key_scale) LPM_MX_FWD1(N, true); \
+        else LPM_MX_FWD1(N, false);    \
+    } while (0)
+    if (nkt <= 4) LPM_MX_FWD(4);
+    else if (nkt <= 8) LPM_MX_FWD(8);
+    else if (nkt <= 16) LPM_MX_FWD(16);
+    else if (nkt <= 20) LPM_MX_FWD(20);
+    else LPM_MX_FWD(32);
+#undef LPM_MX_FWD
+#undef LPM_MX_FWD1
+#undef LPM_MX_FWD2
+    return check_launch("lpm_mha_fwd_x3");
+}
+
+extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
+                              int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
+                              const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
+                              const float* corr_b, float* dz_partial, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o && dout && lse, LPM_ERR_BADARG, "lpm_mha_bwd_x3: null pointer");
+    LPM_REQUIRE((dq && dk && dv) || (!dq && !dk && !dv && dz_partial), LPM_ERR_BADARG,
+                "lpm_mha_bwd_x3: give dq, dk, dv together, or none of them (statistics-only pass needs dz_partial)");
+    LPM_REQUIRE((corr_a == nullptr) == (corr_b == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd_x3: corr_a/corr_b go together");
+    LPM_MX_CHECK("lpm_mha_bwd_x3");
+    LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd_x3: key_scale/key_shift go together");
+    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0, LPM_ERR_BADARG, "lpm_mha_bwd_x3: bad ldo/ldd");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+                LPM_ERR_BADARG, "lpm_mha_bwd_x3: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int nkt = (L + 15) / 16;
+    dim3 grid(B * h);
+#define LPM_MX_BWD2(N, AFF, DD)                                                                                            do {                                                                                                                       if (dq) {                                                                                                                  auto kq = mha_bwd_dq_x3_kernel<N, AFF, DD>;                                                                            const size_t lq = mx_bwd_dq_lds(N * 16, DD);                                                                           if (int rc = mx_reserve(kq, lq, "lpm_mha_bwd_x3")) return rc;                                                          hipLaunchKernelGGL(kq, grid, dim3(256), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dq,                                ldd, corr_a, corr_b);                                                                           }                                                                                                                      auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                                           const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                                          if (int rc = mx_reserve(kk, lk, "lpm_mha_bwd_x3")) return rc;                                                          hipLaunchKernelGGL(kk, grid, dim3(256), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv,                            ldd, corr_a, corr_b, dz_partial);                                                               } while (0)
+#define LPM_MX_BWD1(N, AFF)            \
+    do {                               \
+        if (d == 16) LPM_MX_BWD2(N, AFF, 16); \
+        else LPM_MX_BWD2(N, AFF, 8);   \
+    } while (0)
+#define LPM_MX_BWD(N)                  \
+    do {                               \
+        if (key_scale) LPM_MX_BWD1(N, true); \
+        else LPM_MX_BWD1(N, false);    \
+    } while (0)
+    if (nkt <= 4) LPM_MX_BWD(4);
+    else if (nkt <= 8) LPM_MX_BWD(8);
+    else if (nkt <= 16) LPM_MX_BWD(16);
+    else if (nkt <= 20) LPM_MX_BWD(20);
+    else LPM_MX_BWD(32);
+#undef LPM_MX_BWD
+#undef LPM_MX_BWD1
+#undef LPM_MX_BWD2
+    return check_launch("lpm_mha_bwd_x3");
+}

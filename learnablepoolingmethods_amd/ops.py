@@ -30,6 +30,13 @@ VLAD_TILES3 = os.environ.get("LPM_VLAD_TILES3", "1") != "0"
 # D %% 16 == 0 and K <= 512) or "f32" (exact fp32 MFMA).
 ASSIGN_PRECISION = os.environ.get("LPM_ASSIGN_PRECISION", "bf16x3")
 
+# Matrix-core arithmetic of the attention core K4: "bf16x3" (split-bf16 operands, v_mfma_f32_16x16x32_bf16) or "f32".
+MHA_PRECISION = os.environ.get("LPM_MHA_PRECISION", "bf16x3")
+# The logits_bn variant (MultiHeadAttentionBN, NetVladV2) defaults to exact fp32: batch norm over the key-position channel
+# makes the q / k gradients differences of nearly cancelling sums, and the 1e-5 element error of the split-bf16 kernels
+# (fine at the kernel level) is amplified ~500x in the small NetVladV2 parity case -- 1e-2 on whole-model gradients.
+MHA_BN_PRECISION = os.environ.get("LPM_MHA_BN_PRECISION", "f32")
+
 # Split-bf16 tile copies of the most recent frame_sample_bn output (produced by the same kernel that writes the fp32
 # frames): {"base": weakref to y, "F": F, "Dv": .., "video": tensor, "audio": tensor|None}.  ops.netvlad / vlad_aggregate
 # look a column-slice view of y up here instead of re-reading it through lpm_split_frames.
@@ -734,6 +741,24 @@ def _mha_dims(q, num_heads):
     return B, L, F // num_heads
 
 
+def _mha_fwd_fn(lib, bn=False):
+    prec = MHA_BN_PRECISION if bn else MHA_PRECISION
+    if prec == "bf16x3":
+        return lib._lpm_mha_fwd_x3
+    if prec == "f32":
+        return lib._lpm_mha_fwd
+    raise LpmError(f"unknown attention precision {prec!r} (bf16x3 | f32)")
+
+
+def _mha_bwd_fn(lib, bn=False):
+    prec = MHA_BN_PRECISION if bn else MHA_PRECISION
+    if prec == "bf16x3":
+        return lib._lpm_mha_bwd_x3
+    if prec == "f32":
+        return lib._lpm_mha_bwd
+    raise LpmError(f"unknown attention precision {prec!r} (bf16x3 | f32)")
+
+
 def _qkv_operands(q, k, v):
     """q, k, v as the kernels take them: [B, L, h*d] with unit column stride and ONE common row stride (column views of a
     fused [B, L, 3*h*d] projection qualify); anything else is made contiguous."""
@@ -762,8 +787,9 @@ class _MHACore(torch.autograd.Function):
         B, L, d = _mha_dims(q, num_heads)
         o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
         lse = _empty((B, num_heads, L), q)
-        lib.check(lib._lpm_mha_fwd(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, None, None, ptr(o),
-                                   o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
+        with _timed("mha_fwd", (B, L, num_heads, d)):
+            lib.check(_mha_fwd_fn(lib)(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, None, None, ptr(o),
+                                       o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
         ctx.dims = (B, L, num_heads, d, scale)
         ctx.save_for_backward(q, k, v, o, lse)
         return o
@@ -775,7 +801,7 @@ class _MHACore(torch.autograd.Function):
         q, k, v, o, lse = ctx.saved_tensors
         do = do.contiguous()
         dq, dk, dv = _dqkv_buffers(q)
-        lib.check(lib._lpm_mha_bwd(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d,
+        lib.check(_mha_bwd_fn(lib)(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d,
                                    scale, None, None, ptr(dq), ptr(dk), ptr(dv), dq.stride(1), None, None, None, stream_ptr()),
                   "lpm_mha_bwd")
         return dq, dk, dv, None, None
@@ -807,7 +833,7 @@ class _MHACoreBN(torch.autograd.Function):
             mean, var = moving_mean.detach().clone(), moving_var.detach().clone()
         o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
         lse = _empty((B, h, L), q)
-        lib.check(lib._lpm_mha_fwd(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, h, d, 1.0, ptr(kscale), ptr(kshift), ptr(o),
+        lib.check(_mha_fwd_fn(lib, bn=True)(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, h, d, 1.0, ptr(kscale), ptr(kshift), ptr(o),
                                    o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
         ctx.dims = (B, L, h, d, is_training)
         ctx.save_for_backward(q, k, v, o, lse, kscale, kshift, mean, var, gamma)
@@ -822,7 +848,7 @@ class _MHACoreBN(torch.autograd.Function):
         st = stream_ptr()
         # pass 1: column sums of dz and dz*s over (B, h, query)
         partial = _empty((B * h, 2, L), q)
-        lib.check(lib._lpm_mha_bwd(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
+        lib.check(_mha_bwd_fn(lib, bn=True)(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
                                    ptr(kscale), ptr(kshift), None, None, None, q.stride(1), None, None, ptr(partial), st),
                   "lpm_mha_bwd(stats)")
         sums = partial.to(torch.float64).sum(0)                      # [2, L]  (tiny)
@@ -839,7 +865,7 @@ class _MHACoreBN(torch.autograd.Function):
         else:
             corr_a = corr_b = None
         dq, dk, dv = _dqkv_buffers(q)
-        lib.check(lib._lpm_mha_bwd(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
+        lib.check(_mha_bwd_fn(lib, bn=True)(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
                                    ptr(kscale), ptr(kshift), ptr(dq), ptr(dk), ptr(dv), dq.stride(1), ptr(corr_a), ptr(corr_b),
                                    None, st), "lpm_mha_bwd")
         return dq, dk, dv, dgamma, dbeta, None, None, None, None

@@ -21,6 +21,16 @@ def vlad_precision(request):
     ops.VLAD_PRECISION, ops.ASSIGN_PRECISION = old
 
 
+@pytest.fixture(params=["bf16x3", "f32"])
+def mha_precision(request):
+    """Both matrix-core arithmetics of the attention core K4."""
+    from learnablepoolingmethods_amd import ops
+    old = ops.MHA_PRECISION, ops.MHA_BN_PRECISION
+    ops.MHA_PRECISION = ops.MHA_BN_PRECISION = request.param
+    yield request.param
+    ops.MHA_PRECISION, ops.MHA_BN_PRECISION = old
+
+
 def _netvlad_inputs(B, T, D, K, ld=None, seed=0, dev=None):
     g = torch.Generator().manual_seed(seed)
     ld = ld or D
@@ -240,8 +250,9 @@ def test_frame_permutation_invariance_full_size():
     assert torch.allclose(o.norm(dim=(1, 2)), torch.ones(B, device=dev), atol=1e-5)
 
 
-@pytest.mark.parametrize("B,L,h,d", [(2, 256, 4, 16), (3, 64, 16, 8), (2, 300, 8, 16), (1, 33, 2, 16), (2, 16, 1, 8)])
-def test_mha_core(B, L, h, d):
+@pytest.mark.parametrize("B,L,h,d", [(2, 256, 4, 16), (3, 64, 16, 8), (2, 300, 8, 16), (1, 33, 2, 16), (2, 16, 1, 8), (4, 12, 16, 8),
+                                     (2, 500, 2, 16)])
+def test_mha_core(B, L, h, d, mha_precision):
     from learnablepoolingmethods_amd import ops
     dev = cuda()
     g = torch.Generator().manual_seed(L)
@@ -260,8 +271,9 @@ def test_mha_core(B, L, h, d):
     assert_close(vg.grad, vd.grad, what="dv")
 
 
-@pytest.mark.parametrize("B,L,h,d,training", [(2, 48, 2, 16, True), (2, 300, 8, 16, True), (2, 30, 8, 16, False)])
-def test_mha_core_logits_bn(B, L, h, d, training):
+@pytest.mark.parametrize("B,L,h,d,training", [(2, 48, 2, 16, True), (2, 300, 8, 16, True), (2, 30, 8, 16, False), (4, 12, 64, 16, True),
+                                              (4, 12, 16, 8, True)])
+def test_mha_core_logits_bn(B, L, h, d, training, mha_precision):
     """MultiHeadAttentionBN core: batch_norm over the key-position channel of [B,h,Lq,Lk] (transformer_utils.py:652-659)."""
     from learnablepoolingmethods_amd import ops
     dev = cuda()

@@ -1,0 +1,34 @@
+"""Whole-model gradient error (relative L2 vs the fp64 oracle) of the small NetVladV2 case per attention arithmetic."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import lpm_oracle as O
+from tests._util import rel_l2
+from tests.test_gpu_models import _well_conditioned
+from learnablepoolingmethods_amd import ops, registry
+from learnablepoolingmethods_amd.train import Trainer
+
+dev = torch.device("cuda:0")
+cfg = O.OracleConfig(model="NetVladV2", iterations=12, cluster_size=16, hidden_size=32, vocab_size=40,
+                     base_learning_rate=1e-3, v2_dropout_rate=0.0)
+B, MF, feat = 4, 16, 1152
+x, nf, lab = O.make_synthetic_batch(B, MF, feat, cfg.vocab_size, seed=7, min_frames=max(2, MF // 3))
+p = _well_conditioned({k: v.double() for k, v in O.init_params(cfg, feat, seed=1007).items()})
+_, _, raw_grads, _ = O.loss_and_grads(p, x.double(), nf, lab, cfg)
+gscale = max(float(g.abs().max()) for g in raw_grads.values())
+for prec in ("f32", "bf16x3"):
+    ops.MHA_PRECISION = prec
+    tr = Trainer(registry.get_model("NetVladV2"), vocab_size=cfg.vocab_size, batch_size=B, base_learning_rate=cfg.base_learning_rate,
+                 learning_rate_decay=cfg.learning_rate_decay, learning_rate_decay_examples=cfg.learning_rate_decay_examples,
+                 device=dev, model_kwargs=dict(iterations=cfg.iterations, cluster_size=cfg.cluster_size, hidden_size=cfg.hidden_size,
+                                               dropout_rate=0.0))
+    tr.build(x, nf, lab)
+    tr.store.load({"tower/" + k: v for k, v in p.items()})
+    tr.step(x, nf, lab)
+    errs = []
+    for n in O.trainable_names(p, cfg):
+        a0, _ = tr.arena.segment("tower/" + n)
+        g = tr.arena.grad[a0:a0 + p[n].numel()].reshape(p[n].shape)
+        errs.append((rel_l2(g, raw_grads[n], floor=1e-4 * gscale * raw_grads[n].numel() ** 0.5), n))
+    errs.sort(reverse=True)
+    print(prec, " ".join(f"{n.split('/')[-3] if n.count('/')>1 else ''}/{n.split('/')[-2] if '/' in n else ''}/{n.split('/')[-1]}={e:.1e}" for e, n in errs[:8]))
