@@ -18,6 +18,9 @@ LIBDIR = os.path.join(PKG, "_lib")
 LIB = os.path.join(LIBDIR, "liblpm_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# per-file extras.  mha_x3: keep the small 16x16 MFMA accumulators in VGPRs (the AGPR form costs a v_accvgpr_read per
+# score in a VALU-bound kernel).
+EXTRA_FLAGS = {"mha_x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -37,6 +40,7 @@ def _digest(paths) -> str:
         with open(p, "rb") as f:
             h.update(p.encode() + b"\0" + f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -54,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print("[lpm build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

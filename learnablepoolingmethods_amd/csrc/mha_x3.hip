@@ -15,6 +15,10 @@
 
 namespace lpm {
 
+constexpr float MX_LOG2E = 1.4426950408889634f;
+constexpr float MX_LN2 = 0.6931471805599453f;
+// Probabilities are formed with v_exp_f32 (2^x) directly: the log2(e) factor rides in the query scale (or, for the
+// logits_bn variant, is applied to z once), saving a multiply per score.
 typedef __bf16 mx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 mx_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float mx_f32x2 __attribute__((ext_vector_type(2)));
@@ -112,7 +116,7 @@ __device__ __forceinline__ void mx_col_frags(const mx_u32x4& hi, const mx_u32x4&
     }
 }
 
-template <int NKT, bool AFFINE, int D>
+template <int NKT, bool AFFINE, int D, bool RAGGED>
 __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, int64_t ld, int L, int h, float scale,
                                                          const float* __restrict__ key_scale, const float* __restrict__ key_shift,
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = NKT * 16;
     constexpr int NQ = (NKT + 3) / 4;
-    const int nkt = (L + 15) >> 4;
+    const int nkt = (L + 15) >> 4;                       // RAGGED = false: L == LP, no padded keys to mask
+    const float qmul = AFFINE ? scale : scale * MX_LOG2E;
     unsigned char* Kp = smem;
     unsigned char* Vt = Kp + mx_rowplanes_bytes(LP, D);
     float* ksc = reinterpret_cast<float*>(Vt + mx_tplanes_bytes(LP));
@@ -132,15 +137,15 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
     const int b = lid / h, hh = lid % h;
     const int TS = mx_tstride(LP);
 
-    if (L != LP || D < 16) {                // padded keys and (d = 8) the unused rows of V^T must read as zero
+    if (RAGGED || D < 16) {                 // padded keys and (d = 8) the unused rows of V^T must read as zero
         for (int i = tid; i < (mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP)) / 16; i += 256)
             reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
     }
     if (AFFINE) {
         for (int i = tid; i < LP; i += 256) {
-            ksc[i] = (i < L) ? key_scale[i] : 1.f;
-            ksh[i] = (i < L) ? key_shift[i] : 0.f;
+            ksc[i] = (i < L) ? key_scale[i] * MX_LOG2E : 1.f;      // z in log2 units
+            ksh[i] = (i < L) ? key_shift[i] * MX_LOG2E : 0.f;
         }
     }
     mx_stage_rows<D>(Kp, k, ld, b, L, LP, hh, 1.f, tid);
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
         if (qrow < L) {
             const float* p = q + ((int64_t)b * L + qrow) * ld + hh * D + ((D == 16) ? 8 * (g & 1) : 0);
             const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
-            const float qv[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+            const float qv[8] = {a.x * qmul, a.y * qmul, a.z * qmul, a.w * qmul, c.x * qmul, c.y * qmul, c.z * qmul, c.w * qmul};
             mx_split8(qv, qh, ql);
         }
         mx_u32x4 b1, b2;
@@ -170,14 +175,14 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
             const mx_u32x4 a = mx_row_frag<D>(Kp, LP, kt, l15, g);
             acc = mx_mfma(a, b1, acc);
             if (D == 16) acc = mx_mfma(a, b2, acc);
+            if (AFFINE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaf(acc[r], ksc[kt * 16 + 4 * g + r], ksh[kt * 16 + 4 * g + r]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + 4 * g + r;
-                float z = acc[r];
-                if (AFFINE) z = fmaf(z, ksc[key], ksh[key]);
-                if (L != LP && key >= L) z = -INFINITY;
-                acc[r] = z;
-                m = fmaxf(m, z);
+                if (RAGGED && kt * 16 + 4 * g + r >= L) acc[r] = -INFINITY;
+                m = fmaxf(m, acc[r]);
             }
             p[kt] = acc;
         }
@@ -190,8 +195,8 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
             float e8[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                e8[r] = __expf(p[2 * j][r] - m);
-                e8[4 + r] = __expf(p[2 * j + 1][r] - m);
+                e8[r] = __builtin_amdgcn_exp2f(p[2 * j][r] - m);
+                e8[4 + r] = __builtin_amdgcn_exp2f(p[2 * j + 1][r] - m);
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) sum += e8[r];
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
                 const float4 ov = make_float4((oa[0] + ob[0]) * inv, (oa[1] + ob[1]) * inv, (oa[2] + ob[2]) * inv, (oa[3] + ob[3]) * inv);
                 *reinterpret_cast<float4*>(o + ((int64_t)b * L + qrow) * ldo + hh * D + 4 * g) = ov;
             }
-            if (g == 0) lse[((int64_t)b * h + hh) * L + qrow] = m + __logf(sum);
+            if (g == 0) lse[((int64_t)b * h + hh) * L + qrow] = m * MX_LN2 + __logf(sum);
         }
     }
 }
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
 //       S^T = K Q^T, dP^T = V dO^T (2 MFMAs each), dS^T in registers, dQ^T += K^T dS^T (3 MFMAs per 32 keys)
 //   mha_bwd_dkv_x3_kernel: Q (pre-scaled) and dO row planes + their transposes in LDS; a wave owns key tiles:
 //       S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS; also the logits_bn column sums (dz_partial).
-template <int NKT, bool AFFINE, int D>
+template <int NKT, bool AFFINE, int D, bool RAGGED>
 __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
                                                             const float* __restrict__ dout, int64_t ldo,
@@ -233,6 +238,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = NKT * 16;
     const int nkt = (L + 15) >> 4;
+    const float qmul = AFFINE ? scale : scale * MX_LOG2E;      // scores in log2 units (AFFINE: z is converted instead)
     unsigned char* Kp = smem;
     unsigned char* Vp = Kp + mx_rowplanes_bytes(LP, D);
     unsigned char* Kt = Vp + mx_rowplanes_bytes(LP, D);
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
     const int b = lid / h, hh = lid % h;
     const int TS = mx_tstride(LP);
 
-    if (L != LP || D < 16) {
+    if (RAGGED || D < 16) {
         for (int i = tid; i < (2 * mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP)) / 16; i += 256)
             reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
             const int c0 = hh * D + ((D == 16) ? 8 * (g & 1) : 0);
             const float* qp = q + ((int64_t)b * L + qrow) * ld + c0;
             const float4 a = *reinterpret_cast<const float4*>(qp), c = *reinterpret_cast<const float4*>(qp + 4);
-            const float qv[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+            const float qv[8] = {a.x * qmul, a.y * qmul, a.z * qmul, a.w * qmul, c.x * qmul, c.y * qmul, c.z * qmul, c.w * qmul};
             mx_split8(qv, qh, ql);
             const int64_t off = ((int64_t)b * L + qrow) * ldo + c0;
             const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
         }
         if (D == 16) dpart += __shfl_xor(dpart, 16, 64);       // the two 8-column halves live in lane groups g and g^1
         const float dqv = dpart;                               // D_q = <dO_q, O_q>
-        const float lq = qok ? lse[((int64_t)b * h + hh) * L + qrow] : INFINITY;
+        const float lq = qok ? lse[((int64_t)b * h + hh) * L + qrow] * MX_LOG2E : INFINITY;
         mx_u32x4 qb1, qb2, gb1, gb2;
         mx_col_frags<D>(qh, ql, g, qb1, qb2);
         mx_col_frags<D>(gh, gl, g, gb1, gb2);
@@ -304,15 +310,25 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
                     st = mx_mfma(ka, qb2, st);
                     dp = mx_mfma(va, gb2, dp);
                 }
+                float z[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + 4 * g + r;
-                    float z = st[r];
-                    if (AFFINE) z = fmaf(z, ksc[key], ksh[key]);
-                    if (L != LP && key >= L) z = -INFINITY;
-                    const float pr = __expf(z - lq);
+                    z[r] = st[r];
+                    if (AFFINE) z[r] = fmaf(st[r], ksc[kt * 16 + 4 * g + r], ksh[kt * 16 + 4 * g + r]) * MX_LOG2E;
+                }
+                if (RAGGED) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + 4 * g + r >= L) z[r] = -INFINITY;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(z[r] - lq);
                     float dsv = pr * (dp[r] - dqv);
-                    if (AFFINE) dsv = dsv * ksc[key] - cas[key] - st[r] * cbs[key];
+                    if (AFFINE) {
+                        const int key = kt * 16 + 4 * g + r;
+                        dsv = dsv * ksc[key] - cas[key] - st[r] * cbs[key];
+                    }
                     ds8[4 * t + r] = dsv;
                 }
             }
@@ -345,7 +361,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
     constexpr int LP = NKT * 16;
     constexpr int NH = D / 8;
     const int nkt = (L + 15) >> 4;
-    unsigned char* Qp = smem;                                   // scale * Q
+    const float qmul = AFFINE ? scale : scale * MX_LOG2E;       // scores in log2 units (AFFINE: z is converted instead)
+    unsigned char* Qp = smem;                                   // qmul * Q
     unsigned char* Gp = Qp + mx_rowplanes_bytes(LP, D);         // dO
     unsigned char* Qt = Gp + mx_rowplanes_bytes(LP, D);
     unsigned char* Gt = Qt + mx_tplanes_bytes(LP);
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
             reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
     }
     for (int i = tid; i < LP; i += 256) {
-        lses[i] = (i < L) ? lse[((int64_t)b * h + hh) * L + i] : INFINITY;     // padded queries -> p = 0
+        lses[i] = (i < L) ? lse[((int64_t)b * h + hh) * L + i] * MX_LOG2E : INFINITY;     // padded queries -> p = 0
         Dq[i] = 0.f;
     }
     __syncthreads();
@@ -381,7 +398,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
             const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
             const float4 oa = *reinterpret_cast<const float4*>(o + off), oc = *reinterpret_cast<const float4*>(o + off + 4);
             part = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
-            const float qv[8] = {qa.x * scale, qa.y * scale, qa.z * scale, qa.w * scale, qc.x * scale, qc.y * scale, qc.z * scale, qc.w * scale};
+            const float qv[8] = {qa.x * qmul, qa.y * qmul, qa.z * qmul, qa.w * qmul, qc.x * qmul, qc.y * qmul, qc.z * qmul, qc.w * qmul};
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
             mx_u32x4 qh, ql, gh, gl;
             mx_split8(qv, qh, ql);
@@ -448,9 +465,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
                     const int qr = qt * 16 + 4 * g + r;
                     const float sraw = st[r];
                     float z = sraw;
-                    if (AFFINE) z = fmaf(sraw, sck, shk);
+                    if (AFFINE) z = fmaf(sraw, sck, shk) * MX_LOG2E;
                     if (!kok) z = -INFINITY;
-                    const float pr = __expf(z - lq4[r]);
+                    const float pr = __builtin_amdgcn_exp2f(z - lq4[r]);
                     const float dz = pr * (dp[r] - dq4[r]);
                     float dsv = dz;
                     if (AFFINE) {
@@ -479,7 +496,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
         }
         if (!stats_only && kok && 4 * g < D) {
             const int64_t off = ((int64_t)b * L + krow) * ldd + hh * D + 4 * g;
-            *reinterpret_cast<float4*>(dk + off) = make_float4(dka[0] + dkb[0], dka[1] + dkb[1], dka[2] + dkb[2], dka[3] + dkb[3]);
+            const float kmul = AFFINE ? 1.f : MX_LN2;      // the staged Q carried log2(e)
+            *reinterpret_cast<float4*>(dk + off) = make_float4((dka[0] + dkb[0]) * kmul, (dka[1] + dkb[1]) * kmul, (dka[2] + dkb[2]) * kmul,
+                                                               (dka[3] + dkb[3]) * kmul);
             *reinterpret_cast<float4*>(dv + off) = make_float4(dva[0] + dvb[0], dva[1] + dvb[1], dva[2] + dvb[2], dva[3] + dvb[3]);
         }
         if (dz_partial) {
@@ -528,22 +547,23 @@ extern "C" int lpm_mha_fwd_x3(const float* q, const float* k, const float* v, in
     hipStream_t s = (hipStream_t)stream;
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
-#define LPM_MX_FWD2(N, AFF, DD)                                                                                  \
+#define LPM_MX_FWD3(N, AFF, DD, RG)                                                                              \
     do {                                                                                                         \
-        auto kern = mha_fwd_x3_kernel<N, AFF, DD>;                                                               \
+        auto kern = mha_fwd_x3_kernel<N, AFF, DD, RG>;                                                           \
         const size_t lds = mx_fwd_lds(N * 16, DD);                                                               \
         if (int rc = mx_reserve(kern, lds, "lpm_mha_fwd_x3")) return rc;                                         \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ld, L, h, scale, key_scale, key_shift, o, ldo, lse); \
     } while (0)
-#define LPM_MX_FWD1(N, AFF)            \
+#define LPM_MX_FWD1(N, AFF, RG)        \
     do {                               \
-        if (d == 16) LPM_MX_FWD2(N, AFF, 16); \
-        else LPM_MX_FWD2(N, AFF, 8);   \
+        if (d == 16) LPM_MX_FWD3(N, AFF, 16, RG); \
+        else LPM_MX_FWD3(N, AFF, 8, RG); \
     } while (0)
 #define LPM_MX_FWD(N)                  \
     do {                               \
-        if (key_scale) LPM_MX_FWD1(N, true); \
-        else LPM_MX_FWD1(N, false);    \
+        if (key_scale) LPM_MX_FWD1(N, true, true); \
+        else if (L == N * 16) LPM_MX_FWD1(N, false, false); \
+        else LPM_MX_FWD1(N, false, true); \
     } while (0)
     if (nkt <= 4) LPM_MX_FWD(4);
     else if (nkt <= 8) LPM_MX_FWD(8);
@@ -552,7 +572,7 @@ extern "C" int lpm_mha_fwd_x3(const float* q, const float* k, const float* v, in
     else LPM_MX_FWD(32);
 #undef LPM_MX_FWD
 #undef LPM_MX_FWD1
-#undef LPM_MX_FWD2
+#undef LPM_MX_FWD3
     return check_launch("lpm_mha_fwd_x3");
 }
 
@@ -573,16 +593,31 @@ extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, in
     hipStream_t s = (hipStream_t)stream;
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
-#define LPM_MX_BWD2(N, AFF, DD)                                                                                            do {                                                                                                                       if (dq) {                                                                                                                  auto kq = mha_bwd_dq_x3_kernel<N, AFF, DD>;                                                                            const size_t lq = mx_bwd_dq_lds(N * 16, DD);                                                                           if (int rc = mx_reserve(kq, lq, "lpm_mha_bwd_x3")) return rc;                                                          hipLaunchKernelGGL(kq, grid, dim3(256), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dq,                                ldd, corr_a, corr_b);                                                                           }                                                                                                                      auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                                           const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                                          if (int rc = mx_reserve(kk, lk, "lpm_mha_bwd_x3")) return rc;                                                          hipLaunchKernelGGL(kk, grid, dim3(256), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv,                            ldd, corr_a, corr_b, dz_partial);                                                               } while (0)
-#define LPM_MX_BWD1(N, AFF)            \
+#define LPM_MX_BWD3(N, AFF, DD, RG)                                                                                    \
+    do {                                                                                                               \
+        if (dq) {                                                                                                      \
+            auto kq = mha_bwd_dq_x3_kernel<N, AFF, DD, RG>;                                                            \
+            const size_t lq = mx_bwd_dq_lds(N * 16, DD);                                                               \
+            if (int rc = mx_reserve(kq, lq, "lpm_mha_bwd_x3")) return rc;                                              \
+            hipLaunchKernelGGL(kq, grid, dim3(256), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dq, \
+                               ldd, corr_a, corr_b);                                                                   \
+        }                                                                                                              \
+        auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                                   \
+        const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                                  \
+        if (int rc = mx_reserve(kk, lk, "lpm_mha_bwd_x3")) return rc;                                                  \
+        hipLaunchKernelGGL(kk, grid, dim3(256), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv, \
+                           ldd, corr_a, corr_b, dz_partial);                                                           \
+    } while (0)
+#define LPM_MX_BWD1(N, AFF, RG)        \
     do {                               \
-        if (d == 16) LPM_MX_BWD2(N, AFF, 16); \
-        else LPM_MX_BWD2(N, AFF, 8);   \
+        if (d == 16) LPM_MX_BWD3(N, AFF, 16, RG); \
+        else LPM_MX_BWD3(N, AFF, 8, RG); \
     } while (0)
 #define LPM_MX_BWD(N)                  \
     do {                               \
-        if (key_scale) LPM_MX_BWD1(N, true); \
-        else LPM_MX_BWD1(N, false);    \
+        if (key_scale) LPM_MX_BWD1(N, true, true); \
+        else if (L == N * 16) LPM_MX_BWD1(N, false, false); \
+        else LPM_MX_BWD1(N, false, true); \
     } while (0)
     if (nkt <= 4) LPM_MX_BWD(4);
     else if (nkt <= 8) LPM_MX_BWD(8);
@@ -591,6 +626,6 @@ extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, in
     else LPM_MX_BWD(32);
 #undef LPM_MX_BWD
 #undef LPM_MX_BWD1
-#undef LPM_MX_BWD2
+#undef LPM_MX_BWD3
     return check_launch("lpm_mha_bwd_x3");
 }
