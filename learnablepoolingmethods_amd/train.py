@@ -31,7 +31,11 @@ def learning_rate(base_learning_rate, global_step, batch_size, num_towers, decay
 class ParameterArena:
     """Flat fp32 arenas (param / grad / adam m / adam v) with every trainable variable a view into them."""
 
-    def __init__(self, store: vs.VariableStore, first: Optional[List[str]] = None):
+    def __init__(self, store: vs.VariableStore, first: Optional[List[str]] = None, gather: bool = False):
+        """gather=False: every variable's .grad IS its slice of the gradient arena (autograd accumulates in place; one tiny
+        add kernel per variable per step).  gather=True: .grad stays None during backward (autograd adopts each producer's
+        tensor) and ``collect`` moves all of them into the arena with one multi-tensor copy."""
+        self.gather = gather
         tv = store.trainable_variables()
         names = [n for n in (first or []) if n in tv] + [n for n in tv if n not in (first or [])]
         self.names = names
@@ -50,14 +54,17 @@ class ParameterArena:
         self.offsets_host = offs
         self.offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
         self.views: Dict[str, torch.Tensor] = {}
+        self.grad_views: Dict[str, torch.Tensor] = {}
         with torch.no_grad():
             for n, o in zip(names, offs):
                 t = tv[n]
                 pv = self.param[o:o + t.numel()].view(t.shape)
                 pv.copy_(t)
                 t.data = pv                                   # the variable now lives in the arena
-                t.grad = self.grad[o:o + t.numel()].view(t.shape)
+                if not gather:
+                    t.grad = self.grad[o:o + t.numel()].view(t.shape)
                 self.views[n] = t
+                self.grad_views[n] = self.grad[o:o + t.numel()].view(t.shape)
         store.frozen = True
         self._scratch = None
         self.direct = []          # (name, offset, numel): gradients their producer writes straight into the arena
@@ -72,22 +79,50 @@ class ParameterArena:
         t._lpm_grad_ready = on_ready
         self.direct.append((name, a0, t.numel()))
 
-    def collect_direct(self):
-        """After backward: a direct variable the producer did not reach gets a zero gradient, and anything autograd
-        accumulated for it on the side (another use of the variable) is folded into the arena."""
+    def collect(self):
+        """After backward: make the gradient arena complete.  Direct variables: a producer that was not reached leaves a
+        zero gradient, anything autograd accumulated on the side is folded in.  gather mode: every other variable's
+        gradient is copied into its arena slice (one multi-tensor copy for the contiguous ones)."""
+        direct = set()
         for name, a0, n in self.direct:
+            direct.add(name)
             t = self.views[name]
             if not t._lpm_grad_written:
                 t._lpm_grad_view.zero_()
             if t.grad is not None:
                 t._lpm_grad_view.add_(t.grad)
                 t.grad = None
+        if not self.gather:
+            return
+        dst, src = [], []
+        with torch.no_grad():
+            for name in self.names:
+                if name in direct:
+                    continue
+                t, gv = self.views[name], self.grad_views[name]
+                g = t.grad
+                if g is None:
+                    gv.zero_()
+                elif g.is_contiguous() and g.dtype == gv.dtype:
+                    dst.append(gv)
+                    src.append(g)
+                else:
+                    gv.copy_(g)
+                t.grad = None
+            if dst:
+                torch._foreach_copy_(dst, src)
 
     def segment(self, name: str):
         i = self.names.index(name)
         return self.offsets_host[i], self.offsets_host[i + 1]
 
     def zero_grad(self):
+        if self.gather:                       # nothing to clear: collect() overwrites every slice
+            for name in self.names:
+                self.views[name].grad = None
+            for name, _, _ in self.direct:
+                self.views[name]._lpm_grad_written = False
+            return
         if not self.direct:
             self.grad.zero_()
             return
@@ -186,7 +221,7 @@ class Trainer:
                     v.zero_()
                 elif n.endswith("/moving_variance"):
                     v.fill_(1.0)
-        self.arena = ParameterArena(self.store, first=["tower/hidden1_weights"])
+        self.arena = ParameterArena(self.store, first=["tower/hidden1_weights"], gather=self.device.type == "cuda")
         a0, a1 = self.arena.segment("tower/hidden1_weights")
         self.sync = GradientSynchronizer(self.arena.grad, [(a0, a1), (a1, self.arena.total)], self.group)
         # hidden1_weights' gradient is complete right after the projection GEMM's backward: start its all-reduce
@@ -220,7 +255,7 @@ class Trainer:
             reg_loss = reg_loss + torch.stack(reg_losses).sum()                                 # :301-303
         final_loss = self.reg_penalty * reg_loss + label_loss                                   # :321
         final_loss.backward()                                                                   # :322-323
-        self.arena.collect_direct()
+        self.arena.collect()
         self.sync.finish()                                                                      # utils.combine_gradients :330
         lr = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers,
                            self.lr_decay_examples, self.lr_decay)                               # :244-249
