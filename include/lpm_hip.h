@@ -48,6 +48,10 @@ enum {
 int lpm_version(void);
 const char* lpm_last_error(void);
 
+/* Input normalisation of the training step (tf.nn.l2_normalize(model_input_raw, 2), train.py:262-264):
+ * y[r,:] = x[r,:] * rsqrt(max(sum x[r,:]^2, 1e-12)) for `rows` rows of F floats (F %% 4 == 0, F <= 2048).  y may alias x. */
+int lpm_l2_normalize_rows(const float* x, int64_t rows, int F, float* y, lpm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a2 + a3: SampleUniformFrames + input_bn
  *   replaces model_utils.py:101-122 (gather_nd) + frame_level_models.py:2265-2271 (slim.batch_norm).

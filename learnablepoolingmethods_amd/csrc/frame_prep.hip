@@ -199,6 +199,33 @@ __global__ __launch_bounds__(1024) void frame_bn_bwd_reduce_kernel(const float* 
     }
 }
 
+// Input normalisation of the training step (train.py:262-264, tf.nn.l2_normalize(model_input_raw, 2)): every frame row
+// x <- x * rsqrt(max(sum x^2, 1e-12)).  One wave per row, float4 lanes; one read and one write of the batch.
+__global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __restrict__ x, int64_t rows, int F,
+                                                                float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int F4 = F >> 2;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const float4* src = reinterpret_cast<const float4*>(x + r * F);
+        float4 v[8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (c < F4) ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+        ss = wave_sum(ss);
+        const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+        float4* dst = reinterpret_cast<float4*>(y + r * F);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            if (c < F4) dst[c] = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+        }
+    }
+}
+
 }  // namespace lpm
 
 static inline int fp_nblk(int B, int S) { return (B * S + lpm::FP_ROWS - 1) / lpm::FP_ROWS; }
@@ -269,4 +296,15 @@ extern "C" int lpm_frame_bn_bwd(const float* dy, int64_t lddy, const float* raw,
     hipLaunchKernelGGL(frame_bn_bwd_reduce_kernel, dim3((F + 63) / 64), dim3(1024), 0, s, (const float*)workspace, nblk, F, mean,
                        var, eps, dgamma, dbeta);
     return check_launch("lpm_frame_bn_bwd");
+}
+
+extern "C" int lpm_l2_normalize_rows(const float* x, int64_t rows, int F, float* y, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x && y, LPM_ERR_BADARG, "lpm_l2_normalize_rows: null pointer");
+    LPM_REQUIRE(rows > 0 && F > 0 && F % 4 == 0 && F <= 2048 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_l2_normalize_rows: need F %% 4 == 0, F <= 2048, 16-byte aligned pointers (F=%d)", F);
+    const int64_t want = (rows + 3) / 4;
+    hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       F, y);
+    return check_launch("lpm_l2_normalize_rows");
 }

@@ -332,6 +332,7 @@ static inline int dw_splits(int B, int T, int D, int K) {
     const int steps = B * ((T + 15) / 16);
     int z = (512 + blocks - 1) / blocks;
     if (z > steps / 8) z = steps / 8;
+    if (z > 32) z = 32;                       // the reduce pass reads z partial copies of dW
     return z < 1 ? 1 : z;
 }
 

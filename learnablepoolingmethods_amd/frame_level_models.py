@@ -110,11 +110,15 @@ class NetVladV1(models.BaseModel):
 
         video_NetVLAD = NetVLAD(1024, max_frames, cluster_size, add_batch_norm, is_training, "netvlad_rgb_scope")
         audio_NetVLAD = NetVLAD(128, max_frames, cluster_size // 4, add_batch_norm, is_training, "netvlad_audio_scope")
+        if has_audio and reshaped_input.is_cuda:
+            rgb, audio = ops.split_columns(reshaped_input, 1024)      # the two slices, sharing one gradient buffer
+        else:
+            rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
         with vs.variable_scope("video_VLAD"):
-            vlad_video = video_NetVLAD.forward(reshaped_input[:, 0:1024], kmajor=encoder)     # :2273-2274
+            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder)                           # :2273-2274
         if has_audio:
             with vs.variable_scope("audio_VLAD"):
-                vlad_audio = audio_NetVLAD.forward(reshaped_input[:, 1024:], kmajor=encoder)  # :2276-2277
+                vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder)                     # :2276-2277
 
         if encoder:
             # tokens = clusters (App. C5): the pooling kernel already wrote the [B, K, D] view

@@ -100,6 +100,17 @@ def folded_eval_affine(gamma, beta, moving_mean, moving_var, eps=BN_EPS):
     return scale, beta - moving_mean * scale
 
 
+def l2_normalize_rows(x):
+    """tf.nn.l2_normalize over the last axis of the input batch (train.py:262-264): one read, one write.  The frames are
+    data -- no gradient."""
+    lib = _capi.load()
+    x = _f32(x, "model_input_raw").contiguous()
+    F = x.shape[-1]
+    y = torch.empty_like(x)
+    lib.check(lib._lpm_l2_normalize_rows(ptr(x), x.numel() // F, F, ptr(y), stream_ptr()), "lpm_l2_normalize_rows")
+    return y
+
+
 # ----------------------------------------------------------------------------------------------
 # a2 + a3: SampleUniformFrames + input_bn
 # ----------------------------------------------------------------------------------------------
@@ -159,6 +170,49 @@ class _FrameSampleBN(torch.autograd.Function):
         lib.check(lib._lpm_frame_bn_bwd(ptr(dy), dy.stride(0), ptr(raw), ptr(nf), B, MF, F, ctx.S, ptr(mean), ptr(var),
                                         BN_EPS, ptr(dgamma), ptr(dbeta), ptr(ws), wsb, stream_ptr()), "lpm_frame_bn_bwd")
         return None, None, dgamma, dbeta, None, None, None, None, None
+
+
+class _SplitColumns(torch.autograd.Function):
+    """x [M, F] -> (x[:, :c], x[:, c:]) as views.  The two streams' pooling ops write their input gradients as column views
+    of ONE shared [M, F] buffer (the ``_lpm_dx_slot`` they find on their input), and the backward hands that buffer on as
+    the gradient of x: no zero-fill, scatter-copy and add per stream (what two plain slices cost in autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        a, b = x[:, :c], x[:, c:]
+        slot = {"buf": None, "shape": tuple(x.shape), "device": x.device}
+        ctx.slot, ctx.c = slot, c
+        a._lpm_dx_slot, b._lpm_dx_slot = (slot, 0), (slot, c)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, da, db):
+        slot, c = ctx.slot, ctx.c
+        buf, slot["buf"] = slot["buf"], None
+        M, F = slot["shape"]
+        if (buf is not None and da is not None and db is not None and da.stride() == (F, 1) and db.stride() == (F, 1)
+                and da.data_ptr() == buf.data_ptr() and db.data_ptr() == buf.data_ptr() + c * buf.element_size()):
+            return buf, None
+        if da is None:
+            da = torch.zeros((M, c), dtype=torch.float32, device=slot["device"])
+        if db is None:
+            db = torch.zeros((M, F - c), dtype=torch.float32, device=slot["device"])
+        return torch.cat([da, db], dim=1), None
+
+
+def split_columns(x, c):
+    """(x[:, :c], x[:, c:]) with a shared gradient buffer (see _SplitColumns)."""
+    return _SplitColumns.apply(x, int(c))
+
+
+def _dx_slot_view(slot_ref, D):
+    """The [M, D] column view of the shared input-gradient buffer this op should write dx into (None: allocate its own)."""
+    if slot_ref is None:
+        return None
+    slot, c0 = slot_ref
+    if slot["buf"] is None:
+        slot["buf"] = torch.empty(slot["shape"], dtype=torch.float32, device=slot["device"])
+    return slot["buf"][:, c0:c0 + D]
 
 
 def frame_sample_bn(raw, num_frames, S, gamma=None, beta=None, moving_mean=None, moving_var=None, is_training=True):
@@ -271,13 +325,14 @@ def _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, s
     return dassign, dcentres, (ws, wsb)
 
 
-def _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, like, B, T, D, K):
-    """Second half: dx = sum_k a dU (+ dl . W^T when the assignment GEMM's tiles are given)."""
+def _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, like, B, T, D, K, out=None):
+    """Second half: dx = sum_k a dU (+ dl . W^T when the assignment GEMM's tiles are given), into ``out`` (a [B*T, D] view
+    with unit column stride, e.g. a column slice of a wider gradient buffer) when given."""
     ws, wsb = wspace
-    dx = _empty((B * T, D), like)
+    dx = out if out is not None else _empty((B * T, D), like)
     with _timed("vlad_aggregate_bwd_dx", (B, T, D, K)):
-        lib.check(lib._lpm_vlad_aggregate_bwd_tiles_dx(ptr(ws), wsb, ptr(dlr), ptr(wtt), B, T, D, K, ptr(dx), D, 0, stream_ptr()),
-                  "lpm_vlad_aggregate_bwd_tiles_dx")
+        lib.check(lib._lpm_vlad_aggregate_bwd_tiles_dx(ptr(ws), wsb, ptr(dlr), ptr(wtt), B, T, D, K, ptr(dx), dx.stride(0), 0,
+                                                       stream_ptr()), "lpm_vlad_aggregate_bwd_tiles_dx")
     return dx
 
 
@@ -360,6 +415,7 @@ class _NetVLAD(torch.autograd.Function):
         centres = W2.reshape(D, K).contiguous() if W2 is not None else None
         out, nrm, asum, colsq, csq, gsq, xt = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor)
         ctx.dims = (B, T, D, K, flags, kmajor, use_bn, is_training, W2 is not None, tiles)
+        ctx.dx_slot = getattr(x, "_lpm_dx_slot", None)
         ctx.save_for_backward(x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr)
         return out
 
@@ -401,7 +457,7 @@ class _NetVLAD(torch.autograd.Function):
         else:   # plain fp32 library GEMM (hipBLASLt through torch)
             dW = x.t().matmul(dl)
         if k3_tiles:
-            dx = _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, x, B, T, D, K)
+            dx = _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, x, B, T, D, K, out=_dx_slot_view(ctx.dx_slot, D))
             if not tiles:
                 dx.addmm_(dl, W.t())
         elif tiles:

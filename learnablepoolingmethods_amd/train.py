@@ -208,13 +208,18 @@ class Trainer:
             reg_losses = self.store.pop_regularization_losses()
         return result, reg_losses
 
+    def _normalize_input(self, raw):
+        if raw.is_cuda and raw.shape[-1] % 4 == 0 and raw.shape[-1] <= 2048 and not raw.requires_grad:
+            return ops.l2_normalize_rows(raw)
+        return layers.l2_normalize(raw, 2)
+
     def build(self, model_input_raw, num_frames, labels):
         """Create every variable (a throw-away forward: moving statistics are restored afterwards),
         then move the trainable ones into the flat arenas and set up the gradient buckets."""
         if self.arena is not None:
             return
         with torch.no_grad():
-            x = layers.l2_normalize(model_input_raw.to(self.device), 2)
+            x = self._normalize_input(model_input_raw.to(self.device))
             self._forward(x, num_frames, labels)
             for n, v in self.store.vars.items():       # undo the moving-average side effects of the dry run
                 if n.endswith("/moving_mean"):
@@ -246,7 +251,7 @@ class Trainer:
         num_frames = num_frames.to(dev)
         self.build(model_input_raw, num_frames, labels)
         self.arena.zero_grad()
-        model_input = layers.l2_normalize(model_input_raw, 2)                                   # train.py:262-264
+        model_input = self._normalize_input(model_input_raw)                                    # train.py:262-264
         result, reg_losses = self._forward(model_input, num_frames, labels, **kw)
         predictions = result["predictions"]
         label_loss = result["loss"] if "loss" in result else self.loss_fn.calculate_loss(predictions, labels)  # :291-294
@@ -269,6 +274,6 @@ class Trainer:
     @torch.no_grad()
     def predict(self, model_input_raw, num_frames, **kw):
         """eval.build_graph path: same forward with is_training=False (eval.py:143-150)."""
-        x = layers.l2_normalize(model_input_raw.to(self.device), 2)
+        x = self._normalize_input(model_input_raw.to(self.device))
         result, _ = self._forward(x, num_frames.to(self.device), None, is_training=False, **kw)
         return result["predictions"]

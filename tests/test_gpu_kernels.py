@@ -488,3 +488,16 @@ def test_fused_qkv_projection_through_attention():
     assert_close(xg.grad, x64.grad, 1e-4, "dx")
     for name, a, b in zip("qkv", Wg, W64):
         assert_close(a.grad, b.grad, 1e-4, f"dW{name}")
+
+
+@pytest.mark.parametrize("shape", [(3, 30, 1152), (80, 7, 1024), (2, 5, 128), (1, 1, 2048)])
+def test_l2_normalize_rows(shape):
+    """tf.nn.l2_normalize(model_input_raw, 2) (train.py:262-264), including all-zero (padded) frames (eps clamp)."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(shape[1])
+    x = torch.randn(*shape, generator=g) * 3
+    x[0, 0] = 0.0
+    y = ops.l2_normalize_rows(x.to(dev))
+    assert_close(y, O.l2_normalize(x.double(), 2), 1e-6, "l2_normalize")
+    assert float(y[0, 0].abs().max()) == 0.0
