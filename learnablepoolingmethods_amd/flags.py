@@ -32,6 +32,8 @@ FLAGS.define("netvlad_relu", False, ":2203")
 FLAGS.define("gating", True, ":2205")
 FLAGS.define("gating_remove_diag", False, ":2207")
 FLAGS.define("netvlad_encoder", True, "build extension: False = gated NetVLAD without the cluster encoders (BASELINE cfg-5)")
+FLAGS.define("audio_side_stream", True, "build extension: run the audio stream (NetVLAD + encoder, ~100 latency-bound small "
+             "launches per step) on a second HIP stream next to the video stream")
 FLAGS.define("dense_precision", "bf16x3", "build extension: encoder dense GEMMs as split-bf16 ('bf16x3', ~4e-6) or 'f32'")
 # video_level_models.py
 FLAGS.define("moe_num_mixtures", 2, "video_level_models.py:27")

@@ -114,10 +114,15 @@ class NetVladV1(models.BaseModel):
             rgb, audio = ops.split_columns(reshaped_input, 1024)      # the two slices, sharing one gradient buffer
         else:
             rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
+        # the audio branch is ~100 small, latency-bound launches per step: it runs on a second stream beside the video branch
+        # (variables are still created in the reference's order: video_VLAD, audio_VLAD, video_attention, audio_attention)
+        import contextlib
+        use_side = has_audio and reshaped_input.is_cuda and FLAGS.audio_side_stream
+        side = ops.side_stream(audio, reshaped_input) if use_side else contextlib.nullcontext()
         with vs.variable_scope("video_VLAD"):
             vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder)                           # :2273-2274
         if has_audio:
-            with vs.variable_scope("audio_VLAD"):
+            with side, vs.variable_scope("audio_VLAD"):
                 vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder)                     # :2276-2277
 
         if encoder:
@@ -128,11 +133,13 @@ class NetVladV1(models.BaseModel):
                     ff_relu_dropout=0.1, is_train=is_training, scope_id="encode1")
                 vlad_video = video_encoder_block.forward(vlad_video).reshape(-1, 1024 * cluster_size)        # :2282-2292
             if has_audio:
-                with vs.variable_scope("audio_attention"):
+                with side, vs.variable_scope("audio_attention"):
                     audio_encoder_block = transformer_utils.TransformerEncoder(
                         feature_size=128, hidden_size=128, num_heads=16, attention_dropout=0.1, ff_filter_size=4 * 128,
                         ff_relu_dropout=0.1, is_train=is_training, scope_id="encode2")
                     vlad_audio = audio_encoder_block.forward(vlad_audio).reshape(-1, 128 * (cluster_size // 4))  # :2294-2304
+        if use_side:
+            side.join(vlad_audio)
 
         vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video             # :2309
         return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,

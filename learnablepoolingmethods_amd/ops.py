@@ -172,6 +172,50 @@ class _FrameSampleBN(torch.autograd.Function):
         return None, None, dgamma, dbeta, None, None, None, None, None
 
 
+# ----------------------------------------------------------------------------------------------
+# second HIP stream for the audio branch
+# ----------------------------------------------------------------------------------------------
+_SIDE_STREAMS = {}
+
+
+class side_stream:
+    """``with side_stream(*inputs) as s:`` runs the enclosed launches on a secondary HIP stream that first waits for the
+    work queued so far on the current stream; ``s.join(*outputs)`` makes the current stream wait for it.  Autograd replays
+    every node on the stream its forward ran on, so the backward of the enclosed ops overlaps the same way.  Tensors
+    crossing streams are recorded with the allocator."""
+
+    def __init__(self, *inputs):
+        self.inputs = [t for t in inputs if t is not None]
+        self.forked = False
+
+    def __enter__(self):
+        if not self.forked:                                 # re-entering continues on the side stream without a new fork
+            self.forked = True
+            self.main = torch.cuda.current_stream()
+            dev = self.main.device
+            if dev not in _SIDE_STREAMS:
+                _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            self.side = _SIDE_STREAMS[dev]
+            self.side.wait_stream(self.main)
+            for t in self.inputs:
+                t.record_stream(self.side)
+            for key in ("video", "audio"):                  # tile copies written by frame_sample_bn on the main stream
+                t = _XT_CACHE.get(key)
+                if t is not None:
+                    t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+    def join(self, *outputs):
+        self.main.wait_stream(self.side)
+        for t in outputs:
+            t.record_stream(self.main)
+
+
 class _SplitColumns(torch.autograd.Function):
     """x [M, F] -> (x[:, :c], x[:, c:]) as views.  The two streams' pooling ops write their input gradients as column views
     of ONE shared [M, F] buffer (the ``_lpm_dx_slot`` they find on their input), and the backward hands that buffer on as
