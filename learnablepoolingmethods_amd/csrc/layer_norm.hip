@@ -3,8 +3,11 @@
 // encoder), gamma/beta over the last axis, variance epsilon 1e-12.  A per-row LayerNorm kernel gets 80 rows of
 // 1 MB each -- 80 workgroups on 256 CUs; here each example is cut into row chunks (grid = B x NB) with a
 // partial-sum hand-off between two light HBM-bound passes, and the residual add is fused into pass 1.
-//   fwd : z = a (+ r);  y = (z - mean) * rstd * gamma + beta        saves z, stats[b] = (mean, rstd)
+//   fwd : z = act(a + bias) (+ r);  y = (z - mean) * rstd * gamma + beta        saves z, stats[b] = (mean, rstd)
 //   bwd : g = dy*gamma; dz = rstd * (g - mean_e(g) - zhat * mean_e(g*zhat));  dgamma = sum dy*zhat; dbeta = sum dy
+// The producing dense layer's bias add and ReLU (tf.layers.dense(..., use_bias=True[, activation=relu]) at
+// transformer_utils.py:583 and :708-711) ride in pass 1 of the forward; in the backward da = dz * [a + bias > 0] and
+// dbias = column sums of da come out of the apply pass -- two elementwise passes and a reduction per layer less.
 #include "lpm_common.h"
 
 namespace lpm {
@@ -21,6 +24,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {   // 256 thread
 
 // pass 1: z = a + r (written when r != NULL), partial[b][chunk] = (sum z, sum z^2)
 __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                           const float* __restrict__ bias, int relu, int F,
                                                            int64_t n_per, float* __restrict__ z,
                                                            float* __restrict__ partial) {
     __shared__ float sh[4];
@@ -31,13 +35,21 @@ __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restri
     const float4* rp = r ? reinterpret_cast<const float4*>(r + (int64_t)b * n_per) : nullptr;
     float4* zp = reinterpret_cast<float4*>(z + (int64_t)b * n_per);
     float s = 0.f, q = 0.f;
+    const int F4 = F / 4;
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         float4 v = ap[i];
+        if (bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(bias + (int)(i % F4) * 4);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            if (relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+        }
         if (rp) {
             const float4 w = rp[i];
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-            zp[i] = v;
         }
+        if (rp || bias) zp[i] = v;
         s += (v.x + v.y) + (v.z + v.w);
         q = fmaf(v.x, v.x, q); q = fmaf(v.y, v.y, q); q = fmaf(v.z, v.z, q); q = fmaf(v.w, v.w, q);
     }
@@ -137,13 +149,19 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restri
     }
 }
 
-// backward pass 2: dz = rstd * (g - S1/N - zhat * S2/N)
+// backward pass 2: dz = rstd * (g - S1/N - zhat * S2/N).  With a fused bias (act_a != NULL): da = dz * [act_a + bias > 0]
+// when relu (written to `da`), da = dz otherwise, and the per-(example, chunk) column partials of da -> biaspart for dbias.
+// Threads are laid out (row group, float4 column) with F4 dividing 256 and chunks of whole rows, as in pass 1.
 __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ partial, int64_t n_per, int F,
-                                                           float* __restrict__ dz) {
-    const int b = blockIdx.x, ch = blockIdx.y;
+                                                           const float* __restrict__ partial, int L, int F,
+                                                           float* __restrict__ dz, const float* __restrict__ act_a,
+                                                           const float* __restrict__ bias, int relu, float* __restrict__ da,
+                                                           float* __restrict__ biaspart) {
+    __shared__ float4 cs[256];
+    const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    const int64_t n_per = (int64_t)L * F;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int i = 0; i < LN_NB; ++i) {
@@ -152,22 +170,60 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
     }
     const float m1 = (float)(s1 / (double)n_per), m2 = (float)(s2 / (double)n_per);
     const float mean = stats[2 * b], rstd = stats[2 * b + 1];
-    const int64_t n4 = n_per / 4, per = (n4 + LN_NB - 1) / LN_NB;
-    const int64_t i0 = ch * per, i1 = min(n4, i0 + per);
-    const int F4 = F / 4;
-    const float4* dp = reinterpret_cast<const float4*>(dy + (int64_t)b * n_per);
-    const float4* zp = reinterpret_cast<const float4*>(z + (int64_t)b * n_per);
-    float4* op = reinterpret_cast<float4*>(dz + (int64_t)b * n_per);
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const int c = (int)(i % F4) * 4;
-        const float4 d = dp[i], v = zp[i];
-        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const int F4 = F / 4, RG = 256 / F4;
+    const int c4 = tid % F4, rg = tid / F4;
+    const int rows_per = (L + LN_NB - 1) / LN_NB;
+    const int l0 = ch * rows_per, l1 = min(L, l0 + rows_per);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bb = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    for (int l = l0 + rg; l < l1; l += RG) {
+        const int64_t off = ((int64_t)b * L + l) * F + 4 * c4;
+        const float4 d = *reinterpret_cast<const float4*>(dy + off), v = *reinterpret_cast<const float4*>(z + off);
         float4 o;
         o.x = rstd * (d.x * g.x - m1 - (v.x - mean) * rstd * m2);
         o.y = rstd * (d.y * g.y - m1 - (v.y - mean) * rstd * m2);
         o.z = rstd * (d.z * g.z - m1 - (v.z - mean) * rstd * m2);
         o.w = rstd * (d.w * g.w - m1 - (v.w - mean) * rstd * m2);
-        op[i] = o;
+        *reinterpret_cast<float4*>(dz + off) = o;
+        if (bias) {
+            if (relu) {
+                const float4 av = *reinterpret_cast<const float4*>(act_a + off);
+                o.x = (av.x + bb.x > 0.f) ? o.x : 0.f;
+                o.y = (av.y + bb.y > 0.f) ? o.y : 0.f;
+                o.z = (av.z + bb.z > 0.f) ? o.z : 0.f;
+                o.w = (av.w + bb.w > 0.f) ? o.w : 0.f;
+                *reinterpret_cast<float4*>(da + off) = o;
+            }
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+    }
+    if (bias) {
+        cs[tid] = acc;
+        __syncthreads();
+        if (rg == 0) {
+            for (int i = 1; i < RG; ++i) {
+                const float4 a = cs[i * F4 + c4];
+                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+            }
+            *reinterpret_cast<float4*>(biaspart + ((int64_t)b * LN_NB + ch) * F + 4 * c4) = acc;
+        }
+    }
+}
+
+// [nblk][F] partials -> out [F]
+__global__ __launch_bounds__(1024) void ln_bias_colreduce_kernel(const float* __restrict__ part, int nblk, int F, float* out) {
+    __shared__ double sh[16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0;
+    if (c < F)
+        for (int b = rg; b < nblk; b += 16) s += (double)part[(int64_t)b * F + c];
+    sh[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < F) {
+        for (int i = 1; i < 16; ++i) s += sh[i][cl];
+        out[c] = (float)s;
     }
 }
 
@@ -201,7 +257,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_colreduce_kernel(const float* __r
 }  // namespace lpm
 
 extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
-    return ((size_t)B * lpm::LN_NB * 2 + (size_t)B * lpm::LN_NB * 2 * F) * sizeof(float);
+    return ((size_t)B * lpm::LN_NB * 2 + (size_t)B * lpm::LN_NB * 3 * F) * sizeof(float);
 }
 
 #define LPM_LN_CHECK(name)                                                                                              \
@@ -209,34 +265,52 @@ extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
                 name ": need F in {128,256,512,1024} (F=%d)", F);                                                        \
     LPM_REQUIRE(workspace && workspace_bytes >= lpm_layer_norm_workspace_bytes(B, F), LPM_ERR_WORKSPACE, name ": workspace too small")
 
-extern "C" int lpm_layer_norm_fwd(const float* a, const float* r, const float* gamma, const float* beta, int B, int L, int F,
-                                  float eps, float* y, float* z, float* stats, void* workspace, size_t workspace_bytes,
-                                  lpm_stream_t stream) {
+extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma,
+                                      const float* beta, int B, int L, int F, float eps, float* y, float* z, float* stats,
+                                      void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
     using namespace lpm;
-    LPM_REQUIRE(a && gamma && beta && y && stats && (z || !r), LPM_ERR_BADARG, "lpm_layer_norm_fwd: null pointer (z is required with a residual)");
-    LPM_LN_CHECK("lpm_layer_norm_fwd");
+    LPM_REQUIRE(a && gamma && beta && y && stats && (z || (!r && !bias)), LPM_ERR_BADARG,
+                "lpm_layer_norm_act_fwd: null pointer (z is required with a residual or a bias)");
+    LPM_REQUIRE(bias || !relu, LPM_ERR_BADARG, "lpm_layer_norm_act_fwd: relu needs the bias it follows");
+    LPM_LN_CHECK("lpm_layer_norm_act_fwd");
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
     const int64_t n_per = (int64_t)L * F;
     dim3 grid(B, LN_NB);
-    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, n_per, z, partial);
-    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, r ? z : a, partial, gamma, beta, n_per, F, eps, y, stats);
-    return check_launch("lpm_layer_norm_fwd");
+    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial);
+    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias) ? z : a, partial, gamma, beta, n_per, F, eps, y, stats);
+    return check_launch("lpm_layer_norm_act_fwd");
+}
+
+extern "C" int lpm_layer_norm_fwd(const float* a, const float* r, const float* gamma, const float* beta, int B, int L, int F,
+                                  float eps, float* y, float* z, float* stats, void* workspace, size_t workspace_bytes,
+                                  lpm_stream_t stream) {
+    return lpm_layer_norm_act_fwd(a, nullptr, 0, r, gamma, beta, B, L, F, eps, y, z, stats, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lpm_layer_norm_act_bwd(const float* dy, const float* z, const float* stats, const float* gamma, const float* a,
+                                      const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
+                                      float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dy && z && stats && gamma && dz && dgamma && dbeta, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: null pointer");
+    LPM_REQUIRE(!bias || dbias, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: a fused bias needs dbias");
+    LPM_REQUIRE(!relu || (bias && a && da), LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: relu needs a, bias and da");
+    LPM_LN_CHECK("lpm_layer_norm_act_bwd");
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* colpart = partial + (size_t)B * LN_NB * 2;
+    float* biaspart = colpart + (size_t)B * LN_NB * 2 * F;
+    dim3 grid(B, LN_NB);
+    hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart);
+    hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart);
+    hipLaunchKernelGGL(ln_bwd_colreduce_kernel, dim3((F + 63) / 64), dim3(1024), 0, s, colpart, B * LN_NB, F, dgamma, dbeta);
+    if (bias) hipLaunchKernelGGL(ln_bias_colreduce_kernel, dim3((F + 63) / 64), dim3(1024), 0, s, biaspart, B * LN_NB, F, dbias);
+    return check_launch("lpm_layer_norm_act_bwd");
 }
 
 extern "C" int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, const float* gamma, int B, int L, int F,
                                   float* dz, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                   lpm_stream_t stream) {
-    using namespace lpm;
-    LPM_REQUIRE(dy && z && stats && gamma && dz && dgamma && dbeta, LPM_ERR_BADARG, "lpm_layer_norm_bwd: null pointer");
-    LPM_LN_CHECK("lpm_layer_norm_bwd");
-    hipStream_t s = (hipStream_t)stream;
-    float* partial = (float*)workspace;
-    float* colpart = partial + (size_t)B * LN_NB * 2;
-    const int64_t n_per = (int64_t)L * F;
-    dim3 grid(B, LN_NB);
-    hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart);
-    hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, n_per, F, dz);
-    hipLaunchKernelGGL(ln_bwd_colreduce_kernel, dim3((F + 63) / 64), dim3(1024), 0, s, colpart, B * LN_NB, F, dgamma, dbeta);
-    return check_launch("lpm_layer_norm_bwd");
+    return lpm_layer_norm_act_bwd(dy, z, stats, gamma, nullptr, nullptr, 0, B, L, F, dz, nullptr, dgamma, dbeta, nullptr, workspace,
+                                  workspace_bytes, stream);
 }

@@ -49,15 +49,21 @@ def batch_norm(x: torch.Tensor, is_training: bool, scope: str) -> torch.Tensor:
     return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
 
 
-def layer_norm(x: torch.Tensor, scope: str = "LayerNorm", residual: torch.Tensor = None) -> torch.Tensor:
-    """tf.contrib.layers.layer_norm(x [+ residual]) with TF1 defaults: moments over ALL non-batch axes, gamma/beta
-    [last], eps 1e-12 (transformer_utils.py:407,411,454,713).  [B,L,F] tensors on the GPU take the fused
-    residual + layer-norm HIP kernels (csrc/layer_norm.hip)."""
+def layer_norm(x: torch.Tensor, scope: str = "LayerNorm", residual: torch.Tensor = None, bias: torch.Tensor = None,
+               relu: bool = False) -> torch.Tensor:
+    """tf.contrib.layers.layer_norm(act(x + bias) [+ residual]) with TF1 defaults: moments over ALL non-batch axes,
+    gamma/beta [last], eps 1e-12 (transformer_utils.py:407,411,454,713).  ``bias`` / ``relu`` are the tail of the dense
+    layer that produced x (tf.layers.dense(use_bias=True[, activation=relu])), handed over so that [B,L,F] tensors on the
+    GPU take ONE fused bias + activation + residual + layer-norm kernel pair (csrc/layer_norm.hip)."""
     with vs.variable_scope(scope):
         beta = vs.get_variable("beta", [x.shape[-1]], vs.zeros_initializer(), device=x.device)
         gamma = vs.get_variable("gamma", [x.shape[-1]], vs.ones_initializer(), device=x.device)
     if x.is_cuda and x.dim() == 3 and x.shape[-1] in ops.LN_FEATURES:
-        return ops.residual_layer_norm(x, residual, gamma, beta)
+        return ops.residual_layer_norm(x, residual, gamma, beta, bias=bias, relu=relu)
+    if bias is not None:
+        x = x + bias
+    if relu:
+        x = torch.relu(x)
     if residual is not None:
         x = x + residual
     y = F.layer_norm(x, tuple(x.shape[1:]), None, None, LN_EPS)
@@ -92,14 +98,17 @@ def qkv_projections(queries: torch.Tensor, keys: torch.Tensor, units: int):
             dense(keys, units, use_bias=False, name="v"))
 
 
-def dense(x: torch.Tensor, units: int, use_bias: bool, name: str, activation=None) -> torch.Tensor:
-    """tf.layers.dense: contracts the last axis; glorot-uniform kernel, zero bias."""
+def dense(x: torch.Tensor, units: int, use_bias: bool, name: str, activation=None, defer_bias: bool = False):
+    """tf.layers.dense: contracts the last axis; glorot-uniform kernel, zero bias.  defer_bias: return (x W, bias) and leave
+    the bias add (and activation) to the caller -- the fused layer_norm that follows takes them."""
     kernel, bias = dense_variables(name, x.shape[-1], units, use_bias, x.device)
     rows = x.numel() // x.shape[-1]
     if use_split_gemm(x, rows, units):
         y = ops.dense_x3(x.reshape(rows, x.shape[-1]), kernel).reshape(*x.shape[:-1], units)
     else:
         y = x.matmul(kernel)
+    if defer_bias:
+        return y, bias
     if use_bias:
         y = y + bias
     return activation(y) if activation is not None else y

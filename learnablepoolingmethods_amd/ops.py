@@ -791,42 +791,48 @@ LN_FEATURES = (128, 256, 512, 1024)
 
 
 class _ResidualLayerNorm(torch.autograd.Function):
+    """y = layer_norm(act(a + bias) + r): TF1 joint moments, with the producing dense layer's bias add / ReLU fused in."""
+
     @staticmethod
-    def forward(ctx, a, r, gamma, beta):
+    def forward(ctx, a, r, gamma, beta, bias, relu):
         lib = _capi.load()
         a = _f32(a, "layer_norm input").contiguous()
         B, L, F = a.shape
         r = r.contiguous() if r is not None else None
+        bias = bias.contiguous() if bias is not None else None
         y = torch.empty_like(a)
-        z = torch.empty_like(a) if r is not None else a
+        z = torch.empty_like(a) if (r is not None or bias is not None) else a
         stats = _empty((B, 2), a)
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
-        lib.check(lib._lpm_layer_norm_fwd(ptr(a), ptr(r), ptr(gamma), ptr(beta), B, L, F, LN_EPS, ptr(y),
-                                          ptr(z) if r is not None else None, ptr(stats), ptr(ws), wsb, stream_ptr()),
-                  "lpm_layer_norm_fwd")
-        ctx.has_r = r is not None
-        ctx.save_for_backward(z, stats, gamma)
+        lib.check(lib._lpm_layer_norm_act_fwd(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(gamma), ptr(beta), B, L, F, LN_EPS,
+                                              ptr(y), ptr(z) if z is not a else None, ptr(stats), ptr(ws), wsb, stream_ptr()),
+                  "lpm_layer_norm_act_fwd")
+        ctx.has_r, ctx.relu, ctx.has_bias = r is not None, bool(relu), bias is not None
+        ctx.save_for_backward(z, stats, gamma, a if relu else None, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _capi.load()
-        z, stats, gamma = ctx.saved_tensors
+        z, stats, gamma, a, bias = ctx.saved_tensors
         B, L, F = z.shape
         dy = dy.contiguous()
         dz = torch.empty_like(z)
+        da = torch.empty_like(z) if ctx.relu else None
         dgamma, dbeta = _empty((F,), z), _empty((F,), z)
+        dbias = _empty((F,), z) if ctx.has_bias else None
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=z.device)
-        lib.check(lib._lpm_layer_norm_bwd(ptr(dy), ptr(z), ptr(stats), ptr(gamma), B, L, F, ptr(dz), ptr(dgamma), ptr(dbeta),
-                                          ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_bwd")
-        return dz, (dz if ctx.has_r else None), dgamma, dbeta
+        lib.check(lib._lpm_layer_norm_act_bwd(ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias), 1 if ctx.relu else 0, B, L,
+                                              F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), wsb, stream_ptr()),
+                  "lpm_layer_norm_act_bwd")
+        return (da if ctx.relu else dz), (dz if ctx.has_r else None), dgamma, dbeta, dbias, None
 
 
-def residual_layer_norm(a, r, gamma, beta):
-    """layer_norm(a + r) with TF1 joint moments; a, r: [B, L, F]."""
-    return _ResidualLayerNorm.apply(a, r, gamma, beta)
+def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False):
+    """layer_norm(act(a + bias) + r) with TF1 joint moments; a, r: [B, L, F]; act = relu when ``relu`` (needs ``bias``)."""
+    return _ResidualLayerNorm.apply(a, r, gamma, beta, bias, bool(relu))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -18,12 +18,14 @@ class MultiHeadAttention(modules.BaseModule):
         self.attention_dropout = attention_dropout
         self.is_train = is_train
 
-    def forward(self, queries, keys):
+    def forward(self, queries, keys, defer_bias=False):
+        """defer_bias: return (output without the output_transform bias, bias) -- the caller's fused residual layer_norm adds it."""
         q, k, v = layers.qkv_projections(queries, keys, self.hidden_size)          # :559-561
         depth = self.hidden_size // self.num_heads
         # split_heads, q *= depth**-0.5, softmax(q k^T) v, combine_heads (:564-581): one kernel
         attention_output = ops.mha_core(q, k, v, self.num_heads, depth ** -0.5)
-        return layers.dense(attention_output, self.feature_size, use_bias=True, name="output_transform")  # :583
+        return layers.dense(attention_output, self.feature_size, use_bias=True, name="output_transform",
+                            defer_bias=defer_bias)                                 # :583
 
 
 class MultiHeadAttentionBN(modules.BaseModule):
@@ -63,7 +65,8 @@ class FeedForwardNetwork(modules.BaseModule):
             w1, b1 = layers.dense_variables(n1, inputs.shape[-1], self.filter_size, True, inputs.device)
             w2, b2 = layers.dense_variables(n2, self.filter_size, self.feature_size, True, inputs.device)
             output = ops.ffn_x3(inputs.reshape(rows, inputs.shape[-1]), w1, b1, w2).reshape(*inputs.shape[:-1], self.feature_size)
-            output = torch.relu(output + b2)
+            # relu(output + b2) + inputs, then layer_norm (:708-713): one fused kernel pair
+            return layers.layer_norm(output, "LayerNorm_1", residual=inputs, bias=b2, relu=True)
         else:
             filter_output = layers.dense(inputs, self.filter_size, True, n1, torch.relu)                       # :701-704
             output = layers.dense(filter_output, self.feature_size, True, n2, torch.relu)                      # :708-711
@@ -102,8 +105,8 @@ class TransformerEncoder(modules.BaseModule):
         self.ff_network = FeedForwardNetwork(feature_size, ff_filter_size, ff_relu_dropout, is_train, scope_id)
 
     def forward(self, inputs, **unused_params):
-        attention = self.multi_head_attention.forward(inputs, inputs)
-        attention = layers.layer_norm(attention, "LayerNorm", residual=inputs)         # attention + inputs :405-407
+        attention, bias = self.multi_head_attention.forward(inputs, inputs, defer_bias=True)
+        attention = layers.layer_norm(attention, "LayerNorm", residual=inputs, bias=bias)   # attention + inputs :405-407
         ff_output = self.ff_network.forward(attention)                                 # adds its own residual + LayerNorm_1
         return layers.layer_norm(ff_output, "LayerNorm_2", residual=attention)         # ff_output + attention :409-411
 

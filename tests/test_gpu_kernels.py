@@ -412,6 +412,36 @@ def test_residual_layer_norm(B, L, F, res):
     assert_close(bg.grad, p["ln/beta"].grad, tol=1e-4, what="layer_norm dbeta")
 
 
+@pytest.mark.parametrize("B,L,F,res,relu", [(3, 256, 1024, True, True), (2, 64, 128, True, False), (4, 300, 128, False, True),
+                                             (2, 7, 256, True, True)])
+def test_residual_layer_norm_fused_bias_activation(B, L, F, res, relu):
+    """layer_norm(act(a + bias) + r): the dense layer's bias add / ReLU fused into the residual layer norm
+    (transformer_utils.py:583 + :405-407 and :708-713), backward incl. dbias and the ReLU mask."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(L + F)
+    a, r, dy = (torch.randn(B, L, F, generator=g) for _ in range(3))
+    gamma, beta = 1 + 0.2 * torch.randn(F, generator=g), 0.1 * torch.randn(F, generator=g)
+    bias = 0.3 * torch.randn(F, generator=g)
+    p = {"ln/gamma": gamma.double().requires_grad_(True), "ln/beta": beta.double().requires_grad_(True)}
+    ad, rd, bd = a.double().requires_grad_(True), r.double().requires_grad_(True), bias.double().requires_grad_(True)
+    t = ad + bd
+    if relu:
+        t = torch.relu(t)
+    ref = O.layer_norm(t + rd if res else t, p, "ln")
+    ref.backward(dy.double())
+    ag, rg, gg, bg, biasg = (x.to(dev).requires_grad_(True) for x in (a, r, gamma, beta, bias))
+    y = ops.residual_layer_norm(ag, rg if res else None, gg, bg, bias=biasg, relu=relu)
+    assert_close(y, ref, tol=1e-5, what="layer_norm fwd")
+    y.backward(dy.to(dev))
+    assert_close(ag.grad, ad.grad, tol=1e-4, what="layer_norm da")
+    if res:
+        assert_close(rg.grad, rd.grad, tol=1e-4, what="layer_norm dr")
+    assert_close(gg.grad, p["ln/gamma"].grad, tol=1e-4, what="layer_norm dgamma")
+    assert_close(bg.grad, p["ln/beta"].grad, tol=1e-4, what="layer_norm dbeta")
+    assert_close(biasg.grad, bd.grad, tol=1e-4, what="layer_norm dbias")
+
+
 def test_ffn_split_bf16_fused_bias_relu():
     """FeedForwardNetwork core relu(y W1 + b1) W2 with the inner bias + ReLU fused into the operand split."""
     from learnablepoolingmethods_amd import ops
