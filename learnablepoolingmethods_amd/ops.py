@@ -659,16 +659,14 @@ def _dw_x3(x3, dy3, K, N):
     [3M,K] and [3M,N] their rows pair up plane by plane, so dW = xh^T dyh + xl^T dyh + xh^T dyl is one bf16 GEMM with a
     3M-deep reduction and fp32 accumulation.  hipBLASLt does not split a long reduction with a small output by itself
     (one 61440-deep GEMM: 0.45-0.94 PFLOP/s executed at cfg-2), so it is handed over as a batched GEMM over S slices of the
-    reduction plus a sum, computing dW^T when the output is large (measured best: 0.93-1.1 PFLOP/s, tools/bench_dw_gemms.py)."""
+    reduction plus a sum (0.93-1.06 PFLOP/s, tools/bench_dw_gemms.py; the dW^T form is ~4 % faster still but hands autograd
+    a transposed gradient that it then copies)."""
     M3 = 3 * x3.shape[0]
-    small = K * N <= (1 << 20)
-    S = 8 if small else 4
+    S = 8 if K * N <= (1 << 20) else 4
     if M3 % S or M3 // S < 512:
         return torch.mm(x3.view(M3, K).t(), dy3.view(M3, N), out_dtype=torch.float32)
     xb, db = x3.view(S, M3 // S, K), dy3.view(S, M3 // S, N)
-    if small:
-        return torch.bmm(xb.transpose(1, 2), db, out_dtype=torch.float32).sum(0)
-    return torch.bmm(db.transpose(1, 2), xb, out_dtype=torch.float32).sum(0).t()
+    return torch.bmm(xb.transpose(1, 2), db, out_dtype=torch.float32).sum(0)
 
 
 class _FFNX3(torch.autograd.Function):
