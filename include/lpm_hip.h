@@ -48,6 +48,13 @@ enum {
 int lpm_version(void);
 const char* lpm_last_error(void);
 
+/* Kernel timing for bench.py: while enabled, the K1 (video stream, tag 1) and K2 (tag 2) forward launches are issued with
+ * hipExtLaunchKernelGGL and a start/stop HIP event pair on their own stream, i.e. the elapsed time is the kernel's duration
+ * as rocprofv3 --kernel-trace reports it.  lpm_kernel_timing_read synchronises, returns up to `max` durations (ms) of `tag`
+ * in launch order and releases their events. */
+void lpm_kernel_timing_enable(int on);
+int lpm_kernel_timing_read(int tag, float* ms, int max);
+
 /* Input normalisation of the training step (tf.nn.l2_normalize(model_input_raw, 2), train.py:262-264):
  * y[r,:] = x[r,:] * rsqrt(max(sum x[r,:]^2, 1e-12)) for `rows` rows of F floats (F %% 4 == 0, F <= 2048).  y may alias x. */
 int lpm_l2_normalize_rows(const float* x, int64_t rows, int F, float* y, lpm_stream_t stream);

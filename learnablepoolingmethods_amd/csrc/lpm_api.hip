@@ -1,5 +1,7 @@
 // C-ABI housekeeping: version + thread-local error string (include/lpm_hip.h).
 #include "lpm_common.h"
+#include <mutex>
+#include <vector>
 
 namespace lpm {
 static thread_local char g_err[512] = "";
@@ -9,7 +11,48 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- kernel timing with HIP events attached to the launch itself ---------------------------------------------------------
+// hipExtLaunchKernelGGL stamps a start and a stop event around ONE kernel on its own stream: the elapsed time is the kernel's
+// duration (what rocprofv3 --kernel-trace reports), free of the dispatch gaps an event pair recorded around the launch call
+// also brackets once a second stream is active.  bench.py switches it on for the timed steps (roofline of K2, K1 figure).
+namespace {
+struct TimedLaunch { int tag; hipEvent_t e0, e1; };
+std::mutex g_timing_mu;
+std::vector<TimedLaunch> g_timed;
+bool g_timing_on = false;
+}  // namespace
+bool timing_request(int tag, hipEvent_t* e0, hipEvent_t* e1) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (!g_timing_on) return false;
+    if (hipEventCreate(e0) != hipSuccess || hipEventCreate(e1) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    g_timed.push_back({tag, *e0, *e1});
+    return true;
+}
 }  // namespace lpm
+
+extern "C" void lpm_kernel_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(lpm::g_timing_mu);
+    lpm::g_timing_on = on != 0;
+}
+extern "C" int lpm_kernel_timing_read(int tag, float* ms, int max) {
+    std::lock_guard<std::mutex> lk(lpm::g_timing_mu);
+    int n = 0;
+    std::vector<lpm::TimedLaunch> keep;
+    for (auto& t : lpm::g_timed) {
+        if (t.tag != tag) { keep.push_back(t); continue; }
+        float v = 0.f;
+        if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&v, t.e0, t.e1) == hipSuccess && n < max) ms[n++] = v;
+        else (void)hipGetLastError();
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    lpm::g_timed.swap(keep);
+    return n;
+}
 
 extern "C" int lpm_version(void) { return LPM_VERSION; }
 extern "C" const char* lpm_last_error(void) { return lpm::g_err; }

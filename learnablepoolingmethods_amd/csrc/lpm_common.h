@@ -1,6 +1,7 @@
 // Shared device/host helpers for liblpm_hip.so (gfx950 only: 64-wide wavefronts, MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -17,6 +18,9 @@ constexpr float kL2Eps = 1e-12f;  // tf.nn.l2_normalize epsilon
 
 // thread-local error string behind lpm_last_error()
 void set_error(const char* fmt, ...);
+// kernel timing (lpm_api.hip): when enabled, hands out a start/stop event pair for a hipExtLaunchKernelGGL launch
+enum { LPM_TIMING_K1 = 1, LPM_TIMING_K2 = 2 };
+bool timing_request(int tag, hipEvent_t* e0, hipEvent_t* e1);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

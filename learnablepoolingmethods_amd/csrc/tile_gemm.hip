@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g)
 int tg_ntw(int cols) { const int nt = (cols + 31) / 32; return nt <= 4 ? 1 : (nt <= 8 ? 2 : (nt <= 16 ? 4 : 2)); }
 
 template <int EPI>
-static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override = 0) {
+static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override = 0,
+                     int timing_tag = 0) {
     if (EPI == TG_EPI_STORE && (g.cols_valid % 4 != 0 || g.ldo % 4 != 0 || g.out_batch % 4 != 0 || g.out_split % 4 != 0 ||
                                 ((uintptr_t)g.out & 15) != 0)) {
         set_error("%s: the output needs 16-byte aligned rows (columns and leading dimension multiples of 4)", what);
@@ -246,7 +247,11 @@ static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t 
             set_error("%s: cannot reserve %zu bytes of LDS", what, lds);                                               \
             return LPM_ERR_LAUNCH;                                                                                     \
         }                                                                                                              \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);                                                     \
+        hipEvent_t e0, e1;                                                                                             \
+        if (timing_tag && timing_request(timing_tag, &e0, &e1))                                                        \
+            hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, stream, e0, e1, 0, g);                                   \
+        else                                                                                                           \
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);                                                 \
     } while (0)
     if (ntw == 1) LPM_TG_LAUNCH(1);
     else if (ntw == 2) LPM_TG_LAUNCH(2);
@@ -383,7 +388,7 @@ extern "C" int lpm_assign_gemm_tiles_fwd(const void* xr, const void* wt, int B, 
     g.rb_per_batch = MT / 2; g.steps_per_split = DS; g.total_steps = DS;
     g.out = logits; g.ldo = K; g.out_batch = (int64_t)T * K; g.out_split = 0;
     g.rows_valid = T; g.cols_valid = K; g.accumulate = 0; g.stats = partial;
-    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd");
+    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd", 0, D >= 1024 ? LPM_TIMING_K1 : 0);
 }
 
 extern "C" int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T, int D, int K, float* dx, int64_t lddx,

@@ -249,8 +249,13 @@ extern "C" int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, con
         return LPM_ERR_LAUNCH;
     }
     dim3 grid(B * (K / 128) * (D / 128));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
-                       residual, nrm, asum, colsq_part);
+    hipEvent_t e0, e1;
+    if (timing_request(LPM_TIMING_K2, &e0, &e1))
+        hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T,
+                              D, K, S, KT, residual, nrm, asum, colsq_part);
+    else
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
+                           residual, nrm, asum, colsq_part);
     return check_launch("lpm_vlad_aggregate_tiles3_fwd");
 }
 
