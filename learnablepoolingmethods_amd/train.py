@@ -31,13 +31,15 @@ def learning_rate(base_learning_rate, global_step, batch_size, num_towers, decay
 class ParameterArena:
     """Flat fp32 arenas (param / grad / adam m / adam v) with every trainable variable a view into them."""
 
-    def __init__(self, store: vs.VariableStore, first: Optional[List[str]] = None, gather: bool = False):
+    def __init__(self, store: vs.VariableStore, first: Optional[List[str]] = None, gather: bool = False, bucket_of=None):
         """gather=False: every variable's .grad IS its slice of the gradient arena (autograd accumulates in place; one tiny
         add kernel per variable per step).  gather=True: .grad stays None during backward (autograd adopts each producer's
         tensor) and ``collect`` moves all of them into the arena with one multi-tensor copy."""
         self.gather = gather
         tv = store.trainable_variables()
         names = [n for n in (first or []) if n in tv] + [n for n in tv if n not in (first or [])]
+        if bucket_of is not None:             # stable sort: variables of one all-reduce bucket are contiguous in the arena
+            names = sorted(names, key=bucket_of)
         self.names = names
         offs, cur = [], 0
         for n in names:
@@ -79,8 +81,26 @@ class ParameterArena:
         t._lpm_grad_ready = on_ready
         self.direct.append((name, a0, t.numel()))
 
-    def collect(self):
-        """After backward: make the gradient arena complete.  Direct variables: a producer that was not reached leaves a
+    def gather_names(self, names):
+        """Copy the gradients of ``names`` (gather mode) into their arena slices and release them."""
+        dst, src = [], []
+        with torch.no_grad():
+            for name in names:
+                t, gv = self.views[name], self.grad_views[name]
+                g = t.grad
+                if g is None:
+                    gv.zero_()
+                elif g.is_contiguous() and g.dtype == gv.dtype:
+                    dst.append(gv)
+                    src.append(g)
+                else:
+                    gv.copy_(g)
+                t.grad = None
+            if dst:
+                torch._foreach_copy_(dst, src)
+
+    def collect(self, skip=()):
+        """After backward: make the gradient arena complete (``skip``: names already gathered by a bucket hook).  Direct variables: a producer that was not reached leaves a
         zero gradient, anything autograd accumulated on the side is folded in.  gather mode: every other variable's
         gradient is copied into its arena slice (one multi-tensor copy for the contiguous ones)."""
         direct = set()
@@ -94,23 +114,7 @@ class ParameterArena:
                 t.grad = None
         if not self.gather:
             return
-        dst, src = [], []
-        with torch.no_grad():
-            for name in self.names:
-                if name in direct:
-                    continue
-                t, gv = self.views[name], self.grad_views[name]
-                g = t.grad
-                if g is None:
-                    gv.zero_()
-                elif g.is_contiguous() and g.dtype == gv.dtype:
-                    dst.append(gv)
-                    src.append(g)
-                else:
-                    gv.copy_(g)
-                t.grad = None
-            if dst:
-                torch._foreach_copy_(dst, src)
+        self.gather_names([n for n in self.names if n not in direct and n not in skip])
 
     def segment(self, name: str):
         i = self.names.index(name)
@@ -158,6 +162,9 @@ class GradientSynchronizer:
         if not self.active or i in self.done:
             return
         a, b = self.buckets[i]
+        if b <= a:
+            self.done.add(i)
+            return
         self.pending.append(dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.done.add(i)
 
@@ -167,6 +174,69 @@ class GradientSynchronizer:
         for w in self.pending:
             w.wait()
         self.pending, self.done = [], set()
+
+
+def dp_bucket_of(name: str) -> int:
+    """All-reduce buckets in the order backward completes them: 1 head (MoE, gating, hidden1_bn) -> 0 hidden1_weights ->
+    2 encoders -> 3 NetVLAD pooling + input_bn.  (0 comes first in the arena: the optimiser kernel wants it chunk-aligned
+    at the front and it is 85 % of the payload.)"""
+    if name.endswith("hidden1_weights"):
+        return 0
+    if "_attention/" in name or "cluster_attention" in name:
+        return 2
+    if "_VLAD/" in name or "input_bn" in name:
+        return 3
+    return 1
+
+
+class BucketGather:
+    """Data parallelism in gather mode: the moment every variable of a bucket has its gradient (autograd post-accumulate
+    hooks, counted per step), the bucket is copied into the gradient arena and its all-reduce is launched -- the head
+    bucket rides under the whole backward, the encoder bucket under the NetVLAD backward; only the small pooling bucket is
+    exposed.  Gradients of the audio branch are produced on the side stream: the gather runs on the main stream after it
+    has been made to wait for every stream that was used."""
+
+    def __init__(self, arena: ParameterArena, sync: "GradientSynchronizer", bucket_names: Dict[int, List[str]], early: List[int]):
+        self.arena, self.sync = arena, sync
+        self.bucket_names = bucket_names
+        self.early = [b for b in early if bucket_names.get(b)]
+        self.owner = {n: b for b in self.early for n in bucket_names[b]}
+        self.seen: Dict[int, set] = {}
+        self.gathered = set()
+        self.main_stream = None
+        for n, b in self.owner.items():
+            arena.views[n].register_post_accumulate_grad_hook(lambda p, n=n, b=b: self._hook(n, b))
+
+    def arm(self):
+        self.seen = {b: set() for b in self.early}
+        self.gathered = set()
+        if self.arena.device.type == "cuda":
+            self.main_stream = torch.cuda.current_stream()
+
+    def _hook(self, name, b):
+        seen = self.seen.get(b)
+        if seen is None or b in self.gathered:
+            return
+        seen.add(name)
+        if len(seen) < len(self.bucket_names[b]):
+            return
+        self.gathered.add(b)
+        if self.main_stream is not None:
+            from . import ops
+            cur = torch.cuda.current_stream()          # the stream of the node whose gradient completed the bucket
+            with torch.cuda.stream(self.main_stream):
+                if cur != self.main_stream:
+                    self.main_stream.wait_stream(cur)
+                for side in ops._SIDE_STREAMS.values():
+                    self.main_stream.wait_stream(side)
+                self.arena.gather_names(self.bucket_names[b])
+                self.sync.launch(b)
+        else:
+            self.arena.gather_names(self.bucket_names[b])
+            self.sync.launch(b)
+
+    def gathered_names(self):
+        return {n for b in self.gathered for n in self.bucket_names[b]}
 
 
 class Trainer:
@@ -192,6 +262,7 @@ class Trainer:
         self.global_step = 0
         self.arena: Optional[ParameterArena] = None
         self.sync: Optional[GradientSynchronizer] = None
+        self.bucket_gather = None
 
     @property
     def num_towers(self) -> int:
@@ -226,9 +297,19 @@ class Trainer:
                     v.zero_()
                 elif n.endswith("/moving_variance"):
                     v.fill_(1.0)
-        self.arena = ParameterArena(self.store, first=["tower/hidden1_weights"], gather=self.device.type == "cuda")
-        a0, a1 = self.arena.segment("tower/hidden1_weights")
-        self.sync = GradientSynchronizer(self.arena.grad, [(a0, a1), (a1, self.arena.total)], self.group)
+        gather = self.device.type == "cuda"
+        self.arena = ParameterArena(self.store, first=["tower/hidden1_weights"], gather=gather, bucket_of=dp_bucket_of)
+        bucket_names: Dict[int, List[str]] = {}
+        for n in self.arena.names:
+            bucket_names.setdefault(dp_bucket_of(n), []).append(n)
+        ranges = []
+        for b in range(4):                                # contiguous arena slice per bucket (empty buckets: empty slice)
+            names = bucket_names.get(b, [])
+            if names:
+                ranges.append((self.arena.segment(names[0])[0], self.arena.segment(names[-1])[1]))
+            else:
+                ranges.append((ranges[-1][1], ranges[-1][1]) if ranges else (0, 0))
+        self.sync = GradientSynchronizer(self.arena.grad, ranges, self.group)
         # hidden1_weights' gradient is complete right after the projection GEMM's backward: start its all-reduce
         # there and let it ride under the encoder / NetVLAD backward.
         early = (lambda: self.sync.launch(0)) if self.sync.active else None
@@ -236,6 +317,11 @@ class Trainer:
             self.arena.mark_direct("tower/hidden1_weights", on_ready=early)
         elif early is not None:
             self.arena.views["tower/hidden1_weights"].register_post_accumulate_grad_hook(lambda p: early())
+        # the head and encoder buckets are gathered + all-reduced from hooks as backward completes them
+        import os
+        early_buckets = [int(b) for b in os.environ.get("LPM_DP_EARLY_BUCKETS", "1,2").split(",") if b != ""]
+        self.bucket_gather = (BucketGather(self.arena, self.sync, bucket_names, early=early_buckets)
+                              if (gather and self.sync.active and early_buckets) else None)
         if self.sync.active:
             # every rank must start from identical weights (the reference shares variables across towers)
             dist.broadcast(self.arena.param, src=0, group=self.group)
@@ -251,6 +337,8 @@ class Trainer:
         num_frames = num_frames.to(dev)
         self.build(model_input_raw, num_frames, labels)
         self.arena.zero_grad()
+        if self.bucket_gather is not None:
+            self.bucket_gather.arm()
         model_input = self._normalize_input(model_input_raw)                                    # train.py:262-264
         result, reg_losses = self._forward(model_input, num_frames, labels, **kw)
         predictions = result["predictions"]
@@ -260,7 +348,7 @@ class Trainer:
             reg_loss = reg_loss + torch.stack(reg_losses).sum()                                 # :301-303
         final_loss = self.reg_penalty * reg_loss + label_loss                                   # :321
         final_loss.backward()                                                                   # :322-323
-        self.arena.collect()
+        self.arena.collect(skip=self.bucket_gather.gathered_names() if self.bucket_gather is not None else ())
         self.sync.finish()                                                                      # utils.combine_gradients :330
         lr = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers,
                            self.lr_decay_examples, self.lr_decay)                               # :244-249

@@ -103,3 +103,87 @@ def test_gradient_sum_allreduce_matches_tower_combine():
     # SUM, not mean
     mean = {n: ref[n] / world for n in ref}
     assert not torch.allclose(res[0][0]["tower/hidden1_weights"], mean["tower/hidden1_weights"])
+
+
+# ---- gather-mode arenas with per-bucket hooks (the GPU trainer's data-parallel path, exercised here on CPU/gloo) --------
+_BUCKET_VARS = {"tower/hidden1_weights": [10, 6], "tower/hidden1_bn/beta": [6], "tower/gates/weights": [6, 4],
+                "tower/video_attention/q/kernel": [10, 10], "tower/audio_attention/LayerNorm/gamma": [10],
+                "tower/video_VLAD/cluster_weights": [10, 10], "tower/input_bn/gamma": [10]}
+
+
+def _bucket_loss(v, x, y):
+    x = x * v["tower/input_bn/gamma"]
+    x = torch.tanh(x @ v["tower/video_VLAD/cluster_weights"])
+    x = x + torch.tanh(x @ v["tower/video_attention/q/kernel"]) * v["tower/audio_attention/LayerNorm/gamma"]
+    h = torch.tanh(x @ v["tower/hidden1_weights"] + v["tower/hidden1_bn/beta"])
+    return ((torch.sigmoid(h @ v["tower/gates/weights"]) - y) ** 2).sum(dim=1).mean()
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from learnablepoolingmethods_amd import train
+    from learnablepoolingmethods_amd import variables as vs
+    store = vs.VariableStore(device="cpu", seed=rank)
+    with vs.use_store(store):
+        for n, shape in _BUCKET_VARS.items():
+            vs.get_variable(n, shape, vs.random_normal_initializer(0.3))
+    arena = train.ParameterArena(store, first=["tower/hidden1_weights"], gather=True, bucket_of=train.dp_bucket_of)
+    names = {}
+    for n in arena.names:
+        names.setdefault(train.dp_bucket_of(n), []).append(n)
+    ranges = [(arena.segment(names[b][0])[0], arena.segment(names[b][-1])[1]) for b in range(4)]
+    sync = train.GradientSynchronizer(arena.grad, ranges)
+    bg = train.BucketGather(arena, sync, names, early=[0, 1, 2])
+    dist.broadcast(arena.param, src=0)
+    g = torch.Generator().manual_seed(11)
+    X, Y = torch.randn(8, 10, generator=g), torch.rand(8, 4, generator=g)
+    sl = slice(rank * 4, rank * 4 + 4)
+    out = []
+    for step in range(2):                                  # twice: the per-step re-arming must work
+        arena.zero_grad()
+        bg.arm()
+        _bucket_loss(arena.views, X[sl], Y[sl]).backward()
+        early = sorted(bg.gathered)
+        arena.collect(skip=bg.gathered_names())
+        sync.finish()
+        out.append(({n: arena.grad_views[n].detach().numpy().copy() for n in arena.names}, early))
+    params = {n: arena.views[n].detach().numpy().copy() for n in arena.names}
+    q.put((rank, out, params, [list(r) for r in ranges], list(arena.names)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bucketed_gather_allreduce():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, out, params, ranges, names = q.get(timeout=120)
+        res[r] = (out, {n: torch.from_numpy(v) for n, v in params.items()}, ranges, names)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from learnablepoolingmethods_amd import train
+    names = res[0][3]
+    assert [train.dp_bucket_of(n) for n in names] == sorted(train.dp_bucket_of(n) for n in names), "buckets contiguous in the arena"
+    assert names[0] == "tower/hidden1_weights"
+    g = torch.Generator().manual_seed(11)
+    X, Y = torch.randn(8, 10, generator=g), torch.rand(8, 4, generator=g)
+    tower = []
+    for r in range(world):
+        leaf = {n: v.clone().requires_grad_(True) for n, v in res[0][1].items()}
+        _bucket_loss(leaf, X[r * 4:(r + 1) * 4], Y[r * 4:(r + 1) * 4]).backward()
+        tower.append({n: v.grad for n, v in leaf.items()})
+    ref = O.combine_gradients(tower)
+    for r in range(world):
+        for grads, early in res[r][0]:
+            assert early == [0, 1, 2], "head, hidden1 and encoder buckets must be gathered + launched from their hooks"
+            for n in ref:
+                assert torch.allclose(torch.from_numpy(grads[n]), ref[n], rtol=1e-6, atol=1e-7), n
