@@ -59,6 +59,12 @@ int lpm_kernel_timing_read(int tag, float* ms, int max);
  * y[r,:] = x[r,:] * rsqrt(max(sum x[r,:]^2, 1e-12)) for `rows` rows of F floats (F %% 4 == 0, F <= 2048).  y may alias x. */
 int lpm_l2_normalize_rows(const float* x, int64_t rows, int F, float* y, lpm_stream_t stream);
 
+/* The frame reader's tail folded into the same pass (readers.py:176-193, utils.py:28-43, train.py:262-264): quantised uint8
+ * frames q [B, max_frames, F] -> Dequantize (q * range/255 + range/512 + min) -> frames >= num_frames[b] set to 0 (the
+ * reader pads after dequantising) -> per-frame L2 normalisation -> y fp32 [B, max_frames, F].  F %% 4 == 0, F <= 2048. */
+int lpm_dequantize_l2_normalize(const unsigned char* q, const int32_t* num_frames, int B, int max_frames, int F,
+                                float max_quantized_value, float min_quantized_value, float* y, lpm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a2 + a3: SampleUniformFrames + input_bn
  *   replaces model_utils.py:101-122 (gather_nd) + frame_level_models.py:2265-2271 (slim.batch_norm).

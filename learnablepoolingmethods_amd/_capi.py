@@ -31,6 +31,7 @@ SIGNATURES = {
     "lpm_kernel_timing_enable": (None, [_i]),
     "lpm_kernel_timing_read": (_i, [_i, C.POINTER(C.c_float), _i]),
     "lpm_l2_normalize_rows": (_i, [_f, _l, _i, _f, _f]),
+    "lpm_dequantize_l2_normalize": (_i, [_f, _f, _i, _i, _i, _fl, _fl, _f, _f]),
     "lpm_frame_stats_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_frame_stats": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),
     "lpm_frame_apply": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f]),

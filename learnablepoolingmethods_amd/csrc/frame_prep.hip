@@ -199,6 +199,46 @@ __global__ __launch_bounds__(1024) void frame_bn_bwd_reduce_kernel(const float* 
     }
 }
 
+// The reader's output folded into the same pass (readers.py:176-193 + utils.py:28-43 + train.py:262-264): quantised uint8
+// frames -> Dequantize (q * range/255 + range/512 + min) -> zero the frames at and beyond num_frames (the reader pads
+// AFTER dequantising, so padding is exactly 0) -> L2-normalise each frame.  1 byte read, 4 bytes written per feature.
+__global__ __launch_bounds__(256) void dequantize_l2_normalize_kernel(const unsigned char* __restrict__ q,
+                                                                      const int32_t* __restrict__ num_frames, int64_t rows,
+                                                                      int max_frames, int F, float scalar, float bias,
+                                                                      float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int F4 = F >> 2;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int b = (int)(r / max_frames), t = (int)(r % max_frames);
+        float4* dst = reinterpret_cast<float4*>(y + r * F);
+        if (t >= num_frames[b]) {                       // wave-uniform
+            for (int c = lane; c < F4; c += 64) dst[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const uchar4* src = reinterpret_cast<const uchar4*>(q + r * F);
+        float4 v[8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < F4) {
+                const uchar4 u = src[c];
+                v[i] = make_float4(fmaf((float)u.x, scalar, bias), fmaf((float)u.y, scalar, bias), fmaf((float)u.z, scalar, bias),
+                                   fmaf((float)u.w, scalar, bias));
+            }
+            ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+        ss = wave_sum(ss);
+        const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            if (c < F4) dst[c] = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+        }
+    }
+}
+
 // Input normalisation of the training step (train.py:262-264, tf.nn.l2_normalize(model_input_raw, 2)): every frame row
 // x <- x * rsqrt(max(sum x^2, 1e-12)).  One wave per row, float4 lanes; one read and one write of the batch.
 __global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __restrict__ x, int64_t rows, int F,
@@ -307,4 +347,19 @@ extern "C" int lpm_l2_normalize_rows(const float* x, int64_t rows, int F, float*
     hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, rows,
                        F, y);
     return check_launch("lpm_l2_normalize_rows");
+}
+
+extern "C" int lpm_dequantize_l2_normalize(const unsigned char* q, const int32_t* num_frames, int B, int max_frames, int F,
+                                           float max_quantized_value, float min_quantized_value, float* y, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && num_frames && y, LPM_ERR_BADARG, "lpm_dequantize_l2_normalize: null pointer");
+    LPM_REQUIRE(max_quantized_value > min_quantized_value, LPM_ERR_BADARG, "lpm_dequantize_l2_normalize: empty quantisation range");
+    LPM_REQUIRE(B > 0 && max_frames > 0 && F > 0 && F % 4 == 0 && F <= 2048 && (((uintptr_t)q & 3) | ((uintptr_t)y & 15)) == 0,
+                LPM_ERR_UNSUPPORTED_SHAPE, "lpm_dequantize_l2_normalize: need F %% 4 == 0, F <= 2048, aligned pointers (F=%d)", F);
+    const float range = max_quantized_value - min_quantized_value;
+    const float scalar = range / 255.0f, bias = range / 512.0f + min_quantized_value;
+    const int64_t rows = (int64_t)B * max_frames, want = (rows + 3) / 4;
+    hipLaunchKernelGGL(dequantize_l2_normalize_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, q,
+                       num_frames, rows, max_frames, F, scalar, bias, y);
+    return check_launch("lpm_dequantize_l2_normalize");
 }

@@ -111,6 +111,23 @@ def l2_normalize_rows(x):
     return y
 
 
+def dequantize_l2_normalize(q, num_frames, max_quantized_value=2.0, min_quantized_value=-2.0):
+    """Quantised reader output (uint8 [B, max_frames, F]) -> dequantised (utils.Dequantize), zero-padded past num_frames,
+    L2-normalised fp32 frames: the reader's tail (readers.py:176-193) and train.py:262-264 as one pass."""
+    lib = _capi.load()
+    if q.dtype != torch.uint8 or q.dim() != 3:
+        raise LpmError("dequantize_l2_normalize: expected a uint8 [batch, max_frames, feature] tensor")
+    q = q.contiguous()
+    B, MF, F = q.shape
+    nf = num_frames.to(device=q.device, dtype=torch.int32).reshape(-1).contiguous()
+    if nf.numel() != B:
+        raise LpmError("dequantize_l2_normalize: num_frames must have one entry per clip")
+    y = torch.empty((B, MF, F), dtype=torch.float32, device=q.device)
+    lib.check(lib._lpm_dequantize_l2_normalize(ptr(q), ptr(nf), B, MF, F, float(max_quantized_value), float(min_quantized_value),
+                                               ptr(y), stream_ptr()), "lpm_dequantize_l2_normalize")
+    return y
+
+
 # ----------------------------------------------------------------------------------------------
 # a2 + a3: SampleUniformFrames + input_bn
 # ----------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
-from . import FLAGS, layers, losses, ops
+from . import FLAGS, layers, losses, ops, utils
 from . import variables as vs
 
 ARENA_ALIGN = 4096   # LPM_ARENA_ALIGN: every variable starts on a chunk boundary of the optimizer kernel
@@ -279,7 +279,13 @@ class Trainer:
             reg_losses = self.store.pop_regularization_losses()
         return result, reg_losses
 
-    def _normalize_input(self, raw):
+    def _normalize_input(self, raw, num_frames=None):
+        if raw.dtype == torch.uint8:          # quantised reader output: dequantise + pad + normalise in one pass
+            if raw.is_cuda:
+                return ops.dequantize_l2_normalize(raw, num_frames)
+            t = torch.arange(raw.shape[1], device=raw.device).view(1, -1, 1)
+            x = torch.where(t < num_frames.view(-1, 1, 1), utils.Dequantize(raw.float()), torch.zeros((), device=raw.device))
+            return layers.l2_normalize(x, 2)
         if raw.is_cuda and raw.shape[-1] % 4 == 0 and raw.shape[-1] <= 2048 and not raw.requires_grad:
             return ops.l2_normalize_rows(raw)
         return layers.l2_normalize(raw, 2)
@@ -290,7 +296,7 @@ class Trainer:
         if self.arena is not None:
             return
         with torch.no_grad():
-            x = self._normalize_input(model_input_raw.to(self.device))
+            x = self._normalize_input(model_input_raw.to(self.device), num_frames.to(self.device))
             self._forward(x, num_frames, labels)
             for n, v in self.store.vars.items():       # undo the moving-average side effects of the dry run
                 if n.endswith("/moving_mean"):
@@ -339,7 +345,7 @@ class Trainer:
         self.arena.zero_grad()
         if self.bucket_gather is not None:
             self.bucket_gather.arm()
-        model_input = self._normalize_input(model_input_raw)                                    # train.py:262-264
+        model_input = self._normalize_input(model_input_raw, num_frames)                        # train.py:262-264
         result, reg_losses = self._forward(model_input, num_frames, labels, **kw)
         predictions = result["predictions"]
         label_loss = result["loss"] if "loss" in result else self.loss_fn.calculate_loss(predictions, labels)  # :291-294
@@ -362,6 +368,6 @@ class Trainer:
     @torch.no_grad()
     def predict(self, model_input_raw, num_frames, **kw):
         """eval.build_graph path: same forward with is_training=False (eval.py:143-150)."""
-        x = self._normalize_input(model_input_raw.to(self.device))
+        x = self._normalize_input(model_input_raw.to(self.device), num_frames.to(self.device))
         result, _ = self._forward(x, num_frames.to(self.device), None, is_training=False, **kw)
         return result["predictions"]

@@ -183,3 +183,28 @@ def test_train_steps_v2():
     cfg = O.OracleConfig(model="NetVladV2", iterations=12, cluster_size=16, hidden_size=32, vocab_size=40,
                          base_learning_rate=1e-3, v2_dropout_rate=0.0)
     _train_compare("NetVladV2", cfg, 1152, 4, 16, 2, dev, dropout_rate=0.0)
+
+
+def test_train_step_accepts_quantised_reader_output():
+    """The trainer fed with the reader's uint8 frames (dequantise + pad + L2-normalise fused on the device) takes the same
+    step as when fed the reference's float matrix."""
+    from learnablepoolingmethods_amd import registry, utils
+    from learnablepoolingmethods_amd.train import Trainer
+    dev = cuda()
+    B, MF = 4, 30
+    g = torch.Generator().manual_seed(5)
+    q = torch.randint(0, 256, (B, MF, 1152), generator=g, dtype=torch.uint8)
+    nf = torch.tensor([30, 12, 25, 7], dtype=torch.int32)
+    lab = torch.zeros(B, 40)
+    lab[torch.arange(B), torch.tensor([1, 5, 9, 30])] = 1.0
+    t = torch.arange(MF).view(1, -1, 1)
+    raw = torch.where(t < nf.view(-1, 1, 1), utils.Dequantize(q.float()), torch.zeros(()))
+    outs = []
+    for x in (q, raw):
+        tr = Trainer(registry.get_model("NetVladV1"), vocab_size=40, batch_size=B, base_learning_rate=1e-3, device=dev, seed=3,
+                     model_kwargs=dict(iterations=30, cluster_size=32, hidden_size=64))
+        outs.append(tr.step(x, nf, lab))
+    # the two paths round the dequantised value differently (one fma on the device vs multiply + add on the host): 1e-7 on the
+    # inputs, amplified by the freshly initialised (saturating) network
+    assert_close(outs[0]["loss"], outs[1]["loss"].double().cpu(), 1e-4, "loss")
+    assert_close(outs[0]["predictions"], outs[1]["predictions"].double().cpu(), 1e-3, "predictions")
