@@ -32,6 +32,9 @@ FLAGS.define("netvlad_relu", False, ":2203")
 FLAGS.define("gating", True, ":2205")
 FLAGS.define("gating_remove_diag", False, ":2207")
 FLAGS.define("netvlad_encoder", True, "build extension: False = gated NetVLAD without the cluster encoders (BASELINE cfg-5)")
+FLAGS.define("sample_random_frames", True, "frame_level_models.py:40: random frames (True) or a random contiguous sequence")
+FLAGS.define("rgb_det_reg", 1e-4, "frame_level_models.py:2213: orthogonality penalty on the rgb cluster centres (WillowModelReg)")
+FLAGS.define("audio_det_reg", 1e-4, "frame_level_models.py:2209: orthogonality penalty on the audio cluster centres")
 FLAGS.define("audio_side_stream", True, "build extension: run the audio stream (NetVLAD + encoder, ~100 latency-bound small "
              "launches per step) on a second HIP stream next to the video stream")
 FLAGS.define("dense_precision", "bf16x3", "build extension: encoder dense GEMMs as split-bf16 ('bf16x3', ~4e-6) or 'f32'")

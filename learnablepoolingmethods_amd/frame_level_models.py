@@ -12,7 +12,7 @@ import math
 
 import torch
 
-from . import FLAGS, layers, models, ops, transformer_utils, video_level_models, video_pooling_modules
+from . import FLAGS, layers, model_utils, models, ops, transformer_utils, video_level_models, video_pooling_modules
 from . import variables as vs
 
 
@@ -142,6 +142,40 @@ class NetVladV1(models.BaseModel):
             side.join(vlad_audio)
 
         vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video             # :2309
+        return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
+                                      remove_diag, is_training, **unused_params)
+
+
+class WillowModelReg(models.BaseModel):
+    """WILLOW model with orthogonal regularisation (frame_level_models.py:2516-2635): random frame
+    sampling, input_bn, NetVladOrthoReg on both streams, then the shared projection / context gating / MoE tail."""
+
+    def create_model(self, model_input, vocab_size, num_frames, iterations=None, add_batch_norm=None,
+                     sample_random_frames=None, cluster_size=None, hidden_size=None, is_training=True,
+                     frame_uniform=None, **unused_params):
+        iterations = iterations or FLAGS.iterations
+        add_batch_norm = add_batch_norm or FLAGS.netvlad_add_batch_norm
+        random_frames = sample_random_frames or FLAGS.sample_random_frames
+        cluster_size = cluster_size or FLAGS.netvlad_cluster_size
+        hidden1_size = hidden_size or FLAGS.netvlad_hidden_size
+        relu, gating, remove_diag = FLAGS.netvlad_relu, FLAGS.gating, FLAGS.gating_remove_diag
+        unused_params.pop("labels", None)
+        sampler = model_utils.SampleRandomFrames if random_frames else model_utils.SampleRandomSequence
+        model_input = sampler(model_input, num_frames.reshape(-1, 1), iterations, uniform=frame_uniform)      # :2539-2544
+        max_frames, feature_size = model_input.shape[1], model_input.shape[2]
+        reshaped_input = model_input.reshape(-1, feature_size)
+        video_NetVLAD = video_pooling_modules.NetVladOrthoReg(1024, max_frames, cluster_size, add_batch_norm, is_training,
+                                                              FLAGS.rgb_det_reg, "netvlad_rgb_scope")
+        audio_NetVLAD = video_pooling_modules.NetVladOrthoReg(128, max_frames, cluster_size // 4, add_batch_norm, is_training,
+                                                              FLAGS.audio_det_reg, "netvlad_audio_scope")
+        if add_batch_norm:
+            reshaped_input = layers.batch_norm(reshaped_input, is_training, "input_bn")                       # :2558-2564
+        has_audio = feature_size > 1024                                                                       # App. C9
+        with vs.variable_scope("video_VLAD"):
+            vlad = video_NetVLAD.forward(reshaped_input[:, 0:1024])
+        if has_audio:
+            with vs.variable_scope("audio_VLAD"):
+                vlad = torch.cat([vlad, audio_NetVLAD.forward(reshaped_input[:, 1024:])], 1)
         return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
                                       remove_diag, is_training, **unused_params)
 

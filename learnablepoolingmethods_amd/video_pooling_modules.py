@@ -1,10 +1,43 @@
-"""NetVladAttenCluster (reference: video_pooling_modules.py:1589-1663)."""
+"""NetVladOrthoReg and NetVladAttenCluster (reference: video_pooling_modules.py:1499-1586, 1589-1663)."""
 from __future__ import annotations
 
 import math
 
-from . import modules, ops, transformer_utils
+from . import layers, module_utils, modules, ops, transformer_utils
 from . import variables as vs
+
+
+class NetVladOrthoReg(modules.BaseModule):
+    """NetVLAD from WILLOW's model with orthogonal regularisation (video_pooling_modules.py:1499-1586): the pooling is
+    NetVLAD's (same K1/K2/K3 kernels) with a 2-D ``cluster_weights2`` [D, K] and scope-id-suffixed variable names; the
+    penalty ``det_reg * sum |W2n^T W2n - I|`` is collected as a regularisation loss."""
+
+    def __init__(self, feature_size, max_frames, cluster_size, batch_norm, is_training, det_reg=None, scope_id=None):
+        self.feature_size = feature_size
+        self.max_frames = max_frames
+        self.is_training = is_training
+        self.batch_norm = batch_norm
+        self.cluster_size = int(cluster_size)
+        self.det_reg = det_reg
+        self.scope_id = scope_id
+
+    def forward(self, inputs, **unused_params):
+        D, K, dev = self.feature_size, self.cluster_size, inputs.device
+        sid = "" if self.scope_id is None else str(self.scope_id)
+        std = 1 / math.sqrt(D)
+        cluster_weights = vs.get_variable("cluster_weights" + sid, [D, K], vs.random_normal_initializer(std), device=dev)
+        bn = bias = None
+        if self.batch_norm:
+            bn = layers.bn_variables("cluster_bn", K, dev)
+        else:
+            bias = vs.get_variable("cluster_biases" + sid, [K], vs.random_normal_initializer(std), device=dev)
+        cluster_weights2 = vs.get_variable("cluster_weights2", [D, K], vs.random_normal_initializer(std), device=dev)
+        if self.det_reg is not None:
+            reg = module_utils.orthogonal_regularizer(self.det_reg, self.scope_id)(cluster_weights2)
+            if reg is not None:
+                vs.default_store().add_regularization_loss(reg)
+        return ops.netvlad(inputs, cluster_weights, cluster_weights2.reshape(1, D, K), self.max_frames, bn=bn, bias=bias,
+                           is_training=self.is_training)
 
 
 class NetVladAttenCluster(modules.BaseModule):

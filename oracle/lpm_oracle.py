@@ -36,7 +36,7 @@ L2N_EPS = 1e-12    # tf.nn.l2_normalize epsilon
 class OracleConfig:
     """Flag defaults: frame_level_models.py:35,2197-2207; video_level_models.py:26-36;
     train.py:78-108; README.md:12-18 for the values the metric uses."""
-    model: str = "NetVladV1"            # "NetVladV1" | "NetVladV2"
+    model: str = "NetVladV1"            # "NetVladV1" | "NetVladV2" | "WillowModelReg" (SURVEY 8f rank 3)
     iterations: int = 30                # frame_level_models.py:35
     cluster_size: int = 256             # :2199
     hidden_size: int = 1024             # :2201
@@ -55,6 +55,9 @@ class OracleConfig:
     learning_rate_decay_examples: float = 4000000.0
     regularization_penalty: float = 1.0
     clip_gradient_norm: float = 1.0
+    rgb_det_reg: float = 1e-4           # frame_level_models.py:2213 (WillowModelReg / NetVladOrthoReg)
+    audio_det_reg: float = 1e-4         # :2209
+    sample_random_frames: bool = True   # :40
     video_dim: int = 1024               # frame_level_models.py:2261,2274
     audio_dim: int = 128                # :2263,2277
 
@@ -117,6 +120,45 @@ def sample_uniform_frames(model_input: torch.Tensor, num_frames, num_samples: in
     idx = torch.from_numpy(sample_uniform_frame_index(nf, num_samples)).long()
     b = torch.arange(model_input.shape[0]).unsqueeze(1).expand_as(idx)
     return model_input[b, idx]
+
+
+def sample_random_frames(model_input: torch.Tensor, num_frames, num_samples: int, uniform: torch.Tensor) -> torch.Tensor:
+    """SampleRandomFrames (model_utils.py:60-78): idx[b,j] = int32(u[b,j] * fp32(nf[b])), u ~ U[0,1) [B, S] (given here)."""
+    nf = torch.as_tensor(num_frames).reshape(-1, 1).to(torch.float32)
+    idx = (uniform.to(torch.float32) * nf).to(torch.int32).long()
+    b = torch.arange(model_input.shape[0]).unsqueeze(1).expand_as(idx)
+    return model_input[b, idx]
+
+
+def sample_random_sequence(model_input: torch.Tensor, num_frames, num_samples: int, uniform: torch.Tensor) -> torch.Tensor:
+    """SampleRandomSequence (model_utils.py:26-57): a contiguous run starting at int32(u[b] * fp32(max(nf - S, 0) + 1)),
+    clamped to nf - 1; u ~ U[0,1) [B, 1]."""
+    nf = torch.as_tensor(num_frames).reshape(-1, 1).to(torch.float32)
+    max_start = torch.clamp(nf - num_samples, min=0.0)
+    start = (uniform.to(torch.float32).reshape(-1, 1) * (max_start + 1.0)).to(torch.int32)
+    idx = torch.minimum(start + torch.arange(num_samples, dtype=torch.int32).unsqueeze(0), (nf - 1).to(torch.int32)).long()
+    b = torch.arange(model_input.shape[0]).unsqueeze(1).expand_as(idx)
+    return model_input[b, idx]
+
+
+def orthogonal_regularizer(weights: torch.Tensor, scale: float) -> torch.Tensor:
+    """module_utils.py:55-90: scale * sum |W^T W - I| with W = l2_normalize(weights, axis=1) (each ROW of the [D,K] matrix
+    normalised over the clusters), W^T W [K,K]."""
+    w = l2_normalize(weights, 1)
+    det = w.transpose(0, 1) @ w - torch.eye(w.shape[1], dtype=w.dtype)
+    return scale * det.abs().sum()
+
+
+def netvlad_orthoreg_forward(x2d, params, scope, scope_id, S, add_batch_norm=True, is_training=True, updates=None):
+    """NetVladOrthoReg.forward (video_pooling_modules.py:1520-1586): NetVLAD with a 2-D cluster_weights2 and variable names
+    suffixed by the scope id ("cluster_weights<scope_id>"); the orthogonality penalty is a regulariser on cluster_weights2."""
+    act = x2d @ params[f"{scope}/cluster_weights{scope_id}"]
+    if add_batch_norm:
+        act = batch_norm(act, params, scope + "/cluster_bn", is_training, updates)
+    else:
+        act = act + params[f"{scope}/cluster_biases{scope_id}"]
+    assign = torch.softmax(act, dim=-1).reshape(-1, S, act.shape[-1])
+    return vlad_aggregate(assign, x2d.reshape(-1, S, x2d.shape[-1]), params[scope + "/cluster_weights2"])
 
 
 # --------------------------------------------------------------------------------------
@@ -274,7 +316,12 @@ def cross_entropy_loss(predictions, labels):
 def regularization_loss(params, cfg: OracleConfig):
     """slim.l2_regularizer(moe_l2) on the two MoE FC weights: s * sum(w^2)/2
     (video_level_models.py:91,113; collected at train.py:301-303)."""
-    return cfg.moe_l2 * 0.5 * ((params["gates/weights"] ** 2).sum() + (params["experts/weights"] ** 2).sum())
+    reg = cfg.moe_l2 * 0.5 * ((params["gates/weights"] ** 2).sum() + (params["experts/weights"] ** 2).sum())
+    if cfg.model == "WillowModelReg":       # orthogonal_regularizer on both cluster_weights2 (video_pooling_modules.py:1561-1568)
+        reg = reg + orthogonal_regularizer(params["video_VLAD/cluster_weights2"], cfg.rgb_det_reg)
+        if "audio_VLAD/cluster_weights2" in params:
+            reg = reg + orthogonal_regularizer(params["audio_VLAD/cluster_weights2"], cfg.audio_det_reg)
+    return reg
 
 
 # --------------------------------------------------------------------------------------
@@ -287,7 +334,11 @@ def model_forward(params, model_input, num_frames, cfg: OracleConfig, is_trainin
     (train.py:262-264).  Returns predictions [B, vocab]."""
     inter = {}
     S, K = cfg.iterations, cfg.cluster_size
-    x = sample_uniform_frames(model_input, num_frames, S)                   # :2255
+    if cfg.model == "WillowModelReg":       # :2539-2544; the uniform draws come in through dropout_masks["frame_uniform"]
+        u = (dropout_masks or {})["frame_uniform"]
+        x = (sample_random_frames if cfg.sample_random_frames else sample_random_sequence)(model_input, num_frames, S, u)
+    else:
+        x = sample_uniform_frames(model_input, num_frames, S)               # :2255
     feat = x.shape[2]
     x2d = x.reshape(-1, feat)                                               # :2259
     if cfg.add_batch_norm:
@@ -312,6 +363,13 @@ def model_forward(params, model_input, num_frames, cfg: OracleConfig, is_trainin
             if has_audio:
                 ta = va.reshape(B, cfg.audio_dim, Ka).transpose(1, 2)
                 va = transformer_encoder(ta, params, "audio_attention", 16, "encode2").reshape(B, -1)  # :2294-2304
+    elif cfg.model == "WillowModelReg":
+        vv = netvlad_orthoreg_forward(xv, params, "video_VLAD", "netvlad_rgb_scope", S, cfg.add_batch_norm, is_training, updates)
+        inter["vlad_video"] = vv
+        if has_audio:
+            va = netvlad_orthoreg_forward(xa, params, "audio_VLAD", "netvlad_audio_scope", S, cfg.add_batch_norm, is_training,
+                                          updates)
+            inter["vlad_audio"] = va
     elif cfg.model == "NetVladV2":
         vv = netvlad_atten_cluster_forward(xv, params, "video_VLAD", S, is_training, cfg.v2_dropout_rate,
                                            dm.get("video"), updates)       # :2437-2438
@@ -378,7 +436,13 @@ def init_params(cfg: OracleConfig, feature_size: int = 1152, seed: int = 1000,
     for name, D, Ks, heads, sid in streams:
         sc = f"{name}_VLAD"
         vlad_dim += D * Ks
-        if cfg.model == "NetVladV1":
+        if cfg.model == "WillowModelReg":
+            sid2 = "netvlad_rgb_scope" if name == "video" else "netvlad_audio_scope"
+            p[f"{sc}/cluster_weights{sid2}"] = _normal(g, (D, Ks), 1 / math.sqrt(D), dtype)
+            _bn(p, sc + "/cluster_bn", Ks, dtype)
+            p[f"{sc}/cluster_biases{sid2}"] = _normal(g, (Ks,), 1 / math.sqrt(D), dtype)
+            p[sc + "/cluster_weights2"] = _normal(g, (D, Ks), 1 / math.sqrt(D), dtype)
+        elif cfg.model == "NetVladV1":
             p[sc + "/cluster_weights"] = _normal(g, (D, Ks), 1 / math.sqrt(D), dtype)
             _bn(p, sc + "/cluster_bn", Ks, dtype)
             p[sc + "/cluster_biases"] = _normal(g, (Ks,), 1 / math.sqrt(D), dtype)
@@ -433,7 +497,7 @@ def trainable_names(params, cfg: Optional[OracleConfig] = None) -> List[str]:
     for n in params:
         if n.endswith("/moving_mean") or n.endswith("/moving_variance"):
             continue
-        if n.endswith("/cluster_biases") and (cfg is None or cfg.add_batch_norm):
+        if "/cluster_biases" in n and (cfg is None or cfg.add_batch_norm):
             continue
         out.append(n)
     return out
