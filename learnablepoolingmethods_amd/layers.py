@@ -35,6 +35,10 @@ def batch_norm(x: torch.Tensor, is_training: bool, scope: str) -> torch.Tensor:
     (rank-2/4) path, the biased one otherwise."""
     C = x.shape[-1]
     gamma, beta, mm, mv = bn_variables(scope, C, x.device)
+    if is_training and x.dim() == 2 and x.is_cuda and x.shape[0] > 1:
+        # the fused rank-2 path in one library kernel each way: batch statistics, normalisation and the moving-average
+        # update (unbiased variance into the moving average, exactly TF's fused batch norm) instead of ~12 small kernels
+        return F.batch_norm(x, mm, mv, gamma, beta, True, 1.0 - BN_DECAY, BN_EPS)
     if is_training:
         red = tuple(range(x.dim() - 1))
         n = x.numel() // C
