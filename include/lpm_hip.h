@@ -319,6 +319,21 @@ int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, int B, int L
                         lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * MoeModel tail + CrossEntropyLoss (video_level_models.py:116-126, losses.py:41-51), fused:
+ *   g = softmax over the m+1 gate activations of a (clip, class), e = sigmoid of its m expert activations,
+ *   predictions[b,c] = sum_{i<m} g_i e_i;   loss = mean_b sum_c -[y log(p+eps) + (1-y) log(1-p+eps)].
+ * gate_act [B, V*(m+1)], expert_act [B, V*m] (bias added), labels [B,V] float 0/1 (NULL: predictions only, then loss and
+ * loss_partial [lpm_moe_ce_nblk(B,V)] must be NULL too).  Backward: dgate_act / dexpert_act from dloss (scalar on the
+ * device) and/or dpredictions [B,V] (either may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+int lpm_moe_ce_nblk(int B, int V);
+int lpm_moe_ce_fwd(const float* gate_act, const float* expert_act, const float* labels, int B, int V, int num_mixtures, float eps,
+                   float* predictions, float* loss, float* loss_partial, lpm_stream_t stream);
+int lpm_moe_ce_bwd(const float* gate_act, const float* expert_act, const float* labels, const float* dloss,
+                   const float* dpredictions, int B, int V, int num_mixtures, float eps, float* dgate_act, float* dexpert_act,
+                   lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a14 + a15: per-variable clip_by_norm + TF-style Adam over a flat parameter arena
  *   replaces utils.clip_gradient_norms (utils.py:170-189) + tf.train.AdamOptimizer.apply_gradients
  *   (train.py:336).  `offsets` [ntensors+1] (int64, DEVICE) delimits each variable inside the

@@ -85,6 +85,9 @@ SIGNATURES = {
     "lpm_mha_bwd_x3": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _l, _f, _f, _f, _f]),
     "lpm_mha_logit_stats_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_mha_logit_stats": (_i, [_f, _f, _l, _i, _i, _i, _i, _f, _f]),
+    "lpm_moe_ce_nblk": (_i, [_i, _i]),
+    "lpm_moe_ce_fwd": (_i, [_f, _f, _f, _i, _i, _i, _fl, _f, _f, _f, _f]),
+    "lpm_moe_ce_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _f, _f]),
     "lpm_clip_adam_scratch_bytes": (_s, [_l, _i]),
     "lpm_multi_tensor_clip_adam": (_i, [_f, _f, _f, _f, _f, _i, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _f]),
 }

@@ -102,7 +102,6 @@ class NetVladV1(models.BaseModel):
         hidden1_size = hidden_size or FLAGS.netvlad_hidden_size
         relu, gating, remove_diag = FLAGS.netvlad_relu, FLAGS.gating, FLAGS.gating_remove_diag
         encoder = FLAGS.netvlad_encoder if encoder is None else encoder
-        unused_params.pop("labels", None)
 
         reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training)
         max_frames, feature_size = iterations, model_input.shape[2]
@@ -159,7 +158,6 @@ class WillowModelReg(models.BaseModel):
         cluster_size = cluster_size or FLAGS.netvlad_cluster_size
         hidden1_size = hidden_size or FLAGS.netvlad_hidden_size
         relu, gating, remove_diag = FLAGS.netvlad_relu, FLAGS.gating, FLAGS.gating_remove_diag
-        unused_params.pop("labels", None)
         sampler = model_utils.SampleRandomFrames if random_frames else model_utils.SampleRandomSequence
         model_input = sampler(model_input, num_frames.reshape(-1, 1), iterations, uniform=frame_uniform)      # :2539-2544
         max_frames, feature_size = model_input.shape[1], model_input.shape[2]
@@ -191,7 +189,6 @@ class NetVladV2(models.BaseModel):
         cluster_size = cluster_size or FLAGS.netvlad_cluster_size
         hidden1_size = hidden_size or FLAGS.netvlad_hidden_size
         relu, gating, remove_diag = FLAGS.netvlad_relu, FLAGS.gating, FLAGS.gating_remove_diag
-        unused_params.pop("labels", None)
         dm = dropout_masks or {}
 
         reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training)

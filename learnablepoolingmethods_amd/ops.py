@@ -999,6 +999,53 @@ def mha_core_bn(q, k, v, num_heads, gamma, beta, moving_mean, moving_var, is_tra
 # ----------------------------------------------------------------------------------------------
 # a14 + a15: clip + Adam over flat arenas
 # ----------------------------------------------------------------------------------------------
+class _MoeCrossEntropy(torch.autograd.Function):
+    """(gate_act, expert_act, labels) -> (predictions, loss): MoeModel's mixture tail + CrossEntropyLoss in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, gate_act, expert_act, labels, num_mixtures, eps):
+        lib = _capi.load()
+        gate_act, expert_act = _f32(gate_act, "gate activations").contiguous(), _f32(expert_act, "expert activations").contiguous()
+        B = gate_act.shape[0]
+        V = gate_act.shape[1] // (num_mixtures + 1)
+        if gate_act.shape[1] != V * (num_mixtures + 1) or expert_act.shape != (B, V * num_mixtures):
+            raise LpmError("moe_cross_entropy: activations do not match num_mixtures")
+        pred = _empty((B, V), gate_act)
+        loss = part = None
+        if labels is not None:
+            labels = labels.to(device=gate_act.device, dtype=torch.float32).contiguous()
+            loss = _empty((), gate_act)
+            part = _empty((lib._lpm_moe_ce_nblk(B, V),), gate_act)
+        lib.check(lib._lpm_moe_ce_fwd(ptr(gate_act), ptr(expert_act), ptr(labels), B, V, num_mixtures, eps, ptr(pred), ptr(loss),
+                                      ptr(part), stream_ptr()), "lpm_moe_ce_fwd")
+        ctx.dims = (B, V, num_mixtures, eps)
+        ctx.save_for_backward(gate_act, expert_act, labels)
+        if labels is None:
+            ctx.mark_non_differentiable()
+            return pred, None
+        return pred, loss
+
+    @staticmethod
+    def backward(ctx, dpred, dloss):
+        lib = _capi.load()
+        B, V, m, eps = ctx.dims
+        gate_act, expert_act, labels = ctx.saved_tensors
+        dgate, dexpert = torch.empty_like(gate_act), torch.empty_like(expert_act)
+        if dloss is None and labels is not None:
+            dloss = torch.zeros((), dtype=torch.float32, device=gate_act.device)
+        dloss = dloss.contiguous() if dloss is not None else None
+        dpred = dpred.contiguous() if dpred is not None else None
+        lib.check(lib._lpm_moe_ce_bwd(ptr(gate_act), ptr(expert_act), ptr(labels), ptr(dloss), ptr(dpred), B, V, m, eps, ptr(dgate),
+                                      ptr(dexpert), stream_ptr()), "lpm_moe_ce_bwd")
+        return dgate, dexpert, None, None, None
+
+
+def moe_cross_entropy(gate_act, expert_act, labels, num_mixtures, eps=10e-6):
+    """MoeModel mixture tail (video_level_models.py:116-126) + CrossEntropyLoss (losses.py:41-51) -> (predictions, loss);
+    labels None -> (predictions, None)."""
+    return _MoeCrossEntropy.apply(gate_act, expert_act, labels, int(num_mixtures), float(eps))
+
+
 def clip_adam_step(param, grad, m, v, offsets, ntensors, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8,
                    scratch: Optional[torch.Tensor] = None):
     lib = _capi.load()

@@ -258,6 +258,8 @@ class Trainer:
         self.device = torch.device(device)
         self.group = group
         self.store = vs.VariableStore(device=self.device, seed=seed)
+        self.store.analytic_l2 = self.device.type == "cuda"       # L2 weight penalties enter as gradients (see step)
+        self._l2_regs = []
         self.model_kwargs = dict(model_kwargs or {})
         self.global_step = 0
         self.arena: Optional[ParameterArena] = None
@@ -274,9 +276,11 @@ class Trainer:
     def _forward(self, model_input, num_frames, labels, **kw):
         with vs.use_store(self.store):
             with vs.variable_scope("tower"):
+                fused = labels is not None and type(self.loss_fn) is losses.CrossEntropyLoss
                 result = self.model.create_model(model_input, num_frames=num_frames, vocab_size=self.vocab_size,
-                                                 labels=labels, **{**self.model_kwargs, **kw})
+                                                 labels=labels, fused_cross_entropy=fused, **{**self.model_kwargs, **kw})
             reg_losses = self.store.pop_regularization_losses()
+            self._l2_regs = self.store.pop_l2_regularizers()
         return result, reg_losses
 
     def _normalize_input(self, raw, num_frames=None):
@@ -354,6 +358,13 @@ class Trainer:
             reg_loss = reg_loss + torch.stack(reg_losses).sum()                                 # :301-303
         final_loss = self.reg_penalty * reg_loss + label_loss                                   # :321
         final_loss.backward()                                                                   # :322-323
+        if self._l2_regs:                                          # d/dw [penalty * scale * sum(w^2)/2] = penalty * scale * w
+            with torch.no_grad():
+                for scale in sorted({sc for _, sc in self._l2_regs}):
+                    ws = [w for w, sc in self._l2_regs if sc == scale and w.grad is not None]
+                    if ws:
+                        torch._foreach_add_([w.grad for w in ws], ws, alpha=self.reg_penalty * scale)
+            self._l2_regs = []
         self.arena.collect(skip=self.bucket_gather.gathered_names() if self.bucket_gather is not None else ())
         self.sync.finish()                                                                      # utils.combine_gradients :330
         lr = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers,

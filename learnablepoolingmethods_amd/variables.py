@@ -22,6 +22,8 @@ class VariableStore:
         self.trainable: Dict[str, bool] = {}
         self._scope: List[str] = []
         self._reg_losses: List[torch.Tensor] = []
+        self._l2_regs = []                  # (variable, scale) pairs when analytic_l2 is set
+        self.analytic_l2 = False
         self._gen_seed = seed
         self._gen: Optional[torch.Generator] = None
         self.frozen = False
@@ -80,6 +82,20 @@ class VariableStore:
     # -- regularisation collection (tf.losses.get_regularization_losses, train.py:301-303) ------
     def add_regularization_loss(self, t: torch.Tensor):
         self._reg_losses.append(t)
+
+    def add_l2_regularizer(self, var: torch.Tensor, scale: float):
+        """slim.l2_regularizer(scale)(var) = scale * sum(var^2) / 2.  With ``analytic_l2`` set (the GPU trainer) only
+        (var, scale) is recorded and the trainer adds the gradient scale * var itself after backward -- the loss value is
+        not needed there -- instead of building ~10 small kernels of graph per weight; otherwise the loss tensor is
+        collected like any other regularisation loss."""
+        if getattr(self, "analytic_l2", False):
+            self._l2_regs.append((var, float(scale)))
+        else:
+            self._reg_losses.append(scale * 0.5 * (var * var).sum())
+
+    def pop_l2_regularizers(self):
+        out, self._l2_regs = self._l2_regs, []
+        return out
 
     def pop_regularization_losses(self) -> List[torch.Tensor]:
         out, self._reg_losses = self._reg_losses, []

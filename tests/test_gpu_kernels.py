@@ -549,3 +549,29 @@ def test_dequantize_l2_normalize(B, MF, F):
     assert_close(y, O.l2_normalize(x, 2), 1e-6, "dequantize + l2_normalize")
     for b in range(B):
         assert float(y[b, int(nf[b]):].abs().max() if int(nf[b]) < MF else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("B,V,m", [(80, 3862, 2), (5, 40, 4), (3, 17, 1)])
+def test_moe_cross_entropy_fused(B, V, m):
+    """MoeModel mixture tail + CrossEntropyLoss as one kernel pair (video_level_models.py:116-126, losses.py:41-51)."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(V + m)
+    ga, ea = 2 * torch.randn(B, V * (m + 1), generator=g), 2 * torch.randn(B, V * m, generator=g)
+    y = (torch.rand(B, V, generator=g) < 0.05).float()
+    dpred = 0.01 * torch.randn(B, V, generator=g)
+    gad, ead = ga.double().requires_grad_(True), ea.double().requires_grad_(True)
+    gating = torch.softmax(gad.reshape(-1, m + 1), dim=-1)
+    pr = (gating[:, :m] * torch.sigmoid(ead.reshape(-1, m))).sum(1).reshape(B, V)
+    ls = O.cross_entropy_loss(pr, y.double())
+    (1.7 * ls + (pr * dpred.double()).sum()).backward()
+    gag, eag = ga.to(dev).requires_grad_(True), ea.to(dev).requires_grad_(True)
+    p, l = ops.moe_cross_entropy(gag, eag, y.to(dev), m)
+    assert_close(p, pr, 1e-5, "predictions")
+    assert_close(l, ls, 1e-5, "loss")
+    (1.7 * l + (p * dpred.to(dev)).sum()).backward()
+    assert_close(gag.grad, gad.grad, 1e-4, "d gate activations")
+    assert_close(eag.grad, ead.grad, 1e-4, "d expert activations")
+    p2, none = ops.moe_cross_entropy(ga.to(dev), ea.to(dev), None, m)
+    assert none is None
+    assert_close(p2, pr, 1e-5, "predictions without labels")
