@@ -211,53 +211,44 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
     }
 }
 
-// [nblk][F] partials -> out [F]
-__global__ __launch_bounds__(1024) void ln_bias_colreduce_kernel(const float* __restrict__ part, int nblk, int F, float* out) {
-    __shared__ double sh[16][64];
+// Column reductions of the per-(example, chunk) partials, two stages so that the 1280 partial rows of cfg-2 are spread over
+// 256 workgroups instead of 16 (one launch of 16 workgroups walking 80 rows each took 25-47 us; latency, not bandwidth):
+//   stage 1, grid (ceil(F/64), LN_RS): slice y sums rows y, y + LN_RS, ... of `narr` arrays laid out [nblk][narr][F] -> tmp[y][narr][F]
+//   stage 2, grid (ceil(F/64)):        sums the LN_RS slices in fp64 -> out arrays
+constexpr int LN_RS = 16;
+__global__ __launch_bounds__(256) void ln_colreduce1_kernel(const float* __restrict__ part, int nblk, int narr, int F,
+                                                            float* __restrict__ tmp) {
+    __shared__ float sh[4][3][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s = 0.0;
-    if (c < F)
-        for (int b = rg; b < nblk; b += 16) s += (double)part[(int64_t)b * F + c];
-    sh[rg][cl] = s;
-    __syncthreads();
-    if (rg == 0 && c < F) {
-        for (int i = 1; i < 16; ++i) s += sh[i][cl];
-        out[c] = (float)s;
-    }
-}
-
-// column partials [nblk][2][F] -> dgamma, dbeta
-__global__ __launch_bounds__(1024) void ln_bwd_colreduce_kernel(const float* __restrict__ colpart, int nblk, int F,
-                                                                float* dgamma, float* dbeta) {
-    __shared__ double sh[2][16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s = 0.0, q = 0.0;
+    const int c = blockIdx.x * 64 + cl, y = blockIdx.y;
+    float acc[3] = {0.f, 0.f, 0.f};
     if (c < F) {
-        for (int b = rg; b < nblk; b += 16) {
-            const float* p = colpart + (int64_t)b * 2 * F;
-            s += (double)p[c];
-            q += (double)p[F + c];
+        for (int b = y + LN_RS * rg; b < nblk; b += LN_RS * 4) {
+            const float* p = part + (int64_t)b * narr * F + c;
+            for (int a = 0; a < narr; ++a) acc[a] += p[(int64_t)a * F];
         }
     }
-    sh[0][rg][cl] = s;
-    sh[1][rg][cl] = q;
+    for (int a = 0; a < narr; ++a) sh[rg][a][cl] = acc[a];
     __syncthreads();
-    if (rg == 0 && c < F) {
-        for (int i = 1; i < 16; ++i) {
-            s += sh[0][i][cl];
-            q += sh[1][i][cl];
-        }
-        dgamma[c] = (float)s;
-        dbeta[c] = (float)q;
+    if (rg == 0 && c < F)
+        for (int a = 0; a < narr; ++a) tmp[((int64_t)y * narr + a) * F + c] = (sh[0][a][cl] + sh[1][a][cl]) + (sh[2][a][cl] + sh[3][a][cl]);
+}
+__global__ __launch_bounds__(64) void ln_colreduce2_kernel(const float* __restrict__ tmp, int narr, int F, float* out0, float* out1,
+                                                           float* out2) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= F) return;
+    float* outs[3] = {out0, out1, out2};
+    for (int a = 0; a < narr; ++a) {
+        double s = 0.0;
+        for (int y = 0; y < LN_RS; ++y) s += (double)tmp[((int64_t)y * narr + a) * F + c];
+        outs[a][c] = (float)s;
     }
 }
 
 }  // namespace lpm
 
 extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
-    return ((size_t)B * lpm::LN_NB * 2 + (size_t)B * lpm::LN_NB * 3 * F) * sizeof(float);
+    return ((size_t)B * lpm::LN_NB * 2 + (size_t)B * lpm::LN_NB * 3 * F + (size_t)lpm::LN_RS * 3 * F) * sizeof(float);
 }
 
 #define LPM_LN_CHECK(name)                                                                                              \
@@ -300,11 +291,17 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, const float* z, const flo
     float* partial = (float*)workspace;
     float* colpart = partial + (size_t)B * LN_NB * 2;
     float* biaspart = colpart + (size_t)B * LN_NB * 2 * F;
+    float* tmp = biaspart + (size_t)B * LN_NB * F;
     dim3 grid(B, LN_NB);
+    const int cb = (F + 63) / 64, nblk = B * LN_NB;
     hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart);
+    hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, colpart, nblk, 2, F, tmp);
+    hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 2, F, dgamma, dbeta, (float*)nullptr);
     hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart);
-    hipLaunchKernelGGL(ln_bwd_colreduce_kernel, dim3((F + 63) / 64), dim3(1024), 0, s, colpart, B * LN_NB, F, dgamma, dbeta);
-    if (bias) hipLaunchKernelGGL(ln_bias_colreduce_kernel, dim3((F + 63) / 64), dim3(1024), 0, s, biaspart, B * LN_NB, F, dbias);
+    if (bias) {
+        hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, biaspart, nblk, 1, F, tmp);
+        hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 1, F, dbias, (float*)nullptr, (float*)nullptr);
+    }
     return check_launch("lpm_layer_norm_act_bwd");
 }
 
