@@ -239,3 +239,22 @@ def test_willow_model_reg_forward_backward():
         g = tr.arena.grad[a0:a0 + p[n].numel()].reshape(p[n].shape)
         e = rel_l2(g, grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5)
         assert e <= 5e-3, f"gradient {n}: relative L2 error {e:.3e}"
+
+
+def test_training_is_bitwise_reproducible_across_runs():
+    """Two trainers from the same seed on the same batch take bit-identical steps: the two-stream schedule (audio branch on a
+    second HIP stream), the shared gradient buffers and the arena gather leave no ordering-dependent result behind."""
+    from learnablepoolingmethods_amd import registry
+    from learnablepoolingmethods_amd.train import Trainer
+    dev = cuda()
+    B, MF = 6, 40
+    x, nf, lab = O.make_synthetic_batch(B, MF, 1152, 50, seed=21, min_frames=10)
+    finals = []
+    for _ in range(2):
+        tr = Trainer(registry.get_model("NetVladV1"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=11,
+                     model_kwargs=dict(iterations=32, cluster_size=64, hidden_size=64))
+        losses = [tr.step(x, nf, lab)["loss"].item() for _ in range(4)]
+        torch.cuda.synchronize()
+        finals.append((losses, tr.arena.param.clone(), tr.arena.m.clone()))
+    assert finals[0][0] == finals[1][0], f"losses differ: {finals[0][0]} vs {finals[1][0]}"
+    assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
