@@ -376,6 +376,42 @@ class Trainer:
         return {"loss": label_loss.detach(), "predictions": predictions.detach(), "learning_rate": lr,
                 "global_step": self.global_step}
 
+    # -- checkpoint / resume (train.py:501-515,593: Supervisor-saved variables + Adam slots + global_step) ------------------
+    def state_dict(self) -> Dict[str, object]:
+        """Everything a resumed run needs, keyed by the reference's TF variable names (``tower/video_VLAD/cluster_weights``,
+        ``tower/video_attention/q/kernel``, ..., Adam slots as ``<name>/Adam`` and ``<name>/Adam_1``) plus ``global_step``."""
+        if self.arena is None:
+            raise RuntimeError("state_dict() needs a built trainer: run build() or one step first")
+        out: Dict[str, object] = {n: v.detach().clone().cpu() for n, v in self.store.vars.items()}
+        for n in self.arena.names:
+            a0, _ = self.arena.segment(n)
+            k = self.arena.views[n].numel()
+            shape = self.arena.views[n].shape
+            out[n + "/Adam"] = self.arena.m[a0:a0 + k].view(shape).clone().cpu()
+            out[n + "/Adam_1"] = self.arena.v[a0:a0 + k].view(shape).clone().cpu()
+        out["global_step"] = int(self.global_step)
+        return out
+
+    def load_state_dict(self, state: Dict[str, object]):
+        if self.arena is None:
+            raise RuntimeError("load_state_dict() needs a built trainer: run build() first")
+        with torch.no_grad():
+            self.store.load({n: v for n, v in state.items() if n in self.store.vars}, strict=False)
+            for n in self.arena.names:
+                a0, _ = self.arena.segment(n)
+                k = self.arena.views[n].numel()
+                if n + "/Adam" in state:
+                    self.arena.m[a0:a0 + k].copy_(torch.as_tensor(state[n + "/Adam"]).reshape(-1))
+                if n + "/Adam_1" in state:
+                    self.arena.v[a0:a0 + k].copy_(torch.as_tensor(state[n + "/Adam_1"]).reshape(-1))
+        self.global_step = int(state.get("global_step", self.global_step))
+
+    def save(self, path: str):
+        torch.save(self.state_dict(), path)
+
+    def restore(self, path: str):
+        self.load_state_dict(torch.load(path, map_location="cpu"))
+
     @torch.no_grad()
     def predict(self, model_input_raw, num_frames, **kw):
         """eval.build_graph path: same forward with is_training=False (eval.py:143-150)."""

@@ -125,3 +125,13 @@ def test_random_frame_sampling_index_rules():
     seq = model_utils.SampleRandomSequence(x, nf, 6, uniform=torch.tensor([[0.99], [0.5], [0.5]])).squeeze(-1)
     # clip 0: max start 4 -> int(0.99 * 5) = 4 -> frames 4..9; clip 1: nf 4 < 6 -> start 0, clamped to frame 3; clip 2: start int(0.5*2)=1
     assert seq.tolist() == [[4, 5, 6, 7, 8, 9], [10, 11, 12, 13, 13, 13], [21, 22, 23, 24, 25, 26]]
+
+
+def test_inference_csv_format():
+    """inference.py:88-96,182: header, top-k in descending score order, "%i %g" pairs, byte ids decoded."""
+    from learnablepoolingmethods_amd import inference
+    p = torch.tensor([[0.1, 0.9, 0.5, 0.0], [0.25, 1e-7, 0.75, 0.123456789]])
+    lines = list(inference.format_lines([b"ab12", "cd34"], p, 3))
+    assert lines == ["ab12,1 0.9 2 0.5 0 0.1\n", "cd34,2 0.75 0 0.25 3 0.123457\n"]
+    assert inference.CSV_HEADER == "VideoId,LabelConfidencePairs\n"
+    assert list(inference.format_lines(["x"], p[:1], 10)) == ["x,1 0.9 2 0.5 0 0.1 3 0\n"]       # top_k larger than the vocabulary
