@@ -228,6 +228,14 @@ int lpm_vlad_aggregate_bwd_tiles_dx(const void* workspace, size_t workspace_byte
  *   in : dlt [M,K] (grad wrt gamma*Lhat+beta), logits L [M,K], mean, var [K], gamma [K]
  *   out: dl [M,K] (may alias dlt), dgamma [K], dbeta [K].   workspace: lpm_bn_bwd_workspace_bytes(M,K).
  * ------------------------------------------------------------------------------------------- */
+/* Channel-last training batch norm of a [M, C] matrix (slim.batch_norm on the V2 encoder's [B, L, C] tensors,
+ * transformer_utils.py:666,747,760, seen as M = B*L rows): y = (x - mean) * rsqrt(var + eps) * gamma + beta with the batch
+ * statistics written to mean / var and folded into the moving averages (biased_moving_variance != 0: TF's non-fused path,
+ * which rank-3 inputs take; 0: the fused path's unbiased estimate).  The backward is lpm_bn_bwd with logits := x. */
+size_t lpm_bn_rows_workspace_bytes(int M, int C);
+int lpm_bn_rows_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float decay,
+                    int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean, float* moving_var,
+                    void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 size_t lpm_bn_bwd_workspace_bytes(int M, int K);
 int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var, const float* gamma,
                float eps, int M, int K, float* dl, float* dgamma, float* dbeta, void* workspace,

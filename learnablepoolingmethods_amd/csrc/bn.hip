@@ -128,7 +128,65 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// ---- channel-last batch norm of a [M, C] matrix (the V2 encoder's [B, L, C] tensors seen as rows) -----------------------------
+// statistics: per 64-row block column (sum, sum of squares) -> partial [nblk][2][C]  (then bn_fold_kernel)
+__global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ partial) {
+    const int r0 = blockIdx.x * BNB_ROWS, r1 = min(M, r0 + BNB_ROWS);
+    const int C4 = C / 4;
+    for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+        for (int r = r0; r < r1; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)r * C + 4 * c4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+        }
+        float* p = partial + (int64_t)blockIdx.x * 2 * C + 4 * c4;
+        *reinterpret_cast<float4*>(p) = s;
+        *reinterpret_cast<float4*>(p + C) = q;
+    }
+}
+// y = x * scale[c] + shift[c]
+__global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int64_t total4, int C4,
+                                                            float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 a = *reinterpret_cast<const float4*>(scale + c), b = *reinterpret_cast<const float4*>(shift + c);
+        reinterpret_cast<float4*>(y)[i] = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
+    }
+}
+
 }  // namespace lpm
+
+extern "C" size_t lpm_bn_rows_workspace_bytes(int M, int C) {
+    const int nblk = (M + lpm::BNB_ROWS - 1) / lpm::BNB_ROWS;
+    return ((size_t)nblk * 2 * C + 2 * (size_t)C) * sizeof(float);
+}
+
+extern "C" int lpm_bn_rows_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float decay,
+                               int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
+                               float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x && y && mean && var && workspace, LPM_ERR_BADARG, "lpm_bn_rows_fwd: null pointer");
+    LPM_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_bn_rows_fwd: need C %% 4 == 0 and 16-byte aligned pointers (M=%d C=%d)", M, C);
+    LPM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), LPM_ERR_BADARG, "lpm_bn_rows_fwd: moving statistics go together");
+    LPM_REQUIRE(workspace_bytes >= lpm_bn_rows_workspace_bytes(M, C), LPM_ERR_WORKSPACE, "lpm_bn_rows_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (M + BNB_ROWS - 1) / BNB_ROWS;
+    float* partial = (float*)workspace;
+    float* scale = partial + (size_t)nblk * 2 * C;
+    float* shift = scale + C;
+    hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(nblk), dim3(256), 0, s, x, M, C, partial);
+    const double unbias = (biased_moving_variance || M <= 1) ? 1.0 : (double)M / (double)(M - 1);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partial, nblk, C, 1.0 / (double)M, unbias, gamma, beta, eps,
+                       decay, mean, var, scale, shift, moving_mean, moving_var);
+    const int64_t total4 = (int64_t)M * C / 4;
+    const int64_t want = (total4 + 255) / 256;
+    hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, x, scale, shift, total4, C / 4, y);
+    return check_launch("lpm_bn_rows_fwd");
+}
 
 extern "C" int lpm_bn_fold(const float* partial, int nblk, int C, int64_t rows, const float* gamma, const float* beta,
                            float eps, float decay, float* mean, float* var, float* scale, float* shift,

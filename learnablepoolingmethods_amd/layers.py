@@ -39,6 +39,10 @@ def batch_norm(x: torch.Tensor, is_training: bool, scope: str) -> torch.Tensor:
         # the fused rank-2 path in one library kernel each way: batch statistics, normalisation and the moving-average
         # update (unbiased variance into the moving average, exactly TF's fused batch norm) instead of ~12 small kernels
         return F.batch_norm(x, mm, mv, gamma, beta, True, 1.0 - BN_DECAY, BN_EPS)
+    if is_training and x.dim() == 3 and x.is_cuda and C % 4 == 0:
+        # the V2 encoder's [B, L, C] tensors (up to 393 MB): hand-written channel-last kernels, 3 launches forward and 3
+        # backward instead of ~30 elementwise / reduction passes; rank 3 takes TF's non-fused path (biased moving variance)
+        return ops.batch_norm_rows(x, gamma, beta, mm, mv, biased_moving_variance=True)
     if is_training:
         red = tuple(range(x.dim() - 1))
         n = x.numel() // C

@@ -798,6 +798,47 @@ def projection(x, W):
     return _Projection.apply(x, W)
 
 
+class _BatchNormRows(torch.autograd.Function):
+    """Training-mode slim.batch_norm over the rows of a channel-last tensor: column statistics, normalisation and the moving
+    averages in three launches; backward = lpm_bn_bwd (two column reductions + one elementwise pass)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, biased_moving):
+        lib = _capi.load()
+        x2 = _f32(x, "batch_norm input").contiguous().view(-1, x.shape[-1])
+        M, C = x2.shape
+        y = torch.empty_like(x2)
+        mean, var = _empty((C,), x2), _empty((C,), x2)
+        wsb = lib._lpm_bn_rows_workspace_bytes(M, C)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x2.device)
+        lib.check(lib._lpm_bn_rows_fwd(ptr(x2), M, C, ptr(gamma), ptr(beta), BN_EPS, BN_DECAY, 1 if biased_moving else 0, ptr(y),
+                                       ptr(mean), ptr(var), ptr(moving_mean), ptr(moving_var), ptr(ws), wsb, stream_ptr()),
+                  "lpm_bn_rows_fwd")
+        ctx.save_for_backward(x2, mean, var, gamma)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _capi.load()
+        x2, mean, var, gamma = ctx.saved_tensors
+        M, C = x2.shape
+        dy2 = dy.contiguous().view(M, C)
+        dx = torch.empty_like(x2)
+        dgamma, dbeta = _empty((C,), x2), _empty((C,), x2)
+        wsb = lib._lpm_bn_bwd_workspace_bytes(M, C)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x2.device)
+        lib.check(lib._lpm_bn_bwd(ptr(dy2), ptr(x2), ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, C, ptr(dx), ptr(dgamma), ptr(dbeta),
+                                  ptr(ws), wsb, stream_ptr()), "lpm_bn_bwd")
+        return dx.view(ctx.shape), dgamma, dbeta, None, None, None
+
+
+def batch_norm_rows(x, gamma, beta, moving_mean, moving_var, biased_moving_variance):
+    """Training-mode batch norm of a channel-last tensor (channels = last axis, statistics over all other axes); updates the
+    moving statistics in place.  x.shape[-1] %% 4 == 0."""
+    return _BatchNormRows.apply(x, gamma, beta, moving_mean, moving_var, bool(biased_moving_variance))
+
+
 # ----------------------------------------------------------------------------------------------
 # residual add + layer_norm (TF1 defaults: moments over all non-batch axes)
 # ----------------------------------------------------------------------------------------------

@@ -575,3 +575,31 @@ def test_moe_cross_entropy_fused(B, V, m):
     p2, none = ops.moe_cross_entropy(ga.to(dev), ea.to(dev), None, m)
     assert none is None
     assert_close(p2, pr, 1e-5, "predictions without labels")
+
+
+@pytest.mark.parametrize("B,L,C", [(4, 300, 1024), (3, 17, 256), (2, 5, 4096)])
+def test_batch_norm_rows_rank3(B, L, C):
+    """slim.batch_norm on a [B, L, C] tensor (transformer_utils.py:666,747,760): batch statistics over B*L rows, the BIASED
+    variance into the moving average (TF's non-fused path), backward through the statistics."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(C + L)
+    x, dy = 2 * torch.randn(B, L, C, generator=g) + 0.5, torch.randn(B, L, C, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    mm, mv = 0.1 * torch.randn(C, generator=g), 1 + 0.3 * torch.rand(C, generator=g)
+    p = {"bn/gamma": gamma.double().requires_grad_(True), "bn/beta": beta.double().requires_grad_(True),
+         "bn/moving_mean": mm.double(), "bn/moving_variance": mv.double()}
+    xd = x.double().requires_grad_(True)
+    upd = {}
+    ref = O.batch_norm(xd, p, "bn", True, upd)
+    ref.backward(dy.double())
+    xg, gg, bg = (t.to(dev).requires_grad_(True) for t in (x, gamma, beta))
+    mmg, mvg = mm.to(dev), mv.to(dev)
+    y = ops.batch_norm_rows(xg, gg, bg, mmg, mvg, biased_moving_variance=True)
+    assert_close(y, ref, 1e-5, "batch_norm fwd")
+    y.backward(dy.to(dev))
+    assert_close(xg.grad, xd.grad, 1e-4, "dx")
+    assert_close(gg.grad, p["bn/gamma"].grad, 1e-4, "dgamma")
+    assert_close(bg.grad, p["bn/beta"].grad, 1e-4, "dbeta")
+    assert_close(mmg, mm.double() * 0.999 + upd["bn/moving_mean"] * 0.001, tol=1e-6, what="moving_mean")
+    assert_close(mvg, mv.double() * 0.999 + upd["bn/moving_variance"] * 0.001, tol=1e-6, what="moving_variance")
