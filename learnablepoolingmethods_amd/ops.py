@@ -1093,7 +1093,8 @@ def clip_adam_step(param, grad, m, v, offsets, ntensors, clip_norm, lr, step, be
     total = param.numel()
     if scratch is None:
         scratch = torch.empty(lib._lpm_clip_adam_scratch_bytes(total, ntensors) // 4, dtype=torch.float32, device=param.device)
-    lib.check(lib._lpm_multi_tensor_clip_adam(ptr(param), ptr(grad), ptr(m), ptr(v), ptr(offsets), ntensors, total,
-                                              float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch),
-                                              stream_ptr()), "lpm_multi_tensor_clip_adam")
+    with _timed("clip_adam", (total, ntensors)):
+        lib.check(lib._lpm_multi_tensor_clip_adam(ptr(param), ptr(grad), ptr(m), ptr(v), ptr(offsets), ntensors, total,
+                                                  float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch),
+                                                  stream_ptr()), "lpm_multi_tensor_clip_adam")
     return scratch
