@@ -104,12 +104,18 @@ __global__ __launch_bounds__(512, 4) void vlad_aggregate_tiles3_kernel(
         if (dw == 0 && half == 0) ssum[(kw * 2 + c) * 32 + l31] = asum_l[c];
     }
     if (residual) {
-        // centres rows d0..d0+31, columns k0 + kw*64 .. +63 -> wave-private LDS tile (coalesced 256-byte rows)
+        // centres rows d0..d0+31, columns k0 + kw*64 .. +63 -> wave-private LDS tile (coalesced 256-byte rows).  All eight
+        // loads are issued before the first LDS write: one global round trip instead of eight back to back.
+        float4 cw[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-            const float4 w = *reinterpret_cast<const float4*>(centres + (int64_t)(d0 + row) * K + k0 + kw * 64 + c4);
-            *reinterpret_cast<float4*>(wl + row * T3_WS + c4) = w;
+            cw[it] = *reinterpret_cast<const float4*>(centres + (int64_t)(d0 + row) * K + k0 + kw * 64 + c4);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            *reinterpret_cast<float4*>(wl + row * T3_WS + c4) = cw[it];
         }
     }
     __syncthreads();
