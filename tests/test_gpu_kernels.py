@@ -603,3 +603,52 @@ def test_batch_norm_rows_rank3(B, L, C):
     assert_close(bg.grad, p["bn/beta"].grad, 1e-4, "dbeta")
     assert_close(mmg, mm.double() * 0.999 + upd["bn/moving_mean"] * 0.001, tol=1e-6, what="moving_mean")
     assert_close(mvg, mv.double() * 0.999 + upd["bn/moving_variance"] * 0.001, tol=1e-6, what="moving_variance")
+
+
+def test_netvlad_batch_split_invariance_full_size():
+    """Size-independent property at BASELINE cfg-2 shapes, forward AND backward: with inference-mode batch norm (a fixed
+    affine) clips are independent, so pooling the 80-clip batch equals pooling its two halves -- descriptors and input
+    gradients clip by clip, weight gradients as the sum of the halves'."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, T, D, K = 80, 300, 1024, 256
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(B * T, 1152, device=dev, generator=g)
+    W = (torch.randn(D, K, device=dev, generator=g) / 32).requires_grad_(True)
+    W2 = (torch.randn(1, D, K, device=dev, generator=g) / 32).requires_grad_(True)
+    bn = (1 + 0.1 * torch.randn(K, device=dev, generator=g), 0.1 * torch.randn(K, device=dev, generator=g),
+          0.1 * torch.randn(K, device=dev, generator=g), 1 + 0.2 * torch.rand(K, device=dev, generator=g))
+    R = torch.randn(B, D * K, device=dev, generator=g)
+
+    def run(rows, r):
+        xi = x[rows, :D].detach().requires_grad_(True)
+        out = ops.netvlad(xi, W, W2, T, bn=bn, is_training=False)
+        gx, gW, gW2 = torch.autograd.grad((out * r).sum(), [xi, W, W2])
+        return out.detach(), gx, gW, gW2
+    full = run(slice(0, B * T), R)
+    h = B // 2
+    a, b = run(slice(0, h * T), R[:h]), run(slice(h * T, B * T), R[h:])
+    assert rel_err(torch.cat([a[0], b[0]]), full[0]) < 1e-6
+    assert rel_err(torch.cat([a[1], b[1]]), full[1]) < 1e-5
+    assert rel_err(a[2] + b[2], full[2]) < 1e-4 and rel_err(a[3] + b[3], full[3]) < 1e-4
+
+
+def test_attention_properties_full_size(mha_precision):
+    """Size-independent properties of the attention core at the cfg-2 video-encoder shape (B=80, L=256, h=64, d=16):
+    invariance to a joint permutation of keys and values; softmax rows sum to one (constant values come back unchanged) and,
+    with constant values, no gradient reaches the queries or keys."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, L, h, d = 80, 256, 64, 16
+    g = torch.Generator(device=dev).manual_seed(2)
+    q, k, v, do = (torch.randn(B, L, h * d, device=dev, generator=g) for _ in range(4))
+    o = ops.mha_core(q, k, v, h, d ** -0.5)
+    perm = torch.randperm(L, device=dev, generator=g)
+    assert rel_err(ops.mha_core(q, k[:, perm], v[:, perm], h, d ** -0.5), o) < 2e-5
+    qg, kg = q.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    ones = torch.full_like(v, 0.75)
+    oc = ops.mha_core(qg, kg, ones, h, d ** -0.5)
+    assert float((oc - 0.75).abs().max()) < 2e-5
+    oc.backward(do)
+    scale = float(do.abs().max())
+    assert float(qg.grad.abs().max()) < 1e-4 * scale and float(kg.grad.abs().max()) < 1e-4 * scale
