@@ -20,7 +20,8 @@ __all__ = [
     "OracleConfig", "l2_normalize", "batch_norm", "layer_norm", "sample_uniform_frame_index",
     "sample_uniform_frames", "netvlad_forward", "lightvlad_forward", "netvlad_atten_cluster_forward",
     "vlad_aggregate", "multi_head_attention", "multi_head_attention_bn", "attention_core",
-    "transformer_encoder", "transformer_encoder_mod", "moe_forward", "cross_entropy_loss",
+    "transformer_encoder", "transformer_encoder_mod", "one_fc_attention_forward", "attention_modules_mha",
+    "transformer_encoder_block", "moe_forward", "cross_entropy_loss",
     "model_forward", "init_params", "trainable_names", "loss_and_grads", "combine_gradients",
     "clip_gradient_norms", "learning_rate", "adam_tf_update", "train_step", "make_synthetic_batch",
     "BN_EPS", "BN_DECAY", "LN_EPS", "L2N_EPS",
@@ -290,6 +291,54 @@ def netvlad_atten_cluster_forward(x2d, params, scope, S, is_training=True, dropo
         v = l2_normalize(rsum, 1).reshape(x.shape[0], -1)                  # :1655-1656
         return l2_normalize(v, 1)                                          # :1657
     return vlad_aggregate(sims, x, centres)
+
+
+# --------------------------------------------------------------------------------------
+# attention_modules.py (OneFcAttention, MultiHeadAttention, TransformerEncoderBlock)
+# --------------------------------------------------------------------------------------
+def one_fc_attention_forward(x2d, params, scope, num_frames, do_shift=True):
+    """attention_modules.OneFcAttention.forward (attention_modules.py:29-64): one-layer attention whose softmax runs over
+    the FRAMES of a clip (dim=1, :37), weighted frame sums per cluster, then shift, per-cluster L2 and 1/sqrt(K)."""
+    pre = scope + "/" if scope else ""
+    W = params[pre + "one_fc_attention_weight"]                            # [F,K] :30-33
+    F, K = W.shape
+    att = (x2d @ W).reshape(-1, num_frames, K) * (1.0 / math.sqrt(F))      # :34-36
+    att = torch.softmax(att, dim=1)                                        # :37
+    act = att.transpose(1, 2) @ x2d.reshape(-1, num_frames, F)             # [B,K,F] :39-41
+    act = act.reshape(-1, F)                                               # :44
+    if do_shift:
+        act = params[pre + "alpha"] * act + params[pre + "beta"]           # :46-57
+        act = l2_normalize(act, 1) * (1.0 / math.sqrt(K))                  # :58-59
+    return act.reshape(-1, K * F)                                          # :61
+
+
+def attention_modules_mha(x2d, params, scope, num_heads, num_units, max_frames, block_id):
+    """attention_modules.MultiHeadAttention.forward (:78-112): per head its own relu(dense) q, k, v (default layer names
+    dense, dense_1, dense_2 under Block<b>Layer<i>), logits divided by sqrt(num_units) TWICE (:95-96), heads concatenated."""
+    pre = scope + "/" if scope else ""
+    outs = []
+    for i in range(num_heads):
+        sc = f"{pre}Block{block_id}Layer{i}"
+        q, k, v = (torch.relu(x2d @ params[f"{sc}/{n}/kernel"] + params[f"{sc}/{n}/bias"]).reshape(-1, max_frames, num_units)
+                   for n in ("dense", "dense_1", "dense_2"))                # :81-89
+        logits = q @ k.transpose(1, 2) / math.sqrt(num_units) / math.sqrt(num_units)   # :92-96
+        outs.append(torch.softmax(logits, dim=-1) @ v)                     # :96-98
+    return torch.cat(outs, dim=2)                                          # :104-110
+
+
+def transformer_encoder_block(x2d, params, scope, num_units, max_frames, feature_size, num_heads, block_id):
+    """attention_modules.TransformerEncoderBlock.forward (:130-161).  The first layer_norm sees a rank-2 tensor (per-row
+    moments), the second a rank-3 one (moments over frames AND units jointly); there is no second residual (:156)."""
+    pre = scope + "/" if scope else ""
+    att = attention_modules_mha(x2d, params, scope, num_heads, num_units, max_frames, block_id)       # :133-135
+    att = att.reshape(-1, num_units * num_heads)                                                       # :138
+    att = torch.relu(att @ params[pre + "dense/kernel"] + params[pre + "dense/bias"])                  # :141
+    att = layer_norm(att + x2d, params, pre + "LayerNorm")                                             # :145-146
+    out = att.reshape(-1, max_frames, feature_size)                                                    # :149
+    out = torch.relu(out @ params[pre + "conv1d/kernel"][0] + params[pre + "conv1d/bias"])             # :150-151
+    out = out @ params[pre + "conv1d_1/kernel"][0] + params[pre + "conv1d_1/bias"]                     # :152
+    out = layer_norm(out, params, pre + "LayerNorm_1")                                                 # :155
+    return out.reshape(-1, feature_size)                                                               # :156
 
 
 # --------------------------------------------------------------------------------------

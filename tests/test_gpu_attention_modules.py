@@ -1,0 +1,95 @@
+"""-m gpu: attention_modules vs the oracle's restatement: forward values and whole-module gradients,
+weights exchanged by TF variable name."""
+import pytest
+import torch
+
+from oracle import lpm_oracle as O
+from tests._util import cuda, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(build, ref_fn, x, dev, alter=None, tol=2e-5, gtol=2e-4):
+    """build(x_dev) -> product output inside a fresh store; ref_fn(params64, x64) -> oracle output."""
+    from learnablepoolingmethods_amd import variables as vs
+    store = vs.VariableStore(device=dev, seed=3)
+    xd = x.to(dev).requires_grad_(True)
+    with vs.use_store(store):
+        with torch.no_grad():
+            build(xd)                                   # creates the variables
+        if alter:
+            with torch.no_grad():
+                alter(store.vars)
+        out = build(xd)
+    names = sorted(store.trainable_variables())
+    params = {n: store.vars[n].detach().double().cpu().requires_grad_(True) for n in names}
+    x64 = x.double().requires_grad_(True)
+    ref = ref_fn(params, x64)
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < tol, f"forward {rel_l2(out, ref):.3e}"
+    g = torch.Generator().manual_seed(5)
+    R = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    gref = torch.autograd.grad((ref * R).sum(), [x64] + [params[n] for n in names])
+    gout = torch.autograd.grad((out * R.float().to(dev)).sum(), [xd] + [store.vars[n] for n in names])
+    for n, a, b in zip(["input"] + names, gout, gref):
+        assert rel_l2(a, b) < gtol, f"gradient of {n}: {rel_l2(a, b):.3e}"
+    return names
+
+
+@pytest.mark.parametrize("F,T,K,alpha,beta", [(256, 40, 128, None, None), (128, 30, 128, -0.7, 0.3), (1024, 300, 128, 1.3, -0.05)])
+def test_one_fc_attention_matches_oracle(F, T, K, alpha, beta):
+    from learnablepoolingmethods_amd import attention_modules
+    dev = cuda()
+    B = 3
+    x = torch.randn(B * T, F, generator=torch.Generator().manual_seed(0))
+
+    def alter(v):
+        if alpha is not None:
+            v["alpha"].fill_(alpha)
+            v["beta"].fill_(beta)
+        v["one_fc_attention_weight"].mul_(8.0)          # a peaked attention, not a near-uniform one
+    names = _run(lambda xd: attention_modules.OneFcAttention(F, T, K, do_shift=True).forward(xd),
+                 lambda p, x64: O.one_fc_attention_forward(x64, p, "", T, do_shift=True), x, dev, alter)
+    assert names == ["alpha", "beta", "one_fc_attention_weight"]
+
+
+def test_one_fc_attention_without_shift():
+    from learnablepoolingmethods_amd import attention_modules
+    dev = cuda()
+    F, T, K, B = 64, 20, 12, 4
+    x = torch.randn(B * T, F, generator=torch.Generator().manual_seed(1))
+    _run(lambda xd: attention_modules.OneFcAttention(F, T, K, do_shift=False).forward(xd),
+         lambda p, x64: O.one_fc_attention_forward(x64, p, "", T, do_shift=False), x, dev)
+
+
+@pytest.mark.parametrize("units,heads,L", [(16, 4, 40), (8, 8, 64), (32, 2, 24)])
+def test_multi_head_attention_matches_oracle(units, heads, L):
+    """Head widths 8 / 16 run as one K4 launch, 32 as library batched GEMMs."""
+    from learnablepoolingmethods_amd import attention_modules
+    dev = cuda()
+    F, B = 48, 5
+    x = torch.randn(B * L, F, generator=torch.Generator().manual_seed(2))
+    names = _run(lambda xd: attention_modules.MultiHeadAttention(heads, units, L, 2).forward(xd),
+                 lambda p, x64: O.attention_modules_mha(x64, p, "", heads, units, L, 2), x, dev,
+                 alter=lambda v: [t.mul_(4.0) for n, t in v.items() if n.endswith("kernel")])
+    assert f"Block2Layer{heads - 1}/dense_2/bias" in names and len(names) == 6 * heads
+
+
+@pytest.mark.parametrize("F,heads,L", [(128, 2, 32), (16, 3, 20)])
+def test_transformer_encoder_block_matches_oracle(F, heads, L):
+    from learnablepoolingmethods_amd import attention_modules
+    dev = cuda()
+    B = 40 if F == 128 else 3            # 1280 rows: the dense layers take the split-bf16 GEMM path
+    x = torch.randn(B * L, F, generator=torch.Generator().manual_seed(3))
+
+    def alter(v):
+        for n, t in v.items():
+            if n.endswith("bias") or n.endswith("beta"):
+                t.normal_(0.0, 0.1, generator=None)
+    # 1.8 M ReLU inputs computed to ~5e-6: a handful land on the other side of zero than in the fp64 oracle, and each such
+    # unit moves the (small) gradient tensors' Frobenius norm by ~1/sqrt(elements) ~ 1.7e-3 (measured: every intermediate
+    # VALUE and the gradient at each ReLU OUTPUT agree to 5e-6, the gradient at its input differs in those few elements only)
+    names = _run(lambda xd: attention_modules.TransformerEncoderBlock(True, F, L, F, heads, 0).forward(xd),
+                 lambda p, x64: O.transformer_encoder_block(x64, p, "", F, L, F, heads, 0), x, dev, alter, tol=3e-5,
+                 gtol=1e-2 if F == 128 else 5e-4)
+    assert {"dense/kernel", "conv1d/kernel", "conv1d_1/bias", "LayerNorm/gamma", "LayerNorm_1/beta"} <= set(names)

@@ -135,3 +135,29 @@ def test_inference_csv_format():
     assert lines == ["ab12,1 0.9 2 0.5 0 0.1\n", "cd34,2 0.75 0 0.25 3 0.123457\n"]
     assert inference.CSV_HEADER == "VideoId,LabelConfidencePairs\n"
     assert list(inference.format_lines(["x"], p[:1], 10)) == ["x,1 0.9 2 0.5 0 0.1 3 0\n"]       # top_k larger than the vocabulary
+
+
+def test_attention_modules_host_side_and_variable_names():
+    """attention_modules on the CPU: the library-GEMM branches (head width not 8/16, do_shift=False) equal the oracle and the
+    variables carry TF1's default layer names; the pooling branch that needs the HIP kernels fails loudly without a GPU."""
+    from learnablepoolingmethods_amd import attention_modules
+    from learnablepoolingmethods_amd._capi import LpmError
+    F, L, heads, B = 12, 6, 2, 3
+    x = torch.randn(B * L, F, generator=torch.Generator().manual_seed(0))
+    store = vs.VariableStore(device="cpu", seed=2)
+    with vs.use_store(store), vs.variable_scope("tower"):
+        out = attention_modules.TransformerEncoderBlock(True, F, L, F, heads, 1).forward(x)
+    names = set(store.vars)
+    assert {"tower/Block1Layer0/dense/kernel", "tower/Block1Layer1/dense_2/bias", "tower/dense/kernel", "tower/conv1d/kernel",
+            "tower/conv1d_1/bias", "tower/LayerNorm/gamma", "tower/LayerNorm_1/beta"} <= names
+    assert tuple(store.vars["tower/conv1d/kernel"].shape) == (1, F, 4 * F)
+    ref = O.transformer_encoder_block(x.double(), {k: v.detach().double() for k, v in store.vars.items()}, "tower", F, L, F,
+                                      heads, 1)
+    assert out.shape == (B * L, F) and float((out.detach().double() - ref).abs().max()) < 1e-5
+    store = vs.VariableStore(device="cpu", seed=2)
+    with vs.use_store(store):
+        raw = attention_modules.OneFcAttention(F, L, 5, do_shift=False).forward(x)
+        ref = O.one_fc_attention_forward(x.double(), {k: v.detach().double() for k, v in store.vars.items()}, "", L, False)
+        assert float((raw.detach().double() - ref).abs().max()) < 1e-5
+        with pytest.raises(LpmError):
+            attention_modules.OneFcAttention(F, L, 5, do_shift=True).forward(x)
