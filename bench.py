@@ -99,6 +99,9 @@ def main():
     # LPM_SHARE_GPU=1 (debug only): several ranks on ONE GPU over gloo, to exercise the data-parallel code path on a
     # single-GPU box; the measured configuration is always one rank per GPU over RCCL.
     share = os.environ.get("LPM_SHARE_GPU") == "1"
+    if os.environ.get("LPM_SINGLE_STREAM") == "1":     # profiling only: per-kernel durations without a concurrent neighbour
+        from learnablepoolingmethods_amd import FLAGS as _flags
+        _flags.audio_side_stream = False
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
