@@ -24,12 +24,12 @@ __device__ __forceinline__ f32x16 t3_mfma(t3_u32x4 a, t3_u32x4 b, f32x16 c) {
 }
 __device__ __forceinline__ float t3_bf(unsigned h) { return __uint_as_float(h << 16); }
 
-constexpr int T3_NS = 4;                  // ring stages
+constexpr int T3_NS = 3;                  // ring stages (48 KB: three workgroups per CU)
 constexpr int T3_STAGE = 16 * 1024;       // bytes per stage: 4 A tiles + 4 x tiles, 2 planes, 1 KB each
-constexpr int T3_WS = 68;                 // epilogue per-wave tile row stride (floats): 272 B, 16-B aligned, conflict-free
-constexpr int T3_EPI = 8 * 32 * T3_WS * 4;  // epilogue bytes (8 waves x [32 d][64 k + pad])
+constexpr int T3_WS = 36;                 // epilogue per-wave tile row stride (floats): 144 B, 16-B aligned
+constexpr int T3_EPI = 8 * 32 * T3_WS * 4;  // epilogue bytes (8 waves x [32 d][32 k + pad]), overlays the ring
 
-__global__ __launch_bounds__(512, 4) void vlad_aggregate_tiles3_kernel(
+__global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
     const uint4* __restrict__ at, const uint4* __restrict__ xt, const float* __restrict__ centres, int T, int D, int K,
     int S, int KT, int residual, float* __restrict__ nrm, float* __restrict__ asum, float* __restrict__ colsq_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object (guide 5, trap (a))
@@ -93,69 +93,62 @@ __global__ __launch_bounds__(512, 4) void vlad_aggregate_tiles3_kernel(
     }
     __syncthreads();     // no DMA in flight any more: the ring is reused by the epilogue
 
-    // ---- epilogue: residual, partial column square norms, coalesced d-major store of U -----------------
+    // ---- epilogue: transpose through LDS, then residual + partial column square norms ride on the coalesced d-major store.
+    // Two passes (one per 32-cluster tile of the wave) through a wave-private [32 d][32 k] LDS tile that overlays the ring,
+    // so the workgroup's LDS stays at 3 ring stages and THREE workgroups share a CU.  Each lane of the store pass owns 4
+    // fixed cluster columns over 4 rows: the centres are read from global in exactly the store's pattern (issued before the
+    // transposes, no LDS staging), the residual and the squares are applied to the values as they leave LDS, and the column
+    // norms need three cross-lane steps instead of a 32-lane butterfly per accumulator register.
     float* wl = reinterpret_cast<float*>(smem) + wave * (32 * T3_WS);
-    float* red = reinterpret_cast<float*>(smem + T3_EPI);        // [4 dw][128 k]
-    float* ssum = red + 4 * 128;                                 // [128 k]
+    float* red = reinterpret_cast<float*>(smem + T3_NS * T3_STAGE);   // [4 dw][128 k]
+    float* ssum = red + 4 * 128;                                      // [128 k]
     const int k0 = kb * 128, d0 = ds * 128 + dw * 32;
+    const int srow = lane >> 3, c4 = (lane & 7) * 4;            // store pass: row it*8 + srow, columns c4..c4+3 of the tile's 32
+    float4 cw[2][4];
+    if (residual) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                cw[c][it] = *reinterpret_cast<const float4*>(centres + (int64_t)(d0 + it * 8 + srow) * K + k0 + kw * 64 + c * 32 + c4);
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         asum_l[c] += __shfl_xor(asum_l[c], 32, 64);
         if (dw == 0 && half == 0) ssum[(kw * 2 + c) * 32 + l31] = asum_l[c];
     }
-    if (residual) {
-        // centres rows d0..d0+31, columns k0 + kw*64 .. +63 -> wave-private LDS tile (coalesced 256-byte rows).  All eight
-        // loads are issued before the first LDS write: one global round trip instead of eight back to back.
-        float4 cw[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-            cw[it] = *reinterpret_cast<const float4*>(centres + (int64_t)(d0 + row) * K + k0 + kw * 64 + c4);
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-            *reinterpret_cast<float4*>(wl + row * T3_WS + c4) = cw[it];
-        }
-    }
     __syncthreads();
-    float part[2][16];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (residual) w = *reinterpret_cast<const float4*>(wl + l31 * T3_WS + c * 32 + 8 * q + 4 * half);
-            const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * q + j;
-                const float u = acc[c][r] - ssum[(kw * 2 + c) * 32 + 8 * q + 4 * half + j] * wv[j];
-                acc[c][r] = u;
-                part[c][r] = u * u;
-            }
-        }
-    }
-    __syncthreads();     // all reads of the centres tile done before it is overwritten with U
+    float* ob = nrm + ((int64_t)b * D + d0) * K + k0 + kw * 64;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(wl + l31 * T3_WS + c * 32 + 8 * q + 4 * half) =
+            *reinterpret_cast<float4*>(wl + l31 * T3_WS + 8 * q + 4 * half) =
                 make_float4(acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // wave-private tile: program order within the wave is enough
+        __builtin_amdgcn_wave_barrier();
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (residual) s4 = *reinterpret_cast<const float4*>(ssum + (kw * 2 + c) * 32 + c4);
+        float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = half_sum(part[c][r]);
-            if (l31 == 0) red[dw * 128 + (kw * 2 + c) * 32 + mfma32_row(r, lane)] = v;
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + srow;
+            float4 u = *reinterpret_cast<const float4*>(wl + row * T3_WS + c4);
+            if (residual) {
+                u.x -= s4.x * cw[c][it].x; u.y -= s4.y * cw[c][it].y; u.z -= s4.z * cw[c][it].z; u.w -= s4.w * cw[c][it].w;
+            }
+            sq.x = fmaf(u.x, u.x, sq.x); sq.y = fmaf(u.y, u.y, sq.y); sq.z = fmaf(u.z, u.z, sq.z); sq.w = fmaf(u.w, u.w, sq.w);
+            *reinterpret_cast<float4*>(ob + (int64_t)row * K + c * 32 + c4) = u;
         }
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            sq.x += __shfl_xor(sq.x, m, 64); sq.y += __shfl_xor(sq.y, m, 64); sq.z += __shfl_xor(sq.z, m, 64); sq.w += __shfl_xor(sq.w, m, 64);
+        }
+        if (lane < 8) *reinterpret_cast<float4*>(red + dw * 128 + (kw * 2 + c) * 32 + c4) = sq;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                            // all reads of the tile done before pass 1 overwrites it
     }
     __syncthreads();
-    float* ob = nrm + ((int64_t)b * D + d0) * K + k0 + kw * 64;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-        *reinterpret_cast<float4*>(ob + (int64_t)row * K + c4) = *reinterpret_cast<const float4*>(wl + row * T3_WS + c4);
-    }
     if (tid < 128) {
         colsq_part[((int64_t)b * P + ds) * K + k0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
         if (ds == 0) asum[(int64_t)b * K + k0 + tid] = ssum[tid];
@@ -246,8 +239,8 @@ extern "C" int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, con
     LPM_REQUIRE((((uintptr_t)at | (uintptr_t)xt | (uintptr_t)centres | (uintptr_t)nrm) & 15) == 0, LPM_ERR_BADARG,
                 "lpm_vlad_aggregate_tiles3_fwd: pointers must be 16-byte aligned");
     const int S = (T + 15) / 16, KT = K / 32;
-    const size_t lds = (size_t)T3_EPI + (4 * 128 + 128) * sizeof(float);
-    static_assert(T3_EPI >= T3_NS * T3_STAGE, "epilogue region must cover the DMA ring");
+    const size_t lds = (size_t)T3_NS * T3_STAGE + (4 * 128 + 128) * sizeof(float);
+    static_assert(T3_EPI <= T3_NS * T3_STAGE, "the epilogue tiles overlay the DMA ring");
     auto kern = vlad_aggregate_tiles3_kernel;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
