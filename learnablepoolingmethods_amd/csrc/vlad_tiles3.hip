@@ -8,10 +8,15 @@
 // tiles + 4 column tiles (hi and lo planes, 16 KB) into LDS ONCE with LDS-DMA -- the tile format is lane-linear,
 // so a 1 KB fragment is exactly one wave-wide global_load_lds_dwordx4 -- and its 8 waves (2 cluster pairs x 4
 // column tiles, 64 x 32 accumulator tile each) read their fragments from LDS with conflict-free ds_read_b128.
-// L2 -> CU traffic drops to A x D/128 + x x K/128 = 394 MB at cfg-2.  A 4-stage ring keeps three steps of DMA in
+// L2 -> CU traffic drops to A x D/128 + x x K/128 = 394 MB at cfg-2.  A 3-stage ring keeps two steps of DMA in
 // flight across ONE raw s_barrier per step with hand-counted vmcnt (cdna guide: never __syncthreads with glds in
-// flight).  Because a workgroup no longer sees all D columns of a cluster, the intra-normalisation moves to the
-// finalize pass: this kernel writes the un-normalised residual sums U and per-column-slab partial square norms.
+// flight); 48 KB of ring + 2.5 KB of reduction scratch and <= 80 VGPRs put three workgroups on a CU.  Because a
+// workgroup no longer sees all D columns of a cluster, the intra-normalisation moves to the finalize pass: this
+// kernel writes the un-normalised residual sums U and per-column-slab partial square norms.
+// Measured at cfg-2 (80 x 300 x 1024 x 256, tools/time_k2.py): 63 us.  Ablations of this form: DMA + barriers only
+// 36 us, LDS fragment reads only 23 us, reads + MFMAs without DMA 40 us, loop without epilogue 48 us, epilogue only
+// 19 us -- the loop is bound by the delivery path and by LDS read bandwidth (48 KB of fragment reads per 16 KB
+// staged), not by HBM or the matrix pipe (15 us busy).
 #include "lpm_common.h"
 
 namespace lpm {
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    float asum_l[2] = {0.f, 0.f};
+    float asum_w = 0.f;     // partial assignment sum of cluster row l31 of tile (kw, dw >> 1)
 
 #pragma unroll
     for (int s = 0; s < T3_NS - 1; ++s)
@@ -86,9 +91,16 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
             acc[c] = t3_mfma(ah, xh, acc[c]);
             acc[c] = t3_mfma(ah, xl, acc[c]);
             acc[c] = t3_mfma(al, xh, acc[c]);
+            // assignment sums: the four column-tile waves of a cluster pair split the work (tile c = dw >> 1, frame pairs
+            // 2 * (dw & 1) .. + 1 of the fragment); the epilogue adds their partial sums.  All of it on every wave was the
+            // largest VALU consumer of the loop (64 ops per wave-step next to six MFMAs).
+            if (c == (dw >> 1)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                asum_l[c] += (t3_bf(ah[q] & 0xffffu) + t3_bf(al[q] & 0xffffu)) + (t3_bf(ah[q] >> 16) + t3_bf(al[q] >> 16));
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const unsigned h = (dw & 1) ? ah[2 + q2] : ah[q2], l = (dw & 1) ? al[2 + q2] : al[q2];
+                    asum_w += (t3_bf(h & 0xffffu) + t3_bf(l & 0xffffu)) + (t3_bf(h >> 16) + t3_bf(l >> 16));
+                }
+            }
         }
     }
     __syncthreads();     // no DMA in flight any more: the ring is reused by the epilogue
@@ -112,11 +124,10 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
             for (int it = 0; it < 4; ++it)
                 cw[c][it] = *reinterpret_cast<const float4*>(centres + (int64_t)(d0 + it * 8 + srow) * K + k0 + kw * 64 + c * 32 + c4);
     }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        asum_l[c] += __shfl_xor(asum_l[c], 32, 64);
-        if (dw == 0 && half == 0) ssum[(kw * 2 + c) * 32 + l31] = asum_l[c];
-    }
+    asum_w += __shfl_xor(asum_w, 32, 64);
+    if (half == 0) red[(dw & 1) * 128 + (kw * 2 + (dw >> 1)) * 32 + l31] = asum_w;      // two partial sums per cluster
+    __syncthreads();
+    if (tid < 128) ssum[tid] = red[tid] + red[128 + tid];
     __syncthreads();
     float* ob = nrm + ((int64_t)b * D + d0) * K + k0 + kw * 64;
 #pragma unroll
