@@ -179,6 +179,20 @@ def test_train_steps_v1_audio():
     _train_compare("NetVladV1", cfg, 1152, 4, 16, 2, dev)
 
 
+def test_train_steps_v1_relu6_and_remove_diag():
+    """The non-default branches of the shared tail: hidden1_bn + relu6 instead of the bias (netvlad_relu,
+    frame_level_models.py:2321-2337) and context gating with the diagonal removed (gating_remove_diag, :2349-2352)."""
+    from learnablepoolingmethods_amd import FLAGS
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", iterations=12, cluster_size=16, hidden_size=32, vocab_size=40,
+                         base_learning_rate=1e-3, relu=True, remove_diag=True, encoder=False)
+    FLAGS.netvlad_relu, FLAGS.gating_remove_diag = True, True
+    try:     # without the cluster encoders: their 262 k FFN ReLU inputs flip ~1 mask per run at 5e-6 (see _train_compare)
+        _train_compare("NetVladV1", cfg, 1152, 4, 16, 2, dev, encoder=False)
+    finally:
+        FLAGS.reset()
+
+
 def test_train_steps_v2():
     dev = cuda()
     cfg = O.OracleConfig(model="NetVladV2", iterations=12, cluster_size=16, hidden_size=32, vocab_size=40,
