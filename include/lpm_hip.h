@@ -281,13 +281,15 @@ int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, cons
 /* The same with the producing dense layer's bias add (and ReLU) fused: z = act(a + bias) (+ r), act = relu when `relu`
  * (tf.layers.dense(use_bias=True[, activation=relu]) at transformer_utils.py:583, :708-711 followed by the residual
  * layer_norm).  Backward: dz as above (= the residual's gradient), da = dz * [a + bias > 0] (written to `da` only when
- * relu; otherwise da = dz), dbias = column sums of da.  bias == NULL reduces to lpm_layer_norm_fwd / _bwd. */
+ * relu; otherwise da = dz), dbias = column sums of da.  bias == NULL reduces to lpm_layer_norm_fwd / _bwd.
+ * dr_extra (optional, [B,L,F]): added to the residual's gradient on its way out (dz = dz + dr_extra; da is then written
+ * separately, `da` required) -- a second consumer's gradient of the residual tensor, folded in without an add pass. */
 int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma, const float* beta,
                            int B, int L, int F, float eps, float* y, float* z, float* stats, void* workspace,
                            size_t workspace_bytes, lpm_stream_t stream);
 int lpm_layer_norm_act_bwd(const float* dy, const float* z, const float* stats, const float* gamma, const float* a,
                            const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma, float* dbeta,
-                           float* dbias, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+                           float* dbias, const float* dr_extra, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4: multi-head attention core  o = softmax(scale * q k^T) v   per (batch, head)

@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restri
 
 // backward pass 2: dz = rstd * (g - S1/N - zhat * S2/N).  With a fused bias (act_a != NULL): da = dz * [act_a + bias > 0]
 // when relu (written to `da`), da = dz otherwise, and the per-(example, chunk) column partials of da -> biaspart for dbias.
+// dr_extra != NULL: the residual's gradient leaves as dz + dr_extra (another consumer's gradient of the same tensor, e.g. the
+// dy of this very layer norm when its residual also feeds the next one) -- the add rides on the store; da is then written
+// separately even without a ReLU.
 // Threads are laid out (row group, float4 column) with F4 dividing 256 and chunks of whole rows, as in pass 1.
 __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                            const float* __restrict__ stats,
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ partial, int L, int F,
                                                            float* __restrict__ dz, const float* __restrict__ act_a,
                                                            const float* __restrict__ bias, int relu, float* __restrict__ da,
-                                                           float* __restrict__ biaspart) {
+                                                           float* __restrict__ biaspart, const float* __restrict__ dr_extra) {
     __shared__ float4 cs[256];
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const int64_t n_per = (int64_t)L * F;
@@ -185,18 +188,21 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
         o.y = rstd * (d.y * g.y - m1 - (v.y - mean) * rstd * m2);
         o.z = rstd * (d.z * g.z - m1 - (v.z - mean) * rstd * m2);
         o.w = rstd * (d.w * g.w - m1 - (v.w - mean) * rstd * m2);
-        *reinterpret_cast<float4*>(dz + off) = o;
-        if (bias) {
-            if (relu) {
-                const float4 av = *reinterpret_cast<const float4*>(act_a + off);
-                o.x = (av.x + bb.x > 0.f) ? o.x : 0.f;
-                o.y = (av.y + bb.y > 0.f) ? o.y : 0.f;
-                o.z = (av.z + bb.z > 0.f) ? o.z : 0.f;
-                o.w = (av.w + bb.w > 0.f) ? o.w : 0.f;
-                *reinterpret_cast<float4*>(da + off) = o;
-            }
-            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        if (dr_extra) {
+            const float4 e = *reinterpret_cast<const float4*>(dr_extra + off);
+            *reinterpret_cast<float4*>(dz + off) = make_float4(o.x + e.x, o.y + e.y, o.z + e.z, o.w + e.w);
+        } else {
+            *reinterpret_cast<float4*>(dz + off) = o;
         }
+        if (relu) {
+            const float4 av = *reinterpret_cast<const float4*>(act_a + off);
+            o.x = (av.x + bb.x > 0.f) ? o.x : 0.f;
+            o.y = (av.y + bb.y > 0.f) ? o.y : 0.f;
+            o.z = (av.z + bb.z > 0.f) ? o.z : 0.f;
+            o.w = (av.w + bb.w > 0.f) ? o.w : 0.f;
+        }
+        if (da && (relu || dr_extra)) *reinterpret_cast<float4*>(da + off) = o;
+        if (bias) { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
     }
     if (bias) {
         cs[tid] = acc;
@@ -281,9 +287,11 @@ extern "C" int lpm_layer_norm_fwd(const float* a, const float* r, const float* g
 
 extern "C" int lpm_layer_norm_act_bwd(const float* dy, const float* z, const float* stats, const float* gamma, const float* a,
                                       const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
-                                      float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+                                      float* dbeta, float* dbias, const float* dr_extra, void* workspace, size_t workspace_bytes,
+                                      lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(dy && z && stats && gamma && dz && dgamma && dbeta, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: null pointer");
+    LPM_REQUIRE(!dr_extra || da, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: dr_extra needs a separate da");
     LPM_REQUIRE(!bias || dbias, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: a fused bias needs dbias");
     LPM_REQUIRE(!relu || (bias && a && da), LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: relu needs a, bias and da");
     LPM_LN_CHECK("lpm_layer_norm_act_bwd");
@@ -297,7 +305,8 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, const float* z, const flo
     hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart);
     hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, colpart, nblk, 2, F, tmp);
     hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 2, F, dgamma, dbeta, (float*)nullptr);
-    hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart);
+    hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
+                       dr_extra);
     if (bias) {
         hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, biaspart, nblk, 1, F, tmp);
         hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 1, F, dbias, (float*)nullptr, (float*)nullptr);
@@ -308,6 +317,6 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, const float* z, const flo
 extern "C" int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, const float* gamma, int B, int L, int F,
                                   float* dz, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                   lpm_stream_t stream) {
-    return lpm_layer_norm_act_bwd(dy, z, stats, gamma, nullptr, nullptr, 0, B, L, F, dz, nullptr, dgamma, dbeta, nullptr, workspace,
-                                  workspace_bytes, stream);
+    return lpm_layer_norm_act_bwd(dy, z, stats, gamma, nullptr, nullptr, 0, B, L, F, dz, nullptr, dgamma, dbeta, nullptr, nullptr,
+                                  workspace, workspace_bytes, stream);
 }

@@ -598,9 +598,12 @@ def _split_weight(W, need_t=True):
     return w3n, w3k
 
 
-def _mm3(a3, w3):
-    """a3 [M,3K] . w3 [N,3K]^T with fp32 accumulation and output (the weight image is stored transposed)."""
-    return torch.mm(a3, w3.t(), out_dtype=torch.float32)
+def _mm3(a3, w3, acc=None):
+    """a3 [M,3K] . w3 [N,3K]^T with fp32 accumulation and output (the weight image is stored transposed).  acc: an fp32
+    [M,N] tensor the product is added to IN PLACE (the GEMM's beta = 1 instead of a separate add pass)."""
+    if acc is None:
+        return torch.mm(a3, w3.t(), out_dtype=torch.float32)
+    return torch.addmm(acc, a3, w3.t(), out_dtype=torch.float32, out=acc)
 
 
 class _DenseX3(torch.autograd.Function):
@@ -650,7 +653,8 @@ class _QKVX3(torch.autograd.Function):
         return qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
 
     @staticmethod
-    def backward(ctx, dq, dk, dv):
+    def backward(ctx, dq, dk, dv, acc=None):
+        """acc (block Functions only): dx is accumulated into it in place."""
         x3, w3k = ctx.saved_tensors
         K, N = ctx.dims
         M = x3.shape[0]
@@ -662,7 +666,7 @@ class _QKVX3(torch.autograd.Function):
         else:
             dqkv = torch.cat([dq, dk, dv], dim=1)
         dy3 = _split_rows(dqkv, grad=True)
-        dx = _mm3(dy3, w3k) if ctx.needs_input_grad[0] else None
+        dx = _mm3(dy3, w3k, acc) if ctx.needs_input_grad[0] else None
         dW = _dw_x3(x3, dy3, K, 3 * N)
         return dx, dW[:, :N], dW[:, N:2 * N], dW[:, 2 * N:]
 
@@ -706,7 +710,8 @@ class _FFNX3(torch.autograd.Function):
         return _mm3(f3, w23n)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, acc=None):
+        """acc (block Functions only): dy is accumulated into it in place."""
         lib = _capi.load()
         y3, f3, w13k, w23k = ctx.saved_tensors
         F, H, N = ctx.dims
@@ -721,7 +726,7 @@ class _FFNX3(torch.autograd.Function):
         lib.check(lib._lpm_split_rows_relu_bwd(ptr(df), M, H, ptr(f3), ptr(dp3), ptr(db1), ptr(ws), wsb, stream_ptr()),
                   "lpm_split_rows_relu_bwd")
         del df
-        dy = _mm3(dp3, w13k)
+        dy = _mm3(dp3, w13k, acc)
         dW1 = _dw_x3(y3, dp3, F, H)
         return dy, dW1, db1, dW2
 
@@ -869,21 +874,23 @@ class _ResidualLayerNorm(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dr_extra=None):
+        """dr_extra (block Functions only): a second consumer's gradient of the residual tensor, added to the residual's
+        gradient on its way out of the kernel."""
         lib = _capi.load()
         z, stats, gamma, a, bias = ctx.saved_tensors
         B, L, F = z.shape
         dy = dy.contiguous()
         dz = torch.empty_like(z)
-        da = torch.empty_like(z) if ctx.relu else None
+        da = torch.empty_like(z) if (ctx.relu or dr_extra is not None) else None
         dgamma, dbeta = _empty((F,), z), _empty((F,), z)
         dbias = _empty((F,), z) if ctx.has_bias else None
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=z.device)
         lib.check(lib._lpm_layer_norm_act_bwd(ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias), 1 if ctx.relu else 0, B, L,
-                                              F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), wsb, stream_ptr()),
-                  "lpm_layer_norm_act_bwd")
-        return (da if ctx.relu else dz), (dz if ctx.has_r else None), dgamma, dbeta, dbias, None
+                                              F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(dr_extra), ptr(ws), wsb,
+                                              stream_ptr()), "lpm_layer_norm_act_bwd")
+        return (da if da is not None else dz), (dz if ctx.has_r else None), dgamma, dbeta, dbias, None
 
 
 def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False):
@@ -972,6 +979,104 @@ class _MHACore(torch.autograd.Function):
 def mha_core(q, k, v, num_heads, scale):
     """softmax(scale * q k^T) v per head on [B, L, h*d] projections (transformer_utils.py:564-581)."""
     return _MHACore.apply(q, k, v, int(num_heads), float(scale))
+
+
+# ----------------------------------------------------------------------------------------------
+# a6 as two block Functions: the sub-layers run as plain routines (their own forward / backward code, a stand-in ctx) so
+# that the block's backward decides where gradients of a shared tensor meet -- in a GEMM's beta = 1 or on a layer-norm
+# kernel's store instead of in three [B*L, F] add passes per encoder that autograd would insert.
+# ----------------------------------------------------------------------------------------------
+class _SubCtx:
+    def __init__(self):
+        self.needs_input_grad = (True,) * 12
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+def _pack_subs(ctx, subs):
+    flat, counts = [], []
+    for c in subs:
+        flat += list(c.saved_tensors)
+        counts.append(len(c.saved_tensors))
+        c.saved_tensors = ()
+    ctx.save_for_backward(*flat)
+    ctx.subs, ctx.counts = subs, counts
+
+
+def _unpack_subs(ctx):
+    flat, i = ctx.saved_tensors, 0
+    for c, n in zip(ctx.subs, ctx.counts):
+        c.saved_tensors = flat[i:i + n]
+        i += n
+    return ctx.subs
+
+
+class _AttnBlockX3(torch.autograd.Function):
+    """y = layer_norm(MHA(x, x) Wo + bo + x)  (transformer_utils.py:403-407 with :552-586): fused q/k/v GEMM, K4, output
+    GEMM, fused bias + residual layer norm.  Backward: the residual's gradient dz is the beta = 1 operand of the q/k/v
+    input-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale):
+        x = _f32(x, "attention block input").contiguous()
+        B, L, F = x.shape
+        N = Wq.shape[1]
+        cq, cm, co, cl = _SubCtx(), _SubCtx(), _SubCtx(), _SubCtx()
+        q, k, v = _QKVX3.forward(cq, x.view(B * L, F), Wq, Wk, Wv)
+        o = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale)
+        att = _DenseX3.forward(co, o.view(B * L, N), Wo)
+        y = _ResidualLayerNorm.forward(cl, att.view(B, L, Wo.shape[1]), x, gamma, beta, bo, False)
+        _pack_subs(ctx, (cq, cm, co, cl))
+        ctx.shape = (B, L, F, N)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cq, cm, co, cl = _unpack_subs(ctx)
+        B, L, F, N = ctx.shape
+        _, dz, dgamma, dbeta, dbo, _ = _ResidualLayerNorm.backward(cl, dy)          # no ReLU: da is dz
+        do, dWo = _DenseX3.backward(co, dz.view(B * L, F))
+        dq, dk, dv, _, _ = _MHACore.backward(cm, do.view(B, L, N))
+        dx, dWq, dWk, dWv = _QKVX3.backward(cq, dq.view(B * L, N), dk.view(B * L, N), dv.view(B * L, N), acc=dz.view(B * L, F))
+        return dx.view(B, L, F), dWq, dWk, dWv, dWo, dbo, dgamma, dbeta, None, None
+
+
+def attention_block_x3(x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale):
+    return _AttnBlockX3.apply(x, Wq, Wk, Wv, Wo, bo, gamma, beta, int(num_heads), float(scale))
+
+
+class _FFNBlockX3(torch.autograd.Function):
+    """out = layer_norm(n + y),  n = layer_norm(relu(relu(y W1 + b1) W2 + b2) + y)  (transformer_utils.py:409-411 with
+    :696-715).  y feeds the first GEMM and both residuals; backward: the outer layer norm's dz2 is the inner one's incoming
+    gradient AND its residual's second gradient (added on the inner kernel's store), and the sum is the beta = 1 operand of
+    the first GEMM's input-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, y, W1, b1, W2, b2, g1, be1, g2, be2):
+        y = _f32(y, "ffn block input").contiguous()
+        B, L, F = y.shape
+        cf, c1, c2 = _SubCtx(), _SubCtx(), _SubCtx()
+        pre = _FFNX3.forward(cf, y.view(B * L, F), W1, b1, W2)
+        n = _ResidualLayerNorm.forward(c1, pre.view(B, L, F), y, g1, be1, b2, True)
+        out = _ResidualLayerNorm.forward(c2, n, y, g2, be2, None, False)
+        _pack_subs(ctx, (cf, c1, c2))
+        ctx.shape = (B, L, F)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cf, c1, c2 = _unpack_subs(ctx)
+        B, L, F = ctx.shape
+        dz2, _, dg2, dbe2, _, _ = _ResidualLayerNorm.backward(c2, dout)           # gradient of n; y receives the same
+        da1, dzy, dg1, dbe1, db2, _ = _ResidualLayerNorm.backward(c1, dz2, dr_extra=dz2)   # dzy = dz1 + dz2
+        dy, dW1, db1, dW2 = _FFNX3.backward(cf, da1.view(B * L, F), acc=dzy.view(B * L, F))
+        return dy.view(B, L, F), dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2
+
+
+def ffn_block_x3(y, W1, b1, W2, b2, g1, be1, g2, be2):
+    return _FFNBlockX3.apply(y, W1, b1, W2, b2, g1, be1, g2, be2)
 
 
 class _MHACoreBN(torch.autograd.Function):

@@ -104,7 +104,40 @@ class TransformerEncoder(modules.BaseModule):
         self.multi_head_attention = MultiHeadAttention(feature_size, hidden_size, num_heads, attention_dropout, is_train)
         self.ff_network = FeedForwardNetwork(feature_size, ff_filter_size, ff_relu_dropout, is_train, scope_id)
 
+    def _fused_blocks(self, inputs):
+        """The same encoder as two block Functions (ops._AttnBlockX3, ops._FFNBlockX3): identical kernels and variables
+        (created in the unfused path's order), but the three gradient sums of the shared tensors happen inside a GEMM /
+        a layer-norm kernel instead of as add passes."""
+        from . import variables as vs
+        F_, dev = inputs.shape[-1], inputs.device
+        hidden, filt = self.hidden_size, self.ff_network.filter_size
+        wq, _ = layers.dense_variables("q", F_, hidden, False, dev)
+        wk, _ = layers.dense_variables("k", F_, hidden, False, dev)
+        wv, _ = layers.dense_variables("v", F_, hidden, False, dev)
+        wo, bo = layers.dense_variables("output_transform", hidden, self.feature_size, True, dev)
+
+        def ln_vars(scope):
+            with vs.variable_scope(scope):
+                beta = vs.get_variable("beta", [F_], vs.zeros_initializer(), device=dev)
+                gamma = vs.get_variable("gamma", [F_], vs.ones_initializer(), device=dev)
+            return gamma, beta
+        g0, be0 = ln_vars("LayerNorm")
+        w1, b1 = layers.dense_variables("filter_output{}".format(self.scope_id), F_, filt, True, dev)
+        w2, b2 = layers.dense_variables("ff_output{}".format(self.scope_id), filt, self.feature_size, True, dev)
+        g1, be1 = ln_vars("LayerNorm_1")
+        g2, be2 = ln_vars("LayerNorm_2")
+        depth = hidden // self.num_heads
+        attention = ops.attention_block_x3(inputs, wq, wk, wv, wo, bo, g0, be0, self.num_heads, depth ** -0.5)   # :403-407
+        return ops.ffn_block_x3(attention, w1, b1, w2, b2, g1, be1, g2, be2)                                       # :409-411
+
     def forward(self, inputs, **unused_params):
+        from . import FLAGS
+        rows = inputs.numel() // inputs.shape[-1]
+        if (FLAGS.fused_encoder_blocks and inputs.dim() == 3 and inputs.shape[-1] == self.feature_size
+                and self.feature_size in ops.LN_FEATURES and layers.use_split_gemm(inputs, rows, self.hidden_size)
+                and self.ff_network.filter_size % 8 == 0 and self.hidden_size // self.num_heads in (8, 16)
+                and inputs.shape[1] <= 512):
+            return self._fused_blocks(inputs)
         attention, bias = self.multi_head_attention.forward(inputs, inputs, defer_bias=True)
         attention = layers.layer_norm(attention, "LayerNorm", residual=inputs, bias=bias)   # attention + inputs :405-407
         ff_output = self.ff_network.forward(attention)                                 # adds its own residual + LayerNorm_1

@@ -93,3 +93,44 @@ def test_transformer_encoder_block_matches_oracle(F, heads, L):
                  lambda p, x64: O.transformer_encoder_block(x64, p, "", F, L, F, heads, 0), x, dev, alter, tol=3e-5,
                  gtol=1e-2 if F == 128 else 5e-4)
     assert {"dense/kernel", "conv1d/kernel", "conv1d_1/bias", "LayerNorm/gamma", "LayerNorm_1/beta"} <= set(names)
+
+
+def test_v1_encoder_block_functions_match_the_layerwise_path():
+    """transformer_utils.TransformerEncoder as two block Functions (gradient sums of shared tensors folded into a GEMM's
+    beta = 1 and the layer-norm kernel) against the same encoder layer by layer: same variables, same forward values, the
+    gradients of the input and of every variable agree to fp32 summation-order noise.  Also against the oracle."""
+    from learnablepoolingmethods_amd import FLAGS, transformer_utils
+    from learnablepoolingmethods_amd import variables as vs
+    dev = cuda()
+    B, L, F, heads = 16, 64, 128, 8
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, L, F, generator=g)
+    R = torch.randn(B, L, F, generator=g).to(dev)
+    store = vs.VariableStore(device=dev, seed=4)
+
+    def run(fused):
+        FLAGS.fused_encoder_blocks = fused
+        try:
+            xd = x.to(dev).requires_grad_(True)
+            with vs.use_store(store), vs.variable_scope("enc"):
+                enc = transformer_utils.TransformerEncoder(F, F, heads, 0.1, 4 * F, 0.1, True, "encode1")
+                out = enc.forward(xd)
+            names = sorted(store.trainable_variables())
+            grads = torch.autograd.grad((out * R).sum(), [xd] + [store.vars[n] for n in names])
+            return out.detach(), names, grads
+        finally:
+            FLAGS.reset()
+    with torch.no_grad(), vs.use_store(store), vs.variable_scope("enc"):
+        transformer_utils.TransformerEncoder(F, F, heads, 0.1, 4 * F, 0.1, True, "encode1").forward(x.to(dev))
+        for n, t in store.vars.items():
+            if n.endswith("bias") or n.endswith("beta"):
+                t.normal_(0.0, 0.1)
+    out_f, names_f, g_f = run(True)
+    out_u, names_u, g_u = run(False)
+    assert names_f == names_u and len(names_f) == 15
+    assert rel_l2(out_f, out_u) < 1e-6
+    for n, a, b in zip(["input"] + names_f, g_f, g_u):
+        assert rel_l2(a, b) < 2e-6, f"{n}: {rel_l2(a, b):.3e}"
+    p = {n: store.vars[n].detach().double().cpu() for n in names_f}
+    ref = O.transformer_encoder(x.double(), p, "enc", heads, "encode1")
+    assert rel_l2(out_f, ref) < 2e-5
