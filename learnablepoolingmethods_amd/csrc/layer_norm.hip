@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restri
 __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ partial,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int64_t n_per, int F,
-                                                           float eps, float* __restrict__ y, float* __restrict__ stats) {
+                                                           float eps, float* __restrict__ y, int64_t y_batch,
+                                                           float* __restrict__ stats) {
     const int b = blockIdx.x, ch = blockIdx.y;
     double s = 0.0, q = 0.0;
 #pragma unroll
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
     const int64_t i0 = ch * per, i1 = min(n4, i0 + per);
     const int F4 = F / 4;
     const float4* zp = reinterpret_cast<const float4*>(z + (int64_t)b * n_per);
-    float4* yp = reinterpret_cast<float4*>(y + (int64_t)b * n_per);
+    float4* yp = reinterpret_cast<float4*>(y + (int64_t)b * y_batch);
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         const int c = (int)(i % F4) * 4;
         const float4 v = zp[i];
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
 __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, int L, int F,
-                                                           float* __restrict__ partial, float* __restrict__ colpart) {
+                                                           float* __restrict__ partial, float* __restrict__ colpart,
+                                                           int64_t dy_batch) {
     __shared__ float sh[4];
     __shared__ float4 cs[2][256];
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restri
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int l = l0 + rg; l < l1; l += RG) {
         const int64_t off = ((int64_t)b * L + l) * F + 4 * c4;
-        const float4 d = *reinterpret_cast<const float4*>(dy + off);
+        const float4 d = *reinterpret_cast<const float4*>(dy + (int64_t)b * dy_batch + (int64_t)l * F + 4 * c4);
         const float4 v = *reinterpret_cast<const float4*>(z + off);
         const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
         const float gx = d.x * g4.x, gy = d.y * g4.y, gz = d.z * g4.z, gw = d.w * g4.w;
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ partial, int L, int F,
                                                            float* __restrict__ dz, const float* __restrict__ act_a,
                                                            const float* __restrict__ bias, int relu, float* __restrict__ da,
-                                                           float* __restrict__ biaspart, const float* __restrict__ dr_extra) {
+                                                           float* __restrict__ biaspart, const float* __restrict__ dr_extra,
+                                                           int64_t dy_batch) {
     __shared__ float4 cs[256];
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const int64_t n_per = (int64_t)L * F;
@@ -182,7 +185,8 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
     if (bias) bb = *reinterpret_cast<const float4*>(bias + 4 * c4);
     for (int l = l0 + rg; l < l1; l += RG) {
         const int64_t off = ((int64_t)b * L + l) * F + 4 * c4;
-        const float4 d = *reinterpret_cast<const float4*>(dy + off), v = *reinterpret_cast<const float4*>(z + off);
+        const float4 d = *reinterpret_cast<const float4*>(dy + (int64_t)b * dy_batch + (int64_t)l * F + 4 * c4);
+        const float4 v = *reinterpret_cast<const float4*>(z + off);
         float4 o;
         o.x = rstd * (d.x * g.x - m1 - (v.x - mean) * rstd * m2);
         o.y = rstd * (d.y * g.y - m1 - (v.y - mean) * rstd * m2);
@@ -263,8 +267,8 @@ extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
     LPM_REQUIRE(workspace && workspace_bytes >= lpm_layer_norm_workspace_bytes(B, F), LPM_ERR_WORKSPACE, name ": workspace too small")
 
 extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma,
-                                      const float* beta, int B, int L, int F, float eps, float* y, float* z, float* stats,
-                                      void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+                                      const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride,
+                                      float* z, float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(a && gamma && beta && y && stats && (z || (!r && !bias)), LPM_ERR_BADARG,
                 "lpm_layer_norm_act_fwd: null pointer (z is required with a residual or a bias)");
@@ -273,19 +277,23 @@ extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int rel
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
     const int64_t n_per = (int64_t)L * F;
+    const int64_t yb = y_batch_stride ? y_batch_stride : n_per;
+    LPM_REQUIRE(yb >= n_per && yb % 4 == 0 && ((uintptr_t)y & 15) == 0, LPM_ERR_BADARG,
+                "lpm_layer_norm_act_fwd: y_batch_stride must be >= L*F and a multiple of 4, y 16-byte aligned");
     dim3 grid(B, LN_NB);
     hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial);
-    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias) ? z : a, partial, gamma, beta, n_per, F, eps, y, stats);
+    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias) ? z : a, partial, gamma, beta, n_per, F, eps, y, yb, stats);
     return check_launch("lpm_layer_norm_act_fwd");
 }
 
 extern "C" int lpm_layer_norm_fwd(const float* a, const float* r, const float* gamma, const float* beta, int B, int L, int F,
                                   float eps, float* y, float* z, float* stats, void* workspace, size_t workspace_bytes,
                                   lpm_stream_t stream) {
-    return lpm_layer_norm_act_fwd(a, nullptr, 0, r, gamma, beta, B, L, F, eps, y, z, stats, workspace, workspace_bytes, stream);
+    return lpm_layer_norm_act_fwd(a, nullptr, 0, r, gamma, beta, B, L, F, eps, y, 0, z, stats, workspace, workspace_bytes, stream);
 }
 
-extern "C" int lpm_layer_norm_act_bwd(const float* dy, const float* z, const float* stats, const float* gamma, const float* a,
+extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats,
+                                      const float* gamma, const float* a,
                                       const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
                                       float* dbeta, float* dbias, const float* dr_extra, void* workspace, size_t workspace_bytes,
                                       lpm_stream_t stream) {
@@ -302,11 +310,14 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, const float* z, const flo
     float* tmp = biaspart + (size_t)B * LN_NB * F;
     dim3 grid(B, LN_NB);
     const int cb = (F + 63) / 64, nblk = B * LN_NB;
-    hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart);
+    const int64_t dyb = dy_batch_stride ? dy_batch_stride : (int64_t)L * F;
+    LPM_REQUIRE(dyb >= (int64_t)L * F && dyb % 4 == 0 && ((uintptr_t)dy & 15) == 0, LPM_ERR_BADARG,
+                "lpm_layer_norm_act_bwd: dy_batch_stride must be >= L*F and a multiple of 4, dy 16-byte aligned");
+    hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart, dyb);
     hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, colpart, nblk, 2, F, tmp);
     hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 2, F, dgamma, dbeta, (float*)nullptr);
     hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
-                       dr_extra);
+                       dr_extra, dyb);
     if (bias) {
         hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, biaspart, nblk, 1, F, tmp);
         hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 1, F, dbias, (float*)nullptr, (float*)nullptr);
@@ -317,6 +328,6 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, const float* z, const flo
 extern "C" int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, const float* gamma, int B, int L, int F,
                                   float* dz, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                   lpm_stream_t stream) {
-    return lpm_layer_norm_act_bwd(dy, z, stats, gamma, nullptr, nullptr, 0, B, L, F, dz, nullptr, dgamma, dbeta, nullptr, nullptr,
+    return lpm_layer_norm_act_bwd(dy, 0, z, stats, gamma, nullptr, nullptr, 0, B, L, F, dz, nullptr, dgamma, dbeta, nullptr, nullptr,
                                   workspace, workspace_bytes, stream);
 }

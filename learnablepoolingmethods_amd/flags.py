@@ -37,6 +37,8 @@ FLAGS.define("rgb_det_reg", 1e-4, "frame_level_models.py:2213: orthogonality pen
 FLAGS.define("audio_det_reg", 1e-4, "frame_level_models.py:2209: orthogonality penalty on the audio cluster centres")
 FLAGS.define("fused_encoder_blocks", True, "build extension: run the V1 cluster encoder as two block Functions whose backward "
              "folds the gradient sums of shared tensors into GEMM accumulation / the layer-norm kernel (no add passes)")
+FLAGS.define("descriptor_slots", True, "build extension: both encoders write their pooled descriptor into one shared buffer "
+             "(no concat copy forward, no slice copies backward); needs fused_encoder_blocks")
 FLAGS.define("audio_side_stream", True, "build extension: run the audio stream (NetVLAD + encoder, ~100 latency-bound small "
              "launches per step) on a second HIP stream next to the video stream")
 FLAGS.define("dense_precision", "bf16x3", "build extension: encoder dense GEMMs as split-bf16 ('bf16x3', ~4e-6) or 'f32'")

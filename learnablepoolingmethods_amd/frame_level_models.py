@@ -124,23 +124,38 @@ class NetVladV1(models.BaseModel):
             with side, vs.variable_scope("audio_VLAD"):
                 vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder)                     # :2276-2277
 
+        slots = None
         if encoder:
             # tokens = clusters (App. C5): the pooling kernel already wrote the [B, K, D] view
             with vs.variable_scope("video_attention"):
                 video_encoder_block = transformer_utils.TransformerEncoder(
                     feature_size=1024, hidden_size=1024, num_heads=64, attention_dropout=0.1, ff_filter_size=4 * 1024,
                     ff_relu_dropout=0.1, is_train=is_training, scope_id="encode1")
-                vlad_video = video_encoder_block.forward(vlad_video).reshape(-1, 1024 * cluster_size)        # :2282-2292
             if has_audio:
-                with side, vs.variable_scope("audio_attention"):
+                with vs.variable_scope("audio_attention"):
                     audio_encoder_block = transformer_utils.TransformerEncoder(
                         feature_size=128, hidden_size=128, num_heads=16, attention_dropout=0.1, ff_filter_size=4 * 128,
                         ff_relu_dropout=0.1, is_train=is_training, scope_id="encode2")
-                    vlad_audio = audio_encoder_block.forward(vlad_audio).reshape(-1, 128 * (cluster_size // 4))  # :2294-2304
+                if FLAGS.descriptor_slots and video_encoder_block.fused(vlad_video) and audio_encoder_block.fused(vlad_audio):
+                    # both encoders write their result straight into one [B, 1024 K + 128 K/4] buffer: the concat below and
+                    # the slicing of its gradient cost nothing
+                    slots = ops.DescriptorSlots(vlad_video.shape[0], [(cluster_size, 1024), (cluster_size // 4, 128)], vlad_video)
+            with vs.variable_scope("video_attention"):
+                vlad_video = video_encoder_block.forward(vlad_video, out_slot=slots.slots[0] if slots else None)   # :2282-2292
+            if has_audio:
+                with side, vs.variable_scope("audio_attention"):
+                    vlad_audio = audio_encoder_block.forward(vlad_audio, out_slot=slots.slots[1] if slots else None)  # :2294-2304
+            if slots is None:
+                vlad_video = vlad_video.reshape(-1, 1024 * cluster_size)
+                if has_audio:
+                    vlad_audio = vlad_audio.reshape(-1, 128 * (cluster_size // 4))
         if use_side:
             side.join(vlad_audio)
 
-        vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video             # :2309
+        if slots is not None:
+            vlad = slots.join(vlad_video, vlad_audio)                                          # :2309, in place
+        else:
+            vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video         # :2309
         return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
                                       remove_diag, is_training, **unused_params)
 

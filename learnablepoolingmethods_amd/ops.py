@@ -851,24 +851,44 @@ LN_EPS = 1e-12
 LN_FEATURES = (128, 256, 512, 1024)
 
 
+class OutputSlot:
+    """A [B, L, F] clip-slot of a wider [B, total] buffer (ops.DescriptorSlots): handed to a Function as a plain Python
+    object so that autograd does not track the buffer; ``view()`` is the strided tensor the kernel writes."""
+
+    def __init__(self, base, offset, L, F):
+        self.base, self.offset, self.L, self.F = base, int(offset), int(L), int(F)
+
+    def view(self):
+        B, tot = self.base.shape
+        return torch.as_strided(self.base, (B, self.L, self.F), (tot, self.F, 1), self.offset)
+
+
+def _batch_strided(t, L, F):
+    """t as the layer-norm kernels can read / write it: [B, L, F] with contiguous clips at a 16-byte-aligned batch stride."""
+    return (t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == F and t.stride(0) >= L * F and t.stride(0) % 4 == 0
+            and t.data_ptr() % 16 == 0)
+
+
 class _ResidualLayerNorm(torch.autograd.Function):
     """y = layer_norm(act(a + bias) + r): TF1 joint moments, with the producing dense layer's bias add / ReLU fused in."""
 
     @staticmethod
-    def forward(ctx, a, r, gamma, beta, bias, relu):
+    def forward(ctx, a, r, gamma, beta, bias, relu, out=None):
         lib = _capi.load()
         a = _f32(a, "layer_norm input").contiguous()
         B, L, F = a.shape
         r = r.contiguous() if r is not None else None
         bias = bias.contiguous() if bias is not None else None
-        y = torch.empty_like(a)
+        y = out.view() if out is not None else torch.empty_like(a)
+        if tuple(y.shape) != (B, L, F) or not _batch_strided(y, L, F):
+            raise LpmError("layer_norm: output slot does not match [B, L, F] with contiguous clips")
         z = torch.empty_like(a) if (r is not None or bias is not None) else a
         stats = _empty((B, 2), a)
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
         lib.check(lib._lpm_layer_norm_act_fwd(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(gamma), ptr(beta), B, L, F, LN_EPS,
-                                              ptr(y), ptr(z) if z is not a else None, ptr(stats), ptr(ws), wsb, stream_ptr()),
-                  "lpm_layer_norm_act_fwd")
+                                              ptr(y), y.stride(0), ptr(z) if z is not a else None, ptr(stats), ptr(ws), wsb,
+                                              stream_ptr()), "lpm_layer_norm_act_fwd")
         ctx.has_r, ctx.relu, ctx.has_bias = r is not None, bool(relu), bias is not None
         ctx.save_for_backward(z, stats, gamma, a if relu else None, bias)
         return y
@@ -880,22 +900,23 @@ class _ResidualLayerNorm(torch.autograd.Function):
         lib = _capi.load()
         z, stats, gamma, a, bias = ctx.saved_tensors
         B, L, F = z.shape
-        dy = dy.contiguous()
+        if not _batch_strided(dy, L, F):          # a column slice of a wider gradient buffer is read in place
+            dy = dy.contiguous()
         dz = torch.empty_like(z)
         da = torch.empty_like(z) if (ctx.relu or dr_extra is not None) else None
         dgamma, dbeta = _empty((F,), z), _empty((F,), z)
         dbias = _empty((F,), z) if ctx.has_bias else None
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=z.device)
-        lib.check(lib._lpm_layer_norm_act_bwd(ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias), 1 if ctx.relu else 0, B, L,
-                                              F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(dr_extra), ptr(ws), wsb,
-                                              stream_ptr()), "lpm_layer_norm_act_bwd")
-        return (da if da is not None else dz), (dz if ctx.has_r else None), dgamma, dbeta, dbias, None
+        lib.check(lib._lpm_layer_norm_act_bwd(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
+                                              1 if ctx.relu else 0, B, L, F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias),
+                                              ptr(dr_extra), ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_bwd")
+        return (da if da is not None else dz), (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None
 
 
 def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False):
     """layer_norm(act(a + bias) + r) with TF1 joint moments; a, r: [B, L, F]; act = relu when ``relu`` (needs ``bias``)."""
-    return _ResidualLayerNorm.apply(a, r, gamma, beta, bias, bool(relu))
+    return _ResidualLayerNorm.apply(a, r, gamma, beta, bias, bool(relu), None)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1036,7 +1057,7 @@ class _AttnBlockX3(torch.autograd.Function):
     def backward(ctx, dy):
         cq, cm, co, cl = _unpack_subs(ctx)
         B, L, F, N = ctx.shape
-        _, dz, dgamma, dbeta, dbo, _ = _ResidualLayerNorm.backward(cl, dy)          # no ReLU: da is dz
+        _, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]         # no ReLU: da is dz
         do, dWo = _DenseX3.backward(co, dz.view(B * L, F))
         dq, dk, dv, _, _ = _MHACore.backward(cm, do.view(B, L, N))
         dx, dWq, dWk, dWv = _QKVX3.backward(cq, dq.view(B * L, N), dk.view(B * L, N), dv.view(B * L, N), acc=dz.view(B * L, F))
@@ -1054,13 +1075,13 @@ class _FFNBlockX3(torch.autograd.Function):
     the first GEMM's input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, y, W1, b1, W2, b2, g1, be1, g2, be2):
+    def forward(ctx, y, W1, b1, W2, b2, g1, be1, g2, be2, out=None):
         y = _f32(y, "ffn block input").contiguous()
         B, L, F = y.shape
         cf, c1, c2 = _SubCtx(), _SubCtx(), _SubCtx()
         pre = _FFNX3.forward(cf, y.view(B * L, F), W1, b1, W2)
         n = _ResidualLayerNorm.forward(c1, pre.view(B, L, F), y, g1, be1, b2, True)
-        out = _ResidualLayerNorm.forward(c2, n, y, g2, be2, None, False)
+        out = _ResidualLayerNorm.forward(c2, n, y, g2, be2, None, False, out)
         _pack_subs(ctx, (cf, c1, c2))
         ctx.shape = (B, L, F)
         return out
@@ -1069,14 +1090,55 @@ class _FFNBlockX3(torch.autograd.Function):
     def backward(ctx, dout):
         cf, c1, c2 = _unpack_subs(ctx)
         B, L, F = ctx.shape
-        dz2, _, dg2, dbe2, _, _ = _ResidualLayerNorm.backward(c2, dout)           # gradient of n; y receives the same
-        da1, dzy, dg1, dbe1, db2, _ = _ResidualLayerNorm.backward(c1, dz2, dr_extra=dz2)   # dzy = dz1 + dz2
+        dz2, _, dg2, dbe2 = _ResidualLayerNorm.backward(c2, dout)[:4]             # gradient of n; y receives the same
+        da1, dzy, dg1, dbe1, db2 = _ResidualLayerNorm.backward(c1, dz2, dr_extra=dz2)[:5]   # dzy = dz1 + dz2
         dy, dW1, db1, dW2 = _FFNX3.backward(cf, da1.view(B * L, F), acc=dzy.view(B * L, F))
-        return dy.view(B, L, F), dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2
+        return dy.view(B, L, F), dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2, None
 
 
-def ffn_block_x3(y, W1, b1, W2, b2, g1, be1, g2, be2):
-    return _FFNBlockX3.apply(y, W1, b1, W2, b2, g1, be1, g2, be2)
+def ffn_block_x3(y, W1, b1, W2, b2, g1, be1, g2, be2, out=None):
+    """out: an ops.OutputSlot -- the block's result is written straight into that clip-slot of a wider buffer."""
+    return _FFNBlockX3.apply(y, W1, b1, W2, b2, g1, be1, g2, be2, out)
+
+
+class DescriptorSlots:
+    """The pooled descriptors of the streams side by side in ONE [B, sum_i L_i * F_i] buffer (tf.concat(..., 1) at
+    frame_level_models.py:2309): every stream's encoder writes its slot in place, ``join`` hands the buffer to the
+    projection and routes the column slices of its gradient back -- no concat copy forward, no slice copies backward."""
+
+    def __init__(self, batch, dims, like):
+        self.dims = [(int(L), int(F)) for L, F in dims]
+        offs, cur = [], 0
+        for L, F in self.dims:
+            offs.append(cur)
+            cur += L * F
+        self.total = cur
+        self.base = torch.empty((batch, cur), dtype=torch.float32, device=like.device)
+        self.slots = [OutputSlot(self.base, o, L, F) for o, (L, F) in zip(offs, self.dims)]
+        self.offsets = offs
+
+    def join(self, *parts):
+        return _JoinSlots.apply(self, *parts)
+
+
+class _JoinSlots(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, slots, *parts):
+        for p, slot in zip(parts, slots.slots):
+            v = slot.view()
+            if p.data_ptr() != v.data_ptr() or tuple(p.shape) != tuple(v.shape) or p.stride() != v.stride():
+                raise LpmError("DescriptorSlots.join: a part was not written into its slot")
+        ctx.slots = slots
+        return slots.base.view_as(slots.base)
+
+    @staticmethod
+    def backward(ctx, d):
+        sl = ctx.slots
+        B = d.shape[0]
+        out = []
+        for o, (L, F) in zip(sl.offsets, sl.dims):
+            out.append(d[:, o:o + L * F].view(B, L, F))
+        return (None, *out)
 
 
 class _MHACoreBN(torch.autograd.Function):

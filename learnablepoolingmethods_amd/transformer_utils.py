@@ -104,7 +104,7 @@ class TransformerEncoder(modules.BaseModule):
         self.multi_head_attention = MultiHeadAttention(feature_size, hidden_size, num_heads, attention_dropout, is_train)
         self.ff_network = FeedForwardNetwork(feature_size, ff_filter_size, ff_relu_dropout, is_train, scope_id)
 
-    def _fused_blocks(self, inputs):
+    def _fused_blocks(self, inputs, out_slot=None):
         """The same encoder as two block Functions (ops._AttnBlockX3, ops._FFNBlockX3): identical kernels and variables
         (created in the unfused path's order), but the three gradient sums of the shared tensors happen inside a GEMM /
         a layer-norm kernel instead of as add passes."""
@@ -128,16 +128,22 @@ class TransformerEncoder(modules.BaseModule):
         g2, be2 = ln_vars("LayerNorm_2")
         depth = hidden // self.num_heads
         attention = ops.attention_block_x3(inputs, wq, wk, wv, wo, bo, g0, be0, self.num_heads, depth ** -0.5)   # :403-407
-        return ops.ffn_block_x3(attention, w1, b1, w2, b2, g1, be1, g2, be2)                                       # :409-411
+        return ops.ffn_block_x3(attention, w1, b1, w2, b2, g1, be1, g2, be2, out=out_slot)                         # :409-411
 
-    def forward(self, inputs, **unused_params):
+    def fused(self, inputs):
+        """Whether ``forward`` takes the block-Function path for this input (then it can write into an ops.OutputSlot)."""
         from . import FLAGS
         rows = inputs.numel() // inputs.shape[-1]
-        if (FLAGS.fused_encoder_blocks and inputs.dim() == 3 and inputs.shape[-1] == self.feature_size
+        return bool(FLAGS.fused_encoder_blocks and inputs.is_cuda and inputs.dim() == 3 and inputs.shape[-1] == self.feature_size
                 and self.feature_size in ops.LN_FEATURES and layers.use_split_gemm(inputs, rows, self.hidden_size)
                 and self.ff_network.filter_size % 8 == 0 and self.hidden_size // self.num_heads in (8, 16)
-                and inputs.shape[1] <= 512):
-            return self._fused_blocks(inputs)
+                and inputs.shape[1] <= 512)
+
+    def forward(self, inputs, out_slot=None, **unused_params):
+        if self.fused(inputs):
+            return self._fused_blocks(inputs, out_slot)
+        if out_slot is not None:
+            raise ValueError("out_slot needs the block-Function path (TransformerEncoder.fused)")
         attention, bias = self.multi_head_attention.forward(inputs, inputs, defer_bias=True)
         attention = layers.layer_norm(attention, "LayerNorm", residual=inputs, bias=bias)   # attention + inputs :405-407
         ff_output = self.ff_network.forward(attention)                                 # adds its own residual + LayerNorm_1

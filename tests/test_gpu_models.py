@@ -275,6 +275,32 @@ def test_training_is_bitwise_reproducible_across_runs():
     assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
 
 
+def test_block_functions_and_descriptor_slots_do_not_change_the_step():
+    """The encoder as block Functions writing into the shared descriptor buffer (the default at production sizes) against
+    the layer-by-layer graph with a real concat: same loss, same gradient arena to summation-order noise, and the default
+    path is itself bitwise repeatable with the audio branch on its own stream."""
+    from learnablepoolingmethods_amd import FLAGS, registry
+    from learnablepoolingmethods_amd.train import Trainer
+    dev = cuda()
+    B, MF = 16, 40                      # 16 x 256 and 16 x 64 tokens: both encoders take the split-GEMM / block path
+    x, nf, lab = O.make_synthetic_batch(B, MF, 1152, 50, seed=23, min_frames=10)
+    res = []
+    for fused, slots in ((True, True), (True, True), (True, False), (False, False)):
+        FLAGS.fused_encoder_blocks, FLAGS.descriptor_slots = fused, slots
+        try:
+            tr = Trainer(registry.get_model("NetVladV1"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=13,
+                         model_kwargs=dict(iterations=32, cluster_size=256, hidden_size=64))
+            loss = tr.step(x, nf, lab)["loss"].item()
+            torch.cuda.synchronize()
+            res.append((loss, tr.arena.grad.clone(), tr.arena.param.clone()))
+        finally:
+            FLAGS.reset()
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for other in res[2:]:
+        assert abs(other[0] - res[0][0]) <= 1e-6 * abs(res[0][0])
+        assert rel_l2(other[1], res[0][1]) < 5e-6
+
+
 def test_checkpoint_resume_and_inference_csv(tmp_path):
     """Save after two steps, restore into a fresh trainer: the third step is bit-identical to the uninterrupted run
     (variables, Adam slots, global_step under the reference's TF names).  Then reader -> predict -> CSV end to end."""
