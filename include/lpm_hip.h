@@ -328,6 +328,12 @@ int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, c
                 int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
                 const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
                 const float* corr_b, float* dz_partial, lpm_stream_t stream);
+/* The same backward (no logits_bn) writing the q/k/v gradients ONLY as the split-bf16 gradient image the projection GEMMs read:
+ * dqkv3 [B*L, 9*h*d] bf16, row = [hi | hi | lo] planes of the concatenated columns [dq | dk | dv] (what lpm_split_rows with
+ * order = 1 would produce from the fp32 gradients) -- the fp32 dq/dk/dv and the split pass over them never exist. */
+int lpm_mha_bwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
+                         int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, void* dqkv3,
+                         lpm_stream_t stream);
 size_t lpm_mha_logit_stats_workspace_bytes(int B, int L, int h);
 int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float* partial,
                         lpm_stream_t stream);

@@ -45,6 +45,22 @@ __device__ __forceinline__ void mx_split8(const float* v, mx_u32x4& hi, mx_u32x4
         lo[i] = l;
     }
 }
+// Gradient-image output (img = plane stride in bf16 elements, 0 = plain fp32 output): the 4 values go out as bf16 hi / hi /
+// lo planes [hi | hi | lo] at p, p + img, p + 2 img -- the operand image the q/k/v weight- and input-gradient GEMMs read
+// (ops._split_rows(grad=True)), so the fp32 gradient and the split pass over it never exist.
+__device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img, float a, float b, float c, float d) {
+    if (img == 0) {
+        *reinterpret_cast<float4*>(base + off) = make_float4(a, b, c, d);
+    } else {
+        unsigned h0, l0, h1, l1;
+        mx_split2(a, b, h0, l0);
+        mx_split2(c, d, h1, l1);
+        unsigned short* p = reinterpret_cast<unsigned short*>(base) + off;
+        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(p + img) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(p + 2 * (int64_t)img) = make_uint2(l0, l1);
+    }
+}
 // position of key (or query) `i` inside its 32-block in the permuted order: i = 16 t + 4 g + e  ->  8 g + 4 t + e
 __device__ __forceinline__ int mx_perm(int i) { return (i & ~31) | (((i >> 2) & 3) << 3) | (((i >> 4) & 1) << 2) | (i & 3); }
 
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
                                                             const float* __restrict__ lse, int L, int h, float scale,
                                                             const float* __restrict__ key_scale, const float* __restrict__ key_shift,
                                                             float* __restrict__ dq, int64_t ldd, const float* __restrict__ corr_a,
-                                                            const float* __restrict__ corr_b) {
+                                                            const float* __restrict__ corr_b, int img) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = NKT * 16;
     const int nkt = (L + 15) >> 4;
@@ -340,11 +356,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
             dqb = mx_mfma(kh, dl, dqb);
             dqa = mx_mfma(kl, dh, dqa);
         }
-        if (qok && 4 * g < D) {
-            const float4 ov = make_float4((dqa[0] + dqb[0]) * scale, (dqa[1] + dqb[1]) * scale, (dqa[2] + dqb[2]) * scale,
-                                          (dqa[3] + dqb[3]) * scale);
-            *reinterpret_cast<float4*>(dq + ((int64_t)b * L + qrow) * ldd + hh * D + 4 * g) = ov;
-        }
+        if (qok && 4 * g < D)
+            mx_store_grad4(dq, ((int64_t)b * L + qrow) * ldd + hh * D + 4 * g, img, (dqa[0] + dqb[0]) * scale, (dqa[1] + dqb[1]) * scale,
+                           (dqa[2] + dqb[2]) * scale, (dqa[3] + dqb[3]) * scale);
     }
 }
 
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
                                                              const float* __restrict__ key_scale, const float* __restrict__ key_shift,
                                                              float* __restrict__ dk, float* __restrict__ dv, int64_t ldd,
                                                              const float* __restrict__ corr_a, const float* __restrict__ corr_b,
-                                                             float* __restrict__ dz_partial) {
+                                                             float* __restrict__ dz_partial, int img) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = NKT * 16;
     constexpr int NH = D / 8;
@@ -497,9 +511,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
         if (!stats_only && kok && 4 * g < D) {
             const int64_t off = ((int64_t)b * L + krow) * ldd + hh * D + 4 * g;
             const float kmul = AFFINE ? 1.f : MX_LN2;      // the staged Q carried log2(e)
-            *reinterpret_cast<float4*>(dk + off) = make_float4((dka[0] + dkb[0]) * kmul, (dka[1] + dkb[1]) * kmul, (dka[2] + dkb[2]) * kmul,
-                                                               (dka[3] + dkb[3]) * kmul);
-            *reinterpret_cast<float4*>(dv + off) = make_float4(dva[0] + dvb[0], dva[1] + dvb[1], dva[2] + dvb[2], dva[3] + dvb[3]);
+            mx_store_grad4(dk, off, img, (dka[0] + dkb[0]) * kmul, (dka[1] + dkb[1]) * kmul, (dka[2] + dkb[2]) * kmul, (dka[3] + dkb[3]) * kmul);
+            mx_store_grad4(dv, off, img, dva[0] + dvb[0], dva[1] + dvb[1], dva[2] + dvb[2], dva[3] + dvb[3]);
         }
         if (dz_partial) {
             zs += __shfl_xor(zs, 16, 64); zs += __shfl_xor(zs, 32, 64);
@@ -576,20 +589,11 @@ extern "C" int lpm_mha_fwd_x3(const float* q, const float* k, const float* v, in
     return check_launch("lpm_mha_fwd_x3");
 }
 
-extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
-                              int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
-                              const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
-                              const float* corr_b, float* dz_partial, lpm_stream_t stream) {
+static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout, int64_t ldo,
+                         const float* lse, int B, int L, int h, int d, float scale, const float* key_scale, const float* key_shift,
+                         float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a, const float* corr_b, float* dz_partial,
+                         int img, lpm_stream_t stream, const char* what) {
     using namespace lpm;
-    LPM_REQUIRE(q && k && v && o && dout && lse, LPM_ERR_BADARG, "lpm_mha_bwd_x3: null pointer");
-    LPM_REQUIRE((dq && dk && dv) || (!dq && !dk && !dv && dz_partial), LPM_ERR_BADARG,
-                "lpm_mha_bwd_x3: give dq, dk, dv together, or none of them (statistics-only pass needs dz_partial)");
-    LPM_REQUIRE((corr_a == nullptr) == (corr_b == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd_x3: corr_a/corr_b go together");
-    LPM_MX_CHECK("lpm_mha_bwd_x3");
-    LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd_x3: key_scale/key_shift go together");
-    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0, LPM_ERR_BADARG, "lpm_mha_bwd_x3: bad ldo/ldd");
-    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
-                LPM_ERR_BADARG, "lpm_mha_bwd_x3: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
@@ -598,15 +602,15 @@ extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, in
         if (dq) {                                                                                                      \
             auto kq = mha_bwd_dq_x3_kernel<N, AFF, DD, RG>;                                                            \
             const size_t lq = mx_bwd_dq_lds(N * 16, DD);                                                               \
-            if (int rc = mx_reserve(kq, lq, "lpm_mha_bwd_x3")) return rc;                                              \
+            if (int rc = mx_reserve(kq, lq, what)) return rc;                                                          \
             hipLaunchKernelGGL(kq, grid, dim3(256), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dq, \
-                               ldd, corr_a, corr_b);                                                                   \
+                               ldd, corr_a, corr_b, img);                                                              \
         }                                                                                                              \
         auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                                   \
         const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                                  \
-        if (int rc = mx_reserve(kk, lk, "lpm_mha_bwd_x3")) return rc;                                                  \
+        if (int rc = mx_reserve(kk, lk, what)) return rc;                                                              \
         hipLaunchKernelGGL(kk, grid, dim3(256), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv, \
-                           ldd, corr_a, corr_b, dz_partial);                                                           \
+                           ldd, corr_a, corr_b, dz_partial, img);                                                      \
     } while (0)
 #define LPM_MX_BWD1(N, AFF, RG)        \
     do {                               \
@@ -627,5 +631,38 @@ extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, in
 #undef LPM_MX_BWD
 #undef LPM_MX_BWD1
 #undef LPM_MX_BWD3
-    return check_launch("lpm_mha_bwd_x3");
+    return check_launch(what);
+}
+
+extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
+                              int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
+                              const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
+                              const float* corr_b, float* dz_partial, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o && dout && lse, LPM_ERR_BADARG, "lpm_mha_bwd_x3: null pointer");
+    LPM_REQUIRE((dq && dk && dv) || (!dq && !dk && !dv && dz_partial), LPM_ERR_BADARG,
+                "lpm_mha_bwd_x3: give dq, dk, dv together, or none of them (statistics-only pass needs dz_partial)");
+    LPM_REQUIRE((corr_a == nullptr) == (corr_b == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd_x3: corr_a/corr_b go together");
+    LPM_MX_CHECK("lpm_mha_bwd_x3");
+    LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd_x3: key_scale/key_shift go together");
+    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0, LPM_ERR_BADARG, "lpm_mha_bwd_x3: bad ldo/ldd");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+                LPM_ERR_BADARG, "lpm_mha_bwd_x3: pointers must be 16-byte aligned");
+    return mx_bwd_launch(q, k, v, ld, o, dout, ldo, lse, B, L, h, d, scale, key_scale, key_shift, dq, dk, dv, ldd, corr_a, corr_b,
+                         dz_partial, 0, stream, "lpm_mha_bwd_x3");
+}
+
+extern "C" int lpm_mha_bwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
+                                    int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, void* dqkv3,
+                                    lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o && dout && lse && dqkv3, LPM_ERR_BADARG, "lpm_mha_bwd_x3_image: null pointer");
+    LPM_MX_CHECK("lpm_mha_bwd_x3_image");
+    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0, LPM_ERR_BADARG, "lpm_mha_bwd_x3_image: bad ldo");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dqkv3) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_mha_bwd_x3_image: pointers must be 16-byte aligned");
+    const int N = h * d;                                  // image row: [hi(3N) | hi(3N) | lo(3N)] over the columns [dq | dk | dv]
+    unsigned short* base = (unsigned short*)dqkv3;
+    return mx_bwd_launch(q, k, v, ld, o, dout, ldo, lse, B, L, h, d, scale, nullptr, nullptr, (float*)base, (float*)(base + N),
+                         (float*)(base + 2 * N), (int64_t)9 * N, nullptr, nullptr, nullptr, 3 * N, stream, "lpm_mha_bwd_x3_image");
 }

@@ -39,6 +39,8 @@ FLAGS.define("fused_encoder_blocks", True, "build extension: run the V1 cluster 
              "folds the gradient sums of shared tensors into GEMM accumulation / the layer-norm kernel (no add passes)")
 FLAGS.define("descriptor_slots", True, "build extension: both encoders write their pooled descriptor into one shared buffer "
              "(no concat copy forward, no slice copies backward); needs fused_encoder_blocks")
+FLAGS.define("mha_gradient_image", True, "build extension: inside the encoder block Functions the attention backward writes the "
+             "q/k/v gradients directly as the split-bf16 operand image of the projection GEMMs (no fp32 gradients, no split pass)")
 FLAGS.define("audio_side_stream", True, "build extension: run the audio stream (NetVLAD + encoder, ~100 latency-bound small "
              "launches per step) on a second HIP stream next to the video stream")
 FLAGS.define("dense_precision", "bf16x3", "build extension: encoder dense GEMMs as split-bf16 ('bf16x3', ~4e-6) or 'f32'")

@@ -653,19 +653,21 @@ class _QKVX3(torch.autograd.Function):
         return qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
 
     @staticmethod
-    def backward(ctx, dq, dk, dv, acc=None):
-        """acc (block Functions only): dx is accumulated into it in place."""
+    def backward(ctx, dq, dk, dv, acc=None, dy3=None):
+        """acc (block Functions only): dx is accumulated into it in place.  dy3: the gradient image of [dq | dk | dv] when
+        the attention backward produced it directly (then dq, dk, dv are None)."""
         x3, w3k = ctx.saved_tensors
         K, N = ctx.dims
         M = x3.shape[0]
-        esz = dq.element_size()
-        adjacent = (dq.stride() == (3 * N, 1) and dk.stride() == (3 * N, 1) and dv.stride() == (3 * N, 1)
-                    and dk.data_ptr() == dq.data_ptr() + N * esz and dv.data_ptr() == dq.data_ptr() + 2 * N * esz)
-        if adjacent:      # the attention backward wrote all three into one buffer
-            dqkv = torch.as_strided(dq, (M, 3 * N), (3 * N, 1))
-        else:
-            dqkv = torch.cat([dq, dk, dv], dim=1)
-        dy3 = _split_rows(dqkv, grad=True)
+        if dy3 is None:
+            esz = dq.element_size()
+            adjacent = (dq.stride() == (3 * N, 1) and dk.stride() == (3 * N, 1) and dv.stride() == (3 * N, 1)
+                        and dk.data_ptr() == dq.data_ptr() + N * esz and dv.data_ptr() == dq.data_ptr() + 2 * N * esz)
+            if adjacent:      # the attention backward wrote all three into one buffer
+                dqkv = torch.as_strided(dq, (M, 3 * N), (3 * N, 1))
+            else:
+                dqkv = torch.cat([dq, dk, dv], dim=1)
+            dy3 = _split_rows(dqkv, grad=True)
         dx = _mm3(dy3, w3k, acc) if ctx.needs_input_grad[0] else None
         dW = _dw_x3(x3, dy3, K, 3 * N)
         return dx, dW[:, :N], dW[:, N:2 * N], dW[:, 2 * N:]
@@ -985,11 +987,18 @@ class _MHACore(torch.autograd.Function):
         return o
 
     @staticmethod
-    def backward(ctx, do):
+    def backward(ctx, do, image=False):
+        """image (block Functions only, split-bf16 arithmetic): return the q/k/v gradients as the [B*L, 9*h*d] bf16 gradient
+        image of [dq | dk | dv] that ops._QKVX3.backward feeds its GEMMs, written by the kernels themselves."""
         lib = _capi.load()
         B, L, h, d, scale = ctx.dims
         q, k, v, o, lse = ctx.saved_tensors
         do = do.contiguous()
+        if image:
+            dy3 = torch.empty((B * L, 9 * h * d), dtype=torch.bfloat16, device=q.device)
+            lib.check(lib._lpm_mha_bwd_x3_image(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d,
+                                                scale, ptr(dy3), stream_ptr()), "lpm_mha_bwd_x3_image")
+            return dy3
         dq, dk, dv = _dqkv_buffers(q)
         lib.check(_mha_bwd_fn(lib)(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d,
                                    scale, None, None, ptr(dq), ptr(dk), ptr(dv), dq.stride(1), None, None, None, stream_ptr()),
@@ -1059,8 +1068,13 @@ class _AttnBlockX3(torch.autograd.Function):
         B, L, F, N = ctx.shape
         _, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]         # no ReLU: da is dz
         do, dWo = _DenseX3.backward(co, dz.view(B * L, F))
-        dq, dk, dv, _, _ = _MHACore.backward(cm, do.view(B, L, N))
-        dx, dWq, dWk, dWv = _QKVX3.backward(cq, dq.view(B * L, N), dk.view(B * L, N), dv.view(B * L, N), acc=dz.view(B * L, F))
+        from . import FLAGS
+        if MHA_PRECISION == "bf16x3" and FLAGS.mha_gradient_image:
+            dy3 = _MHACore.backward(cm, do.view(B, L, N), image=True)          # the kernels write the GEMM operand image
+            dx, dWq, dWk, dWv = _QKVX3.backward(cq, None, None, None, acc=dz.view(B * L, F), dy3=dy3)
+        else:
+            dq, dk, dv, _, _ = _MHACore.backward(cm, do.view(B, L, N))
+            dx, dWq, dWk, dWv = _QKVX3.backward(cq, dq.view(B * L, N), dk.view(B * L, N), dv.view(B * L, N), acc=dz.view(B * L, F))
         return dx.view(B, L, F), dWq, dWk, dWv, dWo, dbo, dgamma, dbeta, None, None
 
 
