@@ -284,6 +284,8 @@ int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, cons
  * relu; otherwise da = dz), dbias = column sums of da.  bias == NULL reduces to lpm_layer_norm_fwd / _bwd.
  * dr_extra (optional, [B,L,F]): added to the residual's gradient on its way out (dz = dz + dr_extra; da is then written
  * separately, `da` required) -- a second consumer's gradient of the residual tensor, folded in without an add pass.
+ * da_image (optional, [B*L, 3F] bf16): da written as the split-bf16 gradient image [hi | hi | lo] the next GEMMs read
+ * (lpm_split_rows order 1) instead of / besides fp32 `da` (which may then be NULL).
  * y_batch_stride / dy_batch_stride (floats, 0 = L*F): y may be one clip-slot of a wider [B, total] buffer (the pooled
  * descriptors of both streams side by side, tf.concat at frame_level_models.py:2309 without the copy) and dy the matching
  * column slice of that buffer's gradient. */
@@ -293,7 +295,8 @@ int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const fl
 int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats, const float* gamma,
                            const float* a,
                            const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma, float* dbeta,
-                           float* dbias, const float* dr_extra, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+                           float* dbias, const float* dr_extra, void* da_image, void* workspace, size_t workspace_bytes,
+                           lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4: multi-head attention core  o = softmax(scale * q k^T) v   per (batch, head)

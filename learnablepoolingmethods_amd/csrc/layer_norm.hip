@@ -14,6 +14,14 @@ namespace lpm {
 
 constexpr int LN_NB = 16;   // chunks per example
 
+typedef __bf16 ln_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ln_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned ln_bf16_pair(float a, float b) {     // (a, b) -> packed bf16, round to nearest even
+    const ln_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ln_bf16x2));
+}
+__device__ __forceinline__ float ln_bf16_up(unsigned h) { return __uint_as_float(h << 16); }
+
 __device__ __forceinline__ float block_sum(float v, float* sh) {   // 256 threads; result in every thread
     v = wave_sum(v);
     __syncthreads();
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dz, const float* __restrict__ act_a,
                                                            const float* __restrict__ bias, int relu, float* __restrict__ da,
                                                            float* __restrict__ biaspart, const float* __restrict__ dr_extra,
-                                                           int64_t dy_batch) {
+                                                           int64_t dy_batch, unsigned short* __restrict__ da_img) {
     __shared__ float4 cs[256];
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const int64_t n_per = (int64_t)L * F;
@@ -206,6 +214,15 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
             o.w = (av.w + bb.w > 0.f) ? o.w : 0.f;
         }
         if (da && (relu || dr_extra)) *reinterpret_cast<float4*>(da + off) = o;
+        if (da_img) {      // da only feeds GEMMs: it leaves as their split-bf16 gradient image, row = [hi | hi | lo] planes of F
+            unsigned short* p = da_img + ((int64_t)b * L + l) * 3 * F + 4 * c4;
+            const uint2 hi = make_uint2(ln_bf16_pair(o.x, o.y), ln_bf16_pair(o.z, o.w));
+            const uint2 lo = make_uint2(ln_bf16_pair(o.x - ln_bf16_up(hi.x & 0xffffu), o.y - ln_bf16_up(hi.x >> 16)),
+                                        ln_bf16_pair(o.z - ln_bf16_up(hi.y & 0xffffu), o.w - ln_bf16_up(hi.y >> 16)));
+            *reinterpret_cast<uint2*>(p) = hi;
+            *reinterpret_cast<uint2*>(p + F) = hi;
+            *reinterpret_cast<uint2*>(p + 2 * F) = lo;
+        }
         if (bias) { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
     }
     if (bias) {
@@ -295,13 +312,13 @@ extern "C" int lpm_layer_norm_fwd(const float* a, const float* r, const float* g
 extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats,
                                       const float* gamma, const float* a,
                                       const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
-                                      float* dbeta, float* dbias, const float* dr_extra, void* workspace, size_t workspace_bytes,
-                                      lpm_stream_t stream) {
+                                      float* dbeta, float* dbias, const float* dr_extra, void* da_image, void* workspace,
+                                      size_t workspace_bytes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(dy && z && stats && gamma && dz && dgamma && dbeta, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: null pointer");
-    LPM_REQUIRE(!dr_extra || da, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: dr_extra needs a separate da");
+    LPM_REQUIRE(!dr_extra || da || da_image, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: dr_extra needs a separate da (or da_image)");
+    LPM_REQUIRE(!relu || (bias && a && (da || da_image)), LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: relu needs a, bias and da / da_image");
     LPM_REQUIRE(!bias || dbias, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: a fused bias needs dbias");
-    LPM_REQUIRE(!relu || (bias && a && da), LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: relu needs a, bias and da");
     LPM_LN_CHECK("lpm_layer_norm_act_bwd");
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
@@ -317,7 +334,7 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, 
     hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, colpart, nblk, 2, F, tmp);
     hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 2, F, dgamma, dbeta, (float*)nullptr);
     hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
-                       dr_extra, dyb);
+                       dr_extra, dyb, (unsigned short*)da_image);
     if (bias) {
         hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, biaspart, nblk, 1, F, tmp);
         hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 1, F, dbias, (float*)nullptr, (float*)nullptr);
@@ -328,6 +345,6 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, 
 extern "C" int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, const float* gamma, int B, int L, int F,
                                   float* dz, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                   lpm_stream_t stream) {
-    return lpm_layer_norm_act_bwd(dy, 0, z, stats, gamma, nullptr, nullptr, 0, B, L, F, dz, nullptr, dgamma, dbeta, nullptr, nullptr,
+    return lpm_layer_norm_act_bwd(dy, 0, z, stats, gamma, nullptr, nullptr, 0, B, L, F, dz, nullptr, dgamma, dbeta, nullptr, nullptr, nullptr,
                                   workspace, workspace_bytes, stream);
 }

@@ -712,13 +712,14 @@ class _FFNX3(torch.autograd.Function):
         return _mm3(f3, w23n)
 
     @staticmethod
-    def backward(ctx, dout, acc=None):
-        """acc (block Functions only): dy is accumulated into it in place."""
+    def backward(ctx, dout, acc=None, do3=None):
+        """Block Functions only -- acc: dy is accumulated into it in place; do3: dout already as its gradient image."""
         lib = _capi.load()
         y3, f3, w13k, w23k = ctx.saved_tensors
         F, H, N = ctx.dims
         M = y3.shape[0]
-        do3 = _split_rows(dout.contiguous(), grad=True)
+        if do3 is None:
+            do3 = _split_rows(dout.contiguous(), grad=True)
         df = _mm3(do3, w23k)                                              # [M, H]
         dW2 = _dw_x3(f3, do3, H, N)
         dp3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=df.device)
@@ -896,24 +897,27 @@ class _ResidualLayerNorm(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy, dr_extra=None):
-        """dr_extra (block Functions only): a second consumer's gradient of the residual tensor, added to the residual's
-        gradient on its way out of the kernel."""
+    def backward(ctx, dy, dr_extra=None, da_image=False):
+        """Block Functions only -- dr_extra: a second consumer's gradient of the residual tensor, added to the residual's
+        gradient on its way out of the kernel; da_image: da is returned as the [B*L, 3F] bf16 gradient image the next GEMMs
+        read (ops._split_rows(grad=True)) instead of in fp32."""
         lib = _capi.load()
         z, stats, gamma, a, bias = ctx.saved_tensors
         B, L, F = z.shape
         if not _batch_strided(dy, L, F):          # a column slice of a wider gradient buffer is read in place
             dy = dy.contiguous()
         dz = torch.empty_like(z)
-        da = torch.empty_like(z) if (ctx.relu or dr_extra is not None) else None
+        img = torch.empty((B * L, 3 * F), dtype=torch.bfloat16, device=z.device) if da_image else None
+        da = torch.empty_like(z) if ((ctx.relu or dr_extra is not None) and not da_image) else None
         dgamma, dbeta = _empty((F,), z), _empty((F,), z)
         dbias = _empty((F,), z) if ctx.has_bias else None
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=z.device)
         lib.check(lib._lpm_layer_norm_act_bwd(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
                                               1 if ctx.relu else 0, B, L, F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias),
-                                              ptr(dr_extra), ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_bwd")
-        return (da if da is not None else dz), (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None
+                                              ptr(dr_extra), ptr(img), ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_bwd")
+        first = img if da_image else (da if da is not None else dz)
+        return first, (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None
 
 
 def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False):
@@ -1105,8 +1109,13 @@ class _FFNBlockX3(torch.autograd.Function):
         cf, c1, c2 = _unpack_subs(ctx)
         B, L, F = ctx.shape
         dz2, _, dg2, dbe2 = _ResidualLayerNorm.backward(c2, dout)[:4]             # gradient of n; y receives the same
-        da1, dzy, dg1, dbe1, db2 = _ResidualLayerNorm.backward(c1, dz2, dr_extra=dz2)[:5]   # dzy = dz1 + dz2
-        dy, dW1, db1, dW2 = _FFNX3.backward(cf, da1.view(B * L, F), acc=dzy.view(B * L, F))
+        from . import FLAGS
+        if FLAGS.ln_gradient_image:               # the ReLU-masked da1 only feeds the FFN's GEMMs: it leaves the kernel as their image
+            do3, dzy, dg1, dbe1, db2 = _ResidualLayerNorm.backward(c1, dz2, dr_extra=dz2, da_image=True)[:5]
+            dy, dW1, db1, dW2 = _FFNX3.backward(cf, None, acc=dzy.view(B * L, F), do3=do3)
+        else:
+            da1, dzy, dg1, dbe1, db2 = _ResidualLayerNorm.backward(c1, dz2, dr_extra=dz2)[:5]   # dzy = dz1 + dz2
+            dy, dW1, db1, dW2 = _FFNX3.backward(cf, da1.view(B * L, F), acc=dzy.view(B * L, F))
         return dy.view(B, L, F), dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2, None
 
 
