@@ -621,10 +621,12 @@ class _DenseX3(torch.autograd.Function):
         return _mm3(x3, w3n)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy3=None):
+        """dy3 (block Functions only): dy already as its gradient image."""
         x3, w3k = ctx.saved_tensors
         K, N = ctx.dims
-        dy3 = _split_rows(dy.contiguous(), grad=True)
+        if dy3 is None:
+            dy3 = _split_rows(dy.contiguous(), grad=True)
         dx = _mm3(dy3, w3k) if ctx.needs_input_grad[0] else None
         dW = _dw_x3(x3, dy3, K, N) if ctx.needs_input_grad[1] else None
         return dx, dW
@@ -1070,9 +1072,9 @@ class _AttnBlockX3(torch.autograd.Function):
     def backward(ctx, dy):
         cq, cm, co, cl = _unpack_subs(ctx)
         B, L, F, N = ctx.shape
-        _, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]         # no ReLU: da is dz
-        do, dWo = _DenseX3.backward(co, dz.view(B * L, F))
         from . import FLAGS
+        _, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]         # no ReLU: da is dz
+        do, dWo = _DenseX3.backward(co, dz.view(B * L, F))   # (dz also as an image from the kernel: measured neutral, not kept)
         if MHA_PRECISION == "bf16x3" and FLAGS.mha_gradient_image:
             dy3 = _MHACore.backward(cm, do.view(B, L, N), image=True)          # the kernels write the GEMM operand image
             dx, dWq, dWk, dWv = _QKVX3.backward(cq, None, None, None, acc=dz.view(B * L, F), dy3=dy3)
