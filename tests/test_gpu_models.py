@@ -292,13 +292,14 @@ def test_block_functions_and_descriptor_slots_do_not_change_the_step():
                          model_kwargs=dict(iterations=32, cluster_size=256, hidden_size=64))
             loss = tr.step(x, nf, lab)["loss"].item()
             torch.cuda.synchronize()
-            res.append((loss, tr.arena.grad.clone(), tr.arena.param.clone()))
+            res.append((loss, tr.arena.grad.clone(), tr.arena.param.clone(), tr.predict(x, nf).clone()))
         finally:
             FLAGS.reset()
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     for other in res[2:]:
         assert abs(other[0] - res[0][0]) <= 1e-6 * abs(res[0][0])
         assert rel_l2(other[1], res[0][1]) < 5e-6
+        assert rel_l2(other[3], res[0][3]) < 5e-6           # the inference-mode forward (no autograd) takes the same paths
 
 
 def test_checkpoint_resume_and_inference_csv(tmp_path):
