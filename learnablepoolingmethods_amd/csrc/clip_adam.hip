@@ -37,8 +37,17 @@ __global__ __launch_bounds__(256) void ca_tensor_factor_kernel(const float* __re
                                                                float* __restrict__ factor) {
     const int t = blockIdx.x;
     const int64_t c0 = offsets[t] / CA_CHUNK, c1 = (offsets[t + 1] + CA_CHUNK - 1) / CA_CHUNK;
-    double s = 0.0;
-    for (int64_t c = c0 + threadIdx.x; c < c1; c += 256) s += (double)chunk_ss[c];
+    // four independent partial sums per thread: the 33.8 k chunk sums of hidden1_weights are otherwise 132 dependent
+    // load -> add rounds of one workgroup (42 us of pure latency); the order of the additions stays fixed
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int64_t c = c0 + threadIdx.x; c < c1; c += 1024) {
+        const float a = chunk_ss[c];
+        const float b = (c + 256 < c1) ? chunk_ss[c + 256] : 0.f;
+        const float d = (c + 512 < c1) ? chunk_ss[c + 512] : 0.f;
+        const float e = (c + 768 < c1) ? chunk_ss[c + 768] : 0.f;
+        s0 += (double)a; s1 += (double)b; s2 += (double)d; s3 += (double)e;
+    }
+    const double s = (s0 + s1) + (s2 + s3);
     __shared__ double sh[256];
     sh[threadIdx.x] = s;
     __syncthreads();

@@ -1253,6 +1253,7 @@ class _MoeCrossEntropy(torch.autograd.Function):
                                       ptr(part), stream_ptr()), "lpm_moe_ce_fwd")
         ctx.dims = (B, V, num_mixtures, eps)
         ctx.save_for_backward(gate_act, expert_act, labels)
+        ctx.set_materialize_grads(False)      # an unused output (the predictions, in training) arrives as None, not as zeros
         if labels is None:
             ctx.mark_non_differentiable()
             return pred, None
