@@ -18,10 +18,20 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(const float* __restrict__
     const int c = blockIdx.x * 64 + cl;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        for (int b = rg; b < nblk; b += 16) {
-            const float* p = partial + (int64_t)b * 2 * C;
-            s += (double)p[c];
-            q += (double)p[C + c];
+        for (int b = rg; b < nblk; b += 64) {        // four partial rows per round: independent loads, fixed order of additions
+            float ps[4], pq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = b + 16 * u;
+                const float* p = partial + (int64_t)min(bb, nblk - 1) * 2 * C;
+                ps[u] = (bb < nblk) ? p[c] : 0.f;
+                pq[u] = (bb < nblk) ? p[C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += (double)ps[u];
+                q += (double)pq[u];
+            }
         }
     }
     sh[0][rg][cl] = s;
@@ -80,10 +90,20 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __rest
     const int c = blockIdx.x * 64 + cl;
     double s = 0.0, q = 0.0;
     if (c < K) {
-        for (int b = rg; b < nblk; b += 16) {
-            const float* p = partial + (int64_t)b * 2 * K;
-            s += (double)p[c];
-            q += (double)p[K + c];
+        for (int b = rg; b < nblk; b += 64) {        // four partial rows per round: independent loads, fixed order of additions
+            float ps[4], pq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = b + 16 * u;
+                const float* p = partial + (int64_t)min(bb, nblk - 1) * 2 * K;
+                ps[u] = (bb < nblk) ? p[c] : 0.f;
+                pq[u] = (bb < nblk) ? p[K + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += (double)ps[u];
+                q += (double)pq[u];
+            }
         }
     }
     sh[0][rg][cl] = s;

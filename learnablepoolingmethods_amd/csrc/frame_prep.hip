@@ -178,10 +178,20 @@ __global__ __launch_bounds__(1024) void frame_bn_bwd_reduce_kernel(const float* 
     const int c = blockIdx.x * 64 + cl;
     double s = 0.0, q = 0.0;
     if (c < F) {
-        for (int b = rg; b < nblk; b += 16) {
-            const float* p = partial + (int64_t)b * 2 * F;
-            s += (double)p[c];
-            q += (double)p[F + c];
+        for (int b = rg; b < nblk; b += 64) {        // four partial rows per round: independent loads, fixed order of additions
+            float ps[4], pq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = b + 16 * u;
+                const float* p = partial + (int64_t)min(bb, nblk - 1) * 2 * F;
+                ps[u] = (bb < nblk) ? p[c] : 0.f;
+                pq[u] = (bb < nblk) ? p[F + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += (double)ps[u];
+                q += (double)pq[u];
+            }
         }
     }
     sh[0][rg][cl] = s;

@@ -250,9 +250,19 @@ __global__ __launch_bounds__(256) void ln_colreduce1_kernel(const float* __restr
     const int c = blockIdx.x * 64 + cl, y = blockIdx.y;
     float acc[3] = {0.f, 0.f, 0.f};
     if (c < F) {
-        for (int b = y + LN_RS * rg; b < nblk; b += LN_RS * 4) {
-            const float* p = part + (int64_t)b * narr * F + c;
-            for (int a = 0; a < narr; ++a) acc[a] += p[(int64_t)a * F];
+        for (int b = y + LN_RS * rg; b < nblk; b += LN_RS * 16) {     // four rows per round: independent loads, same order of additions
+            float v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = b + LN_RS * 4 * u;
+                const float* p = part + (int64_t)min(bb, nblk - 1) * narr * F + c;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) v[u][a] = (a < narr && bb < nblk) ? p[(int64_t)a * F] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[a] += v[u][a];
         }
     }
     for (int a = 0; a < narr; ++a) sh[rg][a][cl] = acc[a];
