@@ -211,6 +211,11 @@ int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const float* asu
  * clip as split-bf16 fragment tiles and both GEMMs of the backward run through the tile GEMM (csrc/tile_gemm.h):
  *   lpm_vlad_aggregate_bwd_tiles:    dassign (softmax backward fused in the epilogue) and dcentres; xr = row tiles of x
  *                                    (lpm_split_rows_tiles).  Leaves the dU and assignment tiles in `workspace`.
+ *                                    g0 (optional, [B, D]): "no input gradient" mode for frames that come straight out of
+ *                                    input_bn (frame_level_models.py:2265-2277) -- writes g0[b][d] = sum_k dU_b[d,k] U_b[d,k]
+ *                                    and dcentres = -sum_b asum_b dU_b (also without RESIDUAL), from which the caller forms
+ *                                    input_bn's gamma / beta gradients in closed form; the dx operands are NOT produced
+ *                                    (lpm_vlad_aggregate_bwd_tiles_dx must not follow).
  *   lpm_vlad_aggregate_bwd_tiles_dx: dx[B*T, D] (=, or += when accumulate_dx) sum_k a dU  [+ dl . w^T when dlr / wtt, the row
  *                                    tiles of the assignment GEMM's dlogits and the weight tiles of w^T, are given: the
  *                                    soft-assignment GEMM's input gradient rides in the same pass].  Same workspace. */
@@ -218,7 +223,7 @@ size_t lpm_vlad_bwd_tiles_workspace_bytes(int B, int T, int D, int K);
 int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm, const float* asum, const float* colsq,
                                  const float* csq, const float* gsq, const float* assign, const float* scale,
                                  const float* shift, const void* xr, const float* centres, int B, int T, int D, int K,
-                                 int flags, float* dassign, float* dcentres, void* workspace, size_t workspace_bytes,
+                                 int flags, float* dassign, float* dcentres, float* g0, void* workspace, size_t workspace_bytes,
                                  lpm_stream_t stream);
 int lpm_vlad_aggregate_bwd_tiles_dx(const void* workspace, size_t workspace_bytes, const void* dlr, const void* wtt, int B,
                                     int T, int D, int K, float* dx, int64_t lddx, int accumulate_dx, lpm_stream_t stream);

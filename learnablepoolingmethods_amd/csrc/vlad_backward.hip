@@ -355,15 +355,19 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
 // grid (D/32, B): one workgroup stages a [32 d][K] chunk of dU in LDS and emits both tile forms from it.
 __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __restrict__ dO, const float* __restrict__ N,
                                                                 const float* __restrict__ ug, const float* __restrict__ vg,
-                                                                int D, int K, uint4* __restrict__ ub1, uint4* __restrict__ ub2) {
-    extern __shared__ float dus[];           // [32][K+1], then u[K], v[K]
+                                                                int D, int K, uint4* __restrict__ ub1, uint4* __restrict__ ub2,
+                                                                const float* __restrict__ colsq, float* __restrict__ g0) {
+    extern __shared__ float dus[];           // [32][K+1], then u[K], v[K] (, then rn[K], prod [32][K+1] when g0)
     const int KS = K + 1;
     float* cu = dus + 32 * KS;
     float* cv = cu + K;
+    float* rn = cv + K;                      // g0 only: norm of the un-normalised column, U = N * rn
+    float* prod = rn + K;                    // g0 only: dU * U
     const int tid = threadIdx.x, b = blockIdx.y, d0 = blockIdx.x * 32;
     for (int k = tid; k < K; k += 256) {
         cu[k] = ug[(int64_t)b * K + k];
         cv[k] = vg[(int64_t)b * K + k];
+        if (g0) rn[k] = sqrtf(fmaxf(colsq[(int64_t)b * K + k], kL2Eps));
     }
     __syncthreads();
     const int K4 = K / 4;
@@ -378,8 +382,27 @@ __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __r
         dst[1] = cu[k + 1] * a.y - cv[k + 1] * n.y;
         dst[2] = cu[k + 2] * a.z - cv[k + 2] * n.z;
         dst[3] = cu[k + 3] * a.w - cv[k + 3] * n.w;
+        if (g0) {
+            float* pd = prod + r * KS + k;
+            pd[0] = dst[0] * n.x * rn[k + 0];
+            pd[1] = dst[1] * n.y * rn[k + 1];
+            pd[2] = dst[2] * n.z * rn[k + 2];
+            pd[3] = dst[3] * n.w * rn[k + 3];
+        }
     }
     __syncthreads();
+    if (g0) {
+        // g0[b][d] = sum_k dU[d,k] U[d,k]: the only thing the input batch norm's gamma gradient needs from this clip when the
+        // frames themselves need no gradient (see ops._NetVLAD.backward); fixed summation order (lane-strided, then the wave tree)
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = wave * 8 + rr;
+            float acc = 0.f;
+            for (int k = lane; k < K; k += 64) acc += prod[r * KS + k];
+            acc = wave_sum(acc);
+            if (lane == 0) g0[(int64_t)b * D + d0 + r] = acc;
+        }
+    }
     const int KT = K / 32, DS = D / 16, KS16 = K / 16, DT = D / 32;
     for (int it = tid; it < 2 * KT * 64; it += 256) {            // reduction over d, columns k
         const int lane = it & 63, kt = (it >> 6) % KT, dsl = (it >> 6) / KT;
@@ -393,6 +416,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __r
         ub1[base] = hi;
         ub1[base + 64] = lo;
     }
+    if (ub2 == nullptr) return;                                  // no input gradient wanted: the dx GEMM's operand is not needed
     for (int it = tid; it < KS16 * 64; it += 256) {              // reduction over k, columns d
         const int lane = it & 63, ks = it >> 6;
         const int dl = lane & 31, k = ks * 16 + 8 * (lane >> 5);
@@ -566,11 +590,12 @@ extern "C" size_t lpm_vlad_bwd_tiles_workspace_bytes(int B, int T, int D, int K)
 extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm, const float* asum, const float* colsq,
                                             const float* csq, const float* gsq, const float* assign, const float* scale,
                                             const float* shift, const void* xr, const float* centres, int B, int T, int D,
-                                            int K, int flags, float* dassign, float* dcentres, void* workspace,
+                                            int K, int flags, float* dassign, float* dcentres, float* g0, void* workspace,
                                             size_t workspace_bytes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(dout && nrm && asum && colsq && csq && gsq && assign && xr && dassign && workspace, LPM_ERR_BADARG,
                 "lpm_vlad_aggregate_bwd_tiles: null pointer");
+    LPM_REQUIRE(!g0 || dcentres, LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd_tiles: g0 needs a dcentres buffer (with or without RESIDUAL)");
     const bool residual = (flags & LPM_VLAD_RESIDUAL) != 0;
     const bool sm = (flags & LPM_VLAD_SOFTMAX) != 0;
     LPM_REQUIRE(!residual || (centres && dcentres), LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd_tiles: RESIDUAL needs centres/dcentres");
@@ -598,16 +623,16 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr, D, K, dots);
     hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil);
     {
-        const size_t lds = (size_t)(32 * (K + 1) + 2 * K) * sizeof(float);
+        const size_t lds = (size_t)(32 * (K + 1) + 2 * K + (g0 ? K + 32 * (K + 1) : 0)) * sizeof(float);
         auto kern = vlad_bwd_du_tiles_kernel;
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             set_error("lpm_vlad_aggregate_bwd_tiles: cannot reserve %zu bytes of LDS", lds);
             return LPM_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(256), lds, s, dO, nrm, u, v, D, K, ub1, ub2);
+        hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(256), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0);
     }
-    {
+    if (!g0) {       // the assignment's row tiles are the A operand of the dx GEMM only
         const size_t lds = (size_t)32 * (K + 1) * sizeof(float);
         if (sm) {
             auto kern = vlad_bwd_assign_rows_kernel<true>;
@@ -628,7 +653,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     g.logits = assign; g.scale = scale; g.shift = shift; g.ctil = ctil; g.softmax = sm ? 1 : 0;
     const int rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles");
     if (rc != LPM_OK) return rc;
-    if (residual) {
+    if (residual || g0) {        // dcentres = - sum_b asum_b dU_b: the centres' gradient, and (g0) the input batch norm's beta term
         const int64_t n4 = (int64_t)D * K / 4;
         hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dO, nrm, asum, u, v, B, D, K,
                            dcentres);

@@ -28,7 +28,8 @@ class NetVLAD():
         self.add_batch_norm = add_batch_norm
         self.cluster_size = int(cluster_size)
 
-    def forward(self, reshaped_input, kmajor=False):
+    def forward(self, reshaped_input, kmajor=False, input_affine=None):
+        """input_affine: (gamma, beta) slices of input_bn when reshaped_input is its (gradient-free) output, see ops.netvlad."""
         D, K, dev = self.feature_size, self.cluster_size, reshaped_input.device
         std = 1 / math.sqrt(D)
         cluster_weights = vs.get_variable("cluster_weights", [D, K], vs.random_normal_initializer(std), device=dev)   # :2775
@@ -43,7 +44,7 @@ class NetVLAD():
                                                device=dev)                                                           # :2805-2808
         # matmul -> cluster_bn -> softmax -> a^T x - sum(a) W2 -> l2norm(D) -> flatten -> l2norm  (:2781-2822)
         return ops.netvlad(reshaped_input, cluster_weights, cluster_weights2, self.max_frames, bn=bn, bias=bias,
-                           is_training=self.is_training, kmajor=kmajor)
+                           is_training=self.is_training, kmajor=kmajor, input_affine=input_affine)
 
 
 class LightVLAD(NetVLAD):
@@ -109,7 +110,17 @@ class NetVladV1(models.BaseModel):
 
         video_NetVLAD = NetVLAD(1024, max_frames, cluster_size, add_batch_norm, is_training, "netvlad_rgb_scope")
         audio_NetVLAD = NetVLAD(128, max_frames, cluster_size // 4, add_batch_norm, is_training, "netvlad_audio_scope")
-        if has_audio and reshaped_input.is_cuda:
+        aff_v = aff_a = None
+        if (FLAGS.input_bn_grad_shortcut and add_batch_norm and is_training and reshaped_input.is_cuda and torch.is_grad_enabled()
+                and ops.netvlad_input_shortcut_ok(max_frames, 1024, cluster_size)
+                and (not has_audio or ops.netvlad_input_shortcut_ok(max_frames, 128, cluster_size // 4))):
+            # the frames need no gradient of their own, only input_bn's gamma / beta do: the pooling ops take those as inputs and
+            # return their gradients in closed form (ops._NetVLAD.backward); the [B*S, 1152] input gradient is never formed
+            g_in, b_in, _, _ = layers.bn_variables("input_bn", feature_size, reshaped_input.device)
+            with torch.no_grad():
+                rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
+            aff_v, aff_a = (g_in[0:1024], b_in[0:1024]), (g_in[1024:], b_in[1024:])
+        elif has_audio and reshaped_input.is_cuda:
             rgb, audio = ops.split_columns(reshaped_input, 1024)      # the two slices, sharing one gradient buffer
         else:
             rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
@@ -119,10 +130,10 @@ class NetVladV1(models.BaseModel):
         use_side = has_audio and reshaped_input.is_cuda and FLAGS.audio_side_stream
         side = ops.side_stream(audio, reshaped_input) if use_side else contextlib.nullcontext()
         with vs.variable_scope("video_VLAD"):
-            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder)                           # :2273-2274
+            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v)       # :2273-2274
         if has_audio:
             with side, vs.variable_scope("audio_VLAD"):
-                vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder)                     # :2276-2277
+                vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder, input_affine=aff_a) # :2276-2277
 
         slots = None
         if encoder:

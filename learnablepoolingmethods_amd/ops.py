@@ -368,22 +368,26 @@ def _bwd_tiles_ok(lib, T, D, K):
     return VLAD_PRECISION == "bf16x3" and bool(lib._lpm_assign_gemm_tiles_supported(T, D, K))
 
 
-def _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, shift, x, xr, centres, B, T, D, K, flags, kmajor):
-    """First half of K3's tile form: -> dassign, dcentres, (workspace, bytes) for _aggregate_bwd_tiles_dx."""
+def _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, shift, x, xr, centres, B, T, D, K, flags, kmajor,
+                         no_dx=False):
+    """First half of K3's tile form: -> dassign, dcentres, (workspace, bytes) for _aggregate_bwd_tiles_dx, g0.
+    no_dx: the frames need no gradient -- the dx operands are not produced; g0 [B, D] = sum_k dU U and dcentres = -sum_b asum dU
+    (also without a residual term) come back instead (see _NetVLAD.backward)."""
     st = stream_ptr()
     if xr is None:
         xr = _tile_buffer(lib._lpm_row_tiles_bytes(B, T, D), x)
         lib.check(lib._lpm_split_rows_tiles(ptr(x), x.stride(0), B, T, D, ptr(xr), st), "lpm_split_rows_tiles")
     dassign = _empty((B * T, K), x)
-    dcentres = _empty((D, K), x) if centres is not None else None
+    dcentres = _empty((D, K), x) if (centres is not None or no_dx) else None
+    g0 = _empty((B, D), x) if no_dx else None
     wsb = lib._lpm_vlad_bwd_tiles_workspace_bytes(B, T, D, K)
     ws = _tile_buffer(wsb, x)
     fl = flags | (LPM_VLAD_OUT_KMAJOR if kmajor else 0)
     with _timed("vlad_aggregate_bwd", (B, T, D, K)):
         lib.check(lib._lpm_vlad_aggregate_bwd_tiles(ptr(dout), ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(assign),
                                                     ptr(scale), ptr(shift), ptr(xr), ptr(centres), B, T, D, K, fl, ptr(dassign),
-                                                    ptr(dcentres), ptr(ws), wsb, st), "lpm_vlad_aggregate_bwd_tiles")
-    return dassign, dcentres, (ws, wsb)
+                                                    ptr(dcentres), ptr(g0), ptr(ws), wsb, st), "lpm_vlad_aggregate_bwd_tiles")
+    return dassign, dcentres, (ws, wsb), g0
 
 
 def _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, like, B, T, D, K, out=None):
@@ -429,7 +433,9 @@ class _NetVLAD(torch.autograd.Function):
     cluster_biases; cluster_weights2 [1,D,K] (None = LightVLAD).  frame_level_models.py:2773-2824."""
 
     @staticmethod
-    def forward(ctx, x, W, gamma, beta, moving_mean, moving_var, bias, W2, T, is_training, kmajor):
+    def forward(ctx, x, W, gamma, beta, moving_mean, moving_var, bias, W2, T, is_training, kmajor, in_gamma=None, in_beta=None):
+        """in_gamma / in_beta ([D] slices of input_bn's gamma / beta): x is input_bn's output for these columns and needs no
+        gradient of its own -- the backward then returns input_bn's gamma / beta gradients in closed form instead of dx."""
         lib = _capi.load()
         x = _rows(x, "reshaped_input")
         W = _f32(W, "cluster_weights").contiguous()
@@ -477,19 +483,24 @@ class _NetVLAD(torch.autograd.Function):
         out, nrm, asum, colsq, csq, gsq, xt = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor)
         ctx.dims = (B, T, D, K, flags, kmajor, use_bn, is_training, W2 is not None, tiles)
         ctx.dx_slot = getattr(x, "_lpm_dx_slot", None)
-        ctx.save_for_backward(x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr)
+        ctx.no_dx = in_gamma is not None and tiles and _bwd_tiles_ok(lib, T, D, K)
+        if in_gamma is not None and not ctx.no_dx:
+            raise LpmError("netvlad: the input_bn gradient shortcut needs the tile (bf16x3) forms of K1 and K3 for this shape")
+        ctx.save_for_backward(x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr,
+                              in_gamma, in_beta)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _capi.load()
         B, T, D, K, flags, kmajor, use_bn, is_training, has_w2, tiles = ctx.dims
-        x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr = ctx.saved_tensors
+        x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr, in_gamma, in_beta = ctx.saved_tensors
         dout = _f32(dout, "dout").contiguous()
         k3_tiles = _bwd_tiles_ok(lib, T, D, K)
+        no_dx = ctx.no_dx
         if k3_tiles:
-            dlt, dcentres, wspace = _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, xr,
-                                                         centres, B, T, D, K, flags, kmajor)
+            dlt, dcentres, wspace, g0 = _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, xr,
+                                                             centres, B, T, D, K, flags, kmajor, no_dx=no_dx)
             dx = None
         else:
             dlt, dx, dcentres = _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, centres, B, T, D,
@@ -514,9 +525,26 @@ class _NetVLAD(torch.autograd.Function):
         dlr = wtt = None
         if tiles:
             dW = _assign_gemm_dw_tiles(lib, x, xt, dl, B, T, D, K)
-            dlr, wtt = _assign_gemm_dx_operands(lib, W, dl, B, T, D, K)
+            if not no_dx:
+                dlr, wtt = _assign_gemm_dx_operands(lib, W, dl, B, T, D, K)
         else:   # plain fp32 library GEMM (hipBLASLt through torch)
             dW = x.t().matmul(dl)
+        if no_dx:
+            # x = gamma_in * xhat + beta_in straight out of input_bn and nobody wants d/dx itself.  With V_b = sum_t a x (= U_b +
+            # asum_b W2) and dx = sum_k a dU_b + dl W^T (App. F.2):
+            #   d beta_in [c]            = sum_r dx[r,c]            = sum_b sum_k asum_b[k] dU_b[c,k] + sum_k W[c,k] colsum(dl)[k]
+            #   gamma_in[c] d gamma_in[c] = sum_r dx[r,c] (x - beta) = sum_b sum_k dU_b[c,k] V_b[c,k] + sum_k W[c,k] dW[c,k] - beta_in d beta_in
+            # and sum_b asum_b dU_b = -dcentres, sum_b sum_k dU_b U_b = g0.sum(0), sum_r x dl = dW: everything is already there
+            # (dx, a [B*T, D] GEMM pair plus a pass over the frames, is not formed).  colsum(dl) = 0 after a training-mode
+            # batch norm (its backward removes the batch mean).
+            s1 = -dcentres.sum(1)
+            d_in_beta = s1 if (use_bn and is_training) else s1 + W.matmul(dl.sum(0))
+            g = g0.sum(0) + (W * dW).sum(1)
+            if has_w2:
+                g = g - (dcentres * centres).sum(1)
+            d_in_gamma = (g - in_beta * d_in_beta) / in_gamma
+            dW2 = dcentres.reshape(1, D, K) if has_w2 else None
+            return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta
         if k3_tiles:
             dx = _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, x, B, T, D, K, out=_dx_slot_view(ctx.dx_slot, D))
             if not tiles:
@@ -527,14 +555,23 @@ class _NetVLAD(torch.autograd.Function):
         else:
             dx.addmm_(dl, W.t())
         dW2 = dcentres.reshape(1, D, K) if has_w2 else None
-        return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None
+        return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, None, None
 
 
-def netvlad(x, cluster_weights, cluster_weights2, max_frames, bn=None, bias=None, is_training=True, kmajor=False):
-    """bn = (gamma, beta, moving_mean, moving_var) or None (then ``bias`` = cluster_biases)."""
+def netvlad(x, cluster_weights, cluster_weights2, max_frames, bn=None, bias=None, is_training=True, kmajor=False,
+            input_affine=None):
+    """bn = (gamma, beta, moving_mean, moving_var) or None (then ``bias`` = cluster_biases).  input_affine = (gamma, beta) slices
+    of the input batch norm whose output x is (x itself then needs no gradient): see _NetVLAD.forward."""
     g, b, mm, mv = bn if bn is not None else (None, None, None, None)
+    ig, ib = input_affine if input_affine is not None else (None, None)
     return _NetVLAD.apply(x, cluster_weights, g, b, mm, mv, bias, cluster_weights2, int(max_frames), bool(is_training),
-                          bool(kmajor))
+                          bool(kmajor), ig, ib)
+
+
+def netvlad_input_shortcut_ok(T, D, K):
+    """The input_bn gradient shortcut needs K1 and K3 in their tile (split-bf16) forms for this shape."""
+    lib = _capi.load()
+    return (ASSIGN_PRECISION == "bf16x3" and bool(lib._lpm_assign_gemm_tiles_supported(T, D, K)) and _bwd_tiles_ok(lib, T, D, K))
 
 
 class _VladAggregate(torch.autograd.Function):
@@ -561,8 +598,8 @@ class _VladAggregate(torch.autograd.Function):
         B, T, D, K, flags, kmajor, sshape = ctx.dims
         sims2, x, centres, nrm, asum, colsq, csq, gsq = ctx.saved_tensors
         if _bwd_tiles_ok(lib, T, D, K):
-            dsims, dcentres, wspace = _aggregate_bwd_tiles(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x,
-                                                           None, centres, B, T, D, K, flags, kmajor)
+            dsims, dcentres, wspace, _ = _aggregate_bwd_tiles(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x,
+                                                              None, centres, B, T, D, K, flags, kmajor)
             dx = _aggregate_bwd_tiles_dx(lib, wspace, None, None, x, B, T, D, K)
         else:
             dsims, dx, dcentres = _aggregate_bwd(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x, centres,
