@@ -90,7 +90,8 @@ def test_netvlad_kmajor_layout_and_eval_mode(vlad_precision):
     dev = cuda()
     B, T, D, K = 3, 20, 128, 32
     full, W, gamma, beta, W2, dout = _netvlad_inputs(B, T, D, K, seed=5)
-    mm, mv = 0.1 * torch.randn(K), 1 + 0.2 * torch.rand(K)
+    gmv = torch.Generator().manual_seed(6)
+    mm, mv = 0.1 * torch.randn(K, generator=gmv), 1 + 0.2 * torch.rand(K, generator=gmv)
     p = {"s/cluster_weights": W.double(), "s/cluster_bn/gamma": gamma.double(), "s/cluster_bn/beta": beta.double(),
          "s/cluster_weights2": W2.double(), "s/cluster_bn/moving_mean": mm.double(), "s/cluster_bn/moving_variance": mv.double()}
     for k in ("s/cluster_weights", "s/cluster_weights2", "s/cluster_bn/gamma", "s/cluster_bn/beta"):
