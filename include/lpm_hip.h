@@ -297,6 +297,14 @@ int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, cons
 int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma, const float* beta,
                            int B, int L, int F, float eps, float* y, int64_t y_batch_stride, float* z, float* stats,
                            void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+/* layer_norm(layer_norm(act(a + bias) + r; gamma1, beta1) + r; gamma2, beta2) -- the tail of the V1 encoder
+ * (transformer_utils.py:708-713 followed by :409-411; both layer norms add the same residual r) in three passes: the first
+ * layer norm's apply pass adds r again and reduces the second one's statistics.  Saves z1/stats1 and z2/stats2, which
+ * lpm_layer_norm_act_bwd takes unchanged for either layer norm. */
+int lpm_layer_norm_pair_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma1, const float* beta1,
+                            const float* gamma2, const float* beta2, int B, int L, int F, float eps, float* y,
+                            int64_t y_batch_stride, float* z1, float* stats1, float* z2, float* stats2, void* workspace,
+                            size_t workspace_bytes, lpm_stream_t stream);
 int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats, const float* gamma,
                            const float* a,
                            const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma, float* dbeta,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "lpm_layer_norm_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _f, _f, _f, _s, _f]),
     "lpm_layer_norm_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _s, _f]),
     "lpm_layer_norm_act_fwd": (_i, [_f, _f, _i, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _s, _f]),
+    "lpm_layer_norm_pair_fwd": (_i, [_f, _f, _i, _f, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_layer_norm_act_bwd": (_i, [_f, _l, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_mha_fwd": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),
     "lpm_mha_fwd_x3": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),

@@ -69,12 +69,16 @@ __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restri
     }
 }
 
-// pass 2: y = (z - mean) * rstd * gamma + beta
+// pass 2: y = (z - mean) * rstd * gamma + beta.  r2 != NULL (layer-norm pair): what leaves is y + r2 -- the NEXT layer norm's
+// residual sum -- together with its per-chunk (sum, sum of squares) in partial_next, so the next layer norm needs no statistics
+// pass of its own.
 __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ partial,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int64_t n_per, int F,
                                                            float eps, float* __restrict__ y, int64_t y_batch,
-                                                           float* __restrict__ stats) {
+                                                           float* __restrict__ stats, const float* __restrict__ r2,
+                                                           float* __restrict__ partial_next) {
+    __shared__ float sh[4];
     const int b = blockIdx.x, ch = blockIdx.y;
     double s = 0.0, q = 0.0;
 #pragma unroll
@@ -94,7 +98,9 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
     const int64_t i0 = ch * per, i1 = min(n4, i0 + per);
     const int F4 = F / 4;
     const float4* zp = reinterpret_cast<const float4*>(z + (int64_t)b * n_per);
+    const float4* rp = r2 ? reinterpret_cast<const float4*>(r2 + (int64_t)b * n_per) : nullptr;
     float4* yp = reinterpret_cast<float4*>(y + (int64_t)b * y_batch);
+    float ns = 0.f, nq = 0.f;
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         const int c = (int)(i % F4) * 4;
         const float4 v = zp[i];
@@ -104,7 +110,21 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
         o.y = fmaf((v.y - mean) * rstd, g.y, bt.y);
         o.z = fmaf((v.z - mean) * rstd, g.z, bt.z);
         o.w = fmaf((v.w - mean) * rstd, g.w, bt.w);
+        if (rp) {
+            const float4 w = rp[i];
+            o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w;
+            ns += (o.x + o.y) + (o.z + o.w);
+            nq = fmaf(o.x, o.x, nq); nq = fmaf(o.y, o.y, nq); nq = fmaf(o.z, o.z, nq); nq = fmaf(o.w, o.w, nq);
+        }
         yp[i] = o;
+    }
+    if (rp) {
+        ns = block_sum(ns, sh);
+        nq = block_sum(nq, sh);
+        if (threadIdx.x == 0) {
+            partial_next[((int64_t)b * LN_NB + ch) * 2] = ns;
+            partial_next[((int64_t)b * LN_NB + ch) * 2 + 1] = nq;
+        }
     }
 }
 
@@ -309,8 +329,38 @@ extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int rel
                 "lpm_layer_norm_act_fwd: y_batch_stride must be >= L*F and a multiple of 4, y 16-byte aligned");
     dim3 grid(B, LN_NB);
     hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial);
-    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias) ? z : a, partial, gamma, beta, n_per, F, eps, y, yb, stats);
+    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias) ? z : a, partial, gamma, beta, n_per, F, eps, y, yb, stats,
+                       (const float*)nullptr, (float*)nullptr);
     return check_launch("lpm_layer_norm_act_fwd");
+}
+
+// layer_norm(layer_norm(act(a + bias) + r; gamma1, beta1) + r; gamma2, beta2): the two layer norms at the end of the V1 encoder
+// (transformer_utils.py:712-713 then :409-411), which add the SAME residual.  Three passes instead of four: the first layer
+// norm's apply pass adds r again and reduces the second one's statistics on the way out (its output n is never stored).
+// Saves for the backward: z1, stats1 (first layer norm), z2, stats2 (second); y = the result, batch stride as above.
+extern "C" int lpm_layer_norm_pair_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma1,
+                                       const float* beta1, const float* gamma2, const float* beta2, int B, int L, int F, float eps,
+                                       float* y, int64_t y_batch_stride, float* z1, float* stats1, float* z2, float* stats2,
+                                       void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(a && r && gamma1 && beta1 && gamma2 && beta2 && y && z1 && stats1 && z2 && stats2, LPM_ERR_BADARG,
+                "lpm_layer_norm_pair_fwd: null pointer");
+    LPM_REQUIRE(bias || !relu, LPM_ERR_BADARG, "lpm_layer_norm_pair_fwd: relu needs the bias it follows");
+    LPM_LN_CHECK("lpm_layer_norm_pair_fwd");
+    hipStream_t s = (hipStream_t)stream;
+    float* partial1 = (float*)workspace;
+    float* partial2 = partial1 + (size_t)B * LN_NB * 2;       // (the backward's column-partial region: free in the forward)
+    const int64_t n_per = (int64_t)L * F;
+    const int64_t yb = y_batch_stride ? y_batch_stride : n_per;
+    LPM_REQUIRE(yb >= n_per && yb % 4 == 0 && ((uintptr_t)y & 15) == 0, LPM_ERR_BADARG,
+                "lpm_layer_norm_pair_fwd: y_batch_stride must be >= L*F and a multiple of 4, y 16-byte aligned");
+    dim3 grid(B, LN_NB);
+    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z1, partial1);
+    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z1, (const float*)partial1, gamma1, beta1, n_per, F, eps,
+                       z2, n_per, stats1, r, partial2);
+    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z2, (const float*)partial2, gamma2, beta2, n_per, F, eps,
+                       y, yb, stats2, (const float*)nullptr, (float*)nullptr);
+    return check_launch("lpm_layer_norm_pair_fwd");
 }
 
 extern "C" int lpm_layer_norm_fwd(const float* a, const float* r, const float* gamma, const float* beta, int B, int L, int F,

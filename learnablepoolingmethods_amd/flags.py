@@ -45,6 +45,8 @@ FLAGS.define("ln_gradient_image", True, "build extension: the FFN block's inner 
              "gradient directly as the split-bf16 operand image of the FFN backward GEMMs")
 FLAGS.define("input_bn_grad_shortcut", True, "build extension: NetVladV1 training forms input_bn's gamma / beta gradients in closed "
              "form from quantities the pooling backward already has; the [B*S, 1152] input gradient is never computed")
+FLAGS.define("ln_pair_forward", True, "build extension: the two layer norms at the end of the V1 encoder share a residual and run "
+             "as one three-pass kernel sequence (the first one's output is never stored)")
 FLAGS.define("audio_side_stream", True, "build extension: run the audio stream (NetVLAD + encoder, ~100 latency-bound small "
              "launches per step) on a second HIP stream next to the video stream")
 FLAGS.define("dense_precision", "bf16x3", "build extension: encoder dense GEMMs as split-bf16 ('bf16x3', ~4e-6) or 'f32'")

@@ -1125,6 +1125,30 @@ def attention_block_x3(x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale):
     return _AttnBlockX3.apply(x, Wq, Wk, Wv, Wo, bo, gamma, beta, int(num_heads), float(scale))
 
 
+def _ln_pair_forward(c1, c2, a, r, g1, be1, bias, g2, be2, out=None):
+    """layer_norm(layer_norm(relu(a + bias) + r; g1, be1) + r; g2, be2) through lpm_layer_norm_pair_fwd; fills the two sub-contexts
+    exactly as two _ResidualLayerNorm.forward calls would, so the backward is unchanged."""
+    lib = _capi.load()
+    a = _f32(a, "layer_norm input").contiguous()
+    B, L, F = a.shape
+    r, bias = r.contiguous(), bias.contiguous()
+    y = out.view() if out is not None else torch.empty_like(a)
+    if tuple(y.shape) != (B, L, F) or not _batch_strided(y, L, F):
+        raise LpmError("layer_norm: output slot does not match [B, L, F] with contiguous clips")
+    z1, z2 = torch.empty_like(a), torch.empty_like(a)
+    stats1, stats2 = _empty((B, 2), a), _empty((B, 2), a)
+    wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
+    lib.check(lib._lpm_layer_norm_pair_fwd(ptr(a), ptr(bias), 1, ptr(r), ptr(g1), ptr(be1), ptr(g2), ptr(be2), B, L, F, LN_EPS, ptr(y),
+                                           y.stride(0), ptr(z1), ptr(stats1), ptr(z2), ptr(stats2), ptr(ws), wsb, stream_ptr()),
+              "lpm_layer_norm_pair_fwd")
+    c1.has_r, c1.relu, c1.has_bias = True, True, True
+    c1.save_for_backward(z1, stats1, g1, a, bias)
+    c2.has_r, c2.relu, c2.has_bias = True, False, False
+    c2.save_for_backward(z2, stats2, g2, None, None)
+    return y
+
+
 class _FFNBlockX3(torch.autograd.Function):
     """out = layer_norm(n + y),  n = layer_norm(relu(relu(y W1 + b1) W2 + b2) + y)  (transformer_utils.py:409-411 with
     :696-715).  y feeds the first GEMM and both residuals; backward: the outer layer norm's dz2 is the inner one's incoming
@@ -1137,8 +1161,12 @@ class _FFNBlockX3(torch.autograd.Function):
         B, L, F = y.shape
         cf, c1, c2 = _SubCtx(), _SubCtx(), _SubCtx()
         pre = _FFNX3.forward(cf, y.view(B * L, F), W1, b1, W2)
-        n = _ResidualLayerNorm.forward(c1, pre.view(B, L, F), y, g1, be1, b2, True)
-        out = _ResidualLayerNorm.forward(c2, n, y, g2, be2, None, False, out)
+        from . import FLAGS
+        if FLAGS.ln_pair_forward:      # three passes for the two layer norms: n itself is never stored
+            out = _ln_pair_forward(c1, c2, pre.view(B, L, F), y, g1, be1, b2, g2, be2, out)
+        else:
+            n = _ResidualLayerNorm.forward(c1, pre.view(B, L, F), y, g1, be1, b2, True)
+            out = _ResidualLayerNorm.forward(c2, n, y, g2, be2, None, False, out)
         _pack_subs(ctx, (cf, c1, c2))
         ctx.shape = (B, L, F)
         return out
