@@ -347,9 +347,14 @@ int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, c
 /* The same backward (no logits_bn) writing the q/k/v gradients ONLY as the split-bf16 gradient image the projection GEMMs read:
  * dqkv3 [B*L, 9*h*d] bf16, row = [hi | hi | lo] planes of the concatenated columns [dq | dk | dv] (what lpm_split_rows with
  * order = 1 would produce from the fp32 gradients) -- the fp32 dq/dk/dv and the split pass over them never exist. */
-int lpm_mha_bwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
-                         int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, void* dqkv3,
+int lpm_mha_bwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, const void* o, int o_is_image,
+                         const float* dout, int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, void* dqkv3,
                          lpm_stream_t stream);
+/* The forward writing its result ONLY as the split-bf16 activation image the output projection GEMM reads: o3 [B*L, 3*h*d]
+ * bf16, row = [hi | lo | hi] planes (lpm_split_rows order 0).  lpm_mha_bwd_x3_image takes it back with o_is_image = 1 (it
+ * rebuilds o = hi + lo for D_q = <dO_q, O_q>); with o_is_image = 0 `o` is the fp32 [B, L, ldo] tensor (ldo shared with dout). */
+int lpm_mha_fwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d, float scale,
+                         void* o3, float* lse, lpm_stream_t stream);
 size_t lpm_mha_logit_stats_workspace_bytes(int B, int L, int h);
 int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float* partial,
                         lpm_stream_t stream);

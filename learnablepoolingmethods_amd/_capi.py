@@ -86,7 +86,8 @@ SIGNATURES = {
     "lpm_mha_fwd_x3": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),
     "lpm_mha_bwd": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _l, _f, _f, _f, _f]),
     "lpm_mha_bwd_x3": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _l, _f, _f, _f, _f]),
-    "lpm_mha_bwd_x3_image": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f]),
+    "lpm_mha_bwd_x3_image": (_i, [_f, _f, _f, _l, _f, _i, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f]),
+    "lpm_mha_fwd_x3_image": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f]),
     "lpm_mha_logit_stats_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_mha_logit_stats": (_i, [_f, _f, _l, _i, _i, _i, _i, _f, _f]),
     "lpm_moe_ce_nblk": (_i, [_i, _i]),

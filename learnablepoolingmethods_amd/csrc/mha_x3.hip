@@ -61,6 +61,35 @@ __device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img
         *reinterpret_cast<uint2*>(p + 2 * (int64_t)img) = make_uint2(l0, l1);
     }
 }
+// Activation-image output / input of the attention result (oimg = plane stride in bf16 elements = h*d, 0 = plain fp32): row =
+// [hi | lo | hi] planes, the operand image of the output projection GEMM (ops._split_rows): the forward writes it instead of an
+// fp32 o and the backward kernels rebuild o = hi + lo (2^-17) for D_q = <dO_q, O_q>.
+__device__ __forceinline__ void mx_store_act4(float* base, int64_t row, int64_t ldo, int col, int oimg, float a, float b, float c, float d) {
+    if (oimg == 0) {
+        *reinterpret_cast<float4*>(base + row * ldo + col) = make_float4(a, b, c, d);
+    } else {
+        unsigned h0, l0, h1, l1;
+        mx_split2(a, b, h0, l0);
+        mx_split2(c, d, h1, l1);
+        unsigned short* p = reinterpret_cast<unsigned short*>(base) + row * 3 * (int64_t)oimg + col;
+        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(p + oimg) = make_uint2(l0, l1);
+        *reinterpret_cast<uint2*>(p + 2 * (int64_t)oimg) = make_uint2(h0, h1);
+    }
+}
+__device__ __forceinline__ void mx_load_o8(const float* base, int64_t row, int64_t ldo, int col, int oimg, float4& a, float4& c) {
+    if (oimg == 0) {
+        a = *reinterpret_cast<const float4*>(base + row * ldo + col);
+        c = *reinterpret_cast<const float4*>(base + row * ldo + col + 4);
+    } else {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + row * 3 * (int64_t)oimg + col;
+        const uint4 h = *reinterpret_cast<const uint4*>(p), l = *reinterpret_cast<const uint4*>(p + oimg);
+        a = make_float4(__uint_as_float(h.x << 16) + __uint_as_float(l.x << 16), __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u),
+                        __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16), __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u));
+        c = make_float4(__uint_as_float(h.z << 16) + __uint_as_float(l.z << 16), __uint_as_float(h.z & 0xffff0000u) + __uint_as_float(l.z & 0xffff0000u),
+                        __uint_as_float(h.w << 16) + __uint_as_float(l.w << 16), __uint_as_float(h.w & 0xffff0000u) + __uint_as_float(l.w & 0xffff0000u));
+    }
+}
 // position of key (or query) `i` inside its 32-block in the permuted order: i = 16 t + 4 g + e  ->  8 g + 4 t + e
 __device__ __forceinline__ int mx_perm(int i) { return (i & ~31) | (((i >> 2) & 3) << 3) | (((i >> 4) & 1) << 2) | (i & 3); }
 
@@ -136,7 +165,7 @@ template <int NKT, bool AFFINE, int D, bool RAGGED>
 __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, int64_t ld, int L, int h, float scale,
                                                          const float* __restrict__ key_scale, const float* __restrict__ key_shift,
-                                                         float* __restrict__ o, int64_t ldo, float* __restrict__ lse) {
+                                                         float* __restrict__ o, int64_t ldo, float* __restrict__ lse, int oimg) {
     static_assert(NKT % 2 == 0, "key tiles come in pairs (32-deep PV reduction)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = NKT * 16;
@@ -228,10 +257,9 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
         if (qrow < L) {
-            if (4 * g < D) {
-                const float4 ov = make_float4((oa[0] + ob[0]) * inv, (oa[1] + ob[1]) * inv, (oa[2] + ob[2]) * inv, (oa[3] + ob[3]) * inv);
-                *reinterpret_cast<float4*>(o + ((int64_t)b * L + qrow) * ldo + hh * D + 4 * g) = ov;
-            }
+            if (4 * g < D)
+                mx_store_act4(o, (int64_t)b * L + qrow, ldo, hh * D + 4 * g, oimg, (oa[0] + ob[0]) * inv, (oa[1] + ob[1]) * inv,
+                              (oa[2] + ob[2]) * inv, (oa[3] + ob[3]) * inv);
             if (g == 0) lse[((int64_t)b * h + hh) * L + qrow] = m * MX_LN2 + __logf(sum);
         }
     }
@@ -250,7 +278,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
                                                             const float* __restrict__ lse, int L, int h, float scale,
                                                             const float* __restrict__ key_scale, const float* __restrict__ key_shift,
                                                             float* __restrict__ dq, int64_t ldd, const float* __restrict__ corr_a,
-                                                            const float* __restrict__ corr_b, int img) {
+                                                            const float* __restrict__ corr_b, int img, int oimg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = NKT * 16;
     const int nkt = (L + 15) >> 4;
@@ -300,7 +328,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
             mx_split8(qv, qh, ql);
             const int64_t off = ((int64_t)b * L + qrow) * ldo + c0;
             const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
-            const float4 oa = *reinterpret_cast<const float4*>(o + off), oc = *reinterpret_cast<const float4*>(o + off + 4);
+            float4 oa, oc;
+            mx_load_o8(o, (int64_t)b * L + qrow, ldo, c0, oimg, oa, oc);
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
             mx_split8(gv, gh, gl);
             dpart = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
@@ -370,7 +399,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
                                                              const float* __restrict__ key_scale, const float* __restrict__ key_shift,
                                                              float* __restrict__ dk, float* __restrict__ dv, int64_t ldd,
                                                              const float* __restrict__ corr_a, const float* __restrict__ corr_b,
-                                                             float* __restrict__ dz_partial, int img) {
+                                                             float* __restrict__ dz_partial, int img, int oimg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = NKT * 16;
     constexpr int NH = D / 8;
@@ -410,7 +439,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
             const int64_t off = ((int64_t)b * L + row) * ldo + hh * D + 8 * hf;
             const float4 qa = *reinterpret_cast<const float4*>(qp), qc = *reinterpret_cast<const float4*>(qp + 4);
             const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
-            const float4 oa = *reinterpret_cast<const float4*>(o + off), oc = *reinterpret_cast<const float4*>(o + off + 4);
+            float4 oa, oc;
+            mx_load_o8(o, (int64_t)b * L + row, ldo, hh * D + 8 * hf, oimg, oa, oc);
             part = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
             const float qv[8] = {qa.x * qmul, qa.y * qmul, qa.z * qmul, qa.w * qmul, qc.x * qmul, qc.y * qmul, qc.z * qmul, qc.w * qmul};
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
@@ -547,16 +577,10 @@ static int mx_reserve(KernT kern, size_t bytes, const char* what) {
                 name ": need d in {8,16} and L <= 512 (L=%d d=%d)", L, d);                                          \
     LPM_REQUIRE(ld >= (int64_t)h * d && ld % 4 == 0, LPM_ERR_BADARG, name ": bad leading dimension")
 
-extern "C" int lpm_mha_fwd_x3(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d, float scale,
-                              const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse,
-                              lpm_stream_t stream) {
+static int mx_fwd_launch(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d, float scale,
+                         const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse, int oimg,
+                         lpm_stream_t stream, const char* what) {
     using namespace lpm;
-    LPM_REQUIRE(q && k && v && o && lse, LPM_ERR_BADARG, "lpm_mha_fwd_x3: null pointer");
-    LPM_MX_CHECK("lpm_mha_fwd_x3");
-    LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_fwd_x3: key_scale/key_shift go together");
-    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0, LPM_ERR_BADARG, "lpm_mha_fwd_x3: bad ldo");
-    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, LPM_ERR_BADARG,
-                "lpm_mha_fwd_x3: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
@@ -564,8 +588,8 @@ extern "C" int lpm_mha_fwd_x3(const float* q, const float* k, const float* v, in
     do {                                                                                                         \
         auto kern = mha_fwd_x3_kernel<N, AFF, DD, RG>;                                                           \
         const size_t lds = mx_fwd_lds(N * 16, DD);                                                               \
-        if (int rc = mx_reserve(kern, lds, "lpm_mha_fwd_x3")) return rc;                                         \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ld, L, h, scale, key_scale, key_shift, o, ldo, lse); \
+        if (int rc = mx_reserve(kern, lds, what)) return rc;                                                     \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ld, L, h, scale, key_scale, key_shift, o, ldo, lse, oimg); \
     } while (0)
 #define LPM_MX_FWD1(N, AFF, RG)        \
     do {                               \
@@ -586,13 +610,36 @@ extern "C" int lpm_mha_fwd_x3(const float* q, const float* k, const float* v, in
 #undef LPM_MX_FWD
 #undef LPM_MX_FWD1
 #undef LPM_MX_FWD3
-    return check_launch("lpm_mha_fwd_x3");
+    return check_launch(what);
+}
+
+extern "C" int lpm_mha_fwd_x3(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d, float scale,
+                              const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse,
+                              lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o && lse, LPM_ERR_BADARG, "lpm_mha_fwd_x3: null pointer");
+    LPM_MX_CHECK("lpm_mha_fwd_x3");
+    LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_fwd_x3: key_scale/key_shift go together");
+    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0, LPM_ERR_BADARG, "lpm_mha_fwd_x3: bad ldo");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_mha_fwd_x3: pointers must be 16-byte aligned");
+    return mx_fwd_launch(q, k, v, ld, B, L, h, d, scale, key_scale, key_shift, o, ldo, lse, 0, stream, "lpm_mha_fwd_x3");
+}
+
+extern "C" int lpm_mha_fwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d,
+                                    float scale, void* o3, float* lse, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o3 && lse, LPM_ERR_BADARG, "lpm_mha_fwd_x3_image: null pointer");
+    LPM_MX_CHECK("lpm_mha_fwd_x3_image");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o3) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_mha_fwd_x3_image: pointers must be 16-byte aligned");
+    return mx_fwd_launch(q, k, v, ld, B, L, h, d, scale, nullptr, nullptr, (float*)o3, 0, lse, h * d, stream, "lpm_mha_fwd_x3_image");
 }
 
 static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout, int64_t ldo,
                          const float* lse, int B, int L, int h, int d, float scale, const float* key_scale, const float* key_shift,
                          float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a, const float* corr_b, float* dz_partial,
-                         int img, lpm_stream_t stream, const char* what) {
+                         int img, int oimg, lpm_stream_t stream, const char* what) {
     using namespace lpm;
     hipStream_t s = (hipStream_t)stream;
     const int nkt = (L + 15) / 16;
@@ -604,13 +651,13 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
             const size_t lq = mx_bwd_dq_lds(N * 16, DD);                                                               \
             if (int rc = mx_reserve(kq, lq, what)) return rc;                                                          \
             hipLaunchKernelGGL(kq, grid, dim3(256), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dq, \
-                               ldd, corr_a, corr_b, img);                                                              \
+                               ldd, corr_a, corr_b, img, oimg);                                                        \
         }                                                                                                              \
         auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                                   \
         const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                                  \
         if (int rc = mx_reserve(kk, lk, what)) return rc;                                                              \
         hipLaunchKernelGGL(kk, grid, dim3(256), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv, \
-                           ldd, corr_a, corr_b, dz_partial, img);                                                      \
+                           ldd, corr_a, corr_b, dz_partial, img, oimg);                                                \
     } while (0)
 #define LPM_MX_BWD1(N, AFF, RG)        \
     do {                               \
@@ -649,12 +696,12 @@ extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, in
     LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
                 LPM_ERR_BADARG, "lpm_mha_bwd_x3: pointers must be 16-byte aligned");
     return mx_bwd_launch(q, k, v, ld, o, dout, ldo, lse, B, L, h, d, scale, key_scale, key_shift, dq, dk, dv, ldd, corr_a, corr_b,
-                         dz_partial, 0, stream, "lpm_mha_bwd_x3");
+                         dz_partial, 0, 0, stream, "lpm_mha_bwd_x3");
 }
 
-extern "C" int lpm_mha_bwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
-                                    int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, void* dqkv3,
-                                    lpm_stream_t stream) {
+extern "C" int lpm_mha_bwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, const void* o, int o_is_image,
+                                    const float* dout, int64_t ldo, const float* lse, int B, int L, int h, int d, float scale,
+                                    void* dqkv3, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(q && k && v && o && dout && lse && dqkv3, LPM_ERR_BADARG, "lpm_mha_bwd_x3_image: null pointer");
     LPM_MX_CHECK("lpm_mha_bwd_x3_image");
@@ -663,6 +710,7 @@ extern "C" int lpm_mha_bwd_x3_image(const float* q, const float* k, const float*
                 "lpm_mha_bwd_x3_image: pointers must be 16-byte aligned");
     const int N = h * d;                                  // image row: [hi(3N) | hi(3N) | lo(3N)] over the columns [dq | dk | dv]
     unsigned short* base = (unsigned short*)dqkv3;
-    return mx_bwd_launch(q, k, v, ld, o, dout, ldo, lse, B, L, h, d, scale, nullptr, nullptr, (float*)base, (float*)(base + N),
-                         (float*)(base + 2 * N), (int64_t)9 * N, nullptr, nullptr, nullptr, 3 * N, stream, "lpm_mha_bwd_x3_image");
+    return mx_bwd_launch(q, k, v, ld, (const float*)o, dout, ldo, lse, B, L, h, d, scale, nullptr, nullptr, (float*)base, (float*)(base + N),
+                         (float*)(base + 2 * N), (int64_t)9 * N, nullptr, nullptr, nullptr, 3 * N, o_is_image ? N : 0, stream,
+                         "lpm_mha_bwd_x3_image");
 }

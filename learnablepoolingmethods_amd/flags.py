@@ -39,8 +39,9 @@ FLAGS.define("fused_encoder_blocks", True, "build extension: run the V1 cluster 
              "folds the gradient sums of shared tensors into GEMM accumulation / the layer-norm kernel (no add passes)")
 FLAGS.define("descriptor_slots", True, "build extension: both encoders write their pooled descriptor into one shared buffer "
              "(no concat copy forward, no slice copies backward); needs fused_encoder_blocks")
-FLAGS.define("mha_gradient_image", True, "build extension: inside the encoder block Functions the attention backward writes the "
-             "q/k/v gradients directly as the split-bf16 operand image of the projection GEMMs (no fp32 gradients, no split pass)")
+FLAGS.define("mha_gradient_image", True, "build extension: inside the encoder block Functions the attention kernels write their "
+             "result and the q/k/v gradients directly as the split-bf16 operand images of the projection GEMMs (no fp32 copies, no "
+             "split passes)")
 FLAGS.define("ln_gradient_image", True, "build extension: the FFN block's inner layer-norm backward writes the ReLU-masked "
              "gradient directly as the split-bf16 operand image of the FFN backward GEMMs")
 FLAGS.define("input_bn_grad_shortcut", True, "build extension: NetVladV1 training forms input_bn's gamma / beta gradients in closed "

@@ -648,13 +648,15 @@ class _DenseX3(torch.autograd.Function):
     error (a plain bf16 GEMM: 2.5e-3, outside the parity bar; the fp32 GEMM: 1.5e-6 at 2-3x the time)."""
 
     @staticmethod
-    def forward(ctx, x2d, W):
-        x2d = _rows(x2d, "dense input")
+    def forward(ctx, x2d, W, x3=None):
+        """x3 (block Functions only): the input already as its activation image (then x2d is None)."""
         W = _f32(W, "dense kernel").contiguous()
-        x3 = _split_rows(x2d)
+        if x3 is None:
+            x2d = _rows(x2d, "dense input")
+            x3 = _split_rows(x2d)
         w3n, w3k = _split_weight(W, need_t=ctx.needs_input_grad[0])
         ctx.save_for_backward(x3, w3k)
-        ctx.dims = (x2d.shape[1], W.shape[1])
+        ctx.dims = (W.shape[0], W.shape[1])
         return _mm3(x3, w3n)
 
     @staticmethod
@@ -1016,16 +1018,25 @@ def _dqkv_buffers(q):
 
 class _MHACore(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, num_heads, scale):
+    def forward(ctx, q, k, v, num_heads, scale, image=False):
+        """image (block Functions only, split-bf16 arithmetic): the result is written ONLY as the [B*L, 3*h*d] bf16 activation image
+        of the output projection GEMM (and kept in that form for the backward)."""
         lib = _capi.load()
         q, k, v = _qkv_operands(q, k, v)
         B, L, d = _mha_dims(q, num_heads)
-        o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
         lse = _empty((B, num_heads, L), q)
-        with _timed("mha_fwd", (B, L, num_heads, d)):
-            lib.check(_mha_fwd_fn(lib)(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, None, None, ptr(o),
-                                       o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
         ctx.dims = (B, L, num_heads, d, scale)
+        ctx.o_image = bool(image)
+        if image:
+            o = torch.empty((B * L, 3 * num_heads * d), dtype=torch.bfloat16, device=q.device)
+            with _timed("mha_fwd", (B, L, num_heads, d)):
+                lib.check(lib._lpm_mha_fwd_x3_image(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, ptr(o), ptr(lse),
+                                                    stream_ptr()), "lpm_mha_fwd_x3_image")
+        else:
+            o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+            with _timed("mha_fwd", (B, L, num_heads, d)):
+                lib.check(_mha_fwd_fn(lib)(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, None, None, ptr(o),
+                                           o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
         ctx.save_for_backward(q, k, v, o, lse)
         return o
 
@@ -1037,21 +1048,24 @@ class _MHACore(torch.autograd.Function):
         B, L, h, d, scale = ctx.dims
         q, k, v, o, lse = ctx.saved_tensors
         do = do.contiguous()
+        o_image = getattr(ctx, "o_image", False)
         if image:
             dy3 = torch.empty((B * L, 9 * h * d), dtype=torch.bfloat16, device=q.device)
-            lib.check(lib._lpm_mha_bwd_x3_image(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d,
-                                                scale, ptr(dy3), stream_ptr()), "lpm_mha_bwd_x3_image")
+            lib.check(lib._lpm_mha_bwd_x3_image(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), 1 if o_image else 0, ptr(do), do.stride(1),
+                                                ptr(lse), B, L, h, d, scale, ptr(dy3), stream_ptr()), "lpm_mha_bwd_x3_image")
             return dy3
+        if o_image:
+            raise LpmError("mha backward: an image-form attention output needs the image-form backward")
         dq, dk, dv = _dqkv_buffers(q)
         lib.check(_mha_bwd_fn(lib)(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d,
                                    scale, None, None, ptr(dq), ptr(dk), ptr(dv), dq.stride(1), None, None, None, stream_ptr()),
                   "lpm_mha_bwd")
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None
 
 
 def mha_core(q, k, v, num_heads, scale):
     """softmax(scale * q k^T) v per head on [B, L, h*d] projections (transformer_utils.py:564-581)."""
-    return _MHACore.apply(q, k, v, int(num_heads), float(scale))
+    return _MHACore.apply(q, k, v, int(num_heads), float(scale), False)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1098,8 +1112,13 @@ class _AttnBlockX3(torch.autograd.Function):
         N = Wq.shape[1]
         cq, cm, co, cl = _SubCtx(), _SubCtx(), _SubCtx(), _SubCtx()
         q, k, v = _QKVX3.forward(cq, x.view(B * L, F), Wq, Wk, Wv)
-        o = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale)
-        att = _DenseX3.forward(co, o.view(B * L, N), Wo)
+        from . import FLAGS
+        if MHA_PRECISION == "bf16x3" and FLAGS.mha_gradient_image:     # the attention result only as the output GEMM's operand image
+            o3 = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale, image=True)
+            att = _DenseX3.forward(co, None, Wo, x3=o3)
+        else:
+            o = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale)
+            att = _DenseX3.forward(co, o.view(B * L, N), Wo)
         y = _ResidualLayerNorm.forward(cl, att.view(B, L, Wo.shape[1]), x, gamma, beta, bo, False)
         _pack_subs(ctx, (cq, cm, co, cl))
         ctx.shape = (B, L, F, N)
@@ -1112,11 +1131,11 @@ class _AttnBlockX3(torch.autograd.Function):
         from . import FLAGS
         _, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]         # no ReLU: da is dz
         do, dWo = _DenseX3.backward(co, dz.view(B * L, F))   # (dz also as an image from the kernel: measured neutral, not kept)
-        if MHA_PRECISION == "bf16x3" and FLAGS.mha_gradient_image:
+        if cm.o_image:
             dy3 = _MHACore.backward(cm, do.view(B, L, N), image=True)          # the kernels write the GEMM operand image
             dx, dWq, dWk, dWv = _QKVX3.backward(cq, None, None, None, acc=dz.view(B * L, F), dy3=dy3)
         else:
-            dq, dk, dv, _, _ = _MHACore.backward(cm, do.view(B, L, N))
+            dq, dk, dv = _MHACore.backward(cm, do.view(B, L, N))[:3]
             dx, dWq, dWk, dWv = _QKVX3.backward(cq, dq.view(B * L, N), dk.view(B * L, N), dv.view(B * L, N), acc=dz.view(B * L, F))
         return dx.view(B, L, F), dWq, dWk, dWv, dWo, dbo, dgamma, dbeta, None, None
 

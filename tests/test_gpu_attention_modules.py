@@ -131,8 +131,8 @@ def test_v1_encoder_block_functions_match_the_layerwise_path():
     out_u, names_u, g_u = run(False)
     assert names_f == names_u and len(names_f) == 15
     assert rel_l2(out_f, out_u) < 1e-6
-    for n, a, b in zip(["input"] + names_f, g_f, g_u):
-        assert rel_l2(a, b) < 2e-6, f"{n}: {rel_l2(a, b):.3e}"
+    for n, a, b in zip(["input"] + names_f, g_f, g_u):     # (the block path keeps the attention result as hi + lo bf16 planes: 2^-17)
+        assert rel_l2(a, b) < 1e-5, f"{n}: {rel_l2(a, b):.3e}"
     p = {n: store.vars[n].detach().double().cpu() for n in names_f}
     ref = O.transformer_encoder(x.double(), p, "enc", heads, "encode1")
     assert rel_l2(out_f, ref) < 2e-5

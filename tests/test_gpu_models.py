@@ -299,8 +299,8 @@ def test_block_functions_and_descriptor_slots_do_not_change_the_step():
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     for other in res[2:]:
         assert abs(other[0] - res[0][0]) <= 1e-6 * abs(res[0][0])
-        assert rel_l2(other[1], res[0][1]) < 5e-6
-        assert rel_l2(other[3], res[0][3]) < 5e-6           # the inference-mode forward (no autograd) takes the same paths
+        assert rel_l2(other[1], res[0][1]) < 2e-5
+        assert rel_l2(other[3], res[0][3]) < 2e-5           # the inference-mode forward (no autograd) takes the same paths
 
 
 def test_input_bn_gradient_shortcut_matches_the_input_gradient_path():
