@@ -225,6 +225,14 @@ int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm, const floa
                                  const float* shift, const void* xr, const float* centres, int B, int T, int D, int K,
                                  int flags, float* dassign, float* dcentres, float* g0, void* workspace, size_t workspace_bytes,
                                  lpm_stream_t stream);
+/* input_bn's gradients in the "no input gradient" mode (frames x = gamma xhat + beta straight out of input_bn,
+ * frame_level_models.py:2265-2277, columns [0, D) of one stream), from lpm_vlad_aggregate_bwd_tiles' g0 [B, D] and dcentres [D, K],
+ * the soft-assignment GEMM's W [D, K] and weight gradient dW [D, K], centres [D, K] (NULL without a residual term) and
+ * colsum_dl [K] = column sums of the logit gradient (NULL when zero, i.e. after a training-mode batch norm):
+ *   dbeta = -rowsum(dcentres) + W colsum_dl;   dgamma = (sum_b g0 + rowsum(W o dW) - rowsum(dcentres o centres) - beta dbeta) / gamma */
+int lpm_input_bn_grads(const float* dcentres, const float* centres, const float* W, const float* dW, const float* g0,
+                       const float* colsum_dl, const float* gamma, const float* beta, int B, int D, int K, float* dgamma,
+                       float* dbeta, lpm_stream_t stream);
 int lpm_vlad_aggregate_bwd_tiles_dx(const void* workspace, size_t workspace_bytes, const void* dlr, const void* wtt, int B,
                                     int T, int D, int K, float* dx, int64_t lddx, int accumulate_dx, lpm_stream_t stream);
 

@@ -67,6 +67,7 @@ SIGNATURES = {
                                     _i, _f, _f, _s, _f]),
     "lpm_vlad_bwd_tiles_workspace_bytes": (_s, [_i, _i, _i, _i]),
     "lpm_vlad_aggregate_bwd_tiles": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _s, _f]),
+    "lpm_input_bn_grads": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f]),
     "lpm_vlad_aggregate_bwd_tiles_dx": (_i, [_f, _s, _f, _f, _i, _i, _i, _i, _f, _l, _i, _f]),
     "lpm_bn_rows_workspace_bytes": (_s, [_i, _i]),
     "lpm_bn_rows_fwd": (_i, [_f, _i, _i, _f, _f, _fl, _fl, _i, _f, _f, _f, _f, _f, _f, _s, _f]),

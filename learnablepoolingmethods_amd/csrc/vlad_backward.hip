@@ -661,6 +661,48 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     return check_launch("lpm_vlad_aggregate_bwd_tiles");
 }
 
+// ---- input_bn's gamma / beta gradients from K3's by-products ("no input gradient" mode, see lpm_hip.h) ---------------------
+namespace lpm {
+// one wave per feature column d:
+//   dbeta[d]  = -sum_k dcentres[d,k] + sum_k W[d,k] cs[k]
+//   dgamma[d] = (sum_b g0[b,d] + sum_k W[d,k] dW[d,k] - sum_k dcentres[d,k] centres[d,k] - beta[d] dbeta[d]) / gamma[d]
+__global__ __launch_bounds__(256) void input_bn_grads_kernel(const float* __restrict__ dcentres, const float* __restrict__ centres,
+                                                             const float* __restrict__ W, const float* __restrict__ dW,
+                                                             const float* __restrict__ g0, const float* __restrict__ cs,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int B,
+                                                             int D, int K, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int lane = threadIdx.x & 63, d = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d >= D) return;                                    // wave-uniform
+    float s1 = 0.f, wc = 0.f, wdw = 0.f, dc = 0.f, g = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const int64_t i = (int64_t)d * K + k;
+        const float dce = dcentres[i], w = W[i];
+        s1 -= dce;
+        if (cs) wc = fmaf(w, cs[k], wc);
+        wdw = fmaf(w, dW[i], wdw);
+        if (centres) dc = fmaf(dce, centres[i], dc);
+    }
+    for (int b = lane; b < B; b += 64) g += g0[(int64_t)b * D + d];
+    s1 = wave_sum(s1); wc = wave_sum(wc); wdw = wave_sum(wdw); dc = wave_sum(dc); g = wave_sum(g);
+    if (lane == 0) {
+        const float db = s1 + wc;
+        dbeta[d] = db;
+        dgamma[d] = (g + wdw - dc - beta[d] * db) / gamma[d];
+    }
+}
+}  // namespace lpm
+
+extern "C" int lpm_input_bn_grads(const float* dcentres, const float* centres, const float* W, const float* dW, const float* g0,
+                                  const float* colsum_dl, const float* gamma, const float* beta, int B, int D, int K, float* dgamma,
+                                  float* dbeta, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dcentres && W && dW && g0 && gamma && beta && dgamma && dbeta, LPM_ERR_BADARG, "lpm_input_bn_grads: null pointer");
+    LPM_REQUIRE(B > 0 && D > 0 && K > 0, LPM_ERR_BADARG, "lpm_input_bn_grads: bad sizes");
+    hipLaunchKernelGGL(input_bn_grads_kernel, dim3((D + 3) / 4), dim3(256), 0, (hipStream_t)stream, dcentres, centres, W, dW, g0, colsum_dl,
+                       gamma, beta, B, D, K, dgamma, dbeta);
+    return check_launch("lpm_input_bn_grads");
+}
+
 extern "C" int lpm_vlad_aggregate_bwd_tiles_dx(const void* workspace, size_t workspace_bytes, const void* dlr, const void* wtt, int B,
                                                int T, int D, int K, float* dx, int64_t lddx, int accumulate_dx,
                                                lpm_stream_t stream) {

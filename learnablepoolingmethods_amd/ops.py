@@ -537,12 +537,11 @@ class _NetVLAD(torch.autograd.Function):
             # and sum_b asum_b dU_b = -dcentres, sum_b sum_k dU_b U_b = g0.sum(0), sum_r x dl = dW: everything is already there
             # (dx, a [B*T, D] GEMM pair plus a pass over the frames, is not formed).  colsum(dl) = 0 after a training-mode
             # batch norm (its backward removes the batch mean).
-            s1 = -dcentres.sum(1)
-            d_in_beta = s1 if (use_bn and is_training) else s1 + W.matmul(dl.sum(0))
-            g = g0.sum(0) + (W * dW).sum(1)
-            if has_w2:
-                g = g - (dcentres * centres).sum(1)
-            d_in_gamma = (g - in_beta * d_in_beta) / in_gamma
+            cs = None if (use_bn and is_training) else dl.sum(0)
+            d_in_gamma, d_in_beta = _empty((D,), x), _empty((D,), x)
+            lib.check(lib._lpm_input_bn_grads(ptr(dcentres), ptr(centres) if has_w2 else None, ptr(W), ptr(dW), ptr(g0), ptr(cs),
+                                              ptr(in_gamma.contiguous()), ptr(in_beta.contiguous()), B, D, K, ptr(d_in_gamma),
+                                              ptr(d_in_beta), stream_ptr()), "lpm_input_bn_grads")
             dW2 = dcentres.reshape(1, D, K) if has_w2 else None
             return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta
         if k3_tiles:
