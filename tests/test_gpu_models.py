@@ -338,6 +338,31 @@ def test_input_bn_gradient_shortcut_matches_the_input_gradient_path():
     _train_compare("NetVladV1", cfg, 1152, 4, 30, 1, dev)
 
 
+@pytest.mark.parametrize("B", [1, 13])
+def test_ragged_batch_sizes_through_one_trainer(B):
+    """Batch sizes that are not multiples of any tile (a single clip; 13 clips, then the 10-clip tail of an epoch through the
+    same trainer): every shape-dependent path (skinny weight gradient, block Functions, descriptor slots, closed-form input_bn
+    gradients) either applies or falls back, losses and inference outputs stay finite and the step matches the oracle's."""
+    from learnablepoolingmethods_amd import registry
+    from learnablepoolingmethods_amd.train import Trainer
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", iterations=20, cluster_size=64, hidden_size=48, vocab_size=60, base_learning_rate=1e-3)
+    x, nf, lab = O.make_synthetic_batch(B, 30, 1152, 60, seed=40 + B, min_frames=5)
+    tr = Trainer(registry.get_model("NetVladV1"), vocab_size=60, batch_size=B, base_learning_rate=1e-3, device=dev, seed=3,
+                 model_kwargs=dict(iterations=20, cluster_size=64, hidden_size=48))
+    tr.build(x, nf, lab)
+    p = _well_conditioned({k: v.double() for k, v in O.init_params(cfg, 1152, seed=77).items()})
+    tr.store.load({"tower/" + k: v for k, v in p.items()})
+    out = tr.step(x, nf, lab)
+    if B > 1:     # (one clip: every batch norm sees a single row, the reference itself is degenerate there)
+        _, _, info = O.train_step(p, {"step": 0, "m": {}, "v": {}}, x.double(), nf, lab, cfg, 1)
+        assert_close(out["loss"], info["loss"], tol=1e-4, what="loss")
+        assert_close(out["predictions"], info["predictions"], what="predictions")
+        tail = tr.step(x[:B - 3], nf[:B - 3], lab[:B - 3])
+        assert torch.isfinite(tail["loss"]) and tail["predictions"].shape == (B - 3, 60)
+    assert torch.isfinite(out["loss"]) and torch.isfinite(tr.predict(x, nf)).all()
+
+
 def test_checkpoint_resume_and_inference_csv(tmp_path):
     """Save after two steps, restore into a fresh trainer: the third step is bit-identical to the uninterrupted run
     (variables, Adam slots, global_step under the reference's TF names).  Then reader -> predict -> CSV end to end."""
