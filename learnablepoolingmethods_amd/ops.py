@@ -32,10 +32,14 @@ ASSIGN_PRECISION = os.environ.get("LPM_ASSIGN_PRECISION", "bf16x3")
 
 # Matrix-core arithmetic of the attention core K4: "bf16x3" (split-bf16 operands, v_mfma_f32_16x16x32_bf16) or "f32".
 MHA_PRECISION = os.environ.get("LPM_MHA_PRECISION", "bf16x3")
-# The logits_bn variant (MultiHeadAttentionBN, NetVladV2) defaults to exact fp32: batch norm over the key-position channel
-# makes the q / k gradients differences of nearly cancelling sums, and the 1e-5 element error of the split-bf16 kernels
-# (fine at the kernel level) is amplified ~500x in the small NetVladV2 parity case -- 1e-2 on whole-model gradients.
-MHA_BN_PRECISION = os.environ.get("LPM_MHA_BN_PRECISION", "f32")
+# The logits_bn variant (MultiHeadAttentionBN, NetVladV2) runs its FORWARD in exact fp32 and both backward passes on the bf16
+# pipe ("mixed"): the attention output goes straight into attention_bn, a batch norm over nearly constant columns (softmax
+# close to uniform, outputs close to the mean of v), which amplifies the 1e-5 element error of a split-bf16 forward ~500x --
+# 1e-2 on whole-model gradients in the small NetVladV2 parity case, while the same arithmetic in the backward passes alone
+# stays at the fp32 kernels' 2e-4 (tools/debug_v2_grad.py).  "f32" / "bf16x3": every pass in that arithmetic.
+MHA_BN_PRECISION = os.environ.get("LPM_MHA_BN_PRECISION", "mixed")
+# "mixed": arithmetic per pass (forward, backward statistics pass, backward main pass)
+MHA_BN_MIXED = os.environ.get("LPM_MHA_BN_MIXED", "f32,bf16x3,bf16x3")
 
 # Split-bf16 tile copies of the most recent frame_sample_bn output (produced by the same kernel that writes the fp32
 # frames): {"base": weakref to y, "F": F, "Dv": .., "video": tensor, "audio": tensor|None}.  ops.netvlad / vlad_aggregate
@@ -977,8 +981,16 @@ def _mha_dims(q, num_heads):
     return B, L, F // num_heads
 
 
-def _mha_fwd_fn(lib, bn=False):
-    prec = MHA_BN_PRECISION if bn else MHA_PRECISION
+def _bn_pass_precision(which):
+    """MHA_BN_PRECISION = "mixed": per-pass arithmetic of the logits_bn attention, as 'fwd,stats,main' in MHA_BN_MIXED."""
+    if MHA_BN_PRECISION != "mixed":
+        return MHA_BN_PRECISION
+    fwd, stats, main = MHA_BN_MIXED.split(",")
+    return {"fwd": fwd, "stats": stats, "main": main}[which]
+
+
+def _mha_fwd_fn(lib, bn=False, which="fwd"):
+    prec = _bn_pass_precision(which) if bn else MHA_PRECISION
     if prec == "bf16x3":
         return lib._lpm_mha_fwd_x3
     if prec == "f32":
@@ -986,8 +998,8 @@ def _mha_fwd_fn(lib, bn=False):
     raise LpmError(f"unknown attention precision {prec!r} (bf16x3 | f32)")
 
 
-def _mha_bwd_fn(lib, bn=False):
-    prec = MHA_BN_PRECISION if bn else MHA_PRECISION
+def _mha_bwd_fn(lib, bn=False, which="main"):
+    prec = _bn_pass_precision(which) if bn else MHA_PRECISION
     if prec == "bf16x3":
         return lib._lpm_mha_bwd_x3
     if prec == "f32":
@@ -1285,9 +1297,9 @@ class _MHACoreBN(torch.autograd.Function):
         st = stream_ptr()
         # pass 1: column sums of dz and dz*s over (B, h, query)
         partial = _empty((B * h, 2, L), q)
-        lib.check(_mha_bwd_fn(lib, bn=True)(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
-                                   ptr(kscale), ptr(kshift), None, None, None, q.stride(1), None, None, ptr(partial), st),
-                  "lpm_mha_bwd(stats)")
+        lib.check(_mha_bwd_fn(lib, bn=True, which="stats")(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L,
+                                                           h, d, 1.0, ptr(kscale), ptr(kshift), None, None, None, q.stride(1), None, None,
+                                                           ptr(partial), st), "lpm_mha_bwd(stats)")
         sums = partial.to(torch.float64).sum(0)                      # [2, L]  (tiny)
         sdz, sdzs = sums[0], sums[1]
         rstd = torch.rsqrt(var.double() + BN_EPS)

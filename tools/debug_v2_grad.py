@@ -16,8 +16,9 @@ x, nf, lab = O.make_synthetic_batch(B, MF, feat, cfg.vocab_size, seed=7, min_fra
 p = _well_conditioned({k: v.double() for k, v in O.init_params(cfg, feat, seed=1007).items()})
 _, _, raw_grads, _ = O.loss_and_grads(p, x.double(), nf, lab, cfg)
 gscale = max(float(g.abs().max()) for g in raw_grads.values())
-for prec in ("f32", "bf16x3"):
-    ops.MHA_PRECISION = prec
+for prec in ("f32", "bf16x3", "f32,bf16x3,bf16x3", "f32,f32,bf16x3", "f32,bf16x3,f32", "bf16x3,f32,f32"):
+    ops.MHA_BN_PRECISION = "mixed" if "," in prec else prec
+    ops.MHA_BN_MIXED = prec if "," in prec else ops.MHA_BN_MIXED
     tr = Trainer(registry.get_model("NetVladV2"), vocab_size=cfg.vocab_size, batch_size=B, base_learning_rate=cfg.base_learning_rate,
                  learning_rate_decay=cfg.learning_rate_decay, learning_rate_decay_examples=cfg.learning_rate_decay_examples,
                  device=dev, model_kwargs=dict(iterations=cfg.iterations, cluster_size=cfg.cluster_size, hidden_size=cfg.hidden_size,
