@@ -322,7 +322,7 @@ def test_input_bn_gradient_shortcut_matches_the_input_gradient_path():
             tr.build(x, nf, lab)
             with torch.no_grad():          # non-trivial affine parameters (the reference initialises gamma = 1, beta = 0)
                 g = torch.Generator(device=dev).manual_seed(3)
-                tr.store.vars["tower/input_bn/gamma"].copy_(1 + 0.3 * torch.randn(1152, device=dev, generator=g))
+                tr.store.vars["tower/input_bn/gamma"].copy_(1 + 0.6 * (torch.rand(1152, device=dev, generator=g) - 0.5))
                 tr.store.vars["tower/input_bn/beta"].copy_(0.2 * torch.randn(1152, device=dev, generator=g))
             loss = tr.step(x, nf, lab)["loss"].item()
             grads = {n: tr.arena.grad[tr.arena.segment(n)[0]:tr.arena.segment(n)[0] + tr.arena.views[n].numel()].clone()
@@ -336,6 +336,17 @@ def test_input_bn_gradient_shortcut_matches_the_input_gradient_path():
         assert rel_l2(res[0][1][n], res[1][1][n]) < tol, f"{n}: {rel_l2(res[0][1][n], res[1][1][n]):.3e}"
     cfg = O.OracleConfig(model="NetVladV1", iterations=24, cluster_size=128, hidden_size=32, vocab_size=40, base_learning_rate=1e-3)
     _train_compare("NetVladV1", cfg, 1152, 4, 30, 1, dev)
+    # a gamma element within rounding of zero: the watch on min |gamma| switches the model to the explicit path (with a warning)
+    tr = Trainer(registry.get_model("NetVladV1"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=17,
+                 model_kwargs=dict(iterations=32, cluster_size=128, hidden_size=64))
+    tr.build(x, nf, lab)
+    with torch.no_grad():
+        tr.store.vars["tower/input_bn/gamma"][5] = 1e-6
+    with pytest.warns(UserWarning, match="closed-form gamma / beta gradients are switched off"):
+        out = tr.step(x, nf, lab)
+    a0, _ = tr.arena.segment("tower/input_bn/gamma")
+    assert torch.isfinite(out["loss"]) and torch.isfinite(tr.arena.grad[a0:a0 + 1152]).all()
+    assert tr.store.vars["tower/input_bn/gamma"]._lpm_gamma_watch.disabled
 
 
 @pytest.mark.parametrize("B", [1, 13])
