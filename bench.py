@@ -21,6 +21,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# RCCL's cross-process buffer sharing needs dmabuf IPC on this pool's host driver (already exported by the image; kept
+# here so that a bare environment still works).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -17,18 +17,28 @@ static size_t tg_lds_bytes(int ntw, int epi) {
     return ring > e ? ring : e;
 }
 
-template <int NTW, int EPI>
-__global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g) {
+// MW = 1: 256 threads, 64 rows per workgroup, blockIdx.x = (batch, 64-row block).
+// MW = 2 (STORE only): 512 threads, 128 rows per workgroup = two row groups of four waves each; the row tiles of all
+// batches are ONE flat sequence (a_batch == a_tiles * a_tile, b_batch == 0, no second operand pair, one split) and
+// blockIdx.x counts groups of four consecutive tiles, which may straddle two batches.  24 KB staged per 128 x 256 x 16
+// products (131 MFMA-flop per byte against 77 for the 64-row form), NS-stage ring with NS - 2 younger steps in flight.
+template <int NTW, int EPI, int MW, int NS>
+__global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmArgs g) {
+    static_assert(MW == 1 || EPI == TG_EPI_STORE, "the 128-row form has the store epilogue only");
     constexpr int NTB = 4 * NTW;                   // column tiles per workgroup
-    constexpr int NP = 4 + 2 * NTB;                // 1 KB pieces per stage
-    constexpr int PW = NP / 4;                     // pieces per wave per stage
+    constexpr int NWV = 4 * MW;                    // waves per workgroup
+    constexpr int NRP = 4 * MW;                    // row-tile pieces per stage (2 MW tiles x 2 planes)
+    constexpr int NP = NRP + 2 * NTB;              // 1 KB pieces per stage
+    constexpr int PW = NP / NWV;                   // pieces per wave per stage
+    static_assert(NP % NWV == 0, "pieces must divide over the waves");
     constexpr int STAGE = NP * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave >> 2, cw = wave & 3;       // row group, column slice
     const int l31 = lane & 31;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int batch = lid / g.rb_per_batch, rb = lid % g.rb_per_batch;
+    const int batch = MW == 1 ? lid / g.rb_per_batch : 0, rb = MW == 1 ? lid % g.rb_per_batch : 0;
     const int cb = blockIdx.y, split = blockIdx.z;
     const int step0 = split * g.steps_per_split;
     const int nstep1 = min(g.steps_per_split, g.total_steps - step0);
@@ -40,29 +50,34 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g)
     int64_t sstep[PW], sstep2[PW];
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
-        const int p = wave + 4 * j;
-        if (p < 4) {
-            const int t = min(rb * 2 + (p >> 1), g.a_tiles - 1);
-            src[j] = g.a + batch * g.a_batch + t * g.a_tile + step0 * g.a_step + (p & 1) * 64 + lane;
+        const int p = wave + NWV * j;
+        if (p < NRP) {
+            if (MW == 1) {
+                const int t = min(rb * 2 + (p >> 1), g.a_tiles - 1);
+                src[j] = g.a + batch * g.a_batch + t * g.a_tile + step0 * g.a_step + (p & 1) * 64 + lane;
+                src2[j] = g.a2 + batch * g.a2_batch + t * g.a2_tile + (p & 1) * 64 + lane;
+            } else {
+                src[j] = g.a + (int64_t)(lid * 2 * MW + (p >> 1)) * g.a_tile + step0 * g.a_step + (p & 1) * 64 + lane;
+                src2[j] = nullptr;
+            }
             sstep[j] = g.a_step;
-            src2[j] = g.a2 + batch * g.a2_batch + t * g.a2_tile + (p & 1) * 64 + lane;
             sstep2[j] = g.a2_step;
         } else {
-            const int ct = cb * NTB + ((p - 4) >> 1);
-            src[j] = g.b + batch * g.b_batch + min(ct, g.b_tiles - 1) * g.b_tile + step0 * g.b_step + ((p - 4) & 1) * 64 + lane;
+            const int ct = cb * NTB + ((p - NRP) >> 1);
+            src[j] = g.b + batch * g.b_batch + min(ct, g.b_tiles - 1) * g.b_tile + step0 * g.b_step + ((p - NRP) & 1) * 64 + lane;
             sstep[j] = g.b_step;
-            src2[j] = g.b2 + batch * g.b2_batch + min(ct, g.b2_tiles - 1) * g.b2_tile + ((p - 4) & 1) * 64 + lane;
+            src2[j] = g.b2 + batch * g.b2_batch + min(ct, g.b2_tiles - 1) * g.b2_tile + ((p - NRP) & 1) * 64 + lane;
             sstep2[j] = g.b2_step;
         }
     }
     auto issue = [&](int s) {
-        unsigned char* st = smem + (s % TG_NS) * STAGE;
-        const bool second = s >= nstep1;       // wave-uniform
+        unsigned char* st = smem + (s % NS) * STAGE;
+        const bool second = MW == 1 && s >= nstep1;       // wave-uniform
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
             const uint4* q = second ? src2[j] + (s - nstep1) * sstep2[j] : src[j] + s * sstep[j];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
-                                             (__attribute__((address_space(3))) void*)(st + (wave + 4 * j) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(st + (wave + NWV * j) * 1024), 16, 0, 0);
         }
     };
 
@@ -75,31 +90,95 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g)
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
 #pragma unroll
-    for (int s = 0; s < TG_NS - 1; ++s)
+    for (int s = 0; s < NS - 1; ++s)
         if (s < nstep) issue(s);
-    for (int s = 0; s < nstep; ++s) {
-        if (s + 1 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // one younger step in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // step s is in LDS for everyone; stage (s-1) % NS is free again
-        asm volatile("" ::: "memory");
-        if (s + TG_NS - 1 < nstep) issue(s + TG_NS - 1);
-        const tg_u32x4* f = reinterpret_cast<const tg_u32x4*>(smem + (s % TG_NS) * STAGE) + lane;
-        tg_u32x4 ah[2], al[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            ah[m] = f[(m * 2 + 0) * 64];
-            al[m] = f[(m * 2 + 1) * 64];
-        }
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const int nt = wave * NTW + n;
-            const tg_u32x4 bh = f[(4 + nt * 2 + 0) * 64], bl = f[(4 + nt * 2 + 1) * 64];
+    if constexpr (MW == 1) {
+        for (int s = 0; s < nstep; ++s) {
+            if (s + 1 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // one younger step in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // step s is in LDS for everyone; stage (s-1) % NS is free again
+            asm volatile("" ::: "memory");
+            if (s + NS - 1 < nstep) issue(s + NS - 1);
+            const tg_u32x4* f = reinterpret_cast<const tg_u32x4*>(smem + (s % NS) * STAGE) + lane;
+            tg_u32x4 ah[2], al[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                acc[m][n] = tg_mfma(ah[m], bh, acc[m][n]);
-                acc[m][n] = tg_mfma(ah[m], bl, acc[m][n]);
-                acc[m][n] = tg_mfma(al[m], bh, acc[m][n]);
+                ah[m] = f[(m * 2 + 0) * 64];
+                al[m] = f[(m * 2 + 1) * 64];
             }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int nt = wave * NTW + n;
+                const tg_u32x4 bh = f[(4 + nt * 2 + 0) * 64], bl = f[(4 + nt * 2 + 1) * 64];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m][n] = tg_mfma(ah[m], bh, acc[m][n]);
+                    acc[m][n] = tg_mfma(ah[m], bl, acc[m][n]);
+                    acc[m][n] = tg_mfma(al[m], bh, acc[m][n]);
+                }
+            }
+        }
+    } else {
+        // Software-pipelined: the fragments of step s + 1 are read from LDS while the matrix pipe works on step s (two
+        // register sets, the loop unrolled by two), so the only wait inside a step is the barrier itself.  The barrier
+        // at the top of step s says: step s + 1 has landed for everyone, everyone holds the fragments of step s in
+        // registers, everyone is done with step s - 1 -> stage (s - 1) % NS takes step s + NS - 1.  NS - 2 steps are in
+        // flight behind the one being read.  (nstep >= NS is the launcher's condition.)
+        static_assert(NS == 4 || NS == 5, "ring depth of the 128-row form");
+        struct Frag { tg_u32x4 ah[2], al[2], bh[NTW], bl[NTW]; };
+        auto read_frags = [&](int s, Frag& fr) {
+            const tg_u32x4* f = reinterpret_cast<const tg_u32x4*>(smem + (s % NS) * STAGE) + lane;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                fr.ah[m] = f[((rg * 2 + m) * 2 + 0) * 64];
+                fr.al[m] = f[((rg * 2 + m) * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                fr.bh[n] = f[(NRP + (cw * NTW + n) * 2 + 0) * 64];
+                fr.bl[n] = f[(NRP + (cw * NTW + n) * 2 + 1) * 64];
+            }
+        };
+        auto body = [&](int s, Frag& cur, Frag& nxt) {
+            if (s + 1 < nstep) {                   // step s + 1 must have landed; younger steps issued: min(NS - 3, nstep - 2 - s)
+                if (NS == 5 && s + 3 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+                else if (s + 2 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // the fragments of step s, read during step s - 1, are complete (as a builtin, so that the compiler's own
+            // counter bookkeeping sees it and does not wait for the reads of step s + 1 in front of the MFMAs)
+            __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // The matrix pipe gets work straight after the barrier; the DMA issue (address arithmetic + NS-stage ring
+            // writes) and the LDS reads of the next fragments go into the shadow of MFMAs already queued -- with all
+            // eight waves released together, a wave that first issued its DMA pieces and reads left the pipe idle for
+            // a few hundred cycles per step.  term-major order: four different accumulators between dependent MFMAs.
+            auto mfma_term = [&](int t) {
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][n] = tg_mfma(t == 2 ? cur.al[m] : cur.ah[m], t == 1 ? cur.bl[n] : cur.bh[n], acc[m][n]);
+            };
+            mfma_term(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + NS - 1 < nstep) issue(s + NS - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_term(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < nstep) read_frags(s + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_term(2);
+        };
+        Frag fa, fb;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");      // step 0 has landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(0, fa);
+        for (int s = 0; s < nstep; s += 2) {
+            body(s, fa, fb);
+            if (s + 1 < nstep) body(s + 1, fb, fa);
         }
     }
 
@@ -109,12 +188,12 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g)
         // access is a 16-byte piece of a contiguous row segment: 32 rows x 128*NTW columns per pass
         constexpr int ESTR = 128 * NTW + 4;
         constexpr int C4 = 32 * NTW;
-        float* es = reinterpret_cast<float*>(smem);
+        float* es = reinterpret_cast<float*>(smem) + rg * 32 * ESTR;      // one staging tile per row group
         float* ob = g.out + batch * g.out_batch + split * g.out_split;
         if (g.stats) {
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
-                const int col = (cb * NTB + wave * NTW + n) * 32 + l31;
+                const int col = (cb * NTB + cw * NTW + n) * 32 + l31;
                 float cs = 0.f, cq = 0.f;
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -127,27 +206,33 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g)
                 cs += __shfl_xor(cs, 32, 64);
                 cq += __shfl_xor(cq, 32, 64);
                 if (lane < 32 && col < N) {
-                    float* p = g.stats + (int64_t)lid * 2 * N;
+                    float* p = g.stats + (int64_t)(lid * MW + rg) * 2 * N;    // one statistics row per 64-row group
                     p[col] = cs;
                     p[N + col] = cq;
                 }
             }
         }
         __syncthreads();                       // nothing in flight (the last step waited for vmcnt(0)): the ring is free
+        const int tl = tid & 255;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             if (m) __syncthreads();
 #pragma unroll
             for (int n = 0; n < NTW; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) es[mfma32_row(r, lane) * ESTR + (wave * NTW + n) * 32 + l31] = acc[m][n][r];
+                for (int r = 0; r < 16; ++r) es[mfma32_row(r, lane) * ESTR + (cw * NTW + n) * 32 + l31] = acc[m][n][r];
             __syncthreads();
-            for (int i = tid; i < 32 * C4; i += 256) {
+            // MW == 2: tile index in the flat sequence -> (batch, row tile within the batch)
+            const int ft = lid * 2 * MW + rg * 2 + m;
+            const int tb = MW == 1 ? 0 : ft / g.a_tiles;
+            const int row0 = MW == 1 ? rb * 64 + m * 32 : (ft - tb * g.a_tiles) * 32;
+            float* obt = ob + (int64_t)tb * g.out_batch;
+            for (int i = tl; i < 32 * C4; i += 256) {
                 const int row = i / C4, c4 = (i % C4) * 4;
-                const int grow = rb * 64 + m * 32 + row, gcol = cb * NTB * 32 + c4;
+                const int grow = row0 + row, gcol = cb * NTB * 32 + c4;
                 if (grow < g.rows_valid && gcol < N) {
                     float4 v = *reinterpret_cast<const float4*>(es + row * ESTR + c4);
-                    float4* p = reinterpret_cast<float4*>(ob + (int64_t)grow * g.ldo + gcol);
+                    float4* p = reinterpret_cast<float4*>(obt + (int64_t)grow * g.ldo + gcol);
                     if (g.accumulate) {
                         const float4 o = *p;
                         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -227,9 +312,25 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs g)
 // 256-column blocks beyond.
 int tg_ntw(int cols) { const int nt = (cols + 31) / 32; return nt <= 4 ? 1 : (nt <= 8 ? 2 : (nt <= 16 ? 4 : 2)); }
 
+static int tg_wide_enabled() {
+    static const int on = [] {
+        const char* e = getenv("LPM_TILE_GEMM_WIDE");      // 0: never use the 128-row form (A/B switch)
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return on;
+}
+
+// The 128-row form applies when the row tiles of all batches form one flat sequence that divides into groups of four, the
+// B operand is shared, there is one reduction segment and one 256-column block: K1's forward at K = 256.
+static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw) {
+    return tg_wide_enabled() && ntw == 2 && g.cols_valid <= 256 && splits == 1 && g.steps2 == 0 && g.a2 == nullptr && g.b_batch == 0 &&
+           g.a_batch == (int64_t)g.a_tiles * g.a_tile && g.rb_per_batch * 2 == g.a_tiles && ((int64_t)nbatch * g.a_tiles) % 4 == 0 &&
+           g.steps_per_split >= 16;     // (>= the ring depth)
+}
+
 template <int EPI>
 static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override = 0,
-                     int timing_tag = 0) {
+                     int timing_tag = 0, int allow_wide = 0) {
     if (EPI == TG_EPI_STORE && (g.cols_valid % 4 != 0 || g.ldo % 4 != 0 || g.out_batch % 4 != 0 || g.out_split % 4 != 0 ||
                                 ((uintptr_t)g.out & 15) != 0)) {
         set_error("%s: the output needs 16-byte aligned rows (columns and leading dimension multiples of 4)", what);
@@ -237,11 +338,14 @@ static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t 
     }
     const int ntw = ntw_override ? ntw_override : tg_ntw(g.cols_valid);
     const int nt = (g.cols_valid + 31) / 32;
-    dim3 grid((unsigned)(nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)), (unsigned)splits);
-    const size_t lds = tg_lds_bytes(ntw, EPI);
-#define LPM_TG_LAUNCH(NTW)                                                                                             \
+    const bool wide = EPI == TG_EPI_STORE && allow_wide && tg_wide_ok(g, nbatch, splits, ntw);
+    dim3 grid((unsigned)(wide ? nbatch * g.a_tiles / 4 : nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)),
+              (unsigned)splits);
+    constexpr int WIDE_NS = 4;
+    const size_t lds = wide ? (size_t)WIDE_NS * (8 + 8 * ntw) * 1024 : tg_lds_bytes(ntw, EPI);
+#define LPM_TG_LAUNCH_K(KERN, THREADS)                                                                                 \
     do {                                                                                                               \
-        auto kern = tile_gemm_kernel<NTW, EPI>;                                                                        \
+        auto kern = KERN;                                                                                              \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
             (void)hipGetLastError();                                                                                   \
             set_error("%s: cannot reserve %zu bytes of LDS", what, lds);                                               \
@@ -249,14 +353,17 @@ static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t 
         }                                                                                                              \
         hipEvent_t e0, e1;                                                                                             \
         if (timing_tag && timing_request(timing_tag, &e0, &e1))                                                        \
-            hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, stream, e0, e1, 0, g);                                   \
+            hipExtLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, e0, e1, 0, g);                               \
         else                                                                                                           \
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);                                                 \
+            hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, g);                                             \
     } while (0)
-    if (ntw == 1) LPM_TG_LAUNCH(1);
+#define LPM_TG_LAUNCH(NTW) LPM_TG_LAUNCH_K((tile_gemm_kernel<NTW, EPI, 1, TG_NS>), 256)
+    if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS>), 512);
+    else if (ntw == 1) LPM_TG_LAUNCH(1);
     else if (ntw == 2) LPM_TG_LAUNCH(2);
     else LPM_TG_LAUNCH(4);
 #undef LPM_TG_LAUNCH
+#undef LPM_TG_LAUNCH_K
     return check_launch(what);
 }
 
@@ -388,7 +495,7 @@ extern "C" int lpm_assign_gemm_tiles_fwd(const void* xr, const void* wt, int B, 
     g.rb_per_batch = MT / 2; g.steps_per_split = DS; g.total_steps = DS;
     g.out = logits; g.ldo = K; g.out_batch = (int64_t)T * K; g.out_split = 0;
     g.rows_valid = T; g.cols_valid = K; g.accumulate = 0; g.stats = partial;
-    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd", 0, D >= 1024 ? LPM_TIMING_K1 : 0);
+    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd", 0, D >= 1024 ? LPM_TIMING_K1 : 0, 1);
 }
 
 extern "C" int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T, int D, int K, float* dx, int64_t lddx,

@@ -141,11 +141,14 @@ def test_lightvlad_and_bias_mode(vlad_precision):
 
 
 @pytest.mark.parametrize("B,T,D,K,ld,off", [(3, 30, 1024, 32, 1024, 0), (2, 300, 128, 64, 1152, 1024), (20, 300, 1024, 256, 1152, 0),
-                                              (1, 77, 256, 512, 256, 0), (1, 1, 32, 32, 32, 0), (5, 129, 1024, 288, 1024, 0)])
+                                              (1, 77, 256, 512, 256, 0), (1, 1, 32, 32, 32, 0), (5, 129, 1024, 288, 1024, 0),
+                                              (6, 129, 512, 256, 512, 0), (3, 300, 256, 256, 256, 0), (2, 33, 1024, 256, 1024, 0)])
 def test_assign_gemm_tiles(B, T, D, K, ld, off):
     """K1 and its backward on the bf16 pipe through the C ABI (frame_level_models.py:2781-2789 and TF autodiff of it):
     logits + per-workgroup column statistics, dx += dl . W^T, dW = x^T . dl.  Ragged frame counts (zero-padded tail
-    tiles), strided inputs, K below / across / at the column-block limits."""
+    tiles), strided inputs, K below / across / at the column-block limits.  K = 256 with a tile count divisible by four
+    takes the 128-row workgroup form, whose four-tile groups straddle clips (20 x 300, 6 x 129, 2 x 33 frames); 3 x 300 does
+    not divide and stays on the 64-row form."""
     from learnablepoolingmethods_amd import _capi
     from learnablepoolingmethods_amd._capi import ptr, stream_ptr
     lib = _capi.load()
