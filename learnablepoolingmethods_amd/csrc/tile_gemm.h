@@ -14,6 +14,8 @@
 // Per reduction step the workgroup brings 2 row tiles + 4*NTW column tiles (hi, lo) into a 3-stage LDS ring by LDS-DMA
 // with ONE raw s_barrier per step and hand-counted vmcnt (cdna guide 5: no __syncthreads with glds in flight, a single
 // extern LDS object); 6*NTW MFMAs per wave per step.
+// 128-row form (tile_gemm.hip, MW = 2; K1's forward at K = 256): 512 threads = two row groups of four waves over one flat
+// row-tile sequence, 4-stage ring, the fragment reads of step s + 1 issued under the MFMAs of step s.
 #pragma once
 #include "lpm_common.h"
 
