@@ -235,6 +235,63 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
     }
 }
 
+// k-major finalize for K <= 512 (App. C5: the [B, K, D] layout NetVladV1's cluster encoder reads): the same arithmetic as
+// vlad_finalize2_kernel<true>, but every global access is 16 bytes wide.  R d-rows x K values are scaled by 1/n_k, written
+// back in place (d-major, what the backward reads) and staged, times 1/sqrt(g), in an LDS tile whose row stride K + 2 makes
+// the transposed read conflict-free (bank = 8 dq + 2 j + k over the 64 lanes of a wave); the tile leaves as float4 pieces
+// along d: 4 R contiguous bytes per cluster row.   grid (B, D/R).
+template <int R>
+__global__ __launch_bounds__(256) void vlad_finalize2_kmajor4_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
+                                                                     int P, int D, int K, float* __restrict__ out,
+                                                                     float* __restrict__ colsq, float* __restrict__ csq,
+                                                                     float* __restrict__ gsq) {
+    extern __shared__ float fs[];            // [K] inv_n, [4] partial sums, [R][K + 2] tile
+    float* invn = fs;
+    float* wg = fs + K;
+    float* tile = fs + K + 4;                // (K % 4 == 0: 16-byte aligned)
+    const int TS = K + 2;
+    const int b = blockIdx.x, d0 = blockIdx.y * R, tid = threadIdx.x;
+    float g = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        float n = 0.f;
+        for (int p = 0; p < P; ++p) n += colsq_part[((int64_t)b * P + p) * K + k];
+        const float iv = rsqrtf(fmaxf(n, kL2Eps));
+        const float c = n * iv * iv;
+        invn[k] = iv;
+        g += c;
+        if (blockIdx.y == 0) {
+            colsq[(int64_t)b * K + k] = n;
+            csq[(int64_t)b * K + k] = c;
+        }
+    }
+    g = wave_sum(g);
+    if ((tid & 63) == 0) wg[tid >> 6] = g;
+    __syncthreads();
+    const float tot = (wg[0] + wg[1]) + (wg[2] + wg[3]);
+    const float ig = rsqrtf(fmaxf(tot, kL2Eps));
+    if (blockIdx.y == 0 && tid == 0) gsq[b] = tot;
+    float4* src4 = reinterpret_cast<float4*>(nrm + ((int64_t)b * D + d0) * K);
+    const int K4 = K / 4;
+    for (int i = tid; i < R * K4; i += 256) {
+        const int row = i / K4, k = (i - row * K4) * 4;
+        float4 v = src4[i];
+        const float4 iv = *reinterpret_cast<const float4*>(invn + k);
+        v.x *= iv.x; v.y *= iv.y; v.z *= iv.z; v.w *= iv.w;
+        src4[i] = v;
+        float2* t2 = reinterpret_cast<float2*>(tile + row * TS + k);        // 8-byte aligned: TS and k are even
+        t2[0] = make_float2(v.x * ig, v.y * ig);
+        t2[1] = make_float2(v.z * ig, v.w * ig);
+    }
+    __syncthreads();
+    float* dst = out + (int64_t)b * K * D + d0;
+    constexpr int Q = R / 4;
+    for (int i = tid; i < K * Q; i += 256) {
+        const int k = i / Q, dq = i - k * Q;
+        const float* t = tile + (4 * dq) * TS + k;
+        *reinterpret_cast<float4*>(dst + (int64_t)k * D + 4 * dq) = make_float4(t[0], t[TS], t[2 * TS], t[3 * TS]);
+    }
+}
+
 }  // namespace lpm
 
 extern "C" int lpm_vlad_tiles3_supported(int D, int K) { return (D % 128 == 0 && K % 128 == 0 && D >= 128 && K >= 128) ? 1 : 0; }
@@ -277,6 +334,22 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
                 "lpm_vlad_finalize2_fwd: need D %% 32 == 0, K %% 4 == 0 (D=%d K=%d)", D, K);
     dim3 grid(B, D / 32);
     const size_t lds = (size_t)(K + 32 * 33 + 4) * sizeof(float);
+    static const int wide = [] { const char* e = getenv("LPM_FINALIZE_KMAJOR4"); return e ? atoi(e) : 32; }();   // 0: scalar form (A/B)
+    if ((flags & LPM_VLAD_OUT_KMAJOR) && wide && K <= 512 && (((uintptr_t)nrm | (uintptr_t)out) & 15) == 0) {
+        const int R = (wide == 64 && D % 64 == 0) ? 64 : 32;
+        const size_t lds4 = (size_t)(K + 4 + R * (K + 2)) * sizeof(float);
+        dim3 grid4(B, D / R);
+        auto launch = [&](auto kern) -> int {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("lpm_vlad_finalize2_fwd: cannot reserve %zu bytes of LDS", lds4);
+                return LPM_ERR_LAUNCH;
+            }
+            hipLaunchKernelGGL(kern, grid4, dim3(256), lds4, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq, csq, gsq);
+            return check_launch("lpm_vlad_finalize2_fwd");
+        };
+        return R == 64 ? launch(vlad_finalize2_kmajor4_kernel<64>) : launch(vlad_finalize2_kmajor4_kernel<32>);
+    }
     if (flags & LPM_VLAD_OUT_KMAJOR)
         hipLaunchKernelGGL(vlad_finalize2_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq,
                            csq, gsq);
