@@ -22,7 +22,7 @@ namespace lpm {
 
 constexpr int VB_TS = 32;     // frames per workgroup in the main kernel
 constexpr int VB_DC = 32;     // d rows per staged chunk
-constexpr int VB_DSPLIT = 4;  // column-dot split over D
+constexpr int VB_DSPLIT = 16; // column-dot split over D (B x 16 workgroups keep enough loads in flight: 58 -> see DESIGN)
 
 // [B,K,D] -> [B,D,K]
 __global__ __launch_bounds__(256) void vlad_kmajor_to_dmajor_kernel(const float* __restrict__ src, int D, int K,
@@ -43,6 +43,37 @@ __global__ __launch_bounds__(256) void vlad_kmajor_to_dmajor_kernel(const float*
         const int d = d0 + ty + 8 * i, k = k0 + tx;
         if (k < K) o[(int64_t)d * K + k] = tile[tx][ty + 8 * i];
     }
+}
+
+// [B,K,D] -> [B,D,K] for D % 64 == 0 and K % 64 == 0: 64 x 64 tiles, 16-byte global accesses on both sides; the LDS row
+// stride 65 keeps the scalar tile writes (bank = k + 4 q + j) and the transposed reads (bank = 4 kq + j + d) conflict-free.
+__global__ __launch_bounds__(256) void vlad_kmajor_to_dmajor64_kernel(const float* __restrict__ src, int D, int K,
+                                                                      float* __restrict__ dst) {
+    __shared__ float tile[64 * 65];
+    const int b = blockIdx.z, d0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const float* s = src + (int64_t)b * K * D;
+    float* o = dst + (int64_t)b * D * K;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + 256 * it, k = i >> 4, q = i & 15;
+        const float4 v = *reinterpret_cast<const float4*>(s + (int64_t)(k0 + k) * D + d0 + 4 * q);
+        float* t = tile + k * 65 + 4 * q;
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + 256 * it, d = i >> 4, kq = i & 15;
+        const float* t = tile + (4 * kq) * 65 + d;
+        *reinterpret_cast<float4*>(o + (int64_t)(d0 + d) * K + k0 + 4 * kq) = make_float4(t[0], t[65], t[130], t[195]);
+    }
+}
+
+static void launch_kmajor_to_dmajor(const float* src, int B, int D, int K, float* dst, hipStream_t s) {
+    if (D % 64 == 0 && K % 64 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0)
+        hipLaunchKernelGGL(vlad_kmajor_to_dmajor64_kernel, dim3(D / 64, K / 64, B), dim3(256), 0, s, src, D, K, dst);
+    else
+        hipLaunchKernelGGL(vlad_kmajor_to_dmajor_kernel, dim3(D / 32, (K + 31) / 32, B), dim3(256), 0, s, src, D, K, dst);
 }
 
 // dots[b][split][0..2][k]: <dO_k,N_k>, <dO_k,W2_k>, <N_k,W2_k> over the split's quarter of D
@@ -320,19 +351,22 @@ __global__ __launch_bounds__(256) void vlad_bwd_main_kernel(
     }
 }
 
-// dW2[d,k] = - sum_b s[b,k] * (u[b,k] dO[b,d,k] - v[b,k] N[b,d,k])
+// dW2[d,k] = - sum_b s[b,k] * (u[b,k] dO[b,d,k] - v[b,k] N[b,d,k]).  blockIdx.y splits the clips (a thread per float4 of
+// [D, K] alone is 256 workgroups at cfg-2's video shape and 8 at the audio shape: too few loads in flight); the partial sums
+// are added in split order by vlad_bwd_dcentres_reduce_kernel, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __restrict__ dO,
                                                                 const float* __restrict__ N,
                                                                 const float* __restrict__ asum,
                                                                 const float* __restrict__ u,
                                                                 const float* __restrict__ v, int B, int D, int K,
-                                                                float* __restrict__ dW2) {
+                                                                int bper, float* __restrict__ dW2) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index into [D,K]
     const int64_t n4 = (int64_t)D * K / 4;
     if (i >= n4) return;
     const int k = (int)((i * 4) % K);
+    const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = 0; b < B; ++b) {
+    for (int b = b0; b < b1; ++b) {
         const float4 a = reinterpret_cast<const float4*>(dO + (int64_t)b * D * K)[i];
         const float4 n = reinterpret_cast<const float4*>(N + (int64_t)b * D * K)[i];
         const float4 s = *reinterpret_cast<const float4*>(asum + (int64_t)b * K + k);
@@ -343,7 +377,42 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
         acc.z -= s.z * (uu.z * a.z - vv.z * n.z);
         acc.w -= s.w * (uu.w * a.w - vv.w * n.w);
     }
-    reinterpret_cast<float4*>(dW2)[i] = acc;
+    reinterpret_cast<float4*>(dW2)[(int64_t)blockIdx.y * n4 + i] = acc;
+}
+
+__global__ __launch_bounds__(256) void vlad_bwd_dcentres_reduce_kernel(const float4* __restrict__ part, int Z, int64_t n4,
+                                                                       float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = part[i];
+    for (int z = 1; z < Z; ++z) {
+        const float4 p = part[(int64_t)z * n4 + i];
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    out[i] = s;
+}
+
+constexpr int VB_DC_SPLITS = 16;          // most clip splits of the centres' gradient (its partial sums live in the workspace)
+static int dcentres_splits(int B, int D, int K) {
+    const int64_t wgx = ((int64_t)D * K / 4 + 255) / 256;
+    int z = (int)((1024 + wgx - 1) / wgx);
+    if (z > VB_DC_SPLITS) z = VB_DC_SPLITS;
+    if (z > B) z = B;
+    return z < 1 ? 1 : z;
+}
+// part: room for dcentres_splits(B, D, K) x [D, K] floats, or null (then one pass straight into dW2)
+static void launch_dcentres(const float* dO, const float* N, const float* asum, const float* u, const float* v, int B, int D, int K,
+                            float* part, float* dW2, hipStream_t s) {
+    const int64_t n4 = (int64_t)D * K / 4;
+    const unsigned wgx = (unsigned)((n4 + 255) / 256);
+    const int Z = part ? dcentres_splits(B, D, K) : 1;
+    if (Z == 1) {
+        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, B, dW2);
+        return;
+    }
+    const int bper = (B + Z - 1) / Z, Zeff = (B + bper - 1) / bper;
+    hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx, (unsigned)Zeff), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, bper, part);
+    hipLaunchKernelGGL(vlad_bwd_dcentres_reduce_kernel, dim3(wgx), dim3(256), 0, s, (const float4*)part, Zeff, n4, (float4*)dW2);
 }
 
 // ---- split-bf16 tile form of the main step (VLAD_PRECISION bf16x3) --------------------------------------------------
@@ -529,7 +598,7 @@ extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const
     float* dod = ctil + (size_t)B * K;   // d-major copy of dout when it arrives k-major
     const float* dO = dout;
     if (flags & LPM_VLAD_OUT_KMAJOR) {
-        hipLaunchKernelGGL(vlad_kmajor_to_dmajor_kernel, dim3(D / 32, (K + 31) / 32, B), dim3(256), 0, s, dout, D, K, dod);
+        launch_kmajor_to_dmajor(dout, B, D, K, dod, s);
         dO = dod;
     }
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr,
@@ -554,9 +623,7 @@ extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const
     else { if (sm) LPM_VB_LAUNCH(4, true); else LPM_VB_LAUNCH(4, false); }
 #undef LPM_VB_LAUNCH
     if (residual) {
-        const int64_t n4 = (int64_t)D * K / 4;
-        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dO, nrm, asum, u, v,
-                           B, D, K, dcentres);
+        launch_dcentres(dO, nrm, asum, u, v, B, D, K, nullptr, dcentres, s);
     }
     return check_launch("lpm_vlad_aggregate_bwd");
 }
@@ -564,7 +631,7 @@ extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const
 // ---- tile form: workspace = [dots | u | v | ctil | d-major dout copy | ub1 | ub2 | ar] ------------------------------
 namespace lpm {
 struct BwdTilesLayout {
-    size_t dots, u, v, ctil, dod, ub1, ub2, ar, total;     // byte offsets
+    size_t dots, u, v, ctil, dod, ub1, ub2, ar, dcp, total;     // byte offsets
     int MT;
 };
 static BwdTilesLayout bwd_tiles_layout(int B, int T, int D, int K) {
@@ -580,6 +647,7 @@ static BwdTilesLayout bwd_tiles_layout(int B, int T, int D, int K) {
     L.ub2 = o; o += (size_t)B * D * K * 4;
     L.MT = 2 * ((T + 63) / 64);
     L.ar = o; o += (size_t)B * L.MT * (K / 16) * 2048;
+    L.dcp = o; o += (size_t)dcentres_splits(B, D, K) * D * K * 4;       // partial sums of the centres' gradient
     L.total = o;
     return L;
 }
@@ -617,7 +685,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     uint4* ar = (uint4*)(ws + L.ar);
     const float* dO = dout;
     if (flags & LPM_VLAD_OUT_KMAJOR) {
-        hipLaunchKernelGGL(vlad_kmajor_to_dmajor_kernel, dim3(D / 32, (K + 31) / 32, B), dim3(256), 0, s, dout, D, K, dod);
+        launch_kmajor_to_dmajor(dout, B, D, K, dod, s);
         dO = dod;
     }
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr, D, K, dots);
@@ -654,9 +722,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     const int rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles");
     if (rc != LPM_OK) return rc;
     if (residual || g0) {        // dcentres = - sum_b asum_b dU_b: the centres' gradient, and (g0) the input batch norm's beta term
-        const int64_t n4 = (int64_t)D * K / 4;
-        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dO, nrm, asum, u, v, B, D, K,
-                           dcentres);
+        launch_dcentres(dO, nrm, asum, u, v, B, D, K, (float*)(ws + L.dcp), dcentres, s);
     }
     return check_launch("lpm_vlad_aggregate_bwd_tiles");
 }
