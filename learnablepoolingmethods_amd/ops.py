@@ -36,7 +36,7 @@ MHA_PRECISION = os.environ.get("LPM_MHA_PRECISION", "bf16x3")
 # pipe ("mixed"): the attention output goes straight into attention_bn, a batch norm over nearly constant columns (softmax
 # close to uniform, outputs close to the mean of v), which amplifies the 1e-5 element error of a split-bf16 forward ~500x --
 # 1e-2 on whole-model gradients in the small NetVladV2 parity case, while the same arithmetic in the backward passes alone
-# stays at the fp32 kernels' 2e-4 (tools/debug_v2_grad.py).  "f32" / "bf16x3": every pass in that arithmetic.
+# stays at the fp32 kernels' 2e-4 (tests/diagnostics/debug_v2_grad.py).  "f32" / "bf16x3": every pass in that arithmetic.
 MHA_BN_PRECISION = os.environ.get("LPM_MHA_BN_PRECISION", "mixed")
 # "mixed": arithmetic per pass (forward, backward statistics pass, backward main pass)
 MHA_BN_MIXED = os.environ.get("LPM_MHA_BN_MIXED", "f32,bf16x3,bf16x3")

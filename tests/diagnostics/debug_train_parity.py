@@ -1,6 +1,6 @@
 """Per-variable gradient / update parity report (GPU box): product Trainer vs oracle train_step."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import lpm_oracle as O
 from learnablepoolingmethods_amd import registry, ops

@@ -1,6 +1,6 @@
 """Whole-model gradient error (relative L2 vs the fp64 oracle) of the small NetVladV2 case per attention arithmetic."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import lpm_oracle as O
 from tests._util import rel_l2

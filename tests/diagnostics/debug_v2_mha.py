@@ -1,6 +1,6 @@
 """Capture the attention-core operands inside the small NetVladV2 model and compare both arithmetics against fp64."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import lpm_oracle as O
 from tests.test_gpu_models import _well_conditioned

@@ -1,9 +1,9 @@
 """Data-parallel consistency on the GPU box: N ranks (one per GPU over RCCL; LPM_SHARE_GPU=1: all on GPU 0 over gloo) take
 steps on different shards; afterwards every rank must hold bit-identical parameters and Adam slots, and the summed-gradient
 step must equal what one rank computes on the concatenated batch's tower gradients (checked through the loss trajectory).
-Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/dp_check.py"""
+Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tests/diagnostics/dp_check.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.distributed as dist
 from learnablepoolingmethods_amd import registry

@@ -1,6 +1,6 @@
 """Prints the relative error of both K2 arithmetics against the fp64 oracle at cfg-2 layer sizes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import lpm_oracle as O
 from learnablepoolingmethods_amd import ops
