@@ -1,0 +1,26 @@
+"""Is the training step host-bound?  Enqueue time of N steps (no synchronisation inside) against their GPU completion time."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from learnablepoolingmethods_amd import registry
+from learnablepoolingmethods_amd.train import Trainer
+
+dev = torch.device("cuda:0")
+trainer = Trainer(registry.get_model("NetVladV1"), vocab_size=bench.VOCAB, batch_size=bench.PER_GPU_BATCH, device=dev, seed=1234,
+                  model_kwargs=bench.CFG, **bench.TRAIN)
+raw, nf, labels = bench.synthetic_batch(bench.PER_GPU_BATCH, dev, seed=0)
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 3.0:
+    trainer.step(raw, nf, labels)
+torch.cuda.synchronize()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+for rep in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        trainer.step(raw, nf, labels)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"enqueue {1e3 * (t1 - t0) / N:.3f} ms/step   complete {1e3 * (t2 - t0) / N:.3f} ms/step   (queue drained {1e3 * (t2 - t1):.2f} ms after the last enqueue)")
