@@ -37,14 +37,16 @@ __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restri
                                                            float* __restrict__ partial) {
     __shared__ float sh[4];
     const int b = blockIdx.x, ch = blockIdx.y;
-    const int64_t n4 = n_per / 4, per = (n4 + LN_NB - 1) / LN_NB;
-    const int64_t i0 = ch * per, i1 = min(n4, i0 + per);
+    const int64_t n4 = n_per / 4;
     const float4* ap = reinterpret_cast<const float4*>(a + (int64_t)b * n_per);
     const float4* rp = r ? reinterpret_cast<const float4*>(r + (int64_t)b * n_per) : nullptr;
     float4* zp = reinterpret_cast<float4*>(z + (int64_t)b * n_per);
     float s = 0.f, q = 0.f;
     const int F4 = F / 4;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    // chunk ch takes the 256-float4 pieces ch, ch + LN_NB, ...: at any moment the LN_NB workgroups of an example read
+    // LN_NB consecutive 4 KB pieces (contiguous chunks put every workgroup of the grid at the same offset of its own
+    // 64 KB-aligned range at the same time: the same few HBM channels for everyone, ~3 TB/s)
+    for (int64_t i = (int64_t)ch * 256 + threadIdx.x; i < n4; i += (int64_t)LN_NB * 256) {
         float4 v = ap[i];
         if (bias) {
             const float4 bb = *reinterpret_cast<const float4*>(bias + (int)(i % F4) * 4);
@@ -94,14 +96,13 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
         stats[2 * b] = mean;
         stats[2 * b + 1] = rstd;
     }
-    const int64_t n4 = n_per / 4, per = (n4 + LN_NB - 1) / LN_NB;
-    const int64_t i0 = ch * per, i1 = min(n4, i0 + per);
+    const int64_t n4 = n_per / 4;
     const int F4 = F / 4;
     const float4* zp = reinterpret_cast<const float4*>(z + (int64_t)b * n_per);
     const float4* rp = r2 ? reinterpret_cast<const float4*>(r2 + (int64_t)b * n_per) : nullptr;
     float4* yp = reinterpret_cast<float4*>(y + (int64_t)b * y_batch);
     float ns = 0.f, nq = 0.f;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    for (int64_t i = (int64_t)ch * 256 + threadIdx.x; i < n4; i += (int64_t)LN_NB * 256) {      // interleaved pieces, as in pass 1
         const int c = (int)(i % F4) * 4;
         const float4 v = zp[i];
         const float4 g = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
 
 // backward pass 1: per (example, chunk): sums of g and g*zhat (g = dy*gamma) and the column partials of
 // dy*zhat / dy for dgamma / dbeta.  Threads are laid out (row group, float4 column) with F4 = F/4 dividing 256,
-// and chunks are whole rows, so a thread always sees the same 4 columns.
+// and chunks are sets of whole rows, so a thread always sees the same 4 columns.
 __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, int L, int F,
@@ -141,13 +142,11 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restri
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const int F4 = F / 4, RG = 256 / F4;
     const int c4 = tid % F4, rg = tid / F4;
-    const int rows_per = (L + LN_NB - 1) / LN_NB;
-    const int l0 = ch * rows_per, l1 = min(L, l0 + rows_per);
     const float mean = stats[2 * b], rstd = stats[2 * b + 1];
     const float4 g4 = *reinterpret_cast<const float4*>(gamma + 4 * c4);
     float s1 = 0.f, s2 = 0.f;
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int l = l0 + rg; l < l1; l += RG) {
+    for (int l = ch * RG + rg; l < L; l += LN_NB * RG) {      // row groups ch, ch + LN_NB, ...: see ln_fwd_stats_kernel
         const int64_t off = ((int64_t)b * L + l) * F + 4 * c4;
         const float4 d = *reinterpret_cast<const float4*>(dy + (int64_t)b * dy_batch + (int64_t)l * F + 4 * c4);
         const float4 v = *reinterpret_cast<const float4*>(z + off);
@@ -206,12 +205,10 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
     const float mean = stats[2 * b], rstd = stats[2 * b + 1];
     const int F4 = F / 4, RG = 256 / F4;
     const int c4 = tid % F4, rg = tid / F4;
-    const int rows_per = (L + LN_NB - 1) / LN_NB;
-    const int l0 = ch * rows_per, l1 = min(L, l0 + rows_per);
     const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c4);
     float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) bb = *reinterpret_cast<const float4*>(bias + 4 * c4);
-    for (int l = l0 + rg; l < l1; l += RG) {
+    for (int l = ch * RG + rg; l < L; l += LN_NB * RG) {      // row groups ch, ch + LN_NB, ...: see ln_fwd_stats_kernel
         const int64_t off = ((int64_t)b * L + l) * F + 4 * c4;
         const float4 d = *reinterpret_cast<const float4*>(dy + (int64_t)b * dy_batch + (int64_t)l * F + 4 * c4);
         const float4 v = *reinterpret_cast<const float4*>(z + off);
