@@ -76,23 +76,26 @@ static void launch_kmajor_to_dmajor(const float* src, int B, int D, int K, float
         hipLaunchKernelGGL(vlad_kmajor_to_dmajor_kernel, dim3(D / 32, (K + 31) / 32, B), dim3(256), 0, s, src, D, K, dst);
 }
 
-// dots[b][split][0..2][k]: <dO_k,N_k>, <dO_k,W2_k>, <N_k,W2_k> over the split's quarter of D
+// dots[b][split][0..2][k]: <dO_k,N_k>, <dO_k,W2_k>, <N_k,W2_k> over the split's rows of D
 __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __restrict__ dO,
                                                                const float* __restrict__ N,
                                                                const float* __restrict__ W2, int D, int K,
                                                                float* __restrict__ dots) {
     const int b = blockIdx.x, sp = blockIdx.y;
-    const int dper = D / VB_DSPLIT, d0 = sp * dper;
-    const float* pdo = dO + ((int64_t)b * D + d0) * K;
-    const float* pn = N + ((int64_t)b * D + d0) * K;
-    const float* pw = W2 ? W2 + (int64_t)d0 * K : nullptr;
+    // split sp takes rows sp, sp + VB_DSPLIT, ...: the splits of a clip read VB_DSPLIT consecutive rows at a time (contiguous
+    // quarter-ranges put every workgroup of the grid at the same offset of a 64 KB-aligned range: HBM channel aliasing)
+    const float* pdo = dO + ((int64_t)b * D + sp) * K;
+    const float* pn = N + ((int64_t)b * D + sp) * K;
+    const float* pw = W2 ? W2 + (int64_t)sp * K : nullptr;
+    const int64_t rs = (int64_t)VB_DSPLIT * K;
+    const int dper = D / VB_DSPLIT;
     float* out = dots + ((int64_t)b * VB_DSPLIT + sp) * 3 * K;
     for (int k = threadIdx.x; k < K; k += 256) {
         float p = 0.f, dw = 0.f, nw = 0.f;
 #pragma unroll 4
         for (int d = 0; d < dper; ++d) {
-            const float a = pdo[(int64_t)d * K + k], n = pn[(int64_t)d * K + k];
-            const float w = pw ? pw[(int64_t)d * K + k] : 0.f;
+            const float a = pdo[d * rs + k], n = pn[d * rs + k];
+            const float w = pw ? pw[d * rs + k] : 0.f;
             p = fmaf(a, n, p);
             dw = fmaf(a, w, dw);
             nw = fmaf(n, w, nw);

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
 
 // finalize for the un-normalised form: per clip n_k = sum_p colsq_part, inv_n = rsqrt(max(n,eps)), c_k = n inv_n^2,
 // g = sum_k c_k;  nrm <- U * inv_n (in place, d-major: what the backward reads);  out = nrm * rsqrt(max(g,eps)) laid out
-// d-major [B, D*K] or k-major [B,K,D].   grid (B, D/32).
+// d-major [B, D*K] or k-major [B,K,D].   grid (D/32, B).
 template <bool KMAJOR>
 __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
                                                              int P, int D, int K, float* __restrict__ out,
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
     float* invn = fs;
     float* tile = fs + K;
     float* wg = tile + 32 * 33;
-    const int b = blockIdx.x, d0 = blockIdx.y * 32, tid = threadIdx.x;
+    const int b = blockIdx.y, d0 = blockIdx.x * 32, tid = threadIdx.x;   // consecutive workgroups: consecutive 32-row chunks of one clip
     float g = 0.f;
     for (int k = tid; k < K; k += 256) {
         float n = 0.f;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
         const float c = n * iv * iv;
         invn[k] = iv;
         g += c;
-        if (blockIdx.y == 0) {
+        if (blockIdx.x == 0) {
             colsq[(int64_t)b * K + k] = n;
             csq[(int64_t)b * K + k] = c;
         }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
     __syncthreads();
     const float tot = (wg[0] + wg[1]) + (wg[2] + wg[3]);
     const float ig = rsqrtf(fmaxf(tot, kL2Eps));
-    if (blockIdx.y == 0 && tid == 0) gsq[b] = tot;
+    if (blockIdx.x == 0 && tid == 0) gsq[b] = tot;
     float* src = nrm + ((int64_t)b * D + d0) * K;
     if (!KMAJOR) {
         float* dst = out + ((int64_t)b * D + d0) * K;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
 // vlad_finalize2_kernel<true>, but every global access is 16 bytes wide.  R d-rows x K values are scaled by 1/n_k, written
 // back in place (d-major, what the backward reads) and staged, times 1/sqrt(g), in an LDS tile whose row stride K + 2 makes
 // the transposed read conflict-free (bank = 8 dq + 2 j + k over the 64 lanes of a wave); the tile leaves as float4 pieces
-// along d: 4 R contiguous bytes per cluster row.   grid (B, D/R).
+// along d: 4 R contiguous bytes per cluster row.   grid (D/R, B).
 template <int R>
 __global__ __launch_bounds__(256) void vlad_finalize2_kmajor4_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
                                                                      int P, int D, int K, float* __restrict__ out,
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kmajor4_kernel(float* __re
     float* wg = fs + K;
     float* tile = fs + K + 4;                // (K % 4 == 0: 16-byte aligned)
     const int TS = K + 2;
-    const int b = blockIdx.x, d0 = blockIdx.y * R, tid = threadIdx.x;
+    const int b = blockIdx.y, d0 = blockIdx.x * R, tid = threadIdx.x;    // consecutive workgroups: consecutive R-row chunks of one clip
     float g = 0.f;
     for (int k = tid; k < K; k += 256) {
         float n = 0.f;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kmajor4_kernel(float* __re
         const float c = n * iv * iv;
         invn[k] = iv;
         g += c;
-        if (blockIdx.y == 0) {
+        if (blockIdx.x == 0) {
             colsq[(int64_t)b * K + k] = n;
             csq[(int64_t)b * K + k] = c;
         }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kmajor4_kernel(float* __re
     __syncthreads();
     const float tot = (wg[0] + wg[1]) + (wg[2] + wg[3]);
     const float ig = rsqrtf(fmaxf(tot, kL2Eps));
-    if (blockIdx.y == 0 && tid == 0) gsq[b] = tot;
+    if (blockIdx.x == 0 && tid == 0) gsq[b] = tot;
     float4* src4 = reinterpret_cast<float4*>(nrm + ((int64_t)b * D + d0) * K);
     const int K4 = K / 4;
     for (int i = tid; i < R * K4; i += 256) {
@@ -332,13 +332,13 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
     LPM_REQUIRE(nrm && colsq_part && out && colsq && csq && gsq, LPM_ERR_BADARG, "lpm_vlad_finalize2_fwd: null pointer");
     LPM_REQUIRE(B > 0 && P > 0 && D % 32 == 0 && K % 4 == 0 && K <= 4096, LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_vlad_finalize2_fwd: need D %% 32 == 0, K %% 4 == 0 (D=%d K=%d)", D, K);
-    dim3 grid(B, D / 32);
+    dim3 grid(D / 32, B);
     const size_t lds = (size_t)(K + 32 * 33 + 4) * sizeof(float);
     static const int wide = [] { const char* e = getenv("LPM_FINALIZE_KMAJOR4"); return e ? atoi(e) : 32; }();   // 0: scalar form (A/B)
     if ((flags & LPM_VLAD_OUT_KMAJOR) && wide && K <= 512 && (((uintptr_t)nrm | (uintptr_t)out) & 15) == 0) {
         const int R = (wide == 64 && D % 64 == 0) ? 64 : 32;
         const size_t lds4 = (size_t)(K + 4 + R * (K + 2)) * sizeof(float);
-        dim3 grid4(B, D / R);
+        dim3 grid4(D / R, B);
         auto launch = [&](auto kern) -> int {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4) != hipSuccess) {
                 (void)hipGetLastError();
