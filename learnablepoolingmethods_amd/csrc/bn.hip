@@ -60,25 +60,60 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(const float* __restrict__
 
 // pass 1 of the BN backward: per-block column partials of dlt and dlt*Lhat.
 constexpr int BNB_ROWS = 64;
+// Threads are (row group, float4 column): 256 / (K/4) row groups when K/4 divides 256 (K = 256: four rows of 1 KB per
+// round), else one row group striding the columns; four rounds' loads are issued together.  (One thread per column walking
+// 64 rows with one 4-byte load in flight ran at 1.9 TB/s.)
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dlt,
                                                              const float* __restrict__ logits,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ var, float eps, int M,
                                                              int K, float* __restrict__ partial) {
+    __shared__ float4 red[2][256];
     const int r0 = blockIdx.x * BNB_ROWS;
     const int r1 = min(M, r0 + BNB_ROWS);
-    for (int c = threadIdx.x; c < K; c += 256) {
-        const float mu = mean[c], rstd = rsqrtf(var[c] + eps);
-        float s = 0.f, q = 0.f;
-        for (int r = r0; r < r1; ++r) {
-            const float d = dlt[(int64_t)r * K + c];
-            const float lh = (logits[(int64_t)r * K + c] - mu) * rstd;
-            s += d;
-            q += d * lh;
+    const int tid = threadIdx.x, K4 = K >> 2;
+    const int RG = (K4 < 256 && 256 % K4 == 0) ? 256 / K4 : 1;
+    const int rg = RG > 1 ? tid / K4 : 0;
+    for (int c4 = RG > 1 ? tid % K4 : tid; c4 < K4; c4 += (RG > 1 ? K4 : 256)) {      // RG > 1: exactly one pass, every thread in it
+        const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);
+        const float4 vr = *reinterpret_cast<const float4*>(var + 4 * c4);
+        const float4 rs = make_float4(rsqrtf(vr.x + eps), rsqrtf(vr.y + eps), rsqrtf(vr.z + eps), rsqrtf(vr.w + eps));
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+        auto add = [&](const float4 d, const float4 l) {
+            s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+            q.x += d.x * ((l.x - mu.x) * rs.x); q.y += d.y * ((l.y - mu.y) * rs.y);
+            q.z += d.z * ((l.z - mu.z) * rs.z); q.w += d.w * ((l.w - mu.w) * rs.w);
+        };
+        const float4* dp = reinterpret_cast<const float4*>(dlt) + c4;
+        const float4* lp = reinterpret_cast<const float4*>(logits) + c4;
+        int r = r0 + rg;
+        for (; r + 3 * RG < r1; r += 4 * RG) {
+            float4 d[4], l[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                d[u] = dp[(int64_t)(r + u * RG) * K4];
+                l[u] = lp[(int64_t)(r + u * RG) * K4];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(d[u], l[u]);
         }
-        float* p = partial + (int64_t)blockIdx.x * 2 * K;
-        p[c] = s;
-        p[K + c] = q;
+        for (; r < r1; r += RG) add(dp[(int64_t)r * K4], lp[(int64_t)r * K4]);
+        if (RG > 1) {
+            red[0][tid] = s;
+            red[1][tid] = q;
+            __syncthreads();
+            if (rg == 0)
+                for (int i = 1; i < RG; ++i) {
+                    const float4 a = red[0][i * K4 + c4], b = red[1][i * K4 + c4];
+                    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+                    q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+                }
+        }
+        if (rg == 0) {
+            float* p = partial + (int64_t)blockIdx.x * 2 * K;
+            *reinterpret_cast<float4*>(p + 4 * c4) = s;
+            *reinterpret_cast<float4*>(p + K + 4 * c4) = q;
+        }
     }
 }
 
@@ -151,18 +186,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ---- channel-last batch norm of a [M, C] matrix (the V2 encoder's [B, L, C] tensors seen as rows) -----------------------------
 // statistics: per 64-row block column (sum, sum of squares) -> partial [nblk][2][C]  (then bn_fold_kernel)
 __global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ partial) {
+    __shared__ float4 red[2][256];
     const int r0 = blockIdx.x * BNB_ROWS, r1 = min(M, r0 + BNB_ROWS);
-    const int C4 = C / 4;
-    for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
+    const int tid = threadIdx.x, C4 = C / 4;
+    const int RG = (C4 < 256 && 256 % C4 == 0) ? 256 / C4 : 1;      // thread layout as in bn_bwd_partial_kernel
+    const int rg = RG > 1 ? tid / C4 : 0;
+    for (int c4 = RG > 1 ? tid % C4 : tid; c4 < C4; c4 += (RG > 1 ? C4 : 256)) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
-        for (int r = r0; r < r1; ++r) {
-            const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)r * C + 4 * c4);
+        auto add = [&](const float4 v) {
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+        };
+        const float4* xp = reinterpret_cast<const float4*>(x) + c4;
+        int r = r0 + rg;
+        for (; r + 3 * RG < r1; r += 4 * RG) {              // four rows' loads together, rows consumed in order
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = xp[(int64_t)(r + u * RG) * C4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(v[u]);
         }
-        float* p = partial + (int64_t)blockIdx.x * 2 * C + 4 * c4;
-        *reinterpret_cast<float4*>(p) = s;
-        *reinterpret_cast<float4*>(p + C) = q;
+        for (; r < r1; r += RG) add(xp[(int64_t)r * C4]);
+        if (RG > 1) {
+            red[0][tid] = s;
+            red[1][tid] = q;
+            __syncthreads();
+            if (rg == 0)
+                for (int i = 1; i < RG; ++i) {
+                    const float4 a = red[0][i * C4 + c4], b = red[1][i * C4 + c4];
+                    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+                    q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+                }
+        }
+        if (rg == 0) {
+            float* p = partial + (int64_t)blockIdx.x * 2 * C + 4 * c4;
+            *reinterpret_cast<float4*>(p) = s;
+            *reinterpret_cast<float4*>(p + C) = q;
+        }
     }
 }
 // y = x * scale[c] + shift[c]
@@ -235,6 +295,8 @@ extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* me
     LPM_REQUIRE(dlt && logits && mean && var && dl && dgamma && dbeta && workspace, LPM_ERR_BADARG,
                 "lpm_bn_bwd: null pointer");
     LPM_REQUIRE(M > 0 && K > 0 && K % 4 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_bn_bwd: need K %% 4 == 0 (M=%d K=%d)", M, K);
+    LPM_REQUIRE((((uintptr_t)dlt | (uintptr_t)logits | (uintptr_t)mean | (uintptr_t)var | (uintptr_t)dl | (uintptr_t)workspace) & 15) == 0,
+                LPM_ERR_BADARG, "lpm_bn_bwd: pointers must be 16-byte aligned");
     LPM_REQUIRE(workspace_bytes >= lpm_bn_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE, "lpm_bn_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int nblk = (M + BNB_ROWS - 1) / BNB_ROWS;
