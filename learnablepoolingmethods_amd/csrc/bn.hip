@@ -163,24 +163,50 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float eps, int M, int K,
                                                            float* __restrict__ dl) {
+    // dl = A d + Bq (l - mean) + Cq per column, A = gamma rstd, Bq = -gamma rstd^2 dgamma / M, Cq = -gamma rstd dbeta / M.  When the
+    // grid stride is a multiple of the row length a thread keeps its four columns and the coefficients are formed once (the
+    // launcher arranges that); otherwise once per element group.  (l - mean) is formed first: columns with |mean| >> sigma.
     const int64_t total4 = (int64_t)M * K / 4;
     const float invM = 1.f / (float)M;
     const int K4 = K / 4;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % K4) * 4;
-        const float4 d = reinterpret_cast<const float4*>(dlt)[i];
-        const float4 l = reinterpret_cast<const float4*>(logits)[i];
-        float o[4];
-        const float dv[4] = {d.x, d.y, d.z, d.w}, lv[4] = {l.x, l.y, l.z, l.w};
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const bool fixed = (stride % K4) == 0;
+    float4 A, Bq, Cq, mu;
+    auto coeffs = [&](int c) {
+        const float4 vr = *reinterpret_cast<const float4*>(var + c);
+        mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 dg = *reinterpret_cast<const float4*>(dgamma + c), db = *reinterpret_cast<const float4*>(dbeta + c);
+        const float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float rx = rsqrtf(vr.x + eps), ry = rsqrtf(vr.y + eps), rz = rsqrtf(vr.z + eps), rw = rsqrtf(vr.w + eps);
+        A = make_float4(g.x * rx, g.y * ry, g.z * rz, g.w * rw);
+        Bq = make_float4(-A.x * rx * (dg.x * invM), -A.y * ry * (dg.y * invM), -A.z * rz * (dg.z * invM), -A.w * rw * (dg.w * invM));
+        Cq = make_float4(-A.x * (db.x * invM), -A.y * (db.y * invM), -A.z * (db.z * invM), -A.w * (db.w * invM));
+    };
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (fixed && i0 < total4) coeffs((int)(i0 % K4) * 4);
+    auto one = [&](int64_t i, const float4 d, const float4 l) {
+        if (!fixed) coeffs((int)(i % K4) * 4);
+        float4 o;
+        o.x = fmaf(A.x, d.x, fmaf(Bq.x, l.x - mu.x, Cq.x));
+        o.y = fmaf(A.y, d.y, fmaf(Bq.y, l.y - mu.y, Cq.y));
+        o.z = fmaf(A.z, d.z, fmaf(Bq.z, l.z - mu.z, Cq.z));
+        o.w = fmaf(A.w, d.w, fmaf(Bq.w, l.w - mu.w, Cq.w));
+        reinterpret_cast<float4*>(dl)[i] = o;
+    };
+    const float4* dp = reinterpret_cast<const float4*>(dlt);
+    const float4* lp = reinterpret_cast<const float4*>(logits);
+    int64_t i = i0;
+    for (; i + 3 * stride < total4; i += 4 * stride) {          // four grid strides' loads together
+        float4 d[4], l[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float rstd = rsqrtf(var[c + j] + eps);
-            const float lh = (lv[j] - mean[c + j]) * rstd;
-            const float g = gamma ? gamma[c + j] : 1.f;
-            o[j] = g * rstd * (dv[j] - dbeta[c + j] * invM - lh * dgamma[c + j] * invM);
+        for (int u = 0; u < 4; ++u) {
+            d[u] = dp[i + u * stride];
+            l[u] = lp[i + u * stride];
         }
-        reinterpret_cast<float4*>(dl)[i] = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(i + u * stride, d[u], l[u]);
     }
+    for (; i < total4; i += stride) one(i, dp[i], lp[i]);
 }
 
 // ---- channel-last batch norm of a [M, C] matrix (the V2 encoder's [B, L, C] tensors seen as rows) -----------------------------
@@ -295,7 +321,7 @@ extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* me
     LPM_REQUIRE(dlt && logits && mean && var && dl && dgamma && dbeta && workspace, LPM_ERR_BADARG,
                 "lpm_bn_bwd: null pointer");
     LPM_REQUIRE(M > 0 && K > 0 && K % 4 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_bn_bwd: need K %% 4 == 0 (M=%d K=%d)", M, K);
-    LPM_REQUIRE((((uintptr_t)dlt | (uintptr_t)logits | (uintptr_t)mean | (uintptr_t)var | (uintptr_t)dl | (uintptr_t)workspace) & 15) == 0,
+    LPM_REQUIRE((((uintptr_t)dlt | (uintptr_t)logits | (uintptr_t)mean | (uintptr_t)var | (uintptr_t)dl | (uintptr_t)workspace | (uintptr_t)gamma | (uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0,
                 LPM_ERR_BADARG, "lpm_bn_bwd: pointers must be 16-byte aligned");
     LPM_REQUIRE(workspace_bytes >= lpm_bn_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE, "lpm_bn_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -305,7 +331,13 @@ extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* me
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((K + 63) / 64), dim3(1024), 0, s, partial, nblk, K, dgamma, dbeta);
     const int64_t total4 = (int64_t)M * K / 4;
     const int64_t want = (total4 + 255) / 256;
-    const int grid = (int)(want < 2048 ? want : 2048);
+    int grid = (int)(want < 2048 ? want : 2048);
+    {   // a grid stride that is a multiple of the row length K/4 lets a thread keep its columns (coefficients formed once)
+        const int K4 = K / 4;
+        int step = K4;                                   // smallest workgroup count g with (g * 256) % K4 == 0: K4 / gcd(K4, 256)
+        for (int a = K4, b = 256; b;) { const int t = a % b; a = b; b = t; step = K4 / a; }
+        if (step <= grid) grid = grid / step * step;
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, dlt, logits, mean, var, gamma, dgamma, dbeta,
                        eps, M, K, dl);
     return check_launch("lpm_bn_bwd");
