@@ -656,3 +656,45 @@ def test_attention_properties_full_size(mha_precision):
     oc.backward(do)
     scale = float(do.abs().max())
     assert float(qg.grad.abs().max()) < 1e-4 * scale and float(kg.grad.abs().max()) < 1e-4 * scale
+
+
+_K1_FORM_SCRIPT = r"""
+import sys, torch
+from learnablepoolingmethods_amd import _capi
+from learnablepoolingmethods_amd._capi import ptr, stream_ptr
+lib = _capi.load()
+dev = torch.device("cuda:0")
+B, T, D, K = 8, 300, 512, 256
+g = torch.Generator().manual_seed(5)
+x = torch.randn(B * T, D, generator=g).to(dev)
+W = (torch.randn(D, K, generator=g) / D ** 0.5).to(dev)
+buf = lambda n: torch.empty(n // 4, dtype=torch.int32, device=dev)
+xr, wt = buf(lib._lpm_row_tiles_bytes(B, T, D)), buf(lib._lpm_weight_tiles_bytes(D, K))
+logits = torch.zeros(B * T, K, device=dev)
+partial = torch.zeros(lib._lpm_assign_gemm_tiles_nblk(B, T), 2, K, device=dev)
+st = stream_ptr()
+lib.check(lib._lpm_split_rows_tiles(ptr(x), D, B, T, D, ptr(xr), st), "split")
+lib.check(lib._lpm_split_weight_tiles(ptr(W), D, K, 0, ptr(wt), st), "split")
+lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st), "k1")
+torch.cuda.synchronize()
+torch.save({"logits": logits.cpu(), "partial": partial.cpu()}, sys.argv[1])
+"""
+
+
+@pytest.mark.gpu
+def test_assign_gemm_row_forms_bit_identical(tmp_path):
+    """K1's 128-row workgroup form (default at K = 256 when the tile count divides by four) and its 64-row form
+    (LPM_TILE_GEMM_WIDE=0, read once per process: hence two child processes) accumulate every output in the same order:
+    logits and the per-64-row statistics rows must agree bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for wide in ("1", "0"):
+        out = tmp_path / f"k1_{wide}.pt"
+        env = dict(os.environ, LPM_TILE_GEMM_WIDE=wide, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", _K1_FORM_SCRIPT, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(out))
+    assert torch.equal(outs[0]["logits"], outs[1]["logits"])
+    assert torch.equal(outs[0]["partial"], outs[1]["partial"])
+    assert float(outs[0]["logits"].abs().max()) > 0
