@@ -42,7 +42,10 @@ enum {
 enum {
     LPM_VLAD_SOFTMAX = 1,      /* `assign` holds logits; apply affine + softmax over K (NetVLAD)      */
     LPM_VLAD_RESIDUAL = 2,     /* subtract (sum_t a) * centres (NetVLAD, NetVladAttenCluster)           */
-    LPM_VLAD_OUT_KMAJOR = 4    /* lpm_vlad_finalize_*: descriptor laid out [B,K,D] instead of [B,D*K]   */
+    LPM_VLAD_OUT_KMAJOR = 4,   /* lpm_vlad_finalize_*: descriptor laid out [B,K,D] instead of [B,D*K]   */
+    LPM_VLAD_NRM_RAW = 8       /* lpm_vlad_finalize2_fwd: leave `nrm` as the un-normalised sums U (no in-place write of the
+                                  intra-normalised copy); lpm_vlad_aggregate_bwd_tiles: `nrm` holds U and the normalised
+                                  descriptor is rebuilt as U * rsqrt(max(colsq, eps)) where it is read                     */
 };
 
 int lpm_version(void);

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "liblpm_hip.so")
 LPM_VLAD_SOFTMAX = 1
 LPM_VLAD_RESIDUAL = 2
 LPM_VLAD_OUT_KMAJOR = 4
+LPM_VLAD_NRM_RAW = 8
 
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header
 _f = C.c_void_p      # device pointer

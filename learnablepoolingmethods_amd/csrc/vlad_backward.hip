@@ -80,7 +80,9 @@ static void launch_kmajor_to_dmajor(const float* src, int B, int D, int K, float
 __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __restrict__ dO,
                                                                const float* __restrict__ N,
                                                                const float* __restrict__ W2, int D, int K,
-                                                               float* __restrict__ dots) {
+                                                               float* __restrict__ dots, const float* __restrict__ colsq_raw) {
+    // colsq_raw != NULL (LPM_VLAD_NRM_RAW): N holds the un-normalised sums U and N = U * rsqrt(max(colsq, eps)) per column --
+    // the product vlad_finalize2 would have stored
     const int b = blockIdx.x, sp = blockIdx.y;
     // split sp takes rows sp, sp + VB_DSPLIT, ...: the splits of a clip read VB_DSPLIT consecutive rows at a time (contiguous
     // quarter-ranges put every workgroup of the grid at the same offset of a 64 KB-aligned range: HBM channel aliasing)
@@ -92,9 +94,10 @@ __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __re
     float* out = dots + ((int64_t)b * VB_DSPLIT + sp) * 3 * K;
     for (int k = threadIdx.x; k < K; k += 256) {
         float p = 0.f, dw = 0.f, nw = 0.f;
+        const float iv = colsq_raw ? rsqrtf(fmaxf(colsq_raw[(int64_t)b * K + k], kL2Eps)) : 1.f;
 #pragma unroll 4
         for (int d = 0; d < dper; ++d) {
-            const float a = pdo[d * rs + k], n = pn[d * rs + k];
+            const float a = pdo[d * rs + k], n = colsq_raw ? pn[d * rs + k] * iv : pn[d * rs + k];
             const float w = pw ? pw[d * rs + k] : 0.f;
             p = fmaf(a, n, p);
             dw = fmaf(a, w, dw);
@@ -362,7 +365,8 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
                                                                 const float* __restrict__ asum,
                                                                 const float* __restrict__ u,
                                                                 const float* __restrict__ v, int B, int D, int K,
-                                                                int bper, float* __restrict__ dW2) {
+                                                                int bper, float* __restrict__ dW2,
+                                                                const float* __restrict__ colsq_raw) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index into [D,K]
     const int64_t n4 = (int64_t)D * K / 4;
     if (i >= n4) return;
@@ -371,7 +375,12 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = b0; b < b1; ++b) {
         const float4 a = reinterpret_cast<const float4*>(dO + (int64_t)b * D * K)[i];
-        const float4 n = reinterpret_cast<const float4*>(N + (int64_t)b * D * K)[i];
+        float4 n = reinterpret_cast<const float4*>(N + (int64_t)b * D * K)[i];
+        if (colsq_raw) {                   // N = U * rsqrt(max(colsq, eps)): see vlad_bwd_coldots_kernel
+            const float4 c = *reinterpret_cast<const float4*>(colsq_raw + (int64_t)b * K + k);
+            n.x *= rsqrtf(fmaxf(c.x, kL2Eps)); n.y *= rsqrtf(fmaxf(c.y, kL2Eps));
+            n.z *= rsqrtf(fmaxf(c.z, kL2Eps)); n.w *= rsqrtf(fmaxf(c.w, kL2Eps));
+        }
         const float4 s = *reinterpret_cast<const float4*>(asum + (int64_t)b * K + k);
         const float4 uu = *reinterpret_cast<const float4*>(u + (int64_t)b * K + k);
         const float4 vv = *reinterpret_cast<const float4*>(v + (int64_t)b * K + k);
@@ -405,16 +414,17 @@ static int dcentres_splits(int B, int D, int K) {
 }
 // part: room for dcentres_splits(B, D, K) x [D, K] floats, or null (then one pass straight into dW2)
 static void launch_dcentres(const float* dO, const float* N, const float* asum, const float* u, const float* v, int B, int D, int K,
-                            float* part, float* dW2, hipStream_t s) {
+                            float* part, float* dW2, hipStream_t s, const float* colsq_raw = nullptr) {
     const int64_t n4 = (int64_t)D * K / 4;
     const unsigned wgx = (unsigned)((n4 + 255) / 256);
     const int Z = part ? dcentres_splits(B, D, K) : 1;
     if (Z == 1) {
-        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, B, dW2);
+        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, B, dW2, colsq_raw);
         return;
     }
     const int bper = (B + Z - 1) / Z, Zeff = (B + bper - 1) / bper;
-    hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx, (unsigned)Zeff), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, bper, part);
+    hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx, (unsigned)Zeff), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, bper, part,
+                       colsq_raw);
     hipLaunchKernelGGL(vlad_bwd_dcentres_reduce_kernel, dim3(wgx), dim3(256), 0, s, (const float4*)part, Zeff, n4, (float4*)dW2);
 }
 
@@ -428,18 +438,20 @@ static void launch_dcentres(const float* dO, const float* N, const float* asum, 
 __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __restrict__ dO, const float* __restrict__ N,
                                                                 const float* __restrict__ ug, const float* __restrict__ vg,
                                                                 int D, int K, uint4* __restrict__ ub1, uint4* __restrict__ ub2,
-                                                                const float* __restrict__ colsq, float* __restrict__ g0) {
-    extern __shared__ float dus[];           // [32][K+1], then u[K], v[K] (, then rn[K], prod [32][K+1] when g0)
+                                                                const float* __restrict__ colsq, float* __restrict__ g0, int raw) {
+    // raw (LPM_VLAD_NRM_RAW): N holds the un-normalised sums U; N = U * rsqrt(max(colsq, eps)), and g0's U is read as it is
+    extern __shared__ float dus[];           // [32][K+1], then u[K], v[K], rn[K] (, then prod [32][K+1] when g0)
     const int KS = K + 1;
     float* cu = dus + 32 * KS;
     float* cv = cu + K;
-    float* rn = cv + K;                      // g0 only: norm of the un-normalised column, U = N * rn
+    float* rn = cv + K;                      // g0 && !raw: norm of the un-normalised column, U = N * rn;  raw: its inverse
     float* prod = rn + K;                    // g0 only: dU * U
     const int tid = threadIdx.x, b = blockIdx.y, d0 = blockIdx.x * 32;
     for (int k = tid; k < K; k += 256) {
         cu[k] = ug[(int64_t)b * K + k];
         cv[k] = vg[(int64_t)b * K + k];
-        if (g0) rn[k] = sqrtf(fmaxf(colsq[(int64_t)b * K + k], kL2Eps));
+        if (raw) rn[k] = rsqrtf(fmaxf(colsq[(int64_t)b * K + k], kL2Eps));
+        else if (g0) rn[k] = sqrtf(fmaxf(colsq[(int64_t)b * K + k], kL2Eps));
     }
     __syncthreads();
     const int K4 = K / 4;
@@ -448,7 +460,11 @@ __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __r
     for (int i = tid; i < 32 * K4; i += 256) {
         const int r = i / K4, k = (i % K4) * 4;
         const float4 a = *reinterpret_cast<const float4*>(ob + (int64_t)r * K + k);
-        const float4 n = *reinterpret_cast<const float4*>(nb + (int64_t)r * K + k);
+        float4 n = *reinterpret_cast<const float4*>(nb + (int64_t)r * K + k);
+        const float4 nu = n;               // raw: the un-normalised value
+        if (raw) {
+            n.x *= rn[k + 0]; n.y *= rn[k + 1]; n.z *= rn[k + 2]; n.w *= rn[k + 3];
+        }
         float* dst = dus + r * KS + k;
         dst[0] = cu[k + 0] * a.x - cv[k + 0] * n.x;
         dst[1] = cu[k + 1] * a.y - cv[k + 1] * n.y;
@@ -456,10 +472,10 @@ __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __r
         dst[3] = cu[k + 3] * a.w - cv[k + 3] * n.w;
         if (g0) {
             float* pd = prod + r * KS + k;
-            pd[0] = dst[0] * n.x * rn[k + 0];
-            pd[1] = dst[1] * n.y * rn[k + 1];
-            pd[2] = dst[2] * n.z * rn[k + 2];
-            pd[3] = dst[3] * n.w * rn[k + 3];
+            pd[0] = raw ? dst[0] * nu.x : dst[0] * n.x * rn[k + 0];
+            pd[1] = raw ? dst[1] * nu.y : dst[1] * n.y * rn[k + 1];
+            pd[2] = raw ? dst[2] * nu.z : dst[2] * n.z * rn[k + 2];
+            pd[3] = raw ? dst[3] * nu.w : dst[3] * n.w * rn[k + 3];
         }
     }
     __syncthreads();
@@ -605,7 +621,7 @@ extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const
         dO = dod;
     }
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr,
-                       D, K, dots);
+                       D, K, dots, (const float*)nullptr);
     hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil);
     const int nts = (T + VB_TS - 1) / VB_TS;
     const size_t lds = bwd_main_lds_bytes(K);
@@ -691,17 +707,21 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
         launch_kmajor_to_dmajor(dout, B, D, K, dod, s);
         dO = dod;
     }
-    hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr, D, K, dots);
+    const bool raw = (flags & LPM_VLAD_NRM_RAW) != 0;
+    const float* colsq_raw = raw ? colsq : nullptr;
+    hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr, D, K, dots,
+                       colsq_raw);
     hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil);
     {
-        const size_t lds = (size_t)(32 * (K + 1) + 2 * K + (g0 ? K + 32 * (K + 1) : 0)) * sizeof(float);
+        const size_t lds = (size_t)(32 * (K + 1) + 3 * K + (g0 ? 32 * (K + 1) : 0)) * sizeof(float);
         auto kern = vlad_bwd_du_tiles_kernel;
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             set_error("lpm_vlad_aggregate_bwd_tiles: cannot reserve %zu bytes of LDS", lds);
             return LPM_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(256), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0);
+        hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(256), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0,
+                           raw ? 1 : 0);
     }
     if (!g0) {       // the assignment's row tiles are the A operand of the dx GEMM only
         const size_t lds = (size_t)32 * (K + 1) * sizeof(float);
@@ -725,7 +745,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     const int rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles");
     if (rc != LPM_OK) return rc;
     if (residual || g0) {        // dcentres = - sum_b asum_b dU_b: the centres' gradient, and (g0) the input batch norm's beta term
-        launch_dcentres(dO, nrm, asum, u, v, B, D, K, (float*)(ws + L.dcp), dcentres, s);
+        launch_dcentres(dO, nrm, asum, u, v, B, D, K, (float*)(ws + L.dcp), dcentres, s, colsq_raw);
     }
     return check_launch("lpm_vlad_aggregate_bwd_tiles");
 }

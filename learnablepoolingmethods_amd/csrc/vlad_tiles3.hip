@@ -173,7 +173,8 @@ template <bool KMAJOR>
 __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
                                                              int P, int D, int K, float* __restrict__ out,
                                                              float* __restrict__ colsq, float* __restrict__ csq,
-                                                             float* __restrict__ gsq) {
+                                                             float* __restrict__ gsq, int keep_u) {
+    // keep_u (LPM_VLAD_NRM_RAW): nrm is left as the un-normalised sums U (the tile backward rebuilds N = U * inv_n itself)
     extern __shared__ float fs[];            // [K] inv_n, then [32][33] transpose tile, [4] partial sums
     float* invn = fs;
     float* tile = fs + K;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
             const int k = (i % K4) * 4;
             float4 v = reinterpret_cast<const float4*>(src)[i];
             v.x *= invn[k]; v.y *= invn[k + 1]; v.z *= invn[k + 2]; v.w *= invn[k + 3];
-            reinterpret_cast<float4*>(src)[i] = v;
+            if (!keep_u) reinterpret_cast<float4*>(src)[i] = v;
             v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
             reinterpret_cast<float4*>(dst)[i] = v;
         }
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
                 float v = 0.f;
                 if (k < K) {
                     v = src[(int64_t)dl * K + k] * invn[k];
-                    src[(int64_t)dl * K + k] = v;
+                    if (!keep_u) src[(int64_t)dl * K + k] = v;
                 }
                 tile[dl * 33 + tx] = v * ig;
             }
@@ -244,7 +245,7 @@ template <int R>
 __global__ __launch_bounds__(256) void vlad_finalize2_kmajor4_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
                                                                      int P, int D, int K, float* __restrict__ out,
                                                                      float* __restrict__ colsq, float* __restrict__ csq,
-                                                                     float* __restrict__ gsq) {
+                                                                     float* __restrict__ gsq, int keep_u) {
     extern __shared__ float fs[];            // [K] inv_n, [4] partial sums, [R][K + 2] tile
     float* invn = fs;
     float* wg = fs + K;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kmajor4_kernel(float* __re
         float4 v = src4[i];
         const float4 iv = *reinterpret_cast<const float4*>(invn + k);
         v.x *= iv.x; v.y *= iv.y; v.z *= iv.z; v.w *= iv.w;
-        src4[i] = v;
+        if (!keep_u) src4[i] = v;
         float2* t2 = reinterpret_cast<float2*>(tile + row * TS + k);        // 8-byte aligned: TS and k are even
         t2[0] = make_float2(v.x * ig, v.y * ig);
         t2[1] = make_float2(v.z * ig, v.w * ig);
@@ -333,6 +334,7 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
     LPM_REQUIRE(B > 0 && P > 0 && D % 32 == 0 && K % 4 == 0 && K <= 4096, LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_vlad_finalize2_fwd: need D %% 32 == 0, K %% 4 == 0 (D=%d K=%d)", D, K);
     dim3 grid(D / 32, B);
+    const int keep_u = (flags & LPM_VLAD_NRM_RAW) ? 1 : 0;
     const size_t lds = (size_t)(K + 32 * 33 + 4) * sizeof(float);
     static const int wide = [] { const char* e = getenv("LPM_FINALIZE_KMAJOR4"); return e ? atoi(e) : 32; }();   // 0: scalar form (A/B)
     if ((flags & LPM_VLAD_OUT_KMAJOR) && wide && K <= 512 && (((uintptr_t)nrm | (uintptr_t)out) & 15) == 0) {
@@ -345,16 +347,16 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
                 set_error("lpm_vlad_finalize2_fwd: cannot reserve %zu bytes of LDS", lds4);
                 return LPM_ERR_LAUNCH;
             }
-            hipLaunchKernelGGL(kern, grid4, dim3(256), lds4, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq, csq, gsq);
+            hipLaunchKernelGGL(kern, grid4, dim3(256), lds4, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq, csq, gsq, keep_u);
             return check_launch("lpm_vlad_finalize2_fwd");
         };
         return R == 64 ? launch(vlad_finalize2_kmajor4_kernel<64>) : launch(vlad_finalize2_kmajor4_kernel<32>);
     }
     if (flags & LPM_VLAD_OUT_KMAJOR)
         hipLaunchKernelGGL(vlad_finalize2_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq,
-                           csq, gsq);
+                           csq, gsq, keep_u);
     else
         hipLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out,
-                           colsq, csq, gsq);
+                           colsq, csq, gsq, keep_u);
     return check_launch("lpm_vlad_finalize2_fwd");
 }

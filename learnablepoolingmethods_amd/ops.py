@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import LPM_VLAD_OUT_KMAJOR, LPM_VLAD_RESIDUAL, LPM_VLAD_SOFTMAX, LpmError, ptr, stream_ptr
+from ._capi import LPM_VLAD_NRM_RAW, LPM_VLAD_OUT_KMAJOR, LPM_VLAD_RESIDUAL, LPM_VLAD_SOFTMAX, LpmError, ptr, stream_ptr
 
 BN_EPS = 1e-3     # slim.batch_norm epsilon
 BN_DECAY = 0.999  # slim.batch_norm decay
@@ -305,8 +305,15 @@ def _cached_tiles(x, B, T, D):
     return None
 
 
-def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor):
-    """-> out, nrm, asum, colsq, csq, gsq, xt (the split-bf16 frame tiles of x, or None on the fp32 path)."""
+def _nrm_raw_ok(lib, T, D, K):
+    """The forward may leave ``nrm`` un-normalised (no in-place write in the finalize pass): the LDS-shared K2 form produces
+    it and K3's tile form, which rebuilds the normalised value where it reads it, will consume it."""
+    return (VLAD_PRECISION == "bf16x3" and VLAD_TILES3 and bool(lib._lpm_vlad_tiles3_supported(D, K)) and _bwd_tiles_ok(lib, T, D, K))
+
+
+def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor, nrm_raw=False):
+    """-> out, nrm, asum, colsq, csq, gsq, xt (the split-bf16 frame tiles of x, or None on the fp32 path).
+    nrm_raw (only with _nrm_raw_ok): ``nrm`` comes back as the un-normalised sums U."""
     xt = None
     nrm = _empty((B, D, K), x)
     asum, colsq, csq = (_empty((B, K), x) for _ in range(3))
@@ -329,9 +336,12 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
                                                              ptr(asum), ptr(part), st), "lpm_vlad_aggregate_tiles3_fwd")
             out = _empty((B, K, D) if kmajor else (B, D * K), x)
             gsq = _empty((B,), x)
-            lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, LPM_VLAD_OUT_KMAJOR if kmajor else 0,
-                                                  ptr(out), ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_finalize2_fwd")
+            ffl = (LPM_VLAD_OUT_KMAJOR if kmajor else 0) | (LPM_VLAD_NRM_RAW if nrm_raw else 0)
+            lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, ffl, ptr(out), ptr(colsq), ptr(csq), ptr(gsq), st),
+                      "lpm_vlad_finalize2_fwd")
             return out, nrm, asum, colsq, csq, gsq, xt
+        if nrm_raw:
+            raise LpmError("internal: nrm_raw without the LDS-shared aggregation form")
         with _timed("vlad_aggregate_fwd", (B, T, D, K)):
             lib.check(lib._lpm_vlad_aggregate_tiles_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
                                                         ptr(colsq), ptr(csq), st), "lpm_vlad_aggregate_tiles_fwd")
@@ -373,7 +383,7 @@ def _bwd_tiles_ok(lib, T, D, K):
 
 
 def _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, shift, x, xr, centres, B, T, D, K, flags, kmajor,
-                         no_dx=False):
+                         no_dx=False, nrm_raw=False):
     """First half of K3's tile form: -> dassign, dcentres, (workspace, bytes) for _aggregate_bwd_tiles_dx, g0.
     no_dx: the frames need no gradient -- the dx operands are not produced; g0 [B, D] = sum_k dU U and dcentres = -sum_b asum dU
     (also without a residual term) come back instead (see _NetVLAD.backward)."""
@@ -386,7 +396,7 @@ def _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, s
     g0 = _empty((B, D), x) if no_dx else None
     wsb = lib._lpm_vlad_bwd_tiles_workspace_bytes(B, T, D, K)
     ws = _tile_buffer(wsb, x)
-    fl = flags | (LPM_VLAD_OUT_KMAJOR if kmajor else 0)
+    fl = flags | (LPM_VLAD_OUT_KMAJOR if kmajor else 0) | (LPM_VLAD_NRM_RAW if nrm_raw else 0)
     with _timed("vlad_aggregate_bwd", (B, T, D, K)):
         lib.check(lib._lpm_vlad_aggregate_bwd_tiles(ptr(dout), ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(assign),
                                                     ptr(scale), ptr(shift), ptr(xr), ptr(centres), B, T, D, K, fl, ptr(dassign),
@@ -484,7 +494,9 @@ class _NetVLAD(torch.autograd.Function):
             scale, shift = None, bias.contiguous()
         flags = LPM_VLAD_SOFTMAX | (LPM_VLAD_RESIDUAL if W2 is not None else 0)
         centres = W2.reshape(D, K).contiguous() if W2 is not None else None
-        out, nrm, asum, colsq, csq, gsq, xt = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor)
+        ctx.nrm_raw = _nrm_raw_ok(lib, T, D, K)
+        out, nrm, asum, colsq, csq, gsq, xt = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor,
+                                                             nrm_raw=ctx.nrm_raw)
         ctx.dims = (B, T, D, K, flags, kmajor, use_bn, is_training, W2 is not None, tiles)
         ctx.dx_slot = getattr(x, "_lpm_dx_slot", None)
         ctx.no_dx = in_gamma is not None and tiles and _bwd_tiles_ok(lib, T, D, K)
@@ -502,9 +514,11 @@ class _NetVLAD(torch.autograd.Function):
         dout = _f32(dout, "dout").contiguous()
         k3_tiles = _bwd_tiles_ok(lib, T, D, K)
         no_dx = ctx.no_dx
+        if ctx.nrm_raw and not k3_tiles:
+            raise LpmError("netvlad: the forward left nrm un-normalised for the tile backward, which is no longer selected")
         if k3_tiles:
             dlt, dcentres, wspace, g0 = _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, xr,
-                                                             centres, B, T, D, K, flags, kmajor, no_dx=no_dx)
+                                                             centres, B, T, D, K, flags, kmajor, no_dx=no_dx, nrm_raw=ctx.nrm_raw)
             dx = None
         else:
             dlt, dx, dcentres = _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, centres, B, T, D,
@@ -590,7 +604,9 @@ class _VladAggregate(torch.autograd.Function):
         sims2 = _f32(sims, "cluster_similarities").reshape(M, K).contiguous()
         centres = _f32(centres, "cluster_centers").contiguous()
         flags = LPM_VLAD_RESIDUAL
-        out, nrm, asum, colsq, csq, gsq, _ = _aggregate_fwd(lib, sims2, None, None, x, centres, B, T, D, K, flags, kmajor)
+        ctx.nrm_raw = _nrm_raw_ok(lib, T, D, K)
+        out, nrm, asum, colsq, csq, gsq, _ = _aggregate_fwd(lib, sims2, None, None, x, centres, B, T, D, K, flags, kmajor,
+                                                            nrm_raw=ctx.nrm_raw)
         ctx.dims = (B, T, D, K, flags, kmajor, sims.shape)
         ctx.save_for_backward(sims2, x, centres, nrm, asum, colsq, csq, gsq)
         return out
@@ -600,9 +616,11 @@ class _VladAggregate(torch.autograd.Function):
         lib = _capi.load()
         B, T, D, K, flags, kmajor, sshape = ctx.dims
         sims2, x, centres, nrm, asum, colsq, csq, gsq = ctx.saved_tensors
+        if ctx.nrm_raw and not _bwd_tiles_ok(lib, T, D, K):
+            raise LpmError("vlad_aggregate: the forward left nrm un-normalised for the tile backward, which is no longer selected")
         if _bwd_tiles_ok(lib, T, D, K):
             dsims, dcentres, wspace, _ = _aggregate_bwd_tiles(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x,
-                                                              None, centres, B, T, D, K, flags, kmajor)
+                                                              None, centres, B, T, D, K, flags, kmajor, nrm_raw=ctx.nrm_raw)
             dx = _aggregate_bwd_tiles_dx(lib, wspace, None, None, x, B, T, D, K)
         else:
             dsims, dx, dcentres = _aggregate_bwd(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x, centres,
