@@ -601,6 +601,8 @@ extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const
     const bool residual = (flags & LPM_VLAD_RESIDUAL) != 0;
     const bool sm = (flags & LPM_VLAD_SOFTMAX) != 0;
     LPM_REQUIRE(!residual || (centres && dcentres), LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd: RESIDUAL needs centres/dcentres");
+    LPM_REQUIRE(!(flags & LPM_VLAD_NRM_RAW), LPM_ERR_BADARG,
+                "lpm_vlad_aggregate_bwd: LPM_VLAD_NRM_RAW (un-normalised nrm) is understood by lpm_vlad_aggregate_bwd_tiles only");
     LPM_REQUIRE(B > 0 && T > 0 && ldx >= D && lddx >= D, LPM_ERR_BADARG, "lpm_vlad_aggregate_bwd: bad sizes");
     LPM_REQUIRE(D % 128 == 0 && K % 4 == 0 && K <= 512 && ldx % 4 == 0, LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_vlad_aggregate_bwd: need D %% 128 == 0, K %% 4 == 0, K <= 512, ldx %% 4 == 0 (D=%d K=%d)", D, K);

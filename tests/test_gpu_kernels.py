@@ -698,3 +698,53 @@ def test_assign_gemm_row_forms_bit_identical(tmp_path):
     assert torch.equal(outs[0]["logits"], outs[1]["logits"])
     assert torch.equal(outs[0]["partial"], outs[1]["partial"])
     assert float(outs[0]["logits"].abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kmajor", [False, True])
+def test_netvlad_raw_nrm_matches_normalised_nrm(kmajor, monkeypatch):
+    """LPM_VLAD_NRM_RAW (the finalize pass leaves nrm un-normalised, K3's tile form rebuilds U * rsqrt(max(colsq, eps)) where it
+    reads it) against the path that stores the intra-normalised copy: same descriptor bit for bit, gradients to rounding of
+    the one product that is formed in a different place.  frame_level_models.py:2803-2824 and TF autodiff of it."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    if ops.VLAD_PRECISION != "bf16x3":
+        pytest.skip("the raw form belongs to the bf16x3 tile path")
+    B, T, D, K = 3, 77, 256, 128
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(B * T, D, generator=g).to(dev)
+    W0 = (torch.randn(D, K, generator=g) / D ** 0.5).to(dev)
+    W20 = (torch.randn(1, D, K, generator=g) / D ** 0.5).to(dev)
+    dout = torch.randn(B, K, D, generator=g).to(dev) if kmajor else torch.randn(B, D * K, generator=g).to(dev)
+    res = []
+    for raw in (True, False):
+        if not raw:
+            monkeypatch.setattr(ops, "_nrm_raw_ok", lambda lib, T, D, K: False)
+        else:
+            assert ops._nrm_raw_ok(__import__("learnablepoolingmethods_amd")._capi.load(), T, D, K)
+        x, W, W2 = (t.clone().requires_grad_(True) for t in (x0, W0, W20))
+        gam, bet = torch.ones(K, device=dev, requires_grad=True), torch.zeros(K, device=dev, requires_grad=True)
+        out = ops.netvlad(x, W, W2, T, bn=(gam, bet, torch.zeros(K, device=dev), torch.ones(K, device=dev)), kmajor=kmajor)
+        out.backward(dout)
+        res.append((out.detach(), x.grad, W.grad, W2.grad, gam.grad, bet.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b, what in zip(res[0][1:], res[1][1:], ("dx", "dW", "dW2", "dgamma", "dbeta")):
+        assert_close(a, b.double().cpu(), 1e-5, what)
+
+
+@pytest.mark.gpu
+def test_raw_nrm_flag_is_rejected_by_the_fp32_backward():
+    from learnablepoolingmethods_amd import _capi
+    from learnablepoolingmethods_amd._capi import ptr, stream_ptr
+    lib = _capi.load()
+    dev = cuda()
+    B, T, D, K = 1, 16, 128, 32
+    z = lambda *s: torch.zeros(*s, device=dev)
+    wsb = lib._lpm_vlad_bwd_workspace_bytes(B, D, K)
+    ws = torch.empty(max(wsb, 16) // 4, dtype=torch.int32, device=dev)
+    rc = lib._lpm_vlad_aggregate_bwd(ptr(z(B, D * K)), ptr(z(B, D, K)), ptr(z(B, K)), ptr(z(B, K)), ptr(z(B, K)), ptr(z(B)),
+                                     ptr(z(B * T, K)), None, None, ptr(z(B * T, D)), D, None, B, T, D, K, _capi.LPM_VLAD_NRM_RAW,
+                                     ptr(z(B * T, K)), ptr(z(B * T, D)), D, 0, None, ptr(ws), ws.numel() * 4, stream_ptr())
+    assert rc != 0
+    with pytest.raises(_capi.LpmError, match="NRM_RAW"):
+        lib.check(rc, "lpm_vlad_aggregate_bwd")
