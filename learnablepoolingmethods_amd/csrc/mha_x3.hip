@@ -391,8 +391,11 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
     }
 }
 
+// Eight waves per (batch, head): the workgroup's LDS (66 KB at L = 256: two workgroups per CU) is the same for four or eight
+// waves, and 110 registers fit four waves per SIMD -- twice the waves to hide the MFMA -> exp2 / split -> MFMA chain behind.
+constexpr int MX_DKV_NT = 512;
 template <int NKT, bool AFFINE, int D>
-__global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(MX_DKV_NT) void mha_bwd_dkv_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
                                                              const float* __restrict__ dout, int64_t ldo,
                                                              const float* __restrict__ lse, int L, int h, float scale,
@@ -419,16 +422,16 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
     const int TS = mx_tstride(LP);
 
     if (L != LP || D < 16) {
-        for (int i = tid; i < (2 * mx_rowplanes_bytes(LP, D) + 2 * mx_tplanes_bytes(LP)) / 16; i += 256)
+        for (int i = tid; i < (2 * mx_rowplanes_bytes(LP, D) + 2 * mx_tplanes_bytes(LP)) / 16; i += MX_DKV_NT)
             reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
     }
-    for (int i = tid; i < LP; i += 256) {
+    for (int i = tid; i < LP; i += MX_DKV_NT) {
         lses[i] = (i < L) ? lse[((int64_t)b * h + hh) * L + i] * MX_LOG2E : INFINITY;     // padded queries -> p = 0
         Dq[i] = 0.f;
     }
     __syncthreads();
     // Q (scaled) and dO: row planes and transposed planes from ONE pass over global memory; D_q = <dO_q, O_q>
-    for (int i0 = 0; i0 < L * NH; i0 += 256) {
+    for (int i0 = 0; i0 < L * NH; i0 += MX_DKV_NT) {
         const int i = i0 + tid;
         float part = 0.f;
         int row = 0;
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_x3_kernel(const float* __rest
     __syncthreads();
 
 #pragma unroll 1
-    for (int kt = wave; kt < nkt; kt += 4) {
+    for (int kt = wave; kt < nkt; kt += MX_DKV_NT / 64) {
         const int krow = kt * 16 + l15;
         const bool kok = krow < L;
         mx_u32x4 kh = {0u, 0u, 0u, 0u}, kl = kh, vh = kh, vl = kh;
@@ -656,7 +659,7 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
         auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                                   \
         const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                                  \
         if (int rc = mx_reserve(kk, lk, what)) return rc;                                                              \
-        hipLaunchKernelGGL(kk, grid, dim3(256), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv, \
+        hipLaunchKernelGGL(kk, grid, dim3(MX_DKV_NT), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv, \
                            ldd, corr_a, corr_b, dz_partial, img, oimg);                                                \
     } while (0)
 #define LPM_MX_BWD1(N, AFF, RG)        \
