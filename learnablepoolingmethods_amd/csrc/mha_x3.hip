@@ -103,9 +103,9 @@ __host__ __device__ constexpr int mx_tplanes_bytes(int LP) { return 2 * 16 * mx_
 // stage rows [0, L) of head hh of a [B, L, ld] tensor as row planes (optionally scaled)
 template <int D>
 __device__ __forceinline__ void mx_stage_rows(unsigned char* dst, const float* __restrict__ src, int64_t ld, int b, int L, int LP,
-                                              int hh, float mul, int tid) {
+                                              int hh, float mul, int tid, int nt = 256) {
     constexpr int NH = D / 8;
-    for (int i = tid; i < L * NH; i += 256) {
+    for (int i = tid; i < L * NH; i += nt) {
         const int row = i / NH, hf = i % NH;
         const float* p = src + ((int64_t)b * L + row) * ld + hh * D + 8 * hf;
         const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
@@ -119,10 +119,10 @@ __device__ __forceinline__ void mx_stage_rows(unsigned char* dst, const float* _
 // stage the same rows transposed and permuted: T[plane][d][perm(row)]
 template <int D>
 __device__ __forceinline__ void mx_stage_transposed(unsigned char* dst, const float* __restrict__ src, int64_t ld, int b, int L,
-                                                    int LP, int hh, int tid) {
+                                                    int LP, int hh, int tid, int nt = 256) {
     constexpr int NH = D / 8;
     const int TS = mx_tstride(LP);
-    for (int i = tid; i < L * NH; i += 256) {
+    for (int i = tid; i < L * NH; i += nt) {
         const int row = i / NH, hf = i % NH;
         const float* p = src + ((int64_t)b * L + row) * ld + hh * D + 8 * hf;
         const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
@@ -271,8 +271,9 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
 //       S^T = K Q^T, dP^T = V dO^T (2 MFMAs each), dS^T in registers, dQ^T += K^T dS^T (3 MFMAs per 32 keys)
 //   mha_bwd_dkv_x3_kernel: Q (pre-scaled) and dO row planes + their transposes in LDS; a wave owns key tiles:
 //       S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS; also the logits_bn column sums (dz_partial).
+constexpr int MX_DQ_NT = 512;      // eight waves per workgroup, as for the dK/dV kernel below
 template <int NKT, bool AFFINE, int D, bool RAGGED>
-__global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(MX_DQ_NT) void mha_bwd_dq_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
                                                             const float* __restrict__ dout, int64_t ldo,
                                                             const float* __restrict__ lse, int L, int h, float scale,
@@ -297,25 +298,25 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_x3_kernel(const float* __restr
     const int TS = mx_tstride(LP);
 
     if (RAGGED || D < 16) {
-        for (int i = tid; i < (2 * mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP)) / 16; i += 256)
+        for (int i = tid; i < (2 * mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP)) / 16; i += MX_DQ_NT)
             reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
     }
     if (AFFINE) {
-        for (int i = tid; i < LP; i += 256) {
+        for (int i = tid; i < LP; i += MX_DQ_NT) {
             ksc[i] = (i < L) ? key_scale[i] : 1.f;
             ksh[i] = (i < L) ? key_shift[i] : 0.f;
             cas[i] = (corr_a && i < L) ? corr_a[i] : 0.f;
             cbs[i] = (corr_b && i < L) ? corr_b[i] : 0.f;
         }
     }
-    mx_stage_rows<D>(Kp, k, ld, b, L, LP, hh, 1.f, tid);
-    mx_stage_rows<D>(Vp, v, ld, b, L, LP, hh, 1.f, tid);
-    mx_stage_transposed<D>(Kt, k, ld, b, L, LP, hh, tid);
+    mx_stage_rows<D>(Kp, k, ld, b, L, LP, hh, 1.f, tid, MX_DQ_NT);
+    mx_stage_rows<D>(Vp, v, ld, b, L, LP, hh, 1.f, tid, MX_DQ_NT);
+    mx_stage_transposed<D>(Kt, k, ld, b, L, LP, hh, tid, MX_DQ_NT);
     __syncthreads();
 
 #pragma unroll 1
-    for (int qt = wave; qt < nkt; qt += 4) {
+    for (int qt = wave; qt < nkt; qt += MX_DQ_NT / 64) {
         const int qrow = qt * 16 + l15;
         const bool qok = qrow < L;
         mx_u32x4 qh = {0u, 0u, 0u, 0u}, ql = qh, gh = qh, gl = qh;
@@ -653,7 +654,7 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
             auto kq = mha_bwd_dq_x3_kernel<N, AFF, DD, RG>;                                                            \
             const size_t lq = mx_bwd_dq_lds(N * 16, DD);                                                               \
             if (int rc = mx_reserve(kq, lq, what)) return rc;                                                          \
-            hipLaunchKernelGGL(kq, grid, dim3(256), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dq, \
+            hipLaunchKernelGGL(kq, grid, dim3(MX_DQ_NT), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dq, \
                                ldd, corr_a, corr_b, img, oimg);                                                        \
         }                                                                                                              \
         auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                                   \
