@@ -394,9 +394,10 @@ __global__ __launch_bounds__(MX_DQ_NT) void mha_bwd_dq_x3_kernel(const float* __
 
 // Eight waves per (batch, head): the workgroup's LDS (66 KB at L = 256: two workgroups per CU) is the same for four or eight
 // waves, and 110 registers fit four waves per SIMD -- twice the waves to hide the MFMA -> exp2 / split -> MFMA chain behind.
-constexpr int MX_DKV_NT = 512;
+// Past L = 256 (NKT >= 20: 85 KB and more) only ONE workgroup fits a CU: sixteen waves there.
+__host__ __device__ constexpr int mx_dkv_nt(int nkt) { return nkt >= 20 ? 1024 : 512; }
 template <int NKT, bool AFFINE, int D>
-__global__ __launch_bounds__(MX_DKV_NT) void mha_bwd_dkv_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
                                                              const float* __restrict__ dout, int64_t ldo,
                                                              const float* __restrict__ lse, int L, int h, float scale,
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(MX_DKV_NT) void mha_bwd_dkv_x3_kernel(const float* 
                                                              float* __restrict__ dz_partial, int img, int oimg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = NKT * 16;
+    constexpr int MX_DKV_NT = mx_dkv_nt(NKT);
     constexpr int NH = D / 8;
     const int nkt = (L + 15) >> 4;
     const float qmul = AFFINE ? scale : scale * MX_LOG2E;       // scores in log2 units (AFFINE: z is converted instead)
@@ -660,7 +662,7 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
         auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                                   \
         const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                                  \
         if (int rc = mx_reserve(kk, lk, what)) return rc;                                                              \
-        hipLaunchKernelGGL(kk, grid, dim3(MX_DKV_NT), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv, \
+        hipLaunchKernelGGL(kk, grid, dim3(mx_dkv_nt(N)), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv, \
                            ldd, corr_a, corr_b, dz_partial, img, oimg);                                                \
     } while (0)
 #define LPM_MX_BWD1(N, AFF, RG)        \
