@@ -435,7 +435,10 @@ static void launch_dcentres(const float* dO, const float* N, const float* asum, 
 //   dx[t,d] = sum_k a[t,k] dU[d,k]      A = row tiles of the assignment, B = ub2[b][k-step][d-tile]  (+ dl . W^T as a second
 //                                       reduction segment when the caller chains the assignment GEMM's backward)
 // grid (D/32, B): one workgroup stages a [32 d][K] chunk of dU in LDS and emits both tile forms from it.
-__global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __restrict__ dO, const float* __restrict__ N,
+// 512 threads: the [32][K + 1] staging tiles (69 KB with the g0 products at K = 256) allow two workgroups per CU whatever
+// their size, and a streaming kernel wants more than two waves per SIMD
+constexpr int VB_DU_NT = 512;
+__global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float* __restrict__ dO, const float* __restrict__ N,
                                                                 const float* __restrict__ ug, const float* __restrict__ vg,
                                                                 int D, int K, uint4* __restrict__ ub1, uint4* __restrict__ ub2,
                                                                 const float* __restrict__ colsq, float* __restrict__ g0, int raw) {
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __r
     float* rn = cv + K;                      // g0 && !raw: norm of the un-normalised column, U = N * rn;  raw: its inverse
     float* prod = rn + K;                    // g0 only: dU * U
     const int tid = threadIdx.x, b = blockIdx.y, d0 = blockIdx.x * 32;
-    for (int k = tid; k < K; k += 256) {
+    for (int k = tid; k < K; k += VB_DU_NT) {
         cu[k] = ug[(int64_t)b * K + k];
         cv[k] = vg[(int64_t)b * K + k];
         if (raw) rn[k] = rsqrtf(fmaxf(colsq[(int64_t)b * K + k], kL2Eps));
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __r
     const int K4 = K / 4;
     const float* ob = dO + ((int64_t)b * D + d0) * K;
     const float* nb = N + ((int64_t)b * D + d0) * K;
-    for (int i = tid; i < 32 * K4; i += 256) {
+    for (int i = tid; i < 32 * K4; i += VB_DU_NT) {
         const int r = i / K4, k = (i % K4) * 4;
         const float4 a = *reinterpret_cast<const float4*>(ob + (int64_t)r * K + k);
         float4 n = *reinterpret_cast<const float4*>(nb + (int64_t)r * K + k);
@@ -483,8 +486,9 @@ __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __r
         // g0[b][d] = sum_k dU[d,k] U[d,k]: the only thing the input batch norm's gamma gradient needs from this clip when the
         // frames themselves need no gradient (see ops._NetVLAD.backward); fixed summation order (lane-strided, then the wave tree)
         const int lane = tid & 63, wave = tid >> 6;
-        for (int rr = 0; rr < 8; ++rr) {
-            const int r = wave * 8 + rr;
+        constexpr int RPW = 32 / (VB_DU_NT / 64);       // rows per wave
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
             float acc = 0.f;
             for (int k = lane; k < K; k += 64) acc += prod[r * KS + k];
             acc = wave_sum(acc);
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __r
         }
     }
     const int KT = K / 32, DS = D / 16, KS16 = K / 16, DT = D / 32;
-    for (int it = tid; it < 2 * KT * 64; it += 256) {            // reduction over d, columns k
+    for (int it = tid; it < 2 * KT * 64; it += VB_DU_NT) {            // reduction over d, columns k
         const int lane = it & 63, kt = (it >> 6) % KT, dsl = (it >> 6) / KT;
         const int k = kt * 32 + (lane & 31), dl = dsl * 16 + 8 * (lane >> 5);
         float v[8];
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_du_tiles_kernel(const float* __r
         ub1[base + 64] = lo;
     }
     if (ub2 == nullptr) return;                                  // no input gradient wanted: the dx GEMM's operand is not needed
-    for (int it = tid; it < KS16 * 64; it += 256) {              // reduction over k, columns d
+    for (int it = tid; it < KS16 * 64; it += VB_DU_NT) {              // reduction over k, columns d
         const int lane = it & 63, ks = it >> 6;
         const int dl = lane & 31, k = ks * 16 + 8 * (lane >> 5);
         float v[8];
@@ -722,7 +726,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
             set_error("lpm_vlad_aggregate_bwd_tiles: cannot reserve %zu bytes of LDS", lds);
             return LPM_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(256), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0,
+        hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(VB_DU_NT), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0,
                            raw ? 1 : 0);
     }
     if (!g0) {       // the assignment's row tiles are the A operand of the dx GEMM only
