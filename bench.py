@@ -249,6 +249,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
+        barrier()                           # tear the process group down together (rank 0 was busy printing)
         dist.destroy_process_group()
 
 
