@@ -48,7 +48,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every csrc/*.hip for gfx950 and link liblpm_hip.so.  Returns the library path."""
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sources()
-    deps = srcs + [os.path.join(CSRC, "lpm_common.h"), os.path.join(PKG, "..", "include", "lpm_hip.h")]
+    deps = (srcs + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+            + [os.path.join(PKG, "..", "include", "lpm_hip.h")])
     stamp = os.path.join(LIBDIR, "build.sha256")
     dig = _digest(deps)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:

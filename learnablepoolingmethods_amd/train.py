@@ -70,6 +70,8 @@ class ParameterArena:
         store.frozen = True
         self._scratch = None
         self.direct = []          # (name, offset, numel): gradients their producer writes straight into the arena
+        self.l2: Dict[str, float] = {}   # gather mode: analytic L2 penalties of the current step (see gather_names)
+        self._name_of = {id(t): n for n, t in self.views.items()}
 
     def mark_direct(self, name: str, on_ready=None):
         """The op producing this variable's gradient writes it into the arena itself (ops._Projection) and returns no
@@ -82,8 +84,15 @@ class ParameterArena:
         self.direct.append((name, a0, t.numel()))
 
     def gather_names(self, names):
-        """Copy the gradients of ``names`` (gather mode) into their arena slices and release them."""
-        dst, src = [], []
+        """Copy the gradients of ``names`` (gather mode) into their arena slices and release them.  Runs on the CURRENT stream:
+        a gradient that was allocated on another stream (the audio branch's side stream) is recorded with the allocator for
+        this one before it is released -- ``wait_stream`` orders the copy behind the producer, but only ``record_stream``
+        keeps the block from being handed out again on its home stream while the copy is still queued here.
+        ``self.l2`` (name -> coefficient, set by the trainer for the current step): the analytic gradient
+        ``coefficient * w`` of an L2 weight penalty is added in the arena right behind the copy, i.e. BEFORE the slice can
+        leave in an all-reduce -- every tower's gradient carries the penalty, as in the reference (train.py:296-303,321)."""
+        dst, src, l2_dst, l2_src, l2_coef = [], [], [], [], []
+        cur = torch.cuda.current_stream() if self.device.type == "cuda" else None
         with torch.no_grad():
             for name in names:
                 t, gv = self.views[name], self.grad_views[name]
@@ -95,9 +104,19 @@ class ParameterArena:
                     src.append(g)
                 else:
                     gv.copy_(g)
+                if g is not None and cur is not None:
+                    g.record_stream(cur)
                 t.grad = None
+                coef = self.l2.get(name)
+                if coef:
+                    l2_dst.append(gv)
+                    l2_src.append(t)
+                    l2_coef.append(coef)
             if dst:
                 torch._foreach_copy_(dst, src)
+            for coef in sorted(set(l2_coef)):
+                sel = [i for i, c in enumerate(l2_coef) if c == coef]
+                torch._foreach_add_([l2_dst[i] for i in sel], [l2_src[i].detach() for i in sel], alpha=coef)
 
     def collect(self, skip=()):
         """After backward: make the gradient arena complete (``skip``: names already gathered by a bucket hook).  Direct variables: a producer that was not reached leaves a
@@ -301,9 +320,15 @@ class Trainer:
             return
         with torch.no_grad():
             x = self._normalize_input(model_input_raw.to(self.device), num_frames.to(self.device))
+            # undo the moving-average side effects of the dry run: statistics that existed before it (e.g. loaded after a
+            # predict()) get their values back, the ones it created start at their initial values
+            before = {n: v.clone() for n, v in self.store.vars.items() if not self.store.trainable[n]}
             self._forward(x, num_frames, labels)
-            for n, v in self.store.vars.items():       # undo the moving-average side effects of the dry run
-                if n.endswith("/moving_mean"):
+            self._l2_regs = []
+            for n, v in self.store.vars.items():
+                if n in before:
+                    v.copy_(before[n])
+                elif n.endswith("/moving_mean"):
                     v.zero_()
                 elif n.endswith("/moving_variance"):
                     v.fill_(1.0)
@@ -357,14 +382,18 @@ class Trainer:
         if reg_losses:
             reg_loss = reg_loss + torch.stack(reg_losses).sum()                                 # :301-303
         final_loss = self.reg_penalty * reg_loss + label_loss                                   # :321
+        # slim.l2_regularizer penalties recorded by the forward (store.analytic_l2, the GPU trainer): d/dw [penalty * scale *
+        # sum(w^2)/2] = penalty * scale * w is added where the gradient enters the arena (ParameterArena.gather_names), which
+        # for the early buckets happens inside backward, before their all-reduce leaves.
+        self.arena.l2 = {}
+        direct = {d[0] for d in self.arena.direct}
+        for w, scale in self._l2_regs:
+            name = self.arena._name_of.get(id(w))
+            if name is None or not self.arena.gather or name in direct:
+                raise RuntimeError("analytic L2 penalty on a variable the gather-mode arena does not gather")
+            self.arena.l2[name] = self.arena.l2.get(name, 0.0) + self.reg_penalty * scale
+        self._l2_regs = []
         final_loss.backward()                                                                   # :322-323
-        if self._l2_regs:                                          # d/dw [penalty * scale * sum(w^2)/2] = penalty * scale * w
-            with torch.no_grad():
-                for scale in sorted({sc for _, sc in self._l2_regs}):
-                    ws = [w for w, sc in self._l2_regs if sc == scale and w.grad is not None]
-                    if ws:
-                        torch._foreach_add_([w.grad for w in ws], ws, alpha=self.reg_penalty * scale)
-            self._l2_regs = []
         self.arena.collect(skip=self.bucket_gather.gathered_names() if self.bucket_gather is not None else ())
         self.sync.finish()                                                                      # utils.combine_gradients :330
         lr = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers,
@@ -382,6 +411,7 @@ class Trainer:
         ``tower/video_attention/q/kernel``, ..., Adam slots as ``<name>/Adam`` and ``<name>/Adam_1``) plus ``global_step``."""
         if self.arena is None:
             raise RuntimeError("state_dict() needs a built trainer: run build() or one step first")
+        self.sync_moving_statistics()
         out: Dict[str, object] = {n: v.detach().clone().cpu() for n, v in self.store.vars.items()}
         for n in self.arena.names:
             a0, _ = self.arena.segment(n)
@@ -392,11 +422,35 @@ class Trainer:
         out["global_step"] = int(self.global_step)
         return out
 
+    def sync_moving_statistics(self):
+        """Data parallelism only (a collective: every rank calls it).  Each rank is a tower with its own batch statistics
+        and keeps its OWN moving averages during training (the reference lets every tower's update op write the shared
+        variables in undefined order, train.py:309-316); before anything reads them across ranks -- a checkpoint, an
+        evaluation -- they are re-synchronised to the mean over ranks, which is what one shared variable receiving every
+        tower's ``decay``-weighted update converges to.  Called by ``state_dict``; call it yourself before a
+        multi-rank ``predict``."""
+        if self.sync is None or not self.sync.active:
+            return
+        stats = [v for n, v in sorted(self.store.vars.items()) if not self.store.trainable[n]]
+        if not stats:
+            return
+        with torch.no_grad():
+            flat = torch.cat([v.reshape(-1) for v in stats])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat /= self.num_towers
+            off = 0
+            for v in stats:
+                v.copy_(flat[off:off + v.numel()].view(v.shape))
+                off += v.numel()
+
     def load_state_dict(self, state: Dict[str, object]):
         if self.arena is None:
             raise RuntimeError("load_state_dict() needs a built trainer: run build() first")
         with torch.no_grad():
             self.store.load({n: v for n, v in state.items() if n in self.store.vars}, strict=False)
+            for v in self.store.vars.values():         # restored weights: the min |gamma| watch decides afresh, synchronously
+                if hasattr(v, "_lpm_gamma_watch"):
+                    del v._lpm_gamma_watch
             for n in self.arena.names:
                 a0, _ = self.arena.segment(n)
                 k = self.arena.views[n].numel()

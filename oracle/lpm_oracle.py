@@ -249,13 +249,27 @@ def multi_head_attention_bn(x, params, scope, num_heads, is_training, updates=No
     return o @ params[scope + "/output_transform/kernel"] + params[scope + "/output_transform/bias"]
 
 
+# Test hook: when a dict, every ReLU site of the encoders records its pre-activation (detached) under the name of the bias
+# variable that feeds it -- tests use it to keep their seeded weights away from pre-activations within rounding of zero, where
+# the derivative of ReLU is discontinuous and ANY two correct implementations may disagree (tests/_util.separate_relu_units).
+RELU_TAPS: Optional[Dict[str, torch.Tensor]] = None
+
+
+def _relu(z, bias_name):
+    if RELU_TAPS is not None:
+        RELU_TAPS[bias_name] = z.detach()
+    return torch.relu(z)
+
+
 def transformer_encoder(x, params, scope, num_heads, scope_id):
     """TransformerEncoder.forward (transformer_utils.py:399-413) with FeedForwardNetwork (:696-715):
     relu on both dense layers, residual+LN inside the FFN and again outside (App. C11)."""
     att = multi_head_attention(x, params, scope, num_heads) + x            # :403-405
     y = layer_norm(att, params, scope + "/LayerNorm")                      # :407
-    f = torch.relu(y @ params[scope + f"/filter_output{scope_id}/kernel"] + params[scope + f"/filter_output{scope_id}/bias"])
-    g = torch.relu(f @ params[scope + f"/ff_output{scope_id}/kernel"] + params[scope + f"/ff_output{scope_id}/bias"])
+    f = _relu(y @ params[scope + f"/filter_output{scope_id}/kernel"] + params[scope + f"/filter_output{scope_id}/bias"],
+              scope + f"/filter_output{scope_id}/bias")
+    g = _relu(f @ params[scope + f"/ff_output{scope_id}/kernel"] + params[scope + f"/ff_output{scope_id}/bias"],
+              scope + f"/ff_output{scope_id}/bias")
     n = layer_norm(g + y, params, scope + "/LayerNorm_1")                  # :712-713
     return layer_norm(n + y, params, scope + "/LayerNorm_2")               # :410-411
 
@@ -269,9 +283,11 @@ def transformer_encoder_mod(x, params, scope, num_heads, scope_id, is_training, 
             dropout_mask = (torch.rand_like(att) >= dropout_rate).to(att.dtype)
         att = att * dropout_mask / (1.0 - dropout_rate)
     y = layer_norm(att + x, params, scope + "/LayerNorm")                  # :451-454
-    f = torch.relu(y @ params[scope + f"/filter_output{scope_id}/kernel"] + params[scope + f"/filter_output{scope_id}/bias"])
+    f = _relu(y @ params[scope + f"/filter_output{scope_id}/kernel"] + params[scope + f"/filter_output{scope_id}/bias"],
+              scope + f"/filter_output{scope_id}/bias")
     f = batch_norm(f, params, scope + "/filter_bn", is_training, updates)  # :747-752
-    o = torch.relu(f @ params[scope + f"/ff_output{scope_id}/kernel"] + params[scope + f"/ff_output{scope_id}/bias"])
+    o = _relu(f @ params[scope + f"/ff_output{scope_id}/kernel"] + params[scope + f"/ff_output{scope_id}/bias"],
+              scope + f"/ff_output{scope_id}/bias")
     return batch_norm(o, params, scope + "/feed_output_bn", is_training, updates)  # :760-765
 
 

@@ -1,0 +1,68 @@
+"""One rank of tests/test_gpu_dp_trainer.py (not a test module).  Started as a fresh child process BEFORE it touches the GPU:
+
+    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_trainer_worker.py <dir> <side_stream 0|1>
+
+All ranks share GPU 0 and exchange gradients over gloo (the boxes of this pool have one GPU; the code path -- arena buckets
+gathered and all-reduced from autograd hooks, early hidden1_weights bucket, per-variable clip + Adam on the summed arena -- is
+the one RCCL drives with one rank per GPU).  Reads <dir>/inputs.pt, writes <dir>/rank<r>.pt."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    out_dir, side = sys.argv[1], sys.argv[2] == "1"
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from learnablepoolingmethods_amd import FLAGS, registry
+    from learnablepoolingmethods_amd.train import Trainer
+    inp = torch.load(os.path.join(out_dir, "inputs.pt"))
+    c = inp["cfg"]
+    FLAGS.moe_l2 = c["moe_l2"]
+    FLAGS.audio_side_stream = side
+    per = inp["per_tower"]
+    sl = slice(rank * per, (rank + 1) * per)
+    x, nf, lab = inp["x"][sl], inp["nf"][sl], inp["lab"][sl]
+    tr = Trainer(registry.get_model("NetVladV1"), vocab_size=c["vocab_size"], batch_size=per, base_learning_rate=c["base_learning_rate"],
+                 learning_rate_decay=c["learning_rate_decay"], learning_rate_decay_examples=c["learning_rate_decay_examples"],
+                 device=dev, seed=100 + rank,           # ranks start DIFFERENT: build() must broadcast rank 0's weights
+                 model_kwargs=dict(iterations=c["iterations"], cluster_size=c["cluster_size"], hidden_size=c["hidden_size"]))
+    tr.build(x, nf, lab)
+    assert tr.sync.active and tr.num_towers == world
+    res = {"early_buckets": tr.bucket_gather.early if tr.bucket_gather is not None else [], "steps": []}
+    if rank == 0:                                       # only rank 0 gets the oracle's weights: the others must receive them
+        tr.store.load({"tower/" + k: v for k, v in inp["params"].items()})
+    dist.broadcast(tr.arena.param, src=0)
+    for n, v in tr.store.vars.items():
+        if not tr.store.trainable[n]:
+            dist.broadcast(v, src=0)
+    names = list(tr.arena.names)
+    for s in range(inp["steps"]):
+        before = {n: tr.store.vars[n].detach().double().cpu() for n in names}
+        o = tr.step(x, nf, lab)
+        torch.cuda.synchronize()
+        grads = {}
+        for n in names:
+            a0, _ = tr.arena.segment(n)
+            grads[n] = tr.arena.grad[a0:a0 + tr.arena.views[n].numel()].reshape(tr.arena.views[n].shape).double().cpu()
+        res["steps"].append(dict(loss=o["loss"].double().cpu(), predictions=o["predictions"].double().cpu(), lr=o["learning_rate"],
+                                 summed=grads, before=before,
+                                 gathered=sorted(tr.bucket_gather.gathered) if tr.bucket_gather is not None else []))
+    res["local_stats"] = {n: v.detach().double().cpu() for n, v in tr.store.vars.items() if not tr.store.trainable[n]}
+    sd = tr.state_dict()                                # a collective: moving statistics averaged over ranks
+    res["state"] = {n: (v.double() if torch.is_tensor(v) else v) for n, v in sd.items()}
+    torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
