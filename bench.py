@@ -81,6 +81,39 @@ def cpu_baseline(budget_s):
                       f"reference, which cannot run here (SURVEY F2)"}
 
 
+class Watchdog:
+    """Multi-rank runs only: a daemon thread that ends THIS rank with a non-zero exit code, after saying where it stood,
+    when the main thread has not reported progress for ``limit`` seconds -- a hang in a collective (a peer that died, a
+    rendezvous that never completed) then shows up in the driver's log as a named phase and collective instead of as a
+    silent time-out of the whole run."""
+
+    def __init__(self, rank, limit):
+        import threading
+        self.rank, self.limit = rank, limit
+        self.phase, self.t = "start", time.monotonic()
+        self.stop = False
+        if limit > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def tick(self, phase):
+        self.phase, self.t = phase, time.monotonic()
+
+    def _run(self):
+        while not self.stop:
+            time.sleep(1.0)
+            idle = time.monotonic() - self.t
+            if idle > self.limit:
+                try:
+                    from learnablepoolingmethods_amd import train
+                    last = train.LAST_COLLECTIVE
+                except Exception:
+                    last = "unknown"
+                sys.stderr.write(f"[bench.py rank {self.rank}] WATCHDOG: no progress for {idle:.0f} s in phase '{self.phase}'; "
+                                 f"last collective on this rank: {last}\n")
+                sys.stderr.flush()
+                os._exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +125,8 @@ def main():
                          "first second, 8.4-8.7k afterwards)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--watchdog-seconds", type=float, default=240.0,
+                    help="N > 1 only: a rank that makes no progress for this long prints its phase and last collective and exits 3")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,12 +143,16 @@ def main():
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    dog = Watchdog(rank, args.watchdog_seconds if world > 1 else 0)
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dog.tick("init_process_group (rendezvous)")
+        to = datetime.timedelta(seconds=max(60.0, 2 * args.watchdog_seconds))   # RCCL's own watchdog, behind ours
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=to)
         else:
-            dist.init_process_group("nccl", device_id=device)       # nccl == RCCL on ROCm
+            dist.init_process_group("nccl", device_id=device, timeout=to)       # nccl == RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from learnablepoolingmethods_amd import ops, registry
@@ -123,17 +162,21 @@ def main():
     trainer = Trainer(model, vocab_size=VOCAB, batch_size=PER_GPU_BATCH, device=device, seed=1234, model_kwargs=CFG, **TRAIN)
     raw, nf, labels = synthetic_batch(PER_GPU_BATCH, device, seed=rank)
 
-    def barrier():
+    def barrier(what="barrier"):
+        dog.tick(what)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        dog.tick(what + " done")
 
     # device spin-up: every rank runs the SAME number of untimed steps (the step contains collectives), sized on rank 0
     spin = 0
     if args.spinup_seconds > 0:
+        dog.tick("first steps (variable creation, arena broadcast, library set-up)")
         for _ in range(2):                                   # builds the variables / arenas, first-use library set-up
             trainer.step(raw, nf, labels)
         torch.cuda.synchronize()
+        dog.tick("spin-up steps")
         t_spin = time.perf_counter()
         for _ in range(3):
             trainer.step(raw, nf, labels)
@@ -143,20 +186,24 @@ def main():
         if world > 1:
             dist.broadcast(n_spin, src=0)
         spin = 5 + int(n_spin.item())
-        for _ in range(spin - 5):
+        for i in range(spin - 5):
             trainer.step(raw, nf, labels)
+            if i % 32 == 0:
+                torch.cuda.synchronize()
+                dog.tick(f"spin-up step {i}")
         torch.cuda.synchronize()
+    dog.tick("warm-up steps")
     for _ in range(args.warmup):
         trainer.step(raw, nf, labels)
     ops.KERNEL_TIMELINE = []
     from learnablepoolingmethods_amd import _capi
     lib = _capi.load()
     lib._lpm_kernel_timing_enable(1)       # K1 / K2 launches carry their own start/stop HIP events (kernel duration proper)
-    barrier()
+    barrier("barrier before the timed steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = trainer.step(raw, nf, labels)
-    barrier()
+    barrier("barrier after the timed steps")
     elapsed = time.perf_counter() - t0
     timeline, ops.KERNEL_TIMELINE = ops.KERNEL_TIMELINE, None
     lib._lpm_kernel_timing_enable(0)
@@ -249,8 +296,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
-        barrier()                           # tear the process group down together (rank 0 was busy printing)
+        barrier("final barrier")            # tear the process group down together (rank 0 was busy printing)
+        dog.tick("destroy_process_group")
         dist.destroy_process_group()
+    dog.stop = True
 
 
 if __name__ == "__main__":

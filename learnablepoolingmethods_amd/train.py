@@ -21,6 +21,15 @@ from . import variables as vs
 
 ARENA_ALIGN = 4096   # LPM_ARENA_ALIGN: every variable starts on a chunk boundary of the optimizer kernel
 
+# The collective this rank entered last (name, arena slice, state): what a watchdog prints when a multi-rank run stops making
+# progress (bench.py --gpus N), so that a hang names the exchange it hangs in.
+LAST_COLLECTIVE = "none yet"
+
+
+def _note(what: str):
+    global LAST_COLLECTIVE
+    LAST_COLLECTIVE = what
+
 
 def learning_rate(base_learning_rate, global_step, batch_size, num_towers, decay_examples, decay):
     """tf.train.exponential_decay(staircase=True) over examples seen (train.py:244-249)."""
@@ -184,14 +193,19 @@ class GradientSynchronizer:
         if b <= a:
             self.done.add(i)
             return
-        self.pending.append(dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        _note(f"all_reduce(SUM) of gradient bucket {i} = arena[{a}:{b}] ({4 * (b - a) >> 20} MiB): launching")
+        self.pending.append((i, dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        _note(f"all_reduce(SUM) of gradient bucket {i} = arena[{a}:{b}] ({4 * (b - a) >> 20} MiB): launched, not yet waited for")
         self.done.add(i)
 
     def finish(self):
         for i in range(len(self.buckets)):
             self.launch(i)
-        for w in self.pending:
+        for i, w in self.pending:
+            _note(f"all_reduce(SUM) of gradient bucket {i}: waiting for completion")
             w.wait()
+        if self.pending:
+            _note(f"all_reduce(SUM) of gradient buckets {[i for i, _ in self.pending]}: complete")
         self.pending, self.done = [], set()
 
 
@@ -359,6 +373,7 @@ class Trainer:
                               if (gather and self.sync.active and early_buckets) else None)
         if self.sync.active:
             # every rank must start from identical weights (the reference shares variables across towers)
+            _note("broadcast of the parameter arena from rank 0 (Trainer.build)")
             dist.broadcast(self.arena.param, src=0, group=self.group)
             for n, v in self.store.vars.items():
                 if not self.store.trainable[n]:
