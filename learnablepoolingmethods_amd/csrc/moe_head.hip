@@ -4,6 +4,11 @@
 // and its backward in closed form:
 //   dL/dp = dloss * (-(y/(p+eps) - (1-y)/(1-p+eps)) / B) + dpred
 //   d/d expert_act_i = dL/dp * g_i e_i (1 - e_i),    d/d gate_act_j = dL/dp * g_j (e_j [j<m] - p)
+// 1 - p and 1 - e_i are formed WITHOUT cancellation: 1 - e_i = sigmoid(-expert_act_i) and, because the m+1 gates sum to one,
+// q = 1 - p = g_m + sum_{i<m} g_i (1 - e_i).  A freshly initialised reference model saturates (hidden1_weights ~ N(0, 1/K) on a
+// layer-normed descriptor gives |activation| ~ 30-70 and predictions within 1e-9 of 0 or 1): with q from the rounded p, fp32
+// holds log(1 - p + eps) and 1 / (1 - p + eps) to 6e-3 only (eps = 1e-5 against a 6e-8 spacing of p next to 1); with q summed
+// from its small terms they are good to fp32 rounding, like the fp64 evaluation of the same formula.
 // ~35 elementwise / reduction launches of the host graph become three.  The two FC layers around it stay library GEMMs.
 #include "lpm_common.h"
 
@@ -11,7 +16,9 @@ namespace lpm {
 
 constexpr int MOE_MAX_MIX = 8;
 
-__device__ __forceinline__ void moe_mix(const float* __restrict__ ga, const float* __restrict__ ea, int m, float* g, float* e, float& p) {
+// -> g (gates), e (experts), ne = 1 - e, p = sum g e, q = 1 - p
+__device__ __forceinline__ void moe_mix(const float* __restrict__ ga, const float* __restrict__ ea, int m, float* g, float* e, float* ne,
+                                        float& p, float& q) {
     float mx = ga[0];
     for (int i = 1; i <= m; ++i) mx = fmaxf(mx, ga[i]);
     float s = 0.f;
@@ -22,9 +29,15 @@ __device__ __forceinline__ void moe_mix(const float* __restrict__ ga, const floa
     const float inv = 1.f / s;
     p = 0.f;
     for (int i = 0; i <= m; ++i) g[i] *= inv;
+    q = g[m];
     for (int i = 0; i < m; ++i) {
-        e[i] = 1.f / (1.f + __expf(-ea[i]));
+        // sigmoid(a) and sigmoid(-a) from one exponential of -|a| (never overflows)
+        const float a = ea[i], t = __expf(-fabsf(a)), r = 1.f / (1.f + t);
+        const float big = r, small = t * r;
+        e[i] = a >= 0.f ? big : small;
+        ne[i] = a >= 0.f ? small : big;
         p = fmaf(g[i], e[i], p);
+        q = fmaf(g[i], ne[i], q);
     }
 }
 
@@ -34,12 +47,12 @@ __global__ __launch_bounds__(256) void moe_ce_fwd_kernel(const float* __restrict
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float l = 0.f;
     if (i < n) {
-        float g[MOE_MAX_MIX + 1], e[MOE_MAX_MIX], p;
-        moe_mix(gate_act + i * (m + 1), expert_act + i * m, m, g, e, p);
+        float g[MOE_MAX_MIX + 1], e[MOE_MAX_MIX], ne[MOE_MAX_MIX], p, q;
+        moe_mix(gate_act + i * (m + 1), expert_act + i * m, m, g, e, ne, p, q);
         pred[i] = p;
         if (labels) {
             const float y = labels[i];
-            l = -(y * __logf(p + eps) + (1.f - y) * __logf(1.f - p + eps));
+            l = -(y * __logf(p + eps) + (1.f - y) * __logf(q + eps));
         }
     }
     if (loss_partial) {
@@ -71,16 +84,16 @@ __global__ __launch_bounds__(256) void moe_ce_bwd_kernel(const float* __restrict
                                                          float inv_batch, float* __restrict__ dgate, float* __restrict__ dexpert) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float g[MOE_MAX_MIX + 1], e[MOE_MAX_MIX], p;
-    moe_mix(gate_act + i * (m + 1), expert_act + i * m, m, g, e, p);
+    float g[MOE_MAX_MIX + 1], e[MOE_MAX_MIX], ne[MOE_MAX_MIX], p, q;
+    moe_mix(gate_act + i * (m + 1), expert_act + i * m, m, g, e, ne, p, q);
     float dp = dpred ? dpred[i] : 0.f;
     if (labels && dloss) {
         const float y = labels[i];
-        dp += dloss[0] * inv_batch * -(y / (p + eps) - (1.f - y) / (1.f - p + eps));
+        dp += dloss[0] * inv_batch * -(y / (p + eps) - (1.f - y) / (q + eps));
     }
     for (int j = 0; j < m; ++j) {
-        dexpert[i * m + j] = dp * g[j] * e[j] * (1.f - e[j]);
-        dgate[i * (m + 1) + j] = dp * g[j] * (e[j] - p);
+        dexpert[i * m + j] = dp * g[j] * e[j] * ne[j];
+        dgate[i * (m + 1) + j] = dp * g[j] * (q - ne[j]);          // e_j - p = (1 - p) - (1 - e_j)
     }
     dgate[i * (m + 1) + m] = dp * g[m] * (0.f - p);
 }

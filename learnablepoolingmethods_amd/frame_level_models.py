@@ -140,6 +140,7 @@ class NetVladV1(models.BaseModel):
         encoder = FLAGS.netvlad_encoder if encoder is None else encoder
 
         reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training)
+        vs.summary("input_bn", reshaped_input)
         max_frames, feature_size = iterations, model_input.shape[2]
         has_audio = feature_size > 1024                                      # App. C9
 
@@ -172,9 +173,11 @@ class NetVladV1(models.BaseModel):
         side = ops.side_stream(audio, reshaped_input) if use_side else contextlib.nullcontext()
         with vs.variable_scope("video_VLAD"):
             vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v)       # :2273-2274
+            vs.summary("vlad_video", vlad_video)     # [B, K, D] (the App. C5 token view) when the encoders follow, else [B, D*K]
         if has_audio:
             with side, vs.variable_scope("audio_VLAD"):
                 vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder, input_affine=aff_a) # :2276-2277
+                vs.summary("vlad_audio", vlad_audio)
 
         slots = None
         if encoder:
@@ -208,6 +211,7 @@ class NetVladV1(models.BaseModel):
             vlad = slots.join(vlad_video, vlad_audio)                                          # :2309, in place
         else:
             vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video         # :2309
+        vs.summary("vlad", vlad)
         return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
                                       remove_diag, is_training, **unused_params)
 
@@ -259,6 +263,7 @@ class NetVladV2(models.BaseModel):
         dm = dropout_masks or {}
 
         reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training)
+        vs.summary("input_bn", reshaped_input)
         max_frames, feature_size = iterations, model_input.shape[2]
         has_audio = feature_size > 1024
 
@@ -269,10 +274,13 @@ class NetVladV2(models.BaseModel):
         with vs.variable_scope("video_VLAD"):
             vlad_video = video_NetVLAD.forward(reshaped_input[:, 0:1024], dropout_mask=dm.get("video"),
                                                dropout_rate=dropout_rate)                      # :2437-2438
+            vs.summary("vlad_video", vlad_video)
         if has_audio:
             with vs.variable_scope("audio_VLAD"):
                 vlad_audio = audio_NetVLAD.forward(reshaped_input[:, 1024:], dropout_mask=dm.get("audio"),
                                                    dropout_rate=dropout_rate)                  # :2440-2441
+                vs.summary("vlad_audio", vlad_audio)
         vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video             # :2445
+        vs.summary("vlad", vlad)
         return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
                                       remove_diag, is_training, **unused_params)

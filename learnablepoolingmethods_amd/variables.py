@@ -27,6 +27,9 @@ class VariableStore:
         self._gen_seed = seed
         self._gen: Optional[torch.Generator] = None
         self.frozen = False
+        # tf.summary.histogram stand-in (frame_level_models.py:2780,2799; train.py:260,285): None = summaries off (nothing is
+        # kept alive); a dict collects the named intermediate tensors of the next forward (detached)
+        self.summaries: Optional[Dict[str, torch.Tensor]] = None
 
     # -- scopes ---------------------------------------------------------------------------------
     @contextlib.contextmanager
@@ -148,3 +151,9 @@ def variable_scope(name: str):
 
 def get_variable(name, shape, initializer, trainable=True, device=None):
     return _default.get_variable(name, shape, initializer, trainable, device)
+
+
+def summary(name: str, tensor: torch.Tensor):
+    """Record an intermediate tensor of the forward under ``name`` when the current store collects summaries."""
+    if _default.summaries is not None:
+        _default.summaries[name] = tensor.detach()

@@ -53,8 +53,13 @@ def main():
         for n in names:
             a0, _ = tr.arena.segment(n)
             grads[n] = tr.arena.grad[a0:a0 + tr.arena.views[n].numel()].reshape(tr.arena.views[n].shape).double().cpu()
+        slots = {}
+        for n in names:
+            a0, _ = tr.arena.segment(n)
+            k, shape = tr.arena.views[n].numel(), tr.arena.views[n].shape
+            slots[n] = (tr.arena.m[a0:a0 + k].reshape(shape).double().cpu(), tr.arena.v[a0:a0 + k].reshape(shape).double().cpu())
         res["steps"].append(dict(loss=o["loss"].double().cpu(), predictions=o["predictions"].double().cpu(), lr=o["learning_rate"],
-                                 summed=grads, before=before,
+                                 summed=grads, before=before, adam=slots,
                                  gathered=sorted(tr.bucket_gather.gathered) if tr.bucket_gather is not None else []))
     res["local_stats"] = {n: v.detach().double().cpu() for n, v in tr.store.vars.items() if not tr.store.trainable[n]}
     sd = tr.state_dict()                                # a collective: moving statistics averaged over ranks
