@@ -79,6 +79,7 @@ def _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_bat
         else:
             raise NotImplementedError("context gating without batch norm is broken in the reference (App. C12)")
         activation = activation * torch.sigmoid(gates)                                                         # :2367-2368
+    vs.summary("activation", activation)
     aggregated_model = getattr(video_level_models, "MoeModel")
     return aggregated_model().create_model(model_input=activation, vocab_size=vocab_size, is_training=is_training,
                                            **unused_params)

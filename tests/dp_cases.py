@@ -41,8 +41,9 @@ def make_case(name):
 
 
 def run_oracle(case):
-    """The reference's multi-tower step, ``steps`` times.  -> dict with, per step, loss / predictions / the SUMMED raw
-    gradients / the clipped gradients, and the final weights, Adam slots and per-tower batch-norm statistics."""
+    """The reference's multi-tower step (train.py:266-336 as oracle.train_step restates it), ``steps`` times, with every
+    tower's gradients computed once.  -> dict with, per step, loss / predictions / the SUMMED raw gradients / the clipped
+    gradients / weights and Adam slots after the step, and the per-tower batch-norm statistics at the end."""
     cfg, x, nf, lab = case["cfg"], case["x"].double(), case["nf"], case["lab"]
     T, per = case["towers"], case["per_tower"]
     p, st = case["params"], {"step": 0, "m": {}, "v": {}}
@@ -53,17 +54,25 @@ def run_oracle(case):
             for ts in tower_stats:
                 ts[n] = p[n].clone()
     for s in range(case["steps"]):
-        raw = []
-        for i in range(T):
+        raw, losses, preds = [], [], []
+        new_p = dict(p)
+        for i in range(T):                                                      # train.py:273-284, one tower per shard
             sl = slice(i * per, (i + 1) * per)
-            _, _, gd, upd = O.loss_and_grads(p, x[sl], nf[sl], lab[sl], cfg)
-            raw.append(gd)
+            pred, loss, gd, upd = O.loss_and_grads(p, x[sl], nf[sl], lab[sl], cfg)
+            raw.append(gd); losses.append(loss); preds.append(pred)
             for n, val in upd.items():
                 tower_stats[i][n] = tower_stats[i][n] * O.BN_DECAY + val * (1 - O.BN_DECAY)
-        summed = O.combine_gradients(raw)
-        p, st, info = O.train_step(p, st, x, nf, lab, cfg, T)
-        out["steps"].append(dict(loss=info["loss"], predictions=info["predictions"], summed=summed, clipped=info["clipped_grads"],
-                                 lr=info["lr"]))
+                new_p[n] = new_p[n] * O.BN_DECAY + val * (1 - O.BN_DECAY)       # shared variables, tower order (:309-316)
+        summed = O.combine_gradients(raw)                                       # :330
+        clipped = O.clip_gradient_norms(summed, cfg.clip_gradient_norm)         # :332-334
+        lr = O.learning_rate(cfg, st["step"], per, T)                           # :244-249
+        t = st["step"] + 1
+        m, v = {}, {}
+        for n, g in clipped.items():
+            new_p[n], m[n], v[n] = O.adam_tf_update(p[n], g, st["m"].get(n, torch.zeros_like(p[n])), st["v"].get(n, torch.zeros_like(p[n])), lr, t)
+        p, st = new_p, {"step": t, "m": m, "v": v}
+        out["steps"].append(dict(loss=torch.stack(losses).mean(), predictions=torch.cat(preds, 0), summed=summed, clipped=clipped, lr=lr,
+                                 params=p, m=m, v=v))
     out["params"], out["m"], out["v"] = p, st["m"], st["v"]
     # what the product reports at a checkpoint: the mean over towers of their own moving averages
     out["moving_mean_of_towers"] = {n: torch.stack([ts[n] for ts in tower_stats]).mean(0) for n in tower_stats[0]}

@@ -40,5 +40,11 @@ def test_two_tower_step_structure():
         s = st0["summed"][n]
         assert float(c.norm()) <= 1.0 + 1e-12
         torch.testing.assert_close(c, s * (1.0 / max(float(s.norm()), 1.0)), rtol=1e-12, atol=1e-15)
-    # one Adam step from zero slots: m = 0.1 g, v = 0.001 g^2
-    torch.testing.assert_close(ref["steps"][0]["lr"], cfg.base_learning_rate)
+    # one Adam step from zero slots: m = 0.1 g, v = 0.001 g^2; and the inline step equals oracle.train_step on the whole batch
+    assert st0["lr"] == cfg.base_learning_rate
+    for n, c in st0["clipped"].items():
+        torch.testing.assert_close(st0["m"][n], 0.1 * c, rtol=1e-12, atol=1e-18)
+    p1, s1, info = O.train_step(p, {"step": 0, "m": {}, "v": {}}, x, nf, lab, cfg, 2)
+    for n in p1:
+        torch.testing.assert_close(st0["params"][n], p1[n], rtol=1e-12, atol=1e-15)
+    torch.testing.assert_close(st0["loss"], info["loss"])
