@@ -65,8 +65,10 @@ def cpu_baseline(budget_s):
     p = O.init_params(cfg, FEATURE, seed=1000)
     st = {"step": 0, "m": {}, "v": {}}
     t0 = time.perf_counter()
-    p, st, _ = O.train_step(p, st, x, nf, lab, cfg, 1)            # warm-up (page-in, thread pools)
+    p0 = p
+    p, st, info0 = O.train_step(p, st, x, nf, lab, cfg, 1)        # warm-up (page-in, thread pools); also the parity sample
     warm = time.perf_counter() - t0
+    first = {"x": x, "nf": nf, "lab": lab, "params": p0, "loss": info0["loss"], "predictions": info0["predictions"]}
     times = []
     while len(times) < 5 and (sum(times) + warm) < budget_s:
         t0 = time.perf_counter()
@@ -78,7 +80,30 @@ def cpu_baseline(budget_s):
     return {"value": round(b / med, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle/lpm_oracle.train_step fp32 torch-CPU, same NetVladV1 cfg-2 layer sizes, batch {b} "
                       f"(1 warm-up + {len(times)} timed steps, median {med:.2f} s/step); stand-in for the TF1 "
-                      f"reference, which cannot run here (SURVEY F2)"}
+                      f"reference, which cannot run here (SURVEY F2)"}, first
+
+
+def parity_check(first, device):
+    """output parity asserted in the same run, outside the timed region.  The CPU baseline's first step (the oracle
+    from its seeded reference-style initialisation on its seeded 4-clip batch of the bench workload's layer sizes) is repeated by
+    the HIP path from the same weights: loss and predictions must agree to the north-star's 1e-3."""
+    from learnablepoolingmethods_amd import registry
+    from learnablepoolingmethods_amd.train import Trainer
+    b = first["x"].shape[0]
+    tr = Trainer(registry.get_model("NetVladV1"), vocab_size=VOCAB, batch_size=b, device=device, seed=1, model_kwargs=CFG, **TRAIN)
+    tr.build(first["x"], first["nf"], first["lab"])
+    tr.store.load({"tower/" + k: v for k, v in first["params"].items()})
+    out = tr.step(first["x"], first["nf"], first["lab"])
+    torch.cuda.synchronize()
+    pred, ref = out["predictions"].double().cpu(), first["predictions"].double()
+    e_pred = float((pred - ref).abs().max() / ref.abs().max())
+    e_loss = abs(float(out["loss"]) - float(first["loss"])) / abs(float(first["loss"]))
+    res = {"against": "cpu_baseline's first step (fp32 oracle, same weights, its 4-clip sample of the workload)",
+           "predictions_max_rel_err": float(f"{e_pred:.3e}"), "loss_rel_err": float(f"{e_loss:.3e}"), "tolerance": 1e-3,
+           "ok": bool(e_pred <= 1e-3 and e_loss <= 1e-3)}
+    del tr
+    torch.cuda.empty_cache()
+    return res
 
 
 class Watchdog:
@@ -293,8 +318,11 @@ def main():
                                  "achieved": round(byts / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(byts / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
+            line["cpu_baseline"], first = cpu_baseline(args.cpu_baseline_seconds)
+            line["parity"] = parity_check(first, device)
         print(json.dumps(line), flush=True)
+        if "parity" in line and not line["parity"]["ok"]:
+            raise SystemExit(f"bench.py: parity check failed: {line['parity']}")
     if world > 1:
         barrier("final barrier")            # tear the process group down together (rank 0 was busy printing)
         dog.tick("destroy_process_group")

@@ -175,14 +175,17 @@ def _well_conditioned(p):
     return p
 
 
-def _train_compare(name, cfg, feat, B, MF, steps, dev, tol=5e-3, **kw):
-    """``tol`` applies to whole-model gradients in the Frobenius norm: one ReLU unit whose pre-activation is within
-    fp32 rounding of zero flips between implementations and alone moves the filter_output kernel gradient by
-    1/sqrt(tokens*units) ~ 2e-3 (observed); the per-kernel tests in test_gpu_kernels.py hold 1e-3 in max-norm."""
+def _train_compare(name, cfg, feat, B, MF, steps, dev, tol=1e-3, **kw):
+    """``tol`` applies to whole-model gradients in the Frobenius norm of each variable (the north-star's 1e-3).  The seeded
+    weights keep every ReLU pre-activation away from zero (tests/_util.separate_relu_units): a unit within fp32 rounding of
+    zero takes its mask from the last bit of whichever arithmetic computed it and alone moves the filter_output kernel
+    gradient by 1/sqrt(tokens*units) ~ 2e-3 -- round 1 carried a 5e-3 tolerance for that."""
     from learnablepoolingmethods_amd import registry
     from learnablepoolingmethods_amd.train import Trainer
+    from tests._util import separate_relu_units
     x, nf, lab = O.make_synthetic_batch(B, MF, feat, cfg.vocab_size, seed=7, min_frames=max(2, MF // 3))
     p = _well_conditioned({k: v.double() for k, v in O.init_params(cfg, feat, seed=1007).items()})
+    p, _ = separate_relu_units(p, [(x.double(), nf, None)], cfg)
     tr = Trainer(registry.get_model(name), vocab_size=cfg.vocab_size, batch_size=B, base_learning_rate=cfg.base_learning_rate,
                  learning_rate_decay=cfg.learning_rate_decay, learning_rate_decay_examples=cfg.learning_rate_decay_examples,
                  device=dev, model_kwargs=dict(iterations=cfg.iterations, cluster_size=cfg.cluster_size,
@@ -241,7 +244,7 @@ def test_train_steps_v1_relu6_and_remove_diag():
     cfg = O.OracleConfig(model="NetVladV1", iterations=12, cluster_size=16, hidden_size=32, vocab_size=40,
                          base_learning_rate=1e-3, relu=True, remove_diag=True, encoder=False)
     FLAGS.netvlad_relu, FLAGS.gating_remove_diag = True, True
-    try:     # without the cluster encoders: their 262 k FFN ReLU inputs flip ~1 mask per run at 5e-6 (see _train_compare)
+    try:     # (without the cluster encoders: this case is about the tail)
         _train_compare("NetVladV1", cfg, 1152, 4, 16, 2, dev, encoder=False)
     finally:
         FLAGS.reset()
@@ -307,7 +310,7 @@ def test_willow_model_reg_forward_backward():
         a0, _ = tr.arena.segment("tower/" + n)
         g = tr.arena.grad[a0:a0 + p[n].numel()].reshape(p[n].shape)
         e = rel_l2(g, grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5)
-        assert e <= 5e-3, f"gradient {n}: relative L2 error {e:.3e}"
+        assert e <= 1e-3, f"gradient {n}: relative L2 error {e:.3e}"
 
 
 def test_training_is_bitwise_reproducible_across_runs():
