@@ -43,9 +43,11 @@ enum {
     LPM_VLAD_SOFTMAX = 1,      /* `assign` holds logits; apply affine + softmax over K (NetVLAD)      */
     LPM_VLAD_RESIDUAL = 2,     /* subtract (sum_t a) * centres (NetVLAD, NetVladAttenCluster)           */
     LPM_VLAD_OUT_KMAJOR = 4,   /* lpm_vlad_finalize_*: descriptor laid out [B,K,D] instead of [B,D*K]   */
-    LPM_VLAD_NRM_RAW = 8       /* lpm_vlad_finalize2_fwd: leave `nrm` as the un-normalised sums U (no in-place write of the
+    LPM_VLAD_NRM_RAW = 8,      /* lpm_vlad_finalize2_fwd: leave `nrm` as the un-normalised sums U (no in-place write of the
                                   intra-normalised copy); lpm_vlad_aggregate_bwd_tiles: `nrm` holds U and the normalised
                                   descriptor is rebuilt as U * rsqrt(max(colsq, eps)) where it is read                     */
+    LPM_VLAD_DEBUG_FALLBACK = 256 /* lpm_vlad_aggregate_fused_fwd, tests only: one workgroup of every clip behaves as if its wait
+                                  for the clip had timed out, so the follow-up finalize pass runs for every clip             */
 };
 
 int lpm_version(void);
@@ -194,6 +196,20 @@ int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, const float* c
                                   int flags, float* nrm, float* asum, float* colsq_part, lpm_stream_t stream);
 int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out,
                            float* colsq, float* csq, float* gsq, lpm_stream_t stream);
+
+/* K2 with the finalize pass fused in (frame_level_models.py:2803-2822 as ONE kernel): the same workgroups, but each waits for
+ * the other workgroups of its clip (per-clip arrival counter, bounded), forms 1/n_k and the clip's 1/sqrt(g) from the partial
+ * norms all of them published, and stores its tile of the NORMALISED descriptor straight from the accumulators into `out`
+ * ([B, D*K], or [B,K,D] with LPM_VLAD_OUT_KMAJOR); colsq, csq [B,K] and gsq [B] as from lpm_vlad_finalize2_fwd.  `nrm` receives
+ * the un-normalised sums only with LPM_VLAD_NRM_RAW (the form lpm_vlad_aggregate_bwd_tiles reads); it must be a valid
+ * [B, D, K] buffer either way (scratch of the follow-up pass that finishes a clip whose workgroups were not resident
+ * together -- results never depend on dispatch order).  workspace: lpm_vlad_fused_workspace_bytes(B, D, K), cleared by the
+ * call itself.  Needs lpm_vlad_fused_supported(D, K): the tiles3 shapes with K <= 512. */
+int lpm_vlad_fused_supported(int D, int K);
+size_t lpm_vlad_fused_workspace_bytes(int B, int D, int K);
+int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                 float* nrm, float* out, float* asum, float* colsq, float* csq, float* gsq, void* workspace,
+                                 size_t workspace_bytes, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3: backward of K2 (TF autodiff of the same lines; formulas SURVEY.md App. F.1-F.3).

@@ -19,6 +19,7 @@ LPM_VLAD_SOFTMAX = 1
 LPM_VLAD_RESIDUAL = 2
 LPM_VLAD_OUT_KMAJOR = 4
 LPM_VLAD_NRM_RAW = 8
+LPM_VLAD_DEBUG_FALLBACK = 256
 
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header
 _f = C.c_void_p      # device pointer
@@ -63,6 +64,9 @@ SIGNATURES = {
     "lpm_vlad_tiles3_supported": (_i, [_i, _i]),
     "lpm_vlad_aggregate_tiles3_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "lpm_vlad_finalize2_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "lpm_vlad_fused_supported": (_i, [_i, _i]),
+    "lpm_vlad_fused_workspace_bytes": (_s, [_i, _i, _i]),
+    "lpm_vlad_aggregate_fused_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_vlad_bwd_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_vlad_aggregate_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _l,
                                     _i, _f, _f, _s, _f]),

@@ -34,9 +34,29 @@ constexpr int T3_STAGE = 16 * 1024;       // bytes per stage: 4 A tiles + 4 x ti
 constexpr int T3_WS = 36;                 // epilogue per-wave tile row stride (floats): 144 B, 16-B aligned
 constexpr int T3_EPI = 8 * 32 * T3_WS * 4;  // epilogue bytes (8 waves x [32 d][32 k + pad]), overlays the ring
 
+// FUSED (lpm_vlad_aggregate_fused_fwd): the finalize pass moves into this kernel.  The K/128 x D/128 workgroups of a clip
+// publish their partial column square norms (write-through stores), count themselves in on a per-clip arrival counter, wait --
+// bounded -- until the clip is complete, read every partial norm of the clip back (L1-bypassing loads), form 1/n_k and the
+// clip's 1/sqrt(g) themselves and store their tile of the NORMALISED descriptor straight from the accumulators, d-major or
+// k-major.  The un-normalised sums never make a round trip through HBM (they are still written, once, when the backward will
+// read them: store_u).  The workgroups of a clip are consecutive in dispatch order on one XCD, so they are co-resident in
+// practice and the wait is a few microseconds of skew; if a workgroup ever times out it leaves its U tile in `nrm`, raises
+// fail[clip], and the caller's follow-up launch (vlad_finalize2 restricted to flagged clips) finishes those clips: the result
+// never depends on dispatch order, only the speed does (cdna guide 6, Guideline 16).
+struct T3Fused {
+    float* out;                 // [B, D*K] or [B, K, D]
+    int kmajor, store_u, debug_fallback;     // debug_fallback (tests): the first column slab of every clip acts as if its wait had timed out
+    float* colsq;               // [B, K] (outputs for the backward, written by the first workgroup of a clip)
+    float* csq;
+    float* gsq;                 // [B]
+    unsigned* arrive;           // [B], zero at launch
+    unsigned* fail;             // [B], zero at launch
+};
+
+template <bool FUSED>
 __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
     const uint4* __restrict__ at, const uint4* __restrict__ xt, const float* __restrict__ centres, int T, int D, int K,
-    int S, int KT, int residual, float* __restrict__ nrm, float* __restrict__ asum, float* __restrict__ colsq_part) {
+    int S, int KT, int residual, float* __restrict__ nrm, float* __restrict__ asum, float* __restrict__ colsq_part, const T3Fused fz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object (guide 5, trap (a))
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
     const int k0 = kb * 128, d0 = ds * 128 + dw * 32;
     const int srow = lane >> 3, c4 = (lane & 7) * 4;            // store pass: row it*8 + srow, columns c4..c4+3 of the tile's 32
     float4 cw[2][4];
-    if (residual) {
+    if (residual && !FUSED) {          // (the fused form holds more live state: it fetches the centres tile by tile below)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -132,6 +152,11 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
     float* ob = nrm + ((int64_t)b * D + d0) * K + k0 + kw * 64;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+        if (FUSED && residual) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                cw[c][it] = *reinterpret_cast<const float4*>(centres + (int64_t)(d0 + it * 8 + srow) * K + k0 + kw * 64 + c * 32 + c4);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(wl + l31 * T3_WS + 8 * q + 4 * half) =
@@ -149,7 +174,17 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
                 u.x -= s4.x * cw[c][it].x; u.y -= s4.y * cw[c][it].y; u.z -= s4.z * cw[c][it].z; u.w -= s4.w * cw[c][it].w;
             }
             sq.x = fmaf(u.x, u.x, sq.x); sq.y = fmaf(u.y, u.y, sq.y); sq.z = fmaf(u.z, u.z, sq.z); sq.w = fmaf(u.w, u.w, sq.w);
-            *reinterpret_cast<float4*>(ob + (int64_t)row * K + c * 32 + c4) = u;
+            if (!FUSED || fz.store_u) *reinterpret_cast<float4*>(ob + (int64_t)row * K + c * 32 + c4) = u;
+            if (FUSED) *reinterpret_cast<float4*>(wl + row * T3_WS + c4) = u;      // the residual goes back into the accumulators
+        }
+        if (FUSED) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(wl + l31 * T3_WS + 8 * q + 4 * half);
+                acc[c][4 * q] = t.x; acc[c][4 * q + 1] = t.y; acc[c][4 * q + 2] = t.z; acc[c][4 * q + 3] = t.w;
+            }
         }
 #pragma unroll
         for (int m = 8; m < 64; m <<= 1) {
@@ -160,9 +195,123 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
         __builtin_amdgcn_wave_barrier();                            // all reads of the tile done before pass 1 overwrites it
     }
     __syncthreads();
+    if (!FUSED) {
+        if (tid < 128) {
+            colsq_part[((int64_t)b * P + ds) * K + k0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            if (ds == 0) asum[(int64_t)b * K + k0 + tid] = ssum[tid];
+        }
+        return;
+    }
+    // ---- publish this workgroup's 128 partial norms write-through, arrive, wait for the clip (Guideline 16, form R1 with sc1 loads)
+    typedef __attribute__((address_space(1))) float gfloat;
+    typedef __attribute__((address_space(1))) unsigned gu32;
     if (tid < 128) {
-        colsq_part[((int64_t)b * P + ds) * K + k0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+        const float pn = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+        __hip_atomic_store((gfloat*)(colsq_part + ((int64_t)b * P + ds) * K + k0 + tid), pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ds == 0) asum[(int64_t)b * K + k0 + tid] = ssum[tid];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
+    __syncthreads();
+    int* okp = reinterpret_cast<int*>(ssum + 128);
+    if (tid == 0) {
+        gu32* arr = (gu32*)(fz.arrive + b);
+        __hip_atomic_fetch_add(arr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned need = (unsigned)(KB * P);
+        const long long t0 = wall_clock64();                   // 100 MHz
+        int ok = 1;
+        while (__hip_atomic_load(arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 200000) { ok = 0; break; }     // 2 ms: dispatch did not keep the clip together
+        }
+        if (fz.debug_fallback && ds == 0) ok = 0;
+        *okp = ok;
+    }
+    __syncthreads();
+    if (*okp == 0) {
+        // fallback: leave the un-normalised tile for the caller's follow-up finalize of this clip
+        if (!fz.store_u) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(wl + l31 * T3_WS + 8 * q + 4 * half) =
+                        make_float4(acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + srow;
+                    *reinterpret_cast<float4*>(ob + (int64_t)row * K + c * 32 + c4) = *reinterpret_cast<const float4*>(wl + row * T3_WS + c4);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (tid == 0) __hip_atomic_store((gu32*)(fz.fail + b), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // ---- every partial norm of the clip -> 1/n_k for all K clusters and the clip's 1/sqrt(g)   (fixed summation order)
+    float* gl = reinterpret_cast<float*>(smem);                // [P][K], overlays the wave tiles (their content lives in acc again)
+    for (int i = tid; i < P * K; i += 512)
+        gl[i] = __hip_atomic_load((gfloat*)(colsq_part + (int64_t)b * P * K + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    float* invn = red;                                         // [K <= 512]
+    float cg = 0.f;
+    if (tid < K) {
+        float n = 0.f;
+        for (int p = 0; p < P; ++p) n += gl[p * K + tid];
+        const float iv = rsqrtf(fmaxf(n, kL2Eps));
+        cg = n * iv * iv;
+        invn[tid] = iv;
+        if (kb == 0 && ds == 0) {
+            fz.colsq[(int64_t)b * K + tid] = n;
+            fz.csq[(int64_t)b * K + tid] = cg;
+        }
+    }
+    cg = wave_sum(cg);
+    float* wg8 = ssum;                                         // [8] per-wave partial sums of g (ssum is dead)
+    if (lane == 0) wg8[wave] = cg;
+    __syncthreads();
+    const float tot = ((wg8[0] + wg8[1]) + (wg8[2] + wg8[3])) + ((wg8[4] + wg8[5]) + (wg8[6] + wg8[7]));
+    const float ig = rsqrtf(fmaxf(tot, kL2Eps));
+    if (kb == 0 && ds == 0 && tid == 0) fz.gsq[b] = tot;
+    // ---- the normalised tile, straight from the accumulators (acc[c][r]: column d = l31, cluster 8 (r >> 2) + 4 half + (r & 3))
+    if (fz.kmajor) {
+        // [B, K, D]: for a fixed register the 32 lanes of a half-wave hold 32 consecutive d of one cluster row: 128-byte segments
+        float* okb = fz.out + ((int64_t)b * K + k0 + kw * 64) * D + d0 + l31;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kl = c * 32 + 8 * q + 4 * half;
+                const float4 iv = *reinterpret_cast<const float4*>(invn + kw * 64 + kl);
+                okb[(int64_t)(kl + 0) * D] = acc[c][4 * q + 0] * (iv.x * ig);
+                okb[(int64_t)(kl + 1) * D] = acc[c][4 * q + 1] * (iv.y * ig);
+                okb[(int64_t)(kl + 2) * D] = acc[c][4 * q + 2] * (iv.z * ig);
+                okb[(int64_t)(kl + 3) * D] = acc[c][4 * q + 3] * (iv.w * ig);
+            }
+    } else {
+        // [B, D*K] d-major: through the wave-private LDS tile like the U store, scaled on the way in
+        float* od = fz.out + ((int64_t)b * D + d0) * K + k0 + kw * 64;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 iv = *reinterpret_cast<const float4*>(invn + kw * 64 + c * 32 + 8 * q + 4 * half);
+                *reinterpret_cast<float4*>(wl + l31 * T3_WS + 8 * q + 4 * half) =
+                    make_float4(acc[c][4 * q] * (iv.x * ig), acc[c][4 * q + 1] * (iv.y * ig), acc[c][4 * q + 2] * (iv.z * ig),
+                                acc[c][4 * q + 3] * (iv.w * ig));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + srow;
+                *reinterpret_cast<float4*>(od + (int64_t)row * K + c * 32 + c4) = *reinterpret_cast<const float4*>(wl + row * T3_WS + c4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -173,8 +322,10 @@ template <bool KMAJOR>
 __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
                                                              int P, int D, int K, float* __restrict__ out,
                                                              float* __restrict__ colsq, float* __restrict__ csq,
-                                                             float* __restrict__ gsq, int keep_u) {
+                                                             float* __restrict__ gsq, int keep_u, const unsigned* __restrict__ only_if) {
     // keep_u (LPM_VLAD_NRM_RAW): nrm is left as the un-normalised sums U (the tile backward rebuilds N = U * inv_n itself)
+    // only_if (the fused kernel's follow-up): clips whose flag is zero are already complete and are not touched
+    if (only_if && only_if[blockIdx.y] == 0) return;
     extern __shared__ float fs[];            // [K] inv_n, then [32][33] transpose tile, [4] partial sums
     float* invn = fs;
     float* tile = fs + K;
@@ -310,7 +461,8 @@ extern "C" int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, con
     const int S = (T + 15) / 16, KT = K / 32;
     const size_t lds = (size_t)T3_NS * T3_STAGE + (4 * 128 + 128) * sizeof(float);
     static_assert(T3_EPI <= T3_NS * T3_STAGE, "the epilogue tiles overlay the DMA ring");
-    auto kern = vlad_aggregate_tiles3_kernel;
+    auto kern = vlad_aggregate_tiles3_kernel<false>;
+    const T3Fused fz{};
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         set_error("lpm_vlad_aggregate_tiles3_fwd: cannot reserve %zu bytes of LDS", lds);
@@ -320,11 +472,72 @@ extern "C" int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, con
     hipEvent_t e0, e1;
     if (timing_request(LPM_TIMING_K2, &e0, &e1))
         hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T,
-                              D, K, S, KT, residual, nrm, asum, colsq_part);
+                              D, K, S, KT, residual, nrm, asum, colsq_part, fz);
     else
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
-                           residual, nrm, asum, colsq_part);
+                           residual, nrm, asum, colsq_part, fz);
     return check_launch("lpm_vlad_aggregate_tiles3_fwd");
+}
+
+// ---- K2 with the finalize pass fused in (see T3Fused): workspace = [colsq_part B*P*K floats | arrive B | fail B] --------------------
+extern "C" int lpm_vlad_fused_supported(int D, int K) {
+    return (lpm_vlad_tiles3_supported(D, K) && K <= 512 && (int64_t)(D / 128) * K * 4 <= lpm::T3_NS * lpm::T3_STAGE) ? 1 : 0;
+}
+extern "C" size_t lpm_vlad_fused_workspace_bytes(int B, int D, int K) {
+    return ((size_t)B * (D / 128) * K + 2 * (size_t)B) * sizeof(float);
+}
+
+extern "C" int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                            float* nrm, float* out, float* asum, float* colsq, float* csq, float* gsq, void* workspace,
+                                            size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(at && xt && nrm && out && asum && colsq && csq && gsq && workspace, LPM_ERR_BADARG,
+                "lpm_vlad_aggregate_fused_fwd: null pointer");
+    const int residual = (flags & LPM_VLAD_RESIDUAL) ? 1 : 0;
+    LPM_REQUIRE(!residual || centres, LPM_ERR_BADARG, "lpm_vlad_aggregate_fused_fwd: RESIDUAL needs centres");
+    LPM_REQUIRE(B > 0 && T > 0 && lpm_vlad_fused_supported(D, K), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_fused_fwd: need D %% 128 == 0, K %% 128 == 0, K <= 512, D/128 * K <= 12288 (D=%d K=%d)", D, K);
+    LPM_REQUIRE(workspace_bytes >= lpm_vlad_fused_workspace_bytes(B, D, K), LPM_ERR_WORKSPACE,
+                "lpm_vlad_aggregate_fused_fwd: workspace too small");
+    LPM_REQUIRE((((uintptr_t)at | (uintptr_t)xt | (uintptr_t)centres | (uintptr_t)nrm | (uintptr_t)out | (uintptr_t)workspace) & 15) == 0,
+                LPM_ERR_BADARG, "lpm_vlad_aggregate_fused_fwd: pointers must be 16-byte aligned");
+    const int S = (T + 15) / 16, KT = K / 32, P = D / 128;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    unsigned* arrive = (unsigned*)(part + (size_t)B * P * K);
+    unsigned* fail = arrive + B;
+    if (hipMemsetAsync(arrive, 0, 2 * (size_t)B * sizeof(unsigned), s) != hipSuccess) {      // counters and flags: zero at every launch
+        (void)hipGetLastError();
+        set_error("lpm_vlad_aggregate_fused_fwd: cannot clear the arrival counters");
+        return LPM_ERR_LAUNCH;
+    }
+    T3Fused fz{};
+    fz.out = out; fz.kmajor = (flags & LPM_VLAD_OUT_KMAJOR) ? 1 : 0; fz.store_u = (flags & LPM_VLAD_NRM_RAW) ? 1 : 0;
+    fz.colsq = colsq; fz.csq = csq; fz.gsq = gsq; fz.arrive = arrive; fz.fail = fail;
+    fz.debug_fallback = (flags & LPM_VLAD_DEBUG_FALLBACK) ? 1 : 0;
+    const size_t lds = (size_t)T3_NS * T3_STAGE + (4 * 128 + 128 + 16) * sizeof(float);
+    auto kern = vlad_aggregate_tiles3_kernel<true>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("lpm_vlad_aggregate_fused_fwd: cannot reserve %zu bytes of LDS", lds);
+        return LPM_ERR_LAUNCH;
+    }
+    dim3 grid(B * (K / 128) * (D / 128));
+    hipEvent_t e0, e1;
+    if (timing_request(LPM_TIMING_K2, &e0, &e1))
+        hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, s, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
+                              residual, nrm, asum, part, fz);
+    else
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT, residual, nrm, asum,
+                           part, fz);
+    // follow-up for clips whose workgroups were not resident together (fail[b] set; none in practice): the plain finalize pass
+    const size_t flds = (size_t)(K + 32 * 33 + 4) * sizeof(float);
+    if (fz.kmajor)
+        hipLaunchKernelGGL(vlad_finalize2_kernel<true>, dim3(D / 32, B), dim3(256), flds, s, nrm, part, P, D, K, out, colsq, csq, gsq, 1, fail);
+    else
+        hipLaunchKernelGGL(vlad_finalize2_kernel<false>, dim3(D / 32, B), dim3(256), flds, s, nrm, part, P, D, K, out, colsq, csq, gsq, 1,
+                           fail);
+    return check_launch("lpm_vlad_aggregate_fused_fwd");
 }
 
 extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out,
@@ -354,9 +567,9 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
     }
     if (flags & LPM_VLAD_OUT_KMAJOR)
         hipLaunchKernelGGL(vlad_finalize2_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq,
-                           csq, gsq, keep_u);
+                           csq, gsq, keep_u, (const unsigned*)nullptr);
     else
         hipLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out,
-                           colsq, csq, gsq, keep_u);
+                           colsq, csq, gsq, keep_u, (const unsigned*)nullptr);
     return check_launch("lpm_vlad_finalize2_fwd");
 }

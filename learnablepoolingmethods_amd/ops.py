@@ -25,6 +25,9 @@ VLAD_PRECISION = os.environ.get("LPM_VLAD_PRECISION", "bf16x3")
 # bf16x3 only: use the LDS-shared 128x128 workgroup form (vlad_tiles3.hip) where the shape allows (D, K multiples of
 # 128); otherwise / when off, the register-streaming form (vlad_tiles.hip).
 VLAD_TILES3 = os.environ.get("LPM_VLAD_TILES3", "1") != "0"
+# ... with the finalize pass fused into the aggregation kernel (lpm_vlad_aggregate_fused_fwd): "0" = two launches (A/B)
+VLAD_FUSED = os.environ.get("LPM_VLAD_FUSED", "1") != "0"
+VLAD_FUSED_DEBUG_FALLBACK = False     # tests: drive every clip through the fused kernel's time-out path + follow-up finalize
 
 # Matrix-core arithmetic of the soft-assignment GEMM K1: "bf16x3" (split-bf16 tiles on the bf16 pipe, default where
 # D %% 16 == 0 and K <= 512) or "f32" (exact fp32 MFMA).
@@ -311,7 +314,7 @@ def _nrm_raw_ok(lib, T, D, K):
     return (VLAD_PRECISION == "bf16x3" and VLAD_TILES3 and bool(lib._lpm_vlad_tiles3_supported(D, K)) and _bwd_tiles_ok(lib, T, D, K))
 
 
-def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor, nrm_raw=False):
+def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor, nrm_raw=False, save_u=True):
     """-> out, nrm, asum, colsq, csq, gsq, xt (the split-bf16 frame tiles of x, or None on the fp32 path).
     nrm_raw (only with _nrm_raw_ok): ``nrm`` comes back as the un-normalised sums U."""
     xt = None
@@ -327,6 +330,21 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
         at = torch.empty(lib._lpm_at_bytes(B, T, K) // 4, dtype=torch.int32, device=x.device)
         with _timed("assign_tiles", (B, T, K)):
             lib.check(lib._lpm_assign_tiles(ptr(assign), ptr(scale), ptr(shift), B, T, K, flags, ptr(at), st), "lpm_assign_tiles")
+        if VLAD_TILES3 and VLAD_FUSED and nrm_raw and lib._lpm_vlad_fused_supported(D, K):
+            # LDS-shared form with both normalisations fused in: the descriptor is written once, normalised; the un-normalised
+            # sums go to HBM only when a backward will read them (save_u: some input of the op requires a gradient)
+            out = _empty((B, K, D) if kmajor else (B, D * K), x)
+            gsq = _empty((B,), x)
+            wsb = lib._lpm_vlad_fused_workspace_bytes(B, D, K)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+            ffl = (flags & LPM_VLAD_RESIDUAL) | (LPM_VLAD_OUT_KMAJOR if kmajor else 0) | (LPM_VLAD_NRM_RAW if save_u else 0)
+            if VLAD_FUSED_DEBUG_FALLBACK:
+                ffl |= _capi.LPM_VLAD_DEBUG_FALLBACK
+            with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+                lib.check(lib._lpm_vlad_aggregate_fused_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, ffl, ptr(nrm), ptr(out), ptr(asum),
+                                                            ptr(colsq), ptr(csq), ptr(gsq), ptr(ws), wsb, st),
+                          "lpm_vlad_aggregate_fused_fwd")
+            return out, nrm, asum, colsq, csq, gsq, xt
         if VLAD_TILES3 and lib._lpm_vlad_tiles3_supported(D, K):
             # LDS-shared form: un-normalised sums + partial square norms; finalize2 applies both normalisations
             P = D // 128
@@ -496,7 +514,7 @@ class _NetVLAD(torch.autograd.Function):
         centres = W2.reshape(D, K).contiguous() if W2 is not None else None
         ctx.nrm_raw = _nrm_raw_ok(lib, T, D, K)
         out, nrm, asum, colsq, csq, gsq, xt = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor,
-                                                             nrm_raw=ctx.nrm_raw)
+                                                             nrm_raw=ctx.nrm_raw, save_u=any(ctx.needs_input_grad))
         ctx.dims = (B, T, D, K, flags, kmajor, use_bn, is_training, W2 is not None, tiles)
         ctx.dx_slot = getattr(x, "_lpm_dx_slot", None)
         ctx.no_dx = in_gamma is not None and tiles and _bwd_tiles_ok(lib, T, D, K)
@@ -606,7 +624,7 @@ class _VladAggregate(torch.autograd.Function):
         flags = LPM_VLAD_RESIDUAL
         ctx.nrm_raw = _nrm_raw_ok(lib, T, D, K)
         out, nrm, asum, colsq, csq, gsq, _ = _aggregate_fwd(lib, sims2, None, None, x, centres, B, T, D, K, flags, kmajor,
-                                                            nrm_raw=ctx.nrm_raw)
+                                                            nrm_raw=ctx.nrm_raw, save_u=any(ctx.needs_input_grad))
         ctx.dims = (B, T, D, K, flags, kmajor, sims.shape)
         ctx.save_for_backward(sims2, x, centres, nrm, asum, colsq, csq, gsq)
         return out

@@ -85,6 +85,70 @@ def test_netvlad_fwd_bwd(B, T, D, K, off, vlad_precision):
     assert torch.allclose(o.norm(dim=1), torch.full((B, K), K ** -0.5, device=dev), atol=1e-5)
 
 
+@pytest.mark.parametrize("B,T,D,K,kmajor", [(4, 300, 1024, 256, True), (4, 300, 1024, 256, False), (3, 50, 256, 512, True),
+                                            (5, 37, 128, 128, False), (2, 300, 1024, 512, False)])
+def test_fused_aggregation_matches_the_two_pass_form(B, T, D, K, kmajor):
+    """K2 with the finalize pass fused in (lpm_vlad_aggregate_fused_fwd, the default where the shape allows) against the two-launch
+    form and against the oracle: forward in both layouts, backward (K3 reads the un-normalised sums the fused kernel stores only when
+    a gradient is wanted), inference (nothing but the descriptor is written), a degenerate (all-zero) cluster column, and the
+    kernel's time-out path driven on purpose -- every clip finished by the follow-up pass instead."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    full, W, gamma, beta, W2, dout = _netvlad_inputs(B, T, D, K, seed=B * 77 + K)
+    ref, dx_ref, p, _ = _oracle_netvlad(full, W, gamma, beta, W2, T, dout)
+    refo = ref.reshape(B, D, K).transpose(1, 2) if kmajor else ref
+    dog = (dout.reshape(B, D, K).transpose(1, 2).contiguous() if kmajor else dout).to(dev)
+
+    def run(fused, fallback=False, grad=True):
+        old = ops.VLAD_FUSED, ops.VLAD_FUSED_DEBUG_FALLBACK
+        ops.VLAD_FUSED, ops.VLAD_FUSED_DEBUG_FALLBACK = fused, fallback
+        try:
+            xg = full.to(dev).requires_grad_(grad)
+            Wg, gg, bg, W2g = (t.to(dev).requires_grad_(grad) for t in (W, gamma, beta, W2))
+            out = ops.netvlad(xg, Wg, W2g, T, bn=(gg, bg, torch.zeros(K, device=dev), torch.ones(K, device=dev)), is_training=True,
+                              kmajor=kmajor)
+            if grad:
+                out.backward(dog)
+                return out.detach(), xg.grad, Wg.grad, W2g.grad
+            return out.detach(), None, None, None
+        finally:
+            ops.VLAD_FUSED, ops.VLAD_FUSED_DEBUG_FALLBACK = old
+    two = run(False)
+    fus = run(True)
+    assert fus[0].shape == refo.shape
+    assert_close(fus[0], refo, what="fused fwd vs oracle")
+    assert_close(fus[0], two[0], tol=1e-6, what="fused fwd vs two-pass")
+    assert_close(fus[1], dx_ref, what="fused dx")
+    assert_close(fus[2], p["s/cluster_weights"].grad, what="fused dW")
+    assert_close(fus[3], p["s/cluster_weights2"].grad, what="fused dW2")
+    for a, b, nm in zip(fus[1:], two[1:], ("dx", "dW", "dW2")):
+        assert_close(a, b, tol=1e-5, what=f"fused vs two-pass {nm}")
+    inf = run(True, grad=False)
+    assert torch.equal(inf[0], fus[0]), "inference (no U stored) and training forward agree bit for bit"
+    fb = run(True, fallback=True)
+    assert_close(fb[0], fus[0], tol=1e-6, what="time-out path fwd")
+    for a, b, nm in zip(fb[1:], fus[1:], ("dx", "dW", "dW2")):
+        assert_close(a, b, tol=1e-5, what=f"time-out path {nm}")
+    fbi = run(True, fallback=True, grad=False)
+    assert_close(fbi[0], fus[0], tol=1e-6, what="time-out path fwd (inference: U written by the fallback itself)")
+    # a degenerate cluster: similarities that are zero for one cluster give an all-zero column (l2_normalize's epsilon clamp)
+    g = torch.Generator().manual_seed(3)
+    sims = torch.rand(B, T, K, generator=g)
+    sims[:, :, 5] = 0.0
+    cen = torch.randn(D, K, generator=g) / D ** 0.5
+    refd = O.vlad_aggregate(sims.double(), full.double().reshape(B, T, D), cen.double())
+    refd = refd.reshape(B, D, K).transpose(1, 2) if kmajor else refd
+    for fused in (True, False):
+        old = ops.VLAD_FUSED
+        ops.VLAD_FUSED = fused
+        try:
+            got = ops.vlad_aggregate(sims.to(dev), full.to(dev), cen.to(dev), T, kmajor=kmajor)
+        finally:
+            ops.VLAD_FUSED = old
+        assert_close(got, refd, what=f"degenerate column (fused={fused})")
+        assert float(got.reshape(B, K, D)[:, 5].abs().max() if kmajor else got.reshape(B, D, K)[:, :, 5].abs().max()) == 0.0
+
+
 def test_netvlad_kmajor_layout_and_eval_mode(vlad_precision):
     from learnablepoolingmethods_amd import ops
     dev = cuda()
