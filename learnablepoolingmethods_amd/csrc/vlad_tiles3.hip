@@ -50,7 +50,7 @@ struct T3Fused {
     float* csq;
     float* gsq;                 // [B]
     unsigned* arrive;           // [B], zero at launch
-    unsigned* fail;             // [B], zero at launch
+    unsigned* fail;             // [B * K/128 * D/128] one flag per workgroup tile, zero at launch
 };
 
 template <bool FUSED>
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
         const long long t0 = wall_clock64();                   // 100 MHz
         int ok = 1;
         while (__hip_atomic_load(arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(16);
             if (wall_clock64() - t0 > 200000) { ok = 0; break; }     // 2 ms: dispatch did not keep the clip together
         }
         if (fz.debug_fallback && ds == 0) ok = 0;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (tid == 0) __hip_atomic_store((gu32*)(fz.fail + b), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store((gu32*)(fz.fail + lid), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     // ---- every partial norm of the clip -> 1/n_k for all K clusters and the clip's 1/sqrt(g)   (fixed summation order)
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int kl = c * 32 + 8 * q + 4 * half;
-                const float4 iv = *reinterpret_cast<const float4*>(invn + kw * 64 + kl);
+                const float4 iv = *reinterpret_cast<const float4*>(invn + k0 + kw * 64 + kl);
                 okb[(int64_t)(kl + 0) * D] = acc[c][4 * q + 0] * (iv.x * ig);
                 okb[(int64_t)(kl + 1) * D] = acc[c][4 * q + 1] * (iv.y * ig);
                 okb[(int64_t)(kl + 2) * D] = acc[c][4 * q + 2] * (iv.z * ig);
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 iv = *reinterpret_cast<const float4*>(invn + kw * 64 + c * 32 + 8 * q + 4 * half);
+                const float4 iv = *reinterpret_cast<const float4*>(invn + k0 + kw * 64 + c * 32 + 8 * q + 4 * half);
                 *reinterpret_cast<float4*>(wl + l31 * T3_WS + 8 * q + 4 * half) =
                     make_float4(acc[c][4 * q] * (iv.x * ig), acc[c][4 * q + 1] * (iv.y * ig), acc[c][4 * q + 2] * (iv.z * ig),
                                 acc[c][4 * q + 3] * (iv.w * ig));
@@ -315,6 +315,45 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
     }
 }
 
+// Follow-up of the fused kernel: one workgroup per (clip, 128 clusters, 128 columns) tile; tiles whose workgroup completed (flag
+// zero: all of them in practice) return at once, a tile whose workgroup gave up waiting is finished here from the U it left in nrm.
+__global__ __launch_bounds__(256) void vlad_fused_fixup_kernel(const float* __restrict__ nrm, const float* __restrict__ colsq_part,
+                                                               const unsigned* __restrict__ fail, int D, int K, T3Fused fz) {
+    const int lid = blockIdx.x;
+    if (fail[lid] == 0) return;
+    const int P = D >> 7, KB = K >> 7;
+    const int b = lid / (KB * P), rem = lid % (KB * P), kb = rem / P, ds = rem % P;
+    __shared__ float invn[512];
+    __shared__ float wg[4];
+    const int tid = threadIdx.x;
+    float g = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        float n = 0.f;
+        for (int p = 0; p < P; ++p) n += colsq_part[((int64_t)b * P + p) * K + k];
+        const float iv = rsqrtf(fmaxf(n, kL2Eps));
+        const float c = n * iv * iv;
+        invn[k] = iv;
+        g += c;
+        if (kb == 0 && ds == 0) {
+            fz.colsq[(int64_t)b * K + k] = n;
+            fz.csq[(int64_t)b * K + k] = c;
+        }
+    }
+    g = wave_sum(g);
+    if ((tid & 63) == 0) wg[tid >> 6] = g;
+    __syncthreads();
+    const float tot = (wg[0] + wg[1]) + (wg[2] + wg[3]);
+    const float ig = rsqrtf(fmaxf(tot, kL2Eps));
+    if (kb == 0 && ds == 0 && tid == 0) fz.gsq[b] = tot;
+    for (int i = tid; i < 128 * 128; i += 256) {
+        const int dl = i >> 7, kl = i & 127;
+        const int d = ds * 128 + dl, k = kb * 128 + kl;
+        const float v = nrm[((int64_t)b * D + d) * K + k] * (invn[k] * ig);
+        if (fz.kmajor) fz.out[((int64_t)b * K + k) * D + d] = v;
+        else fz.out[((int64_t)b * D + d) * K + k] = v;
+    }
+}
+
 // finalize for the un-normalised form: per clip n_k = sum_p colsq_part, inv_n = rsqrt(max(n,eps)), c_k = n inv_n^2,
 // g = sum_k c_k;  nrm <- U * inv_n (in place, d-major: what the backward reads);  out = nrm * rsqrt(max(g,eps)) laid out
 // d-major [B, D*K] or k-major [B,K,D].   grid (D/32, B).
@@ -322,10 +361,8 @@ template <bool KMAJOR>
 __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
                                                              int P, int D, int K, float* __restrict__ out,
                                                              float* __restrict__ colsq, float* __restrict__ csq,
-                                                             float* __restrict__ gsq, int keep_u, const unsigned* __restrict__ only_if) {
+                                                             float* __restrict__ gsq, int keep_u) {
     // keep_u (LPM_VLAD_NRM_RAW): nrm is left as the un-normalised sums U (the tile backward rebuilds N = U * inv_n itself)
-    // only_if (the fused kernel's follow-up): clips whose flag is zero are already complete and are not touched
-    if (only_if && only_if[blockIdx.y] == 0) return;
     extern __shared__ float fs[];            // [K] inv_n, then [32][33] transpose tile, [4] partial sums
     float* invn = fs;
     float* tile = fs + K;
@@ -484,7 +521,7 @@ extern "C" int lpm_vlad_fused_supported(int D, int K) {
     return (lpm_vlad_tiles3_supported(D, K) && K <= 512 && (int64_t)(D / 128) * K * 4 <= lpm::T3_NS * lpm::T3_STAGE) ? 1 : 0;
 }
 extern "C" size_t lpm_vlad_fused_workspace_bytes(int B, int D, int K) {
-    return ((size_t)B * (D / 128) * K + 2 * (size_t)B) * sizeof(float);
+    return ((size_t)B * (D / 128) * K + (size_t)B + (size_t)B * (K / 128) * (D / 128)) * sizeof(float);
 }
 
 extern "C" int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
@@ -506,7 +543,8 @@ extern "C" int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, cons
     float* part = (float*)workspace;
     unsigned* arrive = (unsigned*)(part + (size_t)B * P * K);
     unsigned* fail = arrive + B;
-    if (hipMemsetAsync(arrive, 0, 2 * (size_t)B * sizeof(unsigned), s) != hipSuccess) {      // counters and flags: zero at every launch
+    const size_t ntile = (size_t)B * (K / 128) * (D / 128);
+    if (hipMemsetAsync(arrive, 0, ((size_t)B + ntile) * sizeof(unsigned), s) != hipSuccess) {      // counters and flags: zero at every launch
         (void)hipGetLastError();
         set_error("lpm_vlad_aggregate_fused_fwd: cannot clear the arrival counters");
         return LPM_ERR_LAUNCH;
@@ -530,13 +568,8 @@ extern "C" int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, cons
     else
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT, residual, nrm, asum,
                            part, fz);
-    // follow-up for clips whose workgroups were not resident together (fail[b] set; none in practice): the plain finalize pass
-    const size_t flds = (size_t)(K + 32 * 33 + 4) * sizeof(float);
-    if (fz.kmajor)
-        hipLaunchKernelGGL(vlad_finalize2_kernel<true>, dim3(D / 32, B), dim3(256), flds, s, nrm, part, P, D, K, out, colsq, csq, gsq, 1, fail);
-    else
-        hipLaunchKernelGGL(vlad_finalize2_kernel<false>, dim3(D / 32, B), dim3(256), flds, s, nrm, part, P, D, K, out, colsq, csq, gsq, 1,
-                           fail);
+    // follow-up for tiles whose workgroup gave up waiting for its clip (fail flag set; none in practice)
+    hipLaunchKernelGGL(vlad_fused_fixup_kernel, grid, dim3(256), 0, s, nrm, part, fail, D, K, fz);
     return check_launch("lpm_vlad_aggregate_fused_fwd");
 }
 
@@ -567,9 +600,9 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
     }
     if (flags & LPM_VLAD_OUT_KMAJOR)
         hipLaunchKernelGGL(vlad_finalize2_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq,
-                           csq, gsq, keep_u, (const unsigned*)nullptr);
+                           csq, gsq, keep_u);
     else
         hipLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out,
-                           colsq, csq, gsq, keep_u, (const unsigned*)nullptr);
+                           colsq, csq, gsq, keep_u);
     return check_launch("lpm_vlad_finalize2_fwd");
 }

@@ -25,8 +25,13 @@ VLAD_PRECISION = os.environ.get("LPM_VLAD_PRECISION", "bf16x3")
 # bf16x3 only: use the LDS-shared 128x128 workgroup form (vlad_tiles3.hip) where the shape allows (D, K multiples of
 # 128); otherwise / when off, the register-streaming form (vlad_tiles.hip).
 VLAD_TILES3 = os.environ.get("LPM_VLAD_TILES3", "1") != "0"
-# ... with the finalize pass fused into the aggregation kernel (lpm_vlad_aggregate_fused_fwd): "0" = two launches (A/B)
-VLAD_FUSED = os.environ.get("LPM_VLAD_FUSED", "1") != "0"
+# ... with the finalize pass fused into the aggregation kernel (lpm_vlad_aggregate_fused_fwd).  Off by default: the descriptor is
+# written once and the un-normalised sums never make a round trip (chain traffic 1.15x algorithmic instead of 2.2x), but the
+# per-clip wait inside the kernel costs what the second launch cost -- measured at cfg-2 (tools/time_a5.py, whole a5 chain):
+# 107 us fused vs 107 us two-pass in inference, 134 vs 108 us when the backward's copy of U is stored as well; same picture at
+# B = 128, K = 512 (341 / 396 vs 340 us).  All workgroups reach their epilogue together (1.7 rounds of 768 resident workgroups),
+# so the wait overlaps nothing.
+VLAD_FUSED = os.environ.get("LPM_VLAD_FUSED", "0") == "1"
 VLAD_FUSED_DEBUG_FALLBACK = False     # tests: drive every clip through the fused kernel's time-out path + follow-up finalize
 
 # Matrix-core arithmetic of the soft-assignment GEMM K1: "bf16x3" (split-bf16 tiles on the bf16 pipe, default where
