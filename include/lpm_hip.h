@@ -46,6 +46,9 @@ enum {
     LPM_VLAD_NRM_RAW = 8,      /* lpm_vlad_finalize2_fwd: leave `nrm` as the un-normalised sums U (no in-place write of the
                                   intra-normalised copy); lpm_vlad_aggregate_bwd_tiles: `nrm` holds U and the normalised
                                   descriptor is rebuilt as U * rsqrt(max(colsq, eps)) where it is read                     */
+    LPM_VLAD_OUT_BF16 = 16,    /* lpm_vlad_finalize2_fwd: `out` is bf16 storage (d-major layout only)                   */
+    LPM_VLAD_TILES_BF16 = 32,  /* lpm_vlad_aggregate_bwd_tiles: bf16 storage -- xr and the dU tiles are plain bf16 tiles, `assign`
+                                  holds bf16 logits                                                                         */
     LPM_VLAD_DEBUG_FALLBACK = 256 /* lpm_vlad_aggregate_fused_fwd, tests only: one workgroup of every clip behaves as if its wait
                                   for the clip had timed out, so the follow-up finalize pass runs for every clip             */
 };
@@ -210,6 +213,37 @@ size_t lpm_vlad_fused_workspace_bytes(int B, int D, int K);
 int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
                                  float* nrm, float* out, float* asum, float* colsq, float* csq, float* gsq, void* workspace,
                                  size_t workspace_bytes, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * bf16 storage (BASELINE configs[4]: "Gated NetVLAD K=512 + MoE-4, 300x1152 bf16"): the tensors SURVEY 8(d) counts in the
+ * algorithmic bytes of K1 / K2 -- frames, logits / assignment, descriptor -- live in HBM as bf16; every product is ONE bf16 MFMA
+ * with fp32 accumulation; batch statistics, norms and all gradients stay fp32.  Operand tiles are plain bf16 tiles: the layouts of
+ * the split form with ONE 1 KB plane per (tile, step), and every clip padded with zero frames to whole 64-frame blocks
+ * (lpm_frame_steps_bf16(T) = 4 ceil(T / 64) frame steps, 2 ceil(T / 64) row tiles).  The reference computes in fp32 throughout
+ * (frame_level_models.py:2765-2824); bf16 is the build's choice for this configuration and carries a bf16 tolerance.
+ *   lpm_frame_apply_tiles_bf16 : a2 + a3 -> frame tiles xt_* (K2's operand) AND row tiles xr_* (K1's operand) of both streams in one
+ *                                pass; y (fp32 [B*S, F]) optional (NULL: not written).  Each buffer: lpm_frame_tiles_bf16_bytes.
+ *   lpm_split_weight_tiles_bf16 / lpm_split_frames_bf16 : fp32 matrix -> plain bf16 weight / frame tiles (half the split form's size)
+ *   lpm_assign_gemm_tiles_fwd_bf16 : K1; logits stored as bf16 [B*T, K], BN partial statistics from the fp32 accumulators
+ *   lpm_assign_tiles_bf16          : bf16 logits -> [affine -> softmax] -> plain bf16 assignment tiles
+ *   lpm_vlad_aggregate_tiles3_fwd_bf16 : K2 on those tiles (fp32 sums out, as lpm_vlad_aggregate_tiles3_fwd);
+ *                                lpm_vlad_finalize2_fwd with LPM_VLAD_OUT_BF16 then writes the bf16 descriptor [B, D*K]
+ *   lpm_assign_gemm_tiles_bwd_dw_bf16, lpm_vlad_aggregate_bwd_tiles with LPM_VLAD_TILES_BF16 : the backward on plain bf16 tiles */
+size_t lpm_frame_tiles_bf16_bytes(int B, int S, int D);
+int lpm_frame_steps_bf16(int T);
+int lpm_frame_apply_tiles_bf16(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
+                               const float* scale, const float* shift, float* y, void* xt_video, void* xr_video, int Dv,
+                               void* xt_audio, void* xr_audio, int Da, lpm_stream_t stream);
+int lpm_split_weight_tiles_bf16(const float* w, int R, int N, int transposed, void* wt, lpm_stream_t stream);
+int lpm_split_frames_bf16(const float* x, int64_t ldx, int B, int T, int D, void* xt, lpm_stream_t stream);
+int lpm_assign_gemm_tiles_fwd_bf16(const void* xr, const void* wt, int B, int T, int D, int K, void* logits_bf16, float* partial,
+                                   lpm_stream_t stream);
+int lpm_assign_gemm_tiles_bwd_dw_bf16(const void* xt, const void* dlt, int B, int T, int D, int K, float* dW, void* workspace,
+                                      size_t workspace_bytes, lpm_stream_t stream);
+int lpm_assign_tiles_bf16(const void* assign_bf16, const float* scale, const float* shift, int B, int T, int K, int flags, void* at,
+                          lpm_stream_t stream);
+int lpm_vlad_aggregate_tiles3_fwd_bf16(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                       float* nrm, float* asum, float* colsq_part, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3: backward of K2 (TF autodiff of the same lines; formulas SURVEY.md App. F.1-F.3).

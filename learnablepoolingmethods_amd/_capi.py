@@ -19,6 +19,8 @@ LPM_VLAD_SOFTMAX = 1
 LPM_VLAD_RESIDUAL = 2
 LPM_VLAD_OUT_KMAJOR = 4
 LPM_VLAD_NRM_RAW = 8
+LPM_VLAD_OUT_BF16 = 16
+LPM_VLAD_TILES_BF16 = 32
 LPM_VLAD_DEBUG_FALLBACK = 256
 
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header
@@ -64,6 +66,15 @@ SIGNATURES = {
     "lpm_vlad_tiles3_supported": (_i, [_i, _i]),
     "lpm_vlad_aggregate_tiles3_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "lpm_vlad_finalize2_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "lpm_frame_tiles_bf16_bytes": (_s, [_i, _i, _i]),
+    "lpm_frame_steps_bf16": (_i, [_i]),
+    "lpm_frame_apply_tiles_bf16": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _f, _i, _f]),
+    "lpm_split_weight_tiles_bf16": (_i, [_f, _i, _i, _i, _f, _f]),
+    "lpm_split_frames_bf16": (_i, [_f, _l, _i, _i, _i, _f, _f]),
+    "lpm_assign_gemm_tiles_fwd_bf16": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f]),
+    "lpm_assign_gemm_tiles_bwd_dw_bf16": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _s, _f]),
+    "lpm_assign_tiles_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),
+    "lpm_vlad_aggregate_tiles3_fwd_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "lpm_vlad_fused_supported": (_i, [_i, _i]),
     "lpm_vlad_fused_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_vlad_aggregate_fused_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _s, _f]),

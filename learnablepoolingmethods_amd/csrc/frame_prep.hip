@@ -276,6 +276,76 @@ __global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __r
     }
 }
 
+// bf16 storage (BASELINE cfg-5): the sampled, batch-normalised frames leave ONLY as plain bf16 operand tiles -- frame tiles
+// [b][step][column tile][lane] (K2's operand, reduction over frames) and row tiles [b][row tile][column step][lane] (K1's
+// operand, reduction over features), both padded with zero frames to whole 64-frame blocks (NSP = 4 ceil(S / 64) steps, MT = NSP / 2
+// row tiles) -- and, when y is given, as the fp32 matrix.  Work item = (clip, step, frame half, 8 consecutive columns).
+__global__ __launch_bounds__(256) void frame_apply_tiles_bf16_kernel(const float* __restrict__ raw, const int32_t* __restrict__ num_frames,
+                                                                     int B, int max_frames, int F, int S, float step,
+                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                     float* __restrict__ y, uint4* __restrict__ xtv, uint4* __restrict__ xrv,
+                                                                     int Dv, uint4* __restrict__ xta, uint4* __restrict__ xra, int Da) {
+    const int F8 = F / 8, NSP = 4 * ((S + 63) / 64), MT = NSP / 2;
+    const int64_t total = (int64_t)B * NSP * 2 * F8;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(w % F8);
+        const int64_t r = w / F8;
+        const int kh = (int)(r & 1), st = (int)((r >> 1) % NSP), b = (int)((r >> 1) / NSP);
+        const int c = 8 * c8;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sc[q] = scale ? scale[c + q] : 1.f;
+            sh[q] = scale ? shift[c + q] : 0.f;
+        }
+        const int nf = num_frames[b];
+        float v[8][8];                    // [frame e][column q]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 16 * st + 8 * kh + e;
+            float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+            if (j < S) {
+                int idx = sample_index(j, step, nf);
+                idx = max(0, min(idx, max_frames - 1));
+                const float* src = raw + ((int64_t)b * max_frames + idx) * F + c;
+                f0 = *reinterpret_cast<const float4*>(src);
+                f1 = *reinterpret_cast<const float4*>(src + 4);
+                f0.x = fmaf(f0.x, sc[0], sh[0]); f0.y = fmaf(f0.y, sc[1], sh[1]); f0.z = fmaf(f0.z, sc[2], sh[2]); f0.w = fmaf(f0.w, sc[3], sh[3]);
+                f1.x = fmaf(f1.x, sc[4], sh[4]); f1.y = fmaf(f1.y, sc[5], sh[5]); f1.z = fmaf(f1.z, sc[6], sh[6]); f1.w = fmaf(f1.w, sc[7], sh[7]);
+                if (y) {
+                    float* dst = y + ((int64_t)b * S + j) * F + c;
+                    *reinterpret_cast<float4*>(dst) = f0;
+                    *reinterpret_cast<float4*>(dst + 4) = f1;
+                }
+            }
+            v[e][0] = f0.x; v[e][1] = f0.y; v[e][2] = f0.z; v[e][3] = f0.w; v[e][4] = f1.x; v[e][5] = f1.y; v[e][6] = f1.z; v[e][7] = f1.w;
+        }
+        const bool video = c < Dv;
+        uint4* xt = video ? xtv : xta;
+        uint4* xr = video ? xrv : xra;
+        if (xt == nullptr) continue;
+        const int Dn = video ? Dv : Da, cb = video ? c : c - Dv;
+        unsigned h[8][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[e][q] = fp_bf16_rne(v[e][q]);
+        const int DT = Dn / 32, CS = Dn / 16;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {       // frame tiles: lane = (frame half, column), 8 frames per lane
+            const int d = cb + q;
+            xt[(((int64_t)b * NSP + st) * DT + (d >> 5)) * 64 + kh * 32 + (d & 31)] =
+                make_uint4(h[0][q] | (h[1][q] << 16), h[2][q] | (h[3][q] << 16), h[4][q] | (h[5][q] << 16), h[6][q] | (h[7][q] << 16));
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {       // row tiles: lane = (column half, frame), 8 columns per lane
+            const int j = 16 * st + 8 * kh + e;
+            xr[(((int64_t)b * MT + (j >> 5)) * CS + (cb >> 4)) * 64 + ((cb >> 3) & 1) * 32 + (j & 31)] =
+                make_uint4(h[e][0] | (h[e][1] << 16), h[e][2] | (h[e][3] << 16), h[e][4] | (h[e][5] << 16), h[e][6] | (h[e][7] << 16));
+        }
+    }
+}
+
 }  // namespace lpm
 
 static inline int fp_nblk(int B, int S) { return (B * S + lpm::FP_ROWS - 1) / lpm::FP_ROWS; }
@@ -328,6 +398,27 @@ extern "C" int lpm_frame_apply_tiles(const float* raw, const int32_t* num_frames
     hipLaunchKernelGGL(frame_apply_tiles_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, raw,
                        num_frames, B, max_frames, F, S, step, scale, shift, y, (uint4*)xt_video, Dv, (uint4*)xt_audio, Da);
     return check_launch("lpm_frame_apply_tiles");
+}
+
+// bf16 storage: see frame_apply_tiles_bf16_kernel.  y may be NULL (then the fp32 frames are not written at all); the tile buffers
+// hold lpm_frame_tiles_bf16_bytes(B, S, D) bytes each (frame tiles and row tiles have the same size).
+extern "C" size_t lpm_frame_tiles_bf16_bytes(int B, int S, int D) { return (size_t)B * 4 * ((S + 63) / 64) * (D / 32) * 1024; }
+extern "C" int lpm_frame_apply_tiles_bf16(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
+                                          const float* scale, const float* shift, float* y, void* xt_video, void* xr_video, int Dv,
+                                          void* xt_audio, void* xr_audio, int Da, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_FRAME_CHECK("lpm_frame_apply_tiles_bf16");
+    LPM_REQUIRE(xt_video && xr_video && ((scale == nullptr) == (shift == nullptr)) && ((xt_audio == nullptr) == (xr_audio == nullptr)),
+                LPM_ERR_BADARG, "lpm_frame_apply_tiles_bf16: bad pointers");
+    LPM_REQUIRE(Dv > 0 && Da >= 0 && Dv + Da == F && Dv % 32 == 0 && Da % 32 == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_frame_apply_tiles_bf16: need Dv + Da == F, both multiples of 32 (F=%d Dv=%d Da=%d)", F, Dv, Da);
+    const float step = 1.0f / (float)S;
+    const int64_t total = (int64_t)B * 4 * ((S + 63) / 64) * 2 * (F / 8);
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(frame_apply_tiles_bf16_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       raw, num_frames, B, max_frames, F, S, step, scale, shift, y, (uint4*)xt_video, (uint4*)xr_video, Dv,
+                       (uint4*)xt_audio, (uint4*)xr_audio, Da);
+    return check_launch("lpm_frame_apply_tiles_bf16");
 }
 
 extern "C" int lpm_frame_bn_bwd(const float* dy, int64_t lddy, const float* raw, const int32_t* num_frames, int B,

@@ -42,6 +42,9 @@ __device__ __forceinline__ void tg_split8(const float* v, uint4& hi, uint4& lo) 
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// bf16-storage form (PL = 1, BASELINE cfg-5): the operands are plain bf16 tiles -- ONE 1 KB plane per (tile, step), strides in
+// units of 64 instead of 128 -- and a product is one MFMA.  A ring stage then carries TWO consecutive reduction steps where the
+// split form carries the two planes of one, so the piece bookkeeping, the ring and the counted waits are the same code.
 constexpr int TG_NS = 3;     // LDS ring stages
 enum { TG_EPI_STORE = 0, TG_EPI_SOFTMAX_BWD = 1 };
 
@@ -61,12 +64,14 @@ struct TileGemmArgs {
     int steps_per_split;       // blockIdx.z = split: reduction steps [z * steps_per_split, ...) clipped to total_steps
     int total_steps;
     float* out;                // STORE: out[batch * out_batch + split * out_split + row * ldo + col]
+    int out_bf16;              // STORE: out points at bf16 storage (same index arithmetic, in elements); no accumulate, one split
     int64_t ldo, out_batch, out_split;
     int rows_valid, cols_valid;
     int accumulate;            // STORE: out += result
     float* stats;              // STORE, optional: [gridDim.x][2][cols_valid] per-workgroup column (sum, sum of squares)
     // SOFTMAX_BWD (needs gridDim.y == gridDim.z == 1): out = dlogit~ with a = softmax(logits*scale + shift) recomputed
     const float* logits;       // [batch * rows_valid + row][cols_valid]
+    int logits_bf16;           // ... stored as bf16
     const float* scale;        // [cols] or null
     const float* shift;        // [cols] or null
     const float* ctil;         // [batch][cols]
@@ -75,8 +80,9 @@ struct TileGemmArgs {
 
 // Launchers (defined in tile_gemm.hip, the only translation unit that instantiates the kernel).  nbatch * rb_per_batch
 // workgroup rows, ceil(cols / (128 NTW)) column blocks, `splits` reduction splits.
-int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw = 0);   // ntw 0 = by column count
-int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what);
+// planes: 2 = split-bf16 operands (hi, lo), 1 = plain bf16 operands
+int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw = 0, int planes = 2);   // ntw 0 = by column count
+int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what, int planes = 2);
 int tile_gemm_ntw(int cols);
 
 }  // namespace lpm

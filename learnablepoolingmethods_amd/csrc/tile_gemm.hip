@@ -22,9 +22,12 @@ static size_t tg_lds_bytes(int ntw, int epi) {
 // batches are ONE flat sequence (a_batch == a_tiles * a_tile, b_batch == 0, no second operand pair, one split) and
 // blockIdx.x counts groups of four consecutive tiles, which may straddle two batches.  24 KB staged per 128 x 256 x 16
 // products (131 MFMA-flop per byte against 77 for the 64-row form), NS-stage ring with NS - 2 younger steps in flight.
-template <int NTW, int EPI, int MW, int NS>
+template <int NTW, int EPI, int MW, int NS, int PL>
 __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmArgs g) {
     static_assert(MW == 1 || EPI == TG_EPI_STORE, "the 128-row form has the store epilogue only");
+    static_assert(PL == 1 || PL == 2, "planes");
+    // PL == 1: plain bf16 tiles, a ring stage = two reduction steps ("sub" below is the step within the stage where the split
+    // form has the plane); no second operand pair.
     constexpr int NTB = 4 * NTW;                   // column tiles per workgroup
     constexpr int NWV = 4 * MW;                    // waves per workgroup
     constexpr int NRP = 4 * MW;                    // row-tile pieces per stage (2 MW tiles x 2 planes)
@@ -41,41 +44,48 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
     const int batch = MW == 1 ? lid / g.rb_per_batch : 0, rb = MW == 1 ? lid % g.rb_per_batch : 0;
     const int cb = blockIdx.y, split = blockIdx.z;
     const int step0 = split * g.steps_per_split;
-    const int nstep1 = min(g.steps_per_split, g.total_steps - step0);
-    const int nstep = nstep1 + g.steps2;
+    const int nred = min(g.steps_per_split, g.total_steps - step0);     // reduction steps of this split
+    const int nstep1 = PL == 2 ? nred : (nred + 1) / 2;                   // ring stages
+    const int nstep = nstep1 + (PL == 2 ? g.steps2 : 0);
 
     // this wave's PW pieces of a stage: piece p < 4: row tile p>>1, plane p&1;  else column tile (p-4)>>1, plane (p-4)&1
     const uint4* src[PW];
     const uint4* src2[PW];
     int64_t sstep[PW], sstep2[PW];
+    int sub[PW];                                   // PL == 1: which of the stage's two steps this piece is
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
         const int p = wave + NWV * j;
+        // split form: the piece's plane sits (p & 1) * 64 units into the (tile, step) pair; plain form: same tile, step + (p & 1)
+        const int pl = PL == 2 ? (p & 1) * 64 : 0;
+        sub[j] = p & 1;
         if (p < NRP) {
             if (MW == 1) {
                 const int t = min(rb * 2 + (p >> 1), g.a_tiles - 1);
-                src[j] = g.a + batch * g.a_batch + t * g.a_tile + step0 * g.a_step + (p & 1) * 64 + lane;
-                src2[j] = g.a2 + batch * g.a2_batch + t * g.a2_tile + (p & 1) * 64 + lane;
+                src[j] = g.a + batch * g.a_batch + t * g.a_tile + step0 * g.a_step + pl + lane;
+                src2[j] = PL == 2 ? g.a2 + batch * g.a2_batch + t * g.a2_tile + pl + lane : nullptr;
             } else {
-                src[j] = g.a + (int64_t)(lid * 2 * MW + (p >> 1)) * g.a_tile + step0 * g.a_step + (p & 1) * 64 + lane;
+                src[j] = g.a + (int64_t)(lid * 2 * MW + (p >> 1)) * g.a_tile + step0 * g.a_step + pl + lane;
                 src2[j] = nullptr;
             }
             sstep[j] = g.a_step;
             sstep2[j] = g.a2_step;
         } else {
             const int ct = cb * NTB + ((p - NRP) >> 1);
-            src[j] = g.b + batch * g.b_batch + min(ct, g.b_tiles - 1) * g.b_tile + step0 * g.b_step + ((p - NRP) & 1) * 64 + lane;
+            src[j] = g.b + batch * g.b_batch + min(ct, g.b_tiles - 1) * g.b_tile + step0 * g.b_step + pl + lane;
             sstep[j] = g.b_step;
-            src2[j] = g.b2 + batch * g.b2_batch + min(ct, g.b2_tiles - 1) * g.b2_tile + ((p - NRP) & 1) * 64 + lane;
+            src2[j] = PL == 2 ? g.b2 + batch * g.b2_batch + min(ct, g.b2_tiles - 1) * g.b2_tile + pl + lane : nullptr;
             sstep2[j] = g.b2_step;
         }
     }
     auto issue = [&](int s) {
         unsigned char* st = smem + (s % NS) * STAGE;
-        const bool second = MW == 1 && s >= nstep1;       // wave-uniform
+        const bool second = PL == 2 && MW == 1 && s >= nstep1;       // wave-uniform
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            const uint4* q = second ? src2[j] + (s - nstep1) * sstep2[j] : src[j] + s * sstep[j];
+            // plain form: stage s = steps 2 s and 2 s + 1; past an odd end the piece re-reads the last step (its MFMA is skipped)
+            const uint4* q = PL == 1 ? src[j] + (int64_t)min(2 * s + sub[j], nred - 1) * sstep[j]
+                                     : (second ? src2[j] + (s - nstep1) * sstep2[j] : src[j] + s * sstep[j]);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
                                              (__attribute__((address_space(3))) void*)(st + (wave + NWV * j) * 1024), 16, 0, 0);
         }
@@ -112,9 +122,14 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
                 const tg_u32x4 bh = f[(4 + nt * 2 + 0) * 64], bl = f[(4 + nt * 2 + 1) * 64];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    acc[m][n] = tg_mfma(ah[m], bh, acc[m][n]);
-                    acc[m][n] = tg_mfma(ah[m], bl, acc[m][n]);
-                    acc[m][n] = tg_mfma(al[m], bh, acc[m][n]);
+                    if (PL == 2) {
+                        acc[m][n] = tg_mfma(ah[m], bh, acc[m][n]);
+                        acc[m][n] = tg_mfma(ah[m], bl, acc[m][n]);
+                        acc[m][n] = tg_mfma(al[m], bh, acc[m][n]);
+                    } else {          // (ah, bh) = first step of the stage, (al, bl) = second
+                        acc[m][n] = tg_mfma(ah[m], bh, acc[m][n]);
+                        if (2 * s + 1 < nred) acc[m][n] = tg_mfma(al[m], bl, acc[m][n]);
+                    }
                 }
             }
         }
@@ -158,18 +173,20 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
 #pragma unroll
                 for (int n = 0; n < NTW; ++n)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[m][n] = tg_mfma(t == 2 ? cur.al[m] : cur.ah[m], t == 1 ? cur.bl[n] : cur.bh[n], acc[m][n]);
+                    for (int m = 0; m < 2; ++m) {
+                        if (PL == 2) acc[m][n] = tg_mfma(t == 2 ? cur.al[m] : cur.ah[m], t == 1 ? cur.bl[n] : cur.bh[n], acc[m][n]);
+                        else acc[m][n] = tg_mfma(t ? cur.al[m] : cur.ah[m], t ? cur.bl[n] : cur.bh[n], acc[m][n]);
+                    }
             };
             mfma_term(0);
             __builtin_amdgcn_sched_barrier(0);
             if (s + NS - 1 < nstep) issue(s + NS - 1);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_term(1);
+            if (PL == 2 || 2 * s + 1 < nred) mfma_term(1);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < nstep) read_frags(s + 1, nxt);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_term(2);
+            if (PL == 2) mfma_term(2);
         };
         Frag fa, fb;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");      // step 0 has landed (this wave's pieces)
@@ -230,7 +247,12 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
             for (int i = tl; i < 32 * C4; i += 256) {
                 const int row = i / C4, c4 = (i % C4) * 4;
                 const int grow = row0 + row, gcol = cb * NTB * 32 + c4;
-                if (grow < g.rows_valid && gcol < N) {
+                if (grow < g.rows_valid && gcol < N && g.out_bf16) {
+                    const float4 v = *reinterpret_cast<const float4*>(es + row * ESTR + c4);
+                    unsigned short* pb = reinterpret_cast<unsigned short*>(g.out) + batch * g.out_batch + (int64_t)tb * g.out_batch +
+                                         (int64_t)grow * g.ldo + gcol;
+                    *reinterpret_cast<uint2*>(pb) = make_uint2(tg_rne(v.x) | (tg_rne(v.y) << 16), tg_rne(v.z) | (tg_rne(v.w) << 16));
+                } else if (grow < g.rows_valid && gcol < N) {
                     float4 v = *reinterpret_cast<const float4*>(es + row * ESTR + c4);
                     float4* p = reinterpret_cast<float4*>(obt + (int64_t)grow * g.ldo + gcol);
                     if (g.accumulate) {
@@ -266,12 +288,14 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
             float* out = g.out + grow * N;
             if (g.softmax) {
                 const float* lr = g.logits + grow * N;
+                const unsigned short* lrb = reinterpret_cast<const unsigned short*>(g.logits) + grow * N;
                 float a[KPL], gg[KPL];
                 float mx = -INFINITY;
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) {
                     const int c = lane + 64 * j;
-                    a[j] = (c < N) ? fmaf(lr[c], g.scale ? g.scale[c] : 1.f, g.shift ? g.shift[c] : 0.f) : -INFINITY;
+                    const float lv = (c < N) ? (g.logits_bf16 ? __uint_as_float((unsigned)lrb[c] << 16) : lr[c]) : 0.f;
+                    a[j] = (c < N) ? fmaf(lv, g.scale ? g.scale[c] : 1.f, g.shift ? g.shift[c] : 0.f) : -INFINITY;
                     mx = fmaxf(mx, a[j]);
                 }
                 mx = wave_max(mx);
@@ -322,23 +346,31 @@ static int tg_wide_enabled() {
 
 // The 128-row form applies when the row tiles of all batches form one flat sequence that divides into groups of four, the
 // B operand is shared, there is one reduction segment and one 256-column block: K1's forward at K = 256.
-static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw) {
+static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw, int planes) {
     return tg_wide_enabled() && ntw == 2 && g.cols_valid <= 256 && splits == 1 && g.steps2 == 0 && g.a2 == nullptr && g.b_batch == 0 &&
            g.a_batch == (int64_t)g.a_tiles * g.a_tile && g.rb_per_batch * 2 == g.a_tiles && ((int64_t)nbatch * g.a_tiles) % 4 == 0 &&
-           g.steps_per_split >= 16;     // (>= the ring depth)
+           g.steps_per_split >= (planes == 1 ? 32 : 16);     // (ring stages >= the ring depth)
 }
 
-template <int EPI>
-static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override = 0,
-                     int timing_tag = 0, int allow_wide = 0) {
+template <int EPI, int PL>
+static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override,
+                        int timing_tag, int allow_wide) {
     if (EPI == TG_EPI_STORE && (g.cols_valid % 4 != 0 || g.ldo % 4 != 0 || g.out_batch % 4 != 0 || g.out_split % 4 != 0 ||
                                 ((uintptr_t)g.out & 15) != 0)) {
         set_error("%s: the output needs 16-byte aligned rows (columns and leading dimension multiples of 4)", what);
         return LPM_ERR_BADARG;
     }
+    if (PL == 1 && (g.a2 != nullptr || g.steps2 != 0)) {
+        set_error("%s: the plain-bf16 tile form has no second operand pair", what);
+        return LPM_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (g.out_bf16 && (EPI != TG_EPI_STORE || g.accumulate || splits != 1 || g.ldo % 8 != 0 || g.out_batch % 8 != 0)) {
+        set_error("%s: a bf16 output is written once (no accumulate, one split) with 16-byte aligned rows", what);
+        return LPM_ERR_BADARG;
+    }
     const int ntw = ntw_override ? ntw_override : tg_ntw(g.cols_valid);
     const int nt = (g.cols_valid + 31) / 32;
-    const bool wide = EPI == TG_EPI_STORE && allow_wide && tg_wide_ok(g, nbatch, splits, ntw);
+    const bool wide = EPI == TG_EPI_STORE && allow_wide && tg_wide_ok(g, nbatch, splits, ntw, PL);
     dim3 grid((unsigned)(wide ? nbatch * g.a_tiles / 4 : nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)),
               (unsigned)splits);
     constexpr int WIDE_NS = 4;
@@ -357,8 +389,8 @@ static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t 
         else                                                                                                           \
             hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, g);                                             \
     } while (0)
-#define LPM_TG_LAUNCH(NTW) LPM_TG_LAUNCH_K((tile_gemm_kernel<NTW, EPI, 1, TG_NS>), 256)
-    if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS>), 512);
+#define LPM_TG_LAUNCH(NTW) LPM_TG_LAUNCH_K((tile_gemm_kernel<NTW, EPI, 1, TG_NS, PL>), 256)
+    if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS, PL>), 512);
     else if (ntw == 1) LPM_TG_LAUNCH(1);
     else if (ntw == 2) LPM_TG_LAUNCH(2);
     else LPM_TG_LAUNCH(4);
@@ -367,12 +399,19 @@ static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t 
     return check_launch(what);
 }
 
-
-int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw) {
-    return tg_launch<TG_EPI_STORE>(g, nbatch, splits, stream, what, ntw);
+template <int EPI>
+static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override = 0,
+                     int timing_tag = 0, int allow_wide = 0, int planes = 2) {
+    return planes == 1 ? tg_launch_pl<EPI, 1>(g, nbatch, splits, stream, what, ntw_override, timing_tag, allow_wide)
+                       : tg_launch_pl<EPI, 2>(g, nbatch, splits, stream, what, ntw_override, timing_tag, allow_wide);
 }
-int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what) {
-    return tg_launch<TG_EPI_SOFTMAX_BWD>(g, nbatch, 1, stream, what);
+
+
+int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw, int planes) {
+    return tg_launch<TG_EPI_STORE>(g, nbatch, splits, stream, what, ntw, 0, 0, planes);
+}
+int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what, int planes) {
+    return tg_launch<TG_EPI_SOFTMAX_BWD>(g, nbatch, 1, stream, what, 0, 0, 0, planes);
 }
 int tile_gemm_ntw(int cols) { return tg_ntw(cols); }
 
@@ -405,7 +444,7 @@ __global__ __launch_bounds__(256) void split_rows_tiles_kernel(const float* __re
 
 // B operand of M[R, N] (reduction R, columns N): [rs][nt][plane][lane].  transposed: the source is stored [N, R].
 __global__ __launch_bounds__(256) void split_weight_tiles_kernel(const float* __restrict__ W, int R, int N, int transposed,
-                                                                 uint4* __restrict__ wt) {
+                                                                 uint4* __restrict__ wt, int planes) {
     const int RS = R / 16, NT = (N + 31) / 32;
     const int64_t total = (int64_t)RS * NT * 64;
     for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
@@ -419,6 +458,10 @@ __global__ __launch_bounds__(256) void split_weight_tiles_kernel(const float* __
             v[e] = (col < N) ? (transposed ? W[(int64_t)col * R + r + e] : W[(int64_t)(r + e) * N + col]) : 0.f;
         uint4 hi, lo;
         tg_split8(v, hi, lo);
+        if (planes == 1) {
+            wt[t * 64 + lane] = hi;
+            continue;
+        }
         const int64_t base = t * 128 + lane;
         wt[base] = hi;
         wt[base + 64] = lo;
@@ -439,9 +482,12 @@ __global__ __launch_bounds__(256) void tg_reduce_splits_kernel(const float4* __r
 }
 
 static inline int row_tiles_per_clip(int T) { return 2 * ((T + 63) / 64); }
-static inline int dw_splits(int B, int T, int D, int K) {
+// frame steps per clip: ceil(T / 16) in the split form; the plain-bf16 form pads every clip to whole 64-frame blocks (an even
+// number of steps -- a ring stage carries two -- and the same frames as the row tiles cover)
+static inline int frame_steps(int T, int planes) { return planes == 1 ? 4 * ((T + 63) / 64) : (T + 15) / 16; }
+static inline int dw_splits(int B, int T, int D, int K, int planes = 2) {
     const int blocks = ((D + 63) / 64) * (((K + 31) / 32 + 4 * tg_ntw(K) - 1) / (4 * tg_ntw(K)));
-    const int steps = B * ((T + 15) / 16);
+    const int steps = B * frame_steps(T, planes);
     int z = (512 + blocks - 1) / blocks;
     if (z > steps / 8) z = steps / 8;
     if (z > 32) z = 32;                       // the reduce pass reads z partial copies of dW
@@ -472,30 +518,48 @@ extern "C" int lpm_split_rows_tiles(const float* x, int64_t ldx, int B, int T, i
     return check_launch("lpm_split_rows_tiles");
 }
 
-extern "C" int lpm_split_weight_tiles(const float* w, int R, int N, int transposed, void* wt, lpm_stream_t stream) {
+static int split_weight_tiles_impl(const float* w, int R, int N, int transposed, void* wt, int planes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(w && wt, LPM_ERR_BADARG, "lpm_split_weight_tiles: null pointer");
     LPM_REQUIRE(R > 0 && N > 0 && R % 16 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_split_weight_tiles: need R %% 16 == 0 (R=%d N=%d)", R, N);
     const int64_t total = (int64_t)(R / 16) * ((N + 31) / 32) * 64;
     hipLaunchKernelGGL(split_weight_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, R, N,
-                       transposed, (uint4*)wt);
+                       transposed, (uint4*)wt, planes);
     return check_launch("lpm_split_weight_tiles");
 }
+extern "C" int lpm_split_weight_tiles(const float* w, int R, int N, int transposed, void* wt, lpm_stream_t stream) {
+    return split_weight_tiles_impl(w, R, N, transposed, wt, 2, stream);
+}
+extern "C" int lpm_split_weight_tiles_bf16(const float* w, int R, int N, int transposed, void* wt, lpm_stream_t stream) {
+    return split_weight_tiles_impl(w, R, N, transposed, wt, 1, stream);
+}
 
-extern "C" int lpm_assign_gemm_tiles_fwd(const void* xr, const void* wt, int B, int T, int D, int K, float* logits, float* partial,
-                                         lpm_stream_t stream) {
+static int assign_gemm_tiles_fwd_impl(const void* xr, const void* wt, int B, int T, int D, int K, void* logits, float* partial,
+                                      int planes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(xr && wt && logits && partial, LPM_ERR_BADARG, "lpm_assign_gemm_tiles_fwd: null pointer");
     LPM_REQUIRE(B > 0 && lpm_assign_gemm_tiles_supported(T, D, K), LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_assign_gemm_tiles_fwd: need D %% 32 == 0, K %% 32 == 0, K <= 512 (D=%d K=%d)", D, K);
     const int MT = row_tiles_per_clip(T), DS = D / 16, NT = K / 32;
+    const int64_t U = 64 * planes;             // 16-byte units per (tile, step)
     TileGemmArgs g{};
-    g.a = (const uint4*)xr; g.a_tile = (int64_t)DS * 128; g.a_step = 128; g.a_batch = (int64_t)MT * DS * 128; g.a_tiles = MT;
-    g.b = (const uint4*)wt; g.b_tile = 128; g.b_step = (int64_t)NT * 128; g.b_batch = 0; g.b_tiles = NT;
+    g.a = (const uint4*)xr; g.a_tile = (int64_t)DS * U; g.a_step = U; g.a_batch = (int64_t)MT * DS * U; g.a_tiles = MT;
+    g.b = (const uint4*)wt; g.b_tile = U; g.b_step = (int64_t)NT * U; g.b_batch = 0; g.b_tiles = NT;
     g.rb_per_batch = MT / 2; g.steps_per_split = DS; g.total_steps = DS;
-    g.out = logits; g.ldo = K; g.out_batch = (int64_t)T * K; g.out_split = 0;
+    g.out = (float*)logits; g.out_bf16 = planes == 1 ? 1 : 0; g.ldo = K; g.out_batch = (int64_t)T * K; g.out_split = 0;
     g.rows_valid = T; g.cols_valid = K; g.accumulate = 0; g.stats = partial;
-    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd", 0, D >= 1024 ? LPM_TIMING_K1 : 0, 1);
+    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd", 0, D >= 1024 ? LPM_TIMING_K1 : 0, 1, planes);
+}
+extern "C" int lpm_assign_gemm_tiles_fwd(const void* xr, const void* wt, int B, int T, int D, int K, float* logits, float* partial,
+                                         lpm_stream_t stream) {
+    return assign_gemm_tiles_fwd_impl(xr, wt, B, T, D, K, logits, partial, 2, stream);
+}
+// bf16 storage (BASELINE cfg-5): xr, wt plain bf16 tiles (lpm_frame_apply_tiles_bf16 / lpm_split_weight_tiles_bf16), one MFMA
+// per product, fp32 accumulation; the logits are STORED as bf16 [B*T, K] (K %% 8 == 0), the batch statistics come from the fp32
+// accumulators.
+extern "C" int lpm_assign_gemm_tiles_fwd_bf16(const void* xr, const void* wt, int B, int T, int D, int K, void* logits_bf16,
+                                              float* partial, lpm_stream_t stream) {
+    return assign_gemm_tiles_fwd_impl(xr, wt, B, T, D, K, logits_bf16, partial, 1, stream);
 }
 
 extern "C" int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T, int D, int K, float* dx, int64_t lddx,
@@ -515,27 +579,42 @@ extern "C" int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, in
 }
 
 extern "C" size_t lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(int B, int T, int D, int K) {
-    return (size_t)lpm::dw_splits(B, T, D, K) * D * K * sizeof(float);
+    return (size_t)lpm::dw_splits(B, T, D, K) * D * K * sizeof(float);     // (covers the plain-bf16 form: never more splits)
 }
 
+static int assign_gemm_tiles_bwd_dw_impl(const void* xt, const void* dlt, int B, int T, int D, int K, float* dW, void* workspace,
+                                         size_t workspace_bytes, int planes, lpm_stream_t stream);
 extern "C" int lpm_assign_gemm_tiles_bwd_dw(const void* xt, const void* dlt, int B, int T, int D, int K, float* dW, void* workspace,
                                             size_t workspace_bytes, lpm_stream_t stream) {
+    return assign_gemm_tiles_bwd_dw_impl(xt, dlt, B, T, D, K, dW, workspace, workspace_bytes, 2, stream);
+}
+// bf16 storage: xt, dlt plain bf16 frame tiles with lpm_frame_steps_bf16(T) steps per clip (zero beyond T)
+extern "C" int lpm_assign_gemm_tiles_bwd_dw_bf16(const void* xt, const void* dlt, int B, int T, int D, int K, float* dW, void* workspace,
+                                                 size_t workspace_bytes, lpm_stream_t stream) {
+    return assign_gemm_tiles_bwd_dw_impl(xt, dlt, B, T, D, K, dW, workspace, workspace_bytes, 1, stream);
+}
+extern "C" int lpm_frame_steps_bf16(int T) { return lpm::frame_steps(T, 1); }
+
+static int assign_gemm_tiles_bwd_dw_impl(const void* xt, const void* dlt, int B, int T, int D, int K, float* dW, void* workspace,
+                                         size_t workspace_bytes, int planes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(xt && dlt && dW && workspace, LPM_ERR_BADARG, "lpm_assign_gemm_tiles_bwd_dw: null pointer");
     LPM_REQUIRE(B > 0 && lpm_assign_gemm_tiles_supported(T, D, K), LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_assign_gemm_tiles_bwd_dw: need D %% 32 == 0, K %% 32 == 0, K <= 512 (D=%d K=%d)", D, K);
     LPM_REQUIRE(workspace_bytes >= lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(B, T, D, K), LPM_ERR_BADARG,
                 "lpm_assign_gemm_tiles_bwd_dw: workspace too small");
-    const int S = (T + 15) / 16, DT = D / 32, KT = K / 32;
-    const int Z = dw_splits(B, T, D, K), steps = B * S;
+    const int S = frame_steps(T, planes), DT = D / 32, KT = K / 32;
+    const int Z = dw_splits(B, T, D, K, planes), steps = B * S;
+    const int64_t U = 64 * planes;
     TileGemmArgs g{};
-    g.a = (const uint4*)xt; g.a_tile = 128; g.a_step = (int64_t)DT * 128; g.a_batch = 0; g.a_tiles = DT;
-    g.b = (const uint4*)dlt; g.b_tile = 128; g.b_step = (int64_t)KT * 128; g.b_batch = 0; g.b_tiles = KT;
+    g.a = (const uint4*)xt; g.a_tile = U; g.a_step = (int64_t)DT * U; g.a_batch = 0; g.a_tiles = DT;
+    g.b = (const uint4*)dlt; g.b_tile = U; g.b_step = (int64_t)KT * U; g.b_batch = 0; g.b_tiles = KT;
     g.rb_per_batch = (D + 63) / 64; g.steps_per_split = (steps + Z - 1) / Z; g.total_steps = steps;
+    if (planes == 1 && (g.steps_per_split & 1)) ++g.steps_per_split;          // a ring stage carries two steps: even split boundaries
     g.out = Z > 1 ? (float*)workspace : dW; g.ldo = K; g.out_batch = 0; g.out_split = (int64_t)D * K;
     g.rows_valid = D; g.cols_valid = K; g.accumulate = 0; g.stats = nullptr;
     const int Zeff = (steps + g.steps_per_split - 1) / g.steps_per_split;     // every launched split has >= 1 step
-    const int rc = tg_launch<TG_EPI_STORE>(g, 1, Zeff, (hipStream_t)stream, "lpm_assign_gemm_tiles_bwd_dw");
+    const int rc = tg_launch<TG_EPI_STORE>(g, 1, Zeff, (hipStream_t)stream, "lpm_assign_gemm_tiles_bwd_dw", 0, 0, 0, planes);
     if (rc != LPM_OK || Z == 1) return rc;
     const int64_t n4 = (int64_t)D * K / 4;
     hipLaunchKernelGGL(tg_reduce_splits_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

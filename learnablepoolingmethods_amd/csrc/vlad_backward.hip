@@ -441,7 +441,7 @@ constexpr int VB_DU_NT = 512;
 __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float* __restrict__ dO, const float* __restrict__ N,
                                                                 const float* __restrict__ ug, const float* __restrict__ vg,
                                                                 int D, int K, uint4* __restrict__ ub1, uint4* __restrict__ ub2,
-                                                                const float* __restrict__ colsq, float* __restrict__ g0, int raw) {
+                                                                const float* __restrict__ colsq, float* __restrict__ g0, int raw, int planes) {
     // raw (LPM_VLAD_NRM_RAW): N holds the un-normalised sums U; N = U * rsqrt(max(colsq, eps)), and g0's U is read as it is
     extern __shared__ float dus[];           // [32][K+1], then u[K], v[K], rn[K] (, then prod [32][K+1] when g0)
     const int KS = K + 1;
@@ -504,6 +504,10 @@ __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float
         for (int e = 0; e < 8; ++e) v[e] = dus[(dl + e) * KS + k];
         uint4 hi, lo;
         tg_split8(v, hi, lo);
+        if (planes == 1) {                 // bf16 storage: plain bf16 tiles
+            ub1[(((int64_t)b * DS + d0 / 16 + dsl) * KT + kt) * 64 + lane] = hi;
+            continue;
+        }
         const int64_t base = ((((int64_t)b * DS + d0 / 16 + dsl) * KT + kt) * 2) * 64 + lane;
         ub1[base] = hi;
         ub1[base + 64] = lo;
@@ -698,6 +702,9 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     LPM_REQUIRE(workspace_bytes >= L.total, LPM_ERR_WORKSPACE, "lpm_vlad_aggregate_bwd_tiles: workspace too small");
     LPM_REQUIRE((((uintptr_t)xr | (uintptr_t)dout | (uintptr_t)nrm | (uintptr_t)workspace) & 15) == 0, LPM_ERR_BADARG,
                 "lpm_vlad_aggregate_bwd_tiles: pointers must be 16-byte aligned");
+    const int planes = (flags & LPM_VLAD_TILES_BF16) ? 1 : 2;
+    LPM_REQUIRE(planes == 2 || g0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_bwd_tiles: the bf16-storage form has no input-gradient path (it needs g0: frames without a gradient)");
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     float* dots = (float*)(ws + L.dots);
@@ -727,7 +734,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
             return LPM_ERR_LAUNCH;
         }
         hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(VB_DU_NT), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0,
-                           raw ? 1 : 0);
+                           raw ? 1 : 0, planes);
     }
     if (!g0) {       // the assignment's row tiles are the A operand of the dx GEMM only
         const size_t lds = (size_t)32 * (K + 1) * sizeof(float);
@@ -742,13 +749,14 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
         }
     }
     const int DS = D / 16, KT = K / 32;
+    const int64_t U = 64 * planes;
     TileGemmArgs g{};
-    g.a = (const uint4*)xr; g.a_tile = (int64_t)DS * 128; g.a_step = 128; g.a_batch = (int64_t)L.MT * DS * 128; g.a_tiles = L.MT;
-    g.b = ub1; g.b_tile = 128; g.b_step = (int64_t)KT * 128; g.b_batch = (int64_t)DS * KT * 128; g.b_tiles = KT;
+    g.a = (const uint4*)xr; g.a_tile = (int64_t)DS * U; g.a_step = U; g.a_batch = (int64_t)L.MT * DS * U; g.a_tiles = L.MT;
+    g.b = ub1; g.b_tile = U; g.b_step = (int64_t)KT * U; g.b_batch = (int64_t)DS * KT * U; g.b_tiles = KT;
     g.rb_per_batch = L.MT / 2; g.steps_per_split = DS; g.total_steps = DS;
     g.out = dassign; g.rows_valid = T; g.cols_valid = K;
-    g.logits = assign; g.scale = scale; g.shift = shift; g.ctil = ctil; g.softmax = sm ? 1 : 0;
-    const int rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles");
+    g.logits = assign; g.logits_bf16 = planes == 1 ? 1 : 0; g.scale = scale; g.shift = shift; g.ctil = ctil; g.softmax = sm ? 1 : 0;
+    const int rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles", planes);
     if (rc != LPM_OK) return rc;
     if (residual || g0) {        // dcentres = - sum_b asum_b dU_b: the centres' gradient, and (g0) the input batch norm's beta term
         launch_dcentres(dO, nrm, asum, u, v, B, D, K, (float*)(ws + L.dcp), dcentres, s, colsq_raw);

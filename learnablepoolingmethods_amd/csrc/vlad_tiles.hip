@@ -52,7 +52,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // work item = (clip b, step s, half kh, 4 consecutive d): 8 float4 row loads (coalesced across items),
 // 4 x (hi, lo) 16-byte tile stores.
 __global__ __launch_bounds__(256) void split_frames_kernel(const float* __restrict__ x, int64_t ldx, int B, int T,
-                                                           int D, int S, uint4* __restrict__ xt) {
+                                                           int D, int S, uint4* __restrict__ xt, int planes) {
     const int D4 = D / 4, DT = D / 32;
     const int64_t total = (int64_t)B * S * 2 * D4;
     for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void split_frames_kernel(const float* __restri
             const int d = 4 * d4 + c, dt = d >> 5, j = d & 31;
             uint4 hi, lo;
             split8(v[c], hi, lo);
+            if (planes == 1) {                 // plain bf16 tiles: one plane (S counts the padded steps of lpm_frame_steps_bf16)
+                xt[(((int64_t)b * S + s) * DT + dt) * 64 + kh * 32 + j] = hi;
+                continue;
+            }
             const int64_t base = ((((int64_t)b * S + s) * DT + dt) * 2) * 64 + kh * 32 + j;
             xt[base] = hi;
             xt[base + 64] = lo;
@@ -82,7 +86,8 @@ __global__ __launch_bounds__(256) void split_frames_kernel(const float* __restri
 
 // ---- logits / similarities -> AT -----------------------------------------------------------------
 // one workgroup per (clip, step of 16 frames); K <= 1024.
-template <bool SOFTMAX>
+// BF16IN (bf16 storage): `assign` holds bf16 values and AT is written as ONE plane; S then counts the padded steps
+template <bool SOFTMAX, bool BF16IN>
 __global__ __launch_bounds__(256) void assign_tiles_kernel(const float* __restrict__ assign,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int T, int K, int S,
@@ -97,13 +102,15 @@ __global__ __launch_bounds__(256) void assign_tiles_kernel(const float* __restri
         const int row = wave * 4 + rr, t = 16 * s + row;
         if (t >= T) continue;                // wave-uniform
         const float* ar = assign + ((int64_t)b * T + t) * K;
+        const unsigned short* arb = reinterpret_cast<const unsigned short*>(assign) + ((int64_t)b * T + t) * K;
+        auto ld = [&](int c) { return BF16IN ? bf16_to_f32(arb[c]) : ar[c]; };
         if (SOFTMAX) {
             float v[16];
             float m = -INFINITY;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int c = lane + 64 * j;
-                v[j] = (c < K) ? fmaf(ar[c], scale ? scale[c] : 1.f, shift ? shift[c] : 0.f) : -INFINITY;
+                v[j] = (c < K) ? fmaf(ld(c), scale ? scale[c] : 1.f, shift ? shift[c] : 0.f) : -INFINITY;
                 m = fmaxf(m, v[j]);
             }
             m = wave_max(m);
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void assign_tiles_kernel(const float* __restri
                 if (c < K) as[row * KS + c] = v[j] * inv;
             }
         } else {
-            for (int c = lane; c < K; c += 64) as[row * KS + c] = ar[c];
+            for (int c = lane; c < K; c += 64) as[row * KS + c] = ld(c);
         }
     }
     __syncthreads();
@@ -133,6 +140,10 @@ __global__ __launch_bounds__(256) void assign_tiles_kernel(const float* __restri
         for (int e = 0; e < 8; ++e) v[e] = as[(8 * kh + e) * KS + kt * 32 + i];
         uint4 hi, lo;
         split8(v, hi, lo);
+        if (BF16IN) {
+            at[(((int64_t)b * KT + kt) * S + s) * 64 + ln] = hi;
+            continue;
+        }
         const int64_t base = ((((int64_t)b * KT + kt) * S + s) * 2) * 64 + ln;
         at[base] = hi;
         at[base + 64] = lo;
@@ -336,8 +347,24 @@ extern "C" int lpm_split_frames(const float* x, int64_t ldx, int B, int T, int D
     const int64_t total = (int64_t)B * S * 2 * (D / 4);
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(split_frames_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, x,
-                       ldx, B, T, D, S, (uint4*)xt);
+                       ldx, B, T, D, S, (uint4*)xt, 2);
     return check_launch("lpm_split_frames");
+}
+
+// bf16 storage: fp32 rows -> plain bf16 frame tiles [b][step][column tile][lane], 4 ceil(T / 64) steps per clip (zero beyond T);
+// xt holds lpm_frame_tiles_bf16_bytes(B, T, D) bytes.
+extern "C" int lpm_split_frames_bf16(const float* x, int64_t ldx, int B, int T, int D, void* xt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x && xt, LPM_ERR_BADARG, "lpm_split_frames_bf16: null pointer");
+    LPM_REQUIRE(B > 0 && T > 0 && D > 0 && ldx >= D, LPM_ERR_BADARG, "lpm_split_frames_bf16: bad sizes");
+    LPM_REQUIRE(D % 32 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)xt) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_split_frames_bf16: need D %% 32 == 0, ldx %% 4 == 0, 16-byte aligned pointers (D=%d)", D);
+    const int S = 4 * ((T + 63) / 64);
+    const int64_t total = (int64_t)B * S * 2 * (D / 4);
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(split_frames_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, B, T, D, S, (uint4*)xt, 1);
+    return check_launch("lpm_split_frames_bf16");
 }
 
 extern "C" int lpm_assign_tiles(const float* assign, const float* scale, const float* shift, int B, int T, int K, int flags,
@@ -348,12 +375,30 @@ extern "C" int lpm_assign_tiles(const float* assign, const float* scale, const f
     const int S = vt_steps(T), KT = (K + 31) / 32;
     const size_t lds = (size_t)16 * (KT * 32 + 1) * sizeof(float);
     if (flags & LPM_VLAD_SOFTMAX)
-        hipLaunchKernelGGL(assign_tiles_kernel<true>, dim3(B * S), dim3(256), lds, (hipStream_t)stream, assign, scale, shift, T, K, S,
+        hipLaunchKernelGGL((assign_tiles_kernel<true, false>), dim3(B * S), dim3(256), lds, (hipStream_t)stream, assign, scale, shift, T, K, S,
                            KT, (uint4*)at);
     else
-        hipLaunchKernelGGL(assign_tiles_kernel<false>, dim3(B * S), dim3(256), lds, (hipStream_t)stream, assign, scale, shift, T, K,
+        hipLaunchKernelGGL((assign_tiles_kernel<false, false>), dim3(B * S), dim3(256), lds, (hipStream_t)stream, assign, scale, shift, T, K,
                            S, KT, (uint4*)at);
     return check_launch("lpm_assign_tiles");
+}
+
+// bf16 storage: assign is bf16 [B*T, K]; AT = plain bf16 tiles [b][cluster tile][step][lane] with 4 ceil(T / 64) steps per clip
+// (B * ceil(K / 32) * steps * 1024 bytes).
+extern "C" int lpm_assign_tiles_bf16(const void* assign_bf16, const float* scale, const float* shift, int B, int T, int K, int flags,
+                                     void* at, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(assign_bf16 && at, LPM_ERR_BADARG, "lpm_assign_tiles_bf16: null pointer");
+    LPM_REQUIRE(B > 0 && T > 0 && K > 0 && K <= 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_assign_tiles_bf16: need 0 < K <= 1024 (K=%d)", K);
+    const int S = 4 * ((T + 63) / 64), KT = (K + 31) / 32;
+    const size_t lds = (size_t)16 * (KT * 32 + 1) * sizeof(float);
+    if (flags & LPM_VLAD_SOFTMAX)
+        hipLaunchKernelGGL((assign_tiles_kernel<true, true>), dim3(B * S), dim3(256), lds, (hipStream_t)stream, (const float*)assign_bf16,
+                           scale, shift, T, K, S, KT, (uint4*)at);
+    else
+        hipLaunchKernelGGL((assign_tiles_kernel<false, true>), dim3(B * S), dim3(256), lds, (hipStream_t)stream, (const float*)assign_bf16,
+                           scale, shift, T, K, S, KT, (uint4*)at);
+    return check_launch("lpm_assign_tiles_bf16");
 }
 
 extern "C" int lpm_vlad_aggregate_tiles_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,

@@ -53,7 +53,9 @@ struct T3Fused {
     unsigned* fail;             // [B * K/128 * D/128] one flag per workgroup tile, zero at launch
 };
 
-template <bool FUSED>
+// PL = 1 (bf16 storage): AT / XT are plain bf16 tiles, ONE plane per (tile, step), S (even) steps per clip; a ring stage then
+// carries two consecutive frame steps where the split form carries the two planes of one step, and a product is one MFMA.
+template <bool FUSED, int PL>
 __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
     const uint4* __restrict__ at, const uint4* __restrict__ xt, const float* __restrict__ centres, int T, int D, int K,
     int S, int KT, int residual, float* __restrict__ nrm, float* __restrict__ asum, float* __restrict__ colsq_part, const T3Fused fz) {
@@ -69,9 +71,13 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
 
     // DMA role of this wave: piece (tile = wave >> 1, plane = wave & 1) of the A block and of the x block
     const int ptile = wave >> 1, pplane = wave & 1;
-    const uint4* asrc = at + ((((int64_t)b * KT + kb * 4 + ptile) * S) * 2 + pplane) * 64 + lane;       // + s * 128
-    const uint4* xsrc = xt + ((((int64_t)b * S) * DT + ds * 4 + ptile) * 2 + pplane) * 64 + lane;        // + s * DT * 128
+    // split form: + s * 128 (A), + s * DT * 128 (x);  plain form: the piece is step 2 s + pplane: + s * 128, + s * DT * 128 as well
+    const uint4* asrc = PL == 2 ? at + ((((int64_t)b * KT + kb * 4 + ptile) * S) * 2 + pplane) * 64 + lane
+                                : at + (((int64_t)b * KT + kb * 4 + ptile) * S + pplane) * 64 + lane;
+    const uint4* xsrc = PL == 2 ? xt + ((((int64_t)b * S) * DT + ds * 4 + ptile) * 2 + pplane) * 64 + lane
+                                : xt + (((int64_t)b * S + pplane) * DT + ds * 4 + ptile) * 64 + lane;
     const int adst = (ptile * 2 + pplane) * 1024, xdst = 8192 + (ptile * 2 + pplane) * 1024;
+    const int NST = PL == 2 ? S : S / 2;           // ring stages
 
     auto issue = [&](int s) {
         unsigned char* st = smem + (s % T3_NS) * T3_STAGE;
@@ -90,17 +96,17 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
 
 #pragma unroll
     for (int s = 0; s < T3_NS - 1; ++s)
-        if (s < S) issue(s);
+        if (s < NST) issue(s);
 
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < NST; ++s) {
         // this wave's two pieces of step s have landed when at most 2 * (younger steps in flight) remain
-        const int behind = min(T3_NS - 2, S - 1 - s);
+        const int behind = min(T3_NS - 2, NST - 1 - s);
         if (behind >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (behind == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // everyone's pieces of step s are in LDS; stage (s-1) % NS is free
         asm volatile("" ::: "memory");
-        if (s + T3_NS - 1 < S) issue(s + T3_NS - 1);
+        if (s + T3_NS - 1 < NST) issue(s + T3_NS - 1);
         const unsigned char* st = smem + (s % T3_NS) * T3_STAGE;
         const t3_u32x4* af = reinterpret_cast<const t3_u32x4*>(st) + lane;                 // A tile c, plane p: + (c*2+p)*64
         const t3_u32x4* xf = reinterpret_cast<const t3_u32x4*>(st + 8192) + lane;
@@ -108,9 +114,14 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const t3_u32x4 ah = af[((kw * 2 + c) * 2 + 0) * 64], al = af[((kw * 2 + c) * 2 + 1) * 64];
-            acc[c] = t3_mfma(ah, xh, acc[c]);
-            acc[c] = t3_mfma(ah, xl, acc[c]);
-            acc[c] = t3_mfma(al, xh, acc[c]);
+            if (PL == 2) {
+                acc[c] = t3_mfma(ah, xh, acc[c]);
+                acc[c] = t3_mfma(ah, xl, acc[c]);
+                acc[c] = t3_mfma(al, xh, acc[c]);
+            } else {                // (ah, xh): first frame step of the stage, (al, xl): second
+                acc[c] = t3_mfma(ah, xh, acc[c]);
+                acc[c] = t3_mfma(al, xl, acc[c]);
+            }
             // assignment sums: the four column-tile waves of a cluster pair split the work (tile c = dw >> 1, frame pairs
             // 2 * (dw & 1) .. + 1 of the fragment); the epilogue adds their partial sums.  All of it on every wave was the
             // largest VALU consumer of the loop (64 ops per wave-step next to six MFMAs).
@@ -361,8 +372,9 @@ template <bool KMAJOR>
 __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
                                                              int P, int D, int K, float* __restrict__ out,
                                                              float* __restrict__ colsq, float* __restrict__ csq,
-                                                             float* __restrict__ gsq, int keep_u) {
+                                                             float* __restrict__ gsq, int keep_u, int out_bf16) {
     // keep_u (LPM_VLAD_NRM_RAW): nrm is left as the un-normalised sums U (the tile backward rebuilds N = U * inv_n itself)
+    // out_bf16 (d-major only): `out` is bf16 storage
     extern __shared__ float fs[];            // [K] inv_n, then [32][33] transpose tile, [4] partial sums
     float* invn = fs;
     float* tile = fs + K;
@@ -397,7 +409,13 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
             v.x *= invn[k]; v.y *= invn[k + 1]; v.z *= invn[k + 2]; v.w *= invn[k + 3];
             if (!keep_u) reinterpret_cast<float4*>(src)[i] = v;
             v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
-            reinterpret_cast<float4*>(dst)[i] = v;
+            if (out_bf16) {
+                auto rne = [](float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
+                reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + ((int64_t)b * D + d0) * K)[i] =
+                    make_uint2(rne(v.x) | (rne(v.y) << 16), rne(v.z) | (rne(v.w) << 16));
+            } else {
+                reinterpret_cast<float4*>(dst)[i] = v;
+            }
         }
     } else {
         float* dst = out + (int64_t)b * K * D;
@@ -485,8 +503,20 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kmajor4_kernel(float* __re
 
 extern "C" int lpm_vlad_tiles3_supported(int D, int K) { return (D % 128 == 0 && K % 128 == 0 && D >= 128 && K >= 128) ? 1 : 0; }
 
+static int vlad_aggregate_tiles3_impl(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                      float* nrm, float* asum, float* colsq_part, int planes, lpm_stream_t stream);
 extern "C" int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,
                                              int flags, float* nrm, float* asum, float* colsq_part, lpm_stream_t stream) {
+    return vlad_aggregate_tiles3_impl(at, xt, centres, B, T, D, K, flags, nrm, asum, colsq_part, 2, stream);
+}
+// bf16 storage (BASELINE cfg-5): at = lpm_assign_tiles_bf16, xt = lpm_frame_apply_tiles_bf16 / lpm_split_frames_bf16 (plain bf16
+// tiles, 4 ceil(T / 64) steps per clip); one MFMA per product, fp32 accumulation; outputs as lpm_vlad_aggregate_tiles3_fwd.
+extern "C" int lpm_vlad_aggregate_tiles3_fwd_bf16(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,
+                                                  int flags, float* nrm, float* asum, float* colsq_part, lpm_stream_t stream) {
+    return vlad_aggregate_tiles3_impl(at, xt, centres, B, T, D, K, flags, nrm, asum, colsq_part, 1, stream);
+}
+static int vlad_aggregate_tiles3_impl(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                      float* nrm, float* asum, float* colsq_part, int planes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(at && xt && nrm && asum && colsq_part, LPM_ERR_BADARG, "lpm_vlad_aggregate_tiles3_fwd: null pointer");
     const int residual = (flags & LPM_VLAD_RESIDUAL) ? 1 : 0;
@@ -495,10 +525,10 @@ extern "C" int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, con
                 "lpm_vlad_aggregate_tiles3_fwd: need D %% 128 == 0 and K %% 128 == 0 (D=%d K=%d)", D, K);
     LPM_REQUIRE((((uintptr_t)at | (uintptr_t)xt | (uintptr_t)centres | (uintptr_t)nrm) & 15) == 0, LPM_ERR_BADARG,
                 "lpm_vlad_aggregate_tiles3_fwd: pointers must be 16-byte aligned");
-    const int S = (T + 15) / 16, KT = K / 32;
+    const int S = planes == 1 ? 4 * ((T + 63) / 64) : (T + 15) / 16, KT = K / 32;
     const size_t lds = (size_t)T3_NS * T3_STAGE + (4 * 128 + 128) * sizeof(float);
     static_assert(T3_EPI <= T3_NS * T3_STAGE, "the epilogue tiles overlay the DMA ring");
-    auto kern = vlad_aggregate_tiles3_kernel<false>;
+    auto kern = planes == 1 ? vlad_aggregate_tiles3_kernel<false, 1> : vlad_aggregate_tiles3_kernel<false, 2>;
     const T3Fused fz{};
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
@@ -554,7 +584,7 @@ extern "C" int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, cons
     fz.colsq = colsq; fz.csq = csq; fz.gsq = gsq; fz.arrive = arrive; fz.fail = fail;
     fz.debug_fallback = (flags & LPM_VLAD_DEBUG_FALLBACK) ? 1 : 0;
     const size_t lds = (size_t)T3_NS * T3_STAGE + (4 * 128 + 128 + 16) * sizeof(float);
-    auto kern = vlad_aggregate_tiles3_kernel<true>;
+    auto kern = vlad_aggregate_tiles3_kernel<true, 2>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         set_error("lpm_vlad_aggregate_fused_fwd: cannot reserve %zu bytes of LDS", lds);
@@ -581,6 +611,9 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
                 "lpm_vlad_finalize2_fwd: need D %% 32 == 0, K %% 4 == 0 (D=%d K=%d)", D, K);
     dim3 grid(D / 32, B);
     const int keep_u = (flags & LPM_VLAD_NRM_RAW) ? 1 : 0;
+    const int out_bf16 = (flags & LPM_VLAD_OUT_BF16) ? 1 : 0;
+    LPM_REQUIRE(!out_bf16 || !(flags & LPM_VLAD_OUT_KMAJOR), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_finalize2_fwd: a bf16 descriptor is written in the reference's d-major layout only");
     const size_t lds = (size_t)(K + 32 * 33 + 4) * sizeof(float);
     static const int wide = [] { const char* e = getenv("LPM_FINALIZE_KMAJOR4"); return e ? atoi(e) : 32; }();   // 0: scalar form (A/B)
     if ((flags & LPM_VLAD_OUT_KMAJOR) && wide && K <= 512 && (((uintptr_t)nrm | (uintptr_t)out) & 15) == 0) {
@@ -600,9 +633,9 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
     }
     if (flags & LPM_VLAD_OUT_KMAJOR)
         hipLaunchKernelGGL(vlad_finalize2_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq,
-                           csq, gsq, keep_u);
+                           csq, gsq, keep_u, 0);
     else
         hipLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out,
-                           colsq, csq, gsq, keep_u);
+                           colsq, csq, gsq, keep_u, out_bf16);
     return check_launch("lpm_vlad_finalize2_fwd");
 }

@@ -35,6 +35,9 @@ FLAGS.define("netvlad_encoder", True, "build extension: False = gated NetVLAD wi
 FLAGS.define("sample_random_frames", True, "frame_level_models.py:40: random frames (True) or a random contiguous sequence")
 FLAGS.define("rgb_det_reg", 1e-4, "frame_level_models.py:2213: orthogonality penalty on the rgb cluster centres (WillowModelReg)")
 FLAGS.define("audio_det_reg", 1e-4, "frame_level_models.py:2209: orthogonality penalty on the audio cluster centres")
+FLAGS.define("netvlad_storage", "f32", "build extension: 'bf16' = the frames, logits / assignment and pooled descriptor of the NetVLAD "
+             "streams live in HBM as bf16 with fp32 accumulation (BASELINE configs[4], 'Gated NetVLAD K=512 + MoE-4 ... bf16'); needs "
+             "netvlad_encoder off, batch norm on, cluster_size a multiple of 512")
 FLAGS.define("fused_encoder_blocks", True, "build extension: run the V1 cluster encoder as two block Functions whose backward "
              "folds the gradient sums of shared tensors into GEMM accumulation / the layer-norm kernel (no add passes)")
 FLAGS.define("descriptor_slots", True, "build extension: both encoders write their pooled descriptor into one shared buffer "

@@ -28,7 +28,7 @@ class NetVLAD():
         self.add_batch_norm = add_batch_norm
         self.cluster_size = int(cluster_size)
 
-    def forward(self, reshaped_input, kmajor=False, input_affine=None):
+    def forward(self, reshaped_input, kmajor=False, input_affine=None, storage="f32"):
         """input_affine: (gamma, beta) slices of input_bn when reshaped_input is its (gradient-free) output, see ops.netvlad."""
         D, K, dev = self.feature_size, self.cluster_size, reshaped_input.device
         std = 1 / math.sqrt(D)
@@ -44,7 +44,7 @@ class NetVLAD():
                                                device=dev)                                                           # :2805-2808
         # matmul -> cluster_bn -> softmax -> a^T x - sum(a) W2 -> l2norm(D) -> flatten -> l2norm  (:2781-2822)
         return ops.netvlad(reshaped_input, cluster_weights, cluster_weights2, self.max_frames, bn=bn, bias=bias,
-                           is_training=self.is_training, kmajor=kmajor, input_affine=input_affine)
+                           is_training=self.is_training, kmajor=kmajor, input_affine=input_affine, storage=storage)
 
 
 class LightVLAD(NetVLAD):
@@ -120,10 +120,12 @@ class _GammaWatch:
                           "switched off, the input gradient is formed explicitly from now on")
 
 
-def _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training):
+def _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training, storage="f32"):
     """SampleUniformFrames + reshape + input_bn (frame_level_models.py:2248-2271), one fused kernel pair."""
     bn = layers.bn_variables("input_bn", model_input.shape[2], model_input.device) if add_batch_norm else (None,) * 4
-    return ops.frame_sample_bn(model_input, num_frames.reshape(-1), iterations, *bn, is_training=is_training)
+    # bf16 storage: the fp32 matrix itself is only filled in when summaries are being collected (nothing else reads it)
+    return ops.frame_sample_bn(model_input, num_frames.reshape(-1), iterations, *bn, is_training=is_training, storage=storage,
+                               materialize=storage == "f32" or vs.default_store().summaries is not None)
 
 
 class NetVladV1(models.BaseModel):
@@ -139,9 +141,13 @@ class NetVladV1(models.BaseModel):
         hidden1_size = hidden_size or FLAGS.netvlad_hidden_size
         relu, gating, remove_diag = FLAGS.netvlad_relu, FLAGS.gating, FLAGS.gating_remove_diag
         encoder = FLAGS.netvlad_encoder if encoder is None else encoder
+        storage = FLAGS.netvlad_storage
+        if storage == "bf16" and (encoder or not add_batch_norm or not model_input.is_cuda):
+            raise ValueError("netvlad_storage='bf16' is the gated-NetVLAD configuration: netvlad_encoder off, batch norm on, on the GPU")
 
-        reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training)
-        vs.summary("input_bn", reshaped_input)
+        reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training, storage)
+        if storage == "f32" or vs.default_store().summaries is not None:
+            vs.summary("input_bn", reshaped_input)
         max_frames, feature_size = iterations, model_input.shape[2]
         has_audio = feature_size > 1024                                      # App. C9
 
@@ -173,11 +179,11 @@ class NetVladV1(models.BaseModel):
         use_side = has_audio and reshaped_input.is_cuda and FLAGS.audio_side_stream
         side = ops.side_stream(audio, reshaped_input) if use_side else contextlib.nullcontext()
         with vs.variable_scope("video_VLAD"):
-            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v)       # :2273-2274
+            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v, storage=storage)       # :2273-2274
             vs.summary("vlad_video", vlad_video)     # [B, K, D] (the App. C5 token view) when the encoders follow, else [B, D*K]
         if has_audio:
             with side, vs.variable_scope("audio_VLAD"):
-                vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder, input_affine=aff_a) # :2276-2277
+                vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder, input_affine=aff_a, storage=storage) # :2276-2277
                 vs.summary("vlad_audio", vlad_audio)
 
         slots = None
@@ -213,6 +219,8 @@ class NetVladV1(models.BaseModel):
         else:
             vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video         # :2309
         vs.summary("vlad", vlad)
+        if vlad.dtype != torch.float32:      # bf16 storage: the projection and everything behind it compute in fp32
+            vlad = vlad.float()
         return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
                                       remove_diag, is_training, **unused_params)
 

@@ -91,6 +91,13 @@ def _rows(t: torch.Tensor, what: str) -> torch.Tensor:
     return t
 
 
+def _materialised(t: torch.Tensor, what: str) -> torch.Tensor:
+    base = t._base if t._base is not None else t
+    if getattr(base, "_lpm_unmaterialised", False):
+        raise LpmError(f"{what}: these frames exist as bf16 operand tiles only (frame_sample_bn(storage='bf16', materialize=False))")
+    return t
+
+
 def _empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
@@ -145,7 +152,7 @@ def dequantize_l2_normalize(q, num_frames, max_quantized_value=2.0, min_quantize
 # ----------------------------------------------------------------------------------------------
 class _FrameSampleBN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw, num_frames, gamma, beta, moving_mean, moving_var, S, is_training, use_bn):
+    def forward(ctx, raw, num_frames, gamma, beta, moving_mean, moving_var, S, is_training, use_bn, storage="f32", materialize=True):
         lib = _capi.load()
         raw = _f32(raw, "model_input").contiguous()
         if raw.dim() != 3:
@@ -166,7 +173,23 @@ class _FrameSampleBN(torch.autograd.Function):
         else:
             scale = shift = None
         tiles = VLAD_PRECISION == "bf16x3" and F in (1024, 1152)
-        if tiles:
+        if storage == "bf16":
+            # bf16 storage: the frames leave as plain bf16 operand tiles for K1 (row tiles) and K2 (frame tiles) in one pass; the
+            # fp32 matrix is written only when somebody will look at it (materialize)
+            if F not in (1024, 1152):
+                raise LpmError("frame_sample_bn: bf16 storage needs a 1024- or 1152-wide input")
+            Dv, Da = 1024, F - 1024
+            nb = lambda d: torch.empty(lib._lpm_frame_tiles_bf16_bytes(B, S, d) // 4, dtype=torch.int32, device=raw.device)
+            xtv, xrv = nb(Dv), nb(Dv)
+            xta, xra = (nb(Da), nb(Da)) if Da else (None, None)
+            lib.check(lib._lpm_frame_apply_tiles_bf16(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(y) if materialize else None,
+                                                      ptr(xtv), ptr(xrv), Dv, ptr(xta), ptr(xra), Da, stream_ptr()),
+                      "lpm_frame_apply_tiles_bf16")
+            y._lpm_unmaterialised = not materialize
+            _XT_CACHE.clear()
+            _XT_CACHE.update(base=weakref.ref(y), F=F, Dv=Dv, S=S, B=B, video=xtv, audio=xta, video_rows=xrv, audio_rows=xra,
+                             storage="bf16")
+        elif tiles:
             Dv, Da = 1024, F - 1024
             xtv = torch.empty(lib._lpm_xt_bytes(B, S, Dv) // 4, dtype=torch.int32, device=raw.device)
             xta = torch.empty(lib._lpm_xt_bytes(B, S, Da) // 4, dtype=torch.int32, device=raw.device) if Da else None
@@ -188,7 +211,7 @@ class _FrameSampleBN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         if not ctx.use_bn:
-            return (None,) * 9
+            return (None,) * 11
         lib = _capi.load()
         raw, nf, mean, var = ctx.saved_tensors
         B, MF, F = raw.shape
@@ -198,7 +221,7 @@ class _FrameSampleBN(torch.autograd.Function):
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=raw.device)
         lib.check(lib._lpm_frame_bn_bwd(ptr(dy), dy.stride(0), ptr(raw), ptr(nf), B, MF, F, ctx.S, ptr(mean), ptr(var),
                                         BN_EPS, ptr(dgamma), ptr(dbeta), ptr(ws), wsb, stream_ptr()), "lpm_frame_bn_bwd")
-        return None, None, dgamma, dbeta, None, None, None, None, None
+        return None, None, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -228,7 +251,7 @@ class side_stream:
             self.side.wait_stream(self.main)
             for t in self.inputs:
                 t.record_stream(self.side)
-            for key in ("video", "audio"):                  # tile copies written by frame_sample_bn on the main stream
+            for key in ("video", "audio", "video_rows", "audio_rows"):     # tile copies written by frame_sample_bn on the main stream
                 t = _XT_CACHE.get(key)
                 if t is not None:
                     t.record_stream(self.side)
@@ -288,28 +311,34 @@ def _dx_slot_view(slot_ref, D):
     return slot["buf"][:, c0:c0 + D]
 
 
-def frame_sample_bn(raw, num_frames, S, gamma=None, beta=None, moving_mean=None, moving_var=None, is_training=True):
+def frame_sample_bn(raw, num_frames, S, gamma=None, beta=None, moving_mean=None, moving_var=None, is_training=True, storage="f32",
+                    materialize=True):
     """[B, max_frames, F] -> [B*S, F]: uniform frame sampling (model_utils.py:101-122) fused with
-    input_bn (frame_level_models.py:2265-2271).  The frames are data: no gradient flows to ``raw``."""
+    input_bn (frame_level_models.py:2265-2271).  The frames are data: no gradient flows to ``raw``.
+    storage="bf16" (BASELINE cfg-5): the result is written as plain bf16 operand tiles for ops.netvlad(storage="bf16"); the fp32
+    matrix that is returned is filled in only with ``materialize`` (otherwise it is a handle nobody may read)."""
     use_bn = gamma is not None
-    return _FrameSampleBN.apply(raw, num_frames, gamma, beta, moving_mean, moving_var, int(S), bool(is_training), use_bn)
+    return _FrameSampleBN.apply(raw, num_frames, gamma, beta, moving_mean, moving_var, int(S), bool(is_training), use_bn, storage,
+                                bool(materialize))
 
 
 # ----------------------------------------------------------------------------------------------
 # K1 + K2 (+K3): NetVLAD pooling
 # ----------------------------------------------------------------------------------------------
-def _cached_tiles(x, B, T, D):
-    """The tile copy written by frame_sample_bn, if ``x`` is the rgb / audio column slice of its latest output."""
+def _cached_tiles(x, B, T, D, rows=False, storage="f32"):
+    """The tile copy written by frame_sample_bn, if ``x`` is the rgb / audio column slice of its latest output.  rows: the row
+    tiles (K1's operand; bf16 storage only) instead of the frame tiles."""
     c = _XT_CACHE
-    if not c or c["B"] != B or c["S"] != T:
+    if not c or c["B"] != B or c["S"] != T or c.get("storage", "f32") != storage:
         return None
     base = c["base"]()
     if base is None or x._base is not base or x.stride(0) != c["F"]:
         return None
+    suffix = "_rows" if rows else ""
     if x.storage_offset() == 0 and D == c["Dv"]:
-        return c["video"]
+        return c["video" + suffix]
     if x.storage_offset() == c["Dv"] and D == c["F"] - c["Dv"] and c["audio"] is not None:
-        return c["audio"]
+        return c["audio" + suffix]
     return None
 
 
@@ -470,7 +499,8 @@ class _NetVLAD(torch.autograd.Function):
     cluster_biases; cluster_weights2 [1,D,K] (None = LightVLAD).  frame_level_models.py:2773-2824."""
 
     @staticmethod
-    def forward(ctx, x, W, gamma, beta, moving_mean, moving_var, bias, W2, T, is_training, kmajor, in_gamma=None, in_beta=None):
+    def forward(ctx, x, W, gamma, beta, moving_mean, moving_var, bias, W2, T, is_training, kmajor, in_gamma=None, in_beta=None,
+                storage="f32"):
         """in_gamma / in_beta ([D] slices of input_bn's gamma / beta): x is input_bn's output for these columns and needs no
         gradient of its own -- the backward then returns input_bn's gamma / beta gradients in closed form instead of dx."""
         lib = _capi.load()
@@ -481,6 +511,13 @@ class _NetVLAD(torch.autograd.Function):
         if M % T:
             raise LpmError(f"rows {M} not divisible by max_frames {T}")
         B = M // T
+        ctx.storage = storage
+        if storage == "bf16":
+            return _NetVLAD._forward_bf16(ctx, lib, x, W, gamma, beta, moving_mean, moving_var, bias, W2, B, T, D, K, is_training, kmajor,
+                                          in_gamma, in_beta)
+        if storage != "f32":
+            raise LpmError(f"unknown storage {storage!r} (f32 | bf16)")
+        _materialised(x, "reshaped_input")
         logits = _empty((M, K), x)
         if ASSIGN_PRECISION not in ("bf16x3", "f32"):
             raise LpmError(f"unknown LPM_ASSIGN_PRECISION {ASSIGN_PRECISION!r} (bf16x3 | f32)")
@@ -530,7 +567,123 @@ class _NetVLAD(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _forward_bf16(ctx, lib, x, W, gamma, beta, moving_mean, moving_var, bias, W2, B, T, D, K, is_training, kmajor, in_gamma, in_beta):
+        """bf16 storage (BASELINE cfg-5; include/lpm_hip.h "bf16 storage"): frames, logits / assignment and the descriptor are bf16
+        in HBM, every product one bf16 MFMA with fp32 accumulation; statistics, norms and gradients fp32.  Needs the operand tiles
+        ops.frame_sample_bn(storage="bf16") wrote for x, the LDS-shared K2 form (D, K multiples of 128, K <= 512), the d-major
+        layout, and frames that need no gradient of their own (input_affine, or x.requires_grad False)."""
+        st = stream_ptr()
+        M = B * T
+        if kmajor:
+            raise LpmError("netvlad: bf16 storage writes the descriptor in the reference's d-major layout only")
+        if not (lib._lpm_vlad_tiles3_supported(D, K) and lib._lpm_assign_gemm_tiles_supported(T, D, K) and K % 8 == 0):
+            raise LpmError(f"netvlad: bf16 storage needs D, K multiples of 128 and K <= 512 (D={D} K={K})")
+        if in_gamma is None and ctx.needs_input_grad[0]:
+            raise LpmError("netvlad: bf16 storage has no input-gradient path (pass input_affine, or frames that need no gradient)")
+        xr = _cached_tiles(x, B, T, D, rows=True, storage="bf16")
+        xt = _cached_tiles(x, B, T, D, storage="bf16")
+        if xr is None or xt is None:
+            raise LpmError("netvlad: bf16 storage needs the operand tiles of ops.frame_sample_bn(storage='bf16') for this input")
+        nblk = lib._lpm_assign_gemm_tiles_nblk(B, T)
+        partial = _empty((nblk, 2, K), W)
+        wt = _tile_buffer(lib._lpm_weight_tiles_bytes(D, K) // 2, W)
+        lib.check(lib._lpm_split_weight_tiles_bf16(ptr(W), D, K, 0, ptr(wt), st), "lpm_split_weight_tiles_bf16")
+        logits = torch.empty((M, K), dtype=torch.bfloat16, device=W.device)
+        with _timed("assign_gemm_fwd", (M, D, K)):
+            lib.check(lib._lpm_assign_gemm_tiles_fwd_bf16(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st),
+                      "lpm_assign_gemm_tiles_fwd_bf16")
+        mean = var = None
+        use_bn = gamma is not None
+        if use_bn:
+            if is_training:
+                mean, var, scale, shift = bn_fold(partial, nblk, K, M, gamma, beta, moving_mean, moving_var)
+            else:
+                scale, shift = folded_eval_affine(gamma, beta, moving_mean, moving_var)
+                scale, shift = scale.contiguous(), shift.contiguous()
+                mean, var = moving_mean.detach().clone(), moving_var.detach().clone()
+        else:
+            scale, shift = None, bias.contiguous()
+        flags = LPM_VLAD_SOFTMAX | (LPM_VLAD_RESIDUAL if W2 is not None else 0)
+        centres = W2.reshape(D, K).contiguous() if W2 is not None else None
+        steps = lib._lpm_frame_steps_bf16(T)
+        at = torch.empty(B * (K // 32) * steps * 256, dtype=torch.int32, device=W.device)       # 1 KB per (cluster tile, step)
+        with _timed("assign_tiles", (B, T, K)):
+            lib.check(lib._lpm_assign_tiles_bf16(ptr(logits), ptr(scale), ptr(shift), B, T, K, flags, ptr(at), st), "lpm_assign_tiles_bf16")
+        nrm = _empty((B, D, K), W)
+        asum, colsq, csq = (_empty((B, K), W) for _ in range(3))
+        P = D // 128
+        part = _empty((B, P, K), W)
+        with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+            lib.check(lib._lpm_vlad_aggregate_tiles3_fwd_bf16(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
+                                                              ptr(part), st), "lpm_vlad_aggregate_tiles3_fwd_bf16")
+        out = torch.empty((B, D * K), dtype=torch.bfloat16, device=W.device)
+        gsq = _empty((B,), W)
+        with _timed("vlad_finalize", (B, D, K)):
+            lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, LPM_VLAD_NRM_RAW | _capi.LPM_VLAD_OUT_BF16, ptr(out),
+                                                  ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_finalize2_fwd")
+        ctx.nrm_raw = True
+        ctx.dims = (B, T, D, K, flags, False, use_bn, is_training, W2 is not None, True)
+        ctx.no_dx = True
+        ctx.has_affine = in_gamma is not None
+        ctx.save_for_backward(x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr, in_gamma, in_beta)
+        return out
+
+    @staticmethod
+    def _backward_bf16(ctx, dout):
+        lib = _capi.load()
+        st = stream_ptr()
+        B, T, D, K, flags, kmajor, use_bn, is_training, has_w2, _ = ctx.dims
+        x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr, in_gamma, in_beta = ctx.saved_tensors
+        M = B * T
+        dout = dout.float().contiguous()           # the gradient of a bf16 tensor arrives as bf16; everything below is fp32
+        dlt = _empty((M, K), W)
+        dcentres = _empty((D, K), W)
+        g0 = _empty((B, D), W)
+        wsb = lib._lpm_vlad_bwd_tiles_workspace_bytes(B, T, D, K)
+        ws = _tile_buffer(wsb, W)
+        fl = flags | LPM_VLAD_NRM_RAW | _capi.LPM_VLAD_TILES_BF16
+        with _timed("vlad_aggregate_bwd", (B, T, D, K)):
+            lib.check(lib._lpm_vlad_aggregate_bwd_tiles(ptr(dout), ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(logits),
+                                                        ptr(scale), ptr(shift), ptr(xr), ptr(centres), B, T, D, K, fl, ptr(dlt),
+                                                        ptr(dcentres), ptr(g0), ptr(ws), wsb, st), "lpm_vlad_aggregate_bwd_tiles")
+        dgamma = dbeta = dbias = None
+        if use_bn and is_training:
+            lf = logits.float()
+            dgamma, dbeta = _empty((K,), W), _empty((K,), W)
+            wsb2 = lib._lpm_bn_bwd_workspace_bytes(M, K)
+            ws2 = torch.empty(wsb2 // 4, dtype=torch.float32, device=W.device)
+            lib.check(lib._lpm_bn_bwd(ptr(dlt), ptr(lf), ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, K, ptr(dlt), ptr(dgamma), ptr(dbeta),
+                                      ptr(ws2), wsb2, st), "lpm_bn_bwd")
+            dl = dlt
+        elif use_bn:
+            lhat = (logits.float() - mean) * torch.rsqrt(var + BN_EPS)
+            dgamma, dbeta = (dlt * lhat).sum(0), dlt.sum(0)
+            dl = dlt * scale
+        else:
+            dbias = dlt.sum(0)
+            dl = dlt
+        dlt16 = _tile_buffer(lib._lpm_frame_tiles_bf16_bytes(B, T, K), W)
+        lib.check(lib._lpm_split_frames_bf16(ptr(dl), dl.stride(0), B, T, K, ptr(dlt16), st), "lpm_split_frames_bf16")
+        dW = _empty((D, K), W)
+        wsb3 = lib._lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(B, T, D, K)
+        ws3 = _tile_buffer(max(wsb3, 16), W)
+        with _timed("assign_gemm_bwd_dw", (M, D, K)):
+            lib.check(lib._lpm_assign_gemm_tiles_bwd_dw_bf16(ptr(xt), ptr(dlt16), B, T, D, K, ptr(dW), ptr(ws3), wsb3, st),
+                      "lpm_assign_gemm_tiles_bwd_dw_bf16")
+        d_in_gamma = d_in_beta = None
+        if ctx.has_affine:
+            cs = None if (use_bn and is_training) else dl.sum(0)
+            d_in_gamma, d_in_beta = _empty((D,), W), _empty((D,), W)
+            lib.check(lib._lpm_input_bn_grads(ptr(dcentres), ptr(centres) if has_w2 else None, ptr(W), ptr(dW), ptr(g0), ptr(cs),
+                                              ptr(in_gamma.contiguous()), ptr(in_beta.contiguous()), B, D, K, ptr(d_in_gamma),
+                                              ptr(d_in_beta), st), "lpm_input_bn_grads")
+        dW2 = dcentres.reshape(1, D, K) if has_w2 else None
+        return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None
+
+    @staticmethod
     def backward(ctx, dout):
+        if ctx.storage == "bf16":
+            return _NetVLAD._backward_bf16(ctx, dout)
         lib = _capi.load()
         B, T, D, K, flags, kmajor, use_bn, is_training, has_w2, tiles = ctx.dims
         x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr, in_gamma, in_beta = ctx.saved_tensors
@@ -584,7 +737,7 @@ class _NetVLAD(torch.autograd.Function):
                                               ptr(in_gamma.contiguous()), ptr(in_beta.contiguous()), B, D, K, ptr(d_in_gamma),
                                               ptr(d_in_beta), stream_ptr()), "lpm_input_bn_grads")
             dW2 = dcentres.reshape(1, D, K) if has_w2 else None
-            return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta
+            return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None
         if k3_tiles:
             dx = _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, x, B, T, D, K, out=_dx_slot_view(ctx.dx_slot, D))
             if not tiles:
@@ -595,17 +748,18 @@ class _NetVLAD(torch.autograd.Function):
         else:
             dx.addmm_(dl, W.t())
         dW2 = dcentres.reshape(1, D, K) if has_w2 else None
-        return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, None, None
+        return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, None, None, None
 
 
 def netvlad(x, cluster_weights, cluster_weights2, max_frames, bn=None, bias=None, is_training=True, kmajor=False,
-            input_affine=None):
+            input_affine=None, storage="f32"):
     """bn = (gamma, beta, moving_mean, moving_var) or None (then ``bias`` = cluster_biases).  input_affine = (gamma, beta) slices
-    of the input batch norm whose output x is (x itself then needs no gradient): see _NetVLAD.forward."""
+    of the input batch norm whose output x is (x itself then needs no gradient): see _NetVLAD.forward.  storage="bf16": the
+    descriptor comes back as bf16 [B, D*K] (see _NetVLAD._forward_bf16)."""
     g, b, mm, mv = bn if bn is not None else (None, None, None, None)
     ig, ib = input_affine if input_affine is not None else (None, None)
     return _NetVLAD.apply(x, cluster_weights, g, b, mm, mv, bias, cluster_weights2, int(max_frames), bool(is_training),
-                          bool(kmajor), ig, ib)
+                          bool(kmajor), ig, ib, storage)
 
 
 def netvlad_input_shortcut_ok(T, D, K):

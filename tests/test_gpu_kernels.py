@@ -6,7 +6,7 @@ import torch
 
 from oracle import lpm_oracle as O
 from oracle import numpy_ref as R
-from tests._util import assert_close, cuda, rel_err
+from tests._util import assert_close, cuda, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -812,3 +812,82 @@ def test_raw_nrm_flag_is_rejected_by_the_fp32_backward():
     assert rc != 0
     with pytest.raises(_capi.LpmError, match="NRM_RAW"):
         lib.check(rc, "lpm_vlad_aggregate_bwd")
+
+
+# ---- bf16 storage (BASELINE configs[4]) ------------------------------------------------------------------------------------------
+BF16_FWD_TOL = 2e-2     # vs the exact fp64 oracle, max-norm relative: x, W, logits, assignment and descriptor are each rounded to bf16
+BF16_GRAD_TOL = 5e-2    # (2^-9 relative per element); measured values are printed by the test
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _ste(t):
+    """Round to bf16 in the forward, identity in the backward (what storing a tensor as bf16 between two fp32 computations does)."""
+    return t + (_bf(t) - t).detach()
+
+
+def _oracle_netvlad_bf16(x, W, gamma, beta, W2, T, dout):
+    """The oracle's NetVLAD (frame_level_models.py:2773-2824) with a bf16 rounding at every point where the bf16-storage path keeps a
+    tensor in HBM as bf16: frames, cluster weights (operand tiles), logits, assignment (operand tiles), descriptor."""
+    p = {"W": W.double().requires_grad_(True), "gamma": gamma.double().requires_grad_(True), "beta": beta.double().requires_grad_(True),
+         "W2": W2.double().requires_grad_(True)}
+    xr = _bf(x.double())
+    logits = xr @ _ste(p["W"])
+    mean, var = logits.mean(0), logits.var(0, unbiased=False)          # statistics come from the fp32 accumulators
+    lr = _ste(logits)
+    a = torch.softmax((lr - mean) * torch.rsqrt(var + O.BN_EPS) * p["gamma"] + p["beta"], dim=-1)
+    a = _ste(a).reshape(-1, T, a.shape[-1])
+    out = _ste(O.vlad_aggregate(a, xr.reshape(-1, T, xr.shape[-1]), p["W2"]))
+    out.backward(_bf(dout.double()))
+    return out.detach(), p
+
+
+def test_netvlad_bf16_storage():
+    """ops.netvlad(storage='bf16') on both streams of a 1152-wide input at the cfg-5 layer sizes (video 1024 x 512, audio 128 x 128):
+    forward and the gradients of every variable against (i) the oracle with bf16 roundings at the same storage points -- what the path
+    is supposed to compute, tight -- and (ii) the exact fp64 oracle under the documented bf16 tolerance."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, T = 4, 300
+    g = torch.Generator().manual_seed(12)
+    raw = torch.randn(B, T, 1152, generator=g)
+    nf = torch.full((B,), T, dtype=torch.int32)                 # T of T frames: the uniform sampler is the identity
+    y = ops.frame_sample_bn(raw.to(dev), nf.to(dev), T, storage="bf16", materialize=False)
+    res = {}
+    for name, off, D, K in (("video", 0, 1024, 512), ("audio", 1024, 128, 128)):
+        gg = torch.Generator().manual_seed(K)
+        W = torch.randn(D, K, generator=gg) / D ** 0.5
+        gamma, beta = 1 + 0.3 * torch.randn(K, generator=gg), 0.2 * torch.randn(K, generator=gg)
+        W2 = torch.randn(1, D, K, generator=gg) / D ** 0.5
+        dout = torch.randn(B, D * K, generator=gg)
+        x = raw.reshape(B * T, 1152)[:, off:off + D]
+        ref_b, pb = _oracle_netvlad_bf16(x, W, gamma, beta, W2, T, dout)
+        ref, _, pe, _ = _oracle_netvlad(x, W, gamma, beta, W2, T, dout)
+        Wg, gmg, btg, W2g = (t.to(dev).requires_grad_(True) for t in (W, gamma, beta, W2))
+        with torch.no_grad():
+            xs = y[:, off:off + D]
+        out = ops.netvlad(xs, Wg, W2g, T, bn=(gmg, btg, torch.zeros(K, device=dev), torch.ones(K, device=dev)), is_training=True,
+                          storage="bf16")
+        assert out.dtype == torch.bfloat16 and out.shape == (B, D * K)
+        out.backward(dout.to(dev).to(torch.bfloat16))
+        e = {"fwd vs bf16 oracle": rel_err(out.float(), ref_b), "fwd vs exact": rel_err(out.float(), ref)}
+        for nm, got, kb, ke in (("dW", Wg.grad, "W", "s/cluster_weights"), ("dgamma", gmg.grad, "gamma", "s/cluster_bn/gamma"),
+                                ("dbeta", btg.grad, "beta", "s/cluster_bn/beta"), ("dW2", W2g.grad, "W2", "s/cluster_weights2")):
+            e[nm + " vs bf16 oracle"] = rel_l2(got, pb[kb].grad)
+            e[nm + " vs exact"] = rel_l2(got, pe[ke].grad)
+        res[name] = e
+        print(f"[bf16 storage {name} D={D} K={K}] " + ", ".join(f"{k}: {v:.1e}" for k, v in e.items()))
+        assert e["fwd vs bf16 oracle"] <= 4e-3, "one bf16 ulp of the stored descriptor"
+        assert e["fwd vs exact"] <= BF16_FWD_TOL
+        for k, v in e.items():
+            if k.startswith("d") and k.endswith("bf16 oracle"):
+                assert v <= 2e-2, f"{name} {k}: {v:.2e}"           # the backward rounds dU, dl and the frames once more for its tiles
+            elif k.startswith("d"):
+                assert v <= BF16_GRAD_TOL, f"{name} {k}: {v:.2e}"
+        o = out.float().reshape(B, D, K)                          # norm invariants at bf16 resolution
+        assert torch.allclose(o.norm(dim=(1, 2)), torch.ones(B, device=dev), atol=4e-3)
+    # the fp32 frames were not materialised: an op that would read them says so instead of computing on garbage
+    with pytest.raises(Exception, match="bf16 operand tiles only"):
+        ops.netvlad(y[:, :1024].detach(), torch.zeros(1024, 128, device=dev), None, T, bias=torch.zeros(128, device=dev))

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import lpm_oracle as O
-from tests._util import assert_close, cuda, rel_l2
+from tests._util import assert_close, cuda, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -471,3 +471,92 @@ def test_checkpoint_resume_and_inference_csv(tmp_path):
     lines = out.getvalue().splitlines()
     assert lines[0] == "VideoId,LabelConfidencePairs" and len(lines) == B + 1
     assert lines[1].startswith("vid0,") and len(lines[1].split(",")[1].split()) == 10
+
+
+# ---- BASELINE configs[4]: "Gated NetVLAD K=512 + MoE-4 classifier, 300x1152 bf16, bs=1024 on 8xMI355X" = 128 clips per GPU ---------
+CFG5 = dict(iterations=300, cluster_size=512, hidden_size=1024, moe_num_mixtures=4, encoder=False)
+CFG5_FWD_TOL = 3e-2      # bf16 storage of frames / logits / assignment / descriptor against the exact fp64 oracle (max-norm relative)
+CFG5_GRAD_TOL = 6e-2     # whole-model gradients, Frobenius norm per variable; measured values are printed
+
+
+def _cfg5_trainer(B, dev, storage):
+    from learnablepoolingmethods_amd import FLAGS, registry
+    from learnablepoolingmethods_amd.train import Trainer
+    FLAGS.moe_num_mixtures, FLAGS.netvlad_storage = 4, storage
+    return Trainer(registry.get_model("NetVladV1"), vocab_size=3862, batch_size=B, base_learning_rate=2e-4, device=dev,
+                   model_kwargs=dict(iterations=300, cluster_size=512, hidden_size=1024, encoder=False))
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_cfg5_layer_sizes_reduced_batch(storage):
+    """cfg-5 at its real layer sizes (K = 512 / 128, hidden 1024, MoE-4, 300 x 1152, no cluster encoders) with 8 clips: intermediates,
+    loss, predictions and the gradient of every variable against the fp64 oracle -- with fp32 storage to the usual 1e-3, with the
+    bf16 storage the configuration names to the documented bf16 tolerance."""
+    from learnablepoolingmethods_amd import FLAGS
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", vocab_size=3862, base_learning_rate=2e-4, **CFG5)
+    B = 8
+    x, nf, lab = O.make_synthetic_batch(B, 300, 1152, cfg.vocab_size, seed=5)
+    p = _well_conditioned({k: v.double() for k, v in O.init_params(cfg, 1152, seed=1005).items()})
+    with torch.no_grad():
+        _, inter = O.model_forward(p, x.double(), nf, cfg, True, None, None, return_intermediates=True)
+    pred, loss, grads, _ = O.loss_and_grads(p, x.double(), nf, lab, cfg)
+    try:
+        tr = _cfg5_trainer(B, dev, storage)
+        tr.build(x, nf, lab)
+        tr.store.load({"tower/" + k: v for k, v in p.items()})
+        tr.store.summaries = {}
+        out = tr.step(x, nf, lab)
+        got, tr.store.summaries = tr.store.summaries, None
+    finally:
+        FLAGS.reset()
+    ftol, gtol = (1e-3, 1e-3) if storage == "f32" else (CFG5_FWD_TOL, CFG5_GRAD_TOL)
+    errs = {k: assert_close(got[k].float().reshape(inter[k].shape), inter[k], tol=ftol, what=f"cfg-5 {storage} {k}")
+            for k in ("vlad_video", "vlad_audio", "vlad", "activation")}
+    errs["loss"] = assert_close(out["loss"], loss, tol=ftol, what="loss")
+    errs["predictions"] = assert_close(out["predictions"], pred, tol=ftol, what="predictions")
+    gscale = max(float(g.abs().max()) for g in grads.values())
+    worst = (0.0, "")
+    for n in O.trainable_names(p, cfg):
+        a0, _ = tr.arena.segment("tower/" + n)
+        e = rel_l2(tr.arena.grad[a0:a0 + p[n].numel()].reshape(p[n].shape), grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5)
+        worst = max(worst, (e, n))
+        assert e <= gtol, f"cfg-5 {storage} gradient {n}: relative L2 error {e:.3e} > {gtol:.1e}"
+    print(f"[cfg-5 {storage} B={B}] " + ", ".join(f"{k}: {v:.1e}" for k, v in errs.items()) + f"; worst gradient {worst[0]:.2e} ({worst[1]})")
+
+
+def test_cfg5_full_batch_properties():
+    """cfg-5 at its full per-GPU batch (128 clips, bf16 storage), through size-independent properties: every pooled descriptor has
+    unit norm and every cluster column norm 1/sqrt(K) (frame_level_models.py:2819-2822) at bf16 resolution, the loss is finite and
+    goes down over a few steps on one batch, and the step equals the fp32-storage step of the same trainer state to bf16 accuracy."""
+    from learnablepoolingmethods_amd import FLAGS
+    dev = cuda()
+    B = 128
+    x, nf, lab = O.make_synthetic_batch(B, 300, 1152, 3862, seed=6)
+    res = {}
+    for storage in ("bf16", "f32"):
+        try:
+            tr = _cfg5_trainer(B, dev, storage)
+            tr.store._gen_seed = 77
+            tr.build(x, nf, lab)
+            with torch.no_grad():
+                tr.store.vars["tower/hidden1_weights"].mul_(0.02)
+            tr.store.summaries = {}
+            losses = [float(tr.step(x, nf, lab)["loss"])]
+            got, tr.store.summaries = tr.store.summaries, None
+            a0, _ = tr.arena.segment("tower/video_VLAD/cluster_weights")
+            res[storage] = (losses[0], got, tr.arena.grad[a0:a0 + 1024 * 512].clone())
+            if storage == "bf16":
+                for _ in range(3):
+                    losses.append(float(tr.step(x, nf, lab)["loss"]))
+                assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0], f"losses {losses}"
+                v = got["vlad_video"].float().reshape(B, 1024, 512)
+                assert torch.allclose(v.norm(dim=(1, 2)), torch.ones(B, device=dev), atol=4e-3)
+                assert torch.allclose(v.norm(dim=1), torch.full((B, 512), 512 ** -0.5, device=dev), atol=2e-3 * 512 ** -0.5 * 8)
+            del tr
+            torch.cuda.empty_cache()
+        finally:
+            FLAGS.reset()
+    assert abs(res["bf16"][0] - res["f32"][0]) <= CFG5_FWD_TOL * abs(res["f32"][0])
+    assert rel_err(res["bf16"][1]["vlad"].float(), res["f32"][1]["vlad"]) <= CFG5_FWD_TOL
+    assert rel_l2(res["bf16"][2], res["f32"][2]) <= CFG5_GRAD_TOL
