@@ -29,10 +29,34 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 METRIC = "clips/sec training step, NetVladV1 K=256 300-frame 1152-d, bs=80, 1/2/4/8 GPU"
-CFG = dict(iterations=300, cluster_size=256, hidden_size=512)           # README.md:12-18 with 300 frames (BASELINE)
-PER_GPU_BATCH, MAX_FRAMES, FEATURE, VOCAB = 80, 300, 1152, 3862
+MAX_FRAMES, FEATURE, VOCAB = 300, 1152, 3862
 TRAIN = dict(base_learning_rate=0.0002, learning_rate_decay=0.85, learning_rate_decay_examples=4000000)
 HBM_PEAK_GBS = 8000.0                                                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# The workloads bench.py can time.  cfg2 (the default, what the driver runs) is the configuration BASELINE.json's metric is quoted on;
+# cfg5 is BASELINE configs[4] at its per-GPU share (bs 1024 over 8 GPUs), the HBM-bound residual-aggregation showcase.
+WORKLOADS = {
+    "cfg2": dict(metric=METRIC, model_kwargs=dict(iterations=300, cluster_size=256, hidden_size=512),   # README.md:12-18, 300 frames
+                 oracle=dict(iterations=300, cluster_size=256, hidden_size=512), flags={}, batch=80, elt=4, dtype="f32", parity_tol=1e-3,
+                 workload="NetVladV1 K=256 hidden=512 rgb+audio 1152-d 300 frames, bs 80 per GPU (BASELINE configs[1]; configs[3] at "
+                          "8 GPUs), full training step",
+                 dtype_detail="fp32 storage and accumulation everywhere; K1, K2, K3, K4 and the encoder dense GEMMs feed the bf16 MFMA "
+                              "pipe with split-bf16 (hi+lo) operands, 3 MFMAs per product (~5e-6 relative error)"),
+    "cfg5": dict(metric="clips/sec training step, gated NetVLAD K=512 + MoE-4, 300-frame 1152-d bf16, bs=128 per GPU (BASELINE configs[4])",
+                 model_kwargs=dict(iterations=300, cluster_size=512, hidden_size=1024, encoder=False),
+                 oracle=dict(iterations=300, cluster_size=512, hidden_size=1024, encoder=False, moe_num_mixtures=4),
+                 flags=dict(moe_num_mixtures=4, netvlad_storage="bf16"), batch=128, elt=2, dtype="bf16", parity_tol=2e-2,
+                 workload="gated NetVLAD (NetVladV1 without the cluster encoders) K=512/128 hidden=1024 MoE-4, rgb+audio 1152-d 300 "
+                          "frames, bs 128 per GPU (BASELINE configs[4] = bs 1024 over 8 GPUs), full training step",
+                 dtype_detail="bf16 storage of the frames, logits / assignment and pooled descriptor of both NetVLAD streams, one bf16 MFMA "
+                              "per product with fp32 accumulation; batch statistics, norms, projection, gating, MoE, gradients and the "
+                              "optimiser in fp32"),
+}
+
+
+def set_flags(wl):
+    from learnablepoolingmethods_amd import FLAGS
+    for k, v in wl["flags"].items():
+        setattr(FLAGS, k, v)
 
 
 def synthetic_batch(batch, device, seed):
@@ -51,14 +75,14 @@ def synthetic_batch(batch, device, seed):
 
 
 def k2_algorithmic_bytes(B, T, D, K, elt=4):
-    """read assignment logits + frames once, W2 once per batch, write the descriptor once."""
-    return elt * (B * T * K + B * T * D + D * K + B * D * K)
+    """read assignment logits + frames once, W2 (fp32) once per batch, write the descriptor once."""
+    return elt * (B * T * K + B * T * D + B * D * K) + 4 * D * K
 
 
-def cpu_baseline(budget_s):
+def cpu_baseline(budget_s, wl):
     """The oracle's train_step (fp32, torch CPU) on a bounded sample of the same workload."""
     from oracle import lpm_oracle as O
-    cfg = O.OracleConfig(model="NetVladV1", **CFG, **TRAIN)
+    cfg = O.OracleConfig(model="NetVladV1", **wl["oracle"], **TRAIN)
     b = 4
     torch.set_flush_denormal(True)   # as TF's CPU kernels do; g*g underflows to denormals in Adam otherwise (100x slower)
     x, nf, lab = O.make_synthetic_batch(b, MAX_FRAMES, FEATURE, VOCAB, seed=0)
@@ -78,19 +102,21 @@ def cpu_baseline(budget_s):
         times = [warm]
     med = sorted(times)[len(times) // 2]
     return {"value": round(b / med, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/lpm_oracle.train_step fp32 torch-CPU, same NetVladV1 cfg-2 layer sizes, batch {b} "
+            "sample": f"oracle/lpm_oracle.train_step fp32 torch-CPU, the workload's layer sizes, batch {b} "
                       f"(1 warm-up + {len(times)} timed steps, median {med:.2f} s/step); stand-in for the TF1 "
                       f"reference, which cannot run here (SURVEY F2)"}, first
 
 
-def parity_check(first, device):
+def parity_check(first, device, wl):
     """output parity asserted in the same run, outside the timed region.  The CPU baseline's first step (the oracle
     from its seeded reference-style initialisation on its seeded 4-clip batch of the bench workload's layer sizes) is repeated by
     the HIP path from the same weights: loss and predictions must agree to the north-star's 1e-3."""
     from learnablepoolingmethods_amd import registry
     from learnablepoolingmethods_amd.train import Trainer
     b = first["x"].shape[0]
-    tr = Trainer(registry.get_model("NetVladV1"), vocab_size=VOCAB, batch_size=b, device=device, seed=1, model_kwargs=CFG, **TRAIN)
+    tol = wl["parity_tol"]
+    tr = Trainer(registry.get_model("NetVladV1"), vocab_size=VOCAB, batch_size=b, device=device, seed=1, model_kwargs=wl["model_kwargs"],
+                 **TRAIN)
     tr.build(first["x"], first["nf"], first["lab"])
     tr.store.load({"tower/" + k: v for k, v in first["params"].items()})
     out = tr.step(first["x"], first["nf"], first["lab"])
@@ -99,8 +125,8 @@ def parity_check(first, device):
     e_pred = float((pred - ref).abs().max() / ref.abs().max())
     e_loss = abs(float(out["loss"]) - float(first["loss"])) / abs(float(first["loss"]))
     res = {"against": "cpu_baseline's first step (fp32 oracle, same weights, its 4-clip sample of the workload)",
-           "predictions_max_rel_err": float(f"{e_pred:.3e}"), "loss_rel_err": float(f"{e_loss:.3e}"), "tolerance": 1e-3,
-           "ok": bool(e_pred <= 1e-3 and e_loss <= 1e-3)}
+           "predictions_max_rel_err": float(f"{e_pred:.3e}"), "loss_rel_err": float(f"{e_loss:.3e}"), "tolerance": tol,
+           "ok": bool(e_pred <= tol and e_loss <= tol)}
     del tr
     torch.cuda.empty_cache()
     return res
@@ -150,6 +176,8 @@ def main():
                          "first second, 8.4-8.7k afterwards)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg2",
+                    help="cfg2 (default): the configuration BASELINE.json's metric is quoted on; cfg5: BASELINE configs[4] per GPU")
     ap.add_argument("--watchdog-seconds", type=float, default=240.0,
                     help="N > 1 only: a rank that makes no progress for this long prints its phase and last collective and exits 3")
     args = ap.parse_args()
@@ -183,8 +211,11 @@ def main():
     from learnablepoolingmethods_amd import ops, registry
     from learnablepoolingmethods_amd.train import Trainer
 
+    wl = WORKLOADS[args.config]
+    set_flags(wl)
+    PER_GPU_BATCH = wl["batch"]
     model = registry.get_model("NetVladV1")
-    trainer = Trainer(model, vocab_size=VOCAB, batch_size=PER_GPU_BATCH, device=device, seed=1234, model_kwargs=CFG, **TRAIN)
+    trainer = Trainer(model, vocab_size=VOCAB, batch_size=PER_GPU_BATCH, device=device, seed=1234, model_kwargs=wl["model_kwargs"], **TRAIN)
     raw, nf, labels = synthetic_batch(PER_GPU_BATCH, device, seed=rank)
 
     def barrier(what="barrier"):
@@ -259,10 +290,13 @@ def main():
             # steps); the event pairs recorded AROUND the launch call also bracket cross-queue dispatch gaps now that the
             # audio branch runs on a second stream, and are kept only as a fallback
             avg_ms = sum(k2_ms) / len(k2_ms) if k2_ms else sum(t for _, t in k2) / len(k2)
-            bytes_ = k2_algorithmic_bytes(B, T, D, K)
+            elt = wl["elt"]
+            bytes_ = k2_algorithmic_bytes(B, T, D, K, elt)
             ach = bytes_ / (avg_ms * 1e-3) / 1e9
             prec = ops.VLAD_PRECISION
-            if prec == "bf16x3":
+            if elt == 2:
+                kname = "vlad_aggregate_tiles3_kernel<false,1> (K2, video stream, plain bf16 tiles, one MFMA per product, LDS-DMA)"
+            elif prec == "bf16x3":
                 kname = ("vlad_aggregate_tiles3_kernel (K2, video stream, split-bf16 MFMA, LDS-DMA tiles)" if ops.VLAD_TILES3
                          else "vlad_aggregate_tiles_kernel<8> (K2, video stream, split-bf16 MFMA, register streaming)")
             else:
@@ -279,19 +313,31 @@ def main():
                 if tt:
                     roof[nm + "_avg_ms"] = round(sum(tt) / len(tt), 4)
             pmc = os.path.join(ROOT, "profiles", "k2_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and args.config == "cfg2":
                 try:
                     roof["traffic"] = json.load(open(pmc)).get("bytes_per_launch")
                 except Exception:
                     pass
-        line = {"metric": METRIC, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            # the WHOLE a5 function (frame_level_models.py:2798-2822: BN-affine + softmax -> residual aggregation -> both
+            # normalisations) as the chain of launches that computes it for the video stream: assignment tiles + K2 + finalize.
+            # Event pairs recorded around each launch call on its stream (they include the gap to the previous launch).
+            chain = {}
+            pick = {"assign_tiles": lambda d: d[2] == K, "vlad_aggregate_fwd": lambda d: d[2] == D, "vlad_finalize": lambda d: d[1] == D}
+            for nm, want in pick.items():
+                tt = [a.elapsed_time(b) for (n, d, a, b) in timeline if n == nm and want(d)]
+                if tt:
+                    chain[nm] = sum(tt) / len(tt)
+            if len(chain) == 3:
+                tot = sum(chain.values())
+                roof["a5_function"] = {"launches": "lpm_assign_tiles + K2 + lpm_vlad_finalize2_fwd (video stream)",
+                                       "ms": {k: round(v, 4) for k, v in chain.items()}, "total_ms": round(tot, 4),
+                                       "algorithmic_bytes": bytes_, "achieved": round(bytes_ / (tot * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                       "frac": round(bytes_ / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "timing": "HIP event pairs around each launch call (include inter-launch gaps)"}
+        line = {"metric": wl["metric"], "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "spinup_steps": spin, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "dtype_detail": "fp32 storage and accumulation everywhere; K1, K2, K3, K4 and the encoder dense GEMMs feed the bf16 "
-                                "MFMA pipe with split-bf16 (hi+lo) operands, 3 MFMAs per product (~5e-6 relative error)",
-                "config": {"workload": "NetVladV1 K=256 hidden=512 rgb+audio 1152-d 300 frames, bs 80 per GPU "
-                                       "(BASELINE configs[1]; configs[3] at 8 GPUs), full training step",
-                           "global_batch": global_batch, "seq_len": MAX_FRAMES, "parallelism": f"dp{world}"},
+                "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic", "dtype_detail": wl["dtype_detail"],
+                "config": {"workload": wl["workload"], "global_batch": global_batch, "seq_len": MAX_FRAMES, "parallelism": f"dp{world}"},
                 "final_loss": round(loss, 4)}
         if roof:
             line["roofline"] = roof
@@ -299,7 +345,11 @@ def main():
             M, D, K = k1[0][0]
             avg_ms = sum(k1_ms) / len(k1_ms) if k1_ms else sum(t for _, t in k1) / len(k1)
             fl = 2.0 * M * D * K
-            if ops.ASSIGN_PRECISION == "bf16x3":
+            if wl["elt"] == 2:
+                line["assign_gemm"] = {"avg_kernel_ms": round(avg_ms, 4), "tflops": round(fl / (avg_ms * 1e-3) / 1e12, 2),
+                                       "mfma": "v_mfma_f32_32x32x16_bf16 (plain bf16 operands, fp32 accumulate)",
+                                       "mfma_util_vs_bf16_peak": round(fl / (avg_ms * 1e-3) / 2.5e15, 3)}
+            elif ops.ASSIGN_PRECISION == "bf16x3":
                 # split-bf16: 3 bf16 MFMAs per product -> matrix-pipe utilisation = 3 x useful flops / dense bf16 peak
                 line["assign_gemm"] = {"avg_kernel_ms": round(avg_ms, 4), "tflops": round(fl / (avg_ms * 1e-3) / 1e12, 2),
                                        "mfma": "v_mfma_f32_32x32x16_bf16 x3 (split-bf16 operands, fp32 accumulate)",
@@ -318,8 +368,8 @@ def main():
                                  "achieved": round(byts / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(byts / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], first = cpu_baseline(args.cpu_baseline_seconds)
-            line["parity"] = parity_check(first, device)
+            line["cpu_baseline"], first = cpu_baseline(args.cpu_baseline_seconds, wl)
+            line["parity"] = parity_check(first, device, wl)
         print(json.dumps(line), flush=True)
         if "parity" in line and not line["parity"]["ok"]:
             raise SystemExit(f"bench.py: parity check failed: {line['parity']}")

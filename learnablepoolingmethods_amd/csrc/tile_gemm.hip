@@ -579,7 +579,8 @@ extern "C" int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, in
 }
 
 extern "C" size_t lpm_assign_gemm_tiles_bwd_dw_workspace_bytes(int B, int T, int D, int K) {
-    return (size_t)lpm::dw_splits(B, T, D, K) * D * K * sizeof(float);     // (covers the plain-bf16 form: never more splits)
+    const int z2 = lpm::dw_splits(B, T, D, K, 2), z1 = lpm::dw_splits(B, T, D, K, 1);      // split-bf16 / plain-bf16 tile forms
+    return (size_t)(z1 > z2 ? z1 : z2) * D * K * sizeof(float);
 }
 
 static int assign_gemm_tiles_bwd_dw_impl(const void* xt, const void* dlt, int B, int T, int D, int K, float* dW, void* workspace,

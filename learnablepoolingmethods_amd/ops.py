@@ -389,8 +389,9 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
             out = _empty((B, K, D) if kmajor else (B, D * K), x)
             gsq = _empty((B,), x)
             ffl = (LPM_VLAD_OUT_KMAJOR if kmajor else 0) | (LPM_VLAD_NRM_RAW if nrm_raw else 0)
-            lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, ffl, ptr(out), ptr(colsq), ptr(csq), ptr(gsq), st),
-                      "lpm_vlad_finalize2_fwd")
+            with _timed("vlad_finalize", (B, D, K)):
+                lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, ffl, ptr(out), ptr(colsq), ptr(csq), ptr(gsq), st),
+                          "lpm_vlad_finalize2_fwd")
             return out, nrm, asum, colsq, csq, gsq, xt
         if nrm_raw:
             raise LpmError("internal: nrm_raw without the LDS-shared aggregation form")

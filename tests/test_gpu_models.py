@@ -475,8 +475,8 @@ def test_checkpoint_resume_and_inference_csv(tmp_path):
 
 # ---- BASELINE configs[4]: "Gated NetVLAD K=512 + MoE-4 classifier, 300x1152 bf16, bs=1024 on 8xMI355X" = 128 clips per GPU ---------
 CFG5 = dict(iterations=300, cluster_size=512, hidden_size=1024, moe_num_mixtures=4, encoder=False)
-CFG5_FWD_TOL = 3e-2      # bf16 storage of frames / logits / assignment / descriptor against the exact fp64 oracle (max-norm relative)
-CFG5_GRAD_TOL = 6e-2     # whole-model gradients, Frobenius norm per variable; measured values are printed
+CFG5_FWD_TOL = 2e-2      # bf16 storage of frames / logits / assignment / descriptor against the exact fp64 oracle (max-norm relative);
+CFG5_GRAD_TOL = 3e-2     # whole-model gradients, Frobenius norm per variable.  Measured: descriptors 7e-3, gradients <= 7.5e-3 (printed)
 
 
 def _cfg5_trainer(B, dev, storage):
