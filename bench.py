@@ -270,6 +270,7 @@ def main():
         n = lib._lpm_kernel_timing_read(tag, buf, 4096)
         return [float(buf[i]) for i in range(n)]
     k1_ms, k2_ms = kernel_ms(1), kernel_ms(2)
+    at_ms, fin_ms = kernel_ms(3), kernel_ms(4)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,20 +321,15 @@ def main():
                     pass
             # the WHOLE a5 function (frame_level_models.py:2798-2822: BN-affine + softmax -> residual aggregation -> both
             # normalisations) as the chain of launches that computes it for the video stream: assignment tiles + K2 + finalize.
-            # Event pairs recorded around each launch call on its stream (they include the gap to the previous launch).
-            chain = {}
-            pick = {"assign_tiles": lambda d: d[2] == K, "vlad_aggregate_fwd": lambda d: d[2] == D, "vlad_finalize": lambda d: d[1] == D}
-            for nm, want in pick.items():
-                tt = [a.elapsed_time(b) for (n, d, a, b) in timeline if n == nm and want(d)]
-                if tt:
-                    chain[nm] = sum(tt) / len(tt)
-            if len(chain) == 3:
+            # Durations of the kernels themselves (start / stop events attached to each launch).
+            if at_ms and fin_ms and k2_ms:
+                chain = {"assign_tiles": sum(at_ms) / len(at_ms), "vlad_aggregate": avg_ms, "vlad_finalize": sum(fin_ms) / len(fin_ms)}
                 tot = sum(chain.values())
                 roof["a5_function"] = {"launches": "lpm_assign_tiles + K2 + lpm_vlad_finalize2_fwd (video stream)",
-                                       "ms": {k: round(v, 4) for k, v in chain.items()}, "total_ms": round(tot, 4),
+                                       "kernel_ms": {k: round(v, 4) for k, v in chain.items()}, "total_ms": round(tot, 4),
                                        "algorithmic_bytes": bytes_, "achieved": round(bytes_ / (tot * 1e-3) / 1e9, 1), "unit": "GB/s",
                                        "frac": round(bytes_ / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "timing": "HIP event pairs around each launch call (include inter-launch gaps)"}
+                                       "timing": "HIP events attached to each launch (kernel durations; gaps between the launches excluded)"}
         line = {"metric": wl["metric"], "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "spinup_steps": spin, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic", "dtype_detail": wl["dtype_detail"],

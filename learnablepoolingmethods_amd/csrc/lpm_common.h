@@ -19,7 +19,7 @@ constexpr float kL2Eps = 1e-12f;  // tf.nn.l2_normalize epsilon
 // thread-local error string behind lpm_last_error()
 void set_error(const char* fmt, ...);
 // kernel timing (lpm_api.hip): when enabled, hands out a start/stop event pair for a hipExtLaunchKernelGGL launch
-enum { LPM_TIMING_K1 = 1, LPM_TIMING_K2 = 2 };
+enum { LPM_TIMING_K1 = 1, LPM_TIMING_K2 = 2, LPM_TIMING_ASSIGN_TILES = 3, LPM_TIMING_FINALIZE = 4 };   // (video-stream launches)
 bool timing_request(int tag, hipEvent_t* e0, hipEvent_t* e1);
 
 inline int check_launch(const char* what) {

@@ -374,7 +374,11 @@ extern "C" int lpm_assign_tiles(const float* assign, const float* scale, const f
     LPM_REQUIRE(B > 0 && T > 0 && K > 0 && K <= 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_assign_tiles: need 0 < K <= 1024 (K=%d)", K);
     const int S = vt_steps(T), KT = (K + 31) / 32;
     const size_t lds = (size_t)16 * (KT * 32 + 1) * sizeof(float);
-    if (flags & LPM_VLAD_SOFTMAX)
+    hipEvent_t e0, e1;
+    if ((flags & LPM_VLAD_SOFTMAX) && K >= 256 && timing_request(LPM_TIMING_ASSIGN_TILES, &e0, &e1))
+        hipExtLaunchKernelGGL((assign_tiles_kernel<true, false>), dim3(B * S), dim3(256), lds, (hipStream_t)stream, e0, e1, 0, assign, scale,
+                              shift, T, K, S, KT, (uint4*)at);
+    else if (flags & LPM_VLAD_SOFTMAX)
         hipLaunchKernelGGL((assign_tiles_kernel<true, false>), dim3(B * S), dim3(256), lds, (hipStream_t)stream, assign, scale, shift, T, K, S,
                            KT, (uint4*)at);
     else
@@ -392,7 +396,11 @@ extern "C" int lpm_assign_tiles_bf16(const void* assign_bf16, const float* scale
     LPM_REQUIRE(B > 0 && T > 0 && K > 0 && K <= 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_assign_tiles_bf16: need 0 < K <= 1024 (K=%d)", K);
     const int S = 4 * ((T + 63) / 64), KT = (K + 31) / 32;
     const size_t lds = (size_t)16 * (KT * 32 + 1) * sizeof(float);
-    if (flags & LPM_VLAD_SOFTMAX)
+    hipEvent_t e0, e1;
+    if ((flags & LPM_VLAD_SOFTMAX) && K >= 256 && timing_request(LPM_TIMING_ASSIGN_TILES, &e0, &e1))
+        hipExtLaunchKernelGGL((assign_tiles_kernel<true, true>), dim3(B * S), dim3(256), lds, (hipStream_t)stream, e0, e1, 0,
+                              (const float*)assign_bf16, scale, shift, T, K, S, KT, (uint4*)at);
+    else if (flags & LPM_VLAD_SOFTMAX)
         hipLaunchKernelGGL((assign_tiles_kernel<true, true>), dim3(B * S), dim3(256), lds, (hipStream_t)stream, (const float*)assign_bf16,
                            scale, shift, T, K, S, KT, (uint4*)at);
     else

@@ -626,7 +626,12 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
                 set_error("lpm_vlad_finalize2_fwd: cannot reserve %zu bytes of LDS", lds4);
                 return LPM_ERR_LAUNCH;
             }
-            hipLaunchKernelGGL(kern, grid4, dim3(256), lds4, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq, csq, gsq, keep_u);
+            hipEvent_t e0, e1;
+            if (D >= 1024 && timing_request(LPM_TIMING_FINALIZE, &e0, &e1))
+                hipExtLaunchKernelGGL(kern, grid4, dim3(256), lds4, (hipStream_t)stream, e0, e1, 0, nrm, colsq_part, P, D, K, out, colsq, csq,
+                                      gsq, keep_u);
+            else
+                hipLaunchKernelGGL(kern, grid4, dim3(256), lds4, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq, csq, gsq, keep_u);
             return check_launch("lpm_vlad_finalize2_fwd");
         };
         return R == 64 ? launch(vlad_finalize2_kmajor4_kernel<64>) : launch(vlad_finalize2_kmajor4_kernel<32>);
@@ -634,8 +639,14 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
     if (flags & LPM_VLAD_OUT_KMAJOR)
         hipLaunchKernelGGL(vlad_finalize2_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq,
                            csq, gsq, keep_u, 0);
-    else
-        hipLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out,
-                           colsq, csq, gsq, keep_u, out_bf16);
+    else {
+        hipEvent_t e0, e1;
+        if (D >= 1024 && timing_request(LPM_TIMING_FINALIZE, &e0, &e1))
+            hipExtLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, e0, e1, 0, nrm, colsq_part, P, D, K,
+                                  out, colsq, csq, gsq, keep_u, out_bf16);
+        else
+            hipLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out,
+                               colsq, csq, gsq, keep_u, out_bf16);
+    }
     return check_launch("lpm_vlad_finalize2_fwd");
 }

@@ -92,8 +92,9 @@ def _rows(t: torch.Tensor, what: str) -> torch.Tensor:
 
 
 def _materialised(t: torch.Tensor, what: str) -> torch.Tensor:
-    base = t._base if t._base is not None else t
-    if getattr(base, "_lpm_unmaterialised", False):
+    """Refuse to read the fp32 handle of frames that frame_sample_bn(storage='bf16', materialize=False) wrote as tiles only."""
+    c = _XT_CACHE
+    if c and c.get("unmaterialised") is not None and c["base"]() is not None and t.untyped_storage().data_ptr() == c["unmaterialised"]:
         raise LpmError(f"{what}: these frames exist as bf16 operand tiles only (frame_sample_bn(storage='bf16', materialize=False))")
     return t
 
@@ -185,10 +186,9 @@ class _FrameSampleBN(torch.autograd.Function):
             lib.check(lib._lpm_frame_apply_tiles_bf16(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(y) if materialize else None,
                                                       ptr(xtv), ptr(xrv), Dv, ptr(xta), ptr(xra), Da, stream_ptr()),
                       "lpm_frame_apply_tiles_bf16")
-            y._lpm_unmaterialised = not materialize
             _XT_CACHE.clear()
             _XT_CACHE.update(base=weakref.ref(y), F=F, Dv=Dv, S=S, B=B, video=xtv, audio=xta, video_rows=xrv, audio_rows=xra,
-                             storage="bf16")
+                             storage="bf16", unmaterialised=None if materialize else y.untyped_storage().data_ptr())
         elif tiles:
             Dv, Da = 1024, F - 1024
             xtv = torch.empty(lib._lpm_xt_bytes(B, S, Dv) // 4, dtype=torch.int32, device=raw.device)
