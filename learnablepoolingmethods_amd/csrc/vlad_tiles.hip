@@ -150,6 +150,156 @@ __global__ __launch_bounds__(256) void assign_tiles_kernel(const float* __restri
     }
 }
 
+// Second form of the assignment-tile kernel for K = 64 VPL, VPL in {1, 2, 4, 8} (every NetVLAD stream of the BASELINE configurations):
+// a lane owns VPL CONSECUTIVE clusters, so a row is one or two 16-byte loads per lane, and the four rows of a wave are loaded,
+// reduced and exponentiated together -- 4 x the loads in flight and a quarter of the dependent wave-reduction chains of the
+// row-at-a-time form above (cfg-2 video 17.8 -> see DESIGN; cfg-5 video, K = 512: 52.7 us before).  LDS tile [16][K + 4] (rows
+// 16-byte aligned for the lane's vector store; the column-wise reads of the tile emission hit bank 4 r + i: conflict-free).
+template <bool SOFTMAX, bool BF16IN, int VPL>
+__global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restrict__ assign, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int T, int S, uint4* __restrict__ at) {
+    constexpr int K = 64 * VPL, KS = K + 4, KT = K / 32;
+    __shared__ __attribute__((aligned(16))) float as[16 * KS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / S, s = blockIdx.x % S;
+    const int c0 = lane * VPL;
+    float sc[VPL], sh[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        sc[j] = (SOFTMAX && scale) ? scale[c0 + j] : 1.f;
+        sh[j] = (SOFTMAX && shift) ? shift[c0 + j] : 0.f;
+    }
+    float v[4][VPL];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int t = 16 * s + wave * 4 + rr;
+        if (t < T) {                                         // wave-uniform
+            if (BF16IN) {
+                const unsigned short* p = reinterpret_cast<const unsigned short*>(assign) + ((int64_t)b * T + t) * K + c0;
+                if (VPL == 8) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(p);
+                    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[rr][2 * j] = bf16_to_f32(w[j] & 0xffffu);
+                        v[rr][2 * j + 1] = bf16_to_f32(w[j] >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) v[rr][j] = bf16_to_f32(p[j]);
+                }
+            } else {
+                const float* p = assign + ((int64_t)b * T + t) * K + c0;
+                if (VPL % 4 == 0) {
+#pragma unroll
+                    for (int j = 0; j < VPL; j += 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(p + j);
+                        v[rr][j] = q.x; v[rr][j + 1] = q.y; v[rr][j + 2] = q.z; v[rr][j + 3] = q.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) v[rr][j] = p[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) v[rr][j] = 0.f;
+        }
+    }
+    if (SOFTMAX) {
+        float m[4], sum[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            m[rr] = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                v[rr][j] = fmaf(v[rr][j], sc[j], sh[j]);
+                m[rr] = fmaxf(m[rr], v[rr][j]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) m[rr] = fmaxf(m[rr], __shfl_xor(m[rr], o, 64));
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            sum[rr] = 0.f;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                v[rr][j] = __expf(v[rr][j] - m[rr]);
+                sum[rr] += v[rr][j];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) sum[rr] += __shfl_xor(sum[rr], o, 64);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const bool live = 16 * s + wave * 4 + rr < T;
+            const float inv = live ? 1.f / sum[rr] : 0.f;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) v[rr][j] *= inv;
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        float* dst = as + (wave * 4 + rr) * KS + c0;
+        if (VPL % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < VPL; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(v[rr][j], v[rr][j + 1], v[rr][j + 2], v[rr][j + 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) dst[j] = v[rr][j];
+        }
+    }
+    __syncthreads();
+    for (int slot = tid; slot < KT * 64; slot += 256) {
+        const int kt = slot >> 6, ln = slot & 63;
+        const int kh = ln >> 5, i = ln & 31;
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = as[(8 * kh + e) * KS + kt * 32 + i];
+        uint4 hi, lo;
+        split8(w, hi, lo);
+        if (BF16IN) {
+            at[(((int64_t)b * KT + kt) * S + s) * 64 + ln] = hi;
+            continue;
+        }
+        const int64_t base = ((((int64_t)b * KT + kt) * S + s) * 2) * 64 + ln;
+        at[base] = hi;
+        at[base + 64] = lo;
+    }
+}
+
+template <bool BF16IN>
+static bool launch_assign_tiles2(const void* assign, const float* scale, const float* shift, int B, int T, int K, int S, int softmax,
+                                 void* at, hipStream_t stream, int timing_tag) {
+    if (K != 64 && K != 128 && K != 256 && K != 512) return false;
+    if ((((uintptr_t)assign | (uintptr_t)at) & 15) != 0) return false;
+    static const int on = [] { const char* e = getenv("LPM_ASSIGN_TILES2"); return (e && e[0] == '0') ? 0 : 1; }();     // 0: first form (A/B)
+    if (!on) return false;
+    hipEvent_t e0, e1;
+    const bool timed = timing_tag && timing_request(timing_tag, &e0, &e1);
+#define LPM_AT2(SM, VPL)                                                                                                            \
+    do {                                                                                                                            \
+        if (timed)                                                                                                                  \
+            hipExtLaunchKernelGGL((assign_tiles2_kernel<SM, BF16IN, VPL>), dim3(B * S), dim3(256), 0, stream, e0, e1, 0, (const float*)assign, \
+                                  scale, shift, T, S, (uint4*)at);                                                                  \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((assign_tiles2_kernel<SM, BF16IN, VPL>), dim3(B * S), dim3(256), 0, stream, (const float*)assign, scale, shift, \
+                               T, S, (uint4*)at);                                                                                   \
+    } while (0)
+#define LPM_AT2_K(SM)                                                                                                               \
+    do {                                                                                                                            \
+        if (K == 64) LPM_AT2(SM, 1); else if (K == 128) LPM_AT2(SM, 2); else if (K == 256) LPM_AT2(SM, 4); else LPM_AT2(SM, 8);      \
+    } while (0)
+    if (softmax) LPM_AT2_K(true); else LPM_AT2_K(false);
+#undef LPM_AT2_K
+#undef LPM_AT2
+    return true;
+}
+
 // ---- AT, XT -> intra-normalised descriptor --------------------------------------------------------
 constexpr int VT_WS = 36;    // per-wave LDS tile row stride (floats): 144 B keeps float4 accesses aligned and
                              // conflict-free for the "one row per lane" walk (144*i mod 256 are 16 distinct slots)
@@ -373,6 +523,9 @@ extern "C" int lpm_assign_tiles(const float* assign, const float* scale, const f
     LPM_REQUIRE(assign && at, LPM_ERR_BADARG, "lpm_assign_tiles: null pointer");
     LPM_REQUIRE(B > 0 && T > 0 && K > 0 && K <= 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_assign_tiles: need 0 < K <= 1024 (K=%d)", K);
     const int S = vt_steps(T), KT = (K + 31) / 32;
+    if (launch_assign_tiles2<false>(assign, scale, shift, B, T, K, S, (flags & LPM_VLAD_SOFTMAX) ? 1 : 0, at, (hipStream_t)stream,
+                                    K >= 256 ? LPM_TIMING_ASSIGN_TILES : 0))
+        return check_launch("lpm_assign_tiles");
     const size_t lds = (size_t)16 * (KT * 32 + 1) * sizeof(float);
     hipEvent_t e0, e1;
     if ((flags & LPM_VLAD_SOFTMAX) && K >= 256 && timing_request(LPM_TIMING_ASSIGN_TILES, &e0, &e1))
@@ -395,6 +548,9 @@ extern "C" int lpm_assign_tiles_bf16(const void* assign_bf16, const float* scale
     LPM_REQUIRE(assign_bf16 && at, LPM_ERR_BADARG, "lpm_assign_tiles_bf16: null pointer");
     LPM_REQUIRE(B > 0 && T > 0 && K > 0 && K <= 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_assign_tiles_bf16: need 0 < K <= 1024 (K=%d)", K);
     const int S = 4 * ((T + 63) / 64), KT = (K + 31) / 32;
+    if (launch_assign_tiles2<true>(assign_bf16, scale, shift, B, T, K, S, (flags & LPM_VLAD_SOFTMAX) ? 1 : 0, at, (hipStream_t)stream,
+                                   K >= 256 ? LPM_TIMING_ASSIGN_TILES : 0))
+        return check_launch("lpm_assign_tiles_bf16");
     const size_t lds = (size_t)16 * (KT * 32 + 1) * sizeof(float);
     hipEvent_t e0, e1;
     if ((flags & LPM_VLAD_SOFTMAX) && K >= 256 && timing_request(LPM_TIMING_ASSIGN_TILES, &e0, &e1))
