@@ -49,6 +49,8 @@ enum {
     LPM_VLAD_OUT_BF16 = 16,    /* lpm_vlad_finalize2_fwd: `out` is bf16 storage (d-major layout only)                   */
     LPM_VLAD_TILES_BF16 = 32,  /* lpm_vlad_aggregate_bwd_tiles: bf16 storage -- xr and the dU tiles are plain bf16 tiles, `assign`
                                   holds bf16 logits                                                                         */
+    LPM_VLAD_NRM_BF16 = 64,    /* lpm_vlad_finalize2_fwd: `nrm` holds the un-normalised sums as bf16 (what lpm_vlad_aggregate_tiles3_fwd_bf16
+                                  writes; with LPM_VLAD_NRM_RAW); implied by LPM_VLAD_TILES_BF16 in lpm_vlad_aggregate_bwd_tiles   */
     LPM_VLAD_DEBUG_FALLBACK = 256 /* lpm_vlad_aggregate_fused_fwd, tests only: one workgroup of every clip behaves as if its wait
                                   for the clip had timed out, so the follow-up finalize pass runs for every clip             */
 };
@@ -226,8 +228,9 @@ int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, const float* ce
  *   lpm_split_weight_tiles_bf16 / lpm_split_frames_bf16 : fp32 matrix -> plain bf16 weight / frame tiles (half the split form's size)
  *   lpm_assign_gemm_tiles_fwd_bf16 : K1; logits stored as bf16 [B*T, K], BN partial statistics from the fp32 accumulators
  *   lpm_assign_tiles_bf16          : bf16 logits -> [affine -> softmax] -> plain bf16 assignment tiles
- *   lpm_vlad_aggregate_tiles3_fwd_bf16 : K2 on those tiles (fp32 sums out, as lpm_vlad_aggregate_tiles3_fwd);
- *                                lpm_vlad_finalize2_fwd with LPM_VLAD_OUT_BF16 then writes the bf16 descriptor [B, D*K]
+ *   lpm_vlad_aggregate_tiles3_fwd_bf16 : K2 on those tiles; `nrm` receives the un-normalised sums AS bf16 [B, D, K], the partial
+ *                                norms come from the fp32 accumulators; lpm_vlad_finalize2_fwd with LPM_VLAD_NRM_RAW |
+ *                                LPM_VLAD_NRM_BF16 | LPM_VLAD_OUT_BF16 then writes the bf16 descriptor [B, D*K]
  *   lpm_assign_gemm_tiles_bwd_dw_bf16, lpm_vlad_aggregate_bwd_tiles with LPM_VLAD_TILES_BF16 : the backward on plain bf16 tiles */
 size_t lpm_frame_tiles_bf16_bytes(int B, int S, int D);
 int lpm_frame_steps_bf16(int T);

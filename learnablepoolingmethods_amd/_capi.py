@@ -21,6 +21,7 @@ LPM_VLAD_OUT_KMAJOR = 4
 LPM_VLAD_NRM_RAW = 8
 LPM_VLAD_OUT_BF16 = 16
 LPM_VLAD_TILES_BF16 = 32
+LPM_VLAD_NRM_BF16 = 64
 LPM_VLAD_DEBUG_FALLBACK = 256
 
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header

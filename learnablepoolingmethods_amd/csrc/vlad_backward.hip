@@ -76,18 +76,29 @@ static void launch_kmajor_to_dmajor(const float* src, int B, int D, int K, float
         hipLaunchKernelGGL(vlad_kmajor_to_dmajor_kernel, dim3(D / 32, (K + 31) / 32, B), dim3(256), 0, s, src, D, K, dst);
 }
 
+// bf16 storage: N points at bf16 values (the un-normalised sums as lpm_vlad_aggregate_tiles3_fwd_bf16 stores them)
+__device__ __forceinline__ float vb_ld(const float* p, int64_t i, int bf16) {
+    return bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16) : p[i];
+}
+__device__ __forceinline__ float4 vb_ld4(const float* p, int64_t i4, int bf16) {       // i4: index in units of 4 elements
+    if (!bf16) return reinterpret_cast<const float4*>(p)[i4];
+    const uint2 q = reinterpret_cast<const uint2*>(p)[i4];
+    return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                       __uint_as_float(q.y & 0xffff0000u));
+}
+
 // dots[b][split][0..2][k]: <dO_k,N_k>, <dO_k,W2_k>, <N_k,W2_k> over the split's rows of D
 __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __restrict__ dO,
                                                                const float* __restrict__ N,
                                                                const float* __restrict__ W2, int D, int K,
-                                                               float* __restrict__ dots, const float* __restrict__ colsq_raw) {
+                                                               float* __restrict__ dots, const float* __restrict__ colsq_raw, int n_bf16) {
     // colsq_raw != NULL (LPM_VLAD_NRM_RAW): N holds the un-normalised sums U and N = U * rsqrt(max(colsq, eps)) per column --
     // the product vlad_finalize2 would have stored
     const int b = blockIdx.x, sp = blockIdx.y;
     // split sp takes rows sp, sp + VB_DSPLIT, ...: the splits of a clip read VB_DSPLIT consecutive rows at a time (contiguous
     // quarter-ranges put every workgroup of the grid at the same offset of a 64 KB-aligned range: HBM channel aliasing)
     const float* pdo = dO + ((int64_t)b * D + sp) * K;
-    const float* pn = N + ((int64_t)b * D + sp) * K;
+    const int64_t pn0 = ((int64_t)b * D + sp) * K;
     const float* pw = W2 ? W2 + (int64_t)sp * K : nullptr;
     const int64_t rs = (int64_t)VB_DSPLIT * K;
     const int dper = D / VB_DSPLIT;
@@ -97,7 +108,8 @@ __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __re
         const float iv = colsq_raw ? rsqrtf(fmaxf(colsq_raw[(int64_t)b * K + k], kL2Eps)) : 1.f;
 #pragma unroll 4
         for (int d = 0; d < dper; ++d) {
-            const float a = pdo[d * rs + k], n = colsq_raw ? pn[d * rs + k] * iv : pn[d * rs + k];
+            const float nv = vb_ld(N, pn0 + d * rs + k, n_bf16);
+            const float a = pdo[d * rs + k], n = colsq_raw ? nv * iv : nv;
             const float w = pw ? pw[d * rs + k] : 0.f;
             p = fmaf(a, n, p);
             dw = fmaf(a, w, dw);
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
                                                                 const float* __restrict__ u,
                                                                 const float* __restrict__ v, int B, int D, int K,
                                                                 int bper, float* __restrict__ dW2,
-                                                                const float* __restrict__ colsq_raw) {
+                                                                const float* __restrict__ colsq_raw, int n_bf16) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index into [D,K]
     const int64_t n4 = (int64_t)D * K / 4;
     if (i >= n4) return;
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = b0; b < b1; ++b) {
         const float4 a = reinterpret_cast<const float4*>(dO + (int64_t)b * D * K)[i];
-        float4 n = reinterpret_cast<const float4*>(N + (int64_t)b * D * K)[i];
+        float4 n = vb_ld4(N, (int64_t)b * n4 + i, n_bf16);
         if (colsq_raw) {                   // N = U * rsqrt(max(colsq, eps)): see vlad_bwd_coldots_kernel
             const float4 c = *reinterpret_cast<const float4*>(colsq_raw + (int64_t)b * K + k);
             n.x *= rsqrtf(fmaxf(c.x, kL2Eps)); n.y *= rsqrtf(fmaxf(c.y, kL2Eps));
@@ -414,17 +426,17 @@ static int dcentres_splits(int B, int D, int K) {
 }
 // part: room for dcentres_splits(B, D, K) x [D, K] floats, or null (then one pass straight into dW2)
 static void launch_dcentres(const float* dO, const float* N, const float* asum, const float* u, const float* v, int B, int D, int K,
-                            float* part, float* dW2, hipStream_t s, const float* colsq_raw = nullptr) {
+                            float* part, float* dW2, hipStream_t s, const float* colsq_raw = nullptr, int n_bf16 = 0) {
     const int64_t n4 = (int64_t)D * K / 4;
     const unsigned wgx = (unsigned)((n4 + 255) / 256);
     const int Z = part ? dcentres_splits(B, D, K) : 1;
     if (Z == 1) {
-        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, B, dW2, colsq_raw);
+        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, B, dW2, colsq_raw, n_bf16);
         return;
     }
     const int bper = (B + Z - 1) / Z, Zeff = (B + bper - 1) / bper;
     hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx, (unsigned)Zeff), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, bper, part,
-                       colsq_raw);
+                       colsq_raw, n_bf16);
     hipLaunchKernelGGL(vlad_bwd_dcentres_reduce_kernel, dim3(wgx), dim3(256), 0, s, (const float4*)part, Zeff, n4, (float4*)dW2);
 }
 
@@ -459,11 +471,12 @@ __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float
     __syncthreads();
     const int K4 = K / 4;
     const float* ob = dO + ((int64_t)b * D + d0) * K;
-    const float* nb = N + ((int64_t)b * D + d0) * K;
+    const int64_t nb4 = ((int64_t)b * D + d0) * K4;
+    const int n_bf16 = planes == 1;          // bf16 storage: N holds the sums as bf16
     for (int i = tid; i < 32 * K4; i += VB_DU_NT) {
         const int r = i / K4, k = (i % K4) * 4;
         const float4 a = *reinterpret_cast<const float4*>(ob + (int64_t)r * K + k);
-        float4 n = *reinterpret_cast<const float4*>(nb + (int64_t)r * K + k);
+        float4 n = vb_ld4(N, nb4 + (int64_t)r * K4 + k / 4, n_bf16);
         const float4 nu = n;               // raw: the un-normalised value
         if (raw) {
             n.x *= rn[k + 0]; n.y *= rn[k + 1]; n.z *= rn[k + 2]; n.w *= rn[k + 3];
@@ -631,7 +644,7 @@ extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const
         dO = dod;
     }
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr,
-                       D, K, dots, (const float*)nullptr);
+                       D, K, dots, (const float*)nullptr, 0);
     hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil);
     const int nts = (T + VB_TS - 1) / VB_TS;
     const size_t lds = bwd_main_lds_bytes(K);
@@ -723,7 +736,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     const bool raw = (flags & LPM_VLAD_NRM_RAW) != 0;
     const float* colsq_raw = raw ? colsq : nullptr;
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr, D, K, dots,
-                       colsq_raw);
+                       colsq_raw, planes == 1 ? 1 : 0);
     hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil);
     {
         const size_t lds = (size_t)(32 * (K + 1) + 3 * K + (g0 ? 32 * (K + 1) : 0)) * sizeof(float);
@@ -759,7 +772,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     const int rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles", planes);
     if (rc != LPM_OK) return rc;
     if (residual || g0) {        // dcentres = - sum_b asum_b dU_b: the centres' gradient, and (g0) the input batch norm's beta term
-        launch_dcentres(dO, nrm, asum, u, v, B, D, K, (float*)(ws + L.dcp), dcentres, s, colsq_raw);
+        launch_dcentres(dO, nrm, asum, u, v, B, D, K, (float*)(ws + L.dcp), dcentres, s, colsq_raw, planes == 1 ? 1 : 0);
     }
     return check_launch("lpm_vlad_aggregate_bwd_tiles");
 }

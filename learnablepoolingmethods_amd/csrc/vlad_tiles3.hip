@@ -185,7 +185,13 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
                 u.x -= s4.x * cw[c][it].x; u.y -= s4.y * cw[c][it].y; u.z -= s4.z * cw[c][it].z; u.w -= s4.w * cw[c][it].w;
             }
             sq.x = fmaf(u.x, u.x, sq.x); sq.y = fmaf(u.y, u.y, sq.y); sq.z = fmaf(u.z, u.z, sq.z); sq.w = fmaf(u.w, u.w, sq.w);
-            if (!FUSED || fz.store_u) *reinterpret_cast<float4*>(ob + (int64_t)row * K + c * 32 + c4) = u;
+            if (PL == 1) {        // bf16 storage: the un-normalised sums are kept as bf16 as well (the norms below come from the fp32 values)
+                auto rne = [](float f) { unsigned w = __float_as_uint(f); w += 0x7fffu + ((w >> 16) & 1u); return w >> 16; };
+                unsigned short* obh = reinterpret_cast<unsigned short*>(nrm) + ((int64_t)b * D + d0) * K + k0 + kw * 64;
+                *reinterpret_cast<uint2*>(obh + (int64_t)row * K + c * 32 + c4) = make_uint2(rne(u.x) | (rne(u.y) << 16), rne(u.z) | (rne(u.w) << 16));
+            } else if (!FUSED || fz.store_u) {
+                *reinterpret_cast<float4*>(ob + (int64_t)row * K + c * 32 + c4) = u;
+            }
             if (FUSED) *reinterpret_cast<float4*>(wl + row * T3_WS + c4) = u;      // the residual goes back into the accumulators
         }
         if (FUSED) {
@@ -372,7 +378,7 @@ template <bool KMAJOR>
 __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
                                                              int P, int D, int K, float* __restrict__ out,
                                                              float* __restrict__ colsq, float* __restrict__ csq,
-                                                             float* __restrict__ gsq, int keep_u, int out_bf16) {
+                                                             float* __restrict__ gsq, int keep_u, int out_bf16, int nrm_bf16) {
     // keep_u (LPM_VLAD_NRM_RAW): nrm is left as the un-normalised sums U (the tile backward rebuilds N = U * inv_n itself)
     // out_bf16 (d-major only): `out` is bf16 storage
     extern __shared__ float fs[];            // [K] inv_n, then [32][33] transpose tile, [4] partial sums
@@ -405,9 +411,16 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
         const int n4 = 32 * K / 4, K4 = K / 4;
         for (int i = tid; i < n4; i += 256) {
             const int k = (i % K4) * 4;
-            float4 v = reinterpret_cast<const float4*>(src)[i];
+            float4 v;
+            if (nrm_bf16) {               // (bf16 storage: U as bf16, never written back)
+                const uint2 q = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(nrm) + ((int64_t)b * D + d0) * K)[i];
+                v = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                                __uint_as_float(q.y & 0xffff0000u));
+            } else {
+                v = reinterpret_cast<const float4*>(src)[i];
+            }
             v.x *= invn[k]; v.y *= invn[k + 1]; v.z *= invn[k + 2]; v.w *= invn[k + 3];
-            if (!keep_u) reinterpret_cast<float4*>(src)[i] = v;
+            if (!keep_u && !nrm_bf16) reinterpret_cast<float4*>(src)[i] = v;
             v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
             if (out_bf16) {
                 auto rne = [](float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
@@ -612,8 +625,10 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
     dim3 grid(D / 32, B);
     const int keep_u = (flags & LPM_VLAD_NRM_RAW) ? 1 : 0;
     const int out_bf16 = (flags & LPM_VLAD_OUT_BF16) ? 1 : 0;
-    LPM_REQUIRE(!out_bf16 || !(flags & LPM_VLAD_OUT_KMAJOR), LPM_ERR_UNSUPPORTED_SHAPE,
-                "lpm_vlad_finalize2_fwd: a bf16 descriptor is written in the reference's d-major layout only");
+    const int nrm_bf16 = (flags & LPM_VLAD_NRM_BF16) ? 1 : 0;
+    LPM_REQUIRE(!(out_bf16 || nrm_bf16) || !(flags & LPM_VLAD_OUT_KMAJOR), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_finalize2_fwd: bf16 storage is implemented for the reference's d-major layout only");
+    LPM_REQUIRE(!nrm_bf16 || keep_u, LPM_ERR_BADARG, "lpm_vlad_finalize2_fwd: LPM_VLAD_NRM_BF16 goes with LPM_VLAD_NRM_RAW");
     const size_t lds = (size_t)(K + 32 * 33 + 4) * sizeof(float);
     static const int wide = [] { const char* e = getenv("LPM_FINALIZE_KMAJOR4"); return e ? atoi(e) : 32; }();   // 0: scalar form (A/B)
     if ((flags & LPM_VLAD_OUT_KMAJOR) && wide && K <= 512 && (((uintptr_t)nrm | (uintptr_t)out) & 15) == 0) {
@@ -638,15 +653,15 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
     }
     if (flags & LPM_VLAD_OUT_KMAJOR)
         hipLaunchKernelGGL(vlad_finalize2_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq,
-                           csq, gsq, keep_u, 0);
+                           csq, gsq, keep_u, 0, 0);
     else {
         hipEvent_t e0, e1;
         if (D >= 1024 && timing_request(LPM_TIMING_FINALIZE, &e0, &e1))
             hipExtLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, e0, e1, 0, nrm, colsq_part, P, D, K,
-                                  out, colsq, csq, gsq, keep_u, out_bf16);
+                                  out, colsq, csq, gsq, keep_u, out_bf16, nrm_bf16);
         else
             hipLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out,
-                               colsq, csq, gsq, keep_u, out_bf16);
+                               colsq, csq, gsq, keep_u, out_bf16, nrm_bf16);
     }
     return check_launch("lpm_vlad_finalize2_fwd");
 }

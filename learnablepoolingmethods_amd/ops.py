@@ -610,7 +610,7 @@ class _NetVLAD(torch.autograd.Function):
         at = torch.empty(B * (K // 32) * steps * 256, dtype=torch.int32, device=W.device)       # 1 KB per (cluster tile, step)
         with _timed("assign_tiles", (B, T, K)):
             lib.check(lib._lpm_assign_tiles_bf16(ptr(logits), ptr(scale), ptr(shift), B, T, K, flags, ptr(at), st), "lpm_assign_tiles_bf16")
-        nrm = _empty((B, D, K), W)
+        nrm = torch.empty((B, D, K), dtype=torch.bfloat16, device=W.device)       # the un-normalised sums, bf16 like the descriptor
         asum, colsq, csq = (_empty((B, K), W) for _ in range(3))
         P = D // 128
         part = _empty((B, P, K), W)
@@ -620,7 +620,8 @@ class _NetVLAD(torch.autograd.Function):
         out = torch.empty((B, D * K), dtype=torch.bfloat16, device=W.device)
         gsq = _empty((B,), W)
         with _timed("vlad_finalize", (B, D, K)):
-            lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, LPM_VLAD_NRM_RAW | _capi.LPM_VLAD_OUT_BF16, ptr(out),
+            lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, LPM_VLAD_NRM_RAW | _capi.LPM_VLAD_OUT_BF16 | _capi.LPM_VLAD_NRM_BF16,
+                                                  ptr(out),
                                                   ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_finalize2_fwd")
         ctx.nrm_raw = True
         ctx.dims = (B, T, D, K, flags, False, use_bn, is_training, W2 is not None, True)
