@@ -217,6 +217,22 @@ int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, const float* ce
                                  size_t workspace_bytes, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a9: the VLAD -> hidden projection (frame_level_models.py:2314-2319, tf.matmul(vlad, hidden1_weights)) as weight-stream kernels
+ * (csrc/proj_gemm.hip).  M <= 128 clips against the [Kd, N] fp32 weight (0.55 GB at cfg-2, 2.2 GB at cfg-5), read ONCE per pass from
+ * its fp32 master copy and split into bf16 hi / lo planes in registers (3 MFMAs per product, fp32 accumulation, ~5e-6):
+ *   lpm_proj_fwd : y[M, N]  = x[M, Kd] . W            (split-K partial sums in `workspace` + a fixed-order reduce)
+ *   lpm_proj_dx  : dx[M, Kd] = dy[M, N] . W^T          (dyt = lpm_split_rows_tiles(dy, N, 1, M, N): row tiles of the gradient)
+ * ldx / lddx: row strides of x / dx in floats (>= Kd).  A stride that is a multiple of a large power of two -- cfg-2's Kd = 270 336 =
+ * 2^13 x 33 floats -- puts the M row pieces a workgroup needs per step into the same few L2 / memory channels; callers that own the
+ * buffer pad it (ops.DescriptorSlots).  Needs lpm_proj_supported(M, Kd, N): M <= 128, N %% 512 == 0, Kd %% 16 == 0.  The weight
+ * gradient dW = x^T dy is lpm_skinny_weight_grad_tiles. */
+int lpm_proj_supported(int M, int64_t Kd, int N);
+size_t lpm_proj_fwd_workspace_bytes(int M, int64_t Kd, int N);
+int lpm_proj_fwd(const float* x, int64_t ldx, const float* W, int M, int64_t Kd, int N, float* y, void* workspace,
+                 size_t workspace_bytes, lpm_stream_t stream);
+int lpm_proj_dx(const void* dyt, const float* W, int M, int64_t Kd, int N, float* dx, int64_t lddx, lpm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * bf16 storage (BASELINE configs[4]: "Gated NetVLAD K=512 + MoE-4, 300x1152 bf16"): the tensors SURVEY 8(d) counts in the
  * algorithmic bytes of K1 / K2 -- frames, logits / assignment, descriptor -- live in HBM as bf16; every product is ONE bf16 MFMA
  * with fp32 accumulation; batch statistics, norms and all gradients stay fp32.  Operand tiles are plain bf16 tiles: the layouts of

@@ -1,0 +1,342 @@
+// a9, the VLAD -> hidden projection (frame_level_models.py:2314-2319: tf.matmul(vlad, hidden1_weights)) as weight-stream kernels.
+// M (clips, <= 128) rows against a [Kd, N] fp32 weight of 0.55 GB (cfg-2: Kd = 270 336, N = 512) to 2.2 GB (cfg-5): the weight is read
+// ONCE per pass straight from its fp32 master copy -- no bf16 image of it exists anywhere -- and split into bf16 hi / lo planes in
+// registers, so the pass is bound by the 4 bytes per weight it has to read (a library fp32 GEMM streams it at 2.7 TB/s).
+//
+//   forward  y[M, N]  = x[M, Kd] . W[Kd, N]        split-K: every workgroup owns a range of 16-row slabs of W for one 512-column block,
+//                                                   partial sums [split][M][N] + a reduce pass (tile_gemm's tg_reduce_splits layout)
+//   backward dx[M, Kd] = dy[M, N] . W^T            (lpm_proj_dx below)
+//
+// Forward: 512 threads = 8 waves x 64 columns; per slab the workgroup brings W[16][512] (32 KB, contiguous when N = 512) and
+// x[M][16] (<= 8 KB) into an LDS ring by LDS-DMA -- both images are plain row-major, which is exactly what a lane-linear DMA writes.
+// The B fragment of v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane while W is n-contiguous: a lane gathers its 8 values with
+// eight ds_read_b32 down a column (bank = n mod 32: conflict-free), splits them (hi = bf16(w), lo = bf16(w - hi)) and keeps the two
+// planes in registers; x fragments are two ds_read_b128 per tile.  3 MFMAs per product (x_h W_h + x_h W_l + x_l W_h), fp32
+// accumulation: the error of the split-bf16 tile GEMMs (~5e-6).
+#include "tile_gemm.h"
+
+namespace lpm {
+
+// Ring depth: the pass is a pure stream, so what matters is bytes in flight per CU (HBM latency under load ~2-3 us x 25 GB/s per CU
+// = 50-75 KB): four stages of 34-40 KB, three of them in flight behind the one being consumed (two stages, first form: 2.8 TB/s).
+constexpr int PJ_NS = 4;                           // ring stages
+constexpr int PJ_WBYTES = 16 * 512 * 4;            // W slab
+constexpr int PJ_AUX = 2;                          // LDS-DMA cache policy of the weight stream: nt (every byte is read once, by one CU)
+template <int MT>
+__host__ __device__ constexpr int pj_stage() { return PJ_WBYTES + MT * 32 * 16 * 4; }   // + x slab: MT x 32 rows x 16 floats
+
+// MT = row tiles (ceil(M / 32))
+template <int MT>
+__global__ __launch_bounds__(512, 2) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M,
+                                                          int64_t Kd, int N, int nslab, int splits, float* __restrict__ part, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int nb = blockIdx.y, sp = blockIdx.x;                  // 512-column block, split
+    const int s0 = (int)((int64_t)nslab * sp / splits), s1 = (int)((int64_t)nslab * (sp + 1) / splits);
+    const int ns = s1 - s0;
+
+    // DMA roles.  W: piece p = wave * 4 + j (j < 4): slab row p >> 1, 1 KB half (p & 1) of the row's 512-column segment.
+    //             x: piece = wave: rows wave * 16 + lane / 4 (clamped to M - 1: rows >= M are never stored), 16-byte part lane % 4.
+    const float* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = wave * 4 + j;
+        wsrc[j] = W + ((int64_t)s0 * 16 + (p >> 1)) * N + nb * 512 + (p & 1) * 256 + lane * 4;
+    }
+    constexpr int PJ_STAGE = pj_stage<MT>();
+    const bool xwave = wave < 2 * MT;              // x pieces: 2 MT of 16 rows each, one per wave (wave-uniform)
+    const int xr = min(wave * 16 + (lane >> 2), M - 1);
+    const float* xsrc = x + (int64_t)xr * ldx + (int64_t)s0 * 16 + (lane & 3) * 4;
+    auto issue = [&](int s) {
+        unsigned char* st = smem + (s % PJ_NS) * PJ_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + ((dbg & 2) ? 0 : (int64_t)s * 16 * N)),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * 4 + j) * 1024), 16, 0, PJ_AUX);
+        if (xwave)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + ((dbg & 1) ? 0 : (int64_t)s * 16)),
+                                             (__attribute__((address_space(3))) void*)(st + PJ_WBYTES + wave * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < PJ_NS - 1; ++s)
+        if (s < ns) issue(s);
+    for (int s = 0; s < ns; ++s) {
+        // stage s has landed when at most the pieces of the younger stages in flight (two, fewer at the end) remain: 5 (4) per stage
+        const int young = min(PJ_NS - 2, ns - 1 - s);
+        if (xwave) {
+            if (young == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (young == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (young == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (young == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();              // stage s is in LDS for everyone; stage (s - 1) % NS is free again
+        asm volatile("" ::: "memory");
+        if (s + PJ_NS - 1 < ns) issue(s + PJ_NS - 1);
+        const float* wl = reinterpret_cast<const float*>(smem + (s % PJ_NS) * PJ_STAGE);
+        const float* xl = reinterpret_cast<const float*>(smem + (s % PJ_NS) * PJ_STAGE + PJ_WBYTES);
+        if (dbg & 4) continue;
+        tg_u32x4 bh[2], bl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = wl[(8 * half + e) * 512 + wave * 64 + c * 32 + l31];
+            uint4 hi, lo;
+            tg_split8(v, hi, lo);
+            bh[c] = tg_u32x4{hi.x, hi.y, hi.z, hi.w};
+            bl[c] = tg_u32x4{lo.x, lo.y, lo.z, lo.w};
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 a0 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 16 + 8 * half);
+            const float4 a1 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 16 + 8 * half + 4);
+            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            uint4 hi, lo;
+            tg_split8(v, hi, lo);
+            const tg_u32x4 ah = tg_u32x4{hi.x, hi.y, hi.z, hi.w}, al = tg_u32x4{lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[m][c] = tg_mfma(ah, bh[c], acc[m][c]);
+                acc[m][c] = tg_mfma(ah, bl[c], acc[m][c]);
+                acc[m][c] = tg_mfma(al, bh[c], acc[m][c]);
+            }
+        }
+    }
+    // partial sums of this split: acc[m][c][r] = y[row m * 32 + mfma32_row(r, lane)][column nb * 512 + wave * 64 + c * 32 + l31]
+    float* pb = part + ((int64_t)sp * M) * N + nb * 512 + wave * 64 + l31;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m * 32 + mfma32_row(r, lane);
+            if (row < M) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) pb[(int64_t)row * N + c * 32] = acc[m][c][r];
+            }
+        }
+}
+
+// out[i] = sum_z part[z][i] (float4 granularity): 64 outputs x 4 quarters of the splits per workgroup, the quarters added in a fixed
+// order -- the result does not depend on scheduling
+__global__ __launch_bounds__(256) void proj_reduce_kernel(const float4* __restrict__ part, int Z, int64_t n4, float4* __restrict__ out) {
+    __shared__ float4 sh[3][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    const int z0 = Z * q / 4, z1 = Z * (q + 1) / 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4)
+        for (int z = z0; z < z1; ++z) {
+            const float4 p = part[(int64_t)z * n4 + i];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+    if (q) sh[q - 1][o] = s;
+    __syncthreads();
+    if (q == 0 && i < n4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 p = sh[k][o];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        out[i] = s;
+    }
+}
+
+static int proj_splits(int64_t Kd, int N) {
+    const int nb = N / 512, nslab = (int)(Kd / 16);
+    int sp = 256 / nb;                             // one workgroup per CU
+    if (sp > nslab / 8) sp = nslab / 8;            // >= 8 slabs per workgroup
+    return sp < 1 ? 1 : sp;
+}
+
+// ---- backward: dx[M, Kd] = dy[M, N] . W^T ------------------------------------------------------------------------------------------------
+// Workgroup = 256 rows of W (= 256 columns of dx), 8 waves x 32 rows, the whole reduction over N inside.  Here the B fragment IS
+// W's layout: lane (k-row l31, half) wants 8 consecutive n of its row.  Per MFMA step (16 n) a wave brings its 32 rows x 64 B in by
+// two LDS-DMAs (16 rows x 64 B each), XOR-swizzled at 16-byte granularity through the SOURCE address -- the LDS image stays
+// lane-linear -- so that the 32 lanes of a fragment read, 64 bytes apart, spread over the banks.  dy arrives as split-bf16 row tiles
+// (lpm_split_rows_tiles of the [M, N] matrix: 0.2-1 MB, L2-resident) and goes through the same ring.  Small stages (22-24 KB), SIX of
+// them: five in flight per CU keep the weight stream fed (three stages of 44 KB, first form: 2.7 TB/s).
+constexpr int PD_NS = 6;
+constexpr int PD_WBYTES = 8 * 32 * 64;             // 8 waves x 32 rows x 16 floats = 16 KB
+template <int MT>
+__host__ __device__ constexpr int pd_stage() { return PD_WBYTES + MT * 2048; }    // + MT row tiles x (hi, lo) of one n-step
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void proj_dx_kernel(const uint4* __restrict__ dyt, const float* __restrict__ W, int M, int64_t Kd, int N,
+                                                         float* __restrict__ dx, int64_t lddx) {
+    constexpr int STAGE = pd_stage<MT>();
+    constexpr int NAP = MT * 2;                    // dy pieces (1 KB) per stage: one per wave for waves < NAP
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int64_t k0 = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + wave * 32;     // this wave's 32 rows of W
+    const int NB = N / 16, CS = N / 16;            // n-steps = stages; row-tile stride of dyt
+    // W DMA: piece j (0..1) = rows 16 j .. 16 j + 15 of the wave's 32, lane -> (row r = 16 j + lane / 4, 16-byte slot q = lane % 4);
+    // LDS slot q of row r holds source part q ^ (r & 3)
+    const float* wsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * j + (lane >> 2), q = lane & 3;
+        const int64_t row = min(k0 + r, Kd - 1);
+        wsrc[j] = W + row * N + ((q ^ (r & 3)) * 4);
+    }
+    const bool awave = wave < NAP;                 // dy piece of this wave: (row tile wave >> 1, plane wave & 1)
+    const uint4* asrc = dyt + ((int64_t)(wave >> 1) * CS) * 128 + (wave & 1) * 64 + lane;
+    auto issue = [&](int s) {
+        unsigned char* st = smem + (s % PD_NS) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + s * 16),
+                                             (__attribute__((address_space(3))) void*)(st + wave * 2048 + j * 1024), 16, 0, PJ_AUX);
+        if (awave)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)s * 128),
+                                             (__attribute__((address_space(3))) void*)(st + PD_WBYTES + wave * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < PD_NS - 1; ++s)
+        if (s < NB) issue(s);
+    for (int s = 0; s < NB; ++s) {
+        // younger stages in flight behind stage s: up to PD_NS - 2 = 4, of 3 (2) pieces of this wave each
+        const int young = min(PD_NS - 2, NB - 1 - s);
+        if (awave) {
+            if (young == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (young == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (young == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (young == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (young == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (young == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (young == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (young == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + PD_NS - 1 < NB) issue(s + PD_NS - 1);
+        const unsigned char* st = smem + (s % PD_NS) * STAGE;
+        const float* wl = reinterpret_cast<const float*>(st + wave * 2048) + l31 * 16;        // this lane's row (64 B)
+        const tg_u32x4* af = reinterpret_cast<const tg_u32x4*>(st + PD_WBYTES) + lane;
+        // 8 consecutive n of row l31: 16-byte slots 2 half and 2 half + 1 (swizzled)
+        const int q0 = (2 * half) ^ (l31 & 3), q1 = (2 * half + 1) ^ (l31 & 3);
+        const float4 b0 = *reinterpret_cast<const float4*>(wl + q0 * 4);
+        const float4 b1 = *reinterpret_cast<const float4*>(wl + q1 * 4);
+        const float v[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        uint4 hi, lo;
+        tg_split8(v, hi, lo);
+        const tg_u32x4 bh = tg_u32x4{hi.x, hi.y, hi.z, hi.w}, bl = tg_u32x4{lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const tg_u32x4 ah = af[(m * 2 + 0) * 64], al = af[(m * 2 + 1) * 64];
+            acc[m] = tg_mfma(ah, bh, acc[m]);
+            acc[m] = tg_mfma(ah, bl, acc[m]);
+            acc[m] = tg_mfma(al, bh, acc[m]);
+        }
+    }
+    // dx[row][k0 + l31]: the 32 lanes of a half-wave write 128 contiguous bytes per row
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m * 32 + mfma32_row(r, lane);
+            if (row < M && k0 + l31 < Kd) dx[(int64_t)row * lddx + k0 + l31] = acc[m][r];
+        }
+}
+
+}  // namespace lpm
+
+extern "C" int lpm_proj_supported(int M, int64_t Kd, int N) {
+    return (M > 0 && M <= 128 && N > 0 && N % 512 == 0 && Kd > 0 && Kd % 16 == 0 && Kd / 16 >= 8) ? 1 : 0;
+}
+extern "C" size_t lpm_proj_fwd_workspace_bytes(int M, int64_t Kd, int N) {
+    return (size_t)lpm::proj_splits(Kd, N) * M * N * sizeof(float);
+}
+
+extern "C" int lpm_proj_fwd(const float* x, int64_t ldx, const float* W, int M, int64_t Kd, int N, float* y, void* workspace,
+                            size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x && W && y && workspace, LPM_ERR_BADARG, "lpm_proj_fwd: null pointer");
+    LPM_REQUIRE(lpm_proj_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_proj_fwd: need M <= 128, N %% 512 == 0, Kd %% 16 == 0 (M=%d Kd=%lld N=%d)", M, (long long)Kd, N);
+    LPM_REQUIRE(workspace_bytes >= lpm_proj_fwd_workspace_bytes(M, Kd, N), LPM_ERR_WORKSPACE, "lpm_proj_fwd: workspace too small");
+    LPM_REQUIRE(ldx >= Kd && ldx % 4 == 0, LPM_ERR_BADARG, "lpm_proj_fwd: the row stride of x must be >= Kd and a multiple of 4");
+    LPM_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)workspace) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_proj_fwd: pointers must be 16-byte aligned");
+    const int splits = proj_splits(Kd, N), nslab = (int)(Kd / 16), MT = (M + 31) / 32;
+    dim3 grid(splits, N / 512);
+    hipStream_t s = (hipStream_t)stream;
+#define LPM_PJ(MTV)                                                                                                          \
+    do {                                                                                                                     \
+        auto kern = proj_fwd_kernel<MTV>;                                                                                    \
+        const size_t lds = (size_t)PJ_NS * pj_stage<MTV>();                                                                  \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {    \
+            (void)hipGetLastError();                                                                                         \
+            set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                                 \
+            return LPM_ERR_LAUNCH;                                                                                           \
+        }                                                                                                                    \
+        static const int dbg = [] { const char* e = getenv("LPM_PROJ_DBG"); return e ? atoi(e) : 0; }();                     \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace, dbg);       \
+    } while (0)
+    switch (MT) {
+        case 1: LPM_PJ(1); break;
+        case 2: LPM_PJ(2); break;
+        case 3: LPM_PJ(3); break;
+        default: LPM_PJ(4); break;
+    }
+#undef LPM_PJ
+    const int64_t n4 = (int64_t)M * N / 4;
+    hipLaunchKernelGGL(proj_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s, (const float4*)workspace, splits, n4, (float4*)y);
+    return check_launch("lpm_proj_fwd");
+}
+
+// dyt: lpm_split_rows_tiles(dy, ldx = N, B = 1, T = M, C = N) -- split-bf16 row tiles of the [M, N] gradient
+extern "C" int lpm_proj_dx(const void* dyt, const float* W, int M, int64_t Kd, int N, float* dx, int64_t lddx, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dyt && W && dx, LPM_ERR_BADARG, "lpm_proj_dx: null pointer");
+    LPM_REQUIRE(M > 0 && M <= 128 && N > 0 && N % 16 == 0 && Kd > 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_proj_dx: need M <= 128, N %% 16 == 0 (M=%d N=%d)", M, N);
+    LPM_REQUIRE((((uintptr_t)dyt | (uintptr_t)W | (uintptr_t)dx) & 15) == 0, LPM_ERR_BADARG, "lpm_proj_dx: pointers must be 16-byte aligned");
+    LPM_REQUIRE(lddx >= Kd, LPM_ERR_BADARG, "lpm_proj_dx: the row stride of dx must be >= Kd");
+    const int MT = (M + 31) / 32;
+    dim3 grid((unsigned)((Kd + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+#define LPM_PD(MTV)                                                                                                          \
+    do {                                                                                                                     \
+        auto kern = proj_dx_kernel<MTV>;                                                                                     \
+        const size_t lds = (size_t)PD_NS * pd_stage<MTV>();                                                                  \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {    \
+            (void)hipGetLastError();                                                                                         \
+            set_error("lpm_proj_dx: cannot reserve %zu bytes of LDS", lds);                                                  \
+            return LPM_ERR_LAUNCH;                                                                                           \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)dyt, W, M, Kd, N, dx, lddx);                         \
+    } while (0)
+    switch (MT) {
+        case 1: LPM_PD(1); break;
+        case 2: LPM_PD(2); break;
+        case 3: LPM_PD(3); break;
+        default: LPM_PD(4); break;
+    }
+#undef LPM_PD
+    return check_launch("lpm_proj_dx");
+}

@@ -31,20 +31,26 @@ __device__ __forceinline__ unsigned tg_rne(float v) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+// fp32 -> (hi, lo) bf16 planes, round-to-nearest-even both: v_cvt_pk_bf16_f32 does two elements per instruction (~3 VALU
+// operations per element against ~16 for the integer emulation tg_rne spells out; same bits for finite values)
+typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float tg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tg_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const tg_f32x2 v = {a, b};
+    const tg_bf16x2 h = __builtin_convertvector(v, tg_bf16x2);
+    const tg_f32x2 hf = __builtin_convertvector(h, tg_f32x2);
+    const tg_bf16x2 l = __builtin_convertvector(v - hf, tg_bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 __device__ __forceinline__ void tg_split8(const float* v, uint4& hi, uint4& lo) {
-    unsigned h[8], l[8];
+    unsigned h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        h[e] = tg_rne(v[e]);
-        l[e] = tg_rne(v[e] - __uint_as_float(h[e] << 16));
-    }
-    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    for (int i = 0; i < 4; ++i) tg_split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-// bf16-storage form (PL = 1, BASELINE cfg-5): the operands are plain bf16 tiles -- ONE 1 KB plane per (tile, step), strides in
-// units of 64 instead of 128 -- and a product is one MFMA.  A ring stage then carries TWO consecutive reduction steps where the
-// split form carries the two planes of one, so the piece bookkeeping, the ring and the counted waits are the same code.
 constexpr int TG_NS = 3;     // LDS ring stages
 enum { TG_EPI_STORE = 0, TG_EPI_SOFTMAX_BWD = 1 };
 

@@ -32,6 +32,11 @@ VLAD_TILES3 = os.environ.get("LPM_VLAD_TILES3", "1") != "0"
 # B = 128, K = 512 (341 / 396 vs 340 us).  All workgroups reach their epilogue together (1.7 rounds of 768 resident workgroups),
 # so the wait overlaps nothing.
 VLAD_FUSED = os.environ.get("LPM_VLAD_FUSED", "0") == "1"
+# a9: the hidden projection's forward / input gradient as hand-written weight-stream kernels (csrc/proj_gemm.hip); "0": library GEMMs (A/B)
+PROJ_STREAM = os.environ.get("LPM_PROJ_STREAM", "1") != "0"
+# ... the input-gradient kernel from this hidden size on (measured, rocprofv3 kernel durations: forward 174 + 21 us vs the library's 219 us at
+# cfg-2, 764 vs 1233 us at cfg-5; dx 267 vs 211 us at cfg-2's N = 512 -- the library stays there --, 1108 vs 1232 us at cfg-5's N = 1024)
+PROJ_DX_STREAM_MIN_N = int(os.environ.get("LPM_PROJ_DX_STREAM_MIN_N", "1024"))
 VLAD_FUSED_DEBUG_FALLBACK = False     # tests: drive every clip through the fused kernel's time-out path + follow-up finalize
 
 # Matrix-core arithmetic of the soft-assignment GEMM K1: "bf16x3" (split-bf16 tiles on the bf16 pipe, default where
@@ -1013,6 +1018,18 @@ class _Projection(torch.autograd.Function):
         N = W.shape[1]
         S = next((s for s in (132, 128, 96, 64, 48, 32, 16, 8) if K % s == 0 and K // s >= 512), 1)
         ctx.save_for_backward(x, W)
+        ctx.stream_kernels = (PROJ_STREAM and x.is_cuda and x.dtype == torch.float32 and W.dtype == torch.float32 and x.stride(1) == 1
+                              and x.stride(0) >= K and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+                              and W.is_contiguous() and bool(_capi.load()._lpm_proj_supported(M, K, N)))
+        if ctx.stream_kernels:
+            # hand-written weight-stream kernel: W is read once as fp32 and split into bf16 planes in registers
+            lib = _capi.load()
+            y = _empty((M, N), x)
+            wsb = lib._lpm_proj_fwd_workspace_bytes(M, K, N)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+            with _timed("proj_fwd", (M, K, N)):
+                lib.check(lib._lpm_proj_fwd(ptr(x), x.stride(0), ptr(W), M, K, N, ptr(y), ptr(ws), wsb, stream_ptr()), "lpm_proj_fwd")
+            return y
         if S == 1 or M > 512:
             return x.matmul(W)
         return torch.bmm(x.view(M, S, K // S).transpose(0, 1), W.view(S, K // S, N)).sum(0)
@@ -1021,7 +1038,19 @@ class _Projection(torch.autograd.Function):
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dy.matmul(W.t()) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0] and ctx.stream_kernels and W.shape[1] >= PROJ_DX_STREAM_MIN_N:
+            lib = _capi.load()
+            M, K = x.shape
+            N = W.shape[1]
+            dyt = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), dy)
+            lib.check(lib._lpm_split_rows_tiles(ptr(dy), N, 1, M, N, ptr(dyt), stream_ptr()), "lpm_split_rows_tiles")
+            # the gradient gets the row stride of x: a padded descriptor buffer (ops.DescriptorSlots) keeps both off the channel aliasing
+            dx = torch.empty_strided((M, K), (x.stride(0), 1), dtype=torch.float32, device=x.device)
+            with _timed("proj_dx", (M, K, N)):
+                lib.check(lib._lpm_proj_dx(ptr(dyt), ptr(W), M, K, N, ptr(dx), dx.stride(0), stream_ptr()), "lpm_proj_dx")
+        elif ctx.needs_input_grad[0]:
+            dx = dy.matmul(W.t())
         if not ctx.needs_input_grad[1]:
             return dx, None
         skinny = x.shape[0] % 16 == 0 and dy.shape[1] % 32 == 0 and x.is_contiguous()

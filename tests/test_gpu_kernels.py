@@ -536,10 +536,12 @@ def test_ffn_split_bf16_fused_bias_relu():
     assert int((err > 1e-4).sum()) <= 20, f"{int((err > 1e-4).sum())} of {M} dy rows differ: not ReLU-flip noise"
 
 
-@pytest.mark.parametrize("B,KV,H", [(80, 33792, 512), (16, 4224, 64), (6, 2048, 96)])
+@pytest.mark.parametrize("B,KV,H", [(80, 33792, 512), (16, 4224, 64), (6, 2048, 96), (128, 16896, 1024), (13, 2064, 512), (48, 4112, 512),
+                                    (80, 270336, 512)])
 def test_projection_skinny_gemms(B, KV, H):
-    """VLAD -> hidden1 projection (frame_level_models.py:2314-2319): split-K forward, dx, and the weight gradient written
-    by the tile GEMM straight into a caller-owned buffer (the trainer's gradient arena).  B = 6 takes the library path."""
+    """VLAD -> hidden1 projection (frame_level_models.py:2314-2319): forward and dx by the weight-stream kernels (csrc/proj_gemm.hip:
+    H a multiple of 512; cfg-2's and cfg-5's shapes, ragged row counts, an odd number of 16-row slabs) or the library (the other
+    shapes), and the weight gradient written by the tile GEMM straight into a caller-owned buffer (the trainer's gradient arena)."""
     from learnablepoolingmethods_amd import ops
     dev = cuda()
     g = torch.Generator().manual_seed(B + H)
@@ -548,8 +550,13 @@ def test_projection_skinny_gemms(B, KV, H):
     dy = torch.randn(B, H, generator=g).to(dev)
     view = torch.full((KV, H), float("nan"), device=dev)
     W._lpm_grad_view = view
-    y = ops.projection(x, W)
-    y.backward(dy)
+    old = ops.PROJ_DX_STREAM_MIN_N
+    ops.PROJ_DX_STREAM_MIN_N = 512            # the hand-written dx kernel on every shape it supports, not only where it is the default
+    try:
+        y = ops.projection(x, W)
+        y.backward(dy)
+    finally:
+        ops.PROJ_DX_STREAM_MIN_N = old
     x64, W64, dy64 = x.detach().double().cpu(), W.detach().double().cpu(), dy.double().cpu()
     assert_close(y, x64 @ W64, 2e-5, "y")
     assert_close(x.grad, dy64 @ W64.t(), 2e-5, "dx")
