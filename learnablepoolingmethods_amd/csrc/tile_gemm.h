@@ -74,6 +74,7 @@ struct TileGemmArgs {
     int64_t ldo, out_batch, out_split;
     int rows_valid, cols_valid;
     int accumulate;            // STORE: out += result
+    int nt_store;              // STORE: non-temporal stores (the 0.5-2 GB hidden1 weight gradient)
     float* stats;              // STORE, optional: [gridDim.x][2][cols_valid] per-workgroup column (sum, sum of squares)
     // SOFTMAX_BWD (needs gridDim.y == gridDim.z == 1): out = dlogit~ with a = softmax(logits*scale + shift) recomputed
     const float* logits;       // [batch * rows_valid + row][cols_valid]

@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
                         const float4 o = *p;
                         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     }
-                    *p = v;
+                    if (g.nt_store)      // a result far larger than the caches, read much later
+                        __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+                    else *p = v;
                 }
             }
         }
@@ -347,7 +349,8 @@ static int tg_wide_enabled() {
 // The 128-row form applies when the row tiles of all batches form one flat sequence that divides into groups of four, the
 // B operand is shared, there is one reduction segment and one 256-column block: K1's forward at K = 256.
 static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw, int planes) {
-    return tg_wide_enabled() && ntw == 2 && g.cols_valid <= 256 && splits == 1 && g.steps2 == 0 && g.a2 == nullptr && g.b_batch == 0 &&
+    return tg_wide_enabled() && ntw == 2 && (g.cols_valid <= 256 || g.cols_valid % 256 == 0) && splits == 1 && g.steps2 == 0 &&
+           g.a2 == nullptr && g.b_batch == 0 &&
            g.a_batch == (int64_t)g.a_tiles * g.a_tile && g.rb_per_batch * 2 == g.a_tiles && ((int64_t)nbatch * g.a_tiles) % 4 == 0 &&
            g.steps_per_split >= (planes == 1 ? 32 : 16);     // (ring stages >= the ring depth)
 }
@@ -548,7 +551,9 @@ static int assign_gemm_tiles_fwd_impl(const void* xr, const void* wt, int B, int
     g.rb_per_batch = MT / 2; g.steps_per_split = DS; g.total_steps = DS;
     g.out = (float*)logits; g.out_bf16 = planes == 1 ? 1 : 0; g.ldo = K; g.out_batch = (int64_t)T * K; g.out_split = 0;
     g.rows_valid = T; g.cols_valid = K; g.accumulate = 0; g.stats = partial;
-    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd", 0, D >= 1024 ? LPM_TIMING_K1 : 0, 1, planes);
+    // K = 512 (cfg-5's video stream): the 128-row form on two 256-column blocks instead of the 64-row x 512-column form (93.8 us there)
+    const int ntw = (K == 512 && T >= 32) ? 2 : 0;
+    return tg_launch<TG_EPI_STORE>(g, B, 1, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd", ntw, D >= 1024 ? LPM_TIMING_K1 : 0, 1, planes);
 }
 extern "C" int lpm_assign_gemm_tiles_fwd(const void* xr, const void* wt, int B, int T, int D, int K, float* logits, float* partial,
                                          lpm_stream_t stream) {
@@ -638,6 +643,8 @@ extern "C" int lpm_skinny_weight_grad_tiles(const void* xt, const void* dyt, int
     g.b = (const uint4*)dyt; g.b_tile = 128; g.b_step = (int64_t)NT2 * 128; g.b_batch = 0; g.b_tiles = NT2;
     g.rb_per_batch = (N1 + 63) / 64; g.steps_per_split = R / 16; g.total_steps = R / 16;
     g.out = dW; g.ldo = N2; g.rows_valid = N1; g.cols_valid = N2;
+    static const int nt = [] { const char* e = getenv("LPM_DW_NT_STORE"); return (e && e[0] == '0') ? 0 : 1; }();      // 0: plain stores (A/B)
+    g.nt_store = nt;
     // 5 reduction steps and a 554 MB store: narrow column blocks (36 KB of LDS, 4 workgroups per CU) so that one workgroup's
     // store overlaps its neighbours' loads (measured at cfg-2: 145 us with 128-column blocks, 215 us with 512)
     return tile_gemm_store(g, 1, 1, (hipStream_t)stream, "lpm_skinny_weight_grad_tiles", 1);
