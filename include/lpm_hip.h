@@ -51,6 +51,8 @@ enum {
                                   holds bf16 logits                                                                         */
     LPM_VLAD_NRM_BF16 = 64,    /* lpm_vlad_finalize2_fwd: `nrm` holds the un-normalised sums as bf16 (what lpm_vlad_aggregate_tiles3_fwd_bf16
                                   writes; with LPM_VLAD_NRM_RAW); implied by LPM_VLAD_TILES_BF16 in lpm_vlad_aggregate_bwd_tiles   */
+    LPM_VLAD_RAW_KMAJOR = 128, /* lpm_vlad_aggregate_bwd_tiles: `dout` and `nrm` are k-major [B, K, D] and `nrm` holds the un-normalised
+                                  sums lpm_vlad_aggregate_raw_kmajor_fwd stored (split-bf16, no-input-gradient form only)        */
     LPM_VLAD_DEBUG_FALLBACK = 256 /* lpm_vlad_aggregate_fused_fwd, tests only: one workgroup of every clip behaves as if its wait
                                   for the clip had timed out, so the follow-up finalize pass runs for every clip             */
 };
@@ -201,6 +203,22 @@ int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, const float* c
                                   int flags, float* nrm, float* asum, float* colsq_part, lpm_stream_t stream);
 int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out,
                            float* colsq, float* csq, float* gsq, lpm_stream_t stream);
+
+/* K2 for a consumer that applies the normalisation itself (the NetVladV1 cluster encoders, App. C5: tokens = clusters):
+ * lpm_vlad_aggregate_raw_kmajor_fwd stores the UN-normalised residual sums k-major [B, K, D] -- once, straight from the accumulators
+ * -- plus asum and the partial norms colsq_part [B, D/128, K]; lpm_vlad_row_scales turns those into scale [B, K] = 1 / (n_k sqrt(g))
+ * and colsq, csq [B, K], gsq [B], so that descriptor[b, k, :] = raw[b, k, :] * scale[b, k] (frame_level_models.py:2819-2822 as one
+ * factor per row).  No finalize pass: the [B, D, K]-sized tensor is written once and never re-read by the pooling.  Consumers:
+ * lpm_split_rows_scaled (operand image of the q/k/v GEMM), lpm_layer_norm_act_fwd_rs (the encoder's residual); the backward is
+ * lpm_vlad_aggregate_bwd_tiles with LPM_VLAD_RAW_KMAJOR (dout and the sums both k-major: no transposes). */
+int lpm_vlad_aggregate_raw_kmajor_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                      float* raw_kmajor, float* asum, float* colsq_part, lpm_stream_t stream);
+int lpm_vlad_row_scales(const float* colsq_part, int P, int B, int K, float* scale, float* colsq, float* csq, float* gsq,
+                        lpm_stream_t stream);
+int lpm_split_rows_scaled(const float* x, int64_t ldx, int64_t M, int K, const float* row_scale, void* out3, lpm_stream_t stream);
+int lpm_layer_norm_act_fwd_rs(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,
+                              const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, float* z,
+                              float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 
 /* K2 with the finalize pass fused in (frame_level_models.py:2803-2822 as ONE kernel): the same workgroups, but each waits for
  * the other workgroups of its clip (per-clip arrival counter, bounded), forms 1/n_k and the clip's 1/sqrt(g) from the partial

@@ -22,6 +22,7 @@ LPM_VLAD_NRM_RAW = 8
 LPM_VLAD_OUT_BF16 = 16
 LPM_VLAD_TILES_BF16 = 32
 LPM_VLAD_NRM_BF16 = 64
+LPM_VLAD_RAW_KMAJOR = 128
 LPM_VLAD_DEBUG_FALLBACK = 256
 
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header
@@ -80,6 +81,10 @@ SIGNATURES = {
     "lpm_assign_gemm_tiles_bwd_dw_bf16": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _s, _f]),
     "lpm_assign_tiles_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),
     "lpm_vlad_aggregate_tiles3_fwd_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "lpm_vlad_aggregate_raw_kmajor_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "lpm_vlad_row_scales": (_i, [_f, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "lpm_split_rows_scaled": (_i, [_f, _l, _l, _i, _f, _f, _f]),
+    "lpm_layer_norm_act_fwd_rs": (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _s, _f]),
     "lpm_vlad_fused_supported": (_i, [_i, _i]),
     "lpm_vlad_fused_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_vlad_aggregate_fused_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _s, _f]),

@@ -34,7 +34,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {   // 256 thread
 __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restrict__ a, const float* __restrict__ r,
                                                            const float* __restrict__ bias, int relu, int F,
                                                            int64_t n_per, float* __restrict__ z,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, const float* __restrict__ r_scale) {
     __shared__ float sh[4];
     const int b = blockIdx.x, ch = blockIdx.y;
     const int64_t n4 = n_per / 4;
@@ -56,7 +56,11 @@ __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restri
             }
         }
         if (rp) {
-            const float4 w = rp[i];
+            float4 w = rp[i];
+            if (r_scale) {                     // the residual is a lazily normalised descriptor: one factor per (example, row)
+                const float rs = r_scale[(int64_t)b * (n_per / F) + i / F4];
+                w.x *= rs; w.y *= rs; w.z *= rs; w.w *= rs;
+            }
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
         if (rp || bias) zp[i] = v;
@@ -310,13 +314,14 @@ extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
                 name ": need F in {128,256,512,1024} (F=%d)", F);                                                        \
     LPM_REQUIRE(workspace && workspace_bytes >= lpm_layer_norm_workspace_bytes(B, F), LPM_ERR_WORKSPACE, name ": workspace too small")
 
-extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma,
-                                      const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride,
-                                      float* z, float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+static int layer_norm_act_fwd_impl(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,
+                                   const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, float* z,
+                                   float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(a && gamma && beta && y && stats && (z || (!r && !bias)), LPM_ERR_BADARG,
                 "lpm_layer_norm_act_fwd: null pointer (z is required with a residual or a bias)");
     LPM_REQUIRE(bias || !relu, LPM_ERR_BADARG, "lpm_layer_norm_act_fwd: relu needs the bias it follows");
+    LPM_REQUIRE(!r_scale || r, LPM_ERR_BADARG, "lpm_layer_norm_act_fwd: a residual row scale needs the residual");
     LPM_LN_CHECK("lpm_layer_norm_act_fwd");
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
@@ -325,10 +330,25 @@ extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int rel
     LPM_REQUIRE(yb >= n_per && yb % 4 == 0 && ((uintptr_t)y & 15) == 0, LPM_ERR_BADARG,
                 "lpm_layer_norm_act_fwd: y_batch_stride must be >= L*F and a multiple of 4, y 16-byte aligned");
     dim3 grid(B, LN_NB);
-    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial);
+    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial, r_scale);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias) ? z : a, partial, gamma, beta, n_per, F, eps, y, yb, stats,
                        (const float*)nullptr, (float*)nullptr);
     return check_launch("lpm_layer_norm_act_fwd");
+}
+extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma,
+                                      const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride,
+                                      float* z, float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    return layer_norm_act_fwd_impl(a, bias, relu, r, nullptr, gamma, beta, B, L, F, eps, y, y_batch_stride, z, stats, workspace,
+                                   workspace_bytes, stream);
+}
+// ... with the residual given as raw rows times one factor per (example, row): r_scale [B * L] (the pooled descriptor in its lazily
+// normalised form, lpm_vlad_row_scales)
+extern "C" int lpm_layer_norm_act_fwd_rs(const float* a, const float* bias, int relu, const float* r, const float* r_scale,
+                                         const float* gamma, const float* beta, int B, int L, int F, float eps, float* y,
+                                         int64_t y_batch_stride, float* z, float* stats, void* workspace, size_t workspace_bytes,
+                                         lpm_stream_t stream) {
+    return layer_norm_act_fwd_impl(a, bias, relu, r, r_scale, gamma, beta, B, L, F, eps, y, y_batch_stride, z, stats, workspace,
+                                   workspace_bytes, stream);
 }
 
 // layer_norm(layer_norm(act(a + bias) + r; gamma1, beta1) + r; gamma2, beta2): the two layer norms at the end of the V1 encoder
@@ -352,7 +372,7 @@ extern "C" int lpm_layer_norm_pair_fwd(const float* a, const float* bias, int re
     LPM_REQUIRE(yb >= n_per && yb % 4 == 0 && ((uintptr_t)y & 15) == 0, LPM_ERR_BADARG,
                 "lpm_layer_norm_pair_fwd: y_batch_stride must be >= L*F and a multiple of 4, y 16-byte aligned");
     dim3 grid(B, LN_NB);
-    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z1, partial1);
+    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z1, partial1, (const float*)nullptr);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z1, (const float*)partial1, gamma1, beta1, n_per, F, eps,
                        z2, n_per, stats1, r, partial2);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z2, (const float*)partial2, gamma2, beta2, n_per, F, eps,

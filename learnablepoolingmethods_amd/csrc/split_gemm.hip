@@ -27,7 +27,7 @@ __device__ __forceinline__ float sg_bf16_f32(unsigned h) { return __uint_as_floa
 // one thread = 8 consecutive columns of one row
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int K,
                                                          const float* __restrict__ bias, int relu, int order,
-                                                         unsigned short* __restrict__ out3) {
+                                                         unsigned short* __restrict__ out3, const float* __restrict__ row_scale) {
     const int K8 = K / 8;
     const int64_t total = M * K8;
     for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
@@ -36,6 +36,11 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         const float4 a = *reinterpret_cast<const float4*>(x + m * ldx + c);
         const float4 b = *reinterpret_cast<const float4*>(x + m * ldx + c + 4);
         float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (row_scale) {                       // a lazily normalised pooled descriptor: raw sums times one factor per row
+            const float rs = row_scale[m];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= rs;
+        }
         if (bias) {
             const float4 ba = *reinterpret_cast<const float4*>(bias + c), bb = *reinterpret_cast<const float4*>(bias + c + 4);
             v[0] += ba.x; v[1] += ba.y; v[2] += ba.z; v[3] += ba.w;
@@ -171,8 +176,23 @@ extern "C" int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, con
     const int64_t total = M * (K / 8);
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       M, K, bias, relu, order ? 1 : 0, (unsigned short*)out3);
+                       M, K, bias, relu, order ? 1 : 0, (unsigned short*)out3, (const float*)nullptr);
     return check_launch("lpm_split_rows");
+}
+
+// x[m, :] * row_scale[m] -> activation image [hi | lo | hi]: the operand of the q/k/v GEMM when x is the pooled descriptor in its
+// lazily normalised form (lpm_vlad_aggregate_raw_kmajor_fwd + lpm_vlad_row_scales)
+extern "C" int lpm_split_rows_scaled(const float* x, int64_t ldx, int64_t M, int K, const float* row_scale, void* out3, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x && out3 && row_scale, LPM_ERR_BADARG, "lpm_split_rows_scaled: null pointer");
+    LPM_REQUIRE(M > 0 && K > 0 && ldx >= K, LPM_ERR_BADARG, "lpm_split_rows_scaled: bad sizes");
+    LPM_REQUIRE(K % 8 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)out3) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_split_rows_scaled: need K %% 8 == 0, ldx %% 4 == 0, 16-byte aligned pointers (K=%d)", K);
+    const int64_t total = M * (K / 8);
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, ldx, M, K,
+                       (const float*)nullptr, 0, 0, (unsigned short*)out3, row_scale);
+    return check_launch("lpm_split_rows_scaled");
 }
 
 extern "C" size_t lpm_split_rows_relu_bwd_workspace_bytes(int64_t M, int K) {

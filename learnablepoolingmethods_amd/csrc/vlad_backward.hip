@@ -127,15 +127,14 @@ __global__ __launch_bounds__(256) void vlad_bwd_coeff_kernel(const float* __rest
                                                              const float* __restrict__ csq,
                                                              const float* __restrict__ gsq, int K,
                                                              float* __restrict__ u, float* __restrict__ v,
-                                                             float* __restrict__ ctil) {
+                                                             float* __restrict__ ctil, int nsplit) {
     __shared__ float wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* dp = dots + (int64_t)b * VB_DSPLIT * 3 * K;
+    const float* dp = dots + (int64_t)b * nsplit * 3 * K;
     float psum = 0.f;
     for (int k = tid; k < K; k += 256) {
         float p = 0.f;
-#pragma unroll
-        for (int s = 0; s < VB_DSPLIT; ++s) p += dp[s * 3 * K + k];
+        for (int s = 0; s < nsplit; ++s) p += dp[s * 3 * K + k];
         psum += p;
     }
     psum = wave_sum(psum);
@@ -147,8 +146,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_coeff_kernel(const float* __rest
     const float alpha = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_g;   // <dO, O>
     for (int k = tid; k < K; k += 256) {
         float p = 0.f, dw = 0.f, nw = 0.f;
-#pragma unroll
-        for (int s = 0; s < VB_DSPLIT; ++s) {
+        for (int s = 0; s < nsplit; ++s) {
             p += dp[s * 3 * K + k];
             dw += dp[s * 3 * K + K + k];
             nw += dp[s * 3 * K + 2 * K + k];
@@ -599,6 +597,112 @@ __global__ __launch_bounds__(256) void vlad_bwd_assign_rows_kernel(const float* 
     }
 }
 
+// ---- k-major forms (LPM_VLAD_RAW_KMAJOR): dO and the un-normalised sums U are [B, K, D], as the NetVladV1 cluster encoder hands the
+// gradient back and as lpm_vlad_aggregate_raw_kmajor_fwd stored the sums -- no transpose of dO, no d-major copy of U -----------------------
+// one wave per (clip, cluster) row: dots[b][0][0..2][k] = <dO_k, N_k>, <dO_k, W2_k>, <N_k, W2_k>,  N_k = U_k rsqrt(max(colsq, eps))
+__global__ __launch_bounds__(256) void vlad_bwd_coldots_k_kernel(const float* __restrict__ dO, const float* __restrict__ U,
+                                                                 const float* __restrict__ W2T, const float* __restrict__ colsq, int D, int K,
+                                                                 int64_t rows, float* __restrict__ dots) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);           // b * K + k
+    if (row >= rows) return;                                                     // wave-uniform
+    const int k = (int)(row % K);
+    const int64_t b = row / K;
+    const float4* pd = reinterpret_cast<const float4*>(dO + row * D);
+    const float4* pu = reinterpret_cast<const float4*>(U + row * D);
+    const float4* pw = W2T ? reinterpret_cast<const float4*>(W2T + (int64_t)k * D) : nullptr;
+    float p = 0.f, dw = 0.f, nw = 0.f;
+    for (int i = lane; i < D / 4; i += 64) {
+        const float4 a = pd[i], n = pu[i];
+        p = fmaf(a.x, n.x, p); p = fmaf(a.y, n.y, p); p = fmaf(a.z, n.z, p); p = fmaf(a.w, n.w, p);
+        if (pw) {
+            const float4 w = pw[i];
+            dw = fmaf(a.x, w.x, dw); dw = fmaf(a.y, w.y, dw); dw = fmaf(a.z, w.z, dw); dw = fmaf(a.w, w.w, dw);
+            nw = fmaf(n.x, w.x, nw); nw = fmaf(n.y, w.y, nw); nw = fmaf(n.z, w.z, nw); nw = fmaf(n.w, w.w, nw);
+        }
+    }
+    p = wave_sum(p); dw = wave_sum(dw); nw = wave_sum(nw);
+    if (lane == 0) {
+        const float iv = rsqrtf(fmaxf(colsq[row], kL2Eps));
+        float* out = dots + b * 3 * K;
+        out[k] = p * iv;
+        out[K + k] = dw;
+        out[2 * K + k] = nw * iv;
+    }
+}
+
+// dU = u dO - v N as B-operand tiles ub1[b][d-step][k-tile] straight from the k-major tensors: a fragment lane (cluster, d half) wants 8
+// consecutive d of its cluster row -- two float4 of dO and of U, no LDS staging.  grid (D/32, B), 512 threads; g0[b][d] = sum_k dU U (when
+// wanted) is reduced through LDS in a fixed order.
+__global__ __launch_bounds__(512) void vlad_bwd_du_tiles_k_kernel(const float* __restrict__ dO, const float* __restrict__ U,
+                                                                  const float* __restrict__ ug, const float* __restrict__ vg,
+                                                                  const float* __restrict__ colsq, int D, int K, uint4* __restrict__ ub1,
+                                                                  float* __restrict__ g0) {
+    extern __shared__ float pl[];            // g0 only: [32 d][KT * 32 + 1] products summed over nothing yet
+    const int tid = threadIdx.x, b = blockIdx.y, d0 = blockIdx.x * 32;
+    const int KT = K / 32, DS = D / 16;
+    const int KS = K + 1;
+    for (int it = tid; it < 2 * KT * 64; it += 512) {
+        const int lane = it & 63, kt = (it >> 6) % KT, dsl = (it >> 6) / KT;
+        const int k = kt * 32 + (lane & 31), dl = dsl * 16 + 8 * (lane >> 5);
+        const int64_t row = (int64_t)b * K + k;
+        const float uu = ug[row], vv = vg[row], rn = rsqrtf(fmaxf(colsq[row], kL2Eps));
+        const float* po = dO + row * D + d0 + dl;
+        const float* pu = U + row * D + d0 + dl;
+        const float4 a0 = *reinterpret_cast<const float4*>(po), a1 = *reinterpret_cast<const float4*>(po + 4);
+        const float4 n0 = *reinterpret_cast<const float4*>(pu), n1 = *reinterpret_cast<const float4*>(pu + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float nv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = uu * av[e] - vv * (nv[e] * rn);
+            if (g0) pl[(dl + e) * KS + k] = v[e] * nv[e];
+        }
+        uint4 hi, lo;
+        tg_split8(v, hi, lo);
+        const int64_t base = ((((int64_t)b * DS + d0 / 16 + dsl) * KT + kt) * 2) * 64 + lane;
+        ub1[base] = hi;
+        ub1[base + 64] = lo;
+    }
+    if (g0) {
+        __syncthreads();
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            float acc = 0.f;
+            for (int k = lane; k < K; k += 64) acc += pl[r * KS + k];
+            acc = wave_sum(acc);
+            if (lane == 0) g0[(int64_t)b * D + d0 + r] = acc;
+        }
+    }
+}
+
+// dW2^T[k, d] = - sum_b s[b,k] (u[b,k] dO[b,k,d] - v[b,k] N[b,k,d]) over a range of clips per blockIdx.y (partial sums added in split
+// order by vlad_bwd_dcentres_reduce_kernel, then transposed to [D, K])
+__global__ __launch_bounds__(256) void vlad_bwd_dcentres_k_kernel(const float* __restrict__ dO, const float* __restrict__ U,
+                                                                  const float* __restrict__ asum, const float* __restrict__ u,
+                                                                  const float* __restrict__ v, const float* __restrict__ colsq, int B, int D,
+                                                                  int K, int bper, float* __restrict__ part) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index into [K, D]
+    const int64_t n4 = (int64_t)K * D / 4;
+    if (i >= n4) return;
+    const int k = (int)((i * 4) / D);
+    const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = b0; b < b1; ++b) {
+        const int64_t row = (int64_t)b * K + k;
+        const float4 a = reinterpret_cast<const float4*>(dO + (int64_t)b * K * D)[i];
+        const float4 n = reinterpret_cast<const float4*>(U + (int64_t)b * K * D)[i];
+        const float s = asum[row], uu = u[row], vr = v[row] * rsqrtf(fmaxf(colsq[row], kL2Eps));
+        acc.x -= s * (uu * a.x - vr * n.x);
+        acc.y -= s * (uu * a.y - vr * n.y);
+        acc.z -= s * (uu * a.z - vr * n.z);
+        acc.w -= s * (uu * a.w - vr * n.w);
+    }
+    reinterpret_cast<float4*>(part)[(int64_t)blockIdx.y * n4 + i] = acc;
+}
+
 static size_t bwd_main_lds_bytes(int K) {
     const int KS = (K + 31) / 32 * 32 + 1;
     return (size_t)(2 * 32 * KS + 32 * 33 + 4 * 32 * 33 + 3 * K) * sizeof(float);
@@ -645,7 +749,7 @@ extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const
     }
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr,
                        D, K, dots, (const float*)nullptr, 0);
-    hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil);
+    hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil, VB_DSPLIT);
     const int nts = (T + VB_TS - 1) / VB_TS;
     const size_t lds = bwd_main_lds_bytes(K);
     dim3 grid(B * nts);
@@ -729,15 +833,34 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     uint4* ub2 = (uint4*)(ws + L.ub2);
     uint4* ar = (uint4*)(ws + L.ar);
     const float* dO = dout;
-    if (flags & LPM_VLAD_OUT_KMAJOR) {
+    const bool rk = (flags & LPM_VLAD_RAW_KMAJOR) != 0;      // dout AND nrm (the un-normalised sums) are k-major [B, K, D]
+    LPM_REQUIRE(!rk || (g0 && planes == 2 && D % 32 == 0), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_bwd_tiles: the k-major form is the split-bf16, no-input-gradient form (needs g0)");
+    if ((flags & LPM_VLAD_OUT_KMAJOR) && !rk) {
         launch_kmajor_to_dmajor(dout, B, D, K, dod, s);
         dO = dod;
     }
-    const bool raw = (flags & LPM_VLAD_NRM_RAW) != 0;
+    const bool raw = (flags & LPM_VLAD_NRM_RAW) != 0 || rk;
     const float* colsq_raw = raw ? colsq : nullptr;
+    float* w2t = dod;                                        // k-major form: centres^T [K, D] (the d-major copy of dout is not needed there)
+    if (rk) {
+        if (residual) launch_kmajor_to_dmajor(centres, 1, /*D=*/K, /*K=*/D, w2t, s);        // [D, K] -> [K, D]
+        const int64_t rows = (int64_t)B * K;
+        hipLaunchKernelGGL(vlad_bwd_coldots_k_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, nrm, residual ? w2t : nullptr,
+                           colsq, D, K, rows, dots);
+        hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil, 1);
+        const size_t lds = (size_t)32 * (K + 1) * sizeof(float);
+        auto kern = vlad_bwd_du_tiles_k_kernel;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("lpm_vlad_aggregate_bwd_tiles: cannot reserve %zu bytes of LDS", lds);
+            return LPM_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(512), lds, s, dO, nrm, u, v, colsq, D, K, ub1, g0);
+    } else {
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr, D, K, dots,
                        colsq_raw, planes == 1 ? 1 : 0);
-    hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil);
+    hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil, VB_DSPLIT);
     {
         const size_t lds = (size_t)(32 * (K + 1) + 3 * K + (g0 ? 32 * (K + 1) : 0)) * sizeof(float);
         auto kern = vlad_bwd_du_tiles_kernel;
@@ -748,6 +871,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
         }
         hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(VB_DU_NT), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0,
                            raw ? 1 : 0, planes);
+    }
     }
     if (!g0) {       // the assignment's row tiles are the A operand of the dx GEMM only
         const size_t lds = (size_t)32 * (K + 1) * sizeof(float);
@@ -771,7 +895,18 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     g.logits = assign; g.logits_bf16 = planes == 1 ? 1 : 0; g.scale = scale; g.shift = shift; g.ctil = ctil; g.softmax = sm ? 1 : 0;
     const int rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles", planes);
     if (rc != LPM_OK) return rc;
-    if (residual || g0) {        // dcentres = - sum_b asum_b dU_b: the centres' gradient, and (g0) the input batch norm's beta term
+    if ((residual || g0) && rk) {
+        // k-major form: partial sums over clip ranges [z][K][D] -> fixed-order reduce -> [K, D] -> transpose into dcentres [D, K]
+        const int64_t n4 = (int64_t)D * K / 4;
+        const unsigned wgx = (unsigned)((n4 + 255) / 256);
+        const int Z = dcentres_splits(B, D, K), bper = (B + Z - 1) / Z, Zeff = (B + bper - 1) / bper;
+        float* part = (float*)(ws + L.dcp);
+        float* tmp = (float*)(ws + L.ub2);                    // [K, D] (no second dU tile orientation in this form: the region is free)
+        hipLaunchKernelGGL(vlad_bwd_dcentres_k_kernel, dim3(wgx, (unsigned)Zeff), dim3(256), 0, s, dO, nrm, asum, u, v, colsq, B, D, K, bper,
+                           part);
+        hipLaunchKernelGGL(vlad_bwd_dcentres_reduce_kernel, dim3(wgx), dim3(256), 0, s, (const float4*)part, Zeff, n4, (float4*)tmp);
+        launch_kmajor_to_dmajor(tmp, 1, D, K, dcentres, s);
+    } else if (residual || g0) {        // dcentres = - sum_b asum_b dU_b: the centres' gradient, and (g0) the input batch norm's beta term
         launch_dcentres(dO, nrm, asum, u, v, B, D, K, (float*)(ws + L.dcp), dcentres, s, colsq_raw, planes == 1 ? 1 : 0);
     }
     return check_launch("lpm_vlad_aggregate_bwd_tiles");

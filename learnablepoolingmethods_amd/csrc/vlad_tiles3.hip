@@ -46,6 +46,8 @@ constexpr int T3_EPI = 8 * 32 * T3_WS * 4;  // epilogue bytes (8 waves x [32 d][
 struct T3Fused {
     float* out;                 // [B, D*K] or [B, K, D]
     int kmajor, store_u, debug_fallback;     // debug_fallback (tests): the first column slab of every clip acts as if its wait had timed out
+    int raw_kmajor;             // lpm_vlad_aggregate_raw_kmajor_fwd: no wait at all -- `out` receives the UN-normalised sums k-major [B, K, D]
+                                // (the normalisation becomes a [B, K] row scale the descriptor's consumers apply: lpm_vlad_row_scales)
     float* colsq;               // [B, K] (outputs for the backward, written by the first workgroup of a clip)
     float* csq;
     float* gsq;                 // [B]
@@ -217,6 +219,24 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
             colsq_part[((int64_t)b * P + ds) * K + k0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
             if (ds == 0) asum[(int64_t)b * K + k0 + tid] = ssum[tid];
         }
+        return;
+    }
+    if (fz.raw_kmajor) {
+        // the residual sums as they are, k-major, straight from the accumulators (acc[c][r]: column d = l31, cluster 8 (r >> 2) + 4 half
+        // + (r & 3)): for a fixed register the 32 lanes of a half-wave hold 32 consecutive d of one cluster row -- 128-byte segments
+        if (tid < 128) {
+            colsq_part[((int64_t)b * P + ds) * K + k0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            if (ds == 0) asum[(int64_t)b * K + k0 + tid] = ssum[tid];
+        }
+        float* okb = fz.out + ((int64_t)b * K + k0 + kw * 64) * D + d0 + l31;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kl = c * 32 + 8 * q + 4 * half;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) okb[(int64_t)(kl + j) * D] = acc[c][4 * q + j];
+            }
         return;
     }
     // ---- publish this workgroup's 128 partial norms write-through, arrive, wait for the clip (Guideline 16, form R1 with sc1 loads)
@@ -557,6 +577,85 @@ static int vlad_aggregate_tiles3_impl(const void* at, const void* xt, const floa
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
                            residual, nrm, asum, colsq_part, fz);
     return check_launch("lpm_vlad_aggregate_tiles3_fwd");
+}
+
+// ---- K2 writing the un-normalised sums k-major + the row scales that normalise them -----------------------------------------------
+namespace lpm {
+// per clip: n_k = sum_p colsq_part, 1/n_k, c_k, g = sum_k c_k;  scale[b, k] = rsqrt(max(n_k, eps)) * rsqrt(max(g, eps))   (K <= 1024)
+__global__ __launch_bounds__(256) void vlad_row_scales_kernel(const float* __restrict__ colsq_part, int P, int K, float* __restrict__ scale,
+                                                              float* __restrict__ colsq, float* __restrict__ csq, float* __restrict__ gsq) {
+    __shared__ float wg[4];
+    __shared__ float invn[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float g = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        float n = 0.f;
+        for (int p = 0; p < P; ++p) n += colsq_part[((int64_t)b * P + p) * K + k];
+        const float iv = rsqrtf(fmaxf(n, kL2Eps));
+        const float c = n * iv * iv;
+        invn[k] = iv;
+        g += c;
+        colsq[(int64_t)b * K + k] = n;
+        csq[(int64_t)b * K + k] = c;
+    }
+    g = wave_sum(g);
+    if ((tid & 63) == 0) wg[tid >> 6] = g;
+    __syncthreads();
+    const float tot = (wg[0] + wg[1]) + (wg[2] + wg[3]);
+    const float ig = rsqrtf(fmaxf(tot, kL2Eps));
+    if (tid == 0) gsq[b] = tot;
+    for (int k = tid; k < K; k += 256) scale[(int64_t)b * K + k] = invn[k] * ig;
+}
+}  // namespace lpm
+
+// K2 for a consumer that applies the normalisation itself (the NetVladV1 cluster encoders, App. C5: tokens = clusters): the
+// aggregation kernel stores the UN-normalised residual sums k-major [B, K, D] -- once, straight from the accumulators -- and
+// lpm_vlad_row_scales turns the partial norms into scale [B, K] = 1 / (n_k sqrt(g)) (+ colsq, csq, gsq for the backward), so that
+// descriptor[b, k, :] = raw[b, k, :] * scale[b, k] (frame_level_models.py:2819-2822 as a per-row factor).  No finalize pass: the
+// [B, D, K]-sized tensor is written once and never re-read by the pooling.  colsq_part: [B, D/128, K] floats.
+extern "C" int lpm_vlad_aggregate_raw_kmajor_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,
+                                                 int flags, float* raw_kmajor, float* asum, float* colsq_part, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(at && xt && raw_kmajor && asum && colsq_part, LPM_ERR_BADARG, "lpm_vlad_aggregate_raw_kmajor_fwd: null pointer");
+    const int residual = (flags & LPM_VLAD_RESIDUAL) ? 1 : 0;
+    LPM_REQUIRE(!residual || centres, LPM_ERR_BADARG, "lpm_vlad_aggregate_raw_kmajor_fwd: RESIDUAL needs centres");
+    LPM_REQUIRE(B > 0 && T > 0 && lpm_vlad_tiles3_supported(D, K), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_raw_kmajor_fwd: need D %% 128 == 0 and K %% 128 == 0 (D=%d K=%d)", D, K);
+    LPM_REQUIRE((((uintptr_t)at | (uintptr_t)xt | (uintptr_t)centres | (uintptr_t)raw_kmajor) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_vlad_aggregate_raw_kmajor_fwd: pointers must be 16-byte aligned");
+    const int S = (T + 15) / 16, KT = K / 32;
+    T3Fused fz{};
+    fz.out = raw_kmajor; fz.raw_kmajor = 1;
+    const size_t lds = (size_t)T3_NS * T3_STAGE + (4 * 128 + 128 + 16) * sizeof(float);
+    auto kern = vlad_aggregate_tiles3_kernel<true, 2>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("lpm_vlad_aggregate_raw_kmajor_fwd: cannot reserve %zu bytes of LDS", lds);
+        return LPM_ERR_LAUNCH;
+    }
+    dim3 grid(B * (K / 128) * (D / 128));
+    hipEvent_t e0, e1;
+    if (timing_request(LPM_TIMING_K2, &e0, &e1))
+        hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T, D, K,
+                              S, KT, residual, (float*)nullptr, asum, colsq_part, fz);
+    else
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
+                           residual, (float*)nullptr, asum, colsq_part, fz);
+    return check_launch("lpm_vlad_aggregate_raw_kmajor_fwd");
+}
+
+extern "C" int lpm_vlad_row_scales(const float* colsq_part, int P, int B, int K, float* scale, float* colsq, float* csq, float* gsq,
+                                   lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(colsq_part && scale && colsq && csq && gsq, LPM_ERR_BADARG, "lpm_vlad_row_scales: null pointer");
+    LPM_REQUIRE(B > 0 && P > 0 && K > 0 && K <= 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_vlad_row_scales: need 0 < K <= 1024 (K=%d)", K);
+    hipEvent_t e0, e1;
+    if (K >= 256 && timing_request(LPM_TIMING_FINALIZE, &e0, &e1))
+        hipExtLaunchKernelGGL(vlad_row_scales_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, colsq_part, P, K, scale, colsq, csq,
+                              gsq);
+    else
+        hipLaunchKernelGGL(vlad_row_scales_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, colsq_part, P, K, scale, colsq, csq, gsq);
+    return check_launch("lpm_vlad_row_scales");
 }
 
 // ---- K2 with the finalize pass fused in (see T3Fused): workspace = [colsq_part B*P*K floats | arrive B | fail B] --------------------

@@ -38,6 +38,9 @@ FLAGS.define("audio_det_reg", 1e-4, "frame_level_models.py:2209: orthogonality p
 FLAGS.define("netvlad_storage", "f32", "build extension: 'bf16' = the frames, logits / assignment and pooled descriptor of the NetVLAD "
              "streams live in HBM as bf16 with fp32 accumulation (BASELINE configs[4], 'Gated NetVLAD K=512 + MoE-4 ... bf16'); needs "
              "netvlad_encoder off, batch norm on, cluster_size a multiple of 512")
+FLAGS.define("netvlad_lazy_descriptor", True, "build extension: NetVladV1's video pooling hands its cluster encoder the un-normalised "
+             "residual sums [B, K, D] plus one scale per (clip, cluster); the encoder's block Functions apply the scale where they read "
+             "the rows -- the pooled tensor is written once, there is no finalize pass and no transpose in the pooling backward")
 FLAGS.define("fused_encoder_blocks", True, "build extension: run the V1 cluster encoder as two block Functions whose backward "
              "folds the gradient sums of shared tensors into GEMM accumulation / the layer-norm kernel (no add passes)")
 FLAGS.define("descriptor_slots", True, "build extension: both encoders write their pooled descriptor into one shared buffer "

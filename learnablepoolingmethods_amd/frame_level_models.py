@@ -28,8 +28,9 @@ class NetVLAD():
         self.add_batch_norm = add_batch_norm
         self.cluster_size = int(cluster_size)
 
-    def forward(self, reshaped_input, kmajor=False, input_affine=None, storage="f32"):
-        """input_affine: (gamma, beta) slices of input_bn when reshaped_input is its (gradient-free) output, see ops.netvlad."""
+    def forward(self, reshaped_input, kmajor=False, input_affine=None, storage="f32", lazy=False):
+        """input_affine: (gamma, beta) slices of input_bn when reshaped_input is its (gradient-free) output, see ops.netvlad.
+        lazy: hand the k-major descriptor over lazily normalised (ops.netvlad) -- for a consumer that applies the row scale."""
         D, K, dev = self.feature_size, self.cluster_size, reshaped_input.device
         std = 1 / math.sqrt(D)
         cluster_weights = vs.get_variable("cluster_weights", [D, K], vs.random_normal_initializer(std), device=dev)   # :2775
@@ -44,7 +45,7 @@ class NetVLAD():
                                                device=dev)                                                           # :2805-2808
         # matmul -> cluster_bn -> softmax -> a^T x - sum(a) W2 -> l2norm(D) -> flatten -> l2norm  (:2781-2822)
         return ops.netvlad(reshaped_input, cluster_weights, cluster_weights2, self.max_frames, bn=bn, bias=bias,
-                           is_training=self.is_training, kmajor=kmajor, input_affine=input_affine, storage=storage)
+                           is_training=self.is_training, kmajor=kmajor, input_affine=input_affine, storage=storage, lazy=lazy)
 
 
 class LightVLAD(NetVLAD):
@@ -178,9 +179,22 @@ class NetVladV1(models.BaseModel):
         import contextlib
         use_side = has_audio and reshaped_input.is_cuda and FLAGS.audio_side_stream
         side = ops.side_stream(audio, reshaped_input) if use_side else contextlib.nullcontext()
+        # The video descriptor goes to its cluster encoder LAZILY NORMALISED when that encoder will run as block Functions (they apply
+        # the per-cluster scale where they read the rows): the pooling then writes the [B, K, D] tensor once and has no finalize pass.
+        video_encoder_block = None
+        if encoder:
+            video_encoder_block = transformer_utils.TransformerEncoder(
+                feature_size=1024, hidden_size=1024, num_heads=64, attention_dropout=0.1, ff_filter_size=4 * 1024,
+                ff_relu_dropout=0.1, is_train=is_training, scope_id="encode1")
+        batch = model_input.shape[0]
+        lazy_v = bool(encoder and FLAGS.netvlad_lazy_descriptor and storage == "f32" and reshaped_input.is_cuda
+                      and (aff_v is not None or not torch.is_grad_enabled())
+                      and video_encoder_block.fused_shape(batch, cluster_size, True) and ops.netvlad_lazy_ok(max_frames, 1024, cluster_size))
         with vs.variable_scope("video_VLAD"):
-            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v, storage=storage)       # :2273-2274
-            vs.summary("vlad_video", vlad_video)     # [B, K, D] (the App. C5 token view) when the encoders follow, else [B, D*K]
+            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v, storage=storage, lazy=lazy_v)   # :2273-2274
+            if vs.default_store().summaries is not None:
+                # [B, K, D] (the App. C5 token view) when the encoders follow, else [B, D*K]
+                vs.summary("vlad_video", ops.materialise(vlad_video))
         if has_audio:
             with side, vs.variable_scope("audio_VLAD"):
                 vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder, input_affine=aff_a, storage=storage) # :2276-2277
@@ -189,10 +203,6 @@ class NetVladV1(models.BaseModel):
         slots = None
         if encoder:
             # tokens = clusters (App. C5): the pooling kernel already wrote the [B, K, D] view
-            with vs.variable_scope("video_attention"):
-                video_encoder_block = transformer_utils.TransformerEncoder(
-                    feature_size=1024, hidden_size=1024, num_heads=64, attention_dropout=0.1, ff_filter_size=4 * 1024,
-                    ff_relu_dropout=0.1, is_train=is_training, scope_id="encode1")
             if has_audio:
                 with vs.variable_scope("audio_attention"):
                     audio_encoder_block = transformer_utils.TransformerEncoder(

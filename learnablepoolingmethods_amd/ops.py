@@ -353,11 +353,11 @@ def _nrm_raw_ok(lib, T, D, K):
     return (VLAD_PRECISION == "bf16x3" and VLAD_TILES3 and bool(lib._lpm_vlad_tiles3_supported(D, K)) and _bwd_tiles_ok(lib, T, D, K))
 
 
-def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor, nrm_raw=False, save_u=True):
+def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kmajor, nrm_raw=False, save_u=True, lazy=False):
     """-> out, nrm, asum, colsq, csq, gsq, xt (the split-bf16 frame tiles of x, or None on the fp32 path).
     nrm_raw (only with _nrm_raw_ok): ``nrm`` comes back as the un-normalised sums U."""
     xt = None
-    nrm = _empty((B, D, K), x)
+    nrm = None if lazy else _empty((B, D, K), x)
     asum, colsq, csq = (_empty((B, K), x) for _ in range(3))
     if VLAD_PRECISION == "bf16x3":
         st = stream_ptr()
@@ -369,6 +369,22 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
         at = torch.empty(lib._lpm_at_bytes(B, T, K) // 4, dtype=torch.int32, device=x.device)
         with _timed("assign_tiles", (B, T, K)):
             lib.check(lib._lpm_assign_tiles(ptr(assign), ptr(scale), ptr(shift), B, T, K, flags, ptr(at), st), "lpm_assign_tiles")
+        if lazy:
+            # the un-normalised sums k-major, written once, + one scale per (clip, cluster): the consumers normalise (see netvlad())
+            if not (kmajor and VLAD_TILES3 and lib._lpm_vlad_tiles3_supported(D, K) and K <= 1024):
+                raise LpmError("internal: lazy descriptor without the LDS-shared aggregation form")
+            raw = _empty((B, K, D), x)
+            P = D // 128
+            part = _empty((B, P, K), x)
+            with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+                lib.check(lib._lpm_vlad_aggregate_raw_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags & LPM_VLAD_RESIDUAL,
+                                                                 ptr(raw), ptr(asum), ptr(part), st), "lpm_vlad_aggregate_raw_kmajor_fwd")
+            rs = _empty((B, K), x)
+            gsq = _empty((B,), x)
+            with _timed("vlad_finalize", (B, D, K)):
+                lib.check(lib._lpm_vlad_row_scales(ptr(part), P, B, K, ptr(rs), ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_row_scales")
+            raw._lpm_row_scale = rs
+            return raw, raw, asum, colsq, csq, gsq, xt
         if VLAD_TILES3 and VLAD_FUSED and nrm_raw and lib._lpm_vlad_fused_supported(D, K):
             # LDS-shared form with both normalisations fused in: the descriptor is written once, normalised; the un-normalised
             # sums go to HBM only when a backward will read them (save_u: some input of the op requires a gradient)
@@ -441,7 +457,7 @@ def _bwd_tiles_ok(lib, T, D, K):
 
 
 def _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, shift, x, xr, centres, B, T, D, K, flags, kmajor,
-                         no_dx=False, nrm_raw=False):
+                         no_dx=False, nrm_raw=False, raw_kmajor=False):
     """First half of K3's tile form: -> dassign, dcentres, (workspace, bytes) for _aggregate_bwd_tiles_dx, g0.
     no_dx: the frames need no gradient -- the dx operands are not produced; g0 [B, D] = sum_k dU U and dcentres = -sum_b asum dU
     (also without a residual term) come back instead (see _NetVLAD.backward)."""
@@ -455,6 +471,8 @@ def _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, s
     wsb = lib._lpm_vlad_bwd_tiles_workspace_bytes(B, T, D, K)
     ws = _tile_buffer(wsb, x)
     fl = flags | (LPM_VLAD_OUT_KMAJOR if kmajor else 0) | (LPM_VLAD_NRM_RAW if nrm_raw else 0)
+    if raw_kmajor:          # dout and the saved sums are both k-major: no transposes (needs the no-input-gradient form)
+        fl |= _capi.LPM_VLAD_RAW_KMAJOR
     with _timed("vlad_aggregate_bwd", (B, T, D, K)):
         lib.check(lib._lpm_vlad_aggregate_bwd_tiles(ptr(dout), ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(assign),
                                                     ptr(scale), ptr(shift), ptr(xr), ptr(centres), B, T, D, K, fl, ptr(dassign),
@@ -506,7 +524,7 @@ class _NetVLAD(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, gamma, beta, moving_mean, moving_var, bias, W2, T, is_training, kmajor, in_gamma=None, in_beta=None,
-                storage="f32"):
+                storage="f32", lazy=False):
         """in_gamma / in_beta ([D] slices of input_bn's gamma / beta): x is input_bn's output for these columns and needs no
         gradient of its own -- the backward then returns input_bn's gamma / beta gradients in closed form instead of dx."""
         lib = _capi.load()
@@ -518,6 +536,9 @@ class _NetVLAD(torch.autograd.Function):
             raise LpmError(f"rows {M} not divisible by max_frames {T}")
         B = M // T
         ctx.storage = storage
+        ctx.lazy = bool(lazy)
+        if lazy and storage != "f32":
+            raise LpmError("netvlad: the lazily normalised descriptor is an fp32-storage form")
         if storage == "bf16":
             return _NetVLAD._forward_bf16(ctx, lib, x, W, gamma, beta, moving_mean, moving_var, bias, W2, B, T, D, K, is_training, kmajor,
                                           in_gamma, in_beta)
@@ -561,13 +582,23 @@ class _NetVLAD(torch.autograd.Function):
         flags = LPM_VLAD_SOFTMAX | (LPM_VLAD_RESIDUAL if W2 is not None else 0)
         centres = W2.reshape(D, K).contiguous() if W2 is not None else None
         ctx.nrm_raw = _nrm_raw_ok(lib, T, D, K)
+        ctx.no_dx = in_gamma is not None and tiles and _bwd_tiles_ok(lib, T, D, K)
+        if lazy and not (kmajor and ctx.nrm_raw and (ctx.no_dx or not any(ctx.needs_input_grad))):
+            raise LpmError("netvlad: the lazily normalised descriptor needs the k-major layout, the tile forms of K2 / K3 and frames "
+                           "without a gradient of their own (input_affine)")
         out, nrm, asum, colsq, csq, gsq, xt = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor,
-                                                             nrm_raw=ctx.nrm_raw, save_u=any(ctx.needs_input_grad))
+                                                             nrm_raw=ctx.nrm_raw, save_u=any(ctx.needs_input_grad), lazy=lazy)
         ctx.dims = (B, T, D, K, flags, kmajor, use_bn, is_training, W2 is not None, tiles)
         ctx.dx_slot = getattr(x, "_lpm_dx_slot", None)
-        ctx.no_dx = in_gamma is not None and tiles and _bwd_tiles_ok(lib, T, D, K)
         if in_gamma is not None and not ctx.no_dx:
             raise LpmError("netvlad: the input_bn gradient shortcut needs the tile (bf16x3) forms of K1 and K3 for this shape")
+        if lazy:          # nrm IS out (the raw sums): saving an output as such would keep the graph alive through it
+            rs = out._lpm_row_scale
+            nrm = out.detach()
+            ctx.save_for_backward(x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr,
+                                  in_gamma, in_beta)
+            out._lpm_row_scale = rs
+            return out
         ctx.save_for_backward(x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr,
                               in_gamma, in_beta)
         return out
@@ -685,7 +716,7 @@ class _NetVLAD(torch.autograd.Function):
                                               ptr(in_gamma.contiguous()), ptr(in_beta.contiguous()), B, D, K, ptr(d_in_gamma),
                                               ptr(d_in_beta), st), "lpm_input_bn_grads")
         dW2 = dcentres.reshape(1, D, K) if has_w2 else None
-        return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None
+        return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None, None
 
     @staticmethod
     def backward(ctx, dout):
@@ -701,7 +732,8 @@ class _NetVLAD(torch.autograd.Function):
             raise LpmError("netvlad: the forward left nrm un-normalised for the tile backward, which is no longer selected")
         if k3_tiles:
             dlt, dcentres, wspace, g0 = _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, xr,
-                                                             centres, B, T, D, K, flags, kmajor, no_dx=no_dx, nrm_raw=ctx.nrm_raw)
+                                                             centres, B, T, D, K, flags, kmajor, no_dx=no_dx, nrm_raw=ctx.nrm_raw,
+                                                             raw_kmajor=ctx.lazy)
             dx = None
         else:
             dlt, dx, dcentres = _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, centres, B, T, D,
@@ -744,7 +776,7 @@ class _NetVLAD(torch.autograd.Function):
                                               ptr(in_gamma.contiguous()), ptr(in_beta.contiguous()), B, D, K, ptr(d_in_gamma),
                                               ptr(d_in_beta), stream_ptr()), "lpm_input_bn_grads")
             dW2 = dcentres.reshape(1, D, K) if has_w2 else None
-            return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None
+            return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None, None
         if k3_tiles:
             dx = _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, x, B, T, D, K, out=_dx_slot_view(ctx.dx_slot, D))
             if not tiles:
@@ -755,18 +787,56 @@ class _NetVLAD(torch.autograd.Function):
         else:
             dx.addmm_(dl, W.t())
         dW2 = dcentres.reshape(1, D, K) if has_w2 else None
-        return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, None, None, None
+        return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, None, None, None, None
+
+
+class _Materialise(torch.autograd.Function):
+    """raw [B, K, D] x row_scale [B, K] -> the normalised descriptor as an ordinary tensor.  The gradient passes through UNCHANGED: by
+    the contract of the lazily normalised form (netvlad(lazy=True)) the gradient a consumer returns for `raw` IS the gradient with
+    respect to the normalised descriptor -- the Jacobian of both normalisations lives in the pooling op's backward (K3)."""
+
+    @staticmethod
+    def forward(ctx, raw, row_scale):
+        return raw * row_scale.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, None
+
+
+def row_scale_of(x):
+    """The [B, K] row scale of a lazily normalised descriptor (None for an ordinary tensor)."""
+    return getattr(x, "_lpm_row_scale", None)
+
+
+def materialise(x):
+    """An ordinary tensor for any consumer that does not apply the row scale itself."""
+    rs = row_scale_of(x)
+    return x if rs is None else _Materialise.apply(x, rs)
+
+
+def netvlad_lazy_ok(T, D, K):
+    """Shapes for which netvlad(kmajor=True, lazy=True) exists: the LDS-shared K2 form and the tile form of K3."""
+    lib = _capi.load()
+    return (VLAD_PRECISION == "bf16x3" and VLAD_TILES3 and bool(lib._lpm_vlad_tiles3_supported(D, K)) and K <= 512
+            and netvlad_input_shortcut_ok(T, D, K))
 
 
 def netvlad(x, cluster_weights, cluster_weights2, max_frames, bn=None, bias=None, is_training=True, kmajor=False,
-            input_affine=None, storage="f32"):
+            input_affine=None, storage="f32", lazy=False):
     """bn = (gamma, beta, moving_mean, moving_var) or None (then ``bias`` = cluster_biases).  input_affine = (gamma, beta) slices
     of the input batch norm whose output x is (x itself then needs no gradient): see _NetVLAD.forward.  storage="bf16": the
-    descriptor comes back as bf16 [B, D*K] (see _NetVLAD._forward_bf16)."""
+    descriptor comes back as bf16 [B, D*K] (see _NetVLAD._forward_bf16).
+    lazy (with kmajor; netvlad_lazy_ok shapes; frames without a gradient): the result is the LAZILY NORMALISED descriptor -- the
+    un-normalised residual sums [B, K, D], written once by the aggregation kernel, carrying ``_lpm_row_scale`` [B, K] =
+    1 / (n_k sqrt(g)); descriptor = result * scale per (clip, cluster) row (frame_level_models.py:2819-2822).  Consumers that know
+    (ops.attention_block_x3: the operand split of its q/k/v GEMM and its residual layer norm) apply the scale where they read the
+    rows; the gradient they return for it is the gradient with respect to the normalised descriptor.  Everybody else goes through
+    ops.materialise.  No finalize pass, no transposes in the backward."""
     g, b, mm, mv = bn if bn is not None else (None, None, None, None)
     ig, ib = input_affine if input_affine is not None else (None, None)
     return _NetVLAD.apply(x, cluster_weights, g, b, mm, mv, bias, cluster_weights2, int(max_frames), bool(is_training),
-                          bool(kmajor), ig, ib, storage)
+                          bool(kmajor), ig, ib, storage, bool(lazy))
 
 
 def netvlad_input_shortcut_ok(T, D, K):
@@ -819,12 +889,15 @@ def vlad_aggregate(sims, x, centres, max_frames, kmajor=False):
 # ----------------------------------------------------------------------------------------------
 # dense layers of the encoders on the bf16 matrix pipe at fp32-grade accuracy (split-bf16 operands)
 # ----------------------------------------------------------------------------------------------
-def _split_rows(x2d, bias=None, relu=False, grad=False):
+def _split_rows(x2d, bias=None, relu=False, grad=False, row_scale=None):
     """[M,K] fp32 -> [M,3K] bf16 = [hi | lo | hi] (optionally of relu(x + bias)); grad=True: the gradient plane order
     [hi | hi | lo] that pairs with w3k (rows [Wh|Wl|Wh]) and, row by row, with an activation image (see _dw_x3)."""
     lib = _capi.load()
     M, K = x2d.shape
     out = torch.empty((M, 3 * K), dtype=torch.bfloat16, device=x2d.device)
+    if row_scale is not None:       # x2d = the rows of a lazily normalised descriptor (netvlad(lazy=True)): scaled as they are read
+        lib.check(lib._lpm_split_rows_scaled(ptr(x2d), x2d.stride(0), M, K, ptr(row_scale), ptr(out), stream_ptr()), "lpm_split_rows_scaled")
+        return out
     lib.check(lib._lpm_split_rows(ptr(x2d), x2d.stride(0), M, K, ptr(bias), 1 if relu else 0, 1 if grad else 0, ptr(out),
                                   stream_ptr()), "lpm_split_rows")
     return out
@@ -887,11 +960,11 @@ class _QKVX3(torch.autograd.Function):
     q, k, v are returned as column views of one [M, 3N] buffer (the attention kernels take a row stride)."""
 
     @staticmethod
-    def forward(ctx, x2d, Wq, Wk, Wv):
+    def forward(ctx, x2d, Wq, Wk, Wv, row_scale=None):
         x2d = _rows(x2d, "dense input")
         K, N = Wq.shape
         Wcat = torch.cat([_f32(Wq, "q kernel"), _f32(Wk, "k kernel"), _f32(Wv, "v kernel")], dim=1)
-        x3 = _split_rows(x2d)
+        x3 = _split_rows(x2d, row_scale=row_scale)
         w3n, w3k = _split_weight(Wcat, need_t=ctx.needs_input_grad[0])
         ctx.save_for_backward(x3, w3k)
         ctx.dims = (K, N)
@@ -1146,7 +1219,8 @@ class _ResidualLayerNorm(torch.autograd.Function):
     """y = layer_norm(act(a + bias) + r): TF1 joint moments, with the producing dense layer's bias add / ReLU fused in."""
 
     @staticmethod
-    def forward(ctx, a, r, gamma, beta, bias, relu, out=None):
+    def forward(ctx, a, r, gamma, beta, bias, relu, out=None, r_scale=None):
+        """r_scale [B * L] (block Functions only): r holds the rows of a lazily normalised descriptor, scaled as they are read."""
         lib = _capi.load()
         a = _f32(a, "layer_norm input").contiguous()
         B, L, F = a.shape
@@ -1159,9 +1233,14 @@ class _ResidualLayerNorm(torch.autograd.Function):
         stats = _empty((B, 2), a)
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
-        lib.check(lib._lpm_layer_norm_act_fwd(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(gamma), ptr(beta), B, L, F, LN_EPS,
-                                              ptr(y), y.stride(0), ptr(z) if z is not a else None, ptr(stats), ptr(ws), wsb,
-                                              stream_ptr()), "lpm_layer_norm_act_fwd")
+        if r_scale is not None:
+            lib.check(lib._lpm_layer_norm_act_fwd_rs(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(r_scale), ptr(gamma), ptr(beta), B, L, F,
+                                                     LN_EPS, ptr(y), y.stride(0), ptr(z) if z is not a else None, ptr(stats), ptr(ws),
+                                                     wsb, stream_ptr()), "lpm_layer_norm_act_fwd_rs")
+        else:
+            lib.check(lib._lpm_layer_norm_act_fwd(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(gamma), ptr(beta), B, L, F, LN_EPS,
+                                                  ptr(y), y.stride(0), ptr(z) if z is not a else None, ptr(stats), ptr(ws), wsb,
+                                                  stream_ptr()), "lpm_layer_norm_act_fwd")
         ctx.has_r, ctx.relu, ctx.has_bias = r is not None, bool(relu), bias is not None
         ctx.save_for_backward(z, stats, gamma, a if relu else None, bias)
         return y
@@ -1343,12 +1422,15 @@ class _AttnBlockX3(torch.autograd.Function):
     input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale):
+    def forward(ctx, x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale, row_scale=None):
+        """row_scale [B, L]: x is a lazily normalised descriptor (netvlad(lazy=True)) -- its two readers, the q/k/v operand split and the
+        residual layer norm, scale the rows as they read them; the returned gradient is with respect to the normalised x."""
         x = _f32(x, "attention block input").contiguous()
         B, L, F = x.shape
         N = Wq.shape[1]
+        rs = row_scale.reshape(-1).contiguous() if row_scale is not None else None
         cq, cm, co, cl = _SubCtx(), _SubCtx(), _SubCtx(), _SubCtx()
-        q, k, v = _QKVX3.forward(cq, x.view(B * L, F), Wq, Wk, Wv)
+        q, k, v = _QKVX3.forward(cq, x.view(B * L, F), Wq, Wk, Wv, row_scale=rs)
         from . import FLAGS
         if MHA_PRECISION == "bf16x3" and FLAGS.mha_gradient_image:     # the attention result only as the output GEMM's operand image
             o3 = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale, image=True)
@@ -1356,7 +1438,7 @@ class _AttnBlockX3(torch.autograd.Function):
         else:
             o = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale)
             att = _DenseX3.forward(co, o.view(B * L, N), Wo)
-        y = _ResidualLayerNorm.forward(cl, att.view(B, L, Wo.shape[1]), x, gamma, beta, bo, False)
+        y = _ResidualLayerNorm.forward(cl, att.view(B, L, Wo.shape[1]), x, gamma, beta, bo, False, None, rs)
         _pack_subs(ctx, (cq, cm, co, cl))
         ctx.shape = (B, L, F, N)
         return y
@@ -1374,11 +1456,12 @@ class _AttnBlockX3(torch.autograd.Function):
         else:
             dq, dk, dv = _MHACore.backward(cm, do.view(B, L, N))[:3]
             dx, dWq, dWk, dWv = _QKVX3.backward(cq, dq.view(B * L, N), dk.view(B * L, N), dv.view(B * L, N), acc=dz.view(B * L, F))
-        return dx.view(B, L, F), dWq, dWk, dWv, dWo, dbo, dgamma, dbeta, None, None
+        return dx.view(B, L, F), dWq, dWk, dWv, dWo, dbo, dgamma, dbeta, None, None, None
 
 
 def attention_block_x3(x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale):
-    return _AttnBlockX3.apply(x, Wq, Wk, Wv, Wo, bo, gamma, beta, int(num_heads), float(scale))
+    """x may be a lazily normalised descriptor (ops.netvlad(lazy=True)): its row scale is applied where the block reads the rows."""
+    return _AttnBlockX3.apply(x, Wq, Wk, Wv, Wo, bo, gamma, beta, int(num_heads), float(scale), row_scale_of(x))
 
 
 def _ln_pair_forward(c1, c2, a, r, g1, be1, bias, g2, be2, out=None):

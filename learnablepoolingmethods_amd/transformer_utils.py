@@ -132,16 +132,20 @@ class TransformerEncoder(modules.BaseModule):
 
     def fused(self, inputs):
         """Whether ``forward`` takes the block-Function path for this input (then it can write into an ops.OutputSlot)."""
+        return inputs.dim() == 3 and inputs.shape[-1] == self.feature_size and self.fused_shape(inputs.shape[0], inputs.shape[1], inputs.is_cuda)
+
+    def fused_shape(self, batch, tokens, is_cuda):
+        """The same question before the input exists (the pooling op asks, to hand over a lazily normalised descriptor)."""
         from . import FLAGS
-        rows = inputs.numel() // inputs.shape[-1]
-        return bool(FLAGS.fused_encoder_blocks and inputs.is_cuda and inputs.dim() == 3 and inputs.shape[-1] == self.feature_size
-                and self.feature_size in ops.LN_FEATURES and layers.use_split_gemm(inputs, rows, self.hidden_size)
-                and self.ff_network.filter_size % 8 == 0 and self.hidden_size // self.num_heads in (8, 16)
-                and inputs.shape[1] <= 512)
+        return bool(FLAGS.fused_encoder_blocks and is_cuda and self.feature_size in ops.LN_FEATURES
+                    and FLAGS.dense_precision == "bf16x3" and batch * tokens >= 1024 and self.feature_size % 8 == 0
+                    and self.hidden_size % 8 == 0 and self.ff_network.filter_size % 8 == 0
+                    and self.hidden_size // self.num_heads in (8, 16) and tokens <= 512)
 
     def forward(self, inputs, out_slot=None, **unused_params):
         if self.fused(inputs):
             return self._fused_blocks(inputs, out_slot)
+        inputs = ops.materialise(inputs)       # (a lazily normalised descriptor is the block path's business only)
         if out_slot is not None:
             raise ValueError("out_slot needs the block-Function path (TransformerEncoder.fused)")
         attention, bias = self.multi_head_attention.forward(inputs, inputs, defer_bias=True)

@@ -560,3 +560,36 @@ def test_cfg5_full_batch_properties():
     assert abs(res["bf16"][0] - res["f32"][0]) <= CFG5_FWD_TOL * abs(res["f32"][0])
     assert rel_err(res["bf16"][1]["vlad"].float(), res["f32"][1]["vlad"]) <= CFG5_FWD_TOL
     assert rel_l2(res["bf16"][2], res["f32"][2]) <= CFG5_GRAD_TOL
+
+
+def test_lazily_normalised_descriptor_does_not_change_the_step():
+    """NetVladV1's video pooling hands its cluster encoder the un-normalised sums [B, K, D] + one scale per (clip, cluster)
+    (FLAGS.netvlad_lazy_descriptor, ops.netvlad(lazy=True)): no finalize pass, no transposes in the pooling backward.  Against the
+    materialised path on the same step: same loss, same gradient arena to summation-order noise, same inference output; the
+    summaries still show the normalised descriptor.  (test_cfg2_layer_sizes_reduced_batch holds the lazy path to the oracle.)"""
+    from learnablepoolingmethods_amd import FLAGS, ops, registry
+    from learnablepoolingmethods_amd.train import Trainer
+    dev = cuda()
+    B, MF = 16, 40
+    x, nf, lab = O.make_synthetic_batch(B, MF, 1152, 50, seed=31, min_frames=10)
+    res = []
+    for lazy in (True, False, True):
+        FLAGS.netvlad_lazy_descriptor = lazy
+        try:
+            tr = Trainer(registry.get_model("NetVladV1"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=19,
+                         model_kwargs=dict(iterations=32, cluster_size=256, hidden_size=64))
+            tr.build(x, nf, lab)
+            tr.store.summaries = {}
+            loss = tr.step(x, nf, lab)["loss"].item()
+            summ, tr.store.summaries = tr.store.summaries, None
+            torch.cuda.synchronize()
+            res.append((loss, tr.arena.grad.clone(), tr.predict(x, nf).clone(), summ["vlad_video"].clone()))
+        finally:
+            FLAGS.reset()
+    assert res[0][0] == res[2][0] and torch.equal(res[0][1], res[2][1]), "the lazy path is bitwise repeatable"
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0])
+    assert rel_l2(res[0][1], res[1][1]) < 2e-5
+    assert rel_l2(res[0][2], res[1][2]) < 2e-5
+    assert rel_err(res[0][3], res[1][3]) < 1e-6
+    v = res[0][3].reshape(B, 256, 1024)                               # normalised: every cluster row has norm 1 / sqrt(K)
+    assert torch.allclose(v.norm(dim=2), torch.full((B, 256), 256 ** -0.5, device=dev), atol=1e-6)
