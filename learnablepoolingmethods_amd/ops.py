@@ -583,9 +583,8 @@ class _NetVLAD(torch.autograd.Function):
         centres = W2.reshape(D, K).contiguous() if W2 is not None else None
         ctx.nrm_raw = _nrm_raw_ok(lib, T, D, K)
         ctx.no_dx = in_gamma is not None and tiles and _bwd_tiles_ok(lib, T, D, K)
-        if lazy and not (kmajor and ctx.nrm_raw and (ctx.no_dx or not any(ctx.needs_input_grad))):
-            raise LpmError("netvlad: the lazily normalised descriptor needs the k-major layout, the tile forms of K2 / K3 and frames "
-                           "without a gradient of their own (input_affine)")
+        if lazy and not (kmajor and ctx.nrm_raw):
+            raise LpmError("netvlad: the lazily normalised descriptor needs the k-major layout and the tile forms of K2 / K3")
         out, nrm, asum, colsq, csq, gsq, xt = _aggregate_fwd(lib, logits, scale, shift, x, centres, B, T, D, K, flags, kmajor,
                                                              nrm_raw=ctx.nrm_raw, save_u=any(ctx.needs_input_grad), lazy=lazy)
         ctx.dims = (B, T, D, K, flags, kmajor, use_bn, is_training, W2 is not None, tiles)
@@ -728,6 +727,9 @@ class _NetVLAD(torch.autograd.Function):
         dout = _f32(dout, "dout").contiguous()
         k3_tiles = _bwd_tiles_ok(lib, T, D, K)
         no_dx = ctx.no_dx
+        if ctx.lazy and not no_dx:
+            raise LpmError("netvlad: the backward of the lazily normalised descriptor needs frames without a gradient of their own "
+                           "(input_affine): K3's k-major form has no input-gradient path")
         if ctx.nrm_raw and not k3_tiles:
             raise LpmError("netvlad: the forward left nrm un-normalised for the tile backward, which is no longer selected")
         if k3_tiles:
