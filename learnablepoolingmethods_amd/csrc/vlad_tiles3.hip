@@ -228,15 +228,25 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
             colsq_part[((int64_t)b * P + ds) * K + k0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
             if (ds == 0) asum[(int64_t)b * K + k0 + tid] = ssum[tid];
         }
-        float* okb = fz.out + ((int64_t)b * K + k0 + kw * 64) * D + d0 + l31;
+        // through the wave-private LDS tile once more, this time as [32 k][32 d]: the store pass then writes float4 along d
+        // (8 lanes = one 128-byte row piece; 8 stores per lane instead of 32 dword stores)
+        float* okb = fz.out + ((int64_t)b * K + k0 + kw * 64) * D + d0;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int kl = c * 32 + 8 * q + 4 * half;
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) okb[(int64_t)(kl + j) * D] = acc[c][4 * q + j];
+                for (int j = 0; j < 4; ++j) wl[(8 * q + 4 * half + j) * T3_WS + l31] = acc[c][4 * q + j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int kr = it * 8 + srow;                       // cluster row of the tile; c4 = 4 consecutive d
+                *reinterpret_cast<float4*>(okb + (int64_t)(c * 32 + kr) * D + c4) = *reinterpret_cast<const float4*>(wl + kr * T3_WS + c4);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         return;
     }
     // ---- publish this workgroup's 128 partial norms write-through, arrive, wait for the clip (Guideline 16, form R1 with sc1 loads)
