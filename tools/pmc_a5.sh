@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_r02
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-echo "commit ${1:-unknown}; target: python3 tools/run_k2_only.py 6 (B=80 T=300 D=1024 K=256, inference-mode forward: K1, assign_tiles, K2, finalize)" > $OUT/summary.txt
+echo "commit ${1:-unknown}; target: python3 tools/run_k2_only.py 6 (B=80 T=300 D=1024 K=256, training-mode forward of the production chain: K1, assign_tiles2, K2 raw k-major, row scales)" > $OUT/summary.txt
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
@@ -19,9 +19,9 @@ with open(sys.argv[2], "w") as f:
     f.write("kernel,grid,counter,value\n")
     for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(",", ";")[-70:]
-        if any(p in k for p in ("assign_tiles", "vlad_aggregate", "vlad_finalize", "tile_gemm", "split_")):
+        if any(p in k for p in ("assign_tiles", "vlad_aggregate", "vlad_finalize", "vlad_row_scales", "tile_gemm", "split_")):
             f.write(f"{k},{r['Grid_Size']},{r['Counter_Name']},{r['Counter_Value']}\n")
 PY
-  python3 $R/tools/pmc_summary.py $F assign_tiles vlad_aggregate_tiles3 vlad_finalize2 tile_gemm_kernel >> $OUT/summary.txt
+  python3 $R/tools/pmc_summary.py $F assign_tiles vlad_aggregate_tiles3 vlad_finalize2 vlad_row_scales tile_gemm_kernel >> $OUT/summary.txt
 done
 cat $OUT/summary.txt

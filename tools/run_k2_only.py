@@ -12,7 +12,8 @@ W = (torch.randn(D, K, device=dev, generator=g) / 32).requires_grad_(True)      
 W2 = torch.randn(1, D, K, device=dev, generator=g) / 32
 bn = (torch.ones(K, device=dev), torch.zeros(K, device=dev), torch.zeros(K, device=dev), torch.ones(K, device=dev))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+LAZY = (sys.argv[2] if len(sys.argv) > 2 else "lazy") == "lazy"      # the production chain of NetVladV1: lazily normalised descriptor
 for _ in range(n):
-    out = ops.netvlad(x[:, :D], W, W2, T, bn=bn, kmajor=True)
+    out = ops.netvlad(x[:, :D], W, W2, T, bn=bn, kmajor=True, lazy=LAZY)
 torch.cuda.synchronize()
 print("ok", float(out.detach().norm()))
