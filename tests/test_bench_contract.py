@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01_bench_line.json, written by bench.py on the GPU box) keeps the driver's contract:
+"""The committed bench lines (profiles/r02_bench_line.json, r02_bench_line_cfg5.json, written by bench.py on the GPU box) keeps the driver's contract:
 required keys, BASELINE.json's metric, and internally consistent roofline / throughput figures.  CPU-only: it reads the
 committed artefact, it does not run the bench."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_line.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02_bench_line.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -40,3 +40,22 @@ def test_bench_line_figures_are_consistent():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     a = d["assign_gemm"]
     assert abs(a["mfma_util_vs_bf16_peak"] - a["executed_bf16_tflops"] / 2500.0) < 5e-3
+
+
+def test_bench_line_round2_objects():
+    """The whole a5 function beside the K2 kernel, the parity check of the run, and the cfg-5 line (bf16 storage, 2.165 MB/clip)."""
+    d = _line()
+    a5 = d["roofline"]["a5_function"]
+    assert set(a5["kernel_ms"]) == {"assign_tiles", "vlad_aggregate", "vlad_finalize"}
+    assert abs(a5["total_ms"] - sum(a5["kernel_ms"].values())) < 1e-3
+    assert abs(a5["frac"] - a5["algorithmic_bytes"] / (a5["total_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3
+    assert a5["frac"] <= d["roofline"]["frac"]                   # the chain cannot beat its dominant kernel
+    assert d["parity"]["ok"] is True and d["parity"]["predictions_max_rel_err"] <= d["parity"]["tolerance"] == 1e-3
+    with open(os.path.join(ROOT, "profiles", "r02_bench_line_cfg5.json")) as f:
+        c = json.loads(f.read().strip().splitlines()[-1])
+    assert c["dtype"] == "bf16" and c["config"]["global_batch"] == 128 and "configs[4]" in c["metric"]
+    r = c["roofline"]
+    B, T, D, K = 128, 300, 1024, 512
+    assert r["algorithmic_bytes"] == 2 * (B * T * K + B * T * D + B * D * K) + 4 * D * K        # video part of 2.165 MB/clip, bf16
+    assert abs(r["algorithmic_bytes"] / B / 1e6 - 1.99) < 0.02
+    assert c["parity"]["ok"] is True and c["parity"]["tolerance"] == 2e-2
