@@ -95,6 +95,11 @@ int lpm_frame_apply(const float* raw, const int32_t* num_frames, int B, int max_
 int lpm_frame_apply_tiles(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
                           const float* scale, const float* shift, float* y, void* xt_video, int Dv, void* xt_audio, int Da,
                           lpm_stream_t stream);
+/* ... and the split-bf16 ROW tiles K1 reads (the layout of lpm_split_rows_tiles, lpm_row_tiles_bytes(B, S, D) each; xr_* may be
+ * NULL), so that no pass over the fp32 matrix is needed between a3 and K1. */
+int lpm_frame_apply_tiles2(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
+                           const float* scale, const float* shift, float* y, void* xt_video, void* xr_video, int Dv,
+                           void* xt_audio, void* xr_audio, int Da, lpm_stream_t stream);
 int lpm_frame_stats_nblk(int B, int S);   /* rows of `partial` lpm_frame_stats writes (for lpm_bn_fold) */
 /* backward of input_bn's affine parameters only (the frames are data, never a trainable tensor, so no
  * gradient w.r.t. raw is produced): dgamma = sum dy*xhat, dbeta = sum dy over the gathered rows.

@@ -74,6 +74,7 @@ SIGNATURES = {
     "lpm_proj_dx": (_i, [_f, _f, _i, _l, _i, _f, _l, _f]),
     "lpm_frame_tiles_bf16_bytes": (_s, [_i, _i, _i]),
     "lpm_frame_steps_bf16": (_i, [_i]),
+    "lpm_frame_apply_tiles2": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _f, _i, _f]),
     "lpm_frame_apply_tiles_bf16": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _f, _i, _f]),
     "lpm_split_weight_tiles_bf16": (_i, [_f, _i, _i, _i, _f, _f]),
     "lpm_split_frames_bf16": (_i, [_f, _l, _i, _i, _i, _f, _f]),

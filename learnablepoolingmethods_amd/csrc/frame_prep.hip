@@ -280,6 +280,10 @@ __global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __r
 // [b][step][column tile][lane] (K2's operand, reduction over frames) and row tiles [b][row tile][column step][lane] (K1's
 // operand, reduction over features), both padded with zero frames to whole 64-frame blocks (NSP = 4 ceil(S / 64) steps, MT = NSP / 2
 // row tiles) -- and, when y is given, as the fp32 matrix.  Work item = (clip, step, frame half, 8 consecutive columns).
+// PL = 2 (fp32 storage, lpm_frame_apply_tiles2): the same pass writes the SPLIT-bf16 forms -- frame tiles with ceil(S / 16) steps per
+// clip (the layout of lpm_split_frames) and row tiles with 2 ceil(S / 64) tiles per clip (the layout of lpm_split_rows_tiles), hi and
+// lo planes -- so that K1 needs no tile-split pass of its own over the fp32 matrix.
+template <int PL>
 __global__ __launch_bounds__(256) void frame_apply_tiles_bf16_kernel(const float* __restrict__ raw, const int32_t* __restrict__ num_frames,
                                                                      int B, int max_frames, int F, int S, float step,
                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
@@ -325,23 +329,34 @@ __global__ __launch_bounds__(256) void frame_apply_tiles_bf16_kernel(const float
         uint4* xr = video ? xrv : xra;
         if (xt == nullptr) continue;
         const int Dn = video ? Dv : Da, cb = video ? c : c - Dv;
-        unsigned h[8][8];
+        unsigned h[8][8], l[8][8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) h[e][q] = fp_bf16_rne(v[e][q]);
+            for (int q = 0; q < 8; ++q) {
+                h[e][q] = fp_bf16_rne(v[e][q]);
+                if (PL == 2) l[e][q] = fp_bf16_rne(v[e][q] - __uint_as_float(h[e][q] << 16));
+            }
         const int DT = Dn / 32, CS = Dn / 16;
+        const int NSF = PL == 2 ? (S + 15) / 16 : NSP;        // frame-tile steps per clip
+        if (st < NSF) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {       // frame tiles: lane = (frame half, column), 8 frames per lane
-            const int d = cb + q;
-            xt[(((int64_t)b * NSP + st) * DT + (d >> 5)) * 64 + kh * 32 + (d & 31)] =
-                make_uint4(h[0][q] | (h[1][q] << 16), h[2][q] | (h[3][q] << 16), h[4][q] | (h[5][q] << 16), h[6][q] | (h[7][q] << 16));
+            for (int q = 0; q < 8; ++q) {       // frame tiles: lane = (frame half, column), 8 frames per lane
+                const int d = cb + q;
+                const int64_t base = ((((int64_t)b * NSF + st) * DT + (d >> 5)) * PL) * 64 + kh * 32 + (d & 31);
+                xt[base] = make_uint4(h[0][q] | (h[1][q] << 16), h[2][q] | (h[3][q] << 16), h[4][q] | (h[5][q] << 16), h[6][q] | (h[7][q] << 16));
+                if (PL == 2)
+                    xt[base + 64] = make_uint4(l[0][q] | (l[1][q] << 16), l[2][q] | (l[3][q] << 16), l[4][q] | (l[5][q] << 16), l[6][q] | (l[7][q] << 16));
+            }
         }
+        if (xr == nullptr) continue;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {       // row tiles: lane = (column half, frame), 8 columns per lane
             const int j = 16 * st + 8 * kh + e;
-            xr[(((int64_t)b * MT + (j >> 5)) * CS + (cb >> 4)) * 64 + ((cb >> 3) & 1) * 32 + (j & 31)] =
-                make_uint4(h[e][0] | (h[e][1] << 16), h[e][2] | (h[e][3] << 16), h[e][4] | (h[e][5] << 16), h[e][6] | (h[e][7] << 16));
+            const int64_t base = ((((int64_t)b * MT + (j >> 5)) * CS + (cb >> 4)) * PL) * 64 + ((cb >> 3) & 1) * 32 + (j & 31);
+            xr[base] = make_uint4(h[e][0] | (h[e][1] << 16), h[e][2] | (h[e][3] << 16), h[e][4] | (h[e][5] << 16), h[e][6] | (h[e][7] << 16));
+            if (PL == 2)
+                xr[base + 64] = make_uint4(l[e][0] | (l[e][1] << 16), l[e][2] | (l[e][3] << 16), l[e][4] | (l[e][5] << 16), l[e][6] | (l[e][7] << 16));
         }
     }
 }
@@ -415,10 +430,30 @@ extern "C" int lpm_frame_apply_tiles_bf16(const float* raw, const int32_t* num_f
     const float step = 1.0f / (float)S;
     const int64_t total = (int64_t)B * 4 * ((S + 63) / 64) * 2 * (F / 8);
     const int64_t want = (total + 255) / 256;
-    hipLaunchKernelGGL(frame_apply_tiles_bf16_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(frame_apply_tiles_bf16_kernel<1>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
                        raw, num_frames, B, max_frames, F, S, step, scale, shift, y, (uint4*)xt_video, (uint4*)xr_video, Dv,
                        (uint4*)xt_audio, (uint4*)xr_audio, Da);
     return check_launch("lpm_frame_apply_tiles_bf16");
+}
+
+// fp32 storage: a2 + a3 -> y (fp32 [B*S, F]) AND the split-bf16 frame tiles (lpm_xt_bytes each: K2's operand) AND row tiles
+// (lpm_row_tiles_bytes each: K1's operand; NULL: not wanted) of both streams in one pass over the sampled frames.
+extern "C" int lpm_frame_apply_tiles2(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
+                                      const float* scale, const float* shift, float* y, void* xt_video, void* xr_video, int Dv,
+                                      void* xt_audio, void* xr_audio, int Da, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_FRAME_CHECK("lpm_frame_apply_tiles2");
+    LPM_REQUIRE(y && xt_video && ((scale == nullptr) == (shift == nullptr)) && (Da == 0 || xt_audio), LPM_ERR_BADARG,
+                "lpm_frame_apply_tiles2: bad pointers");
+    LPM_REQUIRE(Dv > 0 && Da >= 0 && Dv + Da == F && Dv % 32 == 0 && Da % 32 == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_frame_apply_tiles2: need Dv + Da == F, both multiples of 32 (F=%d Dv=%d Da=%d)", F, Dv, Da);
+    const float step = 1.0f / (float)S;
+    const int64_t total = (int64_t)B * 4 * ((S + 63) / 64) * 2 * (F / 8);
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(frame_apply_tiles_bf16_kernel<2>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       raw, num_frames, B, max_frames, F, S, step, scale, shift, y, (uint4*)xt_video, (uint4*)xr_video, Dv,
+                       (uint4*)xt_audio, (uint4*)xr_audio, Da);
+    return check_launch("lpm_frame_apply_tiles2");
 }
 
 extern "C" int lpm_frame_bn_bwd(const float* dy, int64_t lddy, const float* raw, const int32_t* num_frames, int B,

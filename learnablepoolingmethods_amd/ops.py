@@ -37,6 +37,11 @@ PROJ_STREAM = os.environ.get("LPM_PROJ_STREAM", "1") != "0"
 # ... the input-gradient kernel from this hidden size on (measured, rocprofv3 kernel durations: forward 174 + 21 us vs the library's 219 us at
 # cfg-2, 764 vs 1233 us at cfg-5; dx 267 vs 211 us at cfg-2's N = 512 -- the library stays there --, 1108 vs 1232 us at cfg-5's N = 1024)
 PROJ_DX_STREAM_MIN_N = int(os.environ.get("LPM_PROJ_DX_STREAM_MIN_N", "1024"))
+# a2 + a3 also emit K1's split-bf16 row tiles (lpm_frame_apply_tiles2) instead of a separate lpm_split_rows_tiles pass per stream.
+# Off by default: measured at cfg-2 the step is 8.65 ms with it and 8.59 ms without -- the separate pass (26 us) leaves its 50 MB of
+# tiles in the 256 MB infinity cache right before K1 reads them (K1 44 us), whereas the fused pass writes 300 MB (fp32 matrix, frame
+# tiles, row tiles) and K1 then streams its operand from HBM (53 us), and the fused pass itself grows by the extra stores.
+FRAME_ROW_TILES = os.environ.get("LPM_FRAME_ROW_TILES", "0") == "1"
 VLAD_FUSED_DEBUG_FALLBACK = False     # tests: drive every clip through the fused kernel's time-out path + follow-up finalize
 
 # Matrix-core arithmetic of the soft-assignment GEMM K1: "bf16x3" (split-bf16 tiles on the bf16 pipe, default where
@@ -198,10 +203,18 @@ class _FrameSampleBN(torch.autograd.Function):
             Dv, Da = 1024, F - 1024
             xtv = torch.empty(lib._lpm_xt_bytes(B, S, Dv) // 4, dtype=torch.int32, device=raw.device)
             xta = torch.empty(lib._lpm_xt_bytes(B, S, Da) // 4, dtype=torch.int32, device=raw.device) if Da else None
-            lib.check(lib._lpm_frame_apply_tiles(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(y), ptr(xtv), Dv,
-                                                 ptr(xta), Da, stream_ptr()), "lpm_frame_apply_tiles")
+            xrv = xra = None
+            if FRAME_ROW_TILES:
+                # K1's row-tile operand leaves with the same pass (no lpm_split_rows_tiles over the fp32 matrix afterwards)
+                xrv = torch.empty(lib._lpm_row_tiles_bytes(B, S, Dv) // 4, dtype=torch.int32, device=raw.device)
+                xra = torch.empty(lib._lpm_row_tiles_bytes(B, S, Da) // 4, dtype=torch.int32, device=raw.device) if Da else None
+                lib.check(lib._lpm_frame_apply_tiles2(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(y), ptr(xtv), ptr(xrv),
+                                                      Dv, ptr(xta), ptr(xra), Da, stream_ptr()), "lpm_frame_apply_tiles2")
+            else:
+                lib.check(lib._lpm_frame_apply_tiles(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(y), ptr(xtv), Dv,
+                                                     ptr(xta), Da, stream_ptr()), "lpm_frame_apply_tiles")
             _XT_CACHE.clear()
-            _XT_CACHE.update(base=weakref.ref(y), F=F, Dv=Dv, S=S, B=B, video=xtv, audio=xta)
+            _XT_CACHE.update(base=weakref.ref(y), F=F, Dv=Dv, S=S, B=B, video=xtv, audio=xta, video_rows=xrv, audio_rows=xra)
         else:
             lib.check(lib._lpm_frame_apply(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(y), stream_ptr()),
                       "lpm_frame_apply")
@@ -341,9 +354,9 @@ def _cached_tiles(x, B, T, D, rows=False, storage="f32"):
         return None
     suffix = "_rows" if rows else ""
     if x.storage_offset() == 0 and D == c["Dv"]:
-        return c["video" + suffix]
+        return c.get("video" + suffix)
     if x.storage_offset() == c["Dv"] and D == c["F"] - c["Dv"] and c["audio"] is not None:
-        return c["audio" + suffix]
+        return c.get("audio" + suffix)
     return None
 
 
@@ -554,10 +567,12 @@ class _NetVLAD(torch.autograd.Function):
             st = stream_ptr()
             nblk = lib._lpm_assign_gemm_tiles_nblk(B, T)
             partial = _empty((nblk, 2, K), x)
-            xr = _tile_buffer(lib._lpm_row_tiles_bytes(B, T, D), x)
             wt = _tile_buffer(lib._lpm_weight_tiles_bytes(D, K), x)
-            with _timed("split_rows_tiles", (M, D)):
-                lib.check(lib._lpm_split_rows_tiles(ptr(x), x.stride(0), B, T, D, ptr(xr), st), "lpm_split_rows_tiles")
+            xr = _cached_tiles(x, B, T, D, rows=True)
+            if xr is None:
+                xr = _tile_buffer(lib._lpm_row_tiles_bytes(B, T, D), x)
+                with _timed("split_rows_tiles", (M, D)):
+                    lib.check(lib._lpm_split_rows_tiles(ptr(x), x.stride(0), B, T, D, ptr(xr), st), "lpm_split_rows_tiles")
             lib.check(lib._lpm_split_weight_tiles(ptr(W), D, K, 0, ptr(wt), st), "lpm_split_weight_tiles")
             with _timed("assign_gemm_fwd", (M, D, K)):
                 lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st),

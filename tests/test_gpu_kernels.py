@@ -397,6 +397,35 @@ def test_frame_sample_bn(B, MF, F, S):
     assert_close(mm, upd["input_bn/moving_mean"] * 0.001, tol=1e-4, what="moving_mean")
 
 
+@pytest.mark.parametrize("B,MF,F,S", [(3, 300, 1152, 300), (2, 90, 1024, 70), (2, 64, 1152, 64)])
+def test_frame_sample_bn_tile_copies_are_the_split_of_its_output(B, MF, F, S, monkeypatch):
+    """lpm_frame_apply_tiles2: the frame tiles (K2's operand) and row tiles (K1's operand) written with the fp32 matrix are, bit
+    for bit, what lpm_split_frames / lpm_split_rows_tiles produce from that matrix."""
+    from learnablepoolingmethods_amd import _capi, ops
+    from learnablepoolingmethods_amd.ops import ptr, stream_ptr
+    dev = cuda()
+    lib = _capi.load()
+    x, nf, _ = O.make_synthetic_batch(B, MF, F, 10, seed=S, min_frames=MF // 3)
+    g = torch.Generator().manual_seed(2)
+    gamma, beta = (1 + 0.2 * torch.randn(F, generator=g)).to(dev), (0.1 * torch.randn(F, generator=g)).to(dev)
+    mm, mv = torch.zeros(F, device=dev), torch.ones(F, device=dev)
+    monkeypatch.setattr(ops, "FRAME_ROW_TILES", True)
+    y = ops.frame_sample_bn(x.to(dev), nf.to(dev), S, gamma, beta, mm, mv, True)
+    for name, c0, D in (("video", 0, 1024), ("audio", 1024, F - 1024)):
+        if D == 0:
+            continue
+        xs = y[:, c0:c0 + D]
+        xr = ops._cached_tiles(xs, B, S, D, rows=True)
+        xt = ops._cached_tiles(xs, B, S, D)
+        assert xr is not None and xt is not None, name
+        want_r = torch.empty(lib._lpm_row_tiles_bytes(B, S, D) // 4, dtype=torch.int32, device=dev)
+        lib.check(lib._lpm_split_rows_tiles(ptr(xs), xs.stride(0), B, S, D, ptr(want_r), stream_ptr()), "lpm_split_rows_tiles")
+        want_t = torch.empty(lib._lpm_xt_bytes(B, S, D) // 4, dtype=torch.int32, device=dev)
+        lib.check(lib._lpm_split_frames(ptr(xs), xs.stride(0), B, S, D, ptr(want_t), stream_ptr()), "lpm_split_frames")
+        assert xr.numel() == want_r.numel() and torch.equal(xr, want_r), f"{name}: row tiles differ"
+        assert xt.numel() == want_t.numel() and torch.equal(xt, want_t), f"{name}: frame tiles differ"
+
+
 def test_clip_adam_matches_oracle():
     from learnablepoolingmethods_amd import ops
     from learnablepoolingmethods_amd.train import ARENA_ALIGN
