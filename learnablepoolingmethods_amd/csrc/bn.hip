@@ -5,43 +5,17 @@
 
 namespace lpm {
 
-// partial [nblk, 2, C] -> mean/var/scale/shift (+ moving averages).  One 1024-thread block per
-// 64 columns: 16 row groups stride over the partial rows, fp64 accumulation, LDS tree.
+// partial [nblk, 2, C] -> mean/var/scale/shift (+ moving averages); 1024 threads per 16 columns (partial_colsums16)
 __global__ __launch_bounds__(1024) void bn_fold_kernel(const float* __restrict__ partial, int nblk, int C,
                                                        double inv_rows, double unbias,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, float decay,
                                                        float* mean, float* var, float* scale, float* shift,
                                                        float* moving_mean, float* moving_var) {
-    __shared__ double sh[2][16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C) {
-        for (int b = rg; b < nblk; b += 64) {        // four partial rows per round: independent loads, fixed order of additions
-            float ps[4], pq[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int bb = b + 16 * u;
-                const float* p = partial + (int64_t)min(bb, nblk - 1) * 2 * C;
-                ps[u] = (bb < nblk) ? p[c] : 0.f;
-                pq[u] = (bb < nblk) ? p[C + c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s += (double)ps[u];
-                q += (double)pq[u];
-            }
-        }
-    }
-    sh[0][rg][cl] = s;
-    sh[1][rg][cl] = q;
-    __syncthreads();
-    if (rg == 0 && c < C) {
-        for (int i = 1; i < 16; ++i) {
-            s += sh[0][i][cl];
-            q += sh[1][i][cl];
-        }
+    double s, q;
+    int c;
+    partial_colsums16(partial, nblk, 2 * (int64_t)C, C, C, s, q, c);
+    if (threadIdx.x < 16 && c < C) {
         const double mu = s * inv_rows;
         double vr = q * inv_rows - mu * mu;
         if (vr < 0.0) vr = 0.0;
@@ -120,35 +94,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 // pass 2: reduce partials -> dbeta (sum dlt), dgamma (sum dlt*Lhat)
 __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int K,
                                                              float* dgamma, float* dbeta) {
-    __shared__ double sh[2][16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < K) {
-        for (int b = rg; b < nblk; b += 64) {        // four partial rows per round: independent loads, fixed order of additions
-            float ps[4], pq[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int bb = b + 16 * u;
-                const float* p = partial + (int64_t)min(bb, nblk - 1) * 2 * K;
-                ps[u] = (bb < nblk) ? p[c] : 0.f;
-                pq[u] = (bb < nblk) ? p[K + c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s += (double)ps[u];
-                q += (double)pq[u];
-            }
-        }
-    }
-    sh[0][rg][cl] = s;
-    sh[1][rg][cl] = q;
-    __syncthreads();
-    if (rg == 0 && c < K) {
-        for (int i = 1; i < 16; ++i) {
-            s += sh[0][i][cl];
-            q += sh[1][i][cl];
-        }
+    double s, q;
+    int c;
+    partial_colsums16(partial, nblk, 2 * (int64_t)K, K, K, s, q, c);
+    if (threadIdx.x < 16 && c < K) {
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
     }
@@ -286,7 +235,7 @@ extern "C" int lpm_bn_rows_fwd(const float* x, int M, int C, const float* gamma,
     float* shift = scale + C;
     hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(nblk), dim3(256), 0, s, x, M, C, partial);
     const double unbias = (biased_moving_variance || M <= 1) ? 1.0 : (double)M / (double)(M - 1);
-    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partial, nblk, C, 1.0 / (double)M, unbias, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, partial, nblk, C, 1.0 / (double)M, unbias, gamma, beta, eps,
                        decay, mean, var, scale, shift, moving_mean, moving_var);
     const int64_t total4 = (int64_t)M * C / 4;
     const int64_t want = (total4 + 255) / 256;
@@ -303,7 +252,7 @@ extern "C" int lpm_bn_fold(const float* partial, int nblk, int C, int64_t rows, 
     LPM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), LPM_ERR_BADARG,
                 "lpm_bn_fold: moving_mean and moving_var must be given together");
     const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C,
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C,
                        1.0 / (double)rows, unbias, gamma, beta, eps, decay, mean, var, scale, shift, moving_mean,
                        moving_var);
     return check_launch("lpm_bn_fold");
@@ -328,7 +277,7 @@ extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* me
     const int nblk = (M + BNB_ROWS - 1) / BNB_ROWS;
     float* partial = (float*)workspace;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, dlt, logits, mean, var, eps, M, K, partial);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((K + 63) / 64), dim3(1024), 0, s, partial, nblk, K, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((K + 15) / 16), dim3(1024), 0, s, partial, nblk, K, dgamma, dbeta);
     const int64_t total4 = (int64_t)M * K / 4;
     const int64_t want = (total4 + 255) / 256;
     int grid = (int)(want < 2048 ? want : 2048);

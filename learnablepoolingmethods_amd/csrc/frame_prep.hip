@@ -173,35 +173,10 @@ __global__ __launch_bounds__(1024) void frame_bn_bwd_reduce_kernel(const float* 
                                                                    int F, const float* __restrict__ mean,
                                                                    const float* __restrict__ var, float eps,
                                                                    float* dgamma, float* dbeta) {
-    __shared__ double sh[2][16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < F) {
-        for (int b = rg; b < nblk; b += 64) {        // four partial rows per round: independent loads, fixed order of additions
-            float ps[4], pq[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int bb = b + 16 * u;
-                const float* p = partial + (int64_t)min(bb, nblk - 1) * 2 * F;
-                ps[u] = (bb < nblk) ? p[c] : 0.f;
-                pq[u] = (bb < nblk) ? p[F + c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s += (double)ps[u];
-                q += (double)pq[u];
-            }
-        }
-    }
-    sh[0][rg][cl] = s;
-    sh[1][rg][cl] = q;
-    __syncthreads();
-    if (rg == 0 && c < F) {
-        for (int i = 1; i < 16; ++i) {
-            s += sh[0][i][cl];
-            q += sh[1][i][cl];
-        }
+    double s, q;
+    int c;
+    partial_colsums16(partial, nblk, 2 * (int64_t)F, F, F, s, q, c);
+    if (threadIdx.x < 16 && c < F) {
         // sum dy * xhat = rstd * (sum dy*x - mean * sum dy)
         const double rstd = 1.0 / sqrt((double)var[c] + (double)eps);
         dbeta[c] = (float)s;
@@ -469,7 +444,7 @@ extern "C" int lpm_frame_bn_bwd(const float* dy, int64_t lddy, const float* raw,
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(frame_bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, dy, lddy, raw, num_frames, B, max_frames, F, S,
                        step, (float*)workspace);
-    hipLaunchKernelGGL(frame_bn_bwd_reduce_kernel, dim3((F + 63) / 64), dim3(1024), 0, s, (const float*)workspace, nblk, F, mean,
+    hipLaunchKernelGGL(frame_bn_bwd_reduce_kernel, dim3((F + 15) / 16), dim3(1024), 0, s, (const float*)workspace, nblk, F, mean,
                        var, eps, dgamma, dbeta);
     return check_launch("lpm_frame_bn_bwd");
 }

@@ -9,6 +9,7 @@
 // transformer_utils.py:583 and :708-711) ride in pass 1 of the forward; in the backward da = dz * [a + bias > 0] and
 // dbias = column sums of da come out of the apply pass -- two elementwise passes and a reduction per layer less.
 #include "lpm_common.h"
+#include <atomic>
 
 namespace lpm {
 
@@ -259,54 +260,84 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
     }
 }
 
-// Column reductions of the per-(example, chunk) partials, two stages so that the 1280 partial rows of cfg-2 are spread over
-// 256 workgroups instead of 16 (one launch of 16 workgroups walking 80 rows each took 25-47 us; latency, not bandwidth):
-//   stage 1, grid (ceil(F/64), LN_RS): slice y sums rows y, y + LN_RS, ... of `narr` arrays laid out [nblk][narr][F] -> tmp[y][narr][F]
-//   stage 2, grid (ceil(F/64)):        sums the LN_RS slices in fp64 -> out arrays
+// Column reductions of the per-(example, chunk) partials (1280 rows x 2 x F at cfg-2: 10 MB + 5 MB with a bias) in ONE launch
+// behind the apply pass (they are not on its dependency chain).  grid (ceil(F / 64), LN_RS, 1 or 2): set z = 0 sums the two arrays
+// of colpart [nblk][2][F] -> dgamma, dbeta; set z = 1 (fused bias) sums biaspart [nblk][1][F] -> dbias.  Slice y sums rows y,
+// y + LN_RS, ... into tmp[z][y][.][F] (write-through stores), counts itself in on the (column block, set) counter of this launch's
+// slot, and the workgroup that arrives last adds the LN_RS slices in fp64 IN SLICE ORDER (L2-bypassing loads): which workgroup is
+// last does not change a bit of the result.  (Before: two stages x two launches of ~5 us per reduction, four launches per
+// layer-norm backward with a bias; a single stage of 16-column workgroups read its 64-byte row pieces at 0.9 TB/s: 17 us.)
+// Counters: LN_CR_SLOTS sets handed out round-robin by the host, so that launches in flight on different streams never share one;
+// the last workgroup puts its counter back to zero.
 constexpr int LN_RS = 16;
-__global__ __launch_bounds__(256) void ln_colreduce1_kernel(const float* __restrict__ part, int nblk, int narr, int F,
-                                                            float* __restrict__ tmp) {
-    __shared__ float sh[4][3][64];
+constexpr int LN_CR_SLOTS = 64, LN_CR_PER_SLOT = 32;       // (F / 64 <= 16 column blocks) x 2 sets
+__device__ unsigned ln_cr_counters[LN_CR_SLOTS * LN_CR_PER_SLOT];
+
+__global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restrict__ colpart, const float* __restrict__ biaspart, int nblk,
+                                                           int F, float* __restrict__ tmp, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dbias, int slot) {
+    typedef __attribute__((address_space(1))) float gfloat;
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    __shared__ float sh[4][2][64];
+    __shared__ int last;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl, y = blockIdx.y;
-    float acc[3] = {0.f, 0.f, 0.f};
+    const bool second = blockIdx.z == 1;
+    const int narr = second ? 1 : 2;
+    const float* part = second ? biaspart : colpart;
+    float* tz = tmp + (int64_t)blockIdx.z * LN_RS * 2 * F;
+    float acc0 = 0.f, acc1 = 0.f;
     if (c < F) {
-        for (int b = y + LN_RS * rg; b < nblk; b += LN_RS * 16) {     // four rows per round: independent loads, same order of additions
-            float v[4][3];
+        for (int b = y + LN_RS * rg; b < nblk; b += LN_RS * 4 * 8) {      // eight rows per round: independent loads, fixed order of additions
+            float v0[8], v1[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int bb = b + LN_RS * 4 * u;
                 const float* p = part + (int64_t)min(bb, nblk - 1) * narr * F + c;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) v[u][a] = (a < narr && bb < nblk) ? p[(int64_t)a * F] : 0.f;
+                v0[u] = (bb < nblk) ? p[0] : 0.f;
+                v1[u] = (bb < nblk && !second) ? p[F] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int a = 0; a < 3; ++a) acc[a] += v[u][a];
+            for (int u = 0; u < 8; ++u) {
+                acc0 += v0[u];
+                acc1 += v1[u];
+            }
         }
     }
-    for (int a = 0; a < narr; ++a) sh[rg][a][cl] = acc[a];
+    sh[rg][0][cl] = acc0;
+    sh[rg][1][cl] = acc1;
     __syncthreads();
-    if (rg == 0 && c < F)
-        for (int a = 0; a < narr; ++a) tmp[((int64_t)y * narr + a) * F + c] = (sh[0][a][cl] + sh[1][a][cl]) + (sh[2][a][cl] + sh[3][a][cl]);
-}
-__global__ __launch_bounds__(64) void ln_colreduce2_kernel(const float* __restrict__ tmp, int narr, int F, float* out0, float* out1,
-                                                           float* out2) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= F) return;
-    float* outs[3] = {out0, out1, out2};
-    for (int a = 0; a < narr; ++a) {
-        double s = 0.0;
-        for (int y = 0; y < LN_RS; ++y) s += (double)tmp[((int64_t)y * narr + a) * F + c];
-        outs[a][c] = (float)s;
+    if (rg == 0 && c < F) {
+        for (int a = 0; a < narr; ++a)
+            __hip_atomic_store((gfloat*)(tz + ((int64_t)y * 2 + a) * F + c), (sh[0][a][cl] + sh[1][a][cl]) + (sh[2][a][cl] + sh[3][a][cl]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the storing wave drains its write-through stores
+    __syncthreads();
+    gu32* cnt = (gu32*)(ln_cr_counters + slot * LN_CR_PER_SLOT + blockIdx.z * 16 + blockIdx.x);
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(LN_RS - 1);
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rg == 0 && c < F) {
+        float* outs[2] = {second ? dbias : dgamma, dbeta};
+        for (int a = 0; a < narr; ++a) {
+            float t[LN_RS];
+#pragma unroll
+            for (int i = 0; i < LN_RS; ++i)
+                t[i] = __hip_atomic_load((gfloat*)(tz + ((int64_t)i * 2 + a) * F + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < LN_RS; ++i) s += (double)t[i];
+            outs[a][c] = (float)s;
+        }
     }
 }
 
 }  // namespace lpm
 
 extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
-    return ((size_t)B * lpm::LN_NB * 2 + (size_t)B * lpm::LN_NB * 3 * F + (size_t)lpm::LN_RS * 3 * F) * sizeof(float);
+    return ((size_t)B * lpm::LN_NB * 2 + (size_t)B * lpm::LN_NB * 3 * F + (size_t)lpm::LN_RS * 4 * F) * sizeof(float);
 }
 
 #define LPM_LN_CHECK(name)                                                                                              \
@@ -403,19 +434,17 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, 
     float* biaspart = colpart + (size_t)B * LN_NB * 2 * F;
     float* tmp = biaspart + (size_t)B * LN_NB * F;
     dim3 grid(B, LN_NB);
-    const int cb = (F + 63) / 64, nblk = B * LN_NB;
+    const int nblk = B * LN_NB;
     const int64_t dyb = dy_batch_stride ? dy_batch_stride : (int64_t)L * F;
     LPM_REQUIRE(dyb >= (int64_t)L * F && dyb % 4 == 0 && ((uintptr_t)dy & 15) == 0, LPM_ERR_BADARG,
                 "lpm_layer_norm_act_bwd: dy_batch_stride must be >= L*F and a multiple of 4, dy 16-byte aligned");
     hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart, dyb);
-    hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, colpart, nblk, 2, F, tmp);
-    hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 2, F, dgamma, dbeta, (float*)nullptr);
     hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
                        dr_extra, dyb, (unsigned short*)da_image);
-    if (bias) {
-        hipLaunchKernelGGL(ln_colreduce1_kernel, dim3(cb, LN_RS), dim3(256), 0, s, biaspart, nblk, 1, F, tmp);
-        hipLaunchKernelGGL(ln_colreduce2_kernel, dim3(cb), dim3(64), 0, s, tmp, 1, F, dbias, (float*)nullptr, (float*)nullptr);
-    }
+    static std::atomic<unsigned> next_slot{0};
+    const int slot = (int)(next_slot.fetch_add(1u) % LN_CR_SLOTS);
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((F + 63) / 64, LN_RS, bias ? 2 : 1), dim3(256), 0, s, colpart, biaspart, nblk, F, tmp, dgamma,
+                       dbeta, dbias, slot);
     return check_launch("lpm_layer_norm_act_bwd");
 }
 

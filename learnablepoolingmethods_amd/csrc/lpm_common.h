@@ -39,6 +39,52 @@ inline int check_launch(const char* what) {
         }                             \
     } while (0)
 
+// ---- column sums of per-block partials (the second stage of every two-stage column reduction) --------------------------------
+// part: nblk rows of `row` floats; the sums over the rows of part[.][c] (-> s) and, if off2 > 0, part[.][off2 + c] (-> q), in fp64
+// and in a fixed order.  For a 1024-thread workgroup that owns 16 columns (c = 16 blockIdx.x + (tid & 15)): 64 row groups, every
+// thread loads its rows eight at a time (nblk = 400: ONE round of independent loads -- a 64-column / 16-row-group form walked
+// seven dependent rounds of ~2 us, 14-30 us for under a megabyte of input), the four row groups of a wave meet by shuffles,
+// the sixteen waves through LDS.  The sums come back on the threads with tid < 16.
+__device__ __forceinline__ void partial_colsums16(const float* __restrict__ part, int nblk, int64_t row, int off2, int C, double& s,
+                                                  double& q, int& c) {
+    __shared__ double pcs_sh[2][16][16];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    c = blockIdx.x * 16 + cl;
+    s = 0.0; q = 0.0;
+    if (c < C) {
+        for (int b = rg; b < nblk; b += 64 * 8) {
+            float ps[8], pq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int bb = b + 64 * u;
+                const float* p = part + (int64_t)min(bb, nblk - 1) * row + c;
+                ps[u] = (bb < nblk) ? p[0] : 0.f;
+                pq[u] = (bb < nblk && off2 > 0) ? p[off2] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s += (double)ps[u];
+                q += (double)pq[u];
+            }
+        }
+    }
+    s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);      // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same column
+    s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 16) {
+        pcs_sh[0][wave][cl] = s;
+        pcs_sh[1][wave][cl] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        s = pcs_sh[0][0][cl]; q = pcs_sh[1][0][cl];
+        for (int i = 1; i < 16; ++i) {
+            s += pcs_sh[0][i][cl];
+            q += pcs_sh[1][i][cl];
+        }
+    }
+}
+
 // ---- wave-level reductions (64 lanes) -------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

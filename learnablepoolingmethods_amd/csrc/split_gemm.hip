@@ -105,21 +105,13 @@ __global__ __launch_bounds__(256) void split_rows_relu_bwd_kernel(const float* _
     }
 }
 
-// colpart [nblk][K] -> out [K]  (fp64 accumulation, 16 row groups x 64 columns per workgroup)
+// colpart [nblk][K] -> out [K]  (fp64 accumulation; 1024 threads per 16 columns, partial_colsums16)
 __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ colpart, int nblk, int K,
                                                              float* __restrict__ out) {
-    __shared__ double sh[16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s = 0.0;
-    if (c < K)
-        for (int b = rg; b < nblk; b += 16) s += (double)colpart[(int64_t)b * K + c];
-    sh[rg][cl] = s;
-    __syncthreads();
-    if (rg == 0 && c < K) {
-        for (int i = 1; i < 16; ++i) s += sh[i][cl];
-        out[c] = (float)s;
-    }
+    double s, q;
+    int c;
+    partial_colsums16(colpart, nblk, (int64_t)K, 0, K, s, q, c);
+    if (threadIdx.x < 16 && c < K) out[c] = (float)s;
 }
 
 // grid (K/32, N/32); 32x32 tile through LDS for the transposed image.
@@ -210,7 +202,7 @@ extern "C" int lpm_split_rows_relu_bwd(const float* df, int64_t M, int K, const 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(split_rows_relu_bwd_kernel, dim3(nblk), dim3(256), 0, s, df, M, K, (const unsigned short*)act3,
                        (unsigned short*)out3, (float*)workspace);
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((K + 63) / 64), dim3(1024), 0, s, (const float*)workspace, nblk, K, dbias);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((K + 15) / 16), dim3(1024), 0, s, (const float*)workspace, nblk, K, dbias);
     return check_launch("lpm_split_rows_relu_bwd");
 }
 
