@@ -75,6 +75,9 @@ struct TileGemmArgs {
     int rows_valid, cols_valid;
     int accumulate;            // STORE: out += result
     int nt_store;              // STORE: non-temporal stores (the 0.5-2 GB hidden1 weight gradient)
+    int cols_inner;            // 64-row form: the column blocks of a row block are CONSECUTIVE workgroups of a one-dimensional grid (same
+                               // XCD, same moment: the row block's A tiles come from HBM once and from L2 for the other column blocks)
+                               // instead of gridDim.y slices a whole grid row apart
     float* stats;              // STORE, optional: [gridDim.x][2][cols_valid] per-workgroup column (sum, sum of squares)
     // SOFTMAX_BWD (needs gridDim.y == gridDim.z == 1): out = dlogit~ with a = softmax(logits*scale + shift) recomputed
     const float* logits;       // [batch * rows_valid + row][cols_valid]

@@ -40,9 +40,14 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave >> 2, cw = wave & 3;       // row group, column slice
     const int l31 = lane & 31;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int cb = blockIdx.y;
+    if (MW == 1 && g.cols_inner > 0) {             // one-dimensional grid, column block fastest
+        cb = lid % g.cols_inner;
+        lid /= g.cols_inner;
+    }
     const int batch = MW == 1 ? lid / g.rb_per_batch : 0, rb = MW == 1 ? lid % g.rb_per_batch : 0;
-    const int cb = blockIdx.y, split = blockIdx.z;
+    const int split = blockIdx.z;
     const int step0 = split * g.steps_per_split;
     const int nred = min(g.steps_per_split, g.total_steps - step0);     // reduction steps of this split
     const int nstep1 = PL == 2 ? nred : (nred + 1) / 2;                   // ring stages
@@ -376,6 +381,15 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
     const bool wide = EPI == TG_EPI_STORE && allow_wide && tg_wide_ok(g, nbatch, splits, ntw, PL);
     dim3 grid((unsigned)(wide ? nbatch * g.a_tiles / 4 : nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)),
               (unsigned)splits);
+    TileGemmArgs gl = g;
+    if (!wide && g.cols_inner) {
+        if (g.stats) { set_error("%s: cols_inner and the statistics epilogue index workgroups differently", what); return LPM_ERR_BADARG; }
+        gl.cols_inner = (int)grid.y;
+        grid.x *= grid.y;
+        grid.y = 1;
+    } else {
+        gl.cols_inner = 0;
+    }
     constexpr int WIDE_NS = 4;
     const size_t lds = wide ? (size_t)WIDE_NS * (8 + 8 * ntw) * 1024 : tg_lds_bytes(ntw, EPI);
 #define LPM_TG_LAUNCH_K(KERN, THREADS)                                                                                 \
@@ -388,9 +402,9 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
         }                                                                                                              \
         hipEvent_t e0, e1;                                                                                             \
         if (timing_tag && timing_request(timing_tag, &e0, &e1))                                                        \
-            hipExtLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, e0, e1, 0, g);                               \
+            hipExtLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, e0, e1, 0, gl);                              \
         else                                                                                                           \
-            hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, g);                                             \
+            hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, gl);                                            \
     } while (0)
 #define LPM_TG_LAUNCH(NTW) LPM_TG_LAUNCH_K((tile_gemm_kernel<NTW, EPI, 1, TG_NS, PL>), 256)
     if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS, PL>), 512);
@@ -645,6 +659,10 @@ extern "C" int lpm_skinny_weight_grad_tiles(const void* xt, const void* dyt, int
     g.out = dW; g.ldo = N2; g.rows_valid = N1; g.cols_valid = N2;
     static const int nt = [] { const char* e = getenv("LPM_DW_NT_STORE"); return (e && e[0] == '0') ? 0 : 1; }();      // 0: plain stores (A/B)
     g.nt_store = nt;
+    // the 4 (cfg-2) / 8 (cfg-5) column blocks of a row block as neighbours on one XCD: the activation tiles (86 MB at cfg-2, 277 MB at
+    // cfg-5: more than the infinity cache) are fetched from HBM once instead of once per column block (LPM_DW_COLS_INNER=0: A/B)
+    static const int inner = [] { const char* e = getenv("LPM_DW_COLS_INNER"); return (e && e[0] == '0') ? 0 : 1; }();
+    g.cols_inner = inner;
     // 5 reduction steps and a 554 MB store: narrow column blocks (36 KB of LDS, 4 workgroups per CU) so that one workgroup's
     // store overlaps its neighbours' loads (measured at cfg-2: 145 us with 128-column blocks, 215 us with 512)
     return tile_gemm_store(g, 1, 1, (hipStream_t)stream, "lpm_skinny_weight_grad_tiles", 1);

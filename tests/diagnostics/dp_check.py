@@ -1,6 +1,8 @@
 """Data-parallel consistency on the GPU box: N ranks (one per GPU over RCCL; LPM_SHARE_GPU=1: all on GPU 0 over gloo) take
 steps on different shards; afterwards every rank must hold bit-identical parameters and Adam slots, and the summed-gradient
 step must equal what one rank computes on the concatenated batch's tower gradients (checked through the loss trajectory).
+This is a cross-rank CONSISTENCY diagnostic only (an error common to all ranks passes it): the comparison of two real-Trainer ranks with
+oracle.train_step(num_towers=2) is tests/test_gpu_dp_trainer.py, which pytest collects.
 Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tests/diagnostics/dp_check.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
