@@ -355,14 +355,25 @@ def main():
                 line["assign_gemm"] = {"avg_kernel_ms": round(avg_ms, 4), "tflops": round(fl / (avg_ms * 1e-3) / 1e12, 2),
                                        "mfma": "v_mfma_f32_32x32x2_f32 (exact fp32, peak 157.3 TFLOP/s)"}
         k5 = [(d, a.elapsed_time(b)) for (n, d, a, b) in timeline if n == "clip_adam"]
-        if k5:
-            total = k5[0][0][0]
-            avg_ms = sum(t for _, t in k5) / len(k5)
-            byts = 32.0 * total            # p, m, v read + written (24 B), g read by the norm pass and by the update (8 B)
-            line["clip_adam"] = {"kernels": "ca_chunk_sumsq + ca_tensor_factor + ca_apply (K5: per-variable clip + Adam over the arena)",
-                                 "bound": "hbm", "avg_ms": round(avg_ms, 4), "algorithmic_bytes": int(byts),
+        k5f = [(d, a.elapsed_time(b)) for (n, d, a, b) in timeline if n == "factored_clip_adam"]
+        if k5 or k5f:
+            # generic part: p, m, v read + written (24 B), g read by the norm pass and by the update (8 B).  Factored part
+            # (hidden1_weights, lpm_factored_clip_adam): p, m, v read + written (24 B per parameter) + the two factors' tiles read by
+            # each of its two passes; its gradient (4 B written + 8 B read on the generic path) is never in memory.
+            total = k5[0][0][0] if k5 else 0
+            avg_ms = (sum(t for _, t in k5) / len(k5) if k5 else 0.0) + (sum(t for _, t in k5f) / len(k5f) if k5f else 0.0)
+            byts = 32.0 * total
+            kernels = "ca_chunk_sumsq + ca_tensor_factor + ca_apply (K5: per-variable clip + Adam over the arena)"
+            if k5f:
+                R, N1, N2 = k5f[0][0]
+                byts += 24.0 * N1 * N2 + 2 * 4.0 * R * (N1 + N2)
+                kernels = ("hidden1_weights: tile GEMM (norm pass) + fa_factor + tile GEMM (clip + Adam epilogue), gradient never written; "
+                           "the other variables: " + kernels)
+            line["clip_adam"] = {"kernels": kernels, "bound": "hbm", "avg_ms": round(avg_ms, 4), "algorithmic_bytes": int(byts),
                                  "achieved": round(byts / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(byts / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if k5f:
+                line["clip_adam"]["factored_avg_ms"] = round(sum(t for _, t in k5f) / len(k5f), 4)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], first = cpu_baseline(args.cpu_baseline_seconds, wl)
             line["parity"] = parity_check(first, device, wl)

@@ -492,6 +492,18 @@ int lpm_multi_tensor_clip_adam(float* param, const float* grad, float* m, float*
                                int ntensors, int64_t total, float clip_norm, float lr, float beta1, float beta2,
                                float eps, int64_t step, float* scratch, lpm_stream_t stream);
 
+/* a14 + a15 for a variable whose gradient is dW [N1, N2] = X^T DY, X [R, N1], DY [R, N2], R = the batch over ALL towers (the SUM of
+ * utils.combine_gradients, utils.py:192-213, is the product over the concatenated rows): the hidden projection's weight
+ * (frame_level_models.py:2314-2319), 75 % (cfg-2) ... 94 % (cfg-5) of the model's parameters.  The gradient is never written:
+ * a first tile-GEMM pass yields ||dW|| (fixed summation order), a second one applies clip + TF-Adam to param / m / v in place from
+ * its accumulators.  xt, dyt: lpm_split_weight_tiles of X and DY (not transposed; towers' tile buffers concatenate along R).
+ * Same per-element arithmetic as lpm_skinny_weight_grad_tiles followed by lpm_multi_tensor_clip_adam.  scratch:
+ * lpm_factored_clip_adam_scratch_bytes(N1, N2); on return scratch[bytes/4 - 4] holds the clip factor, [.. - 3] the norm. */
+size_t lpm_factored_clip_adam_scratch_bytes(int N1, int N2);
+int lpm_factored_clip_adam(const void* xt, const void* dyt, int R, int N1, int N2, float* param, float* m, float* v,
+                           float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
+                           size_t scratch_bytes, lpm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,81 @@
+// a14 + a15 for a variable whose gradient is a product of two skinny matrices -- the hidden projection's weight
+// (frame_level_models.py:2314-2319): dW [N1, N2] = X^T DY with X [R, N1] the pooled descriptors and DY [R, N2] the gradient of the
+// projection's output, R = the batch (all towers' clips: utils.combine_gradients' SUM over towers, utils.py:192-213, is the same
+// product over the concatenated rows).  At cfg-2 the variable is 138.4 M of the model's 185 M parameters (553.6 M of 591 M at
+// cfg-5) and its gradient is 554 MB (2.2 GB) that the generic path writes (lpm_skinny_weight_grad_tiles), reads for the norm
+// (ca_chunk_sumsq) and reads again for the update (ca_apply).  Here the gradient never exists in memory:
+//   pass 1  tile GEMM X^T DY, epilogue = sum of squares of the tile -> one partial per workgroup        (reads the operands only)
+//   pass 2  the partials in a fixed order -> factor = clip / max(||dW||, clip)                          (utils.clip_gradient_norms :170-189)
+//   pass 3  tile GEMM again, epilogue = factor, then TF-Adam on the tile of param / m / v in place     (24 B per parameter)
+// against 4 (write) + 4 (norm) + 28 (update) = 36 B per parameter before.  The arithmetic of a gradient element is the tile GEMM's
+// (split-bf16 operands, three MFMAs per product, fp32 accumulation: what lpm_skinny_weight_grad_tiles computes, bit for bit), the
+// update is clip_adam.hip's.  In data-parallel training the towers exchange X and DY tiles (86 MB per tower at cfg-2, all-gather)
+// instead of all-reducing the 554 MB gradient.
+#include "tile_gemm.h"
+
+namespace lpm {
+
+// partial[n] -> factor: 1024 threads, eight loads per thread and round, fp64, fixed order
+__global__ __launch_bounds__(1024) void fa_factor_kernel(const float* __restrict__ partial, int64_t n, float clip, float* __restrict__ factor) {
+    double s = 0.0;
+    for (int64_t c = threadIdx.x; c < n; c += 1024 * 8) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = (c + 1024 * u < n) ? partial[c + 1024 * u] : 0.f;
+        s += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) + (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double sh[16];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < 16; ++i) tot += sh[i];
+        const float nrm = (float)sqrt(tot);
+        factor[0] = clip > 0.f ? clip / fmaxf(nrm, clip) : 1.f;
+        factor[1] = nrm;                      // for the caller's diagnostics (the norm the clip saw)
+    }
+}
+
+static int64_t fa_workgroups(int N1, int N2) { return (int64_t)((N1 + 63) / 64) * ((N2 + 127) / 128); }
+
+}  // namespace lpm
+
+extern "C" size_t lpm_factored_clip_adam_scratch_bytes(int N1, int N2) {
+    return (size_t)(lpm::fa_workgroups(N1, N2) + 4) * sizeof(float);
+}
+
+extern "C" int lpm_factored_clip_adam(const void* xt, const void* dyt, int R, int N1, int N2, float* param, float* m, float* v,
+                                      float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
+                                      size_t scratch_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(xt && dyt && param && m && v && scratch, LPM_ERR_BADARG, "lpm_factored_clip_adam: null pointer");
+    LPM_REQUIRE(R > 0 && R % 16 == 0 && N1 > 0 && N2 > 0 && N2 % 32 == 0 && step >= 1, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_factored_clip_adam: need R %% 16 == 0, N2 %% 32 == 0 and a 1-based step (R=%d N2=%d)", R, N2);
+    LPM_REQUIRE((((uintptr_t)param | (uintptr_t)m | (uintptr_t)v) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_factored_clip_adam: param / m / v must be 16-byte aligned");
+    LPM_REQUIRE(scratch_bytes >= lpm_factored_clip_adam_scratch_bytes(N1, N2), LPM_ERR_WORKSPACE, "lpm_factored_clip_adam: scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int NT1 = (N1 + 31) / 32, NT2 = N2 / 32;
+    const int64_t nwg = fa_workgroups(N1, N2);
+    float* partial = scratch;
+    float* factor = scratch + nwg;
+    TileGemmArgs g{};
+    g.a = (const uint4*)xt; g.a_tile = 128; g.a_step = (int64_t)NT1 * 128; g.a_batch = 0; g.a_tiles = NT1;
+    g.b = (const uint4*)dyt; g.b_tile = 128; g.b_step = (int64_t)NT2 * 128; g.b_batch = 0; g.b_tiles = NT2;
+    g.rb_per_batch = (N1 + 63) / 64; g.steps_per_split = R / 16; g.total_steps = R / 16;
+    g.out = param; g.ldo = N2; g.rows_valid = N1; g.cols_valid = N2;
+    g.cols_inner = 1;                     // the column blocks of a row block as neighbours: X tiles from HBM once
+    g.sumsq = partial;
+    int rc = tile_gemm_store(g, 1, 1, s, "lpm_factored_clip_adam (norm pass)", 1);
+    if (rc != LPM_OK) return rc;
+    hipLaunchKernelGGL(fa_factor_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, nwg, clip_norm, factor);
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    g.sumsq = nullptr;
+    g.adam_p = param; g.adam_m = m; g.adam_v = v; g.adam_factor = factor;
+    g.adam_lr_t = (float)lr_t; g.adam_b1 = beta1; g.adam_b2 = beta2; g.adam_eps = eps;
+    rc = tile_gemm_adam(g, s, "lpm_factored_clip_adam (update pass)");
+    if (rc != LPM_OK) return rc;
+    return check_launch("lpm_factored_clip_adam");
+}

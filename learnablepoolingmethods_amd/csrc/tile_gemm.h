@@ -52,7 +52,7 @@ __device__ __forceinline__ void tg_split8(const float* v, uint4& hi, uint4& lo) 
 }
 
 constexpr int TG_NS = 3;     // LDS ring stages
-enum { TG_EPI_STORE = 0, TG_EPI_SOFTMAX_BWD = 1 };
+enum { TG_EPI_STORE = 0, TG_EPI_SOFTMAX_BWD = 1, TG_EPI_ADAM = 2 };
 
 struct TileGemmArgs {
     const uint4* a;            // strides below are in 16-byte units; a (tile, step) pair is 128 units (hi plane, lo plane)
@@ -78,6 +78,13 @@ struct TileGemmArgs {
     int cols_inner;            // 64-row form: the column blocks of a row block are CONSECUTIVE workgroups of a one-dimensional grid (same
                                // XCD, same moment: the row block's A tiles come from HBM once and from L2 for the other column blocks)
                                // instead of gridDim.y slices a whole grid row apart
+    // STORE variants for a result that is a GRADIENT nobody needs to see (csrc/factored_adam.hip); 64-row form only:
+    float* sumsq;              // != null: nothing is stored; sumsq[workgroup] = sum of squares of the workgroup's valid outputs
+    float* adam_p;             // ADAM epilogue: nothing is stored; the tile is the gradient of adam_p[row * ldo + col]: scaled by *adam_factor
+    float* adam_m;             //          (the clip), then TF-Adam on adam_p / adam_m / adam_v in place (clip_adam.hip's arithmetic)
+    float* adam_v;
+    const float* adam_factor;
+    float adam_lr_t, adam_b1, adam_b2, adam_eps;
     float* stats;              // STORE, optional: [gridDim.x][2][cols_valid] per-workgroup column (sum, sum of squares)
     // SOFTMAX_BWD (needs gridDim.y == gridDim.z == 1): out = dlogit~ with a = softmax(logits*scale + shift) recomputed
     const float* logits;       // [batch * rows_valid + row][cols_valid]
@@ -92,6 +99,7 @@ struct TileGemmArgs {
 // workgroup rows, ceil(cols / (128 NTW)) column blocks, `splits` reduction splits.
 // planes: 2 = split-bf16 operands (hi, lo), 1 = plain bf16 operands
 int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw = 0, int planes = 2);   // ntw 0 = by column count
+int tile_gemm_adam(const TileGemmArgs& g, hipStream_t stream, const char* what);      // 64 x 128 tiles, one batch, one split, split-bf16
 int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what, int planes = 2);
 int tile_gemm_ntw(int cols);
 

@@ -25,6 +25,7 @@ static size_t tg_lds_bytes(int ntw, int epi) {
 template <int NTW, int EPI, int MW, int NS, int PL>
 __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmArgs g) {
     static_assert(MW == 1 || EPI == TG_EPI_STORE, "the 128-row form has the store epilogue only");
+    static_assert(EPI != TG_EPI_ADAM || (NTW == 1 && PL == 2), "the Adam epilogue: 64 x 128 tiles of split-bf16 operands");
     static_assert(PL == 1 || PL == 2, "planes");
     // PL == 1: plain bf16 tiles, a ring stage = two reduction steps ("sub" below is the step within the stage where the split
     // form has the plane); no second operand pair.
@@ -104,6 +105,22 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+    // ADAM epilogue: this thread's 8 float4 of param / m / v (the epilogue's (row, column) mapping) are requested BEFORE the
+    // reduction, so that their HBM round trip runs under it: the kernel is a 24 B-per-parameter stream with a tile GEMM inside,
+    // and a workgroup that asked for its 96 KB only after its last MFMA was bound by that latency (0.75 ms at cfg-2 instead of ~0.5).
+    f32x4 pa[EPI == TG_EPI_ADAM ? 8 : 1], ma[EPI == TG_EPI_ADAM ? 8 : 1], va[EPI == TG_EPI_ADAM ? 8 : 1];
+    if constexpr (EPI == TG_EPI_ADAM) {
+        const int gcol = cb * 128 + (tid & 31) * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int grow = rb * 64 + (j >> 2) * 32 + (tid >> 5) + 8 * (j & 3);
+            const bool ok = grow < g.rows_valid && gcol < g.cols_valid;
+            const int64_t o = ok ? (int64_t)grow * g.ldo + gcol : 0;
+            pa[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.adam_p + o));
+            ma[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.adam_m + o));
+            va[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.adam_v + o));
+        }
+    }
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nstep) issue(s);
@@ -236,6 +253,7 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
         }
         __syncthreads();                       // nothing in flight (the last step waited for vmcnt(0)): the ring is free
         const int tl = tid & 255;
+        float ssq = 0.f;                                            // g.sumsq: this thread's share of the tile's sum of squares
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             if (m) __syncthreads();
@@ -257,6 +275,9 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
                     unsigned short* pb = reinterpret_cast<unsigned short*>(g.out) + batch * g.out_batch + (int64_t)tb * g.out_batch +
                                          (int64_t)grow * g.ldo + gcol;
                     *reinterpret_cast<uint2*>(pb) = make_uint2(tg_rne(v.x) | (tg_rne(v.y) << 16), tg_rne(v.z) | (tg_rne(v.w) << 16));
+                } else if (MW == 1 && g.sumsq && grow < g.rows_valid && gcol < N) {
+                    const float4 v = *reinterpret_cast<const float4*>(es + row * ESTR + c4);
+                    ssq = fmaf(v.x, v.x, ssq); ssq = fmaf(v.y, v.y, ssq); ssq = fmaf(v.z, v.z, ssq); ssq = fmaf(v.w, v.w, ssq);
                 } else if (grow < g.rows_valid && gcol < N) {
                     float4 v = *reinterpret_cast<const float4*>(es + row * ESTR + c4);
                     float4* p = reinterpret_cast<float4*>(obt + (int64_t)grow * g.ldo + gcol);
@@ -267,6 +288,50 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
                     if (g.nt_store)      // a result far larger than the caches, read much later
                         __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
                     else *p = v;
+                }
+            }
+        }
+        if (MW == 1 && g.sumsq) {              // fixed order: thread (loop order) -> wave butterfly -> waves in order
+            ssq = wave_sum(ssq);
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);
+            if (lane == 0) red[wave] = ssq;
+            __syncthreads();
+            if (tid == 0) g.sumsq[blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
+    } else if (EPI == TG_EPI_ADAM) {
+        // the tile is a gradient: through LDS into the row-contiguous mapping of the prefetched param / m / v pieces, clip factor,
+        // TF-Adam (clip_adam.hip's arithmetic), non-temporal stores: every byte of the three arenas is touched once per step
+        constexpr int ESTR = 128 + 4;
+        float* es = reinterpret_cast<float*>(smem);
+        const float fac = *g.adam_factor;
+        const int gcol = cb * 128 + (tid & 31) * 4;
+        __syncthreads();                       // nothing in flight (the last step waited for vmcnt(0)): the ring is free
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (m) __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) es[mfma32_row(r, lane) * ESTR + cw * 32 + l31] = acc[m][0][r];
+            __syncthreads();
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const int j = m * 4 + j4;
+                const int row = (tid >> 5) + 8 * j4, grow = rb * 64 + m * 32 + row;
+                if (grow < g.rows_valid && gcol < N) {
+                    const float4 gg = *reinterpret_cast<const float4*>(es + row * ESTR + (tid & 31) * 4);
+                    const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+                    const int64_t o = (int64_t)grow * g.ldo + gcol;
+                    f32x4 pn, mn, vn;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float gc = gv[q] * fac;
+                        mn[q] = g.adam_b1 * ma[j][q] + (1.f - g.adam_b1) * gc;
+                        vn[q] = g.adam_b2 * va[j][q] + (1.f - g.adam_b2) * gc * gc;
+                        pn[q] = pa[j][q] - g.adam_lr_t * mn[q] / (sqrtf(vn[q]) + g.adam_eps);
+                    }
+                    __builtin_nontemporal_store(pn, reinterpret_cast<f32x4*>(g.adam_p + o));
+                    __builtin_nontemporal_store(mn, reinterpret_cast<f32x4*>(g.adam_m + o));
+                    __builtin_nontemporal_store(vn, reinterpret_cast<f32x4*>(g.adam_v + o));
                 }
             }
         }
@@ -378,6 +443,10 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
     }
     const int ntw = ntw_override ? ntw_override : tg_ntw(g.cols_valid);
     const int nt = (g.cols_valid + 31) / 32;
+    if ((g.sumsq || EPI == TG_EPI_ADAM) && (allow_wide || splits != 1 || nbatch != 1 || g.out_bf16 || g.accumulate)) {
+        set_error("%s: the gradient-consuming epilogues need the 64-row form, one batch, one split", what);
+        return LPM_ERR_BADARG;
+    }
     const bool wide = EPI == TG_EPI_STORE && allow_wide && tg_wide_ok(g, nbatch, splits, ntw, PL);
     dim3 grid((unsigned)(wide ? nbatch * g.a_tiles / 4 : nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)),
               (unsigned)splits);
@@ -407,10 +476,14 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
             hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, gl);                                            \
     } while (0)
 #define LPM_TG_LAUNCH(NTW) LPM_TG_LAUNCH_K((tile_gemm_kernel<NTW, EPI, 1, TG_NS, PL>), 256)
-    if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS, PL>), 512);
-    else if (ntw == 1) LPM_TG_LAUNCH(1);
-    else if (ntw == 2) LPM_TG_LAUNCH(2);
-    else LPM_TG_LAUNCH(4);
+    if constexpr (EPI == TG_EPI_ADAM) {
+        LPM_TG_LAUNCH(1);
+    } else {
+        if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS, PL>), 512);
+        else if (ntw == 1) LPM_TG_LAUNCH(1);
+        else if (ntw == 2) LPM_TG_LAUNCH(2);
+        else LPM_TG_LAUNCH(4);
+    }
 #undef LPM_TG_LAUNCH
 #undef LPM_TG_LAUNCH_K
     return check_launch(what);
@@ -426,6 +499,13 @@ static int tg_launch(const TileGemmArgs& g, int nbatch, int splits, hipStream_t 
 
 int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw, int planes) {
     return tg_launch<TG_EPI_STORE>(g, nbatch, splits, stream, what, ntw, 0, 0, planes);
+}
+int tile_gemm_adam(const TileGemmArgs& g, hipStream_t stream, const char* what) {
+    if (!g.adam_p || !g.adam_m || !g.adam_v || !g.adam_factor || g.cols_valid % 4 != 0 || g.ldo % 4 != 0 || g.stats || g.sumsq) {
+        set_error("%s: the Adam epilogue needs param / m / v / factor and 16-byte aligned rows", what);
+        return LPM_ERR_BADARG;
+    }
+    return tg_launch_pl<TG_EPI_ADAM, 2>(g, 1, 1, stream, what, 1, 0, 0);
 }
 int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what, int planes) {
     return tg_launch<TG_EPI_SOFTMAX_BWD>(g, nbatch, 1, stream, what, 0, 0, 0, planes);

@@ -69,3 +69,6 @@ FLAGS.define("base_learning_rate", 0.01, ":86")
 FLAGS.define("learning_rate_decay", 0.95, ":88")
 FLAGS.define("learning_rate_decay_examples", 4000000, ":91")
 FLAGS.define("clip_gradient_norm", 1.0, ":108")
+FLAGS.define("hidden1_factored_update", True, "build extension: the GPU trainer consumes hidden1_weights' gradient as the product "
+             "descriptors^T . d(activation) it is (lpm_factored_clip_adam): the gradient is never written, the towers all-gather its "
+             "two skinny factors instead of all-reducing it.  False: the generic path (gradient written into the arena)")

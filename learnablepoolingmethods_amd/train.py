@@ -298,6 +298,7 @@ class Trainer:
         self.arena: Optional[ParameterArena] = None
         self.sync: Optional[GradientSynchronizer] = None
         self.bucket_gather = None
+        self.factored = None
 
     @property
     def num_towers(self) -> int:
@@ -362,7 +363,19 @@ class Trainer:
         # hidden1_weights' gradient is complete right after the projection GEMM's backward: start its all-reduce
         # there and let it ride under the encoder / NetVLAD backward.
         early = (lambda: self.sync.launch(0)) if self.sync.active else None
-        if self.device.type == "cuda":
+        h1 = "tower/hidden1_weights"
+        self.factored = None
+        if (self.device.type == "cuda" and FLAGS.hidden1_factored_update and h1 in self.arena.views and self.arena.names[0] == h1
+                and self.arena.views[h1].dim() == 2 and self.arena.views[h1].shape[1] % 32 == 0):
+            # hidden1_weights' gradient is consumed as the product it is (ops.FactoredGradient, lpm_factored_clip_adam): the towers
+            # exchange its two skinny factors instead of all-reducing the gradient, which is never written
+            self.factored = ops.FactoredGradient(on_put=self._factored_put)
+            self.arena.views[h1]._lpm_factored = self.factored
+            n1 = self.arena.offsets_host[1]
+            self._tail_offsets = (self.arena.offsets[1:] - n1).contiguous()
+            self._factored_scratch = self._tail_scratch = None
+            self._factored_work = []
+        elif self.device.type == "cuda":
             self.arena.mark_direct("tower/hidden1_weights", on_ready=early)
         elif early is not None:
             self.arena.views["tower/hidden1_weights"].register_post_accumulate_grad_hook(lambda p: early())
@@ -408,17 +421,76 @@ class Trainer:
                 raise RuntimeError("analytic L2 penalty on a variable the gather-mode arena does not gather")
             self.arena.l2[name] = self.arena.l2.get(name, 0.0) + self.reg_penalty * scale
         self._l2_regs = []
-        final_loss.backward()                                                                   # :322-323
-        self.arena.collect(skip=self.bucket_gather.gathered_names() if self.bucket_gather is not None else ())
+        fg = self.factored
+        if fg is not None:
+            fg.clear()
+            fg.armed = True
+        try:
+            final_loss.backward()                                                               # :322-323
+        finally:
+            if fg is not None:
+                fg.armed = False
+        factored = fg is not None and fg.pending
+        skip = set(self.bucket_gather.gathered_names()) if self.bucket_gather is not None else set()
+        if factored:
+            skip.add(self.arena.names[0])
+        self.arena.collect(skip=skip)
         self.sync.finish()                                                                      # utils.combine_gradients :330
         lr = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers,
                            self.lr_decay_examples, self.lr_decay)                               # :244-249
         self.global_step += 1
-        self.arena._scratch = ops.clip_adam_step(self.arena.param, self.arena.grad, self.arena.m, self.arena.v,
-                                                 self.arena.offsets, len(self.arena.names), self.clip, lr,
-                                                 self.global_step, scratch=self.arena._scratch)  # :332-336
+        if factored:
+            self._factored_finish()
+            a = self.arena
+            n1, k = a.offsets_host[1], a.views[a.names[0]].numel()
+            if len(a.names) > 1:
+                self._tail_scratch = ops.clip_adam_step(a.param[n1:], a.grad[n1:], a.m[n1:], a.v[n1:], self._tail_offsets,
+                                                        len(a.names) - 1, self.clip, lr, self.global_step, scratch=self._tail_scratch)
+            self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, lr, self.global_step,
+                                                  scratch=self._factored_scratch)               # :332-336 for hidden1_weights
+        else:
+            self.arena._scratch = ops.clip_adam_step(self.arena.param, self.arena.grad, self.arena.m, self.arena.v,
+                                                     self.arena.offsets, len(self.arena.names), self.clip, lr,
+                                                     self.global_step, scratch=self.arena._scratch)  # :332-336
         return {"loss": label_loss.detach(), "predictions": predictions.detach(), "learning_rate": lr,
                 "global_step": self.global_step}
+
+    def gradient(self, name: str) -> torch.Tensor:
+        """The raw (summed over towers, un-clipped) gradient of variable ``name`` that the latest ``step`` consumed: its slice of the
+        gradient arena, or -- for hidden1_weights when the factored update ran, whose gradient is never written -- the product of
+        the factors the optimiser used (tests, diagnostics)."""
+        t = self.arena.views[name]
+        if self.factored is not None and self.factored.pending and name == self.arena.names[0]:
+            return self.factored.materialise().view(t.shape)
+        a0, _ = self.arena.segment(name)
+        return self.arena.grad[a0:a0 + t.numel()].view(t.shape)
+
+    def _factored_put(self, fg):
+        """Called inside backward when the projection has handed over its two gradient factors.  Data parallel: the towers' tile
+        buffers are all-gathered (asynchronously, under the rest of backward) -- concatenated along their leading step axis they ARE
+        the factors of the summed gradient (utils.combine_gradients) -- and bucket 0 has nothing left to all-reduce."""
+        self._factored_work = []
+        if not self.sync.active:
+            return
+        n = dist.get_world_size(self.group)
+        xt_all = torch.empty(n * fg.xt.numel(), dtype=fg.xt.dtype, device=fg.xt.device)
+        dyt_all = torch.empty(n * fg.dyt.numel(), dtype=fg.dyt.dtype, device=fg.dyt.device)
+        for what, dst, src in (("descriptor", xt_all, fg.xt), ("output-gradient", dyt_all, fg.dyt)):
+            _note(f"all_gather of the hidden projection's {what} tiles ({dst.numel() * 4 >> 20} MiB over {n} towers): launching")
+            self._factored_work.append((what, dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)))
+        self._factored_all = (xt_all, dyt_all, n * fg.R, fg.xt, fg.dyt)         # (the local buffers stay alive until the wait)
+        self.sync.done.add(0)
+
+    def _factored_finish(self):
+        if not self._factored_work:
+            return
+        for what, w in self._factored_work:
+            _note(f"all_gather of the hidden projection's {what} tiles: waiting for completion")
+            w.wait()
+        _note("all_gather of the hidden projection's tiles: complete")
+        fg = self.factored
+        fg.xt, fg.dyt, fg.R = self._factored_all[:3]
+        self._factored_work, self._factored_all = [], None
 
     # -- checkpoint / resume (train.py:501-515,593: Supervisor-saved variables + Adam slots + global_step) ------------------
     def state_dict(self) -> Dict[str, object]:

@@ -28,8 +28,7 @@ for prec in ("f32", "bf16x3", "f32,bf16x3,bf16x3", "f32,f32,bf16x3", "f32,bf16x3
     tr.step(x, nf, lab)
     errs = []
     for n in O.trainable_names(p, cfg):
-        a0, _ = tr.arena.segment("tower/" + n)
-        g = tr.arena.grad[a0:a0 + p[n].numel()].reshape(p[n].shape)
+        g = tr.gradient("tower/" + n)
         errs.append((rel_l2(g, raw_grads[n], floor=1e-4 * gscale * raw_grads[n].numel() ** 0.5), n))
     errs.sort(reverse=True)
     print(prec, " ".join(f"{n.split('/')[-3] if n.count('/')>1 else ''}/{n.split('/')[-2] if '/' in n else ''}/{n.split('/')[-1]}={e:.1e}" for e, n in errs[:8]))

@@ -1,6 +1,6 @@
 """One rank of tests/test_gpu_dp_trainer.py (not a test module).  Started as a fresh child process BEFORE it touches the GPU:
 
-    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_trainer_worker.py <dir> <side_stream 0|1>
+    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_trainer_worker.py <dir> <side_stream 0|1> [<factored 0|1>]
 
 All ranks share GPU 0 and exchange gradients over gloo (the boxes of this pool have one GPU; the code path -- arena buckets
 gathered and all-reduced from autograd hooks, early hidden1_weights bucket, per-variable clip + Adam on the summed arena -- is
@@ -18,6 +18,7 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     out_dir, side = sys.argv[1], sys.argv[2] == "1"
+    factored = len(sys.argv) < 4 or sys.argv[3] == "1"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -28,6 +29,7 @@ def main():
     c = inp["cfg"]
     FLAGS.moe_l2 = c["moe_l2"]
     FLAGS.audio_side_stream = side
+    FLAGS.hidden1_factored_update = factored
     per = inp["per_tower"]
     sl = slice(rank * per, (rank + 1) * per)
     x, nf, lab = inp["x"][sl], inp["nf"][sl], inp["lab"][sl]
@@ -50,15 +52,18 @@ def main():
         o = tr.step(x, nf, lab)
         torch.cuda.synchronize()
         grads = {}
+        used = tr.factored is not None and tr.factored.pending
+        if used:
+            # hidden1_weights' gradient was never written: what the optimiser consumed is the product of the all-gathered factors
+            assert tr.factored.R == world * per, (tr.factored.R, world, per)
         for n in names:
-            a0, _ = tr.arena.segment(n)
-            grads[n] = tr.arena.grad[a0:a0 + tr.arena.views[n].numel()].reshape(tr.arena.views[n].shape).double().cpu()
+            grads[n] = tr.gradient(n).double().cpu()
         slots = {}
         for n in names:
             a0, _ = tr.arena.segment(n)
             k, shape = tr.arena.views[n].numel(), tr.arena.views[n].shape
             slots[n] = (tr.arena.m[a0:a0 + k].reshape(shape).double().cpu(), tr.arena.v[a0:a0 + k].reshape(shape).double().cpu())
-        res["steps"].append(dict(loss=o["loss"].double().cpu(), predictions=o["predictions"].double().cpu(), lr=o["learning_rate"],
+        res["steps"].append(dict(factored=used, loss=o["loss"].double().cpu(), predictions=o["predictions"].double().cpu(), lr=o["learning_rate"],
                                  summed=grads, before=before, adam=slots,
                                  gathered=sorted(tr.bucket_gather.gathered) if tr.bucket_gather is not None else []))
     res["local_stats"] = {n: v.detach().double().cpu() for n, v in tr.store.vars.items() if not tr.store.trainable[n]}

@@ -37,7 +37,7 @@ def _free_port():
     return p
 
 
-def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420):
+def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420, factored=True):
     cfg = case["cfg"]
     torch.save(dict(cfg=dict(cfg.__dict__), x=case["x"], nf=case["nf"], lab=case["lab"], params=case["params"],
                     per_tower=case["per_tower"], steps=case["steps"]), tmp_path / "inputs.pt")
@@ -47,7 +47,7 @@ def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LPM_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_trainer_worker.py"), str(tmp_path),
-                                       "1" if side_stream else "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                                       "1" if side_stream else "0", "1" if factored else "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     try:
         for p in procs:
@@ -61,13 +61,16 @@ def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420):
     return [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
 
 
-def _check(case, ref, ranks):
+def _check(case, ref, ranks, factored=None):
+    """factored: whether hidden1_weights' update must have run from the all-gathered factors of its gradient (None: not asserted)."""
     cfg = case["cfg"]
     names = dp_cases.O.trainable_names(case["params"], cfg)
     r0 = ranks[0]
     assert r0["early_buckets"] == [1, 2], "head and encoder buckets are all-reduced from hooks inside backward"
     for s, st in enumerate(r0["steps"]):
         assert st["gathered"] == [1, 2], f"step {s}: the early buckets were gathered + launched inside backward"
+        if factored is not None:
+            assert st["factored"] == factored, f"step {s}: factored hidden1 update used = {st['factored']}, expected {factored}"
     # ranks agree bit for bit on everything the all-reduce feeds
     for n in names:
         for key in ("tower/" + n, "tower/" + n + "/Adam", "tower/" + n + "/Adam_1"):
@@ -129,12 +132,15 @@ def _check(case, ref, ranks):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name,side", [("toy", True), ("blocks", True), ("blocks", False)])
-def test_two_ranks_of_the_real_trainer_match_the_two_tower_oracle(name, side, tmp_path):
+@pytest.mark.parametrize("name,side,factored", [("toy", True, True), ("blocks", True, True), ("blocks", False, True), ("blocks", True, False)])
+def test_two_ranks_of_the_real_trainer_match_the_two_tower_oracle(name, side, factored, tmp_path):
+    """factored: hidden1_weights' gradient travels as its two factors (all-gather) and is consumed by lpm_factored_clip_adam -- the
+    16-clip towers of "blocks"; the 4-clip towers of "toy" fall back to the generic route (gradient written, all-reduced as bucket 0),
+    which "blocks" also takes with the flag off."""
     case, ref = _case(name)
-    ranks = _run_ranks(case, tmp_path, side)
-    worst = _check(case, ref, ranks)
-    print(f"[dp {name} side_stream={side}] worst summed-gradient error {worst[0]:.2e} ({worst[1]}); ReLU units moved: {case['relu_report']}")
+    ranks = _run_ranks(case, tmp_path, side, factored=factored)
+    worst = _check(case, ref, ranks, factored=factored and case["per_tower"] % 16 == 0)
+    print(f"[dp {name} side_stream={side} factored={factored}] worst summed-gradient error {worst[0]:.2e} ({worst[1]}); ReLU units moved: {case['relu_report']}")
 
 
 @pytest.mark.timeout(900)

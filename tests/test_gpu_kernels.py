@@ -458,6 +458,50 @@ def test_clip_adam_matches_oracle():
         assert_close(M[o:o + p.numel()].reshape(p.shape), rm, tol=1e-5, what="adam m")
 
 
+@pytest.mark.parametrize("R,N1,N2,gscale", [(32, 1000, 64, 1.0), (80, 4096 + 96, 512, 1e-3), (128, 2048, 1024, 0.05), (160, 640, 128, 1.0)])
+def test_factored_clip_adam_matches_oracle(R, N1, N2, gscale):
+    """lpm_factored_clip_adam: the hidden projection's weight update straight from the two factors of its gradient (dW = X^T DY is
+    never written) against clip_gradient_norms + adam_tf_update on the materialised fp64 gradient, three steps with changing factors;
+    R = 160: two towers' tile buffers concatenated along R (the data-parallel form).  gscale puts the norm on either side of the clip."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(R + N1)
+    p0 = torch.randn(N1, N2, generator=g)
+    P, M, V = p0.clone().to(dev), torch.zeros(N1, N2, device=dev), torch.zeros(N1, N2, device=dev)
+    rp, rm, rv = p0.double(), torch.zeros(N1, N2, dtype=torch.float64), torch.zeros(N1, N2, dtype=torch.float64)
+    fg = ops.FactoredGradient()
+    clipped = []
+    for step in (1, 2, 3):
+        x = torch.randn(R, N1, generator=g)
+        dy = torch.randn(R, N2, generator=g) * gscale
+        fg.clear()
+        if R == 160:                      # two towers: each splits its own 80 rows, the buffers are concatenated
+            halves = []
+            for h in range(2):
+                t = ops.FactoredGradient()
+                t.put(x[80 * h:80 * h + 80].to(dev), dy[80 * h:80 * h + 80].to(dev))
+                halves.append(t)
+            fg.xt, fg.dyt = torch.cat([t.xt for t in halves]), torch.cat([t.dyt for t in halves])
+            fg.R, fg.N1, fg.N2 = R, N1, N2
+        else:
+            fg.put(x.to(dev), dy.to(dev))
+        gref = x.double().t() @ dy.double()
+        assert_close(fg.materialise(), gref, tol=2e-5, what="materialised factors")
+        scratch = fg.clip_adam(P.view(-1), M.view(-1), V.view(-1), 1.0, 2e-4, step)
+        torch.cuda.synchronize()
+        factor, norm = float(scratch[-4]), float(scratch[-3])
+        assert abs(norm - float(gref.norm())) <= 1e-5 * float(gref.norm()), (norm, float(gref.norm()))
+        assert abs(factor - 1.0 / max(float(gref.norm()), 1.0)) < 1e-5
+        clipped.append(factor < 1.0)
+        cl = O.clip_gradient_norms({0: gref}, 1.0)[0]
+        rp, rm, rv = O.adam_tf_update(rp, cl, rm, rv, 2e-4, step)
+    # (an element whose gradient is small against the tile GEMM's 5e-6-of-scale error moves by a visibly different fraction of lr)
+    assert_close(P, rp, tol=3e-6, what="factored adam param")
+    assert_close(M, rm, tol=2e-5, what="factored adam m")
+    assert_close(V, rv, tol=4e-5, what="factored adam v")
+    assert all(clipped) == (gscale * (R * N1 * N2) ** 0.5 > 1.0)
+
+
 def test_capi_rejects_bad_shapes_loudly():
     from learnablepoolingmethods_amd import _capi, ops
     dev = cuda()

@@ -125,8 +125,7 @@ def _full_size_compare(name, cfg, B, seed, dev, scale_hidden1=True, dropout_mask
     gscale = max(float(g.abs().max()) for g in grads.values())
     worst = (0.0, "")
     for n in O.trainable_names(p, cfg):
-        a0, _ = tr.arena.segment("tower/" + n)
-        g = tr.arena.grad[a0:a0 + p[n].numel()].reshape(p[n].shape)
+        g = tr.gradient("tower/" + n)
         e = rel_l2(g, grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5)
         worst = max(worst, (e, n))
         assert e <= grad_tol, f"{name} gradient {n}: relative L2 error {e:.3e} > {grad_tol:.1e}"
@@ -203,8 +202,7 @@ def _train_compare(name, cfg, feat, B, MF, steps, dev, tol=1e-3, **kw):
         assert_close(out["loss"], info["loss"], tol=1e-4, what=f"step {s} loss")
         assert_close(out["predictions"], info["predictions"], what=f"step {s} predictions")
         for n in names:
-            a0, _ = tr.arena.segment("tower/" + n)
-            g = tr.arena.grad[a0:a0 + p[n].numel()].reshape(p[n].shape)      # raw (pre-clip) gradient of this step
+            g = tr.gradient("tower/" + n)      # raw (pre-clip) gradient of this step
             if s == 0:   # later steps start from weights that already differ by Adam's sign noise (see below)
                 e = rel_l2(g, raw_grads[n], floor=1e-4 * gscale * raw_grads[n].numel() ** 0.5)
                 assert e <= tol, f"step {s} gradient {n}: relative L2 error {e:.3e} > {tol:.1e}"
@@ -307,8 +305,7 @@ def test_willow_model_reg_forward_backward():
     assert_close(out["loss"], loss, tol=1e-4, what="loss")
     assert_close(out["predictions"], pred, what="predictions")
     for n in O.trainable_names(p, cfg):
-        a0, _ = tr.arena.segment("tower/" + n)
-        g = tr.arena.grad[a0:a0 + p[n].numel()].reshape(p[n].shape)
+        g = tr.gradient("tower/" + n)
         e = rel_l2(g, grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5)
         assert e <= 1e-3, f"gradient {n}: relative L2 error {e:.3e}"
 
@@ -381,8 +378,7 @@ def test_input_bn_gradient_shortcut_matches_the_input_gradient_path():
                 tr.store.vars["tower/input_bn/gamma"].copy_(1 + 0.6 * (torch.rand(1152, device=dev, generator=g) - 0.5))
                 tr.store.vars["tower/input_bn/beta"].copy_(0.2 * torch.randn(1152, device=dev, generator=g))
             loss = tr.step(x, nf, lab)["loss"].item()
-            grads = {n: tr.arena.grad[tr.arena.segment(n)[0]:tr.arena.segment(n)[0] + tr.arena.views[n].numel()].clone()
-                     for n in tr.arena.names}
+            grads = {n: tr.gradient(n).clone() for n in tr.arena.names}
             res.append((loss, grads))
         finally:
             FLAGS.reset()
@@ -518,8 +514,7 @@ def test_cfg5_layer_sizes_reduced_batch(storage):
     gscale = max(float(g.abs().max()) for g in grads.values())
     worst = (0.0, "")
     for n in O.trainable_names(p, cfg):
-        a0, _ = tr.arena.segment("tower/" + n)
-        e = rel_l2(tr.arena.grad[a0:a0 + p[n].numel()].reshape(p[n].shape), grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5)
+        e = rel_l2(tr.gradient("tower/" + n), grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5)
         worst = max(worst, (e, n))
         assert e <= gtol, f"cfg-5 {storage} gradient {n}: relative L2 error {e:.3e} > {gtol:.1e}"
     print(f"[cfg-5 {storage} B={B}] " + ", ".join(f"{k}: {v:.1e}" for k, v in errs.items()) + f"; worst gradient {worst[0]:.2e} ({worst[1]})")
