@@ -67,8 +67,11 @@ extern "C" int lpm_factored_clip_adam(const void* xt, const void* dyt, int R, in
     g.rb_per_batch = (N1 + 63) / 64; g.steps_per_split = R / 16; g.total_steps = R / 16;
     g.out = param; g.ldo = N2; g.rows_valid = N1; g.cols_valid = N2;
     g.cols_inner = 1;                     // the column blocks of a row block as neighbours: X tiles from HBM once
+    // measurement switches (tools/time_factored.py): 1 = no reduction steps in either pass (the streams alone), 2 = no norm pass
+    static const int dbg = [] { const char* e = getenv("LPM_FA_DBG"); return e ? atoi(e) : 0; }();
+    if (dbg & 1) g.steps_per_split = g.total_steps = 0;
     g.sumsq = partial;
-    int rc = tile_gemm_store(g, 1, 1, s, "lpm_factored_clip_adam (norm pass)", 1);
+    int rc = (dbg & 2) ? LPM_OK : tile_gemm_store(g, 1, 1, s, "lpm_factored_clip_adam (norm pass)", 1);
     if (rc != LPM_OK) return rc;
     hipLaunchKernelGGL(fa_factor_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, nwg, clip_norm, factor);
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));

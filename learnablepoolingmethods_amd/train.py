@@ -365,7 +365,8 @@ class Trainer:
         early = (lambda: self.sync.launch(0)) if self.sync.active else None
         h1 = "tower/hidden1_weights"
         self.factored = None
-        if (self.device.type == "cuda" and FLAGS.hidden1_factored_update and h1 in self.arena.views and self.arena.names[0] == h1
+        if (self.device.type == "cuda" and FLAGS.hidden1_factored_update and self.num_towers <= FLAGS.hidden1_factored_max_towers
+                and h1 in self.arena.views and self.arena.names[0] == h1
                 and self.arena.views[h1].dim() == 2 and self.arena.views[h1].shape[1] % 32 == 0):
             # hidden1_weights' gradient is consumed as the product it is (ops.FactoredGradient, lpm_factored_clip_adam): the towers
             # exchange its two skinny factors instead of all-reducing the gradient, which is never written
