@@ -220,6 +220,16 @@ int lpm_vlad_aggregate_raw_kmajor_fwd(const void* at, const void* xt, const floa
                                       float* raw_kmajor, float* asum, float* colsq_part, lpm_stream_t stream);
 int lpm_vlad_row_scales(const float* colsq_part, int P, int B, int K, float* scale, float* colsq, float* csq, float* gsq,
                         lpm_stream_t stream);
+/* ... and with the SOFTMAX inside the aggregation kernel: frame_level_models.py:2798-2822 as one launch (+ a small row-statistics launch
+ * before it and lpm_vlad_row_scales after it).  logits [B*T, K] fp32 = K1's output, scale / shift [K] = cluster_bn folded (either may
+ * be NULL; shift = the bias without batch norm); per 16-frame step the workgroup's raw logits arrive by LDS-DMA next to the frame tiles
+ * and are turned into split-bf16 A fragments in LDS -- no assignment tensor or tile copy exists anywhere.  flags: LPM_VLAD_SOFTMAX
+ * (required) | LPM_VLAD_RESIDUAL.  stats: lpm_vlad_smx_stats_bytes(B, T) bytes of scratch.  K in {128, 256, 512}, 33 <= T <= 4096. */
+size_t lpm_vlad_smx_stats_bytes(int B, int T);
+int lpm_vlad_smx_supported(int T, int D, int K);
+int lpm_vlad_aggregate_raw_kmajor_smx_fwd(const float* logits, const float* scale, const float* shift, const void* xt,
+                                          const float* centres, int B, int T, int D, int K, int flags, float* raw_kmajor,
+                                          float* asum, float* colsq_part, float* stats, lpm_stream_t stream);
 int lpm_split_rows_scaled(const float* x, int64_t ldx, int64_t M, int K, const float* row_scale, void* out3, lpm_stream_t stream);
 int lpm_layer_norm_act_fwd_rs(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,
                               const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, float* z,

@@ -83,6 +83,9 @@ SIGNATURES = {
     "lpm_assign_tiles_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),
     "lpm_vlad_aggregate_tiles3_fwd_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "lpm_vlad_aggregate_raw_kmajor_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "lpm_vlad_smx_stats_bytes": (_s, [_i, _i]),
+    "lpm_vlad_smx_supported": (_i, [_i, _i, _i]),
+    "lpm_vlad_aggregate_raw_kmajor_smx_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_vlad_row_scales": (_i, [_f, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_split_rows_scaled": (_i, [_f, _l, _l, _i, _f, _f, _f]),
     "lpm_layer_norm_act_fwd_rs": (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _s, _f]),

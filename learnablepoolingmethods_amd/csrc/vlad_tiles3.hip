@@ -33,6 +33,8 @@ constexpr int T3_NS = 3;                  // ring stages (48 KB: three workgroup
 constexpr int T3_STAGE = 16 * 1024;       // bytes per stage: 4 A tiles + 4 x tiles, 2 planes, 1 KB each
 constexpr int T3_WS = 36;                 // epilogue per-wave tile row stride (floats): 144 B, 16-B aligned
 constexpr int T3_EPI = 8 * 32 * T3_WS * 4;  // epilogue bytes (8 waves x [32 d][32 k + pad]), overlays the ring
+constexpr int T3_SMX_RAW = T3_NS * T3_STAGE + (4 * 128 + 128 + 16) * 4;     // SMX: raw-logit ring [NS][8 KB]
+constexpr int T3_SMX_LDS = T3_SMX_RAW + T3_NS * 8192;
 
 // FUSED (lpm_vlad_aggregate_fused_fwd): the finalize pass moves into this kernel.  The K/128 x D/128 workgroups of a clip
 // publish their partial column square norms (write-through stores), count themselves in on a per-clip arrival counter, wait --
@@ -55,12 +57,109 @@ struct T3Fused {
     unsigned* fail;             // [B * K/128 * D/128] one flag per workgroup tile, zero at launch
 };
 
+// SMX (lpm_vlad_aggregate_raw_kmajor_smx_fwd): the softmax moves INTO this kernel -- frame_level_models.py:2798-2822 as one
+// launch (+ the row statistics below and the [B, K] row scales).  No assignment tiles exist: per 16-frame step the workgroup's eight
+// waves read the 16 x 128 logits of its cluster slab (the same 8 KB an A-tile stage was), apply the cluster_bn affine, exp(z - m_t)
+// / sum_t from the per-frame statistics, split into bf16 hi / lo and write the four A fragment tiles of the NEXT step straight into
+// its ring stage; the frame tiles keep arriving by LDS-DMA.
+struct T3Softmax {
+    const float* logits;        // [B*T, K] fp32 (K1's output)
+    const float* scale;         // [K] cluster_bn folded (null: 1)
+    const float* shift;         // [K] (null: 0; the bias when there is no batch norm)
+    const float* stats;         // [B][Tpad][2]: row maximum of z = logits * scale + shift, 1 / sum exp(z - max); (0, 0) for t >= T
+    int Tpad;                   // 16 * steps
+};
+
+// row statistics of the softmax, thread layout and order of operations of assign_tiles2_kernel (vlad_tiles.hip): a lane owns VPL
+// consecutive clusters, a wave four frames, a workgroup one 16-frame step -- so that exp(z - m) * inv here and there are the same bits
+template <int VPL>
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ logits, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int T, int S, float* __restrict__ stats) {
+    constexpr int K = 64 * VPL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / S, s = blockIdx.x % S;
+    const int c0 = lane * VPL;
+    float sc[VPL], sh[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        sc[j] = scale ? scale[c0 + j] : 1.f;
+        sh[j] = shift ? shift[c0 + j] : 0.f;
+    }
+    float v[4][VPL];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int t = 16 * s + wave * 4 + rr;
+        if (t < T) {                                         // wave-uniform
+            const float* p = logits + ((int64_t)b * T + t) * K + c0;
+            if (VPL % 4 == 0) {
+#pragma unroll
+                for (int j = 0; j < VPL; j += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(p + j);
+                    v[rr][j] = q.x; v[rr][j + 1] = q.y; v[rr][j + 2] = q.z; v[rr][j + 3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) v[rr][j] = p[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) v[rr][j] = 0.f;
+        }
+    }
+    float m[4], sum[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        m[rr] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            v[rr][j] = fmaf(v[rr][j], sc[j], sh[j]);
+            m[rr] = fmaxf(m[rr], v[rr][j]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) m[rr] = fmaxf(m[rr], __shfl_xor(m[rr], o, 64));
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        sum[rr] = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) sum[rr] += __expf(v[rr][j] - m[rr]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) sum[rr] += __shfl_xor(sum[rr], o, 64);
+    if (lane < 4) {
+        const int t = 16 * s + wave * 4 + lane;
+        float mm = 0.f, inv = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            if (rr == lane && t < T) { mm = m[rr]; inv = 1.f / sum[rr]; }
+        *reinterpret_cast<float2*>(stats + ((int64_t)b * S * 16 + t) * 2) = make_float2(mm, inv);
+    }
+}
+
+typedef __bf16 t3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float t3_f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed (hi, lo) bf16 pairs, round-to-nearest-even both (v_cvt_pk_bf16_f32; the bits of vlad_tiles.hip's split8)
+__device__ __forceinline__ void t3_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const t3_f32x2 v = {a, b};
+    const t3_bf16x2 h = __builtin_convertvector(v, t3_bf16x2);
+    const t3_f32x2 hf = __builtin_convertvector(h, t3_f32x2);
+    const t3_bf16x2 l = __builtin_convertvector(v - hf, t3_bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
 // PL = 1 (bf16 storage): AT / XT are plain bf16 tiles, ONE plane per (tile, step), S (even) steps per clip; a ring stage then
 // carries two consecutive frame steps where the split form carries the two planes of one step, and a product is one MFMA.
-template <bool FUSED, int PL>
-__global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
+template <bool FUSED, int PL, bool SMX = false>
+__global__ __launch_bounds__(512, SMX ? 4 : 6) void vlad_aggregate_tiles3_kernel(
     const uint4* __restrict__ at, const uint4* __restrict__ xt, const float* __restrict__ centres, int T, int D, int K,
-    int S, int KT, int residual, float* __restrict__ nrm, float* __restrict__ asum, float* __restrict__ colsq_part, const T3Fused fz) {
+    int S, int KT, int residual, float* __restrict__ nrm, float* __restrict__ asum, float* __restrict__ colsq_part, const T3Fused fz,
+    const T3Softmax sm) {
+    static_assert(!SMX || PL == 2, "the in-kernel softmax writes split-bf16 fragments");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object (guide 5, trap (a))
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,12 +179,15 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
                                 : xt + (((int64_t)b * S + pplane) * DT + ds * 4 + ptile) * 64 + lane;
     const int adst = (ptile * 2 + pplane) * 1024, xdst = 8192 + (ptile * 2 + pplane) * 1024;
     const int NST = PL == 2 ? S : S / 2;           // ring stages
+    const int k0s = kb * 128;                      // first cluster of this workgroup's slab
 
-    auto issue = [&](int s) {
+    auto issue = [&](int s) {                 // the pieces of step min(s, NST - 1) into stage s % NS
         unsigned char* st = smem + (s % T3_NS) * T3_STAGE;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)s * 128),
-                                         (__attribute__((address_space(3))) void*)(st + adst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (int64_t)s * DT * 128),
+        const int sc = SMX ? min(s, NST - 1) : s;
+        if (!SMX)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)sc * 128),
+                                             (__attribute__((address_space(3))) void*)(st + adst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (int64_t)sc * DT * 128),
                                          (__attribute__((address_space(3))) void*)(st + xdst), 16, 0, 0);
     };
 
@@ -96,19 +198,8 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     float asum_w = 0.f;     // partial assignment sum of cluster row l31 of tile (kw, dw >> 1)
 
-#pragma unroll
-    for (int s = 0; s < T3_NS - 1; ++s)
-        if (s < NST) issue(s);
-
-    for (int s = 0; s < NST; ++s) {
-        // this wave's two pieces of step s have landed when at most 2 * (younger steps in flight) remain
-        const int behind = min(T3_NS - 2, NST - 1 - s);
-        if (behind >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (behind == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // everyone's pieces of step s are in LDS; stage (s-1) % NS is free
-        asm volatile("" ::: "memory");
-        if (s + T3_NS - 1 < NST) issue(s + T3_NS - 1);
+    // one step's MFMAs + assignment sums from the fragments in stage s % NS
+    auto compute = [&](int s) {
         const unsigned char* st = smem + (s % T3_NS) * T3_STAGE;
         const t3_u32x4* af = reinterpret_cast<const t3_u32x4*>(st) + lane;                 // A tile c, plane p: + (c*2+p)*64
         const t3_u32x4* xf = reinterpret_cast<const t3_u32x4*>(st + 8192) + lane;
@@ -135,6 +226,110 @@ __global__ __launch_bounds__(512, 6) void vlad_aggregate_tiles3_kernel(
                 }
             }
         }
+    };
+
+    if constexpr (!SMX) {
+#pragma unroll
+        for (int s = 0; s < T3_NS - 1; ++s)
+            if (s < NST) issue(s);
+
+        for (int s = 0; s < NST; ++s) {
+            // this wave's two pieces of step s have landed when at most 2 * (younger steps in flight) remain
+            const int behind = min(T3_NS - 2, NST - 1 - s);
+            if (behind >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // everyone's pieces of step s are in LDS; stage (s-1) % NS is free
+            asm volatile("" ::: "memory");
+            if (s + T3_NS - 1 < NST) issue(s + T3_NS - 1);
+            compute(s);
+        }
+    } else {
+        // ---- in-kernel softmax.  Two more LDS-DMA streams ride next to the frame tiles (behind the reduction scratch: T3_SMX_RAW):
+        //   Lg(j): the 16 x 128 raw logits of step j, eight 1 KB pieces -- wave w brings frames w and w + 8 (one 512-byte row each).
+        // The clip's row statistics (max, 1 / sum) sit in LDS from the start.
+        // During step s every wave turns its quarter of A tile tc = w >> 1 of step s + 1 -- lane (half, l31): cluster 32 tc + l31,
+        // frames 8 half + 4 fq + {0..3}, fq = w & 1 -- from raw logits into split-bf16 fragment bytes: affine, exp(z - m) / sum,
+        // hi / lo, two 8-byte LDS stores into stage (s + 1) % NS.  Every step issues the SAME operations -- X(s + 2), Lg(s + 3)
+        // -- sources clamped to the last step past the end -- so the in-order vmcnt at the top of a step is a constant: the youngest
+        // step's two operations stay in flight.
+        const int tc = wave >> 1, fq = wave & 1;
+        unsigned char* rawb = smem + T3_SMX_RAW;                       // [NS][8 pieces][1 KB]
+        const float* lsrc = sm.logits + (int64_t)b * T * K + k0s + (lane & 31) * 4;      // + frame * K
+        const int lfr = wave + 8 * (lane >> 5);                        // the frame of the step this lane's 16 bytes belong to
+        // the clip's row statistics (max, 1 / sum per frame: 8 bytes x Tpad) are copied into LDS once, BEFORE the first DMA is issued:
+        // ordinary loads inside the loop would share the in-order vector-memory counter with the ring
+        float* stl = reinterpret_cast<float*>(rawb + T3_NS * 8192);
+        for (int i = tid; i < sm.Tpad * 2; i += 512) stl[i] = sm.stats[(int64_t)b * sm.Tpad * 2 + i];
+        const unsigned stl_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)stl;      // LDS byte addresses
+        const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        const float csc = sm.scale ? sm.scale[k0s + tc * 32 + l31] : 1.f;
+        const float csh = sm.shift ? sm.shift[k0s + tc * 32 + l31] : 0.f;
+        auto issue_l = [&](int j) {
+            const int jc = min(j, NST - 1);
+            const int t = min(16 * jc + lfr, T - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + (int64_t)t * K),
+                                             (__attribute__((address_space(3))) void*)(rawb + (j % T3_NS) * 8192 + wave * 1024), 16, 0, 0);
+        };
+        // raw logits + statistics of step j -> this wave's quarter of A tile tc of stage j % NS, in two halves: the LDS reads go out
+        // BEFORE the step's MFMAs (their latency runs under the matrix pipe), arithmetic and stores come after.  All LDS traffic of
+        // this path is inline assembly: hipcc puts an s_waitcnt vmcnt(0) in front of an ordinary LDS read or store of these regions
+        // while LDS-DMA is in flight -- draining the two ring steps -- although none of it touches what the DMA writes.  (LDS
+        // returns in order, so these extra reads only make the compiler's own lgkmcnt waits stricter, never wrong.)
+        struct CReg { f32x4 s0, s1; float l[4]; };
+        const unsigned raw_lds = smem_lds + T3_SMX_RAW + (half * 128 + tc * 32 + l31) * 4 + fq * 4096;      // + stage * 8192; frame q: + q * 1024
+        auto convert_read = [&](int j, CReg& r) {
+            const unsigned sa = stl_lds + (16 * j + 8 * half + 4 * fq) * 8;
+            const unsigned ra = raw_lds + (j % T3_NS) * 8192;
+            asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\t"
+                         "ds_read_b32 %2, %7\n\tds_read_b32 %3, %7 offset:1024\n\tds_read_b32 %4, %7 offset:2048\n\tds_read_b32 %5, %7 offset:3072"
+                         : "=&v"(r.s0), "=&v"(r.s1), "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3])
+                         : "v"(sa), "v"(ra)
+                         : "memory");
+        };
+        auto convert_write = [&](int j, CReg& r) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.s0), "+v"(r.s1), "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3])::"memory");
+            const float mx[4] = {r.s0[0], r.s0[2], r.s1[0], r.s1[2]}, iv[4] = {r.s0[1], r.s0[3], r.s1[1], r.s1[3]};
+            float av[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                av[q] = __expf(fmaf(r.l[q], csc, csh) - mx[q]) * iv[q];
+                // the product is ROUNDED before the hi / lo split, as in lpm_assign_tiles: left to itself (fp-contract=fast) hipcc turns
+                // a - hi into fma(e, inv, -hi), i.e. splits the unrounded product, and the two forms stop agreeing bit for bit
+                asm volatile("" : "+v"(av[q]));
+            }
+            unsigned h01, l01, h23, l23;
+            t3_split2(av[0], av[1], h01, l01);
+            t3_split2(av[2], av[3], h23, l23);
+            typedef unsigned t3_u32x2 __attribute__((ext_vector_type(2)));
+            const t3_u32x2 hv = {h01, h23}, lv2 = {l01, l23};
+            const unsigned da = smem_lds + (j % T3_NS) * T3_STAGE + tc * 2048 + lane * 16 + fq * 8;
+            asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:1024" ::"v"(da), "v"(hv), "v"(lv2) : "memory");
+        };
+        CReg cr;
+        issue_l(0);
+        issue(0);
+        issue_l(1);
+        issue(1);
+        issue_l(2);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // Lg(0) has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        convert_read(0, cr);
+        convert_write(0, cr);
+        for (int s = 0; s < NST; ++s) {
+            // oldest first: X(s), Lg(s+1) | X(s+1), Lg(s+2)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this wave's quarter of A(s) (written during step s - 1) is in LDS
+            __builtin_amdgcn_s_barrier();              // X(s), A(s), Lg(s+1) are in LDS for everyone; step s - 1 is done with
+            asm volatile("" ::: "memory");
+            issue(s + 2);
+            issue_l(s + 3);
+            if (s + 1 < NST) convert_read(s + 1, cr);
+            compute(s);
+            if (s + 1 < NST) convert_write(s + 1, cr);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the redundant tail operations
     }
     __syncthreads();     // no DMA in flight any more: the ring is reused by the epilogue
 
@@ -582,10 +777,10 @@ static int vlad_aggregate_tiles3_impl(const void* at, const void* xt, const floa
     hipEvent_t e0, e1;
     if (timing_request(LPM_TIMING_K2, &e0, &e1))
         hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T,
-                              D, K, S, KT, residual, nrm, asum, colsq_part, fz);
+                              D, K, S, KT, residual, nrm, asum, colsq_part, fz, T3Softmax{});
     else
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
-                           residual, nrm, asum, colsq_part, fz);
+                           residual, nrm, asum, colsq_part, fz, T3Softmax{});
     return check_launch("lpm_vlad_aggregate_tiles3_fwd");
 }
 
@@ -636,7 +831,9 @@ extern "C" int lpm_vlad_aggregate_raw_kmajor_fwd(const void* at, const void* xt,
     const int S = (T + 15) / 16, KT = K / 32;
     T3Fused fz{};
     fz.out = raw_kmajor; fz.raw_kmajor = 1;
-    const size_t lds = (size_t)T3_NS * T3_STAGE + (4 * 128 + 128 + 16) * sizeof(float);
+    // LPM_K2_EXTRA_LDS (measurement): bytes of unused LDS added to the launch -- 27000 leaves two workgroups per CU instead of three
+    static const int extra_lds = [] { const char* e = getenv("LPM_K2_EXTRA_LDS"); return e ? atoi(e) : 0; }();
+    const size_t lds = (size_t)T3_NS * T3_STAGE + (4 * 128 + 128 + 16) * sizeof(float) + (size_t)extra_lds;
     auto kern = vlad_aggregate_tiles3_kernel<true, 2>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
@@ -647,11 +844,62 @@ extern "C" int lpm_vlad_aggregate_raw_kmajor_fwd(const void* at, const void* xt,
     hipEvent_t e0, e1;
     if (timing_request(LPM_TIMING_K2, &e0, &e1))
         hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T, D, K,
-                              S, KT, residual, (float*)nullptr, asum, colsq_part, fz);
+                              S, KT, residual, (float*)nullptr, asum, colsq_part, fz, T3Softmax{});
     else
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
-                           residual, (float*)nullptr, asum, colsq_part, fz);
+                           residual, (float*)nullptr, asum, colsq_part, fz, T3Softmax{});
     return check_launch("lpm_vlad_aggregate_raw_kmajor_fwd");
+}
+
+// ... with the softmax inside the aggregation kernel (T3Softmax): logits [B*T, K] fp32 + the folded cluster_bn affine (scale / shift,
+// either may be NULL) in, no assignment tiles.  stats: lpm_vlad_smx_stats_bytes(B, T) bytes of scratch (per-frame row maximum and
+// 1 / row sum, written by a first small launch).  K in {128, 256, 512}, T >= 33.
+extern "C" size_t lpm_vlad_smx_stats_bytes(int B, int T) { return (size_t)B * 16 * ((T + 15) / 16) * 2 * sizeof(float); }
+extern "C" int lpm_vlad_smx_supported(int T, int D, int K) {
+    return (lpm_vlad_tiles3_supported(D, K) && (K == 128 || K == 256 || K == 512) && (T + 15) / 16 >= 3 && T <= 4096) ? 1 : 0;
+}
+extern "C" int lpm_vlad_aggregate_raw_kmajor_smx_fwd(const float* logits, const float* scale, const float* shift, const void* xt,
+                                                     const float* centres, int B, int T, int D, int K, int flags, float* raw_kmajor,
+                                                     float* asum, float* colsq_part, float* stats, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(logits && xt && raw_kmajor && asum && colsq_part && stats, LPM_ERR_BADARG, "lpm_vlad_aggregate_raw_kmajor_smx_fwd: null pointer");
+    const int residual = (flags & LPM_VLAD_RESIDUAL) ? 1 : 0;
+    LPM_REQUIRE(!residual || centres, LPM_ERR_BADARG, "lpm_vlad_aggregate_raw_kmajor_smx_fwd: RESIDUAL needs centres");
+    LPM_REQUIRE((flags & LPM_VLAD_SOFTMAX) != 0, LPM_ERR_BADARG, "lpm_vlad_aggregate_raw_kmajor_smx_fwd: this entry IS the softmax form");
+    LPM_REQUIRE(B > 0 && lpm_vlad_smx_supported(T, D, K), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_raw_kmajor_smx_fwd: need D %% 128 == 0, K in {128, 256, 512}, T >= 33 (T=%d D=%d K=%d)", T, D, K);
+    LPM_REQUIRE((((uintptr_t)logits | (uintptr_t)xt | (uintptr_t)centres | (uintptr_t)raw_kmajor | (uintptr_t)stats) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_vlad_aggregate_raw_kmajor_smx_fwd: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = (T + 15) / 16, KT = K / 32;
+    hipEvent_t e0, e1;
+    const bool timed_st = timing_request(LPM_TIMING_ASSIGN_TILES, &e0, &e1);
+#define LPM_SMX_STATS(VPL)                                                                                                          \
+    do {                                                                                                                            \
+        if (timed_st) hipExtLaunchKernelGGL((softmax_stats_kernel<VPL>), dim3(B * S), dim3(256), 0, s, e0, e1, 0, logits, scale, shift, T, S, stats); \
+        else hipLaunchKernelGGL((softmax_stats_kernel<VPL>), dim3(B * S), dim3(256), 0, s, logits, scale, shift, T, S, stats);       \
+    } while (0)
+    if (K == 128) LPM_SMX_STATS(2); else if (K == 256) LPM_SMX_STATS(4); else LPM_SMX_STATS(8);
+#undef LPM_SMX_STATS
+    T3Fused fz{};
+    fz.out = raw_kmajor; fz.raw_kmajor = 1;
+    T3Softmax sm{logits, scale, shift, stats, 16 * S};
+    const size_t lds = (size_t)T3_SMX_LDS + (size_t)16 * S * 2 * sizeof(float);
+    LPM_REQUIRE(lds <= 160 * 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_vlad_aggregate_raw_kmajor_smx_fwd: T = %d needs %zu bytes of LDS", T, lds);
+    auto kern = vlad_aggregate_tiles3_kernel<true, 2, true>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("lpm_vlad_aggregate_raw_kmajor_smx_fwd: cannot reserve %zu bytes of LDS", lds);
+        return LPM_ERR_LAUNCH;
+    }
+    dim3 grid(B * (K / 128) * (D / 128));
+    if (timing_request(LPM_TIMING_K2, &e0, &e1))
+        hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, s, e0, e1, 0, (const uint4*)nullptr, (const uint4*)xt, centres, T, D, K, S, KT,
+                              residual, (float*)nullptr, asum, colsq_part, fz, sm);
+    else
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)nullptr, (const uint4*)xt, centres, T, D, K, S, KT, residual,
+                           (float*)nullptr, asum, colsq_part, fz, sm);
+    return check_launch("lpm_vlad_aggregate_raw_kmajor_smx_fwd");
 }
 
 extern "C" int lpm_vlad_row_scales(const float* colsq_part, int P, int B, int K, float* scale, float* colsq, float* csq, float* gsq,
@@ -716,10 +964,10 @@ extern "C" int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, cons
     hipEvent_t e0, e1;
     if (timing_request(LPM_TIMING_K2, &e0, &e1))
         hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, s, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
-                              residual, nrm, asum, part, fz);
+                              residual, nrm, asum, part, fz, T3Softmax{});
     else
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT, residual, nrm, asum,
-                           part, fz);
+                           part, fz, T3Softmax{});
     // follow-up for tiles whose workgroup gave up waiting for its clip (fail flag set; none in practice)
     hipLaunchKernelGGL(vlad_fused_fixup_kernel, grid, dim3(256), 0, s, nrm, part, fail, D, K, fz);
     return check_launch("lpm_vlad_aggregate_fused_fwd");

@@ -37,6 +37,15 @@ PROJ_STREAM = os.environ.get("LPM_PROJ_STREAM", "1") != "0"
 # ... the input-gradient kernel from this hidden size on (measured, rocprofv3 kernel durations: forward 174 + 21 us vs the library's 219 us at
 # cfg-2, 764 vs 1233 us at cfg-5; dx 267 vs 211 us at cfg-2's N = 512 -- the library stays there --, 1108 vs 1232 us at cfg-5's N = 1024)
 PROJ_DX_STREAM_MIN_N = int(os.environ.get("LPM_PROJ_DX_STREAM_MIN_N", "1024"))
+# a5 with the softmax inside the aggregation kernel (lpm_vlad_aggregate_raw_kmajor_smx_fwd; the lazily normalised k-major descriptor
+# of the NetVladV1 video stream): no assignment tiles, chain traffic ~1.17x algorithmic instead of 1.4x -- and bit for bit the
+# two-kernel chain's result.  Off by default, it is slower: measured at cfg-2 in the training step (kernel durations) row statistics
+# 8.7 us + aggregation 76.4 us + row scales 5.4 us = 90.5 us against 11.8 + 61.5 + 5.0 = 79 us for lpm_assign_tiles +
+# lpm_vlad_aggregate_raw_kmajor_fwd.  The aggregation loop is bound by LDS bandwidth next to the L2 -> LDS delivery (48 KB of
+# fragment reads per 16 KB staged), and building the A fragments in the kernel adds 8 KB of DMA writes, 8 KB of reads and 8 KB of
+# stores per step (+37 %); the third workgroup per CU it also loses (78 KB of LDS) is worth only 2 us (LPM_K2_EXTRA_LDS=27000 on
+# the two-kernel form: 61.5 -> 63.8 us).
+VLAD_SOFTMAX_FUSED = os.environ.get("LPM_VLAD_SOFTMAX_FUSED", "0") == "1"
 # a2 + a3 also emit K1's split-bf16 row tiles (lpm_frame_apply_tiles2) instead of a separate lpm_split_rows_tiles pass per stream.
 # Off by default: measured at cfg-2 the step is 8.65 ms with it and 8.59 ms without -- the separate pass (26 us) leaves its 50 MB of
 # tiles in the 256 MB infinity cache right before K1 reads them (K1 44 us), whereas the fused pass writes 300 MB (fp32 matrix, frame
@@ -379,6 +388,24 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
             xt = torch.empty(lib._lpm_xt_bytes(B, T, D) // 4, dtype=torch.int32, device=x.device)
             with _timed("split_frames", (B, T, D)):
                 lib.check(lib._lpm_split_frames(ptr(x), x.stride(0), B, T, D, ptr(xt), st), "lpm_split_frames")
+        if (lazy and VLAD_SOFTMAX_FUSED and (flags & LPM_VLAD_SOFTMAX) and kmajor and VLAD_TILES3 and assign.dtype == torch.float32
+                and lib._lpm_vlad_smx_supported(T, D, K)):
+            # softmax -> residual aggregation in ONE kernel (frame_level_models.py:2798-2817): the assignment never exists in memory,
+            # not even as tiles; a small launch before it leaves the per-frame row maximum and 1 / row sum
+            raw = _empty((B, K, D), x)
+            P = D // 128
+            part = _empty((B, P, K), x)
+            stats = torch.empty(lib._lpm_vlad_smx_stats_bytes(B, T) // 4, dtype=torch.float32, device=x.device)
+            with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+                lib.check(lib._lpm_vlad_aggregate_raw_kmajor_smx_fwd(ptr(assign), ptr(scale), ptr(shift), ptr(xt), ptr(centres), B, T, D, K,
+                                                                     flags & (LPM_VLAD_RESIDUAL | LPM_VLAD_SOFTMAX), ptr(raw), ptr(asum),
+                                                                     ptr(part), ptr(stats), st), "lpm_vlad_aggregate_raw_kmajor_smx_fwd")
+            rs = _empty((B, K), x)
+            gsq = _empty((B,), x)
+            with _timed("vlad_finalize", (B, D, K)):
+                lib.check(lib._lpm_vlad_row_scales(ptr(part), P, B, K, ptr(rs), ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_row_scales")
+            raw._lpm_row_scale = rs
+            return raw, raw, asum, colsq, csq, gsq, xt
         at = torch.empty(lib._lpm_at_bytes(B, T, K) // 4, dtype=torch.int32, device=x.device)
         with _timed("assign_tiles", (B, T, K)):
             lib.check(lib._lpm_assign_tiles(ptr(assign), ptr(scale), ptr(shift), B, T, K, flags, ptr(at), st), "lpm_assign_tiles")

@@ -502,6 +502,55 @@ def test_factored_clip_adam_matches_oracle(R, N1, N2, gscale):
     assert all(clipped) == (gscale * (R * N1 * N2) ** 0.5 > 1.0)
 
 
+@pytest.mark.parametrize("B,T,D,K,bn", [(5, 300, 1024, 256, True), (3, 47, 256, 128, True), (2, 64, 128, 512, False), (80, 300, 1024, 256, True)])
+def test_softmax_inside_the_aggregation_kernel_is_bitwise_the_two_kernel_chain(B, T, D, K, bn):
+    """lpm_vlad_aggregate_raw_kmajor_smx_fwd (row statistics + ONE kernel: logits -> softmax -> residual sums, no assignment tiles)
+    against lpm_assign_tiles + lpm_vlad_aggregate_raw_kmajor_fwd on the same logits: the same assignment bits enter the same MFMAs in
+    the same order, so the un-normalised sums, the assignment sums and the partial norms must be IDENTICAL; and the chain itself
+    against the fp64 oracle."""
+    from learnablepoolingmethods_amd import _capi, ops
+    from learnablepoolingmethods_amd.ops import ptr, stream_ptr
+    dev = cuda()
+    lib = _capi.load()
+    assert lib._lpm_vlad_smx_supported(T, D, K)
+    g = torch.Generator().manual_seed(B * T + K)
+    x = torch.randn(B * T, D, generator=g)
+    x = x / x.norm(dim=1, keepdim=True)
+    logits = (torch.randn(B * T, K, generator=g) * 3).to(dev)
+    scale = (1 + 0.3 * torch.randn(K, generator=g)).to(dev) if bn else None
+    shift = (0.2 * torch.randn(K, generator=g)).to(dev)
+    centres = (0.05 * torch.randn(D, K, generator=g)).to(dev)
+    xd = x.to(dev)
+    xt = torch.empty(lib._lpm_xt_bytes(B, T, D) // 4, dtype=torch.int32, device=dev)
+    lib.check(lib._lpm_split_frames(ptr(xd), D, B, T, D, ptr(xt), stream_ptr()), "lpm_split_frames")
+    flags = ops.LPM_VLAD_SOFTMAX | ops.LPM_VLAD_RESIDUAL
+    P = D // 128
+    out = {}
+    for fused in (False, True):
+        raw = torch.full((B, K, D), float("nan"), device=dev)
+        asum, part = torch.empty(B, K, device=dev), torch.empty(B, P, K, device=dev)
+        if fused:
+            stats = torch.empty(lib._lpm_vlad_smx_stats_bytes(B, T) // 4, dtype=torch.float32, device=dev)
+            lib.check(lib._lpm_vlad_aggregate_raw_kmajor_smx_fwd(ptr(logits), ptr(scale), ptr(shift), ptr(xt), ptr(centres), B, T, D, K, flags,
+                                                                 ptr(raw), ptr(asum), ptr(part), ptr(stats), stream_ptr()), "smx")
+        else:
+            at = torch.empty(lib._lpm_at_bytes(B, T, K) // 4, dtype=torch.int32, device=dev)
+            lib.check(lib._lpm_assign_tiles(ptr(logits), ptr(scale), ptr(shift), B, T, K, flags, ptr(at), stream_ptr()), "lpm_assign_tiles")
+            lib.check(lib._lpm_vlad_aggregate_raw_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, ops.LPM_VLAD_RESIDUAL, ptr(raw),
+                                                             ptr(asum), ptr(part), stream_ptr()), "raw_kmajor")
+        torch.cuda.synchronize()
+        out[fused] = (raw, asum, part)
+    for a, b, what in zip(out[True], out[False], ("un-normalised sums", "assignment sums", "partial norms")):
+        assert torch.isfinite(a).all(), what
+        assert torch.equal(a, b), f"{what}: fused softmax differs from the two-kernel chain (max abs {float((a - b).abs().max()):.3e})"
+    # and against fp64: softmax(logits * scale + shift), U[b, k, d] = sum_t a x - (sum_t a) centres
+    z = logits.double().cpu() * (scale.double().cpu() if bn else 1.0) + shift.double().cpu()
+    a = torch.softmax(z, dim=1).reshape(B, T, K)
+    U = torch.einsum("btk,btd->bkd", a, x.double().reshape(B, T, D)) - a.sum(1).unsqueeze(2) * centres.double().cpu().t().unsqueeze(0)
+    assert_close(out[True][0], U, tol=2e-5, what="fused-softmax un-normalised sums")
+    assert_close(out[True][1], a.sum(1), tol=2e-5, what="fused-softmax assignment sums")
+
+
 def test_capi_rejects_bad_shapes_loudly():
     from learnablepoolingmethods_amd import _capi, ops
     dev = cuda()

@@ -568,11 +568,12 @@ def test_lazily_normalised_descriptor_does_not_change_the_step():
     B, MF = 16, 40
     x, nf, lab = O.make_synthetic_batch(B, MF, 1152, 50, seed=31, min_frames=10)
     res = []
-    for lazy in (True, False, True):
-        FLAGS.netvlad_lazy_descriptor = lazy
+    for lazy in (True, False, True, "softmax inside K2"):
+        FLAGS.netvlad_lazy_descriptor = bool(lazy)
+        ops.VLAD_SOFTMAX_FUSED = lazy == "softmax inside K2"
         try:
             tr = Trainer(registry.get_model("NetVladV1"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=19,
-                         model_kwargs=dict(iterations=32, cluster_size=256, hidden_size=64))
+                         model_kwargs=dict(iterations=48, cluster_size=256, hidden_size=64))      # (48 frames: >= 3 steps for the in-kernel softmax)
             tr.build(x, nf, lab)
             tr.store.summaries = {}
             loss = tr.step(x, nf, lab)["loss"].item()
@@ -581,7 +582,10 @@ def test_lazily_normalised_descriptor_does_not_change_the_step():
             res.append((loss, tr.arena.grad.clone(), tr.predict(x, nf).clone(), summ["vlad_video"].clone()))
         finally:
             FLAGS.reset()
+            ops.VLAD_SOFTMAX_FUSED = False
     assert res[0][0] == res[2][0] and torch.equal(res[0][1], res[2][1]), "the lazy path is bitwise repeatable"
+    # ... and with the softmax inside the aggregation kernel (ops.VLAD_SOFTMAX_FUSED) the whole step is the same bits
+    assert res[0][0] == res[3][0] and torch.equal(res[0][1], res[3][1]) and torch.equal(res[0][2], res[3][2]), "softmax inside K2"
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0])
     assert rel_l2(res[0][1], res[1][1]) < 2e-5
     assert rel_l2(res[0][2], res[1][2]) < 2e-5
