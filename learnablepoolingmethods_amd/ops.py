@@ -38,7 +38,7 @@ PROJ_STREAM = os.environ.get("LPM_PROJ_STREAM", "1") != "0"
 # cfg-2, 764 vs 1233 us at cfg-5; dx 267 vs 211 us at cfg-2's N = 512 -- the library stays there --, 1108 vs 1232 us at cfg-5's N = 1024)
 PROJ_DX_STREAM_MIN_N = int(os.environ.get("LPM_PROJ_DX_STREAM_MIN_N", "1024"))
 # a5 with the softmax inside the aggregation kernel (lpm_vlad_aggregate_raw_kmajor_smx_fwd; the lazily normalised k-major descriptor
-# of the NetVladV1 video stream): no assignment tiles, chain traffic ~1.17x algorithmic instead of 1.4x -- and bit for bit the
+# of the NetVladV1 video stream): no assignment tiles, chain traffic 1.30x algorithmic instead of 1.41x (PMC, profiles/pmc_r02_smx) -- and bit for bit the
 # two-kernel chain's result.  Off by default, it is slower: measured at cfg-2 in the training step (kernel durations) row statistics
 # 8.7 us + aggregation 76.4 us + row scales 5.4 us = 90.5 us against 11.8 + 61.5 + 5.0 = 79 us for lpm_assign_tiles +
 # lpm_vlad_aggregate_raw_kmajor_fwd.  The aggregation loop is bound by LDS bandwidth next to the L2 -> LDS delivery (48 KB of

@@ -1,8 +1,9 @@
 # PMC passes over the a5 chain + K1 at cfg-2's video shape (tools/run_k2_only.py): one counter group per rocprofv3 run, nothing
 # but --pmc beside it.  Writes gpurun_out/pmc_r02/<group>.csv (kernel, grid, counter, value: no truncation) and summary.txt.
-# usage: bash tools/pmc_a5.sh <commit>
+# usage: bash tools/pmc_a5.sh <commit> [<output directory under gpurun_out, default pmc_r02>]     (LPM_VLAD_SOFTMAX_FUSED=1 in the environment:
+# the chain with the softmax inside the aggregation kernel)
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/pmc_r02
+OUT=$R/gpurun_out/${2:-pmc_r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "commit ${1:-unknown}; target: python3 tools/run_k2_only.py 6 (B=80 T=300 D=1024 K=256, training-mode forward of the production chain: K1, assign_tiles2, K2 raw k-major, row scales)" > $OUT/summary.txt
@@ -19,9 +20,9 @@ with open(sys.argv[2], "w") as f:
     f.write("kernel,grid,counter,value\n")
     for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(",", ";")[-70:]
-        if any(p in k for p in ("assign_tiles", "vlad_aggregate", "vlad_finalize", "vlad_row_scales", "tile_gemm", "split_")):
+        if any(p in k for p in ("assign_tiles", "softmax_stats", "vlad_aggregate", "vlad_finalize", "vlad_row_scales", "tile_gemm", "split_")):
             f.write(f"{k},{r['Grid_Size']},{r['Counter_Name']},{r['Counter_Value']}\n")
 PY
-  python3 $R/tools/pmc_summary.py $F assign_tiles vlad_aggregate_tiles3 vlad_finalize2 vlad_row_scales tile_gemm_kernel >> $OUT/summary.txt
+  python3 $R/tools/pmc_summary.py $F assign_tiles softmax_stats vlad_aggregate_tiles3 vlad_finalize2 vlad_row_scales tile_gemm_kernel >> $OUT/summary.txt
 done
 cat $OUT/summary.txt
