@@ -513,6 +513,12 @@ size_t lpm_factored_clip_adam_scratch_bytes(int N1, int N2);
 int lpm_factored_clip_adam(const void* xt, const void* dyt, int R, int N1, int N2, float* param, float* m, float* v,
                            float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
                            size_t scratch_bytes, lpm_stream_t stream);
+/* ... with the norm from quadratic forms instead of a first tile-GEMM pass: ||X^T DY||^2 = sum over columns n1 of x_n1^T G x_n1,
+ * G = DY DY^T [R, R] computed by the caller (fp32) and handed over as gdt = lpm_split_rows_tiles(G, R, 1, R, R); x = the fp32 matrix
+ * [R, N1] (row stride ldx) that xt was split from.  2 R^2 N1 flops for the norm instead of 2 R N1 N2.  R <= 128. */
+int lpm_factored_clip_adam_q(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
+                             float* param, float* m, float* v, float clip_norm, float lr, float beta1, float beta2, float eps,
+                             int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,8 @@ PROJ_STREAM = os.environ.get("LPM_PROJ_STREAM", "1") != "0"
 # ... the input-gradient kernel from this hidden size on (measured, rocprofv3 kernel durations: forward 174 + 21 us vs the library's 219 us at
 # cfg-2, 764 vs 1233 us at cfg-5; dx 267 vs 211 us at cfg-2's N = 512 -- the library stays there --, 1108 vs 1232 us at cfg-5's N = 1024)
 PROJ_DX_STREAM_MIN_N = int(os.environ.get("LPM_PROJ_DX_STREAM_MIN_N", "1024"))
+# K5 of hidden1_weights: the gradient's norm from quadratic forms (lpm_factored_clip_adam_q) instead of a tile-GEMM pass; "0": A/B
+FACTORED_NORM_QUADFORM = os.environ.get("LPM_FACTORED_NORM_QUADFORM", "1") != "0"
 # a5 with the softmax inside the aggregation kernel (lpm_vlad_aggregate_raw_kmajor_smx_fwd; the lazily normalised k-major descriptor
 # of the NetVladV1 video stream): no assignment tiles, chain traffic 1.30x algorithmic instead of 1.41x (PMC, profiles/pmc_r02_smx) -- and bit for bit the
 # two-kernel chain's result.  Off by default, it is slower: measured at cfg-2 in the training step (kernel durations) row statistics
@@ -1749,6 +1751,7 @@ class FactoredGradient:
 
     def clear(self):
         self.xt = self.dyt = None
+        self.x = self.dy = None           # the fp32 factors themselves (this rank's; None once tiles of several towers were gathered)
         self.R = self.N1 = self.N2 = 0
         self.puts = 0
 
@@ -1768,6 +1771,7 @@ class FactoredGradient:
         lib.check(lib._lpm_split_weight_tiles(ptr(x), R, N1, 0, ptr(xt), st), "lpm_split_weight_tiles")
         lib.check(lib._lpm_split_weight_tiles(ptr(dy.contiguous()), R, N2, 0, ptr(dyt), st), "lpm_split_weight_tiles")
         self.xt, self.dyt, self.R, self.N1, self.N2 = xt, dyt, R, N1, N2
+        self.x, self.dy = x, dy
         self.puts += 1
         if self.on_put is not None:
             self.on_put(self)
@@ -1787,9 +1791,20 @@ class FactoredGradient:
         if scratch is None or scratch.numel() * 4 < nb:
             scratch = torch.empty(nb // 4, dtype=torch.float32, device=param.device)
         with _timed("factored_clip_adam", (self.R, self.N1, self.N2)):
-            lib.check(lib._lpm_factored_clip_adam(ptr(self.xt), ptr(self.dyt), self.R, self.N1, self.N2, ptr(param), ptr(m), ptr(v),
-                                                  float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch), nb,
-                                                  stream_ptr()), "lpm_factored_clip_adam")
+            quad = (FACTORED_NORM_QUADFORM and self.x is not None and self.x.shape[0] == self.R and self.R <= 128 and self.x.stride(1) == 1
+                    and self.x.dtype == torch.float32)
+            if quad:
+                # the norm from the quadratic forms x_n1^T (DY DY^T) x_n1 (lpm_factored_clip_adam_q): no first GEMM pass over R x N1 x N2
+                G = torch.mm(self.dy, self.dy.t())      # [R, R] fp32 (its entries then enter the MFMAs as bf16 hi + lo: 2^-17 relative)
+                gdt = _tile_buffer(lib._lpm_row_tiles_bytes(1, self.R, self.R), G)
+                lib.check(lib._lpm_split_rows_tiles(ptr(G), self.R, 1, self.R, self.R, ptr(gdt), stream_ptr()), "lpm_split_rows_tiles")
+                lib.check(lib._lpm_factored_clip_adam_q(ptr(self.xt), ptr(self.dyt), ptr(self.x), self.x.stride(0), ptr(gdt), self.R, self.N1,
+                                                        self.N2, ptr(param), ptr(m), ptr(v), float(clip_norm), float(lr), beta1, beta2, eps,
+                                                        int(step), ptr(scratch), nb, stream_ptr()), "lpm_factored_clip_adam_q")
+            else:
+                lib.check(lib._lpm_factored_clip_adam(ptr(self.xt), ptr(self.dyt), self.R, self.N1, self.N2, ptr(param), ptr(m), ptr(v),
+                                                      float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch), nb,
+                                                      stream_ptr()), "lpm_factored_clip_adam")
         return scratch
 
 

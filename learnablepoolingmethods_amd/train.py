@@ -491,6 +491,7 @@ class Trainer:
         _note("all_gather of the hidden projection's tiles: complete")
         fg = self.factored
         fg.xt, fg.dyt, fg.R = self._factored_all[:3]
+        fg.x = fg.dy = None                  # the fp32 factors of the other towers are not here: the norm comes from the GEMM pass
         self._factored_work, self._factored_all = [], None
 
     # -- checkpoint / resume (train.py:501-515,593: Supervisor-saved variables + Adam slots + global_step) ------------------

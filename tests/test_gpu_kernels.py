@@ -487,6 +487,17 @@ def test_factored_clip_adam_matches_oracle(R, N1, N2, gscale):
             fg.put(x.to(dev), dy.to(dev))
         gref = x.double().t() @ dy.double()
         assert_close(fg.materialise(), gref, tol=2e-5, what="materialised factors")
+        if R != 160:
+            # the norm by both routes: a first tile-GEMM pass, and the quadratic forms x_n1^T (DY DY^T) x_n1 (lpm_factored_clip_adam_q)
+            norms = []
+            for quad in (False, True):
+                ops.FACTORED_NORM_QUADFORM = quad
+                Pc, Mc, Vc = P.clone(), M.clone(), V.clone()
+                sc = fg.clip_adam(Pc.view(-1), Mc.view(-1), Vc.view(-1), 1.0, 2e-4, step)
+                torch.cuda.synchronize()
+                norms.append(float(sc[-3]))
+            ops.FACTORED_NORM_QUADFORM = True
+            assert abs(norms[0] - norms[1]) <= 2e-6 * norms[0], f"norm by GEMM pass {norms[0]} vs by quadratic forms {norms[1]}"
         scratch = fg.clip_adam(P.view(-1), M.view(-1), V.view(-1), 1.0, 2e-4, step)
         torch.cuda.synchronize()
         factor, norm = float(scratch[-4]), float(scratch[-3])
