@@ -87,37 +87,76 @@ __device__ __forceinline__ float4 vb_ld4(const float* p, int64_t i4, int bf16) {
                        __uint_as_float(q.y & 0xffff0000u));
 }
 
-// dots[b][split][0..2][k]: <dO_k,N_k>, <dO_k,W2_k>, <N_k,W2_k> over the split's rows of D
+// dots[b][split][0..2][k]: <dO_k,N_k>, <dO_k,W2_k>, <N_k,W2_k> over the split's rows of D.
+// Threads are (row group, 4 consecutive clusters): a row of K clusters is K / 4 16-byte loads per array (8-byte for bf16 N), 256 / (K / 4)
+// row groups walk the split's rows side by side with four rows' loads issued together, and meet through LDS in a fixed order.  (One
+// thread per cluster with one 4-byte load per array in flight: 202 us for the 400 MB of cfg-5's video stream, 2 TB/s.)
 __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __restrict__ dO,
                                                                const float* __restrict__ N,
                                                                const float* __restrict__ W2, int D, int K,
                                                                float* __restrict__ dots, const float* __restrict__ colsq_raw, int n_bf16) {
     // colsq_raw != NULL (LPM_VLAD_NRM_RAW): N holds the un-normalised sums U and N = U * rsqrt(max(colsq, eps)) per column --
     // the product vlad_finalize2 would have stored
-    const int b = blockIdx.x, sp = blockIdx.y;
+    __shared__ float4 red[3][256];
+    const int b = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
     // split sp takes rows sp, sp + VB_DSPLIT, ...: the splits of a clip read VB_DSPLIT consecutive rows at a time (contiguous
     // quarter-ranges put every workgroup of the grid at the same offset of a 64 KB-aligned range: HBM channel aliasing)
-    const float* pdo = dO + ((int64_t)b * D + sp) * K;
-    const int64_t pn0 = ((int64_t)b * D + sp) * K;
-    const float* pw = W2 ? W2 + (int64_t)sp * K : nullptr;
-    const int64_t rs = (int64_t)VB_DSPLIT * K;
+    const int K4 = K >> 2;
+    const int RG = (K4 < 256 && 256 % K4 == 0) ? 256 / K4 : 1;
+    const int rg = RG > 1 ? tid / K4 : 0;
     const int dper = D / VB_DSPLIT;
     float* out = dots + ((int64_t)b * VB_DSPLIT + sp) * 3 * K;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        float p = 0.f, dw = 0.f, nw = 0.f;
-        const float iv = colsq_raw ? rsqrtf(fmaxf(colsq_raw[(int64_t)b * K + k], kL2Eps)) : 1.f;
-#pragma unroll 4
-        for (int d = 0; d < dper; ++d) {
-            const float nv = vb_ld(N, pn0 + d * rs + k, n_bf16);
-            const float a = pdo[d * rs + k], n = colsq_raw ? nv * iv : nv;
-            const float w = pw ? pw[d * rs + k] : 0.f;
-            p = fmaf(a, n, p);
-            dw = fmaf(a, w, dw);
-            nw = fmaf(n, w, nw);
+    for (int c4 = RG > 1 ? tid % K4 : tid; c4 < K4; c4 += (RG > 1 ? K4 : 256)) {        // RG > 1: exactly one pass, every thread in it
+        float4 iv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (colsq_raw) {
+            const float4 cq = *reinterpret_cast<const float4*>(colsq_raw + (int64_t)b * K + 4 * c4);
+            iv = make_float4(rsqrtf(fmaxf(cq.x, kL2Eps)), rsqrtf(fmaxf(cq.y, kL2Eps)), rsqrtf(fmaxf(cq.z, kL2Eps)), rsqrtf(fmaxf(cq.w, kL2Eps)));
         }
-        out[k] = p;
-        out[K + k] = dw;
-        out[2 * K + k] = nw;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), dw = p, nw = p;
+        auto add = [&](const float4 a, float4 n, const float4 w) {
+            n.x *= iv.x; n.y *= iv.y; n.z *= iv.z; n.w *= iv.w;
+            p.x = fmaf(a.x, n.x, p.x); p.y = fmaf(a.y, n.y, p.y); p.z = fmaf(a.z, n.z, p.z); p.w = fmaf(a.w, n.w, p.w);
+            dw.x = fmaf(a.x, w.x, dw.x); dw.y = fmaf(a.y, w.y, dw.y); dw.z = fmaf(a.z, w.z, dw.z); dw.w = fmaf(a.w, w.w, dw.w);
+            nw.x = fmaf(n.x, w.x, nw.x); nw.y = fmaf(n.y, w.y, nw.y); nw.z = fmaf(n.z, w.z, nw.z); nw.w = fmaf(n.w, w.w, nw.w);
+        };
+        // row d of the split = row sp + d * VB_DSPLIT of the clip; in units of float4: ((b * D + sp + d * VB_DSPLIT) * K4 + c4)
+        const int64_t base4 = ((int64_t)b * D + sp) * K4 + c4;
+        const int64_t rs4 = (int64_t)VB_DSPLIT * K4;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        int d = rg;
+        for (; d + 3 * RG < dper; d += 4 * RG) {
+            float4 a[4], n[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i4 = base4 + (int64_t)(d + u * RG) * rs4;
+                a[u] = reinterpret_cast<const float4*>(dO)[i4];
+                n[u] = vb_ld4(N, i4, n_bf16);
+                w[u] = W2 ? reinterpret_cast<const float4*>(W2)[(int64_t)(sp + (d + u * RG) * VB_DSPLIT) * K4 + c4] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(a[u], n[u], w[u]);
+        }
+        for (; d < dper; d += RG) {
+            const int64_t i4 = base4 + (int64_t)d * rs4;
+            add(reinterpret_cast<const float4*>(dO)[i4], vb_ld4(N, i4, n_bf16),
+                W2 ? reinterpret_cast<const float4*>(W2)[(int64_t)(sp + d * VB_DSPLIT) * K4 + c4] : zero);
+        }
+        if (RG > 1) {
+            red[0][tid] = p; red[1][tid] = dw; red[2][tid] = nw;
+            __syncthreads();
+            if (rg == 0)
+                for (int i = 1; i < RG; ++i) {
+                    const float4 x0 = red[0][i * K4 + c4], x1 = red[1][i * K4 + c4], x2 = red[2][i * K4 + c4];
+                    p.x += x0.x; p.y += x0.y; p.z += x0.z; p.w += x0.w;
+                    dw.x += x1.x; dw.y += x1.y; dw.z += x1.z; dw.w += x1.w;
+                    nw.x += x2.x; nw.y += x2.y; nw.z += x2.z; nw.w += x2.w;
+                }
+        }
+        if (rg == 0) {
+            *reinterpret_cast<float4*>(out + 4 * c4) = p;
+            *reinterpret_cast<float4*>(out + K + 4 * c4) = dw;
+            *reinterpret_cast<float4*>(out + 2 * K + 4 * c4) = nw;
+        }
     }
 }
 
@@ -383,6 +422,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
     const int k = (int)((i * 4) % K);
     const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
     for (int b = b0; b < b1; ++b) {
         const float4 a = reinterpret_cast<const float4*>(dO + (int64_t)b * D * K)[i];
         float4 n = vb_ld4(N, (int64_t)b * n4 + i, n_bf16);
@@ -451,15 +491,18 @@ constexpr int VB_DU_NT = 512;
 __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float* __restrict__ dO, const float* __restrict__ N,
                                                                 const float* __restrict__ ug, const float* __restrict__ vg,
                                                                 int D, int K, uint4* __restrict__ ub1, uint4* __restrict__ ub2,
-                                                                const float* __restrict__ colsq, float* __restrict__ g0, int raw, int planes) {
+                                                                const float* __restrict__ colsq, float* __restrict__ g0, int raw, int planes,
+                                                                int rw) {
     // raw (LPM_VLAD_NRM_RAW): N holds the un-normalised sums U; N = U * rsqrt(max(colsq, eps)), and g0's U is read as it is
-    extern __shared__ float dus[];           // [32][K+1], then u[K], v[K], rn[K] (, then prod [32][K+1] when g0)
+    // rw: rows of D per workgroup -- 32, or 16 when only the d-reduction tiles are wanted (ub2 == NULL): half the LDS, so that two
+    // workgroups share a CU at K = 512 as well (cfg-5: 137 KB -> 69 KB with the g0 products)
+    extern __shared__ float dus[];           // [rw][K+1], then u[K], v[K], rn[K] (, then prod [rw][K+1] when g0)
     const int KS = K + 1;
-    float* cu = dus + 32 * KS;
+    float* cu = dus + rw * KS;
     float* cv = cu + K;
     float* rn = cv + K;                      // g0 && !raw: norm of the un-normalised column, U = N * rn;  raw: its inverse
     float* prod = rn + K;                    // g0 only: dU * U
-    const int tid = threadIdx.x, b = blockIdx.y, d0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, b = blockIdx.y, d0 = blockIdx.x * rw;
     for (int k = tid; k < K; k += VB_DU_NT) {
         cu[k] = ug[(int64_t)b * K + k];
         cv[k] = vg[(int64_t)b * K + k];
@@ -471,7 +514,7 @@ __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float
     const float* ob = dO + ((int64_t)b * D + d0) * K;
     const int64_t nb4 = ((int64_t)b * D + d0) * K4;
     const int n_bf16 = planes == 1;          // bf16 storage: N holds the sums as bf16
-    for (int i = tid; i < 32 * K4; i += VB_DU_NT) {
+    for (int i = tid; i < rw * K4; i += VB_DU_NT) {
         const int r = i / K4, k = (i % K4) * 4;
         const float4 a = *reinterpret_cast<const float4*>(ob + (int64_t)r * K + k);
         float4 n = vb_ld4(N, nb4 + (int64_t)r * K4 + k / 4, n_bf16);
@@ -497,7 +540,7 @@ __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float
         // g0[b][d] = sum_k dU[d,k] U[d,k]: the only thing the input batch norm's gamma gradient needs from this clip when the
         // frames themselves need no gradient (see ops._NetVLAD.backward); fixed summation order (lane-strided, then the wave tree)
         const int lane = tid & 63, wave = tid >> 6;
-        constexpr int RPW = 32 / (VB_DU_NT / 64);       // rows per wave
+        const int RPW = rw / (VB_DU_NT / 64);           // rows per wave
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
             float acc = 0.f;
@@ -507,7 +550,7 @@ __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float
         }
     }
     const int KT = K / 32, DS = D / 16, KS16 = K / 16, DT = D / 32;
-    for (int it = tid; it < 2 * KT * 64; it += VB_DU_NT) {            // reduction over d, columns k
+    for (int it = tid; it < (rw / 16) * KT * 64; it += VB_DU_NT) {    // reduction over d, columns k
         const int lane = it & 63, kt = (it >> 6) % KT, dsl = (it >> 6) / KT;
         const int k = kt * 32 + (lane & 31), dl = dsl * 16 + 8 * (lane >> 5);
         float v[8];
@@ -524,6 +567,7 @@ __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float
         ub1[base + 64] = lo;
     }
     if (ub2 == nullptr) return;                                  // no input gradient wanted: the dx GEMM's operand is not needed
+    // (rw == 32 here: a tile of this form is 32 rows of D)
     for (int it = tid; it < KS16 * 64; it += VB_DU_NT) {              // reduction over k, columns d
         const int lane = it & 63, ks = it >> 6;
         const int dl = lane & 31, k = ks * 16 + 8 * (lane >> 5);
@@ -862,15 +906,16 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
                        colsq_raw, planes == 1 ? 1 : 0);
     hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil, VB_DSPLIT);
     {
-        const size_t lds = (size_t)(32 * (K + 1) + 3 * K + (g0 ? 32 * (K + 1) : 0)) * sizeof(float);
+        const int rw = (g0 && K >= 512) ? 16 : 32;          // only the d-reduction tiles: 16-row workgroups keep two per CU at K = 512
+        const size_t lds = (size_t)(rw * (K + 1) + 3 * K + (g0 ? rw * (K + 1) : 0)) * sizeof(float);
         auto kern = vlad_bwd_du_tiles_kernel;
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             set_error("lpm_vlad_aggregate_bwd_tiles: cannot reserve %zu bytes of LDS", lds);
             return LPM_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(VB_DU_NT), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0,
-                           raw ? 1 : 0, planes);
+        hipLaunchKernelGGL(kern, dim3(D / rw, B), dim3(VB_DU_NT), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0,
+                           raw ? 1 : 0, planes, rw);
     }
     }
     if (!g0) {       // the assignment's row tiles are the A operand of the dx GEMM only
