@@ -463,6 +463,58 @@ static int dcentres_splits(int B, int D, int K) {
     return z < 1 ? 1 : z;
 }
 // part: room for dcentres_splits(B, D, K) x [D, K] floats, or null (then one pass straight into dW2)
+// In-place second half of dA -> dlogit~ when the GEMM ran with the plain store epilogue (K > 256): row (b, t) of `dl` holds dA; one
+// wave per row:  g = dA - ctil[b];  softmax: dl = a (g - sum_j a_j g_j) with a = softmax(logits * scale + shift) recomputed;
+// otherwise dl = g.  The arithmetic of tile_gemm's fused epilogue, KPL = K / 64 values per lane.
+template <int KPL>
+__global__ __launch_bounds__(256) void vlad_softmax_bwd_rows_kernel(float* __restrict__ dl, const float* __restrict__ logits, int logits_bf16,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    const float* __restrict__ ctil, int T, int64_t rows, int softmax) {
+    constexpr int K = 64 * KPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = (int)(row / T);
+    float* out = dl + row * K;
+    const float* ct = ctil + (int64_t)b * K;
+    float a[KPL], gg[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) gg[j] = out[lane + 64 * j] - ct[lane + 64 * j];
+    if (!softmax) {
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) out[lane + 64 * j] = gg[j];
+        return;
+    }
+    const float* lr = logits + row * K;
+    const unsigned short* lrb = reinterpret_cast<const unsigned short*>(logits) + row * K;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int c = lane + 64 * j;
+        const float lv = logits_bf16 ? __uint_as_float((unsigned)lrb[c] << 16) : lr[c];
+        a[j] = fmaf(lv, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
+        mx = fmaxf(mx, a[j]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        a[j] = __expf(a[j] - mx);
+        sum += a[j];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        a[j] *= inv;
+        dot = fmaf(a[j], gg[j], dot);
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) out[lane + 64 * j] = a[j] * (gg[j] - dot);
+}
+
 static void launch_dcentres(const float* dO, const float* N, const float* asum, const float* u, const float* v, int B, int D, int K,
                             float* part, float* dW2, hipStream_t s, const float* colsq_raw = nullptr, int n_bf16 = 0) {
     const int64_t n4 = (int64_t)D * K / 4;
@@ -938,7 +990,22 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
     g.rb_per_batch = L.MT / 2; g.steps_per_split = DS; g.total_steps = DS;
     g.out = dassign; g.rows_valid = T; g.cols_valid = K;
     g.logits = assign; g.logits_bf16 = planes == 1 ? 1 : 0; g.scale = scale; g.shift = shift; g.ctil = ctil; g.softmax = sm ? 1 : 0;
-    const int rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles", planes);
+    // K = 512 (cfg-5's video stream): the fused epilogue needs all K columns of a row in one workgroup -- 64 x 512 tiles, 131 KB of
+    // LDS, one workgroup per CU: 367 us.  Two launches instead: the GEMM on 64 x 256 tiles with the plain store (two per CU), then the
+    // row-wise softmax backward in place (LPM_DA_SPLIT=0: the fused form, A/B)
+    static const int da_split = [] { const char* e = getenv("LPM_DA_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
+    int rc;
+    if (da_split && K == 512) {
+        g.ldo = K; g.out_batch = (int64_t)T * K; g.out_split = 0; g.accumulate = 0;
+        rc = tile_gemm_store(g, B, 1, s, "lpm_vlad_aggregate_bwd_tiles", 2, planes);
+        if (rc == LPM_OK) {
+            const int64_t rows = (int64_t)B * T;
+            hipLaunchKernelGGL(vlad_softmax_bwd_rows_kernel<8>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dassign, assign,
+                               planes == 1 ? 1 : 0, scale, shift, ctil, T, rows, sm ? 1 : 0);
+        }
+    } else {
+        rc = tile_gemm_softmax_bwd(g, B, s, "lpm_vlad_aggregate_bwd_tiles", planes);
+    }
     if (rc != LPM_OK) return rc;
     if ((residual || g0) && rk) {
         // k-major form: partial sums over clip ranges [z][K][D] -> fixed-order reduce -> [K, D] -> transpose into dcentres [D, K]
