@@ -208,6 +208,10 @@ int lpm_vlad_aggregate_tiles3_fwd(const void* at, const void* xt, const float* c
                                   int flags, float* nrm, float* asum, float* colsq_part, lpm_stream_t stream);
 int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out,
                            float* colsq, float* csq, float* gsq, lpm_stream_t stream);
+/* ... with the clips' descriptors out_batch_stride elements apart in `out` (>= D * K, a multiple of 4; fp32, d-major or the scalar
+ * k-major form): a column slot of the streams' joined [B, total] buffer -- tf.concat(..., 1) at frame_level_models.py:2309 without a copy */
+int lpm_vlad_finalize2_fwd_ld(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out,
+                              int64_t out_batch_stride, float* colsq, float* csq, float* gsq, lpm_stream_t stream);
 
 /* K2 for a consumer that applies the normalisation itself (the NetVladV1 cluster encoders, App. C5: tokens = clusters):
  * lpm_vlad_aggregate_raw_kmajor_fwd stores the UN-normalised residual sums k-major [B, K, D] -- once, straight from the accumulators
@@ -330,6 +334,13 @@ int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm, const floa
                                  const float* shift, const void* xr, const float* centres, int B, int T, int D, int K,
                                  int flags, float* dassign, float* dcentres, float* g0, void* workspace, size_t workspace_bytes,
                                  lpm_stream_t stream);
+/* ... with the clips' gradients dout_batch_stride elements apart (>= D * K, a multiple of 4; d-major only): a column slice of the
+ * gradient of the joined descriptors, read in place */
+int lpm_vlad_aggregate_bwd_tiles_ld(const float* dout, int64_t dout_batch_stride, const float* nrm, const float* asum,
+                                    const float* colsq, const float* csq, const float* gsq, const float* assign, const float* scale,
+                                    const float* shift, const void* xr, const float* centres, int B, int T, int D, int K, int flags,
+                                    float* dassign, float* dcentres, float* g0, void* workspace, size_t workspace_bytes,
+                                    lpm_stream_t stream);
 /* input_bn's gradients in the "no input gradient" mode (frames x = gamma xhat + beta straight out of input_bn,
  * frame_level_models.py:2265-2277, columns [0, D) of one stream), from lpm_vlad_aggregate_bwd_tiles' g0 [B, D] and dcentres [D, K],
  * the soft-assignment GEMM's W [D, K] and weight gradient dW [D, K], centres [D, K] (NULL without a residual term) and

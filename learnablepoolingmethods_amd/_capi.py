@@ -67,6 +67,7 @@ SIGNATURES = {
     "lpm_vlad_aggregate_tiles_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_vlad_tiles3_supported": (_i, [_i, _i]),
     "lpm_vlad_aggregate_tiles3_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "lpm_vlad_finalize2_fwd_ld": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _l, _f, _f, _f, _f]),
     "lpm_vlad_finalize2_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_proj_supported": (_i, [_i, _l, _i]),
     "lpm_proj_fwd_workspace_bytes": (_s, [_i, _l, _i]),
@@ -96,6 +97,7 @@ SIGNATURES = {
     "lpm_vlad_aggregate_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _l, _f, _i, _i, _i, _i, _i, _f, _f, _l,
                                     _i, _f, _f, _s, _f]),
     "lpm_vlad_bwd_tiles_workspace_bytes": (_s, [_i, _i, _i, _i]),
+    "lpm_vlad_aggregate_bwd_tiles_ld": (_i, [_f, _l, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _s, _f]),
     "lpm_vlad_aggregate_bwd_tiles": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _s, _f]),
     "lpm_input_bn_grads": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f]),
     "lpm_vlad_aggregate_bwd_tiles_dx": (_i, [_f, _s, _f, _f, _i, _i, _i, _i, _f, _l, _i, _f]),

@@ -94,9 +94,10 @@ __device__ __forceinline__ float4 vb_ld4(const float* p, int64_t i4, int bf16) {
 __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __restrict__ dO,
                                                                const float* __restrict__ N,
                                                                const float* __restrict__ W2, int D, int K,
-                                                               float* __restrict__ dots, const float* __restrict__ colsq_raw, int n_bf16) {
+                                                               float* __restrict__ dots, const float* __restrict__ colsq_raw, int n_bf16,
+                                                               int64_t dob) {
     // colsq_raw != NULL (LPM_VLAD_NRM_RAW): N holds the un-normalised sums U and N = U * rsqrt(max(colsq, eps)) per column --
-    // the product vlad_finalize2 would have stored
+    // the product vlad_finalize2 would have stored.  dob: distance between the clips' gradients in dO, in elements (>= D * K)
     __shared__ float4 red[3][256];
     const int b = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
     // split sp takes rows sp, sp + VB_DSPLIT, ...: the splits of a clip read VB_DSPLIT consecutive rows at a time (contiguous
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __re
             nw.x = fmaf(n.x, w.x, nw.x); nw.y = fmaf(n.y, w.y, nw.y); nw.z = fmaf(n.z, w.z, nw.z); nw.w = fmaf(n.w, w.w, nw.w);
         };
         // row d of the split = row sp + d * VB_DSPLIT of the clip; in units of float4: ((b * D + sp + d * VB_DSPLIT) * K4 + c4)
-        const int64_t base4 = ((int64_t)b * D + sp) * K4 + c4;
+        const int64_t base4 = ((int64_t)b * D + sp) * K4 + c4;              // N (contiguous clips)
+        const int64_t obase4 = (int64_t)b * (dob >> 2) + (int64_t)sp * K4 + c4;  // dO
         const int64_t rs4 = (int64_t)VB_DSPLIT * K4;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         int d = rg;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __re
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t i4 = base4 + (int64_t)(d + u * RG) * rs4;
-                a[u] = reinterpret_cast<const float4*>(dO)[i4];
+                a[u] = reinterpret_cast<const float4*>(dO)[obase4 + (int64_t)(d + u * RG) * rs4];
                 n[u] = vb_ld4(N, i4, n_bf16);
                 w[u] = W2 ? reinterpret_cast<const float4*>(W2)[(int64_t)(sp + (d + u * RG) * VB_DSPLIT) * K4 + c4] : zero;
             }
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_coldots_kernel(const float* __re
         }
         for (; d < dper; d += RG) {
             const int64_t i4 = base4 + (int64_t)d * rs4;
-            add(reinterpret_cast<const float4*>(dO)[i4], vb_ld4(N, i4, n_bf16),
+            add(reinterpret_cast<const float4*>(dO)[obase4 + (int64_t)d * rs4], vb_ld4(N, i4, n_bf16),
                 W2 ? reinterpret_cast<const float4*>(W2)[(int64_t)(sp + d * VB_DSPLIT) * K4 + c4] : zero);
         }
         if (RG > 1) {
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
                                                                 const float* __restrict__ u,
                                                                 const float* __restrict__ v, int B, int D, int K,
                                                                 int bper, float* __restrict__ dW2,
-                                                                const float* __restrict__ colsq_raw, int n_bf16) {
+                                                                const float* __restrict__ colsq_raw, int n_bf16, int64_t dob) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index into [D,K]
     const int64_t n4 = (int64_t)D * K / 4;
     if (i >= n4) return;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_dcentres_kernel(const float* __r
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int b = b0; b < b1; ++b) {
-        const float4 a = reinterpret_cast<const float4*>(dO + (int64_t)b * D * K)[i];
+        const float4 a = reinterpret_cast<const float4*>(dO + (int64_t)b * dob)[i];
         float4 n = vb_ld4(N, (int64_t)b * n4 + i, n_bf16);
         if (colsq_raw) {                   // N = U * rsqrt(max(colsq, eps)): see vlad_bwd_coldots_kernel
             const float4 c = *reinterpret_cast<const float4*>(colsq_raw + (int64_t)b * K + k);
@@ -516,17 +518,18 @@ __global__ __launch_bounds__(256) void vlad_softmax_bwd_rows_kernel(float* __res
 }
 
 static void launch_dcentres(const float* dO, const float* N, const float* asum, const float* u, const float* v, int B, int D, int K,
-                            float* part, float* dW2, hipStream_t s, const float* colsq_raw = nullptr, int n_bf16 = 0) {
+                            float* part, float* dW2, hipStream_t s, const float* colsq_raw = nullptr, int n_bf16 = 0, int64_t dob = 0) {
+    if (dob == 0) dob = (int64_t)D * K;
     const int64_t n4 = (int64_t)D * K / 4;
     const unsigned wgx = (unsigned)((n4 + 255) / 256);
     const int Z = part ? dcentres_splits(B, D, K) : 1;
     if (Z == 1) {
-        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, B, dW2, colsq_raw, n_bf16);
+        hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, B, dW2, colsq_raw, n_bf16, dob);
         return;
     }
     const int bper = (B + Z - 1) / Z, Zeff = (B + bper - 1) / bper;
     hipLaunchKernelGGL(vlad_bwd_dcentres_kernel, dim3(wgx, (unsigned)Zeff), dim3(256), 0, s, dO, N, asum, u, v, B, D, K, bper, part,
-                       colsq_raw, n_bf16);
+                       colsq_raw, n_bf16, dob);
     hipLaunchKernelGGL(vlad_bwd_dcentres_reduce_kernel, dim3(wgx), dim3(256), 0, s, (const float4*)part, Zeff, n4, (float4*)dW2);
 }
 
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float
                                                                 const float* __restrict__ ug, const float* __restrict__ vg,
                                                                 int D, int K, uint4* __restrict__ ub1, uint4* __restrict__ ub2,
                                                                 const float* __restrict__ colsq, float* __restrict__ g0, int raw, int planes,
-                                                                int rw) {
+                                                                int rw, int64_t dob) {
     // raw (LPM_VLAD_NRM_RAW): N holds the un-normalised sums U; N = U * rsqrt(max(colsq, eps)), and g0's U is read as it is
     // rw: rows of D per workgroup -- 32, or 16 when only the d-reduction tiles are wanted (ub2 == NULL): half the LDS, so that two
     // workgroups share a CU at K = 512 as well (cfg-5: 137 KB -> 69 KB with the g0 products)
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(VB_DU_NT) void vlad_bwd_du_tiles_kernel(const float
     }
     __syncthreads();
     const int K4 = K / 4;
-    const float* ob = dO + ((int64_t)b * D + d0) * K;
+    const float* ob = dO + (int64_t)b * dob + (int64_t)d0 * K;
     const int64_t nb4 = ((int64_t)b * D + d0) * K4;
     const int n_bf16 = planes == 1;          // bf16 storage: N holds the sums as bf16
     for (int i = tid; i < rw * K4; i += VB_DU_NT) {
@@ -844,7 +847,7 @@ extern "C" int lpm_vlad_aggregate_bwd(const float* dout, const float* nrm, const
         dO = dod;
     }
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr,
-                       D, K, dots, (const float*)nullptr, 0);
+                       D, K, dots, (const float*)nullptr, 0, (int64_t)D * K);
     hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil, VB_DSPLIT);
     const int nts = (T + VB_TS - 1) / VB_TS;
     const size_t lds = bwd_main_lds_bytes(K);
@@ -897,11 +900,39 @@ static BwdTilesLayout bwd_tiles_layout(int B, int T, int D, int K) {
 
 extern "C" size_t lpm_vlad_bwd_tiles_workspace_bytes(int B, int T, int D, int K) { return lpm::bwd_tiles_layout(B, T, D, K).total; }
 
+static int vlad_aggregate_bwd_tiles_impl(const float* dout, int64_t dob, const float* nrm, const float* asum, const float* colsq,
+                                         const float* csq, const float* gsq, const float* assign, const float* scale,
+                                         const float* shift, const void* xr, const float* centres, int B, int T, int D,
+                                         int K, int flags, float* dassign, float* dcentres, float* g0, void* workspace,
+                                         size_t workspace_bytes, lpm_stream_t stream);
 extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm, const float* asum, const float* colsq,
                                             const float* csq, const float* gsq, const float* assign, const float* scale,
                                             const float* shift, const void* xr, const float* centres, int B, int T, int D,
                                             int K, int flags, float* dassign, float* dcentres, float* g0, void* workspace,
                                             size_t workspace_bytes, lpm_stream_t stream) {
+    return vlad_aggregate_bwd_tiles_impl(dout, (int64_t)D * K, nrm, asum, colsq, csq, gsq, assign, scale, shift, xr, centres, B, T, D, K, flags,
+                                         dassign, dcentres, g0, workspace, workspace_bytes, stream);
+}
+// ... with the clips' gradients dout_batch_stride elements apart (>= D * K, a multiple of 4): dout is a column slice of the gradient
+// of the concatenated descriptors (ops.DescriptorSlots), read in place.  d-major gradients only (no LPM_VLAD_OUT_KMAJOR / RAW_KMAJOR).
+extern "C" int lpm_vlad_aggregate_bwd_tiles_ld(const float* dout, int64_t dout_batch_stride, const float* nrm, const float* asum,
+                                               const float* colsq, const float* csq, const float* gsq, const float* assign,
+                                               const float* scale, const float* shift, const void* xr, const float* centres, int B, int T,
+                                               int D, int K, int flags, float* dassign, float* dcentres, float* g0, void* workspace,
+                                               size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dout_batch_stride >= (int64_t)D * K && dout_batch_stride % 4 == 0, LPM_ERR_BADARG,
+                "lpm_vlad_aggregate_bwd_tiles_ld: the batch stride must be >= D * K and a multiple of 4");
+    LPM_REQUIRE(dout_batch_stride == (int64_t)D * K || !(flags & (LPM_VLAD_OUT_KMAJOR | LPM_VLAD_RAW_KMAJOR)), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_aggregate_bwd_tiles_ld: a strided gradient is read in the d-major layout only");
+    return vlad_aggregate_bwd_tiles_impl(dout, dout_batch_stride, nrm, asum, colsq, csq, gsq, assign, scale, shift, xr, centres, B, T, D, K,
+                                         flags, dassign, dcentres, g0, workspace, workspace_bytes, stream);
+}
+static int vlad_aggregate_bwd_tiles_impl(const float* dout, int64_t dob, const float* nrm, const float* asum, const float* colsq,
+                                         const float* csq, const float* gsq, const float* assign, const float* scale,
+                                         const float* shift, const void* xr, const float* centres, int B, int T, int D,
+                                         int K, int flags, float* dassign, float* dcentres, float* g0, void* workspace,
+                                         size_t workspace_bytes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(dout && nrm && asum && colsq && csq && gsq && assign && xr && dassign && workspace, LPM_ERR_BADARG,
                 "lpm_vlad_aggregate_bwd_tiles: null pointer");
@@ -955,7 +986,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
         hipLaunchKernelGGL(kern, dim3(D / 32, B), dim3(512), lds, s, dO, nrm, u, v, colsq, D, K, ub1, g0);
     } else {
     hipLaunchKernelGGL(vlad_bwd_coldots_kernel, dim3(B, VB_DSPLIT), dim3(256), 0, s, dO, nrm, residual ? centres : nullptr, D, K, dots,
-                       colsq_raw, planes == 1 ? 1 : 0);
+                       colsq_raw, planes == 1 ? 1 : 0, dob);
     hipLaunchKernelGGL(vlad_bwd_coeff_kernel, dim3(B), dim3(256), 0, s, dots, colsq, csq, gsq, K, u, v, ctil, VB_DSPLIT);
     {
         const int rw = (g0 && K >= 512) ? 16 : 32;          // only the d-reduction tiles: 16-row workgroups keep two per CU at K = 512
@@ -967,7 +998,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
             return LPM_ERR_LAUNCH;
         }
         hipLaunchKernelGGL(kern, dim3(D / rw, B), dim3(VB_DU_NT), lds, s, dO, nrm, u, v, D, K, ub1, g0 ? (uint4*)nullptr : ub2, colsq, g0,
-                           raw ? 1 : 0, planes, rw);
+                           raw ? 1 : 0, planes, rw, dob);
     }
     }
     if (!g0) {       // the assignment's row tiles are the A operand of the dx GEMM only
@@ -1019,7 +1050,7 @@ extern "C" int lpm_vlad_aggregate_bwd_tiles(const float* dout, const float* nrm,
         hipLaunchKernelGGL(vlad_bwd_dcentres_reduce_kernel, dim3(wgx), dim3(256), 0, s, (const float4*)part, Zeff, n4, (float4*)tmp);
         launch_kmajor_to_dmajor(tmp, 1, D, K, dcentres, s);
     } else if (residual || g0) {        // dcentres = - sum_b asum_b dU_b: the centres' gradient, and (g0) the input batch norm's beta term
-        launch_dcentres(dO, nrm, asum, u, v, B, D, K, (float*)(ws + L.dcp), dcentres, s, colsq_raw, planes == 1 ? 1 : 0);
+        launch_dcentres(dO, nrm, asum, u, v, B, D, K, (float*)(ws + L.dcp), dcentres, s, colsq_raw, planes == 1 ? 1 : 0, dob);
     }
     return check_launch("lpm_vlad_aggregate_bwd_tiles");
 }

@@ -603,9 +603,10 @@ template <bool KMAJOR>
 __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__ nrm, const float* __restrict__ colsq_part,
                                                              int P, int D, int K, float* __restrict__ out,
                                                              float* __restrict__ colsq, float* __restrict__ csq,
-                                                             float* __restrict__ gsq, int keep_u, int out_bf16, int nrm_bf16) {
+                                                             float* __restrict__ gsq, int keep_u, int out_bf16, int nrm_bf16,
+                                                             int64_t out_bs) {
     // keep_u (LPM_VLAD_NRM_RAW): nrm is left as the un-normalised sums U (the tile backward rebuilds N = U * inv_n itself)
-    // out_bf16 (d-major only): `out` is bf16 storage
+    // out_bf16 (d-major only): `out` is bf16 storage;  out_bs: distance between the clips' descriptors in `out`, in elements
     extern __shared__ float fs[];            // [K] inv_n, then [32][33] transpose tile, [4] partial sums
     float* invn = fs;
     float* tile = fs + K;
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
     if (blockIdx.x == 0 && tid == 0) gsq[b] = tot;
     float* src = nrm + ((int64_t)b * D + d0) * K;
     if (!KMAJOR) {
-        float* dst = out + ((int64_t)b * D + d0) * K;
+        float* dst = out + (int64_t)b * out_bs + (int64_t)d0 * K;
         const int n4 = 32 * K / 4, K4 = K / 4;
         for (int i = tid; i < n4; i += 256) {
             const int k = (i % K4) * 4;
@@ -649,14 +650,14 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kernel(float* __restrict__
             v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
             if (out_bf16) {
                 auto rne = [](float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
-                reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + ((int64_t)b * D + d0) * K)[i] =
+                reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + (int64_t)b * out_bs + (int64_t)d0 * K)[i] =
                     make_uint2(rne(v.x) | (rne(v.y) << 16), rne(v.z) | (rne(v.w) << 16));
             } else {
                 reinterpret_cast<float4*>(dst)[i] = v;
             }
         }
     } else {
-        float* dst = out + (int64_t)b * K * D;
+        float* dst = out + (int64_t)b * out_bs;
         const int tx = tid & 31, ty = tid >> 5;
         for (int kb = 0; kb < K; kb += 32) {
 #pragma unroll
@@ -973,8 +974,25 @@ extern "C" int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, cons
     return check_launch("lpm_vlad_aggregate_fused_fwd");
 }
 
+static int vlad_finalize2_impl(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out, int64_t out_bs,
+                               float* colsq, float* csq, float* gsq, lpm_stream_t stream);
 extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out,
                                       float* colsq, float* csq, float* gsq, lpm_stream_t stream) {
+    return vlad_finalize2_impl(nrm, colsq_part, P, B, D, K, flags, out, (int64_t)D * K, colsq, csq, gsq, stream);
+}
+// ... with the clips' descriptors out_batch_stride elements apart in `out` (>= D * K, a multiple of 4): a column slot of a wider
+// [B, total] buffer (ops.DescriptorSlots) -- the concatenation of the streams' descriptors (frame_level_models.py:2309) without a copy
+extern "C" int lpm_vlad_finalize2_fwd_ld(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out,
+                                         int64_t out_batch_stride, float* colsq, float* csq, float* gsq, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(out_batch_stride >= (int64_t)D * K && out_batch_stride % 4 == 0, LPM_ERR_BADARG,
+                "lpm_vlad_finalize2_fwd_ld: the batch stride must be >= D * K and a multiple of 4");
+    LPM_REQUIRE(out_batch_stride == (int64_t)D * K || !(flags & LPM_VLAD_OUT_KMAJOR) || K > 512, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_vlad_finalize2_fwd_ld: the 16-byte k-major form writes contiguous descriptors only");
+    return vlad_finalize2_impl(nrm, colsq_part, P, B, D, K, flags, out, out_batch_stride, colsq, csq, gsq, stream);
+}
+static int vlad_finalize2_impl(float* nrm, const float* colsq_part, int P, int B, int D, int K, int flags, float* out, int64_t out_bs,
+                               float* colsq, float* csq, float* gsq, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(nrm && colsq_part && out && colsq && csq && gsq, LPM_ERR_BADARG, "lpm_vlad_finalize2_fwd: null pointer");
     LPM_REQUIRE(B > 0 && P > 0 && D % 32 == 0 && K % 4 == 0 && K <= 4096, LPM_ERR_UNSUPPORTED_SHAPE,
@@ -1010,15 +1028,15 @@ extern "C" int lpm_vlad_finalize2_fwd(float* nrm, const float* colsq_part, int P
     }
     if (flags & LPM_VLAD_OUT_KMAJOR)
         hipLaunchKernelGGL(vlad_finalize2_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out, colsq,
-                           csq, gsq, keep_u, 0, 0);
+                           csq, gsq, keep_u, 0, 0, out_bs);
     else {
         hipEvent_t e0, e1;
         if (D >= 1024 && timing_request(LPM_TIMING_FINALIZE, &e0, &e1))
             hipExtLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, e0, e1, 0, nrm, colsq_part, P, D, K,
-                                  out, colsq, csq, gsq, keep_u, out_bf16, nrm_bf16);
+                                  out, colsq, csq, gsq, keep_u, out_bf16, nrm_bf16, out_bs);
         else
             hipLaunchKernelGGL(vlad_finalize2_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, nrm, colsq_part, P, D, K, out,
-                               colsq, csq, gsq, keep_u, out_bf16, nrm_bf16);
+                               colsq, csq, gsq, keep_u, out_bf16, nrm_bf16, out_bs);
     }
     return check_launch("lpm_vlad_finalize2_fwd");
 }

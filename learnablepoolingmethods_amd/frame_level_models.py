@@ -28,7 +28,7 @@ class NetVLAD():
         self.add_batch_norm = add_batch_norm
         self.cluster_size = int(cluster_size)
 
-    def forward(self, reshaped_input, kmajor=False, input_affine=None, storage="f32", lazy=False):
+    def forward(self, reshaped_input, kmajor=False, input_affine=None, storage="f32", lazy=False, out_slot=None):
         """input_affine: (gamma, beta) slices of input_bn when reshaped_input is its (gradient-free) output, see ops.netvlad.
         lazy: hand the k-major descriptor over lazily normalised (ops.netvlad) -- for a consumer that applies the row scale."""
         D, K, dev = self.feature_size, self.cluster_size, reshaped_input.device
@@ -45,7 +45,8 @@ class NetVLAD():
                                                device=dev)                                                           # :2805-2808
         # matmul -> cluster_bn -> softmax -> a^T x - sum(a) W2 -> l2norm(D) -> flatten -> l2norm  (:2781-2822)
         return ops.netvlad(reshaped_input, cluster_weights, cluster_weights2, self.max_frames, bn=bn, bias=bias,
-                           is_training=self.is_training, kmajor=kmajor, input_affine=input_affine, storage=storage, lazy=lazy)
+                           is_training=self.is_training, kmajor=kmajor, input_affine=input_affine, storage=storage, lazy=lazy,
+                           out_slot=out_slot)
 
 
 class LightVLAD(NetVLAD):
@@ -190,17 +191,24 @@ class NetVladV1(models.BaseModel):
         lazy_v = bool(encoder and FLAGS.netvlad_lazy_descriptor and storage == "f32" and reshaped_input.is_cuda
                       and (aff_v is not None or not torch.is_grad_enabled())
                       and video_encoder_block.fused_shape(batch, cluster_size, True) and ops.netvlad_lazy_ok(max_frames, 1024, cluster_size))
+        slots = None
+        if (storage == "bf16" and not encoder and has_audio and FLAGS.descriptor_slots and aff_v is not None):
+            # bf16 storage without the cluster encoders (BASELINE configs[4]): the projection behind the pooling computes in fp32, so the
+            # two normalised descriptors leave their finalize passes as fp32 straight into ONE [B, 1024 K + 128 K/4] buffer -- no bf16
+            # copy of the descriptor, no concat, no casts of it or of its gradient
+            slots = ops.DescriptorSlots(batch, [(1, 1024 * cluster_size), (1, 128 * (cluster_size // 4))], reshaped_input)
         with vs.variable_scope("video_VLAD"):
-            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v, storage=storage, lazy=lazy_v)   # :2273-2274
+            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v, storage=storage, lazy=lazy_v,
+                                               out_slot=slots.slots[0] if slots else None)               # :2273-2274
             if vs.default_store().summaries is not None:
                 # [B, K, D] (the App. C5 token view) when the encoders follow, else [B, D*K]
                 vs.summary("vlad_video", ops.materialise(vlad_video))
         if has_audio:
             with side, vs.variable_scope("audio_VLAD"):
-                vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder, input_affine=aff_a, storage=storage) # :2276-2277
+                vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder, input_affine=aff_a, storage=storage,
+                                                   out_slot=slots.slots[1] if slots else None)           # :2276-2277
                 vs.summary("vlad_audio", vlad_audio)
 
-        slots = None
         if encoder:
             # tokens = clusters (App. C5): the pooling kernel already wrote the [B, K, D] view
             if has_audio:

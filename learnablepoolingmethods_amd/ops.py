@@ -566,7 +566,7 @@ class _NetVLAD(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, gamma, beta, moving_mean, moving_var, bias, W2, T, is_training, kmajor, in_gamma=None, in_beta=None,
-                storage="f32", lazy=False):
+                storage="f32", lazy=False, out_slot=None):
         """in_gamma / in_beta ([D] slices of input_bn's gamma / beta): x is input_bn's output for these columns and needs no
         gradient of its own -- the backward then returns input_bn's gamma / beta gradients in closed form instead of dx."""
         lib = _capi.load()
@@ -581,9 +581,11 @@ class _NetVLAD(torch.autograd.Function):
         ctx.lazy = bool(lazy)
         if lazy and storage != "f32":
             raise LpmError("netvlad: the lazily normalised descriptor is an fp32-storage form")
+        if out_slot is not None and storage != "bf16":
+            raise LpmError("netvlad: an output slot is taken by the bf16-storage form only")
         if storage == "bf16":
             return _NetVLAD._forward_bf16(ctx, lib, x, W, gamma, beta, moving_mean, moving_var, bias, W2, B, T, D, K, is_training, kmajor,
-                                          in_gamma, in_beta)
+                                          in_gamma, in_beta, out_slot)
         if storage != "f32":
             raise LpmError(f"unknown storage {storage!r} (f32 | bf16)")
         _materialised(x, "reshaped_input")
@@ -647,7 +649,8 @@ class _NetVLAD(torch.autograd.Function):
         return out
 
     @staticmethod
-    def _forward_bf16(ctx, lib, x, W, gamma, beta, moving_mean, moving_var, bias, W2, B, T, D, K, is_training, kmajor, in_gamma, in_beta):
+    def _forward_bf16(ctx, lib, x, W, gamma, beta, moving_mean, moving_var, bias, W2, B, T, D, K, is_training, kmajor, in_gamma, in_beta,
+                      out_slot=None):
         """bf16 storage (BASELINE cfg-5; include/lpm_hip.h "bf16 storage"): frames, logits / assignment and the descriptor are bf16
         in HBM, every product one bf16 MFMA with fp32 accumulation; statistics, norms and gradients fp32.  Needs the operand tiles
         ops.frame_sample_bn(storage="bf16") wrote for x, the LDS-shared K2 form (D, K multiples of 128, K <= 512), the d-major
@@ -696,12 +699,22 @@ class _NetVLAD(torch.autograd.Function):
         with _timed("vlad_aggregate_fwd", (B, T, D, K)):
             lib.check(lib._lpm_vlad_aggregate_tiles3_fwd_bf16(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
                                                               ptr(part), st), "lpm_vlad_aggregate_tiles3_fwd_bf16")
-        out = torch.empty((B, D * K), dtype=torch.bfloat16, device=W.device)
         gsq = _empty((B,), W)
-        with _timed("vlad_finalize", (B, D, K)):
-            lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K, LPM_VLAD_NRM_RAW | _capi.LPM_VLAD_OUT_BF16 | _capi.LPM_VLAD_NRM_BF16,
-                                                  ptr(out),
-                                                  ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_finalize2_fwd")
+        if out_slot is not None:
+            # the consumer (the hidden projection) computes in fp32: the normalised descriptor leaves the finalize pass as fp32 straight
+            # into its column slot of the streams' joined buffer -- no bf16 copy, no concat, no casts in either direction
+            out = out_slot.view()                    # [B, 1, D * K], clips out_slot.base.shape[1] elements apart
+            if tuple(out.shape) != (B, 1, D * K) or out.dtype != torch.float32:
+                raise LpmError("netvlad: the output slot does not match [B, 1, D * K] fp32")
+            with _timed("vlad_finalize", (B, D, K)):
+                lib.check(lib._lpm_vlad_finalize2_fwd_ld(ptr(nrm), ptr(part), P, B, D, K, LPM_VLAD_NRM_RAW | _capi.LPM_VLAD_NRM_BF16, ptr(out),
+                                                         out.stride(0), ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_finalize2_fwd_ld")
+        else:
+            out = torch.empty((B, D * K), dtype=torch.bfloat16, device=W.device)
+            with _timed("vlad_finalize", (B, D, K)):
+                lib.check(lib._lpm_vlad_finalize2_fwd(ptr(nrm), ptr(part), P, B, D, K,
+                                                      LPM_VLAD_NRM_RAW | _capi.LPM_VLAD_OUT_BF16 | _capi.LPM_VLAD_NRM_BF16, ptr(out),
+                                                      ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_finalize2_fwd")
         ctx.nrm_raw = True
         ctx.dims = (B, T, D, K, flags, False, use_bn, is_training, W2 is not None, True)
         ctx.no_dx = True
@@ -716,7 +729,14 @@ class _NetVLAD(torch.autograd.Function):
         B, T, D, K, flags, kmajor, use_bn, is_training, has_w2, _ = ctx.dims
         x, W, logits, scale, shift, mean, var, gamma, centres, nrm, asum, colsq, csq, gsq, xt, xr, in_gamma, in_beta = ctx.saved_tensors
         M = B * T
-        dout = dout.float().contiguous()           # the gradient of a bf16 tensor arrives as bf16; everything below is fp32
+        # the gradient of a bf16 descriptor arrives as bf16; of a slot (fp32) as a column slice of the joined buffer's gradient, which
+        # K3 reads in place (clips dout.stride(0) elements apart)
+        if dout.dtype == torch.float32 and dout.dim() == 3 and dout.shape[1] == 1 and dout.stride(2) == 1 and dout.stride(0) % 4 == 0 \
+                and dout.stride(0) >= D * K and dout.data_ptr() % 16 == 0:
+            dob = dout.stride(0)
+        else:
+            dout = dout.float().contiguous()
+            dob = D * K
         dlt = _empty((M, K), W)
         dcentres = _empty((D, K), W)
         g0 = _empty((B, D), W)
@@ -724,9 +744,9 @@ class _NetVLAD(torch.autograd.Function):
         ws = _tile_buffer(wsb, W)
         fl = flags | LPM_VLAD_NRM_RAW | _capi.LPM_VLAD_TILES_BF16
         with _timed("vlad_aggregate_bwd", (B, T, D, K)):
-            lib.check(lib._lpm_vlad_aggregate_bwd_tiles(ptr(dout), ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(logits),
-                                                        ptr(scale), ptr(shift), ptr(xr), ptr(centres), B, T, D, K, fl, ptr(dlt),
-                                                        ptr(dcentres), ptr(g0), ptr(ws), wsb, st), "lpm_vlad_aggregate_bwd_tiles")
+            lib.check(lib._lpm_vlad_aggregate_bwd_tiles_ld(ptr(dout), dob, ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(logits),
+                                                           ptr(scale), ptr(shift), ptr(xr), ptr(centres), B, T, D, K, fl, ptr(dlt),
+                                                           ptr(dcentres), ptr(g0), ptr(ws), wsb, st), "lpm_vlad_aggregate_bwd_tiles_ld")
         dgamma = dbeta = dbias = None
         if use_bn and is_training:
             lf = logits.float()
@@ -759,7 +779,7 @@ class _NetVLAD(torch.autograd.Function):
                                               ptr(in_gamma.contiguous()), ptr(in_beta.contiguous()), B, D, K, ptr(d_in_gamma),
                                               ptr(d_in_beta), st), "lpm_input_bn_grads")
         dW2 = dcentres.reshape(1, D, K) if has_w2 else None
-        return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None, None
+        return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None, None, None
 
     @staticmethod
     def backward(ctx, dout):
@@ -822,7 +842,7 @@ class _NetVLAD(torch.autograd.Function):
                                               ptr(in_gamma.contiguous()), ptr(in_beta.contiguous()), B, D, K, ptr(d_in_gamma),
                                               ptr(d_in_beta), stream_ptr()), "lpm_input_bn_grads")
             dW2 = dcentres.reshape(1, D, K) if has_w2 else None
-            return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None, None
+            return None, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, d_in_gamma, d_in_beta, None, None, None
         if k3_tiles:
             dx = _aggregate_bwd_tiles_dx(lib, wspace, dlr, wtt, x, B, T, D, K, out=_dx_slot_view(ctx.dx_slot, D))
             if not tiles:
@@ -833,7 +853,7 @@ class _NetVLAD(torch.autograd.Function):
         else:
             dx.addmm_(dl, W.t())
         dW2 = dcentres.reshape(1, D, K) if has_w2 else None
-        return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, None, None, None, None
+        return dx, dW, dgamma, dbeta, None, None, dbias, dW2, None, None, None, None, None, None, None, None
 
 
 class _Materialise(torch.autograd.Function):
@@ -869,10 +889,11 @@ def netvlad_lazy_ok(T, D, K):
 
 
 def netvlad(x, cluster_weights, cluster_weights2, max_frames, bn=None, bias=None, is_training=True, kmajor=False,
-            input_affine=None, storage="f32", lazy=False):
+            input_affine=None, storage="f32", lazy=False, out_slot=None):
     """bn = (gamma, beta, moving_mean, moving_var) or None (then ``bias`` = cluster_biases).  input_affine = (gamma, beta) slices
     of the input batch norm whose output x is (x itself then needs no gradient): see _NetVLAD.forward.  storage="bf16": the
-    descriptor comes back as bf16 [B, D*K] (see _NetVLAD._forward_bf16).
+    descriptor comes back as bf16 [B, D*K] (see _NetVLAD._forward_bf16) -- or, with out_slot (an ops.OutputSlot of L = 1, F = D*K), as
+    fp32 written straight into that column slot of the streams' joined buffer (ops.DescriptorSlots), returned as the slot's view.
     lazy (with kmajor; netvlad_lazy_ok shapes; frames without a gradient): the result is the LAZILY NORMALISED descriptor -- the
     un-normalised residual sums [B, K, D], written once by the aggregation kernel, carrying ``_lpm_row_scale`` [B, K] =
     1 / (n_k sqrt(g)); descriptor = result * scale per (clip, cluster) row (frame_level_models.py:2819-2822).  Consumers that know
@@ -882,7 +903,7 @@ def netvlad(x, cluster_weights, cluster_weights2, max_frames, bn=None, bias=None
     g, b, mm, mv = bn if bn is not None else (None, None, None, None)
     ig, ib = input_affine if input_affine is not None else (None, None)
     return _NetVLAD.apply(x, cluster_weights, g, b, mm, mv, bias, cluster_weights2, int(max_frames), bool(is_training),
-                          bool(kmajor), ig, ib, storage, bool(lazy))
+                          bool(kmajor), ig, ib, storage, bool(lazy), out_slot)
 
 
 def netvlad_input_shortcut_ok(T, D, K):
