@@ -17,6 +17,7 @@ def main(path, out=None):
     lines = [f"# rocprofv3 --kernel-trace summary of {path}", "", f"total kernel time {total/1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches", "",
              "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
     for n, c, s, a, mn, mx in rows[:60]:
+        n = n.replace("(anonymous namespace)::", "")           # (otherwise at::native::(anonymous namespace)::X is cut at its first parenthesis)
         n = re.sub(r"\(.*", "", n)
         n = n.replace("void ", "")[:110]
         lines.append(f"| `{n}` | {c} | {s/1e6:.3f} | {a/1e3:.1f} | {mn/1e3:.1f} | {mx/1e3:.1f} | {100*s/total:.1f} |")
