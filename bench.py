@@ -41,6 +41,14 @@ WORKLOADS = {
                           "8 GPUs), full training step",
                  dtype_detail="fp32 storage and accumulation everywhere; K1, K2, K3, K4 and the encoder dense GEMMs feed the bf16 MFMA "
                               "pipe with split-bf16 (hi+lo) operands, 3 MFMAs per product (~5e-6 relative error)"),
+    "cfg3": dict(metric="clips/sec training step, NetVladV2 (attention-based cluster similarities) K=256 300-frame 1152-d, bs=80 (BASELINE configs[2])",
+                 model="NetVladV2", model_kwargs=dict(iterations=300, cluster_size=256, hidden_size=512),     # hidden: README.md:17
+                 oracle=dict(iterations=300, cluster_size=256, hidden_size=512), flags={}, batch=80, elt=4, dtype="f32", parity_tol=1e-3,
+                 dropout=True,      # the reference trains the frame encoders with dropout rate 0.9 (transformer_utils.py:450)
+                 workload="NetVladV2 K=256 hidden=512 rgb+audio 1152-d 300 frames, bs 80 on one GPU (BASELINE configs[2]), full training "
+                          "step with the reference's dropout on",
+                 dtype_detail="fp32 storage and accumulation everywhere; K2, K3, K4 and the encoder dense GEMMs feed the bf16 MFMA pipe with "
+                              "split-bf16 (hi+lo) operands, 3 MFMAs per product; the logits_bn attention forward in exact-fp32 MFMA"),
     "cfg5": dict(metric="clips/sec training step, gated NetVLAD K=512 + MoE-4, 300-frame 1152-d bf16, bs=128 per GPU (BASELINE configs[4])",
                  model_kwargs=dict(iterations=300, cluster_size=512, hidden_size=1024, encoder=False),
                  oracle=dict(iterations=300, cluster_size=512, hidden_size=1024, encoder=False, moe_num_mixtures=4),
@@ -82,21 +90,26 @@ def k2_algorithmic_bytes(B, T, D, K, elt=4):
 def cpu_baseline(budget_s, wl):
     """The oracle's train_step (fp32, torch CPU) on a bounded sample of the same workload."""
     from oracle import lpm_oracle as O
-    cfg = O.OracleConfig(model="NetVladV1", **wl["oracle"], **TRAIN)
+    cfg = O.OracleConfig(model=wl.get("model", "NetVladV1"), **wl["oracle"], **TRAIN)
     b = 4
     torch.set_flush_denormal(True)   # as TF's CPU kernels do; g*g underflows to denormals in Adam otherwise (100x slower)
     x, nf, lab = O.make_synthetic_batch(b, MAX_FRAMES, FEATURE, VOCAB, seed=0)
     p = O.init_params(cfg, FEATURE, seed=1000)
+    masks = None
+    if wl.get("dropout"):            # NetVladV2: keep masks (rate 0.9) drawn here and handed to both sides of the parity check
+        g = torch.Generator().manual_seed(5)
+        masks = {"video": (torch.rand(b, MAX_FRAMES, 1024, generator=g) >= 0.9).float(),
+                 "audio": (torch.rand(b, MAX_FRAMES, FEATURE - 1024, generator=g) >= 0.9).float()}
     st = {"step": 0, "m": {}, "v": {}}
     t0 = time.perf_counter()
     p0 = p
-    p, st, info0 = O.train_step(p, st, x, nf, lab, cfg, 1)        # warm-up (page-in, thread pools); also the parity sample
+    p, st, info0 = O.train_step(p, st, x, nf, lab, cfg, 1, dropout_masks=masks)   # warm-up (page-in, thread pools); also the parity sample
     warm = time.perf_counter() - t0
-    first = {"x": x, "nf": nf, "lab": lab, "params": p0, "loss": info0["loss"], "predictions": info0["predictions"]}
+    first = {"x": x, "nf": nf, "lab": lab, "params": p0, "loss": info0["loss"], "predictions": info0["predictions"], "masks": masks}
     times = []
     while len(times) < 5 and (sum(times) + warm) < budget_s:
         t0 = time.perf_counter()
-        p, st, _ = O.train_step(p, st, x, nf, lab, cfg, 1)
+        p, st, _ = O.train_step(p, st, x, nf, lab, cfg, 1, dropout_masks=masks)
         times.append(time.perf_counter() - t0)
     if not times:
         times = [warm]
@@ -115,11 +128,12 @@ def parity_check(first, device, wl):
     from learnablepoolingmethods_amd.train import Trainer
     b = first["x"].shape[0]
     tol = wl["parity_tol"]
-    tr = Trainer(registry.get_model("NetVladV1"), vocab_size=VOCAB, batch_size=b, device=device, seed=1, model_kwargs=wl["model_kwargs"],
-                 **TRAIN)
+    tr = Trainer(registry.get_model(wl.get("model", "NetVladV1")), vocab_size=VOCAB, batch_size=b, device=device, seed=1,
+                 model_kwargs=wl["model_kwargs"], **TRAIN)
     tr.build(first["x"], first["nf"], first["lab"])
     tr.store.load({"tower/" + k: v for k, v in first["params"].items()})
-    out = tr.step(first["x"], first["nf"], first["lab"])
+    kw = {} if first.get("masks") is None else {"dropout_masks": {k: v.to(device) for k, v in first["masks"].items()}}
+    out = tr.step(first["x"], first["nf"], first["lab"], **kw)
     torch.cuda.synchronize()
     pred, ref = out["predictions"].double().cpu(), first["predictions"].double()
     e_pred = float((pred - ref).abs().max() / ref.abs().max())
@@ -177,7 +191,8 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg2",
-                    help="cfg2 (default): the configuration BASELINE.json's metric is quoted on; cfg5: BASELINE configs[4] per GPU")
+                    help="cfg2 (default): the configuration BASELINE.json's metric is quoted on; cfg3: BASELINE configs[2] (NetVladV2); "
+                         "cfg5: BASELINE configs[4] per GPU")
     ap.add_argument("--watchdog-seconds", type=float, default=240.0,
                     help="N > 1 only: a rank that makes no progress for this long prints its phase and last collective and exits 3")
     args = ap.parse_args()
@@ -214,7 +229,7 @@ def main():
     wl = WORKLOADS[args.config]
     set_flags(wl)
     PER_GPU_BATCH = wl["batch"]
-    model = registry.get_model("NetVladV1")
+    model = registry.get_model(wl.get("model", "NetVladV1"))
     trainer = Trainer(model, vocab_size=VOCAB, batch_size=PER_GPU_BATCH, device=device, seed=1234, model_kwargs=wl["model_kwargs"], **TRAIN)
     raw, nf, labels = synthetic_batch(PER_GPU_BATCH, device, seed=rank)
 

@@ -59,3 +59,8 @@ def test_bench_line_round2_objects():
     assert r["algorithmic_bytes"] == 2 * (B * T * K + B * T * D + B * D * K) + 4 * D * K        # video part of 2.165 MB/clip, bf16
     assert abs(r["algorithmic_bytes"] / B / 1e6 - 1.99) < 0.02
     assert c["parity"]["ok"] is True and c["parity"]["tolerance"] == 2e-2
+    with open(os.path.join(ROOT, "profiles", "r02_bench_line_cfg3.json")) as f:
+        v2 = json.loads(f.read().strip().splitlines()[-1])
+    assert v2["dtype"] == "f32" and v2["config"]["global_batch"] == 80 and "configs[2]" in v2["metric"] and "NetVladV2" in v2["metric"]
+    assert abs(v2["value"] - 80 / (v2["ms_per_step"] * 1e-3)) < 0.01 * v2["value"]
+    assert v2["parity"]["ok"] is True and v2["parity"]["tolerance"] == 1e-3
