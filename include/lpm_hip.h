@@ -392,6 +392,13 @@ int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w3k, lpm_str
 size_t lpm_split_rows_relu_bwd_workspace_bytes(int64_t M, int K);
 int lpm_split_rows_relu_bwd(const float* df, int64_t M, int K, const void* act3, void* out3, float* dbias, void* workspace,
                             size_t workspace_bytes, lpm_stream_t stream);
+/* bias (+ ReLU) of a dense layer whose output does not go straight into the next GEMM's operand split (tf.layers.dense(use_bias=True,
+ * activation=relu) in front of a batch norm: transformer_utils.py:741-760).  forward: y <- act(y + bias) IN PLACE;  backward: dx = dy *
+ * [y > 0] with y the forward's output (dx may alias dy; without relu dx is not written), dbias = column sums of the masked gradient. */
+int lpm_bias_act_fwd(float* y, const float* bias, int relu, int64_t M, int C, lpm_stream_t stream);
+size_t lpm_bias_act_bwd_workspace_bytes(int64_t M, int C);
+int lpm_bias_act_bwd(const float* dy, const float* y, int relu, int64_t M, int C, float* dx, float* dbias, void* workspace,
+                     size_t workspace_bytes, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Residual add + tf.contrib.layers.layer_norm with TF1 defaults (transformer_utils.py:405-411,451-454,712-713):

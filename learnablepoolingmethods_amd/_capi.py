@@ -108,6 +108,9 @@ SIGNATURES = {
     "lpm_split_rows": (_i, [_f, _l, _l, _i, _f, _i, _i, _f, _f]),
     "lpm_split_weight": (_i, [_f, _i, _i, _f, _f, _f]),
     "lpm_split_rows_relu_bwd_workspace_bytes": (_s, [_l, _i]),
+    "lpm_bias_act_fwd": (_i, [_f, _f, _i, _l, _i, _f]),
+    "lpm_bias_act_bwd_workspace_bytes": (_s, [_l, _i]),
+    "lpm_bias_act_bwd": (_i, [_f, _f, _i, _l, _i, _f, _f, _f, _s, _f]),
     "lpm_split_rows_relu_bwd": (_i, [_f, _l, _i, _f, _f, _f, _f, _s, _f]),
     "lpm_layer_norm_workspace_bytes": (_s, [_i, _i]),
     "lpm_layer_norm_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _f, _f, _f, _s, _f]),

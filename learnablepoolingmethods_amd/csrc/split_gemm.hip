@@ -187,6 +187,56 @@ extern "C" int lpm_split_rows_scaled(const float* x, int64_t ldx, int64_t M, int
     return check_launch("lpm_split_rows_scaled");
 }
 
+namespace lpm {
+// ---- bias (+ ReLU) of a dense layer whose output goes to something other than the next GEMM's operand split (tf.layers.dense with
+// use_bias / activation=relu, e.g. FeedForwardNetworkMod's layers in front of their batch norms, transformer_utils.py:741-760) ----------
+// forward: y <- act(y + bias) in place, one pass;  backward: dx = dy * [y > 0] (ReLU; y is the saved OUTPUT) and per-32-row column
+// partial sums of dx for the bias gradient (then colsum_reduce_kernel), one pass -- instead of add + relu and threshold + reduce.
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ y, const float* __restrict__ bias, int relu, int64_t total4,
+                                                           int C4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const float4 b = reinterpret_cast<const float4*>(bias)[i % C4];
+        float4 v = reinterpret_cast<float4*>(y)[i];
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+// one workgroup = SR_ROWS rows, all columns (4 per thread and pass); dx may alias dy
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int relu, int64_t M, int C,
+                                                           float* __restrict__ dx, float* __restrict__ colpart) {
+    const int C4 = C / 4;
+    const int64_t r0 = (int64_t)blockIdx.x * SR_ROWS, r1 = min(M, r0 + SR_ROWS);
+    for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t m = r0;
+        for (; m + 3 < r1; m += 4) {                 // four rows' loads together
+            float4 g[4], a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = reinterpret_cast<const float4*>(dy + (m + u) * C)[c4];
+                a[u] = relu ? reinterpret_cast<const float4*>(y + (m + u) * C)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 d = make_float4(a[u].x > 0.f ? g[u].x : 0.f, a[u].y > 0.f ? g[u].y : 0.f, a[u].z > 0.f ? g[u].z : 0.f,
+                                             a[u].w > 0.f ? g[u].w : 0.f);
+                acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+                if (relu) reinterpret_cast<float4*>(dx + (m + u) * C)[c4] = d;
+            }
+        }
+        for (; m < r1; ++m) {
+            const float4 g = reinterpret_cast<const float4*>(dy + m * C)[c4];
+            const float4 a = relu ? reinterpret_cast<const float4*>(y + m * C)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 d = make_float4(a.x > 0.f ? g.x : 0.f, a.y > 0.f ? g.y : 0.f, a.z > 0.f ? g.z : 0.f, a.w > 0.f ? g.w : 0.f);
+            acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+            if (relu) reinterpret_cast<float4*>(dx + m * C)[c4] = d;
+        }
+        reinterpret_cast<float4*>(colpart + (int64_t)blockIdx.x * C)[c4] = acc;
+    }
+}
+}  // namespace lpm
+
 extern "C" size_t lpm_split_rows_relu_bwd_workspace_bytes(int64_t M, int K) {
     return (size_t)((M + lpm::SR_ROWS - 1) / lpm::SR_ROWS) * K * sizeof(float);
 }
@@ -213,4 +263,33 @@ extern "C" int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w
     hipLaunchKernelGGL(split_weight_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, (hipStream_t)stream, W, K, N,
                        (unsigned short*)w3n, (unsigned short*)w3k);
     return check_launch("lpm_split_weight");
+}
+
+extern "C" int lpm_bias_act_fwd(float* y, const float* bias, int relu, int64_t M, int C, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(y && bias, LPM_ERR_BADARG, "lpm_bias_act_fwd: null pointer");
+    LPM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_bias_act_fwd: need C %% 4 == 0 (C=%d)", C);
+    LPM_REQUIRE((((uintptr_t)y | (uintptr_t)bias) & 15) == 0, LPM_ERR_BADARG, "lpm_bias_act_fwd: pointers must be 16-byte aligned");
+    const int64_t total4 = M * (C / 4);
+    const int64_t want = (total4 + 255) / 256;
+    hipLaunchKernelGGL(bias_act_fwd_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, y, bias, relu, total4,
+                       C / 4);
+    return check_launch("lpm_bias_act_fwd");
+}
+extern "C" size_t lpm_bias_act_bwd_workspace_bytes(int64_t M, int C) { return (size_t)((M + lpm::SR_ROWS - 1) / lpm::SR_ROWS) * C * sizeof(float); }
+/* y: the forward's OUTPUT (only read when relu); dx: dy masked (not written without relu: the gradient passes through, dx may be NULL);
+ * dbias [C] = column sums of the masked gradient */
+extern "C" int lpm_bias_act_bwd(const float* dy, const float* y, int relu, int64_t M, int C, float* dx, float* dbias, void* workspace,
+                                size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dy && dbias && workspace && (!relu || (y && dx)), LPM_ERR_BADARG, "lpm_bias_act_bwd: null pointer");
+    LPM_REQUIRE(M > 0 && C > 0 && C % 4 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_bias_act_bwd: need C %% 4 == 0 (C=%d)", C);
+    LPM_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)workspace) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_bias_act_bwd: pointers must be 16-byte aligned");
+    LPM_REQUIRE(workspace_bytes >= lpm_bias_act_bwd_workspace_bytes(M, C), LPM_ERR_WORKSPACE, "lpm_bias_act_bwd: workspace too small");
+    const int nblk = (int)((M + SR_ROWS - 1) / SR_ROWS);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(nblk), dim3(256), 0, s, dy, y, relu, M, C, dx, (float*)workspace);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, (const float*)workspace, nblk, C, dbias);
+    return check_launch("lpm_bias_act_bwd");
 }

@@ -111,12 +111,14 @@ def dense(x: torch.Tensor, units: int, use_bias: bool, name: str, activation=Non
     the bias add (and activation) to the caller -- the fused layer_norm that follows takes them."""
     kernel, bias = dense_variables(name, x.shape[-1], units, use_bias, x.device)
     rows = x.numel() // x.shape[-1]
-    if use_split_gemm(x, rows, units):
-        y = ops.dense_x3(x.reshape(rows, x.shape[-1]), kernel).reshape(*x.shape[:-1], units)
-    else:
-        y = x.matmul(kernel)
+    split = use_split_gemm(x, rows, units)
+    y = ops.dense_x3(x.reshape(rows, x.shape[-1]), kernel) if split else x.matmul(kernel)
     if defer_bias:
-        return y, bias
+        return y.reshape(*x.shape[:-1], units), bias
+    if use_bias and activation in (None, torch.relu) and ops.BIAS_ACT_FUSED and ops.bias_act_ok(y, bias):
+        # one in-place pass over the GEMM's fresh output (one pass in the backward as well) instead of add + relu (threshold + reduce)
+        return ops.bias_act(y, bias, activation is torch.relu).reshape(*x.shape[:-1], units)
+    y = y.reshape(*x.shape[:-1], units)
     if use_bias:
         y = y + bias
     return activation(y) if activation is not None else y

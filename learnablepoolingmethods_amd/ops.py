@@ -37,6 +37,8 @@ PROJ_STREAM = os.environ.get("LPM_PROJ_STREAM", "1") != "0"
 # ... the input-gradient kernel from this hidden size on (measured, rocprofv3 kernel durations: forward 174 + 21 us vs the library's 219 us at
 # cfg-2, 764 vs 1233 us at cfg-5; dx 267 vs 211 us at cfg-2's N = 512 -- the library stays there --, 1108 vs 1232 us at cfg-5's N = 1024)
 PROJ_DX_STREAM_MIN_N = int(os.environ.get("LPM_PROJ_DX_STREAM_MIN_N", "1024"))
+# tf.layers.dense's bias add + ReLU as one in-place pass (ops.bias_act) where the output does not feed the next GEMM's split directly; "0": A/B
+BIAS_ACT_FUSED = os.environ.get("LPM_BIAS_ACT_FUSED", "1") != "0"
 # K5 of hidden1_weights: the gradient's norm from quadratic forms (lpm_factored_clip_adam_q) instead of a tile-GEMM pass; "0": A/B
 FACTORED_NORM_QUADFORM = os.environ.get("LPM_FACTORED_NORM_QUADFORM", "1") != "0"
 # a5 with the softmax inside the aggregation kernel (lpm_vlad_aggregate_raw_kmajor_smx_fwd; the lazily normalised k-major descriptor
@@ -1127,6 +1129,47 @@ def ffn_x3(y2d, W1, b1, W2):
 # ----------------------------------------------------------------------------------------------
 # a9: VLAD -> hidden projection (frame_level_models.py:2314-2319): [B, 270336] x [270336, H], weight-stream bound
 # ----------------------------------------------------------------------------------------------
+class _BiasAct(torch.autograd.Function):
+    """act(y + bias) of tf.layers.dense IN PLACE on the GEMM's fresh output (one pass instead of add + relu); backward: the ReLU mask
+    from the saved output and the bias gradient's column sums in one pass (instead of threshold + reduce)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, relu):
+        lib = _capi.load()
+        C = y.shape[-1]
+        M = y.numel() // C
+        lib.check(lib._lpm_bias_act_fwd(ptr(y), ptr(bias.contiguous()), 1 if relu else 0, M, C, stream_ptr()), "lpm_bias_act_fwd")
+        ctx.mark_dirty(y)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _capi.load()
+        y, = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = dy.shape[-1]
+        M = dy.numel() // C
+        dx = torch.empty_like(dy) if ctx.relu else dy
+        dbias = _empty((C,), dy)
+        wsb = lib._lpm_bias_act_bwd_workspace_bytes(M, C)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=dy.device)
+        lib.check(lib._lpm_bias_act_bwd(ptr(dy), ptr(y), 1 if ctx.relu else 0, M, C, ptr(dx) if ctx.relu else None, ptr(dbias), ptr(ws),
+                                        wsb, stream_ptr()), "lpm_bias_act_bwd")
+        return dx, dbias, None
+
+
+def bias_act_ok(y, bias):
+    return (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and y.shape[-1] % 4 == 0 and y.data_ptr() % 16 == 0
+            and bias is not None and bias.dtype == torch.float32 and y.numel() >= (1 << 16))
+
+
+def bias_act(y, bias, relu):
+    """y must be a tensor nobody else holds (the fresh output of a GEMM): it is overwritten."""
+    return _BiasAct.apply(y, bias, bool(relu))
+
+
 def skinny_weight_grad(x, dy, out=None):
     """dW [N1,N2] = x^T dy for a skinny batch (x [R,N1], dy [R,N2], R %% 16 == 0, N2 %% 32 == 0) on the bf16 pipe with
     split-bf16 operands: one pass, written straight into ``out``."""

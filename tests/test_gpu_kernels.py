@@ -562,6 +562,30 @@ def test_softmax_inside_the_aggregation_kernel_is_bitwise_the_two_kernel_chain(B
     assert_close(out[True][1], a.sum(1), tol=2e-5, what="fused-softmax assignment sums")
 
 
+@pytest.mark.parametrize("M,C,relu", [(24000, 4096, True), (1200, 256, True), (777, 128, False), (20000, 1024, False)])
+def test_bias_act_in_place(M, C, relu):
+    """ops.bias_act: tf.layers.dense's bias add (+ ReLU) as one in-place pass; backward = ReLU mask from the saved output + the bias
+    gradient's column sums, against autograd on the plain formula."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(M + C)
+    y0, b0, dy = torch.randn(M, C, generator=g), torch.randn(C, generator=g), torch.randn(M, C, generator=g)
+    yd, bd = y0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    ref = yd + bd
+    ref = torch.relu(ref) if relu else ref
+    ref.backward(dy.double())
+    src = y0.to(dev).requires_grad_(True)
+    bg = b0.to(dev).requires_grad_(True)
+    pre = src * 1.0                      # a fresh non-leaf tensor, as a GEMM's output is
+    assert ops.bias_act_ok(pre, bg)
+    out = ops.bias_act(pre, bg, relu)
+    assert out.data_ptr() == pre.data_ptr(), "in place"
+    assert_close(out, ref.detach(), tol=1e-6, what="bias_act fwd")
+    out.backward(dy.to(dev))
+    assert_close(src.grad, yd.grad, tol=1e-6, what="bias_act dx")
+    assert_close(bg.grad, bd.grad, tol=2e-5, what="bias_act dbias")
+
+
 def test_capi_rejects_bad_shapes_loudly():
     from learnablepoolingmethods_amd import _capi, ops
     dev = cuda()
