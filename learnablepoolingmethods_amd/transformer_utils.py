@@ -170,7 +170,10 @@ class TransformerEncoderMod(modules.BaseModule):
         rate = (1.0 - self.attention_dropout) if dropout_rate is None else dropout_rate
         if self.is_train and rate > 0.0:
             if dropout_mask is None:
-                dropout_mask = (torch.rand_like(attention) >= rate).to(attention.dtype)
-            attention = attention * dropout_mask / (1.0 - rate)
+                # keep with probability 1 - rate, scale the kept values by 1 / (1 - rate): one fused kernel each way (drawing the mask,
+                # comparing, casting, multiplying and dividing as separate passes cost five over the [B, S, F] tensor)
+                attention = torch.nn.functional.dropout(attention, p=rate, training=True)
+            else:
+                attention = attention * dropout_mask / (1.0 - rate)
         attention = layers.layer_norm(attention, "LayerNorm", residual=inputs)         # :451-454
         return self.ff_network.forward(attention)
