@@ -455,6 +455,65 @@ static int reserve_lds(KernT kern, size_t bytes, const char* what) {
     return LPM_OK;
 }
 
+// The same statistics WITHOUT the L x L logits: over the queries of one (batch, head),  sum_q q.k_j = k_j . s  with  s = sum_q q,  and
+// sum_q (q.k_j)^2 = k_j^T G k_j  with  G = sum_q q q^T  [d, d].  One pass over q (the d x d moment matrix: thread (i, j) walks the
+// queries staged in LDS, fixed order) and one over k (a thread per key: G k_j, then the two dot products), all fp32 FMAs:
+// 2 L d^2 multiply-adds per head instead of L^2 d and the column reductions -- at cfg-3's video stream (80 x 64 heads, L = 300,
+// d = 16) 470 us -> the time to read q and k once.
+__global__ __launch_bounds__(256) void mha_logit_stats_quad_kernel(const float* __restrict__ q, const float* __restrict__ k, int64_t ld, int L,
+                                                                   int h, int d, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;                    // [L][16] (columns >= d are zero)
+    float* G = Qs + (size_t)L * 16;      // [16][16]
+    float* sv = G + 256;                 // [16]
+    const int tid = threadIdx.x;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    for (int i = tid; i < L * 4; i += 256) {           // 16-byte pieces: row i / 4, columns 4 (i % 4) ..
+        const int row = i >> 2, c = (i & 3) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < d) v = *reinterpret_cast<const float4*>(q + ((int64_t)b * L + row) * ld + hh * d + c);
+        *reinterpret_cast<float4*>(Qs + row * 16 + c) = v;
+    }
+    __syncthreads();
+    {
+        const int i = tid >> 4, j = tid & 15;
+        float g = 0.f, si = 0.f;
+        for (int r = 0; r < L; ++r) {
+            const float a = Qs[r * 16 + i];
+            g = fmaf(a, Qs[r * 16 + j], g);
+            si += a;
+        }
+        G[i * 16 + j] = g;
+        if (j == 0) sv[i] = si;
+    }
+    __syncthreads();
+    float* out = partial + (int64_t)lid * 2 * L;
+    for (int key = tid; key < L; key += 256) {
+        float kv[16];
+#pragma unroll
+        for (int c = 0; c < 16; c += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < d) v = *reinterpret_cast<const float4*>(k + ((int64_t)b * L + key) * ld + hh * d + c);
+            kv[c] = v.x; kv[c + 1] = v.y; kv[c + 2] = v.z; kv[c + 3] = v.w;
+        }
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                const float4 gr = *reinterpret_cast<const float4*>(G + i * 16 + j);
+                t = fmaf(gr.x, kv[j], t); t = fmaf(gr.y, kv[j + 1], t); t = fmaf(gr.z, kv[j + 2], t); t = fmaf(gr.w, kv[j + 3], t);
+            }
+            sq = fmaf(kv[i], t, sq);
+            sum = fmaf(kv[i], sv[i], sum);
+        }
+        out[key] = sum;
+        out[L + key] = sq;
+    }
+}
+
 }  // namespace lpm
 
 #define LPM_MHA_CHECK(name)                                                                                       \
@@ -503,6 +562,13 @@ extern "C" int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, i
     LPM_REQUIRE(q && k && partial, LPM_ERR_BADARG, "lpm_mha_logit_stats: null pointer");
     LPM_MHA_CHECK("lpm_mha_logit_stats");
     hipStream_t s = (hipStream_t)stream;
+    static const int quad = [] { const char* e = getenv("LPM_MHA_STATS_QUAD"); return (e && e[0] == '0') ? 0 : 1; }();   // 0: through the logits (A/B)
+    if (quad && (((uintptr_t)q | (uintptr_t)k) & 15) == 0 && d % 4 == 0) {
+        const size_t ldsq = ((size_t)L * 16 + 256 + 16) * sizeof(float);
+        if (int rc = reserve_lds(mha_logit_stats_quad_kernel, ldsq, "lpm_mha_logit_stats")) return rc;
+        hipLaunchKernelGGL(mha_logit_stats_quad_kernel, dim3(B * h), dim3(256), ldsq, s, q, k, ld, L, h, d, partial);
+        return check_launch("lpm_mha_logit_stats");
+    }
     const size_t lds = mha_stats_lds(L);
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
