@@ -461,35 +461,52 @@ static int reserve_lds(KernT kern, size_t bytes, const char* what) {
 // 2 L d^2 multiply-adds per head instead of L^2 d and the column reductions -- at cfg-3's video stream (80 x 64 heads, L = 300,
 // d = 16) 470 us -> the time to read q and k once.
 __global__ __launch_bounds__(256) void mha_logit_stats_quad_kernel(const float* __restrict__ q, const float* __restrict__ k, int64_t ld, int L,
-                                                                   int h, int d, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Qs = smem;                    // [L][16] (columns >= d are zero)
-    float* G = Qs + (size_t)L * 16;      // [16][16]
-    float* sv = G + 256;                 // [16]
-    const int tid = threadIdx.x;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = lid / h, hh = lid % h;
-    for (int i = tid; i < L * 4; i += 256) {           // 16-byte pieces: row i / 4, columns 4 (i % 4) ..
-        const int row = i >> 2, c = (i & 3) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < d) v = *reinterpret_cast<const float4*>(q + ((int64_t)b * L + row) * ld + hh * d + c);
-        *reinterpret_cast<float4*>(Qs + row * 16 + c) = v;
-    }
-    __syncthreads();
-    {
-        const int i = tid >> 4, j = tid & 15;
-        float g = 0.f, si = 0.f;
-        for (int r = 0; r < L; ++r) {
-            const float a = Qs[r * 16 + i];
-            g = fmaf(a, Qs[r * 16 + j], g);
-            si += a;
+                                                                   int h, int d, int nheads, float* __restrict__ partial) {
+    // one WAVE per (batch, head), four consecutive heads per workgroup.  G = Q^T Q on the exact-fp32 matrix pipe: for a group of four
+    // queries lane (l15, g) holds Q[4 s + g][l15], which is its element of BOTH operands of v_mfma_f32_16x16x4_f32 (A = Q^T, B = Q);
+    // acc[r] = G[4 g + r][l15].  No staging: a wave-load touches four 64-byte rows.
+    __shared__ __attribute__((aligned(16))) float Gs[4][16 * 16 + 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int head = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (head >= nheads) return;                                  // (no workgroup barriers below: the tiles are wave-private)
+    const int b = head / h, hh = head % h;
+    const float* qp = q + (int64_t)b * L * ld + hh * d + l15;
+    const bool col = l15 < d;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float sacc = 0.f;
+    const int ns = (L + 3) >> 2;
+    int s = 0;
+    for (; s + 4 < ns; s += 5) {                                 // five groups' loads together
+        float a[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int row = 4 * (s + u) + g;
+            a[u] = (col && row < L) ? qp[(int64_t)row * ld] : 0.f;
         }
-        G[i * 16 + j] = g;
-        if (j == 0) sv[i] = si;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            acc = mfma16(a[u], a[u], acc);
+            sacc += a[u];
+        }
     }
-    __syncthreads();
-    float* out = partial + (int64_t)lid * 2 * L;
-    for (int key = tid; key < L; key += 256) {
+    for (; s < ns; ++s) {
+        const int row = 4 * s + g;
+        const float a = (col && row < L) ? qp[(int64_t)row * ld] : 0.f;
+        acc = mfma16(a, a, acc);
+        sacc += a;
+    }
+    sacc += __shfl_xor(sacc, 16, 64);
+    sacc += __shfl_xor(sacc, 32, 64);                            // sum_q Q[q][l15] on every lane
+    float* G = Gs[wave];
+    float* sv = G + 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[(4 * g + r) * 16 + l15] = acc[r];
+    if (g == 0) sv[l15] = sacc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* out = partial + (int64_t)head * 2 * L;
+    for (int key = lane; key < L; key += 64) {
         float kv[16];
 #pragma unroll
         for (int c = 0; c < 16; c += 4) {
@@ -564,9 +581,7 @@ extern "C" int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, i
     hipStream_t s = (hipStream_t)stream;
     static const int quad = [] { const char* e = getenv("LPM_MHA_STATS_QUAD"); return (e && e[0] == '0') ? 0 : 1; }();   // 0: through the logits (A/B)
     if (quad && (((uintptr_t)q | (uintptr_t)k) & 15) == 0 && d % 4 == 0) {
-        const size_t ldsq = ((size_t)L * 16 + 256 + 16) * sizeof(float);
-        if (int rc = reserve_lds(mha_logit_stats_quad_kernel, ldsq, "lpm_mha_logit_stats")) return rc;
-        hipLaunchKernelGGL(mha_logit_stats_quad_kernel, dim3(B * h), dim3(256), ldsq, s, q, k, ld, L, h, d, partial);
+        hipLaunchKernelGGL(mha_logit_stats_quad_kernel, dim3((B * h + 3) / 4), dim3(256), 0, s, q, k, ld, L, h, d, B * h, partial);
         return check_launch("lpm_mha_logit_stats");
     }
     const size_t lds = mha_stats_lds(L);
