@@ -365,6 +365,17 @@ size_t lpm_bn_rows_workspace_bytes(int M, int C);
 int lpm_bn_rows_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float decay,
                     int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean, float* moving_var,
                     void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+/* ... of act(x + pre_bias): the bias add (+ ReLU) of the dense layer in front (tf.layers.dense(use_bias=True, activation=relu) ->
+ * slim.batch_norm, transformer_utils.py:741-760) rides in the statistics and apply passes; the activation is never stored. */
+int lpm_bn_rows_act_fwd(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
+                        float eps, float decay, int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
+                        float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+/* its backward: x = the raw dense output; dl = the gradient of x (ReLU mask applied), dbias = its column sums */
+int lpm_bn_act_bwd_supported(int M, int K);
+size_t lpm_bn_act_bwd_workspace_bytes(int M, int K);
+int lpm_bn_act_bwd(const float* dlt, const float* x, const float* pre_bias, int pre_relu, const float* mean, const float* var,
+                   const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                   size_t workspace_bytes, lpm_stream_t stream);
 size_t lpm_bn_bwd_workspace_bytes(int M, int K);
 int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var, const float* gamma,
                float eps, int M, int K, float* dl, float* dgamma, float* dbeta, void* workspace,

@@ -32,6 +32,18 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(const float* __restrict__
     }
 }
 
+// Pre-activation of the channel-last batch norms (lpm_bn_rows_act_fwd / lpm_bn_act_bwd): the normalised tensor is act(x + bias) with
+// x the raw output of the dense layer in front (tf.layers.dense(use_bias=True, activation=relu) -> slim.batch_norm,
+// transformer_utils.py:741-760).  It is formed where it is read -- statistics, apply, both backward passes -- and never stored.
+__device__ __forceinline__ float4 bn_preact(float4 v, const float* __restrict__ pb, int c, int relu) {
+    if (pb) {
+        const float4 b = *reinterpret_cast<const float4*>(pb + c);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    }
+    return v;
+}
+
 // pass 1 of the BN backward: per-block column partials of dlt and dlt*Lhat.
 constexpr int BNB_ROWS = 64;
 // Threads are (row group, float4 column): 256 / (K/4) row groups when K/4 divides 256 (K = 256: four rows of 1 KB per
@@ -41,7 +53,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ logits,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ var, float eps, int M,
-                                                             int K, float* __restrict__ partial) {
+                                                             int K, float* __restrict__ partial, const float* __restrict__ pb, int relu) {
     __shared__ float4 red[2][256];
     const int r0 = blockIdx.x * BNB_ROWS;
     const int r1 = min(M, r0 + BNB_ROWS);
@@ -53,7 +65,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const float4 vr = *reinterpret_cast<const float4*>(var + 4 * c4);
         const float4 rs = make_float4(rsqrtf(vr.x + eps), rsqrtf(vr.y + eps), rsqrtf(vr.z + eps), rsqrtf(vr.w + eps));
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
-        auto add = [&](const float4 d, const float4 l) {
+        auto add = [&](const float4 d, float4 l) {
+            l = bn_preact(l, pb, 4 * c4, relu);
             s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
             q.x += d.x * ((l.x - mu.x) * rs.x); q.y += d.y * ((l.y - mu.y) * rs.y);
             q.z += d.z * ((l.z - mu.z) * rs.z); q.w += d.w * ((l.w - mu.w) * rs.w);
@@ -103,6 +116,39 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __rest
     }
 }
 
+// first stage for a tall partial array (rows x K, e.g. 512 x 4096 = 8 MB): grid (ceil(K / 64), BN_CS_SLICES), 256 threads = 4 row groups x
+// 64 columns (256-byte row pieces); slice y sums rows y, y + BN_CS_SLICES, ... -> tmp[y][K]   (16-column workgroups over the tall array
+// read 64-byte pieces: 108 us for 8 MB)
+constexpr int BN_CS_SLICES = 16;
+__global__ __launch_bounds__(256) void bn_colsum_stage1_kernel(const float* __restrict__ part, int rows, int K, float* __restrict__ tmp) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, y = blockIdx.y;
+    float acc = 0.f;
+    if (c < K) {
+        for (int r = y + BN_CS_SLICES * rg; r < rows; r += BN_CS_SLICES * 4 * 4) {      // four rows per round: independent loads, fixed order
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + BN_CS_SLICES * 4 * u;
+                v[u] = rr < rows ? part[(int64_t)rr * K + c] : 0.f;
+            }
+            acc += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < K) tmp[(int64_t)y * K + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+
+// column sums of one array [rows][K] (the bias gradient partials of the pre-activation form)
+__global__ __launch_bounds__(1024) void bn_bwd_colsum_kernel(const float* __restrict__ part, int rows, int K, float* __restrict__ out) {
+    double s, q;
+    int c;
+    partial_colsums16(part, rows, (int64_t)K, 0, K, s, q, c);
+    if (threadIdx.x < 16 && c < K) out[c] = (float)s;
+}
+
 // pass 3: dl = gamma*rstd*(dlt - mean_r(dlt) - Lhat*mean_r(dlt*Lhat))
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dlt,
                                                            const float* __restrict__ logits,
@@ -111,7 +157,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float eps, int M, int K,
-                                                           float* __restrict__ dl) {
+                                                           float* __restrict__ dl, const float* __restrict__ pb, int relu,
+                                                           float* __restrict__ dbpart) {
+    // pb / relu: the normalised tensor was act(logits + pb); dl is then the gradient of the RAW logits (masked where the ReLU was off)
+    // and dbpart [stride / (K/4)][K] receives this thread's column sums of it (the bias gradient; needs the fixed-column arrangement)
     // dl = A d + Bq (l - mean) + Cq per column, A = gamma rstd, Bq = -gamma rstd^2 dgamma / M, Cq = -gamma rstd dbeta / M.  When the
     // grid stride is a multiple of the row length a thread keeps its four columns and the coefficients are formed once (the
     // launcher arranges that); otherwise once per element group.  (l - mean) is formed first: columns with |mean| >> sigma.
@@ -133,13 +182,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     };
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (fixed && i0 < total4) coeffs((int)(i0 % K4) * 4);
-    auto one = [&](int64_t i, const float4 d, const float4 l) {
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto one = [&](int64_t i, const float4 d, float4 l) {
         if (!fixed) coeffs((int)(i % K4) * 4);
+        l = bn_preact(l, pb, (int)(i % K4) * 4, relu);
         float4 o;
         o.x = fmaf(A.x, d.x, fmaf(Bq.x, l.x - mu.x, Cq.x));
         o.y = fmaf(A.y, d.y, fmaf(Bq.y, l.y - mu.y, Cq.y));
         o.z = fmaf(A.z, d.z, fmaf(Bq.z, l.z - mu.z, Cq.z));
         o.w = fmaf(A.w, d.w, fmaf(Bq.w, l.w - mu.w, Cq.w));
+        if (pb && relu) {                  // l = relu(.): zero exactly where the unit was off
+            o.x = l.x > 0.f ? o.x : 0.f; o.y = l.y > 0.f ? o.y : 0.f; o.z = l.z > 0.f ? o.z : 0.f; o.w = l.w > 0.f ? o.w : 0.f;
+        }
+        bsum.x += o.x; bsum.y += o.y; bsum.z += o.z; bsum.w += o.w;
         reinterpret_cast<float4*>(dl)[i] = o;
     };
     const float4* dp = reinterpret_cast<const float4*>(dlt);
@@ -156,11 +211,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         for (int u = 0; u < 4; ++u) one(i + u * stride, d[u], l[u]);
     }
     for (; i < total4; i += stride) one(i, dp[i], lp[i]);
+    if (dbpart && i0 < stride)            // (fixed: the thread kept columns 4 (i0 % K4) ..; threads beyond the data wrote nothing: zero sums)
+        *reinterpret_cast<float4*>(dbpart + (i0 / K4) * K + (i0 % K4) * 4) = bsum;
 }
 
 // ---- channel-last batch norm of a [M, C] matrix (the V2 encoder's [B, L, C] tensors seen as rows) -----------------------------
 // statistics: per 64-row block column (sum, sum of squares) -> partial [nblk][2][C]  (then bn_fold_kernel)
-__global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ partial,
+                                                            const float* __restrict__ pb, int relu) {
     __shared__ float4 red[2][256];
     const int r0 = blockIdx.x * BNB_ROWS, r1 = min(M, r0 + BNB_ROWS);
     const int tid = threadIdx.x, C4 = C / 4;
@@ -168,7 +226,8 @@ __global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restr
     const int rg = RG > 1 ? tid / C4 : 0;
     for (int c4 = RG > 1 ? tid % C4 : tid; c4 < C4; c4 += (RG > 1 ? C4 : 256)) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
-        auto add = [&](const float4 v) {
+        auto add = [&](float4 v) {
+            v = bn_preact(v, pb, 4 * c4, relu);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
         };
@@ -203,10 +262,10 @@ __global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restr
 // y = x * scale[c] + shift[c]
 __global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int64_t total4, int C4,
-                                                            float* __restrict__ y) {
+                                                            float* __restrict__ y, const float* __restrict__ pb, int relu) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 v = bn_preact(reinterpret_cast<const float4*>(x)[i], pb, c, relu);
         const float4 a = *reinterpret_cast<const float4*>(scale + c), b = *reinterpret_cast<const float4*>(shift + c);
         reinterpret_cast<float4*>(y)[i] = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
     }
@@ -219,9 +278,27 @@ extern "C" size_t lpm_bn_rows_workspace_bytes(int M, int C) {
     return ((size_t)nblk * 2 * C + 2 * (size_t)C) * sizeof(float);
 }
 
+static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
+                            float eps, float decay, int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
+                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 extern "C" int lpm_bn_rows_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float decay,
                                int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
                                float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    return bn_rows_fwd_impl(x, nullptr, 0, M, C, gamma, beta, eps, decay, biased_moving_variance, y, mean, var, moving_mean, moving_var,
+                            workspace, workspace_bytes, stream);
+}
+// y = batch_norm(act(x + pre_bias)): the bias add (+ ReLU) of the dense layer in front rides in the statistics and apply passes
+extern "C" int lpm_bn_rows_act_fwd(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
+                                   float eps, float decay, int biased_moving_variance, float* y, float* mean, float* var,
+                                   float* moving_mean, float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(pre_bias && (((uintptr_t)pre_bias) & 15) == 0, LPM_ERR_BADARG, "lpm_bn_rows_act_fwd: needs a 16-byte aligned bias");
+    return bn_rows_fwd_impl(x, pre_bias, pre_relu, M, C, gamma, beta, eps, decay, biased_moving_variance, y, mean, var, moving_mean, moving_var,
+                            workspace, workspace_bytes, stream);
+}
+static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
+                            float eps, float decay, int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
+                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(x && y && mean && var && workspace, LPM_ERR_BADARG, "lpm_bn_rows_fwd: null pointer");
     LPM_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
@@ -233,13 +310,14 @@ extern "C" int lpm_bn_rows_fwd(const float* x, int M, int C, const float* gamma,
     float* partial = (float*)workspace;
     float* scale = partial + (size_t)nblk * 2 * C;
     float* shift = scale + C;
-    hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(nblk), dim3(256), 0, s, x, M, C, partial);
+    hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(nblk), dim3(256), 0, s, x, M, C, partial, pre_bias, pre_relu);
     const double unbias = (biased_moving_variance || M <= 1) ? 1.0 : (double)M / (double)(M - 1);
     hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, partial, nblk, C, 1.0 / (double)M, unbias, gamma, beta, eps,
                        decay, mean, var, scale, shift, moving_mean, moving_var);
     const int64_t total4 = (int64_t)M * C / 4;
     const int64_t want = (total4 + 255) / 256;
-    hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, x, scale, shift, total4, C / 4, y);
+    hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, x, scale, shift, total4, C / 4, y, pre_bias,
+                       pre_relu);
     return check_launch("lpm_bn_rows_fwd");
 }
 
@@ -263,9 +341,50 @@ extern "C" size_t lpm_bn_bwd_workspace_bytes(int M, int K) {
     return (size_t)nblk * 2 * K * sizeof(float);
 }
 
+namespace lpm {
+static int bn_bwd_grid(int M, int K) {
+    const int64_t total4 = (int64_t)M * K / 4;
+    const int64_t want = (total4 + 255) / 256;
+    int grid = (int)(want < 2048 ? want : 2048);
+    // a grid stride that is a multiple of the row length K/4 lets a thread keep its columns (coefficients formed once)
+    const int K4 = K / 4;
+    int step = K4;                                   // smallest workgroup count g with (g * 256) % K4 == 0: K4 / gcd(K4, 256)
+    for (int a = K4, b = 256; b;) { const int t = a % b; a = b; b = t; step = K4 / a; }
+    if (step <= grid) grid = grid / step * step;
+    return grid;
+}
+}  // namespace lpm
+static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_bias, int pre_relu, const float* mean, const float* var,
+                       const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                       size_t workspace_bytes, lpm_stream_t stream);
 extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var,
                           const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta,
                           void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    return bn_bwd_impl(dlt, logits, nullptr, 0, mean, var, gamma, eps, M, K, dl, dgamma, dbeta, nullptr, workspace, workspace_bytes, stream);
+}
+// backward of lpm_bn_rows_act_fwd: x = the RAW dense output it normalised as act(x + pre_bias); dl = the gradient of x (the ReLU mask
+// applied), dbias = its column sums.  0 from lpm_bn_act_bwd_supported: the thread layout cannot keep columns fixed for this shape.
+extern "C" int lpm_bn_act_bwd_supported(int M, int K) {
+    if (M <= 0 || K <= 0 || K % 4) return 0;
+    return ((int64_t)lpm::bn_bwd_grid(M, K) * 256) % (K / 4) == 0 ? 1 : 0;
+}
+extern "C" size_t lpm_bn_act_bwd_workspace_bytes(int M, int K) {
+    const int nblk = (M + lpm::BNB_ROWS - 1) / lpm::BNB_ROWS;
+    const size_t rows = (size_t)lpm::bn_bwd_grid(M, K) * 256 / (size_t)(K / 4);
+    return ((size_t)nblk * 2 * K + rows * K + (size_t)lpm::BN_CS_SLICES * K) * sizeof(float);
+}
+extern "C" int lpm_bn_act_bwd(const float* dlt, const float* x, const float* pre_bias, int pre_relu, const float* mean, const float* var,
+                              const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias,
+                              void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(pre_bias && dbias && (((uintptr_t)pre_bias) & 15) == 0, LPM_ERR_BADARG, "lpm_bn_act_bwd: needs a 16-byte aligned bias and dbias");
+    LPM_REQUIRE(lpm_bn_act_bwd_supported(M, K), LPM_ERR_UNSUPPORTED_SHAPE, "lpm_bn_act_bwd: shape not supported (M=%d K=%d)", M, K);
+    LPM_REQUIRE(workspace_bytes >= lpm_bn_act_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE, "lpm_bn_act_bwd: workspace too small");
+    return bn_bwd_impl(dlt, x, pre_bias, pre_relu, mean, var, gamma, eps, M, K, dl, dgamma, dbeta, dbias, workspace, workspace_bytes, stream);
+}
+static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_bias, int pre_relu, const float* mean, const float* var,
+                       const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                       size_t workspace_bytes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(dlt && logits && mean && var && dl && dgamma && dbeta && workspace, LPM_ERR_BADARG,
                 "lpm_bn_bwd: null pointer");
@@ -276,18 +395,21 @@ extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* me
     hipStream_t s = (hipStream_t)stream;
     const int nblk = (M + BNB_ROWS - 1) / BNB_ROWS;
     float* partial = (float*)workspace;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, dlt, logits, mean, var, eps, M, K, partial);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, dlt, logits, mean, var, eps, M, K, partial, pre_bias, pre_relu);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((K + 15) / 16), dim3(1024), 0, s, partial, nblk, K, dgamma, dbeta);
-    const int64_t total4 = (int64_t)M * K / 4;
-    const int64_t want = (total4 + 255) / 256;
-    int grid = (int)(want < 2048 ? want : 2048);
-    {   // a grid stride that is a multiple of the row length K/4 lets a thread keep its columns (coefficients formed once)
-        const int K4 = K / 4;
-        int step = K4;                                   // smallest workgroup count g with (g * 256) % K4 == 0: K4 / gcd(K4, 256)
-        for (int a = K4, b = 256; b;) { const int t = a % b; a = b; b = t; step = K4 / a; }
-        if (step <= grid) grid = grid / step * step;
-    }
+    const int grid = bn_bwd_grid(M, K);
+    float* dbpart = dbias ? partial + (size_t)nblk * 2 * K : nullptr;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, dlt, logits, mean, var, gamma, dgamma, dbeta,
-                       eps, M, K, dl);
+                       eps, M, K, dl, pre_bias, pre_relu, dbpart);
+    if (dbias) {
+        const int rows = (int)((int64_t)grid * 256 / (K / 4));
+        if (rows > 4 * BN_CS_SLICES) {
+            float* tmp = dbpart + (size_t)rows * K;
+            hipLaunchKernelGGL(bn_colsum_stage1_kernel, dim3((K + 63) / 64, BN_CS_SLICES), dim3(256), 0, s, (const float*)dbpart, rows, K, tmp);
+            hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3((K + 15) / 16), dim3(1024), 0, s, (const float*)tmp, BN_CS_SLICES, K, dbias);
+        } else {
+            hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3((K + 15) / 16), dim3(1024), 0, s, (const float*)dbpart, rows, K, dbias);
+        }
+    }
     return check_launch("lpm_bn_bwd");
 }

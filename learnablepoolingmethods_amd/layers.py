@@ -29,12 +29,22 @@ def bn_variables(scope: str, channels: int, device):
     return gamma, beta, mm, mv
 
 
-def batch_norm(x: torch.Tensor, is_training: bool, scope: str) -> torch.Tensor:
+def batch_norm(x: torch.Tensor, is_training: bool, scope: str, pre_bias: torch.Tensor = None, pre_relu: bool = False) -> torch.Tensor:
     """slim.batch_norm on a tensor whose last axis is the channel (frame_level_models.py:2355;
     transformer_utils.py:666,747,760).  Moving variance gets the unbiased estimate on the fused
-    (rank-2/4) path, the biased one otherwise."""
+    (rank-2/4) path, the biased one otherwise.  pre_bias / pre_relu: x is the raw output of a dense layer whose bias add (and ReLU) the
+    caller deferred (dense(..., defer_bias=True)): the normalised tensor is act(x + pre_bias)."""
     C = x.shape[-1]
     gamma, beta, mm, mv = bn_variables(scope, C, x.device)
+    if pre_bias is not None:
+        if is_training and x.dim() == 3 and ops.batch_norm_rows_act_ok(x, pre_bias):
+            return ops.batch_norm_rows_act(x, pre_bias, pre_relu, gamma, beta, mm, mv, biased_moving_variance=True)
+        if ops.BIAS_ACT_FUSED and x.is_contiguous() and ops.bias_act_ok(x, pre_bias):
+            x = ops.bias_act(x * 1.0 if x._base is not None else x, pre_bias, pre_relu)      # (a view of the GEMM's output: not in place on it)
+        else:
+            x = x + pre_bias
+            if pre_relu:
+                x = torch.relu(x)
     if is_training and x.dim() == 2 and x.is_cuda and x.shape[0] > 1:
         # the fused rank-2 path in one library kernel each way: batch statistics, normalisation and the moving-average
         # update (unbiased variance into the moving average, exactly TF's fused batch norm) instead of ~12 small kernels

@@ -37,6 +37,8 @@ PROJ_STREAM = os.environ.get("LPM_PROJ_STREAM", "1") != "0"
 # ... the input-gradient kernel from this hidden size on (measured, rocprofv3 kernel durations: forward 174 + 21 us vs the library's 219 us at
 # cfg-2, 764 vs 1233 us at cfg-5; dx 267 vs 211 us at cfg-2's N = 512 -- the library stays there --, 1108 vs 1232 us at cfg-5's N = 1024)
 PROJ_DX_STREAM_MIN_N = int(os.environ.get("LPM_PROJ_DX_STREAM_MIN_N", "1024"))
+# ... and inside the channel-last batch norm that follows it (ops.batch_norm_rows_act: FeedForwardNetworkMod); "0": ops.bias_act + plain BN
+BN_ACT_FUSED = os.environ.get("LPM_BN_ACT_FUSED", "1") != "0"
 # tf.layers.dense's bias add + ReLU as one in-place pass (ops.bias_act) where the output does not feed the next GEMM's split directly; "0": A/B
 BIAS_ACT_FUSED = os.environ.get("LPM_BIAS_ACT_FUSED", "1") != "0"
 # K5 of hidden1_weights: the gradient's norm from quadratic forms (lpm_factored_clip_adam_q) instead of a tile-GEMM pass; "0": A/B
@@ -1299,6 +1301,53 @@ class _BatchNormRows(torch.autograd.Function):
         lib.check(lib._lpm_bn_bwd(ptr(dy2), ptr(x2), ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, C, ptr(dx), ptr(dgamma), ptr(dbeta),
                                   ptr(ws), wsb, stream_ptr()), "lpm_bn_bwd")
         return dx.view(ctx.shape), dgamma, dbeta, None, None, None
+
+
+class _BatchNormRowsAct(torch.autograd.Function):
+    """slim.batch_norm(act(x + bias)) over the rows of a channel-last tensor, x the RAW output of the dense layer in front: the bias
+    add and ReLU ride in the batch norm's statistics / apply passes and in both passes of its backward (the activation is never
+    stored; the backward returns the gradient of x with the ReLU mask applied and the bias gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, relu, gamma, beta, moving_mean, moving_var, biased_moving):
+        lib = _capi.load()
+        x2 = _f32(x, "batch_norm input").contiguous().view(-1, x.shape[-1])
+        M, C = x2.shape
+        bias = bias.contiguous()
+        y = torch.empty_like(x2)
+        mean, var = _empty((C,), x2), _empty((C,), x2)
+        wsb = lib._lpm_bn_rows_workspace_bytes(M, C)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x2.device)
+        lib.check(lib._lpm_bn_rows_act_fwd(ptr(x2), ptr(bias), 1 if relu else 0, M, C, ptr(gamma), ptr(beta), BN_EPS, BN_DECAY,
+                                           1 if biased_moving else 0, ptr(y), ptr(mean), ptr(var), ptr(moving_mean), ptr(moving_var), ptr(ws),
+                                           wsb, stream_ptr()), "lpm_bn_rows_act_fwd")
+        ctx.save_for_backward(x2, bias, mean, var, gamma)
+        ctx.shape, ctx.relu = x.shape, bool(relu)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _capi.load()
+        x2, bias, mean, var, gamma = ctx.saved_tensors
+        M, C = x2.shape
+        dy2 = dy.contiguous().view(M, C)
+        dx = torch.empty_like(x2)
+        dgamma, dbeta, dbias = _empty((C,), x2), _empty((C,), x2), _empty((C,), x2)
+        wsb = lib._lpm_bn_act_bwd_workspace_bytes(M, C)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x2.device)
+        lib.check(lib._lpm_bn_act_bwd(ptr(dy2), ptr(x2), ptr(bias), 1 if ctx.relu else 0, ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, C,
+                                      ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), wsb, stream_ptr()), "lpm_bn_act_bwd")
+        return dx.view(ctx.shape), dbias, None, dgamma, dbeta, None, None, None
+
+
+def batch_norm_rows_act_ok(x, bias):
+    C = x.shape[-1]
+    return (BN_ACT_FUSED and x.is_cuda and x.dtype == torch.float32 and bias is not None and C % 4 == 0
+            and bool(_capi.load()._lpm_bn_act_bwd_supported(x.numel() // C, C)))
+
+
+def batch_norm_rows_act(x, bias, relu, gamma, beta, moving_mean, moving_var, biased_moving_variance):
+    return _BatchNormRowsAct.apply(x, bias, bool(relu), gamma, beta, moving_mean, moving_var, bool(biased_moving_variance))
 
 
 def batch_norm_rows(x, gamma, beta, moving_mean, moving_var, biased_moving_variance):

@@ -85,10 +85,11 @@ class FeedForwardNetworkMod(modules.BaseModule):
         self.final_size = final_size
 
     def forward(self, inputs, **unused_params):
-        filter_output = layers.dense(inputs, self.filter_size, True, "filter_output{}".format(self.scope_id), torch.relu)
-        filter_output = layers.batch_norm(filter_output, self.is_train, "filter_bn")
-        output = layers.dense(filter_output, self.final_size, True, "ff_output{}".format(self.scope_id), torch.relu)
-        return layers.batch_norm(output, self.is_train, "feed_output_bn")
+        # relu(dense) -> batch_norm twice (:741-760): the bias add and the ReLU of each dense layer ride in the batch norm's passes
+        pre, b1 = layers.dense(inputs, self.filter_size, True, "filter_output{}".format(self.scope_id), defer_bias=True)
+        filter_output = layers.batch_norm(pre, self.is_train, "filter_bn", pre_bias=b1, pre_relu=True)
+        pre2, b2 = layers.dense(filter_output, self.final_size, True, "ff_output{}".format(self.scope_id), defer_bias=True)
+        return layers.batch_norm(pre2, self.is_train, "feed_output_bn", pre_bias=b2, pre_relu=True)
 
 
 class TransformerEncoder(modules.BaseModule):

@@ -837,6 +837,42 @@ def test_batch_norm_rows_rank3(B, L, C):
     assert_close(mvg, mv.double() * 0.999 + upd["bn/moving_variance"] * 0.001, tol=1e-6, what="moving_variance")
 
 
+@pytest.mark.parametrize("B,L,C,relu", [(4, 300, 4096, True), (3, 300, 256, True), (5, 64, 1024, False), (2, 300, 128, True)])
+def test_batch_norm_rows_with_the_dense_bias_and_relu_inside(B, L, C, relu):
+    """ops.batch_norm_rows_act: slim.batch_norm(act(x + bias)) with x the raw dense output (transformer_utils.py:741-760) -- bias add
+    and ReLU inside the statistics / apply passes and both backward passes -- against the composed fp64 formula: output, the gradient
+    of x (ReLU mask), of the bias, of gamma / beta, and the moving statistics."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(C + L + relu)
+    x, dy = 2 * torch.randn(B, L, C, generator=g), torch.randn(B, L, C, generator=g)
+    bias = 0.5 * torch.randn(C, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    mm, mv = 0.1 * torch.randn(C, generator=g), 1 + 0.3 * torch.rand(C, generator=g)
+    p = {"bn/gamma": gamma.double().requires_grad_(True), "bn/beta": beta.double().requires_grad_(True),
+         "bn/moving_mean": mm.double(), "bn/moving_variance": mv.double()}
+    xd, bd = x.double().requires_grad_(True), bias.double().requires_grad_(True)
+    upd = {}
+    a = xd + bd
+    a = torch.relu(a) if relu else a
+    ref = O.batch_norm(a, p, "bn", True, upd)
+    ref.backward(dy.double())
+    xg, bbg, gg, bg = (t.to(dev).requires_grad_(True) for t in (x, bias, gamma, beta))
+    mmg, mvg = mm.to(dev), mv.to(dev)
+    assert ops.batch_norm_rows_act_ok(xg, bbg)
+    y = ops.batch_norm_rows_act(xg, bbg, relu, gg, bg, mmg, mvg, biased_moving_variance=True)
+    assert_close(y, ref, 1e-5, "batch_norm(act) fwd")
+    y.backward(dy.to(dev))
+    assert_close(xg.grad, xd.grad, 1e-4, "dx")
+    # (without the ReLU a batch norm removes any per-column constant: the bias gradient is exactly zero, ours is rounding noise --
+    # measured against the scale of the gradients that are not)
+    assert_close(bbg.grad, bd.grad, 1e-4, "dbias", floor=float(p["bn/beta"].grad.abs().max()))
+    assert_close(gg.grad, p["bn/gamma"].grad, 1e-4, "dgamma")
+    assert_close(bg.grad, p["bn/beta"].grad, 1e-4, "dbeta")
+    assert_close(mmg, mm.double() * 0.999 + upd["bn/moving_mean"] * 0.001, tol=1e-6, what="moving_mean")
+    assert_close(mvg, mv.double() * 0.999 + upd["bn/moving_variance"] * 0.001, tol=1e-6, what="moving_variance")
+
+
 def test_netvlad_batch_split_invariance_full_size():
     """Size-independent property at BASELINE cfg-2 shapes, forward AND backward: with inference-mode batch norm (a fixed
     affine) clips are independent, so pooling the 80-clip batch equals pooling its two halves -- descriptors and input
