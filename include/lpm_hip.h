@@ -500,6 +500,11 @@ int lpm_mha_fwd_x3_image(const float* q, const float* k, const float* v, int64_t
 size_t lpm_mha_logit_stats_workspace_bytes(int B, int L, int h);
 int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float* partial,
                         lpm_stream_t stream);
+/* logits_bn backward bookkeeping in one launch: partial [nblk][2][L] = lpm_mha_bwd's statistics pass (column sums of dz and dz * s per
+ * (batch, head)) -> dgamma, dbeta and, in training (corr_a / corr_b given), the correction vectors of the main backward pass;
+ * n = B * h * L logits per key position (transformer_utils.py:652-658, backward) */
+int lpm_mha_bn_corrections(const float* partial, int nblk, int L, const float* mean, const float* var, const float* kscale, float eps,
+                           int64_t n, float* dgamma, float* dbeta, float* corr_a, float* corr_b, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MoeModel tail + CrossEntropyLoss (video_level_models.py:116-126, losses.py:41-51), fused:

@@ -149,6 +149,31 @@ __global__ __launch_bounds__(1024) void bn_bwd_colsum_kernel(const float* __rest
     if (threadIdx.x < 16 && c < K) out[c] = (float)s;
 }
 
+// logits_bn backward bookkeeping of the NetVladV2 attention (ops._MHACoreBN.backward): partial [nblk][2][L] holds per (batch, head) the
+// column sums of dz and dz * s over the queries.  -> dbeta = sum dz, dgamma = sum dz * s_hat = rstd (sum dz s - mean sum dz), and the
+// two correction vectors the main pass subtracts (training: the gradient through the batch statistics)
+//   corr_b = kscale * (dgamma / n) * rstd,   corr_a = kscale * (dbeta / n - mean * rstd * dgamma / n)        (fp64, one launch)
+__global__ __launch_bounds__(1024) void mha_bn_corrections_kernel(const float* __restrict__ partial, int nblk, int L,
+                                                                  const float* __restrict__ mean, const float* __restrict__ var,
+                                                                  const float* __restrict__ kscale, float eps, double inv_n,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ corr_a, float* __restrict__ corr_b) {
+    double s, q;
+    int c;
+    partial_colsums16(partial, nblk, 2 * (int64_t)L, L, L, s, q, c);
+    if (threadIdx.x < 16 && c < L) {
+        const double rstd = 1.0 / sqrt((double)var[c] + (double)eps), mu = (double)mean[c];
+        const double sdz_hat = rstd * (q - mu * s);
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)sdz_hat;
+        if (corr_a) {
+            const double c1 = s * inv_n, c2 = sdz_hat * inv_n, ks = (double)kscale[c];
+            corr_b[c] = (float)(ks * c2 * rstd);
+            corr_a[c] = (float)(ks * (c1 - mu * rstd * c2));
+        }
+    }
+}
+
 // pass 3: dl = gamma*rstd*(dlt - mean_r(dlt) - Lhat*mean_r(dlt*Lhat))
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dlt,
                                                            const float* __restrict__ logits,
@@ -412,4 +437,17 @@ static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_b
         }
     }
     return check_launch("lpm_bn_bwd");
+}
+
+/* partial [nblk][2][L] (lpm_mha_bwd's statistics pass) -> dgamma, dbeta of logits_bn and, when corr_a / corr_b are given (training), the
+ * two correction vectors of the main backward pass; n = the number of logits per key position (B * h * L) */
+extern "C" int lpm_mha_bn_corrections(const float* partial, int nblk, int L, const float* mean, const float* var, const float* kscale,
+                                      float eps, int64_t n, float* dgamma, float* dbeta, float* corr_a, float* corr_b, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(partial && mean && var && dgamma && dbeta && ((corr_a == nullptr) == (corr_b == nullptr)) && (!corr_a || kscale), LPM_ERR_BADARG,
+                "lpm_mha_bn_corrections: null pointer");
+    LPM_REQUIRE(nblk > 0 && L > 0 && n > 0, LPM_ERR_BADARG, "lpm_mha_bn_corrections: bad sizes");
+    hipLaunchKernelGGL(mha_bn_corrections_kernel, dim3((L + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nblk, L, mean, var, kscale,
+                       eps, 1.0 / (double)n, dgamma, dbeta, corr_a, corr_b);
+    return check_launch("lpm_mha_bn_corrections");
 }

@@ -1775,19 +1775,11 @@ class _MHACoreBN(torch.autograd.Function):
         lib.check(_mha_bwd_fn(lib, bn=True, which="stats")(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L,
                                                            h, d, 1.0, ptr(kscale), ptr(kshift), None, None, None, q.stride(1), None, None,
                                                            ptr(partial), st), "lpm_mha_bwd(stats)")
-        sums = partial.to(torch.float64).sum(0)                      # [2, L]  (tiny)
-        sdz, sdzs = sums[0], sums[1]
-        rstd = torch.rsqrt(var.double() + BN_EPS)
-        sdz_hat = rstd * (sdzs - mean.double() * sdz)                # sum dz * s_hat
-        dbeta, dgamma = sdz.float(), sdz_hat.float()
-        if is_training:
-            n = float(B * h * L)
-            c1, c2 = sdz / n, sdz_hat / n
-            ks = kscale.double()
-            corr_b = (ks * c2 * rstd).float().contiguous()
-            corr_a = (ks * (c1 - mean.double() * rstd * c2)).float().contiguous()
-        else:
-            corr_a = corr_b = None
+        # dbeta = sum dz, dgamma = sum dz * s_hat and (training) the two correction vectors of the main pass, fp64, in one launch
+        dgamma, dbeta = _empty((L,), q), _empty((L,), q)
+        corr_a, corr_b = (_empty((L,), q), _empty((L,), q)) if is_training else (None, None)
+        lib.check(lib._lpm_mha_bn_corrections(ptr(partial), B * h, L, ptr(mean.contiguous()), ptr(var.contiguous()), ptr(kscale), BN_EPS,
+                                              B * h * L, ptr(dgamma), ptr(dbeta), ptr(corr_a), ptr(corr_b), st), "lpm_mha_bn_corrections")
         dq, dk, dv = _dqkv_buffers(q)
         lib.check(_mha_bwd_fn(lib, bn=True)(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
                                    ptr(kscale), ptr(kshift), ptr(dq), ptr(dk), ptr(dv), dq.stride(1), ptr(corr_a), ptr(corr_b),
