@@ -179,6 +179,36 @@ class Watchdog:
                 os._exit(3)
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (torch.distributed.run, one
+    per GPU, rendezvous on 127.0.0.1) and return the worst exit code.  This parent never initialises the GPU -- it counts devices
+    with torch.cuda.device_count() only, which does not create a HIP context on this image -- and never execs: a process that has
+    touched the GPU must not be replaced.  Rank 0's JSON line reaches stdout through the inherited pipe."""
+    import socket
+    import subprocess
+    phase = "self-launch: device count"
+    share = os.environ.get("LPM_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        sys.stderr.write(f"[bench.py] phase '{phase}': --gpus {n} but this box exposes {have} GPU(s); one rank per GPU is "
+                         f"the only measured configuration (LPM_SHARE_GPU=1 shares GPU 0 over gloo, debug only)\n")
+        return 4
+    with socket.socket() as s:                       # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    phase = "self-launch: torch.distributed.run"
+    sys.stderr.write(f"[bench.py] {phase}: {' '.join(cmd)}\n")
+    sys.stderr.flush()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.stderr.write(f"[bench.py] phase '{phase}': the launcher returned {rc} (the failing rank's own message, with its phase "
+                         f"and last collective, is above)\n")
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +227,8 @@ def main():
                     help="N > 1 only: a rank that makes no progress for this long prints its phase and last collective and exits 3")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

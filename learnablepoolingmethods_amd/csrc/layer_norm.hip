@@ -14,6 +14,8 @@
 namespace lpm {
 
 constexpr int LN_NB = 16;   // chunks per example
+constexpr int LN_RS = 16;               // slices of the backward column reductions (ln_colreduce_kernel)
+constexpr int LN_CR_COUNTERS = 32;      // its per-call arrival counters: (F / 64 <= 16 column blocks) x 2 sets
 
 typedef __bf16 ln_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float ln_f32x2 __attribute__((ext_vector_type(2)));
@@ -141,10 +143,12 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, int L, int F,
                                                            float* __restrict__ partial, float* __restrict__ colpart,
-                                                           int64_t dy_batch) {
+                                                           int64_t dy_batch, unsigned* __restrict__ counters) {
     __shared__ float sh[4];
     __shared__ float4 cs[2][256];
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    // this call's arrival counters of ln_colreduce_kernel (two launches further down the same stream) start from zero
+    if (b == 0 && ch == 0 && tid < LN_CR_COUNTERS) counters[tid] = 0u;
     const int F4 = F / 4, RG = 256 / F4;
     const int c4 = tid % F4, rg = tid / F4;
     const float mean = stats[2 * b], rstd = stats[2 * b + 1];
@@ -267,15 +271,15 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
 // slot, and the workgroup that arrives last adds the LN_RS slices in fp64 IN SLICE ORDER (L2-bypassing loads): which workgroup is
 // last does not change a bit of the result.  (Before: two stages x two launches of ~5 us per reduction, four launches per
 // layer-norm backward with a bias; a single stage of 16-column workgroups read its 64-byte row pieces at 0.9 TB/s: 17 us.)
-// Counters: LN_CR_SLOTS sets handed out round-robin by the host, so that launches in flight on different streams never share one;
-// the last workgroup puts its counter back to zero.
-constexpr int LN_RS = 16;
-constexpr int LN_CR_SLOTS = 64, LN_CR_PER_SLOT = 32;       // (F / 64 <= 16 column blocks) x 2 sets
-__device__ unsigned ln_cr_counters[LN_CR_SLOTS * LN_CR_PER_SLOT];
+// Counters: per CALL, in the caller's workspace behind tmp ((F / 64 <= 16 column blocks) x 2 sets), zeroed by the call's first kernel
+// (ln_bwd_stats_kernel, stream order) -- no persistent device state: an aborted launch or any number of launches in flight on any
+// streams cannot leave a counter shared or non-zero.  The arrival is an acq_rel agent-scope fetch_add: the release orders this
+// workgroup's slice stores before its ticket, the acquire orders the last arriver's slice loads behind it.
 
 __global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restrict__ colpart, const float* __restrict__ biaspart, int nblk,
                                                            int F, float* __restrict__ tmp, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, float* __restrict__ dbias, int slot) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                           unsigned* __restrict__ counters) {
     typedef __attribute__((address_space(1))) float gfloat;
     typedef __attribute__((address_space(1))) unsigned gu32;
     __shared__ float sh[4][2][64];
@@ -314,11 +318,10 @@ __global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restri
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the storing wave drains its write-through stores
     __syncthreads();
-    gu32* cnt = (gu32*)(ln_cr_counters + slot * LN_CR_PER_SLOT + blockIdx.z * 16 + blockIdx.x);
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(LN_RS - 1);
+    gu32* cnt = (gu32*)(counters + blockIdx.z * 16 + blockIdx.x);
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(LN_RS - 1);
     __syncthreads();
     if (!last) return;
-    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (rg == 0 && c < F) {
         float* outs[2] = {second ? dbias : dgamma, dbeta};
         for (int a = 0; a < narr; ++a) {
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restri
 }  // namespace lpm
 
 extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
-    return ((size_t)B * lpm::LN_NB * 2 + (size_t)B * lpm::LN_NB * 3 * F + (size_t)lpm::LN_RS * 4 * F) * sizeof(float);
+    return ((size_t)B * lpm::LN_NB * 2 + (size_t)B * lpm::LN_NB * 3 * F + (size_t)lpm::LN_RS * 4 * F + lpm::LN_CR_COUNTERS) * sizeof(float);
 }
 
 #define LPM_LN_CHECK(name)                                                                                              \
@@ -438,13 +441,12 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, 
     const int64_t dyb = dy_batch_stride ? dy_batch_stride : (int64_t)L * F;
     LPM_REQUIRE(dyb >= (int64_t)L * F && dyb % 4 == 0 && ((uintptr_t)dy & 15) == 0, LPM_ERR_BADARG,
                 "lpm_layer_norm_act_bwd: dy_batch_stride must be >= L*F and a multiple of 4, dy 16-byte aligned");
-    hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart, dyb);
+    unsigned* counters = (unsigned*)(tmp + (size_t)LN_RS * 4 * F);
+    hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart, dyb, counters);
     hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
                        dr_extra, dyb, (unsigned short*)da_image);
-    static std::atomic<unsigned> next_slot{0};
-    const int slot = (int)(next_slot.fetch_add(1u) % LN_CR_SLOTS);
     hipLaunchKernelGGL(ln_colreduce_kernel, dim3((F + 63) / 64, LN_RS, bias ? 2 : 1), dim3(256), 0, s, colpart, biaspart, nblk, F, tmp, dgamma,
-                       dbeta, dbias, slot);
+                       dbeta, dbias, counters);
     return check_launch("lpm_layer_norm_act_bwd");
 }
 

@@ -147,28 +147,41 @@ class NetVladV1(models.BaseModel):
         if storage == "bf16" and (encoder or not add_batch_norm or not model_input.is_cuda):
             raise ValueError("netvlad_storage='bf16' is the gated-NetVLAD configuration: netvlad_encoder off, batch norm on, on the GPU")
 
-        reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training, storage)
-        if storage == "f32" or vs.default_store().summaries is not None:
-            vs.summary("input_bn", reshaped_input)
         max_frames, feature_size = iterations, model_input.shape[2]
         has_audio = feature_size > 1024                                      # App. C9
-
-        video_NetVLAD = NetVLAD(1024, max_frames, cluster_size, add_batch_norm, is_training, "netvlad_rgb_scope")
-        audio_NetVLAD = NetVLAD(128, max_frames, cluster_size // 4, add_batch_norm, is_training, "netvlad_audio_scope")
-        aff_v = aff_a = None
-        if (FLAGS.input_bn_grad_shortcut and add_batch_norm and is_training and reshaped_input.is_cuda and torch.is_grad_enabled()
+        shortcut = False
+        if (FLAGS.input_bn_grad_shortcut and add_batch_norm and is_training and model_input.is_cuda and torch.is_grad_enabled()
                 and ops.netvlad_input_shortcut_ok(max_frames, 1024, cluster_size)
                 and (not has_audio or ops.netvlad_input_shortcut_ok(max_frames, 128, cluster_size // 4))):
             # the frames need no gradient of their own, only input_bn's gamma / beta do: the pooling ops take those as inputs and
             # return their gradients in closed form (ops._NetVLAD.backward); the [B*S, 1152] input gradient is never formed
-            g_in, b_in, _, _ = layers.bn_variables("input_bn", feature_size, reshaped_input.device)
+            g_in, b_in, _, _ = layers.bn_variables("input_bn", feature_size, model_input.device)
             watch = getattr(g_in, "_lpm_gamma_watch", None)
             if watch is None:
                 watch = g_in._lpm_gamma_watch = _GammaWatch()
-            if watch.ok(g_in):
-                with torch.no_grad():
-                    rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
-                aff_v, aff_a = (g_in[0:1024], b_in[0:1024]), (g_in[1024:], b_in[1024:])
+            shortcut = watch.ok(g_in)
+        if storage == "bf16" and is_training and torch.is_grad_enabled() and not shortcut:
+            # bf16 storage writes the frames as operand tiles only and has no input-gradient path: once the closed-form input_bn
+            # gradients are off (min |gamma| below the watch's floor, or the flag), this step runs with fp32 storage -- same model,
+            # same variables, the explicit gradient path -- instead of reaching the pooling op with unmaterialised frames
+            if not getattr(NetVladV1, "_warned_bf16_fallback", False):
+                import warnings
+                NetVladV1._warned_bf16_fallback = True
+                warnings.warn("netvlad_storage='bf16': the closed-form input_bn gradients are unavailable; training steps fall "
+                              "back to fp32 storage (explicit input-gradient path)")
+            storage = "f32"
+
+        reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training, storage)
+        if storage == "f32" or vs.default_store().summaries is not None:
+            vs.summary("input_bn", reshaped_input)
+
+        video_NetVLAD = NetVLAD(1024, max_frames, cluster_size, add_batch_norm, is_training, "netvlad_rgb_scope")
+        audio_NetVLAD = NetVLAD(128, max_frames, cluster_size // 4, add_batch_norm, is_training, "netvlad_audio_scope")
+        aff_v = aff_a = None
+        if shortcut:
+            with torch.no_grad():
+                rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
+            aff_v, aff_a = (g_in[0:1024], b_in[0:1024]), (g_in[1024:], b_in[1024:])
         if aff_v is not None:
             pass
         elif has_audio and reshaped_input.is_cuda:

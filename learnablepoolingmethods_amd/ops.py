@@ -1240,6 +1240,12 @@ class _Projection(torch.autograd.Function):
             return dx, None
         skinny = x.shape[0] % 16 == 0 and dy.shape[1] % 32 == 0 and x.is_contiguous()
         factored = getattr(W, "_lpm_factored", None)
+        if factored is not None and factored.armed and factored.strict and not (skinny and x.is_cuda and not factored.puts):
+            # data parallel: the route selects between two different collectives (all-gather of the factors / all-reduce of bucket 0)
+            # and was agreed across the towers in Trainer.build -- a rank must never switch on local grounds (it would hang the job)
+            raise LpmError(f"hidden projection backward: the towers agreed on the factored gradient route at build time, but this "
+                           f"rank's step does not fit it (clips {x.shape[0]} not a multiple of 16, non-contiguous input, or the "
+                           f"weight used twice): use a fixed per-rank batch or FLAGS.hidden1_factored_update = False")
         if factored is not None and factored.armed and skinny and x.is_cuda and not factored.puts:
             # The trainer's optimiser consumes this gradient as the PRODUCT x^T dy (FactoredGradient): only the two operands leave.
             # (A batch that is not a multiple of 16 clips, or a second use of the weight, takes the generic route below and the
@@ -1849,8 +1855,9 @@ class FactoredGradient:
     start the towers' all-gather of the tiles (concatenating tile buffers along their leading step axis IS the product over all
     towers' clips: utils.combine_gradients' SUM), and ``clip_adam`` runs lpm_factored_clip_adam on the variable's arena slices."""
 
-    def __init__(self, on_put=None):
+    def __init__(self, on_put=None, strict=False):
         self.armed = False
+        self.strict = strict              # data parallel: the route is a cross-rank agreement, a step that does not fit it raises
         self.on_put = on_put
         self.clear()
 

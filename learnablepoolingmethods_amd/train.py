@@ -365,12 +365,24 @@ class Trainer:
         early = (lambda: self.sync.launch(0)) if self.sync.active else None
         h1 = "tower/hidden1_weights"
         self.factored = None
-        if (self.device.type == "cuda" and FLAGS.hidden1_factored_update and self.num_towers <= FLAGS.hidden1_factored_max_towers
-                and h1 in self.arena.views and self.arena.names[0] == h1
-                and self.arena.views[h1].dim() == 2 and self.arena.views[h1].shape[1] % 32 == 0):
+        want_factored = (self.device.type == "cuda" and FLAGS.hidden1_factored_update
+                         and self.num_towers <= FLAGS.hidden1_factored_max_towers
+                         and h1 in self.arena.views and self.arena.names[0] == h1
+                         and self.arena.views[h1].dim() == 2 and self.arena.views[h1].shape[1] % 32 == 0)
+        if self.sync.active:
+            # The route of hidden1_weights' gradient selects between two different collectives, so it is decided ONCE, here, from
+            # the per-rank batch size every rank was built with, and agreed across ranks: factored only if every rank wants it and
+            # all ranks hold the same 16-multiple of clips.  (Single rank: a step that does not fit falls back by itself.)
+            b = int(model_input_raw.shape[0])
+            flag = torch.tensor([1 if (want_factored and b % 16 == 0) else 0, b, -b], dtype=torch.int64, device=self.device)
+            _note("all_reduce(MIN) of the hidden1 gradient-route agreement (Trainer.build)")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            lo, hi = int(flag[1]), -int(flag[2])
+            want_factored = bool(flag[0]) and lo == hi
+        if want_factored:
             # hidden1_weights' gradient is consumed as the product it is (ops.FactoredGradient, lpm_factored_clip_adam): the towers
             # exchange its two skinny factors instead of all-reducing the gradient, which is never written
-            self.factored = ops.FactoredGradient(on_put=self._factored_put)
+            self.factored = ops.FactoredGradient(on_put=self._factored_put, strict=self.sync.active)
             self.arena.views[h1]._lpm_factored = self.factored
             n1 = self.arena.offsets_host[1]
             self._tail_offsets = (self.arena.offsets[1:] - n1).contiguous()
@@ -495,12 +507,18 @@ class Trainer:
         self._factored_work, self._factored_all = [], None
 
     # -- checkpoint / resume (train.py:501-515,593: Supervisor-saved variables + Adam slots + global_step) ------------------
-    def state_dict(self) -> Dict[str, object]:
+    def state_dict(self, sync: bool = False) -> Dict[str, object]:
         """Everything a resumed run needs, keyed by the reference's TF variable names (``tower/video_VLAD/cluster_weights``,
-        ``tower/video_attention/q/kernel``, ..., Adam slots as ``<name>/Adam`` and ``<name>/Adam_1``) plus ``global_step``."""
+        ``tower/video_attention/q/kernel``, ..., Adam slots as ``<name>/Adam`` and ``<name>/Adam_1``) plus ``global_step``.
+
+        No communication by default: a chief-only ``if rank == 0: trainer.save(path)`` (the reference's Supervisor / is_chief
+        pattern, train.py:501-515) must not enter a collective the other ranks never reach.  Data-parallel runs call
+        ``sync_moving_statistics()`` on EVERY rank first (or pass ``sync=True`` on every rank) so that the checkpoint holds the
+        towers' mean moving statistics."""
         if self.arena is None:
             raise RuntimeError("state_dict() needs a built trainer: run build() or one step first")
-        self.sync_moving_statistics()
+        if sync:
+            self.sync_moving_statistics()
         out: Dict[str, object] = {n: v.detach().clone().cpu() for n, v in self.store.vars.items()}
         for n in self.arena.names:
             a0, _ = self.arena.segment(n)
@@ -516,8 +534,8 @@ class Trainer:
         and keeps its OWN moving averages during training (the reference lets every tower's update op write the shared
         variables in undefined order, train.py:309-316); before anything reads them across ranks -- a checkpoint, an
         evaluation -- they are re-synchronised to the mean over ranks, which is what one shared variable receiving every
-        tower's ``decay``-weighted update converges to.  Called by ``state_dict``; call it yourself before a
-        multi-rank ``predict``."""
+        tower's ``decay``-weighted update converges to.  Call it on all ranks before a chief-only ``save`` and
+        before a multi-rank ``predict`` (``state_dict(sync=True)`` does it too; the default ``state_dict()`` never communicates)."""
         if self.sync is None or not self.sync.active:
             return
         stats = [v for n, v in sorted(self.store.vars.items()) if not self.store.trainable[n]]
@@ -525,7 +543,9 @@ class Trainer:
             return
         with torch.no_grad():
             flat = torch.cat([v.reshape(-1) for v in stats])
+            _note(f"all_reduce(SUM) of the batch-norm moving statistics ({flat.numel()} floats, Trainer.sync_moving_statistics)")
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            _note("all_reduce(SUM) of the batch-norm moving statistics: complete")
             flat /= self.num_towers
             off = 0
             for v in stats:
@@ -549,8 +569,8 @@ class Trainer:
                     self.arena.v[a0:a0 + k].copy_(torch.as_tensor(state[n + "/Adam_1"]).reshape(-1))
         self.global_step = int(state.get("global_step", self.global_step))
 
-    def save(self, path: str):
-        torch.save(self.state_dict(), path)
+    def save(self, path: str, sync: bool = False):
+        torch.save(self.state_dict(sync=sync), path)
 
     def restore(self, path: str):
         self.load_state_dict(torch.load(path, map_location="cpu"))

@@ -251,7 +251,7 @@ def multi_head_attention_bn(x, params, scope, num_heads, is_training, updates=No
 
 # Test hook: when a dict, every ReLU site of the encoders records its pre-activation (detached) under the name of the bias
 # variable that feeds it -- tests use it to keep their seeded weights away from pre-activations within rounding of zero, where
-# the derivative of ReLU is discontinuous and ANY two correct implementations may disagree (tests/_util.separate_relu_units).
+# the derivative of ReLU is discontinuous and ANY two correct implementations may disagree (oracle/test_weights.separate_relu_units).
 RELU_TAPS: Optional[Dict[str, torch.Tensor]] = None
 
 

@@ -26,7 +26,7 @@ CASES = {
 def make_case(name):
     """-> dict(cfg, x, nf, lab, params): the global batch (towers x per_tower clips) and fp64 weights with hidden1_weights in the
     well-conditioned regime (tests/test_gpu_models._well_conditioned) and every ReLU pre-activation of every tower kept away
-    from zero (tests/_util.separate_relu_units)."""
+    from zero (oracle/test_weights.separate_relu_units)."""
     c = CASES[name]
     cfg = O.OracleConfig(model="NetVladV1", **c["cfg"])
     B = c["per_tower"] * c["towers"]

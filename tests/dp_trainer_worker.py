@@ -2,9 +2,10 @@
 
     RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_trainer_worker.py <dir> <side_stream 0|1> [<factored 0|1>]
 
-All ranks share GPU 0 and exchange gradients over gloo (the boxes of this pool have one GPU; the code path -- arena buckets
-gathered and all-reduced from autograd hooks, early hidden1_weights bucket, per-variable clip + Adam on the summed arena -- is
-the one RCCL drives with one rank per GPU).  Reads <dir>/inputs.pt, writes <dir>/rank<r>.pt."""
+Default (LPM_DP_BACKEND unset or "gloo"): all ranks share GPU 0 and exchange gradients over gloo (the boxes of this pool have one
+GPU; the code path -- arena buckets gathered and all-reduced from autograd hooks, early hidden1_weights bucket, per-variable clip
++ Adam on the summed arena -- is the one RCCL drives with one rank per GPU).  LPM_DP_BACKEND=nccl: one rank per GPU (cuda:LOCAL_RANK)
+over RCCL, the measured configuration; needs torch.cuda.device_count() >= WORLD_SIZE.  Reads <dir>/inputs.pt, writes <dir>/rank<r>.pt."""
 import os
 import sys
 
@@ -20,9 +21,14 @@ def main():
     out_dir, side = sys.argv[1], sys.argv[2] == "1"
     factored = len(sys.argv) < 4 or sys.argv[3] == "1"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dev = torch.device("cuda", 0)
+    backend = os.environ.get("LPM_DP_BACKEND", "gloo")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)) if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                               # nccl == RCCL on ROCm; one rank per GPU
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from learnablepoolingmethods_amd import FLAGS, registry
     from learnablepoolingmethods_amd.train import Trainer
     inp = torch.load(os.path.join(out_dir, "inputs.pt"))
@@ -67,7 +73,7 @@ def main():
                                  summed=grads, before=before, adam=slots,
                                  gathered=sorted(tr.bucket_gather.gathered) if tr.bucket_gather is not None else []))
     res["local_stats"] = {n: v.detach().double().cpu() for n, v in tr.store.vars.items() if not tr.store.trainable[n]}
-    sd = tr.state_dict()                                # a collective: moving statistics averaged over ranks
+    sd = tr.state_dict(sync=True)                       # sync=True is a collective (every rank calls it): moving statistics averaged over ranks
     res["state"] = {n: (v.double() if torch.is_tensor(v) else v) for n, v in sd.items()}
     torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()

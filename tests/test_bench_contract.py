@@ -64,3 +64,63 @@ def test_bench_line_round2_objects():
     assert v2["dtype"] == "f32" and v2["config"]["global_batch"] == 80 and "configs[2]" in v2["metric"] and "NetVladV2" in v2["metric"]
     assert abs(v2["value"] - 80 / (v2["ms_per_step"] * 1e-3)) < 0.01 * v2["value"]
     assert v2["parity"]["ok"] is True and v2["parity"]["tolerance"] == 1e-3
+
+
+def test_bench_self_launch_spawns_before_any_gpu_call(monkeypatch):
+    """`python bench.py --gpus N` with no launcher: the parent must start the ranks as fresh children via
+    torch.distributed.run BEFORE anything initialises HIP -- only torch.cuda.device_count() is allowed -- relay the launcher's exit
+    code, and never exec.  Every GPU-initialising entry point is booby-trapped here."""
+    import importlib
+    import subprocess
+    import sys
+
+    import torch
+    bench = importlib.import_module("bench")
+
+    def boom(*a, **k):
+        raise AssertionError("the self-launching parent touched the GPU")
+    for name in ("is_available", "init", "set_device", "synchronize", "current_device", "get_device_properties"):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    for name in ("execv", "execve", "execvp", "execl", "execlp"):
+        monkeypatch.setattr(os, name, boom)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("LPM_SHARE_GPU", raising=False)
+    seen = {}
+
+    def fake_call(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    try:
+        bench.main()
+        raise AssertionError("main() must exit with the launcher's code")
+    except SystemExit as e:
+        assert e.code == 7                                  # the worst child rc, as torch.distributed.run reports it
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    # fewer GPUs than ranks: non-zero exit with the phase named, nothing spawned
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    seen.clear()
+    try:
+        bench.main()
+        raise AssertionError
+    except SystemExit as e:
+        assert e.code == 4 and not seen
+
+
+def test_bench_self_launch_on_this_box_names_its_phase():
+    """The real command on a box without (enough) GPUs: exit code 4 and the phase on stderr, no traceback."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LPM_SHARE_GPU")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 4 and "self-launch: device count" in r.stderr and "Traceback" not in r.stderr, r.stderr[-2000:]

@@ -215,6 +215,13 @@ def _stats_worker(rank, world, port, q):
         mv *= float(2 * rank + 1)
     tr.arena = train.ParameterArena(tr.store, first=["tower/hidden1_weights"])
     tr.sync = train.GradientSynchronizer(tr.arena.grad, [(0, tr.arena.total)])
+    if rank == 0:
+        # the reference's chief-only save (train.py:501-515): state_dict() alone never communicates -- rank 1 does not call it
+        # here, so a collective inside it would hang this test -- and it leaves the rank-local statistics untouched
+        chief = tr.state_dict()
+        assert torch.equal(chief["tower/input_bn/moving_mean"], torch.arange(5.0)) and torch.equal(mm, torch.arange(5.0))
+    tr.sync_moving_statistics()                  # the explicit collective, every rank
+    assert "moving statistics" in train.LAST_COLLECTIVE
     sd = tr.state_dict()
     q.put((rank, {n: v.numpy().copy() for n, v in sd.items() if "moving" in n}))
     dist.barrier()
@@ -223,7 +230,8 @@ def _stats_worker(rank, world, port, q):
 
 @pytest.mark.timeout(180)
 def test_moving_statistics_are_averaged_over_ranks_at_checkpoint():
-    """rank-local BN moving averages are re-synchronised (mean over ranks) when a checkpoint is taken."""
+    """rank-local BN moving averages are re-synchronised (mean over ranks) by the explicit
+    sync_moving_statistics() every rank calls before a checkpoint; state_dict() / save() themselves are communication-free."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

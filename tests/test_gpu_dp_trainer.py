@@ -3,7 +3,7 @@ take two ``Trainer.step``s of NetVladV1 on different shards, and everything they
 losses and predictions, weights, Adam slots, batch-norm moving statistics -- is compared with the reference's multi-tower step
 as the oracle restates it (``oracle.train_step(num_towers=2)``; train.py:266-336, utils.py:192-213) on the concatenated batch, and
 with the committed 2-tower fixture.  moe_l2 is raised to 1e-2 so that the regulariser's share of the MoE gradients (a13) is in
-plain sight; the weights keep every ReLU pre-activation away from zero (tests/_util.separate_relu_units), so gradients are held to
+plain sight; the weights keep every ReLU pre-activation away from zero (oracle/test_weights.separate_relu_units), so gradients are held to
 the north-star's 1e-3."""
 import os
 import socket
@@ -37,7 +37,7 @@ def _free_port():
     return p
 
 
-def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420, factored=True):
+def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420, factored=True, backend="gloo"):
     cfg = case["cfg"]
     torch.save(dict(cfg=dict(cfg.__dict__), x=case["x"], nf=case["nf"], lab=case["lab"], params=case["params"],
                     per_tower=case["per_tower"], steps=case["steps"]), tmp_path / "inputs.pt")
@@ -45,7 +45,7 @@ def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420, factored=True)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LPM_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   LPM_SHARE_GPU="0" if backend == "nccl" else "1", LPM_DP_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_trainer_worker.py"), str(tmp_path),
                                        "1" if side_stream else "0", "1" if factored else "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -141,6 +141,42 @@ def test_two_ranks_of_the_real_trainer_match_the_two_tower_oracle(name, side, fa
     ranks = _run_ranks(case, tmp_path, side, factored=factored)
     worst = _check(case, ref, ranks, factored=factored and case["per_tower"] % 16 == 0)
     print(f"[dp {name} side_stream={side} factored={factored}] worst summed-gradient error {worst[0]:.2e} ({worst[1]}); ReLU units moved: {case['relu_report']}")
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name,factored", [("blocks", True), ("blocks", False), ("toy", True)])
+def test_two_ranks_over_rccl_match_the_two_tower_oracle(name, factored, tmp_path):
+    """The measured configuration: one rank per GPU, `nccl` (= RCCL) backend -- bucketed all-reduce from hooks, the factor
+    all-gather, the arena broadcast -- against oracle.train_step(num_towers=2) (train.py:266-336, utils.py:192-213).  Needs two
+    GPUs: skipped on the single-GPU boxes of this pool (where the same code runs over gloo above)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL leg; the gloo legs above cover the same trainer code on one GPU)")
+    case, ref = _case(name)
+    ranks = _run_ranks(case, tmp_path, True, factored=factored, backend="nccl")
+    worst = _check(case, ref, ranks, factored=factored and case["per_tower"] % 16 == 0)
+    print(f"[dp/rccl {name} factored={factored}] worst summed-gradient error {worst[0]:.2e} ({worst[1]})")
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launch_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher: the parent spawns the ranks before it touches the GPU and relays rank 0's JSON
+    line.  On a box with two GPUs this is the RCCL path; on a single-GPU box the same command must exit non-zero with the phase
+    named, and the debug switch LPM_SHARE_GPU=1 (two ranks on GPU 0 over gloo) must complete."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup-seconds", "0",
+           "--no-cpu-baseline"]
+    two = torch.cuda.device_count() >= 2
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if not two:
+        assert r.returncode == 4 and "self-launch: device count" in r.stderr, r.stderr[-2000:]
+        r = subprocess.run(cmd, env=dict(env, LPM_SHARE_GPU="1"), capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 160 and d["scaling"] == "weak" and d["value"] > 0
 
 
 @pytest.mark.timeout(900)

@@ -90,7 +90,7 @@ def test_netvladv2_forward_with_dropout_mask():
 def _full_size_compare(name, cfg, B, seed, dev, scale_hidden1=True, dropout_masks=None, grad_tol=1e-3, **kw):
     """One training step at a BASELINE configuration's real layer sizes through the Trainer against the fp64 oracle: the named
     intermediates of the forward (the product reports them as summaries), loss, predictions and the gradient of EVERY variable.
-    The seeded weights keep all ReLU pre-activations away from zero (tests/_util.separate_relu_units), so the whole-model
+    The seeded weights keep all ReLU pre-activations away from zero (oracle/test_weights.separate_relu_units), so the whole-model
     gradients are held to ``grad_tol`` = the north-star's 1e-3 in the Frobenius norm of each variable."""
     from learnablepoolingmethods_amd import registry
     from learnablepoolingmethods_amd.train import Trainer
@@ -176,7 +176,7 @@ def _well_conditioned(p):
 
 def _train_compare(name, cfg, feat, B, MF, steps, dev, tol=1e-3, **kw):
     """``tol`` applies to whole-model gradients in the Frobenius norm of each variable (the north-star's 1e-3).  The seeded
-    weights keep every ReLU pre-activation away from zero (tests/_util.separate_relu_units): a unit within fp32 rounding of
+    weights keep every ReLU pre-activation away from zero (oracle/test_weights.separate_relu_units): a unit within fp32 rounding of
     zero takes its mask from the last bit of whichever arithmetic computed it and alone moves the filter_output kernel
     gradient by 1/sqrt(tokens*units) ~ 2e-3 -- round 1 carried a 5e-3 tolerance for that."""
     from learnablepoolingmethods_amd import registry
@@ -518,6 +518,49 @@ def test_cfg5_layer_sizes_reduced_batch(storage):
         worst = max(worst, (e, n))
         assert e <= gtol, f"cfg-5 {storage} gradient {n}: relative L2 error {e:.3e} > {gtol:.1e}"
     print(f"[cfg-5 {storage} B={B}] " + ", ".join(f"{k}: {v:.1e}" for k, v in errs.items()) + f"; worst gradient {worst[0]:.2e} ({worst[1]})")
+
+
+def test_cfg5_bf16_storage_survives_the_gamma_watch_switching_off():
+    """once min |gamma| of input_bn falls below the watch's floor the closed-form gamma / beta gradients are switched
+    off; under bf16 storage (frames written as operand tiles only, no input-gradient path) the step must then fall back to fp32
+    storage -- explicit gradient path, same variables -- instead of reaching the pooling op with unmaterialised frames.  The
+    fallback step is held to the fp64 oracle at the fp32 tolerance."""
+    import warnings
+    from learnablepoolingmethods_amd import FLAGS
+    from learnablepoolingmethods_amd import frame_level_models as flm
+    dev = cuda()
+    from learnablepoolingmethods_amd import registry
+    from learnablepoolingmethods_amd.train import Trainer
+    sizes = dict(iterations=300, cluster_size=512, hidden_size=128, encoder=False)     # bf16 storage: D, K multiples of 128 (audio K/4 = 128)
+    cfg = O.OracleConfig(model="NetVladV1", vocab_size=200, base_learning_rate=2e-4, moe_num_mixtures=4, **sizes)
+    B = 4
+    x, nf, lab = O.make_synthetic_batch(B, 300, 1152, cfg.vocab_size, seed=7)
+    p = _well_conditioned({k: v.double() for k, v in O.init_params(cfg, 1152, seed=1007).items()})
+    p["input_bn/gamma"] = p["input_bn/gamma"].clone()
+    p["input_bn/gamma"][5] = 0.05                    # below _GammaWatch.FLOOR
+    pred, loss, grads, _ = O.loss_and_grads(p, x.double(), nf, lab, cfg)
+    try:
+        FLAGS.moe_num_mixtures = 4
+        FLAGS.netvlad_storage = "bf16"
+        flm.NetVladV1._warned_bf16_fallback = False
+        tr = Trainer(registry.get_model("NetVladV1"), vocab_size=cfg.vocab_size, batch_size=B, base_learning_rate=2e-4, device=dev,
+                     model_kwargs=sizes)
+        tr.build(x, nf, lab)
+        tr.store.load({"tower/" + k: v for k, v in p.items()})
+        for v in tr.store.vars.values():
+            if hasattr(v, "_lpm_gamma_watch"):
+                del v._lpm_gamma_watch
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = tr.step(x, nf, lab)
+        assert any("fall" in str(m.message) and "fp32 storage" in str(m.message) for m in w), [str(m.message) for m in w]
+    finally:
+        FLAGS.reset()
+    assert_close(out["predictions"], pred, tol=1e-3, what="predictions")
+    gscale = max(float(g.abs().max()) for g in grads.values())
+    for n in O.trainable_names(p, cfg):
+        e = rel_l2(tr.gradient("tower/" + n), grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5)
+        assert e <= 1e-3, f"gradient {n}: relative L2 error {e:.3e}"
 
 
 def test_cfg5_full_batch_properties():
