@@ -53,8 +53,10 @@ enum {
                                   writes; with LPM_VLAD_NRM_RAW); implied by LPM_VLAD_TILES_BF16 in lpm_vlad_aggregate_bwd_tiles   */
     LPM_VLAD_RAW_KMAJOR = 128, /* lpm_vlad_aggregate_bwd_tiles: `dout` and `nrm` are k-major [B, K, D] and `nrm` holds the un-normalised
                                   sums lpm_vlad_aggregate_raw_kmajor_fwd stored (split-bf16, no-input-gradient form only)        */
-    LPM_VLAD_DEBUG_FALLBACK = 256 /* lpm_vlad_aggregate_fused_fwd, tests only: one workgroup of every clip behaves as if its wait
+    LPM_VLAD_DEBUG_FALLBACK = 256, /* lpm_vlad_aggregate_fused_fwd, tests only: one workgroup of every clip behaves as if its wait
                                   for the clip had timed out, so the follow-up finalize pass runs for every clip             */
+    LPM_VLAD_WIDE_ALL = 512,   /* lpm_vlad_aggregate_kmajor_scaled_fwd (K = 256), tests / A-B: every clip runs as wide items ...    */
+    LPM_VLAD_WIDE_NONE = 1024  /* ... / no clip does (default: whole rounds of clips wide, the rest as 128 x 128 items)          */
 };
 
 int lpm_version(void);
@@ -152,6 +154,10 @@ int lpm_assign_gemm_tiles_fwd(const void* xr, const void* wt, int B, int T, int 
                               lpm_stream_t stream);
 int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T, int D, int K, float* dx, int64_t lddx,
                                  lpm_stream_t stream);
+/* y[M,N] (row stride ldo) = x . w for an encoder dense layer (transformer_utils.py:559-561,583,701-711) on the same tile GEMM:
+ * xr = row tiles of x [M,Kd] (lpm_split_rows_tiles with B = 1, T = M), wt = weight tiles of w [Kd,N]; Kd %% 16 == 0, N %% 32 == 0.
+ * form 0 / 2: 128-row workgroups where the shape allows, 1: 64-row workgroups. */
+int lpm_dense_tiles_fwd(const void* xr, const void* wt, int M, int Kd, int N, float* y, int64_t ldo, int form, lpm_stream_t stream);
 /* dw[N1,N2] = x^T . dy for a skinny batch R (multiple of 16): xt / dyt = weight tiles of x [R,N1] and dy [R,N2]
  * (lpm_split_weight_tiles, not transposed).  The hidden1 weight gradient (frame_level_models.py:2314-2319 backward). */
 int lpm_skinny_weight_grad_tiles(const void* xt, const void* dyt, int R, int N1, int N2, float* dw, lpm_stream_t stream);
@@ -224,6 +230,14 @@ int lpm_vlad_aggregate_raw_kmajor_fwd(const void* at, const void* xt, const floa
                                       float* raw_kmajor, float* asum, float* colsq_part, lpm_stream_t stream);
 int lpm_vlad_row_scales(const float* colsq_part, int P, int B, int K, float* scale, float* colsq, float* csq, float* gsq,
                         lpm_stream_t stream);
+/* K2 + row scales in ONE launch (vlad_kmajor.hip; frame_level_models.py:2803-2822 for the lazily normalised k-major descriptor):
+ * raw_kmajor [B,K,D] un-normalised residual sums, scale [B,K] with descriptor[b,k,:] = raw[b,k,:] * scale[b,k], and asum / colsq /
+ * csq [B,K], gsq [B] for the backward.  K = 256: "wide" workgroups (all clusters x 128 columns) for whole rounds of clips, 128 x 128
+ * items for the rest; other K (multiples of 128, <= 1024): 128 x 128 items.  workspace: lpm_vlad_kmajor_workspace_bytes(B, D, K). */
+size_t lpm_vlad_kmajor_workspace_bytes(int B, int D, int K);
+int lpm_vlad_aggregate_kmajor_scaled_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                         float* raw_kmajor, float* scale, float* asum, float* colsq, float* csq, float* gsq,
+                                         void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 /* ... and with the SOFTMAX inside the aggregation kernel: frame_level_models.py:2798-2822 as one launch (+ a small row-statistics launch
  * before it and lpm_vlad_row_scales after it).  logits [B*T, K] fp32 = K1's output, scale / shift [K] = cluster_bn folded (either may
  * be NULL; shift = the bias without batch norm); per 16-frame step the workgroup's raw logits arrive by LDS-DMA next to the frame tiles

@@ -24,6 +24,8 @@ LPM_VLAD_TILES_BF16 = 32
 LPM_VLAD_NRM_BF16 = 64
 LPM_VLAD_RAW_KMAJOR = 128
 LPM_VLAD_DEBUG_FALLBACK = 256
+LPM_VLAD_WIDE_ALL = 512
+LPM_VLAD_WIDE_NONE = 1024
 
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header
 _f = C.c_void_p      # device pointer
@@ -55,6 +57,7 @@ SIGNATURES = {
     "lpm_split_weight_tiles": (_i, [_f, _i, _i, _i, _f, _f]),
     "lpm_assign_gemm_tiles_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f]),
     "lpm_assign_gemm_tiles_bwd_dx": (_i, [_f, _f, _i, _i, _i, _i, _f, _l, _f]),
+    "lpm_dense_tiles_fwd": (_i, [_f, _f, _i, _i, _i, _f, _l, _i, _f]),
     "lpm_skinny_weight_grad_tiles": (_i, [_f, _f, _i, _i, _i, _f, _f]),
     "lpm_assign_gemm_tiles_bwd_dw_workspace_bytes": (_s, [_i, _i, _i, _i]),
     "lpm_assign_gemm_tiles_bwd_dw": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _s, _f]),
@@ -88,6 +91,8 @@ SIGNATURES = {
     "lpm_vlad_smx_supported": (_i, [_i, _i, _i]),
     "lpm_vlad_aggregate_raw_kmajor_smx_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_vlad_row_scales": (_i, [_f, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "lpm_vlad_kmajor_workspace_bytes": (_s, [_i, _i, _i]),
+    "lpm_vlad_aggregate_kmajor_scaled_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_split_rows_scaled": (_i, [_f, _l, _l, _i, _f, _f, _f]),
     "lpm_layer_norm_act_fwd_rs": (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _s, _f]),
     "lpm_vlad_fused_supported": (_i, [_i, _i]),

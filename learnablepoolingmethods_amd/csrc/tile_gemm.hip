@@ -661,6 +661,24 @@ extern "C" int lpm_assign_gemm_tiles_fwd_bf16(const void* xr, const void* wt, in
     return assign_gemm_tiles_fwd_impl(xr, wt, B, T, D, K, logits_bf16, partial, 1, stream);
 }
 
+// y[M, N] (row stride ldo) = x . w for a dense layer (transformer_utils.py:559-561,583,701-711): xr = row tiles of x [M, Kd]
+// (lpm_split_rows_tiles with B = 1, T = M), wt = weight tiles of w [Kd, N].  form 0: by shape; 1: 64-row workgroups; 2: 128-row.
+extern "C" int lpm_dense_tiles_fwd(const void* xr, const void* wt, int M, int Kd, int N, float* y, int64_t ldo, int form,
+                                   lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(xr && wt && y, LPM_ERR_BADARG, "lpm_dense_tiles_fwd: null pointer");
+    LPM_REQUIRE(M > 0 && Kd > 0 && N > 0 && Kd % 16 == 0 && N % 32 == 0 && ldo >= N, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_dense_tiles_fwd: need Kd %% 16 == 0, N %% 32 == 0 (Kd=%d N=%d)", Kd, N);
+    const int MT = row_tiles_per_clip(M), DS = Kd / 16, NT = N / 32;
+    TileGemmArgs g{};
+    g.a = (const uint4*)xr; g.a_tile = (int64_t)DS * 128; g.a_step = 128; g.a_batch = (int64_t)MT * DS * 128; g.a_tiles = MT;
+    g.b = (const uint4*)wt; g.b_tile = 128; g.b_step = (int64_t)NT * 128; g.b_batch = 0; g.b_tiles = NT;
+    g.rb_per_batch = MT / 2; g.steps_per_split = DS; g.total_steps = DS;
+    g.out = y; g.ldo = ldo; g.out_batch = (int64_t)M * ldo; g.out_split = 0;
+    g.rows_valid = M; g.cols_valid = N;
+    return tg_launch<TG_EPI_STORE>(g, 1, 1, (hipStream_t)stream, "lpm_dense_tiles_fwd", 2, 0, form == 1 ? 0 : 1, 2);
+}
+
 extern "C" int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T, int D, int K, float* dx, int64_t lddx,
                                             lpm_stream_t stream) {
     using namespace lpm;

@@ -59,6 +59,10 @@ VLAD_SOFTMAX_FUSED = os.environ.get("LPM_VLAD_SOFTMAX_FUSED", "0") == "1"
 FRAME_ROW_TILES = os.environ.get("LPM_FRAME_ROW_TILES", "0") == "1"
 VLAD_FUSED_DEBUG_FALLBACK = False     # tests: drive every clip through the fused kernel's time-out path + follow-up finalize
 
+# The lazily normalised k-major descriptor from ONE launch (lpm_vlad_aggregate_kmajor_scaled_fwd, vlad_kmajor.hip: K2 on wide 256 x 128
+# workgroup items + the row scales by the clip's last workgroup).  Built and measured in round 3, NOT faster than the two-launch chain
+# lpm_vlad_aggregate_raw_kmajor_fwd + lpm_vlad_row_scales (78 vs 74 us on one box, tools/time_k2_forms.py): off.
+VLAD_KMAJOR_SCALED = os.environ.get("LPM_VLAD_KMAJOR_SCALED", "0") == "1"
 # Matrix-core arithmetic of the soft-assignment GEMM K1: "bf16x3" (split-bf16 tiles on the bf16 pipe, default where
 # D %% 16 == 0 and K <= 512) or "f32" (exact fp32 MFMA).
 ASSIGN_PRECISION = os.environ.get("LPM_ASSIGN_PRECISION", "bf16x3")
@@ -421,6 +425,19 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
                 raise LpmError("internal: lazy descriptor without the LDS-shared aggregation form")
             raw = _empty((B, K, D), x)
             P = D // 128
+            if VLAD_KMAJOR_SCALED:
+                # K2 and the row scales in one launch (vlad_kmajor.hip): wide workgroups at K = 256, the last workgroup of a clip
+                # turns the clip's partial norms into its row scales
+                rs = _empty((B, K), x)
+                gsq = _empty((B,), x)
+                wsb = lib._lpm_vlad_kmajor_workspace_bytes(B, D, K)
+                ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+                with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+                    lib.check(lib._lpm_vlad_aggregate_kmajor_scaled_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags & LPM_VLAD_RESIDUAL,
+                                                                        ptr(raw), ptr(rs), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq),
+                                                                        ptr(ws), wsb, st), "lpm_vlad_aggregate_kmajor_scaled_fwd")
+                raw._lpm_row_scale = rs
+                return raw, raw, asum, colsq, csq, gsq, xt
             part = _empty((B, P, K), x)
             with _timed("vlad_aggregate_fwd", (B, T, D, K)):
                 lib.check(lib._lpm_vlad_aggregate_raw_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags & LPM_VLAD_RESIDUAL,

@@ -562,6 +562,75 @@ def test_softmax_inside_the_aggregation_kernel_is_bitwise_the_two_kernel_chain(B
     assert_close(out[True][1], a.sum(1), tol=2e-5, what="fused-softmax assignment sums")
 
 
+@pytest.mark.parametrize("B,T,D,K,mode", [(80, 300, 1024, 256, "rounds"), (5, 300, 1024, 256, "all"), (5, 300, 1024, 256, "none"),
+                                          (3, 47, 256, 128, "rounds"), (2, 64, 128, 512, "rounds"), (67, 33, 1024, 256, "rounds")])
+def test_kmajor_scaled_aggregation_in_one_launch(B, T, D, K, mode):
+    """lpm_vlad_aggregate_kmajor_scaled_fwd (vlad_kmajor.hip: K2 on wide workgroups at K = 256 + the row scales by the last workgroup
+    of every clip, ONE launch) against the chain it replaces -- lpm_vlad_aggregate_raw_kmajor_fwd + lpm_vlad_row_scales -- on the same
+    assignment tiles, and against fp64 (frame_level_models.py:2803-2822).  Every MFMA sees the same operands in the same order in
+    both, so with 128 x 128 items only ("none", and any K != 256) the sums and the assignment sums must be IDENTICAL; a wide item adds
+    its assignment sums in another (fixed) order, and the column norms are summed over d in another fixed order in every form:
+    last-bit differences, held to 2e-6 of the tensor scale."""
+    from learnablepoolingmethods_amd import _capi, ops
+    from learnablepoolingmethods_amd.ops import ptr, stream_ptr
+    dev = cuda()
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(B * T + K + 1)
+    x = torch.randn(B * T, D, generator=g)
+    x = x / x.norm(dim=1, keepdim=True)
+    logits = (torch.randn(B * T, K, generator=g) * 3).to(dev)
+    scale = (1 + 0.3 * torch.randn(K, generator=g)).to(dev)
+    shift = (0.2 * torch.randn(K, generator=g)).to(dev)
+    centres = (0.05 * torch.randn(D, K, generator=g)).to(dev)
+    xd = x.to(dev)
+    xt = torch.empty(lib._lpm_xt_bytes(B, T, D) // 4, dtype=torch.int32, device=dev)
+    lib.check(lib._lpm_split_frames(ptr(xd), D, B, T, D, ptr(xt), stream_ptr()), "lpm_split_frames")
+    at = torch.empty(lib._lpm_at_bytes(B, T, K) // 4, dtype=torch.int32, device=dev)
+    lib.check(lib._lpm_assign_tiles(ptr(logits), ptr(scale), ptr(shift), B, T, K, ops.LPM_VLAD_SOFTMAX | ops.LPM_VLAD_RESIDUAL, ptr(at),
+                                    stream_ptr()), "lpm_assign_tiles")
+    P = D // 128
+    nan = float("nan")
+    # the two-launch chain
+    raw0 = torch.full((B, K, D), nan, device=dev)
+    asum0, part0 = torch.empty(B, K, device=dev), torch.empty(B, P, K, device=dev)
+    rs0, colsq0, csq0 = (torch.full((B, K), nan, device=dev) for _ in range(3))
+    gsq0 = torch.full((B,), nan, device=dev)
+    lib.check(lib._lpm_vlad_aggregate_raw_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, ops.LPM_VLAD_RESIDUAL, ptr(raw0), ptr(asum0),
+                                                     ptr(part0), stream_ptr()), "raw_kmajor")
+    lib.check(lib._lpm_vlad_row_scales(ptr(part0), P, B, K, ptr(rs0), ptr(colsq0), ptr(csq0), ptr(gsq0), stream_ptr()), "row_scales")
+    # one launch (twice into the same buffers: the per-call counters must start from zero each time)
+    fl = ops.LPM_VLAD_RESIDUAL | {"rounds": 0, "all": _capi.LPM_VLAD_WIDE_ALL, "none": _capi.LPM_VLAD_WIDE_NONE}[mode]
+    wsb = lib._lpm_vlad_kmajor_workspace_bytes(B, D, K)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        raw1 = torch.full((B, K, D), nan, device=dev)
+        asum1, rs1, colsq1, csq1 = (torch.full((B, K), nan, device=dev) for _ in range(4))
+        gsq1 = torch.full((B,), nan, device=dev)
+        lib.check(lib._lpm_vlad_aggregate_kmajor_scaled_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, fl, ptr(raw1), ptr(rs1), ptr(asum1),
+                                                            ptr(colsq1), ptr(csq1), ptr(gsq1), ptr(ws), wsb, stream_ptr()), "kmajor_scaled")
+    torch.cuda.synchronize()
+    pairs = (("un-normalised sums", raw1, raw0), ("assignment sums", asum1, asum0), ("row scales", rs1, rs0), ("column norms", colsq1, colsq0),
+             ("csq", csq1, csq0), ("gsq", gsq1, gsq0))
+    wide = K == 256 and (mode == "all" or (mode == "rounds" and B >= 64))
+    for what, a, b in pairs:
+        assert torch.isfinite(a).all(), what
+        if wide or what not in ("un-normalised sums", "assignment sums"):
+            assert_close(a, b, tol=2e-6, what=what)      # (the column norms are summed over d in another fixed order than the chain's)
+        else:
+            assert torch.equal(a, b), f"{what}: differs from the two-launch chain (max abs {float((a - b).abs().max()):.3e})"
+    if wide and mode == "rounds":           # the clips past the last whole round ran as 128 x 128 items: sums identical to the chain's
+        nl = (B // 64) * 64
+        assert torch.equal(raw1[nl:], raw0[nl:]) and torch.equal(asum1[nl:], asum0[nl:])
+    z = logits.double().cpu() * scale.double().cpu() + shift.double().cpu()
+    a = torch.softmax(z, dim=1).reshape(B, T, K)
+    U = torch.einsum("btk,btd->bkd", a, x.double().reshape(B, T, D)) - a.sum(1).unsqueeze(2) * centres.double().cpu().t().unsqueeze(0)
+    assert_close(raw1, U, tol=2e-5, what="un-normalised sums vs fp64")
+    n = U.pow(2).sum(2)
+    nrm = U / n.clamp_min(1e-12).sqrt().unsqueeze(2)
+    want = nrm / nrm.pow(2).sum((1, 2)).clamp_min(1e-12).sqrt().view(B, 1, 1)
+    assert_close(raw1.double().cpu() * rs1.double().cpu().unsqueeze(2), want, tol=2e-5, what="scaled descriptor vs fp64")
+
+
 @pytest.mark.parametrize("M,C,relu", [(24000, 4096, True), (1200, 256, True), (777, 128, False), (20000, 1024, False)])
 def test_bias_act_in_place(M, C, relu):
     """ops.bias_act: tf.layers.dense's bias add (+ ReLU) as one in-place pass; backward = ReLU mask from the saved output + the bias
