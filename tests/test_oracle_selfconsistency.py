@@ -96,3 +96,165 @@ def test_fp32_vs_fp64_full_model():
     a = O.model_forward(p32, x, nf, cfg, True)
     b = O.model_forward(p64, x.double(), nf, cfg, True)
     assert (a.double() - b).abs().max().item() < 1e-5
+
+
+# ---- round 3: the numpy restatement beyond NetVLAD (hand-derived backward) against lpm_oracle.py (torch autograd), fp64 ------------
+def _t(a, grad=False):
+    return torch.tensor(a, dtype=torch.float64, requires_grad=grad)
+
+
+def _close(a, b, what, rtol=1e-8, atol=1e-10):
+    np.testing.assert_allclose(a.detach().numpy() if torch.is_tensor(a) else a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+def test_layer_norm_is_joint_over_all_non_batch_axes():
+    """tf.contrib.layers.layer_norm defaults: ONE mean / variance per example over (L, F) -- not per token (App. B)."""
+    rng = np.random.default_rng(11)
+    x, gamma, beta, dy = rng.standard_normal((3, 5, 8)), 1 + 0.3 * rng.standard_normal(8), 0.2 * rng.standard_normal(8), rng.standard_normal((3, 5, 8))
+    y, cache = R.layer_norm_fwd(x, gamma, beta)
+    xt, p = _t(x, True), {"s/gamma": _t(gamma, True), "s/beta": _t(beta, True)}
+    yt = O.layer_norm(xt, p, "s")
+    _close(yt, y, "layer_norm forward")
+    # per-example statistics of the normalised tensor: mean 0, variance 1 over all 40 entries jointly
+    z = (y - beta) / gamma
+    np.testing.assert_allclose(z.mean((1, 2)), 0, atol=1e-12)
+    np.testing.assert_allclose((z ** 2).mean((1, 2)), 1, rtol=1e-9)
+    yt.backward(_t(dy))
+    dx, dg, db = R.layer_norm_bwd(dy, cache)
+    _close(xt.grad, dx, "layer_norm dx")
+    _close(p["s/gamma"].grad, dg, "layer_norm dgamma")
+    _close(p["s/beta"].grad, db, "layer_norm dbeta")
+
+
+def test_batch_norm_rank_2_3_4_and_moving_variance_feed():
+    """slim.batch_norm: channel = last axis at every rank; the moving variance is fed the UNBIASED estimate on the fused (rank 2 / 4)
+    path and the biased one at rank 3 (App. B)."""
+    rng = np.random.default_rng(12)
+    for shape in ((9, 6), (3, 5, 6), (2, 3, 4, 6)):
+        x, gamma, beta, dy = rng.standard_normal(shape), 1 + 0.3 * rng.standard_normal(6), 0.2 * rng.standard_normal(6), rng.standard_normal(shape)
+        y, cache, fed = R.batch_norm_fwd(x, gamma, beta)
+        xt, p = _t(x, True), {"s/gamma": _t(gamma, True), "s/beta": _t(beta, True)}
+        upd = {}
+        yt = O.batch_norm(xt, p, "s", True, upd)
+        _close(yt, y, f"batch_norm forward {shape}")
+        _close(upd["s/moving_mean"], fed["moving_mean"], "moving mean feed")
+        _close(upd["s/moving_variance"], fed["moving_variance"], "moving variance feed")
+        n = x.size // 6
+        biased = x.reshape(-1, 6).var(0)
+        want = biased * n / (n - 1) if len(shape) in (2, 4) else biased
+        np.testing.assert_allclose(fed["moving_variance"], want, rtol=1e-12)
+        yt.backward(_t(dy))
+        dx, dg, db = R.batch_norm_bwd(dy, cache)
+        _close(xt.grad, dx, f"batch_norm dx {shape}")
+        _close(p["s/gamma"].grad, dg, "batch_norm dgamma")
+        _close(p["s/beta"].grad, db, "batch_norm dbeta")
+
+
+def _encoder_params(rng, F, ff, sid, bn=None, final=None, L=None):
+    final = F if final is None else final
+    p = {"q/kernel": rng.standard_normal((F, F)) / F ** 0.5, "k/kernel": rng.standard_normal((F, F)) / F ** 0.5,
+         "v/kernel": rng.standard_normal((F, F)) / F ** 0.5, "output_transform/kernel": rng.standard_normal((F, F)) / F ** 0.5,
+         "output_transform/bias": 0.1 * rng.standard_normal(F),
+         "LayerNorm/gamma": 1 + 0.2 * rng.standard_normal(F), "LayerNorm/beta": 0.1 * rng.standard_normal(F),
+         f"filter_output{sid}/kernel": rng.standard_normal((F, ff)) / F ** 0.5, f"filter_output{sid}/bias": 0.3 * rng.standard_normal(ff),
+         f"ff_output{sid}/kernel": rng.standard_normal((ff, final)) / ff ** 0.5, f"ff_output{sid}/bias": 0.3 * rng.standard_normal(final)}
+    if bn:
+        for name, c in (("logits_bn", L), ("attention_bn", F), ("filter_bn", ff), ("feed_output_bn", final)):
+            p[name + "/gamma"], p[name + "/beta"] = 1 + 0.2 * rng.standard_normal(c), 0.1 * rng.standard_normal(c)
+    else:
+        for name in ("LayerNorm_1", "LayerNorm_2"):
+            p[name + "/gamma"], p[name + "/beta"] = 1 + 0.2 * rng.standard_normal(F), 0.1 * rng.standard_normal(F)
+    return p
+
+
+def test_transformer_encoder_v1_forward_and_every_gradient():
+    """TransformerEncoder (transformer_utils.py:399-413, 696-715): three layer norms, ReLU on BOTH dense layers of the FFN, the FFN's
+    input feeding three places -- numpy chain rule vs torch autograd."""
+    rng = np.random.default_rng(13)
+    B, L, F, h, ff = 3, 6, 16, 4, 24
+    p = _encoder_params(rng, F, ff, "encode1")
+    x, dout = rng.standard_normal((B, L, F)), rng.standard_normal((B, L, F))
+    out, cache = R.transformer_encoder_fwd(x, p, h, "encode1")
+    pt = {"enc/" + k: _t(v, True) for k, v in p.items()}
+    xt = _t(x, True)
+    ot = O.transformer_encoder(xt, pt, "enc", h, "encode1")
+    _close(ot, out, "V1 encoder forward")
+    ot.backward(_t(dout))
+    dx, g = R.transformer_encoder_bwd(dout, cache, p)
+    _close(xt.grad, dx, "V1 encoder dx")
+    assert set(g) == set(p)
+    for k in p:
+        _close(pt["enc/" + k].grad, g[k], f"V1 encoder d {k}")
+
+
+def test_transformer_encoder_mod_v2_forward_and_every_gradient():
+    """TransformerEncoderMod (transformer_utils.py:443-457, 634-677, 737-766): batch norm over the KEY-POSITION channel of the rank-4
+    logits, no q scaling, dropout rate 0.9 through a given keep mask, two batch norms in the FFN, no residual around it."""
+    rng = np.random.default_rng(14)
+    B, L, F, h, ff, final = 3, 7, 16, 2, 24, 5
+    p = _encoder_params(rng, F, ff, "encode", bn=True, final=final, L=L)
+    x, dout = rng.standard_normal((B, L, F)), rng.standard_normal((B, L, final))
+    keep = (rng.random((B, L, F)) >= 0.5).astype(np.float64)
+    out, cache, feeds = R.transformer_encoder_mod_fwd(x, p, h, "encode", keep, rate=0.9)
+    pt = {"enc/" + k: _t(v, True) for k, v in p.items()}
+    xt = _t(x, True)
+    upd = {}
+    ot = O.transformer_encoder_mod(xt, pt, "enc", h, "encode", True, 0.9, _t(keep), upd)
+    _close(ot, out, "V2 encoder forward")
+    for scope, f in feeds.items():
+        _close(upd[f"enc/{scope}/moving_mean"], f["moving_mean"], scope + " moving mean feed")
+        _close(upd[f"enc/{scope}/moving_variance"], f["moving_variance"], scope + " moving variance feed")
+    assert feeds["logits_bn"]["moving_mean"].shape == (L,), "logits_bn's channel is the key position"
+    ot.backward(_t(dout))
+    dx, g = R.transformer_encoder_mod_bwd(dout, cache, p)
+    _close(xt.grad, dx, "V2 encoder dx")
+    assert set(g) == set(p)
+    for k in p:
+        _close(pt["enc/" + k].grad, g[k], f"V2 encoder d {k}", rtol=1e-7, atol=1e-9)
+
+
+def test_netvlad_atten_cluster_forward_and_every_gradient():
+    """NetVladAttenCluster (video_pooling_modules.py:1617-1663): encoder similarities (not a distribution) -> residual sums against
+    cluster_centers -> L2 per cluster over F -> f-major flatten -> L2; also against the reference's literal [B, N, F, C] formulation."""
+    rng = np.random.default_rng(15)
+    B, S, F, K = 2, 5, 32, 6                    # heads = F // 16 = 2 (video_pooling_modules.py:1613)
+    enc = _encoder_params(rng, F, 4 * F, "encode", bn=True, final=K, L=S)
+    p = {"cluster_attention/" + k: v for k, v in enc.items()}
+    p["cluster_centers"] = rng.standard_normal((F, K)) / F ** 0.5
+    x, dout = rng.standard_normal((B * S, F)), rng.standard_normal((B, F * K))
+    keep = (rng.random((B, S, F)) >= 0.4).astype(np.float64)
+    out, cache, _ = R.netvlad_atten_cluster_fwd(x, p, S, F // 16, keep, rate=0.9)
+    pt = {"s/" + k: _t(v, True) for k, v in p.items()}
+    xt = _t(x, True)
+    ot = O.netvlad_atten_cluster_forward(xt, pt, "s", S, True, 0.9, _t(keep))
+    _close(ot, out, "V2 aggregator forward")
+    with torch.no_grad():
+        literal = O.netvlad_atten_cluster_forward(_t(x), pt, "s", S, True, 0.9, _t(keep), explicit_4d=True)
+    _close(literal, out, "V2 aggregator forward, the reference's 4-d formulation")
+    ot.backward(_t(dout))
+    dx, g = R.netvlad_atten_cluster_bwd(dout, cache, p)
+    _close(xt.grad, dx, "V2 aggregator dx", rtol=1e-7, atol=1e-9)
+    assert set(g) == set(p)
+    for k in p:
+        _close(pt["s/" + k].grad, g[k], f"V2 aggregator d {k}", rtol=1e-7, atol=1e-9)
+
+
+def test_combine_clip_and_learning_rate():
+    """utils.py:170-213 (SUM over towers, per-variable clip_by_norm) and train.py:244-252 (staircase decay on examples seen)."""
+    rng = np.random.default_rng(16)
+    towers = [{"a": rng.standard_normal((4, 3)), "b": 5 * rng.standard_normal(7)} for _ in range(3)]
+    s = R.combine_gradients(towers)
+    st = O.combine_gradients([{k: _t(v) for k, v in t.items()} for t in towers])
+    ct = O.clip_gradient_norms(st, 1.0)
+    for k in s:
+        _close(st[k], s[k], "combine " + k)
+        np.testing.assert_allclose(s[k], towers[0][k] + towers[1][k] + towers[2][k], rtol=1e-12)
+        c = R.clip_by_norm(s[k], 1.0)
+        _close(ct[k], c, "clip " + k)
+        assert np.linalg.norm(c) <= 1.0 + 1e-12
+    small = 0.01 * towers[0]["a"]
+    np.testing.assert_array_equal(R.clip_by_norm(small, 1.0), small)          # below the bound: untouched
+    cfg = O.OracleConfig(base_learning_rate=2e-4, learning_rate_decay=0.85, learning_rate_decay_examples=4000000)
+    for step, bs, n in ((0, 80, 1), (49999, 80, 1), (50000, 80, 1), (6250, 80, 8), (31250, 80, 8)):
+        assert R.learning_rate(2e-4, 0.85, 4000000, step, bs, n) == O.learning_rate(cfg, step, bs, n)
+    assert R.learning_rate(2e-4, 0.85, 4000000, 6250, 80, 8) == 2e-4 * 0.85
