@@ -363,10 +363,15 @@ def main():
                 tt = [a.elapsed_time(b) for (n, d, a, b) in timeline if n == nm and d[2] in (1024, 256)]
                 if tt:
                     roof[nm + "_avg_ms"] = round(sum(tt) / len(tt), 4)
-            pmc = os.path.join(ROOT, "profiles", "k2_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            if os.path.exists(pmc) and args.config == "cfg2":
+            # HBM bytes per launch of this kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+            # tools/pmc_a5.sh -> tools/pmc_to_json.py, the guide's gfx950 corrections); the file names its commit
+            pmc = os.path.join(ROOT, "profiles", f"a5_hbm_traffic_{args.config}.json")
+            if os.path.exists(pmc):
                 try:
-                    roof["traffic"] = json.load(open(pmc)).get("bytes_per_launch")
+                    pj = json.load(open(pmc))
+                    roof["traffic"] = pj.get("k2_bytes_per_launch")
+                    roof["traffic_source"] = f"profiles/a5_hbm_traffic_{args.config}.json (commit {pj.get('commit')}): {pj.get('k2_kernel')}"
+                    roof["a5_chain_traffic"] = pj.get("chain_bytes_per_launch")
                 except Exception:
                     pass
             # the WHOLE a5 function (frame_level_models.py:2798-2822: BN-affine + softmax -> residual aggregation -> both

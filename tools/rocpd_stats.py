@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd sqlite database (--kernel-trace) into a per-kernel table
-(name, calls, total ms, avg us, % of GPU time).  Usage: rocpd_stats.py results.db [out.md]"""
+(name, calls, total ms, avg us, % of GPU time) -- EVERY kernel, no cut.  Usage: rocpd_stats.py results.db [out.md [steps]]
+steps: the number of training steps the trace covers (warm-up + spin-up + timed), to print dispatches per step."""
 import re
 import sqlite3
 import sys
 
 
-def main(path, out=None):
+def main(path, out=None, steps=None):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -14,9 +15,11 @@ def main(path, out=None):
     rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                        f"from kernels group by {name_col} order by sum(end-start) desc").fetchall()
     total = sum(r[2] for r in rows)
-    lines = [f"# rocprofv3 --kernel-trace summary of {path}", "", f"total kernel time {total/1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches", "",
+    nd = sum(r[1] for r in rows)
+    per = f" = {nd / int(steps):.0f} dispatches per step over {steps} steps (incl. the first, variable-creating ones)" if steps else ""
+    lines = [f"# rocprofv3 --kernel-trace summary of {path}", "", f"total kernel time {total/1e6:.3f} ms over {nd} dispatches{per}; {len(rows)} distinct kernels, all listed", "",
              "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
-    for n, c, s, a, mn, mx in rows[:60]:
+    for n, c, s, a, mn, mx in rows:
         n = n.replace("(anonymous namespace)::", "")           # (otherwise at::native::(anonymous namespace)::X is cut at its first parenthesis)
         n = re.sub(r"\(.*", "", n)
         n = n.replace("void ", "")[:110]
@@ -28,4 +31,4 @@ def main(path, out=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:4])
