@@ -158,6 +158,19 @@ int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T,
  * xr = row tiles of x [M,Kd] (lpm_split_rows_tiles with B = 1, T = M), wt = weight tiles of w [Kd,N]; Kd %% 16 == 0, N %% 32 == 0.
  * form 0 / 2: 128-row workgroups where the shape allows, 1: 64-row workgroups. */
 int lpm_dense_tiles_fwd(const void* xr, const void* wt, int M, int Kd, int N, float* y, int64_t ldo, int form, lpm_stream_t stream);
+/* FeedForwardNetwork's first dense layer (transformer_utils.py:701-711) and its backward on the 256-row tile GEMM with operand-image
+ * epilogues: the [M, 4F] tensor between the two dense layers exists only as the split-bf16 image the GEMMs downstream read.
+ *   lpm_dense_tiles_supported    : M %% 256 == 0, Kd %% 16 == 0, Kd >= 256, N %% 256 == 0
+ *   lpm_dense_tiles_act_image_fwd: out3 [M,3N] bf16 = [hi|lo|hi] of relu(x . w + bias)   (xr row tiles of x [M,Kd], wt weight tiles of w)
+ *   lpm_dense_tiles_relu_bwd_image: g = (dy . w^T) * [act > 0] -> out3 [M,3N] = [hi|hi|lo] of g, dbias [N] = column sums of g
+ *                                  (dyr row tiles of dy [M,Kd]; wtt = lpm_split_weight_tiles(w [N,Kd], transposed = 1); act3 = the forward's image)
+ *   lpm_image_row_tiles          : an operand image [M,3K] (order 0 [hi|lo|hi], 1 [hi|hi|lo]) -> row tiles (lpm_row_tiles_bytes(1, M, K)) */
+int lpm_dense_tiles_supported(int M, int Kd, int N);
+int lpm_dense_tiles_act_image_fwd(const void* xr, const void* wt, const float* bias, int M, int Kd, int N, void* out3, lpm_stream_t stream);
+size_t lpm_dense_tiles_relu_bwd_workspace_bytes(int M, int N);
+int lpm_dense_tiles_relu_bwd_image(const void* dyr, const void* wtt, const void* act3, int M, int Kd, int N, void* out3, float* dbias,
+                                   void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+int lpm_image_row_tiles(const void* x3, int M, int K, int order, void* out, lpm_stream_t stream);
 /* dw[N1,N2] = x^T . dy for a skinny batch R (multiple of 16): xt / dyt = weight tiles of x [R,N1] and dy [R,N2]
  * (lpm_split_weight_tiles, not transposed).  The hidden1 weight gradient (frame_level_models.py:2314-2319 backward). */
 int lpm_skinny_weight_grad_tiles(const void* xt, const void* dyt, int R, int N1, int N2, float* dw, lpm_stream_t stream);

@@ -58,6 +58,11 @@ SIGNATURES = {
     "lpm_assign_gemm_tiles_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f]),
     "lpm_assign_gemm_tiles_bwd_dx": (_i, [_f, _f, _i, _i, _i, _i, _f, _l, _f]),
     "lpm_dense_tiles_fwd": (_i, [_f, _f, _i, _i, _i, _f, _l, _i, _f]),
+    "lpm_dense_tiles_supported": (_i, [_i, _i, _i]),
+    "lpm_dense_tiles_act_image_fwd": (_i, [_f, _f, _f, _i, _i, _i, _f, _f]),
+    "lpm_dense_tiles_relu_bwd_workspace_bytes": (_s, [_i, _i]),
+    "lpm_dense_tiles_relu_bwd_image": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f, _s, _f]),
+    "lpm_image_row_tiles": (_i, [_f, _i, _i, _i, _f, _f]),
     "lpm_skinny_weight_grad_tiles": (_i, [_f, _f, _i, _i, _i, _f, _f]),
     "lpm_assign_gemm_tiles_bwd_dw_workspace_bytes": (_s, [_i, _i, _i, _i]),
     "lpm_assign_gemm_tiles_bwd_dw": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _s, _f]),

@@ -85,6 +85,18 @@ struct TileGemmArgs {
     float* adam_v;
     const float* adam_factor;
     float adam_lr_t, adam_b1, adam_b2, adam_eps;
+    // STORE, 256-row form only: the result leaves as a split-bf16 operand IMAGE [rows][3 * cols_valid] (split_gemm.hip's format for
+    // the library GEMMs) instead of fp32 -- the [M, 4F] pre-activation of FeedForwardNetwork (transformer_utils.py:701-711) and its
+    // gradient never make their fp32 round trip through HBM:
+    //   img_kind 1 (activation): v = relu(acc + img_bias[col])                  -> planes [hi | lo | hi]
+    //   img_kind 2 (gradient):   v = acc where the forward activation was > 0 (img_mask = ITS image: the hi plane's sign) else 0
+    //                            -> planes [hi | hi | lo];  img_colpart [gridDim.x * 2][cols_valid] = per-128-row-group column sums
+    //                            of v (the bias gradient's partial sums)
+    unsigned short* img;
+    const float* img_bias;
+    const unsigned short* img_mask;
+    float* img_colpart;
+    int img_kind;
     float* stats;              // STORE, optional: [gridDim.x][2][cols_valid] per-workgroup column (sum, sum of squares)
     // SOFTMAX_BWD (needs gridDim.y == gridDim.z == 1): out = dlogit~ with a = softmax(logits*scale + shift) recomputed
     const float* logits;       // [batch * rows_valid + row][cols_valid]
@@ -102,5 +114,9 @@ int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t s
 int tile_gemm_adam(const TileGemmArgs& g, hipStream_t stream, const char* what);      // 64 x 128 tiles, one batch, one split, split-bf16
 int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what, int planes = 2);
 int tile_gemm_ntw(int cols);
+// 256-row form with an image epilogue (g.img, g.img_kind, ...): one batch, one split, columns a multiple of 256, row tiles a multiple of 8
+int tile_gemm_image(const TileGemmArgs& g, hipStream_t stream, const char* what);
+int tile_gemm_image_form();
+int tile_gemm_image_row_groups(int M);
 
 }  // namespace lpm

@@ -22,8 +22,12 @@ static size_t tg_lds_bytes(int ntw, int epi) {
 // batches are ONE flat sequence (a_batch == a_tiles * a_tile, b_batch == 0, no second operand pair, one split) and
 // blockIdx.x counts groups of four consecutive tiles, which may straddle two batches.  24 KB staged per 128 x 256 x 16
 // products (131 MFMA-flop per byte against 77 for the 64-row form), NS-stage ring with NS - 2 younger steps in flight.
-template <int NTW, int EPI, int MW, int NS, int PL>
-__global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmArgs g) {
+// RTW = 4 (MW = 2, STORE only): 256 rows per workgroup -- every wave owns FOUR row tiles x NTW column tiles (128 x 64 accumulators,
+// 128 registers): 32 KB staged per 256 x 256 x 16 products (262 MFMA-flop per byte) and 12 KB of fragment reads per 24 MFMAs and
+// wave instead of 8 KB per 12 -- the LDS read volume is what holds the 128-row form at ~1.1 PFLOP/s on the encoder's dense shapes.
+template <int NTW, int EPI, int MW, int NS, int PL, int RTW = 2>
+__global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3) ? 4 : 2) void tile_gemm_kernel(const TileGemmArgs g) {
+    static_assert(RTW == 2 || (RTW == 4 && MW == 2 && EPI == TG_EPI_STORE && NS >= 4), "four row tiles per wave: pipelined 128-row form only");
     static_assert(MW == 1 || EPI == TG_EPI_STORE, "the 128-row form has the store epilogue only");
     static_assert(EPI != TG_EPI_ADAM || (NTW == 1 && PL == 2), "the Adam epilogue: 64 x 128 tiles of split-bf16 operands");
     static_assert(PL == 1 || PL == 2, "planes");
@@ -31,7 +35,7 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
     // form has the plane); no second operand pair.
     constexpr int NTB = 4 * NTW;                   // column tiles per workgroup
     constexpr int NWV = 4 * MW;                    // waves per workgroup
-    constexpr int NRP = 4 * MW;                    // row-tile pieces per stage (2 MW tiles x 2 planes)
+    constexpr int NRP = 2 * RTW * MW;              // row-tile pieces per stage (RTW MW tiles x 2 planes)
     constexpr int NP = NRP + 2 * NTB;              // 1 KB pieces per stage
     constexpr int PW = NP / NWV;                   // pieces per wave per stage
     static_assert(NP % NWV == 0, "pieces must divide over the waves");
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
                 src[j] = g.a + batch * g.a_batch + t * g.a_tile + step0 * g.a_step + pl + lane;
                 src2[j] = PL == 2 ? g.a2 + batch * g.a2_batch + t * g.a2_tile + pl + lane : nullptr;
             } else {
-                src[j] = g.a + (int64_t)(lid * 2 * MW + (p >> 1)) * g.a_tile + step0 * g.a_step + pl + lane;
+                src[j] = g.a + (int64_t)(lid * RTW * MW + (p >> 1)) * g.a_tile + step0 * g.a_step + pl + lane;
                 src2[j] = nullptr;
             }
             sstep[j] = g.a_step;
@@ -97,9 +101,9 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
         }
     };
 
-    f32x16 acc[2][NTW];
+    f32x16 acc[RTW][NTW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < RTW; ++m)
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
@@ -124,7 +128,40 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nstep) issue(s);
-    if constexpr (MW == 1) {
+    if constexpr (MW == 2 && NS == 3) {
+        // 128-row form, TWO workgroups per CU (72 KB ring, <= 128 VGPRs): no software pipelining inside a workgroup -- the other
+        // workgroup's MFMAs cover this one's barrier, DMA issue and fragment reads, and its epilogue runs under this one's main loop
+        for (int s = 0; s < nstep; ++s) {
+            if (s + 1 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // one younger step in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + NS - 1 < nstep) issue(s + NS - 1);
+            const tg_u32x4* f = reinterpret_cast<const tg_u32x4*>(smem + (s % NS) * STAGE) + lane;
+            tg_u32x4 ah[2], al[2], bh[NTW], bl[NTW];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = f[((rg * 2 + m) * 2 + 0) * 64];
+                al[m] = f[((rg * 2 + m) * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                bh[n] = f[(NRP + (cw * NTW + n) * 2 + 0) * 64];
+                bl[n] = f[(NRP + (cw * NTW + n) * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < (PL == 2 ? 3 : 2); ++t) {
+                if (PL == 1 && t == 1 && !(2 * s + 1 < nred)) break;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        if (PL == 2) acc[m][n] = tg_mfma(t == 2 ? al[m] : ah[m], t == 1 ? bl[n] : bh[n], acc[m][n]);
+                        else acc[m][n] = tg_mfma(t ? al[m] : ah[m], t ? bl[n] : bh[n], acc[m][n]);
+                    }
+            }
+        }
+    } else if constexpr (MW == 1) {
         for (int s = 0; s < nstep; ++s) {
             if (s + 1 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // one younger step in flight
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -161,14 +198,14 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
         // at the top of step s says: step s + 1 has landed for everyone, everyone holds the fragments of step s in
         // registers, everyone is done with step s - 1 -> stage (s - 1) % NS takes step s + NS - 1.  NS - 2 steps are in
         // flight behind the one being read.  (nstep >= NS is the launcher's condition.)
-        static_assert(NS == 4 || NS == 5, "ring depth of the 128-row form");
-        struct Frag { tg_u32x4 ah[2], al[2], bh[NTW], bl[NTW]; };
+        static_assert(NS == 4 || NS == 5, "ring depth of the pipelined 128-row form");
+        struct Frag { tg_u32x4 ah[RTW], al[RTW], bh[NTW], bl[NTW]; };
         auto read_frags = [&](int s, Frag& fr) {
             const tg_u32x4* f = reinterpret_cast<const tg_u32x4*>(smem + (s % NS) * STAGE) + lane;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                fr.ah[m] = f[((rg * 2 + m) * 2 + 0) * 64];
-                fr.al[m] = f[((rg * 2 + m) * 2 + 1) * 64];
+            for (int m = 0; m < RTW; ++m) {
+                fr.ah[m] = f[((rg * RTW + m) * 2 + 0) * 64];
+                fr.al[m] = f[((rg * RTW + m) * 2 + 1) * 64];
             }
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
@@ -195,7 +232,7 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
 #pragma unroll
                 for (int n = 0; n < NTW; ++n)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
+                    for (int m = 0; m < RTW; ++m) {
                         if (PL == 2) acc[m][n] = tg_mfma(t == 2 ? cur.al[m] : cur.ah[m], t == 1 ? cur.bl[n] : cur.bh[n], acc[m][n]);
                         else acc[m][n] = tg_mfma(t ? cur.al[m] : cur.ah[m], t ? cur.bl[n] : cur.bh[n], acc[m][n]);
                     }
@@ -229,7 +266,7 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
         constexpr int C4 = 32 * NTW;
         float* es = reinterpret_cast<float*>(smem) + rg * 32 * ESTR;      // one staging tile per row group
         float* ob = g.out + batch * g.out_batch + split * g.out_split;
-        if (g.stats) {
+        if (RTW == 2 && g.stats) {
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
                 const int col = (cb * NTB + cw * NTW + n) * 32 + l31;
@@ -253,9 +290,88 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
         }
         __syncthreads();                       // nothing in flight (the last step waited for vmcnt(0)): the ring is free
         const int tl = tid & 255;
+        if constexpr (RTW == 4 || (MW == 2 && NS == 3)) {
+            if (g.img) {
+                // image epilogue: thread = 8 fixed columns (c8) x rows (tl >> 5) + 8 k of every 32-row pass; 16-byte stores per plane
+                const int c8 = (tl & 31) * 8, rbase = tl >> 5;
+                const int gcol = cb * NTB * 32 + c8;
+                const bool colok = gcol < N;
+                float bias8[8], colacc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; colacc[e] = 0.f; }
+                if (g.img_kind == 1 && colok) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(g.img_bias + gcol), b1 = *reinterpret_cast<const float4*>(g.img_bias + gcol + 4);
+                    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+                }
+#pragma unroll
+                for (int m = 0; m < RTW; ++m) {
+                    if (m) __syncthreads();
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) es[mfma32_row(r, lane) * ESTR + (cw * NTW + n) * 32 + l31] = acc[m][n][r];
+                    __syncthreads();
+                    const int ft = lid * RTW * MW + rg * RTW + m;
+                    const int tb = ft / g.a_tiles;
+                    const int row0 = (ft - tb * g.a_tiles) * 32;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = rbase + 8 * k, grow = row0 + row;
+                        if (grow < g.rows_valid && colok) {
+                            const int64_t R = (int64_t)tb * g.rows_valid + grow;
+                            const float4 a0 = *reinterpret_cast<const float4*>(es + row * ESTR + c8);
+                            const float4 a1 = *reinterpret_cast<const float4*>(es + row * ESTR + c8 + 4);
+                            float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                            if (g.img_kind == 1) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + bias8[e], 0.f);
+                            } else {
+                                const uint4 hm = *reinterpret_cast<const uint4*>(g.img_mask + R * 3 * N + gcol);      // hi plane of the activation
+                                const unsigned mw[4] = {hm.x, hm.y, hm.z, hm.w};
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const unsigned ah = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                                    const bool on = (ah != 0u) && !(ah & 0x8000u);                  // activation > 0
+                                    v[e] = on ? v[e] : 0.f;
+                                    colacc[e] += v[e];
+                                }
+                            }
+                            uint4 hi, lo;
+                            tg_split8(v, hi, lo);
+                            unsigned short* rowp = g.img + R * 3 * N + gcol;
+                            const tg_u32x4 hv = {hi.x, hi.y, hi.z, hi.w}, lv = {lo.x, lo.y, lo.z, lo.w};
+                            if (g.nt_store) {
+                                __builtin_nontemporal_store(hv, reinterpret_cast<tg_u32x4*>(rowp));
+                                __builtin_nontemporal_store(g.img_kind == 1 ? lv : hv, reinterpret_cast<tg_u32x4*>(rowp + N));
+                                __builtin_nontemporal_store(g.img_kind == 1 ? hv : lv, reinterpret_cast<tg_u32x4*>(rowp + 2 * (int64_t)N));
+                            } else {
+                                *reinterpret_cast<tg_u32x4*>(rowp) = hv;
+                                *reinterpret_cast<tg_u32x4*>(rowp + N) = g.img_kind == 1 ? lv : hv;
+                                *reinterpret_cast<tg_u32x4*>(rowp + 2 * (int64_t)N) = g.img_kind == 1 ? hv : lv;
+                            }
+                        }
+                    }
+                }
+                if (g.img_kind == 2) {
+                    // column sums of the masked gradient over this row group's 32 RTW rows: the 8 row classes of a column group meet
+                    // in LDS and are added in a fixed order
+                    __syncthreads();
+                    float* red = reinterpret_cast<float*>(smem);               // [MW][8][256]
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) red[(rg * 8 + rbase) * 256 + c8 + e] = colacc[e];
+                    __syncthreads();
+                    float sres = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sres += red[(rg * 8 + j) * 256 + tl];
+                    const int col = cb * NTB * 32 + tl;
+                    if (col < N) g.img_colpart[(int64_t)(lid * MW + rg) * N + col] = sres;
+                }
+                return;
+            }
+        }
         float ssq = 0.f;                                            // g.sumsq: this thread's share of the tile's sum of squares
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < RTW; ++m) {
             if (m) __syncthreads();
 #pragma unroll
             for (int n = 0; n < NTW; ++n)
@@ -263,7 +379,7 @@ __global__ __launch_bounds__(256 * MW, 2) void tile_gemm_kernel(const TileGemmAr
                 for (int r = 0; r < 16; ++r) es[mfma32_row(r, lane) * ESTR + (cw * NTW + n) * 32 + l31] = acc[m][n][r];
             __syncthreads();
             // MW == 2: tile index in the flat sequence -> (batch, row tile within the batch)
-            const int ft = lid * 2 * MW + rg * 2 + m;
+            const int ft = lid * RTW * MW + rg * RTW + m;
             const int tb = MW == 1 ? 0 : ft / g.a_tiles;
             const int row0 = MW == 1 ? rb * 64 + m * 32 : (ft - tb * g.a_tiles) * 32;
             float* obt = ob + (int64_t)tb * g.out_batch;
@@ -418,13 +534,15 @@ static int tg_wide_enabled() {
 
 // The 128-row form applies when the row tiles of all batches form one flat sequence that divides into groups of four, the
 // B operand is shared, there is one reduction segment and one 256-column block: K1's forward at K = 256.
-static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw, int planes) {
+static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw, int planes, int tiles_per_wg = 4) {
     return tg_wide_enabled() && ntw == 2 && (g.cols_valid <= 256 || g.cols_valid % 256 == 0) && splits == 1 && g.steps2 == 0 &&
            g.a2 == nullptr && g.b_batch == 0 &&
-           g.a_batch == (int64_t)g.a_tiles * g.a_tile && g.rb_per_batch * 2 == g.a_tiles && ((int64_t)nbatch * g.a_tiles) % 4 == 0 &&
+           g.a_batch == (int64_t)g.a_tiles * g.a_tile && g.rb_per_batch * 2 == g.a_tiles && ((int64_t)nbatch * g.a_tiles) % tiles_per_wg == 0 &&
            g.steps_per_split >= (planes == 1 ? 32 : 16);     // (ring stages >= the ring depth)
 }
 
+// allow_wide: 0 = 64-row form, 1 = 128-row form (one workgroup per CU, software-pipelined, 4-stage ring) where the shape allows,
+// 2 = 128-row form with a 3-stage ring and two workgroups per CU, 3 = 256-row form (four row tiles per wave; no statistics)
 template <int EPI, int PL>
 static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override,
                         int timing_tag, int allow_wide) {
@@ -447,8 +565,9 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
         set_error("%s: the gradient-consuming epilogues need the 64-row form, one batch, one split", what);
         return LPM_ERR_BADARG;
     }
-    const bool wide = EPI == TG_EPI_STORE && allow_wide && tg_wide_ok(g, nbatch, splits, ntw, PL);
-    dim3 grid((unsigned)(wide ? nbatch * g.a_tiles / 4 : nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)),
+    const bool wide4 = EPI == TG_EPI_STORE && allow_wide == 3 && !g.stats && !g.out_bf16 && tg_wide_ok(g, nbatch, splits, ntw, PL, 8);
+    const bool wide = wide4 || (EPI == TG_EPI_STORE && allow_wide && allow_wide != 3 && tg_wide_ok(g, nbatch, splits, ntw, PL));
+    dim3 grid((unsigned)(wide ? nbatch * g.a_tiles / (wide4 ? 8 : 4) : nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)),
               (unsigned)splits);
     TileGemmArgs gl = g;
     if (!wide && g.cols_inner) {
@@ -460,7 +579,9 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
         gl.cols_inner = 0;
     }
     constexpr int WIDE_NS = 4;
-    const size_t lds = wide ? (size_t)WIDE_NS * (8 + 8 * ntw) * 1024 : tg_lds_bytes(ntw, EPI);
+    const bool wide2 = wide && allow_wide == 2;
+    const size_t lds = wide4 ? (size_t)WIDE_NS * (16 + 8 * ntw) * 1024
+                             : (wide ? (size_t)(wide2 ? 3 : WIDE_NS) * (8 + 8 * ntw) * 1024 : tg_lds_bytes(ntw, EPI));
 #define LPM_TG_LAUNCH_K(KERN, THREADS)                                                                                 \
     do {                                                                                                               \
         auto kern = KERN;                                                                                              \
@@ -479,7 +600,9 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
     if constexpr (EPI == TG_EPI_ADAM) {
         LPM_TG_LAUNCH(1);
     } else {
-        if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS, PL>), 512);
+        if (wide4) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS, PL, 4>), 512);
+        else if (wide2) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 3, PL>), 512);
+        else if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS, PL>), 512);
         else if (ntw == 1) LPM_TG_LAUNCH(1);
         else if (ntw == 2) LPM_TG_LAUNCH(2);
         else LPM_TG_LAUNCH(4);
@@ -511,6 +634,31 @@ int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream,
     return tg_launch<TG_EPI_SOFTMAX_BWD>(g, nbatch, 1, stream, what, 0, 0, 0, planes);
 }
 int tile_gemm_ntw(int cols) { return tg_ntw(cols); }
+int tile_gemm_image(const TileGemmArgs& g, hipStream_t stream, const char* what) {
+    if (!g.img || (g.img_kind != 1 && g.img_kind != 2) || (g.img_kind == 1 && !g.img_bias) || (g.img_kind == 2 && (!g.img_mask || !g.img_colpart)) ||
+        g.cols_valid % 256 != 0 || ((uintptr_t)g.img & 15) != 0 || g.stats || g.sumsq || g.accumulate) {
+        set_error("%s: the image epilogue needs its operands, 16-byte aligned, and a multiple of 256 columns", what);
+        return LPM_ERR_BADARG;
+    }
+    if (!tg_wide_ok(g, 1, 1, 2, 2, 8)) {
+        set_error("%s: the image epilogue runs on the 128- / 256-row forms only (row tiles a multiple of 8, >= 16 reduction steps)", what);
+        return LPM_ERR_UNSUPPORTED_SHAPE;
+    }
+    TileGemmArgs gl = g;
+    gl.out = reinterpret_cast<float*>(g.img);      // (the fp32 output checks of the launcher: an aligned non-null pointer; never written)
+    gl.ldo = 4; gl.out_batch = 0; gl.out_split = 0;
+    // non-temporal stores: the 0.5 GB image is read back by the next GEMM long after it has left the caches (-6 us of 520 measured;
+    // LPM_DENSE_IMG_NT=0: plain stores, A/B)
+    static const int nt = [] { const char* e = getenv("LPM_DENSE_IMG_NT"); return (e && e[0] == '0') ? 0 : 1; }();
+    gl.nt_store = nt;
+    return tg_launch_pl<TG_EPI_STORE, 2>(gl, 1, 1, stream, what, 2, 0, tile_gemm_image_form() == 3 ? 2 : 3);
+}
+// 4 (default): 256-row workgroups, one per CU; 3: 128-row workgroups, two per CU (their epilogues overlap the neighbour's main loop)
+int tile_gemm_image_form() {
+    static const int form = [] { const char* e = getenv("LPM_DENSE_IMG_FORM"); return (e && e[0] == '3') ? 3 : 4; }();
+    return form;
+}
+int tile_gemm_image_row_groups(int M) { return tile_gemm_image_form() == 3 ? M / 64 : M / 128; }
 
 // [B*T, C] fp32 (row stride ldx) -> row tiles [b][mt][cs][plane][lane]; mt < 2*ceil(T/64), rows >= T are zero.
 __global__ __launch_bounds__(256) void split_rows_tiles_kernel(const float* __restrict__ x, int64_t ldx, int B, int T, int C, int MT,
@@ -576,6 +724,37 @@ __global__ __launch_bounds__(256) void tg_reduce_splits_kernel(const float4* __r
         s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
     out[i] = s;
+}
+
+// colpart [nblk][N] -> out [N]  (fp64 accumulation; 1024 threads per 16 columns, partial_colsums16)
+__global__ __launch_bounds__(1024) void tg_colsum_reduce_kernel(const float* __restrict__ colpart, int nblk, int N, float* __restrict__ out) {
+    double s, q;
+    int c;
+    partial_colsums16(colpart, nblk, (int64_t)N, 0, N, s, q, c);
+    if (threadIdx.x < 16 && c < N) out[c] = (float)s;
+}
+
+// split-bf16 operand image [M][3K] (split_gemm.hip; lo plane lo_off elements into the row) -> row tiles [mt][cs][plane][lane]
+__global__ __launch_bounds__(256) void image_row_tiles_kernel(const unsigned short* __restrict__ x3, int64_t M, int K, int lo_off, int MT,
+                                                              uint4* __restrict__ out) {
+    const int CS = K / 16;
+    const int64_t total = (int64_t)MT * CS * 64;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(w & 63);
+        const int64_t t = w >> 6;
+        const int cs = (int)(t % CS);
+        const int64_t row = (t / CS) * 32 + (lane & 31);
+        const int c = cs * 16 + 8 * (lane >> 5);
+        uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
+        if (row < M) {
+            const unsigned short* p = x3 + row * 3 * K + c;
+            hi = *reinterpret_cast<const uint4*>(p);
+            lo = *reinterpret_cast<const uint4*>(p + lo_off);
+        }
+        const int64_t base = t * 128 + lane;
+        out[base] = hi;
+        out[base + 64] = lo;
+    }
 }
 
 static inline int row_tiles_per_clip(int T) { return 2 * ((T + 63) / 64); }
@@ -662,7 +841,8 @@ extern "C" int lpm_assign_gemm_tiles_fwd_bf16(const void* xr, const void* wt, in
 }
 
 // y[M, N] (row stride ldo) = x . w for a dense layer (transformer_utils.py:559-561,583,701-711): xr = row tiles of x [M, Kd]
-// (lpm_split_rows_tiles with B = 1, T = M), wt = weight tiles of w [Kd, N].  form 0: by shape; 1: 64-row workgroups; 2: 128-row.
+// (lpm_split_rows_tiles with B = 1, T = M), wt = weight tiles of w [Kd, N].  form 0 / 2: 128-row workgroups (one per CU, pipelined);
+// 1: 64-row workgroups; 3: 128-row workgroups, two per CU; 4: 256-row workgroups (four row tiles per wave).
 extern "C" int lpm_dense_tiles_fwd(const void* xr, const void* wt, int M, int Kd, int N, float* y, int64_t ldo, int form,
                                    lpm_stream_t stream) {
     using namespace lpm;
@@ -676,7 +856,70 @@ extern "C" int lpm_dense_tiles_fwd(const void* xr, const void* wt, int M, int Kd
     g.rb_per_batch = MT / 2; g.steps_per_split = DS; g.total_steps = DS;
     g.out = y; g.ldo = ldo; g.out_batch = (int64_t)M * ldo; g.out_split = 0;
     g.rows_valid = M; g.cols_valid = N;
-    return tg_launch<TG_EPI_STORE>(g, 1, 1, (hipStream_t)stream, "lpm_dense_tiles_fwd", 2, 0, form == 1 ? 0 : 1, 2);
+    return tg_launch<TG_EPI_STORE>(g, 1, 1, (hipStream_t)stream, "lpm_dense_tiles_fwd", 2, 0, form == 1 ? 0 : (form == 3 ? 2 : (form == 4 ? 3 : 1)), 2);
+}
+
+// ---- FeedForwardNetwork's first dense layer and its backward on the 256-row tile GEMM with operand-image epilogues -------------------------
+// (transformer_utils.py:701-711: relu(y W1 + b1) feeds the second dense layer; TF autodiff for the backward).  The [M, 4F] tensor in
+// the middle exists only as the split-bf16 image the library GEMMs downstream read: no fp32 round trip, no separate split pass.
+extern "C" int lpm_dense_tiles_supported(int M, int Kd, int N) {
+    return (M > 0 && M % 256 == 0 && Kd >= 256 && Kd % 16 == 0 && N > 0 && N % 256 == 0) ? 1 : 0;
+}
+static void dense_tiles_args(lpm::TileGemmArgs& g, const void* ar, const void* bt, int M, int Kd, int N) {
+    const int MT = lpm::row_tiles_per_clip(M), DS = Kd / 16, NT = N / 32;
+    g.a = (const uint4*)ar; g.a_tile = (int64_t)DS * 128; g.a_step = 128; g.a_batch = (int64_t)MT * DS * 128; g.a_tiles = MT;
+    g.b = (const uint4*)bt; g.b_tile = 128; g.b_step = (int64_t)NT * 128; g.b_batch = 0; g.b_tiles = NT;
+    g.rb_per_batch = MT / 2; g.steps_per_split = DS; g.total_steps = DS;
+    g.rows_valid = M; g.cols_valid = N;
+}
+// out3 [M, 3N] bf16 = the activation image [hi | lo | hi] of relu(x . w + bias); xr: row tiles of x [M, Kd], wt: weight tiles of w [Kd, N]
+extern "C" int lpm_dense_tiles_act_image_fwd(const void* xr, const void* wt, const float* bias, int M, int Kd, int N, void* out3,
+                                             lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(xr && wt && bias && out3, LPM_ERR_BADARG, "lpm_dense_tiles_act_image_fwd: null pointer");
+    LPM_REQUIRE(lpm_dense_tiles_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_dense_tiles_act_image_fwd: need M %% 256 == 0, Kd %% 16 == 0, Kd >= 256, N %% 256 == 0 (M=%d Kd=%d N=%d)", M, Kd, N);
+    LPM_REQUIRE(((uintptr_t)bias & 15) == 0, LPM_ERR_BADARG, "lpm_dense_tiles_act_image_fwd: bias must be 16-byte aligned");
+    TileGemmArgs g{};
+    dense_tiles_args(g, xr, wt, M, Kd, N);
+    g.img = (unsigned short*)out3; g.img_kind = 1; g.img_bias = bias;
+    return tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_act_image_fwd");
+}
+extern "C" size_t lpm_dense_tiles_relu_bwd_workspace_bytes(int M, int N) { return (size_t)((M + 63) / 64) * N * sizeof(float); }
+// g = (dy . w^T) masked by [act > 0]: out3 [M, 3N] bf16 = its gradient image [hi | hi | lo], dbias [N] = its column sums.
+// dyr: row tiles of dy [M, Kd]; wtt: weight tiles of w^T [Kd, N] (lpm_split_weight_tiles of w [N, Kd] with transposed = 1);
+// act3 [M, 3N]: the forward's activation image (lpm_dense_tiles_act_image_fwd's output).
+extern "C" int lpm_dense_tiles_relu_bwd_image(const void* dyr, const void* wtt, const void* act3, int M, int Kd, int N, void* out3,
+                                              float* dbias, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dyr && wtt && act3 && out3 && dbias && workspace, LPM_ERR_BADARG, "lpm_dense_tiles_relu_bwd_image: null pointer");
+    LPM_REQUIRE(lpm_dense_tiles_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_dense_tiles_relu_bwd_image: need M %% 256 == 0, Kd %% 16 == 0, Kd >= 256, N %% 256 == 0 (M=%d Kd=%d N=%d)", M, Kd, N);
+    LPM_REQUIRE(workspace_bytes >= lpm_dense_tiles_relu_bwd_workspace_bytes(M, N), LPM_ERR_WORKSPACE,
+                "lpm_dense_tiles_relu_bwd_image: workspace too small");
+    LPM_REQUIRE(((uintptr_t)act3 & 15) == 0, LPM_ERR_BADARG, "lpm_dense_tiles_relu_bwd_image: act3 must be 16-byte aligned");
+    TileGemmArgs g{};
+    dense_tiles_args(g, dyr, wtt, M, Kd, N);
+    g.img = (unsigned short*)out3; g.img_kind = 2; g.img_mask = (const unsigned short*)act3; g.img_colpart = (float*)workspace;
+    const int rc = tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_relu_bwd_image");
+    if (rc != LPM_OK) return rc;
+    hipLaunchKernelGGL(tg_colsum_reduce_kernel, dim3((unsigned)((N + 15) / 16)), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace,
+                       tile_gemm_image_row_groups(M), N, dbias);
+    return check_launch("lpm_dense_tiles_relu_bwd_image");
+}
+// x3 [M, 3K] split-bf16 operand image (order 0: activation planes [hi | lo | hi], 1: gradient planes [hi | hi | lo]) -> row tiles of the
+// matrix (lpm_row_tiles_bytes(1, M, K)): the tile GEMM's A operand from a tensor that exists only as its image
+extern "C" int lpm_image_row_tiles(const void* x3, int M, int K, int order, void* out, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x3 && out, LPM_ERR_BADARG, "lpm_image_row_tiles: null pointer");
+    LPM_REQUIRE(M > 0 && K > 0 && K % 16 == 0 && (((uintptr_t)x3 | (uintptr_t)out) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_image_row_tiles: need K %% 16 == 0 and 16-byte aligned pointers (K=%d)", K);
+    const int MT = row_tiles_per_clip(M);
+    const int64_t total = (int64_t)MT * (K / 16) * 64;
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(image_row_tiles_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x3, (int64_t)M, K, order ? 2 * K : K, MT, (uint4*)out);
+    return check_launch("lpm_image_row_tiles");
 }
 
 extern "C" int lpm_assign_gemm_tiles_bwd_dx(const void* dlr, const void* wtt, int B, int T, int D, int K, float* dx, int64_t lddx,

@@ -62,6 +62,7 @@ FLAGS.define("moe_num_mixtures", 2, "video_level_models.py:27")
 FLAGS.define("moe_l2", 1e-8, ":35")
 FLAGS.define("moe_low_rank_gating", -1, ":38")
 FLAGS.define("moe_prob_gating", False, ":41")
+FLAGS.define("moe_prob_gating_input", "prob", ":44")
 # train.py
 FLAGS.define("batch_size", 1024, "train.py:78")
 FLAGS.define("regularization_penalty", 1.0, ":83")

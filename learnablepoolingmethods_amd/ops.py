@@ -63,6 +63,9 @@ VLAD_FUSED_DEBUG_FALLBACK = False     # tests: drive every clip through the fuse
 # workgroup items + the row scales by the clip's last workgroup).  Built and measured in round 3, NOT faster than the two-launch chain
 # lpm_vlad_aggregate_raw_kmajor_fwd + lpm_vlad_row_scales (78 vs 74 us on one box, tools/time_k2_forms.py): off.
 VLAD_KMAJOR_SCALED = os.environ.get("LPM_VLAD_KMAJOR_SCALED", "0") == "1"
+# FeedForwardNetwork's first dense layer and its backward on the hand-written 256-row tile GEMM with operand-image epilogues
+# (lpm_dense_tiles_act_image_fwd / lpm_dense_tiles_relu_bwd_image) where the shape allows; 0: library GEMM + separate split passes (A/B).
+FFN_TILES = os.environ.get("LPM_FFN_TILES", "1") != "0"
 # Matrix-core arithmetic of the soft-assignment GEMM K1: "bf16x3" (split-bf16 tiles on the bf16 pipe, default where
 # D %% 16 == 0 and K <= 512) or "f32" (exact fp32 MFMA).
 ASSIGN_PRECISION = os.environ.get("LPM_ASSIGN_PRECISION", "bf16x3")
@@ -1108,13 +1111,31 @@ class _FFNX3(torch.autograd.Function):
     def forward(ctx, y2d, W1, b1, W2):
         y2d = _rows(y2d, "ffn input")
         W1, W2 = _f32(W1, "W1").contiguous(), _f32(W2, "W2").contiguous()
+        lib = _capi.load()
+        M, F = y2d.shape
+        H = W1.shape[1]
         y3 = _split_rows(y2d)
         w13n, w13k = _split_weight(W1)
-        pre1 = _mm3(y3, w13n)
-        f3 = _split_rows(pre1, bias=b1.contiguous(), relu=True)
-        del pre1
-        w23n, w23k = _split_weight(W2)
-        ctx.save_for_backward(y3, f3, w13k, w23k)
+        ctx.tiles = bool(FFN_TILES and y2d.stride(1) == 1 and lib._lpm_dense_tiles_supported(M, F, H) and lib._lpm_dense_tiles_supported(M, W2.shape[1], H))
+        if ctx.tiles:
+            # the first dense layer on the hand-written 256-row tile GEMM with the bias + ReLU + operand split in its epilogue: the
+            # [M, 4F] pre-activation never exists in fp32 (335 MB written + read at cfg-2), no separate split pass
+            st = stream_ptr()
+            yr = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, F), y2d)
+            lib.check(lib._lpm_split_rows_tiles(ptr(y2d), y2d.stride(0), 1, M, F, ptr(yr), st), "lpm_split_rows_tiles")
+            w1t = _tile_buffer(lib._lpm_weight_tiles_bytes(F, H), y2d)
+            lib.check(lib._lpm_split_weight_tiles(ptr(W1), F, H, 0, ptr(w1t), st), "lpm_split_weight_tiles")
+            f3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=y2d.device)
+            lib.check(lib._lpm_dense_tiles_act_image_fwd(ptr(yr), ptr(w1t), ptr(b1.contiguous()), M, F, H, ptr(f3), st),
+                      "lpm_dense_tiles_act_image_fwd")
+            w23n, _ = _split_weight(W2, need_t=False)
+            ctx.save_for_backward(y3, f3, w13k, W2)
+        else:
+            pre1 = _mm3(y3, w13n)
+            f3 = _split_rows(pre1, bias=b1.contiguous(), relu=True)
+            del pre1
+            w23n, w23k = _split_weight(W2)
+            ctx.save_for_backward(y3, f3, w13k, w23k)
         ctx.dims = (W1.shape[0], W1.shape[1], W2.shape[1])
         return _mm3(f3, w23n)
 
@@ -1127,15 +1148,29 @@ class _FFNX3(torch.autograd.Function):
         M = y3.shape[0]
         if do3 is None:
             do3 = _split_rows(dout.contiguous(), grad=True)
-        df = _mm3(do3, w23k)                                              # [M, H]
         dW2 = _dw_x3(f3, do3, H, N)
-        dp3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=df.device)
-        db1 = _empty((H,), df)
-        wsb = lib._lpm_split_rows_relu_bwd_workspace_bytes(M, H)
-        ws = torch.empty(wsb // 4, dtype=torch.float32, device=df.device)
-        lib.check(lib._lpm_split_rows_relu_bwd(ptr(df), M, H, ptr(f3), ptr(dp3), ptr(db1), ptr(ws), wsb, stream_ptr()),
-                  "lpm_split_rows_relu_bwd")
-        del df
+        dp3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=f3.device)
+        db1 = torch.empty((H,), dtype=torch.float32, device=f3.device)
+        if ctx.tiles:
+            # df = do W2^T on the tile GEMM; ReLU mask (the activation image's hi plane), bias gradient partial sums and the operand
+            # split of the result in its epilogue: df never exists in fp32
+            st = stream_ptr()
+            W2 = w23k                                                     # (saved in its place: the fp32 weight [H, N])
+            dor = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), f3)
+            lib.check(lib._lpm_image_row_tiles(ptr(do3), M, N, 1, ptr(dor), st), "lpm_image_row_tiles")
+            w2tt = _tile_buffer(lib._lpm_weight_tiles_bytes(N, H), f3)
+            lib.check(lib._lpm_split_weight_tiles(ptr(W2), N, H, 1, ptr(w2tt), st), "lpm_split_weight_tiles")
+            wsb = lib._lpm_dense_tiles_relu_bwd_workspace_bytes(M, H)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=f3.device)
+            lib.check(lib._lpm_dense_tiles_relu_bwd_image(ptr(dor), ptr(w2tt), ptr(f3), M, N, H, ptr(dp3), ptr(db1), ptr(ws), wsb, st),
+                      "lpm_dense_tiles_relu_bwd_image")
+        else:
+            df = _mm3(do3, w23k)                                          # [M, H]
+            wsb = lib._lpm_split_rows_relu_bwd_workspace_bytes(M, H)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=df.device)
+            lib.check(lib._lpm_split_rows_relu_bwd(ptr(df), M, H, ptr(f3), ptr(dp3), ptr(db1), ptr(ws), wsb, stream_ptr()),
+                      "lpm_split_rows_relu_bwd")
+            del df
         dy = _mm3(dp3, w13k, acc)
         dW1 = _dw_x3(y3, dp3, F, H)
         return dy, dW1, db1, dW2

@@ -48,6 +48,9 @@ class OracleConfig:
     encoder: bool = True                # False = "gated NetVLAD" of BASELINE cfg-5 (no cluster encoders)
     moe_num_mixtures: int = 2           # video_level_models.py:27
     moe_l2: float = 1e-8                # :35
+    moe_low_rank_gating: int = -1       # :37-39 (-1: one gates layer)
+    moe_prob_gating: bool = False       # :40-42
+    moe_prob_gating_input: str = "prob"  # :43-45
     vocab_size: int = 3862              # readers.py:144
     v2_dropout_rate: float = 0.9        # transformer_utils.py:450 (rate = 1 - 0.1), App. C10
     # training (train.py:78-108)
@@ -360,14 +363,27 @@ def transformer_encoder_block(x2d, params, scope, num_units, max_frames, feature
 # --------------------------------------------------------------------------------------
 # a11-a13: MoeModel, CrossEntropyLoss, regulariser
 # --------------------------------------------------------------------------------------
-def moe_forward(act, params, vocab_size, num_mixtures):
-    """MoeModel.create_model default branch (video_level_models.py:85-126,158)."""
-    gate = act @ params["gates/weights"]                                    # no bias :86-93
+def moe_forward(act, params, vocab_size, num_mixtures, cfg: Optional["OracleConfig"] = None, is_training=True, updates=None):
+    """MoeModel.create_model (video_level_models.py:85-158).  Default branch: one bias-free gates layer.  With cfg:
+    moe_low_rank_gating > 0 -> gates = (act gates1) gates2, both bias-free (:94-108); moe_prob_gating -> the class probabilities are
+    gated by sigmoid(BN(p W)) ('prob' input, W [V, V]) or sigmoid(BN(act W)) (W [H, V]), optionally without W's diagonal (:128-156)."""
+    if "gates1/weights" in params:
+        gate = (act @ params["gates1/weights"]) @ params["gates2/weights"]   # :94-108
+    else:
+        gate = act @ params["gates/weights"]                                # no bias :86-93
     expert = act @ params["experts/weights"] + params["experts/biases"]      # :109-114
     gating = torch.softmax(gate.reshape(-1, num_mixtures + 1), dim=-1)       # :116-118
     experts = torch.sigmoid(expert.reshape(-1, num_mixtures))                # :119-121
     probs = (gating[:, :num_mixtures] * experts).sum(dim=1)                  # :123-124
-    return probs.reshape(-1, vocab_size)                                     # :125-126
+    probs = probs.reshape(-1, vocab_size)                                    # :125-126
+    if cfg is not None and cfg.moe_prob_gating:
+        W = params["gating_prob_weights"]
+        gates = (probs if cfg.moe_prob_gating_input == "prob" else act) @ W  # :129-142
+        if cfg.remove_diag:
+            gates = gates - torch.diagonal(W) * probs                       # :144-147
+        gates = batch_norm(gates, params, "gating_prob_bn", is_training, updates)   # :149-154
+        probs = probs * torch.sigmoid(gates)                                 # :156-158
+    return probs
 
 
 def cross_entropy_loss(predictions, labels):
@@ -381,7 +397,8 @@ def cross_entropy_loss(predictions, labels):
 def regularization_loss(params, cfg: OracleConfig):
     """slim.l2_regularizer(moe_l2) on the two MoE FC weights: s * sum(w^2)/2
     (video_level_models.py:91,113; collected at train.py:301-303)."""
-    reg = cfg.moe_l2 * 0.5 * ((params["gates/weights"] ** 2).sum() + (params["experts/weights"] ** 2).sum())
+    gate_ws = [n for n in ("gates/weights", "gates1/weights", "gates2/weights") if n in params]          # :91,99,106
+    reg = cfg.moe_l2 * 0.5 * (sum((params[n] ** 2).sum() for n in gate_ws) + (params["experts/weights"] ** 2).sum())
     if cfg.model == "WillowModelReg":       # orthogonal_regularizer on both cluster_weights2 (video_pooling_modules.py:1561-1568)
         reg = reg + orthogonal_regularizer(params["video_VLAD/cluster_weights2"], cfg.rgb_det_reg)
         if "audio_VLAD/cluster_weights2" in params:
@@ -462,7 +479,7 @@ def model_forward(params, model_input, num_frames, cfg: OracleConfig, is_trainin
         gates = batch_norm(gates, params, "gating_bn", is_training, updates)  # :2354-2360 (App. C12)
         act = act * torch.sigmoid(gates)                                    # :2367-2368
     inter["activation"] = act
-    pred = moe_forward(act, params, cfg.vocab_size, cfg.moe_num_mixtures)   # :2370-2377
+    pred = moe_forward(act, params, cfg.vocab_size, cfg.moe_num_mixtures, cfg, is_training, updates)   # :2370-2377
     if return_intermediates:
         return pred, inter
     return pred
@@ -550,9 +567,17 @@ def init_params(cfg: OracleConfig, feature_size: int = 1152, seed: int = 1000,
     if cfg.gating:
         p["gating_weights_2"] = _normal(g, (H, H), 1 / math.sqrt(H), dtype)
         _bn(p, "gating_bn", H, dtype)
-    p["gates/weights"] = _glorot(g, H, V * (m + 1), dtype)
+    if cfg.moe_low_rank_gating != -1:
+        p["gates1/weights"] = _glorot(g, H, cfg.moe_low_rank_gating, dtype)
+        p["gates2/weights"] = _glorot(g, cfg.moe_low_rank_gating, V * (m + 1), dtype)
+    else:
+        p["gates/weights"] = _glorot(g, H, V * (m + 1), dtype)
     p["experts/weights"] = _glorot(g, H, V * m, dtype)
     p["experts/biases"] = torch.zeros(V * m, dtype=dtype)
+    if cfg.moe_prob_gating:
+        rows = V if cfg.moe_prob_gating_input == "prob" else H
+        p["gating_prob_weights"] = _normal(g, (rows, V), 1 / math.sqrt(V), dtype)      # :131-140
+        _bn(p, "gating_prob_bn", V, dtype)
     return p
 
 

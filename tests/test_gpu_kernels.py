@@ -736,12 +736,18 @@ def test_residual_layer_norm_fused_bias_activation(B, L, F, res, relu):
     assert_close(biasg.grad, bd.grad, tol=1e-4, what="layer_norm dbias")
 
 
-def test_ffn_split_bf16_fused_bias_relu():
-    """FeedForwardNetwork core relu(y W1 + b1) W2 with the inner bias + ReLU fused into the operand split."""
-    from learnablepoolingmethods_amd import ops
+@pytest.mark.parametrize("M,F,H,tiles", [(2048, 128, 512, False), (2048, 256, 1024, True), (20480, 1024, 4096, True), (2048, 256, 1024, False)])
+def test_ffn_split_bf16_fused_bias_relu(M, F, H, tiles):
+    """FeedForwardNetwork core relu(y W1 + b1) W2 (transformer_utils.py:701-711) with the inner bias + ReLU fused into the operand
+    split -- as a separate pass behind the library GEMM, or (tiles: M % 256 == 0, F >= 256, H % 256 == 0; cfg-2's video encoder is
+    the 20480 x 1024 x 4096 case) in the epilogue of the hand-written 256-row tile GEMM, whose backward twin applies the ReLU mask,
+    sums the bias gradient and splits the result."""
+    from learnablepoolingmethods_amd import _capi, ops
     dev = cuda()
     g = torch.Generator().manual_seed(3)
-    M, F, H = 2048, 128, 512
+    old = ops.FFN_TILES
+    ops.FFN_TILES = tiles
+    assert bool(_capi.load()._lpm_dense_tiles_supported(M, F, H)) == (F >= 256)
     y, W1, b1, W2, dout = (torch.randn(M, F, generator=g), torch.randn(F, H, generator=g) / F ** .5, 0.3 * torch.randn(H, generator=g),
                            torch.randn(H, F, generator=g) / H ** .5, torch.randn(M, F, generator=g))
     yd, W1d, b1d, W2d = (t.double().requires_grad_(True) for t in (y, W1, b1, W2))
@@ -759,7 +765,8 @@ def test_ffn_split_bf16_fused_bias_relu():
         assert e <= 5e-3, f"ffn {nm}: relative L2 error {e:.3e}"
     # and the flips must be isolated: all but a few rows of dy agree to 1e-4 of the tensor scale
     err = (yg.grad.double().cpu() - yd.grad).abs().amax(dim=1) / yd.grad.abs().max()
-    assert int((err > 1e-4).sum()) <= 20, f"{int((err > 1e-4).sum())} of {M} dy rows differ: not ReLU-flip noise"
+    assert int((err > 1e-4).sum()) <= max(20, M // 100), f"{int((err > 1e-4).sum())} of {M} dy rows differ: not ReLU-flip noise"
+    ops.FFN_TILES = old
 
 
 @pytest.mark.parametrize("B,KV,H", [(80, 33792, 512), (16, 4224, 64), (6, 2048, 96), (128, 16896, 1024), (13, 2064, 512), (48, 4112, 512),

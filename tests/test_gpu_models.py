@@ -248,6 +248,22 @@ def test_train_steps_v1_relu6_and_remove_diag():
         FLAGS.reset()
 
 
+@pytest.mark.parametrize("low_rank,prob", [(8, False), (-1, True), (8, True)])
+def test_train_steps_moe_low_rank_and_probability_gating(low_rank, prob):
+    """MoeModel's optional branches through the trainer (video_level_models.py:94-108,128-156): two-layer low-rank gates (both with
+    their L2 regularisers, which enter as gradients) and probability gating behind the fused mixture kernel -- two optimiser steps
+    against the oracle."""
+    from learnablepoolingmethods_amd import FLAGS
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", iterations=12, cluster_size=16, hidden_size=32, vocab_size=40, base_learning_rate=1e-3,
+                         encoder=False, moe_low_rank_gating=low_rank, moe_prob_gating=prob, moe_l2=1e-3)
+    FLAGS.moe_low_rank_gating, FLAGS.moe_prob_gating, FLAGS.moe_l2 = low_rank, prob, 1e-3
+    try:
+        _train_compare("NetVladV1", cfg, 1152, 4, 16, 2, dev, encoder=False)
+    finally:
+        FLAGS.reset()
+
+
 def test_train_steps_v2():
     dev = cuda()
     cfg = O.OracleConfig(model="NetVladV2", iterations=12, cluster_size=16, hidden_size=32, vocab_size=40,

@@ -161,3 +161,47 @@ def test_attention_modules_host_side_and_variable_names():
         assert float((raw.detach().double() - ref).abs().max()) < 1e-5
         with pytest.raises(LpmError):
             attention_modules.OneFcAttention(F, L, 5, do_shift=True).forward(x)
+
+
+@pytest.mark.parametrize("low_rank,prob,inp,remove_diag", [(-1, False, "prob", False), (6, False, "prob", False), (-1, True, "prob", False),
+                                                           (6, True, "prob", True), (-1, True, "input", False)])
+def test_moe_low_rank_and_probability_gating_branches(low_rank, prob, inp, remove_diag):
+    """MoeModel's optional branches (video_level_models.py:37-45,94-108,128-156; off by default): the two-layer low-rank gates and
+    the gating of the class probabilities by sigmoid(BN(p W)) / sigmoid(BN(x W)), with the reference's variable names, L2
+    regularisers on every gates layer, and gradients -- host-side torch against the oracle's restatement (fp64, CPU)."""
+    from learnablepoolingmethods_amd import video_level_models
+    torch.manual_seed(3)
+    B, H, V, m = 5, 12, 7, 3
+    cfg = O.OracleConfig(vocab_size=V, hidden_size=H, moe_num_mixtures=m, moe_low_rank_gating=low_rank, moe_prob_gating=prob,
+                         moe_prob_gating_input=inp, remove_diag=remove_diag, moe_l2=1e-2)
+    act = torch.randn(B, H, dtype=torch.float64)
+    try:
+        FLAGS.moe_num_mixtures, FLAGS.moe_low_rank_gating, FLAGS.moe_prob_gating = m, low_rank, prob
+        FLAGS.moe_prob_gating_input, FLAGS.gating_remove_diag, FLAGS.moe_l2 = inp, remove_diag, 1e-2
+        store = vs.VariableStore(device="cpu", seed=1)
+        with vs.use_store(store):
+            video_level_models.MoeModel().create_model(act.float(), V, is_training=True)          # creates the variables
+            want_names = {"experts/weights", "experts/biases"} | ({"gates/weights"} if low_rank == -1 else {"gates1/weights", "gates2/weights"})
+            if prob:
+                want_names |= {"gating_prob_weights", "gating_prob_bn/beta", "gating_prob_bn/gamma", "gating_prob_bn/moving_mean",
+                               "gating_prob_bn/moving_variance"}
+            assert set(store.vars) == want_names
+            assert store.vars["gating_prob_weights"].shape == ((V, V) if inp == "prob" else (H, V)) if prob else True
+            p = {n: (torch.randn(v.shape, dtype=torch.float64) * 0.3 if v.dim() > 1 or "biases" in n else v.detach().double().clone())
+                 for n, v in store.vars.items()}
+            store.pop_regularization_losses(), store.pop_l2_regularizers()
+            store.vars = {n: p[n].clone().requires_grad_(store.trainable[n]) for n in p}
+            out = video_level_models.MoeModel().create_model(act, V, is_training=True)["predictions"]
+            regs = store.pop_regularization_losses()       # (a CPU store collects slim.l2_regularizer penalties as loss tensors)
+        pt = {n: v.clone().requires_grad_(True) for n, v in p.items()}
+        ref = O.moe_forward(act, pt, V, m, cfg, True, {})
+        assert torch.allclose(out, ref, rtol=1e-10, atol=1e-12)
+        assert len(regs) == (2 if low_rank == -1 else 3)          # one penalty per gates layer + the experts' (:91,99,106,113)
+        assert torch.allclose(torch.stack(regs).sum(), O.regularization_loss(pt, cfg), rtol=1e-12)
+        w = torch.randn_like(out)
+        (out * w).sum().backward()
+        (ref * w).sum().backward()
+        for n in O.trainable_names(p, cfg):
+            assert torch.allclose(store.vars[n].grad, pt[n].grad, rtol=1e-9, atol=1e-12), n
+    finally:
+        FLAGS.reset()

@@ -24,7 +24,7 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-forms = [int(a) for a in sys.argv[1:]] or [2, 1]
+forms = [int(a) for a in sys.argv[1:]] or [2, 4]
 for name, K, N in (("qkv fwd", F, 3 * F), ("o fwd", F, F), ("ffn1 fwd", F, H), ("ffn2 fwd", H, F), ("qkv dx", 3 * F, F)):
     x = torch.randn(M, K, device=dev)
     W = torch.randn(K, N, device=dev) / K ** 0.5
