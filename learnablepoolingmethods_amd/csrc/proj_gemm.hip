@@ -263,6 +263,103 @@ __global__ __launch_bounds__(512, 2) void proj_dx_kernel(const uint4* __restrict
         }
 }
 
+// ---- backward, second form (round 3): every 128-byte line of W is requested ONCE, whole ------------------------------------------------------
+// proj_dx_kernel above walks a row of W in 64-byte pieces (one 16-deep MFMA step per ring stage): each 128-byte line is requested as
+// two halves by two different stages, and with the stream's non-temporal policy the second half comes from HBM again -- the pass ran at
+// 2.2 TB/s (cfg-5) and lost to the library at cfg-2.  Here a stage is 32 columns of the reduction = one whole line per row: a wave
+// brings its 32 rows x 128 B in by four LDS-DMAs of 8 rows x 128 B, XOR-swizzled at 16-byte granularity through the SOURCE address
+// (LDS slot q of row r holds chunk q ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group -- rows r .. r + 15, two rows per 256-byte
+// bank row -- hit 16 different 16-byte slots), and two MFMA steps consume it.  dy's row tiles (L2-resident) ride in the same ring, every
+// wave issuing the same number of pieces per stage (piece ids past the end are clamped duplicates into spare slots), so the counted
+// vmcnt is one constant.  Three stages of 32 KB + 16 KB.
+constexpr int PE_NS = 3;
+constexpr int PE_WBYTES = 8 * 32 * 128;            // 8 waves x 32 rows x 32 floats
+constexpr int PE_APIECES = 16;                     // dy piece slots per stage (2 per wave): MT row tiles x 2 steps x 2 planes <= 16
+constexpr int PE_STAGE = PE_WBYTES + PE_APIECES * 1024;
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void proj_dx2_kernel(const uint4* __restrict__ dyt, const float* __restrict__ W, int M, int64_t Kd, int N,
+                                                          float* __restrict__ dx, int64_t lddx) {
+    static_assert(4 * MT <= PE_APIECES, "dy pieces per stage");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int64_t k0 = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + wave * 32;     // this wave's 32 rows of W
+    const int NB = N / 32, CS = N / 16;            // stages; 16-deep steps per row tile of dyt
+    // W DMA: piece j (0..3) = rows 8 j .. 8 j + 7 of the wave's 32; lane -> (row r = 8 j + lane / 8, LDS slot q = lane % 8)
+    const float* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + (lane >> 3), q = lane & 7;
+        const int64_t row = min(k0 + r, Kd - 1);
+        wsrc[j] = W + row * N + ((q ^ ((r >> 1) & 7)) * 4);
+    }
+    // dy DMA: piece id p = wave + 8 j (j < 2) = (row tile p >> 2, step-in-stage (p >> 1) & 1, plane p & 1); ids >= 4 MT: duplicates of piece 0
+    const uint4* asrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wave + 8 * j, pc = p < 4 * MT ? p : 0;
+        asrc[j] = dyt + ((int64_t)(pc >> 2) * CS + ((pc >> 1) & 1)) * 128 + (pc & 1) * 64 + lane;
+    }
+    auto issue = [&](int s) {
+        unsigned char* st = smem + (s % PE_NS) * PE_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + s * 32),
+                                             (__attribute__((address_space(3))) void*)(st + wave * 4096 + j * 1024), 16, 0, PJ_AUX);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + (int64_t)s * 256),
+                                             (__attribute__((address_space(3))) void*)(st + PE_WBYTES + (wave + 8 * j) * 1024), 16, 0, 0);
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < PE_NS - 1; ++s)
+        if (s < NB) issue(s);
+    for (int s = 0; s < NB; ++s) {
+        const int young = min(PE_NS - 2, NB - 1 - s);      // younger stages in flight behind stage s, 6 pieces of this wave each
+        if (young == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + PE_NS - 1 < NB) issue(s + PE_NS - 1);
+        const unsigned char* st = smem + (s % PE_NS) * PE_STAGE;
+        const float* wl = reinterpret_cast<const float*>(st + wave * 4096) + l31 * 32;         // this lane's row (128 B)
+        const tg_u32x4* af = reinterpret_cast<const tg_u32x4*>(st + PE_WBYTES) + lane;
+        const int sw = (l31 >> 1) & 7;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // 8 consecutive n of row l31, step t: chunks 4 t + 2 half and + 1 (swizzled)
+            const int c0 = 4 * t + 2 * half;
+            const float4 b0 = *reinterpret_cast<const float4*>(wl + ((c0 ^ sw) * 4));
+            const float4 b1 = *reinterpret_cast<const float4*>(wl + (((c0 + 1) ^ sw) * 4));
+            const float v[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            uint4 hi, lo;
+            tg_split8(v, hi, lo);
+            const tg_u32x4 bh = tg_u32x4{hi.x, hi.y, hi.z, hi.w}, bl = tg_u32x4{lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const tg_u32x4 ah = af[((m * 2 + t) * 2 + 0) * 64], al = af[((m * 2 + t) * 2 + 1) * 64];
+                acc[m] = tg_mfma(ah, bh, acc[m]);
+                acc[m] = tg_mfma(ah, bl, acc[m]);
+                acc[m] = tg_mfma(al, bh, acc[m]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m * 32 + mfma32_row(r, lane);
+            if (row < M && k0 + l31 < Kd) dx[(int64_t)row * lddx + k0 + l31] = acc[m][r];
+        }
+}
+
 }  // namespace lpm
 
 extern "C" int lpm_proj_supported(int M, int64_t Kd, int N) {
@@ -320,6 +417,29 @@ extern "C" int lpm_proj_dx(const void* dyt, const float* W, int M, int64_t Kd, i
     const int MT = (M + 31) / 32;
     dim3 grid((unsigned)((Kd + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
+    // second form (whole 128-byte lines of W per stage): N a multiple of 32; LPM_PROJ_DX_FORM=1 selects the first form (A/B)
+    static const int form = [] { const char* e = getenv("LPM_PROJ_DX_FORM"); return (e && e[0] == '1') ? 1 : 2; }();
+    if (form == 2 && N % 32 == 0 && N >= 64) {
+#define LPM_PE(MTV)                                                                                                          \
+    do {                                                                                                                     \
+        auto kern = proj_dx2_kernel<MTV>;                                                                                    \
+        const size_t lds = (size_t)PE_NS * PE_STAGE;                                                                         \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {    \
+            (void)hipGetLastError();                                                                                         \
+            set_error("lpm_proj_dx: cannot reserve %zu bytes of LDS", lds);                                                  \
+            return LPM_ERR_LAUNCH;                                                                                           \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)dyt, W, M, Kd, N, dx, lddx);                         \
+    } while (0)
+        switch (MT) {
+            case 1: LPM_PE(1); break;
+            case 2: LPM_PE(2); break;
+            case 3: LPM_PE(3); break;
+            default: LPM_PE(4); break;
+        }
+#undef LPM_PE
+        return check_launch("lpm_proj_dx");
+    }
 #define LPM_PD(MTV)                                                                                                          \
     do {                                                                                                                     \
         auto kern = proj_dx_kernel<MTV>;                                                                                     \
