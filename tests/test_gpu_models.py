@@ -174,7 +174,7 @@ def _well_conditioned(p):
     return p
 
 
-def _train_compare(name, cfg, feat, B, MF, steps, dev, tol=1e-3, **kw):
+def _train_compare(name, cfg, feat, B, MF, steps, dev, tol=1e-3, stat_tol=1e-3, **kw):
     """``tol`` applies to whole-model gradients in the Frobenius norm of each variable (the north-star's 1e-3).  The seeded
     weights keep every ReLU pre-activation away from zero (oracle/test_weights.separate_relu_units): a unit within fp32 rounding of
     zero takes its mask from the last bit of whichever arithmetic computed it and alone moves the filter_output kernel
@@ -218,7 +218,7 @@ def _train_compare(name, cfg, feat, B, MF, steps, dev, tol=1e-3, **kw):
     for n in p:
         if n.endswith("moving_mean") or n.endswith("moving_variance"):
             # (the batch mean of the logits of batch-normalised frames is zero up to rounding: an absolute floor for it)
-            assert_close(tr.store.vars["tower/" + n], p[n], tol=1e-3, what=f"moving stat {n}", floor=1e-6)
+            assert_close(tr.store.vars["tower/" + n], p[n], tol=stat_tol, what=f"moving stat {n}", floor=1e-6)
 
 
 def test_train_steps_cfg1_v1():
@@ -259,7 +259,10 @@ def test_train_steps_moe_low_rank_and_probability_gating(low_rank, prob):
                          encoder=False, moe_low_rank_gating=low_rank, moe_prob_gating=prob, moe_l2=1e-3)
     FLAGS.moe_low_rank_gating, FLAGS.moe_prob_gating, FLAGS.moe_l2 = low_rank, prob, 1e-3
     try:
-        _train_compare("NetVladV1", cfg, 1152, 4, 16, 2, dev, encoder=False)
+        # (moving statistics after the SECOND step at 5e-3: gating_prob_bn normalises p W, a sum over the 40 class probabilities, and the
+        # second step starts from weights that differ between any two implementations by Adam's sign noise of +-lr on elements whose
+        # gradient is at rounding level -- 3e-3 of a low-rank gates weight; measured 1.6e-3 on its moving mean, 1e-3-level elsewhere)
+        _train_compare("NetVladV1", cfg, 1152, 4, 16, 2, dev, stat_tol=5e-3, encoder=False)
     finally:
         FLAGS.reset()
 
