@@ -105,6 +105,89 @@ __global__ __launch_bounds__(256, 2) void fa_quadform_kernel(const uint4* __rest
     if (tid == 0) partial[blockIdx.x] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// Update pass, second form (round 3): long row pieces, no LDS.  The tile-GEMM form above gives a workgroup a 64 x 128 tile of the
+// [N1, N2] variable: 512-byte pieces of 64 rows 2 KB apart, in three arrays -- 5.4 TB/s, where 128- or 256-wide rows (each
+// workgroup's tile contiguous) stream at 6.2.  Here a workgroup owns 32 rows x 256 columns (1 KB row pieces; the column pieces of the
+// same rows are consecutive workgroups) and there is NO LDS and NO barrier: every wave first requests its param / m / v elements in the MFMA
+// accumulator's own layout (for a fixed register the 32 lanes of a half-wave hold 32 consecutive columns of one row: 128-byte
+// segments, non-temporal), then runs its small GEMM -- R / 16 steps, the A fragment (this row block's X tile) and its two B fragments (DY
+// tiles, 0.2 MB in all: L2-resident) straight from L2 into registers as 16-byte-per-lane fragment loads, double-buffered -- UNDER the
+// HBM round trip of those requests, then clip factor, TF-Adam (clip_adam.hip's arithmetic) and non-temporal stores in the same layout.
+// The gradient element is bit for bit the tile GEMM's (same fragments, same three MFMAs per product in the same order).
+// Workgroup = 256 threads = 32 rows x 256 columns (two workgroups per CU at ~180 registers: one's loads are in flight while the other
+// computes and stores); consecutive workgroups = the N2 / 256 column pieces of the same rows.  Needs N1 %% 32 == 0, N2 %% 256 == 0.
+__global__ __launch_bounds__(256, 2) void fa_update_rows_kernel(const uint4* __restrict__ xt, const uint4* __restrict__ dyt, int steps, int N1,
+                                                                 int N2, int NT1, int NT2, int NCB, float* __restrict__ param,
+                                                                 float* __restrict__ mom, float* __restrict__ var,
+                                                                 const float* __restrict__ factor, float lr_t, float b1, float b2, float eps) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int rb = blockIdx.x / NCB, cb = blockIdx.x % NCB;                    // 32-row block = X tile index; 256-column piece
+    const int64_t row0 = (int64_t)rb * 32;
+    const int ct0 = cb * 8 + wave * 2;                                          // this wave's first 32-column tile
+    f32x16 pa[2], ma[2], va[2];
+    // (uniform base per register + one per-lane offset, as the stores below: SGPR arithmetic, one VGPR of addressing)
+    const unsigned voff = (unsigned)(4 * (lane >> 5) * N2 + l31) * 4u;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t o = (row0 + (r & 3) + 8 * (r >> 2)) * N2 + (ct0 + c) * 32;         // row + 4 half and column + l31 in voff
+            pa[c][r] = __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(param + o) + voff));
+            ma[c][r] = __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(mom + o) + voff));
+            va[c][r] = __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(var + o) + voff));
+        }
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    const uint4* ap = xt + (int64_t)rb * 128 + lane;                            // + s * NT1 * 128; plane: + 64
+    const uint4* bp = dyt + (int64_t)ct0 * 128 + lane;                          // + s * NT2 * 128; column tile c: + c * 128; plane: + 64
+    struct Frag { uint4 ah, al, bh[2], bl[2]; };
+    auto load = [&](int s, Frag& f) {
+        const uint4* a = ap + (int64_t)s * NT1 * 128;
+        const uint4* b = bp + (int64_t)s * NT2 * 128;
+        f.ah = a[0]; f.al = a[64];
+        f.bh[0] = b[0]; f.bl[0] = b[64]; f.bh[1] = b[128]; f.bl[1] = b[192];
+    };
+    auto mac = [&](const Frag& f) {
+        const tg_u32x4 ah = {f.ah.x, f.ah.y, f.ah.z, f.ah.w}, al = {f.al.x, f.al.y, f.al.z, f.al.w};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const tg_u32x4 bh = {f.bh[c].x, f.bh[c].y, f.bh[c].z, f.bh[c].w}, bl = {f.bl[c].x, f.bl[c].y, f.bl[c].z, f.bl[c].w};
+            acc[c] = tg_mfma(ah, bh, acc[c]);
+            acc[c] = tg_mfma(ah, bl, acc[c]);
+            acc[c] = tg_mfma(al, bh, acc[c]);
+        }
+    };
+    Frag fa, fb;
+    if (steps > 0) load(0, fa);
+    for (int s = 0; s < steps; s += 2) {
+        if (s + 1 < steps) load(s + 1, fb);
+        mac(fa);
+        if (s + 1 < steps) {
+            if (s + 2 < steps) load(s + 2, fa);
+            mac(fb);
+        }
+    }
+    const float fac = *factor;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float gc = acc[c][r] * fac;
+            const float mn = b1 * ma[c][r] + (1.f - b1) * gc;
+            const float vn = b2 * va[c][r] + (1.f - b2) * gc * gc;
+            const float pn = pa[c][r] - lr_t * mn / (sqrtf(vn) + eps);
+            const int64_t o = (row0 + (r & 3) + 8 * (r >> 2)) * N2 + (ct0 + c) * 32;
+            __builtin_nontemporal_store(pn, reinterpret_cast<float*>(reinterpret_cast<char*>(param + o) + voff));
+            __builtin_nontemporal_store(mn, reinterpret_cast<float*>(reinterpret_cast<char*>(mom + o) + voff));
+            __builtin_nontemporal_store(vn, reinterpret_cast<float*>(reinterpret_cast<char*>(var + o) + voff));
+        }
+}
+
 }  // namespace lpm
 
 extern "C" size_t lpm_factored_clip_adam_scratch_bytes(int N1, int N2) {
@@ -174,6 +257,17 @@ static int factored_clip_adam_impl(const void* xt, const void* dyt, const float*
     hipLaunchKernelGGL(fa_factor_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, npart, clip_norm, factor);
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
     g.sumsq = nullptr;
+    // whole-row form of the update pass (fa_update_rows_kernel): N2 a multiple of 64, at most 1024; LPM_FA_ROWS=0: the tile-GEMM form (A/B)
+    static const int rows_form = [] { const char* e = getenv("LPM_FA_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
+    // Measured (tools/time_factored.py, whole update incl. the ~75 us norm pass): cfg-2 one tower (R = 80, N2 = 512) 693 us against 728;
+    // cfg-5 (R = 128, N2 = 1024) 2741 against 2418 and eight towers of cfg-2 (R = 640) 1855 against 1749 -- every wave fetching its own
+    // fragments from L2 costs 80 + 160 KB of L2 -> CU traffic per 192 KB of HBM stream at R = 80, but 256 + 512 KB per 384 KB at R = 128:
+    // the whole-row form only where the reduction is short
+    if (rows_form && N2 % 256 == 0 && N1 % 32 == 0 && (int64_t)g.total_steps * N2 <= 5 * 512 && (int64_t)NT1 * (N2 / 256) < ((int64_t)1 << 31)) {
+        hipLaunchKernelGGL(fa_update_rows_kernel, dim3((unsigned)(NT1 * (N2 / 256))), dim3(256), 0, s, (const uint4*)xt, (const uint4*)dyt,
+                           g.total_steps, N1, N2, NT1, NT2, N2 / 256, param, m, v, (const float*)factor, (float)lr_t, beta1, beta2, eps);
+        return check_launch("lpm_factored_clip_adam (update pass, rows)");
+    }
     g.adam_p = param; g.adam_m = m; g.adam_v = v; g.adam_factor = factor;
     g.adam_lr_t = (float)lr_t; g.adam_b1 = beta1; g.adam_b2 = beta2; g.adam_eps = eps;
     rc = tile_gemm_adam(g, s, "lpm_factored_clip_adam (update pass)");
