@@ -736,6 +736,33 @@ def test_residual_layer_norm_fused_bias_activation(B, L, F, res, relu):
     assert_close(biasg.grad, bd.grad, tol=1e-4, what="layer_norm dbias")
 
 
+@pytest.mark.parametrize("M,K,N", [(2048, 512, 768), (1984, 256, 512), (20480, 1024, 1024)])
+@pytest.mark.parametrize("form", [1, 2, 3, 4])
+def test_dense_tile_gemm_forms(M, K, N, form):
+    """lpm_dense_tiles_fwd: an encoder dense layer y = x W (transformer_utils.py:559-561,583,701-711) on the split-bf16 tile GEMM in its
+    four workgroup forms -- 64-row, 128-row pipelined (K1's), 128-row with two workgroups per CU, 256-row with four row tiles per wave --
+    against fp64.  A form whose shape conditions do not hold (1984 rows = 62 row tiles: not a multiple of 4 or 8) must fall back to the
+    64-row form, not fail: same result either way."""
+    from learnablepoolingmethods_amd import _capi
+    from learnablepoolingmethods_amd.ops import ptr, stream_ptr
+    dev = cuda()
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(K, N, generator=g) / K ** 0.5
+    xd, Wd = x.to(dev), W.to(dev)
+    xr = torch.empty(lib._lpm_row_tiles_bytes(1, M, K) // 4, dtype=torch.int32, device=dev)
+    wt = torch.empty(lib._lpm_weight_tiles_bytes(K, N) // 4, dtype=torch.int32, device=dev)
+    lib.check(lib._lpm_split_rows_tiles(ptr(xd), K, 1, M, K, ptr(xr), stream_ptr()), "rows")
+    lib.check(lib._lpm_split_weight_tiles(ptr(Wd), K, N, 0, ptr(wt), stream_ptr()), "weight")
+    y = torch.full((M, N), float("nan"), device=dev)
+    lib.check(lib._lpm_dense_tiles_fwd(ptr(xr), ptr(wt), M, K, N, ptr(y), N, form, stream_ptr()), "dense")
+    torch.cuda.synchronize()
+    ref = x.double() @ W.double()
+    assert torch.isfinite(y).all()
+    assert_close(y, ref, tol=2e-5, what=f"dense tiles form {form}")
+
+
 @pytest.mark.parametrize("M,F,H,tiles", [(2048, 128, 512, False), (2048, 256, 1024, True), (20480, 1024, 4096, True), (2048, 256, 1024, False)])
 def test_ffn_split_bf16_fused_bias_relu(M, F, H, tiles):
     """FeedForwardNetwork core relu(y W1 + b1) W2 (transformer_utils.py:701-711) with the inner bias + ReLU fused into the operand
