@@ -73,6 +73,8 @@ FLAGS.define("clip_gradient_norm", 1.0, ":108")
 FLAGS.define("hidden1_factored_update", True, "build extension: the GPU trainer consumes hidden1_weights' gradient as the product "
              "descriptors^T . d(activation) it is (lpm_factored_clip_adam): the gradient is never written, the towers all-gather its "
              "two skinny factors instead of all-reducing it.  False: the generic path (gradient written into the arena)")
+FLAGS.define("direct_weight_gradients", True, "build extension: single-GPU training writes the encoders' dense-kernel gradients straight "
+             "into the gradient arena from their producers (ops._dw_x3) instead of through autograd's .grad + a gather copy")
 FLAGS.define("hidden1_factored_max_towers", 4, "build extension: ... up to this many towers.  Both passes of the factored update multiply "
              "over ALL towers' clips (R = 80 N at cfg-2: 0.72 ms at N = 1, 0.94 / 1.2 / 1.73 ms at N = 2 / 4 / 8 measured with "
              "tools/time_factored.py) where the generic route costs 0.88 ms of kernels plus a 554 MB all-reduce under the backward")

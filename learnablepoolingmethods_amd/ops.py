@@ -66,6 +66,9 @@ VLAD_KMAJOR_SCALED = os.environ.get("LPM_VLAD_KMAJOR_SCALED", "0") == "1"
 # FeedForwardNetwork's first dense layer and its backward on the hand-written 256-row tile GEMM with operand-image epilogues
 # (lpm_dense_tiles_act_image_fwd / lpm_dense_tiles_relu_bwd_image) where the shape allows; 0: library GEMM + separate split passes (A/B).
 FFN_TILES = os.environ.get("LPM_FFN_TILES", "1") != "0"
+# Run-time switch of the direct weight-gradient writes (ops._dw_x3 -> the trainer's arena slots, FLAGS.direct_weight_gradients): False
+# returns every gradient through autograd (A/B inside one process: tools/ab_flags.py ops.DIRECT_WGRAD).
+DIRECT_WGRAD = True
 # Matrix-core arithmetic of the soft-assignment GEMM K1: "bf16x3" (split-bf16 tiles on the bf16 pipe, default where
 # D %% 16 == 0 and K <= 512) or "f32" (exact fp32 MFMA).
 ASSIGN_PRECISION = os.environ.get("LPM_ASSIGN_PRECISION", "bf16x3")
@@ -1019,6 +1022,7 @@ class _DenseX3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, W, x3=None):
         """x3 (block Functions only): the input already as its activation image (then x2d is None)."""
+        W0 = W
         W = _f32(W, "dense kernel").contiguous()
         if x3 is None:
             x2d = _rows(x2d, "dense input")
@@ -1026,6 +1030,7 @@ class _DenseX3(torch.autograd.Function):
         w3n, w3k = _split_weight(W, need_t=ctx.needs_input_grad[0])
         ctx.save_for_backward(x3, w3k)
         ctx.dims = (W.shape[0], W.shape[1])
+        ctx.wrefs = (W0,)
         return _mm3(x3, w3n)
 
     @staticmethod
@@ -1036,7 +1041,7 @@ class _DenseX3(torch.autograd.Function):
         if dy3 is None:
             dy3 = _split_rows(dy.contiguous(), grad=True)
         dx = _mm3(dy3, w3k) if ctx.needs_input_grad[0] else None
-        dW = _dw_x3(x3, dy3, K, N) if ctx.needs_input_grad[1] else None
+        dW = _dw_x3(x3, dy3, K, N, outs=[(ctx.wrefs[0], 0, N)])[0] if ctx.needs_input_grad[1] else None
         return dx, dW
 
 
@@ -1059,6 +1064,7 @@ class _QKVX3(torch.autograd.Function):
         w3n, w3k = _split_weight(Wcat, need_t=ctx.needs_input_grad[0])
         ctx.save_for_backward(x3, w3k)
         ctx.dims = (K, N)
+        ctx.wrefs = (Wq, Wk, Wv)
         qkv = _mm3(x3, w3n)
         return qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
 
@@ -1079,15 +1085,73 @@ class _QKVX3(torch.autograd.Function):
                 dqkv = torch.cat([dq, dk, dv], dim=1)
             dy3 = _split_rows(dqkv, grad=True)
         dx = _mm3(dy3, w3k, acc) if ctx.needs_input_grad[0] else None
-        dW = _dw_x3(x3, dy3, K, 3 * N)
-        return dx, dW[:, :N], dW[:, N:2 * N], dW[:, 2 * N:]
+        Wq, Wk, Wv = ctx.wrefs
+        dWq, dWk, dWv = _dw_x3(x3, dy3, K, 3 * N, outs=[(Wq, 0, N), (Wk, N, N), (Wv, 2 * N, N)])
+        return dx, dWq, dWk, dWv
 
 
 def qkv_x3(x2d, Wq, Wk, Wv):
     return _QKVX3.apply(x2d, Wq, Wk, Wv)
 
 
-def _dw_x3(x3, dy3, K, N):
+def _grad_slot(W):
+    """The trainer's arena slice for this weight's gradient (ParameterArena.mark_direct) if it may be written directly this step --
+    it exists and nothing has been written to it yet -- else None: the caller returns the gradient to autograd as usual (a second use of
+    the weight in one step accumulates there and ParameterArena.collect folds it in)."""
+    view = getattr(W, "_lpm_grad_view", None) if (W is not None and DIRECT_WGRAD) else None
+    if view is None or getattr(W, "_lpm_grad_written", False):
+        return None
+    return view
+
+
+def _grad_done(W):
+    W._lpm_grad_written = True
+    ready = getattr(W, "_lpm_grad_ready", None)
+    if ready is not None:
+        ready()
+
+
+class _LinearDirect(torch.autograd.Function):
+    """y = x W (+ b) as plain fp32 library GEMMs (the MoE head's slim.fully_connected layers, video_level_models.py:86-114) whose weight
+    gradient x^T dy goes straight into the trainer's arena slot when the weight has a free one (_grad_slot): for the two MoE matrices
+    (10 M parameters at cfg-2) that is one GEMM writing in place instead of a GEMM + a 40 MB gather copy."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.wref = W
+        ctx.has_bias = b is not None
+        return torch.addmm(b, x, W) if b is not None else x.matmul(W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dx = dy.matmul(W.t()) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            slot = _grad_slot(ctx.wref)
+            if slot is not None:
+                torch.mm(x.t(), dy, out=slot)
+                _grad_done(ctx.wref)
+            else:
+                dW = x.t().matmul(dy)
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dW, db
+
+
+def linear_direct(x, W, b=None):
+    return _LinearDirect.apply(x, W, b)
+
+
+def _dw_x3(x3, dy3, K, N, outs=None):
+    """outs: [(weight, first column, columns)] -- the gradient's column blocks belong to these weights; a weight with a free arena slot
+    (_grad_slot) receives its block straight from the split-K sum (no fresh tensor, no AccumulateGrad copy, no gather copy) and the
+    returned tuple holds None in its place.  Without outs: the [K, N] gradient."""
+    res = _dw_x3_impl(x3, dy3, K, N, outs)
+    return res
+
+
+def _dw_x3_impl(x3, dy3, K, N, outs):
     """dW = x^T dy from an activation image x3 [M,3K] = [hi|lo|hi] and a gradient image dy3 [M,3N] = [hi|hi|lo]: seen as
     [3M,K] and [3M,N] their rows pair up plane by plane, so dW = xh^T dyh + xl^T dyh + xh^T dyl is one bf16 GEMM with a
     3M-deep reduction and fp32 accumulation.  hipBLASLt does not split a long reduction with a small output by itself
@@ -1097,9 +1161,32 @@ def _dw_x3(x3, dy3, K, N):
     M3 = 3 * x3.shape[0]
     S = 8 if K * N <= (1 << 20) else 4
     if M3 % S or M3 // S < 512:
-        return torch.mm(x3.view(M3, K).t(), dy3.view(M3, N), out_dtype=torch.float32)
-    xb, db = x3.view(S, M3 // S, K), dy3.view(S, M3 // S, N)
-    return torch.bmm(xb.transpose(1, 2), db, out_dtype=torch.float32).sum(0)
+        full = torch.mm(x3.view(M3, K).t(), dy3.view(M3, N), out_dtype=torch.float32)
+        part = None
+    else:
+        xb, db = x3.view(S, M3 // S, K), dy3.view(S, M3 // S, N)
+        part = torch.bmm(xb.transpose(1, 2), db, out_dtype=torch.float32)           # [S, K, N] partial sums
+        full = None
+    if outs is None:
+        return full if full is not None else part.sum(0)
+    slots = [_grad_slot(W) for W, _, _ in outs]
+    if all(sl is None for sl in slots) and full is None:
+        full = part.sum(0)
+    res = []
+    for (W, c0, nc), sl in zip(outs, slots):
+        if sl is None:
+            res.append(full[:, c0:c0 + nc] if (c0, nc) != (0, N) else full)
+        else:
+            if full is not None:
+                sl.copy_(full[:, c0:c0 + nc])
+            else:
+                torch.sum(part[:, :, c0:c0 + nc], 0, out=sl)
+            _grad_done(W)
+            res.append(None)
+    if full is None and any(sl is None for sl in slots):                              # mixed (never in practice): the rest from one sum
+        full = part.sum(0)
+        res = [full[:, c0:c0 + nc] if r is None and sl is None else r for r, sl, (W, c0, nc) in zip(res, slots, outs)]
+    return tuple(res)
 
 
 class _FFNX3(torch.autograd.Function):
@@ -1110,6 +1197,7 @@ class _FFNX3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y2d, W1, b1, W2):
         y2d = _rows(y2d, "ffn input")
+        W1_0, W2_0 = W1, W2
         W1, W2 = _f32(W1, "W1").contiguous(), _f32(W2, "W2").contiguous()
         lib = _capi.load()
         M, F = y2d.shape
@@ -1137,6 +1225,7 @@ class _FFNX3(torch.autograd.Function):
             w23n, w23k = _split_weight(W2)
             ctx.save_for_backward(y3, f3, w13k, w23k)
         ctx.dims = (W1.shape[0], W1.shape[1], W2.shape[1])
+        ctx.wrefs = (W1_0, W2_0)
         return _mm3(f3, w23n)
 
     @staticmethod
@@ -1148,7 +1237,7 @@ class _FFNX3(torch.autograd.Function):
         M = y3.shape[0]
         if do3 is None:
             do3 = _split_rows(dout.contiguous(), grad=True)
-        dW2 = _dw_x3(f3, do3, H, N)
+        dW2 = _dw_x3(f3, do3, H, N, outs=[(ctx.wrefs[1], 0, N)])[0]
         dp3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=f3.device)
         db1 = torch.empty((H,), dtype=torch.float32, device=f3.device)
         if ctx.tiles:
@@ -1172,7 +1261,7 @@ class _FFNX3(torch.autograd.Function):
                       "lpm_split_rows_relu_bwd")
             del df
         dy = _mm3(dp3, w13k, acc)
-        dW1 = _dw_x3(y3, dp3, F, H)
+        dW1 = _dw_x3(y3, dp3, F, H, outs=[(ctx.wrefs[0], 0, H)])[0]
         return dy, dW1, db1, dW2
 
 

@@ -140,6 +140,9 @@ class ParameterArena:
             if t.grad is not None:
                 t._lpm_grad_view.add_(t.grad)
                 t.grad = None
+            coef = self.l2.get(name)
+            if coef:                          # analytic L2 penalty of a directly written gradient: coefficient * w (see gather_names)
+                t._lpm_grad_view.add_(t.detach(), alpha=coef)
         if not self.gather:
             return
         self.gather_names([n for n in self.names if n not in direct and n not in skip])
@@ -390,6 +393,15 @@ class Trainer:
             self._factored_work = []
         elif self.device.type == "cuda":
             self.arena.mark_direct("tower/hidden1_weights", on_ready=early)
+        if self.device.type == "cuda" and not self.sync.active and FLAGS.direct_weight_gradients:
+            # single GPU: the encoders' dense kernels receive their gradients straight from the split-K sums of their weight-gradient
+            # GEMMs (ops._dw_x3) -- no fresh gradient tensor, no AccumulateGrad copy of a column view, no gather copy into the arena.
+            # (Data parallel: the early buckets are counted from autograd hooks, which a direct write never fires -- unchanged there.)
+            for n in self.arena.names:
+                enc = n.endswith("/kernel") and "_attention/" in n
+                moe = n in ("tower/gates/weights", "tower/experts/weights")          # ops.linear_direct (video_level_models.MoeModel)
+                if (enc or moe) and self.arena.views[n].dim() == 2 and n not in {d[0] for d in self.arena.direct}:
+                    self.arena.mark_direct(n)
         elif early is not None:
             self.arena.views["tower/hidden1_weights"].register_post_accumulate_grad_hook(lambda p: early())
         # the head and encoder buckets are gathered + all-reduced from hooks as backward completes them
@@ -430,7 +442,7 @@ class Trainer:
         direct = {d[0] for d in self.arena.direct}
         for w, scale in self._l2_regs:
             name = self.arena._name_of.get(id(w))
-            if name is None or not self.arena.gather or name in direct:
+            if name is None or not self.arena.gather or (name in direct and self.sync.active):
                 raise RuntimeError("analytic L2 penalty on a variable the gather-mode arena does not gather")
             self.arena.l2[name] = self.arena.l2.get(name, 0.0) + self.reg_penalty * scale
         self._l2_regs = []

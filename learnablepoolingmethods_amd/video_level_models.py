@@ -9,6 +9,14 @@ from . import FLAGS, models
 from . import variables as vs
 
 
+def _linear(x, W, b=None):
+    """x W (+ b); on the GPU through ops.linear_direct (the weight gradient may go straight into the trainer's gradient arena)."""
+    if x.is_cuda and x.dtype == torch.float32 and W.dtype == torch.float32 and x.dim() == 2:
+        from . import ops
+        return ops.linear_direct(x, W, b)
+    return torch.addmm(b, x, W) if b is not None else x.matmul(W)
+
+
 class MoeModel(models.BaseModel):
     """A softmax over a mixture of logistic models (with L2 regularization)."""
 
@@ -28,7 +36,7 @@ class MoeModel(models.BaseModel):
             with vs.variable_scope("gates"):                           # slim.fully_connected, no bias :86-93
                 wg = vs.get_variable("weights", [H, vocab_size * (num_mixtures + 1)], vs.glorot_uniform_initializer(), device=dev)
             store.add_l2_regularizer(wg, l2_penalty)                   # slim.l2_regularizer :91
-            gate_activations = model_input.matmul(wg)
+            gate_activations = _linear(model_input, wg)
         else:                                                          # two bias-free layers through a low_rank_gating bottleneck :94-108
             with vs.variable_scope("gates1"):
                 wg1 = vs.get_variable("weights", [H, low_rank_gating], vs.glorot_uniform_initializer(), device=dev)
@@ -41,7 +49,7 @@ class MoeModel(models.BaseModel):
             we = vs.get_variable("weights", [H, vocab_size * num_mixtures], vs.glorot_uniform_initializer(), device=dev)
             be = vs.get_variable("biases", [vocab_size * num_mixtures], vs.zeros_initializer(), device=dev)
         store.add_l2_regularizer(we, l2_penalty)                       # :113
-        expert_activations = torch.addmm(be, model_input, we)
+        expert_activations = _linear(model_input, we, be)
         fuse_loss = fused_cross_entropy and not gating_probabilities   # (probability gating changes the predictions behind the mixture)
         if model_input.is_cuda and num_mixtures <= 8 and (labels is None or fused_cross_entropy):
             from . import ops
