@@ -1,10 +1,10 @@
-"""Which Python lines issue the small at::native launches of a training step?  One step of a bench.py workload under torch.profiler with
-stacks; prints, for the aten ops that launch the fill / copy / add / mul / sum / cat kernels, their count per step and the innermost
-repo frames.  Usage: python tools/small_ops.py [cfg2|cfg3|cfg5]"""
-import collections, os, sys
+"""Which Python lines issue the small torch launches of a training step?  (torch.profiler has no Python stacks in this build.)  The
+Python entry points of the usual suspects are wrapped for ONE step and every call on a CUDA tensor is counted under its innermost repo
+frames; what the autograd engine issues from C++ (AccumulateGrad copies, zero-filled undefined gradients, the backward of plain torch
+ops) does not pass through here -- the difference to the profiler's per-step counts is theirs.  Usage: python tools/small_ops.py [cfg2|cfg3|cfg5]"""
+import collections, os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from torch.profiler import ProfilerActivity, profile
 import bench
 from learnablepoolingmethods_amd import registry
 from learnablepoolingmethods_amd.train import Trainer
@@ -19,20 +19,37 @@ raw, nf, labels = bench.synthetic_batch(wl["batch"], dev, seed=0)
 for _ in range(5):
     tr.step(raw, nf, labels)
 torch.cuda.synchronize()
-N = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    for _ in range(N):
-        tr.step(raw, nf, labels)
-    torch.cuda.synchronize()
-WANT = ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::mul_", "aten::sum", "aten::cat", "aten::clone",
-        "aten::contiguous", "aten::div", "aten::sub", "aten::neg", "aten::sigmoid", "aten::_foreach_copy_", "aten::_foreach_add_", "aten::zeros",
-        "aten::full", "aten::to", "aten::_to_copy", "aten::stack", "aten::index", "aten::select", "aten::mean", "aten::sqrt", "aten::rsqrt")
 sites = collections.Counter()
-for ev in prof.events():
-    if ev.name in WANT and ev.device_time_total > 0 or (ev.name in WANT and any(k.device_time > 0 for k in getattr(ev, "kernels", []))):
-        frames = [f for f in (ev.stack or []) if "/root/repo" in f or "learnablepoolingmethods_amd" in f or "bench.py" in f]
-        where = " <- ".join(f.split("/")[-1] for f in frames[:3]) or "(no repo frame)"
-        sites[(ev.name, where)] += 1
-print(f"{cfg}: aten ops with device kernels, per step (x{N} steps profiled)")
-for (name, where), c in sorted(sites.items(), key=lambda kv: -kv[1]):
-    print(f"{c / N:6.1f}  {name:22s} {where}")
+
+
+def where():
+    fr = [f for f in traceback.extract_stack()[:-2] if "learnablepoolingmethods_amd" in f.filename]
+    return " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(fr[-3:])) or "(no repo frame)"
+
+
+def wrap(owner, name, label):
+    orig = getattr(owner, name)
+
+    def f(*a, **k):
+        t = next((x for x in list(a) + list(k.values()) if torch.is_tensor(x)), None)
+        devs = str(k.get("device", "")) + (str(t.device) if t is not None else "")
+        if "cuda" in devs or (t is None and name in ("zeros", "full", "empty")):
+            sites[(label, where())] += 1
+        return orig(*a, **k)
+    setattr(owner, name, f)
+    return orig
+
+
+saved = []
+for owner, names in ((torch, ("zeros", "zeros_like", "full", "cat", "sum", "stack", "where", "sigmoid", "clamp")),
+                     (torch.Tensor, ("zero_", "fill_", "sum", "add_", "copy_", "mul", "__mul__", "__rmul__", "__add__", "__radd__", "__sub__", "__truediv__",
+                                     "to", "contiguous", "clone", "float", "mean", "sigmoid", "matmul", "t"))):
+    for n in names:
+        saved.append((owner, n, wrap(owner, n, f"{owner.__name__}.{n}")))
+tr.step(raw, nf, labels)
+torch.cuda.synchronize()
+for owner, n, orig in saved:
+    setattr(owner, n, orig)
+print(f"{cfg}: Python-level calls on CUDA tensors in one step (contiguous / to / t may be no-ops)")
+for (label, w), c in sorted(sites.items(), key=lambda kv: (-kv[1], kv[0])):
+    print(f"{c:4d}  {label:22s} {w}")
