@@ -16,6 +16,10 @@
 // extern LDS object); 6*NTW MFMAs per wave per step.
 // 128-row form (tile_gemm.hip, MW = 2; K1's forward at K = 256): 512 threads = two row groups of four waves over one flat
 // row-tile sequence, 4-stage ring, the fragment reads of step s + 1 issued under the MFMAs of step s.
+// Round 3 (the encoder's dense layers, lpm_dense_tiles_*): the 128-row form with a 3-stage ring and TWO workgroups per CU (no software
+// pipelining: the neighbour covers barriers and epilogues), and the 256-row form (RTW = 4: four row tiles per wave, 128 x 64
+// accumulators, 12 KB of fragment reads per 24 MFMAs instead of 8 KB per 12) whose STORE epilogue can write split-bf16 operand IMAGES
+// with bias + ReLU / ReLU-mask + bias-gradient fused (TileGemmArgs::img).  Measured per shape against hipBLASLt in DESIGN.md section 4.
 #pragma once
 #include "lpm_common.h"
 

@@ -205,3 +205,43 @@ def test_moe_low_rank_and_probability_gating_branches(low_rank, prob, inp, remov
             assert torch.allclose(store.vars[n].grad, pt[n].grad, rtol=1e-9, atol=1e-12), n
     finally:
         FLAGS.reset()
+
+
+def test_direct_gradient_slots_in_the_gather_mode_arena():
+    """ParameterArena.mark_direct + collect (round 3: the encoders' dense kernels and the MoE matrices): a producer writes the gradient
+    into the variable's arena slice itself; collect() zeroes a slot nobody wrote, folds in what autograd accumulated on the side (a second
+    use of the weight), adds the analytic L2 penalty coefficient * w, and leaves the gathered variables to gather_names."""
+    from learnablepoolingmethods_amd import ops
+    store = vs.VariableStore(device="cpu", seed=0)
+    with vs.use_store(store):
+        w = vs.get_variable("experts/weights", [6, 4], vs.random_normal_initializer(1.0))
+        u = vs.get_variable("unused/kernel", [3, 2], vs.random_normal_initializer(1.0))
+        b = vs.get_variable("b", [5], vs.ones_initializer())
+    arena = train.ParameterArena(store, gather=True)
+    arena.mark_direct("experts/weights")
+    arena.mark_direct("unused/kernel")
+    arena.zero_grad()
+    # the producer: ops._grad_slot hands out the free slot once per step
+    slot = ops._grad_slot(w)
+    assert slot is not None and slot.data_ptr() == arena.grad[arena.segment("experts/weights")[0]:].data_ptr()
+    slot.copy_(torch.full((6, 4), 3.0))
+    ops._grad_done(w)
+    assert ops._grad_slot(w) is None                       # second use in the same step: back through autograd
+    w.grad = torch.full((6, 4), 0.5)                       # ... which accumulated this
+    (b.sum() * 2).backward()
+    arena.l2 = {"experts/weights": 0.1}
+    arena.collect()
+    a0, _ = arena.segment("experts/weights")
+    assert torch.allclose(arena.grad[a0:a0 + 24].view(6, 4), 3.0 + 0.5 + 0.1 * w.detach())
+    a1, _ = arena.segment("unused/kernel")
+    assert float(arena.grad[a1:a1 + 6].abs().sum()) == 0.0 and u.grad is None
+    a2, _ = arena.segment("b")
+    assert torch.equal(arena.grad[a2:a2 + 5], torch.full((5,), 2.0)) and b.grad is None
+    arena.zero_grad()
+    assert ops._grad_slot(w) is not None                   # re-armed for the next step
+    old = ops.DIRECT_WGRAD
+    try:
+        ops.DIRECT_WGRAD = False
+        assert ops._grad_slot(w) is None                   # the run-time switch sends everything through autograd
+    finally:
+        ops.DIRECT_WGRAD = old
