@@ -403,6 +403,16 @@ size_t lpm_bn_act_bwd_workspace_bytes(int M, int K);
 int lpm_bn_act_bwd(const float* dlt, const float* x, const float* pre_bias, int pre_relu, const float* mean, const float* var,
                    const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
                    size_t workspace_bytes, lpm_stream_t stream);
+/* FeedForwardNetworkMod (transformer_utils.py:741-756: dense -> relu -> batch_norm -> dense) without the fp32 round trip of the [M, 4F]
+ * tensor between its dense layers: the batch norm writes its result ONLY as the split-bf16 activation image out3 [M, 3C] = [hi|lo|hi]
+ * the second dense layer's GEMM reads, and its backward writes the gradient of the first dense layer's raw output ONLY as the gradient
+ * image dl3 [M, 3K] = [hi|hi|lo].  Arguments otherwise as lpm_bn_rows_act_fwd / lpm_bn_act_bwd; C, K multiples of 8. */
+int lpm_bn_rows_act_image_fwd(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
+                              float eps, float decay, int biased_moving_variance, void* out3, float* mean, float* var, float* moving_mean,
+                              float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+int lpm_bn_act_bwd_image(const float* dlt, const float* x, const float* pre_bias, int pre_relu, const float* mean, const float* var,
+                         const float* gamma, float eps, int M, int K, void* dl3, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                         size_t workspace_bytes, lpm_stream_t stream);
 size_t lpm_bn_bwd_workspace_bytes(int M, int K);
 int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var, const float* gamma,
                float eps, int M, int K, float* dl, float* dgamma, float* dbeta, void* workspace,

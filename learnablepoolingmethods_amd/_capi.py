@@ -117,6 +117,8 @@ SIGNATURES = {
     "lpm_bn_act_bwd_supported": (_i, [_i, _i]),
     "lpm_bn_act_bwd_workspace_bytes": (_s, [_i, _i]),
     "lpm_bn_act_bwd": (_i, [_f, _f, _f, _i, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _f, _s, _f]),
+    "lpm_bn_rows_act_image_fwd": (_i, [_f, _f, _i, _i, _i, _f, _f, _fl, _fl, _i, _f, _f, _f, _f, _f, _f, _s, _f]),
+    "lpm_bn_act_bwd_image": (_i, [_f, _f, _f, _i, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_bn_rows_fwd": (_i, [_f, _i, _i, _f, _f, _fl, _fl, _i, _f, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_bn_bwd_workspace_bytes": (_s, [_i, _i]),
     "lpm_bn_bwd": (_i, [_f, _f, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _s, _f]),

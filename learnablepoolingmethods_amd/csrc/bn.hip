@@ -174,6 +174,24 @@ __global__ __launch_bounds__(1024) void mha_bn_corrections_kernel(const float* _
     }
 }
 
+// A float4 as the split-bf16 operand image of the encoder GEMMs (split_gemm.hip): row-major [M][3 C] bf16, planes [hi | lo | hi]
+// (activations, order 0) or [hi | hi | lo] (gradients, order 1); hi = bf16(v), lo = bf16(v - hi), round-to-nearest-even both.
+__device__ __forceinline__ unsigned bn_rne(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void bn_store_image(unsigned short* __restrict__ img, int64_t row, int c, int C, int order, float4 v) {
+    const unsigned hx = bn_rne(v.x), hy = bn_rne(v.y), hz = bn_rne(v.z), hw = bn_rne(v.w);
+    const unsigned lx = bn_rne(v.x - __uint_as_float(hx << 16)), ly = bn_rne(v.y - __uint_as_float(hy << 16));
+    const unsigned lz = bn_rne(v.z - __uint_as_float(hz << 16)), lw = bn_rne(v.w - __uint_as_float(hw << 16));
+    const uint2 hi = make_uint2(hx | (hy << 16), hz | (hw << 16)), lo = make_uint2(lx | (ly << 16), lz | (lw << 16));
+    unsigned short* p = img + row * 3 * (int64_t)C + c;
+    *reinterpret_cast<uint2*>(p) = hi;
+    *reinterpret_cast<uint2*>(p + C) = order ? hi : lo;
+    *reinterpret_cast<uint2*>(p + 2 * (int64_t)C) = order ? lo : hi;
+}
+
 // pass 3: dl = gamma*rstd*(dlt - mean_r(dlt) - Lhat*mean_r(dlt*Lhat))
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dlt,
                                                            const float* __restrict__ logits,
@@ -183,7 +201,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float eps, int M, int K,
                                                            float* __restrict__ dl, const float* __restrict__ pb, int relu,
-                                                           float* __restrict__ dbpart) {
+                                                           float* __restrict__ dbpart, unsigned short* __restrict__ dl3) {
+    // dl3 != null: the result leaves as the GRADIENT image [M][3K] = [hi | hi | lo] of the dense layer in front instead of as fp32
     // pb / relu: the normalised tensor was act(logits + pb); dl is then the gradient of the RAW logits (masked where the ReLU was off)
     // and dbpart [stride / (K/4)][K] receives this thread's column sums of it (the bias gradient; needs the fixed-column arrangement)
     // dl = A d + Bq (l - mean) + Cq per column, A = gamma rstd, Bq = -gamma rstd^2 dgamma / M, Cq = -gamma rstd dbeta / M.  When the
@@ -220,7 +239,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             o.x = l.x > 0.f ? o.x : 0.f; o.y = l.y > 0.f ? o.y : 0.f; o.z = l.z > 0.f ? o.z : 0.f; o.w = l.w > 0.f ? o.w : 0.f;
         }
         bsum.x += o.x; bsum.y += o.y; bsum.z += o.z; bsum.w += o.w;
-        reinterpret_cast<float4*>(dl)[i] = o;
+        if (dl3) bn_store_image(dl3, i / K4, (int)(i % K4) * 4, K, 1, o);
+        else reinterpret_cast<float4*>(dl)[i] = o;
     };
     const float4* dp = reinterpret_cast<const float4*>(dlt);
     const float4* lp = reinterpret_cast<const float4*>(logits);
@@ -287,12 +307,16 @@ __global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restr
 // y = x * scale[c] + shift[c]
 __global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int64_t total4, int C4,
-                                                            float* __restrict__ y, const float* __restrict__ pb, int relu) {
+                                                            float* __restrict__ y, const float* __restrict__ pb, int relu,
+                                                            unsigned short* __restrict__ y3) {
+    // y3 != null: the result leaves as the ACTIVATION image [M][3C] = [hi | lo | hi] of the next dense layer instead of as fp32
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
         const float4 v = bn_preact(reinterpret_cast<const float4*>(x)[i], pb, c, relu);
         const float4 a = *reinterpret_cast<const float4*>(scale + c), b = *reinterpret_cast<const float4*>(shift + c);
-        reinterpret_cast<float4*>(y)[i] = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
+        const float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
+        if (y3) bn_store_image(y3, i / C4, c, C4 * 4, 0, o);
+        else reinterpret_cast<float4*>(y)[i] = o;
     }
 }
 
@@ -305,7 +329,7 @@ extern "C" size_t lpm_bn_rows_workspace_bytes(int M, int C) {
 
 static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
                             float eps, float decay, int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
-                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3 = nullptr);
 extern "C" int lpm_bn_rows_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float decay,
                                int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
                                float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
@@ -321,11 +345,23 @@ extern "C" int lpm_bn_rows_act_fwd(const float* x, const float* pre_bias, int pr
     return bn_rows_fwd_impl(x, pre_bias, pre_relu, M, C, gamma, beta, eps, decay, biased_moving_variance, y, mean, var, moving_mean, moving_var,
                             workspace, workspace_bytes, stream);
 }
+// out3 [M, 3C] bf16: batch_norm(act(x + pre_bias)) written ONLY as the split-bf16 activation image [hi | lo | hi] the dense layer behind
+// it reads (FeedForwardNetworkMod, transformer_utils.py:741-756: dense -> relu -> batch_norm -> dense): no fp32 copy, no split pass
+extern "C" int lpm_bn_rows_act_image_fwd(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma,
+                                         const float* beta, float eps, float decay, int biased_moving_variance, void* out3, float* mean,
+                                         float* var, float* moving_mean, float* moving_var, void* workspace, size_t workspace_bytes,
+                                         lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(pre_bias && out3 && ((((uintptr_t)pre_bias) | (uintptr_t)out3) & 15) == 0 && C % 8 == 0, LPM_ERR_BADARG,
+                "lpm_bn_rows_act_image_fwd: needs a 16-byte aligned bias and image and C %% 8 == 0");
+    return bn_rows_fwd_impl(x, pre_bias, pre_relu, M, C, gamma, beta, eps, decay, biased_moving_variance, nullptr, mean, var, moving_mean,
+                            moving_var, workspace, workspace_bytes, stream, out3);
+}
 static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
                             float eps, float decay, int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
-                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3) {
     using namespace lpm;
-    LPM_REQUIRE(x && y && mean && var && workspace, LPM_ERR_BADARG, "lpm_bn_rows_fwd: null pointer");
+    LPM_REQUIRE(x && (y || y3) && mean && var && workspace, LPM_ERR_BADARG, "lpm_bn_rows_fwd: null pointer");
     LPM_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_bn_rows_fwd: need C %% 4 == 0 and 16-byte aligned pointers (M=%d C=%d)", M, C);
     LPM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), LPM_ERR_BADARG, "lpm_bn_rows_fwd: moving statistics go together");
@@ -342,7 +378,7 @@ static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu,
     const int64_t total4 = (int64_t)M * C / 4;
     const int64_t want = (total4 + 255) / 256;
     hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, x, scale, shift, total4, C / 4, y, pre_bias,
-                       pre_relu);
+                       pre_relu, (unsigned short*)y3);
     return check_launch("lpm_bn_rows_fwd");
 }
 
@@ -381,7 +417,7 @@ static int bn_bwd_grid(int M, int K) {
 }  // namespace lpm
 static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_bias, int pre_relu, const float* mean, const float* var,
                        const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                       size_t workspace_bytes, lpm_stream_t stream);
+                       size_t workspace_bytes, lpm_stream_t stream, void* dl3 = nullptr);
 extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var,
                           const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta,
                           void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
@@ -407,11 +443,23 @@ extern "C" int lpm_bn_act_bwd(const float* dlt, const float* x, const float* pre
     LPM_REQUIRE(workspace_bytes >= lpm_bn_act_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE, "lpm_bn_act_bwd: workspace too small");
     return bn_bwd_impl(dlt, x, pre_bias, pre_relu, mean, var, gamma, eps, M, K, dl, dgamma, dbeta, dbias, workspace, workspace_bytes, stream);
 }
+// ... with the gradient of x written ONLY as the split-bf16 gradient image dl3 [M, 3K] = [hi | hi | lo] the input-gradient and
+// weight-gradient GEMMs of the dense layer in front read
+extern "C" int lpm_bn_act_bwd_image(const float* dlt, const float* x, const float* pre_bias, int pre_relu, const float* mean, const float* var,
+                                    const float* gamma, float eps, int M, int K, void* dl3, float* dgamma, float* dbeta, float* dbias,
+                                    void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(pre_bias && dbias && dl3 && ((((uintptr_t)pre_bias) | (uintptr_t)dl3) & 15) == 0 && K % 8 == 0, LPM_ERR_BADARG,
+                "lpm_bn_act_bwd_image: needs a 16-byte aligned bias, image and dbias and K %% 8 == 0");
+    LPM_REQUIRE(lpm_bn_act_bwd_supported(M, K), LPM_ERR_UNSUPPORTED_SHAPE, "lpm_bn_act_bwd_image: shape not supported (M=%d K=%d)", M, K);
+    LPM_REQUIRE(workspace_bytes >= lpm_bn_act_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE, "lpm_bn_act_bwd_image: workspace too small");
+    return bn_bwd_impl(dlt, x, pre_bias, pre_relu, mean, var, gamma, eps, M, K, nullptr, dgamma, dbeta, dbias, workspace, workspace_bytes, stream, dl3);
+}
 static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_bias, int pre_relu, const float* mean, const float* var,
                        const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                       size_t workspace_bytes, lpm_stream_t stream) {
+                       size_t workspace_bytes, lpm_stream_t stream, void* dl3) {
     using namespace lpm;
-    LPM_REQUIRE(dlt && logits && mean && var && dl && dgamma && dbeta && workspace, LPM_ERR_BADARG,
+    LPM_REQUIRE(dlt && logits && mean && var && (dl || dl3) && dgamma && dbeta && workspace, LPM_ERR_BADARG,
                 "lpm_bn_bwd: null pointer");
     LPM_REQUIRE(M > 0 && K > 0 && K % 4 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_bn_bwd: need K %% 4 == 0 (M=%d K=%d)", M, K);
     LPM_REQUIRE((((uintptr_t)dlt | (uintptr_t)logits | (uintptr_t)mean | (uintptr_t)var | (uintptr_t)dl | (uintptr_t)workspace | (uintptr_t)gamma | (uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0,
@@ -425,7 +473,7 @@ static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_b
     const int grid = bn_bwd_grid(M, K);
     float* dbpart = dbias ? partial + (size_t)nblk * 2 * K : nullptr;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, dlt, logits, mean, var, gamma, dgamma, dbeta,
-                       eps, M, K, dl, pre_bias, pre_relu, dbpart);
+                       eps, M, K, dl, pre_bias, pre_relu, dbpart, (unsigned short*)dl3);
     if (dbias) {
         const int rows = (int)((int64_t)grid * 256 / (K / 4));
         if (rows > 4 * BN_CS_SLICES) {

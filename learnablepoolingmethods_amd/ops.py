@@ -69,6 +69,9 @@ FFN_TILES = os.environ.get("LPM_FFN_TILES", "1") != "0"
 # Run-time switch of the direct weight-gradient writes (ops._dw_x3 -> the trainer's arena slots, FLAGS.direct_weight_gradients): False
 # returns every gradient through autograd (A/B inside one process: tools/ab_flags.py ops.DIRECT_WGRAD).
 DIRECT_WGRAD = True
+# FeedForwardNetworkMod (NetVladV2's frame encoders) as one node whose batch norm writes the second dense layer's operand image and
+# whose backward writes the first layer's gradient image (ops.ffn_mod_x3); 0: dense / batch_norm / dense as separate nodes (A/B).
+FFN_MOD_FUSED = os.environ.get("LPM_FFN_MOD_FUSED", "1") != "0"
 # Matrix-core arithmetic of the soft-assignment GEMM K1: "bf16x3" (split-bf16 tiles on the bf16 pipe, default where
 # D %% 16 == 0 and K <= 512) or "f32" (exact fp32 MFMA).
 ASSIGN_PRECISION = os.environ.get("LPM_ASSIGN_PRECISION", "bf16x3")
@@ -1485,6 +1488,73 @@ class _BatchNormRowsAct(torch.autograd.Function):
         lib.check(lib._lpm_bn_act_bwd(ptr(dy2), ptr(x2), ptr(bias), 1 if ctx.relu else 0, ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, C,
                                       ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), wsb, stream_ptr()), "lpm_bn_act_bwd")
         return dx.view(ctx.shape), dbias, None, dgamma, dbeta, None, None, None
+
+
+class _FFNModX3(torch.autograd.Function):
+    """FeedForwardNetworkMod up to its second dense layer (transformer_utils.py:741-756): pre2 = BN(relu(y W1 + b1)) W2 as ONE node.
+    The [M, 4F] tensor between the dense layers exists in fp32 only as the first GEMM's raw output (which the batch norm's statistics
+    and backward need); the batch norm writes its result ONLY as the second GEMM's operand image (lpm_bn_rows_act_image_fwd) and its
+    backward writes the gradient of the raw output ONLY as the first layer's gradient image (lpm_bn_act_bwd_image): two 393 MB fp32
+    tensors and two operand-split passes per encoder and step are gone (NetVladV2 at cfg-3)."""
+
+    @staticmethod
+    def forward(ctx, y2d, W1, b1, gamma, beta, moving_mean, moving_var, W2):
+        lib = _capi.load()
+        y2d = _rows(y2d, "ffn input")
+        W1_0, W2_0 = W1, W2
+        W1, W2 = _f32(W1, "W1").contiguous(), _f32(W2, "W2").contiguous()
+        M, F = y2d.shape
+        C = W1.shape[1]
+        y3 = _split_rows(y2d)
+        w13n, w13k = _split_weight(W1)
+        pre = _mm3(y3, w13n)                                               # raw output of the first dense layer [M, C]
+        b1 = b1.contiguous()
+        f3 = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=y2d.device)
+        mean, var = _empty((C,), pre), _empty((C,), pre)
+        wsb = lib._lpm_bn_rows_workspace_bytes(M, C)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=pre.device)
+        lib.check(lib._lpm_bn_rows_act_image_fwd(ptr(pre), ptr(b1), 1, M, C, ptr(gamma), ptr(beta), BN_EPS, BN_DECAY, 1, ptr(f3), ptr(mean),
+                                                 ptr(var), ptr(moving_mean), ptr(moving_var), ptr(ws), wsb, stream_ptr()),
+                  "lpm_bn_rows_act_image_fwd")
+        w23n, w23k = _split_weight(W2)
+        ctx.save_for_backward(y3, pre, b1, mean, var, gamma, f3, w13k, w23k)
+        ctx.dims = (F, C, W2.shape[1])
+        ctx.wrefs = (W1_0, W2_0)
+        return _mm3(f3, w23n)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _capi.load()
+        y3, pre, b1, mean, var, gamma, f3, w13k, w23k = ctx.saved_tensors
+        F, C, N = ctx.dims
+        M = y3.shape[0]
+        do3 = _split_rows(dout.contiguous(), grad=True)
+        dW2 = _dw_x3(f3, do3, C, N, outs=[(ctx.wrefs[1], 0, N)])[0]
+        df = _mm3(do3, w23k)                                               # gradient of the batch norm's output [M, C]
+        dp3 = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=df.device)
+        dgamma, dbeta, db1 = _empty((C,), df), _empty((C,), df), _empty((C,), df)
+        wsb = lib._lpm_bn_act_bwd_workspace_bytes(M, C)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=df.device)
+        lib.check(lib._lpm_bn_act_bwd_image(ptr(df), ptr(pre), ptr(b1), 1, ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, C, ptr(dp3), ptr(dgamma),
+                                            ptr(dbeta), ptr(db1), ptr(ws), wsb, stream_ptr()), "lpm_bn_act_bwd_image")
+        del df
+        dy = _mm3(dp3, w13k) if ctx.needs_input_grad[0] else None
+        dW1 = _dw_x3(y3, dp3, F, C, outs=[(ctx.wrefs[0], 0, C)])[0]
+        return dy, dW1, db1, dgamma, dbeta, None, None, dW2
+
+
+def ffn_mod_x3_ok(x, filter_size, final_size):
+    rows = x.numel() // x.shape[-1]
+    return (FFN_MOD_FUSED and BN_ACT_FUSED and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 8 == 0 and filter_size % 8 == 0
+            and final_size % 8 == 0 and rows >= 1024 and bool(_capi.load()._lpm_bn_act_bwd_supported(rows, filter_size)))
+
+
+def ffn_mod_x3(x, W1, b1, gamma, beta, moving_mean, moving_var, W2):
+    """x [..., F] -> BN(relu(x W1 + b1)) W2 [..., N] (training mode; the batch norm's moving statistics are updated in place, biased
+    variance: the rank-3 path of slim.batch_norm)."""
+    rows = x.numel() // x.shape[-1]
+    out = _FFNModX3.apply(x.reshape(rows, x.shape[-1]), W1, b1, gamma, beta, moving_mean, moving_var, W2)
+    return out.reshape(*x.shape[:-1], W2.shape[1])
 
 
 def batch_norm_rows_act_ok(x, bias):

@@ -86,9 +86,20 @@ class FeedForwardNetworkMod(modules.BaseModule):
 
     def forward(self, inputs, **unused_params):
         # relu(dense) -> batch_norm twice (:741-760): the bias add and the ReLU of each dense layer ride in the batch norm's passes
-        pre, b1 = layers.dense(inputs, self.filter_size, True, "filter_output{}".format(self.scope_id), defer_bias=True)
+        n1, n2 = "filter_output{}".format(self.scope_id), "ff_output{}".format(self.scope_id)
+        rows = inputs.numel() // inputs.shape[-1]
+        if (self.is_train and inputs.dim() == 3 and layers.use_split_gemm(inputs, rows, self.filter_size)
+                and ops.ffn_mod_x3_ok(inputs, self.filter_size, self.final_size)):
+            # dense -> relu -> batch_norm -> dense as ONE node: the [rows, 4F] tensor in the middle leaves the batch norm only as the
+            # second GEMM's operand image, its gradient only as the first layer's gradient image (variables in the unfused order)
+            w1, b1 = layers.dense_variables(n1, inputs.shape[-1], self.filter_size, True, inputs.device)
+            g1, be1, mm1, mv1 = layers.bn_variables("filter_bn", self.filter_size, inputs.device)
+            w2, b2 = layers.dense_variables(n2, self.filter_size, self.final_size, True, inputs.device)
+            pre2 = ops.ffn_mod_x3(inputs, w1, b1, g1, be1, mm1, mv1, w2)
+            return layers.batch_norm(pre2, self.is_train, "feed_output_bn", pre_bias=b2, pre_relu=True)
+        pre, b1 = layers.dense(inputs, self.filter_size, True, n1, defer_bias=True)
         filter_output = layers.batch_norm(pre, self.is_train, "filter_bn", pre_bias=b1, pre_relu=True)
-        pre2, b2 = layers.dense(filter_output, self.final_size, True, "ff_output{}".format(self.scope_id), defer_bias=True)
+        pre2, b2 = layers.dense(filter_output, self.final_size, True, n2, defer_bias=True)
         return layers.batch_norm(pre2, self.is_train, "feed_output_bn", pre_bias=b2, pre_relu=True)
 
 

@@ -736,6 +736,51 @@ def test_residual_layer_norm_fused_bias_activation(B, L, F, res, relu):
     assert_close(biasg.grad, bd.grad, tol=1e-4, what="layer_norm dbias")
 
 
+@pytest.mark.parametrize("M,F,C,N", [(2400, 128, 512, 64), (24000, 1024, 4096, 256)])
+def test_ffn_mod_one_node(M, F, C, N):
+    """FeedForwardNetworkMod up to its second dense layer, BN(relu(y W1 + b1)) W2 (transformer_utils.py:741-756), as ONE node
+    (ops.ffn_mod_x3: the batch norm writes only the second GEMM's operand image, its backward only the first layer's gradient image)
+    against fp64 autograd and against the separate nodes it replaces (dense_x3 -> batch_norm_rows_act -> dense_x3): values, every
+    gradient, moving statistics.  (24000 x 1024 x 4096 x 256 = NetVladV2's video encoder at cfg-3.)"""
+    from learnablepoolingmethods_amd import ops
+    from tests._util import rel_l2
+    dev = cuda()
+    g = torch.Generator().manual_seed(M + C)
+    y, W1, b1 = torch.randn(M, F, generator=g), torch.randn(F, C, generator=g) / F ** .5, 0.3 * torch.randn(C, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    W2, dout = torch.randn(C, N, generator=g) / C ** .5, torch.randn(M, N, generator=g)
+    yd, W1d, b1d, gd, bd, W2d = (t.double().requires_grad_(True) for t in (y, W1, b1, gamma, beta, W2))
+    a = torch.relu(yd @ W1d + b1d)
+    mu, var = a.mean(0), a.var(0, unbiased=False)
+    ref = ((a - mu) * torch.rsqrt(var + 1e-3) * gd + bd) @ W2d
+    ref.backward(dout.double())
+    outs = {}
+    for fused in (True, False):
+        t = [x.to(dev).requires_grad_(True) for x in (y, W1, b1, gamma, beta, W2)]
+        mm, mv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        if fused:
+            out = ops.ffn_mod_x3(t[0], t[1], t[2], t[3], t[4], mm, mv, t[5])
+        else:
+            pre = ops.dense_x3(t[0], t[1])
+            f = ops.batch_norm_rows_act(pre, t[2], True, t[3], t[4], mm, mv, True)
+            out = ops.dense_x3(f, t[5])
+        out.backward(dout.to(dev))
+        outs[fused] = (out.detach(), [x.grad for x in t], mm, mv)
+    out, grads, mm, mv = outs[True]
+    assert_close(out, ref, tol=5e-5, what="ffn_mod forward")
+    assert_close(mm, 0.001 * mu, tol=1e-4, what="moving mean")
+    assert_close(mv, 0.999 + 0.001 * var, tol=1e-4, what="moving variance (biased: rank-3 slim.batch_norm)")
+    for got, want, nm in zip(grads, (yd, W1d, b1d, gd, bd, W2d), ("dy", "dW1", "db1", "dgamma", "dbeta", "dW2")):
+        e = rel_l2(got, want.grad)
+        assert e <= 5e-3, f"ffn_mod {nm}: relative L2 error {e:.3e}"          # (ReLU units within rounding of zero flip: see the FFN test below)
+    # the two routes compute the same thing from the same GEMMs: agreement far below the ReLU-flip noise against fp64
+    o2, g2, mm2, mv2 = outs[False]
+    assert_close(out, o2, tol=2e-6, what="one node vs separate nodes")
+    for a_, b_, nm in zip(grads, g2, ("dy", "dW1", "db1", "dgamma", "dbeta", "dW2")):
+        assert rel_l2(a_, b_) <= 2e-5, f"one node vs separate nodes, {nm}: {rel_l2(a_, b_):.3e}"
+    assert torch.equal(mm, mm2) and torch.equal(mv, mv2)
+
+
 @pytest.mark.parametrize("M,K,N", [(2048, 512, 768), (1984, 256, 512), (20480, 1024, 1024)])
 @pytest.mark.parametrize("form", [1, 2, 3, 4])
 def test_dense_tile_gemm_forms(M, K, N, form):

@@ -19,7 +19,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 wl = bench.WORKLOADS[sys.argv[4] if len(sys.argv) > 4 else "cfg2"]
 bench.set_flags(wl)
 dev = torch.device("cuda:0")
-trainer = Trainer(registry.get_model("NetVladV1"), vocab_size=bench.VOCAB, batch_size=wl["batch"], device=dev, seed=1234,
+trainer = Trainer(registry.get_model(wl.get("model", "NetVladV1")), vocab_size=bench.VOCAB, batch_size=wl["batch"], device=dev, seed=1234,
                   model_kwargs=wl["model_kwargs"], **bench.TRAIN)
 raw, nf, labels = bench.synthetic_batch(wl["batch"], dev, seed=0)
 
