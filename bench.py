@@ -48,7 +48,7 @@ WORKLOADS = {
                  workload="NetVladV2 K=256 hidden=512 rgb+audio 1152-d 300 frames, bs 80 on one GPU (BASELINE configs[2]), full training "
                           "step with the reference's dropout on",
                  dtype_detail="fp32 storage and accumulation everywhere; K2, K3, K4 and the encoder dense GEMMs feed the bf16 MFMA pipe with "
-                              "split-bf16 (hi+lo) operands, 3 MFMAs per product; the logits_bn attention forward in exact-fp32 MFMA"),
+                              "split-bf16 (hi+lo) operands, 3 MFMAs per product (the logits_bn attention forward too at 300 keys; exact fp32 below 128)"),
     "cfg5": dict(metric="clips/sec training step, gated NetVLAD K=512 + MoE-4, 300-frame 1152-d bf16, bs=128 per GPU (BASELINE configs[4])",
                  model_kwargs=dict(iterations=300, cluster_size=512, hidden_size=1024, encoder=False),
                  oracle=dict(iterations=300, cluster_size=512, hidden_size=1024, encoder=False, moe_num_mixtures=4),

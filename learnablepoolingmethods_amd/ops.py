@@ -83,9 +83,15 @@ MHA_PRECISION = os.environ.get("LPM_MHA_PRECISION", "bf16x3")
 # close to uniform, outputs close to the mean of v), which amplifies the 1e-5 element error of a split-bf16 forward ~500x --
 # 1e-2 on whole-model gradients in the small NetVladV2 parity case, while the same arithmetic in the backward passes alone
 # stays at the fp32 kernels' 2e-4 (tests/diagnostics/debug_v2_grad.py).  "f32" / "bf16x3": every pass in that arithmetic.
+# Round 3: that amplification is a property of SHORT sequences (the small parity case has 12 keys: softmax over 12 nearly equal logits,
+# attention_bn over columns whose variance is at rounding level -- still 1e-2 with a split-bf16 forward, debug_v2_grad.py).  At the
+# benchmark's sizes (300 keys, cfg-3) a split-bf16 forward changes nothing measurable: worst whole-model gradient against the fp64 oracle
+# 4.8e-5 (bf16x3 forward) vs 5.1e-5 (fp32 forward) at 80 clips (tests/test_gpu_benched_shapes.py), the whole GPU tier green either way,
+# and the step is 0.2 ms shorter.  "auto" for the forward pass = exact fp32 below MHA_BN_X3_MIN_KEYS keys, split-bf16 from there.
 MHA_BN_PRECISION = os.environ.get("LPM_MHA_BN_PRECISION", "mixed")
 # "mixed": arithmetic per pass (forward, backward statistics pass, backward main pass)
-MHA_BN_MIXED = os.environ.get("LPM_MHA_BN_MIXED", "f32,bf16x3,bf16x3")
+MHA_BN_MIXED = os.environ.get("LPM_MHA_BN_MIXED", "auto,bf16x3,bf16x3")
+MHA_BN_X3_MIN_KEYS = int(os.environ.get("LPM_MHA_BN_X3_MIN_KEYS", "128"))
 
 # Split-bf16 tile copies of the most recent frame_sample_bn output (produced by the same kernel that writes the fp32
 # frames): {"base": weakref to y, "F": F, "Dv": .., "video": tensor, "audio": tensor|None}.  ops.netvlad / vlad_aggregate
@@ -1669,16 +1675,20 @@ def _mha_dims(q, num_heads):
     return B, L, F // num_heads
 
 
-def _bn_pass_precision(which):
-    """MHA_BN_PRECISION = "mixed": per-pass arithmetic of the logits_bn attention, as 'fwd,stats,main' in MHA_BN_MIXED."""
+def _bn_pass_precision(which, L=None):
+    """MHA_BN_PRECISION = "mixed": per-pass arithmetic of the logits_bn attention, as 'fwd,stats,main' in MHA_BN_MIXED ("auto": by the
+    number of keys L, see MHA_BN_X3_MIN_KEYS)."""
     if MHA_BN_PRECISION != "mixed":
         return MHA_BN_PRECISION
     fwd, stats, main = MHA_BN_MIXED.split(",")
-    return {"fwd": fwd, "stats": stats, "main": main}[which]
+    prec = {"fwd": fwd, "stats": stats, "main": main}[which]
+    if prec == "auto":
+        prec = "bf16x3" if (L is not None and L >= MHA_BN_X3_MIN_KEYS) else "f32"
+    return prec
 
 
-def _mha_fwd_fn(lib, bn=False, which="fwd"):
-    prec = _bn_pass_precision(which) if bn else MHA_PRECISION
+def _mha_fwd_fn(lib, bn=False, which="fwd", L=None):
+    prec = _bn_pass_precision(which, L) if bn else MHA_PRECISION
     if prec == "bf16x3":
         return lib._lpm_mha_fwd_x3
     if prec == "f32":
@@ -1686,8 +1696,8 @@ def _mha_fwd_fn(lib, bn=False, which="fwd"):
     raise LpmError(f"unknown attention precision {prec!r} (bf16x3 | f32)")
 
 
-def _mha_bwd_fn(lib, bn=False, which="main"):
-    prec = _bn_pass_precision(which) if bn else MHA_PRECISION
+def _mha_bwd_fn(lib, bn=False, which="main", L=None):
+    prec = _bn_pass_precision(which, L) if bn else MHA_PRECISION
     if prec == "bf16x3":
         return lib._lpm_mha_bwd_x3
     if prec == "f32":
@@ -1974,7 +1984,7 @@ class _MHACoreBN(torch.autograd.Function):
             mean, var = moving_mean.detach().clone(), moving_var.detach().clone()
         o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
         lse = _empty((B, h, L), q)
-        lib.check(_mha_fwd_fn(lib, bn=True)(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, h, d, 1.0, ptr(kscale), ptr(kshift), ptr(o),
+        lib.check(_mha_fwd_fn(lib, bn=True, L=L)(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, h, d, 1.0, ptr(kscale), ptr(kshift), ptr(o),
                                    o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
         ctx.dims = (B, L, h, d, is_training)
         ctx.save_for_backward(q, k, v, o, lse, kscale, kshift, mean, var, gamma)
