@@ -26,15 +26,23 @@ template <int MT>
 __host__ __device__ constexpr int pj_stage() { return PJ_WBYTES + MT * 32 * 16 * 4; }   // + x slab: MT x 32 rows x 16 floats
 
 // MT = row tiles (ceil(M / 32))
-template <int MT>
-__global__ __launch_bounds__(512, 2) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M,
-                                                          int64_t Kd, int N, int nslab, int splits, float* __restrict__ part, int dbg) {
+// XW (round 3): a NINTH wave brings ALL of x in and does nothing else, in PAIRS of slabs: 128 bytes per row (a whole cache line; the
+// first form asked for every line of x twice, 64 bytes at a time, from 2 MT of the computing waves whose in-order vmcnt queue then held
+// the contiguous weight pieces back behind the scattered x pieces).  x has its own ring of two pair-buffers [MT * 32 rows][128 B]
+// behind the four weight stages; a row's eight 16-byte parts sit XOR-swizzled by (row & 7) -- through the SOURCE address, the LDS image
+// stays lane-linear -- so the 32 rows a fragment read touches, 128 bytes apart, spread over all banks (the 64-byte rows of the first
+// form: 4-way conflicts).  Split ranges start on even slabs so that a pair is one aligned line.
+template <int MT, bool XW>
+__global__ __launch_bounds__(XW ? 576 : 512, 2) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M,
+                                                                     int64_t Kd, int N, int nslab, int splits, float* __restrict__ part, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int nb = blockIdx.y, sp = blockIdx.x;                  // 512-column block, split
-    const int s0 = (int)((int64_t)nslab * sp / splits), s1 = (int)((int64_t)nslab * (sp + 1) / splits);
+    const int npair = nslab >> 1;
+    const int s0 = XW ? 2 * (int)((int64_t)npair * sp / splits) : (int)((int64_t)nslab * sp / splits);
+    const int s1 = XW ? (sp == splits - 1 ? nslab : 2 * (int)((int64_t)npair * (sp + 1) / splits)) : (int)((int64_t)nslab * (sp + 1) / splits);
     const int ns = s1 - s0;
 
     // DMA roles.  W: piece p = wave * 4 + j (j < 4): slab row p >> 1, 1 KB half (p & 1) of the row's 512-column segment.
@@ -46,11 +54,43 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_kernel(const float* __restric
         wsrc[j] = W + ((int64_t)s0 * 16 + (p >> 1)) * N + nb * 512 + (p & 1) * 256 + lane * 4;
     }
     constexpr int PJ_STAGE = pj_stage<MT>();
-    const bool xwave = wave < 2 * MT;              // x pieces: 2 MT of 16 rows each, one per wave (wave-uniform)
+    constexpr int PJ_XPAIR = MT * 32 * 128;        // one pair-buffer of x
+    if constexpr (XW) {
+        if (wave == 8) {
+            // the x loader: piece p = 0 .. 4 MT - 1 of a pair = rows 8 p .. 8 p + 7 (clamped to M - 1: rows >= M are never stored), lane ->
+            // (row r = 8 p + lane / 8, LDS slot q = lane % 8) holding source part q ^ (r & 7); parts 0-3 = slab 2 j, parts 4-7 = slab 2 j + 1
+            // (the last pair of an odd range: its second slab is re-read from the first -- nobody consumes it)
+            const int q = lane & 7;
+            const int part = q ^ ((lane >> 3) & 7);                    // (8 p + lane / 8) & 7 == lane / 8
+            const float* xs[4 * MT];
+#pragma unroll
+            for (int p = 0; p < 4 * MT; ++p) xs[p] = x + (int64_t)min(p * 8 + (lane >> 3), M - 1) * ldx + (int64_t)s0 * 16 + part * 4;
+            const int nss = (ns + 1) >> 1;
+            auto issue_x = [&](int j) {
+                unsigned char* st = smem + PJ_NS * PJ_WBYTES + (j & 1) * PJ_XPAIR;
+                const int64_t off = (int64_t)j * 32 - ((part >= 4 && 2 * j + 1 >= ns) ? 16 : 0);
+#pragma unroll
+                for (int p = 0; p < 4 * MT; ++p)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs[p] + off),
+                                                     (__attribute__((address_space(3))) void*)(st + p * 1024), 16, 0, 0);
+            };
+            issue_x(0);
+            for (int s = 0; s < ns; ++s) {
+                // pair j = s / 2 is consumed by stages 2 j and 2 j + 1; at the barrier of stage 2 j the buffer of pair j - 1 is free again
+                if (!(s & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!(s & 1) && (s >> 1) + 1 < nss) issue_x((s >> 1) + 1);
+            }
+            return;
+        }
+    }
+    const bool xwave = !XW && wave < 2 * MT;       // x pieces: 2 MT of 16 rows each, one per wave (wave-uniform)
     const int xr = min(wave * 16 + (lane >> 2), M - 1);
     const float* xsrc = x + (int64_t)xr * ldx + (int64_t)s0 * 16 + (lane & 3) * 4;
+    constexpr int WSTRIDE = XW ? PJ_WBYTES : PJ_STAGE;
     auto issue = [&](int s) {
-        unsigned char* st = smem + (s % PJ_NS) * PJ_STAGE;
+        unsigned char* st = smem + (s % PJ_NS) * WSTRIDE;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + ((dbg & 2) ? 0 : (int64_t)s * 16 * N)),
@@ -86,8 +126,8 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_kernel(const float* __restric
         __builtin_amdgcn_s_barrier();              // stage s is in LDS for everyone; stage (s - 1) % NS is free again
         asm volatile("" ::: "memory");
         if (s + PJ_NS - 1 < ns) issue(s + PJ_NS - 1);
-        const float* wl = reinterpret_cast<const float*>(smem + (s % PJ_NS) * PJ_STAGE);
-        const float* xl = reinterpret_cast<const float*>(smem + (s % PJ_NS) * PJ_STAGE + PJ_WBYTES);
+        const float* wl = reinterpret_cast<const float*>(smem + (s % PJ_NS) * WSTRIDE);
+        const float* xl = reinterpret_cast<const float*>(XW ? smem + PJ_NS * PJ_WBYTES + ((s >> 1) & 1) * PJ_XPAIR : smem + (s % PJ_NS) * PJ_STAGE + PJ_WBYTES);
         if (dbg & 4) continue;
         tg_u32x4 bh[2], bl[2];
 #pragma unroll
@@ -102,8 +142,15 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_kernel(const float* __restric
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const float4 a0 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 16 + 8 * half);
-            const float4 a1 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 16 + 8 * half + 4);
+            float4 a0, a1;
+            if constexpr (XW) {
+                const int p0 = (s & 1) * 4 + 2 * half;                  // this lane's two 16-byte parts of row m * 32 + l31 (row & 7 == l31 & 7)
+                a0 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 32 + ((p0 ^ (l31 & 7)) << 2));
+                a1 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 32 + (((p0 + 1) ^ (l31 & 7)) << 2));
+            } else {
+                a0 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 16 + 8 * half);
+                a1 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 16 + 8 * half + 4);
+            }
             const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             uint4 hi, lo;
             tg_split8(v, hi, lo);
@@ -382,17 +429,28 @@ extern "C" int lpm_proj_fwd(const float* x, int64_t ldx, const float* W, int M, 
     const int splits = proj_splits(Kd, N), nslab = (int)(Kd / 16), MT = (M + 31) / 32;
     dim3 grid(splits, N / 512);
     hipStream_t s = (hipStream_t)stream;
+    static const int xw = [] { const char* e = getenv("LPM_PROJ_XWAVE"); return (e && e[0] == '0') ? 0 : 1; }();   /* 0: x pieces on waves 0 .. 2 MT - 1 (A/B) */
 #define LPM_PJ(MTV)                                                                                                          \
     do {                                                                                                                     \
-        auto kern = proj_fwd_kernel<MTV>;                                                                                    \
-        const size_t lds = (size_t)PJ_NS * pj_stage<MTV>();                                                                  \
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {    \
-            (void)hipGetLastError();                                                                                         \
-            set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                                 \
-            return LPM_ERR_LAUNCH;                                                                                           \
-        }                                                                                                                    \
         static const int dbg = [] { const char* e = getenv("LPM_PROJ_DBG"); return e ? atoi(e) : 0; }();                     \
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace, dbg);       \
+        const size_t lds = (xw && !dbg) ? (size_t)PJ_NS * PJ_WBYTES + 2 * MTV * 4096 : (size_t)PJ_NS * pj_stage<MTV>();      \
+        if (xw && !dbg) {                                                                                                    \
+            auto kern = proj_fwd_kernel<MTV, true>;                                                                          \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+                (void)hipGetLastError();                                                                                     \
+                set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                             \
+                return LPM_ERR_LAUNCH;                                                                                       \
+            }                                                                                                                \
+            hipLaunchKernelGGL(kern, grid, dim3(576), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace, 0);     \
+        } else {                                                                                                             \
+            auto kern = proj_fwd_kernel<MTV, false>;                                                                         \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+                (void)hipGetLastError();                                                                                     \
+                set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                             \
+                return LPM_ERR_LAUNCH;                                                                                       \
+            }                                                                                                                \
+            hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace, dbg);   \
+        }                                                                                                                    \
     } while (0)
     switch (MT) {
         case 1: LPM_PJ(1); break;
