@@ -189,7 +189,7 @@ _LIB: Optional[_Lib] = None
 def load() -> _Lib:
     global _LIB
     if _LIB is None:
-        _LIB = _Lib(LIB_PATH)
+        _LIB = _Lib(os.environ.get("LPM_HIP_LIBRARY") or LIB_PATH)      # (the override: A/B of two builds of the library, tools/)
     return _LIB
 
 

@@ -698,6 +698,9 @@ __global__ __launch_bounds__(256) void vlad_bwd_assign_rows_kernel(const float* 
 
 // ---- k-major forms (LPM_VLAD_RAW_KMAJOR): dO and the un-normalised sums U are [B, K, D], as the NetVladV1 cluster encoder hands the
 // gradient back and as lpm_vlad_aggregate_raw_kmajor_fwd stored the sums -- no transpose of dO, no d-major copy of U -----------------------
+// (Round 3: with packed fp32 instructions allowed, the compiler paired dw and nw into v_pk_fma_f32 and the nw half came out wrong by a
+// few per cent in ~3 % of training steps with a second process on the GPU -- tools/determinism_check.py; the library is built without
+// packed fp32 operations since, _build.py.)
 // one wave per (clip, cluster) row: dots[b][0][0..2][k] = <dO_k, N_k>, <dO_k, W2_k>, <N_k, W2_k>,  N_k = U_k rsqrt(max(colsq, eps))
 __global__ __launch_bounds__(256) void vlad_bwd_coldots_k_kernel(const float* __restrict__ dO, const float* __restrict__ U,
                                                                  const float* __restrict__ W2T, const float* __restrict__ colsq, int D, int K,

@@ -8,6 +8,7 @@ SURVEY.md App. C (C1 scope_id ignored, C5 tokens = clusters, C8 K // 4, C9 rgb-o
 """
 from __future__ import annotations
 
+import contextlib
 import math
 
 import torch
@@ -190,7 +191,6 @@ class NetVladV1(models.BaseModel):
             rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
         # the audio branch is ~100 small, latency-bound launches per step: it runs on a second stream beside the video branch
         # (variables are still created in the reference's order: video_VLAD, audio_VLAD, video_attention, audio_attention)
-        import contextlib
         use_side = has_audio and reshaped_input.is_cuda and FLAGS.audio_side_stream
         side = ops.side_stream(audio, reshaped_input) if use_side else contextlib.nullcontext()
         # The video descriptor goes to its cluster encoder LAZILY NORMALISED when that encoder will run as block Functions (they apply
@@ -311,15 +311,25 @@ class NetVladV2(models.BaseModel):
                                                                   is_training, "netvlad_rgb_scope")
         audio_NetVLAD = video_pooling_modules.NetVladAttenCluster(128, max_frames, cluster_size // 4, add_batch_norm,
                                                                   is_training, "netvlad_audio_scope")
+        if has_audio and reshaped_input.is_cuda:
+            # one contiguous copy per stream (the encoder and the aggregation both want whole rows); their gradients come back as ONE
+            # concatenation instead of two zero-filled [M, 1152] buffers, two slice copies and an add
+            rgb, audio = ops.split_columns(reshaped_input, 1024)
+            rgb, audio = rgb.contiguous(), audio.contiguous()
+        else:
+            rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
+        # the audio stream (128 features, 64 clusters: short, latency-bound launches) runs on a second HIP stream beside the video stream
+        use_side = has_audio and reshaped_input.is_cuda and FLAGS.audio_side_stream
+        side = ops.side_stream(audio, dm.get("audio")) if use_side else contextlib.nullcontext()
         with vs.variable_scope("video_VLAD"):
-            vlad_video = video_NetVLAD.forward(reshaped_input[:, 0:1024], dropout_mask=dm.get("video"),
-                                               dropout_rate=dropout_rate)                      # :2437-2438
+            vlad_video = video_NetVLAD.forward(rgb, dropout_mask=dm.get("video"), dropout_rate=dropout_rate)       # :2437-2438
             vs.summary("vlad_video", vlad_video)
         if has_audio:
-            with vs.variable_scope("audio_VLAD"):
-                vlad_audio = audio_NetVLAD.forward(reshaped_input[:, 1024:], dropout_mask=dm.get("audio"),
-                                                   dropout_rate=dropout_rate)                  # :2440-2441
+            with side, vs.variable_scope("audio_VLAD"):
+                vlad_audio = audio_NetVLAD.forward(audio, dropout_mask=dm.get("audio"), dropout_rate=dropout_rate)  # :2440-2441
                 vs.summary("vlad_audio", vlad_audio)
+            if use_side:
+                side.join(vlad_audio)
         vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video             # :2445
         vs.summary("vlad", vlad)
         return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,

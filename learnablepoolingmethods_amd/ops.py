@@ -97,6 +97,7 @@ MHA_BN_X3_MIN_KEYS = int(os.environ.get("LPM_MHA_BN_X3_MIN_KEYS", "128"))
 # frames): {"base": weakref to y, "F": F, "Dv": .., "video": tensor, "audio": tensor|None}.  ops.netvlad / vlad_aggregate
 # look a column-slice view of y up here instead of re-reading it through lpm_split_frames.
 _XT_CACHE = {}
+DEBUG_TAP = None      # tools/determinism_check.py: a dict that the video stream's pooling backward fills with copies of its intermediates
 
 # bench.py sets this to a list to collect (name, dims, start_event, end_event) around hot-kernel launches
 # on the current stream (HIP events; nothing is recorded or synchronised when it is None).
@@ -837,6 +838,12 @@ class _NetVLAD(torch.autograd.Function):
                                                              centres, B, T, D, K, flags, kmajor, no_dx=no_dx, nrm_raw=ctx.nrm_raw,
                                                              raw_kmajor=ctx.lazy)
             dx = None
+            if DEBUG_TAP is not None and D == 1024:
+                head = wspace[0].view(torch.float32)       # K3's workspace: dots [B][16 slots][3][K] (k-major form: the first B*3*K) | u | v | ctil
+                DEBUG_TAP.update(dout=dout.clone(), dlt_raw=dlt.clone(), dots=head[:B * 3 * K].clone() if ctx.lazy else None,
+                                 u_v_ctil=head[B * 16 * 3 * K:B * 16 * 3 * K + 3 * B * K].clone(), xr=xr.clone(), logits=logits.clone(),
+                                 scale=scale.clone(), shift=shift.clone(), nrm=nrm.clone(), colsq=colsq.clone(), dcentres=dcentres.clone(),
+                                 centres=centres.clone() if centres is not None else None, g0=g0.clone() if g0 is not None else None)
         else:
             dlt, dx, dcentres = _aggregate_bwd(lib, dout, nrm, asum, colsq, csq, gsq, logits, scale, shift, x, centres, B, T, D,
                                                K, flags, kmajor)
@@ -849,6 +856,8 @@ class _NetVLAD(torch.autograd.Function):
             lib.check(lib._lpm_bn_bwd(ptr(dlt), ptr(logits), ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, K, ptr(dlt),
                                       ptr(dgamma), ptr(dbeta), ptr(ws), wsb, stream_ptr()), "lpm_bn_bwd")
             dl = dlt
+            if DEBUG_TAP is not None and D == 1024:
+                DEBUG_TAP.update(dgamma=dgamma.clone(), dbeta=dbeta.clone(), dl=dl.clone(), bn_ws=ws.clone())
         elif use_bn:   # inference-mode statistics are constants
             lhat = (logits - mean) * torch.rsqrt(var + BN_EPS)
             dgamma, dbeta = (dlt * lhat).sum(0), dlt.sum(0)

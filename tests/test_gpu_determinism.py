@@ -1,0 +1,30 @@
+"""-m gpu: a training step is a pure function of (weights, optimiser state, batch).  No kernel on the path uses floating-point
+atomics, so the same step repeated must give the same bits -- also with a second process on the same GPU, which is how the two-rank
+tests and a shared box run.  This is the check that found round 3's intermittent K3 error (a compiler-paired v_pk_fma_f32 whose low
+half went wrong in ~3 % of steps under exactly that contention: tools/determinism_check.py); the library is built
+without packed fp32 instructions since (tests/test_build_flags.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("case,runs", [("blocks", 12), ("cfg3", 5)])
+def test_repeated_step_is_bit_identical_with_two_processes_on_the_gpu(case, runs):
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "determinism_check.py"), case, str(runs), "0" if case == "blocks" else "1", "tap"]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT) for _ in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=800)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for i, p in enumerate(procs):
+        assert p.returncode == 0 and "bit-identical" in outs[i], f"copy {i}:\n{outs[i][-3000:]}"
