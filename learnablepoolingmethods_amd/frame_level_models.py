@@ -311,25 +311,22 @@ class NetVladV2(models.BaseModel):
                                                                   is_training, "netvlad_rgb_scope")
         audio_NetVLAD = video_pooling_modules.NetVladAttenCluster(128, max_frames, cluster_size // 4, add_batch_norm,
                                                                   is_training, "netvlad_audio_scope")
-        if has_audio and reshaped_input.is_cuda:
+        if has_audio and reshaped_input.is_cuda and ops.V2_SPLIT_COLUMNS:
             # one contiguous copy per stream (the encoder and the aggregation both want whole rows); their gradients come back as ONE
             # concatenation instead of two zero-filled [M, 1152] buffers, two slice copies and an add
             rgb, audio = ops.split_columns(reshaped_input, 1024)
             rgb, audio = rgb.contiguous(), audio.contiguous()
         else:
             rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
-        # the audio stream (128 features, 64 clusters: short, latency-bound launches) runs on a second HIP stream beside the video stream
-        use_side = has_audio and reshaped_input.is_cuda and FLAGS.audio_side_stream
-        side = ops.side_stream(audio, dm.get("audio")) if use_side else contextlib.nullcontext()
+        # (NetVladV1 runs its audio stream on a second HIP stream; here that was measured SLOWER -- 10.95 vs 10.84 ms per step at cfg-3,
+        # tools/ab_flags.py: this model's audio stream attends over 300 frames, its launches are long enough to fill the chip by themselves)
         with vs.variable_scope("video_VLAD"):
             vlad_video = video_NetVLAD.forward(rgb, dropout_mask=dm.get("video"), dropout_rate=dropout_rate)       # :2437-2438
             vs.summary("vlad_video", vlad_video)
         if has_audio:
-            with side, vs.variable_scope("audio_VLAD"):
+            with vs.variable_scope("audio_VLAD"):
                 vlad_audio = audio_NetVLAD.forward(audio, dropout_mask=dm.get("audio"), dropout_rate=dropout_rate)  # :2440-2441
                 vs.summary("vlad_audio", vlad_audio)
-            if use_side:
-                side.join(vlad_audio)
         vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video             # :2445
         vs.summary("vlad", vlad)
         return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
