@@ -523,6 +523,13 @@ int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, c
                 int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
                 const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
                 const float* corr_b, float* dz_partial, lpm_stream_t stream);
+/* logits_bn backward in one pass over the scores: after lpm_mha_bwd_x3(dq = NULL, dk, dv, corr_a = corr_b = NULL, dz_partial) -- the
+ * key / value gradients WITHOUT the batch statistics' share, and the statistics --, lpm_mha_bn_corrections, and
+ * lpm_mha_bwd_x3(dq, dk = dv = NULL, corr_a, corr_b) for the query gradient, this subtracts the share from dk in place:
+ *   dk[b, j, head] -= corr_a[j] Sq + corr_b[j] Qm k[b, j, head],   Sq = sum_q scale q,  Qm = sum_q (scale q)(scale q)^T per (b, head)
+ * (the two correction terms of ds are affine in the raw score; transformer_utils.py:652-658, backward).  d in {8, 16}. */
+int lpm_mha_bn_dk_correct(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
+                          const float* corr_b, float* dk, int64_t ldd, lpm_stream_t stream);
 /* The same backward (no logits_bn) writing the q/k/v gradients ONLY as the split-bf16 gradient image the projection GEMMs read:
  * dqkv3 [B*L, 9*h*d] bf16, row = [hi | hi | lo] planes of the concatenated columns [dq | dk | dv] (what lpm_split_rows with
  * order = 1 would produce from the fp32 gradients) -- the fp32 dq/dk/dv and the split pass over them never exist. */

@@ -562,6 +562,79 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
     }
 }
 
+// logits_bn backward in ONE pass over the scores (round 3).  The batch norm's backward subtracts from ds two terms that need sums over
+// every (batch, head, query) first: ds[q, j] = sck[j] dz[q, j] - ca[j] - s[q, j] cb[j] (lpm_mha_bn_corrections).  The statistics pass that
+// produced those sums recomputed S, P and dP for nothing else.  But both terms are AFFINE in s = (scale q) . k, so their share of
+//   dK[j] = sum_q ds[q, j] (scale q)   is   - ca[j] Sq - cb[j] Qm k[j],      Sq = sum_q (scale q),  Qm = sum_q (scale q)(scale q)^T
+// -- a d-vector and a d x d matrix per (batch, head).  So: the dkv kernel runs ONCE with no corrections and emits the statistics on the
+// way (dz_partial), lpm_mha_bn_corrections turns them into ca / cb, the dq kernel (which walks the scores again anyway) applies them
+// in place as before, and this kernel repairs dK: one workgroup per (batch, head), q staged in LDS, 4 threads per key row.
+template <int D>
+__global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restrict__ q, const float* __restrict__ k, int64_t ld, int L, int h,
+                                                            float scale, const float* __restrict__ corr_a, const float* __restrict__ corr_b,
+                                                            float* __restrict__ dk, int64_t ldd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);                 // [L][D], scaled
+    float* Qm = qs + (size_t)L * D;                             // [D][D]
+    float* Sq = Qm + D * D;                                     // [D]
+    const int tid = threadIdx.x;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    constexpr int D4 = D / 4;
+    for (int i = tid; i < L * D4; i += 256) {
+        const int row = i / D4, c4 = i % D4;
+        float4 v = *reinterpret_cast<const float4*>(q + ((int64_t)b * L + row) * ld + hh * D + 4 * c4);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        *reinterpret_cast<float4*>(qs + row * D + 4 * c4) = v;
+    }
+    __syncthreads();
+    if (tid < D * D) {                                          // Qm[a][c] = sum_q q[a] q[c]; four partial sums against the add latency
+        const int a = tid / D, c = tid % D;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = 0;
+        for (; i + 3 < L; i += 4) {
+            s0 = fmaf(qs[i * D + a], qs[i * D + c], s0);
+            s1 = fmaf(qs[(i + 1) * D + a], qs[(i + 1) * D + c], s1);
+            s2 = fmaf(qs[(i + 2) * D + a], qs[(i + 2) * D + c], s2);
+            s3 = fmaf(qs[(i + 3) * D + a], qs[(i + 3) * D + c], s3);
+        }
+        for (; i < L; ++i) s0 = fmaf(qs[i * D + a], qs[i * D + c], s0);
+        Qm[tid] = (s0 + s1) + (s2 + s3);
+        if (c == 0) {                                           // Sq[a]
+            float t0 = 0.f, t1 = 0.f;
+            int j = 0;
+            for (; j + 1 < L; j += 2) { t0 += qs[j * D + a]; t1 += qs[(j + 1) * D + a]; }
+            if (j < L) t0 += qs[j * D + a];
+            Sq[a] = t0 + t1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < L * D4; i += 256) {
+        const int row = i / D4, c4 = i % D4;
+        const float* kp = k + ((int64_t)b * L + row) * ld + hh * D;
+        float kv[D];
+#pragma unroll
+        for (int e = 0; e < D4; ++e) {
+            const float4 t = *reinterpret_cast<const float4*>(kp + 4 * e);
+            kv[4 * e] = t.x; kv[4 * e + 1] = t.y; kv[4 * e + 2] = t.z; kv[4 * e + 3] = t.w;
+        }
+        const float ca = corr_a[row], cb = corr_b[row];
+        float* dp = dk + ((int64_t)b * L + row) * ldd + hh * D + 4 * c4;
+        float4 g = *reinterpret_cast<float4*>(dp);
+        float r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = 4 * c4 + u;
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < D; ++e) t = fmaf(Qm[a * D + e], kv[e], t);
+            r[u] = fmaf(cb, t, ca * Sq[a]);
+        }
+        g.x -= r[0]; g.y -= r[1]; g.z -= r[2]; g.w -= r[3];
+        *reinterpret_cast<float4*>(dp) = g;
+    }
+}
+
 static inline size_t mx_bwd_dq_lds(int LP, int D) { return (size_t)2 * mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP) + 4 * LP * 4; }
 static inline size_t mx_bwd_dkv_lds(int LP, int D) { return (size_t)2 * mx_rowplanes_bytes(LP, D) + 2 * mx_tplanes_bytes(LP) + 2 * LP * 4; }
 static inline size_t mx_fwd_lds(int LP, int D) { return (size_t)mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP) + 2 * LP * 4; }
@@ -659,11 +732,13 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
             hipLaunchKernelGGL(kq, grid, dim3(MX_DQ_NT), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dq, \
                                ldd, corr_a, corr_b, img, oimg);                                                        \
         }                                                                                                              \
-        auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                                   \
-        const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                                  \
-        if (int rc = mx_reserve(kk, lk, what)) return rc;                                                              \
-        hipLaunchKernelGGL(kk, grid, dim3(mx_dkv_nt(N)), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, dv, \
-                           ldd, corr_a, corr_b, dz_partial, img, oimg);                                                \
+        if (dk || dz_partial) {                                                                                        \
+            auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                               \
+            const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                              \
+            if (int rc = mx_reserve(kk, lk, what)) return rc;                                                          \
+            hipLaunchKernelGGL(kk, grid, dim3(mx_dkv_nt(N)), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, \
+                               dv, ldd, corr_a, corr_b, dz_partial, img, oimg);                                        \
+        }                                                                                                              \
     } while (0)
 #define LPM_MX_BWD1(N, AFF, RG)        \
     do {                               \
@@ -693,8 +768,8 @@ extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, in
                               const float* corr_b, float* dz_partial, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(q && k && v && o && dout && lse, LPM_ERR_BADARG, "lpm_mha_bwd_x3: null pointer");
-    LPM_REQUIRE((dq && dk && dv) || (!dq && !dk && !dv && dz_partial), LPM_ERR_BADARG,
-                "lpm_mha_bwd_x3: give dq, dk, dv together, or none of them (statistics-only pass needs dz_partial)");
+    LPM_REQUIRE((dk != nullptr) == (dv != nullptr) && (dq || dk || dz_partial), LPM_ERR_BADARG,
+                "lpm_mha_bwd_x3: dk and dv go together; give dq, (dk, dv) or both -- or none of them with dz_partial (statistics only)");
     LPM_REQUIRE((corr_a == nullptr) == (corr_b == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd_x3: corr_a/corr_b go together");
     LPM_MX_CHECK("lpm_mha_bwd_x3");
     LPM_REQUIRE((key_scale == nullptr) == (key_shift == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd_x3: key_scale/key_shift go together");
@@ -703,6 +778,28 @@ extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, in
                 LPM_ERR_BADARG, "lpm_mha_bwd_x3: pointers must be 16-byte aligned");
     return mx_bwd_launch(q, k, v, ld, o, dout, ldo, lse, B, L, h, d, scale, key_scale, key_shift, dq, dk, dv, ldd, corr_a, corr_b,
                          dz_partial, 0, 0, stream, "lpm_mha_bwd_x3");
+}
+
+extern "C" int lpm_mha_bn_dk_correct(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
+                                     const float* corr_b, float* dk, int64_t ldd, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && corr_a && corr_b && dk, LPM_ERR_BADARG, "lpm_mha_bn_dk_correct: null pointer");
+    LPM_REQUIRE(B > 0 && L > 0 && h > 0 && (d == 8 || d == 16) && ld >= (int64_t)h * d && ld % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0,
+                LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bn_dk_correct: need d in {8, 16} and row strides >= h * d, multiples of 4 (d=%d)", d);
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)dk) & 15) == 0, LPM_ERR_BADARG, "lpm_mha_bn_dk_correct: pointers must be 16-byte aligned");
+    const size_t lds = ((size_t)L * d + d * d + d) * sizeof(float);
+    LPM_REQUIRE(lds <= 160 * 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bn_dk_correct: L = %d does not fit LDS", L);
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 16) {
+        auto kern = mha_bn_dk_fix_kernel<16>;
+        if (int rc = mx_reserve(kern, lds, "lpm_mha_bn_dk_correct")) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd);
+    } else {
+        auto kern = mha_bn_dk_fix_kernel<8>;
+        if (int rc = mx_reserve(kern, lds, "lpm_mha_bn_dk_correct")) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd);
+    }
+    return check_launch("lpm_mha_bn_dk_correct");
 }
 
 extern "C" int lpm_mha_bwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, const void* o, int o_is_image,

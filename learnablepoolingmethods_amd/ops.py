@@ -97,6 +97,7 @@ MHA_BN_X3_MIN_KEYS = int(os.environ.get("LPM_MHA_BN_X3_MIN_KEYS", "128"))
 # frames): {"base": weakref to y, "F": F, "Dv": .., "video": tensor, "audio": tensor|None}.  ops.netvlad / vlad_aggregate
 # look a column-slice view of y up here instead of re-reading it through lpm_split_frames.
 _XT_CACHE = {}
+MHA_BN_ONEPASS = os.environ.get("LPM_MHA_BN_ONEPASS", "1") != "0"      # logits_bn backward without the separate statistics pass (A/B switch)
 V2_SPLIT_COLUMNS = True      # NetVladV2: the two streams' inputs as contiguous copies with ONE concatenated gradient (A/B switch)
 DEBUG_TAP = None      # tools/determinism_check.py: a dict that the video stream's pooling backward fills with copies of its intermediates
 
@@ -2007,6 +2008,24 @@ class _MHACoreBN(torch.autograd.Function):
         q, k, v, o, lse, kscale, kshift, mean, var, gamma = ctx.saved_tensors
         do = do.contiguous()
         st = stream_ptr()
+        if (MHA_BN_ONEPASS and is_training and d in (8, 16) and _bn_pass_precision("stats", L) == "bf16x3"
+                and _bn_pass_precision("main", L) == "bf16x3"):
+            # ONE pass over the scores for dk, dv AND the statistics: the batch statistics' share of ds is affine in the raw score, so its
+            # part of dk is a d-vector and a d x d matrix per (batch, head) away (lpm_mha_bn_dk_correct); dq's pass applies it in place
+            partial = _empty((B * h, 2, L), q)
+            dq, dk, dv = _dqkv_buffers(q)
+            lib.check(lib._lpm_mha_bwd_x3(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
+                                          ptr(kscale), ptr(kshift), None, ptr(dk), ptr(dv), dq.stride(1), None, None, ptr(partial), st),
+                      "lpm_mha_bwd_x3(dk, dv, statistics)")
+            dgamma, dbeta, corr_a, corr_b = (_empty((L,), q) for _ in range(4))
+            lib.check(lib._lpm_mha_bn_corrections(ptr(partial), B * h, L, ptr(mean.contiguous()), ptr(var.contiguous()), ptr(kscale), BN_EPS,
+                                                  B * h * L, ptr(dgamma), ptr(dbeta), ptr(corr_a), ptr(corr_b), st), "lpm_mha_bn_corrections")
+            lib.check(lib._lpm_mha_bwd_x3(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
+                                          ptr(kscale), ptr(kshift), ptr(dq), None, None, dq.stride(1), ptr(corr_a), ptr(corr_b), None, st),
+                      "lpm_mha_bwd_x3(dq)")
+            lib.check(lib._lpm_mha_bn_dk_correct(ptr(q), ptr(k), q.stride(1), B, L, h, d, 1.0, ptr(corr_a), ptr(corr_b), ptr(dk),
+                                                 dk.stride(1), st), "lpm_mha_bn_dk_correct")
+            return dq, dk, dv, dgamma, dbeta, None, None, None, None
         # pass 1: column sums of dz and dz*s over (B, h, query)
         partial = _empty((B * h, 2, L), q)
         lib.check(_mha_bwd_fn(lib, bn=True, which="stats")(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L,
