@@ -6,6 +6,7 @@
 namespace lpm {
 
 // partial [nblk, 2, C] -> mean/var/scale/shift (+ moving averages); 1024 threads per 16 columns (partial_colsums16)
+template <int CW>
 __global__ __launch_bounds__(1024) void bn_fold_kernel(const float* __restrict__ partial, int nblk, int C,
                                                        double inv_rows, double unbias,
                                                        const float* __restrict__ gamma,
@@ -14,8 +15,8 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(const float* __restrict__
                                                        float* moving_mean, float* moving_var) {
     double s, q;
     int c;
-    partial_colsums16(partial, nblk, 2 * (int64_t)C, C, C, s, q, c);
-    if (threadIdx.x < 16 && c < C) {
+    partial_colsums<CW>(partial, nblk, 2 * (int64_t)C, C, C, s, q, c);
+    if (threadIdx.x < CW && c < C) {
         const double mu = s * inv_rows;
         double vr = q * inv_rows - mu * mu;
         if (vr < 0.0) vr = 0.0;
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_colsum_kernel(const float* __rest
 // column sums of dz and dz * s over the queries.  -> dbeta = sum dz, dgamma = sum dz * s_hat = rstd (sum dz s - mean sum dz), and the
 // two correction vectors the main pass subtracts (training: the gradient through the batch statistics)
 //   corr_b = kscale * (dgamma / n) * rstd,   corr_a = kscale * (dbeta / n - mean * rstd * dgamma / n)        (fp64, one launch)
+template <int CW>
 __global__ __launch_bounds__(1024) void mha_bn_corrections_kernel(const float* __restrict__ partial, int nblk, int L,
                                                                   const float* __restrict__ mean, const float* __restrict__ var,
                                                                   const float* __restrict__ kscale, float eps, double inv_n,
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(1024) void mha_bn_corrections_kernel(const float* _
                                                                   float* __restrict__ corr_a, float* __restrict__ corr_b) {
     double s, q;
     int c;
-    partial_colsums16(partial, nblk, 2 * (int64_t)L, L, L, s, q, c);
-    if (threadIdx.x < 16 && c < L) {
+    partial_colsums<CW>(partial, nblk, 2 * (int64_t)L, L, L, s, q, c);
+    if (threadIdx.x < CW && c < L) {
         const double rstd = 1.0 / sqrt((double)var[c] + (double)eps), mu = (double)mean[c];
         const double sdz_hat = rstd * (q - mu * s);
         dbeta[c] = (float)s;
@@ -373,7 +375,7 @@ static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu,
     float* shift = scale + C;
     hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(nblk), dim3(256), 0, s, x, M, C, partial, pre_bias, pre_relu);
     const double unbias = (biased_moving_variance || M <= 1) ? 1.0 : (double)M / (double)(M - 1);
-    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, partial, nblk, C, 1.0 / (double)M, unbias, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_fold_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, s, partial, nblk, C, 1.0 / (double)M, unbias, gamma, beta, eps,
                        decay, mean, var, scale, shift, moving_mean, moving_var);
     const int64_t total4 = (int64_t)M * C / 4;
     const int64_t want = (total4 + 255) / 256;
@@ -391,9 +393,12 @@ extern "C" int lpm_bn_fold(const float* partial, int nblk, int C, int64_t rows, 
     LPM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), LPM_ERR_BADARG,
                 "lpm_bn_fold: moving_mean and moving_var must be given together");
     const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C,
-                       1.0 / (double)rows, unbias, gamma, beta, eps, decay, mean, var, scale, shift, moving_mean,
-                       moving_var);
+    if (partial_colsums_cw(nblk) == 4)
+        hipLaunchKernelGGL(bn_fold_kernel<4>, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C,
+                           1.0 / (double)rows, unbias, gamma, beta, eps, decay, mean, var, scale, shift, moving_mean, moving_var);
+    else
+        hipLaunchKernelGGL(bn_fold_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C,
+                           1.0 / (double)rows, unbias, gamma, beta, eps, decay, mean, var, scale, shift, moving_mean, moving_var);
     return check_launch("lpm_bn_fold");
 }
 
@@ -495,7 +500,11 @@ extern "C" int lpm_mha_bn_corrections(const float* partial, int nblk, int L, con
     LPM_REQUIRE(partial && mean && var && dgamma && dbeta && ((corr_a == nullptr) == (corr_b == nullptr)) && (!corr_a || kscale), LPM_ERR_BADARG,
                 "lpm_mha_bn_corrections: null pointer");
     LPM_REQUIRE(nblk > 0 && L > 0 && n > 0, LPM_ERR_BADARG, "lpm_mha_bn_corrections: bad sizes");
-    hipLaunchKernelGGL(mha_bn_corrections_kernel, dim3((L + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nblk, L, mean, var, kscale,
-                       eps, 1.0 / (double)n, dgamma, dbeta, corr_a, corr_b);
+    if (partial_colsums_cw(nblk) == 4)
+        hipLaunchKernelGGL(mha_bn_corrections_kernel<4>, dim3((L + 3) / 4), dim3(1024), 0, (hipStream_t)stream, partial, nblk, L, mean, var,
+                           kscale, eps, 1.0 / (double)n, dgamma, dbeta, corr_a, corr_b);
+    else
+        hipLaunchKernelGGL(mha_bn_corrections_kernel<16>, dim3((L + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nblk, L, mean, var,
+                           kscale, eps, 1.0 / (double)n, dgamma, dbeta, corr_a, corr_b);
     return check_launch("lpm_mha_bn_corrections");
 }

@@ -45,18 +45,24 @@ inline int check_launch(const char* what) {
 // thread loads its rows eight at a time (nblk = 400: ONE round of independent loads -- a 64-column / 16-row-group form walked
 // seven dependent rounds of ~2 us, 14-30 us for under a megabyte of input), the four row groups of a wave meet by shuffles,
 // the sixteen waves through LDS.  The sums come back on the threads with tid < 16.
-__device__ __forceinline__ void partial_colsums16(const float* __restrict__ part, int nblk, int64_t row, int off2, int C, double& s,
-                                                  double& q, int& c) {
-    __shared__ double pcs_sh[2][16][16];
-    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    c = blockIdx.x * 16 + cl;
+// partial_colsums<4>: the same for a VERY tall array (nblk = batch x heads = 5120 rows of the attention's logits_bn statistics): four
+// columns per workgroup, 256 row groups -- four times the workgroups (75 instead of 19 at 300 columns: the 16-column form took 60-76 us
+// for 12 MB there, one CU's worth of loads in flight per workgroup).  The sums come back on the threads with tid < CW.
+template <int CW>
+__device__ __forceinline__ void partial_colsums(const float* __restrict__ part, int nblk, int64_t row, int off2, int C, double& s,
+                                                double& q, int& c) {
+    static_assert(CW == 16 || CW == 4, "columns per workgroup");
+    constexpr int RG = 1024 / CW;                  // row groups
+    __shared__ double pcs_sh[2][16][CW];
+    const int cl = threadIdx.x & (CW - 1), rg = threadIdx.x / CW;
+    c = blockIdx.x * CW + cl;
     s = 0.0; q = 0.0;
     if (c < C) {
-        for (int b = rg; b < nblk; b += 64 * 8) {
+        for (int b = rg; b < nblk; b += RG * 8) {
             float ps[8], pq[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int bb = b + 64 * u;
+                const int bb = b + RG * u;
                 const float* p = part + (int64_t)min(bb, nblk - 1) * row + c;
                 ps[u] = (bb < nblk) ? p[0] : 0.f;
                 pq[u] = (bb < nblk && off2 > 0) ? p[off2] : 0.f;
@@ -68,15 +74,18 @@ __device__ __forceinline__ void partial_colsums16(const float* __restrict__ part
             }
         }
     }
-    s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);      // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same column
-    s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+#pragma unroll
+    for (int o = CW; o < 64; o <<= 1) {            // lanes that differ only above the column bits hold the same column
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) < 16) {
+    if ((threadIdx.x & 63) < CW) {
         pcs_sh[0][wave][cl] = s;
         pcs_sh[1][wave][cl] = q;
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < CW) {
         s = pcs_sh[0][0][cl]; q = pcs_sh[1][0][cl];
         for (int i = 1; i < 16; ++i) {
             s += pcs_sh[0][i][cl];
@@ -84,6 +93,12 @@ __device__ __forceinline__ void partial_colsums16(const float* __restrict__ part
         }
     }
 }
+__device__ __forceinline__ void partial_colsums16(const float* __restrict__ part, int nblk, int64_t row, int off2, int C, double& s,
+                                                  double& q, int& c) {
+    partial_colsums<16>(part, nblk, row, off2, C, s, q, c);
+}
+// columns per workgroup for a partial array of nblk rows
+__host__ __device__ constexpr int partial_colsums_cw(int nblk) { return nblk >= 2048 ? 4 : 16; }
 
 // ---- wave-level reductions (64 lanes) -------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

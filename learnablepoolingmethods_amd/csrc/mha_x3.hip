@@ -588,29 +588,59 @@ __global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restr
         *reinterpret_cast<float4*>(qs + row * D + 4 * c4) = v;
     }
     __syncthreads();
-    if (tid < D * D) {                                          // Qm[a][c] = sum_q q[a] q[c]; four partial sums against the add latency
-        const int a = tid / D, c = tid % D;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int i = 0;
-        for (; i + 3 < L; i += 4) {
-            s0 = fmaf(qs[i * D + a], qs[i * D + c], s0);
-            s1 = fmaf(qs[(i + 1) * D + a], qs[(i + 1) * D + c], s1);
-            s2 = fmaf(qs[(i + 2) * D + a], qs[(i + 2) * D + c], s2);
-            s3 = fmaf(qs[(i + 3) * D + a], qs[(i + 3) * D + c], s3);
+    // Qm = sum_q q q^T as 4 x 4 register blocks: thread = (row group rg of 256 / (D4 * D4), block row ab, block column cb); a row costs two
+    // 16-byte LDS reads for 16 products (one thread per entry walking every row: 600 scalar LDS reads per thread -- the LDS pipe of a CU
+    // with 20 of these workgroups queued was the whole kernel, 159 us).  The row groups meet through LDS in a fixed order.
+    constexpr int NB = D4 * D4, RG = 256 / NB;
+    float* red = Sq + D;                                        // [RG][D * D] partial blocks, then [RG][D] partial row sums
+    {
+        const int rg = tid / NB, ab = (tid % NB) / D4, cb = tid % D4;
+        float acc[4][4] = {};
+        float sq[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = rg; i < L; i += RG) {
+            const float4 x = *reinterpret_cast<const float4*>(qs + i * D + 4 * ab), y = *reinterpret_cast<const float4*>(qs + i * D + 4 * cb);
+            const float xa[4] = {x.x, x.y, x.z, x.w}, ya[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sq[u] += xa[u];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc[u][w] = fmaf(xa[u], ya[w], acc[u][w]);
+            }
         }
-        for (; i < L; ++i) s0 = fmaf(qs[i * D + a], qs[i * D + c], s0);
-        Qm[tid] = (s0 + s1) + (s2 + s3);
-        if (c == 0) {                                           // Sq[a]
-            float t0 = 0.f, t1 = 0.f;
-            int j = 0;
-            for (; j + 1 < L; j += 2) { t0 += qs[j * D + a]; t1 += qs[(j + 1) * D + a]; }
-            if (j < L) t0 += qs[j * D + a];
-            Sq[a] = t0 + t1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *reinterpret_cast<float4*>(red + rg * D * D + (4 * ab + u) * D + 4 * cb) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+            if (cb == 0) red[RG * D * D + rg * D + 4 * ab + u] = sq[u];
         }
     }
     __syncthreads();
+    if (tid < D * D) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) t += red[r * D * D + tid];
+        Qm[tid] = t;
+        if (tid < D) {
+            float u = 0.f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) u += red[RG * D * D + r * D + tid];
+            Sq[tid] = u;
+        }
+    }
+    __syncthreads();
+    // dk rows: a thread keeps ITS four rows of Qm (c4 = tid % D4 for every row it visits: 256 is a multiple of D4) in registers
+    const int c4 = tid % D4;
+    float qm[4][D], sq4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        sq4[u] = Sq[4 * c4 + u];
+#pragma unroll
+        for (int e = 0; e < D4; ++e) {
+            const float4 t = *reinterpret_cast<const float4*>(Qm + (4 * c4 + u) * D + 4 * e);
+            qm[u][4 * e] = t.x; qm[u][4 * e + 1] = t.y; qm[u][4 * e + 2] = t.z; qm[u][4 * e + 3] = t.w;
+        }
+    }
     for (int i = tid; i < L * D4; i += 256) {
-        const int row = i / D4, c4 = i % D4;
+        const int row = i / D4;
         const float* kp = k + ((int64_t)b * L + row) * ld + hh * D;
         float kv[D];
 #pragma unroll
@@ -624,11 +654,10 @@ __global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restr
         float r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int a = 4 * c4 + u;
             float t = 0.f;
 #pragma unroll
-            for (int e = 0; e < D; ++e) t = fmaf(Qm[a * D + e], kv[e], t);
-            r[u] = fmaf(cb, t, ca * Sq[a]);
+            for (int e = 0; e < D; ++e) t = fmaf(qm[u][e], kv[e], t);
+            r[u] = fmaf(cb, t, ca * sq4[u]);
         }
         g.x -= r[0]; g.y -= r[1]; g.z -= r[2]; g.w -= r[3];
         *reinterpret_cast<float4*>(dp) = g;
@@ -787,7 +816,8 @@ extern "C" int lpm_mha_bn_dk_correct(const float* q, const float* k, int64_t ld,
     LPM_REQUIRE(B > 0 && L > 0 && h > 0 && (d == 8 || d == 16) && ld >= (int64_t)h * d && ld % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0,
                 LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bn_dk_correct: need d in {8, 16} and row strides >= h * d, multiples of 4 (d=%d)", d);
     LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)dk) & 15) == 0, LPM_ERR_BADARG, "lpm_mha_bn_dk_correct: pointers must be 16-byte aligned");
-    const size_t lds = ((size_t)L * d + d * d + d) * sizeof(float);
+    const int rgs = 256 / ((d / 4) * (d / 4));                  // row groups of the Qm pass; their partial blocks and row sums follow Sq
+    const size_t lds = ((size_t)L * d + d * d + d + (size_t)rgs * (d * d + d)) * sizeof(float);
     LPM_REQUIRE(lds <= 160 * 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bn_dk_correct: L = %d does not fit LDS", L);
     hipStream_t s = (hipStream_t)stream;
     if (d == 16) {

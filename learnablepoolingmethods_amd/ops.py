@@ -2020,6 +2020,7 @@ class _MHACoreBN(torch.autograd.Function):
             dgamma, dbeta, corr_a, corr_b = (_empty((L,), q) for _ in range(4))
             lib.check(lib._lpm_mha_bn_corrections(ptr(partial), B * h, L, ptr(mean.contiguous()), ptr(var.contiguous()), ptr(kscale), BN_EPS,
                                                   B * h * L, ptr(dgamma), ptr(dbeta), ptr(corr_a), ptr(corr_b), st), "lpm_mha_bn_corrections")
+            # (the repair of dk on an auxiliary stream beside dq's pass was measured slower: 10.62 vs 10.44 ms per step at cfg-3)
             lib.check(lib._lpm_mha_bwd_x3(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
                                           ptr(kscale), ptr(kshift), ptr(dq), None, None, dq.stride(1), ptr(corr_a), ptr(corr_b), None, st),
                       "lpm_mha_bwd_x3(dq)")

@@ -3,6 +3,7 @@
 TAG=${1:-prof}
 shift
 R=$GRAFT_REPO_ROOT
+mkdir -p $(dirname $R/gpurun_out/${TAG}_x)
 cd /tmp && export TMPDIR=/tmp
 for mode in single two; do
   if [ $mode = single ]; then export LPM_SINGLE_STREAM=1; else unset LPM_SINGLE_STREAM; fi
