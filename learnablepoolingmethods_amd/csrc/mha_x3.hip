@@ -395,7 +395,10 @@ __global__ __launch_bounds__(MX_DQ_NT) void mha_bwd_dq_x3_kernel(const float* __
 // Eight waves per (batch, head): the workgroup's LDS (66 KB at L = 256: two workgroups per CU) is the same for four or eight
 // waves, and 110 registers fit four waves per SIMD -- twice the waves to hide the MFMA -> exp2 / split -> MFMA chain behind.
 // Past L = 256 (NKT >= 20: 85 KB and more) only ONE workgroup fits a CU: sixteen waves there.
-__host__ __device__ constexpr int mx_dkv_nt(int nkt) { return nkt >= 20 ? 1024 : 512; }
+#ifndef LPM_DKV_NT_LONG
+#define LPM_DKV_NT_LONG 1024
+#endif
+__host__ __device__ constexpr int mx_dkv_nt(int nkt) { return nkt >= 20 ? LPM_DKV_NT_LONG : 512; }
 template <int NKT, bool AFFINE, int D>
 __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
