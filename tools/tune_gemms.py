@@ -1,4 +1,4 @@
-"""Run PyTorch TunableOp over every library GEMM shape of the cfg-2 training step (hipBLASLt / rocBLAS solution search)
+"""Run PyTorch TunableOp over every library GEMM shape of a bench.py workload's training step (cfg2 | cfg3 | cfg5) (hipBLASLt / rocBLAS solution search)
 and write the selections to gpurun_out/tunableop_results.csv.  Prints the step time before and after."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,9 +11,12 @@ torch.cuda.set_device(0)
 from learnablepoolingmethods_amd import registry
 from learnablepoolingmethods_amd.train import Trainer
 
-model = registry.get_model("NetVladV1")
-trainer = Trainer(model, vocab_size=bench.VOCAB, batch_size=bench.PER_GPU_BATCH, device=dev, seed=1234, model_kwargs=bench.CFG, **bench.TRAIN)
-raw, nf, labels = bench.synthetic_batch(bench.PER_GPU_BATCH, dev, seed=0)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+wl = bench.WORKLOADS[cfg]
+bench.set_flags(wl)
+trainer = Trainer(registry.get_model(wl.get("model", "NetVladV1")), vocab_size=bench.VOCAB, batch_size=wl["batch"], device=dev, seed=1234,
+                  model_kwargs=wl["model_kwargs"], **bench.TRAIN)
+raw, nf, labels = bench.synthetic_batch(wl["batch"], dev, seed=0)
 
 
 def timed(n):
@@ -27,7 +30,7 @@ def timed(n):
 
 for _ in range(3):
     trainer.step(raw, nf, labels)
-print("before: %.3f ms/step" % timed(8), flush=True)
+print("before: %.3f ms/step" % timed(30), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 tunable.set_filename("gpurun_out/tunableop_results.csv")
 tunable.set_max_tuning_duration(int(os.environ.get("TUNE_MS", "30")))
@@ -41,7 +44,7 @@ print("tuning step took %.1f s, %d entries" % (time.perf_counter() - t0, len(tun
 tunable.tuning_enable(False)
 for _ in range(2):
     trainer.step(raw, nf, labels)
-print("after: %.3f ms/step" % timed(8), flush=True)
+print("after: %.3f ms/step" % timed(30), flush=True)
 tunable.write_file() if hasattr(tunable, "write_file") else None
 for r in tunable.get_results()[:60]:
     print(r)
