@@ -554,10 +554,18 @@ def _aggregate_bwd_tiles(lib, dout, nrm, asum, colsq, csq, gsq, assign, scale, s
     fl = flags | (LPM_VLAD_OUT_KMAJOR if kmajor else 0) | (LPM_VLAD_NRM_RAW if nrm_raw else 0)
     if raw_kmajor:          # dout and the saved sums are both k-major: no transposes (needs the no-input-gradient form)
         fl |= _capi.LPM_VLAD_RAW_KMAJOR
+    # a d-major gradient that is a column slice of the concatenated descriptors' gradient (torch.cat's backward hands out views) is read
+    # in place, clips dout.stride(0) elements apart; anything else contiguous
+    dob = D * K
+    if (dout.dim() == 2 and not kmajor and not raw_kmajor and dout.dtype == torch.float32 and dout.stride(1) == 1
+            and dout.stride(0) >= D * K and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0):
+        dob = dout.stride(0)
+    else:
+        dout = dout.contiguous()
     with _timed("vlad_aggregate_bwd", (B, T, D, K)):
-        lib.check(lib._lpm_vlad_aggregate_bwd_tiles(ptr(dout), ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(assign),
-                                                    ptr(scale), ptr(shift), ptr(xr), ptr(centres), B, T, D, K, fl, ptr(dassign),
-                                                    ptr(dcentres), ptr(g0), ptr(ws), wsb, st), "lpm_vlad_aggregate_bwd_tiles")
+        lib.check(lib._lpm_vlad_aggregate_bwd_tiles_ld(ptr(dout), dob, ptr(nrm), ptr(asum), ptr(colsq), ptr(csq), ptr(gsq), ptr(assign),
+                                                       ptr(scale), ptr(shift), ptr(xr), ptr(centres), B, T, D, K, fl, ptr(dassign),
+                                                       ptr(dcentres), ptr(g0), ptr(ws), wsb, st), "lpm_vlad_aggregate_bwd_tiles")
     return dassign, dcentres, (ws, wsb), g0
 
 
@@ -987,7 +995,7 @@ class _VladAggregate(torch.autograd.Function):
         if ctx.nrm_raw and not _bwd_tiles_ok(lib, T, D, K):
             raise LpmError("vlad_aggregate: the forward left nrm un-normalised for the tile backward, which is no longer selected")
         if _bwd_tiles_ok(lib, T, D, K):
-            dsims, dcentres, wspace, _ = _aggregate_bwd_tiles(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x,
+            dsims, dcentres, wspace, _ = _aggregate_bwd_tiles(lib, _f32(dout, "dout"), nrm, asum, colsq, csq, gsq, sims2, None, None, x,
                                                               None, centres, B, T, D, K, flags, kmajor, nrm_raw=ctx.nrm_raw)
             dx = _aggregate_bwd_tiles_dx(lib, wspace, None, None, x, B, T, D, K)
         else:

@@ -33,6 +33,16 @@ def wrap(owner, name, label):
     def f(*a, **k):
         t = next((x for x in list(a) + list(k.values()) if torch.is_tensor(x)), None)
         devs = str(k.get("device", "")) + (str(t.device) if t is not None else "")
+        if name in ("contiguous", "float", "to", "t") and t is not None:
+            # only the calls that launch something: a real copy / cast
+            noop = (name == "t") or (name == "contiguous" and t.is_contiguous()) or (name == "float" and t.dtype == torch.float32) \
+                or (name == "to" and not any(isinstance(x, torch.dtype) and x != t.dtype for x in list(a) + list(k.values()))
+                    and not any(isinstance(x, (torch.device, str)) for x in list(a[1:]) + list(k.values())))
+            if noop:
+                return orig(*a, **k)
+            label2 = f"{label} {tuple(t.shape)} {t.numel() * t.element_size() >> 20} MiB"
+            sites[(label2, where())] += 1
+            return orig(*a, **k)
         if "cuda" in devs or (t is None and name in ("zeros", "full", "empty")):
             sites[(label, where())] += 1
         return orig(*a, **k)
