@@ -340,7 +340,8 @@ def test_mha_core(B, L, h, d, mha_precision):
 
 
 @pytest.mark.parametrize("B,L,h,d,training", [(2, 48, 2, 16, True), (2, 300, 8, 16, True), (2, 30, 8, 16, False), (4, 12, 64, 16, True),
-                                              (4, 12, 16, 8, True)])
+                                              (4, 12, 16, 8, True),
+                                              (36, 22, 64, 16, True)])      # 2304 (batch, head) rows of statistics: the 4-column reductions
 def test_mha_core_logits_bn(B, L, h, d, training, mha_precision):
     """MultiHeadAttentionBN core: batch_norm over the key-position channel of [B,h,Lq,Lk] (transformer_utils.py:652-659)."""
     from learnablepoolingmethods_amd import ops

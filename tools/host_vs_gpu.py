@@ -1,4 +1,5 @@
-"""Is the training step host-bound?  Enqueue time of N steps (no synchronisation inside) against their GPU completion time."""
+"""Is the training step host-bound?  Enqueue time of N steps (no synchronisation inside) against their GPU completion time.
+  python tools/host_vs_gpu.py [N] [cfg2|cfg3|cfg5]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,9 +8,12 @@ from learnablepoolingmethods_amd import registry
 from learnablepoolingmethods_amd.train import Trainer
 
 dev = torch.device("cuda:0")
-trainer = Trainer(registry.get_model("NetVladV1"), vocab_size=bench.VOCAB, batch_size=bench.PER_GPU_BATCH, device=dev, seed=1234,
-                  model_kwargs=bench.CFG, **bench.TRAIN)
-raw, nf, labels = bench.synthetic_batch(bench.PER_GPU_BATCH, dev, seed=0)
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+wl = bench.WORKLOADS[cfg]
+bench.set_flags(wl)
+trainer = Trainer(registry.get_model(wl.get("model", "NetVladV1")), vocab_size=bench.VOCAB, batch_size=wl["batch"], device=dev, seed=1234,
+                  model_kwargs=wl["model_kwargs"], **bench.TRAIN)
+raw, nf, labels = bench.synthetic_batch(wl["batch"], dev, seed=0)
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 3.0:
     trainer.step(raw, nf, labels)
