@@ -1,0 +1,29 @@
+"""Soak: N training steps of a bench.py workload on one fixed batch; the loss must stay finite and go down (an overfit of one batch).
+  python tools/soak.py [cfg2|cfg3|cfg5] [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from learnablepoolingmethods_amd import registry
+from learnablepoolingmethods_amd.train import Trainer
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+wl = bench.WORKLOADS[cfg]
+bench.set_flags(wl)
+dev = torch.device("cuda:0")
+tr = Trainer(registry.get_model(wl.get("model", "NetVladV1")), vocab_size=bench.VOCAB, batch_size=wl["batch"], device=dev, seed=1234,
+             model_kwargs=wl["model_kwargs"], **bench.TRAIN)
+raw, nf, labels = bench.synthetic_batch(wl["batch"], dev, seed=0)
+losses = []
+t0 = time.perf_counter()
+for s in range(steps):
+    out = tr.step(raw, nf, labels)
+    if s % max(1, steps // 8) == 0 or s == steps - 1:
+        losses.append((s, float(out["loss"])))
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"{cfg}: {steps} steps in {dt:.1f} s; loss " + ", ".join(f"[{s}] {l:.4f}" for s, l in losses))
+ok = all(l == l and abs(l) < 1e6 for _, l in losses) and losses[-1][1] < losses[0][1]
+print("finite and decreasing" if ok else "NOT decreasing / not finite")
+sys.exit(0 if ok else 1)
