@@ -527,9 +527,15 @@ int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, c
  * key / value gradients WITHOUT the batch statistics' share, and the statistics --, lpm_mha_bn_corrections, and
  * lpm_mha_bwd_x3(dq, dk = dv = NULL, corr_a, corr_b) for the query gradient, this subtracts the share from dk in place:
  *   dk[b, j, head] -= corr_a[j] Sq + corr_b[j] Qm k[b, j, head],   Sq = sum_q scale q,  Qm = sum_q (scale q)(scale q)^T per (b, head)
- * (the two correction terms of ds are affine in the raw score; transformer_utils.py:652-658, backward).  d in {8, 16}. */
+ * (the two correction terms of ds are affine in the raw score; transformer_utils.py:652-658, backward).  d in {8, 16}.
+ * moments: NULL, or the forward's lpm_mha_logit_stats_moments output (Qm, Sq of the unscaled q) -- then q is not read. */
 int lpm_mha_bn_dk_correct(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
-                          const float* corr_b, float* dk, int64_t ldd, lpm_stream_t stream);
+                          const float* corr_b, float* dk, int64_t ldd, const float* moments, lpm_stream_t stream);
+/* logits_bn's per-(batch, head) statistics (what lpm_mha_logit_stats computes: partial [B*h][2][L] = sum_q q.k_j and sum_q (q.k_j)^2)
+ * from the d x d moments of q, which it also hands out: moments [B*h][d*d + d] = (Qm = sum_q q q^T, Sq = sum_q q), or NULL.  Given to
+ * lpm_mha_bn_dk_correct (`moments`, of the UNSCALED q; q may then be NULL) the backward does not form them again.  d in {8, 16}. */
+int lpm_mha_logit_stats_moments(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float* partial, float* moments,
+                                lpm_stream_t stream);
 /* The same backward (no logits_bn) writing the q/k/v gradients ONLY as the split-bf16 gradient image the projection GEMMs read:
  * dqkv3 [B*L, 9*h*d] bf16, row = [hi | hi | lo] planes of the concatenated columns [dq | dk | dv] (what lpm_split_rows with
  * order = 1 would produce from the fp32 gradients) -- the fp32 dq/dk/dv and the split pass over them never exist. */

@@ -138,7 +138,8 @@ SIGNATURES = {
     "lpm_mha_fwd": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),
     "lpm_mha_fwd_x3": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),
     "lpm_mha_bwd": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _l, _f, _f, _f, _f]),
-    "lpm_mha_bn_dk_correct": (_i, [_f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f]),
+    "lpm_mha_bn_dk_correct": (_i, [_f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),
+    "lpm_mha_logit_stats_moments": (_i, [_f, _f, _l, _i, _i, _i, _i, _f, _f, _f]),
     "lpm_mha_bwd_x3": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _l, _f, _f, _f, _f]),
     "lpm_mha_bwd_x3_image": (_i, [_f, _f, _f, _l, _f, _i, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f]),
     "lpm_mha_fwd_x3_image": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f]),

@@ -461,7 +461,8 @@ static int reserve_lds(KernT kern, size_t bytes, const char* what) {
 // 2 L d^2 multiply-adds per head instead of L^2 d and the column reductions -- at cfg-3's video stream (80 x 64 heads, L = 300,
 // d = 16) 470 us -> the time to read q and k once.
 __global__ __launch_bounds__(256) void mha_logit_stats_quad_kernel(const float* __restrict__ q, const float* __restrict__ k, int64_t ld, int L,
-                                                                   int h, int d, int nheads, float* __restrict__ partial) {
+                                                                   int h, int d, int nheads, float* __restrict__ partial,
+                                                                   float* __restrict__ moments) {
     // one WAVE per (batch, head), four consecutive heads per workgroup.  G = Q^T Q on the exact-fp32 matrix pipe: for a group of four
     // queries lane (l15, g) holds Q[4 s + g][l15], which is its element of BOTH operands of v_mfma_f32_16x16x4_f32 (A = Q^T, B = Q);
     // acc[r] = G[4 g + r][l15].  No staging: a wave-load touches four 64-byte rows.
@@ -505,6 +506,11 @@ __global__ __launch_bounds__(256) void mha_logit_stats_quad_kernel(const float* 
     if (g == 0) sv[l15] = sacc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (moments) {                                               // [d * d + d] per head: G, then s (lpm_mha_bn_dk_correct reads them in the backward)
+        float* mo = moments + (int64_t)head * (d * d + d);
+        for (int i = lane; i < d * d; i += 64) mo[i] = G[(i / d) * 16 + i % d];
+        if (lane < d) mo[d * d + lane] = sv[lane];
+    }
     float* out = partial + (int64_t)head * 2 * L;
     for (int key = lane; key < L; key += 64) {
         float kv[16];
@@ -581,7 +587,8 @@ extern "C" int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, i
     hipStream_t s = (hipStream_t)stream;
     static const int quad = [] { const char* e = getenv("LPM_MHA_STATS_QUAD"); return (e && e[0] == '0') ? 0 : 1; }();   // 0: through the logits (A/B)
     if (quad && (((uintptr_t)q | (uintptr_t)k) & 15) == 0 && d % 4 == 0) {
-        hipLaunchKernelGGL(mha_logit_stats_quad_kernel, dim3((B * h + 3) / 4), dim3(256), 0, s, q, k, ld, L, h, d, B * h, partial);
+        hipLaunchKernelGGL(mha_logit_stats_quad_kernel, dim3((B * h + 3) / 4), dim3(256), 0, s, q, k, ld, L, h, d, B * h, partial,
+                           (float*)nullptr);
         return check_launch("lpm_mha_logit_stats");
     }
     const size_t lds = mha_stats_lds(L);
@@ -600,6 +607,18 @@ extern "C" int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, i
     else LPM_MHA_ST(32);
 #undef LPM_MHA_ST
     return check_launch("lpm_mha_logit_stats");
+}
+
+extern "C" int lpm_mha_logit_stats_moments(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float* partial, float* moments,
+                                           lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && partial, LPM_ERR_BADARG, "lpm_mha_logit_stats_moments: null pointer");
+    LPM_MHA_CHECK("lpm_mha_logit_stats_moments");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k) & 15) == 0 && d % 4 == 0, LPM_ERR_BADARG,
+                "lpm_mha_logit_stats_moments: q, k must be 16-byte aligned and d a multiple of 4");
+    hipLaunchKernelGGL(mha_logit_stats_quad_kernel, dim3((B * h + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, k, ld, L, h, d, B * h, partial,
+                       moments);
+    return check_launch("lpm_mha_logit_stats_moments");
 }
 
 extern "C" int lpm_mha_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,

@@ -572,17 +572,14 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
 // -- a d-vector and a d x d matrix per (batch, head).  So: the dkv kernel runs ONCE with no corrections and emits the statistics on the
 // way (dz_partial), lpm_mha_bn_corrections turns them into ca / cb, the dq kernel (which walks the scores again anyway) applies them
 // in place as before, and this kernel repairs dK: one workgroup per (batch, head), q staged in LDS, 4 threads per key row.
+// The d x d moment matrix Qm = sum_q (scale q)(scale q)^T and the d-vector Sq = sum_q scale q of one (batch, head): q staged in LDS
+// as fp32 [L][D], Qm as 4 x 4 register blocks -- thread = (row group rg of 256 / (D4 * D4), block row ab, block column cb), a row costs
+// two 16-byte LDS reads for 16 products (one thread per entry walking every row: 600 scalar LDS reads per thread; the LDS pipe of a CU
+// with 20 of these workgroups queued was the whole kernel) -- and the row groups meet through LDS in a fixed order.
+// LDS: qs [L][D] | Qm [D][D] | Sq [D] | red [RG][D * D + D];  256 threads; Qm / Sq valid for everyone on return.
 template <int D>
-__global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restrict__ q, const float* __restrict__ k, int64_t ld, int L, int h,
-                                                            float scale, const float* __restrict__ corr_a, const float* __restrict__ corr_b,
-                                                            float* __restrict__ dk, int64_t ldd) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* qs = reinterpret_cast<float*>(smem);                 // [L][D], scaled
-    float* Qm = qs + (size_t)L * D;                             // [D][D]
-    float* Sq = Qm + D * D;                                     // [D]
-    const int tid = threadIdx.x;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = lid / h, hh = lid % h;
+__device__ __forceinline__ void mx_q_moments(const float* __restrict__ q, int64_t ld, int b, int L, int hh, float scale, float* qs, float* Qm,
+                                             float* Sq, float* red, int tid) {
     constexpr int D4 = D / 4;
     for (int i = tid; i < L * D4; i += 256) {
         const int row = i / D4, c4 = i % D4;
@@ -591,11 +588,7 @@ __global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restr
         *reinterpret_cast<float4*>(qs + row * D + 4 * c4) = v;
     }
     __syncthreads();
-    // Qm = sum_q q q^T as 4 x 4 register blocks: thread = (row group rg of 256 / (D4 * D4), block row ab, block column cb); a row costs two
-    // 16-byte LDS reads for 16 products (one thread per entry walking every row: 600 scalar LDS reads per thread -- the LDS pipe of a CU
-    // with 20 of these workgroups queued was the whole kernel, 159 us).  The row groups meet through LDS in a fixed order.
     constexpr int NB = D4 * D4, RG = 256 / NB;
-    float* red = Sq + D;                                        // [RG][D * D] partial blocks, then [RG][D] partial row sums
     {
         const int rg = tid / NB, ab = (tid % NB) / D4, cb = tid % D4;
         float acc[4][4] = {};
@@ -630,6 +623,30 @@ __global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restr
         }
     }
     __syncthreads();
+}
+__host__ __device__ constexpr int mx_moments_floats(int L, int d) { return L * d + d * d + d + (256 / ((d / 4) * (d / 4))) * (d * d + d); }
+
+template <int D>
+__global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restrict__ q, const float* __restrict__ k, int64_t ld, int L, int h,
+                                                            float scale, const float* __restrict__ corr_a, const float* __restrict__ corr_b,
+                                                            float* __restrict__ dk, int64_t ldd, const float* __restrict__ moments) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    constexpr int D4 = D / 4;
+    float *Qm, *Sq;
+    if (moments) {                                              // the forward's moments (of the unscaled q): Qm scale^2, Sq scale
+        Qm = reinterpret_cast<float*>(smem);
+        Sq = Qm + D * D;
+        for (int i = tid; i < D * D + D; i += 256) Qm[i] = moments[(int64_t)lid * (D * D + D) + i] * (i < D * D ? scale * scale : scale);
+        __syncthreads();
+    } else {
+        float* qs = reinterpret_cast<float*>(smem);
+        Qm = qs + (size_t)L * D;
+        Sq = Qm + D * D;
+        mx_q_moments<D>(q, ld, b, L, hh, scale, qs, Qm, Sq, Sq + D, tid);
+    }
     // dk rows: a thread keeps ITS four rows of Qm (c4 = tid % D4 for every row it visits: 256 is a multiple of D4) in registers
     const int c4 = tid % D4;
     float qm[4][D], sq4[4];
@@ -813,24 +830,23 @@ extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, in
 }
 
 extern "C" int lpm_mha_bn_dk_correct(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
-                                     const float* corr_b, float* dk, int64_t ldd, lpm_stream_t stream) {
+                                     const float* corr_b, float* dk, int64_t ldd, const float* moments, lpm_stream_t stream) {
     using namespace lpm;
-    LPM_REQUIRE(q && k && corr_a && corr_b && dk, LPM_ERR_BADARG, "lpm_mha_bn_dk_correct: null pointer");
+    LPM_REQUIRE((q || moments) && k && corr_a && corr_b && dk, LPM_ERR_BADARG, "lpm_mha_bn_dk_correct: null pointer");
     LPM_REQUIRE(B > 0 && L > 0 && h > 0 && (d == 8 || d == 16) && ld >= (int64_t)h * d && ld % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0,
                 LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bn_dk_correct: need d in {8, 16} and row strides >= h * d, multiples of 4 (d=%d)", d);
     LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)dk) & 15) == 0, LPM_ERR_BADARG, "lpm_mha_bn_dk_correct: pointers must be 16-byte aligned");
-    const int rgs = 256 / ((d / 4) * (d / 4));                  // row groups of the Qm pass; their partial blocks and row sums follow Sq
-    const size_t lds = ((size_t)L * d + d * d + d + (size_t)rgs * (d * d + d)) * sizeof(float);
+    const size_t lds = (moments ? (size_t)(d * d + d) : (size_t)mx_moments_floats(L, d)) * sizeof(float);
     LPM_REQUIRE(lds <= 160 * 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bn_dk_correct: L = %d does not fit LDS", L);
     hipStream_t s = (hipStream_t)stream;
     if (d == 16) {
         auto kern = mha_bn_dk_fix_kernel<16>;
         if (int rc = mx_reserve(kern, lds, "lpm_mha_bn_dk_correct")) return rc;
-        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd);
+        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd, moments);
     } else {
         auto kern = mha_bn_dk_fix_kernel<8>;
         if (int rc = mx_reserve(kern, lds, "lpm_mha_bn_dk_correct")) return rc;
-        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd);
+        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd, moments);
     }
     return check_launch("lpm_mha_bn_dk_correct");
 }

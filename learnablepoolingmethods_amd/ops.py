@@ -97,6 +97,7 @@ MHA_BN_X3_MIN_KEYS = int(os.environ.get("LPM_MHA_BN_X3_MIN_KEYS", "128"))
 # frames): {"base": weakref to y, "F": F, "Dv": .., "video": tensor, "audio": tensor|None}.  ops.netvlad / vlad_aggregate
 # look a column-slice view of y up here instead of re-reading it through lpm_split_frames.
 _XT_CACHE = {}
+MHA_BN_MOMENTS = os.environ.get("LPM_MHA_BN_MOMENTS", "1") != "0"      # ... statistics by lpm_mha_logit_stats_moments, moments kept for the backward
 MHA_BN_ONEPASS = os.environ.get("LPM_MHA_BN_ONEPASS", "1") != "0"      # logits_bn backward without the separate statistics pass (A/B switch)
 V2_SPLIT_COLUMNS = True      # NetVladV2: the two streams' inputs as contiguous copies with ONE concatenated gradient (A/B switch)
 DEBUG_TAP = None      # tools/determinism_check.py: a dict that the video stream's pooling backward fills with copies of its intermediates
@@ -1992,10 +1993,17 @@ class _MHACoreBN(torch.autograd.Function):
         q, k, v = _qkv_operands(q, k, v)
         B, L, d = _mha_dims(q, num_heads)
         h = num_heads
+        moments = None
         if is_training:
             partial = _empty((B * h, 2, L), q)
-            lib.check(lib._lpm_mha_logit_stats(ptr(q), ptr(k), q.stride(1), B, L, h, d, ptr(partial), stream_ptr()),
-                      "lpm_mha_logit_stats")
+            if MHA_BN_MOMENTS and d in (8, 16):
+                # the statistics from the d x d moments of q, which the backward's repair of dk needs again (kept: 272 floats per head)
+                moments = _empty((B * h, d * d + d), q)
+                lib.check(lib._lpm_mha_logit_stats_moments(ptr(q), ptr(k), q.stride(1), B, L, h, d, ptr(partial), ptr(moments), stream_ptr()),
+                          "lpm_mha_logit_stats_moments")
+            else:
+                lib.check(lib._lpm_mha_logit_stats(ptr(q), ptr(k), q.stride(1), B, L, h, d, ptr(partial), stream_ptr()),
+                          "lpm_mha_logit_stats")
             mean, var, kscale, kshift = bn_fold(partial, B * h, L, B * h * L, gamma, beta, moving_mean, moving_var)
         else:
             kscale, kshift = folded_eval_affine(gamma, beta, moving_mean, moving_var)
@@ -2006,6 +2014,7 @@ class _MHACoreBN(torch.autograd.Function):
         lib.check(_mha_fwd_fn(lib, bn=True, L=L)(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, h, d, 1.0, ptr(kscale), ptr(kshift), ptr(o),
                                    o.stride(1), ptr(lse), stream_ptr()), "lpm_mha_fwd")
         ctx.dims = (B, L, h, d, is_training)
+        ctx.moments = moments
         ctx.save_for_backward(q, k, v, o, lse, kscale, kshift, mean, var, gamma)
         return o
 
@@ -2033,7 +2042,7 @@ class _MHACoreBN(torch.autograd.Function):
                                           ptr(kscale), ptr(kshift), ptr(dq), None, None, dq.stride(1), ptr(corr_a), ptr(corr_b), None, st),
                       "lpm_mha_bwd_x3(dq)")
             lib.check(lib._lpm_mha_bn_dk_correct(ptr(q), ptr(k), q.stride(1), B, L, h, d, 1.0, ptr(corr_a), ptr(corr_b), ptr(dk),
-                                                 dk.stride(1), st), "lpm_mha_bn_dk_correct")
+                                                 dk.stride(1), ptr(ctx.moments), st), "lpm_mha_bn_dk_correct")
             return dq, dk, dv, dgamma, dbeta, None, None, None, None
         # pass 1: column sums of dz and dz*s over (B, h, query)
         partial = _empty((B * h, 2, L), q)

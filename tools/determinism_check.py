@@ -16,15 +16,15 @@ side = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
 TAP = len(sys.argv) > 4 and sys.argv[4] == "tap"      # copies of the video pooling backward's intermediates are compared too (ops.DEBUG_TAP)
 from learnablepoolingmethods_amd import ops
 dev = torch.device("cuda:0")
-if cfg == "blocks":                                   # the two-rank test's tower (tests/dp_cases.py), one rank of it
-    from tests import dp_cases
-    case = dp_cases.make_case("blocks")
-    c = case["cfg"]
-    FLAGS.audio_side_stream = side
-    per = case["per_tower"]
-    tr = Trainer(registry.get_model("NetVladV1"), vocab_size=c.vocab_size, batch_size=per, base_learning_rate=2e-4, device=dev, seed=100,
-                 model_kwargs=dict(iterations=c.iterations, cluster_size=c.cluster_size, hidden_size=c.hidden_size))
-    raw, nf, labels = case["x"][:per].to(dev), case["nf"][:per].to(dev), case["lab"][:per].to(dev)
+if cfg == "blocks":                                   # the small tower of the two-rank tests (tests/dp_cases.py "blocks"): 16 clips x 40 frames,
+    FLAGS.audio_side_stream = side                    # K = 256, both encoders as block Functions, closed-form input_bn gradients
+    per, max_frames, vocab = 16, 40, 50
+    tr = Trainer(registry.get_model("NetVladV1"), vocab_size=vocab, batch_size=per, base_learning_rate=2e-4, device=dev, seed=100,
+                 model_kwargs=dict(iterations=32, cluster_size=256, hidden_size=64))
+    g = torch.Generator(device=dev).manual_seed(33)
+    nf = torch.randint(max_frames // 3, max_frames + 1, (per,), device=dev, generator=g, dtype=torch.int32)
+    raw = torch.randn(per, max_frames, 1152, device=dev, generator=g) * (torch.arange(max_frames, device=dev)[None, :, None] < nf[:, None, None])
+    labels = torch.rand(per, vocab, device=dev, generator=g) < 0.06
 else:
     wl = bench.WORKLOADS[cfg]
     bench.set_flags(wl)
