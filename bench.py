@@ -394,6 +394,17 @@ def main():
                 "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic", "dtype_detail": wl["dtype_detail"],
                 "config": {"workload": wl["workload"], "global_batch": global_batch, "seq_len": MAX_FRAMES, "parallelism": f"dp{world}"},
                 "final_loss": round(loss, 4)}
+        # launches per step, from the committed rocprofv3 kernel-trace table of this workload (tools/rocpd_stats.py counts the dispatches
+        # of the profiled run and divides by its steps); not measured live: a profiler would sit inside the timed region
+        import glob
+        import re
+        tag = {"cfg2": "bench"}.get(args.config, args.config)
+        tables = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r03_{tag}_kernel_stats_v*_two_stream.md")),
+                        key=lambda f: int(re.search(r"_v(\d+)_", f).group(1)))
+        if tables:
+            m = re.search(r"= (\d+) dispatches per step", open(tables[-1]).read(4096))
+            if m:
+                line["dispatches_per_step"] = {"value": int(m.group(1)), "source": "profiles/" + os.path.basename(tables[-1])}
         if roof:
             line["roofline"] = roof
         if k1:
