@@ -1,0 +1,14 @@
+# every default-on switch of the round A/B'd in process on ONE box (tools/ab_flags.py: median ms per step of 4 x 40 steps, alternating)
+cd $GRAFT_REPO_ROOT
+run() { echo "== $2: $1"; python tools/ab_flags.py $1 4 40 $2 2>&1 | grep -E "median" ; }
+run ops.FFN_TILES cfg2
+run ops.DIRECT_WGRAD cfg2
+run audio_side_stream cfg2
+run fused_encoder_blocks cfg2
+run ops.DIRECT_WGRAD cfg5
+run ops.PROJ_DX_STREAM_MIN_N=1024,4096 cfg5
+run ops.FFN_MOD_FUSED cfg3
+run ops.MHA_BN_ONEPASS cfg3
+run ops.MHA_BN_MOMENTS cfg3
+run ops.V2_SPLIT_COLUMNS cfg3
+for c in cfg2 cfg5; do for xw in 1 0; do echo "== $c LPM_PROJ_XWAVE=$xw: $(LPM_PROJ_XWAVE=$xw python bench.py --config $c --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['ms_per_step'])")"; done; done
