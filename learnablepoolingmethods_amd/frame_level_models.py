@@ -182,7 +182,11 @@ class NetVladV1(models.BaseModel):
         if shortcut:
             with torch.no_grad():
                 rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
-            aff_v, aff_a = (g_in[0:1024], b_in[0:1024]), (g_in[1024:], b_in[1024:])
+            if ops.SPLIT_VECTOR and g_in.is_cuda and g_in.dim() == 1 and g_in.shape[0] > 1024:
+                (gv, ga), (bv, ba) = ops.split_vector(g_in, 1024), ops.split_vector(b_in, 1024)
+                aff_v, aff_a = (gv, bv), (ga, ba)
+            else:
+                aff_v, aff_a = (g_in[0:1024], b_in[0:1024]), (g_in[1024:], b_in[1024:])
         if aff_v is not None:
             pass
         elif has_audio and reshaped_input.is_cuda:

@@ -99,6 +99,7 @@ MHA_BN_X3_MIN_KEYS = int(os.environ.get("LPM_MHA_BN_X3_MIN_KEYS", "128"))
 _XT_CACHE = {}
 MHA_BN_MOMENTS = os.environ.get("LPM_MHA_BN_MOMENTS", "1") != "0"      # ... statistics by lpm_mha_logit_stats_moments, moments kept for the backward
 MHA_BN_ONEPASS = os.environ.get("LPM_MHA_BN_ONEPASS", "1") != "0"      # logits_bn backward without the separate statistics pass (A/B switch)
+SPLIT_VECTOR = True          # NetVladV1: input_bn's gamma / beta halves with ONE concatenated gradient each (A/B switch)
 V2_SPLIT_COLUMNS = True      # NetVladV2: the two streams' inputs as contiguous copies with ONE concatenated gradient (A/B switch)
 DEBUG_TAP = None      # tools/determinism_check.py: a dict that the video stream's pooling backward fills with copies of its intermediates
 
@@ -350,6 +351,30 @@ class _SplitColumns(torch.autograd.Function):
         if db is None:
             db = torch.zeros((M, F - c), dtype=torch.float32, device=slot["device"])
         return torch.cat([da, db], dim=1), None
+
+
+class _SplitVector(torch.autograd.Function):
+    """v [F] -> (v[:c], v[c:]) as views whose gradients come back as ONE concatenation (two plain slices cost autograd a zero-fill, a
+    scatter copy and an add each: ten 5-us launches per step for input_bn's gamma and beta)."""
+
+    @staticmethod
+    def forward(ctx, v, c):
+        ctx.c, ctx.n, ctx.like = c, v.shape[0], v
+        return v[:c], v[c:]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        c, n, like = ctx.c, ctx.n, ctx.like
+        if da is None:
+            da = torch.zeros(c, dtype=like.dtype, device=like.device)
+        if db is None:
+            db = torch.zeros(n - c, dtype=like.dtype, device=like.device)
+        return torch.cat([da.reshape(-1), db.reshape(-1)]), None
+
+
+def split_vector(v, c):
+    """(v[:c], v[c:]) of a 1-D tensor with a concatenated gradient (see _SplitVector)."""
+    return _SplitVector.apply(v, int(c))
 
 
 def split_columns(x, c):
