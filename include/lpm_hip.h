@@ -550,6 +550,16 @@ int lpm_mha_fwd_x3_image(const float* q, const float* k, const float* v, int64_t
 size_t lpm_mha_logit_stats_workspace_bytes(int B, int L, int h);
 int lpm_mha_logit_stats(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float* partial,
                         lpm_stream_t stream);
+/* slim.batch_norm (training mode) of a SMALL [M, C] matrix, M <= 256 rows, with what follows it, in ONE launch each way -- the clip-level
+ * tail of the model (frame_level_models.py:2321-2327 hidden1_bn + relu6 :2337; :2354-2368 gating_bn + the context gate):
+ *   act 0: y = bn(x);  act 1: y = relu6(bn(x));  act 2: y = mul * sigmoid(bn(x)).
+ * mean / rstd [C]: the batch statistics, kept for the backward; moving_mean / moving_var (or both NULL) are updated in place with
+ * `decay` and the unbiased variance (TF's fused rank-2 batch norm).  Backward: dx, dgamma, dbeta and (act 2) dmul [M, C]. */
+int lpm_bn_small_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float decay, int act,
+                     const float* mul, float* y, float* mean, float* rstd, float* moving_mean, float* moving_var, lpm_stream_t stream);
+int lpm_bn_small_bwd(const float* dy, const float* x, int M, int C, const float* gamma, const float* beta, const float* mean,
+                     const float* rstd, int act, const float* mul, float* dx, float* dgamma, float* dbeta, float* dmul,
+                     lpm_stream_t stream);
 /* logits_bn backward bookkeeping in one launch: partial [nblk][2][L] = lpm_mha_bwd's statistics pass (column sums of dz and dz * s per
  * (batch, head)) -> dgamma, dbeta and, in training (corr_a / corr_b given), the correction vectors of the main backward pass;
  * n = B * h * L logits per key position (transformer_utils.py:652-658, backward) */

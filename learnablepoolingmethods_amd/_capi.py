@@ -112,6 +112,8 @@ SIGNATURES = {
     "lpm_input_bn_grads": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f]),
     "lpm_vlad_aggregate_bwd_tiles_dx": (_i, [_f, _s, _f, _f, _i, _i, _i, _i, _f, _l, _i, _f]),
     "lpm_bn_rows_workspace_bytes": (_s, [_i, _i]),
+    "lpm_bn_small_fwd": (_i, [_f, _i, _i, _f, _f, _fl, _fl, _i, _f, _f, _f, _f, _f, _f, _f]),
+    "lpm_bn_small_bwd": (_i, [_f, _f, _i, _i, _f, _f, _f, _f, _i, _f, _f, _f, _f, _f, _f]),
     "lpm_mha_bn_corrections": (_i, [_f, _i, _i, _f, _f, _f, _fl, _l, _f, _f, _f, _f, _f]),
     "lpm_bn_rows_act_fwd": (_i, [_f, _f, _i, _i, _i, _f, _f, _fl, _fl, _i, _f, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_bn_act_bwd_supported": (_i, [_i, _i]),

@@ -384,6 +384,137 @@ static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu,
     return check_launch("lpm_bn_rows_fwd");
 }
 
+namespace lpm {
+// ---- batch norm of a SMALL [M, C] matrix (M <= 256 rows: the clip-level tail of the model, frame_level_models.py:2321-2368) in ONE launch
+// each way.  torch's fused batch norm is three launches forward and two backward, the activation behind it one or two more; at 80-128
+// rows every one of them is a ~5 us dependent launch that does nothing.  One workgroup per 32 columns, 256 threads = 32 columns x 8 row
+// groups, the rows of a thread in registers (two-pass variance), statistics through LDS in a fixed order.
+//   act 0: y = bn(x)    act 1: y = relu6(bn(x))  (tf.nn.relu6, :2337)    act 2: y = mul * sigmoid(bn(x))  (context gating, :2367-2368)
+// Training mode only: batch statistics, moving averages updated in place with the UNBIASED variance (TF's fused rank-2 batch norm).
+constexpr int BS_RMAX = 32;                // rows per thread: M <= 8 * 32
+__device__ __forceinline__ float bs_colsum(float v, float (*sh)[32], int cl, int rg) {      // sum over the 8 row groups of a column; all threads
+    __syncthreads();
+    sh[rg][cl] = v;
+    __syncthreads();
+    return ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) + ((sh[4][cl] + sh[5][cl]) + (sh[6][cl] + sh[7][cl]));
+}
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, int M, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float decay, int act,
+                                                           const float* __restrict__ mul, float* __restrict__ y, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, float* moving_mean, float* moving_var) {
+    __shared__ float sh[8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    const bool ok = c < C;
+    float v[BS_RMAX];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < BS_RMAX; ++i) {
+        const int r = rg + 8 * i;
+        v[i] = (ok && r < M) ? x[(int64_t)r * C + c] : 0.f;
+        s += v[i];
+    }
+    const float mu = bs_colsum(s, sh, cl, rg) / (float)M;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < BS_RMAX; ++i) {
+        const int r = rg + 8 * i;
+        const float d = (ok && r < M) ? v[i] - mu : 0.f;
+        q = fmaf(d, d, q);
+    }
+    const float var = bs_colsum(q, sh, cl, rg) / (float)M;
+    const float rstd = rsqrtf(var + eps);
+    if (!ok) return;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < BS_RMAX; ++i) {
+        const int r = rg + 8 * i;
+        if (r < M) {
+            float z = fmaf((v[i] - mu) * rstd, g, b);
+            if (act == 1) z = fminf(fmaxf(z, 0.f), 6.f);
+            else if (act == 2) z = mul[(int64_t)r * C + c] / (1.f + __expf(-z));
+            y[(int64_t)r * C + c] = z;
+        }
+    }
+    if (rg == 0) {
+        mean_out[c] = mu;
+        rstd_out[c] = rstd;
+        if (moving_mean) {
+            const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+            moving_mean[c] = moving_mean[c] * decay + mu * (1.f - decay);
+            moving_var[c] = moving_var[c] * decay + unb * (1.f - decay);
+        }
+    }
+}
+// dy -> dx (through the activation and the batch statistics), dgamma, dbeta, and (act 2) dmul = dy * sigmoid(bn(x))
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                                           const float* __restrict__ mul, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dmul) {
+    __shared__ float sh[8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    const bool ok = c < C;
+    const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f, g = (ok && gamma) ? gamma[c] : 1.f, b = (ok && beta) ? beta[c] : 0.f;
+    float xh[BS_RMAX], dz[BS_RMAX];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < BS_RMAX; ++i) {
+        const int r = rg + 8 * i;
+        xh[i] = 0.f; dz[i] = 0.f;
+        if (ok && r < M) {
+            const int64_t o = (int64_t)r * C + c;
+            xh[i] = (x[o] - mu) * rs;
+            const float z = fmaf(xh[i], g, b), d = dy[o];
+            if (act == 1) dz[i] = (z > 0.f && z < 6.f) ? d : 0.f;
+            else if (act == 2) {
+                const float sg = 1.f / (1.f + __expf(-z)), m = mul[o];
+                dmul[o] = d * sg;
+                dz[i] = d * m * sg * (1.f - sg);
+            } else dz[i] = d;
+            s += dz[i];
+            q = fmaf(dz[i], xh[i], q);
+        }
+    }
+    const float sdz = bs_colsum(s, sh, cl, rg), sdzx = bs_colsum(q, sh, cl, rg);
+    if (!ok) return;
+    const float a = g * rs, m1 = sdz / (float)M, m2 = sdzx / (float)M;
+#pragma unroll
+    for (int i = 0; i < BS_RMAX; ++i) {
+        const int r = rg + 8 * i;
+        if (r < M) dx[(int64_t)r * C + c] = a * (dz[i] - m1 - xh[i] * m2);
+    }
+    if (rg == 0) {
+        dgamma[c] = sdzx;
+        dbeta[c] = sdz;
+    }
+}
+}  // namespace lpm
+
+extern "C" int lpm_bn_small_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float decay, int act,
+                                const float* mul, float* y, float* mean, float* rstd, float* moving_mean, float* moving_var,
+                                lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x && y && mean && rstd && (act != 2 || mul), LPM_ERR_BADARG, "lpm_bn_small_fwd: null pointer");
+    LPM_REQUIRE(M > 0 && M <= 8 * BS_RMAX && C > 0 && act >= 0 && act <= 2, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_bn_small_fwd: need 1 <= M <= %d rows and act in {0, 1, 2} (M=%d)", 8 * BS_RMAX, M);
+    LPM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), LPM_ERR_BADARG, "lpm_bn_small_fwd: moving_mean and moving_var go together");
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, M, C, gamma, beta, eps, decay, act, mul,
+                       y, mean, rstd, moving_mean, moving_var);
+    return check_launch("lpm_bn_small_fwd");
+}
+
+extern "C" int lpm_bn_small_bwd(const float* dy, const float* x, int M, int C, const float* gamma, const float* beta, const float* mean,
+                                const float* rstd, int act, const float* mul, float* dx, float* dgamma, float* dbeta, float* dmul,
+                                lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dy && x && mean && rstd && dx && dgamma && dbeta && (act != 2 || (mul && dmul)), LPM_ERR_BADARG, "lpm_bn_small_bwd: null pointer");
+    LPM_REQUIRE(M > 0 && M <= 8 * BS_RMAX && C > 0 && act >= 0 && act <= 2, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_bn_small_bwd: need 1 <= M <= %d rows and act in {0, 1, 2} (M=%d)", 8 * BS_RMAX, M);
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, dy, x, M, C, gamma, beta, mean, rstd, act,
+                       mul, dx, dgamma, dbeta, dmul);
+    return check_launch("lpm_bn_small_bwd");
+}
+
 extern "C" int lpm_bn_fold(const float* partial, int nblk, int C, int64_t rows, const float* gamma, const float* beta,
                            float eps, float decay, float* mean, float* var, float* scale, float* shift,
                            float* moving_mean, float* moving_var, lpm_stream_t stream) {

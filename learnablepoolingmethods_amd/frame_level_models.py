@@ -64,12 +64,15 @@ def _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_bat
     hidden1_weights = vs.get_variable("hidden1_weights", [vlad_dim, hidden1_size],
                                       vs.random_normal_initializer(1 / math.sqrt(cluster_size)), device=dev)   # :2315-2317
     activation = ops.projection(vlad, hidden1_weights) if vlad.is_cuda else vlad.matmul(hidden1_weights)      # :2319
-    if add_batch_norm and relu:
+    small = is_training and ops.bn_small_ok(activation)         # clip-level tensors: batch norm + what follows it in one launch each way
+    if add_batch_norm and relu and small:
+        activation = ops.bn_small(activation, *layers.bn_variables("hidden1_bn", hidden1_size, dev), act=1)    # :2321-2327 + relu6 :2337
+    elif add_batch_norm and relu:
         activation = layers.batch_norm(activation, is_training, "hidden1_bn")                                  # :2321-2327
     else:
         hidden1_biases = vs.get_variable("hidden1_biases", [hidden1_size], vs.random_normal_initializer(0.01), device=dev)
         activation = activation + hidden1_biases                                                               # :2329-2334
-    if relu:
+    if relu and not (add_batch_norm and small):
         activation = torch.clamp(activation, 0.0, 6.0)                                                         # relu6 :2337
     if gating:
         gating_weights = vs.get_variable("gating_weights_2", [hidden1_size, hidden1_size],
@@ -77,11 +80,13 @@ def _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_bat
         gates = activation.matmul(gating_weights)
         if remove_diag:
             gates = gates - torch.diagonal(gating_weights) * activation                                        # :2349-2352
-        if add_batch_norm:
-            gates = layers.batch_norm(gates, is_training, "gating_bn")                                         # :2354-2360
-        else:
+        if not add_batch_norm:
             raise NotImplementedError("context gating without batch norm is broken in the reference (App. C12)")
-        activation = activation * torch.sigmoid(gates)                                                         # :2367-2368
+        if small:
+            activation = ops.bn_small(gates, *layers.bn_variables("gating_bn", hidden1_size, dev), act=2, mul=activation)   # :2354-2368
+        else:
+            gates = layers.batch_norm(gates, is_training, "gating_bn")                                         # :2354-2360
+            activation = activation * torch.sigmoid(gates)                                                     # :2367-2368
     vs.summary("activation", activation)
     aggregated_model = getattr(video_level_models, "MoeModel")
     return aggregated_model().create_model(model_input=activation, vocab_size=vocab_size, is_training=is_training,

@@ -163,6 +163,50 @@ def bn_fold(partial, nblk, C, rows, gamma, beta, moving_mean=None, moving_var=No
     return mean, var, scale, shift
 
 
+class _BNSmall(torch.autograd.Function):
+    """Training-mode slim.batch_norm of a small [M, C] matrix fused with what follows it (lpm_bn_small_fwd / _bwd): act 0 nothing,
+    1 relu6, 2 the context gate  mul * sigmoid(bn(x))."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, act, mul):
+        lib = _capi.load()
+        x = _f32(x, "x").contiguous()
+        M, C = x.shape
+        mul = _f32(mul, "mul").contiguous() if mul is not None else None
+        y, mean, rstd = torch.empty_like(x), _empty((C,), x), _empty((C,), x)
+        lib.check(lib._lpm_bn_small_fwd(ptr(x), M, C, ptr(gamma), ptr(beta), BN_EPS, BN_DECAY, act, ptr(mul), ptr(y), ptr(mean), ptr(rstd),
+                                        ptr(moving_mean), ptr(moving_var), stream_ptr()), "lpm_bn_small_fwd")
+        ctx.act = act
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, mul)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _capi.load()
+        x, gamma, beta, mean, rstd, mul = ctx.saved_tensors
+        M, C = x.shape
+        dy = _f32(dy, "dy").contiguous()
+        dx, dgamma, dbeta = torch.empty_like(x), _empty((C,), x), _empty((C,), x)
+        dmul = torch.empty_like(x) if ctx.act == 2 else None
+        lib.check(lib._lpm_bn_small_bwd(ptr(dy), ptr(x), M, C, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ctx.act, ptr(mul), ptr(dx),
+                                        ptr(dgamma), ptr(dbeta), ptr(dmul), stream_ptr()), "lpm_bn_small_bwd")
+        return dx, dgamma, dbeta, None, None, None, dmul
+
+
+BN_SMALL = True              # the clip-level batch norms (hidden1_bn + relu6, gating_bn + gate) as one launch each way (A/B switch)
+
+
+def bn_small_ok(x, mul=None):
+    return (BN_SMALL and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and 1 < x.shape[0] <= 256
+            and (mul is None or (mul.shape == x.shape and mul.dtype == torch.float32)))
+
+
+def bn_small(x, gamma, beta, moving_mean, moving_var, act=0, mul=None):
+    """act(batch_norm(x)) in training mode for a small [M, C] matrix: act 0 / 1 (relu6) / 2 (mul * sigmoid(.)); moving statistics updated
+    in place (decay BN_DECAY, unbiased variance)."""
+    return _BNSmall.apply(x, gamma, beta, moving_mean, moving_var, int(act), mul)
+
+
 def folded_eval_affine(gamma, beta, moving_mean, moving_var, eps=BN_EPS):
     """Inference-mode batch norm is a constant affine (tiny [C] tensors: plain torch)."""
     scale = gamma * torch.rsqrt(moving_var + eps)

@@ -1242,3 +1242,34 @@ def test_netvlad_bf16_storage():
     # the fp32 frames were not materialised: an op that would read them says so instead of computing on garbage
     with pytest.raises(Exception, match="bf16 operand tiles only"):
         ops.netvlad(y[:, :1024].detach(), torch.zeros(1024, 128, device=dev), None, T, bias=torch.zeros(128, device=dev))
+
+
+@pytest.mark.parametrize("M,C,act", [(80, 512, 1), (80, 512, 2), (128, 1024, 2), (7, 40, 0), (250, 96, 1), (2, 33, 2)])
+def test_bn_small_one_launch_each_way(M, C, act):
+    """lpm_bn_small_fwd / _bwd: the clip-level batch norms with what follows them (frame_level_models.py:2321-2337: hidden1_bn + relu6;
+    :2354-2368: gating_bn + the context gate) against fp64 autograd of the plain formulas; moving statistics with the unbiased variance."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(M + C + act)
+    x, mul, dy = torch.randn(M, C, generator=g) * 2 + 0.5, torch.randn(M, C, generator=g), torch.randn(M, C, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    mm, mv = 0.1 * torch.randn(C, generator=g), 1 + 0.3 * torch.rand(C, generator=g)
+    xd, md, gd, bd = (t.double().requires_grad_(True) for t in (x, mul, gamma, beta))
+    mu, var = xd.mean(0), xd.var(0, unbiased=False)
+    z = (xd - mu) * torch.rsqrt(var + ops.BN_EPS) * gd + bd
+    ref = z if act == 0 else (torch.clamp(z, 0.0, 6.0) if act == 1 else md * torch.sigmoid(z))
+    ref.backward(dy.double())
+    xg, mg, gg, bg = (t.to(dev).requires_grad_(True) for t in (x, mul, gamma, beta))
+    mmg, mvg = mm.to(dev), mv.to(dev)
+    assert ops.bn_small_ok(xg, mg if act == 2 else None)
+    out = ops.bn_small(xg, gg, bg, mmg, mvg, act=act, mul=mg if act == 2 else None)
+    assert_close(out, ref, 1e-5, "bn_small fwd")
+    out.backward(dy.to(dev))
+    assert_close(xg.grad, xd.grad, 2e-5, "dx")
+    assert_close(gg.grad, gd.grad, 2e-5, "dgamma")
+    assert_close(bg.grad, bd.grad, 2e-5, "dbeta")
+    if act == 2:
+        assert_close(mg.grad, md.grad, 1e-5, "dmul")
+    unb = var.detach() * (M / (M - 1))
+    assert_close(mmg, mm.double() * ops.BN_DECAY + mu.detach() * (1 - ops.BN_DECAY), 1e-6, "moving_mean")
+    assert_close(mvg, mv.double() * ops.BN_DECAY + unb * (1 - ops.BN_DECAY), 1e-6, "moving_variance")
