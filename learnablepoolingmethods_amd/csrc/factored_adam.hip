@@ -46,6 +46,11 @@ static int64_t fa_workgroups(int N1, int N2) { return (int64_t)((N1 + 63) / 64) 
 // B = the X weight tiles the update pass reads anyway -- then sum X .* Y with X in fp32 from the projection's input.  2 R^2 N1
 // flops instead of the 2 R N1 N2 of forming the gradient (8 x fewer at cfg-5), 8 bytes per element of X.  R <= 128.
 constexpr int FQ_GRID = 512;
+// XT (round 3): the X of "sum X .* Y" comes out of the SAME tiles (hi + lo: 2^-17 relative, a norm does not see it) instead of a second
+// read of the fp32 matrix -- the pass was 8 bytes per element of X at HBM rate.  A B fragment holds, per 16-row step, rows 8 half + e of
+// column l31; the accumulator wants rows 4 half + i + 8 j: for j even (rows 0-7 of a step) the half-0 lanes' elements 4 half + i, for j odd
+// the half-1 lanes' -- four of the eight values are the lane's own, four its partner's (lane ^ 32): one 4-value exchange per step.
+template <bool XT>
 __global__ __launch_bounds__(256, 2) void fa_quadform_kernel(const uint4* __restrict__ xt, const float* __restrict__ x, int64_t ldx,
                                                              const uint4* __restrict__ gdt, int R, int N1, int NT1, int MT,
                                                              float* __restrict__ partial) {
@@ -65,9 +70,27 @@ __global__ __launch_bounds__(256, 2) void fa_quadform_kernel(const uint4* __rest
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-        for (int s = 0; s < S; ++s) {
+        float xo[XT ? 8 : 1][4], xp[XT ? 8 : 1][4];       // per step: this lane's rows 4 half + i of its own fragment half, and of its partner's
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s >= S) break;
             const uint4 h4 = xt[(((int64_t)s * NT1 + tile) * 2 + 0) * 64 + lane], l4 = xt[(((int64_t)s * NT1 + tile) * 2 + 1) * 64 + lane];
             const tg_u32x4 xh = {h4.x, h4.y, h4.z, h4.w}, xl = {l4.x, l4.y, l4.z, l4.w};
+            if constexpr (XT) {
+                const int hf = lane >> 5;
+                float xf[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned sh = (e & 1) * 16;
+                    xf[e] = __uint_as_float((xh[e >> 1] >> sh) << 16) + __uint_as_float((xl[e >> 1] >> sh) << 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xo[s][i] = hf ? xf[4 + i] : xf[i];                 // own element 4 half + i
+                    const float send = hf ? xf[i] : xf[4 + i];         // the partner's 4 half' + i
+                    xp[s][i] = __shfl_xor(send, 32, 64);
+                }
+            }
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 if (rt < MT) {
@@ -81,6 +104,27 @@ __global__ __launch_bounds__(256, 2) void fa_quadform_kernel(const uint4* __rest
         // acc[rt][r] = (G X)[b = 32 rt + mfma32_row(r, lane)][n1 = 32 tile + l31]
         const int n1 = tile * 32 + l31;
         float part = 0.f;
+        if constexpr (XT) {
+            const int hf = lane >> 5;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                if (rt < MT) {
+#pragma unroll
+                    for (int js = 0; js < 2; ++js) {
+                        const int st = 2 * rt + js;                    // the 16-row step the rows 16 js .. 16 js + 15 of this row tile came from
+                        if (st < S) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float x0 = hf ? xp[st][i] : xo[st][i];      // rows 8 (2 js) + 4 half + i: the half-0 fragment
+                                const float x1 = hf ? xo[st][i] : xp[st][i];      // rows 8 (2 js + 1) + 4 half + i: the half-1 fragment
+                                part = fmaf(acc[rt][4 * (2 * js) + i], x0, part);
+                                part = fmaf(acc[rt][4 * (2 * js + 1) + i], x1, part);
+                            }
+                        }
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             if (rt < MT) {
@@ -241,14 +285,15 @@ static int factored_clip_adam_impl(const void* xt, const void* dyt, const float*
     if (gdt) {
         const int MT = 2 * ((R + 63) / 64);
         const size_t lds = (size_t)MT * (R / 16) * 2048;
-        if (hipFuncSetAttribute((const void*)fa_quadform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        static const int from_tiles = [] { const char* e = getenv("LPM_FQ_TILES"); return (e && e[0] == '0') ? 0 : 1; }();   // 0: X from the fp32 matrix (A/B)
+        auto kern = (from_tiles && R <= 128) ? fa_quadform_kernel<true> : fa_quadform_kernel<false>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             set_error("lpm_factored_clip_adam_q: cannot reserve %zu bytes of LDS", lds);
             return LPM_ERR_LAUNCH;
         }
         npart = FQ_GRID < nwg ? FQ_GRID : nwg;
-        hipLaunchKernelGGL(fa_quadform_kernel, dim3((unsigned)npart), dim3(256), lds, s, (const uint4*)xt, x, ldx, (const uint4*)gdt, R, N1, NT1, MT,
-                           partial);
+        hipLaunchKernelGGL(kern, dim3((unsigned)npart), dim3(256), lds, s, (const uint4*)xt, x, ldx, (const uint4*)gdt, R, N1, NT1, MT, partial);
     } else {
         g.sumsq = partial;
         rc = (dbg & 2) ? LPM_OK : tile_gemm_store(g, 1, 1, s, "lpm_factored_clip_adam (norm pass)", 1);
