@@ -1,4 +1,4 @@
-"""-m "not gpu": the data-parallel path with world_size 2 on the gloo backend (CPU).
+"""-m "not gpu": the data-parallel path with world_size 2 and 8 on the gloo backend (CPU).
 Each rank is a tower (train.py:266-284): it computes gradients on its shard; the arena all-reduce must equal
 utils.combine_gradients (SUM, not mean) of the oracle's per-tower gradients, including the early-launched
 hidden1_weights bucket, and ranks must start from rank 0's weights."""
@@ -67,9 +67,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-def test_gradient_sum_allreduce_matches_tower_combine():
-    world = 2
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 8])          # 8: the tower count of BASELINE configs[3] / [4] (one clip per tower here)
+def test_gradient_sum_allreduce_matches_tower_combine(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -86,14 +86,16 @@ def test_gradient_sum_allreduce_matches_tower_combine():
         assert p.exitcode == 0
     # ranks share rank 0's weights
     for n in res[0][1]:
-        assert torch.equal(res[0][1][n], res[1][1][n])
+        for r in range(1, world):
+            assert torch.equal(res[0][1][n], res[r][1][n])
     # oracle: per-tower gradients on the same shards, SUMMED (utils.py:207-211)
     g = torch.Generator().manual_seed(7)
     X, Y = torch.randn(8, 10, generator=g), torch.rand(8, 4, generator=g)
     tower = []
+    per = 8 // world
     for r in range(world):
         leaf = {n: v.clone().requires_grad_(True) for n, v in res[0][1].items()}
-        _toy_loss(leaf, X[r * 4:(r + 1) * 4], Y[r * 4:(r + 1) * 4]).backward()
+        _toy_loss(leaf, X[r * per:(r + 1) * per], Y[r * per:(r + 1) * per]).backward()
         tower.append({n: v.grad for n, v in leaf.items()})
     ref = O.combine_gradients(tower)
     for r in range(world):
@@ -143,7 +145,8 @@ def _bucket_worker(rank, world, port, q):
     dist.broadcast(arena.param, src=0)
     g = torch.Generator().manual_seed(11)
     X, Y = torch.randn(8, 10, generator=g), torch.rand(8, 4, generator=g)
-    sl = slice(rank * 4, rank * 4 + 4)
+    per = 8 // world
+    sl = slice(rank * per, rank * per + per)
     out = []
     for step in range(2):                                  # twice: the per-step re-arming must work
         arena.zero_grad()
@@ -160,9 +163,9 @@ def _bucket_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-def test_bucketed_gather_allreduce():
-    world = 2
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 8])          # 8 towers: the generic route every variable takes in the 8-GPU configurations
+def test_bucketed_gather_allreduce(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -185,7 +188,8 @@ def test_bucketed_gather_allreduce():
     tower = []
     for r in range(world):
         leaf = {n: v.clone().requires_grad_(True) for n, v in res[0][1].items()}
-        _bucket_loss(leaf, X[r * 4:(r + 1) * 4], Y[r * 4:(r + 1) * 4]).backward()
+        per = 8 // world
+        _bucket_loss(leaf, X[r * per:(r + 1) * per], Y[r * per:(r + 1) * per]).backward()
         tower.append({n: v.grad for n, v in leaf.items()})
     for tg in tower:                       # every tower's gradient includes the penalty term (train.py:296-303,321), then SUM
         for n, c in _L2.items():
