@@ -180,23 +180,24 @@ def test_bench_self_launch_two_ranks(tmp_path):
 
 
 @pytest.mark.timeout(900)
-def test_bench_eight_ranks_share_the_gpu_over_gloo():
-    """`python bench.py --gpus 8` end to end with the tower count of BASELINE configs[3] / [4]: eight ranks of the real cfg-2 trainer
+@pytest.mark.parametrize("config,global_batch", [("cfg2", 640), ("cfg5", 1024)])       # BASELINE configs[3] and configs[4]
+def test_bench_eight_ranks_share_the_gpu_over_gloo(config, global_batch):
+    """`python bench.py --gpus 8` end to end with the tower count of BASELINE configs[3] / [4]: eight ranks of the real trainer
     (here all on GPU 0 over gloo, the debug mode LPM_SHARE_GPU=1 -- the boxes of this pool have one GPU), hidden1_weights on the generic
     route that more than four towers take (its 554 MB bucket all-reduced), one JSON line from rank 0."""
     import json
     if torch.cuda.get_device_properties(0).total_memory < 150 * 2 ** 30:
-        pytest.skip("eight cfg-2 trainers need ~100 GB of HBM")
+        pytest.skip("eight trainers of these configurations need 100-160 GB of HBM")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LPM_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--spinup-seconds", "0",
-           "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--spinup-seconds", "0", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 640 and d["config"]["parallelism"] == "dp8" and d["value"] > 0
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == global_batch and d["config"]["parallelism"] == "dp8" and d["value"] > 0
 
 
 @pytest.mark.timeout(900)
