@@ -265,6 +265,12 @@ int lpm_split_rows_scaled(const float* x, int64_t ldx, int64_t M, int K, const f
 int lpm_layer_norm_act_fwd_rs(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,
                               const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, float* z,
                               float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+/* The same forward with y ALSO written as the split-bf16 activation image y3 [B*L, 3F] bf16 = [hi | lo | hi] (lpm_split_rows order 0) of
+ * the dense layer that reads it next (FeedForwardNetwork's first layer after the attention's layer norm, transformer_utils.py:405-411,
+ * 701-711): the split pass over y is not run.  r_scale may be NULL. */
+int lpm_layer_norm_act_image_fwd(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,
+                                 const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, void* y3, float* z,
+                                 float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 
 /* K2 with the finalize pass fused in (frame_level_models.py:2803-2822 as ONE kernel): the same workgroups, but each waits for
  * the other workgroups of its clip (per-clip arrival counter, bounded), forms 1/n_k and the clip's 1/sqrt(g) from the partial

@@ -100,6 +100,7 @@ SIGNATURES = {
     "lpm_vlad_aggregate_kmajor_scaled_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_split_rows_scaled": (_i, [_f, _l, _l, _i, _f, _f, _f]),
     "lpm_layer_norm_act_fwd_rs": (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _s, _f]),
+    "lpm_layer_norm_act_image_fwd": (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _f, _s, _f]),
     "lpm_vlad_fused_supported": (_i, [_i, _i]),
     "lpm_vlad_fused_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_vlad_aggregate_fused_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _s, _f]),

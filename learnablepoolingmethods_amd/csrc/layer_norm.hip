@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta, int64_t n_per, int F,
                                                            float eps, float* __restrict__ y, int64_t y_batch,
                                                            float* __restrict__ stats, const float* __restrict__ r2,
-                                                           float* __restrict__ partial_next) {
+                                                           float* __restrict__ partial_next, unsigned short* __restrict__ y3) {
+    // y3 != NULL: y ALSO leaves as the split-bf16 activation image [rows][3 F] = [hi | lo | hi] of the dense layer that reads it next
+    // (split_gemm.hip's format): the separate split pass over y (read 4 B, write 6 B per element) is not run
     __shared__ float sh[4];
     const int b = blockIdx.x, ch = blockIdx.y;
     double s = 0.0, q = 0.0;
@@ -125,6 +127,15 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
             nq = fmaf(o.x, o.x, nq); nq = fmaf(o.y, o.y, nq); nq = fmaf(o.z, o.z, nq); nq = fmaf(o.w, o.w, nq);
         }
         yp[i] = o;
+        if (y3) {
+            const unsigned hx = ln_bf16_pair(o.x, o.y), hz = ln_bf16_pair(o.z, o.w);
+            const unsigned lx = ln_bf16_pair(o.x - ln_bf16_up(hx & 0xffffu), o.y - ln_bf16_up(hx >> 16));
+            const unsigned lz = ln_bf16_pair(o.z - ln_bf16_up(hz & 0xffffu), o.w - ln_bf16_up(hz >> 16));
+            unsigned short* p = y3 + ((int64_t)b * (n_per / F) + i / F4) * 3 * F + c;
+            *reinterpret_cast<uint2*>(p) = make_uint2(hx, hz);
+            *reinterpret_cast<uint2*>(p + F) = make_uint2(lx, lz);
+            *reinterpret_cast<uint2*>(p + 2 * F) = make_uint2(hx, hz);
+        }
     }
     if (rp) {
         ns = block_sum(ns, sh);
@@ -350,7 +361,7 @@ extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
 
 static int layer_norm_act_fwd_impl(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,
                                    const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, float* z,
-                                   float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+                                   float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3 = nullptr) {
     using namespace lpm;
     LPM_REQUIRE(a && gamma && beta && y && stats && (z || (!r && !bias)), LPM_ERR_BADARG,
                 "lpm_layer_norm_act_fwd: null pointer (z is required with a residual or a bias)");
@@ -366,7 +377,7 @@ static int layer_norm_act_fwd_impl(const float* a, const float* bias, int relu, 
     dim3 grid(B, LN_NB);
     hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial, r_scale);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias) ? z : a, partial, gamma, beta, n_per, F, eps, y, yb, stats,
-                       (const float*)nullptr, (float*)nullptr);
+                       (const float*)nullptr, (float*)nullptr, (unsigned short*)y3);
     return check_launch("lpm_layer_norm_act_fwd");
 }
 extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma,
@@ -377,6 +388,15 @@ extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int rel
 }
 // ... with the residual given as raw rows times one factor per (example, row): r_scale [B * L] (the pooled descriptor in its lazily
 // normalised form, lpm_vlad_row_scales)
+extern "C" int lpm_layer_norm_act_image_fwd(const float* a, const float* bias, int relu, const float* r, const float* r_scale,
+                                            const float* gamma, const float* beta, int B, int L, int F, float eps, float* y,
+                                            int64_t y_batch_stride, void* y3, float* z, float* stats, void* workspace,
+                                            size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(y3 && ((uintptr_t)y3 & 7) == 0, LPM_ERR_BADARG, "lpm_layer_norm_act_image_fwd: y3 missing or not 8-byte aligned");
+    return layer_norm_act_fwd_impl(a, bias, relu, r, r_scale, gamma, beta, B, L, F, eps, y, y_batch_stride, z, stats, workspace,
+                                   workspace_bytes, stream, y3);
+}
 extern "C" int lpm_layer_norm_act_fwd_rs(const float* a, const float* bias, int relu, const float* r, const float* r_scale,
                                          const float* gamma, const float* beta, int B, int L, int F, float eps, float* y,
                                          int64_t y_batch_stride, float* z, float* stats, void* workspace, size_t workspace_bytes,
@@ -408,9 +428,9 @@ extern "C" int lpm_layer_norm_pair_fwd(const float* a, const float* bias, int re
     dim3 grid(B, LN_NB);
     hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z1, partial1, (const float*)nullptr);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z1, (const float*)partial1, gamma1, beta1, n_per, F, eps,
-                       z2, n_per, stats1, r, partial2);
+                       z2, n_per, stats1, r, partial2, (unsigned short*)nullptr);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z2, (const float*)partial2, gamma2, beta2, n_per, F, eps,
-                       y, yb, stats2, (const float*)nullptr, (float*)nullptr);
+                       y, yb, stats2, (const float*)nullptr, (float*)nullptr, (unsigned short*)nullptr);
     return check_launch("lpm_layer_norm_pair_fwd");
 }
 

@@ -99,6 +99,7 @@ MHA_BN_X3_MIN_KEYS = int(os.environ.get("LPM_MHA_BN_X3_MIN_KEYS", "128"))
 _XT_CACHE = {}
 MHA_BN_MOMENTS = os.environ.get("LPM_MHA_BN_MOMENTS", "1") != "0"      # ... statistics by lpm_mha_logit_stats_moments, moments kept for the backward
 MHA_BN_ONEPASS = os.environ.get("LPM_MHA_BN_ONEPASS", "1") != "0"      # logits_bn backward without the separate statistics pass (A/B switch)
+LN_IMAGE = True              # the attention block's layer norm also writes the operand image of the feed-forward block behind it (A/B switch)
 SPLIT_VECTOR = True          # NetVladV1: input_bn's gamma / beta halves with ONE concatenated gradient each (A/B switch)
 V2_SPLIT_COLUMNS = True      # NetVladV2: the two streams' inputs as contiguous copies with ONE concatenated gradient (A/B switch)
 DEBUG_TAP = None      # tools/determinism_check.py: a dict that the video stream's pooling backward fills with copies of its intermediates
@@ -1293,14 +1294,16 @@ class _FFNX3(torch.autograd.Function):
     hi/lo image, and the backward's ReLU mask, bias gradient and operand split are one pass as well."""
 
     @staticmethod
-    def forward(ctx, y2d, W1, b1, W2):
+    def forward(ctx, y2d, W1, b1, W2, y3=None):
+        """y3: the [M, 3F] activation image of y2d when its producer already wrote it (the attention block's layer norm)."""
         y2d = _rows(y2d, "ffn input")
         W1_0, W2_0 = W1, W2
         W1, W2 = _f32(W1, "W1").contiguous(), _f32(W2, "W2").contiguous()
         lib = _capi.load()
         M, F = y2d.shape
         H = W1.shape[1]
-        y3 = _split_rows(y2d)
+        if y3 is None or tuple(y3.shape) != (M, 3 * F):
+            y3 = _split_rows(y2d)
         w13n, w13k = _split_weight(W1)
         ctx.tiles = bool(FFN_TILES and y2d.stride(1) == 1 and lib._lpm_dense_tiles_supported(M, F, H) and lib._lpm_dense_tiles_supported(M, W2.shape[1], H))
         if ctx.tiles:
@@ -1697,8 +1700,10 @@ class _ResidualLayerNorm(torch.autograd.Function):
     """y = layer_norm(act(a + bias) + r): TF1 joint moments, with the producing dense layer's bias add / ReLU fused in."""
 
     @staticmethod
-    def forward(ctx, a, r, gamma, beta, bias, relu, out=None, r_scale=None):
-        """r_scale [B * L] (block Functions only): r holds the rows of a lazily normalised descriptor, scaled as they are read."""
+    def forward(ctx, a, r, gamma, beta, bias, relu, out=None, r_scale=None, image=False):
+        """r_scale [B * L] (block Functions only): r holds the rows of a lazily normalised descriptor, scaled as they are read.
+        image (block Functions only): y is ALSO written as the [B*L, 3F] bf16 activation image of the dense layer that reads it next
+        and attached to the result as ``y._lpm_y3`` (ops._FFNX3 takes it instead of splitting y again)."""
         lib = _capi.load()
         a = _f32(a, "layer_norm input").contiguous()
         B, L, F = a.shape
@@ -1711,7 +1716,12 @@ class _ResidualLayerNorm(torch.autograd.Function):
         stats = _empty((B, 2), a)
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
-        if r_scale is not None:
+        y3 = torch.empty((B * L, 3 * F), dtype=torch.bfloat16, device=a.device) if image else None
+        if image:
+            lib.check(lib._lpm_layer_norm_act_image_fwd(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(r_scale), ptr(gamma), ptr(beta), B, L,
+                                                        F, LN_EPS, ptr(y), y.stride(0), ptr(y3), ptr(z) if z is not a else None, ptr(stats),
+                                                        ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_image_fwd")
+        elif r_scale is not None:
             lib.check(lib._lpm_layer_norm_act_fwd_rs(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(r_scale), ptr(gamma), ptr(beta), B, L, F,
                                                      LN_EPS, ptr(y), y.stride(0), ptr(z) if z is not a else None, ptr(stats), ptr(ws),
                                                      wsb, stream_ptr()), "lpm_layer_norm_act_fwd_rs")
@@ -1721,6 +1731,8 @@ class _ResidualLayerNorm(torch.autograd.Function):
                                                   stream_ptr()), "lpm_layer_norm_act_fwd")
         ctx.has_r, ctx.relu, ctx.has_bias = r is not None, bool(relu), bias is not None
         ctx.save_for_backward(z, stats, gamma, a if relu else None, bias)
+        if y3 is not None:
+            y._lpm_y3 = y3
         return y
 
     @staticmethod
@@ -1920,7 +1932,8 @@ class _AttnBlockX3(torch.autograd.Function):
         else:
             o = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale)
             att = _DenseX3.forward(co, o.view(B * L, N), Wo)
-        y = _ResidualLayerNorm.forward(cl, att.view(B, L, Wo.shape[1]), x, gamma, beta, bo, False, None, rs)
+        # (the feed-forward block behind this one reads y as a GEMM operand: the layer norm writes that image on its way out)
+        y = _ResidualLayerNorm.forward(cl, att.view(B, L, Wo.shape[1]), x, gamma, beta, bo, False, None, rs, image=LN_IMAGE)
         _pack_subs(ctx, (cq, cm, co, cl))
         ctx.shape = (B, L, F, N)
         return y
@@ -1981,7 +1994,7 @@ class _FFNBlockX3(torch.autograd.Function):
         y = _f32(y, "ffn block input").contiguous()
         B, L, F = y.shape
         cf, c1, c2 = _SubCtx(), _SubCtx(), _SubCtx()
-        pre = _FFNX3.forward(cf, y.view(B * L, F), W1, b1, W2)
+        pre = _FFNX3.forward(cf, y.view(B * L, F), W1, b1, W2, y3=getattr(y, "_lpm_y3", None))
         from . import FLAGS
         if FLAGS.ln_pair_forward:      # three passes for the two layer norms: n itself is never stored
             out = _ln_pair_forward(c1, c2, pre.view(B, L, F), y, g1, be1, b2, g2, be2, out)
