@@ -1273,3 +1273,42 @@ def test_bn_small_one_launch_each_way(M, C, act):
     unb = var.detach() * (M / (M - 1))
     assert_close(mmg, mm.double() * ops.BN_DECAY + mu.detach() * (1 - ops.BN_DECAY), 1e-6, "moving_mean")
     assert_close(mvg, mv.double() * ops.BN_DECAY + unb * (1 - ops.BN_DECAY), 1e-6, "moving_variance")
+
+
+@pytest.mark.parametrize("B,L,F,lazy", [(3, 64, 128, False), (2, 256, 1024, True)])
+def test_layer_norm_image_is_the_split_of_its_output(B, L, F, lazy):
+    """lpm_layer_norm_act_image_fwd: y3 must be bit for bit what lpm_split_rows makes of y (planes [hi | lo | hi]), y itself unchanged."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator(device=dev).manual_seed(F + L)
+    a, r = torch.randn(B, L, F, device=dev, generator=g), torch.randn(B, L, F, device=dev, generator=g)
+    gamma, beta, bias = (torch.randn(F, device=dev, generator=g) for _ in range(3))
+    rs = (torch.rand(B * L, device=dev, generator=g) + 0.5) if lazy else None
+    c0, c1 = ops._SubCtx(), ops._SubCtx()
+    y0 = ops._ResidualLayerNorm.forward(c0, a, r, gamma, beta, bias, False, None, rs)
+    y1 = ops._ResidualLayerNorm.forward(c1, a, r, gamma, beta, bias, False, None, rs, image=True)
+    assert torch.equal(y0, y1)
+    y3 = y1._lpm_y3
+    assert y3.shape == (B * L, 3 * F) and y3.dtype == torch.bfloat16
+    assert torch.equal(y3.view(torch.int16), ops._split_rows(y1.view(B * L, F)).view(torch.int16))
+
+
+@pytest.mark.parametrize("B,L,h,d", [(3, 300, 8, 16), (2, 40, 4, 8)])
+def test_logit_stats_moments(B, L, h, d):
+    """lpm_mha_logit_stats_moments: the same partial statistics as lpm_mha_logit_stats, and the (batch, head) moments of q it hands to the
+    backward: Qm = sum_q q q^T, Sq = sum_q q."""
+    from learnablepoolingmethods_amd import _capi, ops
+    dev = cuda()
+    lib = _capi.load()
+    g = torch.Generator(device=dev).manual_seed(L)
+    F = h * d
+    q, k = torch.randn(B, L, F, device=dev, generator=g), torch.randn(B, L, F, device=dev, generator=g)
+    p0, p1 = (torch.empty(B * h, 2, L, device=dev) for _ in range(2))
+    mo = torch.empty(B * h, d * d + d, device=dev)
+    st = ops.stream_ptr()
+    lib.check(lib._lpm_mha_logit_stats(ops.ptr(q), ops.ptr(k), F, B, L, h, d, ops.ptr(p0), st), "stats")
+    lib.check(lib._lpm_mha_logit_stats_moments(ops.ptr(q), ops.ptr(k), F, B, L, h, d, ops.ptr(p1), ops.ptr(mo), st), "moments")
+    assert torch.equal(p0, p1)
+    qh = q.double().view(B, L, h, d).permute(0, 2, 1, 3).reshape(B * h, L, d)
+    assert_close(mo[:, :d * d].reshape(B * h, d, d), qh.transpose(1, 2) @ qh, 1e-5, "Qm")
+    assert_close(mo[:, d * d:], qh.sum(1), 1e-5, "Sq")
