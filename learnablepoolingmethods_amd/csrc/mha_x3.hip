@@ -399,7 +399,9 @@ __global__ __launch_bounds__(MX_DQ_NT) void mha_bwd_dq_x3_kernel(const float* __
 #define LPM_DKV_NT_LONG 1024
 #endif
 __host__ __device__ constexpr int mx_dkv_nt(int nkt) { return nkt >= 20 ? LPM_DKV_NT_LONG : 512; }
-template <int NKT, bool AFFINE, int D>
+// CORR = false: no correction vectors (the one-pass logits_bn backward's first launch: the batch statistics' share of dk is repaired
+// afterwards) -- two fewer VALU operations per score in a pass whose vector pipe is ~94 % busy (profiles/pmc_r03_mha_bn)
+template <int NKT, bool AFFINE, int D, bool CORR = true>
 __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
                                                              const float* __restrict__ dout, int64_t ldo,
@@ -526,7 +528,8 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
                     if (AFFINE) {
                         zs += dz;
                         zq = fmaf(dz, sraw, zq);
-                        dsv = (qr < L) ? dz * sck - cak - sraw * cbk : 0.f;
+                        if constexpr (CORR) dsv = (qr < L) ? dz * sck - cak - sraw * cbk : 0.f;
+                        else dsv = (qr < L) ? dz * sck : 0.f;
                     }
                     p8[4 * t + r] = pr;
                     ds8[4 * t + r] = dsv;
@@ -782,7 +785,7 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
                                ldd, corr_a, corr_b, img, oimg);                                                        \
         }                                                                                                              \
         if (dk || dz_partial) {                                                                                        \
-            auto kk = mha_bwd_dkv_x3_kernel<N, AFF, DD>;                                                               \
+            auto kk = (AFF && !corr_a) ? mha_bwd_dkv_x3_kernel<N, AFF, DD, false> : mha_bwd_dkv_x3_kernel<N, AFF, DD, true>;          \
             const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                              \
             if (int rc = mx_reserve(kk, lk, what)) return rc;                                                          \
             hipLaunchKernelGGL(kk, grid, dim3(mx_dkv_nt(N)), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, \
