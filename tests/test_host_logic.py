@@ -245,3 +245,17 @@ def test_direct_gradient_slots_in_the_gather_mode_arena():
         assert ops._grad_slot(w) is None                   # the run-time switch sends everything through autograd
     finally:
         ops.DIRECT_WGRAD = old
+
+
+def test_split_vector_hands_back_one_concatenated_gradient():
+    """ops.split_vector (NetVladV1's input_bn gamma / beta halves): the two views carry the right values and their gradients come back
+    as ONE concatenation -- also when only one half was used (the other half's gradient is zero, not missing)."""
+    from learnablepoolingmethods_amd import ops
+    v = torch.arange(10, dtype=torch.float32, requires_grad=True)
+    a, b = ops.split_vector(v, 4)
+    assert torch.equal(a, v[:4]) and torch.equal(b, v[4:])
+    (a * 2).sum().backward(retain_graph=True)
+    assert torch.equal(v.grad, torch.tensor([2.0] * 4 + [0.0] * 6))
+    v.grad = None
+    ((a * 2).sum() + (b * torch.arange(6.0)).sum()).backward()
+    assert torch.equal(v.grad, torch.cat([torch.full((4,), 2.0), torch.arange(6.0)]))
