@@ -258,3 +258,24 @@ def test_combine_clip_and_learning_rate():
     for step, bs, n in ((0, 80, 1), (49999, 80, 1), (50000, 80, 1), (6250, 80, 8), (31250, 80, 8)):
         assert R.learning_rate(2e-4, 0.85, 4000000, step, bs, n) == O.learning_rate(cfg, step, bs, n)
     assert R.learning_rate(2e-4, 0.85, 4000000, 6250, 80, 8) == 2e-4 * 0.85
+
+
+def test_logits_bn_backward_correction_is_affine_in_the_score():
+    """The identity behind lpm_mha_bn_dk_correct: with ds = sck dz - ca - s cb and s = q . k, the share of
+    the two correction terms in dK[j] = sum_q ds[q, j] q is  - ca[j] Sq - cb[j] Qm k[j]  (Sq = sum_q q, Qm = sum_q q q^T), and in
+    dQ[q] = sum_j ds[q, j] k[j] it is  - sum_j ca[j] k[j] - (sum_j cb[j] k[j] k[j]^T) q.  fp64, one (batch, head)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    L, d = 37, 16
+    q, k = rng.normal(size=(L, d)), rng.normal(size=(L, d))
+    dz, sck, ca, cb = rng.normal(size=(L, L)), rng.uniform(0.5, 1.5, L), rng.normal(size=L) * 0.1, rng.normal(size=L) * 0.1
+    s = q @ k.T
+    ds = dz * sck[None, :] - ca[None, :] - s * cb[None, :]
+    dk, dq = ds.T @ q, ds @ k
+    ds0 = dz * sck[None, :]
+    Sq, Qm = q.sum(0), q.T @ q
+    dk_fix = (ds0.T @ q) - ca[:, None] * Sq[None, :] - cb[:, None] * (k @ Qm)
+    assert np.allclose(dk_fix, dk, rtol=1e-12, atol=1e-12)
+    Mk = (k * cb[:, None]).T @ k
+    dq_fix = (ds0 @ k) - (ca[:, None] * k).sum(0)[None, :] - q @ Mk
+    assert np.allclose(dq_fix, dq, rtol=1e-12, atol=1e-12)
