@@ -243,6 +243,14 @@ int lpm_vlad_aggregate_raw_kmajor_fwd(const void* at, const void* xt, const floa
                                       float* raw_kmajor, float* asum, float* colsq_part, lpm_stream_t stream);
 int lpm_vlad_row_scales(const float* colsq_part, int P, int B, int K, float* scale, float* colsq, float* csq, float* gsq,
                         lpm_stream_t stream);
+/* The same function on CLIP-WIDE items (vlad_clip.hip, round 4; K = 256): a workgroup owns all 256 clusters x a third of a clip's
+ * columns (11 / 11 / 10 column tiles at D = 1024), so the frame tiles pass through the LDS-DMA path once and the assignment tiles
+ * three times -- 168 MB per launch at cfg-2 instead of 389 MB, on the path that bounds the 128 x 128 form.  Outputs as
+ * lpm_vlad_aggregate_raw_kmajor_fwd, except colsq_part [B, P, K] with P = lpm_vlad_clip_slabs(D, K) (0: shape not supported);
+ * lpm_vlad_row_scales(colsq_part, P, ...) follows.  Reference: frame_level_models.py:2803-2817. */
+int lpm_vlad_clip_slabs(int D, int K);
+int lpm_vlad_aggregate_clip_kmajor_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                       float* raw_kmajor, float* asum, float* colsq_part, lpm_stream_t stream);
 /* K2 + row scales in ONE launch (vlad_kmajor.hip; frame_level_models.py:2803-2822 for the lazily normalised k-major descriptor):
  * raw_kmajor [B,K,D] un-normalised residual sums, scale [B,K] with descriptor[b,k,:] = raw[b,k,:] * scale[b,k], and asum / colsq /
  * csq [B,K], gsq [B] for the backward.  K = 256: "wide" workgroups (all clusters x 128 columns) for whole rounds of clips, 128 x 128

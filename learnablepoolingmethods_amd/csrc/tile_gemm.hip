@@ -96,8 +96,15 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3) ? 4 : 2) void tile_g
             // plain form: stage s = steps 2 s and 2 s + 1; past an odd end the piece re-reads the last step (its MFMA is skipped)
             const uint4* q = PL == 1 ? src[j] + (int64_t)min(2 * s + sub[j], nred - 1) * sstep[j]
                                      : (second ? src2[j] + (s - nstep1) * sstep2[j] : src[j] + s * sstep[j]);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
-                                             (__attribute__((address_space(3))) void*)(st + (wave + NWV * j) * 1024), 16, 0, 0);
+            // g.nt_load (measurement, LPM_TG_NT): bit 0 = the row-tile (A) pieces, bit 1 = the column-tile (B) pieces take the
+            // non-temporal policy (aux = 2: a stream read once does not displace what the other operand re-reads from L2)
+            const bool is_a = (wave + NWV * j) < NRP;
+            if ((g.nt_load >> (is_a ? 0 : 1)) & 1)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
+                                                 (__attribute__((address_space(3))) void*)(st + (wave + NWV * j) * 1024), 16, 0, 2);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
+                                                 (__attribute__((address_space(3))) void*)(st + (wave + NWV * j) * 1024), 16, 0, 0);
         }
     };
 
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3) ? 4 : 2) void tile_g
         // at the top of step s says: step s + 1 has landed for everyone, everyone holds the fragments of step s in
         // registers, everyone is done with step s - 1 -> stage (s - 1) % NS takes step s + NS - 1.  NS - 2 steps are in
         // flight behind the one being read.  (nstep >= NS is the launcher's condition.)
-        static_assert(NS == 4 || NS == 5, "ring depth of the pipelined 128-row form");
+        static_assert(NS >= 4 && NS <= 6, "ring depth of the pipelined 128-row form");
         struct Frag { tg_u32x4 ah[RTW], al[RTW], bh[NTW], bl[NTW]; };
         auto read_frags = [&](int s, Frag& fr) {
             const tg_u32x4* f = reinterpret_cast<const tg_u32x4*>(smem + (s % NS) * STAGE) + lane;
@@ -215,7 +222,8 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3) ? 4 : 2) void tile_g
         };
         auto body = [&](int s, Frag& cur, Frag& nxt) {
             if (s + 1 < nstep) {                   // step s + 1 must have landed; younger steps issued: min(NS - 3, nstep - 2 - s)
-                if (NS == 5 && s + 3 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+                if (NS >= 6 && s + 4 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PW) : "memory");
+                else if (NS >= 5 && s + 3 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
                 else if (s + 2 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -543,6 +551,7 @@ static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw, i
 
 // allow_wide: 0 = 64-row form, 1 = 128-row form (one workgroup per CU, software-pipelined, 4-stage ring) where the shape allows,
 // 2 = 128-row form with a 3-stage ring and two workgroups per CU, 3 = 256-row form (four row tiles per wave; no statistics)
+constexpr int TG_WIDE_NS_DEFAULT = 4;
 template <int EPI, int PL>
 static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override,
                         int timing_tag, int allow_wide) {
@@ -570,6 +579,8 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
     dim3 grid((unsigned)(wide ? nbatch * g.a_tiles / (wide4 ? 8 : 4) : nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)),
               (unsigned)splits);
     TileGemmArgs gl = g;
+    static const int nt_env = [] { const char* e = getenv("LPM_TG_NT"); return e ? atoi(e) : -1; }();
+    if (nt_env >= 0) gl.nt_load = nt_env;
     if (!wide && g.cols_inner) {
         if (g.stats) { set_error("%s: cols_inner and the statistics epilogue index workgroups differently", what); return LPM_ERR_BADARG; }
         gl.cols_inner = (int)grid.y;
@@ -578,10 +589,12 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
     } else {
         gl.cols_inner = 0;
     }
-    constexpr int WIDE_NS = 4;
+    // ring depth of the pipelined forms (LPM_TG_WIDE_NS / LPM_TG_WIDE4_NS = 4, 5, 6: A/B; NS - 2 steps of LDS-DMA stay in flight)
+    static const int wide_ns = [] { const char* e = getenv("LPM_TG_WIDE_NS"); const int v = e ? atoi(e) : 0; return (v >= 4 && v <= 6) ? v : TG_WIDE_NS_DEFAULT; }();
+    static const int wide4_ns = [] { const char* e = getenv("LPM_TG_WIDE4_NS"); const int v = e ? atoi(e) : 0; return (v >= 4 && v <= 5) ? v : 4; }();
     const bool wide2 = wide && allow_wide == 2;
-    const size_t lds = wide4 ? (size_t)WIDE_NS * (16 + 8 * ntw) * 1024
-                             : (wide ? (size_t)(wide2 ? 3 : WIDE_NS) * (8 + 8 * ntw) * 1024 : tg_lds_bytes(ntw, EPI));
+    const size_t lds = wide4 ? (size_t)wide4_ns * (16 + 8 * ntw) * 1024
+                             : (wide ? (size_t)(wide2 ? 3 : wide_ns) * (8 + 8 * ntw) * 1024 : tg_lds_bytes(ntw, EPI));
 #define LPM_TG_LAUNCH_K(KERN, THREADS)                                                                                 \
     do {                                                                                                               \
         auto kern = KERN;                                                                                              \
@@ -600,9 +613,12 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
     if constexpr (EPI == TG_EPI_ADAM) {
         LPM_TG_LAUNCH(1);
     } else {
-        if (wide4) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS, PL, 4>), 512);
+        if (wide4 && wide4_ns == 5) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 5, PL, 4>), 512);
+        else if (wide4) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL, 4>), 512);
         else if (wide2) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 3, PL>), 512);
-        else if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, WIDE_NS, PL>), 512);
+        else if (wide && wide_ns == 6) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 6, PL>), 512);
+        else if (wide && wide_ns == 5) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 5, PL>), 512);
+        else if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL>), 512);
         else if (ntw == 1) LPM_TG_LAUNCH(1);
         else if (ntw == 2) LPM_TG_LAUNCH(2);
         else LPM_TG_LAUNCH(4);

@@ -30,6 +30,7 @@ __device__ __forceinline__ f32x16 t3_mfma(t3_u32x4 a, t3_u32x4 b, f32x16 c) {
 __device__ __forceinline__ float t3_bf(unsigned h) { return __uint_as_float(h << 16); }
 
 constexpr int T3_NS = 3;                  // ring stages (48 KB: three workgroups per CU)
+constexpr int T3_NT_DEFAULT = 0;          // see t3_nt()
 constexpr int T3_STAGE = 16 * 1024;       // bytes per stage: 4 A tiles + 4 x tiles, 2 planes, 1 KB each
 constexpr int T3_WS = 36;                 // epilogue per-wave tile row stride (floats): 144 B, 16-B aligned
 constexpr int T3_EPI = 8 * 32 * T3_WS * 4;  // epilogue bytes (8 waves x [32 d][32 k + pad]), overlays the ring
@@ -157,7 +158,7 @@ __device__ __forceinline__ void t3_split2(float a, float b, unsigned& hi, unsign
 template <bool FUSED, int PL, bool SMX = false>
 __global__ __launch_bounds__(512, SMX ? 4 : 6) void vlad_aggregate_tiles3_kernel(
     const uint4* __restrict__ at, const uint4* __restrict__ xt, const float* __restrict__ centres, int T, int D, int K,
-    int S, int KT, int residual, float* __restrict__ nrm, float* __restrict__ asum, float* __restrict__ colsq_part, const T3Fused fz,
+    int S, int KT, int resflags, float* __restrict__ nrm, float* __restrict__ asum, float* __restrict__ colsq_part, const T3Fused fz,
     const T3Softmax sm) {
     static_assert(!SMX || PL == 2, "the in-kernel softmax writes split-bf16 fragments");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object (guide 5, trap (a))
@@ -179,16 +180,27 @@ __global__ __launch_bounds__(512, SMX ? 4 : 6) void vlad_aggregate_tiles3_kernel
                                 : xt + (((int64_t)b * S + pplane) * DT + ds * 4 + ptile) * 64 + lane;
     const int adst = (ptile * 2 + pplane) * 1024, xdst = 8192 + (ptile * 2 + pplane) * 1024;
     const int NST = PL == 2 ? S : S / 2;           // ring stages
+    const int residual = resflags & 1;             // bit 0: subtract (sum_t a) * centres; bits 1, 2: LDS-DMA cache policy, see issue()
     const int k0s = kb * 128;                      // first cluster of this workgroup's slab
 
     auto issue = [&](int s) {                 // the pieces of step min(s, NST - 1) into stage s % NS
         unsigned char* st = smem + (s % T3_NS) * T3_STAGE;
         const int sc = SMX ? min(s, NST - 1) : s;
-        if (!SMX)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)sc * 128),
-                                             (__attribute__((address_space(3))) void*)(st + adst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (int64_t)sc * DT * 128),
-                                         (__attribute__((address_space(3))) void*)(st + xdst), 16, 0, 0);
+        // resflags bit 1 / bit 2 (LPM_T3_NT = 1 / 2 / 3): non-temporal policy for the assignment / frame pieces
+        if (!SMX) {
+            if (resflags & 2)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)sc * 128),
+                                                 (__attribute__((address_space(3))) void*)(st + adst), 16, 0, 2);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)sc * 128),
+                                                 (__attribute__((address_space(3))) void*)(st + adst), 16, 0, 0);
+        }
+        if (resflags & 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (int64_t)sc * DT * 128),
+                                             (__attribute__((address_space(3))) void*)(st + xdst), 16, 0, 2);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (int64_t)sc * DT * 128),
+                                             (__attribute__((address_space(3))) void*)(st + xdst), 16, 0, 0);
     };
 
     f32x16 acc[2];
@@ -740,6 +752,13 @@ __global__ __launch_bounds__(256) void vlad_finalize2_kmajor4_kernel(float* __re
 
 }  // namespace lpm
 
+namespace lpm {
+// LDS-DMA cache policy of the aggregation kernel's two streams (bit 0: assignment tiles, bit 1: frame tiles non-temporal)
+static int t3_nt() {
+    static const int v = [] { const char* e = getenv("LPM_T3_NT"); return e ? (atoi(e) & 3) : T3_NT_DEFAULT; }();
+    return v << 1;
+}
+}  // namespace lpm
 extern "C" int lpm_vlad_tiles3_supported(int D, int K) { return (D % 128 == 0 && K % 128 == 0 && D >= 128 && K >= 128) ? 1 : 0; }
 
 static int vlad_aggregate_tiles3_impl(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
@@ -778,10 +797,10 @@ static int vlad_aggregate_tiles3_impl(const void* at, const void* xt, const floa
     hipEvent_t e0, e1;
     if (timing_request(LPM_TIMING_K2, &e0, &e1))
         hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T,
-                              D, K, S, KT, residual, nrm, asum, colsq_part, fz, T3Softmax{});
+                              D, K, S, KT, residual | t3_nt(), nrm, asum, colsq_part, fz, T3Softmax{});
     else
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
-                           residual, nrm, asum, colsq_part, fz, T3Softmax{});
+                           residual | t3_nt(), nrm, asum, colsq_part, fz, T3Softmax{});
     return check_launch("lpm_vlad_aggregate_tiles3_fwd");
 }
 
@@ -845,10 +864,10 @@ extern "C" int lpm_vlad_aggregate_raw_kmajor_fwd(const void* at, const void* xt,
     hipEvent_t e0, e1;
     if (timing_request(LPM_TIMING_K2, &e0, &e1))
         hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T, D, K,
-                              S, KT, residual, (float*)nullptr, asum, colsq_part, fz, T3Softmax{});
+                              S, KT, residual | t3_nt(), (float*)nullptr, asum, colsq_part, fz, T3Softmax{});
     else
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
-                           residual, (float*)nullptr, asum, colsq_part, fz, T3Softmax{});
+                           residual | t3_nt(), (float*)nullptr, asum, colsq_part, fz, T3Softmax{});
     return check_launch("lpm_vlad_aggregate_raw_kmajor_fwd");
 }
 
@@ -896,9 +915,9 @@ extern "C" int lpm_vlad_aggregate_raw_kmajor_smx_fwd(const float* logits, const 
     dim3 grid(B * (K / 128) * (D / 128));
     if (timing_request(LPM_TIMING_K2, &e0, &e1))
         hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, s, e0, e1, 0, (const uint4*)nullptr, (const uint4*)xt, centres, T, D, K, S, KT,
-                              residual, (float*)nullptr, asum, colsq_part, fz, sm);
+                              residual | t3_nt(), (float*)nullptr, asum, colsq_part, fz, sm);
     else
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)nullptr, (const uint4*)xt, centres, T, D, K, S, KT, residual,
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)nullptr, (const uint4*)xt, centres, T, D, K, S, KT, residual | t3_nt(),
                            (float*)nullptr, asum, colsq_part, fz, sm);
     return check_launch("lpm_vlad_aggregate_raw_kmajor_smx_fwd");
 }
@@ -965,9 +984,9 @@ extern "C" int lpm_vlad_aggregate_fused_fwd(const void* at, const void* xt, cons
     hipEvent_t e0, e1;
     if (timing_request(LPM_TIMING_K2, &e0, &e1))
         hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, s, e0, e1, 0, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT,
-                              residual, nrm, asum, part, fz, T3Softmax{});
+                              residual | t3_nt(), nrm, asum, part, fz, T3Softmax{});
     else
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT, residual, nrm, asum,
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)at, (const uint4*)xt, centres, T, D, K, S, KT, residual | t3_nt(), nrm, asum,
                            part, fz, T3Softmax{});
     // follow-up for tiles whose workgroup gave up waiting for its clip (fail flag set; none in practice)
     hipLaunchKernelGGL(vlad_fused_fixup_kernel, grid, dim3(256), 0, s, nrm, part, fail, D, K, fz);

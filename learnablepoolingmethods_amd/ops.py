@@ -63,6 +63,9 @@ VLAD_FUSED_DEBUG_FALLBACK = False     # tests: drive every clip through the fuse
 # workgroup items + the row scales by the clip's last workgroup).  Built and measured in round 3, NOT faster than the two-launch chain
 # lpm_vlad_aggregate_raw_kmajor_fwd + lpm_vlad_row_scales (78 vs 74 us on one box, tools/time_k2_forms.py): off.
 VLAD_KMAJOR_SCALED = os.environ.get("LPM_VLAD_KMAJOR_SCALED", "0") == "1"
+# K2 on clip-wide items (lpm_vlad_aggregate_clip_kmajor_fwd, vlad_clip.hip, round 4; K = 256): all clusters x a third of a clip's
+# columns per workgroup -- 168 MB through the LDS-DMA path instead of 389 MB.  "0": the 128 x 128 form (A/B).
+VLAD_CLIP = os.environ.get("LPM_VLAD_CLIP", "1") != "0"
 # FeedForwardNetwork's first dense layer and its backward on the hand-written 256-row tile GEMM with operand-image epilogues
 # (lpm_dense_tiles_act_image_fwd / lpm_dense_tiles_relu_bwd_image) where the shape allows; 0: library GEMM + separate split passes (A/B).
 FFN_TILES = os.environ.get("LPM_FFN_TILES", "1") != "0"
@@ -527,10 +530,17 @@ def _aggregate_fwd(lib, assign, scale, shift, x, centres, B, T, D, K, flags, kma
                                                                         ptr(ws), wsb, st), "lpm_vlad_aggregate_kmajor_scaled_fwd")
                 raw._lpm_row_scale = rs
                 return raw, raw, asum, colsq, csq, gsq, xt
+            Pc = lib._lpm_vlad_clip_slabs(D, K) if VLAD_CLIP else 0
+            if Pc:
+                P = Pc
             part = _empty((B, P, K), x)
             with _timed("vlad_aggregate_fwd", (B, T, D, K)):
-                lib.check(lib._lpm_vlad_aggregate_raw_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags & LPM_VLAD_RESIDUAL,
-                                                                 ptr(raw), ptr(asum), ptr(part), st), "lpm_vlad_aggregate_raw_kmajor_fwd")
+                if Pc:
+                    lib.check(lib._lpm_vlad_aggregate_clip_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags & LPM_VLAD_RESIDUAL,
+                                                                      ptr(raw), ptr(asum), ptr(part), st), "lpm_vlad_aggregate_clip_kmajor_fwd")
+                else:
+                    lib.check(lib._lpm_vlad_aggregate_raw_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags & LPM_VLAD_RESIDUAL,
+                                                                     ptr(raw), ptr(asum), ptr(part), st), "lpm_vlad_aggregate_raw_kmajor_fwd")
             rs = _empty((B, K), x)
             gsq = _empty((B,), x)
             with _timed("vlad_finalize", (B, D, K)):

@@ -35,3 +35,32 @@ def test_library_flags_produce_no_packed_fp32_instructions(tmp_path):
     # (-Xclang appears twice in NO_PACKED_FP32; the filter above drops every -Xclang, which is what is wanted here)
     asm2 = _device_asm(without, tmp_path, "without_flag.s")
     assert PACKED.search(asm2), "the control compile holds no packed fp32 instruction either: this test cannot see the flag's effect"
+
+
+@pytest.mark.timeout(600)
+def test_clip_wide_aggregation_loop_carries_its_fragments_in_place(tmp_path):
+    """vlad_clip.hip requests the NEXT step's fragments with inline-assembly ds_reads before the loop's back edge and waits for them at
+    the top of the next iteration (hand-counted lgkmcnt).  That is only correct while the compiler keeps every such fragment in the SAME
+    registers at both ends of the back edge: a register copy behind the request reads bits that have not arrived yet (the round-4
+    determinism failure: a v_mov of the next assignment fragment, stale whenever LDS was slower than the copy).  The main loop of every
+    production instantiation must hold no vector register copy and no scratch access."""
+    global SRC
+    keep = SRC
+    try:
+        SRC = os.path.join(_build.CSRC, "vlad_clip.hip")
+        asm = _device_asm(_build.FLAGS, tmp_path, "vlad_clip.s")
+    finally:
+        SRC = keep
+    kernels = re.findall(r"^(_ZN3lpm16vlad_clip_kernelILi\dELi\dELi0EEEvNS_6VCArgsE):[^\n]*\n(.*?)s_endpgm", asm, flags=re.S | re.M)
+    assert len(kernels) >= 2, "production instantiations of vlad_clip_kernel not found in the device assembly"
+    for name, body in kernels:
+        lines = body.splitlines()
+        head = [i for i, l in enumerate(lines) if "Inner Loop Header" in l]
+        assert head, name
+        label = lines[head[0]].split(":")[0].strip()
+        back = [i for i, l in enumerate(lines) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\s*$", l) and i > head[0]]
+        assert back, f"{name}: no back edge to {label}"
+        loop = [l for l in lines[head[0]:back[-1] + 1] if not l.strip().startswith(";")]
+        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == 33, f"{name}: expected the 33 MFMAs of one step in the loop"
+        bad = [l.strip() for l in loop if re.search(r"\b(v_mov_b(32|64)|v_accvgpr_(read|write)\w*|scratch_(load|store)\w*)\b", l)]
+        assert not bad, f"{name}: register copies / scratch traffic inside the main loop: {bad[:6]}"

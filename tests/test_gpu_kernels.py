@@ -632,6 +632,71 @@ def test_kmajor_scaled_aggregation_in_one_launch(B, T, D, K, mode):
     assert_close(raw1.double().cpu() * rs1.double().cpu().unsqueeze(2), want, tol=2e-5, what="scaled descriptor vs fp64")
 
 
+@pytest.mark.parametrize("B,T,D,K,residual", [(80, 300, 1024, 256, True), (5, 300, 1024, 256, False), (3, 47, 256, 256, True),
+                                              (2, 64, 96, 256, True), (7, 33, 1152, 256, True), (4, 16, 384, 256, True)])
+def test_clip_wide_aggregation(B, T, D, K, residual):
+    """lpm_vlad_aggregate_clip_kmajor_fwd (vlad_clip.hip: all 256 clusters x a third of a clip's columns per workgroup, operand roles
+    swapped so that everything per cluster is per lane) + lpm_vlad_row_scales against fp64 (frame_level_models.py:2803-2822) and -- where
+    the 128 x 128 form covers the shape -- against lpm_vlad_aggregate_raw_kmajor_fwd on the same tiles: the same three MFMA terms in the
+    same order over the same frame steps, so the un-normalised sums must be IDENTICAL when there is no residual (the assignment sums
+    are added in another fixed order: last-bit differences with the residual)."""
+    from learnablepoolingmethods_amd import _capi, ops
+    from learnablepoolingmethods_amd.ops import ptr, stream_ptr
+    dev = cuda()
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(B * T + D + 5)
+    x = torch.randn(B * T, D, generator=g)
+    x = x / x.norm(dim=1, keepdim=True)
+    logits = (torch.randn(B * T, K, generator=g) * 3).to(dev)
+    scale = (1 + 0.3 * torch.randn(K, generator=g)).to(dev)
+    shift = (0.2 * torch.randn(K, generator=g)).to(dev)
+    centres = (0.05 * torch.randn(D, K, generator=g)).to(dev)
+    xd = x.to(dev)
+    xt = torch.empty(lib._lpm_xt_bytes(B, T, D) // 4, dtype=torch.int32, device=dev)
+    lib.check(lib._lpm_split_frames(ptr(xd), D, B, T, D, ptr(xt), stream_ptr()), "lpm_split_frames")
+    at = torch.empty(lib._lpm_at_bytes(B, T, K) // 4, dtype=torch.int32, device=dev)
+    lib.check(lib._lpm_assign_tiles(ptr(logits), ptr(scale), ptr(shift), B, T, K, ops.LPM_VLAD_SOFTMAX | ops.LPM_VLAD_RESIDUAL, ptr(at),
+                                    stream_ptr()), "lpm_assign_tiles")
+    fl = ops.LPM_VLAD_RESIDUAL if residual else 0
+    P = lib._lpm_vlad_clip_slabs(D, K)
+    assert P == -(-(D // 32) // 11) and lib._lpm_vlad_clip_slabs(D, 128) == 0 and lib._lpm_vlad_clip_slabs(80, 256) == 0
+    nan = float("nan")
+    for _ in range(2):
+        raw = torch.full((B, K, D), nan, device=dev)
+        asum, part = torch.full((B, K), nan, device=dev), torch.full((B, P, K), nan, device=dev)
+        rs, colsq, csq = (torch.full((B, K), nan, device=dev) for _ in range(3))
+        gsq = torch.full((B,), nan, device=dev)
+        lib.check(lib._lpm_vlad_aggregate_clip_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, fl, ptr(raw), ptr(asum), ptr(part),
+                                                          stream_ptr()), "clip_kmajor")
+        lib.check(lib._lpm_vlad_row_scales(ptr(part), P, B, K, ptr(rs), ptr(colsq), ptr(csq), ptr(gsq), stream_ptr()), "row_scales")
+    torch.cuda.synchronize()
+    for what, t in (("sums", raw), ("assignment sums", asum), ("partial norms", part), ("row scales", rs), ("gsq", gsq)):
+        assert torch.isfinite(t).all(), what
+    z = logits.double().cpu() * scale.double().cpu() + shift.double().cpu()
+    a = torch.softmax(z, dim=1).reshape(B, T, K)
+    U = torch.einsum("btk,btd->bkd", a, x.double().reshape(B, T, D))
+    if residual:
+        U = U - a.sum(1).unsqueeze(2) * centres.double().cpu().t().unsqueeze(0)
+    assert_close(raw, U, tol=2e-5, what="un-normalised sums vs fp64")
+    assert_close(asum, a.sum(1), tol=2e-5, what="assignment sums vs fp64")
+    n = U.pow(2).sum(2)
+    assert_close(colsq, n, tol=2e-5, what="column norms vs fp64")
+    nrm = U / n.clamp_min(1e-12).sqrt().unsqueeze(2)
+    want = nrm / nrm.pow(2).sum((1, 2)).clamp_min(1e-12).sqrt().view(B, 1, 1)
+    assert_close(raw.double().cpu() * rs.double().cpu().unsqueeze(2), want, tol=2e-5, what="scaled descriptor vs fp64")
+    if lib._lpm_vlad_tiles3_supported(D, K):
+        raw0 = torch.full((B, K, D), nan, device=dev)
+        asum0, part0 = torch.empty(B, K, device=dev), torch.empty(B, D // 128, K, device=dev)
+        lib.check(lib._lpm_vlad_aggregate_raw_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, fl, ptr(raw0), ptr(asum0), ptr(part0),
+                                                         stream_ptr()), "raw_kmajor")
+        torch.cuda.synchronize()
+        if residual:
+            assert_close(raw, raw0, tol=2e-6, what="sums vs the 128 x 128 form")
+        else:
+            assert torch.equal(raw, raw0), f"sums differ from the 128 x 128 form (max abs {float((raw - raw0).abs().max()):.3e})"
+        assert_close(asum, asum0, tol=2e-6, what="assignment sums vs the 128 x 128 form")
+
+
 @pytest.mark.parametrize("M,C,relu", [(24000, 4096, True), (1200, 256, True), (777, 128, False), (20000, 1024, False)])
 def test_bias_act_in_place(M, C, relu):
     """ops.bias_act: tf.layers.dense's bias add (+ ReLU) as one in-place pass; backward = ReLU mask from the saved output + the bias

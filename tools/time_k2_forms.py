@@ -1,6 +1,8 @@
 """K2 at cfg-2's video shape (80 x 300 x 1024 x 256), the forms side by side in ONE process, interleaved rounds (guide 5.4 rule 24):
   chain : lpm_vlad_aggregate_raw_kmajor_fwd (128 x 128 items) + lpm_vlad_row_scales         -- two launches
   none / rounds / all : lpm_vlad_aggregate_kmajor_scaled_fwd with no / whole rounds of / all clips as wide (256 x 128) items
+  clip  : lpm_vlad_aggregate_clip_kmajor_fwd (round 4: all clusters x a third of a clip's columns) + lpm_vlad_row_scales
+(K2_FORMS=chain,... restricts the library forms; LPM_VC_DBG ablates the clip form)
 Kernel durations from launch-attached HIP events (the library's timing tags)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,7 +45,21 @@ def one(flag):
     return f
 
 
+Pc = lib._lpm_vlad_clip_slabs(D, K)
+partc = torch.empty(B, max(Pc, 1), K, device=dev)
+
+
+def clip():
+    lib.check(lib._lpm_vlad_aggregate_clip_kmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, ops.LPM_VLAD_RESIDUAL, ptr(raw), ptr(asum),
+                                                      ptr(partc), stream_ptr()), "clip")
+    lib.check(lib._lpm_vlad_row_scales(ptr(partc), Pc, B, K, ptr(rs), ptr(colsq), ptr(csq), ptr(gsq), stream_ptr()), "rs")
+
+
 forms = {"chain": chain, "none": one(_capi.LPM_VLAD_WIDE_NONE), "rounds": one(0), "all": one(_capi.LPM_VLAD_WIDE_ALL)}
+if os.environ.get("K2_FORMS"):
+    forms = {k: v for k, v in forms.items() if k in os.environ["K2_FORMS"].split(",")}
+if Pc:
+    forms["clip"] = clip
 res = {k: [] for k in forms}
 buf = (ctypes.c_float * 64)()
 for rnd in range(12):
