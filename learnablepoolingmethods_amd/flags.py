@@ -78,3 +78,9 @@ FLAGS.define("direct_weight_gradients", True, "build extension: single-GPU train
 FLAGS.define("hidden1_factored_max_towers", 4, "build extension: ... up to this many towers.  Both passes of the factored update multiply "
              "over ALL towers' clips (R = 80 N at cfg-2: 0.72 ms at N = 1, 0.94 / 1.2 / 1.73 ms at N = 2 / 4 / 8 measured with "
              "tools/time_factored.py) where the generic route costs 0.88 ms of kernels plus a 554 MB all-reduce under the backward")
+FLAGS.define("hidden1_sharded_update", True, "build extension (data parallel, route C of DESIGN.md section 6): beyond hidden1_factored_max_towers "
+             "towers hidden1_weights' gradient is reduce-scattered instead of all-reduced, every rank clips (one-float all-reduce of "
+             "the shard norms) and Adam-updates its 1/N shard, and the updated shards are all-gathered under the next forward (waited "
+             "for where the projection reads the variable).  False: route A (bucket all-reduce + full update on every rank)")
+FLAGS.define("hidden1_sharded_min_towers", 0, "build extension: 0 = the sharded route starts right above hidden1_factored_max_towers; "
+             "N > 0 = from N towers on, taking precedence over the factored route (tests, A/B on a real node)")

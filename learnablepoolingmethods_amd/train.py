@@ -212,6 +212,120 @@ class GradientSynchronizer:
         self.pending, self.done = [], set()
 
 
+class ShardedVariableUpdate:
+    """Route C of DESIGN.md section 6 for ONE large variable (hidden1_weights, 85 % of the parameters): ZeRO-1 over the towers.
+
+    utils.combine_gradients SUMs the towers' gradients (utils.py:207-211), clip_gradient_norms clips the summed gradient of every
+    variable to L2 norm ``clip`` (:181-188), Adam applies it (train.py:330-336).  For this variable the sum is a REDUCE-SCATTER of its
+    slice of the gradient arena -- every rank receives the summed gradient of its 1/N shard, half the bytes of an all-reduce on the
+    critical path --, the variable's norm is the one-double all-reduce of the shards' sums of squares, every rank runs clip + Adam on
+    its shard only (1/N of the optimiser's HBM traffic), and the updated shards are ALL-GATHERed into every rank's parameter arena
+    asynchronously: the next step's forward waits for them where it first reads the variable (VariableStore.pending), i.e. the
+    gather rides under frame preparation, pooling and the encoders.  Every rank ends a step with bit-identical parameters by
+    construction: each shard is computed once, by its owner.  Adam moments exist on the owner only (``gather_moments`` before a
+    checkpoint).  Works on any torch.distributed backend (RCCL on the GPU box, gloo in the CPU tests)."""
+
+    def __init__(self, arena: ParameterArena, name: str, group=None, adam_fn=None):
+        self.arena, self.name, self.group = arena, name, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        a0, a1 = arena.segment(name)
+        if not self.supported(arena, name, self.world):
+            raise ValueError(f"{name}: its arena segment of {a1 - a0} floats does not divide into {self.world} chunk-aligned shards")
+        self.a0, self.a1 = a0, a1
+        self.shard = (a1 - a0) // self.world
+        self.lo = a0 + self.rank * self.shard
+        self.hi = self.lo + self.shard
+        self.gshard = torch.zeros(self.shard, dtype=torch.float32, device=arena.device)      # the summed gradient of the shard
+        self.adam_fn = adam_fn                   # (p, g, m, v, lr, step) -> None, in place; None: ops.clip_adam_step
+        self._rs = None
+        self._ag = None
+        self._ag_src = None
+        self._scratch = None
+        self._offsets = torch.tensor([0, self.shard], dtype=torch.int64, device=arena.device)
+        self.launched = False
+        self.last_norm = None                    # 0-dim tensor: the variable's gradient norm of the latest step (diagnostics, tests)
+        self.keep_summed = False                 # tests: keep a copy of the shard's summed, un-clipped gradient (``summed_shard``)
+        self.summed_shard = None
+        # gloo has no reduce-scatter for device tensors (the shared-GPU debug mode): there the same sum arrives as an all-reduce of the
+        # segment of which this rank keeps its shard -- decided from the backend, i.e. identically on every rank
+        self._native_rs = not (dist.get_backend(group) == "gloo" and arena.device.type != "cpu")
+
+    @staticmethod
+    def supported(arena: ParameterArena, name: str, world: int) -> bool:
+        """Shards must be whole optimiser chunks (ARENA_ALIGN floats) and equal: the collective's input is exactly the segment."""
+        if name not in arena.views or world < 2:
+            return False
+        a0, a1 = arena.segment(name)
+        return (a1 - a0) % (world * ARENA_ALIGN) == 0
+
+    def launch(self):
+        """The variable's gradient is complete in the arena: start the reduce-scatter (called by the gradient's producer through
+        ParameterArena.mark_direct, or by the trainer after backward when no producer ran)."""
+        if self.launched:
+            return
+        self.launched = True
+        seg = self.arena.grad[self.a0:self.a1]
+        _note(f"reduce_scatter(SUM) of {self.name}'s gradient = arena[{self.a0}:{self.a1}] ({4 * (self.a1 - self.a0) >> 20} MiB) into "
+              f"{self.world} shards: launching")
+        if self._native_rs:
+            self._rs = dist.reduce_scatter_tensor(self.gshard, seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._rs = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        _note(f"reduce_scatter(SUM) of {self.name}'s gradient: launched, not yet waited for")
+
+    def step(self, clip: float, lr: float, global_step: int):
+        """clip_by_norm + Adam on this rank's shard, then the parameter all-gather (left in flight: ``wait_parameters``)."""
+        a = self.arena
+        self.wait_parameters()                   # (a step without a forward in between: never in the trainer)
+        if not self.launched:
+            self.launch()
+        _note(f"reduce_scatter(SUM) of {self.name}'s gradient: waiting for completion")
+        self._rs.wait()
+        self._rs = None
+        self.launched = False
+        if not self._native_rs:
+            self.gshard.copy_(a.grad[self.lo:self.hi])
+        g = self.gshard
+        if self.keep_summed:
+            self.summed_shard = g.clone()
+        ss = torch.linalg.vector_norm(g, dtype=torch.float64).square().reshape(1)        # this shard's share of ||g||^2
+        _note(f"all_reduce(SUM) of {self.name}'s shard norms (one double)")
+        dist.all_reduce(ss, op=dist.ReduceOp.SUM, group=self.group)                       # identical on every rank
+        norm = ss.sqrt()
+        self.last_norm = norm[0]
+        if clip and clip > 0:                                                             # utils.py:181-188: g * clip / max(norm, clip)
+            g.mul_((clip / torch.clamp(norm, min=clip)).to(torch.float32)[0])
+        p, m, v = a.param[self.lo:self.hi], a.m[self.lo:self.hi], a.v[self.lo:self.hi]
+        if self.adam_fn is not None:
+            self.adam_fn(p, g, m, v, lr, global_step)
+        else:
+            from . import ops
+            # (clip_norm 0: the shard is clipped already -- the kernel's own norm would be the shard's, not the variable's)
+            self._scratch = ops.clip_adam_step(p, g, m, v, self._offsets, 1, 0.0, lr, global_step, scratch=self._scratch)
+        # the updated shard goes out from a private copy: the destination is the whole segment, this rank's shard included
+        self._ag_src = p.clone()
+        _note(f"all_gather of {self.name}'s updated parameter shards ({4 * self.shard >> 20} MiB each): launching")
+        self._ag = dist.all_gather_into_tensor(a.param[self.a0:self.a1], self._ag_src, group=self.group, async_op=True)
+        _note(f"all_gather of {self.name}'s updated parameter shards: launched, waited for by the next read of the variable")
+
+    def wait_parameters(self):
+        if self._ag is not None:
+            _note(f"all_gather of {self.name}'s updated parameter shards: waiting for completion")
+            self._ag.wait()
+            _note(f"all_gather of {self.name}'s updated parameter shards: complete")
+            self._ag = self._ag_src = None
+
+    def gather_moments(self):
+        """A collective (every rank calls it): every rank receives the owners' Adam moments of the variable -- before a checkpoint
+        that must hold them in full (Trainer.state_dict(sync=True))."""
+        a = self.arena
+        for arr, what in ((a.m, "Adam m"), (a.v, "Adam v")):
+            src = arr[self.lo:self.hi].clone()
+            _note(f"all_gather of {self.name}'s {what} shards (ShardedVariableUpdate.gather_moments)")
+            dist.all_gather_into_tensor(arr[self.a0:self.a1], src, group=self.group)
+
+
 def dp_bucket_of(name: str) -> int:
     """All-reduce buckets in the order backward completes them: 1 head (MoE, gating, hidden1_bn) -> 0 hidden1_weights ->
     2 encoders -> 3 NetVLAD pooling + input_bn.  (0 comes first in the arena: the optimiser kernel wants it chunk-aligned
@@ -302,6 +416,7 @@ class Trainer:
         self.sync: Optional[GradientSynchronizer] = None
         self.bucket_gather = None
         self.factored = None
+        self.sharded: Optional[ShardedVariableUpdate] = None
 
     @property
     def num_towers(self) -> int:
@@ -368,21 +483,41 @@ class Trainer:
         early = (lambda: self.sync.launch(0)) if self.sync.active else None
         h1 = "tower/hidden1_weights"
         self.factored = None
-        want_factored = (self.device.type == "cuda" and FLAGS.hidden1_factored_update
+        self.sharded = None
+        # beyond hidden1_factored_max_towers (or from hidden1_sharded_min_towers on): route C, the sharded update
+        shard_from = FLAGS.hidden1_sharded_min_towers or (FLAGS.hidden1_factored_max_towers + 1)
+        want_sharded = (self.sync.active and FLAGS.hidden1_sharded_update and self.num_towers >= shard_from
+                        and h1 in self.arena.views and self.arena.names[0] == h1
+                        and ShardedVariableUpdate.supported(self.arena, h1, self.num_towers))
+        want_factored = (self.device.type == "cuda" and FLAGS.hidden1_factored_update and not want_sharded
                          and self.num_towers <= FLAGS.hidden1_factored_max_towers
                          and h1 in self.arena.views and self.arena.names[0] == h1
                          and self.arena.views[h1].dim() == 2 and self.arena.views[h1].shape[1] % 32 == 0)
         if self.sync.active:
-            # The route of hidden1_weights' gradient selects between two different collectives, so it is decided ONCE, here, from
+            # The route of hidden1_weights' gradient selects between different collectives, so it is decided ONCE, here, from
             # the per-rank batch size every rank was built with, and agreed across ranks: factored only if every rank wants it and
-            # all ranks hold the same 16-multiple of clips.  (Single rank: a step that does not fit falls back by itself.)
+            # all ranks hold the same 16-multiple of clips; sharded only if every rank wants it.  (Single rank: a step that does not
+            # fit falls back by itself.)
             b = int(model_input_raw.shape[0])
-            flag = torch.tensor([1 if (want_factored and b % 16 == 0) else 0, b, -b], dtype=torch.int64, device=self.device)
+            flag = torch.tensor([1 if (want_factored and b % 16 == 0) else 0, b, -b, 1 if want_sharded else 0], dtype=torch.int64,
+                                device=self.device)
             _note("all_reduce(MIN) of the hidden1 gradient-route agreement (Trainer.build)")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             lo, hi = int(flag[1]), -int(flag[2])
             want_factored = bool(flag[0]) and lo == hi
-        if want_factored:
+            want_sharded = bool(flag[3])
+        if want_sharded:
+            # the projection's backward writes the gradient into the arena and starts the reduce-scatter from its callback; the
+            # projection's forward of the NEXT step waits for the parameter all-gather (VariableStore.pending)
+            self.sharded = ShardedVariableUpdate(self.arena, h1, self.group)
+            n1 = self.arena.offsets_host[1]
+            self._tail_offsets = (self.arena.offsets[1:] - n1).contiguous()
+            self._tail_scratch = None
+            if self.device.type == "cuda":
+                self.arena.mark_direct(h1, on_ready=self._sharded_ready)
+            else:
+                self.arena.views[h1].register_post_accumulate_grad_hook(lambda p: self._sharded_ready())
+        elif want_factored:
             # hidden1_weights' gradient is consumed as the product it is (ops.FactoredGradient, lpm_factored_clip_adam): the towers
             # exchange its two skinny factors instead of all-reducing the gradient, which is never written
             self.factored = ops.FactoredGradient(on_put=self._factored_put, strict=self.sync.active)
@@ -391,7 +526,7 @@ class Trainer:
             self._tail_offsets = (self.arena.offsets[1:] - n1).contiguous()
             self._factored_scratch = self._tail_scratch = None
             self._factored_work = []
-        elif self.device.type == "cuda":
+        elif self.device.type == "cuda" and h1 in self.arena.views:
             self.arena.mark_direct("tower/hidden1_weights", on_ready=early)
         if self.device.type == "cuda" and not self.sync.active and FLAGS.direct_weight_gradients:
             # single GPU: the encoders' dense kernels receive their gradients straight from the split-K sums of their weight-gradient
@@ -402,8 +537,12 @@ class Trainer:
                 moe = n in ("tower/gates/weights", "tower/experts/weights")          # ops.linear_direct (video_level_models.MoeModel)
                 if (enc or moe) and self.arena.views[n].dim() == 2 and n not in {d[0] for d in self.arena.direct}:
                     self.arena.mark_direct(n)
-        elif early is not None:
-            self.arena.views["tower/hidden1_weights"].register_post_accumulate_grad_hook(lambda p: early())
+        if (early is not None and self.sharded is None and self.factored is None and self.device.type != "cuda"
+                and h1 in self.arena.views):
+            # in-place arenas (CPU / gloo): bucket 0 leaves from the variable's post-accumulate hook.  (On the GPU the projection's
+            # callback -- mark_direct's on_ready -- or the factor gather does it; a second launcher here would fire before the
+            # accumulate of a weight used twice: ADVICE r3.)
+            self.arena.views[h1].register_post_accumulate_grad_hook(lambda p: early())
         # the head and encoder buckets are gathered + all-reduced from hooks as backward completes them
         import os
         early_buckets = [int(b) for b in os.environ.get("LPM_DP_EARLY_BUCKETS", "1,2").split(",") if b != ""]
@@ -460,11 +599,23 @@ class Trainer:
         if factored:
             skip.add(self.arena.names[0])
         self.arena.collect(skip=skip)
+        if self.sharded is not None:
+            self._sharded_ready()             # (no-op when the projection's backward started the reduce-scatter already)
         self.sync.finish()                                                                      # utils.combine_gradients :330
         lr = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers,
                            self.lr_decay_examples, self.lr_decay)                               # :244-249
         self.global_step += 1
-        if factored:
+        if self.sharded is not None:
+            # route C: every other variable as usual, hidden1_weights on this rank's shard; its parameter all-gather stays in flight
+            # until the next read of the variable (the projection of the next forward, a checkpoint, predict())
+            a = self.arena
+            n1 = a.offsets_host[1]
+            if len(a.names) > 1:
+                self._tail_scratch = ops.clip_adam_step(a.param[n1:], a.grad[n1:], a.m[n1:], a.v[n1:], self._tail_offsets,
+                                                        len(a.names) - 1, self.clip, lr, self.global_step, scratch=self._tail_scratch)
+            self.sharded.step(self.clip, lr, self.global_step)                                  # :332-336 for hidden1_weights
+            self.store.pending[a.names[0]] = self.sharded.wait_parameters
+        elif factored:
             self._factored_finish()
             a = self.arena
             n1, k = a.offsets_host[1], a.views[a.names[0]].numel()
@@ -489,6 +640,11 @@ class Trainer:
             return self.factored.materialise().view(t.shape)
         a0, _ = self.arena.segment(name)
         return self.arena.grad[a0:a0 + t.numel()].view(t.shape)
+
+    def _sharded_ready(self):
+        """hidden1_weights' gradient is complete in the arena (called from the projection's backward, and again after backward)."""
+        self.sharded.launch()
+        self.sync.done.add(0)                 # bucket 0 is this variable: nothing left for the bucket all-reduce
 
     def _factored_put(self, fg):
         """Called inside backward when the projection has handed over its two gradient factors.  Data parallel: the towers' tile
@@ -531,6 +687,11 @@ class Trainer:
             raise RuntimeError("state_dict() needs a built trainer: run build() or one step first")
         if sync:
             self.sync_moving_statistics()
+        if self.sharded is not None:
+            self.sharded.wait_parameters()    # (this rank's own handle: no collective is entered)
+            self.store.pending.pop(self.arena.names[0], None)
+            if sync:
+                self.sharded.gather_moments()
         out: Dict[str, object] = {n: v.detach().clone().cpu() for n, v in self.store.vars.items()}
         for n in self.arena.names:
             a0, _ = self.arena.segment(n)
@@ -539,6 +700,13 @@ class Trainer:
             out[n + "/Adam"] = self.arena.m[a0:a0 + k].view(shape).clone().cpu()
             out[n + "/Adam_1"] = self.arena.v[a0:a0 + k].view(shape).clone().cpu()
         out["global_step"] = int(self.global_step)
+        if self.sync is not None and self.sync.active and not sync:
+            # a chief-only save: this rank's own moving statistics (the towers' mean needs sync_moving_statistics() on every rank
+            # first) and, on the sharded route, Adam moments of hidden1_weights for this rank's shard only -- recorded, not hidden
+            out["bn_statistics_synced"] = False
+            if self.sharded is not None:
+                out["hidden1_adam_shard"] = {"rank": self.sharded.rank, "towers": self.sharded.world,
+                                             "floats": [self.sharded.lo - self.sharded.a0, self.sharded.hi - self.sharded.a0]}
         return out
 
     def sync_moving_statistics(self):
@@ -567,6 +735,9 @@ class Trainer:
     def load_state_dict(self, state: Dict[str, object]):
         if self.arena is None:
             raise RuntimeError("load_state_dict() needs a built trainer: run build() first")
+        if self.sharded is not None:
+            self.sharded.wait_parameters()
+            self.store.pending.pop(self.arena.names[0], None)
         with torch.no_grad():
             self.store.load({n: v for n, v in state.items() if n in self.store.vars}, strict=False)
             for v in self.store.vars.values():         # restored weights: the min |gamma| watch decides afresh, synchronously

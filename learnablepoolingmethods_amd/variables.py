@@ -30,6 +30,10 @@ class VariableStore:
         # tf.summary.histogram stand-in (frame_level_models.py:2780,2799; train.py:260,285): None = summaries off (nothing is
         # kept alive); a dict collects the named intermediate tensors of the next forward (detached)
         self.summaries: Optional[Dict[str, torch.Tensor]] = None
+        # name -> callable run (once) by the next ``get_variable`` of that name, before the tensor is handed out: the data-parallel
+        # trainer parks the wait for a parameter all-gather here (train.ShardedVariableUpdate), so that the collective rides under
+        # the part of the next forward that does not read the variable
+        self.pending: Dict[str, Callable] = {}
 
     # -- scopes ---------------------------------------------------------------------------------
     @contextlib.contextmanager
@@ -53,6 +57,10 @@ class VariableStore:
     def get_variable(self, name: str, shape, initializer: Callable, trainable: bool = True, device=None) -> torch.Tensor:
         full = self.full_name(name)
         if full in self.vars:
+            if self.pending:
+                cb = self.pending.pop(full, None)
+                if cb is not None:
+                    cb()
             v = self.vars[full]
             if tuple(v.shape) != tuple(shape):
                 raise ValueError(f"variable {full}: shape {tuple(v.shape)} != requested {tuple(shape)}")

@@ -19,7 +19,8 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     out_dir, side = sys.argv[1], sys.argv[2] == "1"
-    factored = len(sys.argv) < 4 or sys.argv[3] == "1"
+    route = sys.argv[3] if len(sys.argv) >= 4 else "1"       # "1": factored, "0": generic (bucket all-reduce), "sharded": route C
+    factored = route == "1"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("LPM_DP_BACKEND", "gloo")
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)) if backend == "nccl" else 0)
@@ -36,6 +37,8 @@ def main():
     FLAGS.moe_l2 = c["moe_l2"]
     FLAGS.audio_side_stream = side
     FLAGS.hidden1_factored_update = factored
+    if route == "sharded":
+        FLAGS.hidden1_sharded_min_towers = 2            # (the default starts above hidden1_factored_max_towers = 4 towers)
     per = inp["per_tower"]
     sl = slice(rank * per, (rank + 1) * per)
     x, nf, lab = inp["x"][sl], inp["nf"][sl], inp["lab"][sl]
@@ -45,6 +48,9 @@ def main():
                  model_kwargs=dict(iterations=c["iterations"], cluster_size=c["cluster_size"], hidden_size=c["hidden_size"]))
     tr.build(x, nf, lab)
     assert tr.sync.active and tr.num_towers == world
+    assert (tr.sharded is not None) == (route == "sharded"), "the route of hidden1_weights' gradient is not the requested one"
+    if tr.sharded is not None:
+        tr.sharded.keep_summed = True
     res = {"early_buckets": tr.bucket_gather.early if tr.bucket_gather is not None else [], "steps": []}
     if rank == 0:                                       # only rank 0 gets the oracle's weights: the others must receive them
         tr.store.load({"tower/" + k: v for k, v in inp["params"].items()})
@@ -54,6 +60,8 @@ def main():
             dist.broadcast(v, src=0)
     names = list(tr.arena.names)
     for s in range(inp["steps"]):
+        if tr.sharded is not None:
+            tr.sharded.wait_parameters()                # (read below past get_variable: the parameter all-gather of the previous step)
         before = {n: tr.store.vars[n].detach().double().cpu() for n in names}
         o = tr.step(x, nf, lab)
         torch.cuda.synchronize()
@@ -64,12 +72,20 @@ def main():
             assert tr.factored.R == world * per, (tr.factored.R, world, per)
         for n in names:
             grads[n] = tr.gradient(n).double().cpu()
+        if tr.sharded is not None:
+            # the summed gradient of hidden1_weights exists shard by shard only: put the ranks' shards together (and their Adam moments)
+            sh = tr.sharded
+            parts = [torch.empty_like(sh.summed_shard) for _ in range(world)]
+            dist.all_gather(parts, sh.summed_shard)
+            t = tr.arena.views[names[0]]
+            grads[names[0]] = torch.cat(parts)[:t.numel()].view(t.shape).double().cpu()
+            sh.gather_moments()
         slots = {}
         for n in names:
             a0, _ = tr.arena.segment(n)
             k, shape = tr.arena.views[n].numel(), tr.arena.views[n].shape
             slots[n] = (tr.arena.m[a0:a0 + k].reshape(shape).double().cpu(), tr.arena.v[a0:a0 + k].reshape(shape).double().cpu())
-        res["steps"].append(dict(factored=used, loss=o["loss"].double().cpu(), predictions=o["predictions"].double().cpu(), lr=o["learning_rate"],
+        res["steps"].append(dict(factored=used, sharded=tr.sharded is not None, loss=o["loss"].double().cpu(), predictions=o["predictions"].double().cpu(), lr=o["learning_rate"],
                                  summed=grads, before=before, adam=slots,
                                  gathered=sorted(tr.bucket_gather.gathered) if tr.bucket_gather is not None else []))
     res["local_stats"] = {n: v.detach().double().cpu() for n, v in tr.store.vars.items() if not tr.store.trainable[n]}

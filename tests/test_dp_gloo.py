@@ -250,3 +250,141 @@ def test_moving_statistics_are_averaged_over_ranks_at_checkpoint():
     for r in range(world):
         assert torch.allclose(torch.from_numpy(res[r]["tower/input_bn/moving_mean"]), 1.5 * torch.arange(5.0))
         assert torch.allclose(torch.from_numpy(res[r]["tower/input_bn/moving_variance"]), torch.full((5,), 2.0))
+
+
+# ---- route C: the sharded update of hidden1_weights (train.ShardedVariableUpdate) on gloo ------------------------------------------
+_SHARD_CLIP = 0.05          # well below the gradient norms of the toy problem: the clip factor (one norm over ALL shards) matters
+
+
+def _adam_inplace(p, g, m, v, lr, step):
+    """oracle.adam_tf_update (tf.train.AdamOptimizer, train.py:252,336) on arena slices, in place."""
+    with torch.no_grad():
+        pn, mn, vn = O.adam_tf_update(p, g, m, v, lr, step)
+        p.copy_(pn), m.copy_(mn), v.copy_(vn)
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from learnablepoolingmethods_amd import train
+    from learnablepoolingmethods_amd import variables as vs
+    F = 64 * world                                     # hidden1_weights: 4096 * world floats = `world` one-chunk shards
+    store = vs.VariableStore(device="cpu", seed=rank)  # ranks start DIFFERENT
+    with vs.use_store(store), vs.variable_scope("tower"):
+        vs.get_variable("hidden1_biases", [64], vs.random_normal_initializer(0.1))
+        vs.get_variable("hidden1_weights", [F, 64], vs.random_normal_initializer(0.3))
+        with vs.variable_scope("gates"):
+            vs.get_variable("weights", [64, 4], vs.random_normal_initializer(0.3))
+    h1 = "tower/hidden1_weights"
+    arena = train.ParameterArena(store, first=[h1])
+    a0, a1 = arena.segment(h1)
+    assert train.ShardedVariableUpdate.supported(arena, h1, world) and not train.ShardedVariableUpdate.supported(arena, "tower/hidden1_biases", world)
+    sync = train.GradientSynchronizer(arena.grad, [(a0, a1), (a1, arena.total)])
+    sh = train.ShardedVariableUpdate(arena, h1, adam_fn=_adam_inplace)
+    fired = []
+
+    def ready(_p):
+        fired.append(1)
+        sh.launch()
+        sync.done.add(0)
+    arena.views[h1].register_post_accumulate_grad_hook(ready)
+    dist.broadcast(arena.param, src=0)
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(2 * world, F, generator=g), torch.rand(2 * world, 4, generator=g)
+    sl = slice(2 * rank, 2 * rank + 2)
+    tail = [n for n in arena.names if n != h1]
+    waited = []
+    for step in (1, 2):
+        arena.zero_grad()
+        with vs.use_store(store), vs.variable_scope("tower"):          # the forward fetches the variable: the parked wait runs here
+            had = h1 in store.pending
+            W = vs.get_variable("hidden1_weights", [F, 64], None)
+            waited.append((had, h1 in store.pending, sh._ag is None))
+        v = dict(arena.views)
+        v[h1] = W
+        _toy_loss(v, X[sl], Y[sl]).backward()
+        sync.finish()                                                    # the other variables: bucket all-reduce (SUM)
+        for n in tail:                                                   # ... clip + Adam on every rank (utils.py:181-188)
+            b0, _ = arena.segment(n)
+            k = arena.views[n].numel()
+            gsum = arena.grad[b0:b0 + k]
+            gc = O.clip_gradient_norms({n: gsum.clone()}, _SHARD_CLIP)[n]
+            _adam_inplace(arena.param[b0:b0 + k], gc, arena.m[b0:b0 + k], arena.v[b0:b0 + k], 1e-2, step)
+        sh.step(_SHARD_CLIP, 1e-2, step)
+        assert sh._ag is not None, "the parameter all-gather stays in flight behind step()"
+        store.pending[h1] = sh.wait_parameters
+    sh.wait_parameters()
+    own = (sh.lo - a0, sh.hi - a0)
+    m_own = arena.m[sh.lo:sh.hi].clone()
+    others_zero = bool((arena.m[a0:sh.lo] == 0).all() and (arena.m[sh.hi:a1] == 0).all())     # moments exist on the owner only ...
+    sh.gather_moments()                                                                         # ... until they are gathered
+    out = {n: (arena.views[n].detach().numpy().copy(), arena.m[arena.segment(n)[0]:arena.segment(n)[0] + arena.views[n].numel()].numpy().copy(),
+               arena.v[arena.segment(n)[0]:arena.segment(n)[0] + arena.views[n].numel()].numpy().copy()) for n in arena.names}
+    q.put((rank, out, len(fired), waited, others_zero, own, float(sh.last_norm), bool(torch.equal(arena.m[sh.lo:sh.hi], m_own))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_update_of_hidden1_matches_the_tower_combine(world):
+    """Route C (train.ShardedVariableUpdate; the default for hidden1_weights beyond four towers): reduce-scatter of the gradient
+    segment, ONE norm over all shards (all-reduced sum of squares), clip + Adam on the owner's shard, parameter all-gather left in
+    flight and waited for by the next fetch of the variable -- against utils.combine_gradients + clip_gradient_norms +
+    AdamOptimizer over the towers' gradients as the oracle restates them (utils.py:170-213, train.py:330-336), two steps.  Every
+    rank must end with the SAME bits."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=200)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        out, fired, waited, others_zero, own, norm, own_kept = res[r]
+        assert fired == 2, "the gradient's hook starts the reduce-scatter once per step"
+        assert waited == [(False, False, True), (True, False, True)], waited    # step 2's fetch ran the parked wait; nothing left in flight
+        assert others_zero and own_kept, "Adam moments live on the shard's owner until gather_moments()"
+        assert own == (4096 * r, 4096 * (r + 1))
+        for n in out:
+            for i in range(3):
+                assert (out[n][i] == res[0][0][n][i]).all(), f"rank {r} differs from rank 0 on {n} ({('param', 'Adam m', 'Adam v')[i]})"
+    # the oracle: per-tower gradients on the same shards, SUM, per-variable clip, Adam -- two steps from rank 0's start weights
+    F = 64 * world
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(2 * world, F, generator=g), torch.rand(2 * world, 4, generator=g)
+    import learnablepoolingmethods_amd.variables as vs
+    store = vs.VariableStore(device="cpu", seed=0)
+    with vs.use_store(store), vs.variable_scope("tower"):
+        vs.get_variable("hidden1_biases", [64], vs.random_normal_initializer(0.1))
+        vs.get_variable("hidden1_weights", [F, 64], vs.random_normal_initializer(0.3))
+        with vs.variable_scope("gates"):
+            vs.get_variable("weights", [64, 4], vs.random_normal_initializer(0.3))
+    p = {n: v.detach().clone() for n, v in store.vars.items()}
+    m = {n: torch.zeros_like(v) for n, v in p.items()}
+    v_ = {n: torch.zeros_like(v) for n, v in p.items()}
+    norms = []
+    for step in (1, 2):
+        tower = []
+        for r in range(world):
+            leaf = {n: t.clone().requires_grad_(True) for n, t in p.items()}
+            _toy_loss(leaf, X[2 * r:2 * r + 2], Y[2 * r:2 * r + 2]).backward()
+            tower.append({n: t.grad for n, t in leaf.items()})
+        summed = O.combine_gradients(tower)
+        norms.append(float(summed["tower/hidden1_weights"].norm()))
+        clipped = O.clip_gradient_norms(summed, _SHARD_CLIP)
+        for n in p:
+            p[n], m[n], v_[n] = O.adam_tf_update(p[n], clipped[n], m[n], v_[n], 1e-2, step)
+    assert norms[1] > 4 * _SHARD_CLIP, "the clip must be active for this test to see the norm"
+    assert abs(res[0][5] - norms[1]) <= 1e-5 * norms[1]
+    got = res[0][0]
+    for n in p:
+        assert torch.allclose(torch.from_numpy(got[n][0]), p[n], rtol=2e-5, atol=1e-7), n
+        assert torch.allclose(torch.from_numpy(got[n][1]).view(m[n].shape), m[n], rtol=2e-5, atol=1e-9), n + " (Adam m)"
+        assert torch.allclose(torch.from_numpy(got[n][2]).view(m[n].shape), v_[n], rtol=2e-5, atol=1e-12), n + " (Adam v)"

@@ -37,7 +37,7 @@ def _free_port():
     return p
 
 
-def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420, factored=True, backend="gloo"):
+def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420, factored=True, backend="gloo", route=None):
     cfg = case["cfg"]
     torch.save(dict(cfg=dict(cfg.__dict__), x=case["x"], nf=case["nf"], lab=case["lab"], params=case["params"],
                     per_tower=case["per_tower"], steps=case["steps"]), tmp_path / "inputs.pt")
@@ -47,7 +47,7 @@ def _run_ranks(case, tmp_path, side_stream, world=2, timeout=420, factored=True,
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LPM_SHARE_GPU="0" if backend == "nccl" else "1", LPM_DP_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_trainer_worker.py"), str(tmp_path),
-                                       "1" if side_stream else "0", "1" if factored else "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                                       "1" if side_stream else "0", route or ("1" if factored else "0")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     try:
         for p in procs:
@@ -141,6 +141,20 @@ def test_two_ranks_of_the_real_trainer_match_the_two_tower_oracle(name, side, fa
     ranks = _run_ranks(case, tmp_path, side, factored=factored)
     worst = _check(case, ref, ranks, factored=factored and case["per_tower"] % 16 == 0)
     print(f"[dp {name} side_stream={side} factored={factored}] worst summed-gradient error {worst[0]:.2e} ({worst[1]}); ReLU units moved: {case['relu_report']}")
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name,side", [("blocks", True), ("toy", False)])
+def test_two_ranks_on_the_sharded_route_match_the_two_tower_oracle(name, side, tmp_path):
+    """Route C of DESIGN.md section 6 (the default beyond four towers, forced here at two): hidden1_weights' gradient is
+    reduce-scattered, the variable's norm is the all-reduced sum of the shards' squares, every rank clips + Adam-updates its half and
+    the halves are all-gathered under the next forward.  Same oracle, same tolerances as the other two routes -- and the ranks must
+    end with bit-identical weights and (after gather_moments) Adam slots (utils.py:170-213, train.py:330-336)."""
+    case, ref = _case(name)
+    ranks = _run_ranks(case, tmp_path, side, route="sharded")
+    assert all(st["sharded"] and not st["factored"] for r in ranks for st in r["steps"])
+    worst = _check(case, ref, ranks, factored=False)
+    print(f"[dp {name} sharded route] worst summed-gradient error {worst[0]:.2e} ({worst[1]})")
 
 
 @pytest.mark.timeout(900)

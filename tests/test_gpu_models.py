@@ -657,9 +657,9 @@ def test_lazily_normalised_descriptor_does_not_change_the_step():
     # the forward to 1e-5 -- and the gradients of THIS toy problem to 2e-3 only: its predictions are saturated, and a 2e-7 perturbation
     # of the descriptor moves every gradient by ~5e-4 (measured the same with round 3's one-launch form, tools/debug_clip.py).  Parity of
     # the default path is held against the oracle (test_cfg2_*), not here.
+    # (res[.][2], the predictions AFTER the optimiser step, are not compared: Adam's first step is lr * sign(g))
     assert abs(res[4][0] - res[0][0]) <= 1e-5 * abs(res[0][0])
     assert rel_err(res[4][3], res[0][3]) < 2e-6
-    assert rel_l2(res[4][2], res[0][2]) < 1e-4
     assert rel_l2(res[4][1], res[0][1]) < 2e-3
     assert res[0][0] == res[2][0] and torch.equal(res[0][1], res[2][1]), "the lazy path is bitwise repeatable"
     # ... and with the softmax inside the aggregation kernel (ops.VLAD_SOFTMAX_FUSED) the whole step is the same bits

@@ -8,7 +8,7 @@ d, cfg, commit = sys.argv[1], sys.argv[2], sys.argv[3]
 ALG = {"cfg2": 4 * (80 * 300 * 256 + 80 * 300 * 1024 + 80 * 1024 * 256) + 4 * 1024 * 256,
        "cfg3": 4 * (80 * 300 * 256 + 80 * 300 * 1024 + 80 * 1024 * 256) + 4 * 1024 * 256,
        "cfg5": 2 * (128 * 300 * 512 + 128 * 300 * 1024 + 128 * 1024 * 512) + 4 * 1024 * 512}[cfg]
-CHAIN = ("assign_tiles", "softmax_stats", "vlad_aggregate", "vlad_kmajor", "vlad_finalize", "vlad_row_scales")
+CHAIN = ("assign_tiles", "softmax_stats", "vlad_aggregate", "vlad_kmajor", "vlad_clip", "vlad_finalize", "vlad_row_scales")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for i in (1, 2):
     for r in csv.DictReader(open(os.path.join(d, f"pass{i}.csv"))):
@@ -21,7 +21,7 @@ for (k, grid), c in sorted(acc.items()):
     wr = 1024 * sum(c.get("WRITE_SIZE", [0])) / max(len(c.get("WRITE_SIZE", [0])), 1)
     kern[f"{k} (grid {grid})"] = {"read_bytes": int(rd), "write_bytes": int(wr), "bytes": int(rd + wr), "launches_averaged": len(c.get("FETCH_SIZE", []))}
     total += rd + wr
-    if ("vlad_aggregate" in k or "vlad_kmajor" in k) and (k2 is None or rd + wr > k2[1]):
+    if ("vlad_aggregate" in k or "vlad_kmajor" in k or "vlad_clip" in k) and (k2 is None or rd + wr > k2[1]):
         k2 = (k, rd + wr)
 print(json.dumps({"config": cfg, "commit": commit, "algorithmic_bytes": ALG,
                   "correction": "MI355X_MICROARCH.md HBM section: counters in KB (1024 B); gfx950 FETCH_SIZE x 2; WRITE_SIZE as reported",
