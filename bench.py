@@ -209,6 +209,52 @@ def self_launch(n, argv):
     return rc
 
 
+def run_all(argv):
+    """`--config all`: every single-GPU BASELINE configuration through this same script, each in a FRESH child process (this parent
+    never touches the GPU), their JSON lines relayed in the order cfg3, cfg5, cfg2 -- the line of the configuration BASELINE.json's
+    metric is quoted on comes last.  Returns the worst exit code."""
+    import subprocess
+    rest, skip = [], False
+    for a in argv:                                   # drop "--config all" / "--config=all"
+        if skip:
+            skip = False
+        elif a == "--config":
+            skip = True
+        elif not a.startswith("--config="):
+            rest.append(a)
+    worst = 0
+    for cfg in ("cfg3", "cfg5", "cfg2"):
+        sys.stderr.write(f"[bench.py] --config all: {cfg}\n")
+        sys.stderr.flush()
+        rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--config", cfg, *rest])
+        worst = max(worst, rc)
+    return worst
+
+
+def count_dispatches(step):
+    """Kernel launches of ONE steady-state step, counted live (outside the timed region) with torch.profiler's device activity trace,
+    which sees every kernel of the process -- the library's ctypes launches included.  -> dict or None (profiler unavailable)."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        step()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        dur = []
+        for e in prof.events():
+            if e.device_type == torch.autograd.DeviceType.CUDA and not any(w in e.name for w in ("Memcpy", "Memset", "memcpy", "memset")):
+                dur.append(float(getattr(e, "device_time", 0.0) or getattr(e, "cuda_time", 0.0) or 0.0))
+        if not dur:
+            return None
+        small = [d for d in dur if d < 8.0]
+        return {"value": len(dur), "measured": True, "launches_under_8us": len(small), "under_8us_total_us": round(sum(small), 1),
+                "source": "torch.profiler device activity of one step after the timed region"}
+    except Exception as ex:                          # the count is a diagnostic, never a reason to fail the bench
+        sys.stderr.write(f"[bench.py] dispatch count unavailable: {type(ex).__name__}: {ex}\n")
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,13 +266,19 @@ def main():
                          "first second, 8.4-8.7k afterwards)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg2",
+    ap.add_argument("--no-dispatch-count", action="store_true",
+                    help="skip the live launch count (one more step under torch.profiler after the timed region): for runs that already "
+                         "sit under rocprofv3")
+    ap.add_argument("--config", choices=sorted(WORKLOADS) + ["all"], default="cfg2",
                     help="cfg2 (default): the configuration BASELINE.json's metric is quoted on; cfg3: BASELINE configs[2] (NetVladV2); "
-                         "cfg5: BASELINE configs[4] per GPU")
+                         "cfg5: BASELINE configs[4] per GPU; all: cfg3, cfg5, cfg2 one after the other, each in a fresh process -- three "
+                         "JSON lines, the BASELINE metric's (cfg2) last")
     ap.add_argument("--watchdog-seconds", type=float, default=240.0,
                     help="N > 1 only: a rank that makes no progress for this long prints its phase and last collective and exits 3")
     args = ap.parse_args()
 
+    if args.config == "all":
+        raise SystemExit(run_all(sys.argv[1:]))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,7 +307,7 @@ def main():
             dist.init_process_group("nccl", device_id=device, timeout=to)       # nccl == RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from learnablepoolingmethods_amd import ops, registry
+    from learnablepoolingmethods_amd import FLAGS, ops, registry
     from learnablepoolingmethods_amd.train import Trainer
 
     wl = WORKLOADS[args.config]
@@ -310,6 +362,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timeline, ops.KERNEL_TIMELINE = ops.KERNEL_TIMELINE, None
     lib._lpm_kernel_timing_enable(0)
+    dispatches = count_dispatches(lambda: trainer.step(raw, nf, labels)) if (world == 1 and not args.no_dispatch_count) else None
 
     def kernel_ms(tag):
         import ctypes
@@ -347,6 +400,10 @@ def main():
             elif prec == "bf16x3" and ops.VLAD_TILES3 and ops.VLAD_KMAJOR_SCALED and args.config == "cfg2":
                 kname = ("vlad_kmajor_kernel (K2 + row scales, video stream, split-bf16 MFMA, LDS-DMA tiles, 256 x 128 and 128 x 128 "
                          "workgroup items)")
+            elif (prec == "bf16x3" and ops.VLAD_TILES3 and ops.VLAD_CLIP and args.config == "cfg2" and FLAGS.netvlad_lazy_descriptor
+                  and lib._lpm_vlad_clip_slabs(D, K)):
+                kname = ("vlad_clip_kernel (K2, video stream, split-bf16 MFMA, LDS-DMA tiles, clip-wide items: all 256 clusters x a "
+                         "third of a clip's columns per workgroup)")
             elif prec == "bf16x3":
                 kname = ("vlad_aggregate_tiles3_kernel (K2, video stream, split-bf16 MFMA, LDS-DMA tiles)" if ops.VLAD_TILES3
                          else "vlad_aggregate_tiles_kernel<8> (K2, video stream, split-bf16 MFMA, register streaming)")
@@ -365,13 +422,19 @@ def main():
                     roof[nm + "_avg_ms"] = round(sum(tt) / len(tt), 4)
             # HBM bytes per launch of this kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
             # tools/pmc_a5.sh -> tools/pmc_to_json.py, the guide's gfx950 corrections); the file names its commit
+            # NOT measured by this run: a profiler cannot sit inside the timed region.  The figure is attached only when it describes the
+            # kernel this run timed (same kernel name) and no A/B switch of the library is set in the environment.
             pmc = os.path.join(ROOT, "profiles", f"a5_hbm_traffic_{args.config}.json")
-            if os.path.exists(pmc):
+            ab = sorted(k for k in os.environ if k.startswith("LPM_") and k not in ("LPM_SHARE_GPU", "LPM_DP_BACKEND", "LPM_SINGLE_STREAM"))
+            if os.path.exists(pmc) and not ab:
                 try:
                     pj = json.load(open(pmc))
-                    roof["traffic"] = pj.get("k2_bytes_per_launch")
-                    roof["traffic_source"] = f"profiles/a5_hbm_traffic_{args.config}.json (commit {pj.get('commit')}): {pj.get('k2_kernel')}"
-                    roof["a5_chain_traffic"] = pj.get("chain_bytes_per_launch")
+                    if str(pj.get("k2_kernel", "")).split("<")[0].split("::")[-1] == kname.split(" ")[0].split("<")[0]:
+                        roof["traffic"] = pj.get("k2_bytes_per_launch")
+                        roof["traffic_measured_by_this_run"] = False
+                        roof["traffic_source"] = (f"profiles/a5_hbm_traffic_{args.config}.json, rocprofv3 --pmc passes taken at commit "
+                                                  f"{pj.get('commit')}: {pj.get('k2_kernel')}")
+                        roof["a5_chain_traffic"] = pj.get("chain_bytes_per_launch")
                 except Exception:
                     pass
             # the WHOLE a5 function (frame_level_models.py:2798-2822: BN-affine + softmax -> residual aggregation -> both
@@ -394,17 +457,9 @@ def main():
                 "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic", "dtype_detail": wl["dtype_detail"],
                 "config": {"workload": wl["workload"], "global_batch": global_batch, "seq_len": MAX_FRAMES, "parallelism": f"dp{world}"},
                 "final_loss": round(loss, 4)}
-        # launches per step, from the committed rocprofv3 kernel-trace table of this workload (tools/rocpd_stats.py counts the dispatches
-        # of the profiled run and divides by its steps); not measured live: a profiler would sit inside the timed region
-        import glob
-        import re
-        tag = {"cfg2": "bench"}.get(args.config, args.config)
-        tables = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r03_{tag}_kernel_stats_v*_two_stream.md")),
-                        key=lambda f: int(re.search(r"_v(\d+)_", f).group(1)))
-        if tables:
-            m = re.search(r"= (\d+) dispatches per step", open(tables[-1]).read(4096))
-            if m:
-                line["dispatches_per_step"] = {"value": int(m.group(1)), "source": "profiles/" + os.path.basename(tables[-1])}
+        # launches per step: counted live, on one more step AFTER the timed region (single GPU: the extra steps hold collectives otherwise)
+        if world == 1 and dispatches is not None:
+            line["dispatches_per_step"] = dispatches
         if roof:
             line["roofline"] = roof
         if k1:

@@ -14,7 +14,11 @@
  *     asynchronous; nothing synchronises internally;
  *   - returns LPM_OK (0) or a negative LPM_ERR_*; lpm_last_error() (thread-local
  *     string) says why;
- *   - re-entrant; no global mutable state except the error string.
+ *   - re-entrant.  Mutable state outside the caller's buffers: the thread-local error string, and ONE process-global
+ *     measurement switch -- lpm_kernel_timing_enable(1) makes the K1 / K2 / assignment-tile / finalize launches of EVERY
+ *     thread record start / stop events into the library's own table until lpm_kernel_timing_enable(0); enable it from one
+ *     thread at a time and read the table (lpm_kernel_timing_read) after synchronising the streams (bench.py, tools/).
+ *     Environment switches (LPM_*) are read once, at the first call that consults them.
  */
 #ifndef LPM_HIP_H
 #define LPM_HIP_H

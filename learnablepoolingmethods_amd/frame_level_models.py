@@ -323,6 +323,8 @@ class NetVladV2(models.BaseModel):
         if has_audio and reshaped_input.is_cuda and ops.V2_SPLIT_COLUMNS:
             # one contiguous copy per stream (the encoder and the aggregation both want whole rows); their gradients come back as ONE
             # concatenation instead of two zero-filled [M, 1152] buffers, two slice copies and an add
+            # (the copies do not carry the views' shared-gradient slot -- ops._SplitColumns.backward then concatenates the two
+            # gradients, which is the point here; the slot mechanism itself serves NetVladV1, whose pooling ops write into it)
             rgb, audio = ops.split_columns(reshaped_input, 1024)
             rgb, audio = rgb.contiguous(), audio.contiguous()
         else:

@@ -1742,7 +1742,8 @@ class _ResidualLayerNorm(torch.autograd.Function):
         ctx.has_r, ctx.relu, ctx.has_bias = r is not None, bool(relu), bias is not None
         ctx.save_for_backward(z, stats, gamma, a if relu else None, bias)
         if y3 is not None:
-            y._lpm_y3 = y3
+            # handed to the next block with the identity of the tensor it images: a consumer must see the same storage, untouched
+            y._lpm_y3 = (y3, y.data_ptr(), y._version)
         return y
 
     @staticmethod
@@ -2004,7 +2005,19 @@ class _FFNBlockX3(torch.autograd.Function):
         y = _f32(y, "ffn block input").contiguous()
         B, L, F = y.shape
         cf, c1, c2 = _SubCtx(), _SubCtx(), _SubCtx()
-        pre = _FFNX3.forward(cf, y.view(B * L, F), W1, b1, W2, y3=getattr(y, "_lpm_y3", None))
+        # the layer norm's operand image of y (ops._ResidualLayerNorm(image=True)), only if y is still the tensor it was taken from:
+        # modified in place, re-allocated or replaced in between, the image is dropped and y is split again
+        y3 = None
+        tag = getattr(y, "_lpm_y3", None)
+        if tag is not None:
+            img, dptr, ver = tag
+            if dptr == y.data_ptr() and ver == y._version:
+                y3 = img
+            try:
+                del y._lpm_y3                   # consumed: the image lives as long as this block's saved tensors, not as long as y
+            except AttributeError:
+                pass
+        pre = _FFNX3.forward(cf, y.view(B * L, F), W1, b1, W2, y3=y3)
         from . import FLAGS
         if FLAGS.ln_pair_forward:      # three passes for the two layer norms: n itself is never stored
             out = _ln_pair_forward(c1, c2, pre.view(B, L, F), y, g1, be1, b2, g2, be2, out)
@@ -2088,7 +2101,8 @@ class _MHACoreBN(torch.autograd.Function):
         moments = None
         if is_training:
             partial = _empty((B * h, 2, L), q)
-            if MHA_BN_MOMENTS and d in (8, 16):
+            # (lpm_mha_logit_stats_moments reads q and k as float4: 16-byte aligned views only; anything else takes the general kernel)
+            if MHA_BN_MOMENTS and d in (8, 16) and q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0 and (q.stride(1) * 4) % 16 == 0:
                 # the statistics from the d x d moments of q, which the backward's repair of dk needs again (kept: 272 floats per head)
                 moments = _empty((B * h, d * d + d), q)
                 lib.check(lib._lpm_mha_logit_stats_moments(ptr(q), ptr(k), q.stride(1), B, L, h, d, ptr(partial), ptr(moments), stream_ptr()),
