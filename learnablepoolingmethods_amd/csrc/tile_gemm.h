@@ -79,7 +79,7 @@ struct TileGemmArgs {
     int rows_valid, cols_valid;
     int accumulate;            // STORE: out += result
     int nt_store;              // STORE: non-temporal stores (the 0.5-2 GB hidden1 weight gradient)
-    int nt_load;               // LDS-DMA cache policy: bit 0 = A pieces non-temporal, bit 1 = B pieces non-temporal
+    int dbg;                   // measurement only (LPM_TG_DBG)
     int cols_inner;            // 64-row form: the column blocks of a row block are CONSECUTIVE workgroups of a one-dimensional grid (same
                                // XCD, same moment: the row block's A tiles come from HBM once and from L2 for the other column blocks)
                                // instead of gridDim.y slices a whole grid row apart

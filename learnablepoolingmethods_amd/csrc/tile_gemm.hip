@@ -25,8 +25,10 @@ static size_t tg_lds_bytes(int ntw, int epi) {
 // RTW = 4 (MW = 2, STORE only): 256 rows per workgroup -- every wave owns FOUR row tiles x NTW column tiles (128 x 64 accumulators,
 // 128 registers): 32 KB staged per 256 x 256 x 16 products (262 MFMA-flop per byte) and 12 KB of fragment reads per 24 MFMAs and
 // wave instead of 8 KB per 12 -- the LDS read volume is what holds the 128-row form at ~1.1 PFLOP/s on the encoder's dense shapes.
-template <int NTW, int EPI, int MW, int NS, int PL, int RTW = 2>
-__global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3) ? 4 : 2) void tile_gemm_kernel(const TileGemmArgs g) {
+// FORM 1 (MW = 2, round 4): the two wave groups of a workgroup run in ANTI-PHASE -- see the branch below.
+template <int NTW, int EPI, int MW, int NS, int PL, int RTW = 2, int FORM = 0>
+__global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2) void tile_gemm_kernel(const TileGemmArgs g) {
+    static_assert(FORM == 0 || (MW == 2 && EPI == TG_EPI_STORE), "the anti-phase form: 128- / 256-row workgroups, store epilogue");
     static_assert(RTW == 2 || (RTW == 4 && MW == 2 && EPI == TG_EPI_STORE && NS >= 4), "four row tiles per wave: pipelined 128-row form only");
     static_assert(MW == 1 || EPI == TG_EPI_STORE, "the 128-row form has the store epilogue only");
     static_assert(EPI != TG_EPI_ADAM || (NTW == 1 && PL == 2), "the Adam epilogue: 64 x 128 tiles of split-bf16 operands");
@@ -96,15 +98,10 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3) ? 4 : 2) void tile_g
             // plain form: stage s = steps 2 s and 2 s + 1; past an odd end the piece re-reads the last step (its MFMA is skipped)
             const uint4* q = PL == 1 ? src[j] + (int64_t)min(2 * s + sub[j], nred - 1) * sstep[j]
                                      : (second ? src2[j] + (s - nstep1) * sstep2[j] : src[j] + s * sstep[j]);
-            // g.nt_load (measurement, LPM_TG_NT): bit 0 = the row-tile (A) pieces, bit 1 = the column-tile (B) pieces take the
-            // non-temporal policy (aux = 2: a stream read once does not displace what the other operand re-reads from L2)
-            const bool is_a = (wave + NWV * j) < NRP;
-            if ((g.nt_load >> (is_a ? 0 : 1)) & 1)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
-                                                 (__attribute__((address_space(3))) void*)(st + (wave + NWV * j) * 1024), 16, 0, 2);
-            else
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
-                                                 (__attribute__((address_space(3))) void*)(st + (wave + NWV * j) * 1024), 16, 0, 0);
+            // (default cache policy: the non-temporal policy was measured on both operands, alone and together -- LPM_TG_NT, round 4 --
+            // and changed nothing for K1 and the wide dense shapes, +-5 % either way on the N = 1024 shapes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
+                                             (__attribute__((address_space(3))) void*)(st + (wave + NWV * j) * 1024), 16, 0, 0);
         }
     };
 
@@ -135,7 +132,85 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3) ? 4 : 2) void tile_g
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nstep) issue(s);
-    if constexpr (MW == 2 && NS == 3) {
+    if constexpr (FORM == 1) {
+        // ANTI-PHASE wave groups (round 4).  Measured on the pipelined form below (LPM_TG_DBG ablations, K1 and the 256-row dense form):
+        // its time is the SUM of its matrix time, its fragment-read time and its DMA-issue time -- all eight waves are released by the
+        // same barrier, issue their LDS-DMA pieces and fragment reads at the same moment (an LDS burst of 64-96 KB, then silence) and
+        // the matrix pipe idles meanwhile: the two waves of a SIMD are in the same state.  Here the workgroup's two row groups (waves
+        // 0-3 / 4-7: wave w and wave w + 4 share a SIMD) are half a step apart: a step of a wave is a COMPUTE phase (its MFMAs, nothing
+        // else) and a LOAD phase (DMA issue for step t + NS, fragment reads of step t + 1 into the SAME registers -- the MFMAs that read
+        // them have been issued --, wait), with a barrier behind each; while one group computes the other loads (cdna guide 5.5
+        // T3+T4: the phase interleave is the lever).  One fragment register set (the pipelined form holds two).
+        //   phase 2t: group 0 C(t), group 1 L(t)   |   phase 2t + 1: group 0 L(t + 1), group 1 C(t)
+        // Step k is read in phases 2k - 1 (group 0) and 2k (group 1): every wave has waited for its own pieces of step k before the
+        // barrier that ends phase 2k - 2 -- group 0 at the end of C(k - 1), group 1 at the end of L(k - 1).  L(t + 1) refills stage
+        // t % NS (step t + NS): both groups have read step t by then (phases 2t - 1, 2t).  All NS stages are requested up front.
+        struct Frag { tg_u32x4 ah[RTW], al[RTW], bh[NTW], bl[NTW]; };
+        Frag fr;
+        auto read_frags = [&](int st_, Frag& f_) {
+            const tg_u32x4* f = reinterpret_cast<const tg_u32x4*>(smem + (st_ % NS) * STAGE) + lane;
+#pragma unroll
+            for (int m = 0; m < RTW; ++m) {
+                f_.ah[m] = f[((rg * RTW + m) * 2 + 0) * 64];
+                f_.al[m] = f[((rg * RTW + m) * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                f_.bh[n] = f[(NRP + (cw * NTW + n) * 2 + 0) * 64];
+                f_.bl[n] = f[(NRP + (cw * NTW + n) * 2 + 1) * 64];
+            }
+        };
+        auto mfma_term = [&](int t, int sstep_) {
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                for (int m = 0; m < RTW; ++m) {
+                    if (PL == 2) acc[m][n] = tg_mfma(t == 2 ? fr.al[m] : fr.ah[m], t == 1 ? fr.bl[n] : fr.bh[n], acc[m][n]);
+                    else acc[m][n] = tg_mfma(t ? fr.al[m] : fr.ah[m], t ? fr.bl[n] : fr.bh[n], acc[m][n]);
+                }
+            (void)sstep_;
+        };
+        int hi = min(NS - 2, nstep - 1);               // the youngest step requested so far (the common prologue above: 0 .. NS - 2)
+        if (NS - 1 < nstep) { issue(NS - 1); hi = NS - 1; }
+        auto wait_for = [&](int k) {                   // this wave's pieces of step k have landed (hi - k younger steps stay in flight)
+            if (k >= nstep) return;
+            const int y = hi - k;
+            if (y >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PW) : "memory");
+            else if (y == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+            else if (y == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto sync = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0) (as a builtin: the compiler's counter bookkeeping sees it)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        wait_for(0);
+        sync();
+        read_frags(0, fr);
+        if (rg == 1) {                                 // group 1's idle phase 0 (group 0 computes step 0)
+            wait_for(1);
+            sync();
+        }
+        for (int t = 0; t < nstep; ++t) {
+            // C(t)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_term(0, t);
+            if (PL == 2 || 2 * t + 1 < nred) mfma_term(1, t);
+            if (PL == 2) mfma_term(2, t);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rg == 0) wait_for(t + 1);
+            if (rg == 0 || t + 1 < nstep) sync();
+            if (t + 1 < nstep) {
+                // L(t + 1)
+                if (t + NS < nstep) { issue(t + NS); hi = t + NS; }
+                read_frags(t + 1, fr);
+                if (rg == 1) wait_for(t + 2);
+                sync();
+            }
+        }
+    } else if constexpr (MW == 2 && NS == 3) {
         // 128-row form, TWO workgroups per CU (72 KB ring, <= 128 VGPRs): no software pipelining inside a workgroup -- the other
         // workgroup's MFMAs cover this one's barrier, DMA issue and fragment reads, and its epilogue runs under this one's main loop
         for (int s = 0; s < nstep; ++s) {
@@ -245,25 +320,27 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3) ? 4 : 2) void tile_g
                         else acc[m][n] = tg_mfma(t ? cur.al[m] : cur.ah[m], t ? cur.bl[n] : cur.bh[n], acc[m][n]);
                     }
             };
-            mfma_term(0);
+            if (!(g.dbg & 8)) mfma_term(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + NS - 1 < nstep) issue(s + NS - 1);
+            if (s + NS - 1 < nstep && !(g.dbg & 4)) issue(s + NS - 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (PL == 2 || 2 * s + 1 < nred) mfma_term(1);
+            if ((PL == 2 || 2 * s + 1 < nred) && !(g.dbg & 8)) mfma_term(1);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < nstep) read_frags(s + 1, nxt);
             __builtin_amdgcn_sched_barrier(0);
-            if (PL == 2) mfma_term(2);
+            if (PL == 2 && !(g.dbg & 8)) mfma_term(2);
         };
         Frag fa, fb;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");      // step 0 has landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         read_frags(0, fa);
-        for (int s = 0; s < nstep; s += 2) {
+        const int nrun = (g.dbg & 1) ? 0 : nstep;        // (measurement: LPM_TG_DBG, see the launcher)
+        for (int s = 0; s < nrun; s += 2) {
             body(s, fa, fb);
             if (s + 1 < nstep) body(s + 1, fb, fa);
         }
+        if (g.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     const int N = g.cols_valid;
@@ -409,7 +486,8 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3) ? 4 : 2) void tile_g
                         const float4 o = *p;
                         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     }
-                    if (g.nt_store)      // a result far larger than the caches, read much later
+                    if (g.dbg & 2) { if (v.x == 123456.f) *p = v; }      // (measurement: no stores)
+                    else if (g.nt_store)      // a result far larger than the caches, read much later
                         __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
                     else *p = v;
                 }
@@ -552,6 +630,7 @@ static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw, i
 // allow_wide: 0 = 64-row form, 1 = 128-row form (one workgroup per CU, software-pipelined, 4-stage ring) where the shape allows,
 // 2 = 128-row form with a 3-stage ring and two workgroups per CU, 3 = 256-row form (four row tiles per wave; no statistics)
 constexpr int TG_WIDE_NS_DEFAULT = 4;
+constexpr int TG_AP_DEFAULT = 0;
 template <int EPI, int PL>
 static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override,
                         int timing_tag, int allow_wide) {
@@ -579,8 +658,9 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
     dim3 grid((unsigned)(wide ? nbatch * g.a_tiles / (wide4 ? 8 : 4) : nbatch * g.rb_per_batch), (unsigned)((nt + 4 * ntw - 1) / (4 * ntw)),
               (unsigned)splits);
     TileGemmArgs gl = g;
-    static const int nt_env = [] { const char* e = getenv("LPM_TG_NT"); return e ? atoi(e) : -1; }();
-    if (nt_env >= 0) gl.nt_load = nt_env;
+    // LPM_TG_DBG (measurement, pipelined forms only): 1 no main loop, 2 no stores, 4 no DMA inside the loop, 8 no MFMAs
+    static const int dbg_env = [] { const char* e = getenv("LPM_TG_DBG"); return e ? atoi(e) : 0; }();
+    gl.dbg = dbg_env;
     if (!wide && g.cols_inner) {
         if (g.stats) { set_error("%s: cols_inner and the statistics epilogue index workgroups differently", what); return LPM_ERR_BADARG; }
         gl.cols_inner = (int)grid.y;
@@ -589,9 +669,16 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
     } else {
         gl.cols_inner = 0;
     }
-    // ring depth of the pipelined forms (LPM_TG_WIDE_NS / LPM_TG_WIDE4_NS = 4, 5, 6: A/B; NS - 2 steps of LDS-DMA stay in flight)
-    static const int wide_ns = [] { const char* e = getenv("LPM_TG_WIDE_NS"); const int v = e ? atoi(e) : 0; return (v >= 4 && v <= 6) ? v : TG_WIDE_NS_DEFAULT; }();
+    // ring depth of the pipelined forms (LPM_TG_WIDE_NS / LPM_TG_WIDE4_NS = 4, 5: A/B; NS - 2 steps of LDS-DMA stay in flight).
+    // Round 4, one box: K1 47.6 / 48.8 / 49.8 us at 4 / 5 / 6 stages; the 256-row dense form 3-10 % slower at 5 -- the loop is not
+    // waiting for data in flight.
+    static const int wide_ns = [] { const char* e = getenv("LPM_TG_WIDE_NS"); const int v = e ? atoi(e) : 0; return (v >= 4 && v <= 5) ? v : TG_WIDE_NS_DEFAULT; }();
     static const int wide4_ns = [] { const char* e = getenv("LPM_TG_WIDE4_NS"); const int v = e ? atoi(e) : 0; return (v >= 4 && v <= 5) ? v : 4; }();
+    // LPM_TG_AP (0 / 1): the anti-phase form of the 128- / 256-row workgroups (FORM 1) instead of the pipelined one.  Built and measured in
+    // round 4, NOT faster (one box: K1 59.9 vs 51.2 us, qkv fwd 432 vs 406 us, ffn1 fwd 459 vs 448 us): a LOAD phase (3-4 LDS-DMA
+    // issues + 8-12 fragment reads + two barrier episodes) is longer than a 12- / 24-MFMA COMPUTE phase, and a step costs twice the
+    // longer of the two.  Kept for the A/B.
+    static const int ap = [] { const char* e = getenv("LPM_TG_AP"); return e ? atoi(e) : TG_AP_DEFAULT; }();
     const bool wide2 = wide && allow_wide == 2;
     const size_t lds = wide4 ? (size_t)wide4_ns * (16 + 8 * ntw) * 1024
                              : (wide ? (size_t)(wide2 ? 3 : wide_ns) * (8 + 8 * ntw) * 1024 : tg_lds_bytes(ntw, EPI));
@@ -613,10 +700,11 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
     if constexpr (EPI == TG_EPI_ADAM) {
         LPM_TG_LAUNCH(1);
     } else {
-        if (wide4 && wide4_ns == 5) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 5, PL, 4>), 512);
+        if (wide4 && ap) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL, 4, 1>), 512);
+        else if (wide && !wide2 && ap) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL, 2, 1>), 512);
+        else if (wide4 && wide4_ns == 5) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 5, PL, 4>), 512);
         else if (wide4) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL, 4>), 512);
         else if (wide2) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 3, PL>), 512);
-        else if (wide && wide_ns == 6) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 6, PL>), 512);
         else if (wide && wide_ns == 5) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 5, PL>), 512);
         else if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL>), 512);
         else if (ntw == 1) LPM_TG_LAUNCH(1);

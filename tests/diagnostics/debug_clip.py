@@ -1,6 +1,6 @@
 """K2 forms inside the model: one NetVladV1 step with ops.VLAD_CLIP on / off, per-variable gradient differences."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import lpm_oracle as O
 from learnablepoolingmethods_amd import FLAGS, ops, registry

@@ -655,7 +655,7 @@ def test_lazily_normalised_descriptor_does_not_change_the_step():
             ops.VLAD_CLIP = clip0
     # The clip-wide form of K2 (the default) adds the assignment sums in another fixed order: the descriptor agrees to the last bits,
     # the forward to 1e-5 -- and the gradients of THIS toy problem to 2e-3 only: its predictions are saturated, and a 2e-7 perturbation
-    # of the descriptor moves every gradient by ~5e-4 (measured the same with round 3's one-launch form, tools/debug_clip.py).  Parity of
+    # of the descriptor moves every gradient by ~5e-4 (measured the same with round 3's one-launch form, tests/diagnostics/debug_clip.py).  Parity of
     # the default path is held against the oracle (test_cfg2_*), not here.
     # (res[.][2], the predictions AFTER the optimiser step, are not compared: Adam's first step is lr * sign(g))
     assert abs(res[4][0] - res[0][0]) <= 1e-5 * abs(res[0][0])
