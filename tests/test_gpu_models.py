@@ -87,7 +87,24 @@ def test_netvladv2_forward_with_dropout_mask():
     assert_close(pred, ref, what="V2 predictions")
 
 
-def _full_size_compare(name, cfg, B, seed, dev, scale_hidden1=True, dropout_masks=None, grad_tol=1e-3, **kw):
+def _relu_units_at_rounding_distance(p, x, nf, cfg, dm64, reach=1e-5):
+    """How many ReLU units of the fp64 forward have a pre-activation closer to zero than fp32 arithmetic can resolve (|z| < reach x
+    the site's rms): the units whose mask any fp32 implementation may decide differently from the oracle.  -> {site: (units, total)}"""
+    O.RELU_TAPS = {}
+    try:
+        with torch.no_grad():
+            O.model_forward(p, x, nf, cfg, True, None, dm64)
+        taps = O.RELU_TAPS
+    finally:
+        O.RELU_TAPS = None
+    out = {}
+    for site, z in taps.items():
+        z = z.reshape(-1, z.shape[-1]).double()
+        out[site] = ((z.abs() < reach * float(z.pow(2).mean().sqrt())).any(0).nonzero().flatten(), int(z.shape[-1]))
+    return out
+
+
+def _full_size_compare(name, cfg, B, seed, dev, scale_hidden1=True, dropout_masks=None, grad_tol=1e-3, prepare_relu=True, **kw):
     """One training step at a BASELINE configuration's real layer sizes through the Trainer against the fp64 oracle: the named
     intermediates of the forward (the product reports them as summaries), loss, predictions and the gradient of EVERY variable.
     The seeded weights keep all ReLU pre-activations away from zero (oracle/test_weights.separate_relu_units), so the whole-model
@@ -100,7 +117,15 @@ def _full_size_compare(name, cfg, B, seed, dev, scale_hidden1=True, dropout_mask
     if scale_hidden1:
         p = _well_conditioned(p)
     dm64 = None if dropout_masks is None else {k: v.double() for k, v in dropout_masks.items()}
-    p, report = separate_relu_units(p, [(x.double(), nf, dm64)], cfg)
+    if prepare_relu:
+        p, report = separate_relu_units(p, [(x.double(), nf, dm64)], cfg)
+    at_risk = {}
+    if not prepare_relu:
+        # the weights as initialised: find the ReLU units within fp32 rounding of zero instead of moving them.  Such a unit takes its mask
+        # from the last bit of whichever arithmetic computed it; its own column of the layer's kernel / bias gradient is then a coin
+        # toss between two correct answers and is left out of that variable's comparison -- everything else is held to the tolerance.
+        at_risk = _relu_units_at_rounding_distance(p, x.double(), nf, cfg, dm64)
+        report = {k: (f"{len(v[0])} of {v[1]} at rounding distance",) for k, v in at_risk.items()}
     with torch.no_grad():
         _, inter = O.model_forward(p, x.double(), nf, cfg, True, None, dm64, return_intermediates=True)
     pred, loss, grads, _ = O.loss_and_grads(p, x.double(), nf, lab, cfg, dm64)
@@ -124,11 +149,53 @@ def _full_size_compare(name, cfg, B, seed, dev, scale_hidden1=True, dropout_mask
     errs["predictions"] = assert_close(out["predictions"], pred, what="predictions")
     gscale = max(float(g.abs().max()) for g in grads.values())
     worst = (0.0, "")
+    raw_worst, over = (0.0, ""), []
+    yard = {}
+    if not prepare_relu:
+        # the yardstick at an untouched initialisation: the SAME graph evaluated by the oracle in fp32 (what a TF1 fp32 run is) against
+        # its fp64 evaluation -- how far two correct fp32-grade evaluations of this ill-conditioned start may be apart
+        p32 = {k: v.float() for k, v in p.items()}
+        dm32 = None if dm64 is None else {k: v.float() for k, v in dm64.items()}
+        _, _, g32, _ = O.loss_and_grads(p32, x.float(), nf, lab, cfg, dm32)
+        yard = {n: rel_l2(g32[n].double(), grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5) for n in g32}
     for n in O.trainable_names(p, cfg):
-        g = tr.gradient("tower/" + n)
-        e = rel_l2(g, grads[n], floor=1e-4 * gscale * grads[n].numel() ** 0.5)
+        g = tr.gradient("tower/" + n).double().cpu()
+        ref = grads[n]
+        raw_worst = max(raw_worst, (rel_l2(g, ref, floor=1e-4 * gscale * ref.numel() ** 0.5), n))
+        site = n if n in at_risk else (n[:-len("kernel")] + "bias" if n.endswith("/kernel") else None)
+        if site in at_risk and len(at_risk[site][0]):
+            keep = torch.ones(ref.shape[-1], dtype=torch.bool)
+            keep[at_risk[site][0]] = False
+            g, ref = g[..., keep], ref[..., keep]
+        e = rel_l2(g, ref, floor=1e-4 * gscale * ref.numel() ** 0.5)
         worst = max(worst, (e, n))
-        assert e <= grad_tol, f"{name} gradient {n}: relative L2 error {e:.3e} > {grad_tol:.1e}"
+        if prepare_relu:
+            assert e <= grad_tol, f"{name} gradient {n}: relative L2 error {e:.3e} > {grad_tol:.1e}"
+        else:
+            over.append((e, n))
+    if not prepare_relu:
+        # Untouched initialisation: what the prepared weights of the other tests take out of the comparison is MEASURED here and held to
+        # a bound.  Two effects: (i) ReLU units within rounding of zero (their own kernel / bias columns are left out above; through
+        # the layers below them they still reach every earlier variable), (ii) the saturated head of a freshly initialised model
+        # (|activation| ~ 30-70: an absolute logit error of 1e-5 is a relative error of 1e-5 in every 1 - p, amplified through
+        # the batch norms of NetVladV2).  Bound: every gradient within the north-star's 1e-3 OR within 3 x the WORST distance of the fp32 oracle (the
+        # same graph evaluated in fp32 on the CPU: what a TF1 fp32 run is) from the fp64 oracle on this model; 1e-2 with the at-risk units' own
+        # columns included; the variables above 1e-3 are listed.
+        above = sorted((e, n) for e, n in over if e > grad_tol)
+        print(f"[{name} B={B}] untouched initialisation: {len(over) - len(above)} of {len(over)} gradients within {grad_tol:.0e}; above: "
+              f"{[(n, float(f'{e:.2e}')) for e, n in above]}; worst INCLUDING the columns of the at-risk ReLU units {raw_worst[0]:.2e} "
+              f"({raw_worst[1]}); at-risk units {({k.split('/')[-2]: len(v[0]) for k, v in at_risk.items()})}")
+        yworst = max((v, k) for k, v in yard.items())
+        ratio = max((e / max(yard[n], grad_tol / 4), n) for e, n in over)
+        print(f"[{name} B={B}] the fp32 ORACLE against the fp64 oracle on the same weights: worst gradient {yworst[0]:.2e} ({yworst[1]}), "
+              f"{sum(v > grad_tol for v in yard.values())} of {len(yard)} above {grad_tol:.0e}; the product's error is at most "
+              f"{ratio[0]:.2f} x the fp32 oracle's ({ratio[1]})")
+        assert raw_worst[0] <= 1e-2, f"gradient {raw_worst[1]}: {raw_worst[0]:.3e} > 1e-2 with the at-risk units' own columns included"
+        # (per model, not per variable: an error made in one stream's ill-conditioned batch norms reaches the other stream's gradients
+        # through hidden1_bn's batch statistics)
+        for e, n in over:
+            assert e <= max(grad_tol, 3.0 * yworst[0]), (f"gradient {n}: {e:.3e} > 1e-3 and > 3 x the fp32 oracle's own worst distance from "
+                                                          f"fp64 on this model ({yworst[0]:.3e}, {yworst[1]})")
     print(f"[{name} B={B}] intermediates {({k: f'{v:.1e}' for k, v in errs.items()})}; worst gradient {worst[0]:.2e} ({worst[1]}); "
           f"ReLU units moved {({k.split('/')[-2]: v[0] for k, v in report.items()})}")
     return errs, worst
@@ -150,6 +217,36 @@ def test_cfg2_reference_initialisation_unscaled():
     3e-5 relative error of every gate / expert probability -- tolerance 1e-3 on the whole-model gradients stays."""
     cfg = O.OracleConfig(model="NetVladV1", iterations=300, cluster_size=256, hidden_size=512, base_learning_rate=2e-4)
     _full_size_compare("NetVladV1", cfg, 8, 2, cuda(), scale_hidden1=False)
+
+
+@pytest.mark.parametrize("which", ["cfg2", "cfg3", "cfg5"])
+def test_untouched_reference_initialisation(which):
+    """one case per single-GPU model at the reference's initialisation AS IT IS -- no ReLU-margin preparation of
+    the biases (oracle/test_weights.separate_relu_units), no 0.02 scale on hidden1_weights -- at the BASELINE layer sizes: forward
+    intermediates, loss and predictions at 1e-3 in max-norm; the gradient of every variable within 1e-3 in Frobenius norm OR within
+    three times the worst distance between the oracle's own fp32 and fp64 evaluations of the model's gradients (a freshly initialised model is
+    saturated and ill-conditioned: two correct fp32 evaluations differ by more than 1e-3 there, NetVladV2's batch norms most of all),
+    with the variables above 1e-3 and the number of ReLU units whose fp64 pre-activation lies within fp32 rounding of zero (the
+    units the engineered margins of the other tests move away) printed: the margins are a measured, bounded effect, not a precondition
+    of parity."""
+    dev = cuda()
+    if which == "cfg2":
+        cfg = O.OracleConfig(model="NetVladV1", iterations=300, cluster_size=256, hidden_size=512, base_learning_rate=2e-4)
+        _full_size_compare("NetVladV1", cfg, 8, 12, dev, scale_hidden1=False, prepare_relu=False)
+    elif which == "cfg3":
+        cfg = O.OracleConfig(model="NetVladV2", iterations=300, cluster_size=256, hidden_size=512, base_learning_rate=2e-4)
+        B = 8
+        g = torch.Generator().manual_seed(15)
+        masks = {"video": (torch.rand(B, 300, 1024, generator=g) >= 0.9).float(), "audio": (torch.rand(B, 300, 128, generator=g) >= 0.9).float()}
+        _full_size_compare("NetVladV2", cfg, B, 13, dev, scale_hidden1=False, prepare_relu=False, dropout_masks=masks)
+    else:
+        from learnablepoolingmethods_amd import FLAGS
+        cfg = O.OracleConfig(model="NetVladV1", vocab_size=3862, base_learning_rate=2e-4, **CFG5)
+        FLAGS.moe_num_mixtures = 4
+        try:
+            _full_size_compare("NetVladV1", cfg, 8, 14, dev, scale_hidden1=False, prepare_relu=False, encoder=False)
+        finally:
+            FLAGS.reset()
 
 
 def test_cfg3_layer_sizes_reduced_batch():
