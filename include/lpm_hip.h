@@ -452,6 +452,26 @@ int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const f
 int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, int order, void* out3,
                    lpm_stream_t stream);
 int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w3k, lpm_stream_t stream);
+
+/* Every operand form of every dense-layer weight of a step in ONE launch (weight_pack.hip, round 4): a job names a weight W [K, N]
+ * (row stride ldw) -- or the column block [n_off, n_off + N) of a concatenated weight with Ntot columns (q | k | v) -- and the forms
+ * wanted of it, each optional (NULL): w3n / w3k as lpm_split_weight writes them (of the concatenated weight: w3n [Ntot, 3K],
+ * w3k [K, 3 Ntot]), wt = lpm_split_weight_tiles(W, K, Ntot, transposed = 0) and wtt = lpm_split_weight_tiles of the same storage
+ * with transposed = 1 (the B operand of the input-gradient GEMM; whole weights only).  Bit for bit the single-weight entry points'
+ * outputs.  K, N, n_off, Ntot multiples of 32; at most LPM_WEIGHT_PACK_MAX_JOBS jobs per call.  The job array is HOST memory, read
+ * during the call.  Reference: transformer_utils.py:559-561,583,701-711; frame_level_models.py:2781-2789 (the weights of tf.layers.dense
+ * / tf.matmul, constant within a step). */
+#define LPM_WEIGHT_PACK_MAX_JOBS 24
+typedef struct LpmWeightPackJob {
+    const float* w;     /* device, [K, N] fp32, row stride ldw */
+    int K, N, ldw;
+    int Ntot, n_off;    /* the weight's place in a concatenation along N (whole weight: Ntot = N, n_off = 0) */
+    void* w3n;          /* device outputs, NULL = not wanted */
+    void* w3k;
+    void* wt;
+    void* wtt;
+} LpmWeightPackJob;
+int lpm_weight_pack(const LpmWeightPackJob* jobs, int njobs, lpm_stream_t stream);
 /* backward of the fused relu(x + bias) split (FeedForwardNetwork, transformer_utils.py:701-711): g = df * [act > 0]
  * (act3 = the forward's [M,3K] split image of the activation), out3 = split image of g, dbias [K] = column sums of g.
  * workspace: lpm_split_rows_relu_bwd_workspace_bytes(M, K). */

@@ -158,7 +158,15 @@ SIGNATURES = {
     "lpm_factored_clip_adam_q": (_i, [_f, _f, _f, _l, _f, _i, _i, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
     "lpm_factored_clip_adam": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
     "lpm_multi_tensor_clip_adam": (_i, [_f, _f, _f, _f, _f, _i, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _f]),
+    "lpm_weight_pack": (_i, [_f, _i, _f]),          # (jobs: a HOST array of WeightPackJob)
 }
+WEIGHT_PACK_MAX_JOBS = 24
+
+
+class WeightPackJob(C.Structure):
+    """LpmWeightPackJob of include/lpm_hip.h."""
+    _fields_ = [("w", C.c_void_p), ("K", C.c_int), ("N", C.c_int), ("ldw", C.c_int), ("Ntot", C.c_int), ("n_off", C.c_int),
+                ("w3n", C.c_void_p), ("w3k", C.c_void_p), ("wt", C.c_void_p), ("wtt", C.c_void_p)]
 
 
 class LpmError(RuntimeError):

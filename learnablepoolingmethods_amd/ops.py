@@ -6,6 +6,7 @@ PyTorch only supplies device memory, streams and the autograd tape.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 import weakref
 from typing import Optional
@@ -726,13 +727,12 @@ class _NetVLAD(torch.autograd.Function):
             st = stream_ptr()
             nblk = lib._lpm_assign_gemm_tiles_nblk(B, T)
             partial = _empty((nblk, 2, K), x)
-            wt = _tile_buffer(lib._lpm_weight_tiles_bytes(D, K), x)
             xr = _cached_tiles(x, B, T, D, rows=True)
             if xr is None:
                 xr = _tile_buffer(lib._lpm_row_tiles_bytes(B, T, D), x)
                 with _timed("split_rows_tiles", (M, D)):
                     lib.check(lib._lpm_split_rows_tiles(ptr(x), x.stride(0), B, T, D, ptr(xr), st), "lpm_split_rows_tiles")
-            lib.check(lib._lpm_split_weight_tiles(ptr(W), D, K, 0, ptr(wt), st), "lpm_split_weight_tiles")
+            wt = _weight_tiles(W, D, K, False, x)
             with _timed("assign_gemm_fwd", (M, D, K)):
                 lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st),
                           "lpm_assign_gemm_tiles_fwd")
@@ -1106,9 +1106,124 @@ def _split_rows(x2d, bias=None, relu=False, grad=False, row_scale=None):
     return out
 
 
-def _split_weight(W, need_t=True):
+class WeightPack:
+    """Every operand form of every dense-layer weight of a training step from ONE launch (lpm_weight_pack, weight_pack.hip).
+
+    A weight changes once per step, in the optimiser; the forward and backward consume it as split-bf16 images (w3n, w3k) and fragment
+    tiles (wt, wtt) that round 3 derived where they were used -- 14 small launches per cfg-2 step.  The trainer owns one WeightPack:
+    ``begin_step`` (weights final, before the forward) derives all forms recorded so far in one launch; the consumers ask ``take``
+    for them, which RECORDS what it is asked for -- a form that is not ready (the first step, a model that changed) is computed by the
+    consumer's own call, as without the pack, and is part of the launch from the next step on.  Outside a trainer's step (predict(),
+    the kernel tests) nothing is armed and every consumer computes its own."""
+
+    def __init__(self):
+        self.plan = {}          # key (address and shape of the source weights) -> {"srcs": [tensors], "need": set of forms}
+        self.ready = {}         # key -> {form: tensor}, valid for the current step
+        self.armed = False
+
+    @staticmethod
+    def _ok(w):
+        return (torch.is_tensor(w) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
+                and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 and w.data_ptr() % 16 == 0)
+
+    def begin_step(self):
+        self.ready = {}
+        self.armed = True
+        if not self.plan or not WEIGHT_PACK:
+            return
+        lib = _capi.load()
+        jobs, keep = [], []
+        for key, e in self.plan.items():
+            srcs, need = e["srcs"], e["need"]
+            if not need or not all(self._ok(w) for w in srcs) or len({w.shape[0] for w in srcs}) != 1:
+                continue
+            K = srcs[0].shape[0]
+            Ntot = sum(w.shape[1] for w in srcs)
+            dev = srcs[0].device
+            out = {}
+            if "n" in need:
+                out["n"] = torch.empty((Ntot, 3 * K), dtype=torch.bfloat16, device=dev)
+            if "k" in need:
+                out["k"] = torch.empty((K, 3 * Ntot), dtype=torch.bfloat16, device=dev)
+            if "wt" in need:
+                out["wt"] = torch.empty(lib._lpm_weight_tiles_bytes(K, Ntot) // 4, dtype=torch.int32, device=dev)
+            if "wtt" in need and len(srcs) == 1:
+                out["wtt"] = torch.empty(lib._lpm_weight_tiles_bytes(Ntot, K) // 4, dtype=torch.int32, device=dev)
+            off = 0
+            for w in srcs:
+                j = _capi.WeightPackJob()
+                j.w, j.K, j.N, j.ldw, j.Ntot, j.n_off = w.data_ptr(), K, w.shape[1], w.stride(0), Ntot, off
+                j.w3n = out["n"].data_ptr() if "n" in out else None
+                j.w3k = out["k"].data_ptr() if "k" in out else None
+                j.wt = out["wt"].data_ptr() if "wt" in out else None
+                j.wtt = out["wtt"].data_ptr() if "wtt" in out else None
+                jobs.append(j)
+                off += w.shape[1]
+            self.ready[key] = out
+        st = stream_ptr()
+        for i in range(0, len(jobs), _capi.WEIGHT_PACK_MAX_JOBS):
+            chunk = jobs[i:i + _capi.WEIGHT_PACK_MAX_JOBS]
+            arr = (_capi.WeightPackJob * len(chunk))(*chunk)
+            lib.check(lib._lpm_weight_pack(C.cast(arr, C.c_void_p), len(chunk), st), "lpm_weight_pack")
+
+    def end_step(self):
+        self.armed = False
+        self.ready = {}
+
+    def take(self, srcs, forms):
+        """The forms of the weight (or of the concatenation of the weights) ``srcs`` as a dict, or None -- then the caller computes them
+        itself; either way the request is on record for the next ``begin_step``."""
+        if not self.armed:
+            return None
+        if not all(self._ok(w) for w in srcs):
+            return None
+        # keyed by storage, not by object: autograd hands a saved weight back as a fresh tensor object over the same memory
+        key = tuple((w.data_ptr(), w.shape[0], w.shape[1]) for w in srcs)
+        e = self.plan.get(key)
+        if e is None:
+            e = self.plan[key] = {"srcs": [w.detach() for w in srcs], "need": set()}
+        e["need"].update(forms)
+        got = self.ready.get(key)
+        if got is None or any(f not in got for f in forms):
+            return None
+        return {f: got[f] for f in forms}
+
+
+_ACTIVE_PACK = None      # the WeightPack of the trainer whose step is running (train.Trainer.step), else None
+# "0": every consumer derives its own operand forms, one launch each (A/B)
+WEIGHT_PACK = os.environ.get("LPM_WEIGHT_PACK", "1") != "0"
+
+
+def _packed(srcs, forms):
+    return _ACTIVE_PACK.take(srcs, forms) if _ACTIVE_PACK is not None else None
+
+
+def _weight_tiles(W, R, N, transposed, like):
+    """lpm_split_weight_tiles(W, R, N, transposed) -- from the step's weight pack when it holds the form."""
+    lib = _capi.load()
+    got = _packed([W], ["wtt" if transposed else "wt"])
+    if got is not None:
+        return got["wtt" if transposed else "wt"]
+    wt = _tile_buffer(lib._lpm_weight_tiles_bytes(R, N), like)
+    lib.check(lib._lpm_split_weight_tiles(ptr(W), R, N, 1 if transposed else 0, ptr(wt), stream_ptr()), "lpm_split_weight_tiles")
+    return wt
+
+
+def _split_weight_cat(Ws, need_t=True):
+    """_split_weight of the concatenation of Ws along the columns (q | k | v) -- without forming it when the weight pack has the images."""
+    got = _packed(list(Ws), ["n", "k"] if need_t else ["n"])
+    if got is not None:
+        return got["n"], got.get("k")
+    return _split_weight(torch.cat([_f32(w, "kernel") for w in Ws], dim=1), need_t, pack=False)
+
+
+def _split_weight(W, need_t=True, pack=True):
     """[K,N] fp32 -> w3n [N,3K] (rows [Wh^T|Wh^T|Wl^T]: y = X3 w3n^T) and w3k [K,3N] (rows [Wh|Wl|Wh]: dx = DY3 w3k^T), bf16."""
     lib = _capi.load()
+    if pack:
+        got = _packed([W], ["n", "k"] if need_t else ["n"])
+        if got is not None:
+            return got["n"], got.get("k")
     K, N = W.shape
     w3n = torch.empty((N, 3 * K), dtype=torch.bfloat16, device=W.device)
     w3k = torch.empty((K, 3 * N), dtype=torch.bfloat16, device=W.device) if need_t else None
@@ -1168,9 +1283,8 @@ class _QKVX3(torch.autograd.Function):
     def forward(ctx, x2d, Wq, Wk, Wv, row_scale=None):
         x2d = _rows(x2d, "dense input")
         K, N = Wq.shape
-        Wcat = torch.cat([_f32(Wq, "q kernel"), _f32(Wk, "k kernel"), _f32(Wv, "v kernel")], dim=1)
         x3 = _split_rows(x2d, row_scale=row_scale)
-        w3n, w3k = _split_weight(Wcat, need_t=ctx.needs_input_grad[0])
+        w3n, w3k = _split_weight_cat([Wq, Wk, Wv], need_t=ctx.needs_input_grad[0])
         ctx.save_for_backward(x3, w3k)
         ctx.dims = (K, N)
         ctx.wrefs = (Wq, Wk, Wv)
@@ -1322,8 +1436,7 @@ class _FFNX3(torch.autograd.Function):
             st = stream_ptr()
             yr = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, F), y2d)
             lib.check(lib._lpm_split_rows_tiles(ptr(y2d), y2d.stride(0), 1, M, F, ptr(yr), st), "lpm_split_rows_tiles")
-            w1t = _tile_buffer(lib._lpm_weight_tiles_bytes(F, H), y2d)
-            lib.check(lib._lpm_split_weight_tiles(ptr(W1), F, H, 0, ptr(w1t), st), "lpm_split_weight_tiles")
+            w1t = _weight_tiles(W1, F, H, False, y2d)
             f3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=y2d.device)
             lib.check(lib._lpm_dense_tiles_act_image_fwd(ptr(yr), ptr(w1t), ptr(b1.contiguous()), M, F, H, ptr(f3), st),
                       "lpm_dense_tiles_act_image_fwd")
@@ -1358,8 +1471,7 @@ class _FFNX3(torch.autograd.Function):
             W2 = w23k                                                     # (saved in its place: the fp32 weight [H, N])
             dor = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), f3)
             lib.check(lib._lpm_image_row_tiles(ptr(do3), M, N, 1, ptr(dor), st), "lpm_image_row_tiles")
-            w2tt = _tile_buffer(lib._lpm_weight_tiles_bytes(N, H), f3)
-            lib.check(lib._lpm_split_weight_tiles(ptr(W2), N, H, 1, ptr(w2tt), st), "lpm_split_weight_tiles")
+            w2tt = _weight_tiles(W2, N, H, True, f3)
             wsb = lib._lpm_dense_tiles_relu_bwd_workspace_bytes(M, H)
             ws = torch.empty(wsb // 4, dtype=torch.float32, device=f3.device)
             lib.check(lib._lpm_dense_tiles_relu_bwd_image(ptr(dor), ptr(w2tt), ptr(f3), M, N, H, ptr(dp3), ptr(db1), ptr(ws), wsb, st),

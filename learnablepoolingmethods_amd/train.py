@@ -417,6 +417,7 @@ class Trainer:
         self.bucket_gather = None
         self.factored = None
         self.sharded: Optional[ShardedVariableUpdate] = None
+        self.weight_pack = ops.WeightPack() if self.device.type == "cuda" else None
 
     @property
     def num_towers(self) -> int:
@@ -567,6 +568,19 @@ class Trainer:
         if self.bucket_gather is not None:
             self.bucket_gather.arm()
         model_input = self._normalize_input(model_input_raw, num_frames)                        # train.py:262-264
+        if self.weight_pack is not None:
+            # every dense weight's operand forms for this step's forward AND backward in one launch (ops.WeightPack); a sharded
+            # hidden1_weights is not among them (its all-gather may still be in flight: only the projection reads it)
+            self.weight_pack.begin_step()
+            ops._ACTIVE_PACK = self.weight_pack
+        try:
+            return self._step_body(model_input_raw, model_input, num_frames, labels, kw)
+        finally:
+            if self.weight_pack is not None:
+                ops._ACTIVE_PACK = None
+                self.weight_pack.end_step()
+
+    def _step_body(self, model_input_raw, model_input, num_frames, labels, kw):
         result, reg_losses = self._forward(model_input, num_frames, labels, **kw)
         predictions = result["predictions"]
         label_loss = result["loss"] if "loss" in result else self.loss_fn.calculate_loss(predictions, labels)  # :291-294

@@ -697,6 +697,61 @@ def test_clip_wide_aggregation(B, T, D, K, residual):
         assert_close(asum, asum0, tol=2e-6, what="assignment sums vs the 128 x 128 form")
 
 
+def test_weight_pack_matches_the_single_weight_entry_points():
+    """lpm_weight_pack (weight_pack.hip): every operand form of a list of weights -- among them the column blocks of a concatenated
+    q | k | v weight -- from ONE launch, bit for bit what lpm_split_weight / lpm_split_weight_tiles write one weight at a time
+    (transformer_utils.py:559-561,583,701-711: the kernels of tf.layers.dense, constant within a step); and ops.WeightPack around it:
+    nothing on the first armed step (the requests are recorded), everything from the second, nothing outside a step."""
+    import ctypes as C
+    from learnablepoolingmethods_amd import _capi, ops
+    from learnablepoolingmethods_amd.ops import ptr, stream_ptr
+    dev = cuda()
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(3)
+    Wq, Wk, Wv = (torch.randn(128, 96 if i == 1 else 64, generator=g).to(dev) for i in range(3))
+    W1 = torch.randn(64, 256, generator=g).to(dev)
+    W2 = torch.randn(256, 64, generator=g).to(dev)
+
+    def single(W, need_t=True):
+        K, N = W.shape
+        w3n = torch.empty((N, 3 * K), dtype=torch.bfloat16, device=dev)
+        w3k = torch.empty((K, 3 * N), dtype=torch.bfloat16, device=dev) if need_t else None
+        lib.check(lib._lpm_split_weight(ptr(W), K, N, ptr(w3n), ptr(w3k), stream_ptr()), "split_weight")
+        return w3n, w3k
+
+    def tiles(W, R, N, tr):
+        wt = torch.empty(lib._lpm_weight_tiles_bytes(R, N) // 4, dtype=torch.int32, device=dev)
+        lib.check(lib._lpm_split_weight_tiles(ptr(W), R, N, tr, ptr(wt), stream_ptr()), "split_weight_tiles")
+        return wt
+    cat = torch.cat([Wq, Wk, Wv], 1)
+    want = {"qkv": single(cat), "w1": (single(W1)[1], tiles(W1, 64, 256, 0)), "w2": (single(W2, False)[0], tiles(W2, 64, 256, 1))}
+    pack = ops.WeightPack()
+    assert pack.take([W1], ["k"]) is None                       # not armed: consumers compute their own
+    for step in range(3):
+        pack.begin_step()
+        got_qkv = pack.take([Wq, Wk, Wv], ["n", "k"])
+        got_w1 = pack.take([W1], ["k", "wt"])
+        got_w2 = pack.take([W2.detach()], ["n", "wtt"])          # (a fresh tensor object over the same storage: autograd's saved weight)
+        if step == 0:
+            assert got_qkv is None and got_w1 is None and got_w2 is None
+        else:
+            torch.cuda.synchronize()
+            assert torch.equal(got_qkv["n"], want["qkv"][0]) and torch.equal(got_qkv["k"], want["qkv"][1])
+            assert torch.equal(got_w1["k"], want["w1"][0]) and torch.equal(got_w1["wt"], want["w1"][1])
+            assert torch.equal(got_w2["n"], want["w2"][0]) and torch.equal(got_w2["wtt"], want["w2"][1])
+        pack.end_step()
+    assert len(pack.plan) == 3
+    # shapes the kernel does not take go through the consumers' own calls: never recorded, never an error
+    pack.begin_step()
+    assert pack.take([torch.randn(40, 64, device=dev)], ["n"]) is None and len(pack.plan) == 3
+    pack.end_step()
+    # the C entry refuses what it cannot do
+    j = _capi.WeightPackJob()
+    j.w, j.K, j.N, j.ldw, j.Ntot, j.n_off, j.w3n = W1.data_ptr(), 64, 250, 256, 250, 0, want["w1"][0].data_ptr()
+    arr = (_capi.WeightPackJob * 1)(j)
+    assert lib._lpm_weight_pack(C.cast(arr, C.c_void_p), 1, stream_ptr()) != 0 and "N % 32" in lib.last_error().replace("%%", "%")
+
+
 @pytest.mark.parametrize("M,C,relu", [(24000, 4096, True), (1200, 256, True), (777, 128, False), (20000, 1024, False)])
 def test_bias_act_in_place(M, C, relu):
     """ops.bias_act: tf.layers.dense's bias add (+ ReLU) as one in-place pass; backward = ReLU mask from the saved output + the bias
