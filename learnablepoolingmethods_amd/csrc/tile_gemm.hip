@@ -26,8 +26,11 @@ static size_t tg_lds_bytes(int ntw, int epi) {
 // 128 registers): 32 KB staged per 256 x 256 x 16 products (262 MFMA-flop per byte) and 12 KB of fragment reads per 24 MFMAs and
 // wave instead of 8 KB per 12 -- the LDS read volume is what holds the 128-row form at ~1.1 PFLOP/s on the encoder's dense shapes.
 // FORM 1 (MW = 2, round 4): the two wave groups of a workgroup run in ANTI-PHASE -- see the branch below.
-template <int NTW, int EPI, int MW, int NS, int PL, int RTW = 2, int FORM = 0>
+// DBG 1: the measurement switches of TileGemmArgs::dbg are live (LPM_TG_DBG; a separate instantiation: the production kernels carry no
+// such branches -- as run-time tests around the MFMA groups they cost K1 30 %: 42.5 -> 55.5 us, measured in round 4)
+template <int NTW, int EPI, int MW, int NS, int PL, int RTW = 2, int FORM = 0, int DBG = 0>
 __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2) void tile_gemm_kernel(const TileGemmArgs g) {
+    const int dbg = DBG ? g.dbg : 0;
     static_assert(FORM == 0 || (MW == 2 && EPI == TG_EPI_STORE), "the anti-phase form: 128- / 256-row workgroups, store epilogue");
     static_assert(RTW == 2 || (RTW == 4 && MW == 2 && EPI == TG_EPI_STORE && NS >= 4), "four row tiles per wave: pipelined 128-row form only");
     static_assert(MW == 1 || EPI == TG_EPI_STORE, "the 128-row form has the store epilogue only");
@@ -320,27 +323,27 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                         else acc[m][n] = tg_mfma(t ? cur.al[m] : cur.ah[m], t ? cur.bl[n] : cur.bh[n], acc[m][n]);
                     }
             };
-            if (!(g.dbg & 8)) mfma_term(0);
+            if (!(dbg & 8)) mfma_term(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + NS - 1 < nstep && !(g.dbg & 4)) issue(s + NS - 1);
+            if (s + NS - 1 < nstep && !(dbg & 4)) issue(s + NS - 1);
             __builtin_amdgcn_sched_barrier(0);
-            if ((PL == 2 || 2 * s + 1 < nred) && !(g.dbg & 8)) mfma_term(1);
+            if ((PL == 2 || 2 * s + 1 < nred) && !(dbg & 8)) mfma_term(1);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < nstep) read_frags(s + 1, nxt);
             __builtin_amdgcn_sched_barrier(0);
-            if (PL == 2 && !(g.dbg & 8)) mfma_term(2);
+            if (PL == 2 && !(dbg & 8)) mfma_term(2);
         };
         Frag fa, fb;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");      // step 0 has landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         read_frags(0, fa);
-        const int nrun = (g.dbg & 1) ? 0 : nstep;        // (measurement: LPM_TG_DBG, see the launcher)
+        const int nrun = (dbg & 1) ? 0 : nstep;        // (measurement: LPM_TG_DBG, see the launcher)
         for (int s = 0; s < nrun; s += 2) {
             body(s, fa, fb);
             if (s + 1 < nstep) body(s + 1, fb, fa);
         }
-        if (g.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     const int N = g.cols_valid;
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                         const float4 o = *p;
                         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     }
-                    if (g.dbg & 2) { if (v.x == 123456.f) *p = v; }      // (measurement: no stores)
+                    if (dbg & 2) { if (v.x == 123456.f) *p = v; }      // (measurement: no stores)
                     else if (g.nt_store)      // a result far larger than the caches, read much later
                         __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
                     else *p = v;
@@ -703,9 +706,11 @@ static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream
         if (wide4 && ap) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL, 4, 1>), 512);
         else if (wide && !wide2 && ap) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL, 2, 1>), 512);
         else if (wide4 && wide4_ns == 5) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 5, PL, 4>), 512);
+        else if (wide4 && dbg_env) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL, 4, 0, 1>), 512);
         else if (wide4) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL, 4>), 512);
         else if (wide2) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 3, PL>), 512);
         else if (wide && wide_ns == 5) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 5, PL>), 512);
+        else if (wide && dbg_env) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL, 2, 0, 1>), 512);
         else if (wide) LPM_TG_LAUNCH_K((tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, PL>), 512);
         else if (ntw == 1) LPM_TG_LAUNCH(1);
         else if (ntw == 2) LPM_TG_LAUNCH(2);

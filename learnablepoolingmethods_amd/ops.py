@@ -732,7 +732,12 @@ class _NetVLAD(torch.autograd.Function):
                 xr = _tile_buffer(lib._lpm_row_tiles_bytes(B, T, D), x)
                 with _timed("split_rows_tiles", (M, D)):
                     lib.check(lib._lpm_split_rows_tiles(ptr(x), x.stride(0), B, T, D, ptr(xr), st), "lpm_split_rows_tiles")
-            wt = _weight_tiles(W, D, K, False, x)
+            # NOT from the step's weight pack: K1 streams its 1 MB of weight tiles once per workgroup, a fresh 16 KB per step that all
+            # workgroups of an XCD want at the same moment -- its loop is bound by the latency of that first touch.  Written right here
+            # the tiles are still in the memory-side cache when K1 starts (42.9 us); written at the top of the step, 700 MB of frame
+            # preparation earlier, they come from HBM (54.8 us; measured in one process, LPM_WEIGHT_PACK A/B, round 4).  (Reading them into every XCD's L2 with
+            # a small launch in front of K1 on top of that: no effect, 43.5-45.2 vs 43.9-44.6 us.)
+            wt = _weight_tiles(W, D, K, False, x, pack=False)
             with _timed("assign_gemm_fwd", (M, D, K)):
                 lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st),
                           "lpm_assign_gemm_tiles_fwd")
@@ -1198,10 +1203,10 @@ def _packed(srcs, forms):
     return _ACTIVE_PACK.take(srcs, forms) if _ACTIVE_PACK is not None else None
 
 
-def _weight_tiles(W, R, N, transposed, like):
+def _weight_tiles(W, R, N, transposed, like, pack=True):
     """lpm_split_weight_tiles(W, R, N, transposed) -- from the step's weight pack when it holds the form."""
     lib = _capi.load()
-    got = _packed([W], ["wtt" if transposed else "wt"])
+    got = _packed([W], ["wtt" if transposed else "wt"]) if pack else None
     if got is not None:
         return got["wtt" if transposed else "wt"]
     wt = _tile_buffer(lib._lpm_weight_tiles_bytes(R, N), like)
