@@ -452,6 +452,11 @@ int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const f
 int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, int order, void* out3,
                    lpm_stream_t stream);
 int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w3k, lpm_stream_t stream);
+/* The split-K partial sums [Z, K, N] of a weight-gradient product (a batched library GEMM over Z slices of the token reduction) added in
+ * slice order and written straight into up to three [K, N / nouts] destinations -- the gradient slots of the column blocks of a
+ * concatenated weight (q | k | v): one launch instead of one strided reduction per destination (TF autodiff of tf.layers.dense,
+ * transformer_utils.py:559-561,583,701-711).  N / nouts a multiple of 4; unused destinations NULL. */
+int lpm_sum_splits(const float* part, int Z, int K, int N, float* out0, float* out1, float* out2, int nouts, lpm_stream_t stream);
 
 /* Every operand form of every dense-layer weight of a step in ONE launch (weight_pack.hip, round 4): a job names a weight W [K, N]
  * (row stride ldw) -- or the column block [n_off, n_off + N) of a concatenated weight with Ntot columns (q | k | v) -- and the forms

@@ -158,7 +158,8 @@ SIGNATURES = {
     "lpm_factored_clip_adam_q": (_i, [_f, _f, _f, _l, _f, _i, _i, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
     "lpm_factored_clip_adam": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
     "lpm_multi_tensor_clip_adam": (_i, [_f, _f, _f, _f, _f, _i, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _f]),
-    "lpm_weight_pack": (_i, [_f, _i, _f]),          # (jobs: a HOST array of WeightPackJob)
+    "lpm_weight_pack": (_i, [_f, _i, _f]),
+    "lpm_sum_splits": (_i, [_f, _i, _i, _i, _f, _f, _f, _i, _f]),          # (jobs: a HOST array of WeightPackJob)
 }
 WEIGHT_PACK_MAX_JOBS = 24
 

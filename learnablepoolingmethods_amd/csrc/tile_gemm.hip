@@ -835,6 +835,29 @@ __global__ __launch_bounds__(256) void tg_reduce_splits_kernel(const float4* __r
     out[i] = s;
 }
 
+// outs[i][k][c] = sum_z part[z][k][i * (N / nouts) + c]: the split-K partial sums of a weight-gradient GEMM [Z, K, N] added in slice order
+// straight into up to three destination matrices [K, N / nouts] (the q | k | v kernels' gradient slots: one launch instead of three
+// strided reductions).  float4 granularity; thread = one float4 of one destination row.
+struct SumSplitsArgs { const float* part; float* out[3]; int Z, K, N, nouts; };
+__global__ __launch_bounds__(256) void sum_splits_kernel(const SumSplitsArgs a) {
+    const int Nb = a.N / a.nouts, Nb4 = Nb / 4;
+    const int64_t per = (int64_t)a.K * Nb4, total = per * a.nouts;
+    const int64_t zstride = (int64_t)a.K * a.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int o = (int)(i / per);
+        const int64_t r = i - (int64_t)o * per;
+        const int64_t k = r / Nb4;
+        const int c = (int)(r - k * Nb4) * 4;
+        const float* p = a.part + k * a.N + (int64_t)o * Nb + c;
+        float4 s = *reinterpret_cast<const float4*>(p);
+        for (int z = 1; z < a.Z; ++z) {
+            const float4 q = *reinterpret_cast<const float4*>(p + z * zstride);
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+        *reinterpret_cast<float4*>(a.out[o] + k * Nb + c) = s;
+    }
+}
+
 // colpart [nblk][N] -> out [N]  (fp64 accumulation; 1024 threads per 16 columns, partial_colsums16)
 __global__ __launch_bounds__(1024) void tg_colsum_reduce_kernel(const float* __restrict__ colpart, int nblk, int N, float* __restrict__ out) {
     double s, q;
@@ -880,6 +903,22 @@ static inline int dw_splits(int B, int T, int D, int K, int planes = 2) {
 }
 
 }  // namespace lpm
+
+// Split-K partial sums of a weight-gradient product [Z, K, N] (what a batched library GEMM over Z slices of a long reduction leaves) ->
+// the gradient, added in slice order, written straight into up to three [K, N / nouts] destinations (the column blocks of a concatenated
+// weight: q | k | v): TF autodiff of tf.layers.dense at transformer_utils.py:559-561,583,701-711.  N / nouts a multiple of 4.
+extern "C" int lpm_sum_splits(const float* part, int Z, int K, int N, float* out0, float* out1, float* out2, int nouts, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(part && out0 && Z >= 1 && K > 0 && N > 0 && nouts >= 1 && nouts <= 3, LPM_ERR_BADARG, "lpm_sum_splits: bad arguments");
+    LPM_REQUIRE(N % nouts == 0 && (N / nouts) % 4 == 0 && (nouts < 2 || out1) && (nouts < 3 || out2), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_sum_splits: N / nouts must be a multiple of 4 and every destination given (N=%d nouts=%d)", N, nouts);
+    LPM_REQUIRE((((uintptr_t)part | (uintptr_t)out0 | (uintptr_t)out1 | (uintptr_t)out2) & 15) == 0, LPM_ERR_BADARG, "lpm_sum_splits: 16-byte aligned pointers");
+    SumSplitsArgs a{part, {out0, out1, out2}, Z, K, N, nouts};
+    const int64_t total = (int64_t)K * (N / 4);
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("lpm_sum_splits");
+}
 
 extern "C" size_t lpm_row_tiles_bytes(int B, int T, int C) {
     return (size_t)B * lpm::row_tiles_per_clip(T) * (C / 16) * 2048;

@@ -47,25 +47,41 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const WPArgs a) {
         const float v = g.w[(int64_t)(k0 + kl) * g.ldw + n0 + tx];
         const unsigned h = wp_rne(v);
         const unsigned l = wp_rne(v - __uint_as_float(h << 16));
-        if (w3k) {
-            unsigned short* row = w3k + (int64_t)(k0 + kl) * 3 * g.Ntot + g.n_off + n0 + tx;
-            row[0] = (unsigned short)h;
-            row[g.Ntot] = (unsigned short)l;
-            row[2 * (int64_t)g.Ntot] = (unsigned short)h;
-        }
         th[kl][tx] = (unsigned short)h;
         tl[kl][tx] = (unsigned short)l;
     }
     __syncthreads();
-    if (w3n) {
+    // the two images leave as 16-byte pieces (8 bf16): threads 0-127 write the w3k rows (row k: 8 consecutive n), threads 128-255 the w3n
+    // rows (row n: 8 consecutive k, the tile read down its columns) -- 2-byte stores made this kernel 51 us for 12 jobs at cfg-2
+    {
+        const int r = (tid & 127) >> 2, c8 = (tid & 3) * 8;
+        unsigned hv[4], lv[4];
+        if (tid < 128) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int nl = ty + 8 * i;
-            const unsigned short h = th[tx][nl], l = tl[tx][nl];
-            unsigned short* row = w3n + (int64_t)(g.n_off + n0 + nl) * 3 * g.K + k0 + tx;
-            row[0] = h;
-            row[g.K] = h;
-            row[2 * (int64_t)g.K] = l;
+            for (int e = 0; e < 4; ++e) {
+                hv[e] = (unsigned)th[r][c8 + 2 * e] | ((unsigned)th[r][c8 + 2 * e + 1] << 16);
+                lv[e] = (unsigned)tl[r][c8 + 2 * e] | ((unsigned)tl[r][c8 + 2 * e + 1] << 16);
+            }
+            if (w3k) {
+                unsigned short* row = w3k + (int64_t)(k0 + r) * 3 * g.Ntot + g.n_off + n0 + c8;
+                const uint4 H = make_uint4(hv[0], hv[1], hv[2], hv[3]), L = make_uint4(lv[0], lv[1], lv[2], lv[3]);
+                *reinterpret_cast<uint4*>(row) = H;
+                *reinterpret_cast<uint4*>(row + g.Ntot) = L;
+                *reinterpret_cast<uint4*>(row + 2 * (int64_t)g.Ntot) = H;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hv[e] = (unsigned)th[c8 + 2 * e][r] | ((unsigned)th[c8 + 2 * e + 1][r] << 16);
+                lv[e] = (unsigned)tl[c8 + 2 * e][r] | ((unsigned)tl[c8 + 2 * e + 1][r] << 16);
+            }
+            if (w3n) {
+                unsigned short* row = w3n + (int64_t)(g.n_off + n0 + r) * 3 * g.K + k0 + c8;
+                const uint4 H = make_uint4(hv[0], hv[1], hv[2], hv[3]), L = make_uint4(lv[0], lv[1], lv[2], lv[3]);
+                *reinterpret_cast<uint4*>(row) = H;
+                *reinterpret_cast<uint4*>(row + g.K) = H;
+                *reinterpret_cast<uint4*>(row + 2 * (int64_t)g.K) = L;
+            }
         }
     }
     // fragment tiles: thread = (16-deep step s2, plane, lane); tile[plane][lane][e] = M[outer = 32 tile + (lane & 31)][red = 16 step + 8 (lane >> 5) + e]
@@ -112,7 +128,7 @@ extern "C" int lpm_weight_pack(const LpmWeightPackJob* jobs, int njobs, lpm_stre
         LPM_REQUIRE(g.w3n || g.w3k || g.wt || g.wtt, LPM_ERR_BADARG, "lpm_weight_pack: job %d asks for nothing", j);
         LPM_REQUIRE(!g.wtt || (g.n_off == 0 && g.Ntot == g.N), LPM_ERR_UNSUPPORTED_SHAPE,
                     "lpm_weight_pack: job %d: the transposed tiles are written for whole weights only", j);
-        LPM_REQUIRE((((uintptr_t)g.wt | (uintptr_t)g.wtt) & 15) == 0 && (((uintptr_t)g.w3n | (uintptr_t)g.w3k) & 1) == 0, LPM_ERR_BADARG,
+        LPM_REQUIRE((((uintptr_t)g.wt | (uintptr_t)g.wtt | (uintptr_t)g.w3n | (uintptr_t)g.w3k) & 15) == 0, LPM_ERR_BADARG,
                     "lpm_weight_pack: job %d: misaligned output", j);
         a.first[j] = (int)total;
         a.job[j] = g;

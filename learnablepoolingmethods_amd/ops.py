@@ -1194,6 +1194,8 @@ class WeightPack:
         return {f: got[f] for f in forms}
 
 
+# the split-K partial sums of the encoders' weight-gradient GEMMs added into their arena slots by lpm_sum_splits; "0": torch.sum per slot (A/B)
+SUM_SPLITS = os.environ.get("LPM_SUM_SPLITS", "1") != "0"
 _ACTIVE_PACK = None      # the WeightPack of the trainer whose step is running (train.Trainer.step), else None
 # "0": every consumer derives its own operand forms, one launch each (A/B)
 WEIGHT_PACK = os.environ.get("LPM_WEIGHT_PACK", "1") != "0"
@@ -1398,6 +1400,16 @@ def _dw_x3_impl(x3, dy3, K, N, outs):
     if outs is None:
         return full if full is not None else part.sum(0)
     slots = [_grad_slot(W) for W, _, _ in outs]
+    if (SUM_SPLITS and part is not None and all(sl is not None and sl.is_contiguous() for sl in slots) and len(outs) <= 3
+            and all(nc == N // len(outs) and c0 == i * (N // len(outs)) for i, (_, c0, nc) in enumerate(outs)) and (N // len(outs)) % 4 == 0):
+        # every destination is a free arena slot and the column blocks tile the product evenly: ONE launch adds the split-K partial sums
+        # into all of them (lpm_sum_splits) instead of one strided torch reduction per destination
+        lib = _capi.load()
+        sp = [ptr(sl) for sl in slots] + [None] * (3 - len(slots))
+        lib.check(lib._lpm_sum_splits(ptr(part), part.shape[0], K, N, sp[0], sp[1], sp[2], len(slots), stream_ptr()), "lpm_sum_splits")
+        for W, _, _ in outs:
+            _grad_done(W)
+        return tuple(None for _ in outs)
     if all(sl is None for sl in slots) and full is None:
         full = part.sum(0)
     res = []

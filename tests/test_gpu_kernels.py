@@ -697,6 +697,28 @@ def test_clip_wide_aggregation(B, T, D, K, residual):
         assert_close(asum, asum0, tol=2e-6, what="assignment sums vs the 128 x 128 form")
 
 
+@pytest.mark.parametrize("Z,K,N,nouts", [(4, 128, 384, 3), (8, 64, 64, 1), (2, 96, 256, 2), (1, 32, 12, 3)])
+def test_sum_splits_into_column_block_destinations(Z, K, N, nouts):
+    """lpm_sum_splits: the split-K partial sums [Z, K, N] of a weight-gradient GEMM added in slice order into nouts separate [K, N / nouts]
+    matrices (the q | k | v gradient slots) -- the same additions in the same order as torch.sum over the slices."""
+    from learnablepoolingmethods_amd import _capi
+    from learnablepoolingmethods_amd.ops import ptr, stream_ptr
+    dev = cuda()
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(Z * K + N)
+    part = torch.randn(Z, K, N, generator=g).to(dev)
+    outs = [torch.full((K, N // nouts), float("nan"), device=dev) for _ in range(nouts)]
+    p = [ptr(o) for o in outs] + [None] * (3 - nouts)
+    lib.check(lib._lpm_sum_splits(ptr(part), Z, K, N, p[0], p[1], p[2], nouts, stream_ptr()), "lpm_sum_splits")
+    torch.cuda.synchronize()
+    ref = part[0].clone()
+    for z in range(1, Z):
+        ref += part[z]
+    for i, o in enumerate(outs):
+        assert torch.equal(o, ref[:, i * (N // nouts):(i + 1) * (N // nouts)])
+    assert lib._lpm_sum_splits(ptr(part), Z, K, N, p[0], None, None, 2, stream_ptr()) != 0      # a missing destination is refused
+
+
 def test_weight_pack_matches_the_single_weight_entry_points():
     """lpm_weight_pack (weight_pack.hip): every operand form of a list of weights -- among them the column blocks of a concatenated
     q | k | v weight -- from ONE launch, bit for bit what lpm_split_weight / lpm_split_weight_tiles write one weight at a time
@@ -1408,7 +1430,8 @@ def test_layer_norm_image_is_the_split_of_its_output(B, L, F, lazy):
     y0 = ops._ResidualLayerNorm.forward(c0, a, r, gamma, beta, bias, False, None, rs)
     y1 = ops._ResidualLayerNorm.forward(c1, a, r, gamma, beta, bias, False, None, rs, image=True)
     assert torch.equal(y0, y1)
-    y3 = y1._lpm_y3
+    y3, dptr, ver = y1._lpm_y3                      # (the image travels with the identity of the tensor it images: ops._FFNBlockX3)
+    assert dptr == y1.data_ptr() and ver == y1._version
     assert y3.shape == (B * L, 3 * F) and y3.dtype == torch.bfloat16
     assert torch.equal(y3.view(torch.int16), ops._split_rows(y1.view(B * L, F)).view(torch.int16))
 

@@ -1,4 +1,4 @@
-for v in "LPM_K1_PREFETCH=1" "LPM_K1_PREFETCH=0" "LPM_K1_PREFETCH=1" "LPM_K1_PREFETCH=0"; do
+for v in "LPM_TG_WIDE_NS=4" "LPM_TG_WIDE_NS=5" "LPM_TG_WIDE_NS=4" "LPM_TG_WIDE_NS=5"; do
   env $v python bench.py --no-cpu-baseline --no-dispatch-count > gpurun_out/r04_ab.json 2>/dev/null
   python - <<PY
 import json
