@@ -7,10 +7,10 @@
 //                                                   partial sums [split][M][N] + a reduce pass (tile_gemm's tg_reduce_splits layout)
 //   backward dx[M, Kd] = dy[M, N] . W^T            (lpm_proj_dx below)
 //
-// Forward: 512 threads = 8 waves x 64 columns; per slab the workgroup brings W[16][512] (32 KB, contiguous when N = 512) and
-// x[M][16] (<= 8 KB) into an LDS ring by LDS-DMA -- both images are plain row-major, which is exactly what a lane-linear DMA writes.
-// The B fragment of v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane while W is n-contiguous: a lane gathers its 8 values with
-// eight ds_read_b32 down a column (bank = n mod 32: conflict-free), splits them (hi = bf16(w), lo = bf16(w - hi)) and keeps the two
+// Forward: 8 computing waves x 64 columns + a loader wave for x; per slab the workgroup brings W[16][512] (32 KB, contiguous when N = 512)
+// and, per pair of slabs, x[M][32] into LDS rings by LDS-DMA -- both images are plain row-major, which is exactly what a lane-linear DMA
+// writes.  The B fragment of v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane while W is n-contiguous: a lane gathers its 8 values
+// with eight ds_read_b32 down a column (bank = n mod 32: conflict-free), splits them (hi = bf16(w), lo = bf16(w - hi)) and keeps the two
 // planes in registers; x fragments are two ds_read_b128 per tile.  3 MFMAs per product (x_h W_h + x_h W_l + x_l W_h), fp32
 // accumulation: the error of the split-bf16 tile GEMMs (~5e-6).
 #include "tile_gemm.h"
@@ -18,86 +18,87 @@
 namespace lpm {
 
 // Ring depth: the pass is a pure stream, so what matters is bytes in flight per CU (HBM latency under load ~2-3 us x 25 GB/s per CU
-// = 50-75 KB): four stages of 34-40 KB, three of them in flight behind the one being consumed (two stages, first form: 2.8 TB/s).
+// = 50-75 KB): four stages of 32 KB, three of them in flight behind the one being consumed.
 constexpr int PJ_NS = 4;                           // ring stages
 constexpr int PJ_WBYTES = 16 * 512 * 4;            // W slab
 constexpr int PJ_AUX = 2;                          // LDS-DMA cache policy of the weight stream: nt (every byte is read once, by one CU)
-template <int MT>
-__host__ __device__ constexpr int pj_stage() { return PJ_WBYTES + MT * 32 * 16 * 4; }   // + x slab: MT x 32 rows x 16 floats
 
-// MT = row tiles (ceil(M / 32))
-// XW (round 3): a NINTH wave brings ALL of x in and does nothing else, in PAIRS of slabs: 128 bytes per row (a whole cache line; the
-// first form asked for every line of x twice, 64 bytes at a time, from 2 MT of the computing waves whose in-order vmcnt queue then held
-// the contiguous weight pieces back behind the scattered x pieces).  x has its own ring of two pair-buffers [MT * 32 rows][128 B]
-// behind the four weight stages; a row's eight 16-byte parts sit XOR-swizzled by (row & 7) -- through the SOURCE address, the LDS image
-// stays lane-linear -- so the 32 rows a fragment read touches, 128 bytes apart, spread over all banks (the 64-byte rows of the first
-// form: 4-way conflicts).  Split ranges start on even slabs so that a pair is one aligned line.
-template <int MT, bool XW>
-__global__ __launch_bounds__(XW ? 576 : 512, 2) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M,
-                                                                     int64_t Kd, int N, int nslab, int splits, float* __restrict__ part, int dbg) {
+// MT = row tiles (ceil(M / 32)).  Eight computing waves (64 columns each) bring the weight slabs in; a NINTH wave brings ALL of x in and
+// does nothing else, in PAIRS of slabs: 128 bytes per row = a whole cache line (round 3; before, 2 MT of the computing waves asked for
+// every line of x twice, 64 bytes at a time, and their in-order vmcnt queue held the contiguous weight pieces back behind the scattered
+// x pieces).  x has its own ring of XD pair-buffers of NP pieces (8 rows x 128 bytes each; NP = 4 MT, or 10 for M <= 80 so that three
+// buffers fit) behind the four weight stages; a row's eight 16-byte parts sit XOR-swizzled by (row & 7) -- through the SOURCE address,
+// the LDS image stays lane-linear -- so the 32 rows a fragment read touches, 128 bytes apart, spread over all banks.  Split ranges
+// start on even slabs so that a pair is one aligned line.
+//
+// Round 4 -- THE RING IS READ WITH ds_reads THE COMPILER CANNOT SEE.  To LLVM an LDS-DMA load is a store to LDS that any later LDS read may
+// alias: the plain C++ reads of rounds 1-3 each got an `s_waitcnt vmcnt(0)` in front of them, the loop waited for EVERY stage in flight --
+// also the one it had requested a moment before -- and the four-stage ring ran as "request, wait a full HBM round trip, compute"
+// (cfg-2: 144 us; counted waits as written here: 107 us.  tools/scan_lds_dma_waits.py lists such loops, tests/test_build_flags.py keeps
+// these kernels off that list).  All W reads of a stage are requested at once, the x fragments one row tile ahead; each wait hands its
+// registers over through "+v" operands (the compiler may not touch them earlier, and no scalar load sits in the loop: LDS returns in order,
+// so the lgkmcnt values below count ds_reads only).
+template <int MT, int NP, int XD>
+__global__ __launch_bounds__(576, 1) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M, int64_t Kd,
+                                                          int N, int nslab, int splits, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int nb = blockIdx.y, sp = blockIdx.x;                  // 512-column block, split
     const int npair = nslab >> 1;
-    const int s0 = XW ? 2 * (int)((int64_t)npair * sp / splits) : (int)((int64_t)nslab * sp / splits);
-    const int s1 = XW ? (sp == splits - 1 ? nslab : 2 * (int)((int64_t)npair * (sp + 1) / splits)) : (int)((int64_t)nslab * (sp + 1) / splits);
+    const int s0 = 2 * (int)((int64_t)npair * sp / splits);
+    const int s1 = sp == splits - 1 ? nslab : 2 * (int)((int64_t)npair * (sp + 1) / splits);
     const int ns = s1 - s0;
+    constexpr int PJ_XPAIR = NP * 1024;            // one pair-buffer of x
 
-    // DMA roles.  W: piece p = wave * 4 + j (j < 4): slab row p >> 1, 1 KB half (p & 1) of the row's 512-column segment.
-    //             x: piece = wave: rows wave * 16 + lane / 4 (clamped to M - 1: rows >= M are never stored), 16-byte part lane % 4.
+    if (wave == 8) {
+        // the x loader: piece p = 0 .. NP - 1 of a pair = rows 8 p .. 8 p + 7 (clamped to M - 1: rows >= M are never stored), lane ->
+        // (row r = 8 p + lane / 8, LDS slot q = lane % 8) holding source part q ^ (r & 7); parts 0-3 = slab 2 j, parts 4-7 = slab 2 j + 1
+        // (the last pair of an odd range: its second slab is re-read from the first -- nobody consumes it)
+        const int q = lane & 7;
+        const int part = q ^ ((lane >> 3) & 7);                    // (8 p + lane / 8) & 7 == lane / 8
+        const float* xs[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) xs[p] = x + (int64_t)min(p * 8 + (lane >> 3), M - 1) * ldx + (int64_t)s0 * 16 + part * 4;
+        const int nss = (ns + 1) >> 1;
+        auto issue_x = [&](int j) {
+            unsigned char* st = smem + PJ_NS * PJ_WBYTES + (j % XD) * PJ_XPAIR;
+            const int64_t off = (int64_t)j * 32 - ((part >= 4 && 2 * j + 1 >= ns) ? 16 : 0);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs[p] + off),
+                                                 (__attribute__((address_space(3))) void*)(st + p * 1024), 16, 0, 0);
+        };
+#pragma unroll
+        for (int j = 0; j < XD - 1; ++j)
+            if (j < nss) issue_x(j);
+        for (int s = 0; s < ns; ++s) {
+            // pair j = s / 2 is consumed by stages 2 j and 2 j + 1; at the barrier of stage 2 j the buffer of pair j - 1 is free again and
+            // pairs j .. j + XD - 2 are on their way (LDS-DMA loads of a wave retire in order: NP per pair)
+            if (!(s & 1)) {
+                if (XD > 2 && (s >> 1) + XD - 2 < nss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD - 2) * NP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (!(s & 1) && (s >> 1) + XD - 1 < nss) issue_x((s >> 1) + XD - 1);
+        }
+        return;
+    }
+    // W DMA: piece p = wave * 4 + j (j < 4): slab row p >> 1, 1 KB half (p & 1) of the row's 512-column segment
     const float* wsrc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int p = wave * 4 + j;
         wsrc[j] = W + ((int64_t)s0 * 16 + (p >> 1)) * N + nb * 512 + (p & 1) * 256 + lane * 4;
     }
-    constexpr int PJ_STAGE = pj_stage<MT>();
-    constexpr int PJ_XPAIR = MT * 32 * 128;        // one pair-buffer of x
-    if constexpr (XW) {
-        if (wave == 8) {
-            // the x loader: piece p = 0 .. 4 MT - 1 of a pair = rows 8 p .. 8 p + 7 (clamped to M - 1: rows >= M are never stored), lane ->
-            // (row r = 8 p + lane / 8, LDS slot q = lane % 8) holding source part q ^ (r & 7); parts 0-3 = slab 2 j, parts 4-7 = slab 2 j + 1
-            // (the last pair of an odd range: its second slab is re-read from the first -- nobody consumes it)
-            const int q = lane & 7;
-            const int part = q ^ ((lane >> 3) & 7);                    // (8 p + lane / 8) & 7 == lane / 8
-            const float* xs[4 * MT];
-#pragma unroll
-            for (int p = 0; p < 4 * MT; ++p) xs[p] = x + (int64_t)min(p * 8 + (lane >> 3), M - 1) * ldx + (int64_t)s0 * 16 + part * 4;
-            const int nss = (ns + 1) >> 1;
-            auto issue_x = [&](int j) {
-                unsigned char* st = smem + PJ_NS * PJ_WBYTES + (j & 1) * PJ_XPAIR;
-                const int64_t off = (int64_t)j * 32 - ((part >= 4 && 2 * j + 1 >= ns) ? 16 : 0);
-#pragma unroll
-                for (int p = 0; p < 4 * MT; ++p)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs[p] + off),
-                                                     (__attribute__((address_space(3))) void*)(st + p * 1024), 16, 0, 0);
-            };
-            issue_x(0);
-            for (int s = 0; s < ns; ++s) {
-                // pair j = s / 2 is consumed by stages 2 j and 2 j + 1; at the barrier of stage 2 j the buffer of pair j - 1 is free again
-                if (!(s & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (!(s & 1) && (s >> 1) + 1 < nss) issue_x((s >> 1) + 1);
-            }
-            return;
-        }
-    }
-    const bool xwave = !XW && wave < 2 * MT;       // x pieces: 2 MT of 16 rows each, one per wave (wave-uniform)
-    const int xr = min(wave * 16 + (lane >> 2), M - 1);
-    const float* xsrc = x + (int64_t)xr * ldx + (int64_t)s0 * 16 + (lane & 3) * 4;
-    constexpr int WSTRIDE = XW ? PJ_WBYTES : PJ_STAGE;
     auto issue = [&](int s) {
-        unsigned char* st = smem + (s % PJ_NS) * WSTRIDE;
+        unsigned char* st = smem + (s % PJ_NS) * PJ_WBYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + ((dbg & 2) ? 0 : (int64_t)s * 16 * N)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (int64_t)s * 16 * N),
                                              (__attribute__((address_space(3))) void*)(st + (wave * 4 + j) * 1024), 16, 0, PJ_AUX);
-        if (xwave)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + ((dbg & 1) ? 0 : (int64_t)s * 16)),
-                                             (__attribute__((address_space(3))) void*)(st + PJ_WBYTES + wave * 1024), 16, 0, 0);
     };
 
     f32x16 acc[MT][2];
@@ -107,51 +108,64 @@ __global__ __launch_bounds__(XW ? 576 : 512, 2) void proj_fwd_kernel(const float
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
+    // LDS byte addresses of this lane's reads: the weight column (row 8 half of the slab, column wave * 64 + l31; a fragment = 8 rows down
+    // that column, bank = column mod 32: conflict-free) and, per row tile, part 2 half of its row of an x pair-buffer (rows past the
+    // buffer, >= M, are never stored: clamped)
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned w_lane = (unsigned)((8 * half) * 512 + wave * 64 + l31) * 4u;
+    unsigned x_lane[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int xrow = (NP < 4 * MT) ? min(m * 32 + l31, NP * 8 - 1) : m * 32 + l31;
+        x_lane[m] = (unsigned)(xrow * 128 + (((2 * half) ^ (xrow & 7)) << 4));
+    }
 
 #pragma unroll
     for (int s = 0; s < PJ_NS - 1; ++s)
         if (s < ns) issue(s);
     for (int s = 0; s < ns; ++s) {
-        // stage s has landed when at most the pieces of the younger stages in flight (two, fewer at the end) remain: 5 (4) per stage
+        // stage s has landed when at most the pieces of the younger stages in flight (two, fewer at the end) remain: 4 per stage
         const int young = min(PJ_NS - 2, ns - 1 - s);
-        if (xwave) {
-            if (young == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (young == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (young == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (young == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (young == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (young == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // stage s is in LDS for everyone; stage (s - 1) % NS is free again
         asm volatile("" ::: "memory");
         if (s + PJ_NS - 1 < ns) issue(s + PJ_NS - 1);
-        const float* wl = reinterpret_cast<const float*>(smem + (s % PJ_NS) * WSTRIDE);
-        const float* xl = reinterpret_cast<const float*>(XW ? smem + PJ_NS * PJ_WBYTES + ((s >> 1) & 1) * PJ_XPAIR : smem + (s % PJ_NS) * PJ_STAGE + PJ_WBYTES);
-        if (dbg & 4) continue;
+        const unsigned wa = smem_lds + (unsigned)(s % PJ_NS) * PJ_WBYTES + w_lane;
+        const unsigned xa = smem_lds + PJ_NS * PJ_WBYTES + (unsigned)((s >> 1) % XD) * PJ_XPAIR;
+        float wv[2][8];
+        constexpr bool PRE = MT <= 3;              // x fragments requested one row tile ahead (MT = 4: no registers left for that)
+        f32x4 xv[2][2];
+        auto read_x = [&](int m) {
+            const unsigned a0 = xa + (x_lane[m] ^ ((unsigned)(s & 1) << 6));               // parts p0, p0 + 1 of the row: 16 bytes apart after the swizzle
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xv[PRE ? (m & 1) : 0][0]) : "v"(a0));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xv[PRE ? (m & 1) : 0][1]) : "v"(a0 ^ 16u));
+        };
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(wv[c][e]) : "v"(wa), "n"(e * 2048 + c * 128));
+        if (PRE) read_x(0);
         tg_u32x4 bh[2], bl[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = wl[(8 * half + e) * 512 + wave * 64 + c * 32 + l31];
+            asm volatile("s_waitcnt lgkmcnt(%8)"
+                         : "+v"(wv[c][0]), "+v"(wv[c][1]), "+v"(wv[c][2]), "+v"(wv[c][3]), "+v"(wv[c][4]), "+v"(wv[c][5]), "+v"(wv[c][6]), "+v"(wv[c][7])
+                         : "n"((1 - c) * 8 + (PRE ? 2 : 0)));
             uint4 hi, lo;
-            tg_split8(v, hi, lo);
+            tg_split8(wv[c], hi, lo);
             bh[c] = tg_u32x4{hi.x, hi.y, hi.z, hi.w};
             bl[c] = tg_u32x4{lo.x, lo.y, lo.z, lo.w};
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            float4 a0, a1;
-            if constexpr (XW) {
-                const int p0 = (s & 1) * 4 + 2 * half;                  // this lane's two 16-byte parts of row m * 32 + l31 (row & 7 == l31 & 7)
-                a0 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 32 + ((p0 ^ (l31 & 7)) << 2));
-                a1 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 32 + (((p0 + 1) ^ (l31 & 7)) << 2));
-            } else {
-                a0 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 16 + 8 * half);
-                a1 = *reinterpret_cast<const float4*>(xl + (m * 32 + l31) * 16 + 8 * half + 4);
-            }
-            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            f32x4* xc = xv[PRE ? (m & 1) : 0];
+            if (!PRE) read_x(m);
+            else if (m + 1 < MT) read_x(m + 1);
+            if (PRE && m + 1 < MT) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xc[0]), "+v"(xc[1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0]), "+v"(xc[1]));
+            const float v[8] = {xc[0][0], xc[0][1], xc[0][2], xc[0][3], xc[1][0], xc[1][1], xc[1][2], xc[1][3]};
             uint4 hi, lo;
             tg_split8(v, hi, lo);
             const tg_u32x4 ah = tg_u32x4{hi.x, hi.y, hi.z, hi.w}, al = tg_u32x4{lo.x, lo.y, lo.z, lo.w};
@@ -259,6 +273,9 @@ __global__ __launch_bounds__(512, 2) void proj_dx_kernel(const uint4* __restrict
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned w_lane = (unsigned)(wave * 2048 + l31 * 64 + (((2 * half) ^ (l31 & 3)) << 4));      // this lane's row (64 B), slot of part 2 half
+    const unsigned a_lane = (unsigned)(PD_WBYTES + lane * 16);
 #pragma unroll
     for (int s = 0; s < PD_NS - 1; ++s)
         if (s < NB) issue(s);
@@ -281,23 +298,29 @@ __global__ __launch_bounds__(512, 2) void proj_dx_kernel(const uint4* __restrict
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + PD_NS - 1 < NB) issue(s + PD_NS - 1);
-        const unsigned char* st = smem + (s % PD_NS) * STAGE;
-        const float* wl = reinterpret_cast<const float*>(st + wave * 2048) + l31 * 16;        // this lane's row (64 B)
-        const tg_u32x4* af = reinterpret_cast<const tg_u32x4*>(st + PD_WBYTES) + lane;
-        // 8 consecutive n of row l31: 16-byte slots 2 half and 2 half + 1 (swizzled)
-        const int q0 = (2 * half) ^ (l31 & 3), q1 = (2 * half + 1) ^ (l31 & 3);
-        const float4 b0 = *reinterpret_cast<const float4*>(wl + q0 * 4);
-        const float4 b1 = *reinterpret_cast<const float4*>(wl + q1 * 4);
-        const float v[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        // (the ring is read with ds_reads the compiler cannot see -- proj_fwd_kernel's comment)
+        const unsigned sb = smem_lds + (unsigned)(s % PD_NS) * STAGE;
+        f32x4 b0, b1;
+        tg_u32x4 ah[MT], al[MT];
+        // 8 consecutive n of row l31: 16-byte slots 2 half and 2 half + 1 (swizzled: slot q holds part q ^ (row & 3))
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b0) : "v"(sb + w_lane));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b1) : "v"(sb + (w_lane ^ 16u)));
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[m]) : "v"(sb + a_lane), "n"((m * 2 + 0) * 1024));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[m]) : "v"(sb + a_lane), "n"((m * 2 + 1) * 1024));
+        }
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(2 * MT));
+        const float v[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
         uint4 hi, lo;
         tg_split8(v, hi, lo);
         const tg_u32x4 bh = tg_u32x4{hi.x, hi.y, hi.z, hi.w}, bl = tg_u32x4{lo.x, lo.y, lo.z, lo.w};
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const tg_u32x4 ah = af[(m * 2 + 0) * 64], al = af[(m * 2 + 1) * 64];
-            acc[m] = tg_mfma(ah, bh, acc[m]);
-            acc[m] = tg_mfma(ah, bl, acc[m]);
-            acc[m] = tg_mfma(al, bh, acc[m]);
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ah[m]), "+v"(al[m]) : "n"(2 * (MT - 1 - m)));
+            acc[m] = tg_mfma(ah[m], bh, acc[m]);
+            acc[m] = tg_mfma(ah[m], bl, acc[m]);
+            acc[m] = tg_mfma(al[m], bh, acc[m]);
         }
     }
     // dx[row][k0 + l31]: the 32 lanes of a half-wave write 128 contiguous bytes per row
@@ -365,6 +388,9 @@ __global__ __launch_bounds__(512, 2) void proj_dx2_kernel(const uint4* __restric
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned w_lane = (unsigned)(wave * 4096 + l31 * 128 + (((2 * half) ^ ((l31 >> 1) & 7)) << 4));   // this lane's row (128 B), slot of chunk 2 half
+    const unsigned a_lane = (unsigned)(PE_WBYTES + lane * 16);
 #pragma unroll
     for (int s = 0; s < PE_NS - 1; ++s)
         if (s < NB) issue(s);
@@ -375,26 +401,32 @@ __global__ __launch_bounds__(512, 2) void proj_dx2_kernel(const uint4* __restric
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + PE_NS - 1 < NB) issue(s + PE_NS - 1);
-        const unsigned char* st = smem + (s % PE_NS) * PE_STAGE;
-        const float* wl = reinterpret_cast<const float*>(st + wave * 4096) + l31 * 32;         // this lane's row (128 B)
-        const tg_u32x4* af = reinterpret_cast<const tg_u32x4*>(st + PE_WBYTES) + lane;
-        const int sw = (l31 >> 1) & 7;
+        // (the ring is read with ds_reads the compiler cannot see -- proj_fwd_kernel's comment)
+        const unsigned sb = smem_lds + (unsigned)(s % PE_NS) * PE_STAGE;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            // 8 consecutive n of row l31, step t: chunks 4 t + 2 half and + 1 (swizzled)
-            const int c0 = 4 * t + 2 * half;
-            const float4 b0 = *reinterpret_cast<const float4*>(wl + ((c0 ^ sw) * 4));
-            const float4 b1 = *reinterpret_cast<const float4*>(wl + (((c0 + 1) ^ sw) * 4));
-            const float v[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            // 8 consecutive n of row l31, step t: chunks 4 t + 2 half and + 1 (swizzled: slot q holds chunk q ^ ((row >> 1) & 7))
+            f32x4 b0, b1;
+            tg_u32x4 ah[MT], al[MT];
+            const unsigned wa = sb + (w_lane ^ ((unsigned)t << 6));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b0) : "v"(wa));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b1) : "v"(wa ^ 16u));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[m]) : "v"(sb + a_lane), "n"(((m * 2 + t) * 2 + 0) * 1024));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[m]) : "v"(sb + a_lane), "n"(((m * 2 + t) * 2 + 1) * 1024));
+            }
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(2 * MT));
+            const float v[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             uint4 hi, lo;
             tg_split8(v, hi, lo);
             const tg_u32x4 bh = tg_u32x4{hi.x, hi.y, hi.z, hi.w}, bl = tg_u32x4{lo.x, lo.y, lo.z, lo.w};
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const tg_u32x4 ah = af[((m * 2 + t) * 2 + 0) * 64], al = af[((m * 2 + t) * 2 + 1) * 64];
-                acc[m] = tg_mfma(ah, bh, acc[m]);
-                acc[m] = tg_mfma(ah, bl, acc[m]);
-                acc[m] = tg_mfma(al, bh, acc[m]);
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ah[m]), "+v"(al[m]) : "n"(2 * (MT - 1 - m)));
+                acc[m] = tg_mfma(ah[m], bh, acc[m]);
+                acc[m] = tg_mfma(ah[m], bl, acc[m]);
+                acc[m] = tg_mfma(al[m], bh, acc[m]);
             }
         }
     }
@@ -429,34 +461,24 @@ extern "C" int lpm_proj_fwd(const float* x, int64_t ldx, const float* W, int M, 
     const int splits = proj_splits(Kd, N), nslab = (int)(Kd / 16), MT = (M + 31) / 32;
     dim3 grid(splits, N / 512);
     hipStream_t s = (hipStream_t)stream;
-    static const int xw = [] { const char* e = getenv("LPM_PROJ_XWAVE"); return (e && e[0] == '0') ? 0 : 1; }();   /* 0: x pieces on waves 0 .. 2 MT - 1 (A/B) */
-#define LPM_PJ(MTV)                                                                                                          \
+#define LPM_PJ(MTV, NPV, XDV)                                                                                                \
     do {                                                                                                                     \
-        static const int dbg = [] { const char* e = getenv("LPM_PROJ_DBG"); return e ? atoi(e) : 0; }();                     \
-        const size_t lds = (xw && !dbg) ? (size_t)PJ_NS * PJ_WBYTES + 2 * MTV * 4096 : (size_t)PJ_NS * pj_stage<MTV>();      \
-        if (xw && !dbg) {                                                                                                    \
-            auto kern = proj_fwd_kernel<MTV, true>;                                                                          \
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
-                (void)hipGetLastError();                                                                                     \
-                set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                             \
-                return LPM_ERR_LAUNCH;                                                                                       \
-            }                                                                                                                \
-            hipLaunchKernelGGL(kern, grid, dim3(576), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace, 0);     \
-        } else {                                                                                                             \
-            auto kern = proj_fwd_kernel<MTV, false>;                                                                         \
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
-                (void)hipGetLastError();                                                                                     \
-                set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                             \
-                return LPM_ERR_LAUNCH;                                                                                       \
-            }                                                                                                                \
-            hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace, dbg);   \
+        const size_t lds = (size_t)PJ_NS * PJ_WBYTES + XDV * NPV * 1024;                                                     \
+        auto kern = proj_fwd_kernel<MTV, NPV, XDV>;                                                                          \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {    \
+            (void)hipGetLastError();                                                                                         \
+            set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                                 \
+            return LPM_ERR_LAUNCH;                                                                                           \
         }                                                                                                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(576), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace);            \
     } while (0)
+    /* three pair-buffers of x where they fit beside the four weight stages (measured: no gain over two once the ring is read without the */
+    /* compiler's waits -- kept where it is free) */
     switch (MT) {
-        case 1: LPM_PJ(1); break;
-        case 2: LPM_PJ(2); break;
-        case 3: LPM_PJ(3); break;
-        default: LPM_PJ(4); break;
+        case 1: LPM_PJ(1, 4, 3); break;
+        case 2: LPM_PJ(2, 8, 3); break;
+        case 3: if (M <= 80) LPM_PJ(3, 10, 3); else LPM_PJ(3, 12, 2); break;
+        default: LPM_PJ(4, 16, 2); break;
     }
 #undef LPM_PJ
     const int64_t n4 = (int64_t)M * N / 4;

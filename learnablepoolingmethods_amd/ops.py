@@ -35,9 +35,10 @@ VLAD_TILES3 = os.environ.get("LPM_VLAD_TILES3", "1") != "0"
 VLAD_FUSED = os.environ.get("LPM_VLAD_FUSED", "0") == "1"
 # a9: the hidden projection's forward / input gradient as hand-written weight-stream kernels (csrc/proj_gemm.hip); "0": library GEMMs (A/B)
 PROJ_STREAM = os.environ.get("LPM_PROJ_STREAM", "1") != "0"
-# ... the input-gradient kernel from this hidden size on (measured, rocprofv3 kernel durations: forward 174 + 21 us vs the library's 219 us at
-# cfg-2, 764 vs 1233 us at cfg-5; dx 267 vs 211 us at cfg-2's N = 512 -- the library stays there --, 1108 vs 1232 us at cfg-5's N = 1024)
-PROJ_DX_STREAM_MIN_N = int(os.environ.get("LPM_PROJ_DX_STREAM_MIN_N", "1024"))
+# ... the input-gradient kernel from this hidden size on (rocprofv3 kernel durations, round 4, the rings read without the compiler's
+# vmcnt(0): forward 107 + 22 us vs the library's 202 us at cfg-2, 480 vs 1060 us at cfg-5; dx 135 vs 212 us at cfg-2's N = 512, 455 vs 1000 us
+# at cfg-5's N = 1024.  Rounds 1-3, every stage waiting a full memory round trip: forward 145 / 600, dx 267 -- the library stayed -- / 634)
+PROJ_DX_STREAM_MIN_N = int(os.environ.get("LPM_PROJ_DX_STREAM_MIN_N", "512"))
 # ... and inside the channel-last batch norm that follows it (ops.batch_norm_rows_act: FeedForwardNetworkMod); "0": ops.bias_act + plain BN
 BN_ACT_FUSED = os.environ.get("LPM_BN_ACT_FUSED", "1") != "0"
 # tf.layers.dense's bias add + ReLU as one in-place pass (ops.bias_act) where the output does not feed the next GEMM's split directly; "0": A/B

@@ -11,4 +11,3 @@ run ops.FFN_MOD_FUSED cfg3
 run ops.MHA_BN_ONEPASS cfg3
 run ops.MHA_BN_MOMENTS cfg3
 run ops.V2_SPLIT_COLUMNS cfg3
-for c in cfg2 cfg5; do for xw in 1 0; do echo "== $c LPM_PROJ_XWAVE=$xw: $(LPM_PROJ_XWAVE=$xw python bench.py --config $c --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['ms_per_step'])")"; done; done
