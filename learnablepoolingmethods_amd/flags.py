@@ -84,3 +84,8 @@ FLAGS.define("hidden1_sharded_update", True, "build extension (data parallel, ro
              "for where the projection reads the variable).  False: route A (bucket all-reduce + full update on every rank)")
 FLAGS.define("hidden1_sharded_min_towers", 0, "build extension: 0 = the sharded route starts right above hidden1_factored_max_towers; "
              "N > 0 = from N towers on, taking precedence over the factored route (tests, A/B on a real node)")
+FLAGS.define("library_gemm_selection", True, "build extension: the fp32 library GEMMs the host code leaves to PyTorch (MoE head, context gating, the "
+             "small-batch projections) run on the hipBLASLt / rocBLAS solutions recorded per shape in _tunable/gfx950_fp32_gemm.csv (PyTorch's "
+             "TunableOp with tuning OFF: a recorded shape takes its recorded solution, any other shape the library's default).  The MoE-4 head of "
+             "BASELINE configs[4] is 159 + 87 us forward on the default choices and 47 + 39 us on the recorded ones; the file is ignored (with a "
+             "warning from PyTorch) where its ROCm / hipBLASLt / rocBLAS / device validators do not match")

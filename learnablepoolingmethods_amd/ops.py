@@ -1202,6 +1202,37 @@ _ACTIVE_PACK = None      # the WeightPack of the trainer whose step is running (
 WEIGHT_PACK = os.environ.get("LPM_WEIGHT_PACK", "1") != "0"
 
 
+_LIBRARY_SELECTION = None       # None: not attempted; True / False: recorded solutions active / not (mismatching validators, switched off, ...)
+LIBRARY_GEMM_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_tunable", "gfx950_fp32_gemm.csv")
+
+
+def enable_library_gemm_selection():
+    """FLAGS.library_gemm_selection: hand PyTorch the per-shape hipBLASLt / rocBLAS solutions recorded for the fp32 GEMMs it runs on this path
+    (TunableOp, tuning off -- nothing is searched or timed at run time).  A process that already configured TunableOp itself (the
+    PYTORCH_TUNABLEOP_* environment, e.g. tools/tune_library_gemms.py regenerating the file) is left alone.  Once per process."""
+    global _LIBRARY_SELECTION
+    if _LIBRARY_SELECTION is not None:
+        return _LIBRARY_SELECTION
+    _LIBRARY_SELECTION = False
+    from . import FLAGS
+    if (not FLAGS.library_gemm_selection or os.environ.get("LPM_LIBRARY_GEMM_SELECTION") == "0" or not torch.cuda.is_available()
+            or "PYTORCH_TUNABLEOP_ENABLED" in os.environ or not os.path.exists(LIBRARY_GEMM_FILE)):
+        return False
+    import torch.cuda.tunable as tunable
+    try:
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.record_untuned_enable(False)
+        _LIBRARY_SELECTION = bool(tunable.read_file(LIBRARY_GEMM_FILE))
+        if not _LIBRARY_SELECTION:
+            tunable.enable(False)
+    except Exception as e:      # an older / differently built PyTorch: the library's default choices are what every round before 4 ran on
+        import warnings
+        warnings.warn(f"library GEMM selection not available ({e}); continuing on the library's default solutions")
+        _LIBRARY_SELECTION = False
+    return _LIBRARY_SELECTION
+
+
 def _packed(srcs, forms):
     return _ACTIVE_PACK.take(srcs, forms) if _ACTIVE_PACK is not None else None
 

@@ -418,6 +418,8 @@ class Trainer:
         self.factored = None
         self.sharded: Optional[ShardedVariableUpdate] = None
         self.weight_pack = ops.WeightPack() if self.device.type == "cuda" else None
+        if self.device.type == "cuda":
+            ops.enable_library_gemm_selection()
 
     @property
     def num_towers(self) -> int:

@@ -767,3 +767,20 @@ def test_lazily_normalised_descriptor_does_not_change_the_step():
     assert rel_err(res[0][3], res[1][3]) < 1e-6
     v = res[0][3].reshape(B, 256, 1024)                               # normalised: every cluster row has norm 1 / sqrt(K)
     assert torch.allclose(v.norm(dim=2), torch.full((B, 256), 256 ** -0.5, device=dev), atol=1e-6)
+
+
+def test_trainer_activates_the_recorded_library_gemm_solutions():
+    """A CUDA trainer hands PyTorch the recorded fp32 GEMM solutions (FLAGS.library_gemm_selection; TunableOp on, tuning OFF -- nothing is
+    searched at run time); a process that configured TunableOp through the environment is left alone."""
+    import os
+    import torch.cuda.tunable as tunable
+    from learnablepoolingmethods_amd import ops, registry, train
+    if "PYTORCH_TUNABLEOP_ENABLED" in os.environ or os.environ.get("LPM_LIBRARY_GEMM_SELECTION") == "0":
+        pytest.skip("TunableOp configured by the environment")
+    train.Trainer(registry.get_model("NetVladV1"), vocab_size=16, batch_size=2, device=cuda(), seed=0,
+                  model_kwargs=dict(iterations=4, cluster_size=8, hidden_size=16))
+    if not ops._LIBRARY_SELECTION:
+        pytest.skip("the recorded solutions' validators do not match this box's libraries: PyTorch ignores the file")
+    assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+    shapes = {r[1] for r in tunable.get_results()}
+    assert any(s.startswith("nn_19310_128_1024") for s in shapes), sorted(shapes)[:5]

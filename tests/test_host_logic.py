@@ -259,3 +259,21 @@ def test_split_vector_hands_back_one_concatenated_gradient():
     v.grad = None
     ((a * 2).sum() + (b * torch.arange(6.0)).sum()).backward()
     assert torch.equal(v.grad, torch.cat([torch.full((4,), 2.0), torch.arange(6.0)]))
+
+
+def test_recorded_library_gemm_solutions_file_is_well_formed():
+    """FLAGS.library_gemm_selection: the file PyTorch's TunableOp reads (tuning off) -- validators first, then one recorded solution per
+    fp32 GEMM shape; the MoE-head shapes of the three benchmark configurations are in it."""
+    import os
+    from learnablepoolingmethods_amd import ops
+    assert FLAGS.library_gemm_selection is True
+    lines = [l.strip().split(",") for l in open(ops.LIBRARY_GEMM_FILE) if l.strip()]
+    validators = {l[1]: l[2] for l in lines if l[0] == "Validator"}
+    assert {"PT_VERSION", "HIP_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"} <= set(validators)
+    assert validators["GCN_ARCH_NAME"].startswith("gfx950")
+    entries = [l for l in lines if l[0] != "Validator"]
+    assert all(len(l) == 4 and l[0].startswith("Gemm") and float(l[3]) > 0 for l in entries)
+    keys = {l[1] for l in entries}
+    assert len(keys) == len(entries)
+    for shape in ("nn_11586_80_512", "nn_19310_128_1024", "tn_1024_128_19310", "nt_15448_1024_128"):     # MoE gates / experts, cfg-2 and cfg-5
+        assert any(k.startswith(shape + "_") for k in keys), shape
