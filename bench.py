@@ -312,6 +312,16 @@ def main():
 
     wl = WORKLOADS[args.config]
     set_flags(wl)
+    # A/B on a real node (default: the route Trainer.build agrees on from the tower count): LPM_HIDDEN1_ROUTE=sharded | factored | allreduce
+    route_env = os.environ.get("LPM_HIDDEN1_ROUTE")
+    if route_env == "sharded":
+        FLAGS.hidden1_sharded_update, FLAGS.hidden1_sharded_min_towers = True, 2
+    elif route_env == "factored":
+        FLAGS.hidden1_factored_update, FLAGS.hidden1_factored_max_towers, FLAGS.hidden1_sharded_update = True, 64, False
+    elif route_env == "allreduce":
+        FLAGS.hidden1_factored_update, FLAGS.hidden1_sharded_update = False, False
+    elif route_env:
+        raise SystemExit(f"LPM_HIDDEN1_ROUTE={route_env!r}: sharded | factored | allreduce")
     PER_GPU_BATCH = wl["batch"]
     model = registry.get_model(wl.get("model", "NetVladV1"))
     trainer = Trainer(model, vocab_size=VOCAB, batch_size=PER_GPU_BATCH, device=device, seed=1234, model_kwargs=wl["model_kwargs"], **TRAIN)
@@ -371,10 +381,26 @@ def main():
         return [float(buf[i]) for i in range(n)]
     k1_ms, k2_ms = kernel_ms(1), kernel_ms(2)
     at_ms, fin_ms = kernel_ms(3), kernel_ms(4)
+    replicas = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # after the timed region: do all towers hold the same parameters?  (data-parallel replicas apply identical updates -- on the
+        # sharded route each rank updates its 1/N of hidden1_weights and the all-gather hands everyone the rest: a rank that missed a
+        # collective or read the variable before its gather landed shows up here, on the first real multi-GPU run as well)
+        dog.tick("replica consistency check (all_gather of parameter checksums)")
+        if trainer.sharded is not None:
+            trainer.sharded.wait_parameters()
+        pd = trainer.arena.param.double()
+        cs = torch.stack([pd.sum(), (pd * pd).sum(), pd.abs().max()])
+        del pd
+        allcs = [torch.empty_like(cs) for _ in range(world)]
+        dist.all_gather(allcs, cs)
+        dev_ = max(float((c - allcs[0]).abs().max()) for c in allcs)
+        route = "sharded (C)" if trainer.sharded is not None else ("factored (B)" if trainer.factored is not None else "all-reduce (A)")
+        replicas = {"consistent": dev_ == 0.0, "max_checksum_difference": dev_, "hidden1_weights_route": route,
+                    "checked": "sum, sum of squares and max |.| of the whole parameter arena, float64, every rank against rank 0"}
     loss = float(out["loss"])
 
     if rank == 0:
@@ -460,6 +486,8 @@ def main():
         # launches per step: counted live, on one more step AFTER the timed region (single GPU: the extra steps hold collectives otherwise)
         if world == 1 and dispatches is not None:
             line["dispatches_per_step"] = dispatches
+        if replicas is not None:
+            line["replicas"] = replicas
         if roof:
             line["roofline"] = roof
         if k1:
