@@ -191,6 +191,7 @@ def test_bench_self_launch_two_ranks(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 160 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["replicas"]["consistent"] is True and d["replicas"]["max_checksum_difference"] == 0.0, d["replicas"]
 
 
 @pytest.mark.timeout(900)
@@ -218,6 +219,7 @@ def test_bench_eight_ranks_share_the_gpu_over_gloo(config, global_batch):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == global_batch and d["config"]["parallelism"] == "dp8" and d["value"] > 0
+    assert d["replicas"]["consistent"] is True and d["replicas"]["hidden1_weights_route"].startswith("sharded"), d["replicas"]
 
 
 @pytest.mark.timeout(900)
