@@ -21,7 +21,10 @@ namespace lpm {
 // = 50-75 KB): four stages of 32 KB, three of them in flight behind the one being consumed.
 constexpr int PJ_NS = 4;                           // ring stages
 constexpr int PJ_WBYTES = 16 * 512 * 4;            // W slab
-constexpr int PJ_AUX = 2;                          // LDS-DMA cache policy of the weight stream: nt (every byte is read once, by one CU)
+#ifndef LPM_PJ_AUX
+#define LPM_PJ_AUX 2                                // (a variant build with 0 = the default policy: tools/build_proj_policy_variant.sh, A/B)
+#endif
+constexpr int PJ_AUX = LPM_PJ_AUX;                 // LDS-DMA cache policy of the weight stream: nt (every byte is read once, by one CU)
 
 // MT = row tiles (ceil(M / 32)).  Eight computing waves (64 columns each) bring the weight slabs in; a NINTH wave brings ALL of x in and
 // does nothing else, in PAIRS of slabs: 128 bytes per row = a whole cache line (round 3; before, 2 MT of the computing waves asked for
