@@ -73,6 +73,13 @@ const char* lpm_last_error(void);
 void lpm_kernel_timing_enable(int on);
 int lpm_kernel_timing_read(int tag, float* ms, int max);
 
+/* Measurement only: the shader clock over time.  lpm_clock_sampler launches ONE wave that stores, every `period_ticks` ticks of the
+ * constant 100 MHz counter, the pair (constant counter, shader-clock counter) into out[2 i], out[2 i + 1] (i < n; n * period_ticks / 100
+ * microseconds in all) -- on a stream of its own, before the work to be observed.  lpm_clock_marker stores one such pair into slot
+ * `slot` of `out` from the stream it is launched on (a time stamp in the same time base).  tools/clock_trace.py. */
+int lpm_clock_sampler(uint64_t* out, int n, int period_ticks, lpm_stream_t stream);
+int lpm_clock_marker(uint64_t* out, int slot, lpm_stream_t stream);
+
 /* Input normalisation of the training step (tf.nn.l2_normalize(model_input_raw, 2), train.py:262-264):
  * y[r,:] = x[r,:] * rsqrt(max(sum x[r,:]^2, 1e-12)) for `rows` rows of F floats (F %% 4 == 0, F <= 2048).  y may alias x. */
 int lpm_l2_normalize_rows(const float* x, int64_t rows, int F, float* y, lpm_stream_t stream);

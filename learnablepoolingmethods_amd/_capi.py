@@ -38,6 +38,8 @@ SIGNATURES = {
     "lpm_last_error": (C.c_char_p, []),
     "lpm_kernel_timing_enable": (None, [_i]),
     "lpm_kernel_timing_read": (_i, [_i, C.POINTER(C.c_float), _i]),
+    "lpm_clock_sampler": (_i, [_f, _i, _i, _f]),
+    "lpm_clock_marker": (_i, [_f, _i, _f]),
     "lpm_l2_normalize_rows": (_i, [_f, _l, _i, _f, _f]),
     "lpm_dequantize_l2_normalize": (_i, [_f, _f, _i, _i, _i, _fl, _fl, _f, _f]),
     "lpm_frame_stats_workspace_bytes": (_s, [_i, _i, _i]),

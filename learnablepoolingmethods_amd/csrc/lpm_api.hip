@@ -56,3 +56,42 @@ extern "C" int lpm_kernel_timing_read(int tag, float* ms, int max) {
 
 extern "C" int lpm_version(void) { return LPM_VERSION; }
 extern "C" const char* lpm_last_error(void) { return lpm::g_err; }
+
+// ---- measurement: the shader clock over time ---------------------------------------------------------------------------------------------
+// One wave that does nothing but sample: every `period_ticks` ticks of the constant 100 MHz counter (s_memrealtime) it stores the pair
+// (constant counter, shader-clock counter).  Launched on a stream of its own before the work to be observed, it sits in one wave slot
+// while other streams' kernels run; the ratio of the two counters' differences between neighbouring samples is the shader clock in
+// that interval (tools/clock_trace.py: the DVFS behaviour inside one training step).  lpm_clock_marker stores one such pair from the
+// stream it is launched on -- a time stamp in the sampler's time base between two pieces of work.
+namespace lpm {
+__global__ __launch_bounds__(64) void clock_sampler_kernel(unsigned long long* __restrict__ out, int n, int period_ticks) {
+    if (threadIdx.x != 0) return;
+    unsigned long long next = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < n; ++i) {
+        unsigned long long t;
+        do { t = __builtin_amdgcn_s_memrealtime(); } while (t < next);
+        const unsigned long long c = __builtin_readcyclecounter();
+        __builtin_nontemporal_store(t, out + 2 * i);
+        __builtin_nontemporal_store(c, out + 2 * i + 1);
+        next = t + (unsigned long long)period_ticks;
+    }
+}
+__global__ __launch_bounds__(64) void clock_marker_kernel(unsigned long long* __restrict__ out, int slot) {
+    if (threadIdx.x != 0) return;
+    out[2 * slot] = __builtin_amdgcn_s_memrealtime();
+    out[2 * slot + 1] = __builtin_readcyclecounter();
+}
+}  // namespace lpm
+
+extern "C" int lpm_clock_sampler(uint64_t* out, int n, int period_ticks, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(out && n > 0 && period_ticks > 0, LPM_ERR_BADARG, "lpm_clock_sampler: null pointer or non-positive count / period");
+    hipLaunchKernelGGL(clock_sampler_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, n, period_ticks);
+    return check_launch("lpm_clock_sampler");
+}
+extern "C" int lpm_clock_marker(uint64_t* out, int slot, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(out && slot >= 0, LPM_ERR_BADARG, "lpm_clock_marker: null pointer or negative slot");
+    hipLaunchKernelGGL(clock_marker_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, slot);
+    return check_launch("lpm_clock_marker");
+}
