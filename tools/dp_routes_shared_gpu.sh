@@ -1,3 +1,5 @@
+# bench.py with two ranks sharing the one GPU over gloo on each route of hidden1_weights (LPM_HIDDEN1_ROUTE), cfg-2 and cfg-5, then eight ranks on
+# the default route: prints the replica consistency report of every run
 cd $GRAFT_REPO_ROOT
 for r in sharded factored allreduce; do
   for c in cfg2 cfg5; do
