@@ -985,7 +985,7 @@ def test_ffn_split_bf16_fused_bias_relu(M, F, H, tiles):
 
 
 @pytest.mark.parametrize("B,KV,H", [(80, 33792, 512), (16, 4224, 64), (6, 2048, 96), (128, 16896, 1024), (13, 2064, 512), (48, 4112, 512),
-                                    (80, 270336, 512), (1, 2048, 1024), (97, 1168, 512)])
+                                    (80, 270336, 512), (1, 2048, 1024), (97, 1168, 512), (90, 4112, 512), (65, 8208, 1024)])
 def test_projection_skinny_gemms(B, KV, H):
     """VLAD -> hidden1 projection (frame_level_models.py:2314-2319): forward and dx by the weight-stream kernels (csrc/proj_gemm.hip:
     H a multiple of 512; cfg-2's and cfg-5's shapes, ragged row counts, an odd number of 16-row slabs) or the library (the other
