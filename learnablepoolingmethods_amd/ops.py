@@ -104,7 +104,7 @@ MHA_BN_X3_MIN_KEYS = int(os.environ.get("LPM_MHA_BN_X3_MIN_KEYS", "128"))
 _XT_CACHE = {}
 MHA_BN_MOMENTS = os.environ.get("LPM_MHA_BN_MOMENTS", "1") != "0"      # ... statistics by lpm_mha_logit_stats_moments, moments kept for the backward
 MHA_BN_ONEPASS = os.environ.get("LPM_MHA_BN_ONEPASS", "1") != "0"      # logits_bn backward without the separate statistics pass (A/B switch)
-LN_IMAGE = True              # the attention block's layer norm also writes the operand image of the feed-forward block behind it (A/B switch)
+LN_IMAGE = os.environ.get("LPM_LN_IMAGE", "1") != "0"              # the attention block's layer norm also writes the operand image of the feed-forward block behind it (A/B switch)
 SPLIT_VECTOR = True          # NetVladV1: input_bn's gamma / beta halves with ONE concatenated gradient each (A/B switch)
 V2_SPLIT_COLUMNS = True      # NetVladV2: the two streams' inputs as contiguous copies with ONE concatenated gradient (A/B switch)
 DEBUG_TAP = None      # tools/determinism_check.py: a dict that the video stream's pooling backward fills with copies of its intermediates
@@ -1767,14 +1767,16 @@ class _FFNModX3(torch.autograd.Function):
     tensors and two operand-split passes per encoder and step are gone (NetVladV2 at cfg-3)."""
 
     @staticmethod
-    def forward(ctx, y2d, W1, b1, gamma, beta, moving_mean, moving_var, W2):
+    def forward(ctx, y2d, W1, b1, gamma, beta, moving_mean, moving_var, W2, y3=None):
+        """y3: the operand image of y2d when its producer (the layer norm in front) wrote one."""
         lib = _capi.load()
         y2d = _rows(y2d, "ffn input")
         W1_0, W2_0 = W1, W2
         W1, W2 = _f32(W1, "W1").contiguous(), _f32(W2, "W2").contiguous()
         M, F = y2d.shape
         C = W1.shape[1]
-        y3 = _split_rows(y2d)
+        if y3 is None:
+            y3 = _split_rows(y2d)
         w13n, w13k = _split_weight(W1)
         pre = _mm3(y3, w13n)                                               # raw output of the first dense layer [M, C]
         b1 = b1.contiguous()
@@ -1809,7 +1811,75 @@ class _FFNModX3(torch.autograd.Function):
         del df
         dy = _mm3(dp3, w13k) if ctx.needs_input_grad[0] else None
         dW1 = _dw_x3(y3, dp3, F, C, outs=[(ctx.wrefs[0], 0, C)])[0]
-        return dy, dW1, db1, dgamma, dbeta, None, None, dW2
+        return dy, dW1, db1, dgamma, dbeta, None, None, dW2, None
+
+
+_ZEROS = {}       # (device, length) -> a zero vector, never written
+
+
+class _BNDenseX3(torch.autograd.Function):
+    """slim.batch_norm(x) . W as ONE node (MultiHeadAttentionBN's attention_bn -> output_transform, transformer_utils.py:666-677): the batch
+    norm writes its result ONLY as the GEMM's operand image (lpm_bn_rows_act_image_fwd with a zero bias and no activation) -- the
+    normalised tensor never exists in fp32 and there is no operand-split pass; the backward is the dense layer's followed by lpm_bn_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, W):
+        lib = _capi.load()
+        x2 = _f32(x, "batch_norm input").contiguous()
+        W0 = W
+        W = _f32(W, "dense kernel").contiguous()
+        M, C = x2.shape
+        f3 = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=x2.device)
+        mean, var = _empty((C,), x2), _empty((C,), x2)
+        zero = _ZEROS.get((x2.device, C))
+        if zero is None:
+            zero = _ZEROS[(x2.device, C)] = torch.zeros(C, dtype=torch.float32, device=x2.device)       # (the kernel's bias operand: none here)
+        wsb = lib._lpm_bn_rows_workspace_bytes(M, C)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x2.device)
+        lib.check(lib._lpm_bn_rows_act_image_fwd(ptr(x2), ptr(zero), 0, M, C, ptr(gamma), ptr(beta), BN_EPS, BN_DECAY, 1, ptr(f3), ptr(mean),
+                                                 ptr(var), ptr(moving_mean), ptr(moving_var), ptr(ws), wsb, stream_ptr()),
+                  "lpm_bn_rows_act_image_fwd")
+        w3n, w3k = _split_weight(W)
+        ctx.save_for_backward(x2, mean, var, gamma, f3, w3k)
+        ctx.dims = (C, W.shape[1])
+        ctx.wrefs = (W0,)
+        return _mm3(f3, w3n)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _capi.load()
+        x2, mean, var, gamma, f3, w3k = ctx.saved_tensors
+        C, N = ctx.dims
+        M = x2.shape[0]
+        do3 = _split_rows(dout.contiguous(), grad=True)
+        dW = _dw_x3(f3, do3, C, N, outs=[(ctx.wrefs[0], 0, N)])[0]
+        df = _mm3(do3, w3k)                                                # gradient of the batch norm's output [M, C]
+        dx = torch.empty_like(x2)
+        dgamma, dbeta = _empty((C,), x2), _empty((C,), x2)
+        wsb = lib._lpm_bn_bwd_workspace_bytes(M, C)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x2.device)
+        lib.check(lib._lpm_bn_bwd(ptr(df), ptr(x2), ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, C, ptr(dx), ptr(dgamma), ptr(dbeta),
+                                  ptr(ws), wsb, stream_ptr()), "lpm_bn_bwd")
+        return dx, dgamma, dbeta, None, None, dW
+
+
+# "0": layers.batch_norm + layers.dense as two nodes with an operand-split pass in between (A/B)
+BN_DENSE_FUSED = os.environ.get("LPM_BN_DENSE_FUSED", "1") != "0"
+
+
+def bn_dense_x3_ok(x, units):
+    rows = x.numel() // x.shape[-1]
+    return (BN_DENSE_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] % 8 == 0 and units % 8 == 0 and rows >= 1024)
+
+
+def bn_dense_x3(x, gamma, beta, moving_mean, moving_var, W, bias=None):
+    """x [..., C] -> slim.batch_norm(x) . W (+ bias) [..., N] (training mode; moving statistics updated in place, biased variance: the
+    rank-3 path).  The bias add runs in place on the GEMM's own output (ops.bias_act), before that output is viewed in x's shape."""
+    rows = x.numel() // x.shape[-1]
+    out = _BNDenseX3.apply(x.reshape(rows, x.shape[-1]), gamma, beta, moving_mean, moving_var, W)
+    if bias is not None:
+        out = bias_act(out, bias, False) if (BIAS_ACT_FUSED and bias_act_ok(out, bias)) else out + bias
+    return out.reshape(*x.shape[:-1], W.shape[1])
 
 
 def ffn_mod_x3_ok(x, filter_size, final_size):
@@ -1822,8 +1892,23 @@ def ffn_mod_x3(x, W1, b1, gamma, beta, moving_mean, moving_var, W2):
     """x [..., F] -> BN(relu(x W1 + b1)) W2 [..., N] (training mode; the batch norm's moving statistics are updated in place, biased
     variance: the rank-3 path of slim.batch_norm)."""
     rows = x.numel() // x.shape[-1]
-    out = _FFNModX3.apply(x.reshape(rows, x.shape[-1]), W1, b1, gamma, beta, moving_mean, moving_var, W2)
+    out = _FFNModX3.apply(x.reshape(rows, x.shape[-1]), W1, b1, gamma, beta, moving_mean, moving_var, W2, _take_image(x, rows))
     return out.reshape(*x.shape[:-1], W2.shape[1])
+
+
+def _take_image(y, rows):
+    """The operand image a producer attached to y (``y._lpm_y3``: ops._ResidualLayerNorm(image=True)) -- only if y is still the tensor it
+    was taken from (same storage, not modified in place since); consumed either way."""
+    tag = getattr(y, "_lpm_y3", None)
+    if tag is None:
+        return None
+    img, dptr, ver = tag
+    try:
+        del y._lpm_y3
+    except AttributeError:
+        pass
+    ok = dptr == y.data_ptr() and ver == y._version and y.is_contiguous() and tuple(img.shape) == (rows, 3 * y.shape[-1])
+    return img if ok else None
 
 
 def batch_norm_rows_act_ok(x, bias):
@@ -1928,12 +2013,14 @@ class _ResidualLayerNorm(torch.autograd.Function):
                                               1 if ctx.relu else 0, B, L, F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias),
                                               ptr(dr_extra), ptr(img), ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_bwd")
         first = img if da_image else (da if da is not None else dz)
-        return first, (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None
+        return first, (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None, None, None
 
 
-def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False):
-    """layer_norm(act(a + bias) + r) with TF1 joint moments; a, r: [B, L, F]; act = relu when ``relu`` (needs ``bias``)."""
-    return _ResidualLayerNorm.apply(a, r, gamma, beta, bias, bool(relu), None)
+def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False, image=False):
+    """layer_norm(act(a + bias) + r) with TF1 joint moments; a, r: [B, L, F]; act = relu when ``relu`` (needs ``bias``).
+    image: the result ALSO leaves as the operand image of the dense layer that reads it next, attached as ``y._lpm_y3`` (ops.ffn_mod_x3
+    takes it instead of splitting y again)."""
+    return _ResidualLayerNorm.apply(a, r, gamma, beta, bias, bool(relu), None, None, bool(image) and LN_IMAGE)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -43,6 +43,14 @@ class MultiHeadAttentionBN(modules.BaseModule):
         L = keys.shape[1]
         gamma, beta, mm, mv = layers.bn_variables("logits_bn", L, q.device)        # channel = key position :652-658
         attention_output = ops.mha_core_bn(q, k, v, self.num_heads, gamma, beta, mm, mv, self.is_train)
+        rows = attention_output.numel() // attention_output.shape[-1]
+        if (self.is_train and layers.use_split_gemm(attention_output, rows, self.feature_size)
+                and ops.bn_dense_x3_ok(attention_output, self.feature_size)):
+            # attention_bn -> output_transform as ONE node: the normalised tensor leaves the batch norm only as the GEMM's operand image
+            # (variables in the unfused order: attention_bn's, then the dense layer's)
+            g2, b2, mm2, mv2 = layers.bn_variables("attention_bn", attention_output.shape[-1], attention_output.device)
+            W, bias = layers.dense_variables("output_transform", attention_output.shape[-1], self.feature_size, True, attention_output.device)
+            return ops.bn_dense_x3(attention_output, g2, b2, mm2, mv2, W, bias=bias)
         attention_output = layers.batch_norm(attention_output, self.is_train, "attention_bn")   # :666-671
         return layers.dense(attention_output, self.feature_size, use_bias=True, name="output_transform")
 
@@ -187,5 +195,9 @@ class TransformerEncoderMod(modules.BaseModule):
                 attention = torch.nn.functional.dropout(attention, p=rate, training=True)
             else:
                 attention = attention * dropout_mask / (1.0 - rate)
-        attention = layers.layer_norm(attention, "LayerNorm", residual=inputs)         # :451-454
+        # (the layer norm also writes the operand image of the feed-forward network's first dense layer when that network runs fused)
+        image = bool(self.is_train and attention.dim() == 3
+                     and layers.use_split_gemm(attention, attention.numel() // attention.shape[-1], self.ff_network.filter_size)
+                     and ops.ffn_mod_x3_ok(attention, self.ff_network.filter_size, self.ff_network.final_size))
+        attention = layers.layer_norm(attention, "LayerNorm", residual=inputs, image=image)         # :451-454
         return self.ff_network.forward(attention)
