@@ -539,6 +539,18 @@ int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, const float
                            const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma, float* dbeta,
                            float* dbias, const float* dr_extra, void* da_image, void* workspace, size_t workspace_bytes,
                            lpm_stream_t stream);
+/* ... with tf.layers.dropout between the dense layer and the layer norm (NetVladV2's TransformerEncoderMod, transformer_utils.py:450-454):
+ * y = layer_norm(act(a + bias) * keep * mask_scale + r).  mask [B, L, F]: one byte per element, non-zero = kept, 4-byte aligned;
+ * mask_scale = 1 / keep probability; y3 (optional) as in lpm_layer_norm_act_image_fwd.  The backward returns da (or da_image) =
+ * dz * [ReLU mask] * keep * mask_scale -- the gradient of the dense layer's RAW output -- and dbias = its column sums. */
+int lpm_layer_norm_act_mask_image_fwd(const float* a, const float* bias, int relu, const unsigned char* mask, float mask_scale,
+                                      const float* r, const float* gamma, const float* beta, int B, int L, int F, float eps, float* y,
+                                      int64_t y_batch_stride, void* y3, float* z, float* stats, void* workspace, size_t workspace_bytes,
+                                      lpm_stream_t stream);
+int lpm_layer_norm_act_mask_bwd(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats, const float* gamma,
+                                const float* a, const float* bias, int relu, const unsigned char* mask, float mask_scale, int B, int L,
+                                int F, float* dz, float* da, float* dgamma, float* dbeta, float* dbias, const float* dr_extra,
+                                void* da_image, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4: multi-head attention core  o = softmax(scale * q k^T) v   per (batch, head)

@@ -34,10 +34,14 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {   // 256 thread
 }
 
 // pass 1: z = a + r (written when r != NULL), partial[b][chunk] = (sum z, sum z^2)
+// MASK (NetVladV2's encoder: tf.layers.dropout between the dense layer and the layer norm, transformer_utils.py:450): the keep mask
+// [B, L, F] (one byte per element) and its scale 1 / keep_probability apply to act(a + bias), BEFORE the residual is added.
+template <bool MASK>
 __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restrict__ a, const float* __restrict__ r,
                                                            const float* __restrict__ bias, int relu, int F,
                                                            int64_t n_per, float* __restrict__ z,
-                                                           float* __restrict__ partial, const float* __restrict__ r_scale) {
+                                                           float* __restrict__ partial, const float* __restrict__ r_scale,
+                                                           const unsigned char* __restrict__ mask, float mscale) {
     __shared__ float sh[4];
     const int b = blockIdx.x, ch = blockIdx.y;
     const int64_t n4 = n_per / 4;
@@ -58,6 +62,10 @@ __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restri
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
         }
+        if (MASK) {
+            const uchar4 mk = reinterpret_cast<const uchar4*>(mask + (int64_t)b * n_per)[i];
+            v.x = mk.x ? v.x * mscale : 0.f; v.y = mk.y ? v.y * mscale : 0.f; v.z = mk.z ? v.z * mscale : 0.f; v.w = mk.w ? v.w * mscale : 0.f;
+        }
         if (rp) {
             float4 w = rp[i];
             if (r_scale) {                     // the residual is a lazily normalised descriptor: one factor per (example, row)
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restri
             }
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
-        if (rp || bias) zp[i] = v;
+        if (rp || bias || MASK) zp[i] = v;
         s += (v.x + v.y) + (v.z + v.w);
         q = fmaf(v.x, v.x, q); q = fmaf(v.y, v.y, q); q = fmaf(v.z, v.z, q); q = fmaf(v.w, v.w, q);
     }
@@ -204,6 +212,8 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restri
 // dy of this very layer norm when its residual also feeds the next one) -- the add rides on the store; da is then written
 // separately even without a ReLU.
 // Threads are laid out (row group, float4 column) with F4 dividing 256 and chunks of whole rows, as in pass 1.
+// MASK: da = dz * keep mask * scale (after the ReLU mask, if any): the gradient of the dense layer's raw output through the dropout.
+template <bool MASK>
 __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma,
@@ -211,7 +221,8 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dz, const float* __restrict__ act_a,
                                                            const float* __restrict__ bias, int relu, float* __restrict__ da,
                                                            float* __restrict__ biaspart, const float* __restrict__ dr_extra,
-                                                           int64_t dy_batch, unsigned short* __restrict__ da_img) {
+                                                           int64_t dy_batch, unsigned short* __restrict__ da_img,
+                                                           const unsigned char* __restrict__ mask, float mscale) {
     __shared__ float4 cs[256];
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const int64_t n_per = (int64_t)L * F;
@@ -250,7 +261,11 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
             o.z = (av.z + bb.z > 0.f) ? o.z : 0.f;
             o.w = (av.w + bb.w > 0.f) ? o.w : 0.f;
         }
-        if (da && (relu || dr_extra)) *reinterpret_cast<float4*>(da + off) = o;
+        if (MASK) {
+            const uchar4 mk = *reinterpret_cast<const uchar4*>(mask + off);
+            o.x = mk.x ? o.x * mscale : 0.f; o.y = mk.y ? o.y * mscale : 0.f; o.z = mk.z ? o.z * mscale : 0.f; o.w = mk.w ? o.w * mscale : 0.f;
+        }
+        if (da && (relu || dr_extra || MASK)) *reinterpret_cast<float4*>(da + off) = o;
         if (da_img) {      // da only feeds GEMMs: it leaves as their split-bf16 gradient image, row = [hi | hi | lo] planes of F
             unsigned short* p = da_img + ((int64_t)b * L + l) * 3 * F + 4 * c4;
             const uint2 hi = make_uint2(ln_bf16_pair(o.x, o.y), ln_bf16_pair(o.z, o.w));
@@ -361,10 +376,12 @@ extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
 
 static int layer_norm_act_fwd_impl(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,
                                    const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, float* z,
-                                   float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3 = nullptr) {
+                                   float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3 = nullptr,
+                                   const unsigned char* mask = nullptr, float mask_scale = 1.f) {
     using namespace lpm;
-    LPM_REQUIRE(a && gamma && beta && y && stats && (z || (!r && !bias)), LPM_ERR_BADARG,
-                "lpm_layer_norm_act_fwd: null pointer (z is required with a residual or a bias)");
+    LPM_REQUIRE(a && gamma && beta && y && stats && (z || (!r && !bias && !mask)), LPM_ERR_BADARG,
+                "lpm_layer_norm_act_fwd: null pointer (z is required with a residual, a bias or a mask)");
+    LPM_REQUIRE(!mask || ((uintptr_t)mask & 3) == 0, LPM_ERR_BADARG, "lpm_layer_norm_act_fwd: the keep mask must be 4-byte aligned");
     LPM_REQUIRE(bias || !relu, LPM_ERR_BADARG, "lpm_layer_norm_act_fwd: relu needs the bias it follows");
     LPM_REQUIRE(!r_scale || r, LPM_ERR_BADARG, "lpm_layer_norm_act_fwd: a residual row scale needs the residual");
     LPM_LN_CHECK("lpm_layer_norm_act_fwd");
@@ -375,10 +392,26 @@ static int layer_norm_act_fwd_impl(const float* a, const float* bias, int relu, 
     LPM_REQUIRE(yb >= n_per && yb % 4 == 0 && ((uintptr_t)y & 15) == 0, LPM_ERR_BADARG,
                 "lpm_layer_norm_act_fwd: y_batch_stride must be >= L*F and a multiple of 4, y 16-byte aligned");
     dim3 grid(B, LN_NB);
-    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial, r_scale);
-    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias) ? z : a, partial, gamma, beta, n_per, F, eps, y, yb, stats,
+    if (mask)
+        hipLaunchKernelGGL(ln_fwd_stats_kernel<true>, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial, r_scale, mask, mask_scale);
+    else
+        hipLaunchKernelGGL(ln_fwd_stats_kernel<false>, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial, r_scale,
+                           (const unsigned char*)nullptr, 1.f);
+    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias || mask) ? z : a, partial, gamma, beta, n_per, F, eps, y, yb, stats,
                        (const float*)nullptr, (float*)nullptr, (unsigned short*)y3);
     return check_launch("lpm_layer_norm_act_fwd");
+}
+// ... with tf.layers.dropout between the dense layer and the layer norm (NetVladV2's TransformerEncoderMod, transformer_utils.py:450-454):
+// y = layer_norm(act(a + bias) * keep * mask_scale + r); mask [B, L, F] one byte per element (non-zero = kept), y3 optional
+extern "C" int lpm_layer_norm_act_mask_image_fwd(const float* a, const float* bias, int relu, const unsigned char* mask, float mask_scale,
+                                                 const float* r, const float* gamma, const float* beta, int B, int L, int F, float eps,
+                                                 float* y, int64_t y_batch_stride, void* y3, float* z, float* stats, void* workspace,
+                                                 size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(mask, LPM_ERR_BADARG, "lpm_layer_norm_act_mask_image_fwd: null keep mask");
+    LPM_REQUIRE(!y3 || ((uintptr_t)y3 & 7) == 0, LPM_ERR_BADARG, "lpm_layer_norm_act_mask_image_fwd: y3 not 8-byte aligned");
+    return layer_norm_act_fwd_impl(a, bias, relu, r, nullptr, gamma, beta, B, L, F, eps, y, y_batch_stride, z, stats, workspace,
+                                   workspace_bytes, stream, y3, mask, mask_scale);
 }
 extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma,
                                       const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride,
@@ -426,7 +459,8 @@ extern "C" int lpm_layer_norm_pair_fwd(const float* a, const float* bias, int re
     LPM_REQUIRE(yb >= n_per && yb % 4 == 0 && ((uintptr_t)y & 15) == 0, LPM_ERR_BADARG,
                 "lpm_layer_norm_pair_fwd: y_batch_stride must be >= L*F and a multiple of 4, y 16-byte aligned");
     dim3 grid(B, LN_NB);
-    hipLaunchKernelGGL(ln_fwd_stats_kernel, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z1, partial1, (const float*)nullptr);
+    hipLaunchKernelGGL(ln_fwd_stats_kernel<false>, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z1, partial1, (const float*)nullptr,
+                       (const unsigned char*)nullptr, 1.f);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z1, (const float*)partial1, gamma1, beta1, n_per, F, eps,
                        z2, n_per, stats1, r, partial2, (unsigned short*)nullptr);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z2, (const float*)partial2, gamma2, beta2, n_per, F, eps,
@@ -440,13 +474,15 @@ extern "C" int lpm_layer_norm_fwd(const float* a, const float* r, const float* g
     return lpm_layer_norm_act_fwd(a, nullptr, 0, r, gamma, beta, B, L, F, eps, y, 0, z, stats, workspace, workspace_bytes, stream);
 }
 
-extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats,
+static int layer_norm_act_bwd_impl(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats,
                                       const float* gamma, const float* a,
                                       const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
                                       float* dbeta, float* dbias, const float* dr_extra, void* da_image, void* workspace,
-                                      size_t workspace_bytes, lpm_stream_t stream) {
+                                      size_t workspace_bytes, lpm_stream_t stream, const unsigned char* mask, float mask_scale) {
     using namespace lpm;
     LPM_REQUIRE(dy && z && stats && gamma && dz && dgamma && dbeta, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: null pointer");
+    LPM_REQUIRE(!mask || ((da || da_image) && ((uintptr_t)mask & 3) == 0), LPM_ERR_BADARG,
+                "lpm_layer_norm_act_bwd: a keep mask needs da / da_image and 4-byte alignment");
     LPM_REQUIRE(!dr_extra || da || da_image, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: dr_extra needs a separate da (or da_image)");
     LPM_REQUIRE(!relu || (bias && a && (da || da_image)), LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: relu needs a, bias and da / da_image");
     LPM_REQUIRE(!bias || dbias, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: a fused bias needs dbias");
@@ -463,11 +499,34 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, 
                 "lpm_layer_norm_act_bwd: dy_batch_stride must be >= L*F and a multiple of 4, dy 16-byte aligned");
     unsigned* counters = (unsigned*)(tmp + (size_t)LN_RS * 4 * F);
     hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart, dyb, counters);
-    hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
-                       dr_extra, dyb, (unsigned short*)da_image);
+    if (mask)
+        hipLaunchKernelGGL(ln_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
+                           dr_extra, dyb, (unsigned short*)da_image, mask, mask_scale);
+    else
+        hipLaunchKernelGGL(ln_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
+                           dr_extra, dyb, (unsigned short*)da_image, (const unsigned char*)nullptr, 1.f);
     hipLaunchKernelGGL(ln_colreduce_kernel, dim3((F + 63) / 64, LN_RS, bias ? 2 : 1), dim3(256), 0, s, colpart, biaspart, nblk, F, tmp, dgamma,
                        dbeta, dbias, counters);
     return check_launch("lpm_layer_norm_act_bwd");
+}
+extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats,
+                                      const float* gamma, const float* a,
+                                      const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
+                                      float* dbeta, float* dbias, const float* dr_extra, void* da_image, void* workspace,
+                                      size_t workspace_bytes, lpm_stream_t stream) {
+    return layer_norm_act_bwd_impl(dy, dy_batch_stride, z, stats, gamma, a, bias, relu, B, L, F, dz, da, dgamma, dbeta, dbias, dr_extra,
+                                   da_image, workspace, workspace_bytes, stream, nullptr, 1.f);
+}
+// backward of lpm_layer_norm_act_mask_image_fwd: da (or da_image) = dz * [ReLU mask] * keep * mask_scale, dbias = its column sums
+extern "C" int lpm_layer_norm_act_mask_bwd(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats,
+                                           const float* gamma, const float* a, const float* bias, int relu, const unsigned char* mask,
+                                           float mask_scale, int B, int L, int F, float* dz, float* da, float* dgamma, float* dbeta,
+                                           float* dbias, const float* dr_extra, void* da_image, void* workspace, size_t workspace_bytes,
+                                           lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(mask, LPM_ERR_BADARG, "lpm_layer_norm_act_mask_bwd: null keep mask");
+    return layer_norm_act_bwd_impl(dy, dy_batch_stride, z, stats, gamma, a, bias, relu, B, L, F, dz, da, dgamma, dbeta, dbias, dr_extra,
+                                   da_image, workspace, workspace_bytes, stream, mask, mask_scale);
 }
 
 extern "C" int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, const float* gamma, int B, int L, int F,

@@ -1956,10 +1956,12 @@ class _ResidualLayerNorm(torch.autograd.Function):
     """y = layer_norm(act(a + bias) + r): TF1 joint moments, with the producing dense layer's bias add / ReLU fused in."""
 
     @staticmethod
-    def forward(ctx, a, r, gamma, beta, bias, relu, out=None, r_scale=None, image=False):
+    def forward(ctx, a, r, gamma, beta, bias, relu, out=None, r_scale=None, image=False, mask=None, mask_scale=1.0):
         """r_scale [B * L] (block Functions only): r holds the rows of a lazily normalised descriptor, scaled as they are read.
-        image (block Functions only): y is ALSO written as the [B*L, 3F] bf16 activation image of the dense layer that reads it next
-        and attached to the result as ``y._lpm_y3`` (ops._FFNX3 takes it instead of splitting y again)."""
+        image: y is ALSO written as the [B*L, 3F] bf16 activation image of the dense layer that reads it next and attached to the
+        result as ``y._lpm_y3`` (ops._FFNX3 / ops.ffn_mod_x3 take it instead of splitting y again).
+        mask [B, L, F] uint8 / bool + mask_scale: a dropout between the dense layer and the layer norm (NetVladV2): the keep mask and
+        1 / keep probability apply to act(a + bias) before the residual is added; the backward returns the gradient of a through it."""
         lib = _capi.load()
         a = _f32(a, "layer_norm input").contiguous()
         B, L, F = a.shape
@@ -1973,7 +1975,17 @@ class _ResidualLayerNorm(torch.autograd.Function):
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
         y3 = torch.empty((B * L, 3 * F), dtype=torch.bfloat16, device=a.device) if image else None
-        if image:
+        if mask is not None:
+            if r_scale is not None:
+                raise LpmError("layer_norm: a dropout mask and a residual row scale do not combine")
+            mask = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous()
+            if mask.dtype != torch.uint8 or tuple(mask.shape) != (B, L, F):
+                raise LpmError("layer_norm: the dropout keep mask must be uint8 / bool [B, L, F]")
+            z = torch.empty_like(a) if z is a else z
+            lib.check(lib._lpm_layer_norm_act_mask_image_fwd(ptr(a), ptr(bias), 1 if relu else 0, ptr(mask), float(mask_scale), ptr(r), ptr(gamma),
+                                                             ptr(beta), B, L, F, LN_EPS, ptr(y), y.stride(0), ptr(y3), ptr(z), ptr(stats),
+                                                             ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_mask_image_fwd")
+        elif image:
             lib.check(lib._lpm_layer_norm_act_image_fwd(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(r_scale), ptr(gamma), ptr(beta), B, L,
                                                         F, LN_EPS, ptr(y), y.stride(0), ptr(y3), ptr(z) if z is not a else None, ptr(stats),
                                                         ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_image_fwd")
@@ -1986,6 +1998,7 @@ class _ResidualLayerNorm(torch.autograd.Function):
                                                   ptr(y), y.stride(0), ptr(z) if z is not a else None, ptr(stats), ptr(ws), wsb,
                                                   stream_ptr()), "lpm_layer_norm_act_fwd")
         ctx.has_r, ctx.relu, ctx.has_bias = r is not None, bool(relu), bias is not None
+        ctx.mask, ctx.mask_scale = mask, float(mask_scale)
         ctx.save_for_backward(z, stats, gamma, a if relu else None, bias)
         if y3 is not None:
             # handed to the next block with the identity of the tensor it images: a consumer must see the same storage, untouched
@@ -2003,24 +2016,35 @@ class _ResidualLayerNorm(torch.autograd.Function):
         if not _batch_strided(dy, L, F):          # a column slice of a wider gradient buffer is read in place
             dy = dy.contiguous()
         dz = torch.empty_like(z)
+        mask = getattr(ctx, "mask", None)
         img = torch.empty((B * L, 3 * F), dtype=torch.bfloat16, device=z.device) if da_image else None
-        da = torch.empty_like(z) if ((ctx.relu or dr_extra is not None) and not da_image) else None
+        da = torch.empty_like(z) if ((ctx.relu or dr_extra is not None or mask is not None) and not da_image) else None
         dgamma, dbeta = _empty((F,), z), _empty((F,), z)
         dbias = _empty((F,), z) if ctx.has_bias else None
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=z.device)
-        lib.check(lib._lpm_layer_norm_act_bwd(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
-                                              1 if ctx.relu else 0, B, L, F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias),
-                                              ptr(dr_extra), ptr(img), ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_bwd")
+        if mask is not None:
+            lib.check(lib._lpm_layer_norm_act_mask_bwd(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
+                                                       1 if ctx.relu else 0, ptr(mask), ctx.mask_scale, B, L, F, ptr(dz), ptr(da), ptr(dgamma),
+                                                       ptr(dbeta), ptr(dbias), ptr(dr_extra), ptr(img), ptr(ws), wsb, stream_ptr()),
+                      "lpm_layer_norm_act_mask_bwd")
+        else:
+            lib.check(lib._lpm_layer_norm_act_bwd(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
+                                                  1 if ctx.relu else 0, B, L, F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias),
+                                                  ptr(dr_extra), ptr(img), ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_bwd")
         first = img if da_image else (da if da is not None else dz)
-        return first, (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None, None, None
+        return first, (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None, None, None, None, None
 
 
-def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False, image=False):
+def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False, image=False, mask=None, mask_scale=1.0):
     """layer_norm(act(a + bias) + r) with TF1 joint moments; a, r: [B, L, F]; act = relu when ``relu`` (needs ``bias``).
     image: the result ALSO leaves as the operand image of the dense layer that reads it next, attached as ``y._lpm_y3`` (ops.ffn_mod_x3
     takes it instead of splitting y again)."""
-    return _ResidualLayerNorm.apply(a, r, gamma, beta, bias, bool(relu), None, None, bool(image) and LN_IMAGE)
+    return _ResidualLayerNorm.apply(a, r, gamma, beta, bias, bool(relu), None, None, bool(image) and LN_IMAGE, mask, float(mask_scale))
+
+
+# NetVladV2: tf.layers.dropout between output_transform and the layer norm rides in the layer norm's passes; "0": separate passes (A/B)
+LN_DROPOUT_FUSED = os.environ.get("LPM_LN_DROPOUT_FUSED", "1") != "0"
 
 
 # ----------------------------------------------------------------------------------------------

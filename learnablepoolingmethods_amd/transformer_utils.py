@@ -38,7 +38,9 @@ class MultiHeadAttentionBN(modules.BaseModule):
         self.attention_dropout = attention_dropout
         self.is_train = is_train
 
-    def forward(self, queries, keys):
+    def forward(self, queries, keys, defer_bias=False):
+        """defer_bias: return (raw output of output_transform, its bias) where the fused node allows it -- the caller's layer norm adds
+        the bias (and applies the dropout between the two) in its own passes -- else (output, None)."""
         q, k, v = layers.qkv_projections(queries, keys, self.hidden_size)
         L = keys.shape[1]
         gamma, beta, mm, mv = layers.bn_variables("logits_bn", L, q.device)        # channel = key position :652-658
@@ -50,9 +52,13 @@ class MultiHeadAttentionBN(modules.BaseModule):
             # (variables in the unfused order: attention_bn's, then the dense layer's)
             g2, b2, mm2, mv2 = layers.bn_variables("attention_bn", attention_output.shape[-1], attention_output.device)
             W, bias = layers.dense_variables("output_transform", attention_output.shape[-1], self.feature_size, True, attention_output.device)
-            return ops.bn_dense_x3(attention_output, g2, b2, mm2, mv2, W, bias=bias)
+            if defer_bias:
+                return ops.bn_dense_x3(attention_output, g2, b2, mm2, mv2, W), bias
+            out = ops.bn_dense_x3(attention_output, g2, b2, mm2, mv2, W, bias=bias)
+            return out
         attention_output = layers.batch_norm(attention_output, self.is_train, "attention_bn")   # :666-671
-        return layers.dense(attention_output, self.feature_size, use_bias=True, name="output_transform")
+        out = layers.dense(attention_output, self.feature_size, use_bias=True, name="output_transform")
+        return (out, None) if defer_bias else out
 
 
 class FeedForwardNetwork(modules.BaseModule):
@@ -185,9 +191,26 @@ class TransformerEncoderMod(modules.BaseModule):
         self.ff_network = FeedForwardNetworkMod(feature_size, ff_filter_size, ff_relu_dropout, is_train, scope_id, final_size)
 
     def forward(self, inputs, dropout_mask=None, dropout_rate=None, **unused_params):
-        attention = self.multi_head_attention.forward(inputs, inputs)
-        # tf.layers.dropout(rate = 1.0 - attention_dropout) -- drops 90 % when training (:450, App. C10)
         rate = (1.0 - self.attention_dropout) if dropout_rate is None else dropout_rate
+        if (self.is_train and 0.0 < rate < 1.0 and ops.LN_DROPOUT_FUSED and inputs.is_cuda and inputs.dim() == 3
+                and inputs.shape[-1] in ops.LN_FEATURES):
+            # output_transform's bias add and the dropout ride in the layer norm's passes (forward: z = (a + bias) * keep / (1 - rate) +
+            # inputs; backward: the gradient of a leaves the layer norm masked and scaled, with the bias gradient) when the attention
+            # block hands back its raw GEMM output
+            attention, bias = self.multi_head_attention.forward(inputs, inputs, defer_bias=True)
+            if bias is not None:
+                if dropout_mask is None:
+                    dropout_mask = torch.empty(attention.shape, dtype=torch.uint8, device=attention.device).bernoulli_(1.0 - rate)
+                elif dropout_mask.dtype not in (torch.bool, torch.uint8):
+                    dropout_mask = dropout_mask.ne(0)          # a KEEP mask handed in by a test / the parity step: non-zero = kept
+                image = bool(layers.use_split_gemm(attention, attention.numel() // attention.shape[-1], self.ff_network.filter_size)
+                             and ops.ffn_mod_x3_ok(attention, self.ff_network.filter_size, self.ff_network.final_size))
+                attention = layers.layer_norm(attention, "LayerNorm", residual=inputs, bias=bias, image=image, mask=dropout_mask,
+                                              mask_scale=1.0 / (1.0 - rate))
+                return self.ff_network.forward(attention)
+        else:
+            attention = self.multi_head_attention.forward(inputs, inputs)
+        # tf.layers.dropout(rate = 1.0 - attention_dropout) -- drops 90 % when training (:450, App. C10)
         if self.is_train and rate > 0.0:
             if dropout_mask is None:
                 # keep with probability 1 - rate, scale the kept values by 1 / (1 - rate): one fused kernel each way (drawing the mask,
