@@ -112,6 +112,17 @@ diff.sort()
 print(f"sum over the main stream's intervals present in both (own - library): {sum(d[0] for d in diff):+.1f} us")
 for d, a, b, k in diff[:8] + diff[-12:]:
     print(f"  {d:+7.1f} us   own {a:7.1f}  library {b:7.1f}   interval ending with {k[0]} #{k[1]}")
+if os.environ.get("MARKER_TRACE_ALL") == "1":          # every interval of an even step, in launch order
+    i = 2
+    ent = [e for e in log[bounds[i]:bounds[i + 1]] if e[2] == (main_stream or 0)]
+    seen = {}
+    acc = 0.0
+    print("main stream, launch order: offset in the step, mean interval (both variants where equal), launch")
+    for a, b in zip(ent[:-1], ent[1:]):
+        k = (b[1], seen.get(b[1], 0)); seen[b[1]] = k[1] + 1
+        m = float(np.mean(res[0][k]))
+        acc += m
+        print(f"  {acc:8.1f}  {m:7.1f}  {k[0]} #{k[1]}")
 only0 = [(float(np.mean(v)), k) for k, v in res[0].items() if k not in res[1]]
 only1 = [(float(np.mean(v)), k) for k, v in res[1].items() if k not in res[0]]
 print("only in own-dx steps:", [(round(a, 1), k[0]) for a, k in only0], " only in library-dx steps:", [(round(a, 1), k[0]) for a, k in only1])
