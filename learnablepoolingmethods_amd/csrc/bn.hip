@@ -280,7 +280,14 @@ __global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restr
         };
         const float4* xp = reinterpret_cast<const float4*>(x) + c4;
         int r = r0 + rg;
-        for (; r + 3 * RG < r1; r += 4 * RG) {              // four rows' loads together, rows consumed in order
+        for (; r + 7 * RG < r1; r += 8 * RG) {              // eight rows' loads together (round 4: four left a 375-workgroup grid at
+            float4 v[8];                                    // 3.6 TB/s on the [24000, 4096] tensor of cfg-3), rows consumed in order
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = xp[(int64_t)(r + u * RG) * C4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) add(v[u]);
+        }
+        for (; r + 3 * RG < r1; r += 4 * RG) {
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = xp[(int64_t)(r + u * RG) * C4];
