@@ -1,0 +1,230 @@
+// K1, the soft-assignment GEMM (frame_level_models.py:2781-2789: tf.matmul(reshaped_input, cluster_weights) + the batch statistics
+// of cluster_bn), on FLAT 96-row workgroups (round 4).
+//
+// The 128-row tile GEMM form (tile_gemm.hip, MW = 2) walks the per-clip row tiles four at a time: 80 clips x 10 padded tiles = 800
+// tiles = 200 workgroups on 256 CUs, four tile-times on the critical path, 6 % of the rows padding, and every wave reads 8 KB of
+// fragments out of LDS per 12 MFMAs (64 KB of reads + 24 KB of LDS-DMA writes per step and CU against 768 matrix-pipe cycles: the LDS
+// is as busy as the matrix pipe).  Here:
+//   * the rows of all clips are ONE flat sequence cut into 96-row groups (24 000 rows = 250 workgroups, no padding, three tile-times);
+//     the operand is still the per-clip row-tile image K3's per-clip GEMM needs (lpm_split_rows_tiles) -- an LDS-DMA load takes one
+//     global address PER LANE, so a flat tile is gathered from the one or two per-clip tiles it straddles at no cost;
+//   * wave w owns column tile w (32 clusters) x three row tiles: the A fragments are shared by all eight waves and go through a ring
+//     of 6 KB stages in LDS; the B fragments of a wave are its own and nobody else's -- they go from L2 STRAIGHT INTO REGISTERS
+//     (global_load_dwordx4, four steps ahead), never through LDS: 48 KB of fragment reads + 6 KB of DMA writes per step and CU against
+//     576 matrix-pipe cycles;
+//   * the epilogue takes the column statistics from the accumulators and stores the accumulators as they are (a lane's 16 values of one
+//     column: 32 lanes = one 128-byte line of a row per store) -- no staging tile, no workgroup barrier.
+// LDS-DMA loads and register loads retire in order on one counter (vmcnt): every wave issues them in a fixed order -- per step
+// [A piece of step s + NS (waves 0-5)] [B hi, B lo of step s + DB] -- and waits with hand-counted immediates; the ring and the registers
+// are read by inline assembly behind those waits (the compiler puts vmcnt(0) in front of LDS reads it can see next to an LDS-DMA).
+#include "tile_gemm.h"
+
+namespace lpm {
+
+constexpr int AF_NS = 6;                   // A ring stages
+constexpr int AF_DB = 4;                   // steps of B fragments in flight (register sets)
+constexpr int AF_STAGE = 6 * 1024;         // three row tiles x (hi, lo)
+constexpr int AF_TAIL = 8;                 // peeled last steps (a multiple of 4, >= AF_NS, >= AF_DB)
+constexpr int AF_ROWS = 96;
+
+struct AssignFlatArgs {
+    const uint4* xr;           // per-clip row tiles [b][mt][ds][plane][lane]
+    const uint4* wt;           // weight tiles [ds][nt][plane][lane]
+    int M, T, MT, DS, NT, K;   // rows B*T, frames per clip, row tiles per clip, reduction steps D/16, column tiles K/32, clusters
+    float* logits;             // [M, K]
+    float* stats;              // [nblk][2][K]: rows < gridDim.x written, the rest zeroed
+    int nblk;
+};
+
+// VMEM operations a wave issues in step u of the tail (u < 0: the steady state): its A piece of step u + NS (waves 0-5), the two B
+// loads of step u + DB
+__host__ __device__ constexpr int af_ops(int u, bool loader) {
+    return ((loader && u < AF_TAIL - AF_NS) ? 1 : 0) + (u < AF_TAIL - AF_DB ? 2 : 0);
+}
+// ... and the vmcnt immediate at the top of tail step i (i very negative: steady state): the wave's own piece of A(i + 1) has landed and
+// B(i) is in its registers when at most this many younger operations are outstanding
+__host__ __device__ constexpr int af_wait(int i, bool loader) {
+    int wb = 0;
+    for (int u = i - AF_DB + 1; u < i; ++u) wb += af_ops(u, loader);
+    if (!loader || i + 1 >= AF_TAIL) return wb;
+    const int ua = i + 1 - AF_NS;                       // the step that issued A(i + 1), as its first operation
+    int wa = (ua < AF_TAIL - AF_DB ? 2 : 0);
+    for (int u = ua + 1; u < i; ++u) wa += af_ops(u, loader);
+    return wa < wb ? wa : wb;
+}
+static_assert(af_wait(-100, true) == 9 && af_wait(-100, false) == 6, "steady-state waits");
+
+// (the wait itself carries no operands: waves 0-5 and 6-7 wait with different immediates, and a tied operand in each arm of that branch
+// made the compiler copy the registers in front of one arm's wait -- before the load had written them.  The registers are handed over by
+// one empty statement behind the branch instead.)
+#define AF_WAIT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : : : "memory"); break;
+__device__ __forceinline__ void af_wait_vm(int n) {          // n folds to a constant where this is called
+    switch (n) {
+        AF_WAIT_CASE(1) AF_WAIT_CASE(2) AF_WAIT_CASE(3) AF_WAIT_CASE(4) AF_WAIT_CASE(5) AF_WAIT_CASE(6) AF_WAIT_CASE(7) AF_WAIT_CASE(8)
+        AF_WAIT_CASE(9) AF_WAIT_CASE(10) AF_WAIT_CASE(11) AF_WAIT_CASE(12) AF_WAIT_CASE(13) AF_WAIT_CASE(14)
+        default: asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); break;
+    }
+}
+#undef AF_WAIT_CASE
+
+__global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wg = blockIdx.x, cb = blockIdx.y;
+    const int ct = cb * 8 + wave;                                  // this wave's column tile
+    const bool loader = wave < 6;
+    const int nstep = a.DS;
+
+    // A piece of this wave (waves 0-5): row tile m_ld, plane p_ld of the group; lane (row l31, reduction half) -> its row of the per-clip
+    // image (rows past the end: the last row again -- masked in the epilogue)
+    const uint4* asrc;
+    {
+        const int m_ld = wave >> 1, p_ld = wave & 1;
+        const int64_t R = (int64_t)wg * AF_ROWS + m_ld * 32 + l31;
+        const int64_t Rc = R < a.M ? R : (int64_t)a.M - 1;
+        const int b = (int)(Rc / a.T), t = (int)(Rc - (int64_t)b * a.T);
+        asrc = a.xr + ((int64_t)b * a.MT + (t >> 5)) * a.DS * 128 + p_ld * 64 + half * 32 + (t & 31);
+    }
+    const uint4* bbase = a.wt + (int64_t)ct * 128;                 // wave-uniform; + step * NT * 128
+    const int64_t bstep = (int64_t)a.NT * 128;
+    const unsigned boff = (unsigned)lane * 16u;
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned rd_lane = smem_lds + (unsigned)lane * 16u;
+
+    struct Frag { tg_u32x4 h[3], l[3]; };
+    Frag fa[2];
+    tg_u32x4 bh[AF_DB], bl[AF_DB];
+    f32x16 acc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    auto issue_a = [&](int s, int stage) {                         // loader waves only
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)s * 128),
+                                         (__attribute__((address_space(3))) void*)(smem + stage * AF_STAGE + wave * 1024), 16, 0, 0);
+    };
+    auto issue_b = [&](int s, tg_u32x4& h, tg_u32x4& l) {
+        const uint4* p = bbase + (int64_t)s * bstep;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(h) : "v"(boff), "s"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(l) : "v"(boff), "s"(p) : "memory");
+    };
+    auto read_frags = [&](int stage, Frag& f) {
+        const unsigned ad = rd_lane + (unsigned)stage * AF_STAGE;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.h[m]) : "v"(ad), "n"((m * 2 + 0) * 1024) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.l[m]) : "v"(ad), "n"((m * 2 + 1) * 1024) : "memory");
+        }
+    };
+    auto frags_ready = [&](Frag& f) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.h[0]), "+v"(f.h[1]), "+v"(f.h[2]), "+v"(f.l[0]), "+v"(f.l[1]), "+v"(f.l[2]) : : "memory");
+    };
+
+    // prologue: the operations of the virtual steps -NS .. -1, in the loop's order
+#pragma unroll
+    for (int j = -AF_NS; j < 0; ++j) {
+        if (loader) issue_a(j + AF_NS, j + AF_NS);
+        if (j + AF_DB >= 0) issue_b(j + AF_DB, bh[j + AF_DB], bl[j + AF_DB]);
+    }
+    if (loader) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(AF_NS - 1 + 2 * AF_DB) : "memory");         // A(0): everything younger may fly
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, fa[0]);
+
+    int st = 0;                                                    // s % NS
+    // one step: i = its index in the tail (< 0: steady state), j = s & 3 (B register set), ab = s & 1 (A fragment set)
+    auto step = [&](int s, int i, int j, int ab) __attribute__((always_inline)) {
+        if (loader) af_wait_vm(af_wait(i, true));
+        else af_wait_vm(af_wait(i, false));
+        asm volatile("" : "+v"(bh[j]), "+v"(bl[j]) : : "memory");          // B(s) is in these registers from here on
+        frags_ready(fa[ab]);
+        __builtin_amdgcn_s_barrier();                              // A(s + 1) is in LDS for everyone; everyone holds the fragments of step s
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].h[m], bh[j], acc[m]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int st1 = st + 1 == AF_NS ? 0 : st + 1;
+        if (loader && (i < AF_TAIL - AF_NS)) issue_a(s + AF_NS, st);           // stage s % NS: its fragments are in registers
+        if (i + 1 < AF_TAIL) read_frags(st1, fa[ab ^ 1]);
+        st = st1;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].h[m], bl[j], acc[m]);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].l[m], bh[j], acc[m]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < AF_TAIL - AF_DB) issue_b(s + AF_DB, bh[j], bl[j]);
+    };
+    const int nmain = nstep - AF_TAIL;
+    for (int s0 = 0; s0 < nmain; s0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) step(s0 + j, -100, j, j & 1);
+    }
+#pragma unroll
+    for (int i = 0; i < AF_TAIL; ++i) step(nmain + i, i, i & 3, i & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // epilogue: acc[m][r] = logits[row wg * 96 + m * 32 + mfma32_row(r, lane)][column ct * 32 + l31]
+    const int col = ct * 32 + l31;
+    const int64_t row0 = (int64_t)wg * AF_ROWS + 4 * half;
+    float cs = 0.f, cq = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + m * 32 + (r & 3) + 8 * (r >> 2);
+            const float v = row < a.M ? acc[m][r] : 0.f;
+            cs += v;
+            cq = fmaf(v, v, cq);
+            if (row < a.M) a.logits[row * a.K + col] = acc[m][r];
+        }
+    cs += __shfl_xor(cs, 32, 64);
+    cq += __shfl_xor(cq, 32, 64);
+    if (lane < 32) {
+        float* p = a.stats + (int64_t)wg * 2 * a.K;
+        p[col] = cs;
+        p[a.K + col] = cq;
+    }
+    // the statistics rows nobody owns (the array is sized for the 64-row groups of the per-clip forms)
+    for (int r = gridDim.x + wg; r < a.nblk; r += gridDim.x)
+        a.stats[(int64_t)r * 2 * a.K + (tid >> 8) * a.K + cb * 256 + (tid & 255)] = 0.f;
+}
+
+static int af_enabled() {
+    static const int on = [] {
+        const char* e = getenv("LPM_K1_FLAT");         // 0: the 128-row tile GEMM form (A/B switch)
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return on;
+}
+
+bool assign_flat_ok(int B, int T, int D, int K) {
+    const int DS = D / 16;
+    return af_enabled() && D % 64 == 0 && DS >= AF_TAIL + 4 && K % 256 == 0 && K > 0 && (int64_t)B * T < (int64_t)1 << 31;
+}
+
+int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int D, int K, float* logits, float* stats, int nblk,
+                       int timing_tag, hipStream_t stream, const char* what) {
+    AssignFlatArgs a{};
+    a.xr = (const uint4*)xr; a.wt = (const uint4*)wt;
+    a.M = B * T; a.T = T; a.MT = MT; a.DS = D / 16; a.NT = K / 32; a.K = K;
+    a.logits = logits; a.stats = stats; a.nblk = nblk;
+    const int nwg = (a.M + AF_ROWS - 1) / AF_ROWS;
+    if (nwg > nblk || (((uintptr_t)xr | (uintptr_t)wt) & 15) != 0) {
+        set_error("%s: internal: %d row groups for %d statistics rows, or unaligned tiles", what, nwg, nblk);
+        return LPM_ERR_BADARG;
+    }
+    const dim3 grid((unsigned)nwg, (unsigned)(K / 256));
+    const size_t lds = (size_t)AF_NS * AF_STAGE;
+    hipEvent_t e0, e1;
+    if (timing_tag && timing_request(timing_tag, &e0, &e1))
+        hipExtLaunchKernelGGL(assign_flat_kernel, grid, dim3(512), lds, stream, e0, e1, 0, a);
+    else
+        hipLaunchKernelGGL(assign_flat_kernel, grid, dim3(512), lds, stream, a);
+    return check_launch(what);
+}
+
+}  // namespace lpm

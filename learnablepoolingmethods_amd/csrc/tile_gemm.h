@@ -124,4 +124,10 @@ int tile_gemm_image(const TileGemmArgs& g, hipStream_t stream, const char* what)
 int tile_gemm_image_form();
 int tile_gemm_image_row_groups(int M);
 
+// K1's forward on flat 96-row workgroups (assign_flat.hip): the per-clip row tiles gathered per lane, B fragments straight into registers.
+// stats: [nblk][2][K], nblk >= ceil(B T / 96) rows (the rows past the row groups are zeroed).
+bool assign_flat_ok(int B, int T, int D, int K);
+int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int D, int K, float* logits, float* stats, int nblk,
+                       int timing_tag, hipStream_t stream, const char* what);
+
 }  // namespace lpm

@@ -965,6 +965,10 @@ static int assign_gemm_tiles_fwd_impl(const void* xr, const void* wt, int B, int
     LPM_REQUIRE(B > 0 && lpm_assign_gemm_tiles_supported(T, D, K), LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_assign_gemm_tiles_fwd: need D %% 32 == 0, K %% 32 == 0, K <= 512 (D=%d K=%d)", D, K);
     const int MT = row_tiles_per_clip(T), DS = D / 16, NT = K / 32;
+    // fp32 storage, K a multiple of 256, D a multiple of 64: flat 96-row workgroups (assign_flat.hip; LPM_K1_FLAT=0: the forms below)
+    if (planes == 2 && assign_flat_ok(B, T, D, K))
+        return assign_flat_launch(xr, wt, B, T, MT, D, K, (float*)logits, partial, lpm_assign_gemm_tiles_nblk(B, T),
+                                  D >= 1024 ? LPM_TIMING_K1 : 0, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd");
     const int64_t U = 64 * planes;             // 16-byte units per (tile, step)
     TileGemmArgs g{};
     g.a = (const uint4*)xr; g.a_tile = (int64_t)DS * U; g.a_step = U; g.a_batch = (int64_t)MT * DS * U; g.a_tiles = MT;
