@@ -21,11 +21,14 @@
 
 namespace lpm {
 
-constexpr int AF_NS = 6;                   // A ring stages
-constexpr int AF_DB = 4;                   // steps of B fragments in flight (register sets)
-constexpr int AF_STAGE = 6 * 1024;         // three row tiles x (hi, lo)
-constexpr int AF_TAIL = 8;                 // peeled last steps (a multiple of 4, >= AF_NS, >= AF_DB)
+constexpr int AF_KSTEP = 6 * 1024;         // A bytes per reduction step: three row tiles x (hi, lo)
 constexpr int AF_ROWS = 96;
+// A ring: NS stages of KB reduction steps each, ONE workgroup barrier per stage.  Measured with one step per stage (LPM_K1_DBG
+// ablations, tools/k1_flat_ablate.sh): the loop of 64 barriers alone is 7.8 us and is NOT covered by the MFMAs -- every wave has
+// issued its last MFMA when it arrives, so the matrix pipe idles for the barrier's round trip (MFMAs + barriers 24.8 us against 17.5 us
+// of MFMA issue) -- hence several steps per barrier.
+__host__ __device__ constexpr int af_ns(int KB) { return KB == 1 ? 6 : 4; }
+__host__ __device__ constexpr int af_tail(int KB, int DB) { return KB == 4 ? (DB == 8 ? 16 : 12) : 8; }   // peeled last steps: a multiple of DB and KB, >= (NS - 1) KB
 
 struct AssignFlatArgs {
     const uint4* xr;           // per-clip row tiles [b][mt][ds][plane][lane]
@@ -36,23 +39,24 @@ struct AssignFlatArgs {
     int nblk;
 };
 
-// VMEM operations a wave issues in step u of the tail (u < 0: the steady state): its A piece of step u + NS (waves 0-5), the two B
-// loads of step u + DB
+__host__ __device__ constexpr int af_mod(int u, int n) { return ((u % n) + n) % n; }
+// VMEM operations a wave issues in step u, counted from the start of the tail (u < 0: the steady state, and the prologue's virtual
+// steps): at the first step of a stage the KB pieces of the stage NS - 1 ahead (waves 0-5), at the end of every step the two B loads
+// of step u + DB
+template <int KB, int DB>
 __host__ __device__ constexpr int af_ops(int u, bool loader) {
-    return ((loader && u < AF_TAIL - AF_NS) ? 1 : 0) + (u < AF_TAIL - AF_DB ? 2 : 0);
+    return ((loader && af_mod(u, KB) == 0 && u + (af_ns(KB) - 1) * KB < af_tail(KB, DB)) ? KB : 0) + (u + DB < af_tail(KB, DB) ? 2 : 0);
 }
-// ... and the vmcnt immediate at the top of tail step i (i very negative: steady state): the wave's own piece of A(i + 1) has landed and
-// B(i) is in its registers when at most this many younger operations are outstanding
+// ... and the vmcnt immediate at the top of step i: B(i) is in the wave's registers when at most this many younger operations are
+// outstanding.  The wave's pieces of the NEXT stage, which the barrier at the top of a stage promises to everyone, were requested
+// (NS - 2) KB >= DB steps ago, i.e. before B(i): they have landed as well (loads retire in order).
+template <int KB, int DB>
 __host__ __device__ constexpr int af_wait(int i, bool loader) {
-    int wb = 0;
-    for (int u = i - AF_DB + 1; u < i; ++u) wb += af_ops(u, loader);
-    if (!loader || i + 1 >= AF_TAIL) return wb;
-    const int ua = i + 1 - AF_NS;                       // the step that issued A(i + 1), as its first operation
-    int wa = (ua < AF_TAIL - AF_DB ? 2 : 0);
-    for (int u = ua + 1; u < i; ++u) wa += af_ops(u, loader);
-    return wa < wb ? wa : wb;
+    int w = 0;
+    for (int u = i - DB + 1; u < i; ++u) w += af_ops<KB, DB>(u, loader);
+    return w;
 }
-static_assert(af_wait(-100, true) == 9 && af_wait(-100, false) == 6, "steady-state waits");
+static_assert(af_wait<1, 4>(-400, true) == 9 && af_wait<1, 4>(-400, false) == 6, "steady-state waits");
 
 // (the wait itself carries no operands: waves 0-5 and 6-7 wait with different immediates, and a tied operand in each arm of that branch
 // made the compiler copy the registers in front of one arm's wait -- before the load had written them.  The registers are handed over by
@@ -61,13 +65,22 @@ static_assert(af_wait(-100, true) == 9 && af_wait(-100, false) == 6, "steady-sta
 __device__ __forceinline__ void af_wait_vm(int n) {          // n folds to a constant where this is called
     switch (n) {
         AF_WAIT_CASE(1) AF_WAIT_CASE(2) AF_WAIT_CASE(3) AF_WAIT_CASE(4) AF_WAIT_CASE(5) AF_WAIT_CASE(6) AF_WAIT_CASE(7) AF_WAIT_CASE(8)
-        AF_WAIT_CASE(9) AF_WAIT_CASE(10) AF_WAIT_CASE(11) AF_WAIT_CASE(12) AF_WAIT_CASE(13) AF_WAIT_CASE(14)
+        AF_WAIT_CASE(9) AF_WAIT_CASE(10) AF_WAIT_CASE(11) AF_WAIT_CASE(12) AF_WAIT_CASE(13) AF_WAIT_CASE(14) AF_WAIT_CASE(15)
+        AF_WAIT_CASE(16) AF_WAIT_CASE(17) AF_WAIT_CASE(18) AF_WAIT_CASE(19) AF_WAIT_CASE(20) AF_WAIT_CASE(21) AF_WAIT_CASE(22)
+        AF_WAIT_CASE(23) AF_WAIT_CASE(24) AF_WAIT_CASE(25) AF_WAIT_CASE(26) AF_WAIT_CASE(27) AF_WAIT_CASE(28) AF_WAIT_CASE(29) AF_WAIT_CASE(30)
+        AF_WAIT_CASE(31) AF_WAIT_CASE(32) AF_WAIT_CASE(33) AF_WAIT_CASE(34) AF_WAIT_CASE(35) AF_WAIT_CASE(36)
         default: asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); break;
     }
 }
 #undef AF_WAIT_CASE
 
+// DBG (measurement instantiations, LPM_K1_DBG): 1 no main loop, 2 no stores, 4 no loads inside the loop, 8 no MFMAs, 16 no fragment reads
+template <int KB, int DB, int DBG>
 __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArgs a) {
+    constexpr int NS = af_ns(KB), TAIL = af_tail(KB, DB), STAGE = KB * AF_KSTEP;
+    static_assert((NS - 2) * KB >= DB && TAIL % DB == 0 && TAIL % KB == 0 && TAIL >= (NS - 1) * KB && (DB == 4 || DB == 8),
+                  "A(next stage) must be older than B(i); the tail is whole register rounds and whole stages");
+    constexpr int dbg = DBG;           // (compile-time: run-time tests around the MFMA groups distort what they measure)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,9 +95,9 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
     const uint4* asrc;
     {
         const int m_ld = wave >> 1, p_ld = wave & 1;
-        const int64_t R = (int64_t)wg * AF_ROWS + m_ld * 32 + l31;
-        const int64_t Rc = R < a.M ? R : (int64_t)a.M - 1;
-        const int b = (int)(Rc / a.T), t = (int)(Rc - (int64_t)b * a.T);
+        const unsigned R = (unsigned)wg * AF_ROWS + m_ld * 32 + l31;                 // (B T < 2^31: assign_flat_ok)
+        const unsigned Rc = R < (unsigned)a.M ? R : (unsigned)a.M - 1u;
+        const int b = (int)(Rc / (unsigned)a.T), t = (int)(Rc - (unsigned)b * (unsigned)a.T);
         asrc = a.xr + ((int64_t)b * a.MT + (t >> 5)) * a.DS * 128 + p_ld * 64 + half * 32 + (t & 31);
     }
     const uint4* bbase = a.wt + (int64_t)ct * 128;                 // wave-uniform; + step * NT * 128
@@ -95,24 +108,26 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
 
     struct Frag { tg_u32x4 h[3], l[3]; };
     Frag fa[2];
-    tg_u32x4 bh[AF_DB], bl[AF_DB];
+    tg_u32x4 bh[DB], bl[DB];
     f32x16 acc[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    auto issue_a = [&](int s, int stage) {                         // loader waves only
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)s * 128),
-                                         (__attribute__((address_space(3))) void*)(smem + stage * AF_STAGE + wave * 1024), 16, 0, 0);
+    auto issue_a = [&](int q, int slot) {                          // stage q (steps q KB ..) -> ring slot; loader waves only
+#pragma unroll
+        for (int e = 0; e < KB; ++e)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + (int64_t)(q * KB + e) * 128),
+                                             (__attribute__((address_space(3))) void*)(smem + slot * STAGE + e * AF_KSTEP + wave * 1024), 16, 0, 0);
     };
     auto issue_b = [&](int s, tg_u32x4& h, tg_u32x4& l) {
         const uint4* p = bbase + (int64_t)s * bstep;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(h) : "v"(boff), "s"(p) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(l) : "v"(boff), "s"(p) : "memory");
     };
-    auto read_frags = [&](int stage, Frag& f) {
-        const unsigned ad = rd_lane + (unsigned)stage * AF_STAGE;
+    auto read_frags = [&](unsigned byte_off, Frag& f) {            // byte_off: slot * STAGE + (step within the stage) * AF_KSTEP
+        const unsigned ad = rd_lane + byte_off;
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.h[m]) : "v"(ad), "n"((m * 2 + 0) * 1024) : "memory");
@@ -123,48 +138,56 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.h[0]), "+v"(f.h[1]), "+v"(f.h[2]), "+v"(f.l[0]), "+v"(f.l[1]), "+v"(f.l[2]) : : "memory");
     };
 
-    // prologue: the operations of the virtual steps -NS .. -1, in the loop's order
+    // prologue: the operations of the virtual steps -(NS - 1) KB .. -1, in the loop's order (stages 0 .. NS - 2, B(0 .. DB - 1))
+    static_assert((NS - 1) * KB >= DB, "the prologue's virtual steps cover the B loads");
 #pragma unroll
-    for (int j = -AF_NS; j < 0; ++j) {
-        if (loader) issue_a(j + AF_NS, j + AF_NS);
-        if (j + AF_DB >= 0) issue_b(j + AF_DB, bh[j + AF_DB], bl[j + AF_DB]);
+    for (int u = -(NS - 1) * KB; u < 0; ++u) {
+        if (loader && af_mod(u, KB) == 0) issue_a(u / KB + NS - 1, u / KB + NS - 1);
+        if (u + DB >= 0) issue_b(u + DB, bh[u + DB], bl[u + DB]);
     }
-    if (loader) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(AF_NS - 1 + 2 * AF_DB) : "memory");         // A(0): everything younger may fly
+    // stage 0 (the wave's first KB pieces): everything younger may fly
+    if (loader) af_wait_vm((NS - 2) * KB + 2 * DB);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     read_frags(0, fa[0]);
 
-    int st = 0;                                                    // s % NS
-    // one step: i = its index in the tail (< 0: steady state), j = s & 3 (B register set), ab = s & 1 (A fragment set)
+    int slot = 0;                                                  // (s / KB) % NS
+    // one step: i = its index in the tail (< 0: steady state, same residues mod DB and KB), j = s % DB (B register set), ab = s & 1
     auto step = [&](int s, int i, int j, int ab) __attribute__((always_inline)) {
-        if (loader) af_wait_vm(af_wait(i, true));
-        else af_wait_vm(af_wait(i, false));
+        const int e = af_mod(i, KB);                               // step within its stage
+        if (loader) af_wait_vm(af_wait<KB, DB>(i, true));
+        else af_wait_vm(af_wait<KB, DB>(i, false));
         asm volatile("" : "+v"(bh[j]), "+v"(bl[j]) : : "memory");          // B(s) is in these registers from here on
         frags_ready(fa[ab]);
-        __builtin_amdgcn_s_barrier();                              // A(s + 1) is in LDS for everyone; everyone holds the fragments of step s
-        asm volatile("" ::: "memory");
+        if (e == 0) {
+            __builtin_amdgcn_s_barrier();                          // the next stage is in LDS for everyone; the previous one has been read
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
-        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].h[m], bh[j], acc[m]);
+        for (int m = 0; m < 3; ++m) if (!(dbg & 8)) acc[m] = tg_mfma(fa[ab].h[m], bh[j], acc[m]);
         __builtin_amdgcn_sched_barrier(0);
-        const int st1 = st + 1 == AF_NS ? 0 : st + 1;
-        if (loader && (i < AF_TAIL - AF_NS)) issue_a(s + AF_NS, st);           // stage s % NS: its fragments are in registers
-        if (i + 1 < AF_TAIL) read_frags(st1, fa[ab ^ 1]);
-        st = st1;
+        if (e == 0 && loader && (i + (NS - 1) * KB < TAIL) && !(dbg & 4))
+            issue_a(s / KB + NS - 1, slot == 0 ? NS - 1 : slot - 1);       // into the slot of the stage before this one
+        const int slot1 = slot + 1 == NS ? 0 : slot + 1;
+        if (i + 1 < TAIL && !(dbg & 16)) read_frags((unsigned)((e + 1 == KB ? slot1 : slot) * STAGE + (e + 1 == KB ? 0 : e + 1) * AF_KSTEP), fa[ab ^ 1]);
+        if (e + 1 == KB) slot = slot1;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].h[m], bl[j], acc[m]);
+        for (int m = 0; m < 3; ++m) if (!(dbg & 8)) acc[m] = tg_mfma(fa[ab].h[m], bl[j], acc[m]);
 #pragma unroll
-        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].l[m], bh[j], acc[m]);
+        for (int m = 0; m < 3; ++m) if (!(dbg & 8)) acc[m] = tg_mfma(fa[ab].l[m], bh[j], acc[m]);
         __builtin_amdgcn_sched_barrier(0);
-        if (i < AF_TAIL - AF_DB) issue_b(s + AF_DB, bh[j], bl[j]);
+        if (i + DB < TAIL && !(dbg & 4)) issue_b(s + DB, bh[j], bl[j]);
     };
-    const int nmain = nstep - AF_TAIL;
-    for (int s0 = 0; s0 < nmain; s0 += 4) {
+    const int nmain = nstep - TAIL;
+    for (int s0 = 0; s0 < ((dbg & 1) ? 0 : nmain); s0 += DB) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) step(s0 + j, -100, j, j & 1);
+        for (int j = 0; j < DB; ++j) step(s0 + j, -400 + j, j, j & 1);
     }
+    if (!(dbg & 1)) {
 #pragma unroll
-    for (int i = 0; i < AF_TAIL; ++i) step(nmain + i, i, i & 3, i & 1);
+        for (int i = 0; i < TAIL; ++i) step(nmain + i, i, i % DB, i & 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // epilogue: acc[m][r] = logits[row wg * 96 + m * 32 + mfma32_row(r, lane)][column ct * 32 + l31]
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
             const float v = row < a.M ? acc[m][r] : 0.f;
             cs += v;
             cq = fmaf(v, v, cq);
-            if (row < a.M) a.logits[row * a.K + col] = acc[m][r];
+            if (row < a.M && !(dbg & 2)) a.logits[row * a.K + col] = acc[m][r];
         }
     cs += __shfl_xor(cs, 32, 64);
     cq += __shfl_xor(cq, 32, 64);
@@ -201,9 +224,19 @@ static int af_enabled() {
     return on;
 }
 
+// steps per stage (LPM_K1_KB = 1, 2, 4) and steps of B fragments in flight (LPM_K1_DB = 4; 8 with four steps per stage): A/B switches
+static int af_kb() {
+    static const int kb = [] { const char* e = getenv("LPM_K1_KB"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 2; }();
+    return kb;
+}
+static int af_db() {
+    static const int db = [] { const char* e = getenv("LPM_K1_DB"); const int v = e ? atoi(e) : 0; return (v == 8 && af_kb() == 4) ? 8 : 4; }();
+    return db;
+}
+
 bool assign_flat_ok(int B, int T, int D, int K) {
-    const int DS = D / 16;
-    return af_enabled() && D % 64 == 0 && DS >= AF_TAIL + 4 && K % 256 == 0 && K > 0 && (int64_t)B * T < (int64_t)1 << 31;
+    const int DS = D / 16, db = af_db(), tail = af_tail(af_kb(), db);
+    return af_enabled() && D % 16 == 0 && DS % db == 0 && DS >= tail + db && K % 256 == 0 && K > 0 && (int64_t)B * T < (int64_t)1 << 31;
 }
 
 int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int D, int K, float* logits, float* stats, int nblk,
@@ -218,12 +251,32 @@ int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int
         return LPM_ERR_BADARG;
     }
     const dim3 grid((unsigned)nwg, (unsigned)(K / 256));
-    const size_t lds = (size_t)AF_NS * AF_STAGE;
+    const int kb = af_kb(), db = af_db();
+    static const int dbg_env = [] { const char* e = getenv("LPM_K1_DBG"); return e ? atoi(e) : 0; }();
+    const size_t lds = (size_t)af_ns(kb) * kb * AF_KSTEP;
     hipEvent_t e0, e1;
-    if (timing_tag && timing_request(timing_tag, &e0, &e1))
-        hipExtLaunchKernelGGL(assign_flat_kernel, grid, dim3(512), lds, stream, e0, e1, 0, a);
-    else
-        hipLaunchKernelGGL(assign_flat_kernel, grid, dim3(512), lds, stream, a);
+    const bool timed = !dbg_env && timing_tag && timing_request(timing_tag, &e0, &e1);
+#define AF_LAUNCH(KB, DB, DBG)                                                                              \
+    do {                                                                                                    \
+        if (timed) hipExtLaunchKernelGGL((assign_flat_kernel<KB, DB, DBG>), grid, dim3(512), lds, stream, e0, e1, 0, a); \
+        else hipLaunchKernelGGL((assign_flat_kernel<KB, DB, DBG>), grid, dim3(512), lds, stream, a);       \
+    } while (0)
+    if (dbg_env) {                                     // measurement instantiations (tools/k1_flat_ablate.sh), two steps per barrier
+        switch (dbg_env) {
+            case 1: AF_LAUNCH(2, 4, 1); break;
+            case 4: AF_LAUNCH(2, 4, 4); break;
+            case 8: AF_LAUNCH(2, 4, 8); break;
+            case 16: AF_LAUNCH(2, 4, 16); break;
+            case 20: AF_LAUNCH(2, 4, 20); break;
+            case 28: AF_LAUNCH(2, 4, 28); break;
+            default: set_error("%s: LPM_K1_DBG takes 1, 4, 8, 16, 20, 28", what); return LPM_ERR_BADARG;
+        }
+    }
+    else if (kb == 1) AF_LAUNCH(1, 4, 0);
+    else if (kb == 2) AF_LAUNCH(2, 4, 0);
+    else if (db == 8) AF_LAUNCH(4, 8, 0);
+    else AF_LAUNCH(4, 4, 0);
+#undef AF_LAUNCH
     return check_launch(what);
 }
 

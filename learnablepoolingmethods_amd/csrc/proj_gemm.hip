@@ -41,9 +41,20 @@ constexpr int PJ_AUX = LPM_PJ_AUX;                 // LDS-DMA cache policy of th
 // these kernels off that list).  All W reads of a stage are requested at once, the x fragments one row tile ahead; each wait hands its
 // registers over through "+v" operands (the compiler may not touch them earlier, and no scalar load sits in the loop: LDS returns in order,
 // so the lgkmcnt values below count ds_reads only).
-template <int MT, int NP, int XD>
+// SC (round 4, the lazily normalised d-major descriptor of NetVladV2 / the model without encoders): x is TWO column blocks -- columns
+// < pp.n1a from x (row stride ldx), each multiplied by pp.scale[row][column % pp.ks] as it is brought in (the un-normalised residual sums
+// of the video stream and their per-(clip, cluster) scale 1 / (n_k sqrt g): frame_level_models.py:2819-2822 applied where the operand is
+// read), the rest from pp.x2 as they are (the audio stream's descriptor) -- tf.concat at :2309 / :2445 never materialises.  Only the
+// loader wave differs: its pieces go through registers (load, multiply, ds_write into the same image the LDS-DMA leaves), one pair ahead.
+struct ProjParts {
+    const float* x2;
+    int64_t ldx2, n1a;
+    const float* scale;
+    int ks;
+};
+template <int MT, int NP, int XD, bool SC = false>
 __global__ __launch_bounds__(576, 1) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M, int64_t Kd,
-                                                          int N, int nslab, int splits, float* __restrict__ part) {
+                                                          int N, int nslab, int splits, float* __restrict__ part, const ProjParts pp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,6 +72,55 @@ __global__ __launch_bounds__(576, 1) void proj_fwd_kernel(const float* __restric
         // (the last pair of an odd range: its second slab is re-read from the first -- nobody consumes it)
         const int q = lane & 7;
         const int part = q ^ ((lane >> 3) & 7);                    // (8 p + lane / 8) & 7 == lane / 8
+        if constexpr (SC) {
+            const int nss = (ns + 1) >> 1;
+            // (the scales of a pair ride along with its x pieces where the registers allow; otherwise they are fetched when the pair is
+            // written -- they come from L2, the x pieces from HBM)
+            constexpr bool HOLD = NP <= 10;
+            f32x4 xv[NP], sv[HOLD ? NP : 1];
+            bool firstv = true;
+            int kcv = 0;
+            auto load = [&](int j) {
+                int64_t col = (int64_t)s0 * 16 + (int64_t)j * 32 + part * 4 - ((part >= 4 && 2 * j + 1 >= ns) ? 16 : 0);
+                const bool first = col < pp.n1a;               // (a pair never straddles the blocks: n1a is a multiple of 32, s0 is even)
+                const int kc = first ? (int)(col % pp.ks) : 0;
+                firstv = first; kcv = kc;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int row = min(p * 8 + (lane >> 3), M - 1);
+                    const float* src = first ? x + (int64_t)row * ldx + col : pp.x2 + (int64_t)row * pp.ldx2 + (col - pp.n1a);
+                    xv[p] = *reinterpret_cast<const f32x4*>(src);
+                    if constexpr (HOLD)
+                        sv[p] = first ? *reinterpret_cast<const f32x4*>(pp.scale + (int64_t)row * pp.ks + kc) : f32x4{1.f, 1.f, 1.f, 1.f};
+                }
+            };
+            auto store = [&](int j) {
+                unsigned char* st = smem + PJ_NS * PJ_WBYTES + (j % XD) * PJ_XPAIR;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    f32x4 sc;
+                    if constexpr (HOLD) sc = sv[p];
+                    else sc = firstv ? *reinterpret_cast<const f32x4*>(pp.scale + (int64_t)min(p * 8 + (lane >> 3), M - 1) * pp.ks + kcv)
+                                     : f32x4{1.f, 1.f, 1.f, 1.f};
+                    *reinterpret_cast<f32x4*>(st + p * 1024 + lane * 16) = xv[p] * sc;
+                }
+            };
+            load(0);
+            store(0);
+            if (1 < nss) load(1);
+            for (int s = 0; s < ns; ++s) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): this wave's LDS writes are done
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                // after the barrier of stage 2 j every wave is past pair j - 1: the buffer pair j + 1 goes to (pair j + 1 - XD's) is free
+                if (!(s & 1)) {
+                    const int j = s >> 1;
+                    if (j + 1 < nss) store(j + 1);
+                    if (j + 2 < nss) load(j + 2);
+                }
+            }
+            return;
+        }
         const float* xs[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) xs[p] = x + (int64_t)min(p * 8 + (lane >> 3), M - 1) * ldx + (int64_t)s0 * 16 + part * 4;
@@ -451,14 +511,36 @@ extern "C" size_t lpm_proj_fwd_workspace_bytes(int M, int64_t Kd, int N) {
     return (size_t)lpm::proj_splits(Kd, N) * M * N * sizeof(float);
 }
 
+static int proj_fwd_impl(const float* x, int64_t ldx, const lpm::ProjParts* parts, const float* W, int M, int64_t Kd, int N, float* y,
+                         void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 extern "C" int lpm_proj_fwd(const float* x, int64_t ldx, const float* W, int M, int64_t Kd, int N, float* y, void* workspace,
                             size_t workspace_bytes, lpm_stream_t stream) {
+    return proj_fwd_impl(x, ldx, nullptr, W, M, Kd, N, y, workspace, workspace_bytes, stream);
+}
+// y = [x1 * scale | x2] . W without the concatenation: x1 [M, n1a] (row stride ldx1; n1a a multiple of 32) is multiplied by
+// scale[row][column % ks] where it is read (ks a multiple of 4: the lazily normalised d-major descriptor -- the un-normalised residual
+// sums [M, D, K] and lpm_vlad_row_scales' [M, K]); x2 [M, Kd - n1a] (row stride ldx2; may be NULL when n1a == Kd) enters as it is.
+extern "C" int lpm_proj_fwd_parts(const float* x1, int64_t ldx1, int64_t n1a, const float* scale, int ks, const float* x2, int64_t ldx2,
+                                  const float* W, int M, int64_t Kd, int N, float* y, void* workspace, size_t workspace_bytes,
+                                  lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x1 && scale && (x2 || n1a == Kd), LPM_ERR_BADARG, "lpm_proj_fwd_parts: null pointer");
+    LPM_REQUIRE(n1a > 0 && n1a <= Kd && n1a % 32 == 0 && ks > 0 && ks % 4 == 0 && n1a % ks == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_proj_fwd_parts: the scaled block must be a multiple of 32 columns and of ks (n1a=%lld ks=%d)", (long long)n1a, ks);
+    LPM_REQUIRE(ldx1 >= n1a && ldx1 % 4 == 0 && (n1a == Kd || (ldx2 >= Kd - n1a && ldx2 % 4 == 0)), LPM_ERR_BADARG,
+                "lpm_proj_fwd_parts: row strides must cover their block and be multiples of 4");
+    LPM_REQUIRE((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)scale) & 15) == 0, LPM_ERR_BADARG, "lpm_proj_fwd_parts: pointers must be 16-byte aligned");
+    const ProjParts pp{x2, ldx2, n1a, scale, ks};
+    return proj_fwd_impl(x1, ldx1, &pp, W, M, Kd, N, y, workspace, workspace_bytes, stream);
+}
+static int proj_fwd_impl(const float* x, int64_t ldx, const lpm::ProjParts* parts, const float* W, int M, int64_t Kd, int N, float* y,
+                         void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(x && W && y && workspace, LPM_ERR_BADARG, "lpm_proj_fwd: null pointer");
     LPM_REQUIRE(lpm_proj_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_proj_fwd: need M <= 128, N %% 512 == 0, Kd %% 16 == 0 (M=%d Kd=%lld N=%d)", M, (long long)Kd, N);
     LPM_REQUIRE(workspace_bytes >= lpm_proj_fwd_workspace_bytes(M, Kd, N), LPM_ERR_WORKSPACE, "lpm_proj_fwd: workspace too small");
-    LPM_REQUIRE(ldx >= Kd && ldx % 4 == 0, LPM_ERR_BADARG, "lpm_proj_fwd: the row stride of x must be >= Kd and a multiple of 4");
+    LPM_REQUIRE(parts || (ldx >= Kd && ldx % 4 == 0), LPM_ERR_BADARG, "lpm_proj_fwd: the row stride of x must be >= Kd and a multiple of 4");
     LPM_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)workspace) & 15) == 0, LPM_ERR_BADARG,
                 "lpm_proj_fwd: pointers must be 16-byte aligned");
     const int splits = proj_splits(Kd, N), nslab = (int)(Kd / 16), MT = (M + 31) / 32;
@@ -467,13 +549,14 @@ extern "C" int lpm_proj_fwd(const float* x, int64_t ldx, const float* W, int M, 
 #define LPM_PJ(MTV, NPV, XDV)                                                                                                \
     do {                                                                                                                     \
         const size_t lds = (size_t)PJ_NS * PJ_WBYTES + XDV * NPV * 1024;                                                     \
-        auto kern = proj_fwd_kernel<MTV, NPV, XDV>;                                                                          \
+        auto kern = parts ? proj_fwd_kernel<MTV, NPV, XDV, true> : proj_fwd_kernel<MTV, NPV, XDV, false>;                    \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {    \
             (void)hipGetLastError();                                                                                         \
             set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                                 \
             return LPM_ERR_LAUNCH;                                                                                           \
         }                                                                                                                    \
-        hipLaunchKernelGGL(kern, grid, dim3(576), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace);            \
+        hipLaunchKernelGGL(kern, grid, dim3(576), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace,             \
+                           parts ? *parts : ProjParts{});                                                                    \
     } while (0)
     /* three pair-buffers of x where they fit beside the four weight stages (measured: no gain over two once the ring is read without the */
     /* compiler's waits -- kept where it is free) */

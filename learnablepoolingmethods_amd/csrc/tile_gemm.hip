@@ -822,6 +822,37 @@ __global__ __launch_bounds__(256) void split_weight_tiles_kernel(const float* __
     }
 }
 
+// ... of the matrix [x1 * scale | x2] (lpm_proj_fwd_parts' operand): column c < n1a is x1[r][c] * scale[r][c % ks], the rest x2[r][c - n1a]
+__global__ __launch_bounds__(256) void split_weight_tiles_parts_kernel(const float* __restrict__ x1, int64_t ld1, int64_t n1a,
+                                                                       const float* __restrict__ scale, int ks, const float* __restrict__ x2,
+                                                                       int64_t ld2, int R, int64_t N, uint4* __restrict__ wt) {
+    const int RS = R / 16;
+    const int64_t NT = (N + 31) / 32;
+    const int64_t total = (int64_t)RS * NT * 64;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(w & 63);
+        const int64_t t = w >> 6;
+        const int64_t nt = t % NT;
+        const int rs = (int)(t / NT);
+        const int64_t col = nt * 32 + (lane & 31);
+        const int r = rs * 16 + 8 * (lane >> 5);
+        float v[8];
+        if (col < n1a) {
+            const int kc = (int)(col % ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = x1[(int64_t)(r + e) * ld1 + col] * scale[(int64_t)(r + e) * ks + kc];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (col < N) ? x2[(int64_t)(r + e) * ld2 + (col - n1a)] : 0.f;
+        }
+        uint4 hi, lo;
+        tg_split8(v, hi, lo);
+        const int64_t base = t * 128 + lane;
+        wt[base] = hi;
+        wt[base + 64] = lo;
+    }
+}
+
 // out[i] = sum_z part[z][i]   (float4 granularity)
 __global__ __launch_bounds__(256) void tg_reduce_splits_kernel(const float4* __restrict__ part, int Z, int64_t n4,
                                                                float4* __restrict__ out) {
@@ -950,6 +981,21 @@ static int split_weight_tiles_impl(const float* w, int R, int N, int transposed,
     hipLaunchKernelGGL(split_weight_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, R, N,
                        transposed, (uint4*)wt, planes);
     return check_launch("lpm_split_weight_tiles");
+}
+// the weight tiles (lpm_weight_tiles_bytes(R, N)) of [x1 * scale | x2] [R, N]: see lpm_proj_fwd_parts for the operand's description
+extern "C" int lpm_split_weight_tiles_parts(const float* x1, int64_t ld1, int64_t n1a, const float* scale, int ks, const float* x2, int64_t ld2,
+                                            int R, int64_t N, void* wt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x1 && scale && wt && (x2 || n1a == N), LPM_ERR_BADARG, "lpm_split_weight_tiles_parts: null pointer");
+    LPM_REQUIRE(R > 0 && R % 16 == 0 && N > 0 && n1a > 0 && n1a <= N && n1a % 32 == 0 && ks > 0 && n1a % ks == 0 && ld1 >= n1a &&
+                (n1a == N || ld2 >= N - n1a), LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_split_weight_tiles_parts: need R %% 16 == 0, the scaled block a multiple of 32 columns and of ks (R=%d n1a=%lld ks=%d)", R,
+                (long long)n1a, ks);
+    const int64_t total = (int64_t)(R / 16) * ((N + 31) / 32) * 64;
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(split_weight_tiles_parts_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, (hipStream_t)stream, x1, ld1,
+                       n1a, scale, ks, x2, ld2, R, N, (uint4*)wt);
+    return check_launch("lpm_split_weight_tiles_parts");
 }
 extern "C" int lpm_split_weight_tiles(const float* w, int R, int N, int transposed, void* wt, lpm_stream_t stream) {
     return split_weight_tiles_impl(w, R, N, transposed, wt, 2, stream);

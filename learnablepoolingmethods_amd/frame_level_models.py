@@ -59,11 +59,21 @@ def _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_bat
                            is_training, **unused_params):
     """Shared tail of NetVladV1 / NetVladV2: hidden projection, context gating, MoE
     (frame_level_models.py:2309-2377 == :2445-2513)."""
-    dev = vlad.device
-    vlad_dim = vlad.shape[1]
+    # vlad = (video, audio | None): the video stream's descriptor LAZILY normalised (ops.vlad_aggregate(lazy=True)) and the concat left to
+    # the projection, which reads both blocks where they are (ops.projection_parts)
+    parts = vlad if isinstance(vlad, tuple) else None
+    dev = parts[0].device if parts else vlad.device
+    vlad_dim = sum(p.shape[1] for p in parts if p is not None) if parts else vlad.shape[1]
     hidden1_weights = vs.get_variable("hidden1_weights", [vlad_dim, hidden1_size],
                                       vs.random_normal_initializer(1 / math.sqrt(cluster_size)), device=dev)   # :2315-2317
-    activation = ops.projection(vlad, hidden1_weights) if vlad.is_cuda else vlad.matmul(hidden1_weights)      # :2319
+    if parts and ops.projection_parts_ok(parts[0], ops.row_scale_of(parts[0]), getattr(parts[0], "_lpm_scale_ks", 0), parts[1],
+                                         hidden1_weights):
+        activation = ops.projection_parts(parts[0], parts[1], hidden1_weights)                                 # :2309 / :2445 + :2319
+    else:
+        if parts:
+            vlad = ops.materialise(parts[0])
+            vlad = torch.cat([vlad, parts[1]], 1) if parts[1] is not None else vlad
+        activation = ops.projection(vlad, hidden1_weights) if vlad.is_cuda else vlad.matmul(hidden1_weights)  # :2319
     small = is_training and ops.bn_small_ok(activation)         # clip-level tensors: batch norm + what follows it in one launch each way
     if add_batch_norm and relu and small:
         activation = ops.bn_small(activation, *layers.bn_variables("hidden1_bn", hidden1_size, dev), act=1)    # :2321-2327 + relu6 :2337
@@ -331,14 +341,27 @@ class NetVladV2(models.BaseModel):
             rgb, audio = reshaped_input[:, 0:1024], reshaped_input[:, 1024:]
         # (NetVladV1 runs its audio stream on a second HIP stream; here that was measured SLOWER -- 10.95 vs 10.84 ms per step at cfg-3,
         # tools/ab_flags.py: this model's audio stream attends over 300 frames, its launches are long enough to fill the chip by themselves)
+        # The video descriptor leaves its pooling LAZILY NORMALISED where the projection can take it that way: the un-normalised sums,
+        # written once by the aggregation kernel, + one scale per (clip, cluster) -- no finalize pass, and no tf.concat either (the
+        # projection reads the two streams' blocks where they are)
+        lazy_v = bool(FLAGS.netvlad_lazy_descriptor and reshaped_input.is_cuda and model_input.shape[0] <= 128 and hidden1_size % 512 == 0
+                      and ops.vlad_aggregate_lazy_ok(max_frames, 1024, cluster_size))
         with vs.variable_scope("video_VLAD"):
-            vlad_video = video_NetVLAD.forward(rgb, dropout_mask=dm.get("video"), dropout_rate=dropout_rate)       # :2437-2438
-            vs.summary("vlad_video", vlad_video)
+            vlad_video = video_NetVLAD.forward(rgb, dropout_mask=dm.get("video"), dropout_rate=dropout_rate, lazy=lazy_v)   # :2437-2438
+            if vs.default_store().summaries is not None:
+                vs.summary("vlad_video", ops.materialise(vlad_video))
+        vlad_audio = None
         if has_audio:
             with vs.variable_scope("audio_VLAD"):
                 vlad_audio = audio_NetVLAD.forward(audio, dropout_mask=dm.get("audio"), dropout_rate=dropout_rate)  # :2440-2441
                 vs.summary("vlad_audio", vlad_audio)
-        vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video             # :2445
-        vs.summary("vlad", vlad)
+        if lazy_v:
+            if vs.default_store().summaries is not None:
+                vm = ops.materialise(vlad_video)
+                vs.summary("vlad", torch.cat([vm, vlad_audio], 1) if has_audio else vm)
+            vlad = (vlad_video, vlad_audio)                                                     # :2445 inside the projection
+        else:
+            vlad = torch.cat([vlad_video, vlad_audio], 1) if has_audio else vlad_video          # :2445
+            vs.summary("vlad", vlad)
         return _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_batch_norm, relu, gating,
                                       remove_diag, is_training, **unused_params)

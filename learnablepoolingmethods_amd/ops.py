@@ -999,17 +999,21 @@ class _NetVLAD(torch.autograd.Function):
 
 
 class _Materialise(torch.autograd.Function):
-    """raw [B, K, D] x row_scale [B, K] -> the normalised descriptor as an ordinary tensor.  The gradient passes through UNCHANGED: by
-    the contract of the lazily normalised form (netvlad(lazy=True)) the gradient a consumer returns for `raw` IS the gradient with
-    respect to the normalised descriptor -- the Jacobian of both normalisations lives in the pooling op's backward (K3)."""
+    """raw [B, K, D] x row_scale [B, K] -> the normalised descriptor as an ordinary tensor (ks > 0: raw is d-major, [B, D * ks]).  The
+    gradient passes through UNCHANGED: by the contract of the lazily normalised form (netvlad(lazy=True), vlad_aggregate(lazy=True)) the
+    gradient a consumer returns for `raw` IS the gradient with respect to the normalised descriptor -- the Jacobian of both
+    normalisations lives in the pooling op's backward (K3)."""
 
     @staticmethod
-    def forward(ctx, raw, row_scale):
+    def forward(ctx, raw, row_scale, ks=0):
+        if ks:
+            B = raw.shape[0]
+            return (raw.reshape(B, -1, ks) * row_scale.unsqueeze(1)).reshape(raw.shape)
         return raw * row_scale.unsqueeze(-1)
 
     @staticmethod
     def backward(ctx, d):
-        return d, None
+        return d, None, None
 
 
 def row_scale_of(x):
@@ -1020,7 +1024,7 @@ def row_scale_of(x):
 def materialise(x):
     """An ordinary tensor for any consumer that does not apply the row scale itself."""
     rs = row_scale_of(x)
-    return x if rs is None else _Materialise.apply(x, rs)
+    return x if rs is None else _Materialise.apply(x, rs, int(getattr(x, "_lpm_scale_ks", 0)))
 
 
 def netvlad_lazy_ok(T, D, K):
@@ -1058,7 +1062,7 @@ class _VladAggregate(torch.autograd.Function):
     """Similarities given (no softmax): NetVladAttenCluster tail, video_pooling_modules.py:1641-1658."""
 
     @staticmethod
-    def forward(ctx, sims, x, centres, T, kmajor):
+    def forward(ctx, sims, x, centres, T, kmajor, lazy=False):
         lib = _capi.load()
         x = _rows(x, "inputs")
         M, D = x.shape
@@ -1068,6 +1072,35 @@ class _VladAggregate(torch.autograd.Function):
         centres = _f32(centres, "cluster_centers").contiguous()
         flags = LPM_VLAD_RESIDUAL
         ctx.nrm_raw = _nrm_raw_ok(lib, T, D, K)
+        if lazy:
+            # the LAZILY NORMALISED d-major descriptor: K2 writes the un-normalised sums [B, D, K] once, lpm_vlad_row_scales turns the partial
+            # norms into one factor per (clip, cluster); the consumer (ops.projection_parts) applies it where it reads the operand --
+            # no finalize pass.  The backward is the ordinary one: K3 reads the un-normalised sums anyway (nrm_raw).
+            if kmajor or not vlad_aggregate_lazy_ok(T, D, K):
+                raise LpmError("vlad_aggregate: the lazily normalised d-major descriptor needs the LDS-shared K2 form and K3's tile form")
+            st = stream_ptr()
+            xt = _cached_tiles(x, B, T, D)
+            if xt is None:
+                xt = torch.empty(lib._lpm_xt_bytes(B, T, D) // 4, dtype=torch.int32, device=x.device)
+                with _timed("split_frames", (B, T, D)):
+                    lib.check(lib._lpm_split_frames(ptr(x), x.stride(0), B, T, D, ptr(xt), st), "lpm_split_frames")
+            at = torch.empty(lib._lpm_at_bytes(B, T, K) // 4, dtype=torch.int32, device=x.device)
+            with _timed("assign_tiles", (B, T, K)):
+                lib.check(lib._lpm_assign_tiles(ptr(sims2), None, None, B, T, K, flags, ptr(at), st), "lpm_assign_tiles")
+            raw = _empty((B, D * K), x)
+            asum, colsq, csq, rs = (_empty((B, K), x) for _ in range(4))
+            gsq = _empty((B,), x)
+            P = D // 128
+            part = _empty((B, P, K), x)
+            with _timed("vlad_aggregate_fwd", (B, T, D, K)):
+                lib.check(lib._lpm_vlad_aggregate_tiles3_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(raw), ptr(asum), ptr(part), st),
+                          "lpm_vlad_aggregate_tiles3_fwd")
+            with _timed("vlad_finalize", (B, D, K)):
+                lib.check(lib._lpm_vlad_row_scales(ptr(part), P, B, K, ptr(rs), ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_row_scales")
+            ctx.dims = (B, T, D, K, flags, kmajor, sims.shape)
+            ctx.save_for_backward(sims2, x, centres, raw.detach(), asum, colsq, csq, gsq)      # (raw IS the output: see _NetVLAD.forward)
+            raw._lpm_row_scale, raw._lpm_scale_ks = rs, K
+            return raw
         out, nrm, asum, colsq, csq, gsq, _ = _aggregate_fwd(lib, sims2, None, None, x, centres, B, T, D, K, flags, kmajor,
                                                             nrm_raw=ctx.nrm_raw, save_u=any(ctx.needs_input_grad))
         ctx.dims = (B, T, D, K, flags, kmajor, sims.shape)
@@ -1088,11 +1121,22 @@ class _VladAggregate(torch.autograd.Function):
         else:
             dsims, dx, dcentres = _aggregate_bwd(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x, centres,
                                                  B, T, D, K, flags, kmajor)
-        return dsims.reshape(sshape), dx, dcentres, None, None
+        return dsims.reshape(sshape), dx, dcentres, None, None, None
 
 
-def vlad_aggregate(sims, x, centres, max_frames, kmajor=False):
-    return _VladAggregate.apply(sims, x, centres, int(max_frames), bool(kmajor))
+def vlad_aggregate_lazy_ok(T, D, K):
+    """Shapes for which vlad_aggregate(lazy=True) exists: the LDS-shared K2 form (D, K multiples of 128), K3's tile form, K a multiple of 32."""
+    lib = _capi.load()
+    return (VLAD_PRECISION == "bf16x3" and VLAD_TILES3 and bool(lib._lpm_vlad_tiles3_supported(D, K)) and _bwd_tiles_ok(lib, T, D, K)
+            and K % 32 == 0 and K <= 1024)
+
+
+def vlad_aggregate(sims, x, centres, max_frames, kmajor=False, lazy=False):
+    """lazy (d-major only; vlad_aggregate_lazy_ok shapes): the result is the LAZILY NORMALISED descriptor -- the un-normalised residual sums
+    [B, D * K] carrying ``_lpm_row_scale`` [B, K] and ``_lpm_scale_ks`` = K: descriptor[b, d * K + k] = result[b, d * K + k] * scale[b, k]
+    (video_pooling_modules.py:1655-1658).  ops.projection_parts applies the scale where it reads the operand; the gradient it returns is the
+    gradient with respect to the normalised descriptor.  Everybody else goes through ops.materialise."""
+    return _VladAggregate.apply(sims, x, centres, int(max_frames), bool(kmajor), bool(lazy))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1685,6 +1729,120 @@ class _Projection(torch.autograd.Function):
 
 def projection(x, W):
     return _Projection.apply(x, W)
+
+
+class _ProjectionParts(torch.autograd.Function):
+    """y = [x1 * scale | x2] . W (tf.concat + tf.matmul, frame_level_models.py:2445 + :2319) with x1 the lazily normalised d-major
+    descriptor of the video stream (vlad_aggregate(lazy=True): un-normalised sums + one scale per (clip, cluster)) and x2 the audio
+    stream's descriptor: lpm_proj_fwd_parts reads both where they are and applies the scale as it loads the operand; the weight gradient's
+    X factor is written as tiles by lpm_split_weight_tiles_parts the same way.  The input gradient dx = dy . W^T is ONE [M, Kd] buffer whose
+    column blocks go back as views (K3 reads a strided gradient in place); for x1 it is the gradient with respect to the NORMALISED
+    descriptor (the lazily normalised form's contract)."""
+
+    @staticmethod
+    def forward(ctx, x1, scale, ks, x2, W):
+        lib = _capi.load()
+        M, n1a = x1.shape
+        n1b = x2.shape[1] if x2 is not None else 0
+        Kd, N = n1a + n1b, W.shape[1]
+        if not projection_parts_ok(x1, scale, ks, x2, W):
+            raise LpmError("projection_parts: shapes / layouts outside lpm_proj_fwd_parts' conditions (use ops.materialise + ops.projection)")
+        ctx.save_for_backward(x1, scale, x2, W)
+        ctx.ks = int(ks)
+        y = _empty((M, N), x1)
+        wsb = lib._lpm_proj_fwd_workspace_bytes(M, Kd, N)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x1.device)
+        with _timed("proj_fwd", (M, Kd, N)):
+            lib.check(lib._lpm_proj_fwd_parts(ptr(x1), x1.stride(0), n1a, ptr(scale), int(ks), ptr(x2), x2.stride(0) if x2 is not None else 0,
+                                              ptr(W), M, Kd, N, ptr(y), ptr(ws), wsb, stream_ptr()), "lpm_proj_fwd_parts")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _capi.load()
+        x1, scale, x2, W = ctx.saved_tensors
+        M, n1a = x1.shape
+        n1b = x2.shape[1] if x2 is not None else 0
+        Kd, N = n1a + n1b, W.shape[1]
+        dy = dy.contiguous()
+        st = stream_ptr()
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[3]):
+            if N >= PROJ_DX_STREAM_MIN_N:
+                dyt = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), dy)
+                lib.check(lib._lpm_split_rows_tiles(ptr(dy), N, 1, M, N, ptr(dyt), st), "lpm_split_rows_tiles")
+                dx = _empty((M, Kd), x1)
+                with _timed("proj_dx", (M, Kd, N)):
+                    lib.check(lib._lpm_proj_dx(ptr(dyt), ptr(W), M, Kd, N, ptr(dx), dx.stride(0), st), "lpm_proj_dx")
+            else:
+                dx = dy.matmul(W.t())
+            dx1 = dx[:, :n1a]
+            dx2 = dx[:, n1a:] if x2 is not None else None
+        if not ctx.needs_input_grad[4]:
+            return dx1, None, None, dx2, None
+
+        def x_tiles():
+            xt = _tile_buffer(lib._lpm_weight_tiles_bytes(M, Kd), x1)
+            lib.check(lib._lpm_split_weight_tiles_parts(ptr(x1), x1.stride(0), n1a, ptr(scale), ctx.ks, ptr(x2),
+                                                        x2.stride(0) if x2 is not None else 0, M, Kd, ptr(xt), st), "lpm_split_weight_tiles_parts")
+            return xt
+
+        skinny = M % 16 == 0 and N % 32 == 0
+        factored = getattr(W, "_lpm_factored", None)
+        if factored is not None and factored.armed and factored.strict and not (skinny and not factored.puts):
+            raise LpmError("hidden projection backward: the towers agreed on the factored gradient route at build time, but this rank's "
+                           "step does not fit it (clips not a multiple of 16, or the weight used twice)")
+        if factored is not None and factored.armed and skinny and not factored.puts:
+            factored.put_tiles(x_tiles(), dy, M, Kd)
+            return dx1, None, None, dx2, None
+        if skinny:
+            dyt2 = _tile_buffer(lib._lpm_weight_tiles_bytes(M, N), dy)
+            lib.check(lib._lpm_split_weight_tiles(ptr(dy), M, N, 0, ptr(dyt2), st), "lpm_split_weight_tiles")
+            view = getattr(W, "_lpm_grad_view", None)
+            fresh = view is None or getattr(W, "_lpm_grad_written", False)
+            out = _empty((Kd, N), x1) if fresh else view
+            with _timed("skinny_weight_grad", (M, Kd, N)):
+                lib.check(lib._lpm_skinny_weight_grad_tiles(ptr(x_tiles()), ptr(dyt2), M, Kd, N, ptr(out), st), "lpm_skinny_weight_grad_tiles")
+            dW = out
+        else:
+            xm = _Materialise.forward(None, x1, scale, ctx.ks)
+            dW = (torch.cat([xm, x2], 1) if x2 is not None else xm).t().matmul(dy)
+            view = getattr(W, "_lpm_grad_view", None)
+            fresh = True
+        if view is None:
+            return dx1, None, None, dx2, dW
+        if getattr(W, "_lpm_grad_written", False):
+            view += dW
+        elif fresh:
+            view.copy_(dW)
+        W._lpm_grad_written = True
+        ready = getattr(W, "_lpm_grad_ready", None)
+        if ready is not None:
+            ready()
+        return dx1, None, None, dx2, None
+
+
+def projection_parts_ok(x1, scale, ks, x2, W):
+    """lpm_proj_fwd_parts' conditions (include/lpm_hip.h) for these tensors."""
+    if not (PROJ_STREAM and x1.is_cuda and x1.dtype == torch.float32 and W.dtype == torch.float32 and W.is_contiguous() and x1.dim() == 2
+            and scale is not None and scale.is_contiguous() and scale.dtype == torch.float32):
+        return False
+    M, n1a = x1.shape
+    n1b = 0
+    if x2 is not None:
+        if not (x2.dim() == 2 and x2.shape[0] == M and x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.stride(0) % 4 == 0
+                and x2.data_ptr() % 16 == 0 and x2.shape[1] % 16 == 0):
+            return False
+        n1b = x2.shape[1]
+    ks = int(ks)
+    return (x1.stride(1) == 1 and x1.stride(0) % 4 == 0 and x1.data_ptr() % 16 == 0 and ks > 0 and ks % 4 == 0 and n1a % 32 == 0
+            and n1a % ks == 0 and tuple(scale.shape) == (M, ks) and W.shape[0] == n1a + n1b
+            and bool(_capi.load()._lpm_proj_supported(M, n1a + n1b, W.shape[1])))
+
+
+def projection_parts(x1, x2, W):
+    """[descriptor(x1) | x2] . W for a lazily normalised d-major x1 (see _ProjectionParts); x2 may be None."""
+    return _ProjectionParts.apply(x1, row_scale_of(x1), int(getattr(x1, "_lpm_scale_ks", 0)), x2, W)
 
 
 class _BatchNormRows(torch.autograd.Function):
@@ -2511,6 +2669,7 @@ class FactoredGradient:
         self.xt = self.dyt = None
         self.x = self.dy = None           # the fp32 factors themselves (this rank's; None once tiles of several towers were gathered)
         self.R = self.N1 = self.N2 = 0
+        self.x_in_tiles = False           # put_tiles: X was never an fp32 matrix of its own
         self.puts = 0
 
     @property
@@ -2534,6 +2693,22 @@ class FactoredGradient:
         if self.on_put is not None:
             self.on_put(self)
 
+    def put_tiles(self, xt, dy, R, N1):
+        """``put`` for an X that exists only as its weight tiles (ops._ProjectionParts: the lazily normalised descriptor is scaled as the
+        tiles are written); the quadratic-form norm reads X from the tiles."""
+        if self.puts:
+            raise LpmError("FactoredGradient: the weight was used twice in one step; its gradient is then a sum of two products")
+        lib = _capi.load()
+        N2 = dy.shape[1]
+        dyt = _tile_buffer(lib._lpm_weight_tiles_bytes(R, N2), dy)
+        lib.check(lib._lpm_split_weight_tiles(ptr(dy.contiguous()), R, N2, 0, ptr(dyt), stream_ptr()), "lpm_split_weight_tiles")
+        self.xt, self.dyt, self.R, self.N1, self.N2 = xt, dyt, R, N1, N2
+        self.x, self.dy = None, dy
+        self.x_in_tiles = True
+        self.puts += 1
+        if self.on_put is not None:
+            self.on_put(self)
+
     def materialise(self):
         """dW [N1, N2] from the operands held (tests / diagnostics): what the generic path would have written."""
         lib = _capi.load()
@@ -2551,7 +2726,18 @@ class FactoredGradient:
         with _timed("factored_clip_adam", (self.R, self.N1, self.N2)):
             quad = (FACTORED_NORM_QUADFORM and self.x is not None and self.x.shape[0] == self.R and self.R <= 128 and self.x.stride(1) == 1
                     and self.x.dtype == torch.float32)
-            if quad:
+            tiles_only = (FACTORED_NORM_QUADFORM and self.x is None and self.x_in_tiles and self.dy is not None and self.dy.shape[0] == self.R
+                          and self.R <= 128 and os.environ.get("LPM_FQ_TILES", "1") != "0")
+            if tiles_only:
+                # X lives in its tiles only (put_tiles): the quadratic forms read it from there (fa_quadform_kernel<true>; the fp32
+                # pointer is the A/B form's operand and is not dereferenced)
+                G = torch.mm(self.dy, self.dy.t())
+                gdt = _tile_buffer(lib._lpm_row_tiles_bytes(1, self.R, self.R), G)
+                lib.check(lib._lpm_split_rows_tiles(ptr(G), self.R, 1, self.R, self.R, ptr(gdt), stream_ptr()), "lpm_split_rows_tiles")
+                lib.check(lib._lpm_factored_clip_adam_q(ptr(self.xt), ptr(self.dyt), ptr(self.xt), self.N1, ptr(gdt), self.R, self.N1,
+                                                        self.N2, ptr(param), ptr(m), ptr(v), float(clip_norm), float(lr), beta1, beta2, eps,
+                                                        int(step), ptr(scratch), nb, stream_ptr()), "lpm_factored_clip_adam_q")
+            elif quad:
                 # the norm from the quadratic forms x_n1^T (DY DY^T) x_n1 (lpm_factored_clip_adam_q): no first GEMM pass over R x N1 x N2
                 G = torch.mm(self.dy, self.dy.t())      # [R, R] fp32 (its entries then enter the MFMAs as bf16 hi + lo: 2^-17 relative)
                 gdt = _tile_buffer(lib._lpm_row_tiles_bytes(1, self.R, self.R), G)

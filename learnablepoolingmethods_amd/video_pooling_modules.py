@@ -55,8 +55,8 @@ class NetVladAttenCluster(modules.BaseModule):
         self.dropout_ratio = 0.1
         self.filter_size = 4 * self.encoder_hidden_size   # :1615
 
-    def forward(self, inputs, dropout_mask=None, dropout_rate=None, **unused_params):
-        """inputs [(B*max_frames), F] -> [B, F*K] (f-major), L2-normalised."""
+    def forward(self, inputs, dropout_mask=None, dropout_rate=None, lazy=False, **unused_params):
+        """inputs [(B*max_frames), F] -> [B, F*K] (f-major), L2-normalised (lazy: the lazily normalised form, ops.vlad_aggregate)."""
         reshaped_input = inputs.reshape(-1, self.max_frames, self.feature_size)          # :1623
         with vs.variable_scope("cluster_attention"):
             encoder_block = transformer_utils.TransformerEncoderMod(
@@ -69,4 +69,4 @@ class NetVladAttenCluster(modules.BaseModule):
                                           vs.random_normal_initializer(1 / math.sqrt(self.feature_size)),
                                           device=inputs.device)                                # :1641-1643
         # sum_n sims * (x - c), intra-L2, flatten, L2 (:1646-1658; App. C6/C7) -- HIP kernel K2
-        return ops.vlad_aggregate(cluster_similarities, inputs, cluster_centres, self.max_frames)
+        return ops.vlad_aggregate(cluster_similarities, inputs, cluster_centres, self.max_frames, lazy=lazy)

@@ -6,6 +6,7 @@ import os
 import re
 import shutil
 import subprocess
+import tempfile
 
 import pytest
 
@@ -87,3 +88,45 @@ def test_projection_kernels_keep_their_lds_dma_rings_in_flight():
     for name, waits, smem in rep:
         assert not waits, f"{name}: compiler-inserted vmcnt waits inside an LDS-DMA loop: {waits[:4]}"
         assert not smem, f"{name}: scalar loads inside an LDS-DMA loop (they share lgkmcnt with the counted ds_reads): {smem[:4]}"
+
+
+@pytest.mark.timeout(900)
+def test_flat_k1_loop_keeps_loads_in_flight_and_copies_no_registers():
+    """assign_flat.hip hands registers that asynchronous loads fill (global_load_dwordx4 / ds_read_b128 issued by inline assembly) to the
+    MFMAs behind hand-counted waits: the compiler must not add waits of its own to the loop, and it must not COPY such a register between
+    its load and its wait -- a copy placed in front of the wait reads what the load has not written yet (seen once while the kernel was
+    written: a tied operand in both arms of a branch made it do exactly that)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(_build.CSRC), "..", "tools"))
+    try:
+        import scan_lds_dma_waits as scan
+    finally:
+        sys.path.pop(0)
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    src = os.path.join(_build.CSRC, "assign_flat.hip")
+    rep = scan.scan(src)
+    assert sum("assign_flat_kernel" in n for n, _ in rep) >= 3
+    for name, waits in rep:
+        assert not waits, f"{name}: compiler-inserted vmcnt waits inside the LDS-DMA loop: {waits[:4]}"
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        flags = [f for f in _build.FLAGS if f != "-fPIC"]
+        r = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm = open(out).read()
+    for mangled in re.findall(r"^(_ZN3lpm18assign_flat_kernelILi\dELi\dELi0EEEvNS_14AssignFlatArgsE):", asm, flags=re.M):
+        body = asm[asm.index(mangled + ":"):]
+        body = body[:body.index("s_endpgm")]
+        lines = body.splitlines()
+        head = [i for i, l in enumerate(lines) if "Loop Header" in l]
+        assert head, f"{mangled}: no loop"
+        label = lines[head[0]].split(":")[0].strip()
+        back = [i for i, l in enumerate(lines) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\s*$", l) and i > head[0]]
+        assert back, f"{mangled}: no back edge to {label}"
+        loop = [l for l in lines[head[0]:back[-1] + 1] if not l.strip().startswith(";")]
+        n = sum("v_mfma_f32_32x32x16_bf16" in l for l in loop)
+        assert n in (36, 72), f"{mangled}: expected the 9 MFMAs of each of the 4 or 8 unrolled steps in the loop, found {n}"
+        bad = [l.strip() for l in loop if re.search(r"\b(v_mov_b64|v_accvgpr_(read|write)\w*|scratch_(load|store)\w*)\b", l)]
+        assert not bad, f"{mangled}: register copies / scratch traffic inside the main loop: {bad[:6]}"
+

@@ -1052,6 +1052,90 @@ def test_projection_skinny_gemms(B, KV, H):
     assert_close(W.grad, x64.t() @ dy64, 2e-5, "dW (autograd path)")
 
 
+@pytest.mark.parametrize("B,D,K,NA,H,factored", [(80, 1024, 256, 8192, 512, True), (16, 128, 128, 0, 512, False), (13, 256, 128, 2048, 512, False),
+                                                  (96, 128, 256, 64, 1024, True), (128, 128, 128, 512, 512, True)])
+def test_projection_parts(B, D, K, NA, H, factored):
+    """The projection of a lazily normalised d-major descriptor (frame_level_models.py:2445 + :2319 with the normalisation of
+    video_pooling_modules.py:1655-1658 applied where the operand is read): y = [x1 * scale | x2] . W, dx as views of one buffer, the weight
+    gradient from tiles that carry the scale -- through the caller-owned buffer, autograd, and the factored route's operands."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(B + K + NA)
+    raw = (torch.randn(B, D * K, generator=g) * 3).to(dev)
+    scale = (torch.rand(B, K, generator=g) + 0.5).to(dev) / (D * K) ** 0.5
+    x2 = (torch.randn(B, NA, generator=g) / max(NA, 1) ** 0.5).to(dev).requires_grad_(True) if NA else None
+    Kd = D * K + NA
+    W = (torch.randn(Kd, H, generator=g) / Kd ** 0.5).to(dev).requires_grad_(True)
+    dy = torch.randn(B, H, generator=g).to(dev)
+    x1 = raw.clone().requires_grad_(True)
+    x1._lpm_row_scale, x1._lpm_scale_ks = scale, K
+    assert ops.projection_parts_ok(x1, scale, K, x2, W)
+    xm = (raw.double().cpu().view(B, D, K) * scale.double().cpu().unsqueeze(1)).reshape(B, D * K)
+    x64 = torch.cat([xm, x2.detach().double().cpu()], 1) if NA else xm
+    W64, dy64 = W.detach().double().cpu(), dy.double().cpu()
+    assert_close(ops.materialise(x1), xm, 1e-6, "materialise (d-major)")
+    view = torch.full((Kd, H), float("nan"), device=dev)
+    W._lpm_grad_view = view
+    y = ops.projection_parts(x1, x2, W)
+    y.backward(dy)
+    assert_close(y, x64 @ W64, 2e-5, "y")
+    dx = dy64 @ W64.t()
+    assert_close(x1.grad, dx[:, :D * K], 2e-5, "dx1 (w.r.t. the normalised descriptor)")
+    if NA:
+        assert_close(x2.grad, dx[:, D * K:], 2e-5, "dx2")
+    if B % 16 == 0:
+        assert_close(view, x64.t() @ dy64, 2e-5, "dW")
+        assert W.grad is None and W._lpm_grad_written
+    del W._lpm_grad_view, W._lpm_grad_written
+    W.grad = None
+    ops.projection_parts(x1, x2, W).backward(dy)
+    assert_close(W.grad, x64.t() @ dy64, 2e-5, "dW (autograd path)")
+    if factored:
+        fg = ops.FactoredGradient()
+        fg.armed = True
+        W._lpm_factored = fg
+        W.grad = None
+        ops.projection_parts(x1, x2, W).backward(dy)
+        assert W.grad is None and fg.pending and fg.x_in_tiles
+        assert_close(fg.materialise(), x64.t() @ dy64, 2e-5, "dW from the factored operands")
+        # clip + Adam from the tiles, the norm by the quadratic forms over the tiles
+        param = W.detach().clone().reshape(-1)
+        m, v = torch.zeros_like(param), torch.zeros_like(param)
+        sc = fg.clip_adam(param, m, v, 1.0, 1e-3, 1)
+        gref = x64.t() @ dy64
+        nrm = float(gref.norm())
+        assert abs(float(sc[-3]) - nrm) <= 1e-4 * nrm, "gradient norm from the quadratic forms"
+        gc = gref * (1.0 / max(nrm, 1.0))
+        assert_close(m.view(Kd, H), 0.1 * gc, 1e-4, "Adam m after one step")
+        del W._lpm_factored
+
+
+def test_vlad_aggregate_lazy_matches_the_finalize_form():
+    """NetVladAttenCluster's tail (video_pooling_modules.py:1641-1658) as the lazily normalised d-major descriptor: the un-normalised sums
+    x the row scales ARE the finalize form's descriptor, and the gradients of both forms agree (K3 is the same code)."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, T, D, K = 3, 70, 256, 128
+    assert ops.vlad_aggregate_lazy_ok(T, D, K)
+    g = torch.Generator().manual_seed(11)
+    sims, x, C = torch.randn(B, T, K, generator=g), torch.randn(B * T, D, generator=g), torch.randn(D, K, generator=g) / D ** .5
+    dout = torch.randn(B, D * K, generator=g).to(dev)
+    res = []
+    for lazy in (False, True):
+        sg, xg, cg = (t.to(dev).requires_grad_(True) for t in (sims, x, C))
+        out = ops.vlad_aggregate(sg, xg, cg, T, lazy=lazy)
+        if lazy:
+            assert ops.row_scale_of(out) is not None and out._lpm_scale_ks == K
+            out = ops.materialise(out)
+        out.backward(dout)
+        res.append((out.detach(), sg.grad, xg.grad, cg.grad))
+    for a, b, what in zip(res[1], res[0], ("descriptor", "dsims", "dx", "dcentres")):
+        assert_close(a, b, 2e-6, what)
+    sd, xd, Cd = (t.double().requires_grad_(True) for t in (sims, x, C))
+    ref = O.vlad_aggregate(sd, xd.reshape(B, T, D), Cd)
+    assert_close(res[1][0], ref, 1e-4, "descriptor vs the oracle")
+
+
 def test_fused_qkv_projection_through_attention():
     """q, k, v projections as one split-bf16 GEMM (transformer_utils.py:559-561) feeding the attention kernel through
     column views, and the backward consuming dq|dk|dv from one buffer: against fp64 autograd of the unfused maths."""
