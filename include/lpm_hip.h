@@ -326,12 +326,13 @@ int lpm_proj_dx(const void* dyt, const float* W, int M, int64_t Kd, int N, float
  * where the operand is read (frame_level_models.py:2819-2822 / video_pooling_modules.py:1655-1658 as a factor per (clip, cluster)), and
  * x2 [M, Kd - n1a] (row stride ldx2; NULL when n1a == Kd) is the audio stream's descriptor as it is: neither the finalize pass of the
  * pooling nor tf.concat (:2445) runs.  n1a a multiple of 32 and of ks, ks a multiple of 4; otherwise lpm_proj_fwd's conditions.
+ * x1_bf16: x1 is stored as bf16 (the bf16-storage configuration's un-normalised sums; ldx1 in elements, a multiple of 4).
  * lpm_split_weight_tiles_parts writes the weight tiles (lpm_weight_tiles_bytes(R, N)) of the same virtual matrix: the X factor of the
  * hidden1 weight gradient (lpm_factored_clip_adam*, lpm_skinny_weight_grad_tiles). */
-int lpm_proj_fwd_parts(const float* x1, int64_t ldx1, int64_t n1a, const float* scale, int ks, const float* x2, int64_t ldx2,
+int lpm_proj_fwd_parts(const void* x1, int64_t ldx1, int64_t n1a, int x1_bf16, const float* scale, int ks, const float* x2, int64_t ldx2,
                        const float* W, int M, int64_t Kd, int N, float* y, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
-int lpm_split_weight_tiles_parts(const float* x1, int64_t ld1, int64_t n1a, const float* scale, int ks, const float* x2, int64_t ld2,
-                                 int R, int64_t N, void* wt, lpm_stream_t stream);
+int lpm_split_weight_tiles_parts(const void* x1, int64_t ld1, int64_t n1a, int x1_bf16, const float* scale, int ks, const float* x2,
+                                 int64_t ld2, int R, int64_t N, void* wt, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * bf16 storage (BASELINE configs[4]: "Gated NetVLAD K=512 + MoE-4, 300x1152 bf16"): the tensors SURVEY 8(d) counts in the

@@ -82,8 +82,8 @@ SIGNATURES = {
     "lpm_proj_supported": (_i, [_i, _l, _i]),
     "lpm_proj_fwd_workspace_bytes": (_s, [_i, _l, _i]),
     "lpm_proj_fwd": (_i, [_f, _l, _f, _i, _l, _i, _f, _f, _s, _f]),
-    "lpm_proj_fwd_parts": (_i, [_f, _l, _l, _f, _i, _f, _l, _f, _i, _l, _i, _f, _f, _s, _f]),
-    "lpm_split_weight_tiles_parts": (_i, [_f, _l, _l, _f, _i, _f, _l, _i, _l, _f, _f]),
+    "lpm_proj_fwd_parts": (_i, [_f, _l, _l, _i, _f, _i, _f, _l, _f, _i, _l, _i, _f, _f, _s, _f]),
+    "lpm_split_weight_tiles_parts": (_i, [_f, _l, _l, _i, _f, _i, _f, _l, _i, _l, _f, _f]),
     "lpm_proj_dx": (_i, [_f, _f, _i, _l, _i, _f, _l, _f]),
     "lpm_frame_tiles_bf16_bytes": (_s, [_i, _i, _i]),
     "lpm_frame_steps_bf16": (_i, [_i]),

@@ -51,9 +51,14 @@ struct ProjParts {
     int64_t ldx2, n1a;
     const float* scale;
     int ks;
+    int x1_bf16;               // the first block is stored as bf16 (bf16 storage of the descriptor: BASELINE configs[4]); ldx in elements
+                               // (selects the SC = 2 instantiation)
 };
-template <int MT, int NP, int XD, bool SC = false>
-__global__ __launch_bounds__(576, 1) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M, int64_t Kd,
+// (SC with more than 10 pieces per pair: TWO loader waves, half the pieces each -- sixteen pieces' data and scales do not fit one wave's
+// registers beside what the computing path sets the kernel's allocation to)
+__host__ __device__ constexpr int pj_loaders(int NP, int SC) { return (SC != 0 && NP > 10) ? 2 : 1; }
+template <int MT, int NP, int XD, int SC = 0>
+__global__ __launch_bounds__(512 + 64 * pj_loaders(NP, SC), 1) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M, int64_t Kd,
                                                           int N, int nslab, int splits, float* __restrict__ part, const ProjParts pp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -66,18 +71,23 @@ __global__ __launch_bounds__(576, 1) void proj_fwd_kernel(const float* __restric
     const int ns = s1 - s0;
     constexpr int PJ_XPAIR = NP * 1024;            // one pair-buffer of x
 
-    if (wave == 8) {
+    if (wave >= 8) {
         // the x loader: piece p = 0 .. NP - 1 of a pair = rows 8 p .. 8 p + 7 (clamped to M - 1: rows >= M are never stored), lane ->
         // (row r = 8 p + lane / 8, LDS slot q = lane % 8) holding source part q ^ (r & 7); parts 0-3 = slab 2 j, parts 4-7 = slab 2 j + 1
         // (the last pair of an odd range: its second slab is re-read from the first -- nobody consumes it)
         const int q = lane & 7;
         const int part = q ^ ((lane >> 3) & 7);                    // (8 p + lane / 8) & 7 == lane / 8
-        if constexpr (SC) {
+        if constexpr (SC != 0) {
             const int nss = (ns + 1) >> 1;
-            // (the scales of a pair ride along with its x pieces where the registers allow; otherwise they are fetched when the pair is
-            // written -- they come from L2, the x pieces from HBM)
-            constexpr bool HOLD = NP <= 10;
-            f32x4 xv[NP], sv[HOLD ? NP : 1];
+            // SC 1 (fp32 sums): xv = the pair's x pieces, sv = their scales, riding along where the registers allow (NP <= 10; otherwise the
+            // scales are fetched when the pair is written -- from L2, one dependent round trip per piece: slow, and not a shape any
+            // configuration runs).  SC 2 (bf16 sums): xh = the pieces as they are stored (two registers each), sv = their scales -- or, for a
+            // pair of the second block (fp32, no scales), the pieces themselves.
+            constexpr int NPW = NP / pj_loaders(NP, SC);       // pieces of this loader wave: p0 .. p0 + NPW - 1
+            const int p0 = (wave - 8) * NPW;
+            constexpr bool HOLD = SC == 2 || NPW <= 10;
+            f32x4 xv[SC == 1 ? NPW : 1], sv[HOLD ? NPW : 1];
+            uint2 xh[SC == 2 ? NPW : 1];
             bool firstv = true;
             int kcv = 0;
             auto load = [&](int j) {
@@ -86,23 +96,41 @@ __global__ __launch_bounds__(576, 1) void proj_fwd_kernel(const float* __restric
                 const int kc = first ? (int)(col % pp.ks) : 0;
                 firstv = first; kcv = kc;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const int row = min(p * 8 + (lane >> 3), M - 1);
-                    const float* src = first ? x + (int64_t)row * ldx + col : pp.x2 + (int64_t)row * pp.ldx2 + (col - pp.n1a);
-                    xv[p] = *reinterpret_cast<const f32x4*>(src);
-                    if constexpr (HOLD)
-                        sv[p] = first ? *reinterpret_cast<const f32x4*>(pp.scale + (int64_t)row * pp.ks + kc) : f32x4{1.f, 1.f, 1.f, 1.f};
+                for (int p = 0; p < NPW; ++p) {
+                    const int row = min((p0 + p) * 8 + (lane >> 3), M - 1);
+                    if constexpr (SC == 2) {
+                        if (first) {
+                            xh[p] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + (int64_t)row * ldx + col);
+                            sv[p] = *reinterpret_cast<const f32x4*>(pp.scale + (int64_t)row * pp.ks + kc);
+                        } else {
+                            sv[p] = *reinterpret_cast<const f32x4*>(pp.x2 + (int64_t)row * pp.ldx2 + (col - pp.n1a));
+                        }
+                    } else {
+                        const float* src = first ? x + (int64_t)row * ldx + col : pp.x2 + (int64_t)row * pp.ldx2 + (col - pp.n1a);
+                        xv[p] = *reinterpret_cast<const f32x4*>(src);
+                        if constexpr (HOLD)
+                            sv[p] = first ? *reinterpret_cast<const f32x4*>(pp.scale + (int64_t)row * pp.ks + kc) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    }
                 }
             };
             auto store = [&](int j) {
                 unsigned char* st = smem + PJ_NS * PJ_WBYTES + (j % XD) * PJ_XPAIR;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    f32x4 sc;
-                    if constexpr (HOLD) sc = sv[p];
-                    else sc = firstv ? *reinterpret_cast<const f32x4*>(pp.scale + (int64_t)min(p * 8 + (lane >> 3), M - 1) * pp.ks + kcv)
-                                     : f32x4{1.f, 1.f, 1.f, 1.f};
-                    *reinterpret_cast<f32x4*>(st + p * 1024 + lane * 16) = xv[p] * sc;
+                for (int p = 0; p < NPW; ++p) {
+                    f32x4 v;
+                    if constexpr (SC == 2) {
+                        const uint2 u = xh[p];
+                        const f32x4 xf = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                          __uint_as_float(u.y & 0xffff0000u)};
+                        v = firstv ? xf * sv[p] : sv[p];
+                    } else if constexpr (HOLD) {
+                        v = xv[p] * sv[p];
+                    } else {
+                        const f32x4 sc = firstv ? *reinterpret_cast<const f32x4*>(pp.scale + (int64_t)min((p0 + p) * 8 + (lane >> 3), M - 1) * pp.ks + kcv)
+                                                : f32x4{1.f, 1.f, 1.f, 1.f};
+                        v = xv[p] * sc;
+                    }
+                    *reinterpret_cast<f32x4*>(st + (p0 + p) * 1024 + lane * 16) = v;
                 }
             };
             load(0);
@@ -519,9 +547,10 @@ extern "C" int lpm_proj_fwd(const float* x, int64_t ldx, const float* W, int M, 
 }
 // y = [x1 * scale | x2] . W without the concatenation: x1 [M, n1a] (row stride ldx1; n1a a multiple of 32) is multiplied by
 // scale[row][column % ks] where it is read (ks a multiple of 4: the lazily normalised d-major descriptor -- the un-normalised residual
-// sums [M, D, K] and lpm_vlad_row_scales' [M, K]); x2 [M, Kd - n1a] (row stride ldx2; may be NULL when n1a == Kd) enters as it is.
-extern "C" int lpm_proj_fwd_parts(const float* x1, int64_t ldx1, int64_t n1a, const float* scale, int ks, const float* x2, int64_t ldx2,
-                                  const float* W, int M, int64_t Kd, int N, float* y, void* workspace, size_t workspace_bytes,
+// sums [M, D, K] and lpm_vlad_row_scales' [M, K]; x1_bf16: stored as bf16, ldx1 in elements); x2 [M, Kd - n1a] (row stride ldx2; may be
+// NULL when n1a == Kd) enters as it is.
+extern "C" int lpm_proj_fwd_parts(const void* x1, int64_t ldx1, int64_t n1a, int x1_bf16, const float* scale, int ks, const float* x2,
+                                  int64_t ldx2, const float* W, int M, int64_t Kd, int N, float* y, void* workspace, size_t workspace_bytes,
                                   lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(x1 && scale && (x2 || n1a == Kd), LPM_ERR_BADARG, "lpm_proj_fwd_parts: null pointer");
@@ -530,8 +559,8 @@ extern "C" int lpm_proj_fwd_parts(const float* x1, int64_t ldx1, int64_t n1a, co
     LPM_REQUIRE(ldx1 >= n1a && ldx1 % 4 == 0 && (n1a == Kd || (ldx2 >= Kd - n1a && ldx2 % 4 == 0)), LPM_ERR_BADARG,
                 "lpm_proj_fwd_parts: row strides must cover their block and be multiples of 4");
     LPM_REQUIRE((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)scale) & 15) == 0, LPM_ERR_BADARG, "lpm_proj_fwd_parts: pointers must be 16-byte aligned");
-    const ProjParts pp{x2, ldx2, n1a, scale, ks};
-    return proj_fwd_impl(x1, ldx1, &pp, W, M, Kd, N, y, workspace, workspace_bytes, stream);
+    const ProjParts pp{x2, ldx2, n1a, scale, ks, x1_bf16 ? 1 : 0};
+    return proj_fwd_impl((const float*)x1, ldx1, &pp, W, M, Kd, N, y, workspace, workspace_bytes, stream);
 }
 static int proj_fwd_impl(const float* x, int64_t ldx, const lpm::ProjParts* parts, const float* W, int M, int64_t Kd, int N, float* y,
                          void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
@@ -549,14 +578,15 @@ static int proj_fwd_impl(const float* x, int64_t ldx, const lpm::ProjParts* part
 #define LPM_PJ(MTV, NPV, XDV)                                                                                                \
     do {                                                                                                                     \
         const size_t lds = (size_t)PJ_NS * PJ_WBYTES + XDV * NPV * 1024;                                                     \
-        auto kern = parts ? proj_fwd_kernel<MTV, NPV, XDV, true> : proj_fwd_kernel<MTV, NPV, XDV, false>;                    \
+        auto kern = !parts ? proj_fwd_kernel<MTV, NPV, XDV, 0>                                                               \
+                           : (parts->x1_bf16 ? proj_fwd_kernel<MTV, NPV, XDV, 2> : proj_fwd_kernel<MTV, NPV, XDV, 1>);      \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {    \
             (void)hipGetLastError();                                                                                         \
             set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                                 \
             return LPM_ERR_LAUNCH;                                                                                           \
         }                                                                                                                    \
-        hipLaunchKernelGGL(kern, grid, dim3(576), lds, s, x, ldx, W, M, Kd, N, nslab, splits, (float*)workspace,             \
-                           parts ? *parts : ProjParts{});                                                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(512 + 64 * pj_loaders(NPV, parts ? 1 : 0)), lds, s, x, ldx, W, M, Kd, N, nslab,  \
+                           splits, (float*)workspace, parts ? *parts : ProjParts{});                                         \
     } while (0)
     /* three pair-buffers of x where they fit beside the four weight stages (measured: no gain over two once the ring is read without the */
     /* compiler's waits -- kept where it is free) */

@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256) void split_weight_tiles_kernel(const float* __
 }
 
 // ... of the matrix [x1 * scale | x2] (lpm_proj_fwd_parts' operand): column c < n1a is x1[r][c] * scale[r][c % ks], the rest x2[r][c - n1a]
-__global__ __launch_bounds__(256) void split_weight_tiles_parts_kernel(const float* __restrict__ x1, int64_t ld1, int64_t n1a,
+__global__ __launch_bounds__(256) void split_weight_tiles_parts_kernel(const float* __restrict__ x1, int64_t ld1, int64_t n1a, int x1_bf16,
                                                                        const float* __restrict__ scale, int ks, const float* __restrict__ x2,
                                                                        int64_t ld2, int R, int64_t N, uint4* __restrict__ wt) {
     const int RS = R / 16;
@@ -840,7 +840,11 @@ __global__ __launch_bounds__(256) void split_weight_tiles_parts_kernel(const flo
         if (col < n1a) {
             const int kc = (int)(col % ks);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = x1[(int64_t)(r + e) * ld1 + col] * scale[(int64_t)(r + e) * ks + kc];
+            for (int e = 0; e < 8; ++e) {
+                const float xv = x1_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(x1)[(int64_t)(r + e) * ld1 + col] << 16)
+                                         : x1[(int64_t)(r + e) * ld1 + col];
+                v[e] = xv * scale[(int64_t)(r + e) * ks + kc];
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (col < N) ? x2[(int64_t)(r + e) * ld2 + (col - n1a)] : 0.f;
@@ -983,8 +987,8 @@ static int split_weight_tiles_impl(const float* w, int R, int N, int transposed,
     return check_launch("lpm_split_weight_tiles");
 }
 // the weight tiles (lpm_weight_tiles_bytes(R, N)) of [x1 * scale | x2] [R, N]: see lpm_proj_fwd_parts for the operand's description
-extern "C" int lpm_split_weight_tiles_parts(const float* x1, int64_t ld1, int64_t n1a, const float* scale, int ks, const float* x2, int64_t ld2,
-                                            int R, int64_t N, void* wt, lpm_stream_t stream) {
+extern "C" int lpm_split_weight_tiles_parts(const void* x1, int64_t ld1, int64_t n1a, int x1_bf16, const float* scale, int ks, const float* x2,
+                                            int64_t ld2, int R, int64_t N, void* wt, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(x1 && scale && wt && (x2 || n1a == N), LPM_ERR_BADARG, "lpm_split_weight_tiles_parts: null pointer");
     LPM_REQUIRE(R > 0 && R % 16 == 0 && N > 0 && n1a > 0 && n1a <= N && n1a % 32 == 0 && ks > 0 && n1a % ks == 0 && ld1 >= n1a &&
@@ -993,8 +997,8 @@ extern "C" int lpm_split_weight_tiles_parts(const float* x1, int64_t ld1, int64_
                 (long long)n1a, ks);
     const int64_t total = (int64_t)(R / 16) * ((N + 31) / 32) * 64;
     const int64_t want = (total + 255) / 256;
-    hipLaunchKernelGGL(split_weight_tiles_parts_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, (hipStream_t)stream, x1, ld1,
-                       n1a, scale, ks, x2, ld2, R, N, (uint4*)wt);
+    hipLaunchKernelGGL(split_weight_tiles_parts_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x1, ld1, n1a, x1_bf16 ? 1 : 0, scale, ks, x2, ld2, R, N, (uint4*)wt);
     return check_launch("lpm_split_weight_tiles_parts");
 }
 extern "C" int lpm_split_weight_tiles(const float* w, int R, int N, int transposed, void* wt, lpm_stream_t stream) {

@@ -66,8 +66,8 @@ def _project_gate_classify(vlad, vocab_size, cluster_size, hidden1_size, add_bat
     vlad_dim = sum(p.shape[1] for p in parts if p is not None) if parts else vlad.shape[1]
     hidden1_weights = vs.get_variable("hidden1_weights", [vlad_dim, hidden1_size],
                                       vs.random_normal_initializer(1 / math.sqrt(cluster_size)), device=dev)   # :2315-2317
-    if parts and ops.projection_parts_ok(parts[0], ops.row_scale_of(parts[0]), getattr(parts[0], "_lpm_scale_ks", 0), parts[1],
-                                         hidden1_weights):
+    if parts and ops.projection_parts_ok(getattr(parts[0], "_lpm_raw", parts[0]), ops.row_scale_of(parts[0]),
+                                         getattr(parts[0], "_lpm_scale_ks", 0), parts[1], hidden1_weights):
         activation = ops.projection_parts(parts[0], parts[1], hidden1_weights)                                 # :2309 / :2445 + :2319
     else:
         if parts:
@@ -224,21 +224,28 @@ class NetVladV1(models.BaseModel):
                       and (aff_v is not None or not torch.is_grad_enabled())
                       and video_encoder_block.fused_shape(batch, cluster_size, True) and ops.netvlad_lazy_ok(max_frames, 1024, cluster_size))
         slots = None
-        if (storage == "bf16" and not encoder and has_audio and FLAGS.descriptor_slots and aff_v is not None):
+        # bf16 storage without the cluster encoders (BASELINE configs[4]): the video descriptor LAZILY normalised -- the bf16 sums as the
+        # aggregation kernel wrote them + one scale per (clip, cluster), applied by the projection where it reads them (no finalize pass:
+        # that pass read the sums and wrote the fp32 descriptor, 0.4 GB per step at bs 128), the audio descriptor in an fp32 buffer of its own
+        lazy5 = bool(storage == "bf16" and not encoder and has_audio and FLAGS.netvlad_lazy_descriptor and FLAGS.descriptor_slots
+                     and aff_v is not None and batch <= 128 and hidden1_size % 512 == 0 and cluster_size % 32 == 0)
+        if lazy5:
+            slots = ops.DescriptorSlots(batch, [(1, 128 * (cluster_size // 4))], reshaped_input)
+        elif (storage == "bf16" and not encoder and has_audio and FLAGS.descriptor_slots and aff_v is not None):
             # bf16 storage without the cluster encoders (BASELINE configs[4]): the projection behind the pooling computes in fp32, so the
             # two normalised descriptors leave their finalize passes as fp32 straight into ONE [B, 1024 K + 128 K/4] buffer -- no bf16
             # copy of the descriptor, no concat, no casts of it or of its gradient
             slots = ops.DescriptorSlots(batch, [(1, 1024 * cluster_size), (1, 128 * (cluster_size // 4))], reshaped_input)
         with vs.variable_scope("video_VLAD"):
-            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v, storage=storage, lazy=lazy_v,
-                                               out_slot=slots.slots[0] if slots else None)               # :2273-2274
+            vlad_video = video_NetVLAD.forward(rgb, kmajor=encoder, input_affine=aff_v, storage=storage, lazy=lazy_v or lazy5,
+                                               out_slot=slots.slots[0] if slots and not lazy5 else None)  # :2273-2274
             if vs.default_store().summaries is not None:
                 # [B, K, D] (the App. C5 token view) when the encoders follow, else [B, D*K]
                 vs.summary("vlad_video", ops.materialise(vlad_video))
         if has_audio:
             with side, vs.variable_scope("audio_VLAD"):
                 vlad_audio = audio_NetVLAD.forward(audio, kmajor=encoder, input_affine=aff_a, storage=storage,
-                                                   out_slot=slots.slots[1] if slots else None)           # :2276-2277
+                                                   out_slot=(slots.slots[0 if lazy5 else 1] if slots else None))   # :2276-2277
                 vs.summary("vlad_audio", vlad_audio)
 
         if encoder:
@@ -264,6 +271,11 @@ class NetVladV1(models.BaseModel):
         if use_side:
             side.join(vlad_audio)
 
+        if lazy5:
+            if vs.default_store().summaries is not None:
+                vs.summary("vlad", torch.cat([ops.materialise(vlad_video), vlad_audio.reshape(batch, -1)], 1))
+            return _project_gate_classify((vlad_video, vlad_audio.reshape(batch, -1)), vocab_size, cluster_size, hidden1_size,
+                                          add_batch_norm, relu, gating, remove_diag, is_training, **unused_params)   # :2309 inside the projection
         if slots is not None:
             vlad = slots.join(vlad_video, vlad_audio)                                          # :2309, in place
         else:

@@ -709,13 +709,11 @@ class _NetVLAD(torch.autograd.Function):
         B = M // T
         ctx.storage = storage
         ctx.lazy = bool(lazy)
-        if lazy and storage != "f32":
-            raise LpmError("netvlad: the lazily normalised descriptor is an fp32-storage form")
         if out_slot is not None and storage != "bf16":
             raise LpmError("netvlad: an output slot is taken by the bf16-storage form only")
         if storage == "bf16":
             return _NetVLAD._forward_bf16(ctx, lib, x, W, gamma, beta, moving_mean, moving_var, bias, W2, B, T, D, K, is_training, kmajor,
-                                          in_gamma, in_beta, out_slot)
+                                          in_gamma, in_beta, out_slot, lazy)
         if storage != "f32":
             raise LpmError(f"unknown storage {storage!r} (f32 | bf16)")
         _materialised(x, "reshaped_input")
@@ -784,7 +782,7 @@ class _NetVLAD(torch.autograd.Function):
 
     @staticmethod
     def _forward_bf16(ctx, lib, x, W, gamma, beta, moving_mean, moving_var, bias, W2, B, T, D, K, is_training, kmajor, in_gamma, in_beta,
-                      out_slot=None):
+                      out_slot=None, lazy=False):
         """bf16 storage (BASELINE cfg-5; include/lpm_hip.h "bf16 storage"): frames, logits / assignment and the descriptor are bf16
         in HBM, every product one bf16 MFMA with fp32 accumulation; statistics, norms and gradients fp32.  Needs the operand tiles
         ops.frame_sample_bn(storage="bf16") wrote for x, the LDS-shared K2 form (D, K multiples of 128, K <= 512), the d-major
@@ -834,7 +832,19 @@ class _NetVLAD(torch.autograd.Function):
             lib.check(lib._lpm_vlad_aggregate_tiles3_fwd_bf16(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
                                                               ptr(part), st), "lpm_vlad_aggregate_tiles3_fwd_bf16")
         gsq = _empty((B,), W)
-        if out_slot is not None:
+        if lazy:
+            # LAZILY NORMALISED (d-major, bf16 sums): no finalize pass -- lpm_vlad_row_scales turns the partial norms into one factor per
+            # (clip, cluster) and the consumer (ops.projection_parts) applies it where it reads the sums.  What is returned is an fp32
+            # HANDLE of the descriptor's shape that nobody may read (never written: autograd wants a gradient of the handle's dtype, and
+            # the projection's input gradient is fp32); the sums travel as its ``_lpm_raw``.
+            if out_slot is not None or K % 32:
+                raise LpmError("netvlad: the lazily normalised bf16 descriptor takes no output slot and needs K % 32 == 0")
+            rs = _empty((B, K), W)
+            with _timed("vlad_finalize", (B, D, K)):
+                lib.check(lib._lpm_vlad_row_scales(ptr(part), P, B, K, ptr(rs), ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_row_scales")
+            out = _empty((B, D * K), W)
+            out._lpm_row_scale, out._lpm_scale_ks, out._lpm_raw = rs, K, nrm.view(B, D * K)
+        elif out_slot is not None:
             # the consumer (the hidden projection) computes in fp32: the normalised descriptor leaves the finalize pass as fp32 straight
             # into its column slot of the streams' joined buffer -- no bf16 copy, no concat, no casts in either direction
             out = out_slot.view()                    # [B, 1, D * K], clips out_slot.base.shape[1] elements apart
@@ -865,8 +875,8 @@ class _NetVLAD(torch.autograd.Function):
         M = B * T
         # the gradient of a bf16 descriptor arrives as bf16; of a slot (fp32) as a column slice of the joined buffer's gradient, which
         # K3 reads in place (clips dout.stride(0) elements apart)
-        if dout.dtype == torch.float32 and dout.dim() == 3 and dout.shape[1] == 1 and dout.stride(2) == 1 and dout.stride(0) % 4 == 0 \
-                and dout.stride(0) >= D * K and dout.data_ptr() % 16 == 0:
+        if dout.dtype == torch.float32 and ((dout.dim() == 3 and dout.shape[1] == 1) or dout.dim() == 2) and dout.stride(-1) == 1 \
+                and dout.stride(0) % 4 == 0 and dout.stride(0) >= D * K and dout.data_ptr() % 16 == 0:
             dob = dout.stride(0)
         else:
             dout = dout.float().contiguous()
@@ -1005,7 +1015,10 @@ class _Materialise(torch.autograd.Function):
     normalisations lives in the pooling op's backward (K3)."""
 
     @staticmethod
-    def forward(ctx, raw, row_scale, ks=0):
+    def forward(ctx, raw, row_scale, ks=0, stored=None):
+        """stored: the sums when ``raw`` is only a handle (bf16 storage: _NetVLAD._forward_bf16, lazy)."""
+        if stored is not None:
+            raw = stored.float()
         if ks:
             B = raw.shape[0]
             return (raw.reshape(B, -1, ks) * row_scale.unsqueeze(1)).reshape(raw.shape)
@@ -1013,7 +1026,7 @@ class _Materialise(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d):
-        return d, None, None
+        return d, None, None, None
 
 
 def row_scale_of(x):
@@ -1024,7 +1037,7 @@ def row_scale_of(x):
 def materialise(x):
     """An ordinary tensor for any consumer that does not apply the row scale itself."""
     rs = row_scale_of(x)
-    return x if rs is None else _Materialise.apply(x, rs, int(getattr(x, "_lpm_scale_ks", 0)))
+    return x if rs is None else _Materialise.apply(x, rs, int(getattr(x, "_lpm_scale_ks", 0)), getattr(x, "_lpm_raw", None))
 
 
 def netvlad_lazy_ok(T, D, K):
@@ -1740,8 +1753,10 @@ class _ProjectionParts(torch.autograd.Function):
     descriptor (the lazily normalised form's contract)."""
 
     @staticmethod
-    def forward(ctx, x1, scale, ks, x2, W):
+    def forward(ctx, x1h, stored, scale, ks, x2, W):
+        """x1h: the tensor autograd sees (its gradient is dx1); stored: the sums when x1h is only a handle (bf16 storage), else None."""
         lib = _capi.load()
+        x1 = stored if stored is not None else x1h
         M, n1a = x1.shape
         n1b = x2.shape[1] if x2 is not None else 0
         Kd, N = n1a + n1b, W.shape[1]
@@ -1749,12 +1764,13 @@ class _ProjectionParts(torch.autograd.Function):
             raise LpmError("projection_parts: shapes / layouts outside lpm_proj_fwd_parts' conditions (use ops.materialise + ops.projection)")
         ctx.save_for_backward(x1, scale, x2, W)
         ctx.ks = int(ks)
-        y = _empty((M, N), x1)
+        y = _empty((M, N), W)
         wsb = lib._lpm_proj_fwd_workspace_bytes(M, Kd, N)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=x1.device)
         with _timed("proj_fwd", (M, Kd, N)):
-            lib.check(lib._lpm_proj_fwd_parts(ptr(x1), x1.stride(0), n1a, ptr(scale), int(ks), ptr(x2), x2.stride(0) if x2 is not None else 0,
-                                              ptr(W), M, Kd, N, ptr(y), ptr(ws), wsb, stream_ptr()), "lpm_proj_fwd_parts")
+            lib.check(lib._lpm_proj_fwd_parts(ptr(x1), x1.stride(0), n1a, int(x1.dtype == torch.bfloat16), ptr(scale), int(ks), ptr(x2),
+                                              x2.stride(0) if x2 is not None else 0, ptr(W), M, Kd, N, ptr(y), ptr(ws), wsb, stream_ptr()),
+                      "lpm_proj_fwd_parts")
         return y
 
     @staticmethod
@@ -1767,23 +1783,23 @@ class _ProjectionParts(torch.autograd.Function):
         dy = dy.contiguous()
         st = stream_ptr()
         dx1 = dx2 = None
-        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[3]):
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[4]):
             if N >= PROJ_DX_STREAM_MIN_N:
                 dyt = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), dy)
                 lib.check(lib._lpm_split_rows_tiles(ptr(dy), N, 1, M, N, ptr(dyt), st), "lpm_split_rows_tiles")
-                dx = _empty((M, Kd), x1)
+                dx = _empty((M, Kd), W)
                 with _timed("proj_dx", (M, Kd, N)):
                     lib.check(lib._lpm_proj_dx(ptr(dyt), ptr(W), M, Kd, N, ptr(dx), dx.stride(0), st), "lpm_proj_dx")
             else:
                 dx = dy.matmul(W.t())
             dx1 = dx[:, :n1a]
             dx2 = dx[:, n1a:] if x2 is not None else None
-        if not ctx.needs_input_grad[4]:
-            return dx1, None, None, dx2, None
+        if not ctx.needs_input_grad[5]:
+            return dx1, None, None, None, dx2, None
 
         def x_tiles():
             xt = _tile_buffer(lib._lpm_weight_tiles_bytes(M, Kd), x1)
-            lib.check(lib._lpm_split_weight_tiles_parts(ptr(x1), x1.stride(0), n1a, ptr(scale), ctx.ks, ptr(x2),
+            lib.check(lib._lpm_split_weight_tiles_parts(ptr(x1), x1.stride(0), n1a, int(x1.dtype == torch.bfloat16), ptr(scale), ctx.ks, ptr(x2),
                                                         x2.stride(0) if x2 is not None else 0, M, Kd, ptr(xt), st), "lpm_split_weight_tiles_parts")
             return xt
 
@@ -1794,23 +1810,23 @@ class _ProjectionParts(torch.autograd.Function):
                            "step does not fit it (clips not a multiple of 16, or the weight used twice)")
         if factored is not None and factored.armed and skinny and not factored.puts:
             factored.put_tiles(x_tiles(), dy, M, Kd)
-            return dx1, None, None, dx2, None
+            return dx1, None, None, None, dx2, None
         if skinny:
             dyt2 = _tile_buffer(lib._lpm_weight_tiles_bytes(M, N), dy)
             lib.check(lib._lpm_split_weight_tiles(ptr(dy), M, N, 0, ptr(dyt2), st), "lpm_split_weight_tiles")
             view = getattr(W, "_lpm_grad_view", None)
             fresh = view is None or getattr(W, "_lpm_grad_written", False)
-            out = _empty((Kd, N), x1) if fresh else view
+            out = _empty((Kd, N), W) if fresh else view
             with _timed("skinny_weight_grad", (M, Kd, N)):
                 lib.check(lib._lpm_skinny_weight_grad_tiles(ptr(x_tiles()), ptr(dyt2), M, Kd, N, ptr(out), st), "lpm_skinny_weight_grad_tiles")
             dW = out
         else:
-            xm = _Materialise.forward(None, x1, scale, ctx.ks)
+            xm = _Materialise.forward(None, x1.float(), scale, ctx.ks)
             dW = (torch.cat([xm, x2], 1) if x2 is not None else xm).t().matmul(dy)
             view = getattr(W, "_lpm_grad_view", None)
             fresh = True
         if view is None:
-            return dx1, None, None, dx2, dW
+            return dx1, None, None, None, dx2, dW
         if getattr(W, "_lpm_grad_written", False):
             view += dW
         elif fresh:
@@ -1819,13 +1835,13 @@ class _ProjectionParts(torch.autograd.Function):
         ready = getattr(W, "_lpm_grad_ready", None)
         if ready is not None:
             ready()
-        return dx1, None, None, dx2, None
+        return dx1, None, None, None, dx2, None
 
 
 def projection_parts_ok(x1, scale, ks, x2, W):
     """lpm_proj_fwd_parts' conditions (include/lpm_hip.h) for these tensors."""
-    if not (PROJ_STREAM and x1.is_cuda and x1.dtype == torch.float32 and W.dtype == torch.float32 and W.is_contiguous() and x1.dim() == 2
-            and scale is not None and scale.is_contiguous() and scale.dtype == torch.float32):
+    if not (PROJ_STREAM and x1.is_cuda and x1.dtype in (torch.float32, torch.bfloat16) and W.dtype == torch.float32 and W.is_contiguous()
+            and x1.dim() == 2 and scale is not None and scale.is_contiguous() and scale.dtype == torch.float32):
         return False
     M, n1a = x1.shape
     n1b = 0
@@ -1842,7 +1858,7 @@ def projection_parts_ok(x1, scale, ks, x2, W):
 
 def projection_parts(x1, x2, W):
     """[descriptor(x1) | x2] . W for a lazily normalised d-major x1 (see _ProjectionParts); x2 may be None."""
-    return _ProjectionParts.apply(x1, row_scale_of(x1), int(getattr(x1, "_lpm_scale_ks", 0)), x2, W)
+    return _ProjectionParts.apply(x1, getattr(x1, "_lpm_raw", None), row_scale_of(x1), int(getattr(x1, "_lpm_scale_ks", 0)), x2, W)
 
 
 class _BatchNormRows(torch.autograd.Function):

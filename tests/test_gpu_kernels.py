@@ -1110,6 +1110,35 @@ def test_projection_parts(B, D, K, NA, H, factored):
         del W._lpm_factored
 
 
+def test_projection_parts_bf16_sums_behind_a_handle():
+    """bf16 storage (BASELINE configs[4]): the un-normalised sums are bf16, autograd sees an fp32 handle of the descriptor's shape that
+    is never written (ops._NetVLAD._forward_bf16, lazy); forward, dx and the weight-gradient tiles read the bf16 sums x the scale."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, D, K, NA, H = 32, 128, 128, 256, 512
+    g = torch.Generator().manual_seed(5)
+    raw = (torch.randn(B, D * K, generator=g) * 3).to(dev).to(torch.bfloat16)
+    scale = (torch.rand(B, K, generator=g) + 0.5).to(dev) / (D * K) ** 0.5
+    x2 = (torch.randn(B, NA, generator=g) / NA ** 0.5).to(dev).requires_grad_(True)
+    Kd = D * K + NA
+    W = (torch.randn(Kd, H, generator=g) / Kd ** 0.5).to(dev).requires_grad_(True)
+    dy = torch.randn(B, H, generator=g).to(dev)
+    handle = torch.full((B, D * K), float("nan"), device=dev).requires_grad_(True)
+    handle._lpm_row_scale, handle._lpm_scale_ks, handle._lpm_raw = scale, K, raw
+    xm = (raw.double().cpu().view(B, D, K) * scale.double().cpu().unsqueeze(1)).reshape(B, D * K)
+    x64 = torch.cat([xm, x2.detach().double().cpu()], 1)
+    W64, dy64 = W.detach().double().cpu(), dy.double().cpu()
+    assert_close(ops.materialise(handle), xm, 1e-6, "materialise (bf16 sums)")
+    y = ops.projection_parts(handle, x2, W)
+    y.backward(dy)
+    assert_close(y, x64 @ W64, 2e-5, "y")
+    dx = dy64 @ W64.t()
+    assert handle.grad.dtype == torch.float32
+    assert_close(handle.grad, dx[:, :D * K], 2e-5, "dx1")
+    assert_close(x2.grad, dx[:, D * K:], 2e-5, "dx2")
+    assert_close(W.grad, x64.t() @ dy64, 2e-5, "dW")
+
+
 def test_vlad_aggregate_lazy_matches_the_finalize_form():
     """NetVladAttenCluster's tail (video_pooling_modules.py:1641-1658) as the lazily normalised d-major descriptor: the un-normalised sums
     x the row scales ARE the finalize form's descriptor, and the gradients of both forms agree (K3 is the same code)."""
