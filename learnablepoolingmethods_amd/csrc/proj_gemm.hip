@@ -24,7 +24,11 @@ constexpr int PJ_WBYTES = 16 * 512 * 4;            // W slab
 #ifndef LPM_PJ_AUX
 #define LPM_PJ_AUX 2                                // (a variant build with 0 = the default policy: tools/build_proj_policy_variant.sh, A/B)
 #endif
-constexpr int PJ_AUX = LPM_PJ_AUX;                 // LDS-DMA cache policy of the weight stream: nt (every byte is read once, by one CU)
+constexpr int PJ_AUX = LPM_PJ_AUX;
+#ifndef LPM_PJ_SC_SPLIT
+#define LPM_PJ_SC_SPLIT 0
+#endif
+constexpr bool PJ_SC_SPLIT = LPM_PJ_SC_SPLIT != 0;                 // LDS-DMA cache policy of the weight stream: nt (every byte is read once, by one CU)
 
 // MT = row tiles (ceil(M / 32)).  Eight computing waves (64 columns each) bring the weight slabs in; a NINTH wave brings ALL of x in and
 // does nothing else, in PAIRS of slabs: 128 bytes per row = a whole cache line (round 3; before, 2 MT of the computing waves asked for
@@ -140,11 +144,16 @@ __global__ __launch_bounds__(512 + 64 * pj_loaders(NP, SC), 1) void proj_fwd_ker
                 __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): this wave's LDS writes are done
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                // after the barrier of stage 2 j every wave is past pair j - 1: the buffer pair j + 1 goes to (pair j + 1 - XD's) is free
+                // after the barrier of stage 2 j every wave is past pair j - 1: the buffer pair j + 1 goes to (pair j + 1 - XD's) is free.
+                // (LPM_PJ_SC_SPLIT=1 -- the requests for pair j + 2 one stage later than the write of pair j + 1, so that the load issues
+                // do not delay this wave's arrival at the next barrier -- measured at cfg-3: 318 us against 161: one stage is not enough
+                // for the pieces to arrive, eighty 128-byte lines exactly 1 MB apart)
+                const int j = s >> 1;
                 if (!(s & 1)) {
-                    const int j = s >> 1;
                     if (j + 1 < nss) store(j + 1);
-                    if (j + 2 < nss) load(j + 2);
+                    if (!PJ_SC_SPLIT && j + 2 < nss) load(j + 2);
+                } else if (PJ_SC_SPLIT && j + 2 < nss) {
+                    load(j + 2);
                 }
             }
             return;

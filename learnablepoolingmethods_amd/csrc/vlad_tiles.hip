@@ -159,7 +159,13 @@ template <bool SOFTMAX, bool BF16IN, int VPL>
 __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restrict__ assign, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int T, int S, uint4* __restrict__ at) {
     constexpr int K = 64 * VPL, KS = K + 4, KT = K / 32;
-    __shared__ __attribute__((aligned(16))) float as[16 * KS];
+    // BF16IN (round 4): the tile holds what leaves -- bf16, rounded where the row is stored -- at half the LDS (16.6 instead of 33 KB at
+    // K = 512: eight workgroups per CU instead of four; the kernel is one dependent chain of load, two butterflies, LDS round trip and
+    // store per workgroup, so its rate is its occupancy)
+    constexpr int KS2 = K + 8;                               // bf16 row stride (rows 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) unsigned char as_raw[BF16IN ? 16 * KS2 * 2 : 16 * KS * 4];
+    float* as = reinterpret_cast<float*>(as_raw);
+    unsigned short* as16 = reinterpret_cast<unsigned short*>(as_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / S, s = blockIdx.x % S;
     const int c0 = lane * VPL;
@@ -244,6 +250,21 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
+        if (BF16IN) {
+            unsigned short* dst = as16 + (wave * 4 + rr) * KS2 + c0;
+            if (VPL % 2 == 0) {                             // packed: one store of 2 VPL bytes per lane (4 / 8 / 16)
+                unsigned w2[VPL / 2 > 0 ? VPL / 2 : 1];
+#pragma unroll
+                for (int j = 0; j < VPL / 2; ++j) w2[j] = bf16_rne(v[rr][2 * j]) | (bf16_rne(v[rr][2 * j + 1]) << 16);
+                if (VPL == 8) *reinterpret_cast<uint4*>(dst) = make_uint4(w2[0], w2[1 % (VPL / 2 > 0 ? VPL / 2 : 1)], w2[2 % (VPL / 2 > 0 ? VPL / 2 : 1)], w2[3 % (VPL / 2 > 0 ? VPL / 2 : 1)]);
+                else if (VPL == 4) *reinterpret_cast<uint2*>(dst) = make_uint2(w2[0], w2[1 % (VPL / 2 > 0 ? VPL / 2 : 1)]);
+                else *reinterpret_cast<unsigned*>(dst) = w2[0];
+            } else {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) dst[j] = (unsigned short)bf16_rne(v[rr][j]);
+            }
+            continue;
+        }
         float* dst = as + (wave * 4 + rr) * KS + c0;
         if (VPL % 4 == 0) {
 #pragma unroll
@@ -257,15 +278,18 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
     for (int slot = tid; slot < KT * 64; slot += 256) {
         const int kt = slot >> 6, ln = slot & 63;
         const int kh = ln >> 5, i = ln & 31;
+        if (BF16IN) {
+            unsigned h[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = as16[(8 * kh + e) * KS2 + kt * 32 + i];
+            at[(((int64_t)b * KT + kt) * S + s) * 64 + ln] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            continue;
+        }
         float w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[e] = as[(8 * kh + e) * KS + kt * 32 + i];
         uint4 hi, lo;
         split8(w, hi, lo);
-        if (BF16IN) {
-            at[(((int64_t)b * KT + kt) * S + s) * 64 + ln] = hi;
-            continue;
-        }
         const int64_t base = ((((int64_t)b * KT + kt) * S + s) * 2) * 64 + ln;
         at[base] = hi;
         at[base + 64] = lo;
