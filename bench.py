@@ -426,10 +426,10 @@ def main():
             elif prec == "bf16x3" and ops.VLAD_TILES3 and ops.VLAD_KMAJOR_SCALED and args.config == "cfg2":
                 kname = ("vlad_kmajor_kernel (K2 + row scales, video stream, split-bf16 MFMA, LDS-DMA tiles, 256 x 128 and 128 x 128 "
                          "workgroup items)")
-            elif (prec == "bf16x3" and ops.VLAD_TILES3 and ops.VLAD_CLIP and args.config == "cfg2" and FLAGS.netvlad_lazy_descriptor
+            elif (prec == "bf16x3" and ops.VLAD_TILES3 and ops.VLAD_CLIP and args.config in ("cfg2", "cfg3") and FLAGS.netvlad_lazy_descriptor
                   and lib._lpm_vlad_clip_slabs(D, K)):
                 kname = ("vlad_clip_kernel (K2, video stream, split-bf16 MFMA, LDS-DMA tiles, clip-wide items: all 256 clusters x a "
-                         "third of a clip's columns per workgroup)")
+                         "third of a clip's columns per workgroup" + ("; sums leave d-major)" if args.config == "cfg3" else ")"))
             elif prec == "bf16x3":
                 kname = ("vlad_aggregate_tiles3_kernel (K2, video stream, split-bf16 MFMA, LDS-DMA tiles)" if ops.VLAD_TILES3
                          else "vlad_aggregate_tiles_kernel<8> (K2, video stream, split-bf16 MFMA, register streaming)")

@@ -262,6 +262,9 @@ int lpm_vlad_row_scales(const float* colsq_part, int P, int B, int K, float* sca
 int lpm_vlad_clip_slabs(int D, int K);
 int lpm_vlad_aggregate_clip_kmajor_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
                                        float* raw_kmajor, float* asum, float* colsq_part, lpm_stream_t stream);
+/* ... the same kernel leaving the un-normalised sums d-major [B, D, K] (NetVladV2's lazily normalised descriptor; lpm_vlad_row_scales follows) */
+int lpm_vlad_aggregate_clip_dmajor_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                       float* raw_dmajor, float* asum, float* colsq_part, lpm_stream_t stream);
 /* K2 + row scales in ONE launch (vlad_kmajor.hip; frame_level_models.py:2803-2822 for the lazily normalised k-major descriptor):
  * raw_kmajor [B,K,D] un-normalised residual sums, scale [B,K] with descriptor[b,k,:] = raw[b,k,:] * scale[b,k], and asum / colsq /
  * csq [B,K], gsq [B] for the backward.  K = 256: "wide" workgroups (all clusters x 128 columns) for whole rounds of clips, 128 x 128

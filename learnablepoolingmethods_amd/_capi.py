@@ -102,6 +102,7 @@ SIGNATURES = {
     "lpm_vlad_row_scales": (_i, [_f, _i, _i, _i, _f, _f, _f, _f, _f]),
     "lpm_vlad_clip_slabs": (_i, [_i, _i]),
     "lpm_vlad_aggregate_clip_kmajor_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "lpm_vlad_aggregate_clip_dmajor_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "lpm_vlad_kmajor_workspace_bytes": (_s, [_i, _i, _i]),
     "lpm_vlad_aggregate_kmajor_scaled_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_split_rows_scaled": (_i, [_f, _l, _l, _i, _f, _f, _f]),

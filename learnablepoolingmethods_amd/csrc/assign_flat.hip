@@ -23,10 +23,8 @@ namespace lpm {
 
 constexpr int AF_KSTEP = 6 * 1024;         // A bytes per reduction step: three row tiles x (hi, lo)
 constexpr int AF_ROWS = 96;
-// A ring: NS stages of KB reduction steps each, ONE workgroup barrier per stage.  Measured with one step per stage (LPM_K1_DBG
-// ablations, tools/k1_flat_ablate.sh): the loop of 64 barriers alone is 7.8 us and is NOT covered by the MFMAs -- every wave has
-// issued its last MFMA when it arrives, so the matrix pipe idles for the barrier's round trip (MFMAs + barriers 24.8 us against 17.5 us
-// of MFMA issue) -- hence several steps per barrier.
+// A ring: NS stages of KB reduction steps each, ONE workgroup barrier per stage (LPM_K1_KB).  Measured at cfg-2's shape, kernel alone:
+// 38.5 / 38.0 / 40.8 us with 1 / 2 / 4 steps per barrier -- the barrier is not what the loop waits for; two is the default.
 __host__ __device__ constexpr int af_ns(int KB) { return KB == 1 ? 6 : 4; }
 __host__ __device__ constexpr int af_tail(int KB, int DB) { return KB == 4 ? (DB == 8 ? 16 : 12) : 8; }   // peeled last steps: a multiple of DB and KB, >= (NS - 1) KB
 
@@ -74,13 +72,11 @@ __device__ __forceinline__ void af_wait_vm(int n) {          // n folds to a con
 }
 #undef AF_WAIT_CASE
 
-// DBG (measurement instantiations, LPM_K1_DBG): 1 no main loop, 2 no stores, 4 no loads inside the loop, 8 no MFMAs, 16 no fragment reads
-template <int KB, int DB, int DBG>
+template <int KB, int DB>
 __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArgs a) {
     constexpr int NS = af_ns(KB), TAIL = af_tail(KB, DB), STAGE = KB * AF_KSTEP;
     static_assert((NS - 2) * KB >= DB && TAIL % DB == 0 && TAIL % KB == 0 && TAIL >= (NS - 1) * KB && (DB == 4 || DB == 8),
                   "A(next stage) must be older than B(i); the tail is whole register rounds and whole stages");
-    constexpr int dbg = DBG;           // (compile-time: run-time tests around the MFMA groups distort what they measure)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,30 +160,28 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
             asm volatile("" ::: "memory");
         }
 #pragma unroll
-        for (int m = 0; m < 3; ++m) if (!(dbg & 8)) acc[m] = tg_mfma(fa[ab].h[m], bh[j], acc[m]);
+        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].h[m], bh[j], acc[m]);
         __builtin_amdgcn_sched_barrier(0);
-        if (e == 0 && loader && (i + (NS - 1) * KB < TAIL) && !(dbg & 4))
+        if (e == 0 && loader && (i + (NS - 1) * KB < TAIL))
             issue_a(s / KB + NS - 1, slot == 0 ? NS - 1 : slot - 1);       // into the slot of the stage before this one
         const int slot1 = slot + 1 == NS ? 0 : slot + 1;
-        if (i + 1 < TAIL && !(dbg & 16)) read_frags((unsigned)((e + 1 == KB ? slot1 : slot) * STAGE + (e + 1 == KB ? 0 : e + 1) * AF_KSTEP), fa[ab ^ 1]);
+        if (i + 1 < TAIL) read_frags((unsigned)((e + 1 == KB ? slot1 : slot) * STAGE + (e + 1 == KB ? 0 : e + 1) * AF_KSTEP), fa[ab ^ 1]);
         if (e + 1 == KB) slot = slot1;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 3; ++m) if (!(dbg & 8)) acc[m] = tg_mfma(fa[ab].h[m], bl[j], acc[m]);
+        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].h[m], bl[j], acc[m]);
 #pragma unroll
-        for (int m = 0; m < 3; ++m) if (!(dbg & 8)) acc[m] = tg_mfma(fa[ab].l[m], bh[j], acc[m]);
+        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].l[m], bh[j], acc[m]);
         __builtin_amdgcn_sched_barrier(0);
-        if (i + DB < TAIL && !(dbg & 4)) issue_b(s + DB, bh[j], bl[j]);
+        if (i + DB < TAIL) issue_b(s + DB, bh[j], bl[j]);
     };
     const int nmain = nstep - TAIL;
-    for (int s0 = 0; s0 < ((dbg & 1) ? 0 : nmain); s0 += DB) {
+    for (int s0 = 0; s0 < nmain; s0 += DB) {
 #pragma unroll
         for (int j = 0; j < DB; ++j) step(s0 + j, -400 + j, j, j & 1);
     }
-    if (!(dbg & 1)) {
 #pragma unroll
-        for (int i = 0; i < TAIL; ++i) step(nmain + i, i, i % DB, i & 1);
-    }
+    for (int i = 0; i < TAIL; ++i) step(nmain + i, i, i % DB, i & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // epilogue: acc[m][r] = logits[row wg * 96 + m * 32 + mfma32_row(r, lane)][column ct * 32 + l31]
@@ -202,7 +196,7 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
             const float v = row < a.M ? acc[m][r] : 0.f;
             cs += v;
             cq = fmaf(v, v, cq);
-            if (row < a.M && !(dbg & 2)) a.logits[row * a.K + col] = acc[m][r];
+            if (row < a.M) a.logits[row * a.K + col] = acc[m][r];
         }
     cs += __shfl_xor(cs, 32, 64);
     cq += __shfl_xor(cq, 32, 64);
@@ -252,30 +246,18 @@ int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int
     }
     const dim3 grid((unsigned)nwg, (unsigned)(K / 256));
     const int kb = af_kb(), db = af_db();
-    static const int dbg_env = [] { const char* e = getenv("LPM_K1_DBG"); return e ? atoi(e) : 0; }();
     const size_t lds = (size_t)af_ns(kb) * kb * AF_KSTEP;
     hipEvent_t e0, e1;
-    const bool timed = !dbg_env && timing_tag && timing_request(timing_tag, &e0, &e1);
-#define AF_LAUNCH(KB, DB, DBG)                                                                              \
+    const bool timed = timing_tag && timing_request(timing_tag, &e0, &e1);
+#define AF_LAUNCH(KB, DB)                                                                                   \
     do {                                                                                                    \
-        if (timed) hipExtLaunchKernelGGL((assign_flat_kernel<KB, DB, DBG>), grid, dim3(512), lds, stream, e0, e1, 0, a); \
-        else hipLaunchKernelGGL((assign_flat_kernel<KB, DB, DBG>), grid, dim3(512), lds, stream, a);       \
+        if (timed) hipExtLaunchKernelGGL((assign_flat_kernel<KB, DB>), grid, dim3(512), lds, stream, e0, e1, 0, a); \
+        else hipLaunchKernelGGL((assign_flat_kernel<KB, DB>), grid, dim3(512), lds, stream, a);            \
     } while (0)
-    if (dbg_env) {                                     // measurement instantiations (tools/k1_flat_ablate.sh), two steps per barrier
-        switch (dbg_env) {
-            case 1: AF_LAUNCH(2, 4, 1); break;
-            case 4: AF_LAUNCH(2, 4, 4); break;
-            case 8: AF_LAUNCH(2, 4, 8); break;
-            case 16: AF_LAUNCH(2, 4, 16); break;
-            case 20: AF_LAUNCH(2, 4, 20); break;
-            case 28: AF_LAUNCH(2, 4, 28); break;
-            default: set_error("%s: LPM_K1_DBG takes 1, 4, 8, 16, 20, 28", what); return LPM_ERR_BADARG;
-        }
-    }
-    else if (kb == 1) AF_LAUNCH(1, 4, 0);
-    else if (kb == 2) AF_LAUNCH(2, 4, 0);
-    else if (db == 8) AF_LAUNCH(4, 8, 0);
-    else AF_LAUNCH(4, 4, 0);
+    if (kb == 1) AF_LAUNCH(1, 4);
+    else if (kb == 2) AF_LAUNCH(2, 4);
+    else if (db == 8) AF_LAUNCH(4, 8);
+    else AF_LAUNCH(4, 4);
 #undef AF_LAUNCH
     return check_launch(what);
 }

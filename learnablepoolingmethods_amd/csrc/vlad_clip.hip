@@ -43,7 +43,8 @@ struct VCArgs {
     const uint4* xt;            // frame tiles      [b][S][D/32][plane][lane]   (lpm_split_frames / lpm_frame_apply_tiles)
     const float* centres;       // [D, K] (cluster_weights2) or null
     int T, D, S, P, residual;   // K = 256; P column slabs per clip
-    float* out;                 // [B, K, D] un-normalised residual sums
+    float* out;                 // [B, K, D] un-normalised residual sums (dmajor: [B, D, K])
+    int dmajor;                 // the result leaves d-major (NetVladV2's lazily normalised descriptor, round 4): straight from the accumulators
     float* asum;                // [B, K]
     float* colsq_part;          // [B, P, K]
     int dbg;                    // measurement only (LPM_VC_DBG): 1 no main loop, 2 no stores, 4 no DMA, 8 no MFMAs, 16 no residual loads
@@ -283,9 +284,20 @@ __global__ __launch_bounds__(512, 2) void vlad_clip_kernel(const VCArgs g) {
                     if (residual) u[j] -= asum_l * cen[e & 1][4 * q + j];
                     nsq = fmaf(u[j], u[j], nsq);
                 }
-                *reinterpret_cast<float4*>(tl + l31 * VC_TS + 8 * q + 4 * half) = make_float4(u[0], u[1], u[2], u[3]);
+                    if (g.dmajor) {
+                    // d-major [B, D, K]: an accumulator register is one d of 32 consecutive clusters -- a half-wave's store is one 128-byte
+                    // line of a row, no transposing tile
+                    if (do_store) {
+                        float* od = g.out + ((int64_t)b * D + ct0 * 32 + 32 * e + 8 * q + 4 * half) * K + kcl;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) od[(int64_t)j * K] = u[j];
+                    }
+                } else {
+                    *reinterpret_cast<float4*>(tl + l31 * VC_TS + 8 * q + 4 * half) = make_float4(u[0], u[1], u[2], u[3]);
+                }
             }
             if (residual && e + 2 < ncol) load_centres(e + 2, cen[e & 1]);     // in flight under the next tiles' transposes and stores
+            if (g.dmajor) continue;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // wave-private tile: program order within the wave is enough
             __builtin_amdgcn_wave_barrier();
             if (do_store) {
@@ -316,8 +328,20 @@ extern "C" int lpm_vlad_clip_slabs(int D, int K) {
 // K2 for the lazily normalised k-major descriptor (as lpm_vlad_aggregate_raw_kmajor_fwd), clip-wide items: raw_kmajor [B, K, D]
 // un-normalised residual sums, asum [B, K], colsq_part [B, P, K] with P = lpm_vlad_clip_slabs(D, K); lpm_vlad_row_scales(colsq_part, P, ...)
 // follows.  at / xt: lpm_assign_tiles / frame tiles (split-bf16).
+static int vlad_clip_impl(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags, float* raw_kmajor,
+                          float* asum, float* colsq_part, int dmajor, lpm_stream_t stream);
 extern "C" int lpm_vlad_aggregate_clip_kmajor_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,
                                                   int flags, float* raw_kmajor, float* asum, float* colsq_part, lpm_stream_t stream) {
+    return vlad_clip_impl(at, xt, centres, B, T, D, K, flags, raw_kmajor, asum, colsq_part, 0, stream);
+}
+// ... the same kernel leaving the un-normalised sums d-major [B, D, K] (the reference's own layout, frame_level_models.py:2817-2821:
+// NetVladV2's lazily normalised descriptor; what lpm_vlad_aggregate_tiles3_fwd writes with LPM_VLAD_RESIDUAL only)
+extern "C" int lpm_vlad_aggregate_clip_dmajor_fwd(const void* at, const void* xt, const float* centres, int B, int T, int D, int K,
+                                                  int flags, float* raw_dmajor, float* asum, float* colsq_part, lpm_stream_t stream) {
+    return vlad_clip_impl(at, xt, centres, B, T, D, K, flags, raw_dmajor, asum, colsq_part, 1, stream);
+}
+static int vlad_clip_impl(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags, float* raw_kmajor,
+                          float* asum, float* colsq_part, int dmajor, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(at && xt && raw_kmajor && asum && colsq_part, LPM_ERR_BADARG, "lpm_vlad_aggregate_clip_kmajor_fwd: null pointer");
     const int residual = (flags & LPM_VLAD_RESIDUAL) ? 1 : 0;
@@ -330,7 +354,7 @@ extern "C" int lpm_vlad_aggregate_clip_kmajor_fwd(const void* at, const void* xt
     VCArgs g{};
     g.at = (const uint4*)at; g.xt = (const uint4*)xt; g.centres = centres;
     g.T = T; g.D = D; g.S = (T + 15) / 16; g.P = P; g.residual = residual;
-    g.out = raw_kmajor; g.asum = asum; g.colsq_part = colsq_part;
+    g.out = raw_kmajor; g.asum = asum; g.colsq_part = colsq_part; g.dmajor = dmajor;
     static const int dbg = [] { const char* e = getenv("LPM_VC_DBG"); return e ? atoi(e) : 0; }();
     g.dbg = dbg;
     static const int ns = [] { const char* e = getenv("LPM_VC_NS"); return (e && e[0] == '3') ? 3 : 4; }();

@@ -1103,11 +1103,18 @@ class _VladAggregate(torch.autograd.Function):
             raw = _empty((B, D * K), x)
             asum, colsq, csq, rs = (_empty((B, K), x) for _ in range(4))
             gsq = _empty((B,), x)
-            P = D // 128
+            # K = 256: the clip-wide items of vlad_clip.hip (frame tiles once per clip), leaving the sums d-major straight from the
+            # accumulators; otherwise the 128 x 128 form
+            Pc = lib._lpm_vlad_clip_slabs(D, K) if VLAD_CLIP else 0
+            P = Pc if Pc else D // 128
             part = _empty((B, P, K), x)
             with _timed("vlad_aggregate_fwd", (B, T, D, K)):
-                lib.check(lib._lpm_vlad_aggregate_tiles3_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(raw), ptr(asum), ptr(part), st),
-                          "lpm_vlad_aggregate_tiles3_fwd")
+                if Pc:
+                    lib.check(lib._lpm_vlad_aggregate_clip_dmajor_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(raw), ptr(asum),
+                                                                      ptr(part), st), "lpm_vlad_aggregate_clip_dmajor_fwd")
+                else:
+                    lib.check(lib._lpm_vlad_aggregate_tiles3_fwd(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(raw), ptr(asum),
+                                                                 ptr(part), st), "lpm_vlad_aggregate_tiles3_fwd")
             with _timed("vlad_finalize", (B, D, K)):
                 lib.check(lib._lpm_vlad_row_scales(ptr(part), P, B, K, ptr(rs), ptr(colsq), ptr(csq), ptr(gsq), st), "lpm_vlad_row_scales")
             ctx.dims = (B, T, D, K, flags, kmajor, sims.shape)

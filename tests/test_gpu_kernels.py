@@ -1139,12 +1139,13 @@ def test_projection_parts_bf16_sums_behind_a_handle():
     assert_close(W.grad, x64.t() @ dy64, 2e-5, "dW")
 
 
-def test_vlad_aggregate_lazy_matches_the_finalize_form():
+@pytest.mark.parametrize("B,T,D,K", [(3, 70, 256, 128), (3, 70, 256, 256), (2, 300, 1024, 256)])
+def test_vlad_aggregate_lazy_matches_the_finalize_form(B, T, D, K):
     """NetVladAttenCluster's tail (video_pooling_modules.py:1641-1658) as the lazily normalised d-major descriptor: the un-normalised sums
-    x the row scales ARE the finalize form's descriptor, and the gradients of both forms agree (K3 is the same code)."""
+    x the row scales ARE the finalize form's descriptor, and the gradients of both forms agree (K3 is the same code).  K = 256 takes the
+    clip-wide K2 with d-major stores (one and three column slabs per clip), K = 128 the 128 x 128 form."""
     from learnablepoolingmethods_amd import ops
     dev = cuda()
-    B, T, D, K = 3, 70, 256, 128
     assert ops.vlad_aggregate_lazy_ok(T, D, K)
     g = torch.Generator().manual_seed(11)
     sims, x, C = torch.randn(B, T, K, generator=g), torch.randn(B * T, D, generator=g), torch.randn(D, K, generator=g) / D ** .5
@@ -1158,8 +1159,10 @@ def test_vlad_aggregate_lazy_matches_the_finalize_form():
             out = ops.materialise(out)
         out.backward(dout)
         res.append((out.detach(), sg.grad, xg.grad, cg.grad))
+    # (K = 256: two different K2 kernels -- another summation order of the un-normalised sums, which the normalisations' Jacobian amplifies in
+    # the gradients exactly as between the k-major forms; K = 128: the same kernel both times)
     for a, b, what in zip(res[1], res[0], ("descriptor", "dsims", "dx", "dcentres")):
-        assert_close(a, b, 2e-6, what)
+        assert_close(a, b, 2e-6 if K != 256 else (5e-6 if what == "descriptor" else 2e-3), what)
     sd, xd, Cd = (t.double().requires_grad_(True) for t in (sims, x, C))
     ref = O.vlad_aggregate(sd, xd.reshape(B, T, D), Cd)
     assert_close(res[1][0], ref, 1e-4, "descriptor vs the oracle")

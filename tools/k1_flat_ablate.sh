@@ -1,16 +1,16 @@
-# LPM_K1_DBG ablations of the flat K1 (assign_flat.hip) at cfg-2's shape: kernel durations from rocprofv3 --kernel-trace --stats
-# 0 whole; 1 prologue + epilogue; 2 no stores; 4 no loads in the loop; 8 no MFMAs; 16 no fragment reads; combinations.
-# usage: k1_flat_ablate.sh "<steps per barrier ...>" "<dbg values ...>"
+# The flat K1 (assign_flat.hip) at cfg-2's shape under rocprofv3 --kernel-trace --stats: kernel durations for the A/B switches
+# LPM_K1_KB (reduction steps per barrier: 1, 2, 4) and LPM_K1_DB (steps of B fragments in flight: 4, or 8 with KB = 4), and against the
+# 128-row tile-GEMM form (LPM_K1_FLAT=0).  (The ablation switches the DESIGN.md numbers come from -- no main loop / no stores / no loads /
+# no MFMAs / no fragment reads -- were compiled in for the measurement and removed again; every run below has its own time limit.)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/k1_flat_ablate.txt
 : > $out
-for kb in ${1:-2}; do
-for dbg in ${2:-0 1 3 2 4 8 16 12 20 24 28 30}; do
-  rm -rf /tmp/kfa_$dbg
-  LPM_K1_KB=$kb LPM_K1_DBG=$dbg rocprofv3 --kernel-trace --stats -d /tmp/kfa_$dbg -o out --output-format csv -- python3 $R/tools/k1_fwd_loop.py 40 > /tmp/kfa.log 2>&1
-  f=$(find /tmp/kfa_$dbg -name '*kernel_stats.csv' | head -1)
-  echo "kb=$kb dbg=$dbg $(grep assign_flat $f | cut -d, -f1-7 | cut -c1-200) $(grep 'err vs' /tmp/kfa.log | sed 's/.*err/err/')" >> $out
-done
+for cfg in "1 2 4" "1 1 4" "1 4 4" "1 4 8" "0 2 4"; do
+  set -- $cfg
+  rm -rf /tmp/kfa
+  LPM_K1_FLAT=$1 LPM_K1_KB=$2 LPM_K1_DB=$3 timeout 90 rocprofv3 --kernel-trace --stats -d /tmp/kfa -o out --output-format csv -- python3 $R/tools/k1_fwd_loop.py 40 > /tmp/kfa.log 2>&1
+  f=$(find /tmp/kfa -name '*kernel_stats.csv' | head -1)
+  echo "flat=$1 kb=$2 db=$3 $(grep 'assign_flat\|tile_gemm_kernel' $f | cut -d, -f1-7 | cut -c1-200) $(grep 'err vs' /tmp/kfa.log | sed 's/.*err/err/')" >> $out
 done
 cat $out
