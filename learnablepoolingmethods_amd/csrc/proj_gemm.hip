@@ -25,6 +25,9 @@ constexpr int PJ_WBYTES = 16 * 512 * 4;            // W slab
 #define LPM_PJ_AUX 2                                // (a variant build with 0 = the default policy: tools/build_proj_policy_variant.sh, A/B)
 #endif
 constexpr int PJ_AUX = LPM_PJ_AUX;
+#ifndef LPM_PJ_SC_ONE_LOADER_MAX
+#define LPM_PJ_SC_ONE_LOADER_MAX 4                  // pieces per pair up to which ONE wave loads the scaled x (beyond: two waves, half the pieces each)
+#endif
 #ifndef LPM_PJ_SC_SPLIT
 #define LPM_PJ_SC_SPLIT 0
 #endif
@@ -60,7 +63,7 @@ struct ProjParts {
 };
 // (SC with more than 10 pieces per pair: TWO loader waves, half the pieces each -- sixteen pieces' data and scales do not fit one wave's
 // registers beside what the computing path sets the kernel's allocation to)
-__host__ __device__ constexpr int pj_loaders(int NP, int SC) { return (SC != 0 && NP > 10) ? 2 : 1; }
+__host__ __device__ constexpr int pj_loaders(int NP, int SC) { return (SC != 0 && NP > LPM_PJ_SC_ONE_LOADER_MAX) ? 2 : 1; }
 template <int MT, int NP, int XD, int SC = 0>
 __global__ __launch_bounds__(512 + 64 * pj_loaders(NP, SC), 1) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M, int64_t Kd,
                                                           int N, int nslab, int splits, float* __restrict__ part, const ProjParts pp) {
