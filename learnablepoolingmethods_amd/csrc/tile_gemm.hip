@@ -857,6 +857,63 @@ __global__ __launch_bounds__(256) void split_weight_tiles_parts_kernel(const flo
     }
 }
 
+// ... four adjacent columns per thread (n1a, N multiples of 4; 16-byte aligned rows): a row of the block is one 8- / 16-byte load per thread
+// instead of four 2- / 4-byte ones, the scales one float4; the thread writes its four lanes' planes as 64 contiguous bytes each
+// (cfg-5, bf16 sums: 138 us for 134 MB in + 277 MB out with the one-column form)
+__global__ __launch_bounds__(256) void split_weight_tiles_parts4_kernel(const float* __restrict__ x1, int64_t ld1, int64_t n1a, int x1_bf16,
+                                                                        const float* __restrict__ scale, int ks, const float* __restrict__ x2,
+                                                                        int64_t ld2, int R, int64_t N, uint4* __restrict__ wt) {
+    const int RS = R / 16;
+    const int64_t NT = (N + 31) / 32;
+    const int64_t total = (int64_t)RS * NT * 16;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
+        const int q = (int)(w & 15);
+        const int64_t t = w >> 4;
+        const int64_t nt = t % NT;
+        const int rs = (int)(t / NT);
+        const int cg = q & 7, half = q >> 3;
+        const int64_t col = nt * 32 + cg * 4;
+        const int r = rs * 16 + 8 * half;
+        float v[4][8];
+        if (col < n1a) {
+            const int kc = (int)(col % ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float xv[4];
+                if (x1_bf16) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x1) + (int64_t)(r + e) * ld1 + col);
+                    xv[0] = __uint_as_float(u.x << 16); xv[1] = __uint_as_float(u.x & 0xffff0000u);
+                    xv[2] = __uint_as_float(u.y << 16); xv[3] = __uint_as_float(u.y & 0xffff0000u);
+                } else {
+                    const float4 f = *reinterpret_cast<const float4*>(x1 + (int64_t)(r + e) * ld1 + col);
+                    xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w;
+                }
+                const float4 sc = *reinterpret_cast<const float4*>(scale + (int64_t)(r + e) * ks + kc);
+                v[0][e] = xv[0] * sc.x; v[1][e] = xv[1] * sc.y; v[2][e] = xv[2] * sc.z; v[3][e] = xv[3] * sc.w;
+            }
+        } else if (col < N) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 f = *reinterpret_cast<const float4*>(x2 + (int64_t)(r + e) * ld2 + (col - n1a));
+                v[0][e] = f.x; v[1][e] = f.y; v[2][e] = f.z; v[3][e] = f.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+        }
+        const int64_t base = t * 128 + half * 32 + cg * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 hi, lo;
+            tg_split8(v[j], hi, lo);
+            wt[base + j] = hi;
+            wt[base + 64 + j] = lo;
+        }
+    }
+}
+
 // out[i] = sum_z part[z][i]   (float4 granularity)
 __global__ __launch_bounds__(256) void tg_reduce_splits_kernel(const float4* __restrict__ part, int Z, int64_t n4,
                                                                float4* __restrict__ out) {
@@ -996,6 +1053,16 @@ extern "C" int lpm_split_weight_tiles_parts(const void* x1, int64_t ld1, int64_t
                 "lpm_split_weight_tiles_parts: need R %% 16 == 0, the scaled block a multiple of 32 columns and of ks (R=%d n1a=%lld ks=%d)", R,
                 (long long)n1a, ks);
     const int64_t total = (int64_t)(R / 16) * ((N + 31) / 32) * 64;
+    // four columns per thread where every row piece is an aligned vector (LPM_SWT_PARTS4=0: the one-column form, A/B)
+    static const int four = [] { const char* e = getenv("LPM_SWT_PARTS4"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool al1 = ld1 % 4 == 0 && ((uintptr_t)x1 & (x1_bf16 ? 7 : 15)) == 0 && ks % 4 == 0 && ((uintptr_t)scale & 15) == 0;
+    const bool al2 = n1a == N || (ld2 % 4 == 0 && ((uintptr_t)x2 & 15) == 0);
+    if (four && n1a % 4 == 0 && N % 4 == 0 && al1 && al2) {
+        const int64_t want4 = (total / 4 + 255) / 256;
+        hipLaunchKernelGGL(split_weight_tiles_parts4_kernel, dim3((unsigned)(want4 < 65536 ? want4 : 65536)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x1, ld1, n1a, x1_bf16 ? 1 : 0, scale, ks, x2, ld2, R, N, (uint4*)wt);
+        return check_launch("lpm_split_weight_tiles_parts");
+    }
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(split_weight_tiles_parts_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)x1, ld1, n1a, x1_bf16 ? 1 : 0, scale, ks, x2, ld2, R, N, (uint4*)wt);
