@@ -582,8 +582,17 @@ __global__ __launch_bounds__(256) void vlad_fused_fixup_kernel(const float* __re
     const int tid = threadIdx.x;
     float g = 0.f;
     for (int k = tid; k < K; k += 256) {
+        // (the P partial norms are requested together, eight at a time, and added in slab order: the kernel is one dependent chain of
+        // load -> reduce -> rsqrt -> store per clip, 9 us at P = 8 when every load waited for the previous add)
         float n = 0.f;
-        for (int p = 0; p < P; ++p) n += colsq_part[((int64_t)b * P + p) * K + k];
+        const float* src = colsq_part + (int64_t)b * P * K + k;
+        for (int p0 = 0; p0 < P; p0 += 8) {
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = (p0 + u < P) ? src[(int64_t)(p0 + u) * K] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) n += pv[u];
+        }
         const float iv = rsqrtf(fmaxf(n, kL2Eps));
         const float c = n * iv * iv;
         invn[k] = iv;
