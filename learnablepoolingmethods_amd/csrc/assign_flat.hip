@@ -72,7 +72,7 @@ __device__ __forceinline__ void af_wait_vm(int n) {          // n folds to a con
 }
 #undef AF_WAIT_CASE
 
-template <int KB, int DB>
+template <int KB, int DB, bool AF_LUMP>
 __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArgs a) {
     constexpr int NS = af_ns(KB), TAIL = af_tail(KB, DB), STAGE = KB * AF_KSTEP;
     static_assert((NS - 2) * KB >= DB && TAIL % DB == 0 && TAIL % KB == 0 && TAIL >= (NS - 1) * KB && (DB == 4 || DB == 8),
@@ -159,21 +159,52 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
             __builtin_amdgcn_s_barrier();                          // the next stage is in LDS for everyone; the previous one has been read
             asm volatile("" ::: "memory");
         }
-#pragma unroll
-        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].h[m], bh[j], acc[m]);
+        // ONE non-MFMA operation between consecutive MFMAs: the two waves of a SIMD leave the barrier together and run the same
+        // instruction stream in phase, so a LUMP of seven LDS operations behind the first MFMA group (the first form of this loop) is a
+        // lump for both -- the matrix pipe idles for its length, 15 % of the step.  A single read in front of an MFMA is covered by the
+        // neighbour's MFMA (AF_LUMP, LPM_K1_LUMP=1: the first form, A/B).
+        acc[0] = tg_mfma(fa[ab].h[0], bh[j], acc[0]);
         __builtin_amdgcn_sched_barrier(0);
         if (e == 0 && loader && (i + (NS - 1) * KB < TAIL))
             issue_a(s / KB + NS - 1, slot == 0 ? NS - 1 : slot - 1);       // into the slot of the stage before this one
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1] = tg_mfma(fa[ab].h[1], bh[j], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[2] = tg_mfma(fa[ab].h[2], bh[j], acc[2]);
+        __builtin_amdgcn_sched_barrier(0);
         const int slot1 = slot + 1 == NS ? 0 : slot + 1;
-        if (i + 1 < TAIL) read_frags((unsigned)((e + 1 == KB ? slot1 : slot) * STAGE + (e + 1 == KB ? 0 : e + 1) * AF_KSTEP), fa[ab ^ 1]);
+        const bool rd = i + 1 < TAIL;
+        const unsigned ad = rd_lane + (unsigned)((e + 1 == KB ? slot1 : slot) * STAGE + (e + 1 == KB ? 0 : e + 1) * AF_KSTEP);
+        Frag& fn = fa[ab ^ 1];
         if (e + 1 == KB) slot = slot1;
+#define AF_RD(REG, OFF) if (rd) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(REG) : "v"(ad), "n"(OFF) : "memory")
+        if (AF_LUMP) { AF_RD(fn.h[0], 0); AF_RD(fn.l[0], 1024); AF_RD(fn.h[1], 2048); AF_RD(fn.l[1], 3072); AF_RD(fn.h[2], 4096); AF_RD(fn.l[2], 5120); }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].h[m], bl[j], acc[m]);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) acc[m] = tg_mfma(fa[ab].l[m], bh[j], acc[m]);
+        // (the three products that read the hi plane of B first: its registers are free for the load of step s + DB three MFMAs earlier)
+        if (!AF_LUMP) AF_RD(fn.h[0], 0);
+        acc[0] = tg_mfma(fa[ab].l[0], bh[j], acc[0]);
         __builtin_amdgcn_sched_barrier(0);
-        if (i + DB < TAIL) issue_b(s + DB, bh[j], bl[j]);
+        if (!AF_LUMP) AF_RD(fn.l[0], 1024);
+        acc[1] = tg_mfma(fa[ab].l[1], bh[j], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!AF_LUMP) AF_RD(fn.h[1], 2048);
+        acc[2] = tg_mfma(fa[ab].l[2], bh[j], acc[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more_b = i + DB < TAIL;
+        const uint4* pb = bbase + (int64_t)(s + DB) * bstep;
+        if (!AF_LUMP && more_b) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bh[j]) : "v"(boff), "s"(pb) : "memory");
+        if (!AF_LUMP) AF_RD(fn.l[1], 3072);
+        acc[0] = tg_mfma(fa[ab].h[0], bl[j], acc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!AF_LUMP) AF_RD(fn.h[2], 4096);
+        acc[1] = tg_mfma(fa[ab].h[1], bl[j], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!AF_LUMP) AF_RD(fn.l[2], 5120);
+        acc[2] = tg_mfma(fa[ab].h[2], bl[j], acc[2]);
+        __builtin_amdgcn_sched_barrier(0);
+#undef AF_RD
+        if (!AF_LUMP && more_b) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(bl[j]) : "v"(boff), "s"(pb) : "memory");
+        if (AF_LUMP && more_b) issue_b(s + DB, bh[j], bl[j]);
     };
     const int nmain = nstep - TAIL;
     for (int s0 = 0; s0 < nmain; s0 += DB) {
@@ -249,15 +280,17 @@ int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int
     const size_t lds = (size_t)af_ns(kb) * kb * AF_KSTEP;
     hipEvent_t e0, e1;
     const bool timed = timing_tag && timing_request(timing_tag, &e0, &e1);
-#define AF_LAUNCH(KB, DB)                                                                                   \
+#define AF_LAUNCH(KB, DB, LUMP)                                                                             \
     do {                                                                                                    \
-        if (timed) hipExtLaunchKernelGGL((assign_flat_kernel<KB, DB>), grid, dim3(512), lds, stream, e0, e1, 0, a); \
-        else hipLaunchKernelGGL((assign_flat_kernel<KB, DB>), grid, dim3(512), lds, stream, a);            \
+        if (timed) hipExtLaunchKernelGGL((assign_flat_kernel<KB, DB, LUMP>), grid, dim3(512), lds, stream, e0, e1, 0, a); \
+        else hipLaunchKernelGGL((assign_flat_kernel<KB, DB, LUMP>), grid, dim3(512), lds, stream, a);      \
     } while (0)
-    if (kb == 1) AF_LAUNCH(1, 4);
-    else if (kb == 2) AF_LAUNCH(2, 4);
-    else if (db == 8) AF_LAUNCH(4, 8);
-    else AF_LAUNCH(4, 4);
+    static const int lump = [] { const char* e = getenv("LPM_K1_LUMP"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (lump && kb == 2) AF_LAUNCH(2, 4, true);
+    else if (kb == 1) AF_LAUNCH(1, 4, false);
+    else if (kb == 2) AF_LAUNCH(2, 4, false);
+    else if (db == 8) AF_LAUNCH(4, 8, false);
+    else AF_LAUNCH(4, 4, false);
 #undef AF_LAUNCH
     return check_launch(what);
 }

@@ -40,7 +40,9 @@ FLAGS.define("netvlad_storage", "f32", "build extension: 'bf16' = the frames, lo
              "netvlad_encoder off, batch norm on, cluster_size a multiple of 512")
 FLAGS.define("netvlad_lazy_descriptor", True, "build extension: NetVladV1's video pooling hands its cluster encoder the un-normalised "
              "residual sums [B, K, D] plus one scale per (clip, cluster); the encoder's block Functions apply the scale where they read "
-             "the rows -- the pooled tensor is written once, there is no finalize pass and no transpose in the pooling backward")
+             "the rows -- the pooled tensor is written once, there is no finalize pass and no transpose in the pooling backward.  "
+             "NetVladV2 and the model without cluster encoders (bf16 storage) hand the same form, d-major, to the hidden projection "
+             "(ops.projection_parts: the scale applied where the operand is read, no concat)")
 FLAGS.define("fused_encoder_blocks", True, "build extension: run the V1 cluster encoder as two block Functions whose backward "
              "folds the gradient sums of shared tensors into GEMM accumulation / the layer-norm kernel (no add passes)")
 FLAGS.define("descriptor_slots", True, "build extension: both encoders write their pooled descriptor into one shared buffer "

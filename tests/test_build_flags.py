@@ -115,7 +115,7 @@ def test_flat_k1_loop_keeps_loads_in_flight_and_copies_no_registers():
         r = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         asm = open(out).read()
-    kernels = re.findall(r"^(_ZN3lpm18assign_flat_kernelILi\dELi\dEEEvNS_14AssignFlatArgsE):", asm, flags=re.M)
+    kernels = re.findall(r"^(_ZN3lpm18assign_flat_kernelILi\dELi\dELb\dEEEvNS_14AssignFlatArgsE):", asm, flags=re.M)
     assert len(kernels) >= 3, kernels
     for mangled in kernels:
         body = asm[asm.index(mangled + ":"):]
