@@ -111,6 +111,30 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// ---- wave-wide maximum / sum on the VALU (round 4; the softmax of lpm_assign_tiles and of the in-kernel-softmax K2's row statistics -- the two
+// must add in the SAME order: tests hold them bitwise equal): four DPP steps give every lane its row-of-16 total (quad permutes, half-row mirror, row
+// mirror), four v_readlane + three operations join the rows.  __shfl_xor is ds_bpermute on this target: the softmax's two butterflies
+// were 48 dependent LDS-crossbar round trips per wave (four rows x two reductions x six steps) in a kernel whose rate is its latency.
+template <int CTRL>
+__device__ __forceinline__ float dpp_lanes(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_lanes<0xB1>(v));
+    v = fmaxf(v, dpp_lanes<0x4E>(v));
+    v = fmaxf(v, dpp_lanes<0x141>(v));
+    v = fmaxf(v, dpp_lanes<0x140>(v));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_lanes<0xB1>(v);
+    v += dpp_lanes<0x4E>(v);
+    v += dpp_lanes<0x141>(v);
+    v += dpp_lanes<0x140>(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
 // reduce across the 32 lanes that share (lane >> 5): lanes of one half-wave
 __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll

@@ -155,29 +155,6 @@ __global__ __launch_bounds__(256) void assign_tiles_kernel(const float* __restri
 // reduced and exponentiated together -- 4 x the loads in flight and a quarter of the dependent wave-reduction chains of the
 // row-at-a-time form above (cfg-2 video 17.8 -> see DESIGN; cfg-5 video, K = 512: 52.7 us before).  LDS tile [16][K + 4] (rows
 // 16-byte aligned for the lane's vector store; the column-wise reads of the tile emission hit bank 4 r + i: conflict-free).
-// Wave-wide maximum / sum on the VALU (round 4): four DPP steps give every lane its row-of-16 total (quad permutes, half-row mirror, row
-// mirror), four v_readlane + three operations join the rows.  __shfl_xor is ds_bpermute on this target: the softmax's two butterflies
-// were 48 dependent LDS-crossbar round trips per wave (four rows x two reductions x six steps) in a kernel whose rate is its latency.
-template <int CTRL>
-__device__ __forceinline__ float at_dpp(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float at_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ float at_wave_max(float v) {
-    v = fmaxf(v, at_dpp<0xB1>(v));
-    v = fmaxf(v, at_dpp<0x4E>(v));
-    v = fmaxf(v, at_dpp<0x141>(v));
-    v = fmaxf(v, at_dpp<0x140>(v));
-    return fmaxf(fmaxf(at_lane(v, 0), at_lane(v, 16)), fmaxf(at_lane(v, 32), at_lane(v, 48)));
-}
-__device__ __forceinline__ float at_wave_sum(float v) {
-    v += at_dpp<0xB1>(v);
-    v += at_dpp<0x4E>(v);
-    v += at_dpp<0x141>(v);
-    v += at_dpp<0x140>(v);
-    return (at_lane(v, 0) + at_lane(v, 16)) + (at_lane(v, 32) + at_lane(v, 48));
-}
-
 template <bool SOFTMAX, bool BF16IN, int VPL>
 __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restrict__ assign, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int T, int S, uint4* __restrict__ at) {
@@ -247,7 +224,7 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
             }
         }
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) m[rr] = at_wave_max(m[rr]);
+        for (int rr = 0; rr < 4; ++rr) m[rr] = wave_max_dpp(m[rr]);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             sum[rr] = 0.f;
@@ -258,7 +235,7 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
             }
         }
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) sum[rr] = at_wave_sum(sum[rr]);
+        for (int rr = 0; rr < 4; ++rr) sum[rr] = wave_sum_dpp(sum[rr]);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const bool live = 16 * s + wave * 4 + rr < T;

@@ -118,9 +118,7 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restr
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) m[rr] = fmaxf(m[rr], __shfl_xor(m[rr], o, 64));
+    for (int rr = 0; rr < 4; ++rr) m[rr] = wave_max_dpp(m[rr]);          // (the reductions of assign_tiles2_kernel, in its order)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         sum[rr] = 0.f;
@@ -128,9 +126,7 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restr
         for (int j = 0; j < VPL; ++j) sum[rr] += __expf(v[rr][j] - m[rr]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) sum[rr] += __shfl_xor(sum[rr], o, 64);
+    for (int rr = 0; rr < 4; ++rr) sum[rr] = wave_sum_dpp(sum[rr]);
     if (lane < 4) {
         const int t = 16 * s + wave * 4 + lane;
         float mm = 0.f, inv = 0.f;
