@@ -129,6 +129,28 @@ def test_flat_k1_loop_keeps_loads_in_flight_and_copies_no_registers():
         loop = [l for l in lines[head[0]:back[-1] + 1] if not l.strip().startswith(";")]
         n = sum("v_mfma_f32_32x32x16_bf16" in l for l in loop)
         assert n in (36, 72), f"{mangled}: expected the 9 MFMAs of each of the 4 or 8 unrolled steps in the loop, found {n}"
-        bad = [l.strip() for l in loop if re.search(r"\b(v_mov_b64|v_accvgpr_(read|write)\w*|scratch_(load|store)\w*)\b", l)]
+        bad = [l.strip() for l in loop if re.search(r"\b(v_mov_b(32|64)|v_accvgpr_(read|write)\w*|scratch_(load|store)\w*)\b", l)]
         assert not bad, f"{mangled}: register copies / scratch traffic inside the main loop: {bad[:6]}"
+        # ... and nowhere between the first asynchronous load and the last MFMA (prologue, loop, peeled tail) may a register that such a
+        # load writes be the SOURCE of a copy: the copy would not wait for the load
+        def regs(tok):
+            m = re.match(r"v\[(\d+):(\d+)\]", tok)
+            if m:
+                return set(range(int(m.group(1)), int(m.group(2)) + 1))
+            m = re.match(r"v(\d+)", tok)
+            return {int(m.group(1))} if m else set()
+        first = min(i for i, l in enumerate(lines) if re.match(r"\s*(global_load_dwordx4|ds_read_b128|global_load_lds)", l))
+        last = max(i for i, l in enumerate(lines) if "v_mfma" in l)
+        asyncdst = set()
+        for l in lines[first:last + 1]:
+            m = re.match(r"\s*(global_load_dwordx4|ds_read_b128)\s+(v\[\d+:\d+\])", l)
+            if m:
+                asyncdst |= regs(m.group(2))
+        assert len(asyncdst) >= 64, f"{mangled}: the scan found only {len(asyncdst)} registers written by asynchronous loads"
+        copies = []
+        for l in lines[first:last + 1]:
+            m = re.match(r"\s*v_mov_b(32|64)\w*\s+(\S+),\s*(\S+)", l)
+            if m and (regs(m.group(3)) & asyncdst):
+                copies.append(l.strip())
+        assert not copies, f"{mangled}: copies of registers that asynchronous loads write: {copies[:6]}"
 
