@@ -481,6 +481,74 @@ int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w3k, lpm_str
  * transformer_utils.py:559-561,583,701-711).  N / nouts a multiple of 4; unused destinations NULL. */
 int lpm_sum_splits(const float* part, int Z, int K, int N, float* out0, float* out1, float* out2, int nouts, lpm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Round 5: the operand FORMAT of the dense GEMMs' 16-bit images and fragment tiles (csrc/operand_format.h).
+ *   LPM_OPERAND_BF16X3: x = xh + xl as bf16 planes, three products per a . b (~5e-6 per GEMM) -- every entry point above, and what a
+ *                       NULL format means below.
+ *   LPM_OPERAND_FP16X2: the data operand (activations, gradients) as fp16 (hi, lo) planes, the weight operand rounded once to fp16:
+ *                       TWO products per a . b (~1.4e-4 per GEMM: the weight's 2^-12 rounding).  Image rows are [hi | lo] (2K
+ *                       16-bit words) for activations and gradients alike; weight images [Wh | Wh]; fragment tiles carry (hi, lo)
+ *                       planes for the data operand and the hi plane only for the weight operand.  Every value is multiplied by
+ *                       `scale` (a power of two chosen by the caller so that the tensor sits inside fp16's range; values beyond it
+ *                       saturate at +-65504) before it is split; the consumer of the GEMM multiplies by 1 / scale.
+ * amax (optional, either kind): the producer records max |x| of what it wrote, BEFORE scaling, by an atomic max on *amax (a device
+ * float the caller zeroes) -- the measurement a delayed scale is chosen from (ops.OperandScales).
+ * NetVladV1's encoder GEMMs (transformer_utils.py:559-561,583,701-711 and TF autodiff of them) run on LPM_OPERAND_FP16X2 when the
+ * trainer's scales are calibrated; NetVladV2 stays on LPM_OPERAND_BF16X3 (its logits batch norm amplifies forward errors ~500 x).
+ * ------------------------------------------------------------------------------------------- */
+enum { LPM_OPERAND_BF16X3 = 0, LPM_OPERAND_FP16X2 = 1 };
+typedef struct LpmOperandFormat {
+    int kind;       /* LPM_OPERAND_* */
+    float scale;    /* > 0, a power of two; 1 for LPM_OPERAND_BF16X3 */
+    float* amax;    /* device, may be NULL */
+} LpmOperandFormat;
+/* lpm_split_rows / lpm_split_rows_scaled in either format: x [M,K] (row stride ldx), optionally * row_scale[m], + bias, ReLU ->
+ * image [M, planes K] (bf16x3: `order` 0 = [hi|lo|hi], 1 = [hi|hi|lo]; fp16x2: [hi|lo]). */
+int lpm_split_rows_fmt(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, int order, const float* row_scale,
+                       void* out, const LpmOperandFormat* fmt, lpm_stream_t stream);
+/* lpm_split_rows_relu_bwd in either format: g = alpha * df * [act > 0] (alpha = 1 / the scale of the GEMM operand df came from), the
+ * mask from the hi plane of the forward's activation image in format act_kind, dbias = column sums of g (un-scaled). */
+int lpm_split_rows_relu_bwd_fmt(const float* df, int64_t M, int K, float alpha, const void* act_img, int act_kind, void* out_img, float* dbias,
+                                void* workspace, size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream);
+/* lpm_split_weight in either format.  fp16x2: wn [N, 2K] rows [Wh^T | Wh^T], wk [K, 2N] rows [Wh | Wh] (wk may be NULL). */
+int lpm_split_weight_fmt(const float* W, int K, int N, void* wn, void* wk, int kind, lpm_stream_t stream);
+/* lpm_split_weight_tiles in either format.  fp16x2: the hi plane only, lpm_weight_tiles_bytes(R, N) / 2 bytes. */
+int lpm_split_weight_tiles_fmt(const float* w, int R, int N, int transposed, void* wt, int kind, lpm_stream_t stream);
+/* lpm_split_rows_tiles / lpm_image_row_tiles in either format (fp16x2 row tiles: fp16 (hi, lo) planes, same geometry). */
+int lpm_split_rows_tiles_fmt(const float* x, int64_t ldx, int B, int T, int C, void* out, const LpmOperandFormat* fmt, lpm_stream_t stream);
+int lpm_image_row_tiles_fmt(const void* img, int M, int K, int order, void* out, int kind, lpm_stream_t stream);
+/* lpm_dense_tiles_act_image_fwd / lpm_dense_tiles_relu_bwd_image in either format.  in_inv_scale: 1 / the scale the row tiles of the
+ * data operand were written with (the accumulators are multiplied by it); `fmt`: the format of the image that leaves (and, for the
+ * backward, `act_kind`: the format of the forward's activation image whose hi plane is the ReLU mask).  dbias: column sums of the
+ * UN-scaled masked gradient. */
+int lpm_dense_tiles_act_image_fwd_fmt(const void* xr, const void* wt, const float* bias, int M, int Kd, int N, float in_inv_scale,
+                                      void* out_img, const LpmOperandFormat* fmt, lpm_stream_t stream);
+int lpm_dense_tiles_relu_bwd_image_fmt(const void* dyr, const void* wtt, const void* act_img, int act_kind, int M, int Kd, int N,
+                                       float in_inv_scale, void* out_img, float* dbias, void* workspace, size_t workspace_bytes,
+                                       const LpmOperandFormat* fmt, lpm_stream_t stream);
+/* lpm_layer_norm_act_image_fwd / lpm_layer_norm_act_bwd with the image (y_img / da_image) in either format. */
+int lpm_layer_norm_act_image_fwd_fmt(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,
+                                     const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, void* y_img,
+                                     float* z, float* stats, void* workspace, size_t workspace_bytes, const LpmOperandFormat* fmt,
+                                     lpm_stream_t stream);
+int lpm_layer_norm_act_bwd_fmt(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats, const float* gamma,
+                               const float* a, const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
+                               float* dbeta, float* dbias, const float* dr_extra, void* da_image, void* workspace, size_t workspace_bytes,
+                               const LpmOperandFormat* fmt, lpm_stream_t stream);
+/* lpm_mha_fwd_x3_image / lpm_mha_bwd_x3_image with the images in either format: o_fmt = the format the attention result's image is
+ * written with (forward) / was written with (backward: kind and scale are read, amax ignored), g_fmt = the format of the
+ * [dq | dk | dv] gradient image (fp16x2: row = [hi(3N) | lo(3N)]). */
+int lpm_mha_fwd_x3_image_fmt(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d, float scale,
+                             void* o_img, float* lse, const LpmOperandFormat* o_fmt, lpm_stream_t stream);
+int lpm_mha_bwd_x3_image_fmt(const float* q, const float* k, const float* v, int64_t ld, const void* o_img, const LpmOperandFormat* o_fmt,
+                             const float* dout, int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, void* dqkv_img,
+                             const LpmOperandFormat* g_fmt, lpm_stream_t stream);
+/* lpm_sum_splits for the fp16x2 weight-gradient product dW = xh^T [dyh | dyl]: part [Z, K, 2 N] (the lo half's products in columns
+ * [N, 2N)), out_j[k, n] = alpha * sum_z (part[z, k, j Nj + n] + part[z, k, N + j Nj + n]), Nj = N / nouts; alpha = 1 / (the two
+ * operands' scales).  halves = 1: the plain sum times alpha. */
+int lpm_sum_splits_scaled(const float* part, int Z, int K, int N, int halves, float alpha, float* out0, float* out1, float* out2, int nouts,
+                          lpm_stream_t stream);
+
 /* Every operand form of every dense-layer weight of a step in ONE launch (weight_pack.hip, round 4): a job names a weight W [K, N]
  * (row stride ldw) -- or the column block [n_off, n_off + N) of a concatenated weight with Ntot columns (q | k | v) -- and the forms
  * wanted of it, each optional (NULL): w3n / w3k as lpm_split_weight writes them (of the concatenated weight: w3n [Ntot, 3K],
@@ -498,6 +566,8 @@ typedef struct LpmWeightPackJob {
     void* w3k;
     void* wt;
     void* wtt;
+    int kind;           /* LPM_OPERAND_*: fp16x2 writes w3n as [Ntot, 2K] = [Wh^T | Wh^T], w3k as [K, 2 Ntot] = [Wh | Wh] and the hi plane
+                           only of wt / wtt (lpm_split_weight_fmt, lpm_split_weight_tiles_fmt) */
 } LpmWeightPackJob;
 int lpm_weight_pack(const LpmWeightPackJob* jobs, int njobs, lpm_stream_t stream);
 /* backward of the fused relu(x + bias) split (FeedForwardNetwork, transformer_utils.py:701-711): g = df * [act > 0]

@@ -167,14 +167,35 @@ SIGNATURES = {
     "lpm_multi_tensor_clip_adam": (_i, [_f, _f, _f, _f, _f, _i, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _f]),
     "lpm_weight_pack": (_i, [_f, _i, _f]),
     "lpm_sum_splits": (_i, [_f, _i, _i, _i, _f, _f, _f, _i, _f]),          # (jobs: a HOST array of WeightPackJob)
+    # round 5: the entry points that take an operand format (LpmOperandFormat*: a HOST struct, NULL = split-bf16 x3)
+    "lpm_split_rows_fmt": (_i, [_f, _l, _l, _i, _f, _i, _i, _f, _f, _f, _f]),
+    "lpm_split_rows_relu_bwd_fmt": (_i, [_f, _l, _i, _fl, _f, _i, _f, _f, _f, _s, _f, _f]),
+    "lpm_split_weight_fmt": (_i, [_f, _i, _i, _f, _f, _i, _f]),
+    "lpm_split_weight_tiles_fmt": (_i, [_f, _i, _i, _i, _f, _i, _f]),
+    "lpm_split_rows_tiles_fmt": (_i, [_f, _l, _i, _i, _i, _f, _f, _f]),
+    "lpm_image_row_tiles_fmt": (_i, [_f, _i, _i, _i, _f, _i, _f]),
+    "lpm_dense_tiles_act_image_fwd_fmt": (_i, [_f, _f, _f, _i, _i, _i, _fl, _f, _f, _f]),
+    "lpm_dense_tiles_relu_bwd_image_fmt": (_i, [_f, _f, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _s, _f, _f]),
+    "lpm_layer_norm_act_image_fwd_fmt": (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _f, _s, _f, _f]),
+    "lpm_layer_norm_act_bwd_fmt": (_i, [_f, _l, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _s, _f, _f]),
+    "lpm_mha_fwd_x3_image_fmt": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _f]),
+    "lpm_mha_bwd_x3_image_fmt": (_i, [_f, _f, _f, _l, _f, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f]),
+    "lpm_sum_splits_scaled": (_i, [_f, _i, _i, _i, _i, _fl, _f, _f, _f, _i, _f]),
 }
+LPM_OPERAND_BF16X3 = 0
+LPM_OPERAND_FP16X2 = 1
+
+
+class OperandFormat(C.Structure):
+    """LpmOperandFormat of include/lpm_hip.h (a HOST struct handed over by pointer; read during the call)."""
+    _fields_ = [("kind", C.c_int), ("scale", C.c_float), ("amax", C.c_void_p)]
 WEIGHT_PACK_MAX_JOBS = 24
 
 
 class WeightPackJob(C.Structure):
     """LpmWeightPackJob of include/lpm_hip.h."""
     _fields_ = [("w", C.c_void_p), ("K", C.c_int), ("N", C.c_int), ("ldw", C.c_int), ("Ntot", C.c_int), ("n_off", C.c_int),
-                ("w3n", C.c_void_p), ("w3k", C.c_void_p), ("wt", C.c_void_p), ("wtt", C.c_void_p)]
+                ("w3n", C.c_void_p), ("w3k", C.c_void_p), ("wt", C.c_void_p), ("wtt", C.c_void_p), ("kind", C.c_int)]
 
 
 class LpmError(RuntimeError):

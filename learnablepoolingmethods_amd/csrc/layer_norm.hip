@@ -9,6 +9,7 @@
 // transformer_utils.py:583 and :708-711) ride in pass 1 of the forward; in the backward da = dz * [a + bias > 0] and
 // dbias = column sums of da come out of the apply pass -- two elementwise passes and a reduction per layer less.
 #include "lpm_common.h"
+#include "operand_format.h"
 #include <atomic>
 
 namespace lpm {
@@ -94,7 +95,8 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta, int64_t n_per, int F,
                                                            float eps, float* __restrict__ y, int64_t y_batch,
                                                            float* __restrict__ stats, const float* __restrict__ r2,
-                                                           float* __restrict__ partial_next, unsigned short* __restrict__ y3) {
+                                                           float* __restrict__ partial_next, unsigned short* __restrict__ y3,
+                                                           const OperandFmt fmt) {
     // y3 != NULL: y ALSO leaves as the split-bf16 activation image [rows][3 F] = [hi | lo | hi] of the dense layer that reads it next
     // (split_gemm.hip's format): the separate split pass over y (read 4 B, write 6 B per element) is not run
     __shared__ float sh[4];
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
     const float4* zp = reinterpret_cast<const float4*>(z + (int64_t)b * n_per);
     const float4* rp = r2 ? reinterpret_cast<const float4*>(r2 + (int64_t)b * n_per) : nullptr;
     float4* yp = reinterpret_cast<float4*>(y + (int64_t)b * y_batch);
-    float ns = 0.f, nq = 0.f;
+    float ns = 0.f, nq = 0.f, vmax = 0.f;
     for (int64_t i = (int64_t)ch * 256 + threadIdx.x; i < n4; i += (int64_t)LN_NB * 256) {      // interleaved pieces, as in pass 1
         const int c = (int)(i % F4) * 4;
         const float4 v = zp[i];
@@ -135,7 +137,13 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
             nq = fmaf(o.x, o.x, nq); nq = fmaf(o.y, o.y, nq); nq = fmaf(o.z, o.z, nq); nq = fmaf(o.w, o.w, nq);
         }
         yp[i] = o;
-        if (y3) {
+        if (y3 && fmt.f16) {       // the fp16 two-product format (operand_format.h): [hi | lo] planes of y * scale
+            vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
+            uint2 hi, lo;
+            of_split4(o.x, o.y, o.z, o.w, 1, fmt.scale, hi, lo);
+            of_store_row4(y3 + ((int64_t)b * (n_per / F) + i / F4) * 2 * F, F, c, hi, lo, 1, 0);
+        } else if (y3) {
+            vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
             const unsigned hx = ln_bf16_pair(o.x, o.y), hz = ln_bf16_pair(o.z, o.w);
             const unsigned lx = ln_bf16_pair(o.x - ln_bf16_up(hx & 0xffffu), o.y - ln_bf16_up(hx >> 16));
             const unsigned lz = ln_bf16_pair(o.z - ln_bf16_up(hz & 0xffffu), o.w - ln_bf16_up(hz >> 16));
@@ -153,6 +161,7 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
             partial_next[((int64_t)b * LN_NB + ch) * 2 + 1] = nq;
         }
     }
+    if (y3) of_amax_commit(fmt.amax, vmax);
 }
 
 // backward pass 1: per (example, chunk): sums of g and g*zhat (g = dy*gamma) and the column partials of
@@ -222,8 +231,9 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ bias, int relu, float* __restrict__ da,
                                                            float* __restrict__ biaspart, const float* __restrict__ dr_extra,
                                                            int64_t dy_batch, unsigned short* __restrict__ da_img,
-                                                           const unsigned char* __restrict__ mask, float mscale) {
+                                                           const unsigned char* __restrict__ mask, float mscale, const OperandFmt fmt) {
     __shared__ float4 cs[256];
+    float vmax = 0.f;
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const int64_t n_per = (int64_t)L * F;
     double s1 = 0.0, s2 = 0.0;
@@ -266,7 +276,13 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
             o.x = mk.x ? o.x * mscale : 0.f; o.y = mk.y ? o.y * mscale : 0.f; o.z = mk.z ? o.z * mscale : 0.f; o.w = mk.w ? o.w * mscale : 0.f;
         }
         if (da && (relu || dr_extra || MASK)) *reinterpret_cast<float4*>(da + off) = o;
-        if (da_img) {      // da only feeds GEMMs: it leaves as their split-bf16 gradient image, row = [hi | hi | lo] planes of F
+        if (da_img && fmt.f16) {
+            vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
+            uint2 hi, lo;
+            of_split4(o.x, o.y, o.z, o.w, 1, fmt.scale, hi, lo);
+            of_store_row4(da_img + ((int64_t)b * L + l) * 2 * F, F, 4 * c4, hi, lo, 1, 1);
+        } else if (da_img) {      // da only feeds GEMMs: it leaves as their split-bf16 gradient image, row = [hi | hi | lo] planes of F
+            vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
             unsigned short* p = da_img + ((int64_t)b * L + l) * 3 * F + 4 * c4;
             const uint2 hi = make_uint2(ln_bf16_pair(o.x, o.y), ln_bf16_pair(o.z, o.w));
             const uint2 lo = make_uint2(ln_bf16_pair(o.x - ln_bf16_up(hi.x & 0xffffu), o.y - ln_bf16_up(hi.x >> 16)),
@@ -288,6 +304,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
             *reinterpret_cast<float4*>(biaspart + ((int64_t)b * LN_NB + ch) * F + 4 * c4) = acc;
         }
     }
+    if (da_img) of_amax_commit(fmt.amax, vmax);
 }
 
 // Column reductions of the per-(example, chunk) partials (1280 rows x 2 x F at cfg-2: 10 MB + 5 MB with a bias) in ONE launch
@@ -377,8 +394,9 @@ extern "C" size_t lpm_layer_norm_workspace_bytes(int B, int F) {
 static int layer_norm_act_fwd_impl(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,
                                    const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, float* z,
                                    float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3 = nullptr,
-                                   const unsigned char* mask = nullptr, float mask_scale = 1.f) {
+                                   const unsigned char* mask = nullptr, float mask_scale = 1.f, const LpmOperandFormat* fmt = nullptr) {
     using namespace lpm;
+    if (const int rc = operand_fmt_check(fmt, "lpm_layer_norm_act_fwd")) return rc;
     LPM_REQUIRE(a && gamma && beta && y && stats && (z || (!r && !bias && !mask)), LPM_ERR_BADARG,
                 "lpm_layer_norm_act_fwd: null pointer (z is required with a residual, a bias or a mask)");
     LPM_REQUIRE(!mask || ((uintptr_t)mask & 3) == 0, LPM_ERR_BADARG, "lpm_layer_norm_act_fwd: the keep mask must be 4-byte aligned");
@@ -398,7 +416,7 @@ static int layer_norm_act_fwd_impl(const float* a, const float* bias, int relu, 
         hipLaunchKernelGGL(ln_fwd_stats_kernel<false>, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z, partial, r_scale,
                            (const unsigned char*)nullptr, 1.f);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (r || bias || mask) ? z : a, partial, gamma, beta, n_per, F, eps, y, yb, stats,
-                       (const float*)nullptr, (float*)nullptr, (unsigned short*)y3);
+                       (const float*)nullptr, (float*)nullptr, (unsigned short*)y3, operand_fmt(fmt));
     return check_launch("lpm_layer_norm_act_fwd");
 }
 // ... with tf.layers.dropout between the dense layer and the layer norm (NetVladV2's TransformerEncoderMod, transformer_utils.py:450-454):
@@ -429,6 +447,15 @@ extern "C" int lpm_layer_norm_act_image_fwd(const float* a, const float* bias, i
     LPM_REQUIRE(y3 && ((uintptr_t)y3 & 7) == 0, LPM_ERR_BADARG, "lpm_layer_norm_act_image_fwd: y3 missing or not 8-byte aligned");
     return layer_norm_act_fwd_impl(a, bias, relu, r, r_scale, gamma, beta, B, L, F, eps, y, y_batch_stride, z, stats, workspace,
                                    workspace_bytes, stream, y3);
+}
+extern "C" int lpm_layer_norm_act_image_fwd_fmt(const float* a, const float* bias, int relu, const float* r, const float* r_scale,
+                                                const float* gamma, const float* beta, int B, int L, int F, float eps, float* y,
+                                                int64_t y_batch_stride, void* y3, float* z, float* stats, void* workspace,
+                                                size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(y3 && ((uintptr_t)y3 & 7) == 0, LPM_ERR_BADARG, "lpm_layer_norm_act_image_fwd: y3 missing or not 8-byte aligned");
+    return layer_norm_act_fwd_impl(a, bias, relu, r, r_scale, gamma, beta, B, L, F, eps, y, y_batch_stride, z, stats, workspace,
+                                   workspace_bytes, stream, y3, nullptr, 1.f, fmt);
 }
 extern "C" int lpm_layer_norm_act_fwd_rs(const float* a, const float* bias, int relu, const float* r, const float* r_scale,
                                          const float* gamma, const float* beta, int B, int L, int F, float eps, float* y,
@@ -462,9 +489,9 @@ extern "C" int lpm_layer_norm_pair_fwd(const float* a, const float* bias, int re
     hipLaunchKernelGGL(ln_fwd_stats_kernel<false>, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z1, partial1, (const float*)nullptr,
                        (const unsigned char*)nullptr, 1.f);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z1, (const float*)partial1, gamma1, beta1, n_per, F, eps,
-                       z2, n_per, stats1, r, partial2, (unsigned short*)nullptr);
+                       z2, n_per, stats1, r, partial2, (unsigned short*)nullptr, OperandFmt{0, 1.f, nullptr});
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z2, (const float*)partial2, gamma2, beta2, n_per, F, eps,
-                       y, yb, stats2, (const float*)nullptr, (float*)nullptr, (unsigned short*)nullptr);
+                       y, yb, stats2, (const float*)nullptr, (float*)nullptr, (unsigned short*)nullptr, OperandFmt{0, 1.f, nullptr});
     return check_launch("lpm_layer_norm_pair_fwd");
 }
 
@@ -478,9 +505,11 @@ static int layer_norm_act_bwd_impl(const float* dy, int64_t dy_batch_stride, con
                                       const float* gamma, const float* a,
                                       const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
                                       float* dbeta, float* dbias, const float* dr_extra, void* da_image, void* workspace,
-                                      size_t workspace_bytes, lpm_stream_t stream, const unsigned char* mask, float mask_scale) {
+                                      size_t workspace_bytes, lpm_stream_t stream, const unsigned char* mask, float mask_scale,
+                                      const LpmOperandFormat* fmt = nullptr) {
     using namespace lpm;
     LPM_REQUIRE(dy && z && stats && gamma && dz && dgamma && dbeta, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: null pointer");
+    if (const int rc = operand_fmt_check(fmt, "lpm_layer_norm_act_bwd")) return rc;
     LPM_REQUIRE(!mask || ((da || da_image) && ((uintptr_t)mask & 3) == 0), LPM_ERR_BADARG,
                 "lpm_layer_norm_act_bwd: a keep mask needs da / da_image and 4-byte alignment");
     LPM_REQUIRE(!dr_extra || da || da_image, LPM_ERR_BADARG, "lpm_layer_norm_act_bwd: dr_extra needs a separate da (or da_image)");
@@ -501,10 +530,10 @@ static int layer_norm_act_bwd_impl(const float* dy, int64_t dy_batch_stride, con
     hipLaunchKernelGGL(ln_bwd_stats_kernel, grid, dim3(256), 0, s, dy, z, stats, gamma, L, F, partial, colpart, dyb, counters);
     if (mask)
         hipLaunchKernelGGL(ln_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
-                           dr_extra, dyb, (unsigned short*)da_image, mask, mask_scale);
+                           dr_extra, dyb, (unsigned short*)da_image, mask, mask_scale, operand_fmt(fmt));
     else
         hipLaunchKernelGGL(ln_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, z, stats, gamma, partial, L, F, dz, a, bias, relu, da, biaspart,
-                           dr_extra, dyb, (unsigned short*)da_image, (const unsigned char*)nullptr, 1.f);
+                           dr_extra, dyb, (unsigned short*)da_image, (const unsigned char*)nullptr, 1.f, operand_fmt(fmt));
     hipLaunchKernelGGL(ln_colreduce_kernel, dim3((F + 63) / 64, LN_RS, bias ? 2 : 1), dim3(256), 0, s, colpart, biaspart, nblk, F, tmp, dgamma,
                        dbeta, dbias, counters);
     return check_launch("lpm_layer_norm_act_bwd");
@@ -516,6 +545,14 @@ extern "C" int lpm_layer_norm_act_bwd(const float* dy, int64_t dy_batch_stride, 
                                       size_t workspace_bytes, lpm_stream_t stream) {
     return layer_norm_act_bwd_impl(dy, dy_batch_stride, z, stats, gamma, a, bias, relu, B, L, F, dz, da, dgamma, dbeta, dbias, dr_extra,
                                    da_image, workspace, workspace_bytes, stream, nullptr, 1.f);
+}
+extern "C" int lpm_layer_norm_act_bwd_fmt(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats,
+                                          const float* gamma, const float* a,
+                                          const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
+                                          float* dbeta, float* dbias, const float* dr_extra, void* da_image, void* workspace,
+                                          size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream) {
+    return layer_norm_act_bwd_impl(dy, dy_batch_stride, z, stats, gamma, a, bias, relu, B, L, F, dz, da, dgamma, dbeta, dbias, dr_extra,
+                                   da_image, workspace, workspace_bytes, stream, nullptr, 1.f, fmt);
 }
 // backward of lpm_layer_norm_act_mask_image_fwd: da (or da_image) = dz * [ReLU mask] * keep * mask_scale, dbias = its column sums
 extern "C" int lpm_layer_norm_act_mask_bwd(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats,

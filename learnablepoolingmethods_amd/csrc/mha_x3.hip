@@ -12,6 +12,7 @@
 //   * fp32 -> (hi, lo) splits use v_cvt_pk_bf16_f32 (2.5 VALU ops per element).
 // transformer_utils.py:564-581 (MultiHeadAttention) and :652-659 (logits_bn variant: key_scale / key_shift).
 #include "lpm_common.h"
+#include "operand_format.h"
 
 namespace lpm {
 
@@ -48,10 +49,24 @@ __device__ __forceinline__ void mx_split8(const float* v, mx_u32x4& hi, mx_u32x4
 // Gradient-image output (img = plane stride in bf16 elements, 0 = plain fp32 output): the 4 values go out as bf16 hi / hi /
 // lo planes [hi | hi | lo] at p, p + img, p + 2 img -- the operand image the q/k/v weight- and input-gradient GEMMs read
 // (ops._split_rows(grad=True)), so the fp32 gradient and the split pass over it never exist.
-__device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img, float a, float b, float c, float d) {
+// Round 5: both images also exist in the fp16 two-product format (operand_format.h) -- [hi | lo] planes of value * scale, max |value|
+// recorded for the host's delayed scale.  MxImg carries the formats of the attention result's image (o*) and of the gradient image (g*).
+struct MxImg {
+    int of16; float oscale, oinv; float* oamax;
+    int gf16; float gscale; float* gamax;
+};
+__device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img, float a, float b, float c, float d, const MxImg& im, float& vmax) {
     if (img == 0) {
         *reinterpret_cast<float4*>(base + off) = make_float4(a, b, c, d);
+    } else if (im.gf16) {
+        vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+        uint2 hi, lo;
+        of_split4(a, b, c, d, 1, im.gscale, hi, lo);
+        unsigned short* p = reinterpret_cast<unsigned short*>(base) + off;
+        *reinterpret_cast<uint2*>(p) = hi;
+        *reinterpret_cast<uint2*>(p + img) = lo;
     } else {
+        vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
         unsigned h0, l0, h1, l1;
         mx_split2(a, b, h0, l0);
         mx_split2(c, d, h1, l1);
@@ -64,10 +79,19 @@ __device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img
 // Activation-image output / input of the attention result (oimg = plane stride in bf16 elements = h*d, 0 = plain fp32): row =
 // [hi | lo | hi] planes, the operand image of the output projection GEMM (ops._split_rows): the forward writes it instead of an
 // fp32 o and the backward kernels rebuild o = hi + lo (2^-17) for D_q = <dO_q, O_q>.
-__device__ __forceinline__ void mx_store_act4(float* base, int64_t row, int64_t ldo, int col, int oimg, float a, float b, float c, float d) {
+__device__ __forceinline__ void mx_store_act4(float* base, int64_t row, int64_t ldo, int col, int oimg, float a, float b, float c, float d,
+                                              const MxImg& im, float& vmax) {
     if (oimg == 0) {
         *reinterpret_cast<float4*>(base + row * ldo + col) = make_float4(a, b, c, d);
+    } else if (im.of16) {
+        vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+        uint2 hi, lo;
+        of_split4(a, b, c, d, 1, im.oscale, hi, lo);
+        unsigned short* p = reinterpret_cast<unsigned short*>(base) + row * 2 * (int64_t)oimg + col;
+        *reinterpret_cast<uint2*>(p) = hi;
+        *reinterpret_cast<uint2*>(p + oimg) = lo;
     } else {
+        vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
         unsigned h0, l0, h1, l1;
         mx_split2(a, b, h0, l0);
         mx_split2(c, d, h1, l1);
@@ -77,10 +101,19 @@ __device__ __forceinline__ void mx_store_act4(float* base, int64_t row, int64_t 
         *reinterpret_cast<uint2*>(p + 2 * (int64_t)oimg) = make_uint2(h0, h1);
     }
 }
-__device__ __forceinline__ void mx_load_o8(const float* base, int64_t row, int64_t ldo, int col, int oimg, float4& a, float4& c) {
+__device__ __forceinline__ float mx_h2f(unsigned w, int hi16) { return of_f16_to_f32((unsigned short)(hi16 ? (w >> 16) : (w & 0xffffu))); }
+__device__ __forceinline__ void mx_load_o8(const float* base, int64_t row, int64_t ldo, int col, int oimg, float4& a, float4& c, const MxImg& im) {
     if (oimg == 0) {
         a = *reinterpret_cast<const float4*>(base + row * ldo + col);
         c = *reinterpret_cast<const float4*>(base + row * ldo + col + 4);
+    } else if (im.of16) {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + row * 2 * (int64_t)oimg + col;
+        const uint4 h = *reinterpret_cast<const uint4*>(p), l = *reinterpret_cast<const uint4*>(p + oimg);
+        const float s = im.oinv;
+        a = make_float4((mx_h2f(h.x, 0) + mx_h2f(l.x, 0)) * s, (mx_h2f(h.x, 1) + mx_h2f(l.x, 1)) * s, (mx_h2f(h.y, 0) + mx_h2f(l.y, 0)) * s,
+                        (mx_h2f(h.y, 1) + mx_h2f(l.y, 1)) * s);
+        c = make_float4((mx_h2f(h.z, 0) + mx_h2f(l.z, 0)) * s, (mx_h2f(h.z, 1) + mx_h2f(l.z, 1)) * s, (mx_h2f(h.w, 0) + mx_h2f(l.w, 0)) * s,
+                        (mx_h2f(h.w, 1) + mx_h2f(l.w, 1)) * s);
     } else {
         const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + row * 3 * (int64_t)oimg + col;
         const uint4 h = *reinterpret_cast<const uint4*>(p), l = *reinterpret_cast<const uint4*>(p + oimg);
@@ -165,8 +198,9 @@ template <int NKT, bool AFFINE, int D, bool RAGGED>
 __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, int64_t ld, int L, int h, float scale,
                                                          const float* __restrict__ key_scale, const float* __restrict__ key_shift,
-                                                         float* __restrict__ o, int64_t ldo, float* __restrict__ lse, int oimg) {
+                                                         float* __restrict__ o, int64_t ldo, float* __restrict__ lse, int oimg, const MxImg im) {
     static_assert(NKT % 2 == 0, "key tiles come in pairs (32-deep PV reduction)");
+    float vmax = 0.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = NKT * 16;
     constexpr int NQ = (NKT + 3) / 4;
@@ -259,10 +293,11 @@ __global__ __launch_bounds__(256) void mha_fwd_x3_kernel(const float* __restrict
         if (qrow < L) {
             if (4 * g < D)
                 mx_store_act4(o, (int64_t)b * L + qrow, ldo, hh * D + 4 * g, oimg, (oa[0] + ob[0]) * inv, (oa[1] + ob[1]) * inv,
-                              (oa[2] + ob[2]) * inv, (oa[3] + ob[3]) * inv);
+                              (oa[2] + ob[2]) * inv, (oa[3] + ob[3]) * inv, im, vmax);
             if (g == 0) lse[((int64_t)b * h + hh) * L + qrow] = m * MX_LN2 + __logf(sum);
         }
     }
+    if (oimg) of_amax_commit(im.oamax, vmax);
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------
@@ -279,8 +314,9 @@ __global__ __launch_bounds__(MX_DQ_NT) void mha_bwd_dq_x3_kernel(const float* __
                                                             const float* __restrict__ lse, int L, int h, float scale,
                                                             const float* __restrict__ key_scale, const float* __restrict__ key_shift,
                                                             float* __restrict__ dq, int64_t ldd, const float* __restrict__ corr_a,
-                                                            const float* __restrict__ corr_b, int img, int oimg) {
+                                                            const float* __restrict__ corr_b, int img, int oimg, const MxImg im) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float vmax = 0.f;
     constexpr int LP = NKT * 16;
     const int nkt = (L + 15) >> 4;
     const float qmul = AFFINE ? scale : scale * MX_LOG2E;      // scores in log2 units (AFFINE: z is converted instead)
@@ -330,7 +366,7 @@ __global__ __launch_bounds__(MX_DQ_NT) void mha_bwd_dq_x3_kernel(const float* __
             const int64_t off = ((int64_t)b * L + qrow) * ldo + c0;
             const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
             float4 oa, oc;
-            mx_load_o8(o, (int64_t)b * L + qrow, ldo, c0, oimg, oa, oc);
+            mx_load_o8(o, (int64_t)b * L + qrow, ldo, c0, oimg, oa, oc, im);
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
             mx_split8(gv, gh, gl);
             dpart = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
@@ -388,8 +424,9 @@ __global__ __launch_bounds__(MX_DQ_NT) void mha_bwd_dq_x3_kernel(const float* __
         }
         if (qok && 4 * g < D)
             mx_store_grad4(dq, ((int64_t)b * L + qrow) * ldd + hh * D + 4 * g, img, (dqa[0] + dqb[0]) * scale, (dqa[1] + dqb[1]) * scale,
-                           (dqa[2] + dqb[2]) * scale, (dqa[3] + dqb[3]) * scale);
+                           (dqa[2] + dqb[2]) * scale, (dqa[3] + dqb[3]) * scale, im, vmax);
     }
+    if (img) of_amax_commit(im.gamax, vmax);
 }
 
 // Eight waves per (batch, head): the workgroup's LDS (66 KB at L = 256: two workgroups per CU) is the same for four or eight
@@ -409,8 +446,9 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
                                                              const float* __restrict__ key_scale, const float* __restrict__ key_shift,
                                                              float* __restrict__ dk, float* __restrict__ dv, int64_t ldd,
                                                              const float* __restrict__ corr_a, const float* __restrict__ corr_b,
-                                                             float* __restrict__ dz_partial, int img, int oimg) {
+                                                             float* __restrict__ dz_partial, int img, int oimg, const MxImg im) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float vmax = 0.f;
     constexpr int LP = NKT * 16;
     constexpr int MX_DKV_NT = mx_dkv_nt(NKT);
     constexpr int NH = D / 8;
@@ -451,7 +489,7 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
             const float4 qa = *reinterpret_cast<const float4*>(qp), qc = *reinterpret_cast<const float4*>(qp + 4);
             const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
             float4 oa, oc;
-            mx_load_o8(o, (int64_t)b * L + row, ldo, hh * D + 8 * hf, oimg, oa, oc);
+            mx_load_o8(o, (int64_t)b * L + row, ldo, hh * D + 8 * hf, oimg, oa, oc, im);
             part = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
             const float qv[8] = {qa.x * qmul, qa.y * qmul, qa.z * qmul, qa.w * qmul, qc.x * qmul, qc.y * qmul, qc.z * qmul, qc.w * qmul};
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
@@ -553,8 +591,8 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
         if (!stats_only && kok && 4 * g < D) {
             const int64_t off = ((int64_t)b * L + krow) * ldd + hh * D + 4 * g;
             const float kmul = AFFINE ? 1.f : MX_LN2;      // the staged Q carried log2(e)
-            mx_store_grad4(dk, off, img, (dka[0] + dkb[0]) * kmul, (dka[1] + dkb[1]) * kmul, (dka[2] + dkb[2]) * kmul, (dka[3] + dkb[3]) * kmul);
-            mx_store_grad4(dv, off, img, dva[0] + dvb[0], dva[1] + dvb[1], dva[2] + dvb[2], dva[3] + dvb[3]);
+            mx_store_grad4(dk, off, img, (dka[0] + dkb[0]) * kmul, (dka[1] + dkb[1]) * kmul, (dka[2] + dkb[2]) * kmul, (dka[3] + dkb[3]) * kmul, im, vmax);
+            mx_store_grad4(dv, off, img, dva[0] + dvb[0], dva[1] + dvb[1], dva[2] + dvb[2], dva[3] + dvb[3], im, vmax);
         }
         if (dz_partial) {
             zs += __shfl_xor(zs, 16, 64); zs += __shfl_xor(zs, 32, 64);
@@ -566,6 +604,7 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
             }
         }
     }
+    if (img) of_amax_commit(im.gamax, vmax);
 }
 
 // logits_bn backward in ONE pass over the scores (round 3).  The batch norm's backward subtracts from ds two terms that need sums over
@@ -708,10 +747,15 @@ static int mx_reserve(KernT kern, size_t bytes, const char* what) {
                 name ": need d in {8,16} and L <= 512 (L=%d d=%d)", L, d);                                          \
     LPM_REQUIRE(ld >= (int64_t)h * d && ld % 4 == 0, LPM_ERR_BADARG, name ": bad leading dimension")
 
+static lpm::MxImg mx_img(const LpmOperandFormat* o_fmt, const LpmOperandFormat* g_fmt) {
+    const lpm::OperandFmt fo = lpm::operand_fmt(o_fmt), fg = lpm::operand_fmt(g_fmt);
+    return lpm::MxImg{fo.f16, fo.scale, 1.f / fo.scale, fo.amax, fg.f16, fg.scale, fg.amax};
+}
 static int mx_fwd_launch(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d, float scale,
                          const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse, int oimg,
-                         lpm_stream_t stream, const char* what) {
+                         lpm_stream_t stream, const char* what, const LpmOperandFormat* o_fmt = nullptr) {
     using namespace lpm;
+    const MxImg im = mx_img(o_fmt, nullptr);
     hipStream_t s = (hipStream_t)stream;
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
@@ -720,7 +764,7 @@ static int mx_fwd_launch(const float* q, const float* k, const float* v, int64_t
         auto kern = mha_fwd_x3_kernel<N, AFF, DD, RG>;                                                           \
         const size_t lds = mx_fwd_lds(N * 16, DD);                                                               \
         if (int rc = mx_reserve(kern, lds, what)) return rc;                                                     \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ld, L, h, scale, key_scale, key_shift, o, ldo, lse, oimg); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ld, L, h, scale, key_scale, key_shift, o, ldo, lse, oimg, im); \
     } while (0)
 #define LPM_MX_FWD1(N, AFF, RG)        \
     do {                               \
@@ -766,12 +810,24 @@ extern "C" int lpm_mha_fwd_x3_image(const float* q, const float* k, const float*
                 "lpm_mha_fwd_x3_image: pointers must be 16-byte aligned");
     return mx_fwd_launch(q, k, v, ld, B, L, h, d, scale, nullptr, nullptr, (float*)o3, 0, lse, h * d, stream, "lpm_mha_fwd_x3_image");
 }
+extern "C" int lpm_mha_fwd_x3_image_fmt(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d,
+                                        float scale, void* o3, float* lse, const LpmOperandFormat* o_fmt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o3 && lse, LPM_ERR_BADARG, "lpm_mha_fwd_x3_image: null pointer");
+    LPM_MX_CHECK("lpm_mha_fwd_x3_image");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o3) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_mha_fwd_x3_image: pointers must be 16-byte aligned");
+    if (const int rc = operand_fmt_check(o_fmt, "lpm_mha_fwd_x3_image")) return rc;
+    return mx_fwd_launch(q, k, v, ld, B, L, h, d, scale, nullptr, nullptr, (float*)o3, 0, lse, h * d, stream, "lpm_mha_fwd_x3_image", o_fmt);
+}
 
 static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout, int64_t ldo,
                          const float* lse, int B, int L, int h, int d, float scale, const float* key_scale, const float* key_shift,
                          float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a, const float* corr_b, float* dz_partial,
-                         int img, int oimg, lpm_stream_t stream, const char* what) {
+                         int img, int oimg, lpm_stream_t stream, const char* what, const LpmOperandFormat* o_fmt = nullptr,
+                         const LpmOperandFormat* g_fmt = nullptr) {
     using namespace lpm;
+    const MxImg im = mx_img(o_fmt, g_fmt);
     hipStream_t s = (hipStream_t)stream;
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
@@ -782,14 +838,14 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
             const size_t lq = mx_bwd_dq_lds(N * 16, DD);                                                               \
             if (int rc = mx_reserve(kq, lq, what)) return rc;                                                          \
             hipLaunchKernelGGL(kq, grid, dim3(MX_DQ_NT), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dq, \
-                               ldd, corr_a, corr_b, img, oimg);                                                        \
+                               ldd, corr_a, corr_b, img, oimg, im);                                                    \
         }                                                                                                              \
         if (dk || dz_partial) {                                                                                        \
             auto kk = (AFF && !corr_a) ? mha_bwd_dkv_x3_kernel<N, AFF, DD, false> : mha_bwd_dkv_x3_kernel<N, AFF, DD, true>;          \
             const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                              \
             if (int rc = mx_reserve(kk, lk, what)) return rc;                                                          \
             hipLaunchKernelGGL(kk, grid, dim3(mx_dkv_nt(N)), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, dk, \
-                               dv, ldd, corr_a, corr_b, dz_partial, img, oimg);                                        \
+                               dv, ldd, corr_a, corr_b, dz_partial, img, oimg, im);                                    \
         }                                                                                                              \
     } while (0)
 #define LPM_MX_BWD1(N, AFF, RG)        \
@@ -868,4 +924,23 @@ extern "C" int lpm_mha_bwd_x3_image(const float* q, const float* k, const float*
     return mx_bwd_launch(q, k, v, ld, (const float*)o, dout, ldo, lse, B, L, h, d, scale, nullptr, nullptr, (float*)base, (float*)(base + N),
                          (float*)(base + 2 * N), (int64_t)9 * N, nullptr, nullptr, nullptr, 3 * N, o_is_image ? N : 0, stream,
                          "lpm_mha_bwd_x3_image");
+}
+// ... with the attention result's image (always an image here) and the [dq | dk | dv] gradient image in either operand format
+extern "C" int lpm_mha_bwd_x3_image_fmt(const float* q, const float* k, const float* v, int64_t ld, const void* o_img,
+                                        const LpmOperandFormat* o_fmt, const float* dout, int64_t ldo, const float* lse, int B, int L, int h,
+                                        int d, float scale, void* dqkv_img, const LpmOperandFormat* g_fmt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o_img && dout && lse && dqkv_img, LPM_ERR_BADARG, "lpm_mha_bwd_x3_image: null pointer");
+    LPM_MX_CHECK("lpm_mha_bwd_x3_image");
+    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0, LPM_ERR_BADARG, "lpm_mha_bwd_x3_image: bad ldo");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o_img | (uintptr_t)dout | (uintptr_t)dqkv_img) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_mha_bwd_x3_image: pointers must be 16-byte aligned");
+    if (const int rc = operand_fmt_check(o_fmt, "lpm_mha_bwd_x3_image")) return rc;
+    if (const int rc = operand_fmt_check(g_fmt, "lpm_mha_bwd_x3_image")) return rc;
+    const int N = h * d;
+    const int gf16 = (g_fmt && g_fmt->kind == LPM_OPERAND_FP16X2) ? 1 : 0;      // fp16x2 row: [hi(3N) | lo(3N)]
+    unsigned short* base = (unsigned short*)dqkv_img;
+    return mx_bwd_launch(q, k, v, ld, (const float*)o_img, dout, ldo, lse, B, L, h, d, scale, nullptr, nullptr, (float*)base, (float*)(base + N),
+                         (float*)(base + 2 * N), (int64_t)(gf16 ? 6 : 9) * N, nullptr, nullptr, nullptr, 3 * N, N, stream,
+                         "lpm_mha_bwd_x3_image", o_fmt, g_fmt);
 }

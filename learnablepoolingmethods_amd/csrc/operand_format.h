@@ -1,0 +1,130 @@
+// The two operand formats of the dense GEMMs on the 16-bit matrix pipe (round 5), and what an operand's producer does with them.
+//
+//   LPM_OPERAND_BF16X3 (round 1-4, every model): x = xh + xl in bf16 planes (2^-17 residual), THREE products per a . b
+//       (ah bh + al bh + ah bl) -- ~5e-6 per GEMM.  Activation images [rows][3K] = [hi | lo | hi], gradient images [hi | hi | lo],
+//       weight images with the matching plane orders (split_gemm.hip), fragment tiles with (hi, lo) planes (tile_gemm.h).
+//   LPM_OPERAND_FP16X2 (round 5, NetVladV1): the data operand x = xh + xl in FP16 planes (11 + 11 bits), the weight operand rounded
+//       ONCE to fp16 (11 bits): TWO products per a . b (ah bh + al bh) -- a third of the matrix-pipe work gone, ~1.4e-4 per GEMM
+//       (the weight's 2^-12 rounding; transformer_utils.py:559-561,583,701-711 and TF autodiff of those layers).  Images
+//       [rows][2K] = [hi | lo] for activations AND gradients, weight images [Wh | Wh], fragment tiles (hi, lo) for the data operand and
+//       hi only for the weight operand.  fp16 has five exponent bits: the producer multiplies every value by a power of two (`scale`,
+//       chosen by the host from the tensor's max |.| of an EARLIER step -- ops.OperandScales, delayed scaling) and the GEMM's consumer
+//       multiplies by 1 / scale (exact).  Values beyond the format's range saturate at +-65504 instead of becoming infinite.  The
+//       matrix cores keep fp16 subnormals (measured, tools/fp16_probe.py), so below 2^-14 the pair (hi, lo) degrades into fixed point
+//       with a 2^-25 quantum: with max |x| scale in [2^10, 2^11) every value down to 2^-24 of the tensor's maximum keeps 11 bits.
+// In both formats the producer can record max |x| (before scaling) of what it wrote: one atomic max per wave into *amax.
+#pragma once
+#include "lpm_common.h"
+
+namespace lpm {
+
+struct OperandFmt {
+    int f16;          // 0: split-bf16 x3;  1: split-fp16 x2
+    float scale;      // multiplied in before the split (power of two; 1 for bf16x3)
+    float* amax;      // device, nullable
+};
+inline OperandFmt operand_fmt(const LpmOperandFormat* f) {
+    OperandFmt o{0, 1.f, nullptr};
+    if (f) {
+        o.f16 = f->kind == LPM_OPERAND_FP16X2 ? 1 : 0;
+        o.scale = (f->scale > 0.f) ? f->scale : 1.f;
+        o.amax = f->amax;
+    }
+    return o;
+}
+inline int operand_fmt_check(const LpmOperandFormat* f, const char* what) {
+    if (!f) return LPM_OK;
+    if (f->kind != LPM_OPERAND_BF16X3 && f->kind != LPM_OPERAND_FP16X2) { set_error("%s: unknown operand format %d", what, f->kind); return LPM_ERR_BADARG; }
+    if (!(f->scale > 0.f) || f->scale != f->scale) { set_error("%s: the operand scale must be a positive power of two", what); return LPM_ERR_BADARG; }
+    if (((uintptr_t)f->amax & 3) != 0) { set_error("%s: misaligned amax", what); return LPM_ERR_BADARG; }
+    return LPM_OK;
+}
+__host__ __device__ constexpr int operand_planes(int f16) { return f16 ? 2 : 3; }      // 16-bit planes per image row
+
+typedef _Float16 of_h2 __attribute__((ext_vector_type(2)));
+typedef __bf16 of_b2 __attribute__((ext_vector_type(2)));
+typedef float of_f2 __attribute__((ext_vector_type(2)));
+constexpr float kF16Max = 65504.f;
+
+// two values -> packed (hi, lo) words.  bf16: round-to-nearest-even both (v_cvt_pk_bf16_f32), bit for bit tile_gemm.h's tg_split2.
+// fp16: v * scale clamped to the format's range, hi = rne(v), lo = rne(v - hi).
+__device__ __forceinline__ void of_split2(float a, float b, int f16, float scale, unsigned& hi, unsigned& lo) {
+    if (f16) {
+        const of_f2 v = {__builtin_amdgcn_fmed3f(a * scale, -kF16Max, kF16Max), __builtin_amdgcn_fmed3f(b * scale, -kF16Max, kF16Max)};
+        const of_h2 h = __builtin_convertvector(v, of_h2);
+        const of_f2 hf = __builtin_convertvector(h, of_f2);
+        const of_h2 l = __builtin_convertvector(v - hf, of_h2);
+        hi = __builtin_bit_cast(unsigned, h);
+        lo = __builtin_bit_cast(unsigned, l);
+    } else {
+        const of_f2 v = {a, b};
+        const of_b2 h = __builtin_convertvector(v, of_b2);
+        const of_f2 hf = __builtin_convertvector(h, of_f2);
+        const of_b2 l = __builtin_convertvector(v - hf, of_b2);
+        hi = __builtin_bit_cast(unsigned, h);
+        lo = __builtin_bit_cast(unsigned, l);
+    }
+}
+__device__ __forceinline__ void of_split8(const float* v, int f16, float scale, uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) of_split2(v[2 * i], v[2 * i + 1], f16, scale, h[i], l[i]);
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void of_split4(float a, float b, float c, float d, int f16, float scale, uint2& hi, uint2& lo) {
+    unsigned h0, l0, h1, l1;
+    of_split2(a, b, f16, scale, h0, l0);
+    of_split2(c, d, f16, scale, h1, l1);
+    hi = make_uint2(h0, h1);
+    lo = make_uint2(l0, l1);
+}
+// hi-plane-only (the weight operand of the fp16 form: rounded once)
+__device__ __forceinline__ unsigned of_round2_f16(float a, float b) {
+    const of_f2 v = {__builtin_amdgcn_fmed3f(a, -kF16Max, kF16Max), __builtin_amdgcn_fmed3f(b, -kF16Max, kF16Max)};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, of_h2));
+}
+__device__ __forceinline__ float of_f16_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ float of_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// the value an image holds at (hi, lo), un-scaled
+__device__ __forceinline__ float of_value(unsigned short h, unsigned short l, int f16, float inv_scale) {
+    return f16 ? (of_f16_to_f32(h) + of_f16_to_f32(l)) * inv_scale : of_bf16_to_f32(h) + of_bf16_to_f32(l);
+}
+
+// ---- image rows.  An image row holds K values as planes of K 16-bit words: bf16x3 activation [hi | lo | hi], bf16x3 gradient
+// [hi | hi | lo], fp16x2 (either) [hi | lo].  `grad`: the bf16x3 plane order.
+__device__ __forceinline__ int64_t of_row_stride(int K, int f16) { return (int64_t)operand_planes(f16) * K; }
+__device__ __forceinline__ void of_store_row8(unsigned short* row, int K, int c, const uint4& hi, const uint4& lo, int f16, int grad) {
+    *reinterpret_cast<uint4*>(row + c) = hi;
+    if (f16) {
+        *reinterpret_cast<uint4*>(row + K + c) = lo;
+    } else {
+        *reinterpret_cast<uint4*>(row + K + c) = grad ? hi : lo;
+        *reinterpret_cast<uint4*>(row + 2 * (int64_t)K + c) = grad ? lo : hi;
+    }
+}
+__device__ __forceinline__ void of_store_row4(unsigned short* row, int K, int c, const uint2& hi, const uint2& lo, int f16, int grad) {
+    *reinterpret_cast<uint2*>(row + c) = hi;
+    if (f16) {
+        *reinterpret_cast<uint2*>(row + K + c) = lo;
+    } else {
+        *reinterpret_cast<uint2*>(row + K + c) = grad ? hi : lo;
+        *reinterpret_cast<uint2*>(row + 2 * (int64_t)K + c) = grad ? lo : hi;
+    }
+}
+// "the forward activation was > 0" from the hi plane of its image (either format: sign bit 15, zero = all other bits clear)
+__device__ __forceinline__ bool of_positive(unsigned h16) { return (h16 & 0x7fffu) != 0u && !(h16 & 0x8000u); }
+
+// ---- max |x|: a thread keeps a running maximum, the wave joins and one lane issues the atomic (non-negative floats order like their bits)
+__device__ __forceinline__ float of_amax8(float m, const float* v) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+    return m;
+}
+__device__ __forceinline__ void of_amax_commit(float* amax, float m) {
+    if (!amax) return;
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));
+}
+
+}  // namespace lpm

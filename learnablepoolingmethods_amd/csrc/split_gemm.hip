@@ -13,7 +13,9 @@
 // activation image and a gradient image give the weight gradient as ONE long-reduction GEMM
 //     dW = X3[3M,K]^T . DY3[3M,N] = xh^T dyh + xl^T dyh + xh^T dyl
 // (a 61440-deep reduction at cfg-2: hipBLASLt runs it at ~2x the rate of three separate 20480-deep GEMMs).
+// Round 5: every image here also exists in the fp16 two-product format (operand_format.h): [hi | lo] planes of v * scale.
 #include "lpm_common.h"
+#include "operand_format.h"
 
 namespace lpm {
 
@@ -27,9 +29,11 @@ __device__ __forceinline__ float sg_bf16_f32(unsigned h) { return __uint_as_floa
 // one thread = 8 consecutive columns of one row
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int K,
                                                          const float* __restrict__ bias, int relu, int order,
-                                                         unsigned short* __restrict__ out3, const float* __restrict__ row_scale) {
+                                                         unsigned short* __restrict__ out3, const float* __restrict__ row_scale,
+                                                         const OperandFmt fmt) {
     const int K8 = K / 8;
     const int64_t total = M * K8;
+    float vmax = 0.f;
     for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
         const int64_t m = w / K8;
         const int c = (int)(w % K8) * 8;
@@ -46,20 +50,27 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
             v[0] += ba.x; v[1] += ba.y; v[2] += ba.z; v[3] += ba.w;
             v[4] += bb.x; v[5] += bb.y; v[6] += bb.z; v[7] += bb.w;
         }
-        unsigned h[8], l[8];
+        if (relu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (relu) v[e] = fmaxf(v[e], 0.f);
-            h[e] = sg_bf16_rne(v[e]);
-            l[e] = sg_bf16_rne(v[e] - sg_bf16_f32(h[e]));
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        const uint4 hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-        const uint4 lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-        unsigned short* row = out3 + m * 3 * (int64_t)K;
-        *reinterpret_cast<uint4*>(row + c) = hi;
-        *reinterpret_cast<uint4*>(row + K + c) = order ? hi : lo;
-        *reinterpret_cast<uint4*>(row + 2 * (int64_t)K + c) = order ? lo : hi;
+        vmax = of_amax8(vmax, v);
+        uint4 hi, lo;
+        if (fmt.f16) {
+            of_split8(v, 1, fmt.scale, hi, lo);
+        } else {
+            unsigned h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[e] = sg_bf16_rne(v[e]);
+                l[e] = sg_bf16_rne(v[e] - sg_bf16_f32(h[e]));
+            }
+            hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+        }
+        of_store_row8(out3 + m * of_row_stride(K, fmt.f16), K, c, hi, lo, fmt.f16, order);
     }
+    of_amax_commit(fmt.amax, vmax);
 }
 
 // Backward companion of the fused relu(x + bias) split: g = df * [act > 0] where `act3` is the [M,3K] split image of
@@ -68,10 +79,11 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 // column partial sums of g (the bias gradient) -> colpart [gridDim.x][K].  One workgroup = SR_ROWS rows, all columns.
 constexpr int SR_ROWS = 32;
 __global__ __launch_bounds__(256) void split_rows_relu_bwd_kernel(const float* __restrict__ df, int64_t M, int K,
-                                                                  const unsigned short* __restrict__ act3,
+                                                                  const unsigned short* __restrict__ act3, int act_f16,
                                                                   unsigned short* __restrict__ out3,
-                                                                  float* __restrict__ colpart) {
+                                                                  float* __restrict__ colpart, float alpha, const OperandFmt fmt) {
     const int K8 = K / 8;
+    float vmax = 0.f;
     const int64_t r0 = (int64_t)blockIdx.x * SR_ROWS, r1 = min(M, r0 + SR_ROWS);
     for (int cg = threadIdx.x; cg < K8; cg += 256) {
         const int c = cg * 8;
@@ -79,30 +91,36 @@ __global__ __launch_bounds__(256) void split_rows_relu_bwd_kernel(const float* _
         for (int64_t m = r0; m < r1; ++m) {
             const float4 a = *reinterpret_cast<const float4*>(df + m * K + c);
             const float4 b = *reinterpret_cast<const float4*>(df + m * K + c + 4);
-            const uint4 hm = *reinterpret_cast<const uint4*>(act3 + m * 3 * (int64_t)K + c);   // hi plane of the activation
-            float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const uint4 hm = *reinterpret_cast<const uint4*>(act3 + m * of_row_stride(K, act_f16) + c);   // hi plane of the activation
+            float v[8] = {a.x * alpha, a.y * alpha, a.z * alpha, a.w * alpha, b.x * alpha, b.y * alpha, b.z * alpha, b.w * alpha};
             const unsigned mw[4] = {hm.x, hm.y, hm.z, hm.w};
-            unsigned h[8], l[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const unsigned ah = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-                const bool on = (ah != 0u) && !(ah & 0x8000u);                 // activation > 0
-                v[e] = on ? v[e] : 0.f;
+                v[e] = of_positive(ah) ? v[e] : 0.f;                            // activation > 0
                 acc[e] += v[e];
-                h[e] = sg_bf16_rne(v[e]);
-                l[e] = sg_bf16_rne(v[e] - sg_bf16_f32(h[e]));
             }
-            const uint4 hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-            const uint4 lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-            unsigned short* row = out3 + m * 3 * (int64_t)K;     // gradient plane order [hi | hi | lo]
-            *reinterpret_cast<uint4*>(row + c) = hi;
-            *reinterpret_cast<uint4*>(row + K + c) = hi;
-            *reinterpret_cast<uint4*>(row + 2 * (int64_t)K + c) = lo;
+            vmax = of_amax8(vmax, v);
+            uint4 hi, lo;
+            if (fmt.f16) {
+                of_split8(v, 1, fmt.scale, hi, lo);
+            } else {
+                unsigned h[8], l[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h[e] = sg_bf16_rne(v[e]);
+                    l[e] = sg_bf16_rne(v[e] - sg_bf16_f32(h[e]));
+                }
+                hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+            }
+            of_store_row8(out3 + m * of_row_stride(K, fmt.f16), K, c, hi, lo, fmt.f16, 1);     // (bf16x3: gradient plane order [hi | hi | lo])
         }
         float* cp = colpart + (int64_t)blockIdx.x * K + c;
         *reinterpret_cast<float4*>(cp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         *reinterpret_cast<float4*>(cp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
+    of_amax_commit(fmt.amax, vmax);
 }
 
 // colpart [nblk][K] -> out [K]  (fp64 accumulation; 1024 threads per 16 columns, partial_colsums16)
@@ -118,9 +136,10 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
 //   w3n [N, 3K]: row n = [Wh[:,n] | Wh[:,n] | Wl[:,n]]   (forward: y = X3 . w3n^T, X3 = [xh|xl|xh])
 //   w3k [K, 3N]: row k = [Wh[k,:] | Wl[k,:] | Wh[k,:]]   (input gradient: dx = DY3 . w3k^T, DY3 = [dyh|dyh|dyl])
 // Both are "B stored transposed" (NT) operands: hipBLASLt runs that layout 8-10 % faster than NN at these shapes.
+// f16 (the two-product form): the weight rounded once to fp16, wn [N, 2K] = [Wh^T | Wh^T], wk [K, 2N] = [Wh | Wh].
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int K, int N,
                                                            unsigned short* __restrict__ w3n,
-                                                           unsigned short* __restrict__ w3k) {
+                                                           unsigned short* __restrict__ w3k, int f16) {
     __shared__ unsigned short th[32][33], tl[32][33];
     const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -130,13 +149,22 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
         unsigned h = 0, l = 0;
         if (k < K && n < N) {
             const float v = W[(int64_t)k * N + n];
-            h = sg_bf16_rne(v);
-            l = sg_bf16_rne(v - sg_bf16_f32(h));
-            if (w3k) {
-                unsigned short* row = w3k + (int64_t)k * 3 * N;
-                row[n] = (unsigned short)h;
-                row[N + n] = (unsigned short)l;
-                row[2 * N + n] = (unsigned short)h;
+            if (f16) {
+                h = of_round2_f16(v, 0.f) & 0xffffu;
+                if (w3k) {
+                    unsigned short* row = w3k + (int64_t)k * 2 * N;
+                    row[n] = (unsigned short)h;
+                    row[N + n] = (unsigned short)h;
+                }
+            } else {
+                h = sg_bf16_rne(v);
+                l = sg_bf16_rne(v - sg_bf16_f32(h));
+                if (w3k) {
+                    unsigned short* row = w3k + (int64_t)k * 3 * N;
+                    row[n] = (unsigned short)h;
+                    row[N + n] = (unsigned short)l;
+                    row[2 * N + n] = (unsigned short)h;
+                }
             }
         }
         th[ty + 8 * i][tx] = (unsigned short)h;
@@ -148,28 +176,33 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
         const int n = n0 + ty + 8 * i, k = k0 + tx;
         if (k < K && n < N) {
             const unsigned short h = th[tx][ty + 8 * i], l = tl[tx][ty + 8 * i];
-            unsigned short* row = w3n + (int64_t)n * 3 * K;
+            unsigned short* row = w3n + (int64_t)n * (f16 ? 2 : 3) * K;
             row[k] = h;
             row[K + k] = h;
-            row[2 * K + k] = l;
+            if (!f16) row[2 * K + k] = l;
         }
     }
 }
 
 }  // namespace lpm
 
-extern "C" int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, int order, void* out3,
-                              lpm_stream_t stream) {
+extern "C" int lpm_split_rows_fmt(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, int order, const float* row_scale,
+                                  void* out3, const LpmOperandFormat* fmt, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(x && out3, LPM_ERR_BADARG, "lpm_split_rows: null pointer");
     LPM_REQUIRE(M > 0 && K > 0 && ldx >= K, LPM_ERR_BADARG, "lpm_split_rows: bad sizes");
     LPM_REQUIRE(K % 8 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)out3 | (uintptr_t)bias) & 15) == 0,
                 LPM_ERR_UNSUPPORTED_SHAPE, "lpm_split_rows: need K %% 8 == 0, ldx %% 4 == 0, 16-byte aligned pointers (K=%d)", K);
+    if (const int rc = operand_fmt_check(fmt, "lpm_split_rows")) return rc;
     const int64_t total = M * (K / 8);
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       M, K, bias, relu, order ? 1 : 0, (unsigned short*)out3, (const float*)nullptr);
+                       M, K, bias, relu, order ? 1 : 0, (unsigned short*)out3, row_scale, operand_fmt(fmt));
     return check_launch("lpm_split_rows");
+}
+extern "C" int lpm_split_rows(const float* x, int64_t ldx, int64_t M, int K, const float* bias, int relu, int order, void* out3,
+                              lpm_stream_t stream) {
+    return lpm_split_rows_fmt(x, ldx, M, K, bias, relu, order, nullptr, out3, nullptr, stream);
 }
 
 // x[m, :] * row_scale[m] -> activation image [hi | lo | hi]: the operand of the q/k/v GEMM when x is the pooled descriptor in its
@@ -180,11 +213,7 @@ extern "C" int lpm_split_rows_scaled(const float* x, int64_t ldx, int64_t M, int
     LPM_REQUIRE(M > 0 && K > 0 && ldx >= K, LPM_ERR_BADARG, "lpm_split_rows_scaled: bad sizes");
     LPM_REQUIRE(K % 8 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)out3) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_split_rows_scaled: need K %% 8 == 0, ldx %% 4 == 0, 16-byte aligned pointers (K=%d)", K);
-    const int64_t total = M * (K / 8);
-    const int64_t want = (total + 255) / 256;
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, ldx, M, K,
-                       (const float*)nullptr, 0, 0, (unsigned short*)out3, row_scale);
-    return check_launch("lpm_split_rows_scaled");
+    return lpm_split_rows_fmt(x, ldx, M, K, nullptr, 0, 0, row_scale, out3, nullptr, stream);
 }
 
 namespace lpm {
@@ -243,7 +272,14 @@ extern "C" size_t lpm_split_rows_relu_bwd_workspace_bytes(int64_t M, int K) {
 
 extern "C" int lpm_split_rows_relu_bwd(const float* df, int64_t M, int K, const void* act3, void* out3, float* dbias,
                                        void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    return lpm_split_rows_relu_bwd_fmt(df, M, K, 1.f, act3, LPM_OPERAND_BF16X3, out3, dbias, workspace, workspace_bytes, nullptr, stream);
+}
+extern "C" int lpm_split_rows_relu_bwd_fmt(const float* df, int64_t M, int K, float alpha, const void* act3, int act_kind, void* out3, float* dbias,
+                                           void* workspace, size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream) {
     using namespace lpm;
+    if (const int rc = operand_fmt_check(fmt, "lpm_split_rows_relu_bwd")) return rc;
+    LPM_REQUIRE(alpha > 0.f && (act_kind == LPM_OPERAND_BF16X3 || act_kind == LPM_OPERAND_FP16X2), LPM_ERR_BADARG,
+                "lpm_split_rows_relu_bwd: bad alpha / act_kind");
     LPM_REQUIRE(df && act3 && out3 && dbias && workspace, LPM_ERR_BADARG, "lpm_split_rows_relu_bwd: null pointer");
     LPM_REQUIRE(M > 0 && K > 0 && K % 8 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_split_rows_relu_bwd: need K %% 8 == 0 (K=%d)", K);
     LPM_REQUIRE(workspace_bytes >= lpm_split_rows_relu_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE,
@@ -251,18 +287,22 @@ extern "C" int lpm_split_rows_relu_bwd(const float* df, int64_t M, int K, const 
     const int nblk = (int)((M + SR_ROWS - 1) / SR_ROWS);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(split_rows_relu_bwd_kernel, dim3(nblk), dim3(256), 0, s, df, M, K, (const unsigned short*)act3,
-                       (unsigned short*)out3, (float*)workspace);
+                       act_kind == LPM_OPERAND_FP16X2 ? 1 : 0, (unsigned short*)out3, (float*)workspace, alpha, operand_fmt(fmt));
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((K + 15) / 16), dim3(1024), 0, s, (const float*)workspace, nblk, K, dbias);
     return check_launch("lpm_split_rows_relu_bwd");
 }
 
-extern "C" int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w3k, lpm_stream_t stream) {
+extern "C" int lpm_split_weight_fmt(const float* W, int K, int N, void* w3n, void* w3k, int kind, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(W && w3n, LPM_ERR_BADARG, "lpm_split_weight: null pointer");
     LPM_REQUIRE(K > 0 && N > 0, LPM_ERR_BADARG, "lpm_split_weight: bad sizes");
+    LPM_REQUIRE(kind == LPM_OPERAND_BF16X3 || kind == LPM_OPERAND_FP16X2, LPM_ERR_BADARG, "lpm_split_weight: unknown operand format %d", kind);
     hipLaunchKernelGGL(split_weight_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, (hipStream_t)stream, W, K, N,
-                       (unsigned short*)w3n, (unsigned short*)w3k);
+                       (unsigned short*)w3n, (unsigned short*)w3k, kind == LPM_OPERAND_FP16X2 ? 1 : 0);
     return check_launch("lpm_split_weight");
+}
+extern "C" int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w3k, lpm_stream_t stream) {
+    return lpm_split_weight_fmt(W, K, N, w3n, w3k, LPM_OPERAND_BF16X3, stream);
 }
 
 extern "C" int lpm_bias_act_fwd(float* y, const float* bias, int relu, int64_t M, int C, lpm_stream_t stream) {

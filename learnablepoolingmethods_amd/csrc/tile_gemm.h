@@ -22,6 +22,7 @@
 // with bias + ReLU / ReLU-mask + bias-gradient fused (TileGemmArgs::img).  Measured per shape against hipBLASLt in DESIGN.md section 4.
 #pragma once
 #include "lpm_common.h"
+#include "operand_format.h"
 
 namespace lpm {
 
@@ -29,6 +30,11 @@ typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned tg_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 tg_mfma(tg_u32x4 a, tg_u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tg_bf16x8, a), __builtin_bit_cast(tg_bf16x8, b), c, 0, 0, 0);
+}
+// fp16 operands (PL == 3, the two-product form of round 5: A = (hi, lo) fp16 planes, B = one fp16 plane)
+typedef _Float16 tg_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 tg_mfma_f16(tg_u32x4 a, tg_u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tg_f16x8, a), __builtin_bit_cast(tg_f16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ unsigned tg_rne(float v) {
     unsigned u = __float_as_uint(v);
@@ -102,6 +108,12 @@ struct TileGemmArgs {
     const unsigned short* img_mask;
     float* img_colpart;
     int img_kind;
+    // round 5 (operand_format.h): the image leaves in either operand format -- img_f16 = 1: fp16 planes [hi | lo] of v * img_scale;
+    // img_amax (nullable): max |v| of the launch; mask_f16: the format of img_mask's image (its row stride); alpha: the accumulators
+    // are multiplied by it first (1 / the scale of the data operand's tiles; the launchers set 1 when it is left 0)
+    int img_f16, mask_f16;
+    float img_scale, alpha;
+    float* img_amax;
     float* stats;              // STORE, optional: [gridDim.x][2][cols_valid] per-workgroup column (sum, sum of squares)
     // SOFTMAX_BWD (needs gridDim.y == gridDim.z == 1): out = dlogit~ with a = softmax(logits*scale + shift) recomputed
     const float* logits;       // [batch * rows_valid + row][cols_valid]
@@ -114,13 +126,14 @@ struct TileGemmArgs {
 
 // Launchers (defined in tile_gemm.hip, the only translation unit that instantiates the kernel).  nbatch * rb_per_batch
 // workgroup rows, ceil(cols / (128 NTW)) column blocks, `splits` reduction splits.
-// planes: 2 = split-bf16 operands (hi, lo), 1 = plain bf16 operands
+// planes: 2 = split-bf16 operands (hi, lo), 1 = plain bf16 operands, 3 = the fp16 two-product form (A fp16 (hi, lo) tiles, B fp16 hi-plane
+// tiles of 64 units per (tile, step); image epilogue of the 256-row form only)
 int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw = 0, int planes = 2);   // ntw 0 = by column count
 int tile_gemm_adam(const TileGemmArgs& g, hipStream_t stream, const char* what);      // 64 x 128 tiles, one batch, one split, split-bf16
 int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what, int planes = 2);
 int tile_gemm_ntw(int cols);
 // 256-row form with an image epilogue (g.img, g.img_kind, ...): one batch, one split, columns a multiple of 256, row tiles a multiple of 8
-int tile_gemm_image(const TileGemmArgs& g, hipStream_t stream, const char* what);
+int tile_gemm_image(const TileGemmArgs& g, hipStream_t stream, const char* what, int planes = 2);   // planes 3: the fp16 two-product form
 int tile_gemm_image_form();
 int tile_gemm_image_row_groups(int M);
 

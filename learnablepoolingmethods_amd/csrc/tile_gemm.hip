@@ -35,13 +35,16 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
     static_assert(RTW == 2 || (RTW == 4 && MW == 2 && EPI == TG_EPI_STORE && NS >= 4), "four row tiles per wave: pipelined 128-row form only");
     static_assert(MW == 1 || EPI == TG_EPI_STORE, "the 128-row form has the store epilogue only");
     static_assert(EPI != TG_EPI_ADAM || (NTW == 1 && PL == 2), "the Adam epilogue: 64 x 128 tiles of split-bf16 operands");
-    static_assert(PL == 1 || PL == 2, "planes");
+    static_assert(PL == 1 || PL == 2 || PL == 3, "planes");
+    static_assert(PL != 3 || (MW == 2 && RTW == 4 && EPI == TG_EPI_STORE && FORM == 0 && NS >= 4), "the fp16 two-product form: pipelined 256-row workgroups");
     // PL == 1: plain bf16 tiles, a ring stage = two reduction steps ("sub" below is the step within the stage where the split
     // form has the plane); no second operand pair.
+    // PL == 3 (round 5): fp16 operands, A = (hi, lo) planes, B = the hi plane only (64 units per (tile, step)): a . b = ah bh + al bh.
+    constexpr int PLB = PL == 3 ? 1 : 2;           // pieces per column tile and stage
     constexpr int NTB = 4 * NTW;                   // column tiles per workgroup
     constexpr int NWV = 4 * MW;                    // waves per workgroup
     constexpr int NRP = 2 * RTW * MW;              // row-tile pieces per stage (RTW MW tiles x 2 planes)
-    constexpr int NP = NRP + 2 * NTB;              // 1 KB pieces per stage
+    constexpr int NP = NRP + PLB * NTB;            // 1 KB pieces per stage
     constexpr int PW = NP / NWV;                   // pieces per wave per stage
     static_assert(NP % NWV == 0, "pieces must divide over the waves");
     constexpr int STAGE = NP * 1024;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
     const int split = blockIdx.z;
     const int step0 = split * g.steps_per_split;
     const int nred = min(g.steps_per_split, g.total_steps - step0);     // reduction steps of this split
-    const int nstep1 = PL == 2 ? nred : (nred + 1) / 2;                   // ring stages
+    const int nstep1 = PL >= 2 ? nred : (nred + 1) / 2;                   // ring stages
     const int nstep = nstep1 + (PL == 2 ? g.steps2 : 0);
 
     // this wave's PW pieces of a stage: piece p < 4: row tile p>>1, plane p&1;  else column tile (p-4)>>1, plane (p-4)&1
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
     for (int j = 0; j < PW; ++j) {
         const int p = wave + NWV * j;
         // split form: the piece's plane sits (p & 1) * 64 units into the (tile, step) pair; plain form: same tile, step + (p & 1)
-        const int pl = PL == 2 ? (p & 1) * 64 : 0;
+        const int pl = (PL == 2 || (PL == 3 && p < NRP)) ? (p & 1) * 64 : 0;
         sub[j] = p & 1;
         if (p < NRP) {
             if (MW == 1) {
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
             sstep[j] = g.a_step;
             sstep2[j] = g.a2_step;
         } else {
-            const int ct = cb * NTB + ((p - NRP) >> 1);
+            const int ct = cb * NTB + (PL == 3 ? (p - NRP) : ((p - NRP) >> 1));
             src[j] = g.b + batch * g.b_batch + min(ct, g.b_tiles - 1) * g.b_tile + step0 * g.b_step + pl + lane;
             sstep[j] = g.b_step;
             src2[j] = PL == 2 ? g.b2 + batch * g.b2_batch + min(ct, g.b2_tiles - 1) * g.b2_tile + pl + lane : nullptr;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
         for (int j = 0; j < PW; ++j) {
             // plain form: stage s = steps 2 s and 2 s + 1; past an odd end the piece re-reads the last step (its MFMA is skipped)
             const uint4* q = PL == 1 ? src[j] + (int64_t)min(2 * s + sub[j], nred - 1) * sstep[j]
-                                     : (second ? src2[j] + (s - nstep1) * sstep2[j] : src[j] + s * sstep[j]);
+                                     : ((PL == 2 && second) ? src2[j] + (s - nstep1) * sstep2[j] : src[j] + s * sstep[j]);
             // (default cache policy: the non-temporal policy was measured on both operands, alone and together -- LPM_TG_NT, round 4 --
             // and changed nothing for K1 and the wide dense shapes, +-5 % either way on the N = 1024 shapes)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
         // registers, everyone is done with step s - 1 -> stage (s - 1) % NS takes step s + NS - 1.  NS - 2 steps are in
         // flight behind the one being read.  (nstep >= NS is the launcher's condition.)
         static_assert(NS >= 4 && NS <= 6, "ring depth of the pipelined 128-row form");
-        struct Frag { tg_u32x4 ah[RTW], al[RTW], bh[NTW], bl[NTW]; };
+        struct Frag { tg_u32x4 ah[RTW], al[RTW], bh[NTW], bl[PL == 3 ? 1 : NTW]; };
         auto read_frags = [&](int s, Frag& fr) {
             const tg_u32x4* f = reinterpret_cast<const tg_u32x4*>(smem + (s % NS) * STAGE) + lane;
 #pragma unroll
@@ -294,8 +297,12 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
             }
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
-                fr.bh[n] = f[(NRP + (cw * NTW + n) * 2 + 0) * 64];
-                fr.bl[n] = f[(NRP + (cw * NTW + n) * 2 + 1) * 64];
+                if constexpr (PL == 3) {
+                    fr.bh[n] = f[(NRP + (cw * NTW + n)) * 64];
+                } else {
+                    fr.bh[n] = f[(NRP + (cw * NTW + n) * 2 + 0) * 64];
+                    fr.bl[n] = f[(NRP + (cw * NTW + n) * 2 + 1) * 64];
+                }
             }
         };
         auto body = [&](int s, Frag& cur, Frag& nxt) {
@@ -319,15 +326,16 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                 for (int n = 0; n < NTW; ++n)
 #pragma unroll
                     for (int m = 0; m < RTW; ++m) {
-                        if (PL == 2) acc[m][n] = tg_mfma(t == 2 ? cur.al[m] : cur.ah[m], t == 1 ? cur.bl[n] : cur.bh[n], acc[m][n]);
-                        else acc[m][n] = tg_mfma(t ? cur.al[m] : cur.ah[m], t ? cur.bl[n] : cur.bh[n], acc[m][n]);
+                        if constexpr (PL == 3) acc[m][n] = tg_mfma_f16(t ? cur.al[m] : cur.ah[m], cur.bh[n], acc[m][n]);
+                        else if (PL == 2) acc[m][n] = tg_mfma(t == 2 ? cur.al[m] : cur.ah[m], t == 1 ? cur.bl[n] : cur.bh[n], acc[m][n]);
+                        else acc[m][n] = tg_mfma(t ? cur.al[m] : cur.ah[m], t ? cur.bl[PL == 3 ? 0 : n] : cur.bh[n], acc[m][n]);
                     }
             };
             if (!(dbg & 8)) mfma_term(0);
             __builtin_amdgcn_sched_barrier(0);
             if (s + NS - 1 < nstep && !(dbg & 4)) issue(s + NS - 1);
             __builtin_amdgcn_sched_barrier(0);
-            if ((PL == 2 || 2 * s + 1 < nred) && !(dbg & 8)) mfma_term(1);
+            if ((PL >= 2 || 2 * s + 1 < nred) && !(dbg & 8)) mfma_term(1);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < nstep) read_frags(s + 1, nxt);
             __builtin_amdgcn_sched_barrier(0);
@@ -385,6 +393,9 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                 const int gcol = cb * NTB * 32 + c8;
                 const bool colok = gcol < N;
                 float bias8[8], colacc[8];
+                float vmax = 0.f;                                  // max |v| of what this thread writes (img_amax)
+                const float alpha = g.alpha;
+                const int64_t istride = of_row_stride(N, g.img_f16), mstride = of_row_stride(N, g.mask_f16);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; colacc[e] = 0.f; }
                 if (g.img_kind == 1 && colok) {
@@ -409,26 +420,34 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                             const int64_t R = (int64_t)tb * g.rows_valid + grow;
                             const float4 a0 = *reinterpret_cast<const float4*>(es + row * ESTR + c8);
                             const float4 a1 = *reinterpret_cast<const float4*>(es + row * ESTR + c8 + 4);
-                            float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                            float v[8] = {a0.x * alpha, a0.y * alpha, a0.z * alpha, a0.w * alpha, a1.x * alpha, a1.y * alpha, a1.z * alpha, a1.w * alpha};
                             if (g.img_kind == 1) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + bias8[e], 0.f);
                             } else {
-                                const uint4 hm = *reinterpret_cast<const uint4*>(g.img_mask + R * 3 * N + gcol);      // hi plane of the activation
+                                const uint4 hm = *reinterpret_cast<const uint4*>(g.img_mask + R * mstride + gcol);      // hi plane of the activation
                                 const unsigned mw[4] = {hm.x, hm.y, hm.z, hm.w};
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
                                     const unsigned ah = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-                                    const bool on = (ah != 0u) && !(ah & 0x8000u);                  // activation > 0
-                                    v[e] = on ? v[e] : 0.f;
+                                    v[e] = of_positive(ah) ? v[e] : 0.f;                            // activation > 0
                                     colacc[e] += v[e];
                                 }
                             }
+                            vmax = of_amax8(vmax, v);
                             uint4 hi, lo;
-                            tg_split8(v, hi, lo);
-                            unsigned short* rowp = g.img + R * 3 * N + gcol;
+                            of_split8(v, g.img_f16, g.img_scale, hi, lo);
+                            unsigned short* rowp = g.img + R * istride + gcol;
                             const tg_u32x4 hv = {hi.x, hi.y, hi.z, hi.w}, lv = {lo.x, lo.y, lo.z, lo.w};
-                            if (g.nt_store) {
+                            if (g.img_f16) {
+                                if (g.nt_store) {
+                                    __builtin_nontemporal_store(hv, reinterpret_cast<tg_u32x4*>(rowp));
+                                    __builtin_nontemporal_store(lv, reinterpret_cast<tg_u32x4*>(rowp + N));
+                                } else {
+                                    *reinterpret_cast<tg_u32x4*>(rowp) = hv;
+                                    *reinterpret_cast<tg_u32x4*>(rowp + N) = lv;
+                                }
+                            } else if (g.nt_store) {
                                 __builtin_nontemporal_store(hv, reinterpret_cast<tg_u32x4*>(rowp));
                                 __builtin_nontemporal_store(g.img_kind == 1 ? lv : hv, reinterpret_cast<tg_u32x4*>(rowp + N));
                                 __builtin_nontemporal_store(g.img_kind == 1 ? hv : lv, reinterpret_cast<tg_u32x4*>(rowp + 2 * (int64_t)N));
@@ -454,6 +473,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                     const int col = cb * NTB * 32 + tl;
                     if (col < N) g.img_colpart[(int64_t)(lid * MW + rg) * N + col] = sres;
                 }
+                of_amax_commit(g.img_amax, vmax);
                 return;
             }
         }
@@ -634,6 +654,28 @@ static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw, i
 // 2 = 128-row form with a 3-stage ring and two workgroups per CU, 3 = 256-row form (four row tiles per wave; no statistics)
 constexpr int TG_WIDE_NS_DEFAULT = 4;
 constexpr int TG_AP_DEFAULT = 0;
+// the fp16 two-product form (PL == 3): 256-row workgroups with the image epilogue only
+static int tg_launch_f16_image(const TileGemmArgs& g, hipStream_t stream, const char* what) {
+    if (!tg_wide_ok(g, 1, 1, 2, 3, 8)) {
+        set_error("%s: the fp16 image form needs row tiles a multiple of 8 and >= 16 reduction steps", what);
+        return LPM_ERR_UNSUPPORTED_SHAPE;
+    }
+    const int nt = (g.cols_valid + 31) / 32;
+    dim3 grid((unsigned)(g.a_tiles / 8), (unsigned)((nt + 7) / 8), 1u);
+    TileGemmArgs gl = g;
+    gl.dbg = 0;
+    gl.cols_inner = 0;
+    const size_t lds = (size_t)4 * (16 + 4 * 2) * 1024;           // 4 stages x (16 row-tile pieces + 8 column-tile hi planes)
+    auto kern = tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, 3, 4>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: cannot reserve %zu bytes of LDS", what, lds);
+        return LPM_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, gl);
+    return check_launch(what);
+}
+
 template <int EPI, int PL>
 static int tg_launch_pl(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw_override,
                         int timing_tag, int allow_wide) {
@@ -743,7 +785,7 @@ int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream,
     return tg_launch<TG_EPI_SOFTMAX_BWD>(g, nbatch, 1, stream, what, 0, 0, 0, planes);
 }
 int tile_gemm_ntw(int cols) { return tg_ntw(cols); }
-int tile_gemm_image(const TileGemmArgs& g, hipStream_t stream, const char* what) {
+int tile_gemm_image(const TileGemmArgs& g, hipStream_t stream, const char* what, int planes) {
     if (!g.img || (g.img_kind != 1 && g.img_kind != 2) || (g.img_kind == 1 && !g.img_bias) || (g.img_kind == 2 && (!g.img_mask || !g.img_colpart)) ||
         g.cols_valid % 256 != 0 || ((uintptr_t)g.img & 15) != 0 || g.stats || g.sumsq || g.accumulate) {
         set_error("%s: the image epilogue needs its operands, 16-byte aligned, and a multiple of 256 columns", what);
@@ -754,8 +796,15 @@ int tile_gemm_image(const TileGemmArgs& g, hipStream_t stream, const char* what)
         return LPM_ERR_UNSUPPORTED_SHAPE;
     }
     TileGemmArgs gl = g;
+    if (!(gl.alpha > 0.f)) gl.alpha = 1.f;
+    if (!(gl.img_scale > 0.f)) gl.img_scale = 1.f;
     gl.out = reinterpret_cast<float*>(g.img);      // (the fp32 output checks of the launcher: an aligned non-null pointer; never written)
     gl.ldo = 4; gl.out_batch = 0; gl.out_split = 0;
+    if (planes == 3) {
+        static const int nt3 = [] { const char* e = getenv("LPM_DENSE_IMG_NT"); return (e && e[0] == '0') ? 0 : 1; }();
+        gl.nt_store = nt3;
+        return tg_launch_f16_image(gl, stream, what);
+    }
     // non-temporal stores: the 0.5 GB image is read back by the next GEMM long after it has left the caches (-6 us of 520 measured;
     // LPM_DENSE_IMG_NT=0: plain stores, A/B)
     static const int nt = [] { const char* e = getenv("LPM_DENSE_IMG_NT"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -771,9 +820,10 @@ int tile_gemm_image_row_groups(int M) { return tile_gemm_image_form() == 3 ? M /
 
 // [B*T, C] fp32 (row stride ldx) -> row tiles [b][mt][cs][plane][lane]; mt < 2*ceil(T/64), rows >= T are zero.
 __global__ __launch_bounds__(256) void split_rows_tiles_kernel(const float* __restrict__ x, int64_t ldx, int B, int T, int C, int MT,
-                                                               uint4* __restrict__ out) {
+                                                               uint4* __restrict__ out, const OperandFmt fmt) {
     const int CS = C / 16;
     const int64_t total = (int64_t)B * MT * CS * 64;
+    float vmax = 0.f;
     for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
         const int lane = (int)(w & 63);
         int64_t t = w >> 6;
@@ -788,15 +838,18 @@ __global__ __launch_bounds__(256) void split_rows_tiles_kernel(const float* __re
             const float4 q = *reinterpret_cast<const float4*>(p + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
         }
+        vmax = of_amax8(vmax, v);
         uint4 hi, lo;
-        tg_split8(v, hi, lo);
+        of_split8(v, fmt.f16, fmt.scale, hi, lo);
         const int64_t base = (w >> 6) * 128 + lane;
         out[base] = hi;
         out[base + 64] = lo;
     }
+    of_amax_commit(fmt.amax, vmax);
 }
 
 // B operand of M[R, N] (reduction R, columns N): [rs][nt][plane][lane].  transposed: the source is stored [N, R].
+// planes 2: split-bf16 (hi, lo); 1: plain bf16; 3: fp16, the hi plane only (the weight operand of the two-product form, rounded once)
 __global__ __launch_bounds__(256) void split_weight_tiles_kernel(const float* __restrict__ W, int R, int N, int transposed,
                                                                  uint4* __restrict__ wt, int planes) {
     const int RS = R / 16, NT = (N + 31) / 32;
@@ -810,6 +863,10 @@ __global__ __launch_bounds__(256) void split_weight_tiles_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             v[e] = (col < N) ? (transposed ? W[(int64_t)col * R + r + e] : W[(int64_t)(r + e) * N + col]) : 0.f;
+        if (planes == 3) {
+            wt[t * 64 + lane] = make_uint4(of_round2_f16(v[0], v[1]), of_round2_f16(v[2], v[3]), of_round2_f16(v[4], v[5]), of_round2_f16(v[6], v[7]));
+            continue;
+        }
         uint4 hi, lo;
         tg_split8(v, hi, lo);
         if (planes == 1) {
@@ -930,22 +987,34 @@ __global__ __launch_bounds__(256) void tg_reduce_splits_kernel(const float4* __r
 // outs[i][k][c] = sum_z part[z][k][i * (N / nouts) + c]: the split-K partial sums of a weight-gradient GEMM [Z, K, N] added in slice order
 // straight into up to three destination matrices [K, N / nouts] (the q | k | v kernels' gradient slots: one launch instead of three
 // strided reductions).  float4 granularity; thread = one float4 of one destination row.
-struct SumSplitsArgs { const float* part; float* out[3]; int Z, K, N, nouts; };
+// halves == 2 (the fp16 two-product form, dW = xh^T [dyh | dyl]): part is [Z, K, 2 N], the lo half's products N columns to the right;
+// per slice hi + lo, slices in order, then * alpha (1 / the operands' scales, a power of two: exact).
+struct SumSplitsArgs { const float* part; float* out[3]; int Z, K, N, nouts, halves; float alpha; };
 __global__ __launch_bounds__(256) void sum_splits_kernel(const SumSplitsArgs a) {
     const int Nb = a.N / a.nouts, Nb4 = Nb / 4;
     const int64_t per = (int64_t)a.K * Nb4, total = per * a.nouts;
-    const int64_t zstride = (int64_t)a.K * a.N;
+    const int64_t ldp = (int64_t)a.N * a.halves;
+    const int64_t zstride = (int64_t)a.K * ldp;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int o = (int)(i / per);
         const int64_t r = i - (int64_t)o * per;
         const int64_t k = r / Nb4;
         const int c = (int)(r - k * Nb4) * 4;
-        const float* p = a.part + k * a.N + (int64_t)o * Nb + c;
+        const float* p = a.part + k * ldp + (int64_t)o * Nb + c;
         float4 s = *reinterpret_cast<const float4*>(p);
-        for (int z = 1; z < a.Z; ++z) {
-            const float4 q = *reinterpret_cast<const float4*>(p + z * zstride);
+        if (a.halves == 2) {
+            const float4 q = *reinterpret_cast<const float4*>(p + a.N);
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
+        for (int z = 1; z < a.Z; ++z) {
+            float4 q = *reinterpret_cast<const float4*>(p + z * zstride);
+            if (a.halves == 2) {
+                const float4 q2 = *reinterpret_cast<const float4*>(p + z * zstride + a.N);
+                q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w;
+            }
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+        if (a.alpha != 1.f) { s.x *= a.alpha; s.y *= a.alpha; s.z *= a.alpha; s.w *= a.alpha; }
         *reinterpret_cast<float4*>(a.out[o] + k * Nb + c) = s;
     }
 }
@@ -960,7 +1029,7 @@ __global__ __launch_bounds__(1024) void tg_colsum_reduce_kernel(const float* __r
 
 // split-bf16 operand image [M][3K] (split_gemm.hip; lo plane lo_off elements into the row) -> row tiles [mt][cs][plane][lane]
 __global__ __launch_bounds__(256) void image_row_tiles_kernel(const unsigned short* __restrict__ x3, int64_t M, int K, int lo_off, int MT,
-                                                              uint4* __restrict__ out) {
+                                                              uint4* __restrict__ out, int planes) {
     const int CS = K / 16;
     const int64_t total = (int64_t)MT * CS * 64;
     for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
@@ -971,7 +1040,7 @@ __global__ __launch_bounds__(256) void image_row_tiles_kernel(const unsigned sho
         const int c = cs * 16 + 8 * (lane >> 5);
         uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
         if (row < M) {
-            const unsigned short* p = x3 + row * 3 * K + c;
+            const unsigned short* p = x3 + row * planes * K + c;
             hi = *reinterpret_cast<const uint4*>(p);
             lo = *reinterpret_cast<const uint4*>(p + lo_off);
         }
@@ -999,17 +1068,22 @@ static inline int dw_splits(int B, int T, int D, int K, int planes = 2) {
 // Split-K partial sums of a weight-gradient product [Z, K, N] (what a batched library GEMM over Z slices of a long reduction leaves) ->
 // the gradient, added in slice order, written straight into up to three [K, N / nouts] destinations (the column blocks of a concatenated
 // weight: q | k | v): TF autodiff of tf.layers.dense at transformer_utils.py:559-561,583,701-711.  N / nouts a multiple of 4.
-extern "C" int lpm_sum_splits(const float* part, int Z, int K, int N, float* out0, float* out1, float* out2, int nouts, lpm_stream_t stream) {
+extern "C" int lpm_sum_splits_scaled(const float* part, int Z, int K, int N, int halves, float alpha, float* out0, float* out1, float* out2,
+                                     int nouts, lpm_stream_t stream) {
     using namespace lpm;
-    LPM_REQUIRE(part && out0 && Z >= 1 && K > 0 && N > 0 && nouts >= 1 && nouts <= 3, LPM_ERR_BADARG, "lpm_sum_splits: bad arguments");
+    LPM_REQUIRE(part && out0 && Z >= 1 && K > 0 && N > 0 && nouts >= 1 && nouts <= 3 && (halves == 1 || halves == 2) && alpha > 0.f, LPM_ERR_BADARG,
+                "lpm_sum_splits: bad arguments");
     LPM_REQUIRE(N % nouts == 0 && (N / nouts) % 4 == 0 && (nouts < 2 || out1) && (nouts < 3 || out2), LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_sum_splits: N / nouts must be a multiple of 4 and every destination given (N=%d nouts=%d)", N, nouts);
     LPM_REQUIRE((((uintptr_t)part | (uintptr_t)out0 | (uintptr_t)out1 | (uintptr_t)out2) & 15) == 0, LPM_ERR_BADARG, "lpm_sum_splits: 16-byte aligned pointers");
-    SumSplitsArgs a{part, {out0, out1, out2}, Z, K, N, nouts};
+    SumSplitsArgs a{part, {out0, out1, out2}, Z, K, N, nouts, halves, alpha};
     const int64_t total = (int64_t)K * (N / 4);
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("lpm_sum_splits");
+}
+extern "C" int lpm_sum_splits(const float* part, int Z, int K, int N, float* out0, float* out1, float* out2, int nouts, lpm_stream_t stream) {
+    return lpm_sum_splits_scaled(part, Z, K, N, 1, 1.f, out0, out1, out2, nouts, stream);
 }
 
 extern "C" size_t lpm_row_tiles_bytes(int B, int T, int C) {
@@ -1022,15 +1096,20 @@ extern "C" int lpm_assign_gemm_tiles_supported(int T, int D, int K) {
 }
 
 extern "C" int lpm_split_rows_tiles(const float* x, int64_t ldx, int B, int T, int C, void* out, lpm_stream_t stream) {
+    return lpm_split_rows_tiles_fmt(x, ldx, B, T, C, out, nullptr, stream);
+}
+extern "C" int lpm_split_rows_tiles_fmt(const float* x, int64_t ldx, int B, int T, int C, void* out, const LpmOperandFormat* fmt,
+                                        lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(x && out, LPM_ERR_BADARG, "lpm_split_rows_tiles: null pointer");
+    if (const int rc = operand_fmt_check(fmt, "lpm_split_rows_tiles")) return rc;
     LPM_REQUIRE(B > 0 && T > 0 && C > 0 && C % 16 == 0 && ldx >= C && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0,
                 LPM_ERR_UNSUPPORTED_SHAPE, "lpm_split_rows_tiles: need C %% 16 == 0, ldx %% 4 == 0, aligned pointers (C=%d)", C);
     const int MT = row_tiles_per_clip(T);
     const int64_t total = (int64_t)B * MT * (C / 16) * 64;
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(split_rows_tiles_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       B, T, C, MT, (uint4*)out);
+                       B, T, C, MT, (uint4*)out, operand_fmt(fmt));
     return check_launch("lpm_split_rows_tiles");
 }
 
@@ -1073,6 +1152,10 @@ extern "C" int lpm_split_weight_tiles(const float* w, int R, int N, int transpos
 }
 extern "C" int lpm_split_weight_tiles_bf16(const float* w, int R, int N, int transposed, void* wt, lpm_stream_t stream) {
     return split_weight_tiles_impl(w, R, N, transposed, wt, 1, stream);
+}
+extern "C" int lpm_split_weight_tiles_fmt(const float* w, int R, int N, int transposed, void* wt, int kind, lpm_stream_t stream) {
+    LPM_REQUIRE(kind == LPM_OPERAND_BF16X3 || kind == LPM_OPERAND_FP16X2, LPM_ERR_BADARG, "lpm_split_weight_tiles_fmt: unknown operand format %d", kind);
+    return split_weight_tiles_impl(w, R, N, transposed, wt, kind == LPM_OPERAND_FP16X2 ? 3 : 2, stream);
 }
 
 static int assign_gemm_tiles_fwd_impl(const void* xr, const void* wt, int B, int T, int D, int K, void* logits, float* partial,
@@ -1144,15 +1227,30 @@ static void dense_tiles_args(lpm::TileGemmArgs& g, const void* ar, const void* b
 // out3 [M, 3N] bf16 = the activation image [hi | lo | hi] of relu(x . w + bias); xr: row tiles of x [M, Kd], wt: weight tiles of w [Kd, N]
 extern "C" int lpm_dense_tiles_act_image_fwd(const void* xr, const void* wt, const float* bias, int M, int Kd, int N, void* out3,
                                              lpm_stream_t stream) {
+    return lpm_dense_tiles_act_image_fwd_fmt(xr, wt, bias, M, Kd, N, 1.f, out3, nullptr, stream);
+}
+static void dense_tiles_fmt(lpm::TileGemmArgs& g, const LpmOperandFormat* fmt, float in_inv_scale, int N) {
+    const lpm::OperandFmt f = lpm::operand_fmt(fmt);
+    g.img_f16 = f.f16; g.img_scale = f.scale; g.img_amax = f.amax; g.alpha = in_inv_scale;
+    if (f.f16) {                                   // the weight operand: hi-plane tiles of 64 units
+        const int NT = N / 32;
+        g.b_tile = 64; g.b_step = (int64_t)NT * 64;
+    }
+}
+extern "C" int lpm_dense_tiles_act_image_fwd_fmt(const void* xr, const void* wt, const float* bias, int M, int Kd, int N, float in_inv_scale,
+                                                 void* out3, const LpmOperandFormat* fmt, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(xr && wt && bias && out3, LPM_ERR_BADARG, "lpm_dense_tiles_act_image_fwd: null pointer");
+    if (const int rc = operand_fmt_check(fmt, "lpm_dense_tiles_act_image_fwd")) return rc;
+    LPM_REQUIRE(in_inv_scale > 0.f, LPM_ERR_BADARG, "lpm_dense_tiles_act_image_fwd: in_inv_scale must be positive");
     LPM_REQUIRE(lpm_dense_tiles_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_dense_tiles_act_image_fwd: need M %% 256 == 0, Kd %% 16 == 0, Kd >= 256, N %% 256 == 0 (M=%d Kd=%d N=%d)", M, Kd, N);
     LPM_REQUIRE(((uintptr_t)bias & 15) == 0, LPM_ERR_BADARG, "lpm_dense_tiles_act_image_fwd: bias must be 16-byte aligned");
     TileGemmArgs g{};
     dense_tiles_args(g, xr, wt, M, Kd, N);
     g.img = (unsigned short*)out3; g.img_kind = 1; g.img_bias = bias;
-    return tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_act_image_fwd");
+    dense_tiles_fmt(g, fmt, in_inv_scale, N);
+    return tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_act_image_fwd", g.img_f16 ? 3 : 2);
 }
 extern "C" size_t lpm_dense_tiles_relu_bwd_workspace_bytes(int M, int N) { return (size_t)((M + 63) / 64) * N * sizeof(float); }
 // g = (dy . w^T) masked by [act > 0]: out3 [M, 3N] bf16 = its gradient image [hi | hi | lo], dbias [N] = its column sums.
@@ -1160,8 +1258,16 @@ extern "C" size_t lpm_dense_tiles_relu_bwd_workspace_bytes(int M, int N) { retur
 // act3 [M, 3N]: the forward's activation image (lpm_dense_tiles_act_image_fwd's output).
 extern "C" int lpm_dense_tiles_relu_bwd_image(const void* dyr, const void* wtt, const void* act3, int M, int Kd, int N, void* out3,
                                               float* dbias, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    return lpm_dense_tiles_relu_bwd_image_fmt(dyr, wtt, act3, LPM_OPERAND_BF16X3, M, Kd, N, 1.f, out3, dbias, workspace, workspace_bytes, nullptr, stream);
+}
+extern "C" int lpm_dense_tiles_relu_bwd_image_fmt(const void* dyr, const void* wtt, const void* act3, int act_kind, int M, int Kd, int N,
+                                                  float in_inv_scale, void* out3, float* dbias, void* workspace, size_t workspace_bytes,
+                                                  const LpmOperandFormat* fmt, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(dyr && wtt && act3 && out3 && dbias && workspace, LPM_ERR_BADARG, "lpm_dense_tiles_relu_bwd_image: null pointer");
+    if (const int rc = operand_fmt_check(fmt, "lpm_dense_tiles_relu_bwd_image")) return rc;
+    LPM_REQUIRE(in_inv_scale > 0.f && (act_kind == LPM_OPERAND_BF16X3 || act_kind == LPM_OPERAND_FP16X2), LPM_ERR_BADARG,
+                "lpm_dense_tiles_relu_bwd_image: bad in_inv_scale / act_kind");
     LPM_REQUIRE(lpm_dense_tiles_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_dense_tiles_relu_bwd_image: need M %% 256 == 0, Kd %% 16 == 0, Kd >= 256, N %% 256 == 0 (M=%d Kd=%d N=%d)", M, Kd, N);
     LPM_REQUIRE(workspace_bytes >= lpm_dense_tiles_relu_bwd_workspace_bytes(M, N), LPM_ERR_WORKSPACE,
@@ -1170,7 +1276,9 @@ extern "C" int lpm_dense_tiles_relu_bwd_image(const void* dyr, const void* wtt, 
     TileGemmArgs g{};
     dense_tiles_args(g, dyr, wtt, M, Kd, N);
     g.img = (unsigned short*)out3; g.img_kind = 2; g.img_mask = (const unsigned short*)act3; g.img_colpart = (float*)workspace;
-    const int rc = tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_relu_bwd_image");
+    dense_tiles_fmt(g, fmt, in_inv_scale, N);
+    g.mask_f16 = act_kind == LPM_OPERAND_FP16X2 ? 1 : 0;
+    const int rc = tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_relu_bwd_image", g.img_f16 ? 3 : 2);
     if (rc != LPM_OK) return rc;
     hipLaunchKernelGGL(tg_colsum_reduce_kernel, dim3((unsigned)((N + 15) / 16)), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace,
                        tile_gemm_image_row_groups(M), N, dbias);
@@ -1179,7 +1287,11 @@ extern "C" int lpm_dense_tiles_relu_bwd_image(const void* dyr, const void* wtt, 
 // x3 [M, 3K] split-bf16 operand image (order 0: activation planes [hi | lo | hi], 1: gradient planes [hi | hi | lo]) -> row tiles of the
 // matrix (lpm_row_tiles_bytes(1, M, K)): the tile GEMM's A operand from a tensor that exists only as its image
 extern "C" int lpm_image_row_tiles(const void* x3, int M, int K, int order, void* out, lpm_stream_t stream) {
+    return lpm_image_row_tiles_fmt(x3, M, K, order, out, LPM_OPERAND_BF16X3, stream);
+}
+extern "C" int lpm_image_row_tiles_fmt(const void* x3, int M, int K, int order, void* out, int kind, lpm_stream_t stream) {
     using namespace lpm;
+    LPM_REQUIRE(kind == LPM_OPERAND_BF16X3 || kind == LPM_OPERAND_FP16X2, LPM_ERR_BADARG, "lpm_image_row_tiles: unknown operand format %d", kind);
     LPM_REQUIRE(x3 && out, LPM_ERR_BADARG, "lpm_image_row_tiles: null pointer");
     LPM_REQUIRE(M > 0 && K > 0 && K % 16 == 0 && (((uintptr_t)x3 | (uintptr_t)out) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_image_row_tiles: need K %% 16 == 0 and 16-byte aligned pointers (K=%d)", K);
@@ -1187,7 +1299,8 @@ extern "C" int lpm_image_row_tiles(const void* x3, int M, int K, int order, void
     const int64_t total = (int64_t)MT * (K / 16) * 64;
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(image_row_tiles_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x3, (int64_t)M, K, order ? 2 * K : K, MT, (uint4*)out);
+                       (const unsigned short*)x3, (int64_t)M, K, (kind == LPM_OPERAND_BF16X3 && order) ? 2 * K : K, MT, (uint4*)out,
+                       kind == LPM_OPERAND_FP16X2 ? 2 : 3);
     return check_launch("lpm_image_row_tiles");
 }
 

@@ -1162,17 +1162,163 @@ def vlad_aggregate(sims, x, centres, max_frames, kmajor=False, lazy=False):
 # ----------------------------------------------------------------------------------------------
 # dense layers of the encoders on the bf16 matrix pipe at fp32-grade accuracy (split-bf16 operands)
 # ----------------------------------------------------------------------------------------------
-def _split_rows(x2d, bias=None, relu=False, grad=False, row_scale=None):
+class OperandSite:
+    """One operand of one dense layer (its input activation, or the gradient of its output) in the step that is running: the operand
+    format its producer writes and what its consumers undo.  f16: the fp16 two-product format (csrc/operand_format.h) with the
+    power-of-two ``scale`` (``inv`` = 1 / scale); otherwise split-bf16 x3, scale 1.  Either way the producer records max |x| into the
+    site's slot of OperandScales.amax (``fmt`` = the address of the LpmOperandFormat the library reads)."""
+    __slots__ = ("f16", "scale", "inv", "struct", "fmt", "planes", "dtype")
+
+    def __init__(self, f16, scale, amax_ptr):
+        self.f16 = bool(f16)
+        self.scale = float(scale) if f16 else 1.0
+        self.inv = 1.0 / self.scale
+        self.struct = _capi.OperandFormat(_capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3, self.scale, amax_ptr)
+        self.fmt = C.c_void_p(C.addressof(self.struct))
+        self.planes = 2 if f16 else 3
+        self.dtype = torch.float16 if f16 else torch.bfloat16
+
+
+class OperandScales:
+    """Delayed power-of-two scales for the fp16 two-product operand format (the recipe of fp8 training: the scale of
+    step t comes from the max |x| the producers MEASURED at earlier steps).
+
+    Every operand image of NetVladV1's encoder GEMMs has a site (``site(key)``); its producer -- a split pass, a layer norm, the
+    attention kernels, a tile GEMM's epilogue -- records max |x| into ``amax[slot]`` in BOTH formats.  ``begin_step`` (trainer, before
+    the forward): harvests the read-backs that have completed (never waits), queues the read-back of the step that just ended
+    (device -> pinned host copy + event, then zeroes the buffer: stream order puts it behind that step's kernels), and decides the
+    step's format: fp16x2 when every site that exists has been measured at least once since it was first used, else split-bf16 x3
+    (the first steps of a run, a model that grew a layer) -- a step never mixes formats.  The scale puts the larger of the last two
+    measured maxima at 2^TARGET: [2^10, 2^11), a factor 32 below fp16's largest value for growth between measurement and use (beyond
+    it values saturate at +-65504, finite) and 2^24 above the smallest normal fp16 number; fp16 subnormals are kept by the matrix
+    cores (tools/fp16_probe.py), so (hi, lo) degrades gracefully into fixed point below that.
+    ``calibrate`` (tests, short runs): measure synchronously from one forward + backward that the caller runs in split-bf16."""
+    MAX_SITES = 256
+    TARGET = 10
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.amax = torch.zeros(self.MAX_SITES, dtype=torch.float32, device=self.device)
+        self.slots = {}
+        self.first_step = []                 # slot -> id of the step it was first asked for in
+        self.hist = [[0.0] * self.MAX_SITES, [0.0] * self.MAX_SITES]      # the last two harvested measurements per slot
+        self.measured = -1                   # id of the newest step whose measurement the host holds
+        self.step = -1                       # id of the running step
+        self.pending = []                    # [(step id, pinned tensor, event)] read-backs in flight, oldest first
+        self.RING = 12                       # pinned read-back buffers + events, allocated once (a pinned allocation costs ~1 ms)
+        self._ring = None
+        self._ring_next = 0
+        self.fp16_now = False
+        self.sites = {}                      # key -> OperandSite of the running step
+        self.enabled = True
+        self.steps_fp16 = 0
+        self.saturation_margin = None        # diagnostics: min over sites of 65504 / (scale * newest amax)
+
+    def _harvest(self, wait=False):
+        while self.pending:
+            sid, host, ev = self.pending[0]
+            if not wait and not ev.query():
+                break
+            if wait:
+                ev.synchronize()
+            vals = host.tolist()
+            self.hist[0], self.hist[1] = self.hist[1], vals
+            self.measured = sid
+            self.pending.pop(0)
+
+    def begin_step(self):
+        self._harvest()
+        if self.step >= 0:                   # the step that just ended: its maxima go home behind its kernels
+            if self._ring is None:
+                self._ring = [(torch.empty(self.MAX_SITES, dtype=torch.float32, pin_memory=True), torch.cuda.Event()) for _ in range(self.RING)]
+            if len(self.pending) >= self.RING - 1:   # the host is a ring ahead of the device: wait for the oldest read-back
+                self._harvest_one_blocking()
+            host, ev = self._ring[self._ring_next]
+            self._ring_next = (self._ring_next + 1) % self.RING
+            host.copy_(self.amax, non_blocking=True)
+            ev.record()
+            self.amax.zero_()
+            self.pending.append((self.step, host, ev))
+        self.step += 1
+        self.sites = {}
+        self.fp16_now = bool(self.enabled and self.slots and all(fs <= self.measured for fs in self.first_step))
+        if self.fp16_now:
+            self.steps_fp16 += 1
+
+    def _harvest_one_blocking(self):
+        sid, host, ev = self.pending.pop(0)
+        ev.synchronize()
+        self.hist[0], self.hist[1] = self.hist[1], host.tolist()
+        self.measured = sid
+
+    def calibrate_from_device(self):
+        """Synchronous: the maxima recorded since the last begin_step become the measurement of the running step (tests / the first
+        step of a run: Trainer.calibrate_operand_scales)."""
+        torch.cuda.synchronize(self.device)
+        self._harvest(wait=True)
+        vals = self.amax.tolist()
+        self.hist[0], self.hist[1] = vals, vals
+        self.measured = self.step
+        self.amax.zero_()
+
+    def _scale_of(self, slot):
+        import math
+        a = max(self.hist[0][slot], self.hist[1][slot])
+        if not (a > 0.0) or math.isinf(a) or math.isnan(a):
+            return 1.0
+        return 2.0 ** (self.TARGET - math.floor(math.log2(a)))
+
+    def site(self, key):
+        st = self.sites.get(key)
+        if st is not None:
+            return st
+        slot = self.slots.get(key)
+        if slot is None:
+            slot = len(self.slots)
+            if slot >= self.MAX_SITES:
+                raise LpmError("OperandScales: more operand sites than slots")
+            self.slots[key] = slot
+            self.first_step.append(self.step)
+        # (a site that appears for the first time INSIDE an fp16 step -- a code path the earlier steps did not take -- runs that step in
+        # fp16 with scale 1: a step never mixes formats, and the site is measured from here on)
+        f16 = self.fp16_now
+        st = OperandSite(f16, self._scale_of(slot) if (f16 and self.first_step[slot] <= self.measured) else 1.0,
+                         self.amax.data_ptr() + 4 * slot)
+        self.sites[key] = st
+        return st
+
+    def report(self):
+        """{key: (newest measured max |x|, the scale it gives)} -- diagnostics / DESIGN's table."""
+        return {k: (self.hist[1][sl], self._scale_of(sl)) for k, sl in self.slots.items()}
+
+
+_ACTIVE_SCALES = None    # the OperandScales of the trainer whose step is running (train.Trainer.step; NetVladV1 with FLAGS.dense_arithmetic = "fp16x2"), else None
+
+
+def _site(role, W):
+    """The operand site (role "a": the layer's input activation, "g": the gradient of its output) of the dense layer with kernel W in the
+    running step, or None outside a trainer's step / for a model that stays on split-bf16 x3."""
+    sc = _ACTIVE_SCALES
+    if sc is None or W is None:
+        return None
+    return sc.site((role, W.data_ptr()))
+
+
+def _f16(site):
+    return site is not None and site.f16
+
+
+def _split_rows(x2d, bias=None, relu=False, grad=False, row_scale=None, site=None):
     """[M,K] fp32 -> [M,3K] bf16 = [hi | lo | hi] (optionally of relu(x + bias)); grad=True: the gradient plane order
-    [hi | hi | lo] that pairs with w3k (rows [Wh|Wl|Wh]) and, row by row, with an activation image (see _dw_x3)."""
+    [hi | hi | lo] that pairs with w3k (rows [Wh|Wl|Wh]) and, row by row, with an activation image (see _dw_x3).
+    site (OperandSite): the image in the site's format -- fp16x2: [M,2K] fp16 = [hi | lo] of x * site.scale -- and max |x| recorded.
+    row_scale: x2d = the rows of a lazily normalised descriptor (netvlad(lazy=True)), scaled as they are read."""
     lib = _capi.load()
     M, K = x2d.shape
-    out = torch.empty((M, 3 * K), dtype=torch.bfloat16, device=x2d.device)
-    if row_scale is not None:       # x2d = the rows of a lazily normalised descriptor (netvlad(lazy=True)): scaled as they are read
-        lib.check(lib._lpm_split_rows_scaled(ptr(x2d), x2d.stride(0), M, K, ptr(row_scale), ptr(out), stream_ptr()), "lpm_split_rows_scaled")
-        return out
-    lib.check(lib._lpm_split_rows(ptr(x2d), x2d.stride(0), M, K, ptr(bias), 1 if relu else 0, 1 if grad else 0, ptr(out),
-                                  stream_ptr()), "lpm_split_rows")
+    f16 = _f16(site)
+    out = torch.empty((M, (2 if f16 else 3) * K), dtype=torch.float16 if f16 else torch.bfloat16, device=x2d.device)
+    lib.check(lib._lpm_split_rows_fmt(ptr(x2d), x2d.stride(0), M, K, ptr(bias), 1 if relu else 0, 1 if grad else 0, ptr(row_scale), ptr(out),
+                                      site.fmt if site is not None else None, stream_ptr()), "lpm_split_rows")
     return out
 
 
@@ -1203,30 +1349,41 @@ class WeightPack:
             return
         lib = _capi.load()
         jobs, keep = [], []
+        fp16_now = _ACTIVE_SCALES is not None and _ACTIVE_SCALES.fp16_now
         for key, e in self.plan.items():
             srcs, need = e["srcs"], e["need"]
             if not need or not all(self._ok(w) for w in srcs) or len({w.shape[0] for w in srcs}) != 1:
                 continue
+            # a weight asked for in both operand formats (the fp16 two-product steps of NetVladV1 follow a few split-bf16 ones): only the
+            # forms of the format this step runs in
+            need16 = {f for f in need if f.endswith("16")}
+            f16 = bool(fp16_now and need16)
+            need = need16 if f16 else (need - need16)
+            if not need:
+                continue
+            sfx = "16" if f16 else ""
+            pl, dt, tdiv = (2, torch.float16, 2) if f16 else (3, torch.bfloat16, 1)
             K = srcs[0].shape[0]
             Ntot = sum(w.shape[1] for w in srcs)
             dev = srcs[0].device
             out = {}
-            if "n" in need:
-                out["n"] = torch.empty((Ntot, 3 * K), dtype=torch.bfloat16, device=dev)
-            if "k" in need:
-                out["k"] = torch.empty((K, 3 * Ntot), dtype=torch.bfloat16, device=dev)
-            if "wt" in need:
-                out["wt"] = torch.empty(lib._lpm_weight_tiles_bytes(K, Ntot) // 4, dtype=torch.int32, device=dev)
-            if "wtt" in need and len(srcs) == 1:
-                out["wtt"] = torch.empty(lib._lpm_weight_tiles_bytes(Ntot, K) // 4, dtype=torch.int32, device=dev)
+            if "n" + sfx in need:
+                out["n" + sfx] = torch.empty((Ntot, pl * K), dtype=dt, device=dev)
+            if "k" + sfx in need:
+                out["k" + sfx] = torch.empty((K, pl * Ntot), dtype=dt, device=dev)
+            if "wt" + sfx in need:
+                out["wt" + sfx] = torch.empty(lib._lpm_weight_tiles_bytes(K, Ntot) // 4 // tdiv, dtype=torch.int32, device=dev)
+            if "wtt" + sfx in need and len(srcs) == 1:
+                out["wtt" + sfx] = torch.empty(lib._lpm_weight_tiles_bytes(Ntot, K) // 4 // tdiv, dtype=torch.int32, device=dev)
             off = 0
             for w in srcs:
                 j = _capi.WeightPackJob()
                 j.w, j.K, j.N, j.ldw, j.Ntot, j.n_off = w.data_ptr(), K, w.shape[1], w.stride(0), Ntot, off
-                j.w3n = out["n"].data_ptr() if "n" in out else None
-                j.w3k = out["k"].data_ptr() if "k" in out else None
-                j.wt = out["wt"].data_ptr() if "wt" in out else None
-                j.wtt = out["wtt"].data_ptr() if "wtt" in out else None
+                j.w3n = out["n" + sfx].data_ptr() if "n" + sfx in out else None
+                j.w3k = out["k" + sfx].data_ptr() if "k" + sfx in out else None
+                j.wt = out["wt" + sfx].data_ptr() if "wt" + sfx in out else None
+                j.wtt = out["wtt" + sfx].data_ptr() if "wtt" + sfx in out else None
+                j.kind = _capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3
                 jobs.append(j)
                 off += w.shape[1]
             self.ready[key] = out
@@ -1301,45 +1458,59 @@ def _packed(srcs, forms):
     return _ACTIVE_PACK.take(srcs, forms) if _ACTIVE_PACK is not None else None
 
 
-def _weight_tiles(W, R, N, transposed, like, pack=True):
-    """lpm_split_weight_tiles(W, R, N, transposed) -- from the step's weight pack when it holds the form."""
+def _weight_tiles(W, R, N, transposed, like, pack=True, f16=False):
+    """lpm_split_weight_tiles(W, R, N, transposed) -- from the step's weight pack when it holds the form.  f16: the fp16 two-product
+    format's weight tiles (the hi plane only: half the bytes)."""
     lib = _capi.load()
-    got = _packed([W], ["wtt" if transposed else "wt"]) if pack else None
+    form = ("wtt" if transposed else "wt") + ("16" if f16 else "")
+    got = _packed([W], [form]) if pack else None
     if got is not None:
-        return got["wtt" if transposed else "wt"]
-    wt = _tile_buffer(lib._lpm_weight_tiles_bytes(R, N), like)
-    lib.check(lib._lpm_split_weight_tiles(ptr(W), R, N, 1 if transposed else 0, ptr(wt), stream_ptr()), "lpm_split_weight_tiles")
+        return got[form]
+    wt = _tile_buffer(lib._lpm_weight_tiles_bytes(R, N) // (2 if f16 else 1), like)
+    lib.check(lib._lpm_split_weight_tiles_fmt(ptr(W), R, N, 1 if transposed else 0, ptr(wt),
+                                              _capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3, stream_ptr()), "lpm_split_weight_tiles")
     return wt
 
 
-def _split_weight_cat(Ws, need_t=True):
+def _split_weight_cat(Ws, need_t=True, f16=False):
     """_split_weight of the concatenation of Ws along the columns (q | k | v) -- without forming it when the weight pack has the images."""
-    got = _packed(list(Ws), ["n", "k"] if need_t else ["n"])
+    fn, fk = ("n16", "k16") if f16 else ("n", "k")
+    got = _packed(list(Ws), [fn, fk] if need_t else [fn])
     if got is not None:
-        return got["n"], got.get("k")
-    return _split_weight(torch.cat([_f32(w, "kernel") for w in Ws], dim=1), need_t, pack=False)
+        return got[fn], got.get(fk)
+    return _split_weight(torch.cat([_f32(w, "kernel") for w in Ws], dim=1), need_t, pack=False, f16=f16)
 
 
-def _split_weight(W, need_t=True, pack=True):
-    """[K,N] fp32 -> w3n [N,3K] (rows [Wh^T|Wh^T|Wl^T]: y = X3 w3n^T) and w3k [K,3N] (rows [Wh|Wl|Wh]: dx = DY3 w3k^T), bf16."""
+def _split_weight(W, need_t=True, pack=True, f16=False):
+    """[K,N] fp32 -> w3n [N,3K] (rows [Wh^T|Wh^T|Wl^T]: y = X3 w3n^T) and w3k [K,3N] (rows [Wh|Wl|Wh]: dx = DY3 w3k^T), bf16.
+    f16 (the fp16 two-product format): the weight rounded once to fp16 -- wn [N,2K] = [Wh^T|Wh^T], wk [K,2N] = [Wh|Wh]."""
     lib = _capi.load()
+    fn, fk = ("n16", "k16") if f16 else ("n", "k")
     if pack:
-        got = _packed([W], ["n", "k"] if need_t else ["n"])
+        got = _packed([W], [fn, fk] if need_t else [fn])
         if got is not None:
-            return got["n"], got.get("k")
+            return got[fn], got.get(fk)
     K, N = W.shape
-    w3n = torch.empty((N, 3 * K), dtype=torch.bfloat16, device=W.device)
-    w3k = torch.empty((K, 3 * N), dtype=torch.bfloat16, device=W.device) if need_t else None
-    lib.check(lib._lpm_split_weight(ptr(W), K, N, ptr(w3n), ptr(w3k), stream_ptr()), "lpm_split_weight")
+    pl, dt = (2, torch.float16) if f16 else (3, torch.bfloat16)
+    w3n = torch.empty((N, pl * K), dtype=dt, device=W.device)
+    w3k = torch.empty((K, pl * N), dtype=dt, device=W.device) if need_t else None
+    lib.check(lib._lpm_split_weight_fmt(ptr(W), K, N, ptr(w3n), ptr(w3k), _capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3,
+                                        stream_ptr()), "lpm_split_weight")
     return w3n, w3k
 
 
-def _mm3(a3, w3, acc=None):
+def _mm3(a3, w3, acc=None, alpha=1.0):
     """a3 [M,3K] . w3 [N,3K]^T with fp32 accumulation and output (the weight image is stored transposed).  acc: an fp32
-    [M,N] tensor the product is added to IN PLACE (the GEMM's beta = 1 instead of a separate add pass)."""
+    [M,N] tensor the product is added to IN PLACE (the GEMM's beta = 1 instead of a separate add pass).  alpha (the fp16 two-product
+    format: 1 / the data operand's scale, a power of two) rides in the GEMM."""
+    if alpha == 1.0:
+        if acc is None:
+            return torch.mm(a3, w3.t(), out_dtype=torch.float32)
+        return torch.addmm(acc, a3, w3.t(), out_dtype=torch.float32, out=acc)
     if acc is None:
-        return torch.mm(a3, w3.t(), out_dtype=torch.float32)
-    return torch.addmm(acc, a3, w3.t(), out_dtype=torch.float32, out=acc)
+        out = torch.empty((a3.shape[0], w3.shape[0]), dtype=torch.float32, device=a3.device)
+        return torch.addmm(out, a3, w3.t(), out_dtype=torch.float32, beta=0, alpha=alpha, out=out)
+    return torch.addmm(acc, a3, w3.t(), out_dtype=torch.float32, alpha=alpha, out=acc)
 
 
 class _DenseX3(torch.autograd.Function):
@@ -1351,24 +1522,26 @@ class _DenseX3(torch.autograd.Function):
         """x3 (block Functions only): the input already as its activation image (then x2d is None)."""
         W0 = W
         W = _f32(W, "dense kernel").contiguous()
+        sa = ctx.site_a = _site("a", W0)          # (an image handed in was written in this site's format by its producer)
         if x3 is None:
             x2d = _rows(x2d, "dense input")
-            x3 = _split_rows(x2d)
-        w3n, w3k = _split_weight(W, need_t=ctx.needs_input_grad[0])
+            x3 = _split_rows(x2d, site=sa)
+        w3n, w3k = _split_weight(W, need_t=ctx.needs_input_grad[0], f16=_f16(sa))
         ctx.save_for_backward(x3, w3k)
         ctx.dims = (W.shape[0], W.shape[1])
         ctx.wrefs = (W0,)
-        return _mm3(x3, w3n)
+        return _mm3(x3, w3n, alpha=sa.inv if sa is not None else 1.0)
 
     @staticmethod
     def backward(ctx, dy, dy3=None):
-        """dy3 (block Functions only): dy already as its gradient image."""
+        """dy3 (block Functions only): dy already as its gradient image (in the format of this layer's "g" site)."""
         x3, w3k = ctx.saved_tensors
         K, N = ctx.dims
+        sa, sg = ctx.site_a, _site("g", ctx.wrefs[0])
         if dy3 is None:
-            dy3 = _split_rows(dy.contiguous(), grad=True)
-        dx = _mm3(dy3, w3k) if ctx.needs_input_grad[0] else None
-        dW = _dw_x3(x3, dy3, K, N, outs=[(ctx.wrefs[0], 0, N)])[0] if ctx.needs_input_grad[1] else None
+            dy3 = _split_rows(dy.contiguous(), grad=True, site=sg)
+        dx = _mm3(dy3, w3k, alpha=sg.inv if sg is not None else 1.0) if ctx.needs_input_grad[0] else None
+        dW = _dw_x3(x3, dy3, K, N, outs=[(ctx.wrefs[0], 0, N)], sa=sa, sg=sg)[0] if ctx.needs_input_grad[1] else None
         return dx, dW
 
 
@@ -1386,12 +1559,13 @@ class _QKVX3(torch.autograd.Function):
     def forward(ctx, x2d, Wq, Wk, Wv, row_scale=None):
         x2d = _rows(x2d, "dense input")
         K, N = Wq.shape
-        x3 = _split_rows(x2d, row_scale=row_scale)
-        w3n, w3k = _split_weight_cat([Wq, Wk, Wv], need_t=ctx.needs_input_grad[0])
+        sa = ctx.site_a = _site("a", Wq)
+        x3 = _split_rows(x2d, row_scale=row_scale, site=sa)
+        w3n, w3k = _split_weight_cat([Wq, Wk, Wv], need_t=ctx.needs_input_grad[0], f16=_f16(sa))
         ctx.save_for_backward(x3, w3k)
         ctx.dims = (K, N)
         ctx.wrefs = (Wq, Wk, Wv)
-        qkv = _mm3(x3, w3n)
+        qkv = _mm3(x3, w3n, alpha=sa.inv if sa is not None else 1.0)
         return qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
 
     @staticmethod
@@ -1401,6 +1575,7 @@ class _QKVX3(torch.autograd.Function):
         x3, w3k = ctx.saved_tensors
         K, N = ctx.dims
         M = x3.shape[0]
+        sa, sg = ctx.site_a, _site("g", ctx.wrefs[0])
         if dy3 is None:
             esz = dq.element_size()
             adjacent = (dq.stride() == (3 * N, 1) and dk.stride() == (3 * N, 1) and dv.stride() == (3 * N, 1)
@@ -1409,10 +1584,10 @@ class _QKVX3(torch.autograd.Function):
                 dqkv = torch.as_strided(dq, (M, 3 * N), (3 * N, 1))
             else:
                 dqkv = torch.cat([dq, dk, dv], dim=1)
-            dy3 = _split_rows(dqkv, grad=True)
-        dx = _mm3(dy3, w3k, acc) if ctx.needs_input_grad[0] else None
+            dy3 = _split_rows(dqkv, grad=True, site=sg)
+        dx = _mm3(dy3, w3k, acc, alpha=sg.inv if sg is not None else 1.0) if ctx.needs_input_grad[0] else None
         Wq, Wk, Wv = ctx.wrefs
-        dWq, dWk, dWv = _dw_x3(x3, dy3, K, 3 * N, outs=[(Wq, 0, N), (Wk, N, N), (Wv, 2 * N, N)])
+        dWq, dWk, dWv = _dw_x3(x3, dy3, K, 3 * N, outs=[(Wq, 0, N), (Wk, N, N), (Wv, 2 * N, N)], sa=sa, sg=sg)
         return dx, dWq, dWk, dWv
 
 
@@ -1469,12 +1644,53 @@ def linear_direct(x, W, b=None):
     return _LinearDirect.apply(x, W, b)
 
 
-def _dw_x3(x3, dy3, K, N, outs=None):
+def _dw_x3(x3, dy3, K, N, outs=None, sa=None, sg=None):
     """outs: [(weight, first column, columns)] -- the gradient's column blocks belong to these weights; a weight with a free arena slot
     (_grad_slot) receives its block straight from the split-K sum (no fresh tensor, no AccumulateGrad copy, no gather copy) and the
-    returned tuple holds None in its place.  Without outs: the [K, N] gradient."""
+    returned tuple holds None in its place.  Without outs: the [K, N] gradient.  sa / sg: the operand sites of the two images (fp16
+    two-product format: _dw_x2)."""
+    if _f16(sa) != _f16(sg):
+        raise LpmError("weight gradient: the activation image and the gradient image are in different operand formats")
+    if _f16(sa):
+        return _dw_x2(x3, dy3, K, N, outs, sa.inv * sg.inv)
     res = _dw_x3_impl(x3, dy3, K, N, outs)
     return res
+
+
+def _dw_x2(x2, dy2, K, N, outs, alpha):
+    """The fp16 two-product weight gradient dW = alpha * xh^T [dyh | dyl] from an activation image x2 [M,2K] = [hi|lo] and a gradient
+    image dy2 [M,2N] = [hi|lo]: the activation rounded once to fp16 (its hi plane, read in place with the image's row stride), the
+    gradient exact to 22 bits -- ONE fp16 library GEMM over S slices of the token reduction with a [K, 2N] output per slice, then
+    lpm_sum_splits_scaled adds slices and halves and multiplies by alpha = 1 / (the two operands' scales)."""
+    lib = _capi.load()
+    M = x2.shape[0]
+    S = 8 if K * N <= (1 << 20) else 2
+    while S > 1 and (M % S or M // S < 512):
+        S //= 2
+    xh = x2.view(S, M // S, 2 * K)[:, :, :K]
+    part = torch.bmm(xh.transpose(1, 2), dy2.view(S, M // S, 2 * N), out_dtype=torch.float32)       # [S, K, 2N]
+    slots = [_grad_slot(W) for W, _, _ in outs] if outs is not None else []
+    if (outs is not None and all(sl is not None and sl.is_contiguous() for sl in slots) and len(outs) <= 3
+            and all(nc == N // len(outs) and c0 == i * (N // len(outs)) for i, (_, c0, nc) in enumerate(outs)) and (N // len(outs)) % 4 == 0):
+        sp = [ptr(sl) for sl in slots] + [None] * (3 - len(slots))
+        lib.check(lib._lpm_sum_splits_scaled(ptr(part), S, K, N, 2, alpha, sp[0], sp[1], sp[2], len(slots), stream_ptr()), "lpm_sum_splits_scaled")
+        for W, _, _ in outs:
+            _grad_done(W)
+        return tuple(None for _ in outs)
+    full = torch.empty((K, N), dtype=torch.float32, device=x2.device)
+    lib.check(lib._lpm_sum_splits_scaled(ptr(part), S, K, N, 2, alpha, ptr(full), None, None, 1, stream_ptr()), "lpm_sum_splits_scaled")
+    if outs is None:
+        return full
+    res = []
+    for (W, c0, nc), sl in zip(outs, slots):
+        blk = full[:, c0:c0 + nc] if (c0, nc) != (0, N) else full
+        if sl is None:
+            res.append(blk)
+        else:
+            sl.copy_(blk)
+            _grad_done(W)
+            res.append(None)
+    return tuple(res)
 
 
 def _dw_x3_impl(x3, dy3, K, N, outs):
@@ -1539,31 +1755,38 @@ class _FFNX3(torch.autograd.Function):
         lib = _capi.load()
         M, F = y2d.shape
         H = W1.shape[1]
-        if y3 is None or tuple(y3.shape) != (M, 3 * F):
-            y3 = _split_rows(y2d)
-        w13n, w13k = _split_weight(W1)
+        # operand sites (fp16 two-product format when the trainer's scales are calibrated): y feeds layer 1, the hidden activation layer 2
+        s1, s2 = _site("a", W1_0), _site("a", W2_0)
+        f16 = _f16(s1)
+        ctx.sites = (s1, s2)
+        pl, dt = (2, torch.float16) if f16 else (3, torch.bfloat16)
+        a1 = s1.inv if s1 is not None else 1.0
+        if y3 is None or tuple(y3.shape) != (M, pl * F) or y3.dtype != dt:
+            y3 = _split_rows(y2d, site=s1)
+        w13n, w13k = _split_weight(W1, f16=f16)
         ctx.tiles = bool(FFN_TILES and y2d.stride(1) == 1 and lib._lpm_dense_tiles_supported(M, F, H) and lib._lpm_dense_tiles_supported(M, W2.shape[1], H))
         if ctx.tiles:
             # the first dense layer on the hand-written 256-row tile GEMM with the bias + ReLU + operand split in its epilogue: the
             # [M, 4F] pre-activation never exists in fp32 (335 MB written + read at cfg-2), no separate split pass
             st = stream_ptr()
             yr = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, F), y2d)
-            lib.check(lib._lpm_split_rows_tiles(ptr(y2d), y2d.stride(0), 1, M, F, ptr(yr), st), "lpm_split_rows_tiles")
-            w1t = _weight_tiles(W1, F, H, False, y2d)
-            f3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=y2d.device)
-            lib.check(lib._lpm_dense_tiles_act_image_fwd(ptr(yr), ptr(w1t), ptr(b1.contiguous()), M, F, H, ptr(f3), st),
-                      "lpm_dense_tiles_act_image_fwd")
-            w23n, _ = _split_weight(W2, need_t=False)
+            lib.check(lib._lpm_split_rows_tiles_fmt(ptr(y2d), y2d.stride(0), 1, M, F, ptr(yr), s1.fmt if s1 is not None else None, st),
+                      "lpm_split_rows_tiles")
+            w1t = _weight_tiles(W1, F, H, False, y2d, f16=f16)
+            f3 = torch.empty((M, pl * H), dtype=dt, device=y2d.device)
+            lib.check(lib._lpm_dense_tiles_act_image_fwd_fmt(ptr(yr), ptr(w1t), ptr(b1.contiguous()), M, F, H, a1, ptr(f3),
+                                                             s2.fmt if s2 is not None else None, st), "lpm_dense_tiles_act_image_fwd")
+            w23n, _ = _split_weight(W2, need_t=False, f16=f16)
             ctx.save_for_backward(y3, f3, w13k, W2)
         else:
-            pre1 = _mm3(y3, w13n)
-            f3 = _split_rows(pre1, bias=b1.contiguous(), relu=True)
+            pre1 = _mm3(y3, w13n, alpha=a1)
+            f3 = _split_rows(pre1, bias=b1.contiguous(), relu=True, site=s2)
             del pre1
-            w23n, w23k = _split_weight(W2)
+            w23n, w23k = _split_weight(W2, f16=f16)
             ctx.save_for_backward(y3, f3, w13k, w23k)
         ctx.dims = (W1.shape[0], W1.shape[1], W2.shape[1])
         ctx.wrefs = (W1_0, W2_0)
-        return _mm3(f3, w23n)
+        return _mm3(f3, w23n, alpha=s2.inv if s2 is not None else 1.0)
 
     @staticmethod
     def backward(ctx, dout, acc=None, do3=None):
@@ -1572,10 +1795,16 @@ class _FFNX3(torch.autograd.Function):
         y3, f3, w13k, w23k = ctx.saved_tensors
         F, H, N = ctx.dims
         M = y3.shape[0]
+        s1, s2 = ctx.sites
+        g1, g2 = _site("g", ctx.wrefs[0]), _site("g", ctx.wrefs[1])       # the gradients of the two layers' outputs (do3 arrives in g2's format)
+        f16 = _f16(s1)
+        kind = _capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3
+        pl, dt = (2, torch.float16) if f16 else (3, torch.bfloat16)
+        a2 = g2.inv if g2 is not None else 1.0
         if do3 is None:
-            do3 = _split_rows(dout.contiguous(), grad=True)
-        dW2 = _dw_x3(f3, do3, H, N, outs=[(ctx.wrefs[1], 0, N)])[0]
-        dp3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=f3.device)
+            do3 = _split_rows(dout.contiguous(), grad=True, site=g2)
+        dW2 = _dw_x3(f3, do3, H, N, outs=[(ctx.wrefs[1], 0, N)], sa=s2, sg=g2)[0]
+        dp3 = torch.empty((M, pl * H), dtype=dt, device=f3.device)
         db1 = torch.empty((H,), dtype=torch.float32, device=f3.device)
         if ctx.tiles:
             # df = do W2^T on the tile GEMM; ReLU mask (the activation image's hi plane), bias gradient partial sums and the operand
@@ -1583,21 +1812,21 @@ class _FFNX3(torch.autograd.Function):
             st = stream_ptr()
             W2 = w23k                                                     # (saved in its place: the fp32 weight [H, N])
             dor = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), f3)
-            lib.check(lib._lpm_image_row_tiles(ptr(do3), M, N, 1, ptr(dor), st), "lpm_image_row_tiles")
-            w2tt = _weight_tiles(W2, N, H, True, f3)
+            lib.check(lib._lpm_image_row_tiles_fmt(ptr(do3), M, N, 1, ptr(dor), kind, st), "lpm_image_row_tiles")
+            w2tt = _weight_tiles(W2, N, H, True, f3, f16=f16)
             wsb = lib._lpm_dense_tiles_relu_bwd_workspace_bytes(M, H)
             ws = torch.empty(wsb // 4, dtype=torch.float32, device=f3.device)
-            lib.check(lib._lpm_dense_tiles_relu_bwd_image(ptr(dor), ptr(w2tt), ptr(f3), M, N, H, ptr(dp3), ptr(db1), ptr(ws), wsb, st),
-                      "lpm_dense_tiles_relu_bwd_image")
+            lib.check(lib._lpm_dense_tiles_relu_bwd_image_fmt(ptr(dor), ptr(w2tt), ptr(f3), kind, M, N, H, a2, ptr(dp3), ptr(db1), ptr(ws), wsb,
+                                                              g1.fmt if g1 is not None else None, st), "lpm_dense_tiles_relu_bwd_image")
         else:
-            df = _mm3(do3, w23k)                                          # [M, H]
+            df = _mm3(do3, w23k)                                          # [M, H]  (un-scaled: alpha rides in the split pass below)
             wsb = lib._lpm_split_rows_relu_bwd_workspace_bytes(M, H)
             ws = torch.empty(wsb // 4, dtype=torch.float32, device=df.device)
-            lib.check(lib._lpm_split_rows_relu_bwd(ptr(df), M, H, ptr(f3), ptr(dp3), ptr(db1), ptr(ws), wsb, stream_ptr()),
-                      "lpm_split_rows_relu_bwd")
+            lib.check(lib._lpm_split_rows_relu_bwd_fmt(ptr(df), M, H, a2, ptr(f3), kind, ptr(dp3), ptr(db1), ptr(ws), wsb,
+                                                       g1.fmt if g1 is not None else None, stream_ptr()), "lpm_split_rows_relu_bwd")
             del df
-        dy = _mm3(dp3, w13k, acc)
-        dW1 = _dw_x3(y3, dp3, F, H, outs=[(ctx.wrefs[0], 0, H)])[0]
+        dy = _mm3(dp3, w13k, acc, alpha=g1.inv if g1 is not None else 1.0)
+        dW1 = _dw_x3(y3, dp3, F, H, outs=[(ctx.wrefs[0], 0, H)], sa=s1, sg=g1)[0]
         return dy, dW1, db1, dW2
 
 
@@ -2137,7 +2366,7 @@ class _ResidualLayerNorm(torch.autograd.Function):
     """y = layer_norm(act(a + bias) + r): TF1 joint moments, with the producing dense layer's bias add / ReLU fused in."""
 
     @staticmethod
-    def forward(ctx, a, r, gamma, beta, bias, relu, out=None, r_scale=None, image=False, mask=None, mask_scale=1.0):
+    def forward(ctx, a, r, gamma, beta, bias, relu, out=None, r_scale=None, image=False, mask=None, mask_scale=1.0, site=None):
         """r_scale [B * L] (block Functions only): r holds the rows of a lazily normalised descriptor, scaled as they are read.
         image: y is ALSO written as the [B*L, 3F] bf16 activation image of the dense layer that reads it next and attached to the
         result as ``y._lpm_y3`` (ops._FFNX3 / ops.ffn_mod_x3 take it instead of splitting y again).
@@ -2155,7 +2384,9 @@ class _ResidualLayerNorm(torch.autograd.Function):
         stats = _empty((B, 2), a)
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
-        y3 = torch.empty((B * L, 3 * F), dtype=torch.bfloat16, device=a.device) if image else None
+        # site (block Functions only): the input site of the dense layer that reads y next -- the image in its operand format
+        y3 = (torch.empty((B * L, (2 if _f16(site) else 3) * F), dtype=torch.float16 if _f16(site) else torch.bfloat16, device=a.device)
+              if image else None)
         if mask is not None:
             if r_scale is not None:
                 raise LpmError("layer_norm: a dropout mask and a residual row scale do not combine")
@@ -2167,9 +2398,10 @@ class _ResidualLayerNorm(torch.autograd.Function):
                                                              ptr(beta), B, L, F, LN_EPS, ptr(y), y.stride(0), ptr(y3), ptr(z), ptr(stats),
                                                              ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_mask_image_fwd")
         elif image:
-            lib.check(lib._lpm_layer_norm_act_image_fwd(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(r_scale), ptr(gamma), ptr(beta), B, L,
-                                                        F, LN_EPS, ptr(y), y.stride(0), ptr(y3), ptr(z) if z is not a else None, ptr(stats),
-                                                        ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_image_fwd")
+            lib.check(lib._lpm_layer_norm_act_image_fwd_fmt(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(r_scale), ptr(gamma), ptr(beta), B, L,
+                                                            F, LN_EPS, ptr(y), y.stride(0), ptr(y3), ptr(z) if z is not a else None, ptr(stats),
+                                                            ptr(ws), wsb, site.fmt if site is not None else None, stream_ptr()),
+                      "lpm_layer_norm_act_image_fwd")
         elif r_scale is not None:
             lib.check(lib._lpm_layer_norm_act_fwd_rs(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(r_scale), ptr(gamma), ptr(beta), B, L, F,
                                                      LN_EPS, ptr(y), y.stride(0), ptr(z) if z is not a else None, ptr(stats), ptr(ws),
@@ -2187,7 +2419,7 @@ class _ResidualLayerNorm(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy, dr_extra=None, da_image=False):
+    def backward(ctx, dy, dr_extra=None, da_image=False, site=None):
         """Block Functions only -- dr_extra: a second consumer's gradient of the residual tensor, added to the residual's
         gradient on its way out of the kernel; da_image: da is returned as the [B*L, 3F] bf16 gradient image the next GEMMs
         read (ops._split_rows(grad=True)) instead of in fp32."""
@@ -2198,7 +2430,9 @@ class _ResidualLayerNorm(torch.autograd.Function):
             dy = dy.contiguous()
         dz = torch.empty_like(z)
         mask = getattr(ctx, "mask", None)
-        img = torch.empty((B * L, 3 * F), dtype=torch.bfloat16, device=z.device) if da_image else None
+        # site (block Functions only): the gradient site of the dense layer whose output a is -- the image in its operand format
+        img = (torch.empty((B * L, (2 if _f16(site) else 3) * F), dtype=torch.float16 if _f16(site) else torch.bfloat16, device=z.device)
+               if da_image else None)
         da = torch.empty_like(z) if ((ctx.relu or dr_extra is not None or mask is not None) and not da_image) else None
         dgamma, dbeta = _empty((F,), z), _empty((F,), z)
         dbias = _empty((F,), z) if ctx.has_bias else None
@@ -2210,11 +2444,12 @@ class _ResidualLayerNorm(torch.autograd.Function):
                                                        ptr(dbeta), ptr(dbias), ptr(dr_extra), ptr(img), ptr(ws), wsb, stream_ptr()),
                       "lpm_layer_norm_act_mask_bwd")
         else:
-            lib.check(lib._lpm_layer_norm_act_bwd(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
-                                                  1 if ctx.relu else 0, B, L, F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias),
-                                                  ptr(dr_extra), ptr(img), ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_bwd")
+            lib.check(lib._lpm_layer_norm_act_bwd_fmt(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
+                                                      1 if ctx.relu else 0, B, L, F, ptr(dz), ptr(da), ptr(dgamma), ptr(dbeta), ptr(dbias),
+                                                      ptr(dr_extra), ptr(img), ptr(ws), wsb, site.fmt if site is not None else None,
+                                                      stream_ptr()), "lpm_layer_norm_act_bwd")
         first = img if da_image else (da if da is not None else dz)
-        return first, (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None, None, None, None, None
+        return first, (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None, None, None, None, None, None
 
 
 def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False, image=False, mask=None, mask_scale=1.0):
@@ -2292,20 +2527,23 @@ def _dqkv_buffers(q):
 
 class _MHACore(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, num_heads, scale, image=False):
+    def forward(ctx, q, k, v, num_heads, scale, image=False, site=None):
         """image (block Functions only, split-bf16 arithmetic): the result is written ONLY as the [B*L, 3*h*d] bf16 activation image
-        of the output projection GEMM (and kept in that form for the backward)."""
+        of the output projection GEMM (and kept in that form for the backward).  site: that GEMM's input site -- the image in its
+        operand format (fp16 two-product: [B*L, 2*h*d] fp16)."""
         lib = _capi.load()
         q, k, v = _qkv_operands(q, k, v)
         B, L, d = _mha_dims(q, num_heads)
         lse = _empty((B, num_heads, L), q)
         ctx.dims = (B, L, num_heads, d, scale)
         ctx.o_image = bool(image)
+        ctx.o_site = site
         if image:
-            o = torch.empty((B * L, 3 * num_heads * d), dtype=torch.bfloat16, device=q.device)
+            o = torch.empty((B * L, (2 if _f16(site) else 3) * num_heads * d), dtype=torch.float16 if _f16(site) else torch.bfloat16,
+                            device=q.device)
             with _timed("mha_fwd", (B, L, num_heads, d)):
-                lib.check(lib._lpm_mha_fwd_x3_image(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, ptr(o), ptr(lse),
-                                                    stream_ptr()), "lpm_mha_fwd_x3_image")
+                lib.check(lib._lpm_mha_fwd_x3_image_fmt(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, ptr(o), ptr(lse),
+                                                        site.fmt if site is not None else None, stream_ptr()), "lpm_mha_fwd_x3_image")
         else:
             o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
             with _timed("mha_fwd", (B, L, num_heads, d)):
@@ -2315,14 +2553,24 @@ class _MHACore(torch.autograd.Function):
         return o
 
     @staticmethod
-    def backward(ctx, do, image=False):
+    def backward(ctx, do, image=False, site=None):
         """image (block Functions only, split-bf16 arithmetic): return the q/k/v gradients as the [B*L, 9*h*d] bf16 gradient
-        image of [dq | dk | dv] that ops._QKVX3.backward feeds its GEMMs, written by the kernels themselves."""
+        image of [dq | dk | dv] that ops._QKVX3.backward feeds its GEMMs, written by the kernels themselves.  site: the q/k/v layer's
+        gradient site -- the image in its operand format (fp16 two-product: [B*L, 6*h*d] fp16 = [hi(3N) | lo(3N)])."""
         lib = _capi.load()
         B, L, h, d, scale = ctx.dims
         q, k, v, o, lse = ctx.saved_tensors
         do = do.contiguous()
         o_image = getattr(ctx, "o_image", False)
+        o_site = getattr(ctx, "o_site", None)
+        if image and (site is not None or o_site is not None):
+            if not o_image:
+                raise LpmError("mha backward: operand sites need the image-form attention output")
+            dy3 = torch.empty((B * L, (6 if _f16(site) else 9) * h * d), dtype=torch.float16 if _f16(site) else torch.bfloat16, device=q.device)
+            lib.check(lib._lpm_mha_bwd_x3_image_fmt(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), o_site.fmt if o_site is not None else None,
+                                                    ptr(do), do.stride(1), ptr(lse), B, L, h, d, scale, ptr(dy3),
+                                                    site.fmt if site is not None else None, stream_ptr()), "lpm_mha_bwd_x3_image")
+            return dy3
         if image:
             dy3 = torch.empty((B * L, 9 * h * d), dtype=torch.bfloat16, device=q.device)
             lib.check(lib._lpm_mha_bwd_x3_image(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), 1 if o_image else 0, ptr(do), do.stride(1),
@@ -2380,7 +2628,7 @@ class _AttnBlockX3(torch.autograd.Function):
     input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale, row_scale=None):
+    def forward(ctx, x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale, row_scale=None, next_kernel=None):
         """row_scale [B, L]: x is a lazily normalised descriptor (netvlad(lazy=True)) -- its two readers, the q/k/v operand split and the
         residual layer norm, scale the rows as they read them; the returned gradient is with respect to the normalised x."""
         x = _f32(x, "attention block input").contiguous()
@@ -2391,13 +2639,16 @@ class _AttnBlockX3(torch.autograd.Function):
         q, k, v = _QKVX3.forward(cq, x.view(B * L, F), Wq, Wk, Wv, row_scale=rs)
         from . import FLAGS
         if MHA_PRECISION == "bf16x3" and FLAGS.mha_gradient_image:     # the attention result only as the output GEMM's operand image
-            o3 = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale, image=True)
+            o3 = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale, image=True, site=_site("a", Wo))
             att = _DenseX3.forward(co, None, Wo, x3=o3)
         else:
             o = _MHACore.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), num_heads, scale)
             att = _DenseX3.forward(co, o.view(B * L, N), Wo)
-        # (the feed-forward block behind this one reads y as a GEMM operand: the layer norm writes that image on its way out)
-        y = _ResidualLayerNorm.forward(cl, att.view(B, L, Wo.shape[1]), x, gamma, beta, bo, False, None, rs, image=LN_IMAGE)
+        # (the feed-forward block behind this one reads y as a GEMM operand: the layer norm writes that image on its way out, in the
+        # operand format of that block's first dense layer -- ``next_kernel``)
+        y = _ResidualLayerNorm.forward(cl, att.view(B, L, Wo.shape[1]), x, gamma, beta, bo, False, None, rs, image=LN_IMAGE,
+                                       site=_site("a", next_kernel) if next_kernel is not None else None)
+        ctx.wq = Wq
         _pack_subs(ctx, (cq, cm, co, cl))
         ctx.shape = (B, L, F, N)
         return y
@@ -2410,17 +2661,19 @@ class _AttnBlockX3(torch.autograd.Function):
         _, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]         # no ReLU: da is dz
         do, dWo = _DenseX3.backward(co, dz.view(B * L, F))   # (dz also as an image from the kernel: measured neutral, not kept)
         if cm.o_image:
-            dy3 = _MHACore.backward(cm, do.view(B, L, N), image=True)          # the kernels write the GEMM operand image
+            dy3 = _MHACore.backward(cm, do.view(B, L, N), image=True, site=_site("g", ctx.wq))   # the kernels write the GEMM operand image
             dx, dWq, dWk, dWv = _QKVX3.backward(cq, None, None, None, acc=dz.view(B * L, F), dy3=dy3)
         else:
             dq, dk, dv = _MHACore.backward(cm, do.view(B, L, N))[:3]
             dx, dWq, dWk, dWv = _QKVX3.backward(cq, dq.view(B * L, N), dk.view(B * L, N), dv.view(B * L, N), acc=dz.view(B * L, F))
-        return dx.view(B, L, F), dWq, dWk, dWv, dWo, dbo, dgamma, dbeta, None, None, None
+        return dx.view(B, L, F), dWq, dWk, dWv, dWo, dbo, dgamma, dbeta, None, None, None, None
 
 
-def attention_block_x3(x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale):
-    """x may be a lazily normalised descriptor (ops.netvlad(lazy=True)): its row scale is applied where the block reads the rows."""
-    return _AttnBlockX3.apply(x, Wq, Wk, Wv, Wo, bo, gamma, beta, int(num_heads), float(scale), row_scale_of(x))
+def attention_block_x3(x, Wq, Wk, Wv, Wo, bo, gamma, beta, num_heads, scale, next_kernel=None):
+    """x may be a lazily normalised descriptor (ops.netvlad(lazy=True)): its row scale is applied where the block reads the rows.
+    next_kernel: the kernel of the dense layer that reads the block's result next (FeedForwardNetwork's first layer): the operand
+    image the layer norm hands it is written in that layer's operand format."""
+    return _AttnBlockX3.apply(x, Wq, Wk, Wv, Wo, bo, gamma, beta, int(num_heads), float(scale), row_scale_of(x), next_kernel)
 
 
 def _ln_pair_forward(c1, c2, a, r, g1, be1, bias, g2, be2, out=None):
@@ -2488,7 +2741,7 @@ class _FFNBlockX3(torch.autograd.Function):
         dz2, _, dg2, dbe2 = _ResidualLayerNorm.backward(c2, dout)[:4]             # gradient of n; y receives the same
         from . import FLAGS
         if FLAGS.ln_gradient_image:               # the ReLU-masked da1 only feeds the FFN's GEMMs: it leaves the kernel as their image
-            do3, dzy, dg1, dbe1, db2 = _ResidualLayerNorm.backward(c1, dz2, dr_extra=dz2, da_image=True)[:5]
+            do3, dzy, dg1, dbe1, db2 = _ResidualLayerNorm.backward(c1, dz2, dr_extra=dz2, da_image=True, site=_site("g", cf.wrefs[1]))[:5]
             dy, dW1, db1, dW2 = _FFNX3.backward(cf, None, acc=dzy.view(B * L, F), do3=do3)
         else:
             da1, dzy, dg1, dbe1, db2 = _ResidualLayerNorm.backward(c1, dz2, dr_extra=dz2)[:5]   # dzy = dz1 + dz2

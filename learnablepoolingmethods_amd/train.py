@@ -11,6 +11,7 @@ clip + TF-style Adam is one fused multi-tensor HIP kernel over the arena.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -418,6 +419,13 @@ class Trainer:
         self.factored = None
         self.sharded: Optional[ShardedVariableUpdate] = None
         self.weight_pack = ops.WeightPack() if self.device.type == "cuda" else None
+        # per-model switch (FLAGS.dense_arithmetic): NetVladV1's encoder GEMMs in the fp16 two-product operand format, with the delayed
+        # per-tensor scales this object measures; every other model (NetVladV2: transformer_utils.py:652-671 amplifies forward errors)
+        # stays on split-bf16 x3
+        self.operand_scales = None
+        if (self.device.type == "cuda" and FLAGS.dense_arithmetic == "fp16x2" and type(model).__name__ == "NetVladV1"
+                and os.environ.get("LPM_DENSE_ARITHMETIC", "fp16x2") == "fp16x2"):
+            self.operand_scales = ops.OperandScales(self.device)
         if self.device.type == "cuda":
             ops.enable_library_gemm_selection()
 
@@ -570,6 +578,9 @@ class Trainer:
         if self.bucket_gather is not None:
             self.bucket_gather.arm()
         model_input = self._normalize_input(model_input_raw, num_frames)                        # train.py:262-264
+        if self.operand_scales is not None:
+            self.operand_scales.begin_step()       # harvest the maxima measured so far, decide this step's operand format
+            ops._ACTIVE_SCALES = self.operand_scales
         if self.weight_pack is not None:
             # every dense weight's operand forms for this step's forward AND backward in one launch (ops.WeightPack); a sharded
             # hidden1_weights is not among them (its all-gather may still be in flight: only the projection reads it)
@@ -578,6 +589,7 @@ class Trainer:
         try:
             return self._step_body(model_input_raw, model_input, num_frames, labels, kw)
         finally:
+            ops._ACTIVE_SCALES = None
             if self.weight_pack is not None:
                 ops._ACTIVE_PACK = None
                 self.weight_pack.end_step()
@@ -647,11 +659,63 @@ class Trainer:
         return {"loss": label_loss.detach(), "predictions": predictions.detach(), "learning_rate": lr,
                 "global_step": self.global_step}
 
+    def calibrate_operand_scales(self, model_input_raw, num_frames, labels, **kw):
+        """The fp16 two-product format's scales measured NOW, synchronously, from one forward + backward on this batch in split-bf16
+        (no optimiser step; moving statistics restored): the next ``step`` runs in fp16 with scales that fit it.  Without this call a
+        run's first steps stay on split-bf16 until the asynchronous measurements arrive (two or three steps).  Single tower only (the
+        backward's collectives are not entered here).  No-op for models / flags without operand scales."""
+        sc = self.operand_scales
+        if sc is None:
+            return False
+        if self.sync is not None and self.sync.active:
+            raise RuntimeError("calibrate_operand_scales: single tower only (data-parallel runs calibrate over their first steps)")
+        dev = self.device
+        model_input_raw, labels, num_frames = model_input_raw.to(dev), labels.to(dev), num_frames.to(dev)
+        self.build(model_input_raw, num_frames, labels)
+        before = {n: v.clone() for n, v in self.store.vars.items() if not self.store.trainable[n]}
+        self.arena.zero_grad()
+        model_input = self._normalize_input(model_input_raw, num_frames)
+        was = sc.enabled
+        sc.enabled = False                       # this pass runs in split-bf16 whatever is known so far
+        sc.begin_step()
+        ops._ACTIVE_SCALES = sc
+        fg = self.factored
+        try:
+            result, reg_losses = self._forward(model_input, num_frames, labels, **kw)
+            loss = result["loss"] if "loss" in result else self.loss_fn.calculate_loss(result["predictions"], labels)
+            reg = result.get("regularization_loss", 0.0)
+            if reg_losses:
+                reg = reg + torch.stack(reg_losses).sum()
+            if fg is not None:
+                fg.clear()
+                fg.armed = True
+            (self.reg_penalty * reg + loss).backward()
+        finally:
+            ops._ACTIVE_SCALES = None
+            sc.enabled = was
+            self._l2_regs = []
+            if fg is not None:
+                fg.armed = False
+                fg.clear()
+        sc.calibrate_from_device()
+        with torch.no_grad():
+            for n, v in before.items():
+                self.store.vars[n].copy_(v)
+        for v in self.arena.views.values():      # direct-write marks of the calibration backward
+            if hasattr(v, "_lpm_grad_written"):
+                v._lpm_grad_written = False
+        return True
+
     def gradient(self, name: str) -> torch.Tensor:
         """The raw (summed over towers, un-clipped) gradient of variable ``name`` that the latest ``step`` consumed: its slice of the
         gradient arena, or -- for hidden1_weights when the factored update ran, whose gradient is never written -- the product of
-        the factors the optimiser used (tests, diagnostics)."""
+        the factors the optimiser used (tests, diagnostics).  On the sharded route the summed gradient of hidden1_weights exists only
+        shard by shard on its owners (the arena slice holds this rank's LOCAL gradient after a native reduce-scatter): asking for it
+        raises -- ``sharded.keep_summed`` / ``sharded.summed_shard`` give this rank's shard of the sum."""
         t = self.arena.views[name]
+        if self.sharded is not None and name == self.arena.names[0]:
+            raise RuntimeError(f"gradient({name!r}): on the sharded route the summed gradient exists only as the owners' shards "
+                               f"(set trainer.sharded.keep_summed = True and read trainer.sharded.summed_shard)")
         if self.factored is not None and self.factored.pending and name == self.arena.names[0]:
             return self.factored.materialise().view(t.shape)
         a0, _ = self.arena.segment(name)
@@ -697,8 +761,10 @@ class Trainer:
 
         No communication by default: a chief-only ``if rank == 0: trainer.save(path)`` (the reference's Supervisor / is_chief
         pattern, train.py:501-515) must not enter a collective the other ranks never reach.  Data-parallel runs call
-        ``sync_moving_statistics()`` on EVERY rank first (or pass ``sync=True`` on every rank) so that the checkpoint holds the
-        towers' mean moving statistics."""
+        ``prepare_checkpoint()`` on EVERY rank first (or pass ``sync=True`` on every rank): it averages the towers' moving statistics
+        and, on the sharded route, gathers the owners' Adam moments of hidden1_weights -- the reference's chief holds ALL Adam slots.
+        A chief-only save WITHOUT that on the sharded route holds hidden1_weights' moments for the chief's 1/N shard only; such a
+        checkpoint is marked (``hidden1_adam_shard``) and ``load_state_dict`` refuses to resume from it."""
         if self.arena is None:
             raise RuntimeError("state_dict() needs a built trainer: run build() or one step first")
         if sync:
@@ -708,6 +774,7 @@ class Trainer:
             self.store.pending.pop(self.arena.names[0], None)
             if sync:
                 self.sharded.gather_moments()
+                self._moments_gathered_at = self.global_step
         out: Dict[str, object] = {n: v.detach().clone().cpu() for n, v in self.store.vars.items()}
         for n in self.arena.names:
             a0, _ = self.arena.segment(n)
@@ -719,11 +786,28 @@ class Trainer:
         if self.sync is not None and self.sync.active and not sync:
             # a chief-only save: this rank's own moving statistics (the towers' mean needs sync_moving_statistics() on every rank
             # first) and, on the sharded route, Adam moments of hidden1_weights for this rank's shard only -- recorded, not hidden
-            out["bn_statistics_synced"] = False
-            if self.sharded is not None:
+            out["bn_statistics_synced"] = getattr(self, "_statistics_synced_at", None) == self.global_step
+            if self.sharded is not None and getattr(self, "_moments_gathered_at", None) != self.global_step:
                 out["hidden1_adam_shard"] = {"rank": self.sharded.rank, "towers": self.sharded.world,
                                              "floats": [self.sharded.lo - self.sharded.a0, self.sharded.hi - self.sharded.a0]}
         return out
+
+    def prepare_checkpoint(self):
+        """Data parallelism only (collectives: EVERY rank calls it, at the same step): what a chief-only ``save`` needs to hold the same
+        state as the reference's chief (train.py:501-515) -- the towers' mean moving statistics and, on the sharded route, the owners'
+        Adam moments of hidden1_weights in full on every rank.  ``if rank == 0: trainer.save(path)`` after it writes a complete,
+        unmarked checkpoint."""
+        self.sync_moving_statistics()
+        self._statistics_synced_at = self.global_step
+        if self.sharded is not None:
+            self.wait_pending()
+            self.sharded.gather_moments()
+            self._moments_gathered_at = self.global_step
+
+    def wait_pending(self):
+        """Complete every asynchronous write into the variables (route C's parameter all-gather of hidden1_weights): call it before
+        reading ``store.vars`` / ``arena.param`` directly between steps (``get_variable``, ``state_dict`` and ``load`` do it themselves)."""
+        self.store.drain_pending()
 
     def sync_moving_statistics(self):
         """Data parallelism only (a collective: every rank calls it).  Each rank is a tower with its own batch statistics
@@ -754,6 +838,16 @@ class Trainer:
         if self.sharded is not None:
             self.sharded.wait_parameters()
             self.store.pending.pop(self.arena.names[0], None)
+        shard = state.get("hidden1_adam_shard")
+        if shard is not None:
+            # a chief-only save on the sharded route without prepare_checkpoint() holds real Adam moments of hidden1_weights
+            # for ONE rank's shard; resuming from it would run (N-1)/N of 85 % of the parameters with m = v = 0 under a bias correction
+            # of ~1 (first updates ~ 3 lr sign(g)).  The reference's chief save holds all Adam slots (train.py:501-515).
+            raise RuntimeError(
+                f"checkpoint holds Adam moments of {self.arena.names[0]} for rank {shard.get('rank')}'s shard of {shard.get('towers')} only "
+                f"(floats {shard.get('floats')}): it was saved by one rank of a sharded-update run without Trainer.prepare_checkpoint() "
+                f"/ save(sync=True) on every rank first.  Re-save with the moments gathered, or delete 'hidden1_adam_shard' (and the "
+                f"'/Adam', '/Adam_1' entries of that variable) from the state to restart its moments from zero knowingly.")
         with torch.no_grad():
             self.store.load({n: v for n, v in state.items() if n in self.store.vars}, strict=False)
             for v in self.store.vars.values():         # restored weights: the min |gamma| watch decides afresh, synchronously

@@ -153,7 +153,7 @@ class TransformerEncoder(modules.BaseModule):
         g1, be1 = ln_vars("LayerNorm_1")
         g2, be2 = ln_vars("LayerNorm_2")
         depth = hidden // self.num_heads
-        attention = ops.attention_block_x3(inputs, wq, wk, wv, wo, bo, g0, be0, self.num_heads, depth ** -0.5)   # :403-407
+        attention = ops.attention_block_x3(inputs, wq, wk, wv, wo, bo, g0, be0, self.num_heads, depth ** -0.5, next_kernel=w1)   # :403-407
         return ops.ffn_block_x3(attention, w1, b1, w2, b2, g1, be1, g2, be2, out=out_slot)                         # :409-411
 
     def fused(self, inputs):

@@ -78,8 +78,16 @@ class VariableStore:
     def trainable_variables(self) -> Dict[str, torch.Tensor]:
         return {n: v for n, v in self.vars.items() if self.trainable[n]}
 
+    def drain_pending(self):
+        """Run every parked completion callback (``pending``: an asynchronous write into a variable that its next reader must wait for --
+        route C's parameter all-gather).  ``get_variable`` does it per name; whole-store readers and writers do it here."""
+        while self.pending:
+            _, cb = self.pending.popitem()
+            cb()
+
     def load(self, values: Dict[str, torch.Tensor], strict: bool = False):
         """Copy values in by name (e.g. the oracle's weight dict)."""
+        self.drain_pending()
         with torch.no_grad():
             for n, v in values.items():
                 if n in self.vars:
@@ -88,6 +96,7 @@ class VariableStore:
                     raise KeyError(n)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        self.drain_pending()
         return {n: v.detach().clone() for n, v in self.vars.items()}
 
     # -- regularisation collection (tf.losses.get_regularization_losses, train.py:301-303) ------

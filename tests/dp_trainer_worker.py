@@ -60,8 +60,7 @@ def main():
             dist.broadcast(v, src=0)
     names = list(tr.arena.names)
     for s in range(inp["steps"]):
-        if tr.sharded is not None:
-            tr.sharded.wait_parameters()                # (read below past get_variable: the parameter all-gather of the previous step)
+        tr.wait_pending()                               # (read below past get_variable: the parameter all-gather of the previous step)
         before = {n: tr.store.vars[n].detach().double().cpu() for n in names}
         o = tr.step(x, nf, lab)
         torch.cuda.synchronize()
@@ -71,6 +70,8 @@ def main():
             # hidden1_weights' gradient was never written: what the optimiser consumed is the product of the all-gathered factors
             assert tr.factored.R == world * per, (tr.factored.R, world, per)
         for n in names:
+            if tr.sharded is not None and n == names[0]:
+                continue                                # (Trainer.gradient raises there: the sum exists only as the owners' shards)
             grads[n] = tr.gradient(n).double().cpu()
         if tr.sharded is not None:
             # the summed gradient of hidden1_weights exists shard by shard only: put the ranks' shards together (and their Adam moments)

@@ -388,3 +388,70 @@ def test_sharded_update_of_hidden1_matches_the_tower_combine(world):
         assert torch.allclose(torch.from_numpy(got[n][0]), p[n], rtol=2e-5, atol=1e-7), n
         assert torch.allclose(torch.from_numpy(got[n][1]).view(m[n].shape), m[n], rtol=2e-5, atol=1e-9), n + " (Adam m)"
         assert torch.allclose(torch.from_numpy(got[n][2]).view(m[n].shape), v_[n], rtol=2e-5, atol=1e-12), n + " (Adam v)"
+
+
+def _chief_checkpoint_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from learnablepoolingmethods_amd import train
+    from learnablepoolingmethods_amd import variables as vs
+    tr = train.Trainer(model=None, device="cpu", batch_size=4, seed=0)
+    F = 64 * world
+    with vs.use_store(tr.store), vs.variable_scope("tower"):
+        vs.get_variable("hidden1_weights", [F, 64], vs.random_normal_initializer(0.3))
+        vs.get_variable("hidden1_biases", [64], vs.random_normal_initializer(0.1))
+        with vs.variable_scope("input_bn"):
+            vs.get_variable("moving_mean", [5], vs.zeros_initializer(), trainable=False)
+    h1 = "tower/hidden1_weights"
+    tr.arena = train.ParameterArena(tr.store, first=[h1])
+    a0, a1 = tr.arena.segment(h1)
+    tr.sync = train.GradientSynchronizer(tr.arena.grad, [(a0, a1), (a1, tr.arena.total)])
+    tr.sharded = train.ShardedVariableUpdate(tr.arena, h1, adam_fn=_adam_inplace)
+    sh = tr.sharded
+    tr.arena.grad.normal_(generator=torch.Generator().manual_seed(3 + rank))
+    sh.step(_SHARD_CLIP, 1e-2, 1)                                   # moments now exist on each owner's shard only
+    tr.store.pending[h1] = sh.wait_parameters
+    tr.global_step = 1
+    refused, marker = None, None
+    if rank == 0:
+        # the reference's chief-only save (train.py:501-515) WITHOUT the gather: marked, and refused at load
+        chief = tr.state_dict()
+        marker = chief.get("hidden1_adam_shard")
+        try:
+            tr.load_state_dict(chief)
+            refused = False
+        except RuntimeError as e:
+            refused = "prepare_checkpoint" in str(e)
+    tr.prepare_checkpoint()                                          # every rank: statistics averaged, moments gathered
+    sd = tr.state_dict()
+    ok = "hidden1_adam_shard" not in sd and sd["bn_statistics_synced"] is True
+    tr.load_state_dict(sd)                                           # a complete checkpoint resumes
+    full = bool((sd[h1 + "/Adam"] != 0).reshape(world, -1).any(dim=1).all())     # every shard's moments are there
+    q.put((rank, refused, marker, ok, full))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_chief_only_checkpoint_on_the_sharded_route_is_refused_until_the_moments_are_gathered():
+    """on route C a chief-only state_dict() holds hidden1_weights' Adam moments for the chief's shard only.  It is
+    marked (``hidden1_adam_shard``), load_state_dict refuses it with a message naming the remedy, and after prepare_checkpoint() on every
+    rank the same chief-only save is complete, unmarked and loads (the reference's chief holds all Adam slots, train.py:501-515)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chief_checkpoint_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    refused, marker, ok, full = res[0]
+    assert refused is True and marker is not None and marker["towers"] == 2 and marker["rank"] == 0
+    for r in range(world):
+        assert res[r][2] and res[r][3], f"rank {r}: checkpoint after prepare_checkpoint() must be complete and unmarked"

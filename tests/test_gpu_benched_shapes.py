@@ -69,9 +69,11 @@ def _run(name, storage=None, fwd_tol=1e-3, grad_tol=1e-3):
                      model_kwargs=mk)
         tr.build(x, nf, lab)
         tr.store.load({"tower/" + k: v for k, v in p.items()})
-        tr.store.summaries = {}
         kw = {} if masks is None else {"dropout_masks": {k: v.to(dev) for k, v in masks.items()}}
+        tr.calibrate_operand_scales(x, nf, lab, **kw)      # NetVladV1: the step below runs its encoder GEMMs in the fp16 two-product format
+        tr.store.summaries = {}
         out = tr.step(x, nf, lab, **kw)
+        assert tr.operand_scales is None or tr.operand_scales.steps_fp16 == 1
         torch.cuda.synchronize()
         got, tr.store.summaries = tr.store.summaries, None
     finally:

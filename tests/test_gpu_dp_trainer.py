@@ -158,17 +158,27 @@ def test_two_ranks_on_the_sharded_route_match_the_two_tower_oracle(name, side, t
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name,factored", [("blocks", True), ("blocks", False), ("toy", True)])
-def test_two_ranks_over_rccl_match_the_two_tower_oracle(name, factored, tmp_path):
+@pytest.mark.parametrize("name,route", [("blocks", "factored"), ("blocks", "allreduce"), ("toy", "factored"), ("blocks", "sharded"),
+                                        ("toy", "sharded")])
+def test_two_ranks_over_rccl_match_the_two_tower_oracle(name, route, tmp_path):
     """The measured configuration: one rank per GPU, `nccl` (= RCCL) backend -- bucketed all-reduce from hooks, the factor
-    all-gather, the arena broadcast -- against oracle.train_step(num_towers=2) (train.py:266-336, utils.py:192-213).  Needs two
-    GPUs: skipped on the single-GPU boxes of this pool (where the same code runs over gloo above)."""
+    all-gather, the arena broadcast -- against oracle.train_step(num_towers=2) (train.py:266-336, utils.py:192-213).  "sharded"
+    (ADVICE r4): route C's NATIVE collectives -- dist.reduce_scatter_tensor launched from inside the projection's backward callback and
+    the asynchronous all_gather_into_tensor whose wait is parked on the next read of the variable -- which the gloo legs replace by an
+    in-place all-reduce; the replicas must come out bit-identical (checked by _check on the post-step weights).  Needs two GPUs:
+    skipped on the single-GPU boxes of this pool (where the same trainer code runs over gloo above)."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (RCCL leg; the gloo legs above cover the same trainer code on one GPU)")
     case, ref = _case(name)
-    ranks = _run_ranks(case, tmp_path, True, factored=factored, backend="nccl")
-    worst = _check(case, ref, ranks, factored=factored and case["per_tower"] % 16 == 0)
-    print(f"[dp/rccl {name} factored={factored}] worst summed-gradient error {worst[0]:.2e} ({worst[1]})")
+    if route == "sharded":
+        ranks = _run_ranks(case, tmp_path, True, route="sharded", backend="nccl")
+        assert all(st["sharded"] and not st["factored"] for r in ranks for st in r["steps"])
+        worst = _check(case, ref, ranks, factored=False)
+    else:
+        factored = route == "factored"
+        ranks = _run_ranks(case, tmp_path, True, factored=factored, backend="nccl")
+        worst = _check(case, ref, ranks, factored=factored and case["per_tower"] % 16 == 0)
+    print(f"[dp/rccl {name} route={route}] worst summed-gradient error {worst[0]:.2e} ({worst[1]})")
 
 
 @pytest.mark.timeout(900)

@@ -133,9 +133,14 @@ def _full_size_compare(name, cfg, B, seed, dev, scale_hidden1=True, dropout_mask
                  model_kwargs=dict(iterations=cfg.iterations, cluster_size=cfg.cluster_size, hidden_size=cfg.hidden_size, **kw))
     tr.build(x, nf, lab)
     tr.store.load({"tower/" + k: v for k, v in p.items()})
-    tr.store.summaries = {}
     step_kw = {} if dropout_masks is None else {"dropout_masks": {k: v.to(dev) for k, v in dropout_masks.items()}}
+    # NetVladV1: the encoder GEMMs of the compared step run in the fp16 two-product operand format, scales measured on this batch
+    # (without this call the first steps of a run stay on split-bf16: ops.OperandScales)
+    if tr.calibrate_operand_scales(x, nf, lab, **step_kw):
+        print(f"[{name}] operand scales calibrated: {len(tr.operand_scales.slots)} sites")
+    tr.store.summaries = {}
     out = tr.step(x, nf, lab, **step_kw)
+    assert tr.operand_scales is None or tr.operand_scales.steps_fp16 == 1
     got, tr.store.summaries = tr.store.summaries, None
     K, Ka = cfg.cluster_size, cfg.cluster_size // 4
     errs = {}
