@@ -484,23 +484,31 @@ int lpm_sum_splits(const float* part, int Z, int K, int N, float* out0, float* o
 /* ---------------------------------------------------------------------------------------------
  * Round 5: the operand FORMAT of the dense GEMMs' 16-bit images and fragment tiles (csrc/operand_format.h).
  *   LPM_OPERAND_BF16X3: x = xh + xl as bf16 planes, three products per a . b (~5e-6 per GEMM) -- every entry point above, and what a
- *                       NULL format means below.
- *   LPM_OPERAND_FP16X2: the data operand (activations, gradients) as fp16 (hi, lo) planes, the weight operand rounded once to fp16:
- *                       TWO products per a . b (~1.4e-4 per GEMM: the weight's 2^-12 rounding).  Image rows are [hi | lo] (2K
- *                       16-bit words) for activations and gradients alike; weight images [Wh | Wh]; fragment tiles carry (hi, lo)
- *                       planes for the data operand and the hi plane only for the weight operand.  Every value is multiplied by
- *                       `scale` (a power of two chosen by the caller so that the tensor sits inside fp16's range; values beyond it
- *                       saturate at +-65504) before it is split; the consumer of the GEMM multiplies by 1 / scale.
- * amax (optional, either kind): the producer records max |x| of what it wrote, BEFORE scaling, by an atomic max on *amax (a device
- * float the caller zeroes) -- the measurement a delayed scale is chosen from (ops.OperandScales).
- * NetVladV1's encoder GEMMs (transformer_utils.py:559-561,583,701-711 and TF autodiff of them) run on LPM_OPERAND_FP16X2 when the
- * trainer's scales are calibrated; NetVladV2 stays on LPM_OPERAND_BF16X3 (its logits batch norm amplifies forward errors ~500 x).
+ *                       NULL format means below.  Image rows: [hi | lo | hi] (activations), [hi | hi | lo] (gradients).
+ *   LPM_OPERAND_FP16X3: ACTIVATIONS as fp16 (hi, lo) planes, image rows [hi | lo | hi]: the forward product keeps all three terms
+ *                       against a weight split into fp16 planes as well ([Wh ; Wh ; Wl]) -- ~1e-6 per GEMM.
+ *   LPM_OPERAND_FP16X2: GRADIENTS as fp16 (hi, lo) planes, image rows [hi | lo]: the backward products are TWO-term -- the input
+ *                       gradient against the weight rounded once to fp16 ([Wh ; Wh]), the weight gradient against the activation
+ *                       image's hi plane -- ~1.4e-4 per GEMM (the 2^-12 rounding of the one-plane operand).
+ *   fp16 kinds: every value is multiplied by `scale` (a power of two chosen by the caller so that the tensor sits inside fp16's range;
+ *   values beyond it saturate at +-65504) before it is split; the consumer of the GEMM multiplies by 1 / scale.
+ *   Weight forms of the fp16 kinds (lpm_split_weight_fmt / lpm_split_weight_tiles_fmt / lpm_weight_pack with kind != BF16X3):
+ *   wn [N, 3K] fp16 rows [Wh^T | Wh^T | Wl^T] (forward), wk [K, 2N] fp16 rows [Wh | Wh] (input gradient), weight tiles of W with
+ *   (hi, lo) fp16 planes (forward tile GEMM), weight tiles of W^T with the hi plane only (input-gradient tile GEMM).
+ * amax (optional, any kind): the producer records max |x| of what it wrote, BEFORE scaling, by atomic maxima into the site's
+ * LPM_OPERAND_AMAX_SUB sub-slots amax[LPM_OPERAND_AMAX_STRIDE * i] (one cache line apart, chosen by workgroup: same-address atomics
+ * serialise; the caller zeroes all of them and takes the maximum over them) -- the measurement a delayed scale is chosen from
+ * (ops.OperandScales).
+ * NetVladV1's encoder GEMMs (transformer_utils.py:559-561,583,701-711 and TF autodiff of them) run on the fp16 kinds when the
+ * trainer's scales are calibrated; NetVladV2 stays on LPM_OPERAND_BF16X3.
  * ------------------------------------------------------------------------------------------- */
-enum { LPM_OPERAND_BF16X3 = 0, LPM_OPERAND_FP16X2 = 1 };
+enum { LPM_OPERAND_BF16X3 = 0, LPM_OPERAND_FP16X2 = 1, LPM_OPERAND_FP16X3 = 2 };
+#define LPM_OPERAND_AMAX_SUB 32
+#define LPM_OPERAND_AMAX_STRIDE 16
 typedef struct LpmOperandFormat {
     int kind;       /* LPM_OPERAND_* */
     float scale;    /* > 0, a power of two; 1 for LPM_OPERAND_BF16X3 */
-    float* amax;    /* device, may be NULL */
+    float* amax;    /* device, may be NULL: LPM_OPERAND_AMAX_SUB * LPM_OPERAND_AMAX_STRIDE floats */
 } LpmOperandFormat;
 /* lpm_split_rows / lpm_split_rows_scaled in either format: x [M,K] (row stride ldx), optionally * row_scale[m], + bias, ReLU ->
  * image [M, planes K] (bf16x3: `order` 0 = [hi|lo|hi], 1 = [hi|hi|lo]; fp16x2: [hi|lo]). */
@@ -510,9 +518,10 @@ int lpm_split_rows_fmt(const float* x, int64_t ldx, int64_t M, int K, const floa
  * mask from the hi plane of the forward's activation image in format act_kind, dbias = column sums of g (un-scaled). */
 int lpm_split_rows_relu_bwd_fmt(const float* df, int64_t M, int K, float alpha, const void* act_img, int act_kind, void* out_img, float* dbias,
                                 void* workspace, size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream);
-/* lpm_split_weight in either format.  fp16x2: wn [N, 2K] rows [Wh^T | Wh^T], wk [K, 2N] rows [Wh | Wh] (wk may be NULL). */
+/* lpm_split_weight in either format.  fp16 kinds: wn [N, 3K] fp16 rows [Wh^T | Wh^T | Wl^T], wk [K, 2N] fp16 rows [Wh | Wh] (wk may be NULL). */
 int lpm_split_weight_fmt(const float* W, int K, int N, void* wn, void* wk, int kind, lpm_stream_t stream);
-/* lpm_split_weight_tiles in either format.  fp16x2: the hi plane only, lpm_weight_tiles_bytes(R, N) / 2 bytes. */
+/* lpm_split_weight_tiles in either format.  LPM_OPERAND_FP16X3: fp16 (hi, lo) planes (the forward's weight operand);
+ * LPM_OPERAND_FP16X2: the fp16 hi plane only, lpm_weight_tiles_bytes(R, N) / 2 bytes (the weight operand of a two-term product). */
 int lpm_split_weight_tiles_fmt(const float* w, int R, int N, int transposed, void* wt, int kind, lpm_stream_t stream);
 /* lpm_split_rows_tiles / lpm_image_row_tiles in either format (fp16x2 row tiles: fp16 (hi, lo) planes, same geometry). */
 int lpm_split_rows_tiles_fmt(const float* x, int64_t ldx, int B, int T, int C, void* out, const LpmOperandFormat* fmt, lpm_stream_t stream);
@@ -566,8 +575,8 @@ typedef struct LpmWeightPackJob {
     void* w3k;
     void* wt;
     void* wtt;
-    int kind;           /* LPM_OPERAND_*: fp16x2 writes w3n as [Ntot, 2K] = [Wh^T | Wh^T], w3k as [K, 2 Ntot] = [Wh | Wh] and the hi plane
-                           only of wt / wtt (lpm_split_weight_fmt, lpm_split_weight_tiles_fmt) */
+    int kind;           /* LPM_OPERAND_BF16X3, or an fp16 kind: w3n [Ntot, 3K] fp16 = [Wh^T | Wh^T | Wl^T], w3k [K, 2 Ntot] fp16 = [Wh | Wh], wt with
+                           fp16 (hi, lo) planes, wtt with the fp16 hi plane only (lpm_split_weight_fmt, lpm_split_weight_tiles_fmt) */
 } LpmWeightPackJob;
 int lpm_weight_pack(const LpmWeightPackJob* jobs, int njobs, lpm_stream_t stream);
 /* backward of the fused relu(x + bias) split (FeedForwardNetwork, transformer_utils.py:701-711): g = df * [act > 0]

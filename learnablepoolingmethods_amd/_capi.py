@@ -184,6 +184,9 @@ SIGNATURES = {
 }
 LPM_OPERAND_BF16X3 = 0
 LPM_OPERAND_FP16X2 = 1
+LPM_OPERAND_FP16X3 = 2
+LPM_OPERAND_AMAX_SUB = 32        # sub-slots of a site's max |x| record, LPM_OPERAND_AMAX_STRIDE floats apart (include/lpm_hip.h)
+LPM_OPERAND_AMAX_STRIDE = 16
 
 
 class OperandFormat(C.Structure):

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
             vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
             uint2 hi, lo;
             of_split4(o.x, o.y, o.z, o.w, 1, fmt.scale, hi, lo);
-            of_store_row4(y3 + ((int64_t)b * (n_per / F) + i / F4) * 2 * F, F, c, hi, lo, 1, 0);
+            of_store_row4(y3 + ((int64_t)b * (n_per / F) + i / F4) * fmt.planes * F, F, c, hi, lo, fmt.planes, 0);
         } else if (y3) {
             vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
             const unsigned hx = ln_bf16_pair(o.x, o.y), hz = ln_bf16_pair(o.z, o.w);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
             vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
             uint2 hi, lo;
             of_split4(o.x, o.y, o.z, o.w, 1, fmt.scale, hi, lo);
-            of_store_row4(da_img + ((int64_t)b * L + l) * 2 * F, F, 4 * c4, hi, lo, 1, 1);
+            of_store_row4(da_img + ((int64_t)b * L + l) * fmt.planes * F, F, 4 * c4, hi, lo, fmt.planes, 1);
         } else if (da_img) {      // da only feeds GEMMs: it leaves as their split-bf16 gradient image, row = [hi | hi | lo] planes of F
             vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
             unsigned short* p = da_img + ((int64_t)b * L + l) * 3 * F + 4 * c4;
@@ -489,9 +489,9 @@ extern "C" int lpm_layer_norm_pair_fwd(const float* a, const float* bias, int re
     hipLaunchKernelGGL(ln_fwd_stats_kernel<false>, grid, dim3(256), 0, s, a, r, bias, relu, F, n_per, z1, partial1, (const float*)nullptr,
                        (const unsigned char*)nullptr, 1.f);
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z1, (const float*)partial1, gamma1, beta1, n_per, F, eps,
-                       z2, n_per, stats1, r, partial2, (unsigned short*)nullptr, OperandFmt{0, 1.f, nullptr});
+                       z2, n_per, stats1, r, partial2, (unsigned short*)nullptr, OperandFmt{0, 3, 1.f, nullptr});
     hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(256), 0, s, (const float*)z2, (const float*)partial2, gamma2, beta2, n_per, F, eps,
-                       y, yb, stats2, (const float*)nullptr, (float*)nullptr, (unsigned short*)nullptr, OperandFmt{0, 1.f, nullptr});
+                       y, yb, stats2, (const float*)nullptr, (float*)nullptr, (unsigned short*)nullptr, OperandFmt{0, 3, 1.f, nullptr});
     return check_launch("lpm_layer_norm_pair_fwd");
 }
 

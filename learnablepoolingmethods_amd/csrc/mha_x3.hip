@@ -52,8 +52,8 @@ __device__ __forceinline__ void mx_split8(const float* v, mx_u32x4& hi, mx_u32x4
 // Round 5: both images also exist in the fp16 two-product format (operand_format.h) -- [hi | lo] planes of value * scale, max |value|
 // recorded for the host's delayed scale.  MxImg carries the formats of the attention result's image (o*) and of the gradient image (g*).
 struct MxImg {
-    int of16; float oscale, oinv; float* oamax;
-    int gf16; float gscale; float* gamax;
+    int of16, oplanes; float oscale, oinv; float* oamax;
+    int gf16, gplanes; float gscale; float* gamax;
 };
 __device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img, float a, float b, float c, float d, const MxImg& im, float& vmax) {
     if (img == 0) {
@@ -64,7 +64,12 @@ __device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img
         of_split4(a, b, c, d, 1, im.gscale, hi, lo);
         unsigned short* p = reinterpret_cast<unsigned short*>(base) + off;
         *reinterpret_cast<uint2*>(p) = hi;
-        *reinterpret_cast<uint2*>(p + img) = lo;
+        if (im.gplanes == 2) {
+            *reinterpret_cast<uint2*>(p + img) = lo;
+        } else {
+            *reinterpret_cast<uint2*>(p + img) = hi;
+            *reinterpret_cast<uint2*>(p + 2 * (int64_t)img) = lo;
+        }
     } else {
         vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
         unsigned h0, l0, h1, l1;
@@ -87,9 +92,10 @@ __device__ __forceinline__ void mx_store_act4(float* base, int64_t row, int64_t 
         vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
         uint2 hi, lo;
         of_split4(a, b, c, d, 1, im.oscale, hi, lo);
-        unsigned short* p = reinterpret_cast<unsigned short*>(base) + row * 2 * (int64_t)oimg + col;
+        unsigned short* p = reinterpret_cast<unsigned short*>(base) + row * im.oplanes * (int64_t)oimg + col;
         *reinterpret_cast<uint2*>(p) = hi;
         *reinterpret_cast<uint2*>(p + oimg) = lo;
+        if (im.oplanes == 3) *reinterpret_cast<uint2*>(p + 2 * (int64_t)oimg) = hi;
     } else {
         vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
         unsigned h0, l0, h1, l1;
@@ -107,7 +113,7 @@ __device__ __forceinline__ void mx_load_o8(const float* base, int64_t row, int64
         a = *reinterpret_cast<const float4*>(base + row * ldo + col);
         c = *reinterpret_cast<const float4*>(base + row * ldo + col + 4);
     } else if (im.of16) {
-        const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + row * 2 * (int64_t)oimg + col;
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + row * im.oplanes * (int64_t)oimg + col;
         const uint4 h = *reinterpret_cast<const uint4*>(p), l = *reinterpret_cast<const uint4*>(p + oimg);
         const float s = im.oinv;
         a = make_float4((mx_h2f(h.x, 0) + mx_h2f(l.x, 0)) * s, (mx_h2f(h.x, 1) + mx_h2f(l.x, 1)) * s, (mx_h2f(h.y, 0) + mx_h2f(l.y, 0)) * s,
@@ -749,7 +755,7 @@ static int mx_reserve(KernT kern, size_t bytes, const char* what) {
 
 static lpm::MxImg mx_img(const LpmOperandFormat* o_fmt, const LpmOperandFormat* g_fmt) {
     const lpm::OperandFmt fo = lpm::operand_fmt(o_fmt), fg = lpm::operand_fmt(g_fmt);
-    return lpm::MxImg{fo.f16, fo.scale, 1.f / fo.scale, fo.amax, fg.f16, fg.scale, fg.amax};
+    return lpm::MxImg{fo.f16, fo.planes, fo.scale, 1.f / fo.scale, fo.amax, fg.f16, fg.planes, fg.scale, fg.amax};
 }
 static int mx_fwd_launch(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d, float scale,
                          const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse, int oimg,
@@ -938,9 +944,9 @@ extern "C" int lpm_mha_bwd_x3_image_fmt(const float* q, const float* k, const fl
     if (const int rc = operand_fmt_check(o_fmt, "lpm_mha_bwd_x3_image")) return rc;
     if (const int rc = operand_fmt_check(g_fmt, "lpm_mha_bwd_x3_image")) return rc;
     const int N = h * d;
-    const int gf16 = (g_fmt && g_fmt->kind == LPM_OPERAND_FP16X2) ? 1 : 0;      // fp16x2 row: [hi(3N) | lo(3N)]
+    const int gpl = g_fmt ? operand_kind_planes(g_fmt->kind) : 3;      // two planes: row = [hi(3N) | lo(3N)]
     unsigned short* base = (unsigned short*)dqkv_img;
     return mx_bwd_launch(q, k, v, ld, (const float*)o_img, dout, ldo, lse, B, L, h, d, scale, nullptr, nullptr, (float*)base, (float*)(base + N),
-                         (float*)(base + 2 * N), (int64_t)(gf16 ? 6 : 9) * N, nullptr, nullptr, nullptr, 3 * N, N, stream,
+                         (float*)(base + 2 * N), (int64_t)(3 * gpl) * N, nullptr, nullptr, nullptr, 3 * N, N, stream,
                          "lpm_mha_bwd_x3_image", o_fmt, g_fmt);
 }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
             hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
         }
-        of_store_row8(out3 + m * of_row_stride(K, fmt.f16), K, c, hi, lo, fmt.f16, order);
+        of_store_row8(out3 + m * of_row_stride(K, fmt.planes), K, c, hi, lo, fmt.planes, order);
     }
     of_amax_commit(fmt.amax, vmax);
 }
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 // column partial sums of g (the bias gradient) -> colpart [gridDim.x][K].  One workgroup = SR_ROWS rows, all columns.
 constexpr int SR_ROWS = 32;
 __global__ __launch_bounds__(256) void split_rows_relu_bwd_kernel(const float* __restrict__ df, int64_t M, int K,
-                                                                  const unsigned short* __restrict__ act3, int act_f16,
+                                                                  const unsigned short* __restrict__ act3, int act_planes,
                                                                   unsigned short* __restrict__ out3,
                                                                   float* __restrict__ colpart, float alpha, const OperandFmt fmt) {
     const int K8 = K / 8;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void split_rows_relu_bwd_kernel(const float* _
         for (int64_t m = r0; m < r1; ++m) {
             const float4 a = *reinterpret_cast<const float4*>(df + m * K + c);
             const float4 b = *reinterpret_cast<const float4*>(df + m * K + c + 4);
-            const uint4 hm = *reinterpret_cast<const uint4*>(act3 + m * of_row_stride(K, act_f16) + c);   // hi plane of the activation
+            const uint4 hm = *reinterpret_cast<const uint4*>(act3 + m * of_row_stride(K, act_planes) + c);   // hi plane of the activation
             float v[8] = {a.x * alpha, a.y * alpha, a.z * alpha, a.w * alpha, b.x * alpha, b.y * alpha, b.z * alpha, b.w * alpha};
             const unsigned mw[4] = {hm.x, hm.y, hm.z, hm.w};
 #pragma unroll
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void split_rows_relu_bwd_kernel(const float* _
                 hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                 lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
             }
-            of_store_row8(out3 + m * of_row_stride(K, fmt.f16), K, c, hi, lo, fmt.f16, 1);     // (bf16x3: gradient plane order [hi | hi | lo])
+            of_store_row8(out3 + m * of_row_stride(K, fmt.planes), K, c, hi, lo, fmt.planes, 1);     // (three planes: gradient order [hi | hi | lo])
         }
         float* cp = colpart + (int64_t)blockIdx.x * K + c;
         *reinterpret_cast<float4*>(cp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
 //   w3n [N, 3K]: row n = [Wh[:,n] | Wh[:,n] | Wl[:,n]]   (forward: y = X3 . w3n^T, X3 = [xh|xl|xh])
 //   w3k [K, 3N]: row k = [Wh[k,:] | Wl[k,:] | Wh[k,:]]   (input gradient: dx = DY3 . w3k^T, DY3 = [dyh|dyh|dyl])
 // Both are "B stored transposed" (NT) operands: hipBLASLt runs that layout 8-10 % faster than NN at these shapes.
-// f16 (the two-product form): the weight rounded once to fp16, wn [N, 2K] = [Wh^T | Wh^T], wk [K, 2N] = [Wh | Wh].
+// f16: fp16 planes -- wn [N, 3K] = [Wh^T | Wh^T | Wl^T] (the forward's three-term product), wk [K, 2N] = [Wh | Wh] (the input gradient's
+// two-term product: the weight rounded once).
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int K, int N,
                                                            unsigned short* __restrict__ w3n,
                                                            unsigned short* __restrict__ w3k, int f16) {
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
         if (k < K && n < N) {
             const float v = W[(int64_t)k * N + n];
             if (f16) {
-                h = of_round2_f16(v, 0.f) & 0xffffu;
+                of_split1_f16(v, h, l);
                 if (w3k) {
                     unsigned short* row = w3k + (int64_t)k * 2 * N;
                     row[n] = (unsigned short)h;
@@ -176,10 +177,10 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
         const int n = n0 + ty + 8 * i, k = k0 + tx;
         if (k < K && n < N) {
             const unsigned short h = th[tx][ty + 8 * i], l = tl[tx][ty + 8 * i];
-            unsigned short* row = w3n + (int64_t)n * (f16 ? 2 : 3) * K;
+            unsigned short* row = w3n + (int64_t)n * 3 * K;
             row[k] = h;
             row[K + k] = h;
-            if (!f16) row[2 * K + k] = l;
+            row[2 * K + k] = l;
         }
     }
 }
@@ -278,7 +279,7 @@ extern "C" int lpm_split_rows_relu_bwd_fmt(const float* df, int64_t M, int K, fl
                                            void* workspace, size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream) {
     using namespace lpm;
     if (const int rc = operand_fmt_check(fmt, "lpm_split_rows_relu_bwd")) return rc;
-    LPM_REQUIRE(alpha > 0.f && (act_kind == LPM_OPERAND_BF16X3 || act_kind == LPM_OPERAND_FP16X2), LPM_ERR_BADARG,
+    LPM_REQUIRE(alpha > 0.f && operand_kind_ok(act_kind), LPM_ERR_BADARG,
                 "lpm_split_rows_relu_bwd: bad alpha / act_kind");
     LPM_REQUIRE(df && act3 && out3 && dbias && workspace, LPM_ERR_BADARG, "lpm_split_rows_relu_bwd: null pointer");
     LPM_REQUIRE(M > 0 && K > 0 && K % 8 == 0, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_split_rows_relu_bwd: need K %% 8 == 0 (K=%d)", K);
@@ -287,7 +288,7 @@ extern "C" int lpm_split_rows_relu_bwd_fmt(const float* df, int64_t M, int K, fl
     const int nblk = (int)((M + SR_ROWS - 1) / SR_ROWS);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(split_rows_relu_bwd_kernel, dim3(nblk), dim3(256), 0, s, df, M, K, (const unsigned short*)act3,
-                       act_kind == LPM_OPERAND_FP16X2 ? 1 : 0, (unsigned short*)out3, (float*)workspace, alpha, operand_fmt(fmt));
+                       operand_kind_planes(act_kind), (unsigned short*)out3, (float*)workspace, alpha, operand_fmt(fmt));
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((K + 15) / 16), dim3(1024), 0, s, (const float*)workspace, nblk, K, dbias);
     return check_launch("lpm_split_rows_relu_bwd");
 }
@@ -296,9 +297,9 @@ extern "C" int lpm_split_weight_fmt(const float* W, int K, int N, void* w3n, voi
     using namespace lpm;
     LPM_REQUIRE(W && w3n, LPM_ERR_BADARG, "lpm_split_weight: null pointer");
     LPM_REQUIRE(K > 0 && N > 0, LPM_ERR_BADARG, "lpm_split_weight: bad sizes");
-    LPM_REQUIRE(kind == LPM_OPERAND_BF16X3 || kind == LPM_OPERAND_FP16X2, LPM_ERR_BADARG, "lpm_split_weight: unknown operand format %d", kind);
+    LPM_REQUIRE(operand_kind_ok(kind), LPM_ERR_BADARG, "lpm_split_weight: unknown operand format %d", kind);
     hipLaunchKernelGGL(split_weight_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, (hipStream_t)stream, W, K, N,
-                       (unsigned short*)w3n, (unsigned short*)w3k, kind == LPM_OPERAND_FP16X2 ? 1 : 0);
+                       (unsigned short*)w3n, (unsigned short*)w3k, operand_kind_f16(kind));
     return check_launch("lpm_split_weight");
 }
 extern "C" int lpm_split_weight(const float* W, int K, int N, void* w3n, void* w3k, lpm_stream_t stream) {

@@ -108,10 +108,11 @@ struct TileGemmArgs {
     const unsigned short* img_mask;
     float* img_colpart;
     int img_kind;
-    // round 5 (operand_format.h): the image leaves in either operand format -- img_f16 = 1: fp16 planes [hi | lo] of v * img_scale;
-    // img_amax (nullable): max |v| of the launch; mask_f16: the format of img_mask's image (its row stride); alpha: the accumulators
-    // are multiplied by it first (1 / the scale of the data operand's tiles; the launchers set 1 when it is left 0)
-    int img_f16, mask_f16;
+    // round 5 (operand_format.h): the image leaves in any operand format -- img_f16 = 1: fp16 planes of v * img_scale, img_planes = 3
+    // ([hi | lo | hi] / [hi | hi | lo]) or 2 ([hi | lo]); img_amax (nullable): max |v| of the launch; mask_planes: the planes per row of
+    // img_mask's image (its row stride); alpha: the accumulators are multiplied by it first (1 / the scale of the data operand's tiles;
+    // the launchers set 1 when it is left 0)
+    int img_f16, img_planes, mask_planes;
     float img_scale, alpha;
     float* img_amax;
     float* stats;              // STORE, optional: [gridDim.x][2][cols_valid] per-workgroup column (sum, sum of squares)
@@ -126,8 +127,9 @@ struct TileGemmArgs {
 
 // Launchers (defined in tile_gemm.hip, the only translation unit that instantiates the kernel).  nbatch * rb_per_batch
 // workgroup rows, ceil(cols / (128 NTW)) column blocks, `splits` reduction splits.
-// planes: 2 = split-bf16 operands (hi, lo), 1 = plain bf16 operands, 3 = the fp16 two-product form (A fp16 (hi, lo) tiles, B fp16 hi-plane
-// tiles of 64 units per (tile, step); image epilogue of the 256-row form only)
+// planes: 2 = split-bf16 operands (hi, lo), 1 = plain bf16 operands; fp16 operands (round 5; image epilogue of the 256-row form only):
+// 3 = the two-term product (A fp16 (hi, lo) tiles, B fp16 hi-plane tiles of 64 units per (tile, step)), 4 = the three-term product (both
+// operands fp16 (hi, lo) tiles)
 int tile_gemm_store(const TileGemmArgs& g, int nbatch, int splits, hipStream_t stream, const char* what, int ntw = 0, int planes = 2);   // ntw 0 = by column count
 int tile_gemm_adam(const TileGemmArgs& g, hipStream_t stream, const char* what);      // 64 x 128 tiles, one batch, one split, split-bf16
 int tile_gemm_softmax_bwd(const TileGemmArgs& g, int nbatch, hipStream_t stream, const char* what, int planes = 2);

@@ -35,11 +35,13 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
     static_assert(RTW == 2 || (RTW == 4 && MW == 2 && EPI == TG_EPI_STORE && NS >= 4), "four row tiles per wave: pipelined 128-row form only");
     static_assert(MW == 1 || EPI == TG_EPI_STORE, "the 128-row form has the store epilogue only");
     static_assert(EPI != TG_EPI_ADAM || (NTW == 1 && PL == 2), "the Adam epilogue: 64 x 128 tiles of split-bf16 operands");
-    static_assert(PL == 1 || PL == 2 || PL == 3, "planes");
-    static_assert(PL != 3 || (MW == 2 && RTW == 4 && EPI == TG_EPI_STORE && FORM == 0 && NS >= 4), "the fp16 two-product form: pipelined 256-row workgroups");
+    static_assert(PL >= 1 && PL <= 4, "planes");
+    static_assert(PL < 3 || (MW == 2 && RTW == 4 && EPI == TG_EPI_STORE && FORM == 0 && NS >= 4), "the fp16 forms: pipelined 256-row workgroups");
     // PL == 1: plain bf16 tiles, a ring stage = two reduction steps ("sub" below is the step within the stage where the split
     // form has the plane); no second operand pair.
     // PL == 3 (round 5): fp16 operands, A = (hi, lo) planes, B = the hi plane only (64 units per (tile, step)): a . b = ah bh + al bh.
+    // PL == 4: fp16 operands, both (hi, lo): the three terms of the split form on the fp16 pipe.
+    constexpr bool SPLIT = PL == 2 || PL == 4;     // both operands carry (hi, lo) planes, three terms per product
     constexpr int PLB = PL == 3 ? 1 : 2;           // pieces per column tile and stage
     constexpr int NTB = 4 * NTW;                   // column tiles per workgroup
     constexpr int NWV = 4 * MW;                    // waves per workgroup
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
     const int split = blockIdx.z;
     const int step0 = split * g.steps_per_split;
     const int nred = min(g.steps_per_split, g.total_steps - step0);     // reduction steps of this split
-    const int nstep1 = PL >= 2 ? nred : (nred + 1) / 2;                   // ring stages
+    const int nstep1 = PL >= 2 ? nred : (nred + 1) / 2;                   // ring stages (the second operand pair: split-bf16 only)
     const int nstep = nstep1 + (PL == 2 ? g.steps2 : 0);
 
     // this wave's PW pieces of a stage: piece p < 4: row tile p>>1, plane p&1;  else column tile (p-4)>>1, plane (p-4)&1
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
     for (int j = 0; j < PW; ++j) {
         const int p = wave + NWV * j;
         // split form: the piece's plane sits (p & 1) * 64 units into the (tile, step) pair; plain form: same tile, step + (p & 1)
-        const int pl = (PL == 2 || (PL == 3 && p < NRP)) ? (p & 1) * 64 : 0;
+        const int pl = (SPLIT || (PL == 3 && p < NRP)) ? (p & 1) * 64 : 0;
         sub[j] = p & 1;
         if (p < NRP) {
             if (MW == 1) {
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
 #pragma unroll
                     for (int m = 0; m < RTW; ++m) {
                         if constexpr (PL == 3) acc[m][n] = tg_mfma_f16(t ? cur.al[m] : cur.ah[m], cur.bh[n], acc[m][n]);
+                        else if constexpr (PL == 4) acc[m][n] = tg_mfma_f16(t == 2 ? cur.al[m] : cur.ah[m], t == 1 ? cur.bl[n] : cur.bh[n], acc[m][n]);
                         else if (PL == 2) acc[m][n] = tg_mfma(t == 2 ? cur.al[m] : cur.ah[m], t == 1 ? cur.bl[n] : cur.bh[n], acc[m][n]);
                         else acc[m][n] = tg_mfma(t ? cur.al[m] : cur.ah[m], t ? cur.bl[PL == 3 ? 0 : n] : cur.bh[n], acc[m][n]);
                     }
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < nstep) read_frags(s + 1, nxt);
             __builtin_amdgcn_sched_barrier(0);
-            if (PL == 2 && !(dbg & 8)) mfma_term(2);
+            if (SPLIT && !(dbg & 8)) mfma_term(2);
         };
         Frag fa, fb;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");      // step 0 has landed (this wave's pieces)
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                 float bias8[8], colacc[8];
                 float vmax = 0.f;                                  // max |v| of what this thread writes (img_amax)
                 const float alpha = g.alpha;
-                const int64_t istride = of_row_stride(N, g.img_f16), mstride = of_row_stride(N, g.mask_f16);
+                const int64_t istride = of_row_stride(N, g.img_planes), mstride = of_row_stride(N, g.mask_planes);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; colacc[e] = 0.f; }
                 if (g.img_kind == 1 && colok) {
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                             of_split8(v, g.img_f16, g.img_scale, hi, lo);
                             unsigned short* rowp = g.img + R * istride + gcol;
                             const tg_u32x4 hv = {hi.x, hi.y, hi.z, hi.w}, lv = {lo.x, lo.y, lo.z, lo.w};
-                            if (g.img_f16) {
+                            if (g.img_planes == 2) {
                                 if (g.nt_store) {
                                     __builtin_nontemporal_store(hv, reinterpret_cast<tg_u32x4*>(rowp));
                                     __builtin_nontemporal_store(lv, reinterpret_cast<tg_u32x4*>(rowp + N));
@@ -654,8 +657,8 @@ static bool tg_wide_ok(const TileGemmArgs& g, int nbatch, int splits, int ntw, i
 // 2 = 128-row form with a 3-stage ring and two workgroups per CU, 3 = 256-row form (four row tiles per wave; no statistics)
 constexpr int TG_WIDE_NS_DEFAULT = 4;
 constexpr int TG_AP_DEFAULT = 0;
-// the fp16 two-product form (PL == 3): 256-row workgroups with the image epilogue only
-static int tg_launch_f16_image(const TileGemmArgs& g, hipStream_t stream, const char* what) {
+// the fp16 forms (PL == 3: two terms, B hi-plane tiles; PL == 4: three terms): 256-row workgroups with the image epilogue only
+static int tg_launch_f16_image(const TileGemmArgs& g, hipStream_t stream, const char* what, int planes) {
     if (!tg_wide_ok(g, 1, 1, 2, 3, 8)) {
         set_error("%s: the fp16 image form needs row tiles a multiple of 8 and >= 16 reduction steps", what);
         return LPM_ERR_UNSUPPORTED_SHAPE;
@@ -665,14 +668,17 @@ static int tg_launch_f16_image(const TileGemmArgs& g, hipStream_t stream, const 
     TileGemmArgs gl = g;
     gl.dbg = 0;
     gl.cols_inner = 0;
-    const size_t lds = (size_t)4 * (16 + 4 * 2) * 1024;           // 4 stages x (16 row-tile pieces + 8 column-tile hi planes)
-    auto kern = tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, 3, 4>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    // 4 stages x (16 row-tile pieces + 8 column tiles x (hi) or (hi, lo) planes)
+    const size_t lds = (size_t)4 * (16 + (planes == 3 ? 4 : 8) * 2) * 1024;
+    auto k3 = tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, 3, 4>;
+    auto k4 = tile_gemm_kernel<2, TG_EPI_STORE, 2, 4, 4, 4>;
+    if (hipFuncSetAttribute(planes == 3 ? (const void*)k3 : (const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         set_error("%s: cannot reserve %zu bytes of LDS", what, lds);
         return LPM_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, gl);
+    if (planes == 3) hipLaunchKernelGGL(k3, grid, dim3(512), lds, stream, gl);
+    else hipLaunchKernelGGL(k4, grid, dim3(512), lds, stream, gl);
     return check_launch(what);
 }
 
@@ -800,10 +806,12 @@ int tile_gemm_image(const TileGemmArgs& g, hipStream_t stream, const char* what,
     if (!(gl.img_scale > 0.f)) gl.img_scale = 1.f;
     gl.out = reinterpret_cast<float*>(g.img);      // (the fp32 output checks of the launcher: an aligned non-null pointer; never written)
     gl.ldo = 4; gl.out_batch = 0; gl.out_split = 0;
-    if (planes == 3) {
+    if (gl.img_planes != 2) gl.img_planes = 3;
+    if (gl.mask_planes != 2) gl.mask_planes = 3;
+    if (planes >= 3) {
         static const int nt3 = [] { const char* e = getenv("LPM_DENSE_IMG_NT"); return (e && e[0] == '0') ? 0 : 1; }();
         gl.nt_store = nt3;
-        return tg_launch_f16_image(gl, stream, what);
+        return tg_launch_f16_image(gl, stream, what, planes);
     }
     // non-temporal stores: the 0.5 GB image is read back by the next GEMM long after it has left the caches (-6 us of 520 measured;
     // LPM_DENSE_IMG_NT=0: plain stores, A/B)
@@ -849,7 +857,8 @@ __global__ __launch_bounds__(256) void split_rows_tiles_kernel(const float* __re
 }
 
 // B operand of M[R, N] (reduction R, columns N): [rs][nt][plane][lane].  transposed: the source is stored [N, R].
-// planes 2: split-bf16 (hi, lo); 1: plain bf16; 3: fp16, the hi plane only (the weight operand of the two-product form, rounded once)
+// planes 2: split-bf16 (hi, lo); 1: plain bf16; 3: fp16, the hi plane only (the one-plane operand of a two-term product, rounded once);
+// 4: fp16 (hi, lo)
 __global__ __launch_bounds__(256) void split_weight_tiles_kernel(const float* __restrict__ W, int R, int N, int transposed,
                                                                  uint4* __restrict__ wt, int planes) {
     const int RS = R / 16, NT = (N + 31) / 32;
@@ -868,7 +877,8 @@ __global__ __launch_bounds__(256) void split_weight_tiles_kernel(const float* __
             continue;
         }
         uint4 hi, lo;
-        tg_split8(v, hi, lo);
+        if (planes == 4) of_split8(v, 1, 1.f, hi, lo);
+        else tg_split8(v, hi, lo);
         if (planes == 1) {
             wt[t * 64 + lane] = hi;
             continue;
@@ -1154,8 +1164,8 @@ extern "C" int lpm_split_weight_tiles_bf16(const float* w, int R, int N, int tra
     return split_weight_tiles_impl(w, R, N, transposed, wt, 1, stream);
 }
 extern "C" int lpm_split_weight_tiles_fmt(const float* w, int R, int N, int transposed, void* wt, int kind, lpm_stream_t stream) {
-    LPM_REQUIRE(kind == LPM_OPERAND_BF16X3 || kind == LPM_OPERAND_FP16X2, LPM_ERR_BADARG, "lpm_split_weight_tiles_fmt: unknown operand format %d", kind);
-    return split_weight_tiles_impl(w, R, N, transposed, wt, kind == LPM_OPERAND_FP16X2 ? 3 : 2, stream);
+    LPM_REQUIRE(lpm::operand_kind_ok(kind), LPM_ERR_BADARG, "lpm_split_weight_tiles_fmt: unknown operand format %d", kind);
+    return split_weight_tiles_impl(w, R, N, transposed, wt, kind == LPM_OPERAND_FP16X2 ? 3 : (kind == LPM_OPERAND_FP16X3 ? 4 : 2), stream);
 }
 
 static int assign_gemm_tiles_fwd_impl(const void* xr, const void* wt, int B, int T, int D, int K, void* logits, float* partial,
@@ -1229,10 +1239,11 @@ extern "C" int lpm_dense_tiles_act_image_fwd(const void* xr, const void* wt, con
                                              lpm_stream_t stream) {
     return lpm_dense_tiles_act_image_fwd_fmt(xr, wt, bias, M, Kd, N, 1.f, out3, nullptr, stream);
 }
-static void dense_tiles_fmt(lpm::TileGemmArgs& g, const LpmOperandFormat* fmt, float in_inv_scale, int N) {
+// one_plane_b: the weight operand as fp16 hi-plane tiles of 64 units (the two-term product of the backward)
+static void dense_tiles_fmt(lpm::TileGemmArgs& g, const LpmOperandFormat* fmt, float in_inv_scale, int N, bool one_plane_b) {
     const lpm::OperandFmt f = lpm::operand_fmt(fmt);
-    g.img_f16 = f.f16; g.img_scale = f.scale; g.img_amax = f.amax; g.alpha = in_inv_scale;
-    if (f.f16) {                                   // the weight operand: hi-plane tiles of 64 units
+    g.img_f16 = f.f16; g.img_planes = f.planes; g.img_scale = f.scale; g.img_amax = f.amax; g.alpha = in_inv_scale;
+    if (f.f16 && one_plane_b) {
         const int NT = N / 32;
         g.b_tile = 64; g.b_step = (int64_t)NT * 64;
     }
@@ -1249,8 +1260,8 @@ extern "C" int lpm_dense_tiles_act_image_fwd_fmt(const void* xr, const void* wt,
     TileGemmArgs g{};
     dense_tiles_args(g, xr, wt, M, Kd, N);
     g.img = (unsigned short*)out3; g.img_kind = 1; g.img_bias = bias;
-    dense_tiles_fmt(g, fmt, in_inv_scale, N);
-    return tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_act_image_fwd", g.img_f16 ? 3 : 2);
+    dense_tiles_fmt(g, fmt, in_inv_scale, N, false);      // forward: three terms, the weight tiles carry (hi, lo) like the row tiles
+    return tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_act_image_fwd", g.img_f16 ? 4 : 2);
 }
 extern "C" size_t lpm_dense_tiles_relu_bwd_workspace_bytes(int M, int N) { return (size_t)((M + 63) / 64) * N * sizeof(float); }
 // g = (dy . w^T) masked by [act > 0]: out3 [M, 3N] bf16 = its gradient image [hi | hi | lo], dbias [N] = its column sums.
@@ -1266,8 +1277,7 @@ extern "C" int lpm_dense_tiles_relu_bwd_image_fmt(const void* dyr, const void* w
     using namespace lpm;
     LPM_REQUIRE(dyr && wtt && act3 && out3 && dbias && workspace, LPM_ERR_BADARG, "lpm_dense_tiles_relu_bwd_image: null pointer");
     if (const int rc = operand_fmt_check(fmt, "lpm_dense_tiles_relu_bwd_image")) return rc;
-    LPM_REQUIRE(in_inv_scale > 0.f && (act_kind == LPM_OPERAND_BF16X3 || act_kind == LPM_OPERAND_FP16X2), LPM_ERR_BADARG,
-                "lpm_dense_tiles_relu_bwd_image: bad in_inv_scale / act_kind");
+    LPM_REQUIRE(in_inv_scale > 0.f && operand_kind_ok(act_kind), LPM_ERR_BADARG, "lpm_dense_tiles_relu_bwd_image: bad in_inv_scale / act_kind");
     LPM_REQUIRE(lpm_dense_tiles_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_dense_tiles_relu_bwd_image: need M %% 256 == 0, Kd %% 16 == 0, Kd >= 256, N %% 256 == 0 (M=%d Kd=%d N=%d)", M, Kd, N);
     LPM_REQUIRE(workspace_bytes >= lpm_dense_tiles_relu_bwd_workspace_bytes(M, N), LPM_ERR_WORKSPACE,
@@ -1276,8 +1286,8 @@ extern "C" int lpm_dense_tiles_relu_bwd_image_fmt(const void* dyr, const void* w
     TileGemmArgs g{};
     dense_tiles_args(g, dyr, wtt, M, Kd, N);
     g.img = (unsigned short*)out3; g.img_kind = 2; g.img_mask = (const unsigned short*)act3; g.img_colpart = (float*)workspace;
-    dense_tiles_fmt(g, fmt, in_inv_scale, N);
-    g.mask_f16 = act_kind == LPM_OPERAND_FP16X2 ? 1 : 0;
+    dense_tiles_fmt(g, fmt, in_inv_scale, N, true);       // backward: two terms against hi-plane weight tiles
+    g.mask_planes = operand_kind_planes(act_kind);
     const int rc = tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_relu_bwd_image", g.img_f16 ? 3 : 2);
     if (rc != LPM_OK) return rc;
     hipLaunchKernelGGL(tg_colsum_reduce_kernel, dim3((unsigned)((N + 15) / 16)), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace,
@@ -1291,7 +1301,7 @@ extern "C" int lpm_image_row_tiles(const void* x3, int M, int K, int order, void
 }
 extern "C" int lpm_image_row_tiles_fmt(const void* x3, int M, int K, int order, void* out, int kind, lpm_stream_t stream) {
     using namespace lpm;
-    LPM_REQUIRE(kind == LPM_OPERAND_BF16X3 || kind == LPM_OPERAND_FP16X2, LPM_ERR_BADARG, "lpm_image_row_tiles: unknown operand format %d", kind);
+    LPM_REQUIRE(operand_kind_ok(kind), LPM_ERR_BADARG, "lpm_image_row_tiles: unknown operand format %d", kind);
     LPM_REQUIRE(x3 && out, LPM_ERR_BADARG, "lpm_image_row_tiles: null pointer");
     LPM_REQUIRE(M > 0 && K > 0 && K % 16 == 0 && (((uintptr_t)x3 | (uintptr_t)out) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_image_row_tiles: need K %% 16 == 0 and 16-byte aligned pointers (K=%d)", K);
@@ -1299,8 +1309,8 @@ extern "C" int lpm_image_row_tiles_fmt(const void* x3, int M, int K, int order, 
     const int64_t total = (int64_t)MT * (K / 16) * 64;
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(image_row_tiles_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x3, (int64_t)M, K, (kind == LPM_OPERAND_BF16X3 && order) ? 2 * K : K, MT, (uint4*)out,
-                       kind == LPM_OPERAND_FP16X2 ? 2 : 3);
+                       (const unsigned short*)x3, (int64_t)M, K, (operand_kind_planes(kind) == 3 && order) ? 2 * K : K, MT, (uint4*)out,
+                       operand_kind_planes(kind));
     return check_launch("lpm_image_row_tiles");
 }
 

@@ -12,8 +12,9 @@
 //   wtt  weight tiles of W^T [N/16][K/32][plane][lane]     tile GEMM B operand of the input gradient (lpm_split_weight_tiles of the
 //                                                          same storage with transposed = 1)
 // Bit for bit the outputs of the single-weight entry points (same round-to-nearest-even split).
-// Round 5: a job of kind LPM_OPERAND_FP16X2 writes the forms of the fp16 two-product format (the weight rounded once to fp16):
-// w3n [Ntot, 2K] = [Wh^T | Wh^T], w3k [K, 2 Ntot] = [Wh | Wh], wt / wtt the hi plane only (64 units per tile and step).
+// Round 5: a job of an fp16 kind writes the fp16 forms: w3n [Ntot, 3K] = [Wh^T | Wh^T | Wl^T] (forward, three-term), w3k [K, 2 Ntot] =
+// [Wh | Wh] (input gradient, two-term: the weight rounded once), wt with fp16 (hi, lo) planes, wtt the fp16 hi plane only (64 units per
+// tile and step).
 #include "lpm_common.h"
 #include "operand_format.h"
 
@@ -44,14 +45,19 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const WPArgs a) {
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
     unsigned short* w3k = (unsigned short*)g.w3k;
     unsigned short* w3n = (unsigned short*)g.w3n;
-    const int f16 = g.kind == LPM_OPERAND_FP16X2 ? 1 : 0;          // workgroup-uniform
-    const int np = f16 ? 2 : 3;
+    const int f16 = g.kind != LPM_OPERAND_BF16X3 ? 1 : 0;          // workgroup-uniform
+    const int npk = f16 ? 2 : 3;                                   // planes of a w3k row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int kl = ty + 8 * i;
         const float v = g.w[(int64_t)(k0 + kl) * g.ldw + n0 + tx];
-        const unsigned h = f16 ? (of_round2_f16(v, 0.f) & 0xffffu) : wp_rne(v);
-        const unsigned l = f16 ? 0u : wp_rne(v - __uint_as_float(h << 16));
+        unsigned h, l;
+        if (f16) {
+            of_split1_f16(v, h, l);
+        } else {
+            h = wp_rne(v);
+            l = wp_rne(v - __uint_as_float(h << 16));
+        }
         th[kl][tx] = (unsigned short)h;
         tl[kl][tx] = (unsigned short)l;
     }
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const WPArgs a) {
                 lv[e] = (unsigned)tl[r][c8 + 2 * e] | ((unsigned)tl[r][c8 + 2 * e + 1] << 16);
             }
             if (w3k) {
-                unsigned short* row = w3k + (int64_t)(k0 + r) * np * g.Ntot + g.n_off + n0 + c8;
+                unsigned short* row = w3k + (int64_t)(k0 + r) * npk * g.Ntot + g.n_off + n0 + c8;
                 const uint4 H = make_uint4(hv[0], hv[1], hv[2], hv[3]), L = make_uint4(lv[0], lv[1], lv[2], lv[3]);
                 *reinterpret_cast<uint4*>(row) = H;
                 *reinterpret_cast<uint4*>(row + g.Ntot) = f16 ? H : L;
@@ -81,18 +87,18 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const WPArgs a) {
                 lv[e] = (unsigned)tl[c8 + 2 * e][r] | ((unsigned)tl[c8 + 2 * e + 1][r] << 16);
             }
             if (w3n) {
-                unsigned short* row = w3n + (int64_t)(g.n_off + n0 + r) * np * g.K + k0 + c8;
+                unsigned short* row = w3n + (int64_t)(g.n_off + n0 + r) * 3 * g.K + k0 + c8;
                 const uint4 H = make_uint4(hv[0], hv[1], hv[2], hv[3]), L = make_uint4(lv[0], lv[1], lv[2], lv[3]);
                 *reinterpret_cast<uint4*>(row) = H;
                 *reinterpret_cast<uint4*>(row + g.K) = H;
-                if (!f16) *reinterpret_cast<uint4*>(row + 2 * (int64_t)g.K) = L;
+                *reinterpret_cast<uint4*>(row + 2 * (int64_t)g.K) = L;
             }
         }
     }
     // fragment tiles: thread = (16-deep step s2, plane, lane); tile[plane][lane][e] = M[outer = 32 tile + (lane & 31)][red = 16 step + 8 (lane >> 5) + e]
     const int s2 = tid >> 7, plane = (tid >> 6) & 1, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-    const int tp = f16 ? 1 : 2;                                     // planes per fragment tile
-    if (g.wt && plane < tp) {          // weight tiles of W: outer = column n, reduction = row k
+    const int tp = f16 ? 1 : 2;                                     // planes per fragment tile of W^T (fp16: the hi plane only)
+    if (g.wt) {          // weight tiles of W: outer = column n, reduction = row k
         unsigned v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const WPArgs a) {
             v[e] = lo | (hi << 16);
         }
         const int64_t step = (int64_t)(k0 / 16 + s2), tile = (g.n_off + n0) / 32;
-        ((uint4*)g.wt)[((step * (g.Ntot / 32) + tile) * tp + plane) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
+        ((uint4*)g.wt)[((step * (g.Ntot / 32) + tile) * 2 + plane) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
     }
     if (g.wtt && plane < tp) {         // weight tiles of W^T: outer = row k, reduction = column n
         unsigned v[4];
@@ -132,7 +138,7 @@ extern "C" int lpm_weight_pack(const LpmWeightPackJob* jobs, int njobs, lpm_stre
         LPM_REQUIRE(g.Ntot >= g.n_off + g.N && g.n_off >= 0 && g.n_off % 32 == 0 && g.Ntot % 32 == 0, LPM_ERR_BADARG,
                     "lpm_weight_pack: job %d: column block [%d, %d) of %d", j, g.n_off, g.n_off + g.N, g.Ntot);
         LPM_REQUIRE(g.w3n || g.w3k || g.wt || g.wtt, LPM_ERR_BADARG, "lpm_weight_pack: job %d asks for nothing", j);
-        LPM_REQUIRE(g.kind == LPM_OPERAND_BF16X3 || g.kind == LPM_OPERAND_FP16X2, LPM_ERR_BADARG, "lpm_weight_pack: job %d: unknown operand format %d", j, g.kind);
+        LPM_REQUIRE(operand_kind_ok(g.kind), LPM_ERR_BADARG, "lpm_weight_pack: job %d: unknown operand format %d", j, g.kind);
         LPM_REQUIRE(!g.wtt || (g.n_off == 0 && g.Ntot == g.N), LPM_ERR_UNSUPPORTED_SHAPE,
                     "lpm_weight_pack: job %d: the transposed tiles are written for whole weights only", j);
         LPM_REQUIRE((((uintptr_t)g.wt | (uintptr_t)g.wtt | (uintptr_t)g.w3n | (uintptr_t)g.w3k) & 15) == 0, LPM_ERR_BADARG,

@@ -1163,19 +1163,22 @@ def vlad_aggregate(sims, x, centres, max_frames, kmajor=False, lazy=False):
 # dense layers of the encoders on the bf16 matrix pipe at fp32-grade accuracy (split-bf16 operands)
 # ----------------------------------------------------------------------------------------------
 class OperandSite:
-    """One operand of one dense layer (its input activation, or the gradient of its output) in the step that is running: the operand
-    format its producer writes and what its consumers undo.  f16: the fp16 two-product format (csrc/operand_format.h) with the
-    power-of-two ``scale`` (``inv`` = 1 / scale); otherwise split-bf16 x3, scale 1.  Either way the producer records max |x| into the
-    site's slot of OperandScales.amax (``fmt`` = the address of the LpmOperandFormat the library reads)."""
-    __slots__ = ("f16", "scale", "inv", "struct", "fmt", "planes", "dtype")
+    """One operand of one dense layer (role "a": its input activation, "g": the gradient of its output) in the step that is running: the
+    operand format its producer writes and what its consumers undo (csrc/operand_format.h).  f16: fp16 planes of x * ``scale`` (a power
+    of two; ``inv`` = 1 / scale) -- three planes [hi | lo | hi] for an activation (LPM_OPERAND_FP16X3: the forward keeps all three
+    terms), two [hi | lo] for a gradient (LPM_OPERAND_FP16X2: the backward products are two-term); otherwise split-bf16 x3, scale 1.
+    Either way the producer records max |x| into the site's slot of OperandScales.amax (``fmt`` = the address of the
+    LpmOperandFormat the library reads)."""
+    __slots__ = ("f16", "scale", "inv", "struct", "fmt", "planes", "dtype", "kind")
 
-    def __init__(self, f16, scale, amax_ptr):
+    def __init__(self, f16, scale, amax_ptr, role="a"):
         self.f16 = bool(f16)
         self.scale = float(scale) if f16 else 1.0
         self.inv = 1.0 / self.scale
-        self.struct = _capi.OperandFormat(_capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3, self.scale, amax_ptr)
+        self.kind = (_capi.LPM_OPERAND_FP16X2 if role == "g" else _capi.LPM_OPERAND_FP16X3) if f16 else _capi.LPM_OPERAND_BF16X3
+        self.struct = _capi.OperandFormat(self.kind, self.scale, amax_ptr)
         self.fmt = C.c_void_p(C.addressof(self.struct))
-        self.planes = 2 if f16 else 3
+        self.planes = 2 if (f16 and role == "g") else 3
         self.dtype = torch.float16 if f16 else torch.bfloat16
 
 
@@ -1193,12 +1196,13 @@ class OperandScales:
     it values saturate at +-65504, finite) and 2^24 above the smallest normal fp16 number; fp16 subnormals are kept by the matrix
     cores (tools/fp16_probe.py), so (hi, lo) degrades gracefully into fixed point below that.
     ``calibrate`` (tests, short runs): measure synchronously from one forward + backward that the caller runs in split-bf16."""
-    MAX_SITES = 256
+    MAX_SITES = 64
     TARGET = 10
+    SLOT = _capi.LPM_OPERAND_AMAX_SUB * _capi.LPM_OPERAND_AMAX_STRIDE       # floats per site: its sub-slots, one cache line apart
 
     def __init__(self, device):
         self.device = torch.device(device)
-        self.amax = torch.zeros(self.MAX_SITES, dtype=torch.float32, device=self.device)
+        self.amax = torch.zeros(self.MAX_SITES * self.SLOT, dtype=torch.float32, device=self.device)
         self.slots = {}
         self.first_step = []                 # slot -> id of the step it was first asked for in
         self.hist = [[0.0] * self.MAX_SITES, [0.0] * self.MAX_SITES]      # the last two harvested measurements per slot
@@ -1235,7 +1239,7 @@ class OperandScales:
                 self._harvest_one_blocking()
             host, ev = self._ring[self._ring_next]
             self._ring_next = (self._ring_next + 1) % self.RING
-            host.copy_(self.amax, non_blocking=True)
+            host.copy_(self._compact(), non_blocking=True)
             ev.record()
             self.amax.zero_()
             self.pending.append((self.step, host, ev))
@@ -1244,6 +1248,10 @@ class OperandScales:
         self.fp16_now = bool(self.enabled and self.slots and all(fs <= self.measured for fs in self.first_step))
         if self.fp16_now:
             self.steps_fp16 += 1
+
+    def _compact(self):
+        """[MAX_SITES] = the maximum over each site's sub-slots (one small reduction on the device)."""
+        return self.amax.view(self.MAX_SITES, _capi.LPM_OPERAND_AMAX_SUB, _capi.LPM_OPERAND_AMAX_STRIDE)[:, :, 0].amax(dim=1)
 
     def _harvest_one_blocking(self):
         sid, host, ev = self.pending.pop(0)
@@ -1256,7 +1264,7 @@ class OperandScales:
         step of a run: Trainer.calibrate_operand_scales)."""
         torch.cuda.synchronize(self.device)
         self._harvest(wait=True)
-        vals = self.amax.tolist()
+        vals = self._compact().tolist()
         self.hist[0], self.hist[1] = vals, vals
         self.measured = self.step
         self.amax.zero_()
@@ -1283,7 +1291,7 @@ class OperandScales:
         # fp16 with scale 1: a step never mixes formats, and the site is measured from here on)
         f16 = self.fp16_now
         st = OperandSite(f16, self._scale_of(slot) if (f16 and self.first_step[slot] <= self.measured) else 1.0,
-                         self.amax.data_ptr() + 4 * slot)
+                         self.amax.data_ptr() + 4 * self.SLOT * slot, role=key[0])
         self.sites[key] = st
         return st
 
@@ -1311,12 +1319,13 @@ def _f16(site):
 def _split_rows(x2d, bias=None, relu=False, grad=False, row_scale=None, site=None):
     """[M,K] fp32 -> [M,3K] bf16 = [hi | lo | hi] (optionally of relu(x + bias)); grad=True: the gradient plane order
     [hi | hi | lo] that pairs with w3k (rows [Wh|Wl|Wh]) and, row by row, with an activation image (see _dw_x3).
-    site (OperandSite): the image in the site's format -- fp16x2: [M,2K] fp16 = [hi | lo] of x * site.scale -- and max |x| recorded.
+    site (OperandSite): the image in the site's format -- fp16: planes of x * site.scale, [hi | lo | hi] for an activation site,
+    [hi | lo] for a gradient site -- and max |x| recorded.
     row_scale: x2d = the rows of a lazily normalised descriptor (netvlad(lazy=True)), scaled as they are read."""
     lib = _capi.load()
     M, K = x2d.shape
     f16 = _f16(site)
-    out = torch.empty((M, (2 if f16 else 3) * K), dtype=torch.float16 if f16 else torch.bfloat16, device=x2d.device)
+    out = torch.empty((M, (site.planes if site is not None else 3) * K), dtype=torch.float16 if f16 else torch.bfloat16, device=x2d.device)
     lib.check(lib._lpm_split_rows_fmt(ptr(x2d), x2d.stride(0), M, K, ptr(bias), 1 if relu else 0, 1 if grad else 0, ptr(row_scale), ptr(out),
                                       site.fmt if site is not None else None, stream_ptr()), "lpm_split_rows")
     return out
@@ -1362,17 +1371,18 @@ class WeightPack:
             if not need:
                 continue
             sfx = "16" if f16 else ""
-            pl, dt, tdiv = (2, torch.float16, 2) if f16 else (3, torch.bfloat16, 1)
+            # fp16 forms: n16 [Ntot, 3K] = [Wh^T|Wh^T|Wl^T], k16 [K, 2 Ntot] = [Wh|Wh], wt16 (hi, lo) tiles, wtt16 hi-plane tiles (half the bytes)
+            pk, dt, tdiv = (2, torch.float16, 2) if f16 else (3, torch.bfloat16, 1)
             K = srcs[0].shape[0]
             Ntot = sum(w.shape[1] for w in srcs)
             dev = srcs[0].device
             out = {}
             if "n" + sfx in need:
-                out["n" + sfx] = torch.empty((Ntot, pl * K), dtype=dt, device=dev)
+                out["n" + sfx] = torch.empty((Ntot, 3 * K), dtype=dt, device=dev)
             if "k" + sfx in need:
-                out["k" + sfx] = torch.empty((K, pl * Ntot), dtype=dt, device=dev)
+                out["k" + sfx] = torch.empty((K, pk * Ntot), dtype=dt, device=dev)
             if "wt" + sfx in need:
-                out["wt" + sfx] = torch.empty(lib._lpm_weight_tiles_bytes(K, Ntot) // 4 // tdiv, dtype=torch.int32, device=dev)
+                out["wt" + sfx] = torch.empty(lib._lpm_weight_tiles_bytes(K, Ntot) // 4, dtype=torch.int32, device=dev)
             if "wtt" + sfx in need and len(srcs) == 1:
                 out["wtt" + sfx] = torch.empty(lib._lpm_weight_tiles_bytes(Ntot, K) // 4 // tdiv, dtype=torch.int32, device=dev)
             off = 0
@@ -1383,7 +1393,7 @@ class WeightPack:
                 j.w3k = out["k" + sfx].data_ptr() if "k" + sfx in out else None
                 j.wt = out["wt" + sfx].data_ptr() if "wt" + sfx in out else None
                 j.wtt = out["wtt" + sfx].data_ptr() if "wtt" + sfx in out else None
-                j.kind = _capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3
+                j.kind = _capi.LPM_OPERAND_FP16X3 if f16 else _capi.LPM_OPERAND_BF16X3
                 jobs.append(j)
                 off += w.shape[1]
             self.ready[key] = out
@@ -1459,16 +1469,17 @@ def _packed(srcs, forms):
 
 
 def _weight_tiles(W, R, N, transposed, like, pack=True, f16=False):
-    """lpm_split_weight_tiles(W, R, N, transposed) -- from the step's weight pack when it holds the form.  f16: the fp16 two-product
-    format's weight tiles (the hi plane only: half the bytes)."""
+    """lpm_split_weight_tiles(W, R, N, transposed) -- from the step's weight pack when it holds the form.  f16: fp16 tiles -- of W (the
+    forward's operand) with (hi, lo) planes, of W^T (``transposed``: the input gradient's operand, a two-term product) the hi plane only:
+    half the bytes."""
     lib = _capi.load()
     form = ("wtt" if transposed else "wt") + ("16" if f16 else "")
     got = _packed([W], [form]) if pack else None
     if got is not None:
         return got[form]
-    wt = _tile_buffer(lib._lpm_weight_tiles_bytes(R, N) // (2 if f16 else 1), like)
-    lib.check(lib._lpm_split_weight_tiles_fmt(ptr(W), R, N, 1 if transposed else 0, ptr(wt),
-                                              _capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3, stream_ptr()), "lpm_split_weight_tiles")
+    kind = (_capi.LPM_OPERAND_FP16X2 if transposed else _capi.LPM_OPERAND_FP16X3) if f16 else _capi.LPM_OPERAND_BF16X3
+    wt = _tile_buffer(lib._lpm_weight_tiles_bytes(R, N) // (2 if (f16 and transposed) else 1), like)
+    lib.check(lib._lpm_split_weight_tiles_fmt(ptr(W), R, N, 1 if transposed else 0, ptr(wt), kind, stream_ptr()), "lpm_split_weight_tiles")
     return wt
 
 
@@ -1483,7 +1494,8 @@ def _split_weight_cat(Ws, need_t=True, f16=False):
 
 def _split_weight(W, need_t=True, pack=True, f16=False):
     """[K,N] fp32 -> w3n [N,3K] (rows [Wh^T|Wh^T|Wl^T]: y = X3 w3n^T) and w3k [K,3N] (rows [Wh|Wl|Wh]: dx = DY3 w3k^T), bf16.
-    f16 (the fp16 two-product format): the weight rounded once to fp16 -- wn [N,2K] = [Wh^T|Wh^T], wk [K,2N] = [Wh|Wh]."""
+    f16: fp16 planes -- wn [N,3K] = [Wh^T|Wh^T|Wl^T] (the forward keeps three terms), wk [K,2N] = [Wh|Wh] (the input gradient's two-term
+    product: the weight rounded once)."""
     lib = _capi.load()
     fn, fk = ("n16", "k16") if f16 else ("n", "k")
     if pack:
@@ -1491,10 +1503,10 @@ def _split_weight(W, need_t=True, pack=True, f16=False):
         if got is not None:
             return got[fn], got.get(fk)
     K, N = W.shape
-    pl, dt = (2, torch.float16) if f16 else (3, torch.bfloat16)
-    w3n = torch.empty((N, pl * K), dtype=dt, device=W.device)
-    w3k = torch.empty((K, pl * N), dtype=dt, device=W.device) if need_t else None
-    lib.check(lib._lpm_split_weight_fmt(ptr(W), K, N, ptr(w3n), ptr(w3k), _capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3,
+    pk, dt = (2, torch.float16) if f16 else (3, torch.bfloat16)
+    w3n = torch.empty((N, 3 * K), dtype=dt, device=W.device)
+    w3k = torch.empty((K, pk * N), dtype=dt, device=W.device) if need_t else None
+    lib.check(lib._lpm_split_weight_fmt(ptr(W), K, N, ptr(w3n), ptr(w3k), _capi.LPM_OPERAND_FP16X3 if f16 else _capi.LPM_OPERAND_BF16X3,
                                         stream_ptr()), "lpm_split_weight")
     return w3n, w3k
 
@@ -1658,16 +1670,16 @@ def _dw_x3(x3, dy3, K, N, outs=None, sa=None, sg=None):
 
 
 def _dw_x2(x2, dy2, K, N, outs, alpha):
-    """The fp16 two-product weight gradient dW = alpha * xh^T [dyh | dyl] from an activation image x2 [M,2K] = [hi|lo] and a gradient
-    image dy2 [M,2N] = [hi|lo]: the activation rounded once to fp16 (its hi plane, read in place with the image's row stride), the
-    gradient exact to 22 bits -- ONE fp16 library GEMM over S slices of the token reduction with a [K, 2N] output per slice, then
+    """The fp16 two-term weight gradient dW = alpha * xh^T [dyh | dyl] from an activation image x2 [M,3K] = [hi|lo|hi] (fp16) and a
+    gradient image dy2 [M,2N] = [hi|lo]: the activation rounded once to fp16 (its hi plane, read in place with the image's row stride),
+    the gradient exact to 22 bits -- ONE fp16 library GEMM over S slices of the token reduction with a [K, 2N] output per slice, then
     lpm_sum_splits_scaled adds slices and halves and multiplies by alpha = 1 / (the two operands' scales)."""
     lib = _capi.load()
     M = x2.shape[0]
     S = 8 if K * N <= (1 << 20) else 2
     while S > 1 and (M % S or M // S < 512):
         S //= 2
-    xh = x2.view(S, M // S, 2 * K)[:, :, :K]
+    xh = x2.view(S, M // S, x2.shape[1])[:, :, :K]
     part = torch.bmm(xh.transpose(1, 2), dy2.view(S, M // S, 2 * N), out_dtype=torch.float32)       # [S, K, 2N]
     slots = [_grad_slot(W) for W, _, _ in outs] if outs is not None else []
     if (outs is not None and all(sl is not None and sl.is_contiguous() for sl in slots) and len(outs) <= 3
@@ -1759,9 +1771,9 @@ class _FFNX3(torch.autograd.Function):
         s1, s2 = _site("a", W1_0), _site("a", W2_0)
         f16 = _f16(s1)
         ctx.sites = (s1, s2)
-        pl, dt = (2, torch.float16) if f16 else (3, torch.bfloat16)
+        dt = torch.float16 if f16 else torch.bfloat16
         a1 = s1.inv if s1 is not None else 1.0
-        if y3 is None or tuple(y3.shape) != (M, pl * F) or y3.dtype != dt:
+        if y3 is None or tuple(y3.shape) != (M, 3 * F) or y3.dtype != dt:
             y3 = _split_rows(y2d, site=s1)
         w13n, w13k = _split_weight(W1, f16=f16)
         ctx.tiles = bool(FFN_TILES and y2d.stride(1) == 1 and lib._lpm_dense_tiles_supported(M, F, H) and lib._lpm_dense_tiles_supported(M, W2.shape[1], H))
@@ -1773,7 +1785,7 @@ class _FFNX3(torch.autograd.Function):
             lib.check(lib._lpm_split_rows_tiles_fmt(ptr(y2d), y2d.stride(0), 1, M, F, ptr(yr), s1.fmt if s1 is not None else None, st),
                       "lpm_split_rows_tiles")
             w1t = _weight_tiles(W1, F, H, False, y2d, f16=f16)
-            f3 = torch.empty((M, pl * H), dtype=dt, device=y2d.device)
+            f3 = torch.empty((M, 3 * H), dtype=dt, device=y2d.device)
             lib.check(lib._lpm_dense_tiles_act_image_fwd_fmt(ptr(yr), ptr(w1t), ptr(b1.contiguous()), M, F, H, a1, ptr(f3),
                                                              s2.fmt if s2 is not None else None, st), "lpm_dense_tiles_act_image_fwd")
             w23n, _ = _split_weight(W2, need_t=False, f16=f16)
@@ -1798,7 +1810,8 @@ class _FFNX3(torch.autograd.Function):
         s1, s2 = ctx.sites
         g1, g2 = _site("g", ctx.wrefs[0]), _site("g", ctx.wrefs[1])       # the gradients of the two layers' outputs (do3 arrives in g2's format)
         f16 = _f16(s1)
-        kind = _capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3
+        gkind = _capi.LPM_OPERAND_FP16X2 if f16 else _capi.LPM_OPERAND_BF16X3       # gradient images: [hi | lo] in fp16
+        akind = _capi.LPM_OPERAND_FP16X3 if f16 else _capi.LPM_OPERAND_BF16X3       # the activation image f3 (ReLU mask): [hi | lo | hi]
         pl, dt = (2, torch.float16) if f16 else (3, torch.bfloat16)
         a2 = g2.inv if g2 is not None else 1.0
         if do3 is None:
@@ -1812,17 +1825,17 @@ class _FFNX3(torch.autograd.Function):
             st = stream_ptr()
             W2 = w23k                                                     # (saved in its place: the fp32 weight [H, N])
             dor = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), f3)
-            lib.check(lib._lpm_image_row_tiles_fmt(ptr(do3), M, N, 1, ptr(dor), kind, st), "lpm_image_row_tiles")
+            lib.check(lib._lpm_image_row_tiles_fmt(ptr(do3), M, N, 1, ptr(dor), gkind, st), "lpm_image_row_tiles")
             w2tt = _weight_tiles(W2, N, H, True, f3, f16=f16)
             wsb = lib._lpm_dense_tiles_relu_bwd_workspace_bytes(M, H)
             ws = torch.empty(wsb // 4, dtype=torch.float32, device=f3.device)
-            lib.check(lib._lpm_dense_tiles_relu_bwd_image_fmt(ptr(dor), ptr(w2tt), ptr(f3), kind, M, N, H, a2, ptr(dp3), ptr(db1), ptr(ws), wsb,
+            lib.check(lib._lpm_dense_tiles_relu_bwd_image_fmt(ptr(dor), ptr(w2tt), ptr(f3), akind, M, N, H, a2, ptr(dp3), ptr(db1), ptr(ws), wsb,
                                                               g1.fmt if g1 is not None else None, st), "lpm_dense_tiles_relu_bwd_image")
         else:
             df = _mm3(do3, w23k)                                          # [M, H]  (un-scaled: alpha rides in the split pass below)
             wsb = lib._lpm_split_rows_relu_bwd_workspace_bytes(M, H)
             ws = torch.empty(wsb // 4, dtype=torch.float32, device=df.device)
-            lib.check(lib._lpm_split_rows_relu_bwd_fmt(ptr(df), M, H, a2, ptr(f3), kind, ptr(dp3), ptr(db1), ptr(ws), wsb,
+            lib.check(lib._lpm_split_rows_relu_bwd_fmt(ptr(df), M, H, a2, ptr(f3), akind, ptr(dp3), ptr(db1), ptr(ws), wsb,
                                                        g1.fmt if g1 is not None else None, stream_ptr()), "lpm_split_rows_relu_bwd")
             del df
         dy = _mm3(dp3, w13k, acc, alpha=g1.inv if g1 is not None else 1.0)
@@ -2385,8 +2398,7 @@ class _ResidualLayerNorm(torch.autograd.Function):
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
         # site (block Functions only): the input site of the dense layer that reads y next -- the image in its operand format
-        y3 = (torch.empty((B * L, (2 if _f16(site) else 3) * F), dtype=torch.float16 if _f16(site) else torch.bfloat16, device=a.device)
-              if image else None)
+        y3 = torch.empty((B * L, 3 * F), dtype=torch.float16 if _f16(site) else torch.bfloat16, device=a.device) if image else None
         if mask is not None:
             if r_scale is not None:
                 raise LpmError("layer_norm: a dropout mask and a residual row scale do not combine")
@@ -2530,7 +2542,7 @@ class _MHACore(torch.autograd.Function):
     def forward(ctx, q, k, v, num_heads, scale, image=False, site=None):
         """image (block Functions only, split-bf16 arithmetic): the result is written ONLY as the [B*L, 3*h*d] bf16 activation image
         of the output projection GEMM (and kept in that form for the backward).  site: that GEMM's input site -- the image in its
-        operand format (fp16 two-product: [B*L, 2*h*d] fp16)."""
+        operand format (fp16: the same three planes, fp16 words of o * scale)."""
         lib = _capi.load()
         q, k, v = _qkv_operands(q, k, v)
         B, L, d = _mha_dims(q, num_heads)
@@ -2539,8 +2551,7 @@ class _MHACore(torch.autograd.Function):
         ctx.o_image = bool(image)
         ctx.o_site = site
         if image:
-            o = torch.empty((B * L, (2 if _f16(site) else 3) * num_heads * d), dtype=torch.float16 if _f16(site) else torch.bfloat16,
-                            device=q.device)
+            o = torch.empty((B * L, 3 * num_heads * d), dtype=torch.float16 if _f16(site) else torch.bfloat16, device=q.device)
             with _timed("mha_fwd", (B, L, num_heads, d)):
                 lib.check(lib._lpm_mha_fwd_x3_image_fmt(ptr(q), ptr(k), ptr(v), q.stride(1), B, L, num_heads, d, scale, ptr(o), ptr(lse),
                                                         site.fmt if site is not None else None, stream_ptr()), "lpm_mha_fwd_x3_image")

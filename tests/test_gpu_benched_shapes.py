@@ -73,7 +73,7 @@ def _run(name, storage=None, fwd_tol=1e-3, grad_tol=1e-3):
         tr.calibrate_operand_scales(x, nf, lab, **kw)      # NetVladV1: the step below runs its encoder GEMMs in the fp16 two-product format
         tr.store.summaries = {}
         out = tr.step(x, nf, lab, **kw)
-        assert tr.operand_scales is None or tr.operand_scales.steps_fp16 == 1
+        assert tr.operand_scales is None or not tr.operand_scales.slots or tr.operand_scales.steps_fp16 == 1
         torch.cuda.synchronize()
         got, tr.store.summaries = tr.store.summaries, None
     finally:

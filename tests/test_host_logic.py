@@ -1,7 +1,11 @@
 """-m "not gpu": host-side logic that mirrors the reference's registry / flags / variable scoping /
 training-loop arithmetic (no kernels)."""
+import os
+
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from learnablepoolingmethods_amd import FLAGS, registry, train, utils
 from learnablepoolingmethods_amd import models as lp_models
@@ -277,3 +281,17 @@ def test_recorded_library_gemm_solutions_file_is_well_formed():
     assert len(keys) == len(entries)
     for shape in ("nn_11586_80_512", "nn_19310_128_1024", "tn_1024_128_19310", "nt_15448_1024_128"):     # MoE gates / experts, cfg-2 and cfg-5
         assert any(k.startswith(shape + "_") for k in keys), shape
+
+
+def test_operand_sites_carry_the_header_s_format_kinds():
+    """ops.OperandSite (host side of csrc/operand_format.h): activations ("a") are three fp16 planes, gradients ("g") two; without fp16 both
+    are split-bf16 x3 with scale 1; the enum values are the header's."""
+    import re
+    from learnablepoolingmethods_amd import _capi, ops
+    txt = open(os.path.join(ROOT, "include", "lpm_hip.h")).read()
+    m = re.search(r"enum \{ LPM_OPERAND_BF16X3 = (\d+), LPM_OPERAND_FP16X2 = (\d+), LPM_OPERAND_FP16X3 = (\d+) \}", txt)
+    assert m and (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (_capi.LPM_OPERAND_BF16X3, _capi.LPM_OPERAND_FP16X2, _capi.LPM_OPERAND_FP16X3)
+    a, g, b = ops.OperandSite(True, 1024.0, 0, role="a"), ops.OperandSite(True, 2.0 ** -3, 0, role="g"), ops.OperandSite(False, 8.0, 0, role="g")
+    assert (a.kind, a.planes, a.inv) == (_capi.LPM_OPERAND_FP16X3, 3, 1.0 / 1024) and a.struct.scale == 1024.0
+    assert (g.kind, g.planes, g.inv) == (_capi.LPM_OPERAND_FP16X2, 2, 8.0)
+    assert (b.kind, b.planes, b.scale, b.inv) == (_capi.LPM_OPERAND_BF16X3, 3, 1.0, 1.0)
