@@ -39,8 +39,12 @@ WORKLOADS = {
                  oracle=dict(iterations=300, cluster_size=256, hidden_size=512), flags={}, batch=80, elt=4, dtype="f32", parity_tol=1e-3,
                  workload="NetVladV1 K=256 hidden=512 rgb+audio 1152-d 300 frames, bs 80 per GPU (BASELINE configs[1]; configs[3] at "
                           "8 GPUs), full training step",
-                 dtype_detail="fp32 storage and accumulation everywhere; K1, K2, K3, K4 and the encoder dense GEMMs feed the bf16 MFMA "
-                              "pipe with split-bf16 (hi+lo) operands, 3 MFMAs per product (~5e-6 relative error)"),
+                 dtype_detail="fp32 storage and accumulation everywhere; K1, K2, K3, K4 feed the bf16 MFMA pipe with split-bf16 (hi+lo) operands, "
+                              "3 MFMAs per product (~5e-6 relative error); the encoder dense GEMMs run on fp16 (hi, lo) planes with delayed "
+                              "per-tensor power-of-two scales (ops.OperandScales): forward products 3 MFMAs (~1e-6), input- and weight-gradient "
+                              "products 2 MFMAs with one operand rounded once to fp16 (1.4e-4 rms per GEMM; measured against fp64: 2.1e-4 / "
+                              "2.9e-4 relative L2 on the gradients of a two-layer chain, tests/test_gpu_fp16x2.py); LPM_DENSE_ARITHMETIC=bf16x3 "
+                              "runs them as in rounds 1-4"),
     "cfg3": dict(metric="clips/sec training step, NetVladV2 (attention-based cluster similarities) K=256 300-frame 1152-d, bs=80 (BASELINE configs[2])",
                  model="NetVladV2", model_kwargs=dict(iterations=300, cluster_size=256, hidden_size=512),     # hidden: README.md:17
                  oracle=dict(iterations=300, cluster_size=256, hidden_size=512), flags={}, batch=80, elt=4, dtype="f32", parity_tol=1e-3,
@@ -557,6 +561,14 @@ def main():
             line["replicas"] = replicas
         if others is not None:
             line["other_configs"] = others
+        sc = getattr(trainer, "operand_scales", None)
+        if sc is not None and sc.slots:
+            rep = sc.report()
+            line["operand_formats"] = {"encoder_gemm_steps_on_fp16_planes": sc.steps_fp16, "steps_run": sc.step + 1, "sites": len(rep),
+                                       "log2_scale_range": [int(min(__import__("math").log2(v[1]) for v in rep.values())),
+                                                            int(max(__import__("math").log2(v[1]) for v in rep.values()))],
+                                       "what": "NetVladV1's encoder GEMMs: steps that ran on fp16 planes (the first steps of a run stay on split-bf16 "
+                                               "until every operand's max |x| has been read back once), operand sites and their power-of-two scales"}
         if roof:
             line["roofline"] = roof
         if k1:

@@ -14,6 +14,11 @@
 //     576 matrix-pipe cycles;
 //   * the epilogue takes the column statistics from the accumulators and stores the accumulators as they are (a lane's 16 values of one
 //     column: 32 lanes = one 128-byte line of a row per store) -- no staging tile, no workgroup barrier.
+// PLAIN (round 5, bf16 storage: BASELINE configs[4]): the operands are plain bf16 tiles, one MFMA per product.  A plain tile buffer with
+// D / 16 steps of 64 units IS a split buffer with D / 32 steps of 128 units whose "hi plane" is the even step and whose "lo plane" the
+// odd one: the same loop runs on DOUBLE steps (32 reduction elements) with the products (A.h, B.h) and (A.l, B.l) -- six MFMAs per step
+// instead of nine, the same loads, rings and hand-counted waits; the weight tiles' odd step sits NT tiles (not 1 KB) behind the even
+// one, and the logits leave as bf16.
 // LDS-DMA loads and register loads retire in order on one counter (vmcnt): every wave issues them in a fixed order -- per step
 // [A piece of step s + NS (waves 0-5)] [B hi, B lo of step s + DB] -- and waits with hand-counted immediates; the ring and the registers
 // are read by inline assembly behind those waits (the compiler puts vmcnt(0) in front of LDS reads it can see next to an LDS-DMA).
@@ -32,10 +37,15 @@ struct AssignFlatArgs {
     const uint4* xr;           // per-clip row tiles [b][mt][ds][plane][lane]
     const uint4* wt;           // weight tiles [ds][nt][plane][lane]
     int M, T, MT, DS, NT, K;   // rows B*T, frames per clip, row tiles per clip, reduction steps D/16, column tiles K/32, clusters
-    float* logits;             // [M, K]
+    float* logits;             // [M, K]  (PLAIN: bf16 storage)
     float* stats;              // [nblk][2][K]: rows < gridDim.x written, the rest zeroed
     int nblk;
 };
+__device__ __forceinline__ unsigned af_bf16_rne(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
 
 __host__ __device__ constexpr int af_mod(int u, int n) { return ((u % n) + n) % n; }
 // VMEM operations a wave issues in step u, counted from the start of the tail (u < 0: the steady state, and the prologue's virtual
@@ -72,8 +82,9 @@ __device__ __forceinline__ void af_wait_vm(int n) {          // n folds to a con
 }
 #undef AF_WAIT_CASE
 
-template <int KB, int DB, bool AF_LUMP>
+template <int KB, int DB, bool AF_LUMP, bool PLAIN = false>
 __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArgs a) {
+    static_assert(!(PLAIN && AF_LUMP), "the plain-bf16 form has one loop order");
     constexpr int NS = af_ns(KB), TAIL = af_tail(KB, DB), STAGE = KB * AF_KSTEP;
     static_assert((NS - 2) * KB >= DB && TAIL % DB == 0 && TAIL % KB == 0 && TAIL >= (NS - 1) * KB && (DB == 4 || DB == 8),
                   "A(next stage) must be older than B(i); the tail is whole register rounds and whole stages");
@@ -96,8 +107,9 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
         const int b = (int)(Rc / (unsigned)a.T), t = (int)(Rc - (unsigned)b * (unsigned)a.T);
         asrc = a.xr + ((int64_t)b * a.MT + (t >> 5)) * a.DS * 128 + p_ld * 64 + half * 32 + (t & 31);
     }
-    const uint4* bbase = a.wt + (int64_t)ct * 128;                 // wave-uniform; + step * NT * 128
-    const int64_t bstep = (int64_t)a.NT * 128;
+    const uint4* bbase = a.wt + (int64_t)ct * (PLAIN ? 64 : 128);   // wave-uniform; + step * NT * 128
+    const int64_t bstep = (int64_t)a.NT * 128;                     // (PLAIN: a double step = two plain steps of NT * 64 units)
+    const int64_t blo = PLAIN ? (int64_t)a.NT * 64 : 64;           // the second B piece of a step: the odd plain step / the lo plane
     const unsigned boff = (unsigned)lane * 16u;
     const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned rd_lane = smem_lds + (unsigned)lane * 16u;
@@ -120,7 +132,12 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
     auto issue_b = [&](int s, tg_u32x4& h, tg_u32x4& l) {
         const uint4* p = bbase + (int64_t)s * bstep;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(h) : "v"(boff), "s"(p) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(l) : "v"(boff), "s"(p) : "memory");
+        if (PLAIN) {
+            const uint4* p2 = p + blo;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(l) : "v"(boff), "s"(p2) : "memory");
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(l) : "v"(boff), "s"(p) : "memory");
+        }
     };
     auto read_frags = [&](unsigned byte_off, Frag& f) {            // byte_off: slot * STAGE + (step within the stage) * AF_KSTEP
         const unsigned ad = rd_lane + byte_off;
@@ -163,6 +180,45 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
         // instruction stream in phase, so a LUMP of seven LDS operations behind the first MFMA group (the first form of this loop) is a
         // lump for both -- the matrix pipe idles for its length, 15 % of the step.  A single read in front of an MFMA is covered by the
         // neighbour's MFMA (AF_LUMP, LPM_K1_LUMP=1: the first form, A/B).
+        if constexpr (PLAIN) {
+            // six MFMAs per double step: (A even step, B even step) x 3 row tiles, then the odd pair; the six fragment reads of the next
+            // step one in front of each MFMA but the first (which carries the DMA issue), the B loads when their registers are free
+            const int slot1 = slot + 1 == NS ? 0 : slot + 1;
+            const bool rd = i + 1 < TAIL;
+            const unsigned ad = rd_lane + (unsigned)((e + 1 == KB ? slot1 : slot) * STAGE + (e + 1 == KB ? 0 : e + 1) * AF_KSTEP);
+            Frag& fn = fa[ab ^ 1];
+            const int cur_slot = slot;
+            if (e + 1 == KB) slot = slot1;
+#define AF_RD(REG, OFF) if (rd) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(REG) : "v"(ad), "n"(OFF) : "memory")
+            acc[0] = tg_mfma(fa[ab].h[0], bh[j], acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (e == 0 && loader && (i + (NS - 1) * KB < TAIL))
+                issue_a(s / KB + NS - 1, cur_slot == 0 ? NS - 1 : cur_slot - 1);
+            AF_RD(fn.h[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = tg_mfma(fa[ab].h[1], bh[j], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            AF_RD(fn.l[0], 1024);
+            acc[2] = tg_mfma(fa[ab].h[2], bh[j], acc[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more_b = i + DB < TAIL;
+            const uint4* pb = bbase + (int64_t)(s + DB) * bstep;
+            if (more_b) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bh[j]) : "v"(boff), "s"(pb) : "memory");
+            AF_RD(fn.h[1], 2048);
+            acc[0] = tg_mfma(fa[ab].l[0], bl[j], acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            AF_RD(fn.l[1], 3072);
+            acc[1] = tg_mfma(fa[ab].l[1], bl[j], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            AF_RD(fn.h[2], 4096);
+            acc[2] = tg_mfma(fa[ab].l[2], bl[j], acc[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            AF_RD(fn.l[2], 5120);
+#undef AF_RD
+            const uint4* pb2 = pb + blo;
+            if (more_b) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bl[j]) : "v"(boff), "s"(pb2) : "memory");
+            return;
+        }
         acc[0] = tg_mfma(fa[ab].h[0], bh[j], acc[0]);
         __builtin_amdgcn_sched_barrier(0);
         if (e == 0 && loader && (i + (NS - 1) * KB < TAIL))
@@ -227,7 +283,11 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
             const float v = row < a.M ? acc[m][r] : 0.f;
             cs += v;
             cq = fmaf(v, v, cq);
-            if (row < a.M) a.logits[row * a.K + col] = acc[m][r];
+            if (PLAIN) {
+                if (row < a.M) reinterpret_cast<unsigned short*>(a.logits)[row * a.K + col] = (unsigned short)af_bf16_rne(acc[m][r]);
+            } else {
+                if (row < a.M) a.logits[row * a.K + col] = acc[m][r];
+            }
         }
     cs += __shfl_xor(cs, 32, 64);
     cq += __shfl_xor(cq, 32, 64);
@@ -263,12 +323,18 @@ bool assign_flat_ok(int B, int T, int D, int K) {
     const int DS = D / 16, db = af_db(), tail = af_tail(af_kb(), db);
     return af_enabled() && D % 16 == 0 && DS % db == 0 && DS >= tail + db && K % 256 == 0 && K > 0 && (int64_t)B * T < (int64_t)1 << 31;
 }
+// plain bf16 tiles: double steps of 32 reduction elements (LPM_K1_FLAT_BF16=0: the 128-row tile GEMM form, A/B)
+bool assign_flat_plain_ok(int B, int T, int D, int K) {
+    static const int on = [] { const char* e = getenv("LPM_K1_FLAT_BF16"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int DS = D / 32, tail = af_tail(2, 4);
+    return on && af_enabled() && D % 32 == 0 && DS % 4 == 0 && DS >= tail + 4 && K % 256 == 0 && K > 0 && (int64_t)B * T < (int64_t)1 << 31;
+}
 
 int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int D, int K, float* logits, float* stats, int nblk,
-                       int timing_tag, hipStream_t stream, const char* what) {
+                       int timing_tag, hipStream_t stream, const char* what, int planes) {
     AssignFlatArgs a{};
     a.xr = (const uint4*)xr; a.wt = (const uint4*)wt;
-    a.M = B * T; a.T = T; a.MT = MT; a.DS = D / 16; a.NT = K / 32; a.K = K;
+    a.M = B * T; a.T = T; a.MT = MT; a.DS = D / (planes == 1 ? 32 : 16); a.NT = K / 32; a.K = K;
     a.logits = logits; a.stats = stats; a.nblk = nblk;
     const int nwg = (a.M + AF_ROWS - 1) / AF_ROWS;
     if (nwg > nblk || (((uintptr_t)xr | (uintptr_t)wt) & 15) != 0) {
@@ -286,6 +352,12 @@ int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int
         else hipLaunchKernelGGL((assign_flat_kernel<KB, DB, LUMP>), grid, dim3(512), lds, stream, a);      \
     } while (0)
     static const int lump = [] { const char* e = getenv("LPM_K1_LUMP"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (planes == 1) {
+        const size_t lds1 = (size_t)af_ns(2) * 2 * AF_KSTEP;
+        if (timed) hipExtLaunchKernelGGL((assign_flat_kernel<2, 4, false, true>), grid, dim3(512), lds1, stream, e0, e1, 0, a);
+        else hipLaunchKernelGGL((assign_flat_kernel<2, 4, false, true>), grid, dim3(512), lds1, stream, a);
+        return check_launch(what);
+    }
     if (lump && kb == 2) AF_LAUNCH(2, 4, true);
     else if (kb == 1) AF_LAUNCH(1, 4, false);
     else if (kb == 2) AF_LAUNCH(2, 4, false);

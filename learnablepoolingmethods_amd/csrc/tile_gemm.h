@@ -142,7 +142,8 @@ int tile_gemm_image_row_groups(int M);
 // K1's forward on flat 96-row workgroups (assign_flat.hip): the per-clip row tiles gathered per lane, B fragments straight into registers.
 // stats: [nblk][2][K], nblk >= ceil(B T / 96) rows (the rows past the row groups are zeroed).
 bool assign_flat_ok(int B, int T, int D, int K);
+bool assign_flat_plain_ok(int B, int T, int D, int K);       // planes == 1: plain bf16 tiles, bf16 logits (round 5)
 int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int D, int K, float* logits, float* stats, int nblk,
-                       int timing_tag, hipStream_t stream, const char* what);
+                       int timing_tag, hipStream_t stream, const char* what, int planes = 2);
 
 }  // namespace lpm

@@ -1179,6 +1179,10 @@ static int assign_gemm_tiles_fwd_impl(const void* xr, const void* wt, int B, int
     if (planes == 2 && assign_flat_ok(B, T, D, K))
         return assign_flat_launch(xr, wt, B, T, MT, D, K, (float*)logits, partial, lpm_assign_gemm_tiles_nblk(B, T),
                                   D >= 1024 ? LPM_TIMING_K1 : 0, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd");
+    // bf16 storage: the same flat workgroups on plain tiles (double steps), bf16 logits
+    if (planes == 1 && assign_flat_plain_ok(B, T, D, K))
+        return assign_flat_launch(xr, wt, B, T, MT, D, K, (float*)logits, partial, lpm_assign_gemm_tiles_nblk(B, T),
+                                  D >= 1024 ? LPM_TIMING_K1 : 0, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd_bf16", 1);
     const int64_t U = 64 * planes;             // 16-byte units per (tile, step)
     TileGemmArgs g{};
     g.a = (const uint4*)xr; g.a_tile = (int64_t)DS * U; g.a_step = U; g.a_batch = (int64_t)MT * DS * U; g.a_tiles = MT;

@@ -1187,14 +1187,16 @@ class OperandScales:
     step t comes from the max |x| the producers MEASURED at earlier steps).
 
     Every operand image of NetVladV1's encoder GEMMs has a site (``site(key)``); its producer -- a split pass, a layer norm, the
-    attention kernels, a tile GEMM's epilogue -- records max |x| into ``amax[slot]`` in BOTH formats.  ``begin_step`` (trainer, before
-    the forward): harvests the read-backs that have completed (never waits), queues the read-back of the step that just ended
-    (device -> pinned host copy + event, then zeroes the buffer: stream order puts it behind that step's kernels), and decides the
-    step's format: fp16x2 when every site that exists has been measured at least once since it was first used, else split-bf16 x3
-    (the first steps of a run, a model that grew a layer) -- a step never mixes formats.  The scale puts the larger of the last two
-    measured maxima at 2^TARGET: [2^10, 2^11), a factor 32 below fp16's largest value for growth between measurement and use (beyond
-    it values saturate at +-65504, finite) and 2^24 above the smallest normal fp16 number; fp16 subnormals are kept by the matrix
-    cores (tools/fp16_probe.py), so (hi, lo) degrades gracefully into fixed point below that.
+    attention kernels, a tile GEMM's epilogue -- records max |x| into the site's slot of ``amax`` in BOTH formats.  ``begin_step(t)``
+    (trainer, before the forward): queues the read-back of step t - 1 (device -> pinned host copy + event, then zeroes the buffer:
+    stream order puts it behind that step's kernels), makes sure the read-back of step t - 2 HAS ARRIVED (it waits if the host is more
+    than two steps ahead of the device -- a step is GPU-bound, so normally it does not), and decides the step's format: fp16 when every
+    site that exists was measured at step t - 2 or earlier, else split-bf16 x3 (the first two steps of a run, a model that grew a
+    layer) -- a step never mixes formats.  The delay is FIXED: the scales of step t are a function of the maxima of steps t - 3 and
+    t - 2 and of nothing else, so a run is bit for bit reproducible (tests/test_gpu_determinism.py) whatever the host's timing.
+    The scale puts the larger of those two maxima at 2^TARGET: [2^10, 2^11), a factor 32 below fp16's largest value for growth
+    between measurement and use (beyond it values saturate at +-65504, finite) and 2^24 above the smallest normal fp16 number; fp16
+    subnormals are kept by the matrix cores (tools/fp16_probe.py), so (hi, lo) degrades gracefully into fixed point below that.
     ``calibrate`` (tests, short runs): measure synchronously from one forward + backward that the caller runs in split-bf16."""
     MAX_SITES = 64
     TARGET = 10
@@ -1209,7 +1211,7 @@ class OperandScales:
         self.measured = -1                   # id of the newest step whose measurement the host holds
         self.step = -1                       # id of the running step
         self.pending = []                    # [(step id, pinned tensor, event)] read-backs in flight, oldest first
-        self.RING = 12                       # pinned read-back buffers + events, allocated once (a pinned allocation costs ~1 ms)
+        self.RING = 4                        # pinned read-back buffers + events, allocated once (a pinned allocation costs ~1 ms)
         self._ring = None
         self._ring_next = 0
         self.fp16_now = False
@@ -1231,18 +1233,17 @@ class OperandScales:
             self.pending.pop(0)
 
     def begin_step(self):
-        self._harvest()
         if self.step >= 0:                   # the step that just ended: its maxima go home behind its kernels
             if self._ring is None:
                 self._ring = [(torch.empty(self.MAX_SITES, dtype=torch.float32, pin_memory=True), torch.cuda.Event()) for _ in range(self.RING)]
-            if len(self.pending) >= self.RING - 1:   # the host is a ring ahead of the device: wait for the oldest read-back
-                self._harvest_one_blocking()
             host, ev = self._ring[self._ring_next]
             self._ring_next = (self._ring_next + 1) % self.RING
             host.copy_(self._compact(), non_blocking=True)
             ev.record()
             self.amax.zero_()
             self.pending.append((self.step, host, ev))
+        while len(self.pending) > 1:         # everything but the read-back just queued: steps <= t - 2, in order (waits if it must)
+            self._harvest_one_blocking()
         self.step += 1
         self.sites = {}
         self.fp16_now = bool(self.enabled and self.slots and all(fs <= self.measured for fs in self.first_step))
@@ -1669,6 +1670,12 @@ def _dw_x3(x3, dy3, K, N, outs=None, sa=None, sg=None):
     return res
 
 
+# terms of the fp16 weight-gradient product: 2 = xh^T [dyh | dyl] (the gradient exact, the activation rounded once: 1.4e-4 per GEMM);
+# 1 = xh^T dyh (both rounded once: 2e-4 per GEMM -- an error that stays in THIS weight's gradient and is not carried further down the
+# backward, unlike an input gradient's).  LPM_DW_TERMS, A/B; measured in tests/test_gpu_fp16x2.py
+DW_TERMS = int(os.environ.get("LPM_DW_TERMS", "1"))
+
+
 def _dw_x2(x2, dy2, K, N, outs, alpha):
     """The fp16 two-term weight gradient dW = alpha * xh^T [dyh | dyl] from an activation image x2 [M,3K] = [hi|lo|hi] (fp16) and a
     gradient image dy2 [M,2N] = [hi|lo]: the activation rounded once to fp16 (its hi plane, read in place with the image's row stride),
@@ -1680,17 +1687,19 @@ def _dw_x2(x2, dy2, K, N, outs, alpha):
     while S > 1 and (M % S or M // S < 512):
         S //= 2
     xh = x2.view(S, M // S, x2.shape[1])[:, :, :K]
-    part = torch.bmm(xh.transpose(1, 2), dy2.view(S, M // S, 2 * N), out_dtype=torch.float32)       # [S, K, 2N]
+    halves = 2 if DW_TERMS == 2 else 1
+    dyv = dy2.view(S, M // S, 2 * N)
+    part = torch.bmm(xh.transpose(1, 2), dyv if halves == 2 else dyv[:, :, :N], out_dtype=torch.float32)       # [S, K, halves N]
     slots = [_grad_slot(W) for W, _, _ in outs] if outs is not None else []
     if (outs is not None and all(sl is not None and sl.is_contiguous() for sl in slots) and len(outs) <= 3
             and all(nc == N // len(outs) and c0 == i * (N // len(outs)) for i, (_, c0, nc) in enumerate(outs)) and (N // len(outs)) % 4 == 0):
         sp = [ptr(sl) for sl in slots] + [None] * (3 - len(slots))
-        lib.check(lib._lpm_sum_splits_scaled(ptr(part), S, K, N, 2, alpha, sp[0], sp[1], sp[2], len(slots), stream_ptr()), "lpm_sum_splits_scaled")
+        lib.check(lib._lpm_sum_splits_scaled(ptr(part), S, K, N, halves, alpha, sp[0], sp[1], sp[2], len(slots), stream_ptr()), "lpm_sum_splits_scaled")
         for W, _, _ in outs:
             _grad_done(W)
         return tuple(None for _ in outs)
     full = torch.empty((K, N), dtype=torch.float32, device=x2.device)
-    lib.check(lib._lpm_sum_splits_scaled(ptr(part), S, K, N, 2, alpha, ptr(full), None, None, 1, stream_ptr()), "lpm_sum_splits_scaled")
+    lib.check(lib._lpm_sum_splits_scaled(ptr(part), S, K, N, halves, alpha, ptr(full), None, None, 1, stream_ptr()), "lpm_sum_splits_scaled")
     if outs is None:
         return full
     res = []

@@ -35,6 +35,10 @@ else:
 torch.manual_seed(7)
 tr.step(raw, nf, labels)                              # builds; the state after this step is the starting point
 torch.cuda.synchronize()
+# NetVladV1: the repeated step runs its encoder GEMMs on fp16 planes with scales measured on this batch (ops.OperandScales: a run's scales
+# are a function of the maxima of earlier steps only -- here every repetition sees the same ones)
+if tr.calibrate_operand_scales(raw, nf, labels):
+    print(f"operand scales calibrated: {len(tr.operand_scales.slots)} sites", flush=True)
 a = tr.arena
 start = dict(param=a.param.clone(), m=a.m.clone(), v=a.v.clone(), step=tr.global_step,
              stats={n: t.detach().clone() for n, t in tr.store.vars.items() if not tr.store.trainable[n]})
