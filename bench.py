@@ -426,6 +426,9 @@ def main():
     from learnablepoolingmethods_amd import _capi
     lib = _capi.load()
     lib._lpm_kernel_timing_enable(1)       # K1 / K2 launches carry their own start/stop HIP events (kernel duration proper)
+    if world > 1:
+        from learnablepoolingmethods_amd import train as _train
+        _train.TRACE.on = True             # three compute-stream events per collective: the overlap evidence printed below
     barrier("barrier before the timed steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -452,7 +455,10 @@ def main():
     k1_ms, k2_ms = kernel_ms(1), kernel_ms(2)
     at_ms, fin_ms = kernel_ms(3), kernel_ms(4)
     replicas = None
+    collectives = None
     if world > 1:
+        _train.TRACE.on = False
+        collectives = _train.TRACE.summary()   # rank 0's view: window = compute between a collective's launch and its wait, exposed = the stall
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -559,6 +565,11 @@ def main():
             line["dispatches_per_step"] = dispatches
         if replicas is not None:
             line["replicas"] = replicas
+        if collectives:
+            line["collectives"] = {"per_step_rank0": collectives,
+                                   "what": "compute-stream events around every asynchronous collective of the timed steps: window_ms = compute "
+                                           "between launch and wait (what it could hide under), exposed_ms = how long the compute stream stood "
+                                           "still for it (train.CollectiveTrace)"}
         if others is not None:
             line["other_configs"] = others
         sc = getattr(trainer, "operand_scales", None)

@@ -173,6 +173,54 @@ class ParameterArena:
             self.grad[cur:].zero_()
 
 
+class CollectiveTrace:
+    """Per-collective overlap evidence for the first real multi-GPU run (bench.py --gpus N switches it on for the
+    timed steps and prints the averages).  For every asynchronous collective of a step three events on the COMPUTE stream: at its
+    launch, just before the step waits for it, and right after that wait.  window = launch -> before-wait: the compute the collective
+    had to hide under; exposed = before-wait -> after-wait: how long the compute stream actually stood still for it.  A collective that
+    is hidden has exposed ~ 0 whatever its own duration.  Off (the default) it costs nothing."""
+
+    def __init__(self):
+        self.on = False
+        self.open = {}           # tag -> (MiB, launch event)
+        self.rows = []           # (tag, MiB, launch, before, after) of finished waits
+
+    def launched(self, tag, nbytes):
+        if self.on and torch.cuda.is_available():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.open[tag] = (nbytes / 2.0 ** 20, e)
+
+    def wait(self, tag, work):
+        if not self.on or tag not in self.open:
+            work.wait()
+            return
+        mib, e0 = self.open.pop(tag)
+        e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e1.record()
+        work.wait()
+        e2.record()
+        self.rows.append((tag, mib, e0, e1, e2))
+
+    def summary(self):
+        """[{collective, MiB, calls, window_ms, exposed_ms}] averaged over the recorded steps (synchronises)."""
+        if not self.rows:
+            return []
+        torch.cuda.synchronize()
+        acc = {}
+        for tag, mib, e0, e1, e2 in self.rows:
+            a = acc.setdefault(tag, [mib, 0, 0.0, 0.0])
+            a[1] += 1
+            a[2] += e0.elapsed_time(e1)
+            a[3] += e1.elapsed_time(e2)
+        self.rows = []
+        return [{"collective": t, "MiB": round(a[0], 1), "calls": a[1], "window_ms": round(a[2] / a[1], 3), "exposed_ms": round(a[3] / a[1], 3)}
+                for t, a in acc.items()]
+
+
+TRACE = CollectiveTrace()
+
+
 class GradientSynchronizer:
     """Cross-rank SUM of the gradient arena (utils.combine_gradients semantics: sum, not mean).
     Buckets are contiguous arena slices; ``early`` buckets are all-reduced from an autograd hook as soon
@@ -199,6 +247,7 @@ class GradientSynchronizer:
             return
         _note(f"all_reduce(SUM) of gradient bucket {i} = arena[{a}:{b}] ({4 * (b - a) >> 20} MiB): launching")
         self.pending.append((i, dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        TRACE.launched(f"all_reduce bucket {i}", 4 * (b - a))
         _note(f"all_reduce(SUM) of gradient bucket {i} = arena[{a}:{b}] ({4 * (b - a) >> 20} MiB): launched, not yet waited for")
         self.done.add(i)
 
@@ -207,7 +256,7 @@ class GradientSynchronizer:
             self.launch(i)
         for i, w in self.pending:
             _note(f"all_reduce(SUM) of gradient bucket {i}: waiting for completion")
-            w.wait()
+            TRACE.wait(f"all_reduce bucket {i}", w)
         if self.pending:
             _note(f"all_reduce(SUM) of gradient buckets {[i for i, _ in self.pending]}: complete")
         self.pending, self.done = [], set()
@@ -273,6 +322,7 @@ class ShardedVariableUpdate:
             self._rs = dist.reduce_scatter_tensor(self.gshard, seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             self._rs = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        TRACE.launched("reduce_scatter hidden1_weights", 4 * (self.a1 - self.a0))
         _note(f"reduce_scatter(SUM) of {self.name}'s gradient: launched, not yet waited for")
 
     def step(self, clip: float, lr: float, global_step: int):
@@ -282,7 +332,7 @@ class ShardedVariableUpdate:
         if not self.launched:
             self.launch()
         _note(f"reduce_scatter(SUM) of {self.name}'s gradient: waiting for completion")
-        self._rs.wait()
+        TRACE.wait("reduce_scatter hidden1_weights", self._rs)
         self._rs = None
         self.launched = False
         if not self._native_rs:
@@ -308,12 +358,13 @@ class ShardedVariableUpdate:
         self._ag_src = p.clone()
         _note(f"all_gather of {self.name}'s updated parameter shards ({4 * self.shard >> 20} MiB each): launching")
         self._ag = dist.all_gather_into_tensor(a.param[self.a0:self.a1], self._ag_src, group=self.group, async_op=True)
+        TRACE.launched("all_gather hidden1_weights parameters", 4 * (self.a1 - self.a0))
         _note(f"all_gather of {self.name}'s updated parameter shards: launched, waited for by the next read of the variable")
 
     def wait_parameters(self):
         if self._ag is not None:
             _note(f"all_gather of {self.name}'s updated parameter shards: waiting for completion")
-            self._ag.wait()
+            TRACE.wait("all_gather hidden1_weights parameters", self._ag)
             _note(f"all_gather of {self.name}'s updated parameter shards: complete")
             self._ag = self._ag_src = None
 
@@ -423,7 +474,9 @@ class Trainer:
         # per-tensor scales this object measures; every other model (NetVladV2: transformer_utils.py:652-671 amplifies forward errors)
         # stays on split-bf16 x3
         self.operand_scales = None
-        if (self.device.type == "cuda" and FLAGS.dense_arithmetic == "fp16x2" and type(model).__name__ == "NetVladV1"
+        # (LPM_V2_FP16=1, measurement only: NetVladV2's plain dense layers and q / k / v on the fp16 formats as well)
+        fp16_models = ("NetVladV1", "NetVladV2") if os.environ.get("LPM_V2_FP16") == "1" else ("NetVladV1",)
+        if (self.device.type == "cuda" and FLAGS.dense_arithmetic == "fp16x2" and type(model).__name__ in fp16_models
                 and os.environ.get("LPM_DENSE_ARITHMETIC", "fp16x2") == "fp16x2"):
             self.operand_scales = ops.OperandScales(self.device)
         if self.device.type == "cuda":
@@ -739,6 +792,7 @@ class Trainer:
         for what, dst, src in (("descriptor", xt_all, fg.xt), ("output-gradient", dyt_all, fg.dyt)):
             _note(f"all_gather of the hidden projection's {what} tiles ({dst.numel() * 4 >> 20} MiB over {n} towers): launching")
             self._factored_work.append((what, dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)))
+            TRACE.launched(f"all_gather {what} tiles", 4 * dst.numel())
         self._factored_all = (xt_all, dyt_all, n * fg.R, fg.xt, fg.dyt)         # (the local buffers stay alive until the wait)
         self.sync.done.add(0)
 
@@ -747,7 +801,7 @@ class Trainer:
             return
         for what, w in self._factored_work:
             _note(f"all_gather of the hidden projection's {what} tiles: waiting for completion")
-            w.wait()
+            TRACE.wait(f"all_gather {what} tiles", w)
         _note("all_gather of the hidden projection's tiles: complete")
         fg = self.factored
         fg.xt, fg.dyt, fg.R = self._factored_all[:3]

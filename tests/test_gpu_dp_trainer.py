@@ -214,7 +214,7 @@ def test_bench_eight_ranks_share_the_gpu_over_gloo(config, global_batch):
     if os.environ.get("LPM_TEST_EIGHT_RANKS") != "1":
         # 31 of 35 runs on five boxes passed (8-40 s each); on ONE box 4 of 6 ended after ~100 s with one rank aborted (SIGABRT; round 4: an illegal-instruction report from the HSA queue under time-slicing)
         # while the two-rank tests of the same box passed -- eight processes on one GPU is not a configuration worth a red tier
-        pytest.skip("opt-in (LPM_TEST_EIGHT_RANKS=1; tools/eight_ranks_loop.sh runs it repeatedly)")
+        pytest.skip("opt-in (LPM_TEST_EIGHT_RANKS=1)")
     if torch.cuda.get_device_properties(0).total_memory < 150 * 2 ** 30:
         pytest.skip("eight trainers of these configurations need 100-160 GB of HBM")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LPM_SHARE_GPU="1")

@@ -5,8 +5,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from learnablepoolingmethods_amd import FLAGS, ops
-from tests.test_gpu_fp16x2 import _calibrated
-from tests._util import rel_l2
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+class _calibrated:
+    """fn once in split-bf16 under an OperandScales (measures max |x| per site), then on fp16 planes with those scales."""
+
+    def __init__(self, dev):
+        self.sc = ops.OperandScales(dev)
+
+    def run(self, fn):
+        sc = self.sc
+        sc.enabled = False
+        sc.begin_step()
+        ops._ACTIVE_SCALES = sc
+        try:
+            fn()
+        finally:
+            ops._ACTIVE_SCALES = None
+        sc.calibrate_from_device()
+        sc.enabled = True
+        sc.begin_step()
+        ops._ACTIVE_SCALES = sc
+        try:
+            return fn()
+        finally:
+            ops._ACTIVE_SCALES = None
+
 
 dev = torch.device("cuda:0")
 B, L, F, heads = 4, 256, 1024, 64
