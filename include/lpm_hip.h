@@ -540,10 +540,23 @@ int lpm_layer_norm_act_image_fwd_fmt(const float* a, const float* bias, int relu
                                      const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride, void* y_img,
                                      float* z, float* stats, void* workspace, size_t workspace_bytes, const LpmOperandFormat* fmt,
                                      lpm_stream_t stream);
+int lpm_layer_norm_act_mask_image_fwd_fmt(const float* a, const float* bias, int relu, const unsigned char* mask, float mask_scale, const float* r,
+                                          const float* gamma, const float* beta, int B, int L, int F, float eps, float* y,
+                                          int64_t y_batch_stride, void* y_img, float* z, float* stats, void* workspace,
+                                          size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream);
 int lpm_layer_norm_act_bwd_fmt(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats, const float* gamma,
                                const float* a, const float* bias, int relu, int B, int L, int F, float* dz, float* da, float* dgamma,
                                float* dbeta, float* dbias, const float* dr_extra, void* da_image, void* workspace, size_t workspace_bytes,
                                const LpmOperandFormat* fmt, lpm_stream_t stream);
+/* lpm_bn_rows_act_image_fwd / lpm_bn_act_bwd_image (NetVladV2's dense -> batch norm -> dense chains, transformer_utils.py:666-677,741-756)
+ * with the image in any operand format. */
+int lpm_bn_rows_act_image_fwd_fmt(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
+                                  float eps, float decay, int biased_moving_variance, void* out_img, float* mean, float* var,
+                                  float* moving_mean, float* moving_var, void* workspace, size_t workspace_bytes,
+                                  const LpmOperandFormat* fmt, lpm_stream_t stream);
+int lpm_bn_act_bwd_image_fmt(const float* dlt, const float* x, const float* pre_bias, int pre_relu, const float* mean, const float* var,
+                             const float* gamma, float eps, int M, int K, void* dl_img, float* dgamma, float* dbeta, float* dbias,
+                             void* workspace, size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream);
 /* lpm_mha_fwd_x3_image / lpm_mha_bwd_x3_image with the images in either format: o_fmt = the format the attention result's image is
  * written with (forward) / was written with (backward: kind and scale are read, amax ignored), g_fmt = the format of the
  * [dq | dk | dv] gradient image (fp16x2: row = [hi(3N) | lo(3N)]). */

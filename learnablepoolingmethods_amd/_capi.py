@@ -177,10 +177,13 @@ SIGNATURES = {
     "lpm_dense_tiles_act_image_fwd_fmt": (_i, [_f, _f, _f, _i, _i, _i, _fl, _f, _f, _f]),
     "lpm_dense_tiles_relu_bwd_image_fmt": (_i, [_f, _f, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _s, _f, _f]),
     "lpm_layer_norm_act_image_fwd_fmt": (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _f, _s, _f, _f]),
+    "lpm_layer_norm_act_mask_image_fwd_fmt": (_i, [_f, _f, _i, _f, _fl, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _f, _s, _f, _f]),
     "lpm_layer_norm_act_bwd_fmt": (_i, [_f, _l, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _s, _f, _f]),
     "lpm_mha_fwd_x3_image_fmt": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _f]),
     "lpm_mha_bwd_x3_image_fmt": (_i, [_f, _f, _f, _l, _f, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f]),
     "lpm_sum_splits_scaled": (_i, [_f, _i, _i, _i, _i, _fl, _f, _f, _f, _i, _f]),
+    "lpm_bn_rows_act_image_fwd_fmt": (_i, [_f, _f, _i, _i, _i, _f, _f, _fl, _fl, _i, _f, _f, _f, _f, _f, _f, _s, _f, _f]),
+    "lpm_bn_act_bwd_image_fmt": (_i, [_f, _f, _f, _i, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _f, _s, _f, _f]),
 }
 LPM_OPERAND_BF16X3 = 0
 LPM_OPERAND_FP16X2 = 1

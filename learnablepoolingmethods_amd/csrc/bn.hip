@@ -2,6 +2,7 @@
 // SURVEY.md App. B): statistics fold (frame_level_models.py:2266,2784) and the backward
 // through the batch statistics of the assignment logits (App. F.4).
 #include "lpm_common.h"
+#include "operand_format.h"
 
 namespace lpm {
 
@@ -183,7 +184,17 @@ __device__ __forceinline__ unsigned bn_rne(float v) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
-__device__ __forceinline__ void bn_store_image(unsigned short* __restrict__ img, int64_t row, int c, int C, int order, float4 v) {
+// Round 5: fmt.f16 -- the fp16 operand formats (operand_format.h): planes of v * scale, three for an activation / two for a gradient;
+// vmax collects max |v| for the host's delayed scale.
+__device__ __forceinline__ void bn_store_image(unsigned short* __restrict__ img, int64_t row, int c, int C, int order, float4 v, const OperandFmt& fmt,
+                                               float& vmax) {
+    vmax = fmaxf(fmaxf(vmax, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+    if (fmt.f16) {
+        uint2 hi, lo;
+        of_split4(v.x, v.y, v.z, v.w, 1, fmt.scale, hi, lo);
+        of_store_row4(img + row * fmt.planes * (int64_t)C, C, c, hi, lo, fmt.planes, order);
+        return;
+    }
     const unsigned hx = bn_rne(v.x), hy = bn_rne(v.y), hz = bn_rne(v.z), hw = bn_rne(v.w);
     const unsigned lx = bn_rne(v.x - __uint_as_float(hx << 16)), ly = bn_rne(v.y - __uint_as_float(hy << 16));
     const unsigned lz = bn_rne(v.z - __uint_as_float(hz << 16)), lw = bn_rne(v.w - __uint_as_float(hw << 16));
@@ -203,7 +214,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float eps, int M, int K,
                                                            float* __restrict__ dl, const float* __restrict__ pb, int relu,
-                                                           float* __restrict__ dbpart, unsigned short* __restrict__ dl3) {
+                                                           float* __restrict__ dbpart, unsigned short* __restrict__ dl3, const OperandFmt fmt) {
+    float vmax = 0.f;
     // dl3 != null: the result leaves as the GRADIENT image [M][3K] = [hi | hi | lo] of the dense layer in front instead of as fp32
     // pb / relu: the normalised tensor was act(logits + pb); dl is then the gradient of the RAW logits (masked where the ReLU was off)
     // and dbpart [stride / (K/4)][K] receives this thread's column sums of it (the bias gradient; needs the fixed-column arrangement)
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             o.x = l.x > 0.f ? o.x : 0.f; o.y = l.y > 0.f ? o.y : 0.f; o.z = l.z > 0.f ? o.z : 0.f; o.w = l.w > 0.f ? o.w : 0.f;
         }
         bsum.x += o.x; bsum.y += o.y; bsum.z += o.z; bsum.w += o.w;
-        if (dl3) bn_store_image(dl3, i / K4, (int)(i % K4) * 4, K, 1, o);
+        if (dl3) bn_store_image(dl3, i / K4, (int)(i % K4) * 4, K, 1, o, fmt, vmax);
         else reinterpret_cast<float4*>(dl)[i] = o;
     };
     const float4* dp = reinterpret_cast<const float4*>(dlt);
@@ -260,6 +272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (; i < total4; i += stride) one(i, dp[i], lp[i]);
     if (dbpart && i0 < stride)            // (fixed: the thread kept columns 4 (i0 % K4) ..; threads beyond the data wrote nothing: zero sums)
         *reinterpret_cast<float4*>(dbpart + (i0 / K4) * K + (i0 % K4) * 4) = bsum;
+    if (dl3) of_amax_commit(fmt.amax, vmax);
 }
 
 // ---- channel-last batch norm of a [M, C] matrix (the V2 encoder's [B, L, C] tensors seen as rows) -----------------------------
@@ -317,16 +330,18 @@ __global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int64_t total4, int C4,
                                                             float* __restrict__ y, const float* __restrict__ pb, int relu,
-                                                            unsigned short* __restrict__ y3) {
+                                                            unsigned short* __restrict__ y3, const OperandFmt fmt) {
+    float vmax = 0.f;
     // y3 != null: the result leaves as the ACTIVATION image [M][3C] = [hi | lo | hi] of the next dense layer instead of as fp32
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
         const float4 v = bn_preact(reinterpret_cast<const float4*>(x)[i], pb, c, relu);
         const float4 a = *reinterpret_cast<const float4*>(scale + c), b = *reinterpret_cast<const float4*>(shift + c);
         const float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
-        if (y3) bn_store_image(y3, i / C4, c, C4 * 4, 0, o);
+        if (y3) bn_store_image(y3, i / C4, c, C4 * 4, 0, o, fmt, vmax);
         else reinterpret_cast<float4*>(y)[i] = o;
     }
+    if (y3) of_amax_commit(fmt.amax, vmax);
 }
 
 }  // namespace lpm
@@ -338,7 +353,8 @@ extern "C" size_t lpm_bn_rows_workspace_bytes(int M, int C) {
 
 static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
                             float eps, float decay, int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
-                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3 = nullptr);
+                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3 = nullptr,
+                            const LpmOperandFormat* fmt = nullptr);
 extern "C" int lpm_bn_rows_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float decay,
                                int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
                                float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
@@ -366,9 +382,20 @@ extern "C" int lpm_bn_rows_act_image_fwd(const float* x, const float* pre_bias, 
     return bn_rows_fwd_impl(x, pre_bias, pre_relu, M, C, gamma, beta, eps, decay, biased_moving_variance, nullptr, mean, var, moving_mean,
                             moving_var, workspace, workspace_bytes, stream, out3);
 }
+extern "C" int lpm_bn_rows_act_image_fwd_fmt(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma,
+                                             const float* beta, float eps, float decay, int biased_moving_variance, void* out_img, float* mean,
+                                             float* var, float* moving_mean, float* moving_var, void* workspace, size_t workspace_bytes,
+                                             const LpmOperandFormat* fmt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(pre_bias && out_img && ((((uintptr_t)pre_bias) | (uintptr_t)out_img) & 15) == 0 && C % 8 == 0, LPM_ERR_BADARG,
+                "lpm_bn_rows_act_image_fwd: needs a 16-byte aligned bias and image and C %% 8 == 0");
+    if (const int rc = operand_fmt_check(fmt, "lpm_bn_rows_act_image_fwd")) return rc;
+    return bn_rows_fwd_impl(x, pre_bias, pre_relu, M, C, gamma, beta, eps, decay, biased_moving_variance, nullptr, mean, var, moving_mean,
+                            moving_var, workspace, workspace_bytes, stream, out_img, fmt);
+}
 static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu, int M, int C, const float* gamma, const float* beta,
                             float eps, float decay, int biased_moving_variance, float* y, float* mean, float* var, float* moving_mean,
-                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3) {
+                            float* moving_var, void* workspace, size_t workspace_bytes, lpm_stream_t stream, void* y3, const LpmOperandFormat* fmt) {
     using namespace lpm;
     LPM_REQUIRE(x && (y || y3) && mean && var && workspace, LPM_ERR_BADARG, "lpm_bn_rows_fwd: null pointer");
     LPM_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, LPM_ERR_UNSUPPORTED_SHAPE,
@@ -387,7 +414,7 @@ static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu,
     const int64_t total4 = (int64_t)M * C / 4;
     const int64_t want = (total4 + 255) / 256;
     hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, x, scale, shift, total4, C / 4, y, pre_bias,
-                       pre_relu, (unsigned short*)y3);
+                       pre_relu, (unsigned short*)y3, operand_fmt(fmt));
     return check_launch("lpm_bn_rows_fwd");
 }
 
@@ -560,7 +587,7 @@ static int bn_bwd_grid(int M, int K) {
 }  // namespace lpm
 static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_bias, int pre_relu, const float* mean, const float* var,
                        const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                       size_t workspace_bytes, lpm_stream_t stream, void* dl3 = nullptr);
+                       size_t workspace_bytes, lpm_stream_t stream, void* dl3 = nullptr, const LpmOperandFormat* fmt = nullptr);
 extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var,
                           const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta,
                           void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
@@ -598,9 +625,21 @@ extern "C" int lpm_bn_act_bwd_image(const float* dlt, const float* x, const floa
     LPM_REQUIRE(workspace_bytes >= lpm_bn_act_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE, "lpm_bn_act_bwd_image: workspace too small");
     return bn_bwd_impl(dlt, x, pre_bias, pre_relu, mean, var, gamma, eps, M, K, nullptr, dgamma, dbeta, dbias, workspace, workspace_bytes, stream, dl3);
 }
+extern "C" int lpm_bn_act_bwd_image_fmt(const float* dlt, const float* x, const float* pre_bias, int pre_relu, const float* mean, const float* var,
+                                        const float* gamma, float eps, int M, int K, void* dl_img, float* dgamma, float* dbeta, float* dbias,
+                                        void* workspace, size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(pre_bias && dbias && dl_img && ((((uintptr_t)pre_bias) | (uintptr_t)dl_img) & 15) == 0 && K % 8 == 0, LPM_ERR_BADARG,
+                "lpm_bn_act_bwd_image: needs a 16-byte aligned bias, image and dbias and K %% 8 == 0");
+    LPM_REQUIRE(lpm_bn_act_bwd_supported(M, K), LPM_ERR_UNSUPPORTED_SHAPE, "lpm_bn_act_bwd_image: shape not supported (M=%d K=%d)", M, K);
+    LPM_REQUIRE(workspace_bytes >= lpm_bn_act_bwd_workspace_bytes(M, K), LPM_ERR_WORKSPACE, "lpm_bn_act_bwd_image: workspace too small");
+    if (const int rc = operand_fmt_check(fmt, "lpm_bn_act_bwd_image")) return rc;
+    return bn_bwd_impl(dlt, x, pre_bias, pre_relu, mean, var, gamma, eps, M, K, nullptr, dgamma, dbeta, dbias, workspace, workspace_bytes, stream,
+                       dl_img, fmt);
+}
 static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_bias, int pre_relu, const float* mean, const float* var,
                        const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                       size_t workspace_bytes, lpm_stream_t stream, void* dl3) {
+                       size_t workspace_bytes, lpm_stream_t stream, void* dl3, const LpmOperandFormat* fmt) {
     using namespace lpm;
     LPM_REQUIRE(dlt && logits && mean && var && (dl || dl3) && dgamma && dbeta && workspace, LPM_ERR_BADARG,
                 "lpm_bn_bwd: null pointer");
@@ -616,7 +655,7 @@ static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_b
     const int grid = bn_bwd_grid(M, K);
     float* dbpart = dbias ? partial + (size_t)nblk * 2 * K : nullptr;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, dlt, logits, mean, var, gamma, dgamma, dbeta,
-                       eps, M, K, dl, pre_bias, pre_relu, dbpart, (unsigned short*)dl3);
+                       eps, M, K, dl, pre_bias, pre_relu, dbpart, (unsigned short*)dl3, operand_fmt(fmt));
     if (dbias) {
         const int rows = (int)((int64_t)grid * 256 / (K / 4));
         if (rows > 4 * BN_CS_SLICES) {

@@ -431,6 +431,16 @@ extern "C" int lpm_layer_norm_act_mask_image_fwd(const float* a, const float* bi
     return layer_norm_act_fwd_impl(a, bias, relu, r, nullptr, gamma, beta, B, L, F, eps, y, y_batch_stride, z, stats, workspace,
                                    workspace_bytes, stream, y3, mask, mask_scale);
 }
+extern "C" int lpm_layer_norm_act_mask_image_fwd_fmt(const float* a, const float* bias, int relu, const unsigned char* mask, float mask_scale,
+                                                     const float* r, const float* gamma, const float* beta, int B, int L, int F, float eps,
+                                                     float* y, int64_t y_batch_stride, void* y3, float* z, float* stats, void* workspace,
+                                                     size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(mask, LPM_ERR_BADARG, "lpm_layer_norm_act_mask_image_fwd: null keep mask");
+    LPM_REQUIRE(!y3 || ((uintptr_t)y3 & 7) == 0, LPM_ERR_BADARG, "lpm_layer_norm_act_mask_image_fwd: y3 not 8-byte aligned");
+    return layer_norm_act_fwd_impl(a, bias, relu, r, nullptr, gamma, beta, B, L, F, eps, y, y_batch_stride, z, stats, workspace,
+                                   workspace_bytes, stream, y3, mask, mask_scale, fmt);
+}
 extern "C" int lpm_layer_norm_act_fwd(const float* a, const float* bias, int relu, const float* r, const float* gamma,
                                       const float* beta, int B, int L, int F, float eps, float* y, int64_t y_batch_stride,
                                       float* z, float* stats, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {

@@ -59,12 +59,12 @@ FLAGS.define("ln_pair_forward", True, "build extension: the two layer norms at t
 FLAGS.define("audio_side_stream", True, "build extension: run the audio stream (NetVLAD + encoder, ~100 latency-bound small "
              "launches per step) on a second HIP stream next to the video stream")
 FLAGS.define("dense_precision", "bf16x3", "build extension: encoder dense GEMMs as split-bf16 ('bf16x3', ~4e-6) or 'f32'")
-FLAGS.define("dense_arithmetic", "fp16x2", "build extension, NetVladV1's cluster encoders only: 'fp16x2' = their dense GEMMs (q|k|v, output "
-             "transform, both FeedForwardNetwork layers and every input / weight gradient of them) read the data operand as fp16 (hi, lo) "
-             "planes and the weight rounded once to fp16 -- two matrix-pipe products per a . b instead of split-bf16's three, ~1.4e-4 "
-             "per GEMM instead of ~5e-6 -- with per-tensor power-of-two scales the trainer measures one step and applies the next "
-             "(ops.OperandScales; the first steps of a run stay on split-bf16 until every operand has been measured); 'bf16x3' = "
-             "split-bf16 throughout.  NetVladV2 is always 'bf16x3': its logits batch norm amplifies forward errors ~500 x")
+FLAGS.define("dense_arithmetic", "fp16x2", "build extension, the encoders' dense GEMMs of NetVladV1 and NetVladV2 (q|k|v, output transform, "
+             "both feed-forward layers and every input / weight gradient of them): 'fp16x2' = fp16 (hi, lo) operand planes with per-tensor "
+             "power-of-two scales the trainer measures at one step and applies two steps later (ops.OperandScales; the first two steps of a "
+             "run stay on split-bf16) -- forward products keep three terms (~1e-6), input gradients two (the weight rounded once to fp16: "
+             "1.4e-4 per GEMM), weight gradients one (both operands rounded once: 2e-4, not carried further down the backward) -- against "
+             "split-bf16's three terms everywhere; 'bf16x3' = split-bf16 throughout (rounds 1-4)")
 # video_level_models.py
 FLAGS.define("moe_num_mixtures", 2, "video_level_models.py:27")
 FLAGS.define("moe_l2", 1e-8, ":35")

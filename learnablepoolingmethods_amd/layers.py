@@ -68,7 +68,7 @@ def batch_norm(x: torch.Tensor, is_training: bool, scope: str, pre_bias: torch.T
 
 
 def layer_norm(x: torch.Tensor, scope: str = "LayerNorm", residual: torch.Tensor = None, bias: torch.Tensor = None,
-               relu: bool = False, image: bool = False, mask: torch.Tensor = None, mask_scale: float = 1.0) -> torch.Tensor:
+               relu: bool = False, image: bool = False, mask: torch.Tensor = None, mask_scale: float = 1.0, next_kernel=None) -> torch.Tensor:
     """tf.contrib.layers.layer_norm(act(x + bias) [+ residual]) with TF1 defaults: moments over ALL non-batch axes,
     gamma/beta [last], eps 1e-12 (transformer_utils.py:407,411,454,713).  ``bias`` / ``relu`` are the tail of the dense
     layer that produced x (tf.layers.dense(use_bias=True[, activation=relu])), handed over so that [B,L,F] tensors on the
@@ -78,7 +78,9 @@ def layer_norm(x: torch.Tensor, scope: str = "LayerNorm", residual: torch.Tensor
         gamma = vs.get_variable("gamma", [x.shape[-1]], vs.ones_initializer(), device=x.device)
     if x.is_cuda and x.dim() == 3 and x.shape[-1] in ops.LN_FEATURES:
         # image, mask / mask_scale (a dropout keep mask applied to act(x + bias) before the residual): see ops.residual_layer_norm
-        return ops.residual_layer_norm(x, residual, gamma, beta, bias=bias, relu=relu, image=image, mask=mask, mask_scale=mask_scale)
+        # next_kernel: the kernel of the dense layer that reads the result next -- the operand image is written in that layer's format
+        return ops.residual_layer_norm(x, residual, gamma, beta, bias=bias, relu=relu, image=image, mask=mask, mask_scale=mask_scale,
+                                       next_kernel=next_kernel)
     if bias is not None:
         x = x + bias
     if relu:

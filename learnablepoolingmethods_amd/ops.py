@@ -2207,23 +2207,27 @@ class _FFNModX3(torch.autograd.Function):
         W1, W2 = _f32(W1, "W1").contiguous(), _f32(W2, "W2").contiguous()
         M, F = y2d.shape
         C = W1.shape[1]
-        if y3 is None:
-            y3 = _split_rows(y2d)
-        w13n, w13k = _split_weight(W1)
-        pre = _mm3(y3, w13n)                                               # raw output of the first dense layer [M, C]
+        s1, s2 = _site("a", W1_0), _site("a", W2_0)        # operand sites (fp16 planes when the trainer's scales are calibrated)
+        f16 = _f16(s1)
+        ctx.sites = (s1, s2)
+        dt = torch.float16 if f16 else torch.bfloat16
+        if y3 is None or y3.dtype != dt:
+            y3 = _split_rows(y2d, site=s1)
+        w13n, w13k = _split_weight(W1, f16=f16)
+        pre = _mm3(y3, w13n, alpha=s1.inv if s1 is not None else 1.0)      # raw output of the first dense layer [M, C]
         b1 = b1.contiguous()
-        f3 = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=y2d.device)
+        f3 = torch.empty((M, 3 * C), dtype=dt, device=y2d.device)
         mean, var = _empty((C,), pre), _empty((C,), pre)
         wsb = lib._lpm_bn_rows_workspace_bytes(M, C)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=pre.device)
-        lib.check(lib._lpm_bn_rows_act_image_fwd(ptr(pre), ptr(b1), 1, M, C, ptr(gamma), ptr(beta), BN_EPS, BN_DECAY, 1, ptr(f3), ptr(mean),
-                                                 ptr(var), ptr(moving_mean), ptr(moving_var), ptr(ws), wsb, stream_ptr()),
-                  "lpm_bn_rows_act_image_fwd")
-        w23n, w23k = _split_weight(W2)
+        lib.check(lib._lpm_bn_rows_act_image_fwd_fmt(ptr(pre), ptr(b1), 1, M, C, ptr(gamma), ptr(beta), BN_EPS, BN_DECAY, 1, ptr(f3), ptr(mean),
+                                                     ptr(var), ptr(moving_mean), ptr(moving_var), ptr(ws), wsb,
+                                                     s2.fmt if s2 is not None else None, stream_ptr()), "lpm_bn_rows_act_image_fwd")
+        w23n, w23k = _split_weight(W2, f16=f16)
         ctx.save_for_backward(y3, pre, b1, mean, var, gamma, f3, w13k, w23k)
         ctx.dims = (F, C, W2.shape[1])
         ctx.wrefs = (W1_0, W2_0)
-        return _mm3(f3, w23n)
+        return _mm3(f3, w23n, alpha=s2.inv if s2 is not None else 1.0)
 
     @staticmethod
     def backward(ctx, dout):
@@ -2231,18 +2235,22 @@ class _FFNModX3(torch.autograd.Function):
         y3, pre, b1, mean, var, gamma, f3, w13k, w23k = ctx.saved_tensors
         F, C, N = ctx.dims
         M = y3.shape[0]
-        do3 = _split_rows(dout.contiguous(), grad=True)
-        dW2 = _dw_x3(f3, do3, C, N, outs=[(ctx.wrefs[1], 0, N)])[0]
-        df = _mm3(do3, w23k)                                               # gradient of the batch norm's output [M, C]
-        dp3 = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=df.device)
+        s1, s2 = ctx.sites
+        g1, g2 = _site("g", ctx.wrefs[0]), _site("g", ctx.wrefs[1])
+        f16 = _f16(s1)
+        do3 = _split_rows(dout.contiguous(), grad=True, site=g2)
+        dW2 = _dw_x3(f3, do3, C, N, outs=[(ctx.wrefs[1], 0, N)], sa=s2, sg=g2)[0]
+        df = _mm3(do3, w23k, alpha=g2.inv if g2 is not None else 1.0)      # gradient of the batch norm's output [M, C]
+        dp3 = torch.empty((M, (2 if f16 else 3) * C), dtype=torch.float16 if f16 else torch.bfloat16, device=df.device)
         dgamma, dbeta, db1 = _empty((C,), df), _empty((C,), df), _empty((C,), df)
         wsb = lib._lpm_bn_act_bwd_workspace_bytes(M, C)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=df.device)
-        lib.check(lib._lpm_bn_act_bwd_image(ptr(df), ptr(pre), ptr(b1), 1, ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, C, ptr(dp3), ptr(dgamma),
-                                            ptr(dbeta), ptr(db1), ptr(ws), wsb, stream_ptr()), "lpm_bn_act_bwd_image")
+        lib.check(lib._lpm_bn_act_bwd_image_fmt(ptr(df), ptr(pre), ptr(b1), 1, ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, C, ptr(dp3), ptr(dgamma),
+                                                ptr(dbeta), ptr(db1), ptr(ws), wsb, g1.fmt if g1 is not None else None, stream_ptr()),
+                  "lpm_bn_act_bwd_image")
         del df
-        dy = _mm3(dp3, w13k) if ctx.needs_input_grad[0] else None
-        dW1 = _dw_x3(y3, dp3, F, C, outs=[(ctx.wrefs[0], 0, C)])[0]
+        dy = _mm3(dp3, w13k, alpha=g1.inv if g1 is not None else 1.0) if ctx.needs_input_grad[0] else None
+        dW1 = _dw_x3(y3, dp3, F, C, outs=[(ctx.wrefs[0], 0, C)], sa=s1, sg=g1)[0]
         return dy, dW1, db1, dgamma, dbeta, None, None, dW2, None
 
 
@@ -2261,21 +2269,23 @@ class _BNDenseX3(torch.autograd.Function):
         W0 = W
         W = _f32(W, "dense kernel").contiguous()
         M, C = x2.shape
-        f3 = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=x2.device)
+        sa = ctx.site_a = _site("a", W0)
+        f16 = _f16(sa)
+        f3 = torch.empty((M, 3 * C), dtype=torch.float16 if f16 else torch.bfloat16, device=x2.device)
         mean, var = _empty((C,), x2), _empty((C,), x2)
         zero = _ZEROS.get((x2.device, C))
         if zero is None:
             zero = _ZEROS[(x2.device, C)] = torch.zeros(C, dtype=torch.float32, device=x2.device)       # (the kernel's bias operand: none here)
         wsb = lib._lpm_bn_rows_workspace_bytes(M, C)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=x2.device)
-        lib.check(lib._lpm_bn_rows_act_image_fwd(ptr(x2), ptr(zero), 0, M, C, ptr(gamma), ptr(beta), BN_EPS, BN_DECAY, 1, ptr(f3), ptr(mean),
-                                                 ptr(var), ptr(moving_mean), ptr(moving_var), ptr(ws), wsb, stream_ptr()),
-                  "lpm_bn_rows_act_image_fwd")
-        w3n, w3k = _split_weight(W)
+        lib.check(lib._lpm_bn_rows_act_image_fwd_fmt(ptr(x2), ptr(zero), 0, M, C, ptr(gamma), ptr(beta), BN_EPS, BN_DECAY, 1, ptr(f3), ptr(mean),
+                                                     ptr(var), ptr(moving_mean), ptr(moving_var), ptr(ws), wsb,
+                                                     sa.fmt if sa is not None else None, stream_ptr()), "lpm_bn_rows_act_image_fwd")
+        w3n, w3k = _split_weight(W, f16=f16)
         ctx.save_for_backward(x2, mean, var, gamma, f3, w3k)
         ctx.dims = (C, W.shape[1])
         ctx.wrefs = (W0,)
-        return _mm3(f3, w3n)
+        return _mm3(f3, w3n, alpha=sa.inv if sa is not None else 1.0)
 
     @staticmethod
     def backward(ctx, dout):
@@ -2283,9 +2293,10 @@ class _BNDenseX3(torch.autograd.Function):
         x2, mean, var, gamma, f3, w3k = ctx.saved_tensors
         C, N = ctx.dims
         M = x2.shape[0]
-        do3 = _split_rows(dout.contiguous(), grad=True)
-        dW = _dw_x3(f3, do3, C, N, outs=[(ctx.wrefs[0], 0, N)])[0]
-        df = _mm3(do3, w3k)                                                # gradient of the batch norm's output [M, C]
+        sa, sg = ctx.site_a, _site("g", ctx.wrefs[0])
+        do3 = _split_rows(dout.contiguous(), grad=True, site=sg)
+        dW = _dw_x3(f3, do3, C, N, outs=[(ctx.wrefs[0], 0, N)], sa=sa, sg=sg)[0]
+        df = _mm3(do3, w3k, alpha=sg.inv if sg is not None else 1.0)       # gradient of the batch norm's output [M, C]
         dx = torch.empty_like(x2)
         dgamma, dbeta = _empty((C,), x2), _empty((C,), x2)
         wsb = lib._lpm_bn_bwd_workspace_bytes(M, C)
@@ -2415,9 +2426,10 @@ class _ResidualLayerNorm(torch.autograd.Function):
             if mask.dtype != torch.uint8 or tuple(mask.shape) != (B, L, F):
                 raise LpmError("layer_norm: the dropout keep mask must be uint8 / bool [B, L, F]")
             z = torch.empty_like(a) if z is a else z
-            lib.check(lib._lpm_layer_norm_act_mask_image_fwd(ptr(a), ptr(bias), 1 if relu else 0, ptr(mask), float(mask_scale), ptr(r), ptr(gamma),
-                                                             ptr(beta), B, L, F, LN_EPS, ptr(y), y.stride(0), ptr(y3), ptr(z), ptr(stats),
-                                                             ptr(ws), wsb, stream_ptr()), "lpm_layer_norm_act_mask_image_fwd")
+            lib.check(lib._lpm_layer_norm_act_mask_image_fwd_fmt(ptr(a), ptr(bias), 1 if relu else 0, ptr(mask), float(mask_scale), ptr(r), ptr(gamma),
+                                                                 ptr(beta), B, L, F, LN_EPS, ptr(y), y.stride(0), ptr(y3), ptr(z), ptr(stats),
+                                                                 ptr(ws), wsb, site.fmt if site is not None else None, stream_ptr()),
+                      "lpm_layer_norm_act_mask_image_fwd")
         elif image:
             lib.check(lib._lpm_layer_norm_act_image_fwd_fmt(ptr(a), ptr(bias), 1 if relu else 0, ptr(r), ptr(r_scale), ptr(gamma), ptr(beta), B, L,
                                                             F, LN_EPS, ptr(y), y.stride(0), ptr(y3), ptr(z) if z is not a else None, ptr(stats),
@@ -2473,11 +2485,12 @@ class _ResidualLayerNorm(torch.autograd.Function):
         return first, (dz if ctx.has_r else None), dgamma, dbeta, dbias, None, None, None, None, None, None, None
 
 
-def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False, image=False, mask=None, mask_scale=1.0):
+def residual_layer_norm(a, r, gamma, beta, bias=None, relu=False, image=False, mask=None, mask_scale=1.0, next_kernel=None):
     """layer_norm(act(a + bias) + r) with TF1 joint moments; a, r: [B, L, F]; act = relu when ``relu`` (needs ``bias``).
     image: the result ALSO leaves as the operand image of the dense layer that reads it next, attached as ``y._lpm_y3`` (ops.ffn_mod_x3
     takes it instead of splitting y again)."""
-    return _ResidualLayerNorm.apply(a, r, gamma, beta, bias, bool(relu), None, None, bool(image) and LN_IMAGE, mask, float(mask_scale))
+    site = _site("a", next_kernel) if (image and LN_IMAGE and next_kernel is not None) else None
+    return _ResidualLayerNorm.apply(a, r, gamma, beta, bias, bool(relu), None, None, bool(image) and LN_IMAGE, mask, float(mask_scale), site)
 
 
 # NetVladV2: tf.layers.dropout between output_transform and the layer norm rides in the layer norm's passes; "0": separate passes (A/B)

@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 
 from . import layers, modules, ops
+from . import variables as vs
 
 
 class MultiHeadAttention(modules.BaseModule):
@@ -97,6 +98,12 @@ class FeedForwardNetworkMod(modules.BaseModule):
         self.is_train = is_train
         self.scope_id = scope_id
         self.final_size = final_size
+
+    def first_kernel(self):
+        """The first dense layer's kernel if it exists already (never created here: variable creation order is the reference's) -- the
+        layer norm in front writes its operand image in the format of that layer's input site."""
+        with vs.variable_scope("filter_output{}".format(self.scope_id)):
+            return vs.peek_variable("kernel")
 
     def forward(self, inputs, **unused_params):
         # relu(dense) -> batch_norm twice (:741-760): the bias add and the ReLU of each dense layer ride in the batch norm's passes
@@ -206,7 +213,7 @@ class TransformerEncoderMod(modules.BaseModule):
                 image = bool(layers.use_split_gemm(attention, attention.numel() // attention.shape[-1], self.ff_network.filter_size)
                              and ops.ffn_mod_x3_ok(attention, self.ff_network.filter_size, self.ff_network.final_size))
                 attention = layers.layer_norm(attention, "LayerNorm", residual=inputs, bias=bias, image=image, mask=dropout_mask,
-                                              mask_scale=1.0 / (1.0 - rate))
+                                              mask_scale=1.0 / (1.0 - rate), next_kernel=self.ff_network.first_kernel())
                 return self.ff_network.forward(attention)
         else:
             attention = self.multi_head_attention.forward(inputs, inputs)
@@ -222,5 +229,6 @@ class TransformerEncoderMod(modules.BaseModule):
         image = bool(self.is_train and attention.dim() == 3
                      and layers.use_split_gemm(attention, attention.numel() // attention.shape[-1], self.ff_network.filter_size)
                      and ops.ffn_mod_x3_ok(attention, self.ff_network.filter_size, self.ff_network.final_size))
-        attention = layers.layer_norm(attention, "LayerNorm", residual=inputs, image=image)         # :451-454
+        attention = layers.layer_norm(attention, "LayerNorm", residual=inputs, image=image,
+                                      next_kernel=self.ff_network.first_kernel() if image else None)         # :451-454
         return self.ff_network.forward(attention)

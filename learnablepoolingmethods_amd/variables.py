@@ -170,6 +170,12 @@ def get_variable(name, shape, initializer, trainable=True, device=None):
     return _default.get_variable(name, shape, initializer, trainable, device)
 
 
+def peek_variable(name: str):
+    """The variable ``name`` under the current scope if it EXISTS already, else None -- never creates one (creation order is the
+    reference's: a layer that wants to know the kernel of the layer behind it must not create that kernel early)."""
+    return _default.vars.get(_default.full_name(name))
+
+
 def summary(name: str, tensor: torch.Tensor):
     """Record an intermediate tensor of the forward under ``name`` when the current store collects summaries."""
     if _default.summaries is not None:
