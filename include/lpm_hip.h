@@ -526,14 +526,16 @@ int lpm_split_weight_tiles_fmt(const float* w, int R, int N, int transposed, voi
 /* lpm_split_rows_tiles / lpm_image_row_tiles in either format (fp16x2 row tiles: fp16 (hi, lo) planes, same geometry). */
 int lpm_split_rows_tiles_fmt(const float* x, int64_t ldx, int B, int T, int C, void* out, const LpmOperandFormat* fmt, lpm_stream_t stream);
 int lpm_image_row_tiles_fmt(const void* img, int M, int K, int order, void* out, int kind, lpm_stream_t stream);
-/* lpm_dense_tiles_act_image_fwd / lpm_dense_tiles_relu_bwd_image in either format.  in_inv_scale: 1 / the scale the row tiles of the
- * data operand were written with (the accumulators are multiplied by it); `fmt`: the format of the image that leaves (and, for the
- * backward, `act_kind`: the format of the forward's activation image whose hi plane is the ReLU mask).  dbias: column sums of the
- * UN-scaled masked gradient. */
-int lpm_dense_tiles_act_image_fwd_fmt(const void* xr, const void* wt, const float* bias, int M, int Kd, int N, float in_inv_scale,
-                                      void* out_img, const LpmOperandFormat* fmt, lpm_stream_t stream);
-int lpm_dense_tiles_relu_bwd_image_fmt(const void* dyr, const void* wtt, const void* act_img, int act_kind, int M, int Kd, int N,
-                                       float in_inv_scale, void* out_img, float* dbias, void* workspace, size_t workspace_bytes,
+/* lpm_dense_tiles_act_image_fwd / lpm_dense_tiles_relu_bwd_image in either format.  The data operand: row tiles (x_image_kind /
+ * dy_image_kind < 0, lpm_split_rows_tiles_fmt / lpm_image_row_tiles_fmt) or -- no extra pass -- the operand IMAGE itself of that kind
+ * ([M][planes Kd]: an activation image for the forward, a gradient image for the backward), gathered row by row by the kernel's
+ * LDS-DMA loads.  in_inv_scale: 1 / the scale the data operand was written with (the accumulators are multiplied by it); `fmt`: the
+ * format of the image that leaves (and, for the backward, `act_kind`: the format of the forward's activation image whose hi plane
+ * is the ReLU mask).  dbias: column sums of the UN-scaled masked gradient. */
+int lpm_dense_tiles_act_image_fwd_fmt(const void* xr, int x_image_kind, const void* wt, const float* bias, int M, int Kd, int N,
+                                      float in_inv_scale, void* out_img, const LpmOperandFormat* fmt, lpm_stream_t stream);
+int lpm_dense_tiles_relu_bwd_image_fmt(const void* dyr, int dy_image_kind, const void* wtt, const void* act_img, int act_kind, int M, int Kd,
+                                       int N, float in_inv_scale, void* out_img, float* dbias, void* workspace, size_t workspace_bytes,
                                        const LpmOperandFormat* fmt, lpm_stream_t stream);
 /* lpm_layer_norm_act_image_fwd / lpm_layer_norm_act_bwd with the image (y_img / da_image) in either format. */
 int lpm_layer_norm_act_image_fwd_fmt(const float* a, const float* bias, int relu, const float* r, const float* r_scale, const float* gamma,

@@ -174,8 +174,8 @@ SIGNATURES = {
     "lpm_split_weight_tiles_fmt": (_i, [_f, _i, _i, _i, _f, _i, _f]),
     "lpm_split_rows_tiles_fmt": (_i, [_f, _l, _i, _i, _i, _f, _f, _f]),
     "lpm_image_row_tiles_fmt": (_i, [_f, _i, _i, _i, _f, _i, _f]),
-    "lpm_dense_tiles_act_image_fwd_fmt": (_i, [_f, _f, _f, _i, _i, _i, _fl, _f, _f, _f]),
-    "lpm_dense_tiles_relu_bwd_image_fmt": (_i, [_f, _f, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _s, _f, _f]),
+    "lpm_dense_tiles_act_image_fwd_fmt": (_i, [_f, _i, _f, _f, _i, _i, _i, _fl, _f, _f, _f]),
+    "lpm_dense_tiles_relu_bwd_image_fmt": (_i, [_f, _i, _f, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _s, _f, _f]),
     "lpm_layer_norm_act_image_fwd_fmt": (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _f, _s, _f, _f]),
     "lpm_layer_norm_act_mask_image_fwd_fmt": (_i, [_f, _f, _i, _f, _fl, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _f, _s, _f, _f]),
     "lpm_layer_norm_act_bwd_fmt": (_i, [_f, _l, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _s, _f, _f]),

@@ -70,6 +70,11 @@ struct TileGemmArgs {
     int64_t a_tile, a_step, a_batch;
     int64_t b_tile, b_step, b_batch;
     int a_tiles, b_tiles;      // valid tile counts per batch (indices beyond are clamped; their results are masked)
+    // round 5, 128- / 256-row forms: A straight from an operand IMAGE [rows][planes K] (split_gemm.hip) instead of row tiles -- an LDS-DMA
+    // load takes one global address per lane, so lane (row l31, reduction half) fetches its 16 bytes of row 32 tile + l31 itself:
+    // a_img_row = the image's row stride in 16-byte units (0: row tiles), a_img_lo = the lo plane's offset in the same units; the
+    // launcher sets a_tile = 32 a_img_row and a_step = 2.  The row-tile copy of the tensor (a pass of its own) is not made.
+    int a_img_row, a_img_lo;
     // optional second operand pair, reduced after the first into the same accumulators (C = A.B + A2.B2; splits == 1):
     const uint4* a2;
     const uint4* b2;

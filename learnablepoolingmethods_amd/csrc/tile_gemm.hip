@@ -84,6 +84,9 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                 const int t = min(rb * 2 + (p >> 1), g.a_tiles - 1);
                 src[j] = g.a + batch * g.a_batch + t * g.a_tile + step0 * g.a_step + pl + lane;
                 src2[j] = PL == 2 ? g.a2 + batch * g.a2_batch + t * g.a2_tile + pl + lane : nullptr;
+            } else if (g.a_img_row) {          // A from an operand image: this lane's row, its 16-byte half of the step
+                src[j] = g.a + ((int64_t)(lid * RTW * MW + (p >> 1)) * 32 + l31) * g.a_img_row + step0 * g.a_step + (p & 1) * g.a_img_lo + (lane >> 5);
+                src2[j] = nullptr;
             } else {
                 src[j] = g.a + (int64_t)(lid * RTW * MW + (p >> 1)) * g.a_tile + step0 * g.a_step + pl + lane;
                 src2[j] = nullptr;
@@ -1231,9 +1234,17 @@ extern "C" int lpm_dense_tiles_fwd(const void* xr, const void* wt, int M, int Kd
 extern "C" int lpm_dense_tiles_supported(int M, int Kd, int N) {
     return (M > 0 && M % 256 == 0 && Kd >= 256 && Kd % 16 == 0 && N > 0 && N % 256 == 0) ? 1 : 0;
 }
-static void dense_tiles_args(lpm::TileGemmArgs& g, const void* ar, const void* bt, int M, int Kd, int N) {
+// a_kind < 0: `ar` holds row tiles; else an operand image of that kind [M][planes Kd] read in place (order: the three-plane image's plane
+// order -- 0 activation [hi | lo | hi], 1 gradient [hi | hi | lo])
+static void dense_tiles_args(lpm::TileGemmArgs& g, const void* ar, const void* bt, int M, int Kd, int N, int a_kind = -1, int a_order = 0) {
     const int MT = lpm::row_tiles_per_clip(M), DS = Kd / 16, NT = N / 32;
     g.a = (const uint4*)ar; g.a_tile = (int64_t)DS * 128; g.a_step = 128; g.a_batch = (int64_t)MT * DS * 128; g.a_tiles = MT;
+    if (a_kind >= 0) {
+        const int planes = lpm::operand_kind_planes(a_kind);
+        g.a_img_row = planes * Kd / 8;
+        g.a_img_lo = ((planes == 3 && a_order) ? 2 * Kd : Kd) / 8;
+        g.a_tile = (int64_t)32 * g.a_img_row; g.a_step = 2; g.a_batch = (int64_t)MT * g.a_tile;
+    }
     g.b = (const uint4*)bt; g.b_tile = 128; g.b_step = (int64_t)NT * 128; g.b_batch = 0; g.b_tiles = NT;
     g.rb_per_batch = MT / 2; g.steps_per_split = DS; g.total_steps = DS;
     g.rows_valid = M; g.cols_valid = N;
@@ -1241,7 +1252,7 @@ static void dense_tiles_args(lpm::TileGemmArgs& g, const void* ar, const void* b
 // out3 [M, 3N] bf16 = the activation image [hi | lo | hi] of relu(x . w + bias); xr: row tiles of x [M, Kd], wt: weight tiles of w [Kd, N]
 extern "C" int lpm_dense_tiles_act_image_fwd(const void* xr, const void* wt, const float* bias, int M, int Kd, int N, void* out3,
                                              lpm_stream_t stream) {
-    return lpm_dense_tiles_act_image_fwd_fmt(xr, wt, bias, M, Kd, N, 1.f, out3, nullptr, stream);
+    return lpm_dense_tiles_act_image_fwd_fmt(xr, -1, wt, bias, M, Kd, N, 1.f, out3, nullptr, stream);
 }
 // one_plane_b: the weight operand as fp16 hi-plane tiles of 64 units (the two-term product of the backward)
 static void dense_tiles_fmt(lpm::TileGemmArgs& g, const LpmOperandFormat* fmt, float in_inv_scale, int N, bool one_plane_b) {
@@ -1252,17 +1263,19 @@ static void dense_tiles_fmt(lpm::TileGemmArgs& g, const LpmOperandFormat* fmt, f
         g.b_tile = 64; g.b_step = (int64_t)NT * 64;
     }
 }
-extern "C" int lpm_dense_tiles_act_image_fwd_fmt(const void* xr, const void* wt, const float* bias, int M, int Kd, int N, float in_inv_scale,
-                                                 void* out3, const LpmOperandFormat* fmt, lpm_stream_t stream) {
+extern "C" int lpm_dense_tiles_act_image_fwd_fmt(const void* xr, int x_image_kind, const void* wt, const float* bias, int M, int Kd, int N,
+                                                 float in_inv_scale, void* out3, const LpmOperandFormat* fmt, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(xr && wt && bias && out3, LPM_ERR_BADARG, "lpm_dense_tiles_act_image_fwd: null pointer");
+    LPM_REQUIRE(x_image_kind < 0 || (operand_kind_ok(x_image_kind) && Kd % 8 == 0 && ((uintptr_t)xr & 15) == 0), LPM_ERR_BADARG,
+                "lpm_dense_tiles_act_image_fwd: bad operand image (kind %d)", x_image_kind);
     if (const int rc = operand_fmt_check(fmt, "lpm_dense_tiles_act_image_fwd")) return rc;
     LPM_REQUIRE(in_inv_scale > 0.f, LPM_ERR_BADARG, "lpm_dense_tiles_act_image_fwd: in_inv_scale must be positive");
     LPM_REQUIRE(lpm_dense_tiles_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
                 "lpm_dense_tiles_act_image_fwd: need M %% 256 == 0, Kd %% 16 == 0, Kd >= 256, N %% 256 == 0 (M=%d Kd=%d N=%d)", M, Kd, N);
     LPM_REQUIRE(((uintptr_t)bias & 15) == 0, LPM_ERR_BADARG, "lpm_dense_tiles_act_image_fwd: bias must be 16-byte aligned");
     TileGemmArgs g{};
-    dense_tiles_args(g, xr, wt, M, Kd, N);
+    dense_tiles_args(g, xr, wt, M, Kd, N, x_image_kind, 0);
     g.img = (unsigned short*)out3; g.img_kind = 1; g.img_bias = bias;
     dense_tiles_fmt(g, fmt, in_inv_scale, N, false);      // forward: three terms, the weight tiles carry (hi, lo) like the row tiles
     return tile_gemm_image(g, (hipStream_t)stream, "lpm_dense_tiles_act_image_fwd", g.img_f16 ? 4 : 2);
@@ -1273,13 +1286,15 @@ extern "C" size_t lpm_dense_tiles_relu_bwd_workspace_bytes(int M, int N) { retur
 // act3 [M, 3N]: the forward's activation image (lpm_dense_tiles_act_image_fwd's output).
 extern "C" int lpm_dense_tiles_relu_bwd_image(const void* dyr, const void* wtt, const void* act3, int M, int Kd, int N, void* out3,
                                               float* dbias, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
-    return lpm_dense_tiles_relu_bwd_image_fmt(dyr, wtt, act3, LPM_OPERAND_BF16X3, M, Kd, N, 1.f, out3, dbias, workspace, workspace_bytes, nullptr, stream);
+    return lpm_dense_tiles_relu_bwd_image_fmt(dyr, -1, wtt, act3, LPM_OPERAND_BF16X3, M, Kd, N, 1.f, out3, dbias, workspace, workspace_bytes, nullptr, stream);
 }
-extern "C" int lpm_dense_tiles_relu_bwd_image_fmt(const void* dyr, const void* wtt, const void* act3, int act_kind, int M, int Kd, int N,
-                                                  float in_inv_scale, void* out3, float* dbias, void* workspace, size_t workspace_bytes,
+extern "C" int lpm_dense_tiles_relu_bwd_image_fmt(const void* dyr, int dy_image_kind, const void* wtt, const void* act3, int act_kind, int M, int Kd,
+                                                  int N, float in_inv_scale, void* out3, float* dbias, void* workspace, size_t workspace_bytes,
                                                   const LpmOperandFormat* fmt, lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(dyr && wtt && act3 && out3 && dbias && workspace, LPM_ERR_BADARG, "lpm_dense_tiles_relu_bwd_image: null pointer");
+    LPM_REQUIRE(dy_image_kind < 0 || (operand_kind_ok(dy_image_kind) && Kd % 8 == 0 && ((uintptr_t)dyr & 15) == 0), LPM_ERR_BADARG,
+                "lpm_dense_tiles_relu_bwd_image: bad operand image (kind %d)", dy_image_kind);
     if (const int rc = operand_fmt_check(fmt, "lpm_dense_tiles_relu_bwd_image")) return rc;
     LPM_REQUIRE(in_inv_scale > 0.f && operand_kind_ok(act_kind), LPM_ERR_BADARG, "lpm_dense_tiles_relu_bwd_image: bad in_inv_scale / act_kind");
     LPM_REQUIRE(lpm_dense_tiles_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
@@ -1288,7 +1303,7 @@ extern "C" int lpm_dense_tiles_relu_bwd_image_fmt(const void* dyr, const void* w
                 "lpm_dense_tiles_relu_bwd_image: workspace too small");
     LPM_REQUIRE(((uintptr_t)act3 & 15) == 0, LPM_ERR_BADARG, "lpm_dense_tiles_relu_bwd_image: act3 must be 16-byte aligned");
     TileGemmArgs g{};
-    dense_tiles_args(g, dyr, wtt, M, Kd, N);
+    dense_tiles_args(g, dyr, wtt, M, Kd, N, dy_image_kind, 1);
     g.img = (unsigned short*)out3; g.img_kind = 2; g.img_mask = (const unsigned short*)act3; g.img_colpart = (float*)workspace;
     dense_tiles_fmt(g, fmt, in_inv_scale, N, true);       // backward: two terms against hi-plane weight tiles
     g.mask_planes = operand_kind_planes(act_kind);

@@ -1670,6 +1670,9 @@ def _dw_x3(x3, dy3, K, N, outs=None, sa=None, sg=None):
     return res
 
 
+# FeedForwardNetwork's tile GEMMs read their data operand straight from its operand image (per-lane LDS-DMA gather) instead of from a
+# row-tile copy made by a pass of its own (lpm_split_rows_tiles / lpm_image_row_tiles: 96 + 38 us per cfg-2 step); "0": the copies (A/B)
+TILE_GEMM_FROM_IMAGE = os.environ.get("LPM_TILE_GEMM_FROM_IMAGE", "1") != "0"
 # terms of the fp16 weight-gradient product: 2 = xh^T [dyh | dyl] (the gradient exact, the activation rounded once: 1.4e-4 per GEMM);
 # 1 = xh^T dyh (both rounded once: 2e-4 per GEMM -- an error that stays in THIS weight's gradient and is not carried further down the
 # backward, unlike an input gradient's).  LPM_DW_TERMS, A/B; measured in tests/test_gpu_fp16x2.py
@@ -1790,12 +1793,16 @@ class _FFNX3(torch.autograd.Function):
             # the first dense layer on the hand-written 256-row tile GEMM with the bias + ReLU + operand split in its epilogue: the
             # [M, 4F] pre-activation never exists in fp32 (335 MB written + read at cfg-2), no separate split pass
             st = stream_ptr()
-            yr = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, F), y2d)
-            lib.check(lib._lpm_split_rows_tiles_fmt(ptr(y2d), y2d.stride(0), 1, M, F, ptr(yr), s1.fmt if s1 is not None else None, st),
-                      "lpm_split_rows_tiles")
+            akind = _capi.LPM_OPERAND_FP16X3 if f16 else _capi.LPM_OPERAND_BF16X3
+            if TILE_GEMM_FROM_IMAGE:     # the kernel gathers its A fragments from the image y3 row by row: no row-tile copy of y
+                yr, ykind = y3, akind
+            else:
+                yr, ykind = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, F), y2d), -1
+                lib.check(lib._lpm_split_rows_tiles_fmt(ptr(y2d), y2d.stride(0), 1, M, F, ptr(yr), s1.fmt if s1 is not None else None, st),
+                          "lpm_split_rows_tiles")
             w1t = _weight_tiles(W1, F, H, False, y2d, f16=f16)
             f3 = torch.empty((M, 3 * H), dtype=dt, device=y2d.device)
-            lib.check(lib._lpm_dense_tiles_act_image_fwd_fmt(ptr(yr), ptr(w1t), ptr(b1.contiguous()), M, F, H, a1, ptr(f3),
+            lib.check(lib._lpm_dense_tiles_act_image_fwd_fmt(ptr(yr), ykind, ptr(w1t), ptr(b1.contiguous()), M, F, H, a1, ptr(f3),
                                                              s2.fmt if s2 is not None else None, st), "lpm_dense_tiles_act_image_fwd")
             w23n, _ = _split_weight(W2, need_t=False, f16=f16)
             ctx.save_for_backward(y3, f3, w13k, W2)
@@ -1833,12 +1840,15 @@ class _FFNX3(torch.autograd.Function):
             # split of the result in its epilogue: df never exists in fp32
             st = stream_ptr()
             W2 = w23k                                                     # (saved in its place: the fp32 weight [H, N])
-            dor = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), f3)
-            lib.check(lib._lpm_image_row_tiles_fmt(ptr(do3), M, N, 1, ptr(dor), gkind, st), "lpm_image_row_tiles")
+            if TILE_GEMM_FROM_IMAGE:
+                dor, dkind = do3, gkind
+            else:
+                dor, dkind = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), f3), -1
+                lib.check(lib._lpm_image_row_tiles_fmt(ptr(do3), M, N, 1, ptr(dor), gkind, st), "lpm_image_row_tiles")
             w2tt = _weight_tiles(W2, N, H, True, f3, f16=f16)
             wsb = lib._lpm_dense_tiles_relu_bwd_workspace_bytes(M, H)
             ws = torch.empty(wsb // 4, dtype=torch.float32, device=f3.device)
-            lib.check(lib._lpm_dense_tiles_relu_bwd_image_fmt(ptr(dor), ptr(w2tt), ptr(f3), akind, M, N, H, a2, ptr(dp3), ptr(db1), ptr(ws), wsb,
+            lib.check(lib._lpm_dense_tiles_relu_bwd_image_fmt(ptr(dor), dkind, ptr(w2tt), ptr(f3), akind, M, N, H, a2, ptr(dp3), ptr(db1), ptr(ws), wsb,
                                                               g1.fmt if g1 is not None else None, st), "lpm_dense_tiles_relu_bwd_image")
         else:
             df = _mm3(do3, w23k)                                          # [M, H]  (un-scaled: alpha rides in the split pass below)

@@ -37,6 +37,7 @@ tr.step(raw, nf, labels)                              # builds; the state after 
 torch.cuda.synchronize()
 # NetVladV1: the repeated step runs its encoder GEMMs on fp16 planes with scales measured on this batch (ops.OperandScales: a run's scales
 # are a function of the maxima of earlier steps only -- here every repetition sees the same ones)
+torch.manual_seed(11)                                 # (the calibration pass draws the dropout masks of the repeated step: same maxima, same scales)
 if tr.calibrate_operand_scales(raw, nf, labels):
     print(f"operand scales calibrated: {len(tr.operand_scales.slots)} sites", flush=True)
 a = tr.arena
