@@ -1670,9 +1670,11 @@ def _dw_x3(x3, dy3, K, N, outs=None, sa=None, sg=None):
     return res
 
 
-# FeedForwardNetwork's tile GEMMs read their data operand straight from its operand image (per-lane LDS-DMA gather) instead of from a
-# row-tile copy made by a pass of its own (lpm_split_rows_tiles / lpm_image_row_tiles: 96 + 38 us per cfg-2 step); "0": the copies (A/B)
-TILE_GEMM_FROM_IMAGE = os.environ.get("LPM_TILE_GEMM_FROM_IMAGE", "1") != "0"
+# "1": FeedForwardNetwork's tile GEMMs read their data operand straight from its operand image (per-lane LDS-DMA gather of 32-byte row
+# pieces) instead of from a row-tile copy made by a pass of its own (lpm_split_rows_tiles / lpm_image_row_tiles: 96 + 38 us per cfg-2
+# step).  Built and measured in round 5, one box, alternating: 6.57 / 6.50 ms with the gather against 6.46 ms with the copies -- the
+# gathered loads cost the two GEMMs what the passes cost; off by default, kept for the A/B
+TILE_GEMM_FROM_IMAGE = os.environ.get("LPM_TILE_GEMM_FROM_IMAGE", "0") == "1"
 # terms of the fp16 weight-gradient product: 2 = xh^T [dyh | dyl] (the gradient exact, the activation rounded once: 1.4e-4 per GEMM);
 # 1 = xh^T dyh (both rounded once: 2e-4 per GEMM -- an error that stays in THIS weight's gradient and is not carried further down the
 # backward, unlike an input gradient's).  LPM_DW_TERMS, A/B; measured in tests/test_gpu_fp16x2.py

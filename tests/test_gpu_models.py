@@ -199,7 +199,9 @@ def _full_size_compare(name, cfg, B, seed, dev, scale_hidden1=True, dropout_mask
         # (per model, not per variable: an error made in one stream's ill-conditioned batch norms reaches the other stream's gradients
         # through hidden1_bn's batch statistics)
         for e, n in over:
-            assert e <= max(grad_tol, 3.0 * yworst[0]), (f"gradient {n}: {e:.3e} > 1e-3 and > 3 x the fp32 oracle's own worst distance from "
+            # (2 x since round 5 -- 3 x before: test_cfg3_untouched_initialisation_family_by_family shows NetVladV2, the only model that
+            # needs the allowance, at 1.28 x with its dense GEMMs on fp16 planes and at 1.00 x with the logits_bn attention in exact fp32)
+            assert e <= max(grad_tol, 2.0 * yworst[0]), (f"gradient {n}: {e:.3e} > 1e-3 and > 2 x the fp32 oracle's own worst distance from "
                                                           f"fp64 on this model ({yworst[0]:.3e}, {yworst[1]})")
     print(f"[{name} B={B}] intermediates {({k: f'{v:.1e}' for k, v in errs.items()})}; worst gradient {worst[0]:.2e} ({worst[1]}); "
           f"ReLU units moved {({k.split('/')[-2]: v[0] for k, v in report.items()})}")
@@ -229,7 +231,7 @@ def test_untouched_reference_initialisation(which):
     """one case per single-GPU model at the reference's initialisation AS IT IS -- no ReLU-margin preparation of
     the biases (oracle/test_weights.separate_relu_units), no 0.02 scale on hidden1_weights -- at the BASELINE layer sizes: forward
     intermediates, loss and predictions at 1e-3 in max-norm; the gradient of every variable within 1e-3 in Frobenius norm OR within
-    three times the worst distance between the oracle's own fp32 and fp64 evaluations of the model's gradients (a freshly initialised model is
+    twice the worst distance between the oracle's own fp32 and fp64 evaluations of the model's gradients (a freshly initialised model is
     saturated and ill-conditioned: two correct fp32 evaluations differ by more than 1e-3 there, NetVladV2's batch norms most of all),
     with the variables above 1e-3 and the number of ReLU units whose fp64 pre-activation lies within fp32 rounding of zero (the
     units the engineered margins of the other tests move away) printed: the margins are a measured, bounded effect, not a precondition
@@ -252,6 +254,43 @@ def test_untouched_reference_initialisation(which):
             _full_size_compare("NetVladV1", cfg, 8, 14, dev, scale_hidden1=False, prepare_relu=False, encoder=False)
         finally:
             FLAGS.reset()
+
+
+def test_cfg3_untouched_initialisation_family_by_family(monkeypatch):
+    """what costs NetVladV2 its factor over the fp32 oracle at the untouched initialisation?  The same case as
+    test_untouched_reference_initialisation[cfg3] with each kernel family switched to its most exact form in turn -- the dense GEMMs as
+    plain fp32 library GEMMs, the logits_bn attention in exact fp32 MFMA, the pooling (K2 / K3) in exact fp32 MFMA, the dense GEMMs on
+    split-bf16 instead of fp16 planes -- and the worst gradient (Frobenius, at-risk ReLU columns left out) printed per setting.  The
+    table goes into DESIGN.md section 2; the assertion is the tightened bound: every setting within 2 x the fp32 oracle's own worst
+    distance from fp64 (3 x until round 4)."""
+    from learnablepoolingmethods_amd import FLAGS, ops
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV2", iterations=300, cluster_size=256, hidden_size=512, base_learning_rate=2e-4)
+    B = 8
+    g = torch.Generator().manual_seed(15)
+    masks = {"video": (torch.rand(B, 300, 1024, generator=g) >= 0.9).float(), "audio": (torch.rand(B, 300, 128, generator=g) >= 0.9).float()}
+    settings = [("default (dense on fp16 planes, attention mixed, pooling split-bf16)", {}),
+                ("dense GEMMs on split-bf16", {"env": {"LPM_V2_FP16": "0"}}),
+                ("dense GEMMs in fp32 (library)", {"flags": {"dense_precision": "f32"}}),
+                ("logits_bn attention in exact fp32", {"ops": {"MHA_BN_PRECISION": "f32"}}),
+                ("pooling K2 / K3 in exact fp32", {"ops": {"VLAD_PRECISION": "f32"}})]
+    rows = []
+    for name, sw in settings:
+        with monkeypatch.context() as m:
+            for k, v in sw.get("env", {}).items():
+                m.setenv(k, v)
+            for k, v in sw.get("ops", {}).items():
+                m.setattr(ops, k, v)
+            try:
+                for k, v in sw.get("flags", {}).items():
+                    setattr(FLAGS, k, v)
+                _, worst = _full_size_compare("NetVladV2", cfg, B, 13, dev, scale_hidden1=False, prepare_relu=False, dropout_masks=masks)
+            finally:
+                FLAGS.reset()
+        rows.append((name, worst))
+    print("[cfg3 untouched initialisation, family by family] worst gradient (relative L2 to the fp64 oracle; the fp32 oracle's own worst is printed above):")
+    for name, (e, n) in rows:
+        print(f"    {name}: {e:.2e} ({n})")
 
 
 def test_cfg3_layer_sizes_reduced_batch():
