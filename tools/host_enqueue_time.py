@@ -33,3 +33,14 @@ host.sort()
 print(f"{cfg}: host time per step call median {host[N // 2] * 1e3:.2f} ms (min {host[0] * 1e3:.2f}, max {host[-1] * 1e3:.2f}; first four "
       f"{[round(h * 1e3, 2) for h in first]}); all {N} calls returned after {t_enq * 1e3:.1f} ms, the GPU finished after {t_all * 1e3:.1f} ms "
       f"= {t_all / N * 1e3:.2f} ms per step")
+
+# ... and with the queue EMPTY at every call (synchronise first): the call's own cost, nothing blocking it
+alone = []
+for _ in range(20):
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    trainer.step(raw, nf, labels)
+    alone.append(time.perf_counter() - a)
+torch.cuda.synchronize()
+alone.sort()
+print(f"{cfg}: host time of a step call into an empty queue: median {alone[10] * 1e3:.2f} ms (min {alone[0] * 1e3:.2f}, max {alone[-1] * 1e3:.2f})")
