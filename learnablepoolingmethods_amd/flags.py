@@ -81,6 +81,9 @@ FLAGS.define("clip_gradient_norm", 1.0, ":108")
 FLAGS.define("hidden1_factored_update", True, "build extension: the GPU trainer consumes hidden1_weights' gradient as the product "
              "descriptors^T . d(activation) it is (lpm_factored_clip_adam): the gradient is never written, the towers all-gather its "
              "two skinny factors instead of all-reducing it.  False: the generic path (gradient written into the arena)")
+FLAGS.define("hidden1_early_update", True, "build extension, one tower with the factored update: clip + Adam of hidden1_weights run inside backward, "
+             "right behind the projection's input gradient (the clip is per variable, utils.py:181-188: it needs only this variable's "
+             "gradient factors), where the main queue would otherwise idle while the host enqueues the audio encoder's backward")
 FLAGS.define("direct_weight_gradients", True, "build extension: single-GPU training writes the encoders' dense-kernel gradients straight "
              "into the gradient arena from their producers (ops._dw_x3) instead of through autograd's .grad + a gather copy")
 FLAGS.define("hidden1_factored_max_towers", 4, "build extension: ... up to this many towers.  Both passes of the factored update multiply "

@@ -671,6 +671,14 @@ class Trainer:
         if fg is not None:
             fg.clear()
             fg.armed = True
+        # One tower: hidden1_weights is updated INSIDE backward, right behind the projection's input gradient -- its clip is per
+        # variable (utils.py:181-188) and needs only the two factors the projection's backward has just handed over, and nothing reads
+        # the old weight after dx.  The 0.58 ms update pass then fills the stretch in which the host is still enqueueing the ~80 small
+        # launches of the audio encoder's backward and the main queue would run nothing (0.35-0.6 ms per cfg-2 step, tools/step_gaps.py).
+        self._early = None
+        if fg is not None and not self.sync.active and FLAGS.hidden1_early_update:
+            lr0 = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers, self.lr_decay_examples, self.lr_decay)
+            self._early = {"lr": lr0, "step": self.global_step + 1, "done": False}
         try:
             final_loss.backward()                                                               # :322-323
         finally:
@@ -704,8 +712,13 @@ class Trainer:
             if len(a.names) > 1:
                 self._tail_scratch = ops.clip_adam_step(a.param[n1:], a.grad[n1:], a.m[n1:], a.v[n1:], self._tail_offsets,
                                                         len(a.names) - 1, self.clip, lr, self.global_step, scratch=self._tail_scratch)
-            self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, lr, self.global_step,
-                                                  scratch=self._factored_scratch)               # :332-336 for hidden1_weights
+            early = self._early
+            if early is not None and early["done"]:
+                assert early["lr"] == lr and early["step"] == self.global_step     # (the update ran inside backward with these)
+            else:
+                self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, lr, self.global_step,
+                                                      scratch=self._factored_scratch)           # :332-336 for hidden1_weights
+            self._early = None
         else:
             self.arena._scratch = ops.clip_adam_step(self.arena.param, self.arena.grad, self.arena.m, self.arena.v,
                                                      self.arena.offsets, len(self.arena.names), self.clip, lr,
@@ -729,6 +742,7 @@ class Trainer:
         before = {n: v.clone() for n, v in self.store.vars.items() if not self.store.trainable[n]}
         self.arena.zero_grad()
         model_input = self._normalize_input(model_input_raw, num_frames)
+        self._early = None                       # (no optimiser work inside this backward)
         was = sc.enabled
         sc.enabled = False                       # this pass runs in split-bf16 whatever is known so far
         sc.begin_step()
@@ -786,6 +800,13 @@ class Trainer:
         the factors of the summed gradient (utils.combine_gradients) -- and bucket 0 has nothing left to all-reduce."""
         self._factored_work = []
         if not self.sync.active:
+            early = getattr(self, "_early", None)
+            if early is not None and not early["done"]:
+                a = self.arena
+                k = a.views[a.names[0]].numel()
+                self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, early["lr"], early["step"],
+                                                      scratch=self._factored_scratch)           # :332-336 for hidden1_weights, early
+                early["done"] = True
             return
         n = dist.get_world_size(self.group)
         xt_all = torch.empty(n * fg.xt.numel(), dtype=fg.xt.dtype, device=fg.xt.device)
