@@ -22,7 +22,9 @@ ARCH = "gfx950"
 # cent in ~3 % of training steps when a second process shared the GPU -- same inputs, the same call repeated at once correct, scalar
 # v_fmac_f32 never wrong in 440 steps.  (The host pass does not know the feature and says so: filtered below.)
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", *NO_PACKED_FP32]
+# LPM_EXTRA_HIPCC_FLAGS: experiment builds only (e.g. -DLPM_K1_WIDE_EXPERIMENTS for tools/k1_bf16_loop.py); part of the build digest
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", *NO_PACKED_FP32,
+         *os.environ.get("LPM_EXTRA_HIPCC_FLAGS", "").split()]
 # per-file extras.  mha_x3: keep the small 16x16 MFMA accumulators in VGPRs (the AGPR form costs a v_accvgpr_read per
 # score in a VALU-bound kernel).
 EXTRA_FLAGS = {"mha_x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}

@@ -301,6 +301,307 @@ __global__ __launch_bounds__(512, 1) void assign_flat_kernel(const AssignFlatArg
         a.stats[(int64_t)r * 2 * a.K + (tid >> 8) * a.K + cb * 256 + (tid & 255)] = 0.f;
 }
 
+// ---- plain-bf16 K1 on 160-row x 512-column workgroups: one round of the chip (round 5; BASELINE configs[4]) -------------------------
+// The flat form above gives every wave ONE column tile and the group's three row tiles: per double step the eight waves read the same
+// 6 KB of A fragments out of LDS -- 48 KB = 384 LDS cycles against 386 matrix-pipe cycles, with 22 KB through the vector L1 on top
+// (352 cycles at 64 B / clk): three resources within 10 % of each other, and 800 workgroups are 3.1 rounds of 256 CUs (4 rounds at 78 %).
+// Measured 51 us = 0.31 of the bf16 peak at cfg-5 (38 400 x 1024 x 512).
+// Here a workgroup owns 160 rows x all 512 columns -- cfg-5 is 240 workgroups: ONE round at 94 % -- and wave w the column tiles
+// {2 w, 2 w + 1} x all five row tiles: per plain step (16 reduction elements) ten MFMAs (320 matrix-pipe cycles per wave, 640 per SIMD)
+// against five fragment reads per wave (40 KB = 320 LDS cycles per CU: half) and 2 KB of B per wave straight from L2 (16 + 5 KB per
+// step through the vector L1: 330 cycles: half); A leaves HBM once instead of once per column block.
+//   A: the per-clip row tiles gathered per lane by LDS-DMA (as above) into a ring of three 40 KB stages of eight plain steps; wave w
+//      loads the 1 KB piece of plain step w of the stage for each of the five row tiles: every wave issues the same five loads per
+//      stage, so ONE set of hand-counted vmcnt immediates serves the workgroup.  LDS layout [slot][plain step][row tile][lane].
+//   fragments: EIGHT registers for five tiles.  The 40 (step, tile) pairs of a stage take registers n mod 8 in turn; behind the two
+//      MFMAs of pair n the fragment of pair n + 5 (the same tile, next step) is read into register (n + 5) mod 8 -- the one pair n - 3
+//      used, six MFMAs back.  Five reads are always in flight and every pair waits with lgkmcnt(4).  (The first build had five
+//      registers and read the next fragment into the register the MFMA in front of it had just been given: with two waves queueing on a
+//      SIMD's matrix core that MFMA may not have started when the LDS answers -- every second column tile came out wrong once the
+//      timing shifted (seen when one DMA piece per stage was removed: odd column tiles wrong in every row tile, the fifth row tile
+//      intermittently; the same build with one more piece in flight passed every test).  A register is rewritten here only when three
+//      younger MFMA pairs of the same wave have been issued behind its last reader: the core takes a wave's MFMAs in order, so that
+//      reader started >= 5 x 32 cycles earlier.  tests/test_build_flags.py checks the register flow of the built loop.)
+//   stages: at the top of a stage's LAST step the wave drains its reads (lgkmcnt(0): that step's fragments are in registers), the
+//      barrier says the stage's slot is free and the next stage has landed for everyone, and the stage three ahead is requested.
+//   B: two 1 KB fragments per plain step straight into registers, eight steps ahead (L2: the 30 workgroups of an XCD walk B together).
+constexpr int AW_MT = 5, AW_ROWS = AW_MT * 32;
+constexpr int AW_STEP = AW_MT * 1024;      // A bytes per plain step
+constexpr int AW_KB = 8;                   // plain steps per stage (= waves: wave w loads step w's pieces)
+constexpr int AW_STAGE = AW_KB * AW_STEP;
+constexpr int AW_NS = 3, AW_DB = 4, AW_FR = 8;
+static_assert((AW_KB * AW_MT) % AW_FR == 0 && AW_FR >= AW_MT + 2, "the fragment registers rotate with the period of a stage");
+constexpr int AW_TAIL = 3 * AW_KB;         // the last three stages request no further stage
+// VMEM operations of step u (tail-relative; u < 0: steady state and the prologue's virtual steps), in issue order: the five pieces of
+// the stage three ahead at a stage's last step, the two B loads of step u + DB at its end
+constexpr int AW_DMA = AW_MT;             // DMA pieces per wave and stage
+__host__ __device__ constexpr int aw_ops(int u) { return ((af_mod(u, AW_KB) == AW_KB - 1 && u < 0) ? AW_DMA : 0) + (u + AW_DB < AW_TAIL ? 2 : 0); }
+// B(i) was the last thing step i - DB issued: it has landed when at most the operations of the steps in between are outstanding (and
+// with it everything older: the pieces the barrier promises were requested sixteen steps earlier)
+__host__ __device__ constexpr int aw_wait(int i) {
+    int w = 0;
+    for (int u = i - AW_DB + 1; u < i; ++u) w += aw_ops(u);
+    return w;
+}
+static_assert(AW_KB % AW_DB == 0 && AW_TAIL >= AW_DB, "B register sets by step within the stage");
+static_assert(aw_wait(-800) == (AW_DB - 1) * 2 + AW_DMA && aw_wait(-800 + AW_KB - 1) == (AW_DB - 1) * 2 &&
+              aw_wait(0) == (AW_DB - 1) * 2 + AW_DMA && aw_wait(AW_TAIL - 1) == 0, "steady-state and tail waits");
+
+// DBG (timing experiments, -DLPM_K1_WIDE_EXPERIMENTS builds only, LPM_K1_WIDE_DBG=n; results are garbage): 1 no epilogue, 2 no B fragment
+// loads, 4 no DMA, 8 no MFMAs, 16 no fragment reads, 64 no logits stores, 128 non-temporal logits stores
+template <int DBG>
+__global__ __launch_bounds__(512, 1) void assign_wide_kernel(const AssignFlatArgs a) {
+    constexpr int KB = AW_KB, NS = AW_NS, DB = AW_DB, TAIL = AW_TAIL, STAGE = AW_STAGE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wg = blockIdx.x, cb = blockIdx.y;
+    const int ct0 = cb * 16 + wave * 2;                            // this wave's two column tiles
+    const int nstage = a.DS / 4;                                   // a.DS = double steps; a stage = four of them
+
+    // a lane's source unit (16 bytes) in row tile m: row l31 of the tile, reduction half `half` (rows past the end: the last row again --
+    // masked in the epilogue).  Recomputed for every stage (five divisions per eight steps, beside 80 MFMAs): five registers this kernel
+    // does not have -- with them resident the compiler spilled, and a scratch reload inside the loop is a VMEM operation the hand-counted
+    // waits do not know.
+    auto a_unit = [&](int m, int wg_) -> unsigned {
+        const unsigned R = (unsigned)wg_ * AW_ROWS + m * 32 + l31;
+        const unsigned Rc = R < (unsigned)a.M ? R : (unsigned)a.M - 1u;
+        const unsigned b = Rc / (unsigned)a.T, t = Rc - b * (unsigned)a.T;
+        return (b * (unsigned)a.MT + (t >> 5)) * (unsigned)a.DS * 128u + (unsigned)half * 32u + (t & 31u);
+    };
+    const uint4* abase = a.xr + wave * 64;                         // plain step w of a stage: double step w >> 1, parity w & 1
+    const uint4* bbase = a.wt + (int64_t)ct0 * 64;                 // + plain step * NT * 64
+    const int64_t bstep = (int64_t)a.NT * 64;
+    const unsigned boff = (unsigned)lane * 16u;
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned rd_lane = smem_lds + (unsigned)lane * 16u;
+
+    tg_u32x4 fr[AW_FR];
+    tg_u32x4 fb[DB][2];
+    f32x16 acc[AW_MT][2];
+#pragma unroll
+    for (int m = 0; m < AW_MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
+
+    auto issue_stage = [&](int q, int slot) {
+        const uint4* src = abase + (int64_t)q * 512;
+        if (DBG & 4) return;
+        int wg_ = wg;
+        asm volatile("" : "+s"(wg_));                               // (not loop-invariant as far as the optimiser can tell)
+#pragma unroll
+        for (int m = 0; m < AW_MT; ++m)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + a_unit(m, wg_)),
+                                             (__attribute__((address_space(3))) void*)(smem + slot * STAGE + wave * AW_STEP + m * 1024), 16, 0, 0);
+    };
+    auto load_b = [&](int s, int j) {
+        const uint4* p = bbase + (int64_t)s * bstep;
+        if (DBG & 2) return;
+        // ("+v": the load lands in the register the step's MFMAs have just read -- L2 is a microsecond away -- and, the old value being
+        // alive up to here, the allocator cannot give that register to the fragment read in front of this load)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(fb[j][0]) : "v"(boff), "s"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(fb[j][1]) : "v"(boff), "s"(p) : "memory");
+    };
+#pragma unroll
+    for (int j = 0; j < DB; ++j) fb[j][0] = fb[j][1] = tg_u32x4{0u, 0u, 0u, 0u};
+
+    // prologue: the operations of the virtual steps -3 KB .. -1 in the loop's order: stages 0, 1, B(0 .. DB - 2), stage 2, B(DB - 1)
+    issue_stage(0, 0);
+    issue_stage(1, 1);
+#pragma unroll
+    for (int j = 0; j < DB - 1; ++j) load_b(j, j);
+    issue_stage(2, 2);
+    load_b(DB - 1, DB - 1);
+    af_wait_vm(2 * AW_DMA);                                        // stage 0's pieces have landed: at most two stages' worth is outstanding
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < AW_MT; ++m) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[m]) : "v"(rd_lane), "n"(m * 1024) : "memory");
+#pragma unroll
+    for (int m = AW_MT; m < AW_FR; ++m) fr[m] = tg_u32x4{0u, 0u, 0u, 0u};
+
+    int slot = 0;                                                  // (s / KB) % NS
+    // one plain step: i = its index in the tail (< 0: steady state, same residue mod KB), j = s % DB
+    auto step = [&](int s, int i, int j) __attribute__((always_inline)) {
+        const int e = af_mod(i, KB);
+        const bool last_of_stage = e == KB - 1, has_next = i + 1 < TAIL;
+        // (at a stage's last step at most ONE stage of pieces may be outstanding, whatever else is: the barrier's promise does not
+        // lean on fragment loads and DMA pieces retiring in one common order)
+        af_wait_vm(last_of_stage && aw_wait(i) > AW_DMA ? AW_DMA : aw_wait(i));
+        asm volatile("" : "+v"(fb[j][0]), "+v"(fb[j][1]) : : "memory");      // B(s) is in these registers from here on
+        const int nslot = slot + 1 == NS ? 0 : slot + 1;
+        if (last_of_stage) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[(e * AW_MT + 0) % AW_FR]), "+v"(fr[(e * AW_MT + 1) % AW_FR]), "+v"(fr[(e * AW_MT + 2) % AW_FR]),
+                         "+v"(fr[(e * AW_MT + 3) % AW_FR]), "+v"(fr[(e * AW_MT + 4) % AW_FR]) : : "memory");
+            __builtin_amdgcn_s_barrier();                          // this stage's slot is free, the next stage is in LDS for everyone
+            asm volatile("" ::: "memory");
+        }
+        // (the step's offset within the stage rides in the instruction's immediate: as part of the address the compiler kept eight
+        // loop-invariant sums in registers it did not have, spilled them, and put vmcnt(0) behind every reload)
+        const unsigned ad = rd_lane + (unsigned)((last_of_stage ? nslot : slot) * STAGE);
+#pragma unroll
+        for (int m = 0; m < AW_MT; ++m) {
+            tg_u32x4& fa = fr[(e * AW_MT + m) % AW_FR];              // this pair's fragment
+            tg_u32x4& fn = fr[(e * AW_MT + m + AW_MT) % AW_FR];      // the same tile of the next step: the register of three pairs ago
+            if (has_next || m == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa) : : "memory");
+            else if (m == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa) : : "memory");
+            else if (m == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa) : : "memory");
+            else if (m == 3) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa) : : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa) : : "memory");
+            if (!(DBG & 8)) acc[m][0] = tg_mfma(fb[j][0], fa, acc[m][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(DBG & 8)) acc[m][1] = tg_mfma(fb[j][1], fa, acc[m][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 0 && last_of_stage && i < 0) issue_stage(s / KB + NS, slot);
+            if (has_next && !(DBG & 16))
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fn) : "v"(ad), "n"((last_of_stage ? 0 : (e + 1) * AW_STEP) + m * 1024) : "memory");
+            // the fragment of two pairs ago stays ALIVE up to here: without this the register allocator hands the read above the
+            // register this pair's MFMAs have just been given (it knows of no hazard there) and the rotation is undone
+            asm volatile("" : : "v"(fr[(e * AW_MT + m + AW_FR - 2) % AW_FR]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (last_of_stage) slot = nslot;
+        if (i + DB < TAIL) load_b(s + DB, j);
+    };
+    const int nmain = (nstage - 3) * KB;
+    for (int s0 = 0; s0 < nmain; s0 += KB) {
+#pragma unroll
+        for (int e = 0; e < KB; ++e) step(s0 + e, -800 + e, e % DB);
+    }
+#pragma unroll
+    for (int i = 0; i < TAIL; ++i) step(nmain + i, i, i % DB);
+
+    if (DBG & 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int m = 0; m < AW_MT; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[m][c][r];
+        if (t == 12345.f) a.stats[0] = 0.f;
+        return;
+    }
+    // epilogue.  The MFMAs ran TRANSPOSED (srcA = the weight fragment, srcB = the frame fragment): acc[m][c][r] =
+    // logits[row wg * 160 + m * 32 + l31][column (ct0 + c) * 32 + 8 (r >> 2) + 4 half + (r & 3)] -- a lane holds four CONSECUTIVE
+    // columns of one row in four consecutive registers: 8-byte bf16 stores, 40 per wave.  (The first build had the rows in the
+    // registers: 160 two-byte stores per wave, 1 280 per CU at ~16 cycles of address processing each: 20 us of a 68 us kernel.)
+    unsigned short* lg = reinterpret_cast<unsigned short*>(a.logits);
+    float* sp = a.stats + (int64_t)wg * 2 * a.K;
+    bool row_ok[AW_MT];
+#pragma unroll
+    for (int m = 0; m < AW_MT; ++m) row_ok[m] = (int64_t)wg * AW_ROWS + m * 32 + l31 < a.M;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float cs[16], cq[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[r] = cq[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < AW_MT; ++m) {
+            const int64_t row = (int64_t)wg * AW_ROWS + m * 32 + l31;
+            unsigned short* dst = lg + row * a.K + (ct0 + c) * 32 + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const of_f2 v01 = {acc[m][c][4 * g + 0], acc[m][c][4 * g + 1]}, v23 = {acc[m][c][4 * g + 2], acc[m][c][4 * g + 3]};
+                uint2 w;
+                w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, of_b2));
+                w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, of_b2));
+                if (row_ok[m] && !(DBG & 64)) {
+                    if (DBG & 128) __builtin_nontemporal_store(((unsigned long long)w.y << 32) | w.x, reinterpret_cast<unsigned long long*>(dst + 8 * g));
+                    else *reinterpret_cast<uint2*>(dst + 8 * g) = w;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = row_ok[m] ? acc[m][c][r] : 0.f;
+                cs[r] += v;
+                cq[r] = fmaf(v, v, cq[r]);
+            }
+        }
+        // column sums over the 32 lanes (rows) of a half: a halving exchange -- at distance 16, 8, 4, 2 a lane keeps one half of its
+        // registers and receives the partner's copy of that half -- then one plain exchange at distance 1: 16 shuffles for 16 columns.
+        // Lane l31 ends with register R = l31 >> 1: column 8 (R >> 2) + 4 half + (R & 3).  A fixed tree: the same bits every run.
+#pragma unroll
+        for (int lvl = 0; lvl < 4; ++lvl) {
+            const int n = 8 >> lvl, d = 16 >> lvl;                  // registers kept, lane distance
+            const bool up = (l31 & d) != 0;
+#pragma unroll
+            for (int r = 0; r < n; ++r) {
+                // (opaque copies: the optimiser otherwise turns "up ? cs[r + n] : cs[r]" into a DYNAMIC index into the register array --
+                // a 16-way compare / select chain per access, 2 000 v_cndmask in the first build of this epilogue: 11 us)
+                float lo_s = cs[r], hi_s = cs[r + n], lo_q = cq[r], hi_q = cq[r + n];
+                asm volatile("" : "+v"(lo_s), "+v"(hi_s), "+v"(lo_q), "+v"(hi_q));
+                const float ks = up ? hi_s : lo_s, ss = up ? lo_s : hi_s;
+                const float kq = up ? hi_q : lo_q, sq = up ? lo_q : hi_q;
+                cs[r] = ks + __shfl_xor(ss, d, 64);
+                cq[r] = kq + __shfl_xor(sq, d, 64);
+            }
+        }
+        cs[0] += __shfl_xor(cs[0], 1, 64);
+        cq[0] += __shfl_xor(cq[0], 1, 64);
+        const int R = l31 >> 1;
+        const int col = (ct0 + c) * 32 + 8 * (R >> 2) + 4 * half + (R & 3);
+        sp[(l31 & 1) * a.K + col] = (l31 & 1) ? cq[0] : cs[0];
+    }
+    // the statistics rows nobody owns (the array is sized for the 64-row groups of the per-clip forms)
+    for (int r = gridDim.x + wg; r < a.nblk; r += gridDim.x) {
+        float* z = a.stats + (int64_t)r * 2 * a.K + cb * 512 + tid;
+        z[0] = 0.f;
+        z[a.K] = 0.f;
+    }
+}
+
+// LPM_K1_WIDE=0: the flat 96-row plain form (A/B)
+bool assign_wide_ok(int B, int T, int MT, int D, int K, int nblk) {
+    static const int on = [] { const char* e = getenv("LPM_K1_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int DS = D / 32;
+    const int64_t M = (int64_t)B * T;
+    return on && D % 128 == 0 && DS / 4 >= 3 && K % 512 == 0 && K > 0 && M < ((int64_t)1 << 31) && (M + AW_ROWS - 1) / AW_ROWS <= nblk &&
+           (int64_t)B * MT * DS * 128 < ((int64_t)1 << 31);
+}
+int assign_wide_launch(const void* xr, const void* wt, int B, int T, int MT, int D, int K, void* logits_bf16, float* stats, int nblk,
+                       int timing_tag, hipStream_t stream, const char* what) {
+    AssignFlatArgs a{};
+    a.xr = (const uint4*)xr; a.wt = (const uint4*)wt;
+    a.M = B * T; a.T = T; a.MT = MT; a.DS = D / 32; a.NT = K / 32; a.K = K;
+    a.logits = (float*)logits_bf16; a.stats = stats; a.nblk = nblk;
+    const int nwg = (a.M + AW_ROWS - 1) / AW_ROWS;
+    if ((((uintptr_t)xr | (uintptr_t)wt) & 15) != 0) {
+        set_error("%s: internal: unaligned tiles", what);
+        return LPM_ERR_BADARG;
+    }
+    const dim3 grid((unsigned)nwg, (unsigned)(K / 512));
+    const size_t lds = (size_t)AW_NS * AW_STAGE;
+    void (*kern)(const AssignFlatArgs) = assign_wide_kernel<0>;
+#ifdef LPM_K1_WIDE_EXPERIMENTS                                     // tools/k1_bf16_loop.py: build with LPM_EXTRA_HIPCC_FLAGS=-DLPM_K1_WIDE_EXPERIMENTS
+    static const int dbg = [] { const char* e = getenv("LPM_K1_WIDE_DBG"); return e ? atoi(e) : 0; }();
+    switch (dbg) {
+        case 1: kern = assign_wide_kernel<1>; break;
+        case 2: kern = assign_wide_kernel<2>; break;
+        case 4: kern = assign_wide_kernel<4>; break;
+        case 6: kern = assign_wide_kernel<6>; break;
+        case 8: kern = assign_wide_kernel<8>; break;
+        case 16: kern = assign_wide_kernel<16>; break;
+        case 22: kern = assign_wide_kernel<22>; break;
+        case 64: kern = assign_wide_kernel<64>; break;
+        case 128: kern = assign_wide_kernel<128>; break;
+        default: break;
+    }
+#endif
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: cannot reserve %zu bytes of LDS", what, lds);
+        return LPM_ERR_LAUNCH;
+    }
+    hipEvent_t e0, e1;
+    if (timing_tag && timing_request(timing_tag, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(512), lds, stream, e0, e1, 0, a);
+    else hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
+    return check_launch(what);
+}
+
 static int af_enabled() {
     static const int on = [] {
         const char* e = getenv("LPM_K1_FLAT");         // 0: the 128-row tile GEMM form (A/B switch)

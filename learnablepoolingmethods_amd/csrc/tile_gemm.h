@@ -148,6 +148,10 @@ int tile_gemm_image_row_groups(int M);
 // stats: [nblk][2][K], nblk >= ceil(B T / 96) rows (the rows past the row groups are zeroed).
 bool assign_flat_ok(int B, int T, int D, int K);
 bool assign_flat_plain_ok(int B, int T, int D, int K);       // planes == 1: plain bf16 tiles, bf16 logits (round 5)
+// plain bf16 tiles on 160-row x 512-column workgroups (K a multiple of 512: BASELINE configs[4] in one round of the chip)
+bool assign_wide_ok(int B, int T, int MT, int D, int K, int nblk);
+int assign_wide_launch(const void* xr, const void* wt, int B, int T, int MT, int D, int K, void* logits_bf16, float* stats, int nblk,
+                       int timing_tag, hipStream_t stream, const char* what);
 int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int D, int K, float* logits, float* stats, int nblk,
                        int timing_tag, hipStream_t stream, const char* what, int planes = 2);
 

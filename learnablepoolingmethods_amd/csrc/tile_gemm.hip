@@ -1182,6 +1182,10 @@ static int assign_gemm_tiles_fwd_impl(const void* xr, const void* wt, int B, int
     if (planes == 2 && assign_flat_ok(B, T, D, K))
         return assign_flat_launch(xr, wt, B, T, MT, D, K, (float*)logits, partial, lpm_assign_gemm_tiles_nblk(B, T),
                                   D >= 1024 ? LPM_TIMING_K1 : 0, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd");
+    // bf16 storage, K a multiple of 512: 160-row x 512-column workgroups (LPM_K1_WIDE=0: the flat form)
+    if (planes == 1 && assign_wide_ok(B, T, MT, D, K, lpm_assign_gemm_tiles_nblk(B, T)))
+        return assign_wide_launch(xr, wt, B, T, MT, D, K, logits, partial, lpm_assign_gemm_tiles_nblk(B, T),
+                                  D >= 1024 ? LPM_TIMING_K1 : 0, (hipStream_t)stream, "lpm_assign_gemm_tiles_fwd_bf16");
     // bf16 storage: the same flat workgroups on plain tiles (double steps), bf16 logits
     if (planes == 1 && assign_flat_plain_ok(B, T, D, K))
         return assign_flat_launch(xr, wt, B, T, MT, D, K, (float*)logits, partial, lpm_assign_gemm_tiles_nblk(B, T),

@@ -1539,6 +1539,42 @@ def test_netvlad_bf16_storage():
         ops.netvlad(y[:, :1024].detach(), torch.zeros(1024, 128, device=dev), None, T, bias=torch.zeros(128, device=dev))
 
 
+@pytest.mark.parametrize("B,T", [(128, 300), (3, 77), (1, 300), (7, 129), (2, 33), (1, 1)])
+def test_k1_plain_bf16_at_k512(B, T):
+    """K1 on plain bf16 tiles at BASELINE configs[4]'s video sizes (1024 -> 512 clusters; frame_level_models.py:2781-2789) through the C
+    ABI: 160-row x 512-column workgroups when the statistics array has a row per workgroup (B T / 160 <= B ceil(T / 64): 128 x 300 is one
+    round of 240 workgroups; 7 x 129 and 3 x 77 straddle clips and end in a partial group), the flat 96-row form otherwise (1 x 300, 1 x 1).
+    Logits = bf16(frames) . bf16(weights) accumulated in fp32 and stored as bf16: within one bf16 rounding of the fp64 product of the
+    rounded operands; the batch-norm statistics come from the fp32 accumulators."""
+    from learnablepoolingmethods_amd import _capi, ops
+    from learnablepoolingmethods_amd._capi import ptr, stream_ptr
+    lib = _capi.load()
+    dev = cuda()
+    D, K, M = 1024, 512, B * T
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    raw = torch.randn(B, T, 1152, generator=g)
+    nf = torch.full((B,), T, dtype=torch.int32)
+    y = ops.frame_sample_bn(raw.to(dev), nf.to(dev), T, storage="bf16", materialize=True)
+    xr = ops._cached_tiles(y[:, :D], B, T, D, rows=True, storage="bf16")
+    assert xr is not None
+    W = (torch.randn(D, K, generator=g) / D ** 0.5).to(dev)
+    wt = torch.empty(lib._lpm_weight_tiles_bytes(D, K) // 8, dtype=torch.int32, device=dev)
+    st = stream_ptr()
+    lib.check(lib._lpm_split_weight_tiles_bf16(ptr(W), D, K, 0, ptr(wt), st), "lpm_split_weight_tiles_bf16")
+    nblk = lib._lpm_assign_gemm_tiles_nblk(B, T)
+    logits = torch.full((M, K), float("nan"), dtype=torch.bfloat16, device=dev)
+    partial = torch.full((nblk, 2, K), float("nan"), device=dev)
+    lib.check(lib._lpm_assign_gemm_tiles_fwd_bf16(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st), "lpm_assign_gemm_tiles_fwd_bf16")
+    x64 = y[:, :D].to(torch.bfloat16).double().cpu()
+    ref = x64 @ W.to(torch.bfloat16).double().cpu()
+    got = logits.double().cpu()
+    assert torch.isfinite(got).all() and torch.isfinite(partial).all()
+    err = (got - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-6).all()), f"logits: worst {float((err / (ref.abs() + 1e-3)).max()):.2e}"
+    assert_close(partial[:, 0].sum(0), ref.sum(0), 1e-4, "column sums", floor=1e-3 * float(ref.abs().sum(0).max()))
+    assert_close(partial[:, 1].sum(0), (ref * ref).sum(0), 1e-4, "column square sums")
+
+
 @pytest.mark.parametrize("M,C,act", [(80, 512, 1), (80, 512, 2), (128, 1024, 2), (7, 40, 0), (250, 96, 1), (2, 33, 2)])
 def test_bn_small_one_launch_each_way(M, C, act):
     """lpm_bn_small_fwd / _bwd: the clip-level batch norms with what follows them (frame_level_models.py:2321-2337: hidden1_bn + relu6;
