@@ -1681,6 +1681,9 @@ TILE_GEMM_FROM_IMAGE = os.environ.get("LPM_TILE_GEMM_FROM_IMAGE", "0") == "1"
 DW_TERMS = int(os.environ.get("LPM_DW_TERMS", "1"))
 
 
+DW_SLICES = int(os.environ.get("LPM_DW_SLICES", "0"))        # 0: the policy below; n: that many slices of the token reduction (A/B)
+
+
 def _dw_x2(x2, dy2, K, N, outs, alpha):
     """The fp16 two-term weight gradient dW = alpha * xh^T [dyh | dyl] from an activation image x2 [M,3K] = [hi|lo|hi] (fp16) and a
     gradient image dy2 [M,2N] = [hi|lo]: the activation rounded once to fp16 (its hi plane, read in place with the image's row stride),
@@ -1688,7 +1691,7 @@ def _dw_x2(x2, dy2, K, N, outs, alpha):
     lpm_sum_splits_scaled adds slices and halves and multiplies by alpha = 1 / (the two operands' scales)."""
     lib = _capi.load()
     M = x2.shape[0]
-    S = 8 if K * N <= (1 << 20) else 2
+    S = DW_SLICES if DW_SLICES else (8 if K * N <= (1 << 20) else 4)     # (in-step at cfg-2, 2 -> 4 slices: 171 / 174 / 155 -> 146 / 151 / 116 us)
     while S > 1 and (M % S or M // S < 512):
         S //= 2
     xh = x2.view(S, M // S, x2.shape[1])[:, :, :K]
