@@ -336,6 +336,14 @@ int lpm_proj_fwd_parts(const void* x1, int64_t ldx1, int64_t n1a, int x1_bf16, c
                        const float* W, int M, int64_t Kd, int N, float* y, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 int lpm_split_weight_tiles_parts(const void* x1, int64_t ld1, int64_t n1a, int x1_bf16, const float* scale, int ks, const float* x2,
                                  int64_t ld2, int R, int64_t N, void* wt, lpm_stream_t stream);
+/* bf16 storage (BASELINE configs[4]) with a bf16 COMPUTE COPY of hidden1_weights (frame_level_models.py:2309-2319; SURVEY section 7: "keep
+ * master fp32 + bf16 compute copy"): W16 [Kd, N] = bf16(W), kept beside the fp32 master by lpm_factored_clip_adam_copy.  The forward (x1 the
+ * bf16-stored sums, as lpm_proj_fwd_parts with x1_bf16 = 1) and the input gradient (dyt as for lpm_proj_dx; N a multiple of 64) stream
+ * 2 bytes per weight instead of 4 and run one bf16 MFMA per product: x = bf16(x1 * scale), dy = its hi plane -- the arithmetic of this
+ * configuration's other operands. */
+int lpm_proj_fwd_parts_w16(const void* x1, int64_t ldx1, int64_t n1a, const float* scale, int ks, const float* x2, int64_t ldx2,
+                           const void* W16, int M, int64_t Kd, int N, float* y, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+int lpm_proj_dx_w16(const void* dyt, const void* W16, int M, int64_t Kd, int N, float* dx, int64_t lddx, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * bf16 storage (BASELINE configs[4]: "Gated NetVLAD K=512 + MoE-4, 300x1152 bf16"): the tensors SURVEY 8(d) counts in the
@@ -785,6 +793,11 @@ int lpm_factored_clip_adam(const void* xt, const void* dyt, int R, int N1, int N
 int lpm_factored_clip_adam_q(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
                              float* param, float* m, float* v, float clip_norm, float lr, float beta1, float beta2, float eps,
                              int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream);
+/* ... keeping the bf16 compute copy param_bf16 [N1, N2] = bf16(param) beside the master: written by the update pass's epilogue.  x and gdt
+ * both NULL: the norm from a GEMM pass (lpm_factored_clip_adam); both given: from the quadratic forms (lpm_factored_clip_adam_q). */
+int lpm_factored_clip_adam_copy(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
+                                float* param, float* m, float* v, void* param_bf16, float clip_norm, float lr, float beta1, float beta2,
+                                float eps, int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream);
 
 #ifdef __cplusplus
 }

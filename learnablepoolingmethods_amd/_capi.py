@@ -85,6 +85,8 @@ SIGNATURES = {
     "lpm_proj_fwd_parts": (_i, [_f, _l, _l, _i, _f, _i, _f, _l, _f, _i, _l, _i, _f, _f, _s, _f]),
     "lpm_split_weight_tiles_parts": (_i, [_f, _l, _l, _i, _f, _i, _f, _l, _i, _l, _f, _f]),
     "lpm_proj_dx": (_i, [_f, _f, _i, _l, _i, _f, _l, _f]),
+    "lpm_proj_fwd_parts_w16": (_i, [_f, _l, _l, _f, _i, _f, _l, _f, _i, _l, _i, _f, _f, _s, _f]),
+    "lpm_proj_dx_w16": (_i, [_f, _f, _i, _l, _i, _f, _l, _f]),
     "lpm_frame_tiles_bf16_bytes": (_s, [_i, _i, _i]),
     "lpm_frame_steps_bf16": (_i, [_i]),
     "lpm_frame_apply_tiles2": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _f, _i, _f]),
@@ -163,6 +165,7 @@ SIGNATURES = {
     "lpm_clip_adam_scratch_bytes": (_s, [_l, _i]),
     "lpm_factored_clip_adam_scratch_bytes": (_s, [_i, _i]),
     "lpm_factored_clip_adam_q": (_i, [_f, _f, _f, _l, _f, _i, _i, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
+    "lpm_factored_clip_adam_copy": (_i, [_f, _f, _f, _l, _f, _i, _i, _i, _f, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
     "lpm_factored_clip_adam": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
     "lpm_multi_tensor_clip_adam": (_i, [_f, _f, _f, _f, _f, _i, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _f]),
     "lpm_weight_pack": (_i, [_f, _i, _f]),

@@ -240,7 +240,21 @@ extern "C" size_t lpm_factored_clip_adam_scratch_bytes(int N1, int N2) {
 
 static int factored_clip_adam_impl(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
                                    float* param, float* m, float* v, float clip_norm, float lr, float beta1, float beta2, float eps,
-                                   int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream);
+                                   int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream, void* param_bf16 = nullptr);
+// ... keeping a bf16 compute copy of the weight beside its fp32 master (SURVEY section 7 hard part 2; BASELINE configs[4]): param_bf16
+// [N1, N2] receives bf16(param) from the update pass's epilogue -- the copy the projection's forward and input-gradient passes read
+// (lpm_proj_fwd_parts_w16, lpm_proj_dx_w16) instead of streaming the fp32 weight twice more.  x / gdt NULL: the norm from a GEMM pass
+// (lpm_factored_clip_adam), else from the quadratic forms (lpm_factored_clip_adam_q).  The tile-GEMM form of the update pass only.
+extern "C" int lpm_factored_clip_adam_copy(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
+                                           float* param, float* m, float* v, void* param_bf16, float clip_norm, float lr, float beta1,
+                                           float beta2, float eps, int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(param_bf16 && ((uintptr_t)param_bf16 & 7) == 0, LPM_ERR_BADARG, "lpm_factored_clip_adam_copy: the copy must be 8-byte aligned");
+    LPM_REQUIRE((x == nullptr) == (gdt == nullptr) && (!x || (ldx >= N1 && R <= 128)), LPM_ERR_BADARG,
+                "lpm_factored_clip_adam_copy: x and the tiles of DY DY^T come together (row stride >= N1, R <= 128)");
+    return factored_clip_adam_impl(xt, dyt, x, ldx, gdt, R, N1, N2, param, m, v, clip_norm, lr, beta1, beta2, eps, step, scratch, scratch_bytes,
+                                   stream, param_bf16);
+}
 extern "C" int lpm_factored_clip_adam(const void* xt, const void* dyt, int R, int N1, int N2, float* param, float* m, float* v,
                                       float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
                                       size_t scratch_bytes, lpm_stream_t stream) {
@@ -258,7 +272,7 @@ extern "C" int lpm_factored_clip_adam_q(const void* xt, const void* dyt, const f
 }
 static int factored_clip_adam_impl(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
                                    float* param, float* m, float* v, float clip_norm, float lr, float beta1, float beta2, float eps,
-                                   int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream) {
+                                   int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream, void* param_bf16) {
     using namespace lpm;
     LPM_REQUIRE(xt && dyt && param && m && v && scratch, LPM_ERR_BADARG, "lpm_factored_clip_adam: null pointer");
     LPM_REQUIRE(R > 0 && R % 16 == 0 && N1 > 0 && N2 > 0 && N2 % 32 == 0 && step >= 1, LPM_ERR_UNSUPPORTED_SHAPE,
@@ -308,12 +322,12 @@ static int factored_clip_adam_impl(const void* xt, const void* dyt, const float*
     // cfg-5 (R = 128, N2 = 1024) 2741 against 2418 and eight towers of cfg-2 (R = 640) 1855 against 1749 -- every wave fetching its own
     // fragments from L2 costs 80 + 160 KB of L2 -> CU traffic per 192 KB of HBM stream at R = 80, but 256 + 512 KB per 384 KB at R = 128:
     // the whole-row form only where the reduction is short
-    if (rows_form && N2 % 256 == 0 && N1 % 32 == 0 && (int64_t)g.total_steps * N2 <= 5 * 512 && (int64_t)NT1 * (N2 / 256) < ((int64_t)1 << 31)) {
+    if (rows_form && !param_bf16 && N2 % 256 == 0 && N1 % 32 == 0 && (int64_t)g.total_steps * N2 <= 5 * 512 && (int64_t)NT1 * (N2 / 256) < ((int64_t)1 << 31)) {
         hipLaunchKernelGGL(fa_update_rows_kernel, dim3((unsigned)(NT1 * (N2 / 256))), dim3(256), 0, s, (const uint4*)xt, (const uint4*)dyt,
                            g.total_steps, N1, N2, NT1, NT2, N2 / 256, param, m, v, (const float*)factor, (float)lr_t, beta1, beta2, eps);
         return check_launch("lpm_factored_clip_adam (update pass, rows)");
     }
-    g.adam_p = param; g.adam_m = m; g.adam_v = v; g.adam_factor = factor;
+    g.adam_p = param; g.adam_m = m; g.adam_v = v; g.adam_factor = factor; g.adam_p16 = (unsigned short*)param_bf16;
     g.adam_lr_t = (float)lr_t; g.adam_b1 = beta1; g.adam_b2 = beta2; g.adam_eps = eps;
     rc = tile_gemm_adam(g, s, "lpm_factored_clip_adam (update pass)");
     if (rc != LPM_OK) return rc;

@@ -64,7 +64,15 @@ struct ProjParts {
 // (SC with more than 10 pieces per pair: TWO loader waves, half the pieces each -- sixteen pieces' data and scales do not fit one wave's
 // registers beside what the computing path sets the kernel's allocation to)
 __host__ __device__ constexpr int pj_loaders(int NP, int SC) { return (SC != 0 && NP > LPM_PJ_SC_ONE_LOADER_MAX) ? 2 : 1; }
-template <int MT, int NP, int XD, int SC = 0>
+// W16 (round 5, BASELINE configs[4]: "master fp32 + bf16 compute copy"): W points at the bf16 COPY of the weight
+// (written by the Adam epilogue, csrc/tile_gemm.hip) -- half the bytes of the stream.  A slab is 16 rows x 512 columns x 2 bytes = 16 KB,
+// the ring EIGHT stages (seven in flight: 112 KB per CU), a wave brings two 1 KB rows per stage; a lane gathers its 8 values down the
+// column with eight ds_read_u16 and packs pairs into the B fragment (no split: the copy IS the operand), x is rounded once to
+// bf16 as it is read (the descriptor of this configuration is a bf16 tensor): ONE MFMA per product.
+constexpr int PJ16_NS = 8;
+constexpr int PJ16_WBYTES = 16 * 512 * 2;
+static_assert(PJ16_NS * PJ16_WBYTES == PJ_NS * PJ_WBYTES, "the x ring sits behind the weight ring at the same offset in both forms");
+template <int MT, int NP, int XD, int SC = 0, bool W16 = false>
 __global__ __launch_bounds__(512 + 64 * pj_loaders(NP, SC), 1) void proj_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int M, int64_t Kd,
                                                           int N, int nslab, int splits, float* __restrict__ part, const ProjParts pp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -190,18 +198,21 @@ __global__ __launch_bounds__(512 + 64 * pj_loaders(NP, SC), 1) void proj_fwd_ker
         return;
     }
     // W DMA: piece p = wave * 4 + j (j < 4): slab row p >> 1, 1 KB half (p & 1) of the row's 512-column segment
-    const float* wsrc[4];
+    // (W16: piece p = wave * 2 + j (j < 2) = slab row p, its whole 512-column segment)
+    constexpr int WNS = W16 ? PJ16_NS : PJ_NS, WSTAGE = W16 ? PJ16_WBYTES : PJ_WBYTES, WPC = W16 ? 2 : 4;
+    const float* wsrc[WPC];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = wave * 4 + j;
-        wsrc[j] = W + ((int64_t)s0 * 16 + (p >> 1)) * N + nb * 512 + (p & 1) * 256 + lane * 4;
+    for (int j = 0; j < WPC; ++j) {
+        const int p = wave * WPC + j;
+        if (W16) wsrc[j] = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(W) + ((int64_t)s0 * 16 + p) * N + nb * 512 + lane * 8);
+        else wsrc[j] = W + ((int64_t)s0 * 16 + (p >> 1)) * N + nb * 512 + (p & 1) * 256 + lane * 4;
     }
     auto issue = [&](int s) {
-        unsigned char* st = smem + (s % PJ_NS) * PJ_WBYTES;
+        unsigned char* st = smem + (s % WNS) * WSTAGE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (int64_t)s * 16 * N),
-                                             (__attribute__((address_space(3))) void*)(st + (wave * 4 + j) * 1024), 16, 0, PJ_AUX);
+        for (int j = 0; j < WPC; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (int64_t)s * (W16 ? 8 : 16) * N),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * WPC + j) * 1024), 16, 0, PJ_AUX);
     };
 
     f32x16 acc[MT][2];
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(512 + 64 * pj_loaders(NP, SC), 1) void proj_fwd_ker
     // that column, bank = column mod 32: conflict-free) and, per row tile, part 2 half of its row of an x pair-buffer (rows past the
     // buffer, >= M, are never stored: clamped)
     const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned w_lane = (unsigned)((8 * half) * 512 + wave * 64 + l31) * 4u;
+    const unsigned w_lane = (unsigned)((8 * half) * 512 + wave * 64 + l31) * (W16 ? 2u : 4u);
     unsigned x_lane[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -224,19 +235,71 @@ __global__ __launch_bounds__(512 + 64 * pj_loaders(NP, SC), 1) void proj_fwd_ker
     }
 
 #pragma unroll
-    for (int s = 0; s < PJ_NS - 1; ++s)
+    for (int s = 0; s < WNS - 1; ++s)
         if (s < ns) issue(s);
     for (int s = 0; s < ns; ++s) {
-        // stage s has landed when at most the pieces of the younger stages in flight (two, fewer at the end) remain: 4 per stage
-        const int young = min(PJ_NS - 2, ns - 1 - s);
-        if (young == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (young == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage s has landed when at most the pieces of the younger stages in flight (WNS - 2, fewer at the end) remain: WPC per stage
+        const int young = min(WNS - 2, ns - 1 - s);
+        if (W16) {
+            switch (young) {
+                case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        } else {
+            if (young == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (young == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();              // stage s is in LDS for everyone; stage (s - 1) % NS is free again
         asm volatile("" ::: "memory");
-        if (s + PJ_NS - 1 < ns) issue(s + PJ_NS - 1);
-        const unsigned wa = smem_lds + (unsigned)(s % PJ_NS) * PJ_WBYTES + w_lane;
+        if (s + WNS - 1 < ns) issue(s + WNS - 1);
+        const unsigned wa = smem_lds + (unsigned)(s % WNS) * WSTAGE + w_lane;
         const unsigned xa = smem_lds + PJ_NS * PJ_WBYTES + (unsigned)((s >> 1) % XD) * PJ_XPAIR;
+        if constexpr (W16) {
+            // B fragments: register i of column c = (row 2 i, row 2 i + 1) of the lane's eight rows, low half first
+            unsigned bw[2][8];
+            tg_u32x4 bq[2];
+            f32x4 xq[2][2];
+            constexpr bool PRE = MT <= 3;
+            auto read_xq = [&](int m) {
+                const unsigned a0 = xa + (x_lane[m] ^ ((unsigned)(s & 1) << 6));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(xq[PRE ? (m & 1) : 0][0]) : "v"(a0));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(xq[PRE ? (m & 1) : 0][1]) : "v"(a0 ^ 16u));
+            };
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)      // (zero-extending reads + one v_lshl_or per pair: with SRAM ECC a d16 load clears the other half)
+                    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(bw[c][e]) : "v"(wa), "n"(e * 1024 + c * 64));
+            if (PRE) read_xq(0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                asm volatile("s_waitcnt lgkmcnt(%8)"
+                             : "+v"(bw[c][0]), "+v"(bw[c][1]), "+v"(bw[c][2]), "+v"(bw[c][3]), "+v"(bw[c][4]), "+v"(bw[c][5]), "+v"(bw[c][6]), "+v"(bw[c][7])
+                             : "n"((1 - c) * 8 + (PRE ? 2 : 0)));
+                bq[c] = tg_u32x4{bw[c][0] | (bw[c][1] << 16), bw[c][2] | (bw[c][3] << 16), bw[c][4] | (bw[c][5] << 16), bw[c][6] | (bw[c][7] << 16)};
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4* xc = xq[PRE ? (m & 1) : 0];
+                if (!PRE) read_xq(m);
+                else if (m + 1 < MT) read_xq(m + 1);
+                if (PRE && m + 1 < MT) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xc[0]), "+v"(xc[1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0]), "+v"(xc[1]));
+                const float v[8] = {xc[0][0], xc[0][1], xc[0][2], xc[0][3], xc[1][0], xc[1][1], xc[1][2], xc[1][3]};
+                uint4 hi, lo;
+                tg_split8(v, hi, lo);
+                const tg_u32x4 ah = tg_u32x4{hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[m][c] = tg_mfma(ah, bq[c], acc[m][c]);
+            }
+            continue;
+        }
         float wv[2][8];
         constexpr bool PRE = MT <= 3;              // x fragments requested one row tile ahead (MT = 4: no registers left for that)
         f32x4 xv[2][2];
@@ -542,6 +605,99 @@ __global__ __launch_bounds__(512, 2) void proj_dx2_kernel(const uint4* __restric
         }
 }
 
+// ... from the bf16 compute copy of the weight (round 5, BASELINE configs[4]; proj_fwd_kernel's W16 note): a stage is 64 columns of the
+// reduction = one whole 128-byte line per row of the copy, FOUR 16-deep MFMA steps; the lane's B fragment of a step is ONE ds_read_b128
+// of its row (chunk 2 t + half, swizzled as above) -- the copy is the operand, nothing is split -- and dy enters by its hi plane alone
+// (the gradient rounded once to bf16, as every gradient operand of this configuration's backward is): one MFMA per product.
+// dy pieces per stage: MT row tiles x 4 steps (<= 16: two per wave, ids past the end are clamped duplicates).
+constexpr int PF_NS = 3;
+constexpr int PF_WBYTES = 8 * 32 * 128;            // 8 waves x 32 rows x 64 bf16
+constexpr int PF_APIECES = 16;
+constexpr int PF_STAGE = PF_WBYTES + PF_APIECES * 1024;
+
+template <int MT>
+__global__ __launch_bounds__(512, 1) void proj_dx16_kernel(const uint4* __restrict__ dyt, const unsigned short* __restrict__ W16, int M, int64_t Kd, int N,
+                                                           float* __restrict__ dx, int64_t lddx) {
+    static_assert(4 * MT <= PF_APIECES, "dy pieces per stage");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int64_t k0 = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + wave * 32;     // this wave's 32 rows of W
+    const int NB = N / 64, CS = N / 16;            // stages; 16-deep steps per row tile of dyt
+    // W DMA: piece j (0..3) = rows 8 j .. 8 j + 7 of the wave's 32; lane -> (row r = 8 j + lane / 8, LDS slot q = lane % 8 holding chunk
+    // q ^ ((r >> 1) & 7) of the row's eight 16-byte chunks)
+    const unsigned short* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + (lane >> 3), q = lane & 7;
+        const int64_t row = min(k0 + r, Kd - 1);
+        wsrc[j] = W16 + row * N + ((q ^ ((r >> 1) & 7)) * 8);
+    }
+    // dy DMA: piece id p = wave + 8 j (j < 2) = (row tile p >> 2, step-in-stage p & 3), hi plane; ids >= 4 MT: duplicates of piece 0
+    const uint4* asrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wave + 8 * j, pc = p < 4 * MT ? p : 0;
+        asrc[j] = dyt + ((int64_t)(pc >> 2) * CS + (pc & 3)) * 128 + lane;
+    }
+    auto issue = [&](int s) {
+        unsigned char* st = smem + (s % PF_NS) * PF_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + s * 64),
+                                             (__attribute__((address_space(3))) void*)(st + wave * 4096 + j * 1024), 16, 0, PJ_AUX);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + (int64_t)s * 512),
+                                             (__attribute__((address_space(3))) void*)(st + PF_WBYTES + (wave + 8 * j) * 1024), 16, 0, 0);
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned w_lane = (unsigned)(wave * 4096 + l31 * 128 + ((half ^ ((l31 >> 1) & 7)) << 4));       // this lane's row, slot of chunk `half`
+    const unsigned a_lane = (unsigned)(PF_WBYTES + lane * 16);
+#pragma unroll
+    for (int s = 0; s < PF_NS - 1; ++s)
+        if (s < NB) issue(s);
+    for (int s = 0; s < NB; ++s) {
+        const int young = min(PF_NS - 2, NB - 1 - s);      // younger stages in flight behind stage s, 6 pieces of this wave each
+        if (young == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + PF_NS - 1 < NB) issue(s + PF_NS - 1);
+        const unsigned sb = smem_lds + (unsigned)(s % PF_NS) * PF_STAGE;
+        tg_u32x4 b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(b[t]) : "v"(sb + (w_lane ^ ((unsigned)t << 5))));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            tg_u32x4 ah[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[m]) : "v"(sb + a_lane), "n"((m * 4 + t) * 1024));
+            // (LDS returns in order: behind the four B reads of the stage come MT reads per step)
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(b[t]) : "n"(MT));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ah[m]) : "n"(MT - 1 - m));
+                acc[m] = tg_mfma(ah[m], b[t], acc[m]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m * 32 + mfma32_row(r, lane);
+            if (row < M && k0 + l31 < Kd) dx[(int64_t)row * lddx + k0 + l31] = acc[m][r];
+        }
+}
+
 }  // namespace lpm
 
 extern "C" int lpm_proj_supported(int M, int64_t Kd, int N) {
@@ -552,7 +708,7 @@ extern "C" size_t lpm_proj_fwd_workspace_bytes(int M, int64_t Kd, int N) {
 }
 
 static int proj_fwd_impl(const float* x, int64_t ldx, const lpm::ProjParts* parts, const float* W, int M, int64_t Kd, int N, float* y,
-                         void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+                         void* workspace, size_t workspace_bytes, lpm_stream_t stream, bool w16 = false);
 extern "C" int lpm_proj_fwd(const float* x, int64_t ldx, const float* W, int M, int64_t Kd, int N, float* y, void* workspace,
                             size_t workspace_bytes, lpm_stream_t stream) {
     return proj_fwd_impl(x, ldx, nullptr, W, M, Kd, N, y, workspace, workspace_bytes, stream);
@@ -574,8 +730,22 @@ extern "C" int lpm_proj_fwd_parts(const void* x1, int64_t ldx1, int64_t n1a, int
     const ProjParts pp{x2, ldx2, n1a, scale, ks, x1_bf16 ? 1 : 0};
     return proj_fwd_impl((const float*)x1, ldx1, &pp, W, M, Kd, N, y, workspace, workspace_bytes, stream);
 }
+// ... from the bf16 compute copy W16 [Kd, N] of the weight (lpm_factored_clip_adam_copy keeps it): x1 must be the bf16-stored block
+extern "C" int lpm_proj_fwd_parts_w16(const void* x1, int64_t ldx1, int64_t n1a, const float* scale, int ks, const float* x2, int64_t ldx2,
+                                      const void* W16, int M, int64_t Kd, int N, float* y, void* workspace, size_t workspace_bytes,
+                                      lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(x1 && scale && (x2 || n1a == Kd), LPM_ERR_BADARG, "lpm_proj_fwd_parts_w16: null pointer");
+    LPM_REQUIRE(n1a > 0 && n1a <= Kd && n1a % 32 == 0 && ks > 0 && ks % 4 == 0 && n1a % ks == 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_proj_fwd_parts_w16: the scaled block must be a multiple of 32 columns and of ks (n1a=%lld ks=%d)", (long long)n1a, ks);
+    LPM_REQUIRE(ldx1 >= n1a && ldx1 % 4 == 0 && (n1a == Kd || (ldx2 >= Kd - n1a && ldx2 % 4 == 0)), LPM_ERR_BADARG,
+                "lpm_proj_fwd_parts_w16: row strides must cover their block and be multiples of 4");
+    LPM_REQUIRE((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)scale) & 15) == 0, LPM_ERR_BADARG, "lpm_proj_fwd_parts_w16: pointers must be 16-byte aligned");
+    const ProjParts pp{x2, ldx2, n1a, scale, ks, 1};
+    return proj_fwd_impl((const float*)x1, ldx1, &pp, (const float*)W16, M, Kd, N, y, workspace, workspace_bytes, stream, true);
+}
 static int proj_fwd_impl(const float* x, int64_t ldx, const lpm::ProjParts* parts, const float* W, int M, int64_t Kd, int N, float* y,
-                         void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+                         void* workspace, size_t workspace_bytes, lpm_stream_t stream, bool w16) {
     using namespace lpm;
     LPM_REQUIRE(x && W && y && workspace, LPM_ERR_BADARG, "lpm_proj_fwd: null pointer");
     LPM_REQUIRE(lpm_proj_supported(M, Kd, N), LPM_ERR_UNSUPPORTED_SHAPE,
@@ -591,7 +761,8 @@ static int proj_fwd_impl(const float* x, int64_t ldx, const lpm::ProjParts* part
     do {                                                                                                                     \
         const size_t lds = (size_t)PJ_NS * PJ_WBYTES + XDV * NPV * 1024;                                                     \
         auto kern = !parts ? proj_fwd_kernel<MTV, NPV, XDV, 0>                                                               \
-                           : (parts->x1_bf16 ? proj_fwd_kernel<MTV, NPV, XDV, 2> : proj_fwd_kernel<MTV, NPV, XDV, 1>);      \
+                           : (w16 ? proj_fwd_kernel<MTV, NPV, XDV, 2, true>                                                  \
+                                  : (parts->x1_bf16 ? proj_fwd_kernel<MTV, NPV, XDV, 2> : proj_fwd_kernel<MTV, NPV, XDV, 1>)); \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {    \
             (void)hipGetLastError();                                                                                         \
             set_error("lpm_proj_fwd: cannot reserve %zu bytes of LDS", lds);                                                 \
@@ -612,6 +783,38 @@ static int proj_fwd_impl(const float* x, int64_t ldx, const lpm::ProjParts* part
     const int64_t n4 = (int64_t)M * N / 4;
     hipLaunchKernelGGL(proj_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s, (const float4*)workspace, splits, n4, (float4*)y);
     return check_launch("lpm_proj_fwd");
+}
+
+// dx = dy . W^T from the bf16 compute copy W16 [Kd, N]; dyt as for lpm_proj_dx (only its hi plane is read); N a multiple of 64
+extern "C" int lpm_proj_dx_w16(const void* dyt, const void* W16, int M, int64_t Kd, int N, float* dx, int64_t lddx, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dyt && W16 && dx, LPM_ERR_BADARG, "lpm_proj_dx_w16: null pointer");
+    LPM_REQUIRE(M > 0 && M <= 128 && N > 0 && N % 64 == 0 && Kd > 0, LPM_ERR_UNSUPPORTED_SHAPE,
+                "lpm_proj_dx_w16: need M <= 128, N %% 64 == 0 (M=%d N=%d)", M, N);
+    LPM_REQUIRE((((uintptr_t)dyt | (uintptr_t)W16 | (uintptr_t)dx) & 15) == 0, LPM_ERR_BADARG, "lpm_proj_dx_w16: pointers must be 16-byte aligned");
+    LPM_REQUIRE(lddx >= Kd, LPM_ERR_BADARG, "lpm_proj_dx_w16: the row stride of dx must be >= Kd");
+    const int MT = (M + 31) / 32;
+    dim3 grid((unsigned)((Kd + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+#define LPM_PF(MTV)                                                                                                          \
+    do {                                                                                                                     \
+        auto kern = proj_dx16_kernel<MTV>;                                                                                   \
+        const size_t lds = (size_t)PF_NS * PF_STAGE;                                                                         \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {    \
+            (void)hipGetLastError();                                                                                         \
+            set_error("lpm_proj_dx_w16: cannot reserve %zu bytes of LDS", lds);                                              \
+            return LPM_ERR_LAUNCH;                                                                                           \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const uint4*)dyt, (const unsigned short*)W16, M, Kd, N, dx, lddx); \
+    } while (0)
+    switch (MT) {
+        case 1: LPM_PF(1); break;
+        case 2: LPM_PF(2); break;
+        case 3: LPM_PF(3); break;
+        default: LPM_PF(4); break;
+    }
+#undef LPM_PF
+    return check_launch("lpm_proj_dx_w16");
 }
 
 // dyt: lpm_split_rows_tiles(dy, ldx = N, B = 1, T = M, C = N) -- split-bf16 row tiles of the [M, N] gradient

@@ -100,6 +100,7 @@ struct TileGemmArgs {
     float* adam_m;             //          (the clip), then TF-Adam on adam_p / adam_m / adam_v in place (clip_adam.hip's arithmetic)
     float* adam_v;
     const float* adam_factor;
+    unsigned short* adam_p16;  //          optional: the bf16 compute copy of adam_p (same shape and row stride in elements), written beside it
     float adam_lr_t, adam_b1, adam_b2, adam_eps;
     // STORE, 256-row form only: the result leaves as a split-bf16 operand IMAGE [rows][3 * cols_valid] (split_gemm.hip's format for
     // the library GEMMs) instead of fp32 -- the [M, 4F] pre-activation of FeedForwardNetwork (transformer_utils.py:701-711) and its

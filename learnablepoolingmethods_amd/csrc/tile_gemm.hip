@@ -563,6 +563,13 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                     __builtin_nontemporal_store(pn, reinterpret_cast<f32x4*>(g.adam_p + o));
                     __builtin_nontemporal_store(mn, reinterpret_cast<f32x4*>(g.adam_m + o));
                     __builtin_nontemporal_store(vn, reinterpret_cast<f32x4*>(g.adam_v + o));
+                    if (g.adam_p16) {          // the bf16 compute copy (round to nearest even: what the projection's passes read next step)
+                        const of_f2 p01 = {pn[0], pn[1]}, p23 = {pn[2], pn[3]};
+                        uint2 w;
+                        w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(p01, of_b2));
+                        w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(p23, of_b2));
+                        *reinterpret_cast<uint2*>(g.adam_p16 + o) = w;
+                    }
                 }
             }
         }

@@ -81,6 +81,9 @@ FLAGS.define("clip_gradient_norm", 1.0, ":108")
 FLAGS.define("hidden1_factored_update", True, "build extension: the GPU trainer consumes hidden1_weights' gradient as the product "
              "descriptors^T . d(activation) it is (lpm_factored_clip_adam): the gradient is never written, the towers all-gather its "
              "two skinny factors instead of all-reducing it.  False: the generic path (gradient written into the arena)")
+FLAGS.define("hidden1_compute_copy", True, "build extension, netvlad_storage='bf16' with the factored update: hidden1_weights keeps a bf16 "
+             "compute copy beside its fp32 master (SURVEY section 7); the Adam epilogue writes it, the projection's forward and input-gradient "
+             "passes read it (2 bytes per weight instead of 4, one bf16 MFMA per product).  False: both stream the fp32 weight (A/B).")
 FLAGS.define("hidden1_early_update", True, "build extension, one tower with the factored update: clip + Adam of hidden1_weights run inside backward, "
              "right behind the projection's input gradient (the clip is per variable, utils.py:181-188: it needs only this variable's "
              "gradient factors), where the main queue would otherwise idle while the host enqueues the audio encoder's backward")

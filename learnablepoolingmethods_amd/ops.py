@@ -2040,10 +2040,17 @@ class _ProjectionParts(torch.autograd.Function):
         y = _empty((M, N), W)
         wsb = lib._lpm_proj_fwd_workspace_bytes(M, Kd, N)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=x1.device)
+        # bf16 storage with a compute copy of the weight attached (ops.ComputeCopy): both passes read the copy
+        cc = getattr(W, "_lpm_w16", None) if PROJ_W16 else None
+        ctx.w16 = cc.tensor(W) if (cc is not None and x1.dtype == torch.bfloat16) else None
         with _timed("proj_fwd", (M, Kd, N)):
-            lib.check(lib._lpm_proj_fwd_parts(ptr(x1), x1.stride(0), n1a, int(x1.dtype == torch.bfloat16), ptr(scale), int(ks), ptr(x2),
-                                              x2.stride(0) if x2 is not None else 0, ptr(W), M, Kd, N, ptr(y), ptr(ws), wsb, stream_ptr()),
-                      "lpm_proj_fwd_parts")
+            if ctx.w16 is not None:
+                lib.check(lib._lpm_proj_fwd_parts_w16(ptr(x1), x1.stride(0), n1a, ptr(scale), int(ks), ptr(x2), x2.stride(0) if x2 is not None else 0,
+                                                      ptr(ctx.w16), M, Kd, N, ptr(y), ptr(ws), wsb, stream_ptr()), "lpm_proj_fwd_parts_w16")
+            else:
+                lib.check(lib._lpm_proj_fwd_parts(ptr(x1), x1.stride(0), n1a, int(x1.dtype == torch.bfloat16), ptr(scale), int(ks), ptr(x2),
+                                                  x2.stride(0) if x2 is not None else 0, ptr(W), M, Kd, N, ptr(y), ptr(ws), wsb, stream_ptr()),
+                          "lpm_proj_fwd_parts")
         return y
 
     @staticmethod
@@ -2062,7 +2069,10 @@ class _ProjectionParts(torch.autograd.Function):
                 lib.check(lib._lpm_split_rows_tiles(ptr(dy), N, 1, M, N, ptr(dyt), st), "lpm_split_rows_tiles")
                 dx = _empty((M, Kd), W)
                 with _timed("proj_dx", (M, Kd, N)):
-                    lib.check(lib._lpm_proj_dx(ptr(dyt), ptr(W), M, Kd, N, ptr(dx), dx.stride(0), st), "lpm_proj_dx")
+                    if getattr(ctx, "w16", None) is not None and N % 64 == 0:
+                        lib.check(lib._lpm_proj_dx_w16(ptr(dyt), ptr(ctx.w16), M, Kd, N, ptr(dx), dx.stride(0), st), "lpm_proj_dx_w16")
+                    else:
+                        lib.check(lib._lpm_proj_dx(ptr(dyt), ptr(W), M, Kd, N, ptr(dx), dx.stride(0), st), "lpm_proj_dx")
             else:
                 dx = dy.matmul(W.t())
             dx1 = dx[:, :n1a]
@@ -2976,6 +2986,38 @@ def moe_cross_entropy(gate_act, expert_act, labels, num_mixtures, eps=10e-6):
     return _MoeCrossEntropy.apply(gate_act, expert_act, labels, int(num_mixtures), float(eps))
 
 
+class ComputeCopy:
+    """The bf16 compute copy of a weight beside its fp32 master (SURVEY section 7 hard part 2: "keep master fp32 + bf16 compute copy";
+    BASELINE configs[4]).  The owner (train.Trainer) attaches it to the variable as ``W._lpm_w16``; FactoredGradient.clip_adam keeps it
+    current from the update pass's epilogue (lpm_factored_clip_adam_copy), ops._ProjectionParts reads it.  Whatever else writes the
+    master -- a checkpoint load, an update that did not go through that kernel -- makes the copy stale: torch's version counter catches
+    writes through torch, ``invalidate()`` is for writes through raw pointers; a stale copy is rebuilt (one pass over the weight) at its
+    next use, never read."""
+
+    def __init__(self, W):
+        self.buf = torch.empty(W.shape, dtype=torch.bfloat16, device=W.device)
+        self.version = None
+        self.stale = True
+        self.refreshes = 0               # full rebuilds (diagnostics: a training run shows one -- the first use)
+
+    def invalidate(self):
+        self.stale = True
+
+    def tensor(self, W):
+        if self.stale or self.version != W._version:
+            self.buf.copy_(W.detach())                   # fp32 -> bf16, round to nearest even (the epilogue's rounding)
+            self.version, self.stale = W._version, False
+            self.refreshes += 1
+        return self.buf
+
+    def current(self, W):
+        """The buffer for the update pass to write, or None when the copy is stale anyway (it will be rebuilt from the new master)."""
+        return None if (self.stale or self.version != W._version) else self.buf
+
+
+PROJ_W16 = os.environ.get("LPM_PROJ_W16", "1") != "0"       # "0": the projection ignores an attached compute copy (A/B)
+
+
 class FactoredGradient:
     """The gradient of the hidden projection's weight as the product it is: dW = X^T DY with X [R, N1] the projection's input and
     DY [R, N2] the gradient of its output (R = clips).  ``put`` (called by _Projection.backward while ``armed``) keeps the two
@@ -3041,9 +3083,12 @@ class FactoredGradient:
                   "lpm_skinny_weight_grad_tiles")
         return out
 
-    def clip_adam(self, param, m, v, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, scratch=None):
-        """param / m / v: the variable's [N1 * N2] slices of the arenas.  -> scratch (its last four floats: clip factor, norm, -, -)."""
+    def clip_adam(self, param, m, v, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, scratch=None, param_bf16=None):
+        """param / m / v: the variable's [N1 * N2] slices of the arenas.  -> scratch (its last four floats: clip factor, norm, -, -).
+        param_bf16: the variable's bf16 compute copy (ComputeCopy.buf), rewritten from the update pass's epilogue."""
         lib = _capi.load()
+        if param_bf16 is not None:
+            return self._clip_adam_copy(lib, param, m, v, param_bf16, clip_norm, lr, step, beta1, beta2, eps, scratch)
         nb = lib._lpm_factored_clip_adam_scratch_bytes(self.N1, self.N2)
         if scratch is None or scratch.numel() * 4 < nb:
             scratch = torch.empty(nb // 4, dtype=torch.float32, device=param.device)
@@ -3074,6 +3119,32 @@ class FactoredGradient:
                                                       float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch), nb,
                                                       stream_ptr()), "lpm_factored_clip_adam")
         return scratch
+
+
+def _factored_clip_adam_copy(self, lib, param, m, v, param_bf16, clip_norm, lr, step, beta1, beta2, eps, scratch):
+    nb = lib._lpm_factored_clip_adam_scratch_bytes(self.N1, self.N2)
+    if scratch is None or scratch.numel() * 4 < nb:
+        scratch = torch.empty(nb // 4, dtype=torch.float32, device=param.device)
+    if param_bf16.dtype != torch.bfloat16 or param_bf16.numel() != self.N1 * self.N2 or not param_bf16.is_contiguous():
+        raise LpmError("FactoredGradient.clip_adam: the compute copy must be a contiguous bf16 tensor of the weight's size")
+    with _timed("factored_clip_adam", (self.R, self.N1, self.N2)):
+        x = ldx = gdt = None
+        quad = (FACTORED_NORM_QUADFORM and self.x is not None and self.x.shape[0] == self.R and self.R <= 128 and self.x.stride(1) == 1
+                and self.x.dtype == torch.float32)
+        tiles_only = (FACTORED_NORM_QUADFORM and self.x is None and self.x_in_tiles and self.dy is not None and self.dy.shape[0] == self.R
+                      and self.R <= 128 and os.environ.get("LPM_FQ_TILES", "1") != "0")
+        if tiles_only or quad:
+            G = torch.mm(self.dy, self.dy.t())
+            gdt = _tile_buffer(lib._lpm_row_tiles_bytes(1, self.R, self.R), G)
+            lib.check(lib._lpm_split_rows_tiles(ptr(G), self.R, 1, self.R, self.R, ptr(gdt), stream_ptr()), "lpm_split_rows_tiles")
+            x, ldx = (self.xt, self.N1) if tiles_only else (self.x, self.x.stride(0))
+        lib.check(lib._lpm_factored_clip_adam_copy(ptr(self.xt), ptr(self.dyt), ptr(x), ldx or 0, ptr(gdt), self.R, self.N1, self.N2,
+                                                   ptr(param), ptr(m), ptr(v), ptr(param_bf16), float(clip_norm), float(lr), beta1, beta2, eps,
+                                                   int(step), ptr(scratch), nb, stream_ptr()), "lpm_factored_clip_adam_copy")
+    return scratch
+
+
+FactoredGradient._clip_adam_copy = _factored_clip_adam_copy
 
 
 def clip_adam_step(param, grad, m, v, offsets, ntensors, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8,

@@ -468,6 +468,7 @@ class Trainer:
         self.sync: Optional[GradientSynchronizer] = None
         self.bucket_gather = None
         self.factored = None
+        self.w16 = None              # ops.ComputeCopy of hidden1_weights (netvlad_storage='bf16' with the factored update)
         self.sharded: Optional[ShardedVariableUpdate] = None
         self.weight_pack = ops.WeightPack() if self.device.type == "cuda" else None
         # FLAGS.dense_arithmetic: the encoders' dense GEMMs on fp16 planes (three-term forward, two-term input gradients, one-term weight
@@ -548,6 +549,7 @@ class Trainer:
         early = (lambda: self.sync.launch(0)) if self.sync.active else None
         h1 = "tower/hidden1_weights"
         self.factored = None
+        self.w16 = None              # ops.ComputeCopy of hidden1_weights (netvlad_storage='bf16' with the factored update)
         self.sharded = None
         # beyond hidden1_factored_max_towers (or from hidden1_sharded_min_towers on): route C, the sharded update
         shard_from = FLAGS.hidden1_sharded_min_towers or (FLAGS.hidden1_factored_max_towers + 1)
@@ -587,6 +589,10 @@ class Trainer:
             # exchange its two skinny factors instead of all-reducing the gradient, which is never written
             self.factored = ops.FactoredGradient(on_put=self._factored_put, strict=self.sync.active)
             self.arena.views[h1]._lpm_factored = self.factored
+            if FLAGS.netvlad_storage == "bf16" and FLAGS.hidden1_compute_copy and self.device.type == "cuda":
+                # master fp32 + bf16 compute copy (+2 bytes per weight: 1.1 GB at cfg-5); the update pass keeps it current
+                self.w16 = ops.ComputeCopy(self.arena.views[h1])
+                self.arena.views[h1]._lpm_w16 = self.w16
             n1 = self.arena.offsets_host[1]
             self._tail_offsets = (self.arena.offsets[1:] - n1).contiguous()
             self._factored_scratch = self._tail_scratch = None
@@ -717,9 +723,11 @@ class Trainer:
                 assert early["lr"] == lr and early["step"] == self.global_step     # (the update ran inside backward with these)
             else:
                 self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, lr, self.global_step,
-                                                      scratch=self._factored_scratch)           # :332-336 for hidden1_weights
+                                                      scratch=self._factored_scratch, param_bf16=self._w16_current())   # :332-336 for hidden1_weights
             self._early = None
         else:
+            if self.w16 is not None:
+                self.w16.invalidate()          # the generic update writes the master through raw pointers: the copy is rebuilt at its next use
             self.arena._scratch = ops.clip_adam_step(self.arena.param, self.arena.grad, self.arena.m, self.arena.v,
                                                      self.arena.offsets, len(self.arena.names), self.clip, lr,
                                                      self.global_step, scratch=self.arena._scratch)  # :332-336
@@ -789,6 +797,12 @@ class Trainer:
         a0, _ = self.arena.segment(name)
         return self.arena.grad[a0:a0 + t.numel()].view(t.shape)
 
+    def _w16_current(self):
+        """hidden1_weights' bf16 compute copy for the update pass to rewrite (None: there is none, or it is stale and will be rebuilt)."""
+        if self.w16 is None:
+            return None
+        return self.w16.current(self.arena.views[self.arena.names[0]])
+
     def _sharded_ready(self):
         """hidden1_weights' gradient is complete in the arena (called from the projection's backward, and again after backward)."""
         self.sharded.launch()
@@ -805,7 +819,7 @@ class Trainer:
                 a = self.arena
                 k = a.views[a.names[0]].numel()
                 self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, early["lr"], early["step"],
-                                                      scratch=self._factored_scratch)           # :332-336 for hidden1_weights, early
+                                                      scratch=self._factored_scratch, param_bf16=self._w16_current())   # :332-336, early
                 early["done"] = True
             return
         n = dist.get_world_size(self.group)

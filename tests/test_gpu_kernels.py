@@ -1139,6 +1139,84 @@ def test_projection_parts_bf16_sums_behind_a_handle():
     assert_close(W.grad, x64.t() @ dy64, 2e-5, "dW")
 
 
+@pytest.mark.parametrize("B,D,K,NA,H", [(32, 128, 128, 256, 512), (128, 128, 512, 128 * 16, 1024), (80, 64, 96, 0, 512), (7, 64, 64, 64, 576)])
+def test_projection_from_the_bf16_compute_copy(B, D, K, NA, H):
+    """bf16 storage with a bf16 COMPUTE COPY of the projection weight ("master fp32 + bf16 compute copy"; BASELINE
+    configs[4]; frame_level_models.py:2309-2319): forward and input gradient read ops.ComputeCopy's buffer -- y = bf16(x1 * scale | x2) .
+    bf16(W), dx = bf16(dy) . bf16(W)^T with fp32 accumulation, held to the fp64 product of the SAME rounded operands (1e-5: only the
+    accumulation differs) and to the exact product at the bf16 tolerance; the weight gradient keeps its own path (exact operands).
+    H = 576 is not a multiple of 64... of 512: the projection stream does not take it and nothing changes."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(B + H)
+    raw = (torch.randn(B, D * K, generator=g) * 3).to(dev).to(torch.bfloat16)
+    scale = (torch.rand(B, K, generator=g) + 0.5).to(dev) / (D * K) ** 0.5
+    x2 = (torch.randn(B, NA, generator=g) / NA ** 0.5).to(dev).requires_grad_(True) if NA else None
+    Kd = D * K + NA
+    W = (torch.randn(Kd, H, generator=g) / Kd ** 0.5).to(dev).requires_grad_(True)
+    dy = torch.randn(B, H, generator=g).to(dev)
+    handle = torch.full((B, D * K), float("nan"), device=dev).requires_grad_(True)
+    handle._lpm_row_scale, handle._lpm_scale_ks, handle._lpm_raw = scale, K, raw
+    if not ops.projection_parts_ok(raw, scale, K, x2, W):
+        assert H % 512 != 0
+        return
+    cc = ops.ComputeCopy(W)
+    W._lpm_w16 = cc
+    y = ops.projection_parts(handle, x2, W)
+    y.backward(dy)
+    assert cc.refreshes == 1 and torch.equal(cc.buf, W.detach().to(torch.bfloat16))
+    bf = lambda t: t.to(torch.bfloat16).double().cpu()
+    xm = (raw.float().view(B, D, K) * scale.unsqueeze(1)).reshape(B, D * K)          # fp32, as the loader forms it
+    xr = torch.cat([bf(xm), bf(x2.detach())], 1) if NA else bf(xm)
+    xe = torch.cat([xm.double().cpu(), x2.detach().double().cpu()], 1) if NA else xm.double().cpu()
+    Wr, We = bf(W.detach()), W.detach().double().cpu()
+    assert_close(y, xr @ Wr, 1e-5, "y vs the rounded operands")
+    assert_close(y, xe @ We, 1e-2, "y vs exact")
+    dxr = bf(dy) @ Wr.t()
+    assert_close(handle.grad, dxr[:, :D * K], 1e-5, "dx1 vs the rounded operands")
+    assert_close(handle.grad, (dy.double().cpu() @ We.t())[:, :D * K], 1e-2, "dx1 vs exact")
+    if NA:
+        assert_close(x2.grad, dxr[:, D * K:], 1e-5, "dx2 vs the rounded operands")
+    assert_close(W.grad, xe.t() @ dy.double().cpu(), 2e-5, "dW (exact operands, its own path)")
+    # a write to the master through torch makes the copy stale: rebuilt at the next use, never read
+    with torch.no_grad():
+        W.mul_(0.5)
+    y2 = ops.projection_parts(handle, x2, W)
+    assert cc.refreshes == 2
+    assert_close(y2, 0.5 * (xr @ Wr), 1e-5, "y after a write to the master")
+    del W._lpm_w16
+
+
+def test_factored_update_keeps_the_bf16_compute_copy():
+    """lpm_factored_clip_adam_copy: the update pass of the factored gradient (utils.py:170-189 per-variable clip, TF-Adam) writes bf16(new
+    weight) beside the fp32 master from its epilogue -- master and moments bit-identical to the pass without a copy, the copy exactly
+    the rounded master, on both norm routes (quadratic forms over the tiles / the GEMM pass)."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    R, N1, N2 = 128, 4096 + 96, 1024
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(R, N1, generator=g) / N1 ** 0.5).to(dev)
+    dy = torch.randn(R, N2, generator=g).to(dev)
+    p0 = (torch.randn(N1 * N2, generator=g) / 30).to(dev)
+    m0, v0 = (torch.randn(N1 * N2, generator=g) * 1e-3).to(dev), (torch.rand(N1 * N2, generator=g) * 1e-5).to(dev)
+    for quad in (True, False):
+        res = []
+        for copy in (False, True):
+            fg = ops.FactoredGradient()
+            fg.put(x, dy)
+            if not quad:
+                fg.x = fg.dy = None
+            p, m, v = p0.clone(), m0.clone(), v0.clone()
+            c16 = torch.full((N1, N2), float("nan"), dtype=torch.bfloat16, device=dev) if copy else None
+            fg.clip_adam(p, m, v, 1.0, 2e-4, 3, param_bf16=c16)
+            res.append((p, m, v, c16))
+        (p_a, m_a, v_a, _), (p_b, m_b, v_b, c16) = res
+        # (without a copy this shape takes the tile-GEMM form as well: N2 x steps is beyond the whole-row form)
+        assert torch.equal(p_a, p_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b), f"quad={quad}: the copy changed the update"
+        assert torch.equal(c16.reshape(-1), p_b.to(torch.bfloat16)), f"quad={quad}: the copy is not the rounded master"
+        assert not torch.equal(p_b, p0)
+
+
 @pytest.mark.parametrize("B,T,D,K", [(3, 70, 256, 128), (3, 70, 256, 256), (2, 300, 1024, 256)])
 def test_vlad_aggregate_lazy_matches_the_finalize_form(B, T, D, K):
     """NetVladAttenCluster's tail (video_pooling_modules.py:1641-1658) as the lazily normalised d-major descriptor: the un-normalised sums

@@ -688,6 +688,42 @@ def test_cfg5_layer_sizes_reduced_batch(storage):
     print(f"[cfg-5 {storage} B={B}] " + ", ".join(f"{k}: {v:.1e}" for k, v in errs.items()) + f"; worst gradient {worst[0]:.2e} ({worst[1]})")
 
 
+def test_cfg5_keeps_a_bf16_compute_copy_of_hidden1_weights():
+    """SURVEY section 7 hard part 2 ("keep master fp32 + bf16 compute copy"), BASELINE configs[4]: with bf16 storage and the factored
+    update the trainer attaches ops.ComputeCopy to hidden1_weights; the Adam epilogue rewrites it every step (ONE full rebuild in a run:
+    the first use), it is always exactly bf16(master), and three steps with it follow three steps that stream the fp32 weight
+    (FLAGS.hidden1_compute_copy = False) within the bf16 tolerance of this configuration."""
+    from learnablepoolingmethods_amd import FLAGS
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", vocab_size=3862, base_learning_rate=2e-4, **CFG5)
+    B = 16
+    x, nf, lab = O.make_synthetic_batch(B, 300, 1152, cfg.vocab_size, seed=6)
+    p = _well_conditioned({k: v.double() for k, v in O.init_params(cfg, 1152, seed=1006).items()})
+    res = {}
+    for copy in (True, False):
+        try:
+            FLAGS.hidden1_compute_copy = copy
+            tr = _cfg5_trainer(B, dev, "bf16")
+            tr.build(x, nf, lab)
+            tr.store.load({"tower/" + k: v for k, v in p.items()})
+            losses = [float(tr.step(x, nf, lab)["loss"]) for _ in range(3)]
+            W = tr.arena.views["tower/hidden1_weights"]
+            if copy:
+                assert tr.w16 is not None and tr.w16.refreshes == 1, "the copy is rebuilt once (first use), then kept by the update pass"
+                torch.cuda.synchronize()
+                assert torch.equal(tr.w16.buf, W.detach().to(torch.bfloat16)), "the copy is bf16(master) after every step"
+            else:
+                assert tr.w16 is None
+            res[copy] = (losses, W.detach().clone(), tr.predict(x, nf).detach().clone() if hasattr(tr, "predict") else None)
+        finally:
+            FLAGS.reset()
+    la, lb = res[True][0], res[False][0]
+    print(f"[cfg-5 compute copy] losses with the copy {la}, streaming fp32 {lb}")
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= CFG5_FWD_TOL * abs(b) + 1e-3
+    assert rel_l2(res[True][1], res[False][1]) <= 1e-3, "three Adam steps of 2e-4: the two masters stay together"
+
+
 def test_cfg5_bf16_storage_survives_the_gamma_watch_switching_off():
     """once min |gamma| of input_bn falls below the watch's floor the closed-form gamma / beta gradients are switched
     off; under bf16 storage (frames written as operand tiles only, no input-gradient path) the step must then fall back to fp32
