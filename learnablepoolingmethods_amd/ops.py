@@ -2994,8 +2994,11 @@ class ComputeCopy:
     writes through torch, ``invalidate()`` is for writes through raw pointers; a stale copy is rebuilt (one pass over the weight) at its
     next use, never read."""
 
-    def __init__(self, W):
+    def __init__(self, W, also=()):
+        """also: other tensors over the same memory whose in-place writes must be seen as well (the trainer's flat parameter arena: a
+        variable is a view of it with a version counter of its own -- found by tools/determinism_check.py, which resets the ARENA)."""
         self.buf = torch.empty(W.shape, dtype=torch.bfloat16, device=W.device)
+        self.also = tuple(also)
         self.version = None
         self.stale = True
         self.refreshes = 0               # full rebuilds (diagnostics: a training run shows one -- the first use)
@@ -3003,16 +3006,20 @@ class ComputeCopy:
     def invalidate(self):
         self.stale = True
 
+    def _versions(self, W):
+        return (W._version,) + tuple(t._version for t in self.also)
+
     def tensor(self, W):
-        if self.stale or self.version != W._version:
+        v = self._versions(W)
+        if self.stale or self.version != v:
             self.buf.copy_(W.detach())                   # fp32 -> bf16, round to nearest even (the epilogue's rounding)
-            self.version, self.stale = W._version, False
+            self.version, self.stale = v, False
             self.refreshes += 1
         return self.buf
 
     def current(self, W):
         """The buffer for the update pass to write, or None when the copy is stale anyway (it will be rebuilt from the new master)."""
-        return None if (self.stale or self.version != W._version) else self.buf
+        return None if (self.stale or self.version != self._versions(W)) else self.buf
 
 
 PROJ_W16 = os.environ.get("LPM_PROJ_W16", "1") != "0"       # "0": the projection ignores an attached compute copy (A/B)

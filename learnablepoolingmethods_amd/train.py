@@ -591,7 +591,7 @@ class Trainer:
             self.arena.views[h1]._lpm_factored = self.factored
             if FLAGS.netvlad_storage == "bf16" and FLAGS.hidden1_compute_copy and self.device.type == "cuda":
                 # master fp32 + bf16 compute copy (+2 bytes per weight: 1.1 GB at cfg-5); the update pass keeps it current
-                self.w16 = ops.ComputeCopy(self.arena.views[h1])
+                self.w16 = ops.ComputeCopy(self.arena.views[h1], also=(self.arena.param,))
                 self.arena.views[h1]._lpm_w16 = self.w16
             n1 = self.arena.offsets_host[1]
             self._tail_offsets = (self.arena.offsets[1:] - n1).contiguous()
