@@ -153,9 +153,14 @@ __device__ __forceinline__ void t3_split2(float a, float b, unsigned& hi, unsign
 // carries two consecutive frame steps where the split form carries the two planes of one step, and a product is one MFMA.
 // (Round 5: this form runs the video stream of BASELINE configs[4] in 98 us = 0.32 of the HBM peak -- the 52 us quoted in rounds 3
 // and 4 averaged the audio stream's 10 us launches in; the timing sites below now take video launches only.  A 256 x 256 form --
-// one workgroup per CU, assignment tiles 4 x and frame tiles 2 x instead of 8 x and 4 x, six fragment reads per eight MFMAs, 8-byte
-// stores straight from transposed accumulators -- was built, passed every bf16-storage test and ran at 124 us: four rounds of
-// latency-bound workgroups with nothing to overlap their prologue and their 32-byte-per-row epilogue accesses; removed again.)
+// one workgroup per CU, assignment tiles 4 x and frame tiles 2 x instead of 8 x and 4 x, six fragment reads per eight MFMAs -- was
+// built twice and passed every bf16-storage test both times: as 1 024 workgroups (four rounds, every prologue and epilogue exposed)
+// 124 us; as 256 persistent workgroups walking four tiles each with the DMA ring running across the tile boundaries 103 us (after
+// two compiler traps: per-stage 64-bit lane pointers get s_waitcnt vmcnt(0) in front of the reuse of their registers -- buffer loads
+// with scalar offsets instead --, and 64 hoisted epilogue pointers spill, a scratch reload behind every DMA issue).  It moves half the
+// bytes into LDS but with one workgroup per CU nothing shares them in TIME: a clip's re-reads are 25 us apart, miss the XCD's L2 and
+// come back from the fabric at ~3 TB/s, where this form's neighbours (same clip, same cluster slab, consecutive on one XCD, three
+// workgroups per CU) ask for the same tile within microseconds.  Removed again; what helps is the clip-wide form of vlad_clip.hip.)
 template <bool FUSED, int PL, bool SMX = false>
 __global__ __launch_bounds__(512, SMX ? 4 : 6) void vlad_aggregate_tiles3_kernel(
     const uint4* __restrict__ at, const uint4* __restrict__ xt, const float* __restrict__ centres, int T, int D, int K,
