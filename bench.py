@@ -342,6 +342,7 @@ def main():
     if os.environ.get("LPM_SINGLE_STREAM") == "1":     # profiling only: per-kernel durations without a concurrent neighbour
         from learnablepoolingmethods_amd import FLAGS as _flags
         _flags.audio_side_stream = False
+        _flags.hidden1_update_stream = False
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)

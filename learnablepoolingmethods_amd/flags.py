@@ -87,6 +87,12 @@ FLAGS.define("hidden1_compute_copy", True, "build extension, netvlad_storage='bf
 FLAGS.define("hidden1_early_update", True, "build extension, one tower with the factored update: clip + Adam of hidden1_weights run inside backward, "
              "right behind the projection's input gradient (the clip is per variable, utils.py:181-188: it needs only this variable's "
              "gradient factors), where the main queue would otherwise idle while the host enqueues the audio encoder's backward")
+FLAGS.define("hidden1_update_stream", "auto", "build extension, with hidden1_early_update: the update pass of hidden1_weights (HBM-bound: 24-26 bytes "
+             "per weight) runs on a HIP stream of its own behind the projection's input gradient, UNDER the rest of backward; the step joins it "
+             "before it returns.  Measured, alternating on one box: cfg-5 (the gated model: the rest of backward is K3's latency-bound "
+             "kernels) 5.495 -> 5.351 ms; cfg-2 (the rest is the encoders' power-limited GEMMs, which the extra HBM traffic slows) 6.64 -> "
+             "6.70 ms.  'auto': on for netvlad_storage='bf16' (the configuration whose update pass is half the step), off otherwise; "
+             "True / False force it")
 FLAGS.define("direct_weight_gradients", True, "build extension: single-GPU training writes the encoders' dense-kernel gradients straight "
              "into the gradient arena from their producers (ops._dw_x3) instead of through autograd's .grad + a gather copy")
 FLAGS.define("hidden1_factored_max_towers", 4, "build extension: ... up to this many towers.  Both passes of the factored update multiply "

@@ -10,6 +10,7 @@ clip + TF-style Adam is one fused multi-tensor HIP kernel over the arena.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 from typing import Dict, List, Optional
@@ -469,6 +470,7 @@ class Trainer:
         self.bucket_gather = None
         self.factored = None
         self.w16 = None              # ops.ComputeCopy of hidden1_weights (netvlad_storage='bf16' with the factored update)
+        self._update_stream, self._update_joined = None, True
         self.sharded: Optional[ShardedVariableUpdate] = None
         self.weight_pack = ops.WeightPack() if self.device.type == "cuda" else None
         # FLAGS.dense_arithmetic: the encoders' dense GEMMs on fp16 planes (three-term forward, two-term input gradients, one-term weight
@@ -731,6 +733,7 @@ class Trainer:
             self.arena._scratch = ops.clip_adam_step(self.arena.param, self.arena.grad, self.arena.m, self.arena.v,
                                                      self.arena.offsets, len(self.arena.names), self.clip, lr,
                                                      self.global_step, scratch=self.arena._scratch)  # :332-336
+        self._join_update_stream()
         return {"loss": label_loss.detach(), "predictions": predictions.detach(), "learning_rate": lr,
                 "global_step": self.global_step}
 
@@ -797,6 +800,27 @@ class Trainer:
         a0, _ = self.arena.segment(name)
         return self.arena.grad[a0:a0 + t.numel()].view(t.shape)
 
+    def _update_stream_for(self, fg):
+        """The HIP stream hidden1_weights' early update runs on (FLAGS.hidden1_update_stream): it waits for everything queued so far on the
+        current stream -- the projection's input gradient, the factors' tiles -- and the step joins it before it returns
+        (_join_update_stream): nothing on the main stream touches the variable, its moments or its compute copy in between."""
+        if self.device.type != "cuda":
+            return None
+        if self._update_stream is None:
+            self._update_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        self._update_stream.wait_stream(main)
+        for t in (fg.xt, fg.dyt, fg.x, fg.dy, self._factored_scratch):
+            if t is not None:
+                t.record_stream(self._update_stream)
+        self._update_joined = False
+        return self._update_stream
+
+    def _join_update_stream(self):
+        if self._update_stream is not None and not self._update_joined:
+            torch.cuda.current_stream().wait_stream(self._update_stream)
+            self._update_joined = True
+
     def _w16_current(self):
         """hidden1_weights' bf16 compute copy for the update pass to rewrite (None: there is none, or it is stale and will be rebuilt)."""
         if self.w16 is None:
@@ -818,8 +842,14 @@ class Trainer:
             if early is not None and not early["done"]:
                 a = self.arena
                 k = a.views[a.names[0]].numel()
-                self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, early["lr"], early["step"],
-                                                      scratch=self._factored_scratch, param_bf16=self._w16_current())   # :332-336, early
+                want = FLAGS.hidden1_update_stream
+                want = (FLAGS.netvlad_storage == "bf16") if want == "auto" else bool(want)
+                if os.environ.get("LPM_UPDATE_STREAM") in ("0", "1"):          # A/B
+                    want = os.environ["LPM_UPDATE_STREAM"] == "1"
+                us = self._update_stream_for(fg) if want else None
+                with (torch.cuda.stream(us) if us is not None else contextlib.nullcontext()):
+                    self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, early["lr"], early["step"],
+                                                          scratch=self._factored_scratch, param_bf16=self._w16_current())   # :332-336, early
                 early["done"] = True
             return
         n = dist.get_world_size(self.group)
