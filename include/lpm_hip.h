@@ -71,6 +71,10 @@ const char* lpm_last_error(void);
  * as rocprofv3 --kernel-trace reports it.  lpm_kernel_timing_read synchronises, returns up to `max` durations (ms) of `tag`
  * in launch order and releases their events. */
 void lpm_kernel_timing_enable(int on);
+/* K1's hand-scheduled forward forms (csrc/assign_flat.hip) can be switched off for the process: bit 0 the flat 96-row forms, bit 1 the
+ * 160 x 512 plain-bf16 form; lpm_assign_gemm_tiles_fwd[_bf16] then take the tile-GEMM form.  Returns the previous mask.  The Python host
+ * checks every form against the tile-GEMM form once per process (ops._k1_selfcheck) and uses this if they ever disagree. */
+int lpm_k1_forms_disable(int mask);
 int lpm_kernel_timing_read(int tag, float* ms, int max);
 
 /* Measurement only: the shader clock over time.  lpm_clock_sampler launches ONE wave that stores, every `period_ticks` ticks of the

@@ -22,9 +22,16 @@
 // LDS-DMA loads and register loads retire in order on one counter (vmcnt): every wave issues them in a fixed order -- per step
 // [A piece of step s + NS (waves 0-5)] [B hi, B lo of step s + DB] -- and waits with hand-counted immediates; the ring and the registers
 // are read by inline assembly behind those waits (the compiler puts vmcnt(0) in front of LDS reads it can see next to an LDS-DMA).
+#include <atomic>
 #include "tile_gemm.h"
 
 namespace lpm {
+
+// Process-wide mask of K1 forward forms switched OFF at run time (lpm_k1_forms_disable; bit 0: the flat 96-row forms, bit 1: the
+// 160 x 512 plain-bf16 form).  The hand-scheduled forms hand registers to asynchronous loads behind hand-counted waits (below): the
+// host side checks each against the tile-GEMM form once per process on a small problem (ops._k1_selfcheck) and switches a
+// form off -- loudly -- if a toolchain change ever makes it disagree; the ISA scan of tests/test_build_flags.py is the build-time half.
+static std::atomic<int> g_k1_forms_off{0};
 
 constexpr int AF_KSTEP = 6 * 1024;         // A bytes per reduction step: three row tiles x (hi, lo)
 constexpr int AF_ROWS = 96;
@@ -559,7 +566,7 @@ bool assign_wide_ok(int B, int T, int MT, int D, int K, int nblk) {
     static const int on = [] { const char* e = getenv("LPM_K1_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
     const int DS = D / 32;
     const int64_t M = (int64_t)B * T;
-    return on && D % 128 == 0 && DS / 4 >= 3 && K % 512 == 0 && K > 0 && M < ((int64_t)1 << 31) && (M + AW_ROWS - 1) / AW_ROWS <= nblk &&
+    return on && !(g_k1_forms_off.load(std::memory_order_relaxed) & 2) && D % 128 == 0 && DS / 4 >= 3 && K % 512 == 0 && K > 0 && M < ((int64_t)1 << 31) && (M + AW_ROWS - 1) / AW_ROWS <= nblk &&
            (int64_t)B * MT * DS * 128 < ((int64_t)1 << 31);
 }
 int assign_wide_launch(const void* xr, const void* wt, int B, int T, int MT, int D, int K, void* logits_bf16, float* stats, int nblk,
@@ -607,7 +614,7 @@ static int af_enabled() {
         const char* e = getenv("LPM_K1_FLAT");         // 0: the 128-row tile GEMM form (A/B switch)
         return (e && e[0] == '0') ? 0 : 1;
     }();
-    return on;
+    return on && !(g_k1_forms_off.load(std::memory_order_relaxed) & 1);
 }
 
 // steps per stage (LPM_K1_KB = 1, 2, 4) and steps of B fragments in flight (LPM_K1_DB = 4; 8 with four steps per stage): A/B switches
@@ -669,3 +676,7 @@ int assign_flat_launch(const void* xr, const void* wt, int B, int T, int MT, int
 }
 
 }  // namespace lpm
+
+// mask: bit 0 the flat 96-row K1 forms, bit 1 the 160 x 512 plain-bf16 form; returns the previous mask.  Process-wide, like
+// lpm_kernel_timing_enable: set it from one thread before the launches it is meant for.
+extern "C" int lpm_k1_forms_disable(int mask) { return lpm::g_k1_forms_off.exchange(mask & 3); }

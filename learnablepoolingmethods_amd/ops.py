@@ -456,6 +456,73 @@ def frame_sample_bn(raw, num_frames, S, gamma=None, beta=None, moving_mean=None,
 # ----------------------------------------------------------------------------------------------
 # K1 + K2 (+K3): NetVLAD pooling
 # ----------------------------------------------------------------------------------------------
+_K1_CHECKED = set()
+K1_SELFCHECK = os.environ.get("LPM_K1_SELFCHECK", "1") != "0"
+
+
+def _k1_selfcheck(lib, planes, dev):
+    """Once per process and operand form: K1's hand-scheduled forward kernels (csrc/assign_flat.hip: registers handed to asynchronous loads
+    behind hand-counted waits) against the tile-GEMM form of the SAME entry point on a small problem -- logits to 2e-5 of their
+    maximum (fp32; two bf16 ulps for bf16 storage), statistics to 1e-5.  A form that disagrees is switched off for the
+    process (lpm_k1_forms_disable) with a warning: a toolchain change that breaks the inline-assembly register hand-over turns into a
+    slower step, not into wrong logits (tests/test_build_flags.py is the build-time half of this)."""
+    if not K1_SELFCHECK or planes in _K1_CHECKED:
+        return
+    _K1_CHECKED.add(planes)
+    import warnings
+    B, T, D = 3, 120, 1024                               # 360 rows: three clips straddled by the row groups, a partial last group
+    g = torch.Generator(device="cpu").manual_seed(20251)
+    x = torch.randn(B * T, D, generator=g).to(dev)
+    st = stream_ptr()
+    prev = lib._lpm_k1_forms_disable(0)                   # (an earlier check's verdict stays in force: restored below)
+    try:
+        for K, bit in ((256, 1), (512, 2)) if planes == 1 else ((256, 1),):
+            W = (torch.randn(D, K, generator=g) / 32).to(dev)
+            nblk = lib._lpm_assign_gemm_tiles_nblk(B, T)
+            if planes == 2:
+                xr = torch.empty(lib._lpm_row_tiles_bytes(B, T, D) // 4, dtype=torch.int32, device=dev)
+                wt = torch.empty(lib._lpm_weight_tiles_bytes(D, K) // 4, dtype=torch.int32, device=dev)
+                lib.check(lib._lpm_split_rows_tiles(ptr(x), D, B, T, D, ptr(xr), st), "lpm_split_rows_tiles")
+                lib.check(lib._lpm_split_weight_tiles(ptr(W), D, K, 0, ptr(wt), st), "lpm_split_weight_tiles")
+                run = lambda lg, pt: lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(lg), ptr(pt), st), "lpm_assign_gemm_tiles_fwd")
+                dt = torch.float32
+            else:
+                # plain bf16 row tiles come from the frame pass (lpm_frame_apply_tiles_bf16: identity sampling, unit affine), into buffers of
+                # this check's own -- the step's tile cache (_XT_CACHE) is not touched
+                raw = torch.cat([x.view(B, T, D), torch.zeros(B, T, 128, device=dev)], 2).contiguous()
+                nfr = torch.full((B,), T, dtype=torch.int32, device=dev)
+                one, zero = torch.ones(D + 128, device=dev), torch.zeros(D + 128, device=dev)
+                nb = lambda d: torch.empty(lib._lpm_frame_tiles_bf16_bytes(B, T, d) // 4, dtype=torch.int32, device=dev)
+                xtv, xr, xta, xra = nb(D), nb(D), nb(128), nb(128)
+                lib.check(lib._lpm_frame_apply_tiles_bf16(ptr(raw), ptr(nfr), B, T, D + 128, T, ptr(one), ptr(zero), None, ptr(xtv), ptr(xr), D,
+                                                          ptr(xta), ptr(xra), 128, st), "lpm_frame_apply_tiles_bf16")
+                wt = torch.empty(lib._lpm_weight_tiles_bytes(D, K) // 8, dtype=torch.int32, device=dev)
+                lib.check(lib._lpm_split_weight_tiles_bf16(ptr(W), D, K, 0, ptr(wt), st), "lpm_split_weight_tiles_bf16")
+                run = lambda lg, pt: lib.check(lib._lpm_assign_gemm_tiles_fwd_bf16(ptr(xr), ptr(wt), B, T, D, K, ptr(lg), ptr(pt), st),
+                                               "lpm_assign_gemm_tiles_fwd_bf16")
+                dt = torch.bfloat16
+            res = []
+            for mask in (prev & 3, 3):                      # the forms in force; every hand-scheduled form off
+                lib._lpm_k1_forms_disable(mask)
+                lg = torch.zeros((B * T, K), dtype=dt, device=dev)
+                pt = torch.zeros((nblk, 2, K), dtype=torch.float32, device=dev)
+                run(lg, pt)
+                res.append((lg, pt.sum(0)))
+            (la, sa), (lb, sb) = res
+            # (the forms order a step's three split-bf16 products differently: fp32 rounding apart, 1e-6; a bf16 result may land one ulp
+            # apart.  A broken register hand-over gives garbage, orders of magnitude beyond either)
+            tol = 2e-5 if planes == 2 else 2.0 ** -7
+            ok = (bool(((la.float() - lb.float()).abs() <= tol * lb.float().abs().max()).all())
+                  and bool(((sa - sb).abs() <= 1e-5 * sb.abs().max()).all()))
+            if not ok:
+                prev |= bit
+                warnings.warn(f"learnablepoolingmethods_amd: K1's hand-scheduled forward kernel ({'split-bf16' if planes == 2 else 'plain bf16'}, "
+                              f"K={K}) disagrees with the tile-GEMM form on the self-check problem; it is switched OFF for this process "
+                              "(slower, correct).  Rebuild with the pinned toolchain and run tests/test_build_flags.py.")
+    finally:
+        lib._lpm_k1_forms_disable(prev & 3)
+
+
 def _cached_tiles(x, B, T, D, rows=False, storage="f32"):
     """The tile copy written by frame_sample_bn, if ``x`` is the rgb / audio column slice of its latest output.  rows: the row
     tiles (K1's operand; bf16 storage only) instead of the frame tiles."""
@@ -737,6 +804,7 @@ class _NetVLAD(torch.autograd.Function):
             # preparation earlier, they come from HBM (54.8 us; measured in one process, LPM_WEIGHT_PACK A/B, round 4).  (Reading them into every XCD's L2 with
             # a small launch in front of K1 on top of that: no effect, 43.5-45.2 vs 43.9-44.6 us.)
             wt = _weight_tiles(W, D, K, False, x, pack=False)
+            _k1_selfcheck(lib, 2, x.device)
             with _timed("assign_gemm_fwd", (M, D, K)):
                 lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st),
                           "lpm_assign_gemm_tiles_fwd")
@@ -804,6 +872,7 @@ class _NetVLAD(torch.autograd.Function):
         wt = _tile_buffer(lib._lpm_weight_tiles_bytes(D, K) // 2, W)
         lib.check(lib._lpm_split_weight_tiles_bf16(ptr(W), D, K, 0, ptr(wt), st), "lpm_split_weight_tiles_bf16")
         logits = torch.empty((M, K), dtype=torch.bfloat16, device=W.device)
+        _k1_selfcheck(lib, 1, W.device)
         with _timed("assign_gemm_fwd", (M, D, K)):
             lib.check(lib._lpm_assign_gemm_tiles_fwd_bf16(ptr(xr), ptr(wt), B, T, D, K, ptr(logits), ptr(partial), st),
                       "lpm_assign_gemm_tiles_fwd_bf16")

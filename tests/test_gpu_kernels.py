@@ -1653,6 +1653,53 @@ def test_k1_plain_bf16_at_k512(B, T):
     assert_close(partial[:, 1].sum(0), (ref * ref).sum(0), 1e-4, "column square sums")
 
 
+def test_k1_selfcheck_passes_and_the_form_switch_works():
+    """ops._k1_selfcheck: K1's hand-scheduled forward kernels against the tile-GEMM form of the same entry point, once per
+    process -- on this build they agree (no warning, no form switched off); lpm_k1_forms_disable(3) really routes the entry
+    points to the tile-GEMM form (the check would otherwise compare a kernel with itself)."""
+    import warnings
+    from learnablepoolingmethods_amd import _capi, ops
+    lib = _capi.load()
+    dev = cuda()
+    assert lib._lpm_k1_forms_disable(0) == 0, "no form is switched off on a good build"
+    ops._K1_CHECKED.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ops._k1_selfcheck(lib, 2, dev)
+        ops._k1_selfcheck(lib, 1, dev)
+    assert ops._K1_CHECKED == {1, 2} and lib._lpm_k1_forms_disable(0) == 0
+    # the switch changes the kernel that runs: the same call, timed, with and without the flat form (cfg-2's video shape)
+    from learnablepoolingmethods_amd._capi import ptr, stream_ptr
+    B, T, D, K = 80, 300, 1024, 256
+    x = torch.randn(B * T, D, device=dev)
+    W = torch.randn(D, K, device=dev) / 32
+    st = stream_ptr()
+    xr = torch.empty(lib._lpm_row_tiles_bytes(B, T, D) // 4, dtype=torch.int32, device=dev)
+    wt = torch.empty(lib._lpm_weight_tiles_bytes(D, K) // 4, dtype=torch.int32, device=dev)
+    lib.check(lib._lpm_split_rows_tiles(ptr(x), D, B, T, D, ptr(xr), st), "rows")
+    lib.check(lib._lpm_split_weight_tiles(ptr(W), D, K, 0, ptr(wt), st), "weights")
+    nblk = lib._lpm_assign_gemm_tiles_nblk(B, T)
+    out = {}
+    try:
+        for mask in (0, 3):
+            lib._lpm_k1_forms_disable(mask)
+            lg, pt = torch.zeros(B * T, K, device=dev), torch.zeros(nblk, 2, K, device=dev)
+            for _ in range(3):
+                lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(lg), ptr(pt), st), "k1")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(lg), ptr(pt), st), "k1")
+            e1.record()
+            torch.cuda.synchronize()
+            out[mask] = (lg.clone(), e0.elapsed_time(e1) / 10)
+    finally:
+        lib._lpm_k1_forms_disable(0)
+    assert float((out[0][0] - out[3][0]).abs().max()) <= 2e-5 * float(out[3][0].abs().max()), "the two forms agree to fp32 rounding"
+    print(f"[K1 forms] flat {out[0][1] * 1e3:.1f} us, tile-GEMM form {out[3][1] * 1e3:.1f} us")
+    assert out[3][1] > 1.05 * out[0][1], "with the mask set another (slower) kernel runs"
+
+
 @pytest.mark.parametrize("M,C,act", [(80, 512, 1), (80, 512, 2), (128, 1024, 2), (7, 40, 0), (250, 96, 1), (2, 33, 2)])
 def test_bn_small_one_launch_each_way(M, C, act):
     """lpm_bn_small_fwd / _bwd: the clip-level batch norms with what follows them (frame_level_models.py:2321-2337: hidden1_bn + relu6;
