@@ -631,6 +631,7 @@ class Trainer:
 
     def step(self, model_input_raw, num_frames, labels, **kw):
         """One optimiser step on this rank's shard of the global batch.  Returns loss / predictions."""
+        self._join_update_stream()        # (hidden1_weights' update of an interrupted step may still be running on its stream)
         dev = self.device
         model_input_raw = model_input_raw.to(dev)
         labels = labels.to(dev)
@@ -791,6 +792,7 @@ class Trainer:
         the factors the optimiser used (tests, diagnostics).  On the sharded route the summed gradient of hidden1_weights exists only
         shard by shard on its owners (the arena slice holds this rank's LOCAL gradient after a native reduce-scatter): asking for it
         raises -- ``sharded.keep_summed`` / ``sharded.summed_shard`` give this rank's shard of the sum."""
+        self._join_update_stream()        # (hidden1_weights' update of an interrupted step may still be running on its stream)
         t = self.arena.views[name]
         if self.sharded is not None and name == self.arena.names[0]:
             raise RuntimeError(f"gradient({name!r}): on the sharded route the summed gradient exists only as the owners' shards "
@@ -885,6 +887,7 @@ class Trainer:
         and, on the sharded route, gathers the owners' Adam moments of hidden1_weights -- the reference's chief holds ALL Adam slots.
         A chief-only save WITHOUT that on the sharded route holds hidden1_weights' moments for the chief's 1/N shard only; such a
         checkpoint is marked (``hidden1_adam_shard``) and ``load_state_dict`` refuses to resume from it."""
+        self._join_update_stream()        # (hidden1_weights' update of an interrupted step may still be running on its stream)
         if self.arena is None:
             raise RuntimeError("state_dict() needs a built trainer: run build() or one step first")
         if sync:
@@ -927,6 +930,7 @@ class Trainer:
     def wait_pending(self):
         """Complete every asynchronous write into the variables (route C's parameter all-gather of hidden1_weights): call it before
         reading ``store.vars`` / ``arena.param`` directly between steps (``get_variable``, ``state_dict`` and ``load`` do it themselves)."""
+        self._join_update_stream()        # (hidden1_weights' update of an interrupted step may still be running on its stream)
         self.store.drain_pending()
 
     def sync_moving_statistics(self):
@@ -953,6 +957,7 @@ class Trainer:
                 off += v.numel()
 
     def load_state_dict(self, state: Dict[str, object]):
+        self._join_update_stream()        # (hidden1_weights' update of an interrupted step may still be running on its stream)
         if self.arena is None:
             raise RuntimeError("load_state_dict() needs a built trainer: run build() first")
         if self.sharded is not None:
@@ -991,6 +996,7 @@ class Trainer:
     @torch.no_grad()
     def predict(self, model_input_raw, num_frames, **kw):
         """eval.build_graph path: same forward with is_training=False (eval.py:143-150)."""
+        self._join_update_stream()        # (hidden1_weights' update of an interrupted step may still be running on its stream)
         x = self._normalize_input(model_input_raw.to(self.device), num_frames.to(self.device))
         result, _ = self._forward(x, num_frames.to(self.device), None, is_training=False, **kw)
         return result["predictions"]
