@@ -25,5 +25,13 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"{cfg}: {steps} steps in {dt:.1f} s; loss " + ", ".join(f"[{s}] {l:.4f}" for s, l in losses))
 ok = all(l == l and abs(l) < 1e6 for _, l in losses) and losses[-1][1] < losses[0][1]
+if getattr(tr, "w16", None) is not None:               # bf16 storage: the compute copy of hidden1_weights after the run
+    W = tr.arena.views[tr.arena.names[0]]
+    same = bool(torch.equal(tr.w16.buf, W.detach().to(torch.bfloat16)))
+    print(f"compute copy: {tr.w16.refreshes} rebuild(s) in {steps} steps; equals bf16(master): {same}")
+    ok = ok and same and tr.w16.refreshes == 1
+sc = getattr(tr, "operand_scales", None)
+if sc is not None and sc.slots:
+    print(f"operand scales: {sc.steps_fp16} of {steps} steps on fp16 planes, {len(sc.slots)} sites")
 print("finite and decreasing" if ok else "NOT decreasing / not finite")
 sys.exit(0 if ok else 1)
