@@ -295,3 +295,31 @@ def test_operand_sites_carry_the_header_s_format_kinds():
     assert (a.kind, a.planes, a.inv) == (_capi.LPM_OPERAND_FP16X3, 3, 1.0 / 1024) and a.struct.scale == 1024.0
     assert (g.kind, g.planes, g.inv) == (_capi.LPM_OPERAND_FP16X2, 2, 8.0)
     assert (b.kind, b.planes, b.scale, b.inv) == (_capi.LPM_OPERAND_BF16X3, 3, 1.0, 1.0)
+
+
+def test_compute_copy_tracks_every_writer_of_its_master():
+    """ops.ComputeCopy (the bf16 compute copy of hidden1_weights): rebuilt at first use, kept while nothing writes the
+    master, stale after a write through torch to the variable OR to the flat arena it is a view of (two version counters: the variable's
+    `.data` was re-pointed into the arena), stale after invalidate(); `current()` hands the buffer to the update pass only while it is
+    current.  Pure host logic: runs on the CPU."""
+    import torch
+    from learnablepoolingmethods_amd import ops
+    arena = torch.randn(64 * 32 + 100)
+    W = torch.empty(64, 32, requires_grad=True)
+    with torch.no_grad():
+        W.data = arena[:64 * 32].view(64, 32)                   # as ParameterArena binds a variable
+    cc = ops.ComputeCopy(W, also=(arena,))
+    assert cc.current(W) is None and cc.refreshes == 0          # never built: nothing for the update pass to write
+    b = cc.tensor(W)
+    assert cc.refreshes == 1 and torch.equal(b, W.detach().to(torch.bfloat16)) and cc.current(W) is b
+    assert cc.tensor(W) is b and cc.refreshes == 1              # no writer in between: no rebuild
+    with torch.no_grad():
+        W.mul_(2.0)                                             # a write to the variable
+    assert cc.current(W) is None
+    assert torch.equal(cc.tensor(W), W.detach().to(torch.bfloat16)) and cc.refreshes == 2
+    with torch.no_grad():
+        arena.add_(1.0)                                         # a write to the arena (tools/determinism_check.py resets it this way)
+    assert cc.current(W) is None
+    assert torch.equal(cc.tensor(W), W.detach().to(torch.bfloat16)) and cc.refreshes == 3
+    cc.invalidate()                                             # a write through raw pointers (the generic update): told explicitly
+    assert cc.current(W) is None and torch.equal(cc.tensor(W), W.detach().to(torch.bfloat16)) and cc.refreshes == 4
