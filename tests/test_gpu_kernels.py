@@ -1692,12 +1692,14 @@ def test_k1_selfcheck_passes_and_the_form_switch_works():
                 lib.check(lib._lpm_assign_gemm_tiles_fwd(ptr(xr), ptr(wt), B, T, D, K, ptr(lg), ptr(pt), st), "k1")
             e1.record()
             torch.cuda.synchronize()
-            out[mask] = (lg.clone(), e0.elapsed_time(e1) / 10)
+            out[mask] = (lg.clone(), e0.elapsed_time(e1) / 10, int((pt.abs().sum((1, 2)) > 0).sum()))
     finally:
         lib._lpm_k1_forms_disable(0)
     assert float((out[0][0] - out[3][0]).abs().max()) <= 2e-5 * float(out[3][0].abs().max()), "the two forms agree to fp32 rounding"
-    print(f"[K1 forms] flat {out[0][1] * 1e3:.1f} us, tile-GEMM form {out[3][1] * 1e3:.1f} us")
-    assert out[3][1] > 1.05 * out[0][1], "with the mask set another (slower) kernel runs"
+    print(f"[K1 forms] flat {out[0][1] * 1e3:.1f} us ({out[0][2]} statistics rows in use), tile-GEMM form {out[3][1] * 1e3:.1f} us ({out[3][2]})")
+    # another kernel runs with the mask set: the flat form reduces its statistics per 96-row group (250 rows of the partial array at this
+    # shape), the tile-GEMM form per 64- / 128-row block of a clip (not a timing assertion: the box may be shared)
+    assert out[0][2] == (B * T + 95) // 96 and out[3][2] != out[0][2]
 
 
 @pytest.mark.parametrize("M,C,act", [(80, 512, 1), (80, 512, 2), (128, 1024, 2), (7, 40, 0), (250, 96, 1), (2, 33, 2)])
