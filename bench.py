@@ -41,10 +41,12 @@ WORKLOADS = {
                           "8 GPUs), full training step",
                  dtype_detail="fp32 storage and accumulation everywhere; K1, K2, K3, K4 feed the bf16 MFMA pipe with split-bf16 (hi+lo) operands, "
                               "3 MFMAs per product (~5e-6 relative error); the encoder dense GEMMs run on fp16 (hi, lo) planes with delayed "
-                              "per-tensor power-of-two scales (ops.OperandScales): forward products 3 MFMAs (~1e-6), input- and weight-gradient "
-                              "products 2 MFMAs with one operand rounded once to fp16 (1.4e-4 rms per GEMM; measured against fp64: 2.1e-4 / "
-                              "2.9e-4 relative L2 on the gradients of a two-layer chain, tests/test_gpu_fp16x2.py); LPM_DENSE_ARITHMETIC=bf16x3 "
-                              "runs them as in rounds 1-4"),
+                              "per-tensor power-of-two scales (ops.OperandScales): forward products 3 MFMAs (~1e-6); input-gradient products 2 MFMAs, "
+                              "the weight rounded once to fp16 (measured against fp64: 2.1e-4 relative L2 per GEMM); weight-gradient products "
+                              "1 MFMA, BOTH operands rounded once to fp16 (2.9e-4 relative L2; tests/test_gpu_fp16x2.py; LPM_DW_TERMS=2: the "
+                              "gradient operand exact); the attention core's backward (K4) keeps the scores on 3 split-bf16 MFMAs and runs "
+                              "dP / dV / dK / dQ on 2 fp16 MFMAs with V, P and dS rounded once (LPM_MHA_BWD_TERMS=3: split-bf16); "
+                              "LPM_DENSE_ARITHMETIC=bf16x3 runs the dense GEMMs as in rounds 1-4"),
     "cfg3": dict(metric="clips/sec training step, NetVladV2 (attention-based cluster similarities) K=256 300-frame 1152-d, bs=80 (BASELINE configs[2])",
                  model="NetVladV2", model_kwargs=dict(iterations=300, cluster_size=256, hidden_size=512),     # hidden: README.md:17
                  oracle=dict(iterations=300, cluster_size=256, hidden_size=512), flags={}, batch=80, elt=4, dtype="f32", parity_tol=1e-3,

@@ -499,9 +499,11 @@ int lpm_sum_splits(const float* part, int Z, int K, int N, float* out0, float* o
  *                       NULL format means below.  Image rows: [hi | lo | hi] (activations), [hi | hi | lo] (gradients).
  *   LPM_OPERAND_FP16X3: ACTIVATIONS as fp16 (hi, lo) planes, image rows [hi | lo | hi]: the forward product keeps all three terms
  *                       against a weight split into fp16 planes as well ([Wh ; Wh ; Wl]) -- ~1e-6 per GEMM.
- *   LPM_OPERAND_FP16X2: GRADIENTS as fp16 (hi, lo) planes, image rows [hi | lo]: the backward products are TWO-term -- the input
- *                       gradient against the weight rounded once to fp16 ([Wh ; Wh]), the weight gradient against the activation
- *                       image's hi plane -- ~1.4e-4 per GEMM (the 2^-12 rounding of the one-plane operand).
+ *   LPM_OPERAND_FP16X2: GRADIENTS as fp16 (hi, lo) planes, image rows [hi | lo].  The input gradient is a TWO-term product against the
+ *                       weight rounded once to fp16 ([Wh ; Wh]) -- 2.1e-4 relative L2 per GEMM (the 2^-12 rounding of the one-plane
+ *                       operand).  The weight gradient, as the Python host runs it by default (ops.DW_TERMS = 1), is a ONE-term
+ *                       product xh^T dyh of the two images' hi planes -- both operands rounded once, 2.9e-4 per GEMM; with
+ *                       LPM_DW_TERMS=2 it is xh^T [dyh | dyl] (the gradient exact, 1.4e-4).
  *   fp16 kinds: every value is multiplied by `scale` (a power of two chosen by the caller so that the tensor sits inside fp16's range;
  *   values beyond it saturate at +-65504) before it is split; the consumer of the GEMM multiplies by 1 / scale.
  *   Weight forms of the fp16 kinds (lpm_split_weight_fmt / lpm_split_weight_tiles_fmt / lpm_weight_pack with kind != BF16X3):
@@ -579,9 +581,9 @@ int lpm_mha_fwd_x3_image_fmt(const float* q, const float* k, const float* v, int
 int lpm_mha_bwd_x3_image_fmt(const float* q, const float* k, const float* v, int64_t ld, const void* o_img, const LpmOperandFormat* o_fmt,
                              const float* dout, int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, void* dqkv_img,
                              const LpmOperandFormat* g_fmt, lpm_stream_t stream);
-/* lpm_sum_splits for the fp16x2 weight-gradient product dW = xh^T [dyh | dyl]: part [Z, K, 2 N] (the lo half's products in columns
+/* lpm_sum_splits for the fp16 weight-gradient product.  halves = 2 (the two-term form dW = xh^T [dyh | dyl]): part [Z, K, 2 N] (the lo half's products in columns
  * [N, 2N)), out_j[k, n] = alpha * sum_z (part[z, k, j Nj + n] + part[z, k, N + j Nj + n]), Nj = N / nouts; alpha = 1 / (the two
- * operands' scales).  halves = 1: the plain sum times alpha. */
+ * operands' scales).  halves = 1 (the one-term form dW = xh^T dyh, the host's default): part [Z, K, N], the plain sum times alpha. */
 int lpm_sum_splits_scaled(const float* part, int Z, int K, int N, int halves, float alpha, float* out0, float* out1, float* out2, int nouts,
                           lpm_stream_t stream);
 
@@ -707,6 +709,11 @@ int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, c
                 int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
                 const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
                 const float* corr_b, float* dz_partial, lpm_stream_t stream);
+/* Arithmetic of lpm_mha_bwd_x3 / lpm_mha_bwd_x3_image[_fmt] for the process: 2 (default; LPM_MHA_BWD_TERMS) = fp16 planes, two-term
+ * products -- the scores stay split-bf16 x3, dO and the operands re-read from LDS exact as fp16 (hi, lo) under a power-of-two scale the
+ * kernels take from max |dO| themselves, V, P and dS rounded once to fp16 (2^-12: the arithmetic of the dense layers' input gradients);
+ * 3 = split-bf16, three-term products (rounds 2-5).  Any other value only queries.  Returns the previous setting. */
+int lpm_mha_bwd_set_terms(int terms);
 /* logits_bn backward in one pass over the scores: after lpm_mha_bwd_x3(dq = NULL, dk, dv, corr_a = corr_b = NULL, dz_partial) -- the
  * key / value gradients WITHOUT the batch statistics' share, and the statistics --, lpm_mha_bn_corrections, and
  * lpm_mha_bwd_x3(dq, dk = dv = NULL, corr_a, corr_b) for the query gradient, this subtracts the share from dk in place:

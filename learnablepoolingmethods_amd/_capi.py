@@ -95,6 +95,7 @@ SIGNATURES = {
     "lpm_split_frames_bf16": (_i, [_f, _l, _i, _i, _i, _f, _f]),
     "lpm_assign_gemm_tiles_fwd_bf16": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f]),
     "lpm_k1_forms_disable": (_i, [_i]),
+    "lpm_mha_bwd_set_terms": (_i, [_i]),
     "lpm_assign_gemm_tiles_bwd_dw_bf16": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _s, _f]),
     "lpm_assign_tiles_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),
     "lpm_vlad_aggregate_tiles3_fwd_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),

@@ -188,7 +188,7 @@ __device__ __forceinline__ unsigned bn_rne(float v) {
 // vmax collects max |v| for the host's delayed scale.
 __device__ __forceinline__ void bn_store_image(unsigned short* __restrict__ img, int64_t row, int c, int C, int order, float4 v, const OperandFmt& fmt,
                                                float& vmax) {
-    vmax = fmaxf(fmaxf(vmax, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+    vmax = of_amax4(vmax, v.x, v.y, v.z, v.w);
     if (fmt.f16) {
         uint2 hi, lo;
         of_split4(v.x, v.y, v.z, v.w, 1, fmt.scale, hi, lo);

@@ -138,12 +138,12 @@ __global__ __launch_bounds__(256) void ln_fwd_apply_kernel(const float* __restri
         }
         yp[i] = o;
         if (y3 && fmt.f16) {       // the fp16 two-product format (operand_format.h): [hi | lo] planes of y * scale
-            vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
+            vmax = of_amax4(vmax, o.x, o.y, o.z, o.w);
             uint2 hi, lo;
             of_split4(o.x, o.y, o.z, o.w, 1, fmt.scale, hi, lo);
             of_store_row4(y3 + ((int64_t)b * (n_per / F) + i / F4) * fmt.planes * F, F, c, hi, lo, fmt.planes, 0);
         } else if (y3) {
-            vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
+            vmax = of_amax4(vmax, o.x, o.y, o.z, o.w);
             const unsigned hx = ln_bf16_pair(o.x, o.y), hz = ln_bf16_pair(o.z, o.w);
             const unsigned lx = ln_bf16_pair(o.x - ln_bf16_up(hx & 0xffffu), o.y - ln_bf16_up(hx >> 16));
             const unsigned lz = ln_bf16_pair(o.z - ln_bf16_up(hz & 0xffffu), o.w - ln_bf16_up(hz >> 16));
@@ -277,12 +277,12 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
         }
         if (da && (relu || dr_extra || MASK)) *reinterpret_cast<float4*>(da + off) = o;
         if (da_img && fmt.f16) {
-            vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
+            vmax = of_amax4(vmax, o.x, o.y, o.z, o.w);
             uint2 hi, lo;
             of_split4(o.x, o.y, o.z, o.w, 1, fmt.scale, hi, lo);
             of_store_row4(da_img + ((int64_t)b * L + l) * fmt.planes * F, F, 4 * c4, hi, lo, fmt.planes, 1);
         } else if (da_img) {      // da only feeds GEMMs: it leaves as their split-bf16 gradient image, row = [hi | hi | lo] planes of F
-            vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
+            vmax = of_amax4(vmax, o.x, o.y, o.z, o.w);
             unsigned short* p = da_img + ((int64_t)b * L + l) * 3 * F + 4 * c4;
             const uint2 hi = make_uint2(ln_bf16_pair(o.x, o.y), ln_bf16_pair(o.z, o.w));
             const uint2 lo = make_uint2(ln_bf16_pair(o.x - ln_bf16_up(hi.x & 0xffffu), o.y - ln_bf16_up(hi.x >> 16)),

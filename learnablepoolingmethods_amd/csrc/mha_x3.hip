@@ -13,6 +13,8 @@
 // transformer_utils.py:564-581 (MultiHeadAttention) and :652-659 (logits_bn variant: key_scale / key_shift).
 #include "lpm_common.h"
 #include "operand_format.h"
+#include <atomic>
+#include <cstdlib>
 
 namespace lpm {
 
@@ -59,7 +61,7 @@ __device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img
     if (img == 0) {
         *reinterpret_cast<float4*>(base + off) = make_float4(a, b, c, d);
     } else if (im.gf16) {
-        vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+        vmax = of_amax4(vmax, a, b, c, d);
         uint2 hi, lo;
         of_split4(a, b, c, d, 1, im.gscale, hi, lo);
         unsigned short* p = reinterpret_cast<unsigned short*>(base) + off;
@@ -71,7 +73,7 @@ __device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img
             *reinterpret_cast<uint2*>(p + 2 * (int64_t)img) = lo;
         }
     } else {
-        vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+        vmax = of_amax4(vmax, a, b, c, d);
         unsigned h0, l0, h1, l1;
         mx_split2(a, b, h0, l0);
         mx_split2(c, d, h1, l1);
@@ -89,7 +91,7 @@ __device__ __forceinline__ void mx_store_act4(float* base, int64_t row, int64_t 
     if (oimg == 0) {
         *reinterpret_cast<float4*>(base + row * ldo + col) = make_float4(a, b, c, d);
     } else if (im.of16) {
-        vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+        vmax = of_amax4(vmax, a, b, c, d);
         uint2 hi, lo;
         of_split4(a, b, c, d, 1, im.oscale, hi, lo);
         unsigned short* p = reinterpret_cast<unsigned short*>(base) + row * im.oplanes * (int64_t)oimg + col;
@@ -97,7 +99,7 @@ __device__ __forceinline__ void mx_store_act4(float* base, int64_t row, int64_t 
         *reinterpret_cast<uint2*>(p + oimg) = lo;
         if (im.oplanes == 3) *reinterpret_cast<uint2*>(p + 2 * (int64_t)oimg) = hi;
     } else {
-        vmax = fmaxf(fmaxf(vmax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+        vmax = of_amax4(vmax, a, b, c, d);
         unsigned h0, l0, h1, l1;
         mx_split2(a, b, h0, l0);
         mx_split2(c, d, h1, l1);
@@ -129,6 +131,75 @@ __device__ __forceinline__ void mx_load_o8(const float* base, int64_t row, int64
                         __uint_as_float(h.w << 16) + __uint_as_float(l.w << 16), __uint_as_float(h.w & 0xffff0000u) + __uint_as_float(l.w & 0xffff0000u));
     }
 }
+// ---- round 6: the backward's products on TWO terms, fp16 planes (the treatment the dense GEMMs' backward got in round 5) --------------
+// What stays exact: the scores S (split-bf16 x3: they sit under an exp), dO and everything that is linear in it down to the MFMA operand
+// it meets (fp16 hi + lo planes of dO * s, s a power of two chosen from max |dO| -- fp16 has five exponent bits, gradients span 1e-9 ... 20),
+// and the operand that is re-read from LDS (K^T in the dq kernel, Q^T and dO^T in the dkv kernel: fp16 hi + lo).  What is rounded ONCE to
+// fp16 (11 bits, 2^-12 relative: the 1.4e-4 per product of the dense input gradients): V against dO (dP = dO V^T is ONE 32-deep MFMA at
+// d = 16, [Vh | Vh] . [dOh | dOl], instead of two), and the per-score values formed in registers -- P against dO^T, dS against K^T / Q^T:
+// two MFMAs per product instead of three and ONE v_cvt_pk_f16_f32 per pair of scores instead of the (hi, lo) split's five VALU
+// operations, in kernels whose vector pipe is ~94 % busy.  Per 32 keys x 16 queries: dq 11 -> 8 MFMAs, dkv 14 -> 10; VALU operations
+// per score ~10 -> ~7.5 (dq), ~13 -> ~8 (dkv).  LPM_MHA_BWD_TERMS=3 / lpm_mha_bwd_set_terms(3) keeps the three-term bf16 form (A/B).
+typedef _Float16 mx_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mx_mfma_h(mx_u32x4 a, mx_u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_f16x8, a), __builtin_bit_cast(mx_f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ mx_u32x4 mx_round8_h(const float* v) {
+    return mx_u32x4{of_round2_f16(v[0], v[1]), of_round2_f16(v[2], v[3]), of_round2_f16(v[4], v[5]), of_round2_f16(v[6], v[7])};
+}
+__device__ __forceinline__ void mx_split8_h(const float* v, float s, mx_u32x4& hi, mx_u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h, l;
+        of_split2(v[2 * i], v[2 * i + 1], 1, s, h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+// the power of two s with amax * s in [2^4, 2^5) and its inverse (amax == 0 or denormal: 1).  With max |dO| s < 32 a score gradient
+// dS = P (dP - D) stays inside fp16's range while sum_d |V_d| < 1024; beyond, of_round2_f16 saturates.
+__device__ __forceinline__ void mx_pow2_scale(float amax, float& s, float& inv) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    const int se = e == 0 ? 127 : min(max(258 - e, 1), 253);
+    s = __uint_as_float((unsigned)se << 23);
+    inv = __uint_as_float((unsigned)(254 - se) << 23);
+}
+// stage rows [0, L) of head hh as the fp16 hi plane only, D/8 arrays of LP x 16 bytes (the rounded-once operand of dP)
+template <int D>
+__device__ __forceinline__ void mx_stage_rows_h1(unsigned char* dst, const float* __restrict__ src, int64_t ld, int b, int L, int LP, int hh,
+                                                 int tid, int nt) {
+    constexpr int NH = D / 8;
+    for (int i = tid; i < L * NH; i += nt) {
+        const int row = i / NH, hf = i % NH;
+        const float* p = src + ((int64_t)b * L + row) * ld + hh * D + 8 * hf;
+        const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        *reinterpret_cast<mx_u32x4*>(dst + (hf * LP + row) * 16) = mx_round8_h(v);
+    }
+}
+// ... and transposed + permuted as fp16 (hi, lo) planes: T[plane][d][perm(row)]
+template <int D>
+__device__ __forceinline__ void mx_stage_transposed_h(unsigned char* dst, const float* __restrict__ src, int64_t ld, int b, int L, int LP,
+                                                      int hh, int tid, int nt) {
+    constexpr int NH = D / 8;
+    const int TS = LP * 2 + 16;
+    for (int i = tid; i < L * NH; i += nt) {
+        const int row = i / NH, hf = i % NH;
+        const float* p = src + ((int64_t)b * L + row) * ld + hh * D + 8 * hf;
+        const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        mx_u32x4 hi, lo;
+        mx_split8_h(v, 1.f, hi, lo);
+        const int pos = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int dd = 8 * hf + e;
+            *reinterpret_cast<unsigned short*>(dst + dd * TS + pos * 2) = (unsigned short)(hi[e >> 1] >> ((e & 1) * 16));
+            *reinterpret_cast<unsigned short*>(dst + 16 * TS + dd * TS + pos * 2) = (unsigned short)(lo[e >> 1] >> ((e & 1) * 16));
+        }
+    }
+}
+
 // position of key (or query) `i` inside its 32-block in the permuted order: i = 16 t + 4 g + e  ->  8 g + 4 t + e
 __device__ __forceinline__ int mx_perm(int i) { return (i & ~31) | (((i >> 2) & 3) << 3) | (((i >> 4) & 1) << 2) | (i & 3); }
 
@@ -613,6 +684,376 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
     if (img) of_amax_commit(im.gamax, vmax);
 }
 
+// ---- backward on two fp16 terms (round 6; the arithmetic is described with the helpers at the top of the file) -----------------------
+// Same two sweeps, same LDS geometry, same thread counts as the three-term kernels above.  Valid where dS is LINEAR in dO (the scale
+// is taken from max |dO|): the plain attention, and logits_bn's launches without correction vectors (corr_a == NULL: the one-pass
+// backward's dkv kernel) -- with corrections the batch statistics' terms enter dS at the size of the GLOBAL gradient whatever this
+// query's / head's own dO is, and the launcher keeps the three-term kernels (bf16 has fp32's range).
+// Measured (tools/time_mha_bwd.py, rocprofv3; B = 80, h = 64, d = 16): L = 256 dq 215 -> 207 us, dkv 266 -> 234 us; L = 300 with logits_bn
+// dkv 556 -> 487 us -- 5-13 % for 27-29 % of the MFMAs and 25-38 % of the VALU operations per score removed.  The sweeps are bound by
+// neither count: TPW = 2 (a wave runs two tiles side by side through ONE stream of fragment reads: half the LDS traffic per score,
+// twice the independent work per wave, but 140 registers = half the waves) measured dkv 290 us, dq 196 us at L = 256 and dq 401 us
+// against 335 at L = 300 -- what the kernels live on is the number of waves a SIMD can switch between while one waits for its
+// MFMA -> exp2 -> convert -> MFMA chain, and that is capped at four by the 66 KB of staged operands per (batch, head).  TPW = 2 is
+// reachable for L = 256, d = 16 only (LPM_MHA_BWD_TPW=2, the A/B).
+// threads per workgroup: one tile per wave -- as the three-term kernels (dq 512; dkv 512, 1024 from NKT = 20 on); two -- one wave per task
+template <int NKT, int TPW, bool DKV> __host__ __device__ constexpr int mx_h_nt() {
+    constexpr int w = (NKT + TPW - 1) / TPW;
+    return TPW == 1 ? (DKV ? mx_dkv_nt(NKT) : MX_DQ_NT) : (w <= 4 ? 256 : (w >= 16 ? 1024 : 64 * w));
+}
+template <int NKT, bool AFFINE, int D, bool RAGGED, int TPW>
+__global__ __launch_bounds__((mx_h_nt<NKT, TPW, false>())) void mha_bwd_dq_h_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
+                                                            const float* __restrict__ dout, int64_t ldo,
+                                                            const float* __restrict__ lse, int L, int h, float scale,
+                                                            const float* __restrict__ key_scale, const float* __restrict__ key_shift,
+                                                            float* __restrict__ dq, int64_t ldd, const float* __restrict__ corr_a,
+                                                            const float* __restrict__ corr_b, int img, int oimg, const MxImg im) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float vmax = 0.f;
+    constexpr int LP = NKT * 16;
+    constexpr int NT = mx_h_nt<NKT, TPW, false>();
+    const int nkt = (L + 15) >> 4;
+    const float qmul = AFFINE ? scale : scale * MX_LOG2E;      // scores in log2 units (AFFINE: z is converted instead)
+    unsigned char* Kp = smem;                                  // K rows, split-bf16 (hi, lo): the scores stay exact
+    unsigned char* Vp = Kp + mx_rowplanes_bytes(LP, D);        // V rows, the fp16 hi plane (rounded once)
+    unsigned char* Kt = Vp + mx_rowplanes_bytes(LP, D);        // K^T, fp16 (hi, lo)
+    float* ksc = reinterpret_cast<float*>(Kt + mx_tplanes_bytes(LP));
+    float* ksh = ksc + LP;
+    float* cas = ksh + LP;
+    float* cbs = cas + LP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    const int TS = mx_tstride(LP);
+
+    if (RAGGED || D < 16) {
+        for (int i = tid; i < (2 * mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP)) / 16; i += NT)
+            reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+    if (AFFINE) {
+        for (int i = tid; i < LP; i += NT) {
+            ksc[i] = (i < L) ? key_scale[i] : 1.f;
+            ksh[i] = (i < L) ? key_shift[i] : 0.f;
+            cas[i] = (corr_a && i < L) ? corr_a[i] : 0.f;
+            cbs[i] = (corr_b && i < L) ? corr_b[i] : 0.f;
+        }
+    }
+    mx_stage_rows<D>(Kp, k, ld, b, L, LP, hh, 1.f, tid, NT);
+    mx_stage_rows_h1<D>(Vp, v, ld, b, L, LP, hh, tid, NT);
+    mx_stage_transposed_h<D>(Kt, k, ld, b, L, LP, hh, tid, NT);
+    __syncthreads();
+
+    const mx_u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+    for (int t0 = wave * TPW; t0 < nkt; t0 += (NT / 64) * TPW) {
+        mx_u32x4 qb1[TPW], qb2[TPW], gb[TPW];
+        float dqv[TPW], lq[TPW], sq[TPW], sqinv[TPW];
+        f32x4 dqa[TPW], dqb[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int qrow = (t0 + u) * 16 + l15;
+            const bool qok = qrow < L;
+            mx_u32x4 qh = z4, ql = z4, gh = z4, gl = z4;
+            float dpart = 0.f, gmax = 0.f;
+            float gv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (qok) {
+                const int c0 = hh * D + ((D == 16) ? 8 * (g & 1) : 0);
+                const float* qp = q + ((int64_t)b * L + qrow) * ld + c0;
+                const float4 a = *reinterpret_cast<const float4*>(qp), c = *reinterpret_cast<const float4*>(qp + 4);
+                const float qv[8] = {a.x * qmul, a.y * qmul, a.z * qmul, a.w * qmul, c.x * qmul, c.y * qmul, c.z * qmul, c.w * qmul};
+                mx_split8(qv, qh, ql);
+                const int64_t off = ((int64_t)b * L + qrow) * ldo + c0;
+                const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
+                float4 oa, oc;
+                mx_load_o8(o, (int64_t)b * L + qrow, ldo, c0, oimg, oa, oc, im);
+                gv[0] = ga.x; gv[1] = ga.y; gv[2] = ga.z; gv[3] = ga.w; gv[4] = gc.x; gv[5] = gc.y; gv[6] = gc.z; gv[7] = gc.w;
+                gmax = of_amax8(0.f, gv);
+                dpart = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
+            }
+            if (D == 16) {                                         // the two 8-column halves live in lane groups g and g^1
+                dpart += __shfl_xor(dpart, 16, 64);
+                gmax = fmaxf(gmax, __shfl_xor(gmax, 16, 64));
+            }
+            // this query's power-of-two scale s_q (max |dO_q| s_q in [16, 32)).  A lane owns one query COLUMN of every product below, so
+            // dP, D_q, dS and dQ of the query all carry s_q and the store takes it out again.
+            mx_pow2_scale(gmax, sq[u], sqinv[u]);
+            mx_split8_h(gv, sq[u], gh, gl);
+            dqv[u] = dpart * sq[u];                                // D_q = <dO_q, O_q>
+            lq[u] = qok ? lse[((int64_t)b * h + hh) * L + qrow] * MX_LOG2E : INFINITY;
+            mx_col_frags<D>(qh, ql, g, qb1[u], qb2[u]);
+            // dP^T = V dO^T as ONE MFMA: A = [Vh | Vh] (d = 16: arrays g & 1; d = 8: array 0 for every lane group), B = [dOh | dOl]
+            gb[u] = (D == 16) ? ((g < 2) ? gh : gl) : ((g == 0) ? gh : ((g == 1) ? gl : z4));
+            dqa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dqb[u] = dqa[u];
+        }
+#pragma unroll 2
+        for (int j = 0; j < NKT / 2; ++j) {
+            float ds8[TPW][8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = 2 * j + t;
+                const mx_u32x4 ka = mx_row_frag<D>(Kp, LP, kt, l15, g);
+                const mx_u32x4 va = *reinterpret_cast<const mx_u32x4*>(Vp + (((D == 16) ? (g & 1) : 0) * LP + kt * 16 + l15) * 16);
+                float sc4[4], sh4[4], ca4[4], cb4[4];
+                if (AFFINE) {
+                    const float4 a = *reinterpret_cast<const float4*>(ksc + kt * 16 + 4 * g), c = *reinterpret_cast<const float4*>(ksh + kt * 16 + 4 * g);
+                    const float4 e = *reinterpret_cast<const float4*>(cas + kt * 16 + 4 * g), f = *reinterpret_cast<const float4*>(cbs + kt * 16 + 4 * g);
+                    sc4[0] = a.x; sc4[1] = a.y; sc4[2] = a.z; sc4[3] = a.w; sh4[0] = c.x; sh4[1] = c.y; sh4[2] = c.z; sh4[3] = c.w;
+                    ca4[0] = e.x; ca4[1] = e.y; ca4[2] = e.z; ca4[3] = e.w; cb4[0] = f.x; cb4[1] = f.y; cb4[2] = f.z; cb4[3] = f.w;
+                }
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    st = mx_mfma(ka, qb1[u], st);
+                    dp = mx_mfma_h(va, gb[u], dp);
+                    if (D == 16) st = mx_mfma(ka, qb2[u], st);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float z = st[r];
+                        if (AFFINE) z = fmaf(st[r], sc4[r], sh4[r]) * MX_LOG2E;
+                        if (RAGGED && kt * 16 + 4 * g + r >= L) z = -INFINITY;
+                        const float pr = __builtin_amdgcn_exp2f(z - lq[u]);
+                        float dsv = pr * (dp[r] - dqv[u]);
+                        if (AFFINE) dsv = fmaf(dsv, sc4[r], -sq[u] * fmaf(st[r], cb4[r], ca4[r]));
+                        ds8[u][4 * t + r] = dsv;
+                    }
+                }
+            }
+            const unsigned char* kc = Kt + l15 * TS + (32 * j + 8 * g) * 2;
+            const mx_u32x4 kh = *reinterpret_cast<const mx_u32x4*>(kc), kl = *reinterpret_cast<const mx_u32x4*>(kc + 16 * TS);
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                const mx_u32x4 dh = mx_round8_h(ds8[u]);           // dS rounded once; K^T exact: two products, two accumulators
+                dqa[u] = mx_mfma_h(kh, dh, dqa[u]);                // dQ^T[dd, q] += K^T[dd, keys] dS^T[keys, q]
+                dqb[u] = mx_mfma_h(kl, dh, dqb[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int qrow = (t0 + u) * 16 + l15;
+            const float omul = scale * sqinv[u];
+            if (qrow < L && 4 * g < D)
+                mx_store_grad4(dq, ((int64_t)b * L + qrow) * ldd + hh * D + 4 * g, img, (dqa[u][0] + dqb[u][0]) * omul, (dqa[u][1] + dqb[u][1]) * omul,
+                               (dqa[u][2] + dqb[u][2]) * omul, (dqa[u][3] + dqb[u][3]) * omul, im, vmax);
+        }
+    }
+    if (img) of_amax_commit(im.gamax, vmax);
+}
+
+template <int NKT, bool AFFINE, int D, bool CORR, int TPW>
+__global__ __launch_bounds__((mx_h_nt<NKT, TPW, true>())) void mha_bwd_dkv_h_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, int64_t ld, const float* __restrict__ o,
+                                                             const float* __restrict__ dout, int64_t ldo,
+                                                             const float* __restrict__ lse, int L, int h, float scale,
+                                                             const float* __restrict__ key_scale, const float* __restrict__ key_shift,
+                                                             float* __restrict__ dk, float* __restrict__ dv, int64_t ldd,
+                                                             const float* __restrict__ corr_a, const float* __restrict__ corr_b,
+                                                             float* __restrict__ dz_partial, int img, int oimg, const MxImg im) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float vmax = 0.f;
+    constexpr int LP = NKT * 16;
+    constexpr int NT = mx_h_nt<NKT, TPW, true>();
+    constexpr int NH = D / 8;
+    const int nkt = (L + 15) >> 4;
+    const float qmul = AFFINE ? scale : scale * MX_LOG2E;       // scores in log2 units (AFFINE: z is converted instead)
+    unsigned char* Qp = smem;                                   // qmul * Q rows, split-bf16 (hi, lo): the scores stay exact
+    unsigned char* Gp = Qp + mx_rowplanes_bytes(LP, D);         // dO s rows, fp16 (hi, lo)
+    unsigned char* Qt = Gp + mx_rowplanes_bytes(LP, D);         // (qmul * Q)^T, fp16 (hi, lo)
+    unsigned char* Gt = Qt + mx_tplanes_bytes(LP);              // (dO s)^T, fp16 (hi, lo)
+    float* lses = reinterpret_cast<float*>(Gt + mx_tplanes_bytes(LP));
+    float* Dq = lses + LP;
+    unsigned* gmaxw = reinterpret_cast<unsigned*>(Dq + LP);
+    const bool stats_only = (dk == nullptr);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / h, hh = lid % h;
+    const int TS = mx_tstride(LP);
+
+    if (L != LP || D < 16) {
+        for (int i = tid; i < (2 * mx_rowplanes_bytes(LP, D) + 2 * mx_tplanes_bytes(LP)) / 16; i += NT)
+            reinterpret_cast<mx_u32x4*>(smem)[i] = mx_u32x4{0u, 0u, 0u, 0u};
+    }
+    for (int i = tid; i < LP; i += NT) {
+        lses[i] = (i < L) ? lse[((int64_t)b * h + hh) * L + i] * MX_LOG2E : INFINITY;     // padded queries -> p = 0
+        Dq[i] = 0.f;
+    }
+    if (tid == 0) *gmaxw = 0u;
+    __syncthreads();
+    // ONE power-of-two scale s for the (batch, head)'s dO (the reductions below run over queries, so it cannot be per query): max |dO| s
+    // in [16, 32); dP, D_q, dS, the statistics and dK / dV all carry s, the stores take it out.  The maximum comes from a pass of its own
+    // over the head's 16 KB of dO (L2-resident for the staging pass behind it): waves join, one LDS atomic per wave.
+    float gs, gsinv;
+    {
+        float m = 0.f;
+        for (int i = tid; i < L * NH; i += NT) {
+            const int64_t off = ((int64_t)b * L + i / NH) * ldo + hh * D + 8 * (i % NH);
+            const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
+            const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
+            m = of_amax8(m, gv);
+        }
+        m = wave_max(m);
+        if (lane == 0) atomicMax(gmaxw, __float_as_uint(m));
+        __syncthreads();
+        mx_pow2_scale(__uint_as_float(*gmaxw), gs, gsinv);
+    }
+    // Q (scaled) and dO: row planes and transposed planes from ONE pass over global memory; D_q = <dO_q, O_q>
+    for (int i0 = 0; i0 < L * NH; i0 += NT) {
+        const int i = i0 + tid;
+        float part = 0.f;
+        int row = 0;
+        if (i < L * NH) {
+            row = i / NH;
+            const int hf = i % NH;
+            const float* qp = q + ((int64_t)b * L + row) * ld + hh * D + 8 * hf;
+            const int64_t off = ((int64_t)b * L + row) * ldo + hh * D + 8 * hf;
+            const float4 qa = *reinterpret_cast<const float4*>(qp), qc = *reinterpret_cast<const float4*>(qp + 4);
+            const float4 ga = *reinterpret_cast<const float4*>(dout + off), gc = *reinterpret_cast<const float4*>(dout + off + 4);
+            float4 oa, oc;
+            mx_load_o8(o, (int64_t)b * L + row, ldo, hh * D + 8 * hf, oimg, oa, oc, im);
+            part = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
+            const float qv[8] = {qa.x * qmul, qa.y * qmul, qa.z * qmul, qa.w * qmul, qc.x * qmul, qc.y * qmul, qc.z * qmul, qc.w * qmul};
+            const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
+            mx_u32x4 qh, ql, gh, gl, qfh, qfl;
+            mx_split8(qv, qh, ql);
+            mx_split8_h(gv, gs, gh, gl);
+            mx_split8_h(qv, 1.f, qfh, qfl);
+            *reinterpret_cast<mx_u32x4*>(Qp + ((0 * NH + hf) * LP + row) * 16) = qh;
+            *reinterpret_cast<mx_u32x4*>(Qp + ((1 * NH + hf) * LP + row) * 16) = ql;
+            *reinterpret_cast<mx_u32x4*>(Gp + ((0 * NH + hf) * LP + row) * 16) = gh;
+            *reinterpret_cast<mx_u32x4*>(Gp + ((1 * NH + hf) * LP + row) * 16) = gl;
+            const int pos = mx_perm(row);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int dd = 8 * hf + e, sh = (e & 1) * 16;
+                *reinterpret_cast<unsigned short*>(Qt + dd * TS + pos * 2) = (unsigned short)(qfh[e >> 1] >> sh);
+                *reinterpret_cast<unsigned short*>(Qt + 16 * TS + dd * TS + pos * 2) = (unsigned short)(qfl[e >> 1] >> sh);
+                *reinterpret_cast<unsigned short*>(Gt + dd * TS + pos * 2) = (unsigned short)(gh[e >> 1] >> sh);
+                *reinterpret_cast<unsigned short*>(Gt + 16 * TS + dd * TS + pos * 2) = (unsigned short)(gl[e >> 1] >> sh);
+            }
+        }
+        if (NH == 2) part += __shfl_xor(part, 1, 64);          // the two halves of a row sit in adjacent threads
+        if (i < L * NH && (i % NH) == 0) Dq[row] = part * gs;
+    }
+    __syncthreads();
+
+    const mx_u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+    for (int t0 = wave * TPW; t0 < nkt; t0 += (NT / 64) * TPW) {
+        mx_u32x4 kb1[TPW], kb2[TPW], vb[TPW];
+        float sck[TPW], shk[TPW], cak[TPW], cbk[TPW], zs[TPW], zq[TPW];
+        bool kok[TPW];
+        f32x4 dka[TPW], dkb[TPW], dva[TPW], dvb[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int krow = (t0 + u) * 16 + l15;
+            kok[u] = krow < L;
+            mx_u32x4 kh = z4, kl = z4, vh = z4;
+            if (kok[u]) {
+                const int64_t off = ((int64_t)b * L + krow) * ld + hh * D + ((D == 16) ? 8 * (g & 1) : 0);
+                const float4 ka = *reinterpret_cast<const float4*>(k + off), kc = *reinterpret_cast<const float4*>(k + off + 4);
+                const float4 va = *reinterpret_cast<const float4*>(v + off), vc = *reinterpret_cast<const float4*>(v + off + 4);
+                const float kv[8] = {ka.x, ka.y, ka.z, ka.w, kc.x, kc.y, kc.z, kc.w};
+                const float vv[8] = {va.x, va.y, va.z, va.w, vc.x, vc.y, vc.z, vc.w};
+                mx_split8(kv, kh, kl);
+                vh = mx_round8_h(vv);                          // V rounded once: dP = [dOh | dOl] . [Vh | Vh] is one MFMA
+            }
+            mx_col_frags<D>(kh, kl, g, kb1[u], kb2[u]);
+            vb[u] = (D == 16 || g < 2) ? vh : z4;              // d = 8: the A arrays are [dOh | dOl | . | .]
+            sck[u] = (key_scale && kok[u]) ? key_scale[krow] : 1.f;
+            shk[u] = (key_shift && kok[u]) ? key_shift[krow] : 0.f;
+            cak[u] = ((corr_a && kok[u]) ? corr_a[krow] : 0.f) * gs;
+            cbk[u] = ((corr_b && kok[u]) ? corr_b[krow] : 0.f) * gs;
+            zs[u] = zq[u] = 0.f;
+            dka[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dkb[u] = dva[u] = dvb[u] = dka[u];
+        }
+        constexpr int UNR = (AFFINE && TPW == 2) ? 1 : 2;       // (the logits_bn form with two key tiles: 180-215 registers unrolled by two)
+#pragma unroll UNR
+        for (int j = 0; j < NKT / 2; ++j) {
+            float p8[TPW][8], ds8[TPW][8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qt = 2 * j + t;
+                const mx_u32x4 qa = mx_row_frag<D>(Qp, LP, qt, l15, g), ga = mx_row_frag<D>(Gp, LP, qt, l15, g);
+                const float4 lq4v = *reinterpret_cast<const float4*>(lses + qt * 16 + 4 * g);
+                const float4 dq4v = *reinterpret_cast<const float4*>(Dq + qt * 16 + 4 * g);
+                const float lq4[4] = {lq4v.x, lq4v.y, lq4v.z, lq4v.w}, dq4[4] = {dq4v.x, dq4v.y, dq4v.z, dq4v.w};
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    st = mx_mfma(qa, kb1[u], st);              // S[q, key] (scale folded into Q)
+                    dp = mx_mfma_h(ga, vb[u], dp);             // dP[q, key] s = (dO s) V^T
+                    if (D == 16) st = mx_mfma(qa, kb2[u], st);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sraw = st[r];
+                        float z = sraw;
+                        if (AFFINE) z = fmaf(sraw, sck[u], shk[u]) * MX_LOG2E;
+                        if (!kok[u]) z = -INFINITY;
+                        const float pr = __builtin_amdgcn_exp2f(z - lq4[r]);
+                        const float dz = pr * (dp[r] - dq4[r]);
+                        float dsv = dz;
+                        if (AFFINE) {
+                            zs[u] += dz;
+                            zq[u] = fmaf(dz, sraw, zq[u]);
+                            const bool qin = qt * 16 + 4 * g + r < L;
+                            if constexpr (CORR) dsv = qin ? dz * sck[u] - cak[u] - sraw * cbk[u] : 0.f;
+                            else dsv = qin ? dz * sck[u] : 0.f;
+                        }
+                        p8[u][4 * t + r] = pr;
+                        ds8[u][4 * t + r] = dsv;
+                    }
+                }
+            }
+            if (!stats_only) {
+                const int offt = l15 * TS + (32 * j + 8 * g) * 2;
+                const mx_u32x4 gth = *reinterpret_cast<const mx_u32x4*>(Gt + offt), gtl = *reinterpret_cast<const mx_u32x4*>(Gt + 16 * TS + offt);
+                const mx_u32x4 qth = *reinterpret_cast<const mx_u32x4*>(Qt + offt), qtl = *reinterpret_cast<const mx_u32x4*>(Qt + 16 * TS + offt);
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    // P in [0, 1] needs no clamp; dS is clamped to fp16's range (mx_round8_h)
+                    const mx_u32x4 ph = {__builtin_bit_cast(unsigned, __builtin_convertvector(of_f2{p8[u][0], p8[u][1]}, of_h2)),
+                                         __builtin_bit_cast(unsigned, __builtin_convertvector(of_f2{p8[u][2], p8[u][3]}, of_h2)),
+                                         __builtin_bit_cast(unsigned, __builtin_convertvector(of_f2{p8[u][4], p8[u][5]}, of_h2)),
+                                         __builtin_bit_cast(unsigned, __builtin_convertvector(of_f2{p8[u][6], p8[u][7]}, of_h2))};
+                    const mx_u32x4 dh = mx_round8_h(ds8[u]);
+                    dva[u] = mx_mfma_h(gth, ph, dva[u]);       // dV^T[dd, key] += (dO s)^T[dd, q] P[q, key]
+                    dvb[u] = mx_mfma_h(gtl, ph, dvb[u]);
+                    dka[u] = mx_mfma_h(qth, dh, dka[u]);       // dK^T[dd, key] += (scale Q)^T[dd, q] dS[q, key]
+                    dkb[u] = mx_mfma_h(qtl, dh, dkb[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int krow = (t0 + u) * 16 + l15;
+            if (!stats_only && kok[u] && 4 * g < D) {
+                const int64_t off = ((int64_t)b * L + krow) * ldd + hh * D + 4 * g;
+                const float kmul = (AFFINE ? 1.f : MX_LN2) * gsinv;      // the staged Q carried log2(e)
+                mx_store_grad4(dk, off, img, (dka[u][0] + dkb[u][0]) * kmul, (dka[u][1] + dkb[u][1]) * kmul, (dka[u][2] + dkb[u][2]) * kmul,
+                               (dka[u][3] + dkb[u][3]) * kmul, im, vmax);
+                mx_store_grad4(dv, off, img, (dva[u][0] + dvb[u][0]) * gsinv, (dva[u][1] + dvb[u][1]) * gsinv, (dva[u][2] + dvb[u][2]) * gsinv,
+                               (dva[u][3] + dvb[u][3]) * gsinv, im, vmax);
+            }
+            if (dz_partial) {
+                float a = zs[u], c = zq[u];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+                if (g == 0 && kok[u]) {
+                    float* out = dz_partial + ((int64_t)b * h + hh) * 2 * L;
+                    out[krow] = a * gsinv;
+                    out[L + krow] = c * gsinv;
+                }
+            }
+        }
+    }
+    if (img) of_amax_commit(im.gamax, vmax);
+}
+
 // logits_bn backward in ONE pass over the scores (round 3).  The batch norm's backward subtracts from ds two terms that need sums over
 // every (batch, head, query) first: ds[q, j] = sck[j] dz[q, j] - ca[j] - s[q, j] cb[j] (lpm_mha_bn_corrections).  The statistics pass that
 // produced those sums recomputed S, P and dP for nothing else.  But both terms are AFFINE in s = (scale q) . k, so their share of
@@ -733,7 +1174,7 @@ __global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restr
 }
 
 static inline size_t mx_bwd_dq_lds(int LP, int D) { return (size_t)2 * mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP) + 4 * LP * 4; }
-static inline size_t mx_bwd_dkv_lds(int LP, int D) { return (size_t)2 * mx_rowplanes_bytes(LP, D) + 2 * mx_tplanes_bytes(LP) + 2 * LP * 4; }
+static inline size_t mx_bwd_dkv_lds(int LP, int D) { return (size_t)2 * mx_rowplanes_bytes(LP, D) + 2 * mx_tplanes_bytes(LP) + 2 * LP * 4 + 16; }
 static inline size_t mx_fwd_lds(int LP, int D) { return (size_t)mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP) + 2 * LP * 4; }
 
 template <typename KernT>
@@ -752,6 +1193,17 @@ static int mx_reserve(KernT kern, size_t bytes, const char* what) {
     LPM_REQUIRE(B > 0 && L > 0 && h > 0 && (d == 8 || d == 16) && L <= 512, LPM_ERR_UNSUPPORTED_SHAPE,              \
                 name ": need d in {8,16} and L <= 512 (L=%d d=%d)", L, d);                                          \
     LPM_REQUIRE(ld >= (int64_t)h * d && ld % 4 == 0, LPM_ERR_BADARG, name ": bad leading dimension")
+
+// Process-wide arithmetic of the backward kernels: 2 = fp16 two-term products (round 6, default), 3 = split-bf16 three-term products
+// (rounds 2-5).  LPM_MHA_BWD_TERMS sets the default; lpm_mha_bwd_set_terms switches at run time (tests, A/B) and returns the old value.
+static std::atomic<int> g_mha_bwd_terms{[] {
+    const char* e = getenv("LPM_MHA_BWD_TERMS");
+    return (e && e[0] == '3') ? 3 : 2;
+}()};
+extern "C" int lpm_mha_bwd_set_terms(int terms) {
+    if (terms != 2 && terms != 3) return g_mha_bwd_terms.load();
+    return g_mha_bwd_terms.exchange(terms);
+}
 
 static lpm::MxImg mx_img(const LpmOperandFormat* o_fmt, const LpmOperandFormat* g_fmt) {
     const lpm::OperandFmt fo = lpm::operand_fmt(o_fmt), fg = lpm::operand_fmt(g_fmt);
@@ -837,8 +1289,37 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
     hipStream_t s = (hipStream_t)stream;
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
+    // two fp16 terms: only where dS is linear in dO (no correction vectors: see the kernels' header)
+    const bool h16 = g_mha_bwd_terms.load(std::memory_order_relaxed) == 2 && !corr_a;
+    static const int tpw = [] { const char* e = getenv("LPM_MHA_BWD_TPW"); return (e && e[0] == '2') ? 2 : 1; }();   // tiles per wave (A/B)
+#define LPM_MX_BWDH_Q(N, AFF, DD, RG, TP)                                                                              \
+    do {                                                                                                               \
+        auto kq = mha_bwd_dq_h_kernel<N, AFF, DD, RG, TP>;                                                             \
+        const size_t lq = mx_bwd_dq_lds(N * 16, DD);                                                                   \
+        if (int rc = mx_reserve(kq, lq, what)) return rc;                                                              \
+        hipLaunchKernelGGL(kq, grid, dim3(mx_h_nt<N, TP, false>()), lq, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, \
+                           dq, ldd, corr_a, corr_b, img, oimg, im);                                                    \
+    } while (0)
+#define LPM_MX_BWDH_KV(N, AFF, DD, TP)                                                                                 \
+    do {                                                                                                               \
+        auto kk = mha_bwd_dkv_h_kernel<N, AFF, DD, false, TP>;                                                         \
+        const size_t lk = mx_bwd_dkv_lds(N * 16, DD);                                                                  \
+        if (int rc = mx_reserve(kk, lk, what)) return rc;                                                              \
+        hipLaunchKernelGGL(kk, grid, dim3(mx_h_nt<N, TP, true>()), lk, s, q, k, v, ld, o, dout, ldo, lse, L, h, scale, key_scale, key_shift, \
+                           dk, dv, ldd, corr_a, corr_b, dz_partial, img, oimg, im);                                    \
+    } while (0)
+    if (h16 && tpw == 2 && L == 256 && d == 16 && !key_scale) {         // the measured two-tiles-per-wave form (not the default)
+        if (dq) LPM_MX_BWDH_Q(16, false, 16, false, 2);
+        if (dk || dz_partial) LPM_MX_BWDH_KV(16, false, 16, 2);
+        return check_launch(what);
+    }
 #define LPM_MX_BWD3(N, AFF, DD, RG)                                                                                    \
     do {                                                                                                               \
+        if (h16) {                                                                                                     \
+            if (dq) LPM_MX_BWDH_Q(N, AFF, DD, RG, 1);                                                                  \
+            if (dk || dz_partial) LPM_MX_BWDH_KV(N, AFF, DD, 1);                                                       \
+            break;                                                                                                     \
+        }                                                                                                              \
         if (dq) {                                                                                                      \
             auto kq = mha_bwd_dq_x3_kernel<N, AFF, DD, RG>;                                                            \
             const size_t lq = mx_bwd_dq_lds(N * 16, DD);                                                               \
@@ -873,6 +1354,8 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
 #undef LPM_MX_BWD
 #undef LPM_MX_BWD1
 #undef LPM_MX_BWD3
+#undef LPM_MX_BWDH_Q
+#undef LPM_MX_BWDH_KV
     return check_launch(what);
 }
 

@@ -7,10 +7,12 @@
 //     LPM_OPERAND_FP16X3, ACTIVATIONS: x = xh + xl in FP16 planes (11 + 11 bits), image rows [hi | lo | hi] like the bf16 form; the
 //       FORWARD product runs all three terms against a weight that is split as well ([Wh ; Wh ; Wl]): ~1e-6 per GEMM -- the forward
 //       is as exact as before (a forward error would flip ReLU masks: a gradient error of sqrt(forward error)).
-//     LPM_OPERAND_FP16X2, GRADIENTS: dy = dyh + dyl in fp16 planes, image rows [hi | lo]; the BACKWARD products are two-term: the
-//       input gradient dx = [dyh | dyl] . [Wh ; Wh] against the weight rounded ONCE to fp16, the weight gradient dW = xh^T [dyh | dyl]
-//       against the activation's hi plane (read in place from its image) -- ~1.4e-4 per GEMM (the 2^-12 rounding of the one-plane
-//       operand), a third of the backward's matrix-pipe work gone.
+//     LPM_OPERAND_FP16X2, GRADIENTS: dy = dyh + dyl in fp16 planes, image rows [hi | lo].  The input gradient is a two-term product,
+//       dx = [dyh | dyl] . [Wh ; Wh], against the weight rounded ONCE to fp16 (2.1e-4 relative L2 per GEMM against fp64: the 2^-12
+//       rounding of the one-plane operand).  The weight gradient is, by default, the ONE-term product dW = xh^T dyh of the two images'
+//       hi planes read in place (ops.DW_TERMS = 1: both operands rounded once, 2.9e-4 per GEMM -- an error that stays in that weight's
+//       gradient); LPM_DW_TERMS=2 runs dW = xh^T [dyh | dyl] (the gradient exact, 1.4e-4, twice the matrix-pipe work).  Forward 3 +
+//       input gradient 2 + weight gradient 1 = 6 products per GEMM triple against split-bf16's 9.
 //     fp16 has five exponent bits: the producer multiplies every value by a power of two (`scale`, chosen by the host from the tensor's
 //       max |.| of an EARLIER step -- ops.OperandScales, delayed scaling) and the GEMM's consumer multiplies by 1 / scale (exact).
 //       Values beyond the format's range saturate at +-65504 instead of becoming infinite.  The matrix cores keep fp16 subnormals
@@ -136,17 +138,29 @@ __device__ __forceinline__ bool of_positive(unsigned h16) { return (h16 & 0x7fff
 // agent-scope load) and stays silent unless it would raise the value.  That still leaves the first residency of a launch -- 2 000 to
 // 8 000 waves that all look before anyone has written (+25-45 us, measured) -- so a site's slot is OF_AMAX_SUB sub-slots, one cache line
 // apart, chosen by workgroup: the host takes the maximum over them (ops.OperandScales).
+// (as an UNSIGNED maximum of the magnitudes' bit patterns: a NaN input orders above Inf and survives into the slot -- v_max_f32 would drop it,
+// and the fp16 split turns a NaN into a finite -65504 (v_med3_f32): the host must hear about it.  ops.OperandScales.begin_step raises on a
+// harvested maximum that is NaN or Inf -- ADVICE r5)
 __device__ __forceinline__ float of_amax8(float m, const float* v) {
+    unsigned u = __float_as_uint(m);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
-    return m;
+    for (int e = 0; e < 8; ++e) u = max(u, __float_as_uint(v[e]) & 0x7fffffffu);
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ float of_amax4(float m, float a, float b, float c, float d) {
+    const unsigned u = max(max(__float_as_uint(m), __float_as_uint(a) & 0x7fffffffu),
+                           max(max(__float_as_uint(b) & 0x7fffffffu, __float_as_uint(c) & 0x7fffffffu), __float_as_uint(d) & 0x7fffffffu));
+    return __uint_as_float(u);
 }
 constexpr int OF_AMAX_SUB = 32;          // sub-slots per site (== LPM_OPERAND_AMAX_SUB)
 constexpr int OF_AMAX_STRIDE = 16;       // floats between sub-slots: 64 bytes (== LPM_OPERAND_AMAX_STRIDE)
 __device__ __forceinline__ void of_amax_commit(float* amax, float m) {
     if (!amax) return;
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+    unsigned mu = __float_as_uint(m) & 0x7fffffffu;          // the wave's maximum as bits, so that a NaN is not lost on the way
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mu = max(mu, (unsigned)__shfl_xor((int)mu, o, 64));
+    m = __uint_as_float(mu);
+    if ((threadIdx.x & 63) == 0 && mu != 0u) {
         unsigned* slot = reinterpret_cast<unsigned*>(amax) + OF_AMAX_STRIDE * ((blockIdx.x + 7 * blockIdx.y + (threadIdx.x >> 6)) & (OF_AMAX_SUB - 1));
         const unsigned cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__float_as_uint(m) > cur) atomicMax(slot, __float_as_uint(m));

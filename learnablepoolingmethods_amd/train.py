@@ -471,6 +471,7 @@ class Trainer:
         self.factored = None
         self.w16 = None              # ops.ComputeCopy of hidden1_weights (netvlad_storage='bf16' with the factored update)
         self._update_stream, self._update_joined = None, True
+        self._poisoned = None        # the exception of a step that failed behind hidden1_weights' early update (_check_not_poisoned)
         self.sharded: Optional[ShardedVariableUpdate] = None
         self.weight_pack = ops.WeightPack() if self.device.type == "cuda" else None
         # FLAGS.dense_arithmetic: the encoders' dense GEMMs on fp16 planes (three-term forward, two-term input gradients, one-term weight
@@ -628,9 +629,17 @@ class Trainer:
             for n, v in self.store.vars.items():
                 if not self.store.trainable[n]:
                     dist.broadcast(v, src=0, group=self.group)
+            self.invalidate_compute_copies()
+
+    def _check_not_poisoned(self):
+        if self._poisoned is not None:
+            raise RuntimeError("this Trainer is in an inconsistent state: a step failed AFTER hidden1_weights (and its Adam moments) had "
+                               "been advanced inside backward (FLAGS.hidden1_early_update) while global_step and every other variable "
+                               f"stayed behind -- restore() a checkpoint or build a new Trainer.  The step failed with: {self._poisoned!r}")
 
     def step(self, model_input_raw, num_frames, labels, **kw):
         """One optimiser step on this rank's shard of the global batch.  Returns loss / predictions."""
+        self._check_not_poisoned()
         self._join_update_stream()        # (hidden1_weights' update of an interrupted step may still be running on its stream)
         dev = self.device
         model_input_raw = model_input_raw.to(dev)
@@ -651,6 +660,13 @@ class Trainer:
             ops._ACTIVE_PACK = self.weight_pack
         try:
             return self._step_body(model_input_raw, model_input, num_frames, labels, kw)
+        except BaseException as e:
+            # the early update makes a step non-atomic -- ~85 % of the parameters may already be at step t + 1.  A retried
+            # step would apply Adam to them twice and a checkpoint written from an exception handler would be inconsistent: refuse both.
+            early = getattr(self, "_early", None)
+            if early is not None and early.get("done"):
+                self._poisoned = e
+            raise
         finally:
             ops._ACTIVE_SCALES = None
             if self.weight_pack is not None:
@@ -853,6 +869,7 @@ class Trainer:
                     self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, early["lr"], early["step"],
                                                           scratch=self._factored_scratch, param_bf16=self._w16_current())   # :332-336, early
                 early["done"] = True
+                fg.early_done = True          # a second use of the weight in this backward must raise (ops._Projection.backward)
             return
         n = dist.get_world_size(self.group)
         xt_all = torch.empty(n * fg.xt.numel(), dtype=fg.xt.dtype, device=fg.xt.device)
@@ -887,6 +904,7 @@ class Trainer:
         and, on the sharded route, gathers the owners' Adam moments of hidden1_weights -- the reference's chief holds ALL Adam slots.
         A chief-only save WITHOUT that on the sharded route holds hidden1_weights' moments for the chief's 1/N shard only; such a
         checkpoint is marked (``hidden1_adam_shard``) and ``load_state_dict`` refuses to resume from it."""
+        self._check_not_poisoned()
         self._join_update_stream()        # (hidden1_weights' update of an interrupted step may still be running on its stream)
         if self.arena is None:
             raise RuntimeError("state_dict() needs a built trainer: run build() or one step first")
@@ -926,6 +944,13 @@ class Trainer:
             self.wait_pending()
             self.sharded.gather_moments()
             self._moments_gathered_at = self.global_step
+
+    def invalidate_compute_copies(self):
+        """Call after ANY write into the parameters that does not go through torch's in-place ops on the variable or the arena -- a
+        collective into ``arena.param`` (dist.broadcast / all_gather do not bump version counters), a ctypes kernel, a raw-pointer
+        copy: hidden1_weights' bf16 compute copy (ops.ComputeCopy) is rebuilt at its next use."""
+        if self.w16 is not None:
+            self.w16.invalidate()
 
     def wait_pending(self):
         """Complete every asynchronous write into the variables (route C's parameter all-gather of hidden1_weights): call it before
@@ -986,6 +1011,9 @@ class Trainer:
                 if n + "/Adam_1" in state:
                     self.arena.v[a0:a0 + k].copy_(torch.as_tensor(state[n + "/Adam_1"]).reshape(-1))
         self.global_step = int(state.get("global_step", self.global_step))
+        if self.w16 is not None:
+            self.w16.invalidate()          # the master was rewritten (store.load copies through views: version counters see it; belt and braces)
+        self._poisoned = None              # parameters, moments and global_step are one consistent state again
 
     def save(self, path: str, sync: bool = False):
         torch.save(self.state_dict(sync=sync), path)

@@ -58,6 +58,7 @@ def main():
     for n, v in tr.store.vars.items():
         if not tr.store.trainable[n]:
             dist.broadcast(v, src=0)
+    tr.invalidate_compute_copies()                      # (a collective into the arena does not bump torch's version counters: ADVICE r5)
     names = list(tr.arena.names)
     for s in range(inp["steps"]):
         tr.wait_pending()                               # (read below past get_variable: the parameter all-gather of the previous step)

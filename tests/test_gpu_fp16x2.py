@@ -227,3 +227,34 @@ def test_operand_scales_delay_and_warm_in():
     amax, scale = sc.report()[("a", W.data_ptr())]
     assert 2 ** 10 <= max(sc.hist[0][0], sc.hist[1][0]) * scale < 2 ** 11
     assert math.isclose(max(sc.hist[0][0], sc.hist[1][0]), 3.0 * float(x.abs().max()), rel_tol=1e-6), "the larger of the last two measurements"
+
+
+def test_a_nan_operand_reaches_the_host_through_the_recorded_maximum():
+    """the fp16 split clamps with v_med3_f32, which turns a NaN into -65504 -- a NaN activation or gradient entering an encoder
+    GEMM would go on as a finite value.  The producers' recorded maxima keep it (bit-pattern maximum: NaN above Inf above everything
+    finite) and ops.OperandScales raises when the maximum arrives on the host."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    sc = ops.OperandScales(dev)
+    sc.begin_step()
+    W = torch.zeros(64, 64, device=dev)
+    ops._ACTIVE_SCALES = sc
+    try:
+        site = ops._site("a", W)
+        x = torch.randn(256, 64, device=dev)
+        ops._split_rows(x, site=site)
+        sc.calibrate_from_device()                     # finite: fine
+        assert sc.report()[("a", W.data_ptr())][0] == pytest.approx(float(x.abs().max()), rel=1e-6)
+        sc.begin_step()
+        site = ops._site("a", W)
+        x[17, 5] = float("nan")
+        ops._split_rows(x, site=site)
+        with pytest.raises(ops.LpmError, match="NaN / Inf"):
+            sc.calibrate_from_device()
+        x[17, 5] = float("inf")
+        sc.amax.zero_()
+        ops._split_rows(x, site=site)
+        with pytest.raises(ops.LpmError, match="NaN / Inf"):
+            sc.calibrate_from_device()
+    finally:
+        ops._ACTIVE_SCALES = None

@@ -21,13 +21,18 @@ def vlad_precision(request):
     ops.VLAD_PRECISION, ops.ASSIGN_PRECISION = old
 
 
-@pytest.fixture(params=["bf16x3", "f32"])
+@pytest.fixture(params=["bf16x3", "bf16x3/3", "f32"])
 def mha_precision(request):
-    """Both matrix-core arithmetics of the attention core K4."""
-    from learnablepoolingmethods_amd import ops
+    """The matrix-core arithmetics of the attention core K4: split-bf16 with the backward's products on two fp16 terms (round 6, the
+    default) or on three bf16 terms ("bf16x3/3": lpm_mha_bwd_set_terms), and exact fp32."""
+    from learnablepoolingmethods_amd import _capi, ops
+    lib = _capi.load()
     old = ops.MHA_PRECISION, ops.MHA_BN_PRECISION
-    ops.MHA_PRECISION = ops.MHA_BN_PRECISION = request.param
+    prec, _, terms = request.param.partition("/")
+    ops.MHA_PRECISION = ops.MHA_BN_PRECISION = prec
+    prev = lib._lpm_mha_bwd_set_terms(int(terms or 2))
     yield request.param
+    lib._lpm_mha_bwd_set_terms(prev)
     ops.MHA_PRECISION, ops.MHA_BN_PRECISION = old
 
 
@@ -337,6 +342,57 @@ def test_mha_core(B, L, h, d, mha_precision):
     assert_close(qg.grad, qd.grad, what="dq")
     assert_close(kg.grad, kd.grad, what="dk")
     assert_close(vg.grad, vd.grad, what="dv")
+
+
+@pytest.mark.parametrize("L,h,d,bn", [(256, 4, 16, False), (64, 4, 8, False), (300, 4, 16, True), (500, 2, 16, False)])
+@pytest.mark.parametrize("gscale", [1e-9, 1.0, 3e4])
+def test_mha_backward_two_terms_over_the_gradient_range(L, h, d, bn, gscale):
+    """Round 6: the backward's products on two fp16 terms (lpm_mha_bwd_set_terms(2), the default).  fp16 has five exponent bits and the
+    gradient reaching the attention core spans 1e-9 ... 20 over a run: the kernels scale dO by a power of two taken from max |dO| -- per
+    query in the dq kernel, per (batch, head) in the dkv kernel -- so the result must be as good at 1e-9 and at 3e4 as at 1, with one
+    query row 1e6 x smaller than the rest (its dq still to 1e-3 of ITS scale: the per-query scale).  Also prints the two-term
+    form's distance from the fp64 oracle beside the three-term form's (transformer_utils.py:570-578, 640-661)."""
+    from learnablepoolingmethods_amd import _capi, ops
+    lib = _capi.load()
+    dev = cuda()
+    B = 2
+    g = torch.Generator().manual_seed(7 * L + d)
+    F = h * d
+    q, k, v, do = (torch.randn(B, L, F, generator=g) for _ in range(4))
+    do = do * gscale
+    do[:, 3] *= 1e-6
+    sc = 1.0 if bn else d ** -0.5
+    gamma, beta = 1 + 0.2 * torch.randn(L, generator=g), 0.1 * torch.randn(L, generator=g)
+    p = {"bn/gamma": gamma.double().requires_grad_(True), "bn/beta": beta.double().requires_grad_(True),
+         "bn/moving_mean": torch.zeros(L).double(), "bn/moving_variance": torch.ones(L).double()}
+    if bn:
+        q, k = 0.5 * q, 0.5 * k
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    fn = (lambda lg: O.batch_norm(lg, p, "bn", True, {})) if bn else None
+    ref = O._combine_heads(O.attention_core(O._split_heads(qd, h), O._split_heads(kd, h), O._split_heads(vd, h), sc, fn))
+    ref.backward(do.double())
+    dgamma_ref, dbeta_ref = p["bn/gamma"].grad, p["bn/beta"].grad
+    errs = {}
+    for terms in (2, 3):
+        prev = lib._lpm_mha_bwd_set_terms(terms)
+        try:
+            qg, kg, vg = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+            if bn:
+                gg, bg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+                out = ops.mha_core_bn(qg, kg, vg, h, gg, bg, torch.zeros(L, device=dev), torch.ones(L, device=dev), is_training=True)
+            else:
+                out = ops.mha_core(qg, kg, vg, h, sc)
+            out.backward(do.to(dev))
+            errs[terms] = (rel_err(qg.grad, qd.grad), rel_err(kg.grad, kd.grad), rel_err(vg.grad, vd.grad),
+                           rel_err(qg.grad[:, 3], qd.grad[:, 3]))
+            if bn:
+                errs[terms] += (rel_err(gg.grad, dgamma_ref), rel_err(bg.grad, dbeta_ref))
+        finally:
+            lib._lpm_mha_bwd_set_terms(prev)
+    print(f"[K4 backward L={L} d={d} bn={bn} |dO|~{gscale:g}] two terms (dq, dk, dv, dq of the small row, ...): "
+          + ", ".join(f"{e:.1e}" for e in errs[2]) + "; three terms: " + ", ".join(f"{e:.1e}" for e in errs[3]))
+    assert max(errs[2]) <= 1e-3, f"two-term backward: {errs[2]}"
+    assert max(errs[3]) <= 1e-3, f"three-term backward: {errs[3]}"
 
 
 @pytest.mark.parametrize("B,L,h,d,training", [(2, 48, 2, 16, True), (2, 300, 8, 16, True), (2, 30, 8, 16, False), (4, 12, 64, 16, True),
