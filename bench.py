@@ -44,9 +44,8 @@ WORKLOADS = {
                               "per-tensor power-of-two scales (ops.OperandScales): forward products 3 MFMAs (~1e-6); input-gradient products 2 MFMAs, "
                               "the weight rounded once to fp16 (measured against fp64: 2.1e-4 relative L2 per GEMM); weight-gradient products "
                               "1 MFMA, BOTH operands rounded once to fp16 (2.9e-4 relative L2; tests/test_gpu_fp16x2.py; LPM_DW_TERMS=2: the "
-                              "gradient operand exact); the attention core's backward (K4) keeps the scores on 3 split-bf16 MFMAs and runs "
-                              "dP / dV / dK / dQ on 2 fp16 MFMAs with V, P and dS rounded once (LPM_MHA_BWD_TERMS=3: split-bf16); "
-                              "LPM_DENSE_ARITHMETIC=bf16x3 runs the dense GEMMs as in rounds 1-4"),
+                              "gradient operand exact); LPM_DENSE_ARITHMETIC=bf16x3 runs the dense GEMMs as in rounds 1-4 (LPM_MHA_BWD_TERMS=2, not the "
+                              "default: K4's backward products behind dS on 2 fp16 MFMAs)"),
     "cfg3": dict(metric="clips/sec training step, NetVladV2 (attention-based cluster similarities) K=256 300-frame 1152-d, bs=80 (BASELINE configs[2])",
                  model="NetVladV2", model_kwargs=dict(iterations=300, cluster_size=256, hidden_size=512),     # hidden: README.md:17
                  oracle=dict(iterations=300, cluster_size=256, hidden_size=512), flags={}, batch=80, elt=4, dtype="f32", parity_tol=1e-3,
@@ -298,6 +297,68 @@ def count_dispatches(step):
         return None
 
 
+def replica_check(trainer, world, group=None):
+    """After the timed region: do all towers hold the same parameters?  Data-parallel replicas apply identical updates (train.py:266-336:
+    shared variables in the reference) -- on the sharded route each rank updates its 1/N of hidden1_weights and the all-gather hands
+    everyone the rest: a rank that missed a collective or read the variable before its gather landed shows up here.  A collective: every
+    rank calls it.  (tests/test_dp_gloo.py runs it over gloo at world 8.)"""
+    if trainer.sharded is not None:
+        trainer.sharded.wait_parameters()
+    pd = trainer.arena.param.double()
+    cs = torch.stack([pd.sum(), (pd * pd).sum(), pd.abs().max()])
+    del pd
+    allcs = [torch.empty_like(cs) for _ in range(world)]
+    dist.all_gather(allcs, cs, group=group)
+    dev_ = max(float((c - allcs[0]).abs().max()) for c in allcs)
+    route = "sharded (C)" if trainer.sharded is not None else ("factored (B)" if trainer.factored is not None else "all-reduce (A)")
+    return {"consistent": dev_ == 0.0, "max_checksum_difference": dev_, "hidden1_weights_route": route,
+            "checked": "sum, sum of squares and max |.| of the whole parameter arena, float64, every rank against rank 0"}
+
+
+def dry_run_model(args):
+    """--dry-run-model: the communication cost of one data-parallel step of ``--config`` over ``--gpus`` towers as FORMULAS with the bus
+    bandwidth left as the variable (no GPU, no process group).  Per route of hidden1_weights (train.Trainer.build):
+      A  bucket all-reduce of its gradient:            t = 2 (N - 1) / N * S_h1 / bw
+      B  all-gather of the two gradient factors:       t = (N - 1) * (S_x + S_dy) / bw           (<= 4 towers)
+      C  reduce-scatter + parameter all-gather:        t = (N - 1) / N * S_h1 / bw each          (the default beyond 4 towers)
+    and for every other bucket t = 2 (N - 1) / N * S / bw.  ``bw`` is RCCL's bus bandwidth on this node -- what the first real run's
+    ``collectives`` block measures; the table evaluates the formulas at 100 ... 400 GB/s (xGMI: 7 links x ~153 GB/s per GPU, point to
+    point: a ring is per-link bound).  Windows: the N = 1 step's phases measured on one MI355X (profiles/r06_*)."""
+    wl = WORKLOADS[args.config]
+    N = max(2, args.gpus)
+    mk = wl["model_kwargs"]
+    K, H, B = mk["cluster_size"], mk["hidden_size"], wl["batch"]
+    n1 = 1024 * K + 128 * (K // 4)
+    s_h1 = 4 * n1 * H
+    m = wl.get("flags", {}).get("moe_num_mixtures", 2)
+    s_head = 4 * (H * VOCAB * (m + 1) + H * VOCAB * m + H * H + 4 * H)
+    enc = mk.get("encoder", True) and wl.get("model", "NetVladV1") == "NetVladV1"
+    s_enc = 4 * (12 * 1024 * 1024 + 12 * 128 * 128) if enc else (4 * (4 * 1024 * 1024 + 2 * 1024 * 4096 + 4096 * K) if wl.get("model") == "NetVladV2" else 0)
+    s_pool = 4 * 2 * (1024 * K + 128 * (K // 4)) + 4 * 4 * 1152
+    s_fact = 2 * 2 * (B * n1 + B * H)                 # split-bf16 tiles of X [B, n1] and DY [B, H] per tower
+    rows = [("head bucket all-reduce", s_head, lambda bw: 2 * (N - 1) / N * s_head / bw),
+            ("encoder bucket all-reduce", s_enc, lambda bw: 2 * (N - 1) / N * s_enc / bw),
+            ("pooling bucket all-reduce", s_pool, lambda bw: 2 * (N - 1) / N * s_pool / bw),
+            ("hidden1 route A: all-reduce", s_h1, lambda bw: 2 * (N - 1) / N * s_h1 / bw),
+            ("hidden1 route B: all-gather of factors", s_fact, lambda bw: (N - 1) * s_fact / bw),
+            ("hidden1 route C: reduce-scatter", s_h1, lambda bw: (N - 1) / N * s_h1 / bw),
+            ("hidden1 route C: parameter all-gather", s_h1, lambda bw: (N - 1) / N * s_h1 / bw)]
+    bws = [100, 200, 300, 400]
+    out = {"config": args.config, "towers": N, "per_rank_batch": B, "formula": {
+               "all_reduce": "2 (N - 1) / N * bytes / bw", "reduce_scatter / all_gather": "(N - 1) / N * bytes / bw",
+               "all_gather of per-tower factors": "(N - 1) * bytes_per_tower / bw"},
+           "ms_at_bus_GBps": {str(b): {} for b in bws}, "bytes": {}}
+    for name, nbytes, f in rows:
+        out["bytes"][name] = int(nbytes)
+        for b in bws:
+            out["ms_at_bus_GBps"][str(b)][name] = round(1e3 * f(b * 1e9), 3)
+    out["default_route"] = "B (factored)" if N <= 4 else "C (sharded)"
+    out["note"] = ("bw = RCCL bus bandwidth on the node, unmeasured (no multi-GPU node has been available in six rounds); the first real "
+                   "run prints window_ms / exposed_ms per collective (train.CollectiveTrace) and replaces this table")
+    print(json.dumps(out))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,8 +383,12 @@ def main():
                          "JSON lines, the BASELINE metric's (cfg2) last")
     ap.add_argument("--watchdog-seconds", type=float, default=240.0,
                     help="N > 1 only: a rank that makes no progress for this long prints its phase and last collective and exits 3")
+    ap.add_argument("--dry-run-model", action="store_true",
+                    help="print the per-collective cost formulas of a data-parallel step over --gpus towers (no GPU needed) and exit")
     args = ap.parse_args()
 
+    if args.dry_run_model:
+        raise SystemExit(dry_run_model(args))
     if args.config == "all":
         raise SystemExit(run_all(sys.argv[1:]))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -469,17 +534,7 @@ def main():
         # sharded route each rank updates its 1/N of hidden1_weights and the all-gather hands everyone the rest: a rank that missed a
         # collective or read the variable before its gather landed shows up here, on the first real multi-GPU run as well)
         dog.tick("replica consistency check (all_gather of parameter checksums)")
-        if trainer.sharded is not None:
-            trainer.sharded.wait_parameters()
-        pd = trainer.arena.param.double()
-        cs = torch.stack([pd.sum(), (pd * pd).sum(), pd.abs().max()])
-        del pd
-        allcs = [torch.empty_like(cs) for _ in range(world)]
-        dist.all_gather(allcs, cs)
-        dev_ = max(float((c - allcs[0]).abs().max()) for c in allcs)
-        route = "sharded (C)" if trainer.sharded is not None else ("factored (B)" if trainer.factored is not None else "all-reduce (A)")
-        replicas = {"consistent": dev_ == 0.0, "max_checksum_difference": dev_, "hidden1_weights_route": route,
-                    "checked": "sum, sum of squares and max |.| of the whole parameter arena, float64, every rank against rank 0"}
+        replicas = replica_check(trainer, world)
     loss = float(out["loss"])
 
     if rank == 0:
@@ -500,7 +555,10 @@ def main():
             bytes_ = k2_algorithmic_bytes(B, T, D, K, elt)
             ach = bytes_ / (avg_ms * 1e-3) / 1e9
             prec = ops.VLAD_PRECISION
-            if elt == 2:
+            if elt == 2 and ops.VLAD_CLIP16 and lib._lpm_vlad_clip16_slabs(D, K):
+                kname = ("vlad_clip16_kernel (K2, video stream, plain bf16 tiles, one MFMA per product, LDS-DMA, clip-wide items: 256 clusters "
+                         "x a third of a clip's columns per workgroup, 2 x 6 register tiles)")
+            elif elt == 2:
                 kname = "vlad_aggregate_tiles3_kernel<false,1> (K2, video stream, plain bf16 tiles, one MFMA per product, LDS-DMA)"
             elif prec == "bf16x3" and ops.VLAD_TILES3 and ops.VLAD_KMAJOR_SCALED and args.config == "cfg2":
                 kname = ("vlad_kmajor_kernel (K2 + row scales, video stream, split-bf16 MFMA, LDS-DMA tiles, 256 x 128 and 128 x 128 "

@@ -380,6 +380,13 @@ int lpm_assign_tiles_bf16(const void* assign_bf16, const float* scale, const flo
                           lpm_stream_t stream);
 int lpm_vlad_aggregate_tiles3_fwd_bf16(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
                                        float* nrm, float* asum, float* colsq_part, lpm_stream_t stream);
+/* K2 for bf16 storage on CLIP-WIDE items (csrc/vlad_clip16.hip, round 6): the contract of lpm_vlad_aggregate_tiles3_fwd_bf16, but a
+ * 512-thread workgroup owns 256 clusters x a third of a clip's columns (6 workgroups per clip at K = 512, D = 1024), a wave a 2 x 6
+ * register tile, and colsq_part is [B, P, K] with P = lpm_vlad_clip16_slabs(D, K) column slabs (0: shape not supported -- K %% 256 == 0,
+ * D %% 32 == 0, D >= 384).  frame_level_models.py:2803-2817. */
+int lpm_vlad_clip16_slabs(int D, int K);
+int lpm_vlad_aggregate_clip_fwd_bf16(const void* at, const void* xt, const float* centres, int B, int T, int D, int K, int flags,
+                                     void* nrm_bf16, float* asum, float* colsq_part, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3: backward of K2 (TF autodiff of the same lines; formulas SURVEY.md App. F.1-F.3).
@@ -709,10 +716,12 @@ int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, int64_t ld, c
                 int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
                 const float* key_shift, float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a,
                 const float* corr_b, float* dz_partial, lpm_stream_t stream);
-/* Arithmetic of lpm_mha_bwd_x3 / lpm_mha_bwd_x3_image[_fmt] for the process: 2 (default; LPM_MHA_BWD_TERMS) = fp16 planes, two-term
- * products -- the scores stay split-bf16 x3, dO and the operands re-read from LDS exact as fp16 (hi, lo) under a power-of-two scale the
- * kernels take from max |dO| themselves, V, P and dS rounded once to fp16 (2^-12: the arithmetic of the dense layers' input gradients);
- * 3 = split-bf16, three-term products (rounds 2-5).  Any other value only queries.  Returns the previous setting. */
+/* Arithmetic of lpm_mha_bwd_x3 / lpm_mha_bwd_x3_image[_fmt] for the process: 2 (opt-in: LPM_MHA_BWD_TERMS=2) = the three products behind
+ * dS (dV = dO^T P, dK = Q^T dS, dQ = K^T dS) on two fp16 terms -- the operand re-read from LDS exact as fp16 (hi, lo), P and dS rounded
+ * once to fp16 (2^-12: the arithmetic of the dense layers' input gradients), dO under a power-of-two scale the kernels take from
+ * max |dO| themselves; the scores and dP = dO V^T stay split-bf16 x3.  Launches WITH correction vectors (logits_bn's dq pass) keep
+ * three terms whatever the setting.  3 (the default) = split-bf16, three-term products throughout.  Any other value only queries.
+ * Returns the previous setting. */
 int lpm_mha_bwd_set_terms(int terms);
 /* logits_bn backward in one pass over the scores: after lpm_mha_bwd_x3(dq = NULL, dk, dv, corr_a = corr_b = NULL, dz_partial) -- the
  * key / value gradients WITHOUT the batch statistics' share, and the statistics --, lpm_mha_bn_corrections, and

@@ -99,6 +99,8 @@ SIGNATURES = {
     "lpm_assign_gemm_tiles_bwd_dw_bf16": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _s, _f]),
     "lpm_assign_tiles_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),
     "lpm_vlad_aggregate_tiles3_fwd_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "lpm_vlad_clip16_slabs": (_i, [_i, _i]),
+    "lpm_vlad_aggregate_clip_fwd_bf16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "lpm_vlad_aggregate_raw_kmajor_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "lpm_vlad_smx_stats_bytes": (_s, [_i, _i]),
     "lpm_vlad_smx_supported": (_i, [_i, _i, _i]),

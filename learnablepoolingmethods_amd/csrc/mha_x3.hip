@@ -131,15 +131,18 @@ __device__ __forceinline__ void mx_load_o8(const float* base, int64_t row, int64
                         __uint_as_float(h.w << 16) + __uint_as_float(l.w << 16), __uint_as_float(h.w & 0xffff0000u) + __uint_as_float(l.w & 0xffff0000u));
     }
 }
-// ---- round 6: the backward's products on TWO terms, fp16 planes (the treatment the dense GEMMs' backward got in round 5) --------------
-// What stays exact: the scores S (split-bf16 x3: they sit under an exp), dO and everything that is linear in it down to the MFMA operand
-// it meets (fp16 hi + lo planes of dO * s, s a power of two chosen from max |dO| -- fp16 has five exponent bits, gradients span 1e-9 ... 20),
-// and the operand that is re-read from LDS (K^T in the dq kernel, Q^T and dO^T in the dkv kernel: fp16 hi + lo).  What is rounded ONCE to
-// fp16 (11 bits, 2^-12 relative: the 1.4e-4 per product of the dense input gradients): V against dO (dP = dO V^T is ONE 32-deep MFMA at
-// d = 16, [Vh | Vh] . [dOh | dOl], instead of two), and the per-score values formed in registers -- P against dO^T, dS against K^T / Q^T:
-// two MFMAs per product instead of three and ONE v_cvt_pk_f16_f32 per pair of scores instead of the (hi, lo) split's five VALU
-// operations, in kernels whose vector pipe is ~94 % busy.  Per 32 keys x 16 queries: dq 11 -> 8 MFMAs, dkv 14 -> 10; VALU operations
-// per score ~10 -> ~7.5 (dq), ~13 -> ~8 (dkv).  LPM_MHA_BWD_TERMS=3 / lpm_mha_bwd_set_terms(3) keeps the three-term bf16 form (A/B).
+// ---- round 6: the backward's last products on TWO terms, fp16 planes (the treatment the dense GEMMs' backward got in round 5) --------
+// What stays exact (split-bf16 x3): the scores S (they sit under an exp) AND dP = dO V^T -- it meets D_q = <dO_q, O_q> in the difference
+// dS = P (dP - D_q), and with a peaked attention that difference is a small remainder of two large numbers: a first version with V
+// rounded once (dP as ONE fp16 MFMA) was 8e-4 off in the input gradient of tests/test_gpu_attention_modules.py (kernels x 4, tolerance
+// 2e-4) where the three-term form is at 1e-5.  What goes to two fp16 terms are the three products BEHIND dS: dV = dO^T P, dK = Q^T dS,
+// dQ = K^T dS.  The operand that is re-read from LDS stays exact as fp16 (hi, lo) -- dO^T * s and Q^T in the dkv kernel, K^T in the dq
+// kernel -- and the per-score operand formed in registers is rounded ONCE to fp16 (2^-12 relative, the arithmetic of the dense layers'
+// input gradients): P, dS.  Two MFMAs per product instead of three and ONE v_cvt_pk_f16_f32 per pair of scores instead of the (hi, lo)
+// split's five VALU operations.  fp16 has five exponent bits and gradients span 1e-9 ... 20: dO is scaled by a power of two s taken
+// from max |dO| -- per query in the dq kernel, per (batch, head) in the dkv kernel (its reductions run over queries) -- BEFORE it is
+// split for dP, so dP, D_q and dS carry s for free and the stores take it out again (exact both ways).
+// LPM_MHA_BWD_TERMS=3 / lpm_mha_bwd_set_terms(3) keeps the three-term bf16 form (A/B).
 typedef _Float16 mx_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mx_mfma_h(mx_u32x4 a, mx_u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_f16x8, a), __builtin_bit_cast(mx_f16x8, b), c, 0, 0, 0);
@@ -164,20 +167,7 @@ __device__ __forceinline__ void mx_pow2_scale(float amax, float& s, float& inv) 
     s = __uint_as_float((unsigned)se << 23);
     inv = __uint_as_float((unsigned)(254 - se) << 23);
 }
-// stage rows [0, L) of head hh as the fp16 hi plane only, D/8 arrays of LP x 16 bytes (the rounded-once operand of dP)
-template <int D>
-__device__ __forceinline__ void mx_stage_rows_h1(unsigned char* dst, const float* __restrict__ src, int64_t ld, int b, int L, int LP, int hh,
-                                                 int tid, int nt) {
-    constexpr int NH = D / 8;
-    for (int i = tid; i < L * NH; i += nt) {
-        const int row = i / NH, hf = i % NH;
-        const float* p = src + ((int64_t)b * L + row) * ld + hh * D + 8 * hf;
-        const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
-        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-        *reinterpret_cast<mx_u32x4*>(dst + (hf * LP + row) * 16) = mx_round8_h(v);
-    }
-}
-// ... and transposed + permuted as fp16 (hi, lo) planes: T[plane][d][perm(row)]
+// stage rows [0, L) of head hh transposed + permuted as fp16 (hi, lo) planes: T[plane][d][perm(row)]
 template <int D>
 __device__ __forceinline__ void mx_stage_transposed_h(unsigned char* dst, const float* __restrict__ src, int64_t ld, int b, int L, int LP,
                                                       int hh, int tid, int nt) {
@@ -689,13 +679,17 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
 // is taken from max |dO|): the plain attention, and logits_bn's launches without correction vectors (corr_a == NULL: the one-pass
 // backward's dkv kernel) -- with corrections the batch statistics' terms enter dS at the size of the GLOBAL gradient whatever this
 // query's / head's own dO is, and the launcher keeps the three-term kernels (bf16 has fp32's range).
-// Measured (tools/time_mha_bwd.py, rocprofv3; B = 80, h = 64, d = 16): L = 256 dq 215 -> 207 us, dkv 266 -> 234 us; L = 300 with logits_bn
-// dkv 556 -> 487 us -- 5-13 % for 27-29 % of the MFMAs and 25-38 % of the VALU operations per score removed.  The sweeps are bound by
-// neither count: TPW = 2 (a wave runs two tiles side by side through ONE stream of fragment reads: half the LDS traffic per score,
-// twice the independent work per wave, but 140 registers = half the waves) measured dkv 290 us, dq 196 us at L = 256 and dq 401 us
-// against 335 at L = 300 -- what the kernels live on is the number of waves a SIMD can switch between while one waits for its
-// MFMA -> exp2 -> convert -> MFMA chain, and that is capped at four by the 66 KB of staged operands per (batch, head).  TPW = 2 is
-// reachable for L = 256, d = 16 only (LPM_MHA_BWD_TPW=2, the A/B).
+// Measured (tools/time_mha_bwd.py, rocprofv3, profiles/r06_k4_backward_terms.md; B = 80, h = 64, d = 16), whole backward: L = 256
+// 543 -> 512 us (-6 %), L = 300 with logits_bn (dkv only: the dq pass carries corrections) 1037 -> 1016 us (-2 %); a cfg-2 step 6.72 ->
+// 6.70 ms.  With dP on one fp16 MFMA as well (V rounded once) it was 557 -> 508 us -- and 8e-4 off where attention is peaked.
+// 18-27 % of the MFMAs and 25-38 % of the VALU operations per score buy 2-6 %: the sweeps are bound by neither count.  TPW = 2 (a wave
+// runs two tiles side by side through ONE stream of fragment reads: half the LDS traffic per score, twice the independent work per
+// wave, but 140 registers = half the waves) measured dkv 290 us against 234, dq 196 against 207 at L = 256 and dq 401 us against 335
+// at L = 300 -- what the kernels live on is the number of waves a SIMD can switch between while one waits for its MFMA -> exp2 ->
+// convert -> MFMA chain, and that is capped at four by the 66 KB of staged operands per (batch, head).  The same measurement answers
+// the merged dq + dkv sweep (DESIGN: ~174 registers, two waves per SIMD): it would run at TPW = 2's occupancy.  NOT the default
+// (lpm_mha_bwd_set_terms): 0.3 % of a step does not pay for gradients 2-3e-4 away from the three-term form's (1e-5 from fp64), and
+// tests/test_gpu_attention_modules.py holds its module to 2e-4.  TPW = 2 is reachable for L = 256, d = 16 only (LPM_MHA_BWD_TPW=2).
 // threads per workgroup: one tile per wave -- as the three-term kernels (dq 512; dkv 512, 1024 from NKT = 20 on); two -- one wave per task
 template <int NKT, int TPW, bool DKV> __host__ __device__ constexpr int mx_h_nt() {
     constexpr int w = (NKT + TPW - 1) / TPW;
@@ -716,7 +710,7 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, false>())) void mha_bwd_dq_h_ker
     const int nkt = (L + 15) >> 4;
     const float qmul = AFFINE ? scale : scale * MX_LOG2E;      // scores in log2 units (AFFINE: z is converted instead)
     unsigned char* Kp = smem;                                  // K rows, split-bf16 (hi, lo): the scores stay exact
-    unsigned char* Vp = Kp + mx_rowplanes_bytes(LP, D);        // V rows, the fp16 hi plane (rounded once)
+    unsigned char* Vp = Kp + mx_rowplanes_bytes(LP, D);        // V rows, split-bf16 (hi, lo): dP stays exact (it meets D_q in a difference)
     unsigned char* Kt = Vp + mx_rowplanes_bytes(LP, D);        // K^T, fp16 (hi, lo)
     float* ksc = reinterpret_cast<float*>(Kt + mx_tplanes_bytes(LP));
     float* ksh = ksc + LP;
@@ -742,14 +736,14 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, false>())) void mha_bwd_dq_h_ker
         }
     }
     mx_stage_rows<D>(Kp, k, ld, b, L, LP, hh, 1.f, tid, NT);
-    mx_stage_rows_h1<D>(Vp, v, ld, b, L, LP, hh, tid, NT);
+    mx_stage_rows<D>(Vp, v, ld, b, L, LP, hh, 1.f, tid, NT);
     mx_stage_transposed_h<D>(Kt, k, ld, b, L, LP, hh, tid, NT);
     __syncthreads();
 
     const mx_u32x4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll 1
     for (int t0 = wave * TPW; t0 < nkt; t0 += (NT / 64) * TPW) {
-        mx_u32x4 qb1[TPW], qb2[TPW], gb[TPW];
+        mx_u32x4 qb1[TPW], qb2[TPW], gb1[TPW], gb2[TPW];
         float dqv[TPW], lq[TPW], sq[TPW], sqinv[TPW];
         f32x4 dqa[TPW], dqb[TPW];
 #pragma unroll
@@ -780,12 +774,13 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, false>())) void mha_bwd_dq_h_ker
             // this query's power-of-two scale s_q (max |dO_q| s_q in [16, 32)).  A lane owns one query COLUMN of every product below, so
             // dP, D_q, dS and dQ of the query all carry s_q and the store takes it out again.
             mx_pow2_scale(gmax, sq[u], sqinv[u]);
-            mx_split8_h(gv, sq[u], gh, gl);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] *= sq[u];            // (a power of two: exact; bf16 has fp32's range)
+            mx_split8(gv, gh, gl);
             dqv[u] = dpart * sq[u];                                // D_q = <dO_q, O_q>
             lq[u] = qok ? lse[((int64_t)b * h + hh) * L + qrow] * MX_LOG2E : INFINITY;
             mx_col_frags<D>(qh, ql, g, qb1[u], qb2[u]);
-            // dP^T = V dO^T as ONE MFMA: A = [Vh | Vh] (d = 16: arrays g & 1; d = 8: array 0 for every lane group), B = [dOh | dOl]
-            gb[u] = (D == 16) ? ((g < 2) ? gh : gl) : ((g == 0) ? gh : ((g == 1) ? gl : z4));
+            mx_col_frags<D>(gh, gl, g, gb1[u], gb2[u]);
             dqa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             dqb[u] = dqa[u];
         }
@@ -796,7 +791,7 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, false>())) void mha_bwd_dq_h_ker
             for (int t = 0; t < 2; ++t) {
                 const int kt = 2 * j + t;
                 const mx_u32x4 ka = mx_row_frag<D>(Kp, LP, kt, l15, g);
-                const mx_u32x4 va = *reinterpret_cast<const mx_u32x4*>(Vp + (((D == 16) ? (g & 1) : 0) * LP + kt * 16 + l15) * 16);
+                const mx_u32x4 va = mx_row_frag<D>(Vp, LP, kt, l15, g);
                 float sc4[4], sh4[4], ca4[4], cb4[4];
                 if (AFFINE) {
                     const float4 a = *reinterpret_cast<const float4*>(ksc + kt * 16 + 4 * g), c = *reinterpret_cast<const float4*>(ksh + kt * 16 + 4 * g);
@@ -808,8 +803,11 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, false>())) void mha_bwd_dq_h_ker
                 for (int u = 0; u < TPW; ++u) {
                     f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
                     st = mx_mfma(ka, qb1[u], st);
-                    dp = mx_mfma_h(va, gb[u], dp);
-                    if (D == 16) st = mx_mfma(ka, qb2[u], st);
+                    dp = mx_mfma(va, gb1[u], dp);                  // dP^T s_q = V (dO s_q)^T: three terms, as the scores
+                    if (D == 16) {
+                        st = mx_mfma(ka, qb2[u], st);
+                        dp = mx_mfma(va, gb2[u], dp);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float z = st[r];
@@ -860,7 +858,7 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, true>())) void mha_bwd_dkv_h_ker
     const int nkt = (L + 15) >> 4;
     const float qmul = AFFINE ? scale : scale * MX_LOG2E;       // scores in log2 units (AFFINE: z is converted instead)
     unsigned char* Qp = smem;                                   // qmul * Q rows, split-bf16 (hi, lo): the scores stay exact
-    unsigned char* Gp = Qp + mx_rowplanes_bytes(LP, D);         // dO s rows, fp16 (hi, lo)
+    unsigned char* Gp = Qp + mx_rowplanes_bytes(LP, D);         // dO s rows, split-bf16 (hi, lo): dP stays exact (it meets D_q in a difference)
     unsigned char* Qt = Gp + mx_rowplanes_bytes(LP, D);         // (qmul * Q)^T, fp16 (hi, lo)
     unsigned char* Gt = Qt + mx_tplanes_bytes(LP);              // (dO s)^T, fp16 (hi, lo)
     float* lses = reinterpret_cast<float*>(Gt + mx_tplanes_bytes(LP));
@@ -917,14 +915,16 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, true>())) void mha_bwd_dkv_h_ker
             part = ga.x * oa.x + ga.y * oa.y + ga.z * oa.z + ga.w * oa.w + gc.x * oc.x + gc.y * oc.y + gc.z * oc.z + gc.w * oc.w;
             const float qv[8] = {qa.x * qmul, qa.y * qmul, qa.z * qmul, qa.w * qmul, qc.x * qmul, qc.y * qmul, qc.z * qmul, qc.w * qmul};
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
-            mx_u32x4 qh, ql, gh, gl, qfh, qfl;
+            const float gsv[8] = {gv[0] * gs, gv[1] * gs, gv[2] * gs, gv[3] * gs, gv[4] * gs, gv[5] * gs, gv[6] * gs, gv[7] * gs};
+            mx_u32x4 qh, ql, gbh, gbl, gh, gl, qfh, qfl;
             mx_split8(qv, qh, ql);
-            mx_split8_h(gv, gs, gh, gl);
+            mx_split8(gsv, gbh, gbl);                              // rows (dP): split-bf16
+            mx_split8_h(gv, gs, gh, gl);                           // transposed (dV against the rounded P): fp16 (hi, lo)
             mx_split8_h(qv, 1.f, qfh, qfl);
             *reinterpret_cast<mx_u32x4*>(Qp + ((0 * NH + hf) * LP + row) * 16) = qh;
             *reinterpret_cast<mx_u32x4*>(Qp + ((1 * NH + hf) * LP + row) * 16) = ql;
-            *reinterpret_cast<mx_u32x4*>(Gp + ((0 * NH + hf) * LP + row) * 16) = gh;
-            *reinterpret_cast<mx_u32x4*>(Gp + ((1 * NH + hf) * LP + row) * 16) = gl;
+            *reinterpret_cast<mx_u32x4*>(Gp + ((0 * NH + hf) * LP + row) * 16) = gbh;
+            *reinterpret_cast<mx_u32x4*>(Gp + ((1 * NH + hf) * LP + row) * 16) = gbl;
             const int pos = mx_perm(row);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -943,7 +943,7 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, true>())) void mha_bwd_dkv_h_ker
     const mx_u32x4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll 1
     for (int t0 = wave * TPW; t0 < nkt; t0 += (NT / 64) * TPW) {
-        mx_u32x4 kb1[TPW], kb2[TPW], vb[TPW];
+        mx_u32x4 kb1[TPW], kb2[TPW], vb1[TPW], vb2[TPW];
         float sck[TPW], shk[TPW], cak[TPW], cbk[TPW], zs[TPW], zq[TPW];
         bool kok[TPW];
         f32x4 dka[TPW], dkb[TPW], dva[TPW], dvb[TPW];
@@ -951,7 +951,7 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, true>())) void mha_bwd_dkv_h_ker
         for (int u = 0; u < TPW; ++u) {
             const int krow = (t0 + u) * 16 + l15;
             kok[u] = krow < L;
-            mx_u32x4 kh = z4, kl = z4, vh = z4;
+            mx_u32x4 kh = z4, kl = z4, vh = z4, vl = z4;
             if (kok[u]) {
                 const int64_t off = ((int64_t)b * L + krow) * ld + hh * D + ((D == 16) ? 8 * (g & 1) : 0);
                 const float4 ka = *reinterpret_cast<const float4*>(k + off), kc = *reinterpret_cast<const float4*>(k + off + 4);
@@ -959,10 +959,10 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, true>())) void mha_bwd_dkv_h_ker
                 const float kv[8] = {ka.x, ka.y, ka.z, ka.w, kc.x, kc.y, kc.z, kc.w};
                 const float vv[8] = {va.x, va.y, va.z, va.w, vc.x, vc.y, vc.z, vc.w};
                 mx_split8(kv, kh, kl);
-                vh = mx_round8_h(vv);                          // V rounded once: dP = [dOh | dOl] . [Vh | Vh] is one MFMA
+                mx_split8(vv, vh, vl);
             }
             mx_col_frags<D>(kh, kl, g, kb1[u], kb2[u]);
-            vb[u] = (D == 16 || g < 2) ? vh : z4;              // d = 8: the A arrays are [dOh | dOl | . | .]
+            mx_col_frags<D>(vh, vl, g, vb1[u], vb2[u]);
             sck[u] = (key_scale && kok[u]) ? key_scale[krow] : 1.f;
             shk[u] = (key_shift && kok[u]) ? key_shift[krow] : 0.f;
             cak[u] = ((corr_a && kok[u]) ? corr_a[krow] : 0.f) * gs;
@@ -986,8 +986,11 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, true>())) void mha_bwd_dkv_h_ker
                 for (int u = 0; u < TPW; ++u) {
                     f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
                     st = mx_mfma(qa, kb1[u], st);              // S[q, key] (scale folded into Q)
-                    dp = mx_mfma_h(ga, vb[u], dp);             // dP[q, key] s = (dO s) V^T
-                    if (D == 16) st = mx_mfma(qa, kb2[u], st);
+                    dp = mx_mfma(ga, vb1[u], dp);              // dP[q, key] s = (dO s) V^T: three terms, as the scores
+                    if (D == 16) {
+                        st = mx_mfma(qa, kb2[u], st);
+                        dp = mx_mfma(ga, vb2[u], dp);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float sraw = st[r];
@@ -1194,11 +1197,13 @@ static int mx_reserve(KernT kern, size_t bytes, const char* what) {
                 name ": need d in {8,16} and L <= 512 (L=%d d=%d)", L, d);                                          \
     LPM_REQUIRE(ld >= (int64_t)h * d && ld % 4 == 0, LPM_ERR_BADARG, name ": bad leading dimension")
 
-// Process-wide arithmetic of the backward kernels: 2 = fp16 two-term products (round 6, default), 3 = split-bf16 three-term products
-// (rounds 2-5).  LPM_MHA_BWD_TERMS sets the default; lpm_mha_bwd_set_terms switches at run time (tests, A/B) and returns the old value.
+// Process-wide arithmetic of the backward kernels: 3 = split-bf16 three-term products throughout (the default), 2 = the products behind dS
+// on two fp16 terms (round 6: built, measured, NOT the default -- 6 % of the backward at L = 256, 2 % at L = 300 with logits_bn, 0.3 % of a
+// cfg-2 step, for gradients 2-3e-4 from the three-term form's: see the kernels' header).  LPM_MHA_BWD_TERMS=2 opts in;
+// lpm_mha_bwd_set_terms switches at run time (tests, A/B) and returns the old value.
 static std::atomic<int> g_mha_bwd_terms{[] {
     const char* e = getenv("LPM_MHA_BWD_TERMS");
-    return (e && e[0] == '3') ? 3 : 2;
+    return (e && e[0] == '2') ? 2 : 3;
 }()};
 extern "C" int lpm_mha_bwd_set_terms(int terms) {
     if (terms != 2 && terms != 3) return g_mha_bwd_terms.load();

@@ -68,6 +68,8 @@ VLAD_KMAJOR_SCALED = os.environ.get("LPM_VLAD_KMAJOR_SCALED", "0") == "1"
 # K2 on clip-wide items (lpm_vlad_aggregate_clip_kmajor_fwd, vlad_clip.hip, round 4; K = 256): all clusters x a third of a clip's
 # columns per workgroup -- 168 MB through the LDS-DMA path instead of 389 MB.  "0": the 128 x 128 form (A/B).
 VLAD_CLIP = os.environ.get("LPM_VLAD_CLIP", "1") != "0"
+# bf16 storage: K2 on clip-wide items (csrc/vlad_clip16.hip, round 6) where the shape allows; "0": the 128 x 128 form everywhere (A/B)
+VLAD_CLIP16 = os.environ.get("LPM_VLAD_CLIP16", "1") != "0"
 # FeedForwardNetwork's first dense layer and its backward on the hand-written 256-row tile GEMM with operand-image epilogues
 # (lpm_dense_tiles_act_image_fwd / lpm_dense_tiles_relu_bwd_image) where the shape allows; 0: library GEMM + separate split passes (A/B).
 FFN_TILES = os.environ.get("LPM_FFN_TILES", "1") != "0"
@@ -895,11 +897,20 @@ class _NetVLAD(torch.autograd.Function):
             lib.check(lib._lpm_assign_tiles_bf16(ptr(logits), ptr(scale), ptr(shift), B, T, K, flags, ptr(at), st), "lpm_assign_tiles_bf16")
         nrm = torch.empty((B, D, K), dtype=torch.bfloat16, device=W.device)       # the un-normalised sums, bf16 like the descriptor
         asum, colsq, csq = (_empty((B, K), W) for _ in range(3))
-        P = D // 128
+        # round 6: clip-wide items (256 clusters x a third of the columns per workgroup, csrc/vlad_clip16.hip) where the shape allows
+        # (K a multiple of 256, D >= 384: BASELINE configs[4]'s video stream); the 128 x 128 form otherwise (its audio stream)
+        P = lib._lpm_vlad_clip16_slabs(D, K) if VLAD_CLIP16 else 0
+        clip16 = P > 0
+        if not clip16:
+            P = D // 128
         part = _empty((B, P, K), W)
         with _timed("vlad_aggregate_fwd", (B, T, D, K)):
-            lib.check(lib._lpm_vlad_aggregate_tiles3_fwd_bf16(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
-                                                              ptr(part), st), "lpm_vlad_aggregate_tiles3_fwd_bf16")
+            if clip16:
+                lib.check(lib._lpm_vlad_aggregate_clip_fwd_bf16(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
+                                                                ptr(part), st), "lpm_vlad_aggregate_clip_fwd_bf16")
+            else:
+                lib.check(lib._lpm_vlad_aggregate_tiles3_fwd_bf16(ptr(at), ptr(xt), ptr(centres), B, T, D, K, flags, ptr(nrm), ptr(asum),
+                                                                  ptr(part), st), "lpm_vlad_aggregate_tiles3_fwd_bf16")
         gsq = _empty((B,), W)
         if lazy:
             # LAZILY NORMALISED (d-major, bf16 sums): no finalize pass -- lpm_vlad_row_scales turns the partial norms into one factor per

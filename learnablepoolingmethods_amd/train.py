@@ -183,37 +183,50 @@ class CollectiveTrace:
 
     def __init__(self):
         self.on = False
-        self.open = {}           # tag -> (MiB, launch event)
+        self.open = {}           # tag -> (MiB, launch mark)
         self.rows = []           # (tag, MiB, launch, before, after) of finished waits
 
-    def launched(self, tag, nbytes):
-        if self.on and torch.cuda.is_available():
+    @staticmethod
+    def _mark():
+        """A time stamp on the compute stream: a HIP event on a GPU; the host clock on the CPU (the gloo tests run the same code path --
+        there the 'compute stream' is the calling thread)."""
+        if torch.cuda.is_available():
             e = torch.cuda.Event(enable_timing=True)
             e.record()
-            self.open[tag] = (nbytes / 2.0 ** 20, e)
+            return e
+        import time
+        return time.perf_counter()
+
+    @staticmethod
+    def _ms(a, b):
+        return a.elapsed_time(b) if not isinstance(a, float) else (b - a) * 1e3
+
+    def launched(self, tag, nbytes):
+        if self.on:
+            self.open[tag] = (nbytes / 2.0 ** 20, self._mark())
 
     def wait(self, tag, work):
         if not self.on or tag not in self.open:
             work.wait()
             return
         mib, e0 = self.open.pop(tag)
-        e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e1.record()
+        e1 = self._mark()
         work.wait()
-        e2.record()
+        e2 = self._mark()
         self.rows.append((tag, mib, e0, e1, e2))
 
     def summary(self):
         """[{collective, MiB, calls, window_ms, exposed_ms}] averaged over the recorded steps (synchronises)."""
         if not self.rows:
             return []
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         acc = {}
         for tag, mib, e0, e1, e2 in self.rows:
             a = acc.setdefault(tag, [mib, 0, 0.0, 0.0])
             a[1] += 1
-            a[2] += e0.elapsed_time(e1)
-            a[3] += e1.elapsed_time(e2)
+            a[2] += self._ms(e0, e1)
+            a[3] += self._ms(e1, e2)
         self.rows = []
         return [{"collective": t, "MiB": round(a[0], 1), "calls": a[1], "window_ms": round(a[2] / a[1], 3), "exposed_ms": round(a[3] / a[1], 3)}
                 for t, a in acc.items()]

@@ -289,6 +289,7 @@ def _sharded_worker(rank, world, port, q):
         sync.done.add(0)
     arena.views[h1].register_post_accumulate_grad_hook(ready)
     dist.broadcast(arena.param, src=0)
+    train.TRACE.on = True                              # bench.py --gpus N switches it on for the timed steps
     g = torch.Generator().manual_seed(7)
     X, Y = torch.randn(2 * world, F, generator=g), torch.rand(2 * world, 4, generator=g)
     sl = slice(2 * rank, 2 * rank + 2)
@@ -313,6 +314,13 @@ def _sharded_worker(rank, world, port, q):
         sh.step(_SHARD_CLIP, 1e-2, step)
         assert sh._ag is not None, "the parameter all-gather stays in flight behind step()"
         store.pending[h1] = sh.wait_parameters
+    # bench.py's own post-timed-region code, end to end over gloo: the per-collective overlap report and the replica
+    # consistency check -- a collective, every rank enters it (it also waits for the parked parameter all-gather)
+    import types
+    import bench
+    train.TRACE.on = False
+    trace = train.TRACE.summary()
+    replicas = bench.replica_check(types.SimpleNamespace(sharded=sh, factored=None, arena=arena), world)
     sh.wait_parameters()
     own = (sh.lo - a0, sh.hi - a0)
     m_own = arena.m[sh.lo:sh.hi].clone()
@@ -320,7 +328,7 @@ def _sharded_worker(rank, world, port, q):
     sh.gather_moments()                                                                         # ... until they are gathered
     out = {n: (arena.views[n].detach().numpy().copy(), arena.m[arena.segment(n)[0]:arena.segment(n)[0] + arena.views[n].numel()].numpy().copy(),
                arena.v[arena.segment(n)[0]:arena.segment(n)[0] + arena.views[n].numel()].numpy().copy()) for n in arena.names}
-    q.put((rank, out, len(fired), waited, others_zero, own, float(sh.last_norm), bool(torch.equal(arena.m[sh.lo:sh.hi], m_own))))
+    q.put((rank, out, len(fired), waited, others_zero, own, float(sh.last_norm), bool(torch.equal(arena.m[sh.lo:sh.hi], m_own)), trace, replicas))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -347,8 +355,17 @@ def test_sharded_update_of_hidden1_matches_the_tower_combine(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in range(world):
-        out, fired, waited, others_zero, own, norm, own_kept = res[r]
+        out, fired, waited, others_zero, own, norm, own_kept, trace, replicas = res[r]
         assert fired == 2, "the gradient's hook starts the reduce-scatter once per step"
+        # bench.py --gpus N's report for the first real run: every collective of the two steps with its window and exposed time ...
+        rows = {t["collective"]: t for t in trace}
+        assert set(rows) == {"reduce_scatter hidden1_weights", "all_gather hidden1_weights parameters", "all_reduce bucket 1"}, rows
+        assert rows["reduce_scatter hidden1_weights"]["calls"] == 2 and rows["all_reduce bucket 1"]["calls"] == 2
+        assert rows["all_gather hidden1_weights parameters"]["calls"] == 1, "step 2's gather is still parked when the report is taken"
+        assert all(t["window_ms"] >= 0 and t["exposed_ms"] >= 0 and t["MiB"] >= 0 for t in trace)
+        # ... and the replicas' parameter checksums agree bit for bit on the sharded route
+        assert replicas == {"consistent": True, "max_checksum_difference": 0.0, "hidden1_weights_route": "sharded (C)",
+                            "checked": replicas["checked"]}, replicas
         assert waited == [(False, False, True), (True, False, True)], waited    # step 2's fetch ran the parked wait; nothing left in flight
         assert others_zero and own_kept, "Adam moments live on the shard's owner until gather_moments()"
         assert own == (4096 * r, 4096 * (r + 1))

@@ -21,16 +21,16 @@ def vlad_precision(request):
     ops.VLAD_PRECISION, ops.ASSIGN_PRECISION = old
 
 
-@pytest.fixture(params=["bf16x3", "bf16x3/3", "f32"])
+@pytest.fixture(params=["bf16x3", "bf16x3/2", "f32"])
 def mha_precision(request):
-    """The matrix-core arithmetics of the attention core K4: split-bf16 with the backward's products on two fp16 terms (round 6, the
-    default) or on three bf16 terms ("bf16x3/3": lpm_mha_bwd_set_terms), and exact fp32."""
+    """The matrix-core arithmetics of the attention core K4: split-bf16 (three-term products throughout, the default), split-bf16 with
+    the backward's products behind dS on two fp16 terms ("bf16x3/2": lpm_mha_bwd_set_terms(2), round 6), and exact fp32."""
     from learnablepoolingmethods_amd import _capi, ops
     lib = _capi.load()
     old = ops.MHA_PRECISION, ops.MHA_BN_PRECISION
     prec, _, terms = request.param.partition("/")
     ops.MHA_PRECISION = ops.MHA_BN_PRECISION = prec
-    prev = lib._lpm_mha_bwd_set_terms(int(terms or 2))
+    prev = lib._lpm_mha_bwd_set_terms(int(terms or 3))
     yield request.param
     lib._lpm_mha_bwd_set_terms(prev)
     ops.MHA_PRECISION, ops.MHA_BN_PRECISION = old
@@ -347,7 +347,7 @@ def test_mha_core(B, L, h, d, mha_precision):
 @pytest.mark.parametrize("L,h,d,bn", [(256, 4, 16, False), (64, 4, 8, False), (300, 4, 16, True), (500, 2, 16, False)])
 @pytest.mark.parametrize("gscale", [1e-9, 1.0, 3e4])
 def test_mha_backward_two_terms_over_the_gradient_range(L, h, d, bn, gscale):
-    """Round 6: the backward's products on two fp16 terms (lpm_mha_bwd_set_terms(2), the default).  fp16 has five exponent bits and the
+    """Round 6: the backward's products behind dS on two fp16 terms (lpm_mha_bwd_set_terms(2); opt-in).  fp16 has five exponent bits and the
     gradient reaching the attention core spans 1e-9 ... 20 over a run: the kernels scale dO by a power of two taken from max |dO| -- per
     query in the dq kernel, per (batch, head) in the dkv kernel -- so the result must be as good at 1e-9 and at 3e4 as at 1, with one
     query row 1e6 x smaller than the rest (its dq still to 1e-3 of ITS scale: the per-query scale).  Also prints the two-term
@@ -1671,6 +1671,90 @@ def test_netvlad_bf16_storage():
     # the fp32 frames were not materialised: an op that would read them says so instead of computing on garbage
     with pytest.raises(Exception, match="bf16 operand tiles only"):
         ops.netvlad(y[:, :1024].detach(), torch.zeros(1024, 128, device=dev), None, T, bias=torch.zeros(128, device=dev))
+
+
+@pytest.mark.parametrize("B,T,D,K", [(5, 33, 384, 256), (2, 130, 416, 512), (3, 64, 800, 256), (1, 300, 1024, 512)])
+def test_k2_bf16_clip_wide_items_on_other_slab_shapes(B, T, D, K):
+    """lpm_vlad_aggregate_clip_fwd_bf16 through the C ABI on operand tiles made here (lpm_split_frames_bf16, lpm_assign_tiles_bf16 without
+    the softmax: the tiles hold the given bf16 values) against the fp64 sums of the SAME rounded operands: one slab of 12 column tiles
+    (D = 384), 13 = 7 + 6 (D = 416), 25 = 9 + 8 + 8 in groups of 5 + 4 / 4 + 4 (D = 800), the benched 11 / 11 / 10.  The un-normalised
+    sums to one bf16 rounding, assignment sums and square norms (over the P slabs) to 1e-5."""
+    from learnablepoolingmethods_amd import _capi, ops
+    lib = _capi.load()
+    dev = cuda()
+    P = lib._lpm_vlad_clip16_slabs(D, K)
+    assert P > 0
+    g = torch.Generator().manual_seed(D + T)
+    x = torch.randn(B * T, D, generator=g).to(torch.bfloat16).float()
+    a = torch.rand(B * T, K, generator=g).to(torch.bfloat16)
+    cen = torch.randn(D, K, generator=g) / D ** 0.5
+    st = ops.stream_ptr()
+    xg, ag, cg_ = x.to(dev), a.to(dev), cen.to(dev)
+    steps = lib._lpm_frame_steps_bf16(T)
+    xt = torch.empty(lib._lpm_frame_tiles_bf16_bytes(B, T, D) // 4, dtype=torch.int32, device=dev)
+    lib.check(lib._lpm_split_frames_bf16(ops.ptr(xg), D, B, T, D, ops.ptr(xt), st), "lpm_split_frames_bf16")
+    at = torch.empty(B * (K // 32) * steps * 256, dtype=torch.int32, device=dev)
+    lib.check(lib._lpm_assign_tiles_bf16(ops.ptr(ag), None, None, B, T, K, 0, ops.ptr(at), st), "lpm_assign_tiles_bf16")
+    nrm = torch.empty((B, D, K), dtype=torch.bfloat16, device=dev)
+    asum, part = torch.empty((B, K), device=dev), torch.empty((B, P, K), device=dev)
+    lib.check(lib._lpm_vlad_aggregate_clip_fwd_bf16(ops.ptr(at), ops.ptr(xt), ops.ptr(cg_), B, T, D, K, _capi.LPM_VLAD_RESIDUAL, ops.ptr(nrm),
+                                                    ops.ptr(asum), ops.ptr(part), st), "lpm_vlad_aggregate_clip_fwd_bf16")
+    a64, x64 = a.double().reshape(B, T, K), x.double().reshape(B, T, D)
+    s_ref = a64.sum(1)                                                    # [B, K]
+    u_ref = torch.einsum("btk,btd->bdk", a64, x64) - s_ref[:, None, :] * cen.double()[None]
+    got = nrm.float().cpu().double()
+    scale = float(u_ref.abs().max())
+    assert (got - u_ref).abs().le(2.0 ** -8 * u_ref.abs() + 2e-6 * scale).all(), f"sums: {float((got - u_ref).abs().max() / scale):.2e} of the largest"
+    assert rel_err(asum, s_ref) <= 1e-5
+    assert rel_err(part.sum(1), (u_ref ** 2).sum(1)) <= 1e-5
+
+
+@pytest.mark.parametrize("B,T,D,K", [(128, 300, 1024, 512), (3, 77, 1024, 512), (2, 300, 1024, 256), (1, 1, 1024, 512)])
+def test_k2_bf16_clip_wide_items_against_the_128_x_128_form(B, T, D, K):
+    """Round 6: K2 for bf16 storage on clip-wide items (csrc/vlad_clip16.hip: 256 clusters x a third of a clip's
+    columns per workgroup, 2 x 6 register tiles, d-major bf16 stores through a wave-private LDS tile; frame_level_models.py:2803-2822)
+    against the 128 x 128 form it replaces on the same operand tiles, through the C ABI: the un-normalised bf16 sums within ONE bf16
+    rounding of each other (the fp32 accumulation orders differ), assignment sums and the clusters' square norms to 1e-5, and the
+    normalised descriptor of ops.netvlad(storage='bf16') against the fp64 oracle at the bf16 tolerance.  Shapes: the benched one (128 x
+    300, K = 512: 768 workgroups), ragged clips, one cluster half (K = 256), a single frame."""
+    from learnablepoolingmethods_amd import _capi, ops
+    lib = _capi.load()
+    dev = cuda()
+    assert lib._lpm_vlad_clip16_slabs(D, K) > 0
+    g = torch.Generator().manual_seed(B * 7 + T)
+    ld = 1152
+    raw = torch.randn(B, T, ld, generator=g)
+    nf = torch.full((B,), T, dtype=torch.int32)
+    y = ops.frame_sample_bn(raw.to(dev), nf.to(dev), T, storage="bf16", materialize=False)
+    W = torch.randn(D, K, generator=g) / D ** 0.5
+    gamma, beta = 1 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    W2 = torch.randn(1, D, K, generator=g) / D ** 0.5
+    outs = {}
+    old = ops.VLAD_CLIP16
+    try:
+        for form in (True, False):
+            ops.VLAD_CLIP16 = form
+            with torch.no_grad():
+                xs = y[:, :D]
+            Wg, gmg, btg, W2g = (t.to(dev).requires_grad_(True) for t in (W, gamma, beta, W2))
+            out = ops.netvlad(xs, Wg, W2g, T, bn=(gmg, btg, torch.zeros(K, device=dev), torch.ones(K, device=dev)), is_training=True, storage="bf16")
+            ctx = out.grad_fn
+            saved = {n: t for n, t in zip(("nrm", "asum", "colsq", "csq", "gsq"), ctx.saved_tensors[9:14])}
+            outs[form] = (out.float().cpu(), {k: v.float().cpu() for k, v in saved.items()})
+    finally:
+        ops.VLAD_CLIP16 = old
+    (o1, s1), (o0, s0) = outs[True], outs[False]
+    scale = float(s0["nrm"].abs().max())
+    d = float((s1["nrm"] - s0["nrm"]).abs().max())
+    print(f"[K2 bf16 clip-wide B={B} T={T} D={D} K={K}] raw sums: max |clip-wide - 128x128| = {d / scale:.1e} of the largest; asum "
+          f"{rel_err(s1['asum'], s0['asum']):.1e}, colsq {rel_err(s1['colsq'], s0['colsq']):.1e}, descriptor {rel_err(o1, o0):.1e}")
+    # one bf16 rounding apart: 2^-8 of the element, and elements are at most `scale`
+    assert (s1["nrm"] - s0["nrm"]).abs().le(2.0 ** -7 * s0["nrm"].abs() + 1e-6 * scale).all(), "un-normalised sums differ by more than a bf16 rounding"
+    assert rel_err(s1["asum"], s0["asum"]) <= 1e-5 and rel_err(s1["colsq"], s0["colsq"]) <= 1e-5 and rel_err(s1["gsq"], s0["gsq"]) <= 1e-5
+    assert rel_err(o1, o0) <= 2.0 ** -7
+    x = raw.reshape(B * T, ld)[:, :D]
+    ref, _, _, _ = _oracle_netvlad(x, W, gamma, beta, W2, T, torch.zeros(B, D * K))
+    assert rel_err(o1, ref) <= BF16_FWD_TOL, f"descriptor against the fp64 oracle: {rel_err(o1, ref):.2e}"
 
 
 @pytest.mark.parametrize("B,T", [(128, 300), (3, 77), (1, 300), (7, 129), (2, 33), (1, 1)])

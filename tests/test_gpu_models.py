@@ -198,14 +198,32 @@ def _full_size_compare(name, cfg, B, seed, dev, scale_hidden1=True, dropout_mask
         assert raw_worst[0] <= 1e-2, f"gradient {raw_worst[1]}: {raw_worst[0]:.3e} > 1e-2 with the at-risk units' own columns included"
         # (per model, not per variable: an error made in one stream's ill-conditioned batch norms reaches the other stream's gradients
         # through hidden1_bn's batch statistics)
+        # NetVladV1 (round 6): the 3 x allowance is for the variables DIRECTLY BEHIND an at-risk ReLU only -- a unit within
+        # rounding of zero takes its mask from the last bit of whichever arithmetic computed it, its own columns are left out above, and
+        # the layer that feeds it receives the flipped tokens' gradient through one GEMM: FeedForwardNetwork's first layer behind the
+        # second one's ReLU (transformer_utils.py:701-711), the attention block's LayerNorm behind the first one's.  Every other variable is
+        # held to max(1e-3, 1.5 x the fp32 oracle's worst) -- the allowance cannot absorb an arithmetic choice elsewhere.  Measured: the two
+        # variables above 1e-3 are video_attention/filter_outputencode1/{kernel, bias} = 1.15e-3 / 1.12e-3, behind ff_outputencode1's 21 at-risk
+        # units; with that kernel's weight gradient on two terms (LPM_DW_TERMS_FFN1=2) 1.14e-3 -- it is not the one-term product --, with
+        # the dense GEMMs on split-bf16 (LPM_DENSE_ARITHMETIC=bf16x3) every gradient of the model within 1e-3 (worst 5.7e-4).
+        behind = set()
+        for site, (units, _) in at_risk.items():
+            if not len(units):
+                continue
+            scope, layer = site.rsplit("/", 2)[0], site.rsplit("/", 2)[1]
+            if layer.startswith("ff_output"):
+                behind |= {f"{scope}/{layer.replace('ff_output', 'filter_output')}/kernel", f"{scope}/{layer.replace('ff_output', 'filter_output')}/bias"}
+            elif layer.startswith("filter_output"):
+                behind |= {f"{scope}/LayerNorm/gamma", f"{scope}/LayerNorm/beta"}
         for e, n in over:
             # (NetVladV2: 2 x since round 5 -- 3 x before: test_cfg3_untouched_initialisation_family_by_family shows it at 1.28 x with its
             # dense GEMMs on fp16 planes and at 1.00 x with the logits_bn attention in exact fp32)
-            # NetVladV1 (fp32 oracle's worst ~4e-4): the allowance is what it was, 3 x = 1.25e-3 -- it is used by ONE variable, the first
-            # FFN kernel behind a ReLU with 70 at-risk units (1.0e-3 in round 4, 1.15e-3 with the one-term fp16 weight gradient).
-            k = 2.0 if name == "NetVladV2" else 3.0
-            assert e <= max(grad_tol, k * yworst[0]), (f"gradient {n}: {e:.3e} > 1e-3 and > {k:.0f} x the fp32 oracle's own worst distance from "
-                                                        f"fp64 on this model ({yworst[0]:.3e}, {yworst[1]})")
+            k = 2.0 if name == "NetVladV2" else (3.0 if n in behind else 1.5)
+            assert e <= max(grad_tol, k * yworst[0]), (f"gradient {n}: {e:.3e} > 1e-3 and > {k:.1f} x the fp32 oracle's own worst distance from "
+                                                        f"fp64 on this model ({yworst[0]:.3e}, {yworst[1]})"
+                                                        + ("" if name == "NetVladV2" or n in behind else "; not directly behind an at-risk ReLU"))
+        if behind:
+            print(f"[{name} B={B}] directly behind an at-risk ReLU (3 x allowance): {sorted(behind)}")
     print(f"[{name} B={B}] intermediates {({k: f'{v:.1e}' for k, v in errs.items()})}; worst gradient {worst[0]:.2e} ({worst[1]}); "
           f"ReLU units moved {({k.split('/')[-2]: v[0] for k, v in report.items()})}")
     return errs, worst
