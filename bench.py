@@ -262,7 +262,8 @@ def other_configs(args):
             out[cfg] = {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
                         "steps": line["steps"], "warmup": line["warmup"], "dtype": line["dtype"], "final_loss": line.get("final_loss"),
                         "workload": line["config"]["workload"],
-                        "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_kernel_ms")},
+                        "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_kernel_ms", "algorithmic_bytes",
+                                                              "traffic", "traffic_measured_by_this_run", "traffic_source", "a5_chain_traffic")},
                         "a5_function_frac": (roof.get("a5_function") or {}).get("frac"),
                         "assign_gemm": line.get("assign_gemm"), "dispatches_per_step": (line.get("dispatches_per_step") or {}).get("value"),
                         "wall_seconds": round(time.perf_counter() - t0, 1)}

@@ -15,8 +15,8 @@
 // clusters in consecutive registers, so the d-major result [B, D, K] (the reference's own layout, frame_level_models.py:2817-2821) goes
 // through a wave-private fp32 LDS tile [32 d][64 clusters] written with ds_write_b128 and leaves as 16-byte bf16 stores -- 8 lanes =
 // one 128-byte piece of a row; residual (asum x centres, fp32) and the slab's square norms are formed on the way, in fp32.
-// 24 KB per 16-frame step (8 assignment + up to 12 frame pieces + 4 idle slots so that every wave issues three pieces and the in-order
-// vmcnt is one constant), 5-stage ring = 120 KB of LDS, LDS-DMA through buffer loads (resource + step offset in SGPRs).
+// 18-20 KB per 16-frame step (8 assignment + 10-12 frame pieces: two or three per wave), 5-stage ring of 24 KB slots = 120 KB of LDS, LDS-DMA
+// through buffer loads (resource + step offset in SGPRs).
 #include "lpm_common.h"
 
 namespace lpm {
@@ -36,8 +36,8 @@ __device__ __forceinline__ unsigned vb_pack2(float a, float b) {          // rou
 
 constexpr int VB_NCT = 12;                         // column tiles per workgroup at most (two groups of six)
 constexpr int VB_NJ = 6;                           // column tiles per wave
-constexpr int VB_SLOTS = 24;                       // 1 KB slots per stage: 8 assignment pieces, VB_NCT frame pieces, 4 idle
-constexpr int VB_PW = VB_SLOTS / 8;                // pieces per wave and step
+constexpr int VB_SLOTS = 20;                       // 1 KB slots per stage: 8 assignment pieces, VB_NCT frame pieces
+constexpr int VB_PW = 3;                            // pieces per wave and step at most (slot = wave + 8 j)
 constexpr int VB_STAGE = VB_SLOTS * 1024;
 constexpr int VB_WS = 68;                          // epilogue tile row stride in floats (272 B: 16-byte aligned rows, odd multiple of 16 B)
 constexpr int VB_EPI = 8 * 32 * VB_WS * 4;         // 8 wave-private tiles [32 d][64 clusters] fp32: overlays the ring
@@ -48,20 +48,29 @@ struct VBArgs {
     const uint4* xt;            // frame tiles      [b][S][D/32][lane]   (lpm_frame_apply_tiles_bf16 / lpm_split_frames_bf16)
     const float* centres;       // [D, K] (cluster_weights2) or null
     int D, K, S, P, KH, residual;
+    int dbg;                    // measurement only (LPM_VB_DBG): see the kernel
     unsigned short* out;        // [B, D, K] bf16 un-normalised residual sums, d-major
     float* asum;                // [B, K]
     float* colsq_part;          // [B, P, K]
 };
 
-template <int NS>
+// DBG (measurement builds of the SAME kernel, LPM_VB_DBG=n, results are garbage): 1 no main loop, 2 no result stores, 4 no DMA, 8 no MFMAs,
+// 16 no centre loads, 32 no epilogue at all.  The production instantiation (DBG = 0) carries none of these branches.
+template <int NS, int DBG, int AUX>
 __global__ __launch_bounds__(512) void vlad_clip16_kernel(const VBArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // the ONLY LDS object (guide 5, trap (a))
+    const int dbg = DBG ? g.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int D = g.D, K = g.K, S = g.S, P = g.P, KH = g.KH;
     const int DT = D >> 5, KT = K >> 5;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);        // the KH * P workgroups of a clip: consecutive ids, one XCD, the same moment
+    // An ITEM = (clip b, cluster half kh, column slab p); the KH * P items of a clip have consecutive ids (one XCD, the same moment).  One item
+    // per workgroup.  (Measured and not kept, round 6: a PERSISTENT form -- one workgroup per CU walking items lid, lid + 256, ..., requesting
+    // the next item's first stages before it runs the current epilogue, the epilogue's tiles in an LDS region of their own -- 112 us against
+    // 85: the item loop around the 192 accumulators cost the epilogue 75 spilled registers, and with one item per workgroup of the same code
+    // (LPM_VB_GRID = 768) it was 116 us: what the prefetch hides is worth ~4 us, what the spills cost ~30.)
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = lid / (KH * P), rem_ = lid % (KH * P);
     const int kh = rem_ / P, p = rem_ % P;
     const int base = DT / P, rem = DT % P;
@@ -72,17 +81,19 @@ __global__ __launch_bounds__(512) void vlad_clip16_kernel(const VBArgs g) {
     const int cnt = cg == 0 ? n0 : ncol - n0;                 // this wave's column tiles (<= VB_NJ)
     const int jt0 = cg * n0;
 
-    // this wave's three pieces of a stage: slot = wave + 8 j.  slots 0..7: assignment tile kh * 8 + slot; slots 8..19: frame tile
-    // ct0 + min(slot - 8, ncol - 1); slots 20..23: idle (they re-read assignment piece 0: every wave has the same number in flight)
+    // this wave's pieces of a stage: slot = wave + 8 j.  slots 0..7: assignment tile kh * 8 + slot; slots 8..8 + ncol - 1: frame tile
+    // ct0 + slot - 8.  Every wave has pieces j = 0, 1; the third exists for wave + 16 < 8 + ncol only (wave-uniform `has3`): no dummy pieces
+    // (a first version padded every wave to three so that one vmcnt constant served all -- a fifth of the DMA traffic -- and ran no slower
+    // or faster: the DMA volume is not what bounds this kernel).  The waits come in two flavours, selected by a scalar branch.
     __amdgpu_buffer_rsrc_t rsrc[VB_PW];
     unsigned sstep[VB_PW];                         // bytes per step
+    const bool has3 = wave + 16 < 8 + ncol;
 #pragma unroll
     for (int j = 0; j < VB_PW; ++j) {
         const int sl = wave + 8 * j;
         const uint4* src;
-        if (sl < 8 || sl >= 8 + VB_NCT) {
-            const int q = sl < 8 ? sl : 0;
-            src = g.at + (((int64_t)b * KT + kh * 8 + q) * S) * 64;
+        if (sl < 8) {
+            src = g.at + (((int64_t)b * KT + kh * 8 + sl) * S) * 64;
             sstep[j] = 1024u;
         } else {
             src = g.xt + (((int64_t)b * S) * DT + ct0 + min(sl - 8, ncol - 1)) * 64;
@@ -91,13 +102,22 @@ __global__ __launch_bounds__(512) void vlad_clip16_kernel(const VBArgs g) {
         rsrc[j] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(src), 0, 0xffffffff, 0x00020000);
     }
     const unsigned lane_off = (unsigned)lane * 16u;
+    const bool no_dma = (dbg & 4) != 0;
     auto issue = [&](int s) {
+        if (DBG && no_dma) return;
         unsigned char* st = smem + (s % NS) * VB_STAGE;
 #pragma unroll
         for (int j = 0; j < VB_PW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc[j], (__attribute__((address_space(3))) void*)(st + (wave + 8 * j) * 1024), 16, lane_off,
-                                                     (unsigned)s * sstep[j], 0, 2);      // (non-temporal: streamed once per workgroup)
+            if (j < 2 || has3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc[j], (__attribute__((address_space(3))) void*)(st + (wave + 8 * j) * 1024), 16, lane_off,
+                                                         (unsigned)s * sstep[j], 0, AUX);    // (AUX = 2: the non-temporal policy, LPM_VB_NT)
     };
+    // this wave's pieces of a step have landed when at most `steps` younger steps' pieces are outstanding (two or three pieces per step)
+#define VB_VMWAIT(steps)                                                                         \
+    do {                                                                                         \
+        if (has3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (steps)) : "memory");             \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (steps)) : "memory");                  \
+    } while (0)
 
     f32x16 acc[2][VB_NJ];
 #pragma unroll
@@ -108,42 +128,120 @@ __global__ __launch_bounds__(512) void vlad_clip16_kernel(const VBArgs g) {
             for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
     float asum_l[2] = {0.f, 0.f};      // assignment sums of clusters 32 (2 cp + m) + l31 over this lane's 8 frames of every step (group-0 waves)
 
-    // byte offsets of this wave's fragments inside a stage (wave-uniform)
-    const int aoff = (2 * cp) * 1024;
-    int boff[VB_NJ];
-#pragma unroll
-    for (int j = 0; j < VB_NJ; ++j) boff[j] = (8 + jt0 + min(j, cnt - 1)) * 1024;
-
+    // ---- main loop.  The ring: step s lives in stage s % NS, NS - 1 steps are requested ahead.  ONE raw s_barrier per step, placed
+    // BEHIND the step's second MFMA group (vlad_clip.hip's arrangement): barrier B(s + 1) says "step s + 1 has landed for everyone (every
+    // wave waited for its own pieces first) and everyone is past the fragment reads of step s - 1", so stage (s - 1) % NS takes step
+    // s + NS - 1 right behind it and the first fragments of step s + 1 are requested while the last MFMA group of step s is still being
+    // issued: the matrix pipe does not drain at a step boundary.
+    // Fragment reads are inline assembly off two base addresses per stage (A tiles, this wave's B tiles) with immediate offsets and
+    // HAND-COUNTED lgkmcnt (LDS returns in order).  A step is three MFMA groups of four -- (a0, a1) x (b0, b1), x (b2, b3), x (b4, b5) --
+    // over TWO B-pair register sets P, Q that swap roles every step and TWO A sets that alternate (the loop is unrolled by two):
+    //   top of a step, in flight, oldest first:  a (2), first pair (2), second pair (2)
+    //   WAIT(2)  group 0 on the first pair;   first pair  <- (b4, b5)
+    //   WAIT(2)  group 1 on the second pair;  [vmcnt, barrier, DMA issue]  a' <- next A,  second pair <- next (b0, b1)
+    //   WAIT(4)  group 2 on the first pair;   first pair  <- next (b2, b3)          -> the next step's (a, second, first)
+    // A wave with fewer than six column tiles reads the slot behind its own -- the other group's first tile, or a slot no DMA writes
+    // (whatever bits the LDS holds) -- into accumulators it never stores.
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;      // LDS byte address
+    const unsigned rd_a = smem_lds + lane_off + (unsigned)(2 * cp) * 1024u;
+    const unsigned rd_b = smem_lds + lane_off + (unsigned)(8 + jt0) * 1024u;
+    struct Pair { vb_u32x4 x, y; };
+// ("+v": the new fragment is tied to the register quad of the one it replaces -- vlad_clip.hip: with plain outputs hipcc gives every read a
+// fresh quad, fragments the register file and spills accumulator tiles)
+#define VB_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(base), "n"(off))
+#define VB_RD_PAIR(f, base, j0)                  \
+    do {                                         \
+        VB_RD(f.x, base, (j0) * 1024);           \
+        VB_RD(f.y, base, (j0) * 1024 + 1024);    \
+    } while (0)
+#define VB_WAIT(n)                                                  \
+    do {                                                            \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory");  \
+        __builtin_amdgcn_sched_barrier(0);                          \
+    } while (0)
+    const bool no_mfma = (dbg & 8) != 0;
+    auto group = [&](int j0, const Pair& f, const Pair& a) {
+        if (DBG && no_mfma) {
+            asm volatile("" ::"v"(f.x), "v"(f.y), "v"(a.x), "v"(a.y));
+            return;
+        }
+        acc[0][j0] = vb_mfma(a.x, f.x, acc[0][j0]);
+        acc[1][j0] = vb_mfma(a.y, f.x, acc[1][j0]);
+        acc[0][j0 + 1] = vb_mfma(a.x, f.y, acc[0][j0 + 1]);
+        acc[1][j0 + 1] = vb_mfma(a.y, f.y, acc[1][j0 + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const vb_u32x4 zero4 = {0u, 0u, 0u, 0u};
+    Pair pa = {zero4, zero4}, pb = pa, a0 = pa, a1 = pa;
+    const int nloop = (DBG && (dbg & 1)) ? 0 : S;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < S) issue(s);
-    for (int s = 0; s < S; ++s) {
-        // this wave's pieces of step s have landed when at most VB_PW * (younger steps in flight) remain
-        const int behind = min(NS - 2, S - 1 - s);
-        if (behind >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * VB_PW) : "memory");
-        else if (behind == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * VB_PW) : "memory");
-        else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VB_PW) : "memory");
+        if (s < nloop) issue(s);
+    if (nloop > 0) {
+        // step 0 has landed (this wave's pieces; min(NS - 2, S - 1) younger steps stay in flight), then for everyone
+        const int behind = min(NS - 2, S - 1);
+        if (behind >= 3) VB_VMWAIT(3);
+        else if (behind == 2) VB_VMWAIT(2);
+        else if (behind == 1) VB_VMWAIT(1);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();              // everyone's pieces of step s are in LDS; stage (s - 1) % NS is free
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + NS - 1 < S) issue(s + NS - 1);
-        const vb_u32x4* f = reinterpret_cast<const vb_u32x4*>(smem + (s % NS) * VB_STAGE) + lane;
-        const vb_u32x4 a0 = f[aoff / 16], a1 = f[aoff / 16 + 64];
-#pragma unroll
-        for (int j = 0; j < VB_NJ; ++j) {
-            const vb_u32x4 bj = f[boff[j] / 16];
-            acc[0][j] = vb_mfma(a0, bj, acc[0][j]);
-            acc[1][j] = vb_mfma(a1, bj, acc[1][j]);
-        }
+        VB_RD_PAIR(a0, rd_a, 0);
+        VB_RD_PAIR(pa, rd_b, 0);
+        VB_RD_PAIR(pb, rd_b, 2);
+    }
+    // one step: a = this step's A fragments, an = the next step's; first / second = the B-pair sets in this step's roles
+    auto body = [&](int s, Pair& a, Pair& an, Pair& first, Pair& second) {
+        const unsigned so = (unsigned)((s % NS) * VB_STAGE), son = (unsigned)(((s + 1) % NS) * VB_STAGE);
+        const bool more = s + 1 < S;               // workgroup-uniform
+        VB_WAIT(2);
+        group(0, first, a);
+        VB_RD_PAIR(first, rd_b + so, 4);
         if (cg == 0) {                             // wave-uniform: the cluster pair's first column group keeps the assignment sums
 #pragma unroll
             for (int w2 = 0; w2 < 4; ++w2) {
-                asum_l[0] += vb_bf(a0[w2] & 0xffffu) + vb_bf(a0[w2] >> 16);
-                asum_l[1] += vb_bf(a1[w2] & 0xffffu) + vb_bf(a1[w2] >> 16);
+                asum_l[0] += vb_bf(a.x[w2] & 0xffffu) + vb_bf(a.x[w2] >> 16);
+                asum_l[1] += vb_bf(a.y[w2] & 0xffffu) + vb_bf(a.y[w2] >> 16);
             }
+            // pinned here (vlad_clip.hip: left free, hipcc sinks these additions behind the request for the NEXT step's A fragments, keeps
+            // both generations alive and copies a register whose ds_read has just been issued)
+            asm volatile("" : "+v"(asum_l[0]), "+v"(asum_l[1]));
         }
+        __builtin_amdgcn_sched_barrier(0);
+        VB_WAIT(2);
+        group(2, second, a);
+        if (more) {
+            // B(s + 1): this wave's pieces of step s + 1 have landed (min(NS - 3, S - 2 - s) younger steps stay in flight) ...
+            const int behind = min(NS - 3, S - 2 - s);
+            if (behind >= 2) VB_VMWAIT(2);
+            else if (behind == 1) VB_VMWAIT(1);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // ... everyone's have, and everyone is past the reads of step s - 1
+            asm volatile("" ::: "memory");
+            if (s + NS - 1 < S) issue(s + NS - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            VB_RD_PAIR(an, rd_a + son, 0);
+            VB_RD_PAIR(second, rd_b + son, 0);
+            VB_WAIT(4);                            // oldest first: first = (b4, b5) (2), an (2), second (2)
+        } else {
+            VB_WAIT(0);
+        }
+        group(4, first, a);
+        if (more) {
+            VB_RD_PAIR(first, rd_b + son, 2);      // the state the next step expects: an (2), second = its first pair (2), first = its second (2)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int s = 0; s < nloop; s += 2) {
+        body(s, a0, a1, pa, pb);
+        if (s + 1 < S) body(s + 1, a1, a0, pb, pa);
     }
+#undef VB_RD
+#undef VB_RD_PAIR
+#undef VB_WAIT
+#undef VB_VMWAIT
     __syncthreads();         // no DMA in flight (the last step waited for vmcnt(0)), all fragment reads done: the ring is scratch now
+    if (DBG && (dbg & 32)) return;
 
     // ---- epilogue
     float* sas = reinterpret_cast<float*>(smem + VB_EPI);     // [256] assignment sums of this cluster half
@@ -160,7 +258,8 @@ __global__ __launch_bounds__(512) void vlad_clip16_kernel(const VBArgs g) {
     if (p == 0 && tid < 256) g.asum[(int64_t)b * K + kbase + tid] = sas[tid];
     float* wl = reinterpret_cast<float*>(smem) + wave * (32 * VB_WS);
     const int srow = lane >> 3, k8 = (lane & 7) * 8;          // store pass: d row it * 8 + srow, clusters k8 .. k8 + 7 of the wave's 64
-    const bool residual = g.residual != 0;
+    const bool residual = g.residual != 0 && !(DBG && (dbg & 16));
+    const bool do_store = !(DBG && (dbg & 2));
     float s8[8], nsq[8];
     {
         const float4 sa = *reinterpret_cast<const float4*>(sas + cp * 64 + k8), sb = *reinterpret_cast<const float4*>(sas + cp * 64 + k8 + 4);
@@ -169,6 +268,9 @@ __global__ __launch_bounds__(512) void vlad_clip16_kernel(const VBArgs g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) nsq[e] = 0.f;
     const int kcol = kbase + cp * 64 + k8;                    // this lane's first cluster in the store pass
+    // (Two centre tiles in flight -- tile j + 1 requested as soon as tile j's accumulators have gone to LDS, vlad_clip.hip's arrangement --
+    // was tried: 64 registers of centres beside 192 accumulators spilled 92 registers.  One tile's 32, requested at the top of its
+    // iteration, under the LDS round trip of the accumulators.)
 #pragma unroll
     for (int j = 0; j < VB_NJ; ++j) {
         if (j < cnt) {                                        // wave-uniform
@@ -203,7 +305,7 @@ __global__ __launch_bounds__(512) void vlad_clip16_kernel(const VBArgs g) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) nsq[e] = fmaf(u[e], u[e], nsq[e]);      // (the norms come from the fp32 values)
                 const uint4 w = make_uint4(vb_pack2(u[0], u[1]), vb_pack2(u[2], u[3]), vb_pack2(u[4], u[5]), vb_pack2(u[6], u[7]));
-                *reinterpret_cast<uint4*>(g.out + ((int64_t)b * D + d0 + row) * K + kcol) = w;
+                if (do_store) *reinterpret_cast<uint4*>(g.out + ((int64_t)b * D + d0 + row) * K + kcol) = w;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                  // all reads of the tile done before the next column tile overwrites it
@@ -254,10 +356,14 @@ extern "C" int lpm_vlad_aggregate_clip_fwd_bf16(const void* at, const void* xt, 
     g.at = (const uint4*)at; g.xt = (const uint4*)xt; g.centres = centres;
     g.D = D; g.K = K; g.S = 4 * ((T + 63) / 64); g.P = P; g.KH = K / 256; g.residual = residual;
     g.out = (unsigned short*)nrm_bf16; g.asum = asum; g.colsq_part = colsq_part;
-    static const int ns = [] { const char* e = getenv("LPM_VB_NS"); return (e && e[0] == '4') ? 4 : 5; }();
-    const size_t ring = (size_t)ns * VB_STAGE, epi = (size_t)VB_EPI + VB_TAIL;
+    static const int dbg = [] { const char* e = getenv("LPM_VB_DBG"); return e ? atoi(e) : 0; }();
+    g.dbg = dbg;
+    constexpr int NS = 4;
+    const size_t ring = (size_t)NS * VB_STAGE, epi = (size_t)VB_EPI + VB_TAIL;
     const size_t lds = ring > epi ? ring : epi;
-    void (*kern)(const VBArgs) = ns == 4 ? vlad_clip16_kernel<4> : vlad_clip16_kernel<5>;
+    static const int nt = [] { const char* e = getenv("LPM_VB_NT"); return (e && e[0] == '0') ? 0 : 1; }();
+    void (*kern)(const VBArgs) = dbg ? (nt ? vlad_clip16_kernel<NS, 1, 2> : vlad_clip16_kernel<NS, 1, 0>)
+                                     : (nt ? vlad_clip16_kernel<NS, 0, 2> : vlad_clip16_kernel<NS, 0, 0>);
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         set_error("lpm_vlad_aggregate_clip_fwd_bf16: cannot reserve %zu bytes of LDS", lds);

@@ -292,6 +292,11 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
     }
 }
 
+// (Round 6, measured and removed: a third form for bf16 logits at K = 512 without LDS -- a WAVE owns the 8 frames of one fragment half x
+// all 512 clusters, a lane 8 consecutive clusters, and each lane then holds eight consecutive 16-byte words of its tile: 128 contiguous
+// bytes per lane, 5 120 independent waves, no barrier.  39.2 us against this form's 30.9 (tools/time_k2_bf16.py): one store instruction
+// of it writes 64 sixteen-byte pieces 128 bytes apart -- eight partial-line writes per line where the LDS round trip below buys whole
+// 1 KB tile pieces per instruction.)
 template <bool BF16IN>
 static bool launch_assign_tiles2(const void* assign, const float* scale, const float* shift, int B, int T, int K, int S, int softmax,
                                  void* at, hipStream_t stream, int timing_tag) {

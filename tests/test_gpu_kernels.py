@@ -1752,7 +1752,8 @@ def test_k2_bf16_clip_wide_items_against_the_128_x_128_form(B, T, D, K):
     assert (s1["nrm"] - s0["nrm"]).abs().le(2.0 ** -7 * s0["nrm"].abs() + 1e-6 * scale).all(), "un-normalised sums differ by more than a bf16 rounding"
     assert rel_err(s1["asum"], s0["asum"]) <= 1e-5 and rel_err(s1["colsq"], s0["colsq"]) <= 1e-5 and rel_err(s1["gsq"], s0["gsq"]) <= 1e-5
     assert rel_err(o1, o0) <= 2.0 ** -7
-    x = raw.reshape(B * T, ld)[:, :D]
+    # (S of S frames: the uniform sampler's fp32 index arithmetic is NOT the identity for every S -- 77 repeats frames -- so the oracle samples too)
+    x = O.sample_uniform_frames(raw, nf, T).reshape(B * T, ld)[:, :D]
     ref, _, _, _ = _oracle_netvlad(x, W, gamma, beta, W2, T, torch.zeros(B, D * K))
     assert rel_err(o1, ref) <= BF16_FWD_TOL, f"descriptor against the fp64 oracle: {rel_err(o1, ref):.2e}"
 

@@ -15,6 +15,10 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 wl = bench.WORKLOADS[cfg]
 bench.set_flags(wl)
+if os.environ.get("LPM_SINGLE_STREAM") == "1":     # as bench.py: the audio branch and the hidden1 update on the main stream
+    from learnablepoolingmethods_amd import FLAGS as _flags
+    _flags.audio_side_stream = False
+    _flags.hidden1_update_stream = False
 dev = torch.device("cuda:0")
 tr = Trainer(registry.get_model(wl.get("model", "NetVladV1")), vocab_size=bench.VOCAB, batch_size=wl["batch"], device=dev, seed=1234,
              model_kwargs=wl["model_kwargs"], **bench.TRAIN)

@@ -1,0 +1,7 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r06
+timeout 600 python tests/diagnostics/debug_bf16_ragged.py > gpurun_out/r06/debug_ragged.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_kernels.py -q -s -k "k2_bf16_clip or netvlad_bf16_storage" 2>&1 | grep -E "^\[|passed|failed|Error|assert" | cut -c1-300 > gpurun_out/r06/clip16_tests2.log
+timeout 600 python bench.py --config cfg5 --no-cpu-baseline --steps 40 > gpurun_out/r06/bench7_cfg5.json 2> gpurun_out/r06/bench7_cfg5.err
+LPM_VB_NS=4 timeout 600 python bench.py --config cfg5 --no-cpu-baseline --steps 40 > gpurun_out/r06/bench7_cfg5_ns4.json 2> gpurun_out/r06/bench7_cfg5_ns4.err
