@@ -1,4 +1,4 @@
-"""The committed bench lines (profiles/r05_bench_line.json, r05_bench_line_cfg3.json, r05_bench_line_cfg5.json, written by bench.py on the GPU box) keep the driver's contract:
+"""The committed bench lines (profiles/r06_bench_line.json, r06_bench_line_cfg3.json, r06_bench_line_cfg5.json, written by bench.py on the GPU box) keep the driver's contract:
 required keys, BASELINE.json's metric, and internally consistent roofline / throughput figures.  CPU-only: it reads the
 committed artefact, it does not run the bench."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_bench_line.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -53,7 +53,7 @@ def test_bench_line_round2_objects():
     assert abs(a5["frac"] - a5["algorithmic_bytes"] / (a5["total_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3
     assert a5["frac"] <= d["roofline"]["frac"]                   # the chain cannot beat its dominant kernel
     assert d["parity"]["ok"] is True and d["parity"]["predictions_max_rel_err"] <= d["parity"]["tolerance"] == 1e-3
-    with open(os.path.join(ROOT, "profiles", "r05_bench_line_cfg5.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_bench_line_cfg5.json")) as f:
         c = json.loads(f.read().strip().splitlines()[-1])
     assert c["dtype"] == "bf16" and c["config"]["global_batch"] == 128 and "configs[4]" in c["metric"]
     r = c["roofline"]
@@ -61,7 +61,7 @@ def test_bench_line_round2_objects():
     assert r["algorithmic_bytes"] == 2 * (B * T * K + B * T * D + B * D * K) + 4 * D * K        # video part of 2.165 MB/clip, bf16
     assert abs(r["algorithmic_bytes"] / B / 1e6 - 1.99) < 0.02
     assert c["parity"]["ok"] is True and c["parity"]["tolerance"] == 2e-2
-    with open(os.path.join(ROOT, "profiles", "r05_bench_line_cfg3.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_bench_line_cfg3.json")) as f:
         v2 = json.loads(f.read().strip().splitlines()[-1])
     assert v2["dtype"] == "f32" and v2["config"]["global_batch"] == 80 and "configs[2]" in v2["metric"] and "NetVladV2" in v2["metric"]
     assert abs(v2["value"] - 80 / (v2["ms_per_step"] * 1e-3)) < 0.01 * v2["value"]
@@ -81,7 +81,7 @@ def test_bench_line_round5_objects():
     f = d["operand_formats"]
     assert f["sites"] > 0 and f["steps_run"] - f["encoder_gemm_steps_on_fp16_planes"] == 2     # the two calibration-free first steps
     assert "fp16" in d["dtype_detail"]
-    with open(os.path.join(ROOT, "profiles", "r05_bench_line_default_run.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r06_bench_line_default_run.json")) as fh:
         dflt = json.loads(fh.read().strip().splitlines()[-1])
     assert dflt["metric"] == d["metric"] and abs(dflt["value"] - d["value"]) < 0.05 * d["value"]
     o = dflt["other_configs"]

@@ -1,7 +1,7 @@
-"""Splits the output of `python bench.py --config all` (three JSON lines) into profiles/r05_bench_line{,_cfg3,_cfg5}.json.
-usage: python tools/store_bench_lines.py gpurun_out/<tag>/bench_all.jsonl [prefix, default profiles/r05_bench_line]"""
+"""Splits the output of `python bench.py --config all` (three JSON lines) into profiles/r06_bench_line{,_cfg3,_cfg5}.json.
+usage: python tools/store_bench_lines.py gpurun_out/<tag>/bench_all.jsonl [prefix, default profiles/r06_bench_line]"""
 import json, sys
-prefix = sys.argv[2] if len(sys.argv) > 2 else "profiles/r05_bench_line"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "profiles/r06_bench_line"
 for l in open(sys.argv[1]):
     l = l.strip()
     if not l.startswith("{"):
