@@ -48,14 +48,14 @@ struct VBArgs {
     const uint4* xt;            // frame tiles      [b][S][D/32][lane]   (lpm_frame_apply_tiles_bf16 / lpm_split_frames_bf16)
     const float* centres;       // [D, K] (cluster_weights2) or null
     int D, K, S, P, KH, residual;
-    int dbg;                    // measurement only (LPM_VB_DBG): see the kernel
+    int dbg, delay_us;          // measurement only (LPM_VB_DBG, LPM_VB_DELAY): see the kernel
     unsigned short* out;        // [B, D, K] bf16 un-normalised residual sums, d-major
     float* asum;                // [B, K]
     float* colsq_part;          // [B, P, K]
 };
 
 // DBG (measurement builds of the SAME kernel, LPM_VB_DBG=n, results are garbage): 1 no main loop, 2 no result stores, 4 no DMA, 8 no MFMAs,
-// 16 no centre loads, 32 no epilogue at all.  The production instantiation (DBG = 0) carries none of these branches.
+// 16 no centre loads, 32 no epilogue at all, 64 every second workgroup of the first round starts LPM_VB_DELAY us late (results correct).  The production instantiation (DBG = 0) carries none of these branches.
 template <int NS, int DBG, int AUX>
 __global__ __launch_bounds__(512) void vlad_clip16_kernel(const VBArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // the ONLY LDS object (guide 5, trap (a))
@@ -71,6 +71,12 @@ __global__ __launch_bounds__(512) void vlad_clip16_kernel(const VBArgs g) {
     // 85: the item loop around the 192 accumulators cost the epilogue 75 spilled registers, and with one item per workgroup of the same code
     // (LPM_VB_GRID = 768) it was 116 us: what the prefetch hides is worth ~4 us, what the spills cost ~30.)
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    if (DBG && (dbg & 64) && blockIdx.x < 256 && (blockIdx.x & 1)) {
+        // measurement: put every second workgroup of the FIRST round g.delay_us behind (do the rounds' load and store phases overlap
+        // across CUs once they are out of step?)
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)g.delay_us * 100ull) __builtin_amdgcn_s_sleep(16);      // (100 MHz counter)
+    }
     const int b = lid / (KH * P), rem_ = lid % (KH * P);
     const int kh = rem_ / P, p = rem_ % P;
     const int base = DT / P, rem = DT % P;
@@ -358,6 +364,8 @@ extern "C" int lpm_vlad_aggregate_clip_fwd_bf16(const void* at, const void* xt, 
     g.out = (unsigned short*)nrm_bf16; g.asum = asum; g.colsq_part = colsq_part;
     static const int dbg = [] { const char* e = getenv("LPM_VB_DBG"); return e ? atoi(e) : 0; }();
     g.dbg = dbg;
+    static const int delay = [] { const char* e = getenv("LPM_VB_DELAY"); return e ? atoi(e) : 8; }();
+    g.delay_us = delay;
     constexpr int NS = 4;
     const size_t ring = (size_t)NS * VB_STAGE, epi = (size_t)VB_EPI + VB_TAIL;
     const size_t lds = ring > epi ? ring : epi;
