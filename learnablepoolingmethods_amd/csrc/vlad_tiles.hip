@@ -155,7 +155,11 @@ __global__ __launch_bounds__(256) void assign_tiles_kernel(const float* __restri
 // reduced and exponentiated together -- 4 x the loads in flight and a quarter of the dependent wave-reduction chains of the
 // row-at-a-time form above (cfg-2 video 17.8 -> see DESIGN; cfg-5 video, K = 512: 52.7 us before).  LDS tile [16][K + 4] (rows
 // 16-byte aligned for the lane's vector store; the column-wise reads of the tile emission hit bank 4 r + i: conflict-free).
-template <bool SOFTMAX, bool BF16IN, int VPL>
+// NSTEP = 2 (round 6; bf16 logits at K = 512, BASELINE configs[4]'s video stream): a workgroup takes TWO consecutive frame steps, the second
+// step's rows requested together with the first's -- 2 560 one-step workgroups over 8 resident per CU were 1.25 rounds of one dependent
+// chain each (load, two butterflies, LDS round trip, store); 1 280 two-step workgroups are one round and the second chain's loads ride
+// under the first chain's arithmetic.  Same reductions in the same order: bit-identical tiles.
+template <bool SOFTMAX, bool BF16IN, int VPL, int NSTEP = 1>
 __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restrict__ assign, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int T, int S, uint4* __restrict__ at) {
     constexpr int K = 64 * VPL, KS = K + 4, KT = K / 32;
@@ -167,7 +171,8 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
     float* as = reinterpret_cast<float*>(as_raw);
     unsigned short* as16 = reinterpret_cast<unsigned short*>(as_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / S, s = blockIdx.x % S;
+    const int SB = S / NSTEP;                                // (S a multiple of NSTEP: the launcher's condition)
+    const int b = blockIdx.x / SB, s0 = (blockIdx.x % SB) * NSTEP;
     const int c0 = lane * VPL;
     float sc[VPL], sh[VPL];
 #pragma unroll
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
         sh[j] = (SOFTMAX && shift) ? shift[c0 + j] : 0.f;
     }
     float v[4][VPL];
+    auto load_rows = [&](int s) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int t = 16 * s + wave * 4 + rr;
@@ -212,6 +218,11 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
             for (int j = 0; j < VPL; ++j) v[rr][j] = 0.f;
         }
     }
+    };
+    load_rows(s0);
+#pragma unroll
+    for (int ss = 0; ss < NSTEP; ++ss) {
+    const int s = s0 + ss;
     if (SOFTMAX) {
         float m[4], sum[4];
 #pragma unroll
@@ -270,6 +281,7 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
             for (int j = 0; j < VPL; ++j) dst[j] = v[rr][j];
         }
     }
+    if (ss + 1 < NSTEP) load_rows(s + 1);                  // (the rows of this step are in LDS: their registers take the next step's, in flight under the emission below)
     __syncthreads();
     for (int slot = tid; slot < KT * 64; slot += 256) {
         const int kt = slot >> 6, ln = slot & 63;
@@ -290,6 +302,8 @@ __global__ __launch_bounds__(256) void assign_tiles2_kernel(const float* __restr
         at[base] = hi;
         at[base + 64] = lo;
     }
+    if (ss + 1 < NSTEP) __syncthreads();                    // the tile is read: the next step may overwrite it
+    }
 }
 
 // (Round 6, measured and removed: a third form for bf16 logits at K = 512 without LDS -- a WAVE owns the 8 frames of one fragment half x
@@ -306,6 +320,15 @@ static bool launch_assign_tiles2(const void* assign, const float* scale, const f
     if (!on) return false;
     hipEvent_t e0, e1;
     const bool timed = timing_tag && timing_request(timing_tag, &e0, &e1);
+    static const int two = [] { const char* e = getenv("LPM_ASSIGN_TILES_NSTEP"); return (e && e[0] == '1') ? 0 : 1; }();     // "1": one step per workgroup (A/B)
+    if (BF16IN && K == 512 && S % 2 == 0 && two) {
+        auto kern = softmax ? assign_tiles2_kernel<true, BF16IN, 8, 2> : assign_tiles2_kernel<false, BF16IN, 8, 2>;
+        if (timed)
+            hipExtLaunchKernelGGL(kern, dim3(B * S / 2), dim3(256), 0, stream, e0, e1, 0, (const float*)assign, scale, shift, T, S, (uint4*)at);
+        else
+            hipLaunchKernelGGL(kern, dim3(B * S / 2), dim3(256), 0, stream, (const float*)assign, scale, shift, T, S, (uint4*)at);
+        return true;
+    }
 #define LPM_AT2(SM, VPL)                                                                                                            \
     do {                                                                                                                            \
         if (timed)                                                                                                                  \
