@@ -67,6 +67,37 @@ def test_clip_wide_aggregation_loop_carries_its_fragments_in_place(tmp_path):
         assert not bad, f"{name}: register copies / scratch traffic inside the main loop: {bad[:6]}"
 
 
+@pytest.mark.timeout(600)
+def test_bf16_clip_wide_aggregation_loop_carries_its_fragments_in_place(tmp_path):
+    """vlad_clip16.hip (round 6: K2 for bf16 storage) uses vlad_clip.hip's technique -- fragments requested by inline-assembly ds_reads
+    across the loop's back edge, waited for with hand-counted lgkmcnt -- over two rotating B-pair register sets and two alternating A sets
+    (the loop holds two steps).  The same condition holds: in the main loop of the production instantiations no vector register copy and
+    no scratch access, the 24 MFMAs of two steps, and no s_waitcnt vmcnt(0) other than the ones the source places at the end of the
+    frame loop (the compiler must not drain the LDS-DMA ring on its own)."""
+    global SRC
+    keep = SRC
+    try:
+        SRC = os.path.join(_build.CSRC, "vlad_clip16.hip")
+        asm = _device_asm(_build.FLAGS, tmp_path, "vlad_clip16.s")
+    finally:
+        SRC = keep
+    kernels = re.findall(r"^(_ZN3lpm18vlad_clip16_kernelILi\dELi0ELi\dEEEvNS_6VBArgsE):[^\n]*\n(.*?)s_endpgm", asm, flags=re.S | re.M)
+    assert len(kernels) >= 2, "production instantiations of vlad_clip16_kernel not found in the device assembly"
+    for name, body in kernels:
+        assert "scratch_" not in body, f"{name}: scratch traffic (spilled registers)"
+        lines = body.splitlines()
+        head = [i for i, l in enumerate(lines) if "Inner Loop Header" in l]
+        assert head, name
+        label = lines[head[0]].split(":")[0].strip()
+        back = [i for i, l in enumerate(lines) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\s*$", l) and i > head[0]]
+        assert back, f"{name}: no back edge to {label}"
+        loop = [l for l in lines[head[0]:back[-1] + 1] if not l.strip().startswith(";")]
+        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == 24, f"{name}: expected the 24 MFMAs of two steps in the loop"
+        assert sum("ds_read_b128" in l for l in loop) == 16, f"{name}: expected the 16 fragment reads of two steps in the loop"
+        bad = [l.strip() for l in loop if re.search(r"\b(v_mov_b(32|64)|v_accvgpr_(read|write)\w*|scratch_(load|store)\w*)\b", l)]
+        assert not bad, f"{name}: register copies / scratch traffic inside the main loop: {bad[:6]}"
+
+
 @pytest.mark.timeout(900)
 def test_projection_kernels_keep_their_lds_dma_rings_in_flight():
     """To LLVM an LDS-DMA load (global_load_lds) is a store to LDS that any later LDS read may alias: a plain C++ read of such a ring gets an
