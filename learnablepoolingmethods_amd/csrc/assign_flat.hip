@@ -339,6 +339,7 @@ constexpr int AW_STAGE = AW_KB * AW_STEP;
 constexpr int AW_NS = 3, AW_DB = 4, AW_FR = 8;
 static_assert((AW_KB * AW_MT) % AW_FR == 0 && AW_FR >= AW_MT + 2, "the fragment registers rotate with the period of a stage");
 constexpr int AW_TAIL = 3 * AW_KB;         // the last three stages request no further stage
+constexpr int AW_EW = 144;                 // bytes between the rows of a wave's epilogue tile (128 of bf16 logits + 16)
 // VMEM operations of step u (tail-relative; u < 0: steady state and the prologue's virtual steps), in issue order: the five pieces of
 // the stage three ahead at a stage's last step, the two B loads of step u + DB at its end
 constexpr int AW_DMA = AW_MT;             // DMA pieces per wave and stage
@@ -494,13 +495,47 @@ __global__ __launch_bounds__(512, 1) void assign_wide_kernel(const AssignFlatArg
     }
     // epilogue.  The MFMAs ran TRANSPOSED (srcA = the weight fragment, srcB = the frame fragment): acc[m][c][r] =
     // logits[row wg * 160 + m * 32 + l31][column (ct0 + c) * 32 + 8 (r >> 2) + 4 half + (r & 3)] -- a lane holds four CONSECUTIVE
-    // columns of one row in four consecutive registers: 8-byte bf16 stores, 40 per wave.  (The first build had the rows in the
-    // registers: 160 two-byte stores per wave, 1 280 per CU at ~16 cycles of address processing each: 20 us of a 68 us kernel.)
+    // columns of one row in four consecutive registers.  (The first build had the rows in the registers: 160 two-byte stores per wave,
+    // 1 280 per CU at ~16 cycles of address processing each: 20 us of a 68 us kernel.  Round 5 stored the four columns as 8 bytes: 40
+    // stores per wave, each instruction 32 sixteen-byte pieces 1 KB apart -- the 39 MB left at 3 TB/s.)  Round 6: the wave's 32 x 64
+    // bf16 tile of row tile m goes through a wave-private LDS tile (the ring is free behind the barrier; rows AW_EW bytes apart) and
+    // leaves as 16-byte stores, eight lanes to a row's 128 bytes: 20 store instructions per wave, every one writing eight whole lines.
     unsigned short* lg = reinterpret_cast<unsigned short*>(a.logits);
     float* sp = a.stats + (int64_t)wg * 2 * a.K;
     bool row_ok[AW_MT];
 #pragma unroll
     for (int m = 0; m < AW_MT; ++m) row_ok[m] = (int64_t)wg * AW_ROWS + m * 32 + l31 < a.M;
+    __syncthreads();                                               // everybody's last fragment reads are behind it: the ring is free
+    {
+        unsigned char* tile = smem + wave * (32 * AW_EW);
+        const int prow = lane >> 3, piece = lane & 7;
+#pragma unroll
+        for (int m = 0; m < AW_MT; ++m) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const of_f2 v01 = {acc[m][c][4 * g + 0], acc[m][c][4 * g + 1]}, v23 = {acc[m][c][4 * g + 2], acc[m][c][4 * g + 3]};
+                    uint2 w;
+                    w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, of_b2));
+                    w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, of_b2));
+                    *reinterpret_cast<uint2*>(tile + l31 * AW_EW + c * 64 + g * 16 + half * 8) = w;
+                }
+            __builtin_amdgcn_wave_barrier();                       // (a wave's LDS operations complete in order: no s_barrier)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = j * 8 + prow;
+                const tg_u32x4 v = *reinterpret_cast<const tg_u32x4*>(tile + r * AW_EW + piece * 16);
+                const int64_t row = (int64_t)wg * AW_ROWS + m * 32 + r;
+                unsigned short* dst = lg + row * a.K + ct0 * 32 + piece * 8;
+                if (row < a.M && !(DBG & 64)) {
+                    if (DBG & 128) __builtin_nontemporal_store(v, reinterpret_cast<tg_u32x4*>(dst));
+                    else *reinterpret_cast<tg_u32x4*>(dst) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         float cs[16], cq[16];
@@ -508,19 +543,6 @@ __global__ __launch_bounds__(512, 1) void assign_wide_kernel(const AssignFlatArg
         for (int r = 0; r < 16; ++r) cs[r] = cq[r] = 0.f;
 #pragma unroll
         for (int m = 0; m < AW_MT; ++m) {
-            const int64_t row = (int64_t)wg * AW_ROWS + m * 32 + l31;
-            unsigned short* dst = lg + row * a.K + (ct0 + c) * 32 + 4 * half;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const of_f2 v01 = {acc[m][c][4 * g + 0], acc[m][c][4 * g + 1]}, v23 = {acc[m][c][4 * g + 2], acc[m][c][4 * g + 3]};
-                uint2 w;
-                w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, of_b2));
-                w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, of_b2));
-                if (row_ok[m] && !(DBG & 64)) {
-                    if (DBG & 128) __builtin_nontemporal_store(((unsigned long long)w.y << 32) | w.x, reinterpret_cast<unsigned long long*>(dst + 8 * g));
-                    else *reinterpret_cast<uint2*>(dst + 8 * g) = w;
-                }
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = row_ok[m] ? acc[m][c][r] : 0.f;
