@@ -731,6 +731,23 @@ int lpm_mha_bwd_set_terms(int terms);
  * moments: NULL, or the forward's lpm_mha_logit_stats_moments output (Qm, Sq of the unscaled q) -- then q is not read. */
 int lpm_mha_bn_dk_correct(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
                           const float* corr_b, float* dk, int64_t ldd, const float* moments, lpm_stream_t stream);
+/* The same backward with the q / k / v gradients leaving as the [dq | dk | dv] GRADIENT IMAGE that the q/k/v layer's input- and weight-
+ * gradient GEMMs read (lpm_mha_bwd_x3_image_fmt's image; g_fmt NULL: split-bf16 [hi | hi | lo] planes of 3 h d columns, fp16 two-product:
+ * [hi | lo]) -- no fp32 [B*L, 3 h d] gradient and no lpm_split_rows pass over it (round 6).  Three launches, each writing its own columns:
+ *   lpm_mha_bwd_x3_bn_image_fmt(dk_plain != NULL, corr_a = corr_b = NULL, dz_partial): the key / value sweep -- dv into the image, dk
+ *       WITHOUT the batch statistics' share into dk_plain [B*L, h*d] fp32, the statistics into dz_partial;
+ *   lpm_mha_bn_corrections;
+ *   lpm_mha_bwd_x3_bn_image_fmt(dk_plain = NULL, corr_a, corr_b, dz_partial = NULL): the query sweep -- dq into the image;
+ *   lpm_mha_bn_dk_correct_image: dk_plain minus the share (lpm_mha_bn_dk_correct's formula) into dk's columns of the image.
+ * o and dout are plain fp32 (the attention result of this variant is batch-normalised before its GEMM).  All pointers 16-byte aligned.
+ * Replaces the tail of /root/reference/transformer_utils.py:652-661's backward in front of :559-561's. */
+int lpm_mha_bwd_x3_bn_image_fmt(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout, int64_t ldo,
+                                const float* lse, int B, int L, int h, int d, float scale, const float* key_scale, const float* key_shift,
+                                float* dk_plain, const float* corr_a, const float* corr_b, float* dz_partial, void* dqkv_img,
+                                const LpmOperandFormat* g_fmt, lpm_stream_t stream);
+int lpm_mha_bn_dk_correct_image(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
+                                const float* corr_b, const float* dk_plain, const float* moments, void* dqkv_img,
+                                const LpmOperandFormat* g_fmt, lpm_stream_t stream);
 /* logits_bn's per-(batch, head) statistics (what lpm_mha_logit_stats computes: partial [B*h][2][L] = sum_q q.k_j and sum_q (q.k_j)^2)
  * from the d x d moments of q, which it also hands out: moments [B*h][d*d + d] = (Qm = sum_q q q^T, Sq = sum_q q), or NULL.  Given to
  * lpm_mha_bn_dk_correct (`moments`, of the UNSCALED q; q may then be NULL) the backward does not form them again.  d in {8, 16}. */

@@ -189,6 +189,8 @@ SIGNATURES = {
     "lpm_mha_fwd_x3_image_fmt": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _f]),
     "lpm_mha_bwd_x3_image_fmt": (_i, [_f, _f, _f, _l, _f, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f]),
     "lpm_sum_splits_scaled": (_i, [_f, _i, _i, _i, _i, _fl, _f, _f, _f, _i, _f]),
+    "lpm_mha_bwd_x3_bn_image_fmt": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "lpm_mha_bn_dk_correct_image": (_i, [_f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f]),
     "lpm_bn_rows_act_image_fwd_fmt": (_i, [_f, _f, _i, _i, _i, _f, _f, _fl, _fl, _i, _f, _f, _f, _f, _f, _f, _s, _f, _f]),
     "lpm_bn_act_bwd_image_fmt": (_i, [_f, _f, _f, _i, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _f, _s, _f, _f]),
 }

@@ -56,7 +56,11 @@ __device__ __forceinline__ void mx_split8(const float* v, mx_u32x4& hi, mx_u32x4
 struct MxImg {
     int of16, oplanes; float oscale, oinv; float* oamax;
     int gf16, gplanes; float gscale; float* gamax;
+    // logits_bn's one-pass backward: the key / value sweep's dk still lacks the batch statistics' share (lpm_mha_bn_dk_correct), so it
+    // leaves as plain fp32 rows dk_ld floats apart while dv goes into the gradient image; the repair writes dk's part of the image
+    int dk_plain; long long dk_ld;
 };
+
 __device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img, float a, float b, float c, float d, const MxImg& im, float& vmax) {
     if (img == 0) {
         *reinterpret_cast<float4*>(base + off) = make_float4(a, b, c, d);
@@ -82,6 +86,11 @@ __device__ __forceinline__ void mx_store_grad4(float* base, int64_t off, int img
         *reinterpret_cast<uint2*>(p + img) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(p + 2 * (int64_t)img) = make_uint2(l0, l1);
     }
+}
+// the key gradient of one lane: four consecutive columns (from head column c) of global key row `row`
+__device__ __forceinline__ void mx_store_dk4(float* dk, int64_t row, int64_t ldd, int c, int img, float a, float b, float cc, float d, const MxImg& im, float& vmax) {
+    if (im.dk_plain) *reinterpret_cast<float4*>(dk + row * im.dk_ld + c) = make_float4(a, b, cc, d);
+    else mx_store_grad4(dk, row * ldd + c, img, a, b, cc, d, im, vmax);
 }
 // Activation-image output / input of the attention result (oimg = plane stride in bf16 elements = h*d, 0 = plain fp32): row =
 // [hi | lo | hi] planes, the operand image of the output projection GEMM (ops._split_rows): the forward writes it instead of an
@@ -658,7 +667,7 @@ __global__ __launch_bounds__(mx_dkv_nt(NKT)) void mha_bwd_dkv_x3_kernel(const fl
         if (!stats_only && kok && 4 * g < D) {
             const int64_t off = ((int64_t)b * L + krow) * ldd + hh * D + 4 * g;
             const float kmul = AFFINE ? 1.f : MX_LN2;      // the staged Q carried log2(e)
-            mx_store_grad4(dk, off, img, (dka[0] + dkb[0]) * kmul, (dka[1] + dkb[1]) * kmul, (dka[2] + dkb[2]) * kmul, (dka[3] + dkb[3]) * kmul, im, vmax);
+            mx_store_dk4(dk, (int64_t)b * L + krow, ldd, hh * D + 4 * g, img, (dka[0] + dkb[0]) * kmul, (dka[1] + dkb[1]) * kmul, (dka[2] + dkb[2]) * kmul, (dka[3] + dkb[3]) * kmul, im, vmax);
             mx_store_grad4(dv, off, img, dva[0] + dvb[0], dva[1] + dvb[1], dva[2] + dvb[2], dva[3] + dvb[3], im, vmax);
         }
         if (dz_partial) {
@@ -1037,8 +1046,8 @@ __global__ __launch_bounds__((mx_h_nt<NKT, TPW, true>())) void mha_bwd_dkv_h_ker
             if (!stats_only && kok[u] && 4 * g < D) {
                 const int64_t off = ((int64_t)b * L + krow) * ldd + hh * D + 4 * g;
                 const float kmul = (AFFINE ? 1.f : MX_LN2) * gsinv;      // the staged Q carried log2(e)
-                mx_store_grad4(dk, off, img, (dka[u][0] + dkb[u][0]) * kmul, (dka[u][1] + dkb[u][1]) * kmul, (dka[u][2] + dkb[u][2]) * kmul,
-                               (dka[u][3] + dkb[u][3]) * kmul, im, vmax);
+                mx_store_dk4(dk, (int64_t)b * L + krow, ldd, hh * D + 4 * g, img, (dka[u][0] + dkb[u][0]) * kmul, (dka[u][1] + dkb[u][1]) * kmul,
+                             (dka[u][2] + dkb[u][2]) * kmul, (dka[u][3] + dkb[u][3]) * kmul, im, vmax);
                 mx_store_grad4(dv, off, img, (dva[u][0] + dvb[u][0]) * gsinv, (dva[u][1] + dvb[u][1]) * gsinv, (dva[u][2] + dvb[u][2]) * gsinv,
                                (dva[u][3] + dvb[u][3]) * gsinv, im, vmax);
             }
@@ -1121,8 +1130,12 @@ __host__ __device__ constexpr int mx_moments_floats(int L, int d) { return L * d
 template <int D>
 __global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restrict__ q, const float* __restrict__ k, int64_t ld, int L, int h,
                                                             float scale, const float* __restrict__ corr_a, const float* __restrict__ corr_b,
-                                                            float* __restrict__ dk, int64_t ldd, const float* __restrict__ moments) {
+                                                            float* __restrict__ dk, int64_t ldd, const float* __restrict__ moments,
+                                                            float* __restrict__ dk_img, int64_t ldi, int img, const MxImg im) {
+    // dk_img != NULL: the repaired rows leave as dk's part of the [dq | dk | dv] gradient image (row stride ldi, plane stride img, both in
+    // 16-bit elements; mx_store_grad4) instead of in place -- dk itself is then the key / value sweep's plain fp32 scratch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float vmax = 0.f;
     const int tid = threadIdx.x;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = lid / h, hh = lid % h;
@@ -1172,8 +1185,10 @@ __global__ __launch_bounds__(256) void mha_bn_dk_fix_kernel(const float* __restr
             r[u] = fmaf(cb, t, ca * sq4[u]);
         }
         g.x -= r[0]; g.y -= r[1]; g.z -= r[2]; g.w -= r[3];
-        *reinterpret_cast<float4*>(dp) = g;
+        if (dk_img) mx_store_grad4(dk_img, ((int64_t)b * L + row) * ldi + hh * D + 4 * c4, img, g.x, g.y, g.z, g.w, im, vmax);
+        else *reinterpret_cast<float4*>(dp) = g;
     }
+    if (dk_img) of_amax_commit(im.gamax, vmax);
 }
 
 static inline size_t mx_bwd_dq_lds(int LP, int D) { return (size_t)2 * mx_rowplanes_bytes(LP, D) + mx_tplanes_bytes(LP) + 4 * LP * 4; }
@@ -1212,7 +1227,7 @@ extern "C" int lpm_mha_bwd_set_terms(int terms) {
 
 static lpm::MxImg mx_img(const LpmOperandFormat* o_fmt, const LpmOperandFormat* g_fmt) {
     const lpm::OperandFmt fo = lpm::operand_fmt(o_fmt), fg = lpm::operand_fmt(g_fmt);
-    return lpm::MxImg{fo.f16, fo.planes, fo.scale, 1.f / fo.scale, fo.amax, fg.f16, fg.planes, fg.scale, fg.amax};
+    return lpm::MxImg{fo.f16, fo.planes, fo.scale, 1.f / fo.scale, fo.amax, fg.f16, fg.planes, fg.scale, fg.amax, 0, 0};
 }
 static int mx_fwd_launch(const float* q, const float* k, const float* v, int64_t ld, int B, int L, int h, int d, float scale,
                          const float* key_scale, const float* key_shift, float* o, int64_t ldo, float* lse, int oimg,
@@ -1288,9 +1303,13 @@ static int mx_bwd_launch(const float* q, const float* k, const float* v, int64_t
                          const float* lse, int B, int L, int h, int d, float scale, const float* key_scale, const float* key_shift,
                          float* dq, float* dk, float* dv, int64_t ldd, const float* corr_a, const float* corr_b, float* dz_partial,
                          int img, int oimg, lpm_stream_t stream, const char* what, const LpmOperandFormat* o_fmt = nullptr,
-                         const LpmOperandFormat* g_fmt = nullptr) {
+                         const LpmOperandFormat* g_fmt = nullptr, int64_t dk_plain_ld = 0) {
     using namespace lpm;
-    const MxImg im = mx_img(o_fmt, g_fmt);
+    MxImg im = mx_img(o_fmt, g_fmt);
+    if (dk_plain_ld) {                                      // dk: plain fp32 rows (dk_plain_ld floats apart) beside an image-form dv
+        im.dk_plain = 1;
+        im.dk_ld = dk_plain_ld;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int nkt = (L + 15) / 16;
     dim3 grid(B * h);
@@ -1382,26 +1401,76 @@ extern "C" int lpm_mha_bwd_x3(const float* q, const float* k, const float* v, in
                          dz_partial, 0, 0, stream, "lpm_mha_bwd_x3");
 }
 
-extern "C" int lpm_mha_bn_dk_correct(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
-                                     const float* corr_b, float* dk, int64_t ldd, const float* moments, lpm_stream_t stream) {
+static int mx_dk_correct_launch(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
+                                const float* corr_b, float* dk, int64_t ldd, const float* moments, float* dk_img, int64_t ldi, int img,
+                                const LpmOperandFormat* g_fmt, lpm_stream_t stream, const char* what) {
     using namespace lpm;
-    LPM_REQUIRE((q || moments) && k && corr_a && corr_b && dk, LPM_ERR_BADARG, "lpm_mha_bn_dk_correct: null pointer");
-    LPM_REQUIRE(B > 0 && L > 0 && h > 0 && (d == 8 || d == 16) && ld >= (int64_t)h * d && ld % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0,
-                LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bn_dk_correct: need d in {8, 16} and row strides >= h * d, multiples of 4 (d=%d)", d);
-    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)dk) & 15) == 0, LPM_ERR_BADARG, "lpm_mha_bn_dk_correct: pointers must be 16-byte aligned");
+    if (!((q || moments) && k && corr_a && corr_b && dk)) { set_error("%s: null pointer", what); return LPM_ERR_BADARG; }
+    if (!(B > 0 && L > 0 && h > 0 && (d == 8 || d == 16) && ld >= (int64_t)h * d && ld % 4 == 0 && ldd >= (int64_t)h * d && ldd % 4 == 0)) {
+        set_error("%s: need d in {8, 16} and row strides >= h * d, multiples of 4 (d=%d)", what, d);
+        return LPM_ERR_UNSUPPORTED_SHAPE;
+    }
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)dk | (uintptr_t)dk_img) & 15) != 0) { set_error("%s: pointers must be 16-byte aligned", what); return LPM_ERR_BADARG; }
     const size_t lds = (moments ? (size_t)(d * d + d) : (size_t)mx_moments_floats(L, d)) * sizeof(float);
-    LPM_REQUIRE(lds <= 160 * 1024, LPM_ERR_UNSUPPORTED_SHAPE, "lpm_mha_bn_dk_correct: L = %d does not fit LDS", L);
+    if (lds > 160 * 1024) { set_error("%s: L = %d does not fit LDS", what, L); return LPM_ERR_UNSUPPORTED_SHAPE; }
+    const MxImg im = mx_img(nullptr, g_fmt);
     hipStream_t s = (hipStream_t)stream;
     if (d == 16) {
         auto kern = mha_bn_dk_fix_kernel<16>;
-        if (int rc = mx_reserve(kern, lds, "lpm_mha_bn_dk_correct")) return rc;
-        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd, moments);
+        if (int rc = mx_reserve(kern, lds, what)) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd, moments, dk_img, ldi, img, im);
     } else {
         auto kern = mha_bn_dk_fix_kernel<8>;
-        if (int rc = mx_reserve(kern, lds, "lpm_mha_bn_dk_correct")) return rc;
-        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd, moments);
+        if (int rc = mx_reserve(kern, lds, what)) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, ld, L, h, scale, corr_a, corr_b, dk, ldd, moments, dk_img, ldi, img, im);
     }
-    return check_launch("lpm_mha_bn_dk_correct");
+    return check_launch(what);
+}
+extern "C" int lpm_mha_bn_dk_correct(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
+                                     const float* corr_b, float* dk, int64_t ldd, const float* moments, lpm_stream_t stream) {
+    return mx_dk_correct_launch(q, k, ld, B, L, h, d, scale, corr_a, corr_b, dk, ldd, moments, nullptr, 0, 0, nullptr, stream, "lpm_mha_bn_dk_correct");
+}
+
+// logits_bn's one-pass backward with the q / k / v gradients leaving as the [dq | dk | dv] GRADIENT IMAGE the q/k/v layer's GEMMs read
+// (round 6: cfg-3 paid a 295 MB -> 295 MB lpm_split_rows pass per step for it).  Three launches write one image, each its own columns:
+//   lpm_mha_bwd_x3_bn_image_fmt(dk_plain != NULL, corr NULL, dz_partial): the key / value sweep -- dv into the image, dk WITHOUT the batch
+//       statistics' share into dk_plain [B*L, h*d] fp32, the statistics into dz_partial;
+//   lpm_mha_bwd_x3_bn_image_fmt(dk_plain NULL, corr_a, corr_b): the query sweep -- dq into the image;
+//   lpm_mha_bn_dk_correct_image: dk_plain minus the share -> dk's columns of the image.
+// g_fmt: the image's operand format (NULL: split-bf16 [hi | hi | lo] planes; fp16 two-product: [hi | lo]); o, dout plain fp32.
+extern "C" int lpm_mha_bwd_x3_bn_image_fmt(const float* q, const float* k, const float* v, int64_t ld, const float* o, const float* dout,
+                                           int64_t ldo, const float* lse, int B, int L, int h, int d, float scale, const float* key_scale,
+                                           const float* key_shift, float* dk_plain, const float* corr_a, const float* corr_b, float* dz_partial,
+                                           void* dqkv_img, const LpmOperandFormat* g_fmt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(q && k && v && o && dout && lse && dqkv_img && key_scale && key_shift, LPM_ERR_BADARG, "lpm_mha_bwd_x3_bn_image: null pointer");
+    LPM_REQUIRE((corr_a == nullptr) == (corr_b == nullptr), LPM_ERR_BADARG, "lpm_mha_bwd_x3_bn_image: corr_a/corr_b go together");
+    LPM_REQUIRE((dk_plain != nullptr) != (corr_a != nullptr), LPM_ERR_BADARG,
+                "lpm_mha_bwd_x3_bn_image: either the key / value sweep (dk_plain, no corrections) or the query sweep (corrections, no dk_plain)");
+    LPM_MX_CHECK("lpm_mha_bwd_x3_bn_image");
+    LPM_REQUIRE(ldo >= (int64_t)h * d && ldo % 4 == 0, LPM_ERR_BADARG, "lpm_mha_bwd_x3_bn_image: bad ldo");
+    LPM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dqkv_img | (uintptr_t)dk_plain) & 15) == 0,
+                LPM_ERR_BADARG, "lpm_mha_bwd_x3_bn_image: pointers must be 16-byte aligned");
+    if (const int rc = operand_fmt_check(g_fmt, "lpm_mha_bwd_x3_bn_image")) return rc;
+    const int N = h * d;
+    const int gpl = g_fmt ? operand_kind_planes(g_fmt->kind) : 3;
+    unsigned short* base = (unsigned short*)dqkv_img;
+    if (dk_plain)
+        return mx_bwd_launch(q, k, v, ld, o, dout, ldo, lse, B, L, h, d, scale, key_scale, key_shift, nullptr, dk_plain, (float*)(base + 2 * N),
+                             (int64_t)(3 * gpl) * N, nullptr, nullptr, dz_partial, 3 * N, 0, stream, "lpm_mha_bwd_x3_bn_image", nullptr, g_fmt, N);
+    return mx_bwd_launch(q, k, v, ld, o, dout, ldo, lse, B, L, h, d, scale, key_scale, key_shift, (float*)base, nullptr, nullptr,
+                         (int64_t)(3 * gpl) * N, corr_a, corr_b, nullptr, 3 * N, 0, stream, "lpm_mha_bwd_x3_bn_image", nullptr, g_fmt);
+}
+extern "C" int lpm_mha_bn_dk_correct_image(const float* q, const float* k, int64_t ld, int B, int L, int h, int d, float scale, const float* corr_a,
+                                           const float* corr_b, const float* dk_plain, const float* moments, void* dqkv_img,
+                                           const LpmOperandFormat* g_fmt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(dqkv_img, LPM_ERR_BADARG, "lpm_mha_bn_dk_correct_image: null pointer");
+    if (const int rc = operand_fmt_check(g_fmt, "lpm_mha_bn_dk_correct_image")) return rc;
+    const int N = h * d;
+    const int gpl = g_fmt ? operand_kind_planes(g_fmt->kind) : 3;
+    return mx_dk_correct_launch(q, k, ld, B, L, h, d, scale, corr_a, corr_b, const_cast<float*>(dk_plain), N, moments,
+                                (float*)((unsigned short*)dqkv_img + N), (int64_t)(3 * gpl) * N, 3 * N, g_fmt, stream, "lpm_mha_bn_dk_correct_image");
 }
 
 extern "C" int lpm_mha_bwd_x3_image(const float* q, const float* k, const float* v, int64_t ld, const void* o, int o_is_image,

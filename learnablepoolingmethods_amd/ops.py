@@ -2998,14 +2998,38 @@ class _MHACoreBN(torch.autograd.Function):
         return o
 
     @staticmethod
-    def backward(ctx, do):
+    def backward(ctx, do, image=False, site=None):
+        """image (ops._QKVAttnBNX3 only): the q / k / v gradients as the [B*L, 9 h d] bf16 / [B*L, 6 h d] fp16 gradient image of
+        [dq | dk | dv] that ops._QKVX3.backward feeds its GEMMs (site: the q/k/v layer's gradient site), written by the three kernels of
+        the one-pass backward themselves; returned in dq's place with dk = dv = None.  Where the one-pass form does not apply the plain
+        gradients come back and the caller splits them."""
         lib = _capi.load()
         B, L, h, d, is_training = ctx.dims
         q, k, v, o, lse, kscale, kshift, mean, var, gamma = ctx.saved_tensors
         do = do.contiguous()
         st = stream_ptr()
-        if (MHA_BN_ONEPASS and is_training and d in (8, 16) and _bn_pass_precision("stats", L) == "bf16x3"
-                and _bn_pass_precision("main", L) == "bf16x3"):
+        onepass = (MHA_BN_ONEPASS and is_training and d in (8, 16) and _bn_pass_precision("stats", L) == "bf16x3"
+                   and _bn_pass_precision("main", L) == "bf16x3")
+        if onepass and image:
+            N = h * d
+            f16 = _f16(site)
+            fmt = site.fmt if site is not None else None
+            dy3 = torch.empty((B * L, (6 if f16 else 9) * N), dtype=torch.float16 if f16 else torch.bfloat16, device=q.device)
+            dkp = torch.empty((B * L, N), dtype=torch.float32, device=q.device)      # dk before the statistics' share is taken out
+            partial = _empty((B * h, 2, L), q)
+            lib.check(lib._lpm_mha_bwd_x3_bn_image_fmt(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
+                                                       ptr(kscale), ptr(kshift), ptr(dkp), None, None, ptr(partial), ptr(dy3), fmt, st),
+                      "lpm_mha_bwd_x3_bn_image(dk, dv, statistics)")
+            dgamma, dbeta, corr_a, corr_b = (_empty((L,), q) for _ in range(4))
+            lib.check(lib._lpm_mha_bn_corrections(ptr(partial), B * h, L, ptr(mean.contiguous()), ptr(var.contiguous()), ptr(kscale), BN_EPS,
+                                                  B * h * L, ptr(dgamma), ptr(dbeta), ptr(corr_a), ptr(corr_b), st), "lpm_mha_bn_corrections")
+            lib.check(lib._lpm_mha_bwd_x3_bn_image_fmt(ptr(q), ptr(k), ptr(v), q.stride(1), ptr(o), ptr(do), o.stride(1), ptr(lse), B, L, h, d, 1.0,
+                                                       ptr(kscale), ptr(kshift), None, ptr(corr_a), ptr(corr_b), None, ptr(dy3), fmt, st),
+                      "lpm_mha_bwd_x3_bn_image(dq)")
+            lib.check(lib._lpm_mha_bn_dk_correct_image(ptr(q), ptr(k), q.stride(1), B, L, h, d, 1.0, ptr(corr_a), ptr(corr_b), ptr(dkp),
+                                                       ptr(ctx.moments), ptr(dy3), fmt, st), "lpm_mha_bn_dk_correct_image")
+            return dy3, None, None, dgamma, dbeta, None, None, None, None
+        if onepass:
             # ONE pass over the scores for dk, dv AND the statistics: the batch statistics' share of ds is affine in the raw score, so its
             # part of dk is a d-vector and a d x d matrix per (batch, head) away (lpm_mha_bn_dk_correct); dq's pass applies it in place
             partial = _empty((B * h, 2, L), q)
@@ -3042,6 +3066,53 @@ class _MHACoreBN(torch.autograd.Function):
 
 def mha_core_bn(q, k, v, num_heads, gamma, beta, moving_mean, moving_var, is_training=True):
     return _MHACoreBN.apply(q, k, v, gamma, beta, moving_mean, moving_var, int(num_heads), bool(is_training))
+
+
+# LPM_MHA_BN_GRAD_IMAGE=0: the q/k/v layer and the logits_bn attention as two autograd nodes again (fp32 dq | dk | dv + an operand-split pass)
+MHA_BN_GRAD_IMAGE = os.environ.get("LPM_MHA_BN_GRAD_IMAGE", "1") != "0"
+
+
+class _QKVAttnBNX3(torch.autograd.Function):
+    """MultiHeadAttentionBN up to the combined heads (transformer_utils.py:559-561 + :652-661) as ONE node: the fused q/k/v GEMM and the
+    logits_bn attention.  Forward: the two Functions' forwards unchanged.  Backward: the attention kernels write [dq | dk | dv] as the
+    gradient image of the q/k/v layer's GEMMs -- at cfg-3 the fp32 [24000, 3072] gradient and the lpm_split_rows pass over it (190 us of
+    an 8.85 ms step for the frames, 2 x 295 MB) never exist.  Same values bit for bit: the image is the split of the same fp32 numbers."""
+
+    @staticmethod
+    def forward(ctx, x, Wq, Wk, Wv, gamma, beta, moving_mean, moving_var, num_heads):
+        x = _f32(x, "attention input").contiguous()
+        B, L, F = x.shape
+        N = Wq.shape[1]
+        cq, cm = _SubCtx(), _SubCtx()
+        cq.needs_input_grad = (ctx.needs_input_grad[0],) + (True,) * 11
+        q, k, v = _QKVX3.forward(cq, x.view(B * L, F), Wq, Wk, Wv)
+        o = _MHACoreBN.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), gamma, beta, moving_mean, moving_var, num_heads, True)
+        ctx.wq = Wq
+        _pack_subs(ctx, (cq, cm))
+        ctx.shape = (B, L, F, N)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        cq, cm = _unpack_subs(ctx)
+        B, L, F, N = ctx.shape
+        got = _MHACoreBN.backward(cm, do, image=True, site=_site("g", ctx.wq))
+        dgamma, dbeta = got[3], got[4]
+        if got[1] is None:                                   # the kernels wrote the GEMMs' operand image
+            dx, dWq, dWk, dWv = _QKVX3.backward(cq, None, None, None, dy3=got[0])
+        else:
+            dx, dWq, dWk, dWv = _QKVX3.backward(cq, got[0].reshape(B * L, N), got[1].reshape(B * L, N), got[2].reshape(B * L, N))
+        return (dx.view(B, L, F) if dx is not None else None), dWq, dWk, dWv, dgamma, dbeta, None, None, None
+
+
+def qkv_attention_bn_ok(x, hidden, num_heads):
+    """Whether MultiHeadAttentionBN's self-attention front runs as ops.qkv_attention_bn_x3 for this [B, L, F] input (training only)."""
+    return bool(MHA_BN_GRAD_IMAGE and MHA_BN_ONEPASS and x.is_cuda and x.dim() == 3 and hidden % num_heads == 0 and hidden // num_heads in (8, 16)
+                and x.shape[1] <= 512 and _bn_pass_precision("stats", x.shape[1]) == "bf16x3" and _bn_pass_precision("main", x.shape[1]) == "bf16x3")
+
+
+def qkv_attention_bn_x3(x, Wq, Wk, Wv, gamma, beta, moving_mean, moving_var, num_heads):
+    return _QKVAttnBNX3.apply(x, Wq, Wk, Wv, gamma, beta, moving_mean, moving_var, int(num_heads))
 
 
 # ----------------------------------------------------------------------------------------------

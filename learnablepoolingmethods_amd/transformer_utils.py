@@ -42,10 +42,21 @@ class MultiHeadAttentionBN(modules.BaseModule):
     def forward(self, queries, keys, defer_bias=False):
         """defer_bias: return (raw output of output_transform, its bias) where the fused node allows it -- the caller's layer norm adds
         the bias (and applies the dropout between the two) in its own passes -- else (output, None)."""
-        q, k, v = layers.qkv_projections(queries, keys, self.hidden_size)
         L = keys.shape[1]
-        gamma, beta, mm, mv = layers.bn_variables("logits_bn", L, q.device)        # channel = key position :652-658
-        attention_output = ops.mha_core_bn(q, k, v, self.num_heads, gamma, beta, mm, mv, self.is_train)
+        rows = queries.numel() // queries.shape[-1]
+        if (queries is keys and self.is_train and layers.use_split_gemm(queries, rows, self.hidden_size)
+                and ops.qkv_attention_bn_ok(queries, self.hidden_size, self.num_heads)):
+            # q/k/v projections + logits_bn attention as ONE node, so that its backward hands [dq | dk | dv] to the projections' GEMMs as
+            # their operand image (same variables, same order: q, k, v kernels, then logits_bn's)
+            wq, _ = layers.dense_variables("q", queries.shape[-1], self.hidden_size, False, queries.device)
+            wk, _ = layers.dense_variables("k", queries.shape[-1], self.hidden_size, False, queries.device)
+            wv, _ = layers.dense_variables("v", queries.shape[-1], self.hidden_size, False, queries.device)
+            gamma, beta, mm, mv = layers.bn_variables("logits_bn", L, queries.device)    # channel = key position :652-658
+            attention_output = ops.qkv_attention_bn_x3(queries, wq, wk, wv, gamma, beta, mm, mv, self.num_heads)
+        else:
+            q, k, v = layers.qkv_projections(queries, keys, self.hidden_size)
+            gamma, beta, mm, mv = layers.bn_variables("logits_bn", L, q.device)        # channel = key position :652-658
+            attention_output = ops.mha_core_bn(q, k, v, self.num_heads, gamma, beta, mm, mv, self.is_train)
         rows = attention_output.numel() // attention_output.shape[-1]
         if (self.is_train and layers.use_split_gemm(attention_output, rows, self.feature_size)
                 and ops.bn_dense_x3_ok(attention_output, self.feature_size)):

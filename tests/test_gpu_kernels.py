@@ -429,6 +429,37 @@ def test_mha_core_logits_bn(B, L, h, d, training, mha_precision):
         assert_close(mvg, mv.double() * 0.999 + upd["bn/moving_variance"] * 0.001, tol=1e-5, what="moving_var")
 
 
+@pytest.mark.parametrize("B,L,h,d,fmt", [(2, 300, 8, 16, "bf16x3"), (2, 300, 8, 16, "fp16"), (3, 40, 4, 8, "fp16"), (4, 12, 64, 16, "bf16x3"),
+                                         (2, 300, 8, 16, None)])
+def test_mha_logits_bn_backward_writes_the_qkv_gradient_image(B, L, h, d, fmt):
+    """logits_bn's one-pass backward with [dq | dk | dv] leaving as the q/k/v layer's gradient image (lpm_mha_bwd_x3_bn_image_fmt twice +
+    lpm_mha_bn_dk_correct_image; transformer_utils.py:652-661 in front of :559-561, backward): the image is, bit for bit, lpm_split_rows of the
+    plain entry points' fp32 gradients in the same operand format, and the recorded max |x| is the same number."""
+    from learnablepoolingmethods_amd import _capi, ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(7 * L + h)
+    F = h * d
+    qkv = (0.5 * torch.randn(B, L, 3 * F, generator=g)).to(dev)            # column views of one buffer, as the fused projection hands them over
+    q, k, v = qkv[..., :F], qkv[..., F:2 * F], qkv[..., 2 * F:]
+    do = (0.3 * torch.randn(B, L, F, generator=g)).to(dev)
+    gamma, beta = (1 + 0.2 * torch.randn(L, generator=g)).to(dev), (0.1 * torch.randn(L, generator=g)).to(dev)
+    mm, mv = torch.zeros(L, device=dev), torch.ones(L, device=dev)
+    ctx = ops._SubCtx()
+    ops._MHACoreBN.forward(ctx, q, k, v, gamma, beta, mm, mv, h, True)
+    plain = ops._MHACoreBN.backward(ctx, do)
+    dqkv = torch.cat([t.reshape(B * L, F) for t in plain[:3]], dim=1).contiguous()
+    amax_a = torch.zeros(_capi.LPM_OPERAND_AMAX_SUB * _capi.LPM_OPERAND_AMAX_STRIDE, device=dev)
+    amax_b = torch.zeros_like(amax_a)
+    mk = lambda amax: None if fmt is None else ops.OperandSite(fmt == "fp16", 2.0 ** 9, amax.data_ptr(), role="g")
+    want = ops._split_rows(dqkv, grad=True, site=mk(amax_a))
+    got = ops._MHACoreBN.backward(ctx, do, image=True, site=mk(amax_b))
+    assert got[1] is None and got[2] is None and got[0].dtype == want.dtype and tuple(got[0].shape) == tuple(want.shape)
+    assert torch.equal(got[0].view(torch.int16), want.view(torch.int16))
+    assert torch.equal(got[3], plain[3]) and torch.equal(got[4], plain[4])                 # dgamma, dbeta: the same statistics
+    if fmt is not None:
+        assert float(amax_b.max()) == float(amax_a.max()) == float(dqkv.abs().max())
+
+
 @pytest.mark.parametrize("B,MF,F,S", [(4, 30, 1024, 30), (3, 300, 1152, 300), (2, 300, 1152, 256), (5, 40, 128, 7)])
 def test_frame_sample_bn(B, MF, F, S):
     from learnablepoolingmethods_amd import model_utils, ops

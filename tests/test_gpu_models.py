@@ -542,6 +542,34 @@ def test_block_functions_and_descriptor_slots_do_not_change_the_step():
         assert rel_l2(other[3], res[0][3]) < 2e-5           # the inference-mode forward (no autograd) takes the same paths
 
 
+def test_logits_bn_attention_gradient_image_does_not_change_the_step():
+    """MultiHeadAttentionBN's q/k/v projections + logits_bn attention as one node whose backward writes [dq | dk | dv] as the projections'
+    operand image (ops._QKVAttnBNX3, round 6) against the two-node graph with the fp32 gradient and the operand-split pass: the image is
+    the split of the same fp32 numbers, so four steps -- two on split-bf16 operands, two on the fp16 planes with their recorded scales --
+    end in the same parameters bit for bit."""
+    from learnablepoolingmethods_amd import ops, registry
+    from learnablepoolingmethods_amd.train import Trainer
+    dev = cuda()
+    B, MF = 8, 150                      # 1 200 frame tokens: the encoders' dense layers take the split-GEMM path
+    x, nf, lab = O.make_synthetic_batch(B, MF, 1152, 50, seed=29, min_frames=100)
+    res = []
+    for image in (True, False, True):
+        flag0, ops.MHA_BN_GRAD_IMAGE = ops.MHA_BN_GRAD_IMAGE, image
+        torch.manual_seed(77)               # the encoders' dropout masks (rate 0.9) come from the global generator
+        try:
+            tr = Trainer(registry.get_model("NetVladV2"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=13,
+                         model_kwargs=dict(iterations=MF, cluster_size=32, hidden_size=64))
+            losses = [tr.step(x, nf, lab)["loss"].item() for _ in range(4)]
+            torch.cuda.synchronize()
+            res.append((losses, tr.arena.grad.clone(), tr.arena.param.clone()))
+        finally:
+            ops.MHA_BN_GRAD_IMAGE = flag0
+    assert all(l == l for l in res[0][0])
+    for other in res[1:]:
+        assert other[0] == res[0][0]
+        assert torch.equal(other[1], res[0][1]) and torch.equal(other[2], res[0][2])
+
+
 def test_input_bn_gradient_shortcut_matches_the_input_gradient_path():
     """NetVladV1 training never forms the [B*S, 1152] input gradient: input_bn's gamma / beta gradients come in closed form
     from K3's by-products (ops._NetVLAD.backward).  Against the explicit path (dx GEMMs + frame pass) on the same step, and
