@@ -835,6 +835,19 @@ int lpm_factored_clip_adam_q(const void* xt, const void* dyt, const float* x, in
 int lpm_factored_clip_adam_copy(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
                                 float* param, float* m, float* v, void* param_bf16, float clip_norm, float lr, float beta1, float beta2,
                                 float eps, int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream);
+/* ... and returning the projection's INPUT gradient with it (round 6): dx [R, N1] (row stride ld_dx) = DY W_old^T, formed inside the update
+ * pass from the weights it streams anyway instead of by lpm_proj_dx_w16 from 2 more bytes per weight.  dy_bf16 = DY [R, N2] rounded once to
+ * bf16, row-major, 16-byte aligned (dx too; ld_dx a multiple of 4); W_old enters by its bf16 rounding -- the compute copy's values, i.e. what the forward multiplied by:
+ * lpm_proj_dx_w16's arithmetic, one bf16 MFMA per product.  A workgroup owns 64 rows of the variable and ALL its columns, so the partial
+ * sums of a dx element meet in registers in a fixed order; the update itself is lpm_factored_clip_adam_copy's bit for bit.
+ * lpm_factored_fold_supported: R % 16 == 0, R <= 128, N1 % 64 == 0, N2 % 128 == 0; elsewhere LPM_ERR_UNSUPPORTED_SHAPE.
+ * The caller must not have read dx's consumers' input before this returns on `stream`: the call sits INSIDE the backward pass, at the
+ * projection (frame_level_models.py:2309-2319 backward + utils.py:170-189 + train.py:332-336 for this one variable). */
+int lpm_factored_fold_supported(int R, int N1, int N2);
+int lpm_factored_clip_adam_copy_dx(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
+                                   float* param, float* m, float* v, void* param_bf16, const void* dy_bf16, float* dx, int64_t ld_dx,
+                                   float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
+                                   size_t scratch_bytes, lpm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -170,6 +170,8 @@ SIGNATURES = {
     "lpm_factored_clip_adam_scratch_bytes": (_s, [_i, _i]),
     "lpm_factored_clip_adam_q": (_i, [_f, _f, _f, _l, _f, _i, _i, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
     "lpm_factored_clip_adam_copy": (_i, [_f, _f, _f, _l, _f, _i, _i, _i, _f, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
+    "lpm_factored_clip_adam_copy_dx": (_i, [_f, _f, _f, _l, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
+    "lpm_factored_fold_supported": (_i, [_i, _i, _i]),
     "lpm_factored_clip_adam": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
     "lpm_multi_tensor_clip_adam": (_i, [_f, _f, _f, _f, _f, _i, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _f]),
     "lpm_weight_pack": (_i, [_f, _i, _f]),

@@ -48,6 +48,9 @@ __device__ __forceinline__ float4 bn_preact(float4 v, const float* __restrict__ 
 
 // pass 1 of the BN backward: per-block column partials of dlt and dlt*Lhat.
 constexpr int BNB_ROWS = 64;
+// column chunks (gridDim.y) of the two statistics passes: one per 256 float4 column groups, at most 8; the per-block partial sums of a
+// column are the same numbers whichever workgroup forms them
+static inline unsigned bn_col_chunks(int C) { const int c = (C / 4 + 255) / 256; return (unsigned)(c < 1 ? 1 : (c > 8 ? 8 : c)); }
 // Threads are (row group, float4 column): 256 / (K/4) row groups when K/4 divides 256 (K = 256: four rows of 1 KB per
 // round), else one row group striding the columns; four rounds' loads are issued together.  (One thread per column walking
 // 64 rows with one 4-byte load in flight ran at 1.9 TB/s.)
@@ -62,7 +65,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const int tid = threadIdx.x, K4 = K >> 2;
     const int RG = (K4 < 256 && 256 % K4 == 0) ? 256 / K4 : 1;
     const int rg = RG > 1 ? tid / K4 : 0;
-    for (int c4 = RG > 1 ? tid % K4 : tid; c4 < K4; c4 += (RG > 1 ? K4 : 256)) {      // RG > 1: exactly one pass, every thread in it
+    // (gridDim.y column chunks: a [24000, 4096] tensor is 375 row blocks -- 1.5 rounds of the chip at one 4-wave workgroup per CU, each
+    // thread walking four column groups one after the other with 32 KB in flight per CU: 3.9 TB/s; as 375 x 4 workgroups 6 per CU)
+    for (int c4 = RG > 1 ? tid % K4 : tid + 256 * (int)blockIdx.y; c4 < K4; c4 += (RG > 1 ? K4 : 256 * (int)gridDim.y)) {      // RG > 1: exactly one pass, every thread in it
         const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);
         const float4 vr = *reinterpret_cast<const float4*>(var + 4 * c4);
         const float4 rs = make_float4(rsqrtf(vr.x + eps), rsqrtf(vr.y + eps), rsqrtf(vr.z + eps), rsqrtf(vr.w + eps));
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restr
     const int tid = threadIdx.x, C4 = C / 4;
     const int RG = (C4 < 256 && 256 % C4 == 0) ? 256 / C4 : 1;      // thread layout as in bn_bwd_partial_kernel
     const int rg = RG > 1 ? tid / C4 : 0;
-    for (int c4 = RG > 1 ? tid % C4 : tid; c4 < C4; c4 += (RG > 1 ? C4 : 256)) {
+    for (int c4 = RG > 1 ? tid % C4 : tid + 256 * (int)blockIdx.y; c4 < C4; c4 += (RG > 1 ? C4 : 256 * (int)gridDim.y)) {     // (column chunks: see bn_bwd_partial_kernel)
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
         auto add = [&](float4 v) {
             v = bn_preact(v, pb, 4 * c4, relu);
@@ -407,7 +412,7 @@ static int bn_rows_fwd_impl(const float* x, const float* pre_bias, int pre_relu,
     float* partial = (float*)workspace;
     float* scale = partial + (size_t)nblk * 2 * C;
     float* shift = scale + C;
-    hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(nblk), dim3(256), 0, s, x, M, C, partial, pre_bias, pre_relu);
+    hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(nblk, bn_col_chunks(C)), dim3(256), 0, s, x, M, C, partial, pre_bias, pre_relu);
     const double unbias = (biased_moving_variance || M <= 1) ? 1.0 : (double)M / (double)(M - 1);
     hipLaunchKernelGGL(bn_fold_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, s, partial, nblk, C, 1.0 / (double)M, unbias, gamma, beta, eps,
                        decay, mean, var, scale, shift, moving_mean, moving_var);
@@ -650,7 +655,7 @@ static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_b
     hipStream_t s = (hipStream_t)stream;
     const int nblk = (M + BNB_ROWS - 1) / BNB_ROWS;
     float* partial = (float*)workspace;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, dlt, logits, mean, var, eps, M, K, partial, pre_bias, pre_relu);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, bn_col_chunks(K)), dim3(256), 0, s, dlt, logits, mean, var, eps, M, K, partial, pre_bias, pre_relu);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((K + 15) / 16), dim3(1024), 0, s, partial, nblk, K, dgamma, dbeta);
     const int grid = bn_bwd_grid(M, K);
     float* dbpart = dbias ? partial + (size_t)nblk * 2 * K : nullptr;

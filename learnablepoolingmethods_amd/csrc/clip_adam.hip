@@ -93,13 +93,7 @@ __global__ __launch_bounds__(256) void ca_apply_kernel(float* __restrict__ p, co
                 mm = *reinterpret_cast<float4*>(m + e);
                 vv = *reinterpret_cast<float4*>(v + e);
             }
-#define LPM_ADAM1(c)                                             \
-    {                                                            \
-        const float gc = gg.c * f;                               \
-        mm.c = b1 * mm.c + (1.f - b1) * gc;                      \
-        vv.c = b2 * vv.c + (1.f - b2) * gc * gc;                 \
-        pp.c -= lr_t * mm.c / (sqrtf(vv.c) + eps);               \
-    }
+#define LPM_ADAM1(c) adam_element(gg.c * f, pp.c, mm.c, vv.c, lr_t, b1, b2, eps);
             LPM_ADAM1(x) LPM_ADAM1(y) LPM_ADAM1(z) LPM_ADAM1(w)
 #undef LPM_ADAM1
             if (nt) {

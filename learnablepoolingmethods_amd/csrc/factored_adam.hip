@@ -11,6 +11,7 @@
 // (split-bf16 operands, three MFMAs per product, fp32 accumulation: what lpm_skinny_weight_grad_tiles computes, bit for bit), the
 // update is clip_adam.hip's.  In data-parallel training the towers exchange X and DY tiles (86 MB per tower at cfg-2, all-gather)
 // instead of all-reducing the 554 MB gradient.
+#include <type_traits>
 #include "tile_gemm.h"
 
 namespace lpm {
@@ -221,15 +222,196 @@ __global__ __launch_bounds__(256, 2) void fa_update_rows_kernel(const uint4* __r
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float gc = acc[c][r] * fac;
-            const float mn = b1 * ma[c][r] + (1.f - b1) * gc;
-            const float vn = b2 * va[c][r] + (1.f - b2) * gc * gc;
-            const float pn = pa[c][r] - lr_t * mn / (sqrtf(vn) + eps);
+            float pn = pa[c][r], mn = ma[c][r], vn = va[c][r];
+            adam_element(acc[c][r] * fac, pn, mn, vn, lr_t, b1, b2, eps);
             const int64_t o = (row0 + (r & 3) + 8 * (r >> 2)) * N2 + (ct0 + c) * 32;
             __builtin_nontemporal_store(pn, reinterpret_cast<float*>(reinterpret_cast<char*>(param + o) + voff));
             __builtin_nontemporal_store(mn, reinterpret_cast<float*>(reinterpret_cast<char*>(mom + o) + voff));
             __builtin_nontemporal_store(vn, reinterpret_cast<float*>(reinterpret_cast<char*>(var + o) + voff));
         }
+}
+
+
+// Update pass, third form (round 6; VERDICT r3-r5: "the projection's input gradient folded into the update pass"): the variable keeps a
+// bf16 compute copy (BASELINE configs[4]), and the projection's input gradient dX = DY W_old^T reads exactly the weights this pass
+// streams anyway -- 1.1 GB of copy that lpm_proj_dx_w16 read once more per step.  A workgroup owns 64 rows x ALL N2 columns and walks
+// the row block's 128-column pieces, so that the partial dX [R, 64] of the pieces meet in its registers in a fixed order (the tile-GEMM
+// form's eight column blocks of a row block are eight workgroups: their partial sums would have to meet in HBM).  Per piece:
+//   G = X^T DY of the 64 x 128 tile: the row block's X tiles sit in LDS for the workgroup's whole life (HBM / L2 once, not once per
+//       column block), wave w's DY fragments come straight from L2 into registers; three MFMAs per product in the tile GEMM's order:
+//       the gradient element is the tile GEMM's bit for bit;
+//   through LDS into the row-contiguous mapping of the param / m / v pieces requested one piece ahead (16-byte non-temporal accesses),
+//       clip factor, TF-Adam (clip_adam.hip's arithmetic), the new weight's bf16 copy;
+//   bf16(W_old) of the tile -- the values the forward multiplied by -- into LDS [64][128] (over the gradient's staging tile), and
+//       dX[b-tile w][64 rows] += DY16[b-tile w][128 columns] . W16^T: A = 16-byte pieces of the bf16 DY rows from L2, B = 16-byte row
+//       pieces of the LDS tile, one MFMA per product (lpm_proj_dx_w16's arithmetic: both operands rounded once to bf16).
+// Needs N1 % 64 == 0, N2 % 128 == 0, R % 16 == 0, R <= 128.  256 threads, 4 KB x R / 16 + 33 KB of LDS, two workgroups per CU.
+constexpr int FF_ES = 132;            // floats between the rows of the gradient's staging tile
+constexpr int FF_WS = 136;            // bf16 elements between the rows of the old weight's tile (272 bytes: fragments stay 16-byte aligned)
+template <bool DX>
+__global__ __launch_bounds__(256, 2) void fa_update_fold_kernel(const uint4* __restrict__ xt, const uint4* __restrict__ dyt, int RS, int N1, int N2,
+                                                                 int NT1, int NT2, float* __restrict__ param, float* __restrict__ mom,
+                                                                 float* __restrict__ var, unsigned short* __restrict__ p16,
+                                                                 const float* __restrict__ factor, float lr_t, float b1, float b2, float eps,
+                                                                 const unsigned short* __restrict__ dy16, int R, float* __restrict__ dx, int64_t ldx,
+                                                                 int dbg) {
+    // dbg (tools/time_factored_fold.py, LPM_FA_FOLD_DBG; results are garbage): 4 no dX stores, 16 no gradient GEMM
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tg_u32x4* sA = reinterpret_cast<tg_u32x4*>(smem);                      // [row tile][step][plane][lane]
+    float* es = reinterpret_cast<float*>(smem + (size_t)RS * 4096);        // [64][FF_ES] fp32; then, over it, [64][FF_WS] bf16
+    unsigned short* ws = reinterpret_cast<unsigned short*>(es);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int rb = blockIdx.x;
+    const int tcol = (tid & 31) * 4, trow = tid >> 5;                      // this thread's four columns of a piece; rows trow + 8 j
+    const int NCB = N2 / 128;
+    for (int p = wave; p < 4 * RS; p += 4) {
+        const int m = p / (2 * RS), rem = p - m * 2 * RS;
+        const uint4 t = xt[((int64_t)(rem >> 1) * NT1 + rb * 2 + m) * 128 + (rem & 1) * 64 + lane];
+        sA[p * 64 + lane] = tg_u32x4{t.x, t.y, t.z, t.w};
+    }
+    f32x4 pa[8], ma[8], va[8];
+    // (a uniform base per piece and row group + ONE per-lane offset, as fa_update_rows_kernel: scalar address arithmetic, one register)
+    const unsigned voff = (unsigned)(trow * N2 + tcol) * 4u;
+    auto load_pmv = [&](int cb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t o = ((int64_t)rb * 64 + 8 * j) * N2 + cb * 128;
+            pa[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(param + o) + voff));
+            ma[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(mom + o) + voff));
+            va[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(var + o) + voff));
+        }
+    };
+    load_pmv(0);
+    f32x16 dxacc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dxacc[n][r] = 0.f;
+    const float fac = *factor;
+    const bool dxw = DX && wave * 32 < R;                                  // this wave owns a tile of clips (wave-uniform)
+    const int brow = min(wave * 32 + l31, R - 1);                          // (rows past the end: the last row again, masked at the store)
+    __syncthreads();
+    // One piece.  LAST (compile time): no further piece to request -- the loop body is straight-line code, so that the compiler's count of
+    // outstanding loads in front of each wait is exact: waits placed at the join behind a conditional load are the conservative ones, and
+    // three builds of this kernel that differed in nothing else ran 2.69 / 2.89 / 3.21 ms.  Waves without a tile of clips (R < 128)
+    // run the dX part on the last row again and store nothing.
+    auto piece = [&](const int cb, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        // ---- G = X^T DY of the piece: wave w = column tile cb * 4 + w, both row tiles --------------------------------------------
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        const uint4* bp = dyt + (int64_t)(cb * 4 + wave) * 128 + lane;     // + s * NT2 * 128; plane: + 64
+        struct Frag { uint4 bh, bl; };
+        auto load = [&](int s, Frag& f) {
+            const uint4* b = bp + (int64_t)s * NT2 * 128;
+            f.bh = b[0];
+            f.bl = b[64];
+        };
+        auto mac = [&](int s, const Frag& f) {
+            const tg_u32x4 bh = {f.bh.x, f.bh.y, f.bh.z, f.bh.w}, bl = {f.bl.x, f.bl.y, f.bl.z, f.bl.w};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const tg_u32x4 ah = sA[((m * RS + s) * 2 + 0) * 64 + lane], al = sA[((m * RS + s) * 2 + 1) * 64 + lane];
+                acc[m] = tg_mfma(ah, bh, acc[m]);
+                acc[m] = tg_mfma(ah, bl, acc[m]);
+                acc[m] = tg_mfma(al, bh, acc[m]);
+            }
+        };
+        Frag fa, fb;
+        const int RSd = (dbg & 16) ? 0 : RS;
+        if (RSd > 0) load(0, fa);
+        for (int s = 0; s < RSd; s += 2) {
+            if (s + 1 < RSd) load(s + 1, fb);
+            mac(s, fa);
+            if (s + 1 < RSd) {
+                if (s + 2 < RSd) load(s + 2, fa);
+                mac(s + 1, fb);
+            }
+        }
+        // ---- through LDS into the row-contiguous mapping; clip factor, TF-Adam, stores ----------------------------------------------
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) es[(m * 32 + mfma32_row(r, lane)) * FF_ES + wave * 32 + l31] = acc[m][r];
+        __syncthreads();
+        uint2 w16[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 gg = *reinterpret_cast<const float4*>(es + (trow + 8 * j) * FF_ES + tcol);
+            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+            const int64_t o = ((int64_t)rb * 64 + 8 * j) * N2 + cb * 128;
+            f32x4 pn, mn, vn;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float pe = pa[j][q], me = ma[j][q], ve = va[j][q];
+                adam_element(gv[q] * fac, pe, me, ve, lr_t, b1, b2, eps);
+                pn[q] = pe; mn[q] = me; vn[q] = ve;
+            }
+            __builtin_nontemporal_store(pn, reinterpret_cast<f32x4*>(reinterpret_cast<char*>(param + o) + voff));
+            __builtin_nontemporal_store(mn, reinterpret_cast<f32x4*>(reinterpret_cast<char*>(mom + o) + voff));
+            __builtin_nontemporal_store(vn, reinterpret_cast<f32x4*>(reinterpret_cast<char*>(var + o) + voff));
+            const of_f2 p01 = {pn[0], pn[1]}, p23 = {pn[2], pn[3]};
+            uint2 w;
+            w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(p01, of_b2));
+            w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(p23, of_b2));
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p16 + o) + (voff >> 1)) = w;
+            if (DX) {                                   // the weight the forward multiplied by: bf16 of the OLD master
+                const of_f2 o01 = {pa[j][0], pa[j][1]}, o23 = {pa[j][2], pa[j][3]};
+                w16[j].x = __builtin_bit_cast(unsigned, __builtin_convertvector(o01, of_b2));
+                w16[j].y = __builtin_bit_cast(unsigned, __builtin_convertvector(o23, of_b2));
+            }
+        }
+        if (!DX) {
+            if (!LAST) load_pmv(cb + 1);
+            __syncthreads();                            // the staging tile is free for the next piece
+            return;
+        }
+        // ---- dX += DY16 . W16^T over the piece's 128 columns ------------------------------------------------------------------------
+        tg_u32x4 da[8];                                 // requested BEFORE the next piece's param / m / v: loads return in order
+        {
+            const unsigned short* dyp = dy16 + (int64_t)brow * N2 + cb * 128 + half * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) da[ks] = *reinterpret_cast<const tg_u32x4*>(dyp + ks * 16);
+        }
+        if (!LAST) load_pmv(cb + 1);
+        __syncthreads();                                // everybody has read its gradient values: the tile takes the old weights
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<uint2*>(ws + (trow + 8 * j) * FF_WS + tcol) = w16[j];
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const tg_u32x4 wb = *reinterpret_cast<const tg_u32x4*>(ws + (n * 32 + l31) * FF_WS + ks * 16 + half * 8);
+                dxacc[n] = tg_mfma(da[ks], wb, dxacc[n]);
+            }
+        __syncthreads();                                // the fragment reads are done: the next piece's gradient may land
+    };
+    for (int cb = 0; cb + 1 < NCB; ++cb) piece(cb, std::false_type{});
+    piece(NCB - 1, std::true_type{});
+    if (DX && !(dbg & 4)) {
+        // dX [R, 64] of the row block: through the staging tile (free behind the last piece's barrier) as [clip][64 rows], so that it leaves
+        // as 16-byte stores, sixteen lanes to a clip's 256 bytes (the accumulators hold one row per lane: 4-byte stores, 77 us of them)
+        float* dt = es;
+        if (dxw) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dt[(wave * 32 + mfma32_row(r, lane)) * 64 + n * 32 + l31] = dxacc[n][r];
+        }
+        __syncthreads();
+        const int c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int b = ps * 16 + (tid >> 4);
+            if (b < R) *reinterpret_cast<float4*>(dx + (int64_t)b * ldx + (int64_t)rb * 64 + c4) = *reinterpret_cast<const float4*>(dt + b * 64 + c4);
+        }
+    }
 }
 
 }  // namespace lpm
@@ -240,7 +422,8 @@ extern "C" size_t lpm_factored_clip_adam_scratch_bytes(int N1, int N2) {
 
 static int factored_clip_adam_impl(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
                                    float* param, float* m, float* v, float clip_norm, float lr, float beta1, float beta2, float eps,
-                                   int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream, void* param_bf16 = nullptr);
+                                   int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream, void* param_bf16 = nullptr,
+                                   const void* dy_bf16 = nullptr, float* dx = nullptr, int64_t ld_dx = 0);
 // ... keeping a bf16 compute copy of the weight beside its fp32 master (SURVEY section 7 hard part 2; BASELINE configs[4]): param_bf16
 // [N1, N2] receives bf16(param) from the update pass's epilogue -- the copy the projection's forward and input-gradient passes read
 // (lpm_proj_fwd_parts_w16, lpm_proj_dx_w16) instead of streaming the fp32 weight twice more.  x / gdt NULL: the norm from a GEMM pass
@@ -254,6 +437,25 @@ extern "C" int lpm_factored_clip_adam_copy(const void* xt, const void* dyt, cons
                 "lpm_factored_clip_adam_copy: x and the tiles of DY DY^T come together (row stride >= N1, R <= 128)");
     return factored_clip_adam_impl(xt, dyt, x, ldx, gdt, R, N1, N2, param, m, v, clip_norm, lr, beta1, beta2, eps, step, scratch, scratch_bytes,
                                    stream, param_bf16);
+}
+// lpm_factored_clip_adam_copy that also returns the projection's INPUT gradient dx [R, N1] (row stride ld_dx) = DY W_old^T, formed from the
+// weights the update pass streams anyway (fa_update_fold_kernel): dy_bf16 = DY [R, N2] rounded once to bf16 (row-major), W_old by its
+// bf16 rounding -- the compute copy's values, lpm_proj_dx_w16's arithmetic.  lpm_factored_fold_supported says where it applies.
+extern "C" int lpm_factored_fold_supported(int R, int N1, int N2) {
+    return (R > 0 && R % 16 == 0 && R <= 128 && N1 > 0 && N1 % 64 == 0 && N2 > 0 && N2 % 128 == 0) ? 1 : 0;
+}
+extern "C" int lpm_factored_clip_adam_copy_dx(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
+                                              float* param, float* m, float* v, void* param_bf16, const void* dy_bf16, float* dx, int64_t ld_dx,
+                                              float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
+                                              size_t scratch_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(param_bf16 && ((uintptr_t)param_bf16 & 7) == 0, LPM_ERR_BADARG, "lpm_factored_clip_adam_copy_dx: the copy must be 8-byte aligned");
+    LPM_REQUIRE((x == nullptr) == (gdt == nullptr) && (!x || (ldx >= N1 && R <= 128)), LPM_ERR_BADARG,
+                "lpm_factored_clip_adam_copy_dx: x and the tiles of DY DY^T come together (row stride >= N1, R <= 128)");
+    LPM_REQUIRE(dy_bf16 && dx && ld_dx >= N1 && ld_dx % 4 == 0 && (((uintptr_t)dy_bf16 | (uintptr_t)dx) & 15) == 0, LPM_ERR_BADARG,
+                "lpm_factored_clip_adam_copy_dx: needs the bf16 DY and dx 16-byte aligned, dx with a row stride >= N1 and a multiple of 4");
+    return factored_clip_adam_impl(xt, dyt, x, ldx, gdt, R, N1, N2, param, m, v, clip_norm, lr, beta1, beta2, eps, step, scratch, scratch_bytes,
+                                   stream, param_bf16, dy_bf16, dx, ld_dx);
 }
 extern "C" int lpm_factored_clip_adam(const void* xt, const void* dyt, int R, int N1, int N2, float* param, float* m, float* v,
                                       float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
@@ -272,7 +474,8 @@ extern "C" int lpm_factored_clip_adam_q(const void* xt, const void* dyt, const f
 }
 static int factored_clip_adam_impl(const void* xt, const void* dyt, const float* x, int64_t ldx, const void* gdt, int R, int N1, int N2,
                                    float* param, float* m, float* v, float clip_norm, float lr, float beta1, float beta2, float eps,
-                                   int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream, void* param_bf16) {
+                                   int64_t step, float* scratch, size_t scratch_bytes, lpm_stream_t stream, void* param_bf16,
+                                   const void* dy_bf16, float* dx, int64_t ld_dx) {
     using namespace lpm;
     LPM_REQUIRE(xt && dyt && param && m && v && scratch, LPM_ERR_BADARG, "lpm_factored_clip_adam: null pointer");
     LPM_REQUIRE(R > 0 && R % 16 == 0 && N1 > 0 && N2 > 0 && N2 % 32 == 0 && step >= 1, LPM_ERR_UNSUPPORTED_SHAPE,
@@ -326,6 +529,28 @@ static int factored_clip_adam_impl(const void* xt, const void* dyt, const float*
         hipLaunchKernelGGL(fa_update_rows_kernel, dim3((unsigned)(NT1 * (N2 / 256))), dim3(256), 0, s, (const uint4*)xt, (const uint4*)dyt,
                            g.total_steps, N1, N2, NT1, NT2, N2 / 256, param, m, v, (const float*)factor, (float)lr_t, beta1, beta2, eps);
         return check_launch("lpm_factored_clip_adam (update pass, rows)");
+    }
+    // the row-block form (fa_update_fold_kernel): always when the projection's input gradient rides along; without it only on request
+    // (LPM_FA_FOLD=2: A/B of the two streaming patterns; 0: never -- then a dx request is an error)
+    static const int fold = [] { const char* e = getenv("LPM_FA_FOLD"); return e ? atoi(e) : 1; }();
+    const bool fold_ok = param_bf16 && lpm_factored_fold_supported(R, N1, N2) && fold != 0;
+    if (dx && !fold_ok) {
+        set_error("lpm_factored_clip_adam_copy_dx: needs the compute copy, N1 %% 64 == 0, N2 %% 128 == 0, R %% 16 == 0 and R <= 128 (R=%d N1=%d N2=%d)", R, N1, N2);
+        return LPM_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (fold_ok && (dx || fold == 2)) {
+        const int RS = R / 16;
+        static const int fdbg = [] { const char* e = getenv("LPM_FA_FOLD_DBG"); return e ? atoi(e) : 0; }();
+        const size_t lds = (size_t)RS * 4096 + (size_t)64 * FF_ES * sizeof(float);
+        auto kern = dx ? fa_update_fold_kernel<true> : fa_update_fold_kernel<false>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("lpm_factored_clip_adam (update pass, row blocks): cannot reserve %zu bytes of LDS", lds);
+            return LPM_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(N1 / 64)), dim3(256), lds, s, (const uint4*)xt, (const uint4*)dyt, RS, N1, N2, NT1, NT2, param, m, v,
+                           (unsigned short*)param_bf16, (const float*)factor, (float)lr_t, beta1, beta2, eps, (const unsigned short*)dy_bf16, R, dx, ld_dx, fdbg);
+        return check_launch("lpm_factored_clip_adam (update pass, row blocks)");
     }
     g.adam_p = param; g.adam_m = m; g.adam_v = v; g.adam_factor = factor; g.adam_p16 = (unsigned short*)param_bf16;
     g.adam_lr_t = (float)lr_t; g.adam_b1 = beta1; g.adam_b2 = beta2; g.adam_eps = eps;

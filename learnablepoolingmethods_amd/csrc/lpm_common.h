@@ -156,6 +156,18 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// TF-Adam on one element given its CLIPPED gradient gc (train.py:332-336 -> tf.train.AdamOptimizer: m, v, then the step with both bias
+// corrections folded into lr_t).  Every product and sum is rounded on its own -- no fused multiply-add: WHICH product of
+// "b1 m + (1 - b1) g" the compiler fuses differed between two kernels holding the same source line (round 6: the row-block update pass
+// against the tile-GEMM form -- one ulp of m in a quarter of the elements) -- so that every update kernel of the library (clip_adam.hip,
+// tile_gemm.hip's Adam epilogue, factored_adam.hip's two other forms) writes the same bits for the same inputs.
+__device__ __forceinline__ void adam_element(float gc, float& p, float& m, float& v, float lr_t, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    m = b1 * m + (1.f - b1) * gc;
+    v = b2 * v + (1.f - b2) * gc * gc;
+    p = p - lr_t * m / (sqrtf(v) + eps);
+}
+
 // XCD-aware block remap: hardware places consecutive block ids round-robin over the 8 XCDs
 // (speed only, never correctness).  Returns a logical id such that logical ids
 // [g*per, (g+1)*per) of one group land on the same XCD when nblk % 8 == 0 handling is

@@ -555,10 +555,9 @@ __global__ __launch_bounds__(256 * MW, (MW == 2 && NS == 3 && FORM == 0) ? 4 : 2
                     f32x4 pn, mn, vn;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float gc = gv[q] * fac;
-                        mn[q] = g.adam_b1 * ma[j][q] + (1.f - g.adam_b1) * gc;
-                        vn[q] = g.adam_b2 * va[j][q] + (1.f - g.adam_b2) * gc * gc;
-                        pn[q] = pa[j][q] - g.adam_lr_t * mn[q] / (sqrtf(vn[q]) + g.adam_eps);
+                        float pe = pa[j][q], me = ma[j][q], ve = va[j][q];
+                        adam_element(gv[q] * fac, pe, me, ve, g.adam_lr_t, g.adam_b1, g.adam_b2, g.adam_eps);
+                        pn[q] = pe; mn[q] = me; vn[q] = ve;
                     }
                     __builtin_nontemporal_store(pn, reinterpret_cast<f32x4*>(g.adam_p + o));
                     __builtin_nontemporal_store(mn, reinterpret_cast<f32x4*>(g.adam_m + o));

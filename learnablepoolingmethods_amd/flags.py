@@ -93,6 +93,13 @@ FLAGS.define("hidden1_update_stream", "auto", "build extension, with hidden1_ear
              "kernels) 5.495 -> 5.351 ms; cfg-2 (the rest is the encoders' power-limited GEMMs, which the extra HBM traffic slows) 6.64 -> "
              "6.70 ms.  'auto': on for netvlad_storage='bf16' (the configuration whose update pass is half the step), off otherwise; "
              "True / False force it")
+FLAGS.define("hidden1_fold_input_gradient", False, "build extension, one tower with hidden1_early_update and the bf16 compute copy: the projection's "
+             "INPUT gradient dx = dy W^T is formed inside hidden1_weights' update pass, from the weights that pass streams anyway "
+             "(lpm_factored_clip_adam_copy_dx: VERDICT r3-r5), instead of by lpm_proj_dx_w16 from 2 more bytes per weight; the update then runs "
+             "on the main stream (the rest of backward waits for dx) whatever hidden1_update_stream says.  Built and measured in round 6, NOT the "
+             "default: the pass saves 60-165 us of the two kernels' 2.8 ms box to box and gives up the update stream's overlap with the rest of "
+             "backward (~0.14 ms) -- cfg-5 5.431 -> 5.339 ms on one box, 5.275 -> 5.33 ms on another (profiles/r06_update_pass_fold.md).  "
+             "LPM_FOLD_DX=0/1 overrides")
 FLAGS.define("direct_weight_gradients", True, "build extension: single-GPU training writes the encoders' dense-kernel gradients straight "
              "into the gradient arena from their producers (ops._dw_x3) instead of through autograd's .grad + a gather copy")
 FLAGS.define("hidden1_factored_max_towers", 4, "build extension: ... up to this many towers.  Both passes of the factored update multiply "

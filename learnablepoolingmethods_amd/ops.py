@@ -2172,7 +2172,25 @@ class _ProjectionParts(torch.autograd.Function):
         dy = dy.contiguous()
         st = stream_ptr()
         dx1 = dx2 = None
-        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[4]):
+        want_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[4])
+        factored = getattr(W, "_lpm_factored", None)
+        # the input gradient from INSIDE the weight's update pass (FLAGS.hidden1_fold_input_gradient): the trainer offered it for this step
+        # (``fold_dx``), the forward read the compute copy, the shape fits -- then the factors are handed over first and dx comes back
+        fold = (want_dx and ctx.needs_input_grad[5] and factored is not None and factored.armed and not factored.puts
+                and getattr(factored, "fold_dx", False) and getattr(ctx, "w16", None) is not None and M % 16 == 0
+                and bool(lib._lpm_factored_fold_supported(M, Kd, N)))
+        if fold:
+            dx = _empty((M, Kd), W)
+            factored.dx_out = dx
+            xt = _tile_buffer(lib._lpm_weight_tiles_bytes(M, Kd), x1)
+            lib.check(lib._lpm_split_weight_tiles_parts(ptr(x1), x1.stride(0), n1a, int(x1.dtype == torch.bfloat16), ptr(scale), ctx.ks, ptr(x2),
+                                                        x2.stride(0) if x2 is not None else 0, M, Kd, ptr(xt), st), "lpm_split_weight_tiles_parts")
+            factored.put_tiles(xt, dy, M, Kd)                     # -> Trainer._factored_put: clip + Adam + dx in one pass over the weight
+            factored.dx_out = None
+            if factored.dx_done:
+                return dx[:, :n1a], None, None, None, (dx[:, n1a:] if x2 is not None else None), None
+            want_dx, dx = True, None                             # (the trainer did not run the update now: dx by its own pass below)
+        if want_dx:
             if N >= PROJ_DX_STREAM_MIN_N:
                 dyt = _tile_buffer(lib._lpm_row_tiles_bytes(1, M, N), dy)
                 lib.check(lib._lpm_split_rows_tiles(ptr(dy), N, 1, M, N, ptr(dyt), st), "lpm_split_rows_tiles")
@@ -2196,7 +2214,8 @@ class _ProjectionParts(torch.autograd.Function):
             return xt
 
         skinny = M % 16 == 0 and N % 32 == 0
-        factored = getattr(W, "_lpm_factored", None)
+        if fold:                                                 # (the factors are with the trainer already; only dx was missing)
+            return dx1, None, None, None, dx2, None
         if factored is not None and factored.armed and factored.strict and not (skinny and not factored.puts):
             raise LpmError("hidden projection backward: the towers agreed on the factored gradient route at build time, but this rank's "
                            "step does not fit it (clips not a multiple of 16, or the weight used twice)")
@@ -3220,6 +3239,8 @@ class FactoredGradient:
 
     def clear(self):
         self.early_done = False           # the trainer's early update consumed this step's product inside backward (Trainer._factored_put)
+        self.dx_out = None                # ops._ProjectionParts.backward: "form my input gradient here if the update runs now" ...
+        self.dx_done = False              # ... and the trainer's answer (Trainer._factored_put)
         self.xt = self.dyt = None
         self.x = self.dy = None           # the fp32 factors themselves (this rank's; None once tiles of several towers were gathered)
         self.R = self.N1 = self.N2 = 0
@@ -3271,12 +3292,20 @@ class FactoredGradient:
                   "lpm_skinny_weight_grad_tiles")
         return out
 
-    def clip_adam(self, param, m, v, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, scratch=None, param_bf16=None):
+    def fold_supported(self):
+        """Whether the update pass can return the projection's input gradient for the operands held (lpm_factored_fold_supported)."""
+        return bool(self.pending and self.dy is not None and _capi.load()._lpm_factored_fold_supported(self.R, self.N1, self.N2))
+
+    def clip_adam(self, param, m, v, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, scratch=None, param_bf16=None, dx=None):
         """param / m / v: the variable's [N1 * N2] slices of the arenas.  -> scratch (its last four floats: clip factor, norm, -, -).
-        param_bf16: the variable's bf16 compute copy (ComputeCopy.buf), rewritten from the update pass's epilogue."""
+        param_bf16: the variable's bf16 compute copy (ComputeCopy.buf), rewritten from the update pass's epilogue.
+        dx [R, N1] (with param_bf16; ``fold_supported``): receives the projection's INPUT gradient DY W_old^T, formed inside the update
+        pass from the weights it streams (lpm_factored_clip_adam_copy_dx) -- the caller is the projection's backward itself."""
         lib = _capi.load()
+        if dx is not None and param_bf16 is None:
+            raise LpmError("FactoredGradient.clip_adam: the input gradient rides in the update pass of a variable with a compute copy only")
         if param_bf16 is not None:
-            return self._clip_adam_copy(lib, param, m, v, param_bf16, clip_norm, lr, step, beta1, beta2, eps, scratch)
+            return self._clip_adam_copy(lib, param, m, v, param_bf16, clip_norm, lr, step, beta1, beta2, eps, scratch, dx)
         nb = lib._lpm_factored_clip_adam_scratch_bytes(self.N1, self.N2)
         if scratch is None or scratch.numel() * 4 < nb:
             scratch = torch.empty(nb // 4, dtype=torch.float32, device=param.device)
@@ -3309,7 +3338,7 @@ class FactoredGradient:
         return scratch
 
 
-def _factored_clip_adam_copy(self, lib, param, m, v, param_bf16, clip_norm, lr, step, beta1, beta2, eps, scratch):
+def _factored_clip_adam_copy(self, lib, param, m, v, param_bf16, clip_norm, lr, step, beta1, beta2, eps, scratch, dx=None):
     nb = lib._lpm_factored_clip_adam_scratch_bytes(self.N1, self.N2)
     if scratch is None or scratch.numel() * 4 < nb:
         scratch = torch.empty(nb // 4, dtype=torch.float32, device=param.device)
@@ -3326,6 +3355,15 @@ def _factored_clip_adam_copy(self, lib, param, m, v, param_bf16, clip_norm, lr, 
             gdt = _tile_buffer(lib._lpm_row_tiles_bytes(1, self.R, self.R), G)
             lib.check(lib._lpm_split_rows_tiles(ptr(G), self.R, 1, self.R, self.R, ptr(gdt), stream_ptr()), "lpm_split_rows_tiles")
             x, ldx = (self.xt, self.N1) if tiles_only else (self.x, self.x.stride(0))
+        if dx is not None:
+            if self.dy is None or tuple(dx.shape) != (self.R, self.N1) or dx.dtype != torch.float32 or dx.stride(1) != 1:
+                raise LpmError("FactoredGradient.clip_adam: dx must be an fp32 [R, N1] matrix and this rank's DY must be at hand")
+            dy16 = self.dy.to(torch.bfloat16).contiguous()               # round to nearest even: the hi plane of DY's split
+            lib.check(lib._lpm_factored_clip_adam_copy_dx(ptr(self.xt), ptr(self.dyt), ptr(x), ldx or 0, ptr(gdt), self.R, self.N1, self.N2,
+                                                          ptr(param), ptr(m), ptr(v), ptr(param_bf16), ptr(dy16), ptr(dx), dx.stride(0),
+                                                          float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch), nb,
+                                                          stream_ptr()), "lpm_factored_clip_adam_copy_dx")
+            return scratch
         lib.check(lib._lpm_factored_clip_adam_copy(ptr(self.xt), ptr(self.dyt), ptr(x), ldx or 0, ptr(gdt), self.R, self.N1, self.N2,
                                                    ptr(param), ptr(m), ptr(v), ptr(param_bf16), float(clip_norm), float(lr), beta1, beta2, eps,
                                                    int(step), ptr(scratch), nb, stream_ptr()), "lpm_factored_clip_adam_copy")

@@ -709,6 +709,7 @@ class Trainer:
         if fg is not None:
             fg.clear()
             fg.armed = True
+            fg.fold_dx = False
         # One tower: hidden1_weights is updated INSIDE backward, right behind the projection's input gradient -- its clip is per
         # variable (utils.py:181-188) and needs only the two factors the projection's backward has just handed over, and nothing reads
         # the old weight after dx.  The 0.58 ms update pass then fills the stretch in which the host is still enqueueing the ~80 small
@@ -717,6 +718,10 @@ class Trainer:
         if fg is not None and not self.sync.active and FLAGS.hidden1_early_update:
             lr0 = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers, self.lr_decay_examples, self.lr_decay)
             self._early = {"lr": lr0, "step": self.global_step + 1, "done": False}
+            fold = FLAGS.hidden1_fold_input_gradient
+            if os.environ.get("LPM_FOLD_DX") in ("0", "1"):                # A/B
+                fold = os.environ["LPM_FOLD_DX"] == "1"
+            fg.fold_dx = bool(fold and self.w16 is not None)               # (offered; the projection's backward takes it if the shape fits)
         try:
             final_loss.backward()                                                               # :322-323
         finally:
@@ -877,10 +882,21 @@ class Trainer:
                 want = (FLAGS.netvlad_storage == "bf16") if want == "auto" else bool(want)
                 if os.environ.get("LPM_UPDATE_STREAM") in ("0", "1"):          # A/B
                     want = os.environ["LPM_UPDATE_STREAM"] == "1"
-                us = self._update_stream_for(fg) if want else None
-                with (torch.cuda.stream(us) if us is not None else contextlib.nullcontext()):
+                w16 = self._w16_current()
+                if fg.dx_out is not None:
+                    # the projection's backward handed the factors over BEFORE forming its input gradient: dx rides in this pass, on the
+                    # stream backward runs on -- or, should the pass not apply after all, nothing runs now: the projection then reads
+                    # the old copy for dx first and the update follows backward (an update here would rewrite the copy under it)
+                    if w16 is None or not fg.fold_supported():
+                        return
                     self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, early["lr"], early["step"],
-                                                          scratch=self._factored_scratch, param_bf16=self._w16_current())   # :332-336, early
+                                                          scratch=self._factored_scratch, param_bf16=w16, dx=fg.dx_out)      # :332-336, early
+                    fg.dx_done = True
+                else:
+                    us = self._update_stream_for(fg) if want else None
+                    with (torch.cuda.stream(us) if us is not None else contextlib.nullcontext()):
+                        self._factored_scratch = fg.clip_adam(a.param[:k], a.m[:k], a.v[:k], self.clip, early["lr"], early["step"],
+                                                              scratch=self._factored_scratch, param_bf16=w16)   # :332-336, early
                 early["done"] = True
                 fg.early_done = True          # a second use of the weight in this backward must raise (ops._Projection.backward)
             return

@@ -1304,6 +1304,42 @@ def test_factored_update_keeps_the_bf16_compute_copy():
         assert not torch.equal(p_b, p0)
 
 
+@pytest.mark.parametrize("R,N1,N2", [(128, 4096 + 64, 1024), (80, 512, 256), (32, 192, 128), (16, 64, 384)])
+def test_factored_update_returns_the_projection_input_gradient(R, N1, N2, monkeypatch):
+    """lpm_factored_clip_adam_copy_dx (round 6): the update pass of the variable with a bf16 compute copy also returns the projection's
+    input gradient dx = DY W_old^T (frame_level_models.py:2314-2319, backward) from the weights it streams.  The update is
+    lpm_factored_clip_adam_copy's bit for bit (master, moments, copy); dx is the product of the two operands rounded once to bf16 --
+    lpm_proj_dx_w16's arithmetic -- to fp32 summation order, and within 2e-3 of the fp64 product of the unrounded operands."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(R + N2)
+    x = (torch.randn(R, N1, generator=g) / N1 ** 0.5).to(dev)
+    dy = torch.randn(R, N2, generator=g).to(dev)
+    p0 = (torch.randn(N1 * N2, generator=g) / 30).to(dev)
+    m0, v0 = (torch.randn(N1 * N2, generator=g) * 1e-3).to(dev), (torch.rand(N1 * N2, generator=g) * 1e-5).to(dev)
+    res = []
+    for fold in (False, True):
+        fg = ops.FactoredGradient()
+        fg.put(x, dy)
+        assert fg.fold_supported()
+        p, m, v = p0.clone(), m0.clone(), v0.clone()
+        c16 = p0.view(N1, N2).to(torch.bfloat16).contiguous()
+        dx = torch.full((R, N1), float("nan"), device=dev) if fold else None
+        fg.clip_adam(p, m, v, 1.0, 2e-4, 3, param_bf16=c16, dx=dx)
+        res.append((p, m, v, c16, dx))
+    (p_a, m_a, v_a, c_a, _), (p_b, m_b, v_b, c_b, dx) = res
+    assert torch.equal(p_a, p_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b) and torch.equal(c_a, c_b), "the fold changed the update"
+    assert not torch.equal(p_b, p0)
+    w16 = p0.view(N1, N2).to(torch.bfloat16).double()
+    want = dy.to(torch.bfloat16).double() @ w16.t()
+    assert float((dx.double() - want).norm() / want.norm()) < 2e-6
+    exact = dy.double() @ p0.view(N1, N2).double().t()
+    assert float((dx.double() - exact).norm() / exact.norm()) < 4e-3
+    # the row-block form WITHOUT the input gradient (LPM_FA_FOLD=2 selects it for the A/B of the two streaming patterns) is the same update too
+    lib = ops._capi.load()
+    assert lib._lpm_factored_fold_supported(R, N1, N2) == 1 and lib._lpm_factored_fold_supported(R, N1 + 32, N2) == 0
+
+
 @pytest.mark.parametrize("B,T,D,K", [(3, 70, 256, 128), (3, 70, 256, 256), (2, 300, 1024, 256)])
 def test_vlad_aggregate_lazy_matches_the_finalize_form(B, T, D, K):
     """NetVladAttenCluster's tail (video_pooling_modules.py:1641-1658) as the lazily normalised d-major descriptor: the un-normalised sums

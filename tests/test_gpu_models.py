@@ -770,6 +770,43 @@ def test_cfg5_keeps_a_bf16_compute_copy_of_hidden1_weights():
     assert rel_l2(res[True][1], res[False][1]) <= 1e-3, "three Adam steps of 2e-4: the two masters stay together"
 
 
+def test_cfg5_input_gradient_folded_into_the_update_pass_does_not_change_the_step():
+    """FLAGS.hidden1_fold_input_gradient (round 6): with the compute copy and the early update, the projection's input
+    gradient comes out of hidden1_weights' update pass (lpm_factored_clip_adam_copy_dx) instead of lpm_proj_dx_w16.  Same operands (dy and
+    the old weight rounded once to bf16), another summation order: three steps end within fp32 rounding of the two-pass schedule, the copy is
+    still exactly bf16(master), and the update really did run inside the projection's backward."""
+    from learnablepoolingmethods_amd import FLAGS
+    dev = cuda()
+    cfg = O.OracleConfig(model="NetVladV1", vocab_size=3862, base_learning_rate=2e-4, **CFG5)
+    B = 16
+    x, nf, lab = O.make_synthetic_batch(B, 300, 1152, cfg.vocab_size, seed=8)
+    p = _well_conditioned({k: v.double() for k, v in O.init_params(cfg, 1152, seed=1008).items()})
+    res = {}
+    for fold in (True, False):
+        try:
+            FLAGS.hidden1_fold_input_gradient = fold
+            tr = _cfg5_trainer(B, dev, "bf16")
+            tr.build(x, nf, lab)
+            tr.store.load({"tower/" + k: v for k, v in p.items()})
+            losses, folded = [], []
+            for _ in range(3):
+                losses.append(float(tr.step(x, nf, lab)["loss"]))
+                folded.append(bool(tr.factored.dx_done))
+            torch.cuda.synchronize()
+            W = tr.arena.views["tower/hidden1_weights"]
+            assert folded == [fold] * 3, f"fold={fold}: the projection's backward took the {'other' if fold else 'folded'} route: {folded}"
+            assert tr.w16.refreshes == 1 and torch.equal(tr.w16.buf, W.detach().to(torch.bfloat16))
+            res[fold] = (losses, tr.arena.param.detach().clone())
+        finally:
+            FLAGS.reset()
+    print(f"[cfg-5 dx fold] losses folded {res[True][0]}, two passes {res[False][0]}")
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 2e-5 * abs(b)
+    # (Adam's first steps move every element by ~lr whatever its gradient's size: the few elements whose gradient changes sign within the
+    # summation-order noise differ by 2 lr per step -- 1e-6 of the elements at 4e-2 of a typical weight)
+    assert rel_l2(res[True][1], res[False][1]) <= 2e-4
+
+
 def test_cfg5_bf16_storage_survives_the_gamma_watch_switching_off():
     """once min |gamma| of input_bn falls below the watch's floor the closed-form gamma / beta gradients are switched
     off; under bf16 storage (frames written as operand tiles only, no input-gradient path) the step must then fall back to fp32

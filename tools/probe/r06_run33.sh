@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r06
+timeout 1700 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/r06/full_gpu_head2.log
+timeout 300 python __graft_entry__.py smoke > gpurun_out/r06/smoke_head2.log 2>&1
+timeout 600 python bench.py > gpurun_out/r06/bench33_default.json 2> gpurun_out/r06/bench33_default.err
