@@ -50,7 +50,11 @@ __device__ __forceinline__ float4 bn_preact(float4 v, const float* __restrict__ 
 constexpr int BNB_ROWS = 64;
 // column chunks (gridDim.y) of the two statistics passes: one per 256 float4 column groups, at most 8; the per-block partial sums of a
 // column are the same numbers whichever workgroup forms them
-static inline unsigned bn_col_chunks(int C) { const int c = (C / 4 + 255) / 256; return (unsigned)(c < 1 ? 1 : (c > 8 ? 8 : c)); }
+static inline unsigned bn_col_chunks(int C) {
+    static const int cap = [] { const char* e = getenv("LPM_BN_COL_CHUNKS"); return e ? atoi(e) : 8; }();      // 1: one chunk, the round-5 launch (A/B)
+    const int c = (C / 4 + 255) / 256;
+    return (unsigned)(c < 1 ? 1 : (c > cap ? (cap < 1 ? 1 : cap) : c));
+}
 // Threads are (row group, float4 column): 256 / (K/4) row groups when K/4 divides 256 (K = 256: four rows of 1 KB per
 // round), else one row group striding the columns; four rounds' loads are issued together.  (One thread per column walking
 // 64 rows with one 4-byte load in flight ran at 1.9 TB/s.)
