@@ -67,6 +67,14 @@ def batch_norm(x: torch.Tensor, is_training: bool, scope: str, pre_bias: torch.T
     return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
 
 
+def layer_norm_variables(scope: str, features: int, device):
+    """tf.contrib.layers.layer_norm's variables in its creation order: beta (zeros), gamma (ones) -> (gamma, beta)."""
+    with vs.variable_scope(scope):
+        beta = vs.get_variable("beta", [features], vs.zeros_initializer(), device=device)
+        gamma = vs.get_variable("gamma", [features], vs.ones_initializer(), device=device)
+    return gamma, beta
+
+
 def layer_norm(x: torch.Tensor, scope: str = "LayerNorm", residual: torch.Tensor = None, bias: torch.Tensor = None,
                relu: bool = False, image: bool = False, mask: torch.Tensor = None, mask_scale: float = 1.0, next_kernel=None) -> torch.Tensor:
     """tf.contrib.layers.layer_norm(act(x + bias) [+ residual]) with TF1 defaults: moments over ALL non-batch axes,

@@ -3124,6 +3124,58 @@ class _QKVAttnBNX3(torch.autograd.Function):
         return (dx.view(B, L, F) if dx is not None else None), dWq, dWk, dWv, dgamma, dbeta, None, None, None
 
 
+# LPM_ATTN_BLOCK_BN=0: MultiHeadAttentionBN + the encoder's first layer norm as separate autograd nodes (A/B)
+ATTN_BLOCK_BN = os.environ.get("LPM_ATTN_BLOCK_BN", "1") != "0"
+
+
+class _AttnBlockBNX3(torch.autograd.Function):
+    """TransformerEncoderMod up to its first layer norm (transformer_utils.py:444-454 with :589-677) as ONE node:
+    y = layer_norm(dropout(attention_bn(MHA_logits_bn(x, x)) Wo + bo) + x).  Forward: the four Functions' forwards unchanged (q/k/v GEMM,
+    logits_bn attention, attention_bn + output transform, bias + dropout + residual layer norm).  Backward: what the node buys is WHERE the
+    two gradients of x meet -- the residual's dz is the beta = 1 operand of the q/k/v input-gradient GEMM instead of a [B L, F] add pass that
+    autograd would insert (49 us for the frames of cfg-3) -- and the attention's [dq | dk | dv] image as in ops._QKVAttnBNX3."""
+
+    @staticmethod
+    def forward(ctx, x, Wq, Wk, Wv, lgamma, lbeta, lmm, lmv, g2, b2, mm2, mv2, Wo, bo, gamma, beta, num_heads, mask, mask_scale, image, site):
+        x = _f32(x, "attention block input").contiguous()
+        B, L, F = x.shape
+        N = Wq.shape[1]
+        cq, cm, co, cl = _SubCtx(), _SubCtx(), _SubCtx(), _SubCtx()
+        cq.needs_input_grad = (ctx.needs_input_grad[0],) + (True,) * 11
+        q, k, v = _QKVX3.forward(cq, x.view(B * L, F), Wq, Wk, Wv)
+        o = _MHACoreBN.forward(cm, q.view(B, L, N), k.view(B, L, N), v.view(B, L, N), lgamma, lbeta, lmm, lmv, num_heads, True)
+        att = _BNDenseX3.forward(co, o.view(B * L, N), g2, b2, mm2, mv2, Wo)
+        y = _ResidualLayerNorm.forward(cl, att.view(B, L, Wo.shape[1]), x, gamma, beta, bo, False, None, None, image=image, mask=mask,
+                                       mask_scale=mask_scale, site=site)
+        ctx.wq = Wq
+        _pack_subs(ctx, (cq, cm, co, cl))
+        ctx.shape = (B, L, F, N)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cq, cm, co, cl = _unpack_subs(ctx)
+        B, L, F, N = ctx.shape
+        first, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]       # first: the gradient of att through the dropout mask
+        do, dg2, db2, _, _, dWo = _BNDenseX3.backward(co, first.view(B * L, -1))
+        got = _MHACoreBN.backward(cm, do.view(B, L, N), image=True, site=_site("g", ctx.wq))
+        acc = dz.view(B * L, F) if cq.needs_input_grad[0] else None
+        if got[1] is None:
+            dx, dWq, dWk, dWv = _QKVX3.backward(cq, None, None, None, acc=acc, dy3=got[0])
+        else:
+            dx, dWq, dWk, dWv = _QKVX3.backward(cq, got[0].reshape(B * L, N), got[1].reshape(B * L, N), got[2].reshape(B * L, N), acc=acc)
+        return ((dx.view(B, L, F) if dx is not None else None), dWq, dWk, dWv, got[3], got[4], None, None, dg2, db2, None, None, dWo, dbo,
+                dgamma, dbeta, None, None, None, None, None)
+
+
+def attention_block_bn_x3(x, Wq, Wk, Wv, logits_bn, attention_bn, Wo, bo, gamma, beta, num_heads, mask, mask_scale, image=False, next_kernel=None):
+    """logits_bn / attention_bn: (gamma, beta, moving_mean, moving_variance) of the two batch norms.  mask: the dropout KEEP mask
+    (uint8 / bool [B, L, F]); image / next_kernel as ops.residual_layer_norm."""
+    site = _site("a", next_kernel) if (image and LN_IMAGE and next_kernel is not None) else None
+    return _AttnBlockBNX3.apply(x, Wq, Wk, Wv, *logits_bn, *attention_bn, Wo, bo, gamma, beta, int(num_heads), mask, float(mask_scale),
+                                bool(image) and LN_IMAGE, site)
+
+
 def qkv_attention_bn_ok(x, hidden, num_heads):
     """Whether MultiHeadAttentionBN's self-attention front runs as ops.qkv_attention_bn_x3 for this [B, L, F] input (training only)."""
     return bool(MHA_BN_GRAD_IMAGE and MHA_BN_ONEPASS and x.is_cuda and x.dim() == 3 and hidden % num_heads == 0 and hidden // num_heads in (8, 16)

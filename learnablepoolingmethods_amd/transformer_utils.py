@@ -215,6 +215,32 @@ class TransformerEncoderMod(modules.BaseModule):
             # output_transform's bias add and the dropout ride in the layer norm's passes (forward: z = (a + bias) * keep / (1 - rate) +
             # inputs; backward: the gradient of a leaves the layer norm masked and scaled, with the bias gradient) when the attention
             # block hands back its raw GEMM output
+            mha = self.multi_head_attention
+            rows = inputs.numel() // inputs.shape[-1]
+            if (ops.ATTN_BLOCK_BN and layers.use_split_gemm(inputs, rows, mha.hidden_size)
+                    and ops.qkv_attention_bn_ok(inputs, mha.hidden_size, mha.num_heads)
+                    and layers.use_split_gemm(inputs, rows, mha.feature_size) and mha.hidden_size % 8 == 0 and mha.feature_size % 8 == 0
+                    and ops.BN_DENSE_FUSED and inputs.dtype == torch.float32):
+                # the whole attention half of the encoder as ONE node (ops._AttnBlockBNX3): same kernels, same variables in the same
+                # order (q, k, v kernels; logits_bn; attention_bn; output_transform; LayerNorm), and the two gradients of ``inputs`` meet
+                # in the q/k/v input-gradient GEMM instead of in an add pass
+                dev, F_ = inputs.device, inputs.shape[-1]
+                wq, _ = layers.dense_variables("q", F_, mha.hidden_size, False, dev)
+                wk, _ = layers.dense_variables("k", F_, mha.hidden_size, False, dev)
+                wv, _ = layers.dense_variables("v", F_, mha.hidden_size, False, dev)
+                lbn = layers.bn_variables("logits_bn", inputs.shape[1], dev)
+                abn = layers.bn_variables("attention_bn", mha.hidden_size, dev)
+                wo, bo = layers.dense_variables("output_transform", mha.hidden_size, mha.feature_size, True, dev)
+                if dropout_mask is None:
+                    dropout_mask = torch.empty((*inputs.shape[:-1], mha.feature_size), dtype=torch.uint8, device=dev).bernoulli_(1.0 - rate)
+                elif dropout_mask.dtype not in (torch.bool, torch.uint8):
+                    dropout_mask = dropout_mask.ne(0)
+                image = bool(layers.use_split_gemm(inputs, rows, self.ff_network.filter_size)
+                             and ops.ffn_mod_x3_ok(inputs, self.ff_network.filter_size, self.ff_network.final_size))
+                gamma, beta = layers.layer_norm_variables("LayerNorm", mha.feature_size, dev)
+                attention = ops.attention_block_bn_x3(inputs, wq, wk, wv, lbn, abn, wo, bo, gamma, beta, mha.num_heads, dropout_mask,
+                                                      1.0 / (1.0 - rate), image=image, next_kernel=self.ff_network.first_kernel())
+                return self.ff_network.forward(attention)
             attention, bias = self.multi_head_attention.forward(inputs, inputs, defer_bias=True)
             if bias is not None:
                 if dropout_mask is None:

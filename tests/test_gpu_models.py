@@ -555,6 +555,7 @@ def test_logits_bn_attention_gradient_image_does_not_change_the_step():
     res = []
     for image in (True, False, True):
         flag0, ops.MHA_BN_GRAD_IMAGE = ops.MHA_BN_GRAD_IMAGE, image
+        blk0, ops.ATTN_BLOCK_BN = ops.ATTN_BLOCK_BN, False      # (the whole-attention-half node adds dz in a GEMM's beta = 1: another rounding)
         torch.manual_seed(77)               # the encoders' dropout masks (rate 0.9) come from the global generator
         try:
             tr = Trainer(registry.get_model("NetVladV2"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=13,
@@ -563,11 +564,44 @@ def test_logits_bn_attention_gradient_image_does_not_change_the_step():
             torch.cuda.synchronize()
             res.append((losses, tr.arena.grad.clone(), tr.arena.param.clone()))
         finally:
-            ops.MHA_BN_GRAD_IMAGE = flag0
+            ops.MHA_BN_GRAD_IMAGE, ops.ATTN_BLOCK_BN = flag0, blk0
     assert all(l == l for l in res[0][0])
     for other in res[1:]:
         assert other[0] == res[0][0]
         assert torch.equal(other[1], res[0][1]) and torch.equal(other[2], res[0][2])
+
+
+def test_v2_attention_half_as_one_node_does_not_change_the_step():
+    """TransformerEncoderMod's attention half as ONE autograd node (ops._AttnBlockBNX3, round 6: q/k/v GEMM, logits_bn attention,
+    attention_bn + output transform, bias + dropout + residual layer norm) against the node-by-node graph: the same kernels; the residual's
+    gradient enters the q/k/v input-gradient GEMM as its beta = 1 operand instead of through an add pass -- one rounding placed differently.
+    First step: identical loss (the forward is the same code), gradients to fp32 rounding; after four steps the parameters agree to the few
+    elements whose Adam step changes sign within that noise."""
+    from learnablepoolingmethods_amd import ops, registry
+    from learnablepoolingmethods_amd.train import Trainer
+    dev = cuda()
+    B, MF = 8, 150
+    x, nf, lab = O.make_synthetic_batch(B, MF, 1152, 50, seed=31, min_frames=100)
+    res = []
+    for block in (True, False):
+        blk0, ops.ATTN_BLOCK_BN = ops.ATTN_BLOCK_BN, block
+        torch.manual_seed(79)
+        try:
+            tr = Trainer(registry.get_model("NetVladV2"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=13,
+                         model_kwargs=dict(iterations=MF, cluster_size=32, hidden_size=64))
+            first = tr.step(x, nf, lab)["loss"].item()
+            g1 = tr.arena.grad.clone()
+            losses = [first] + [tr.step(x, nf, lab)["loss"].item() for _ in range(3)]
+            torch.cuda.synchronize()
+            res.append((losses, g1, tr.arena.param.clone()))
+        finally:
+            ops.ATTN_BLOCK_BN = blk0
+    (la, ga, pa), (lb, gb, pb) = res
+    assert la[0] == lb[0], "the forward is the same kernels in the same order"
+    assert rel_l2(ga, gb) < 2e-6
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 1e-4 * abs(b)
+    assert rel_l2(pa, pb) < 5e-3
 
 
 def test_input_bn_gradient_shortcut_matches_the_input_gradient_path():
