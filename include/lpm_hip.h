@@ -682,6 +682,12 @@ int lpm_layer_norm_act_mask_bwd(const float* dy, int64_t dy_batch_stride, const 
                                 const float* a, const float* bias, int relu, const unsigned char* mask, float mask_scale, int B, int L,
                                 int F, float* dz, float* da, float* dgamma, float* dbeta, float* dbias, const float* dr_extra,
                                 void* da_image, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
+/* ... with da_image in either operand format (fmt NULL: split-bf16 [hi | hi | lo]; fp16 two-product: [hi | lo] of value * scale, max |value|
+ * recorded) -- lpm_layer_norm_act_bwd_fmt's image for the masked form (round 6). */
+int lpm_layer_norm_act_mask_bwd_fmt(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats, const float* gamma,
+                                    const float* a, const float* bias, int relu, const unsigned char* mask, float mask_scale, int B, int L,
+                                    int F, float* dz, float* da, float* dgamma, float* dbeta, float* dbias, const float* dr_extra,
+                                    void* da_image, void* workspace, size_t workspace_bytes, const LpmOperandFormat* fmt, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4: multi-head attention core  o = softmax(scale * q k^T) v   per (batch, head)

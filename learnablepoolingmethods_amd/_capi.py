@@ -153,6 +153,7 @@ SIGNATURES = {
     "lpm_layer_norm_act_bwd": (_i, [_f, _l, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_layer_norm_act_mask_image_fwd": (_i, [_f, _f, _i, _f, _fl, _f, _f, _f, _i, _i, _i, _fl, _f, _l, _f, _f, _f, _f, _s, _f]),
     "lpm_layer_norm_act_mask_bwd": (_i, [_f, _l, _f, _f, _f, _f, _f, _i, _f, _fl, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _s, _f]),
+    "lpm_layer_norm_act_mask_bwd_fmt": (_i, [_f, _l, _f, _f, _f, _f, _f, _i, _f, _fl, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _s, _f, _f]),
     "lpm_mha_fwd": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),
     "lpm_mha_fwd_x3": (_i, [_f, _f, _f, _l, _i, _i, _i, _i, _fl, _f, _f, _f, _l, _f, _f]),
     "lpm_mha_bwd": (_i, [_f, _f, _f, _l, _f, _f, _l, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _f, _f, _l, _f, _f, _f, _f]),

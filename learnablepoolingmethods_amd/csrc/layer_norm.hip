@@ -576,6 +576,19 @@ extern "C" int lpm_layer_norm_act_mask_bwd(const float* dy, int64_t dy_batch_str
                                    da_image, workspace, workspace_bytes, stream, mask, mask_scale);
 }
 
+// ... with da_image in either operand format (round 6: the V2 encoder's attention half as one node hands the masked gradient straight to
+// attention_bn + output_transform's backward as its GEMMs' operand image)
+extern "C" int lpm_layer_norm_act_mask_bwd_fmt(const float* dy, int64_t dy_batch_stride, const float* z, const float* stats,
+                                               const float* gamma, const float* a, const float* bias, int relu, const unsigned char* mask,
+                                               float mask_scale, int B, int L, int F, float* dz, float* da, float* dgamma, float* dbeta,
+                                               float* dbias, const float* dr_extra, void* da_image, void* workspace, size_t workspace_bytes,
+                                               const LpmOperandFormat* fmt, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_REQUIRE(mask, LPM_ERR_BADARG, "lpm_layer_norm_act_mask_bwd: null keep mask");
+    return layer_norm_act_bwd_impl(dy, dy_batch_stride, z, stats, gamma, a, bias, relu, B, L, F, dz, da, dgamma, dbeta, dbias, dr_extra,
+                                   da_image, workspace, workspace_bytes, stream, mask, mask_scale, fmt);
+}
+
 extern "C" int lpm_layer_norm_bwd(const float* dy, const float* z, const float* stats, const float* gamma, int B, int L, int F,
                                   float* dz, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                   lpm_stream_t stream) {

@@ -2441,13 +2441,15 @@ class _BNDenseX3(torch.autograd.Function):
         return _mm3(f3, w3n, alpha=sa.inv if sa is not None else 1.0)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, do3=None):
+        """do3 (block Functions only): dout already as its gradient image, in the format of this layer's "g" site."""
         lib = _capi.load()
         x2, mean, var, gamma, f3, w3k = ctx.saved_tensors
         C, N = ctx.dims
         M = x2.shape[0]
         sa, sg = ctx.site_a, _site("g", ctx.wrefs[0])
-        do3 = _split_rows(dout.contiguous(), grad=True, site=sg)
+        if do3 is None:
+            do3 = _split_rows(dout.contiguous(), grad=True, site=sg)
         dW = _dw_x3(f3, do3, C, N, outs=[(ctx.wrefs[0], 0, N)], sa=sa, sg=sg)[0]
         df = _mm3(do3, w3k, alpha=sg.inv if sg is not None else 1.0)       # gradient of the batch norm's output [M, C]
         dx = torch.empty_like(x2)
@@ -2625,9 +2627,10 @@ class _ResidualLayerNorm(torch.autograd.Function):
         wsb = lib._lpm_layer_norm_workspace_bytes(B, F)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=z.device)
         if mask is not None:
-            lib.check(lib._lpm_layer_norm_act_mask_bwd(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
-                                                       1 if ctx.relu else 0, ptr(mask), ctx.mask_scale, B, L, F, ptr(dz), ptr(da), ptr(dgamma),
-                                                       ptr(dbeta), ptr(dbias), ptr(dr_extra), ptr(img), ptr(ws), wsb, stream_ptr()),
+            lib.check(lib._lpm_layer_norm_act_mask_bwd_fmt(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
+                                                           1 if ctx.relu else 0, ptr(mask), ctx.mask_scale, B, L, F, ptr(dz), ptr(da), ptr(dgamma),
+                                                           ptr(dbeta), ptr(dbias), ptr(dr_extra), ptr(img), ptr(ws), wsb,
+                                                           site.fmt if site is not None else None, stream_ptr()),
                       "lpm_layer_norm_act_mask_bwd")
         else:
             lib.check(lib._lpm_layer_norm_act_bwd_fmt(ptr(dy), dy.stride(0), ptr(z), ptr(stats), ptr(gamma), ptr(a), ptr(bias),
@@ -3126,6 +3129,7 @@ class _QKVAttnBNX3(torch.autograd.Function):
 
 # LPM_ATTN_BLOCK_BN=0: MultiHeadAttentionBN + the encoder's first layer norm as separate autograd nodes (A/B)
 ATTN_BLOCK_BN = os.environ.get("LPM_ATTN_BLOCK_BN", "1") != "0"
+ATTN_BLOCK_BN_LN_IMAGE = os.environ.get("LPM_ATTN_BLOCK_LN_IMAGE", "1") != "0"      # "0": the masked gradient in fp32 + an operand-split pass (A/B)
 
 
 class _AttnBlockBNX3(torch.autograd.Function):
@@ -3156,8 +3160,13 @@ class _AttnBlockBNX3(torch.autograd.Function):
     def backward(ctx, dy):
         cq, cm, co, cl = _unpack_subs(ctx)
         B, L, F, N = ctx.shape
-        first, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]       # first: the gradient of att through the dropout mask
-        do, dg2, db2, _, _, dWo = _BNDenseX3.backward(co, first.view(B * L, -1))
+        if ATTN_BLOCK_BN_LN_IMAGE:
+            # the gradient of att through the dropout mask leaves the layer norm as the operand image of the output transform's GEMMs
+            img, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy, da_image=True, site=_site("g", co.wrefs[0]))[:5]
+            do, dg2, db2, _, _, dWo = _BNDenseX3.backward(co, None, do3=img)
+        else:
+            first, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]
+            do, dg2, db2, _, _, dWo = _BNDenseX3.backward(co, first.view(B * L, -1))
         got = _MHACoreBN.backward(cm, do.view(B, L, N), image=True, site=_site("g", ctx.wq))
         acc = dz.view(B * L, F) if cq.needs_input_grad[0] else None
         if got[1] is None:
