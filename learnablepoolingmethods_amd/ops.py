@@ -1155,8 +1155,10 @@ class _VladAggregate(torch.autograd.Function):
     """Similarities given (no softmax): NetVladAttenCluster tail, video_pooling_modules.py:1641-1658."""
 
     @staticmethod
-    def forward(ctx, sims, x, centres, T, kmajor, lazy=False):
+    def forward(ctx, sims, x, centres, T, kmajor, lazy=False, grad_join=None):
+        """grad_join (ops.GradJoin, accepted by the frame encoder's node): the gradient of x goes there instead of to autograd."""
         lib = _capi.load()
+        ctx.join = grad_join if (grad_join is not None and grad_join.accepted) else None
         x = _rows(x, "inputs")
         M, D = x.shape
         K = centres.shape[1]
@@ -1221,7 +1223,10 @@ class _VladAggregate(torch.autograd.Function):
         else:
             dsims, dx, dcentres = _aggregate_bwd(lib, dout.contiguous(), nrm, asum, colsq, csq, gsq, sims2, None, None, x, centres,
                                                  B, T, D, K, flags, kmajor)
-        return dsims.reshape(sshape), dx, dcentres, None, None, None
+        if ctx.join is not None and dx is not None and ctx.needs_input_grad[1]:
+            ctx.join.put(dx)                      # (the encoder's node, which runs after this one, adds it to the frames' other gradient)
+            dx = None
+        return dsims.reshape(sshape), dx, dcentres, None, None, None, None
 
 
 def vlad_aggregate_lazy_ok(T, D, K):
@@ -1231,12 +1236,44 @@ def vlad_aggregate_lazy_ok(T, D, K):
             and K % 32 == 0 and K <= 1024)
 
 
-def vlad_aggregate(sims, x, centres, max_frames, kmajor=False, lazy=False):
+class GradJoin:
+    """One tensor read by TWO nodes of one module, handed to both explicitly (NetVladAttenCluster: the frames feed the frame encoder AND the
+    aggregation, video_pooling_modules.py:1623-1658).  Autograd would add the two gradients in a pass of its own ([24 000, 1 024] at
+    cfg-3: 49 us).  The encoder's output feeds the aggregation, so in every backward pass the aggregation's node runs FIRST: it ``put``s its
+    gradient of the frames here instead of returning it, and the encoder's attention-half node (ops._AttnBlockBNX3) -- which ``accept``ed
+    the join in its forward -- takes it as the second gradient of its residual tensor: added on the layer-norm backward's store, carried
+    into the q/k/v input-gradient GEMM's beta = 1 operand.  Not accepted (the encoder took another path): the aggregation returns its
+    gradient to autograd as always."""
+
+    puts = 0                 # (diagnostics / tests: gradients that took this route in the process)
+
+    def __init__(self):
+        self.accepted = False
+        self.dx = None
+
+    def accept(self):
+        self.accepted, self.dx = True, None
+
+    def put(self, dx):
+        if self.dx is not None:
+            raise LpmError("GradJoin: a second gradient arrived before the first was taken (two backward passes over one forward?)")
+        self.dx = dx
+        GradJoin.puts += 1
+
+    def take(self):
+        dx, self.dx = self.dx, None
+        return dx
+
+
+GRAD_JOIN = os.environ.get("LPM_GRAD_JOIN", "1") != "0"        # "0": autograd adds the frames' two gradients (A/B)
+
+
+def vlad_aggregate(sims, x, centres, max_frames, kmajor=False, lazy=False, grad_join=None):
     """lazy (d-major only; vlad_aggregate_lazy_ok shapes): the result is the LAZILY NORMALISED descriptor -- the un-normalised residual sums
     [B, D * K] carrying ``_lpm_row_scale`` [B, K] and ``_lpm_scale_ks`` = K: descriptor[b, d * K + k] = result[b, d * K + k] * scale[b, k]
     (video_pooling_modules.py:1655-1658).  ops.projection_parts applies the scale where it reads the operand; the gradient it returns is the
     gradient with respect to the normalised descriptor.  Everybody else goes through ops.materialise."""
-    return _VladAggregate.apply(sims, x, centres, int(max_frames), bool(kmajor), bool(lazy))
+    return _VladAggregate.apply(sims, x, centres, int(max_frames), bool(kmajor), bool(lazy), grad_join)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -3140,7 +3177,12 @@ class _AttnBlockBNX3(torch.autograd.Function):
     autograd would insert (49 us for the frames of cfg-3) -- and the attention's [dq | dk | dv] image as in ops._QKVAttnBNX3."""
 
     @staticmethod
-    def forward(ctx, x, Wq, Wk, Wv, lgamma, lbeta, lmm, lmv, g2, b2, mm2, mv2, Wo, bo, gamma, beta, num_heads, mask, mask_scale, image, site):
+    def forward(ctx, x, Wq, Wk, Wv, lgamma, lbeta, lmm, lmv, g2, b2, mm2, mv2, Wo, bo, gamma, beta, num_heads, mask, mask_scale, image, site,
+                grad_join=None):
+        ctx.join = None
+        if grad_join is not None and GRAD_JOIN and ctx.needs_input_grad[0] and x.dtype == torch.float32:
+            grad_join.accept()                    # a second reader of x (ops.vlad_aggregate) will leave its gradient there
+            ctx.join = grad_join
         x = _f32(x, "attention block input").contiguous()
         B, L, F = x.shape
         N = Wq.shape[1]
@@ -3160,12 +3202,15 @@ class _AttnBlockBNX3(torch.autograd.Function):
     def backward(ctx, dy):
         cq, cm, co, cl = _unpack_subs(ctx)
         B, L, F, N = ctx.shape
+        extra = ctx.join.take() if ctx.join is not None else None        # the aggregation's gradient of the same frames (ops.GradJoin)
+        if extra is not None:
+            extra = extra.reshape(B, L, F).contiguous()
         if ATTN_BLOCK_BN_LN_IMAGE:
             # the gradient of att through the dropout mask leaves the layer norm as the operand image of the output transform's GEMMs
-            img, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy, da_image=True, site=_site("g", co.wrefs[0]))[:5]
+            img, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy, dr_extra=extra, da_image=True, site=_site("g", co.wrefs[0]))[:5]
             do, dg2, db2, _, _, dWo = _BNDenseX3.backward(co, None, do3=img)
         else:
-            first, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy)[:5]
+            first, dz, dgamma, dbeta, dbo = _ResidualLayerNorm.backward(cl, dy, dr_extra=extra)[:5]
             do, dg2, db2, _, _, dWo = _BNDenseX3.backward(co, first.view(B * L, -1))
         got = _MHACoreBN.backward(cm, do.view(B, L, N), image=True, site=_site("g", ctx.wq))
         acc = dz.view(B * L, F) if cq.needs_input_grad[0] else None
@@ -3174,15 +3219,16 @@ class _AttnBlockBNX3(torch.autograd.Function):
         else:
             dx, dWq, dWk, dWv = _QKVX3.backward(cq, got[0].reshape(B * L, N), got[1].reshape(B * L, N), got[2].reshape(B * L, N), acc=acc)
         return ((dx.view(B, L, F) if dx is not None else None), dWq, dWk, dWv, got[3], got[4], None, None, dg2, db2, None, None, dWo, dbo,
-                dgamma, dbeta, None, None, None, None, None)
+                dgamma, dbeta, None, None, None, None, None, None)
 
 
-def attention_block_bn_x3(x, Wq, Wk, Wv, logits_bn, attention_bn, Wo, bo, gamma, beta, num_heads, mask, mask_scale, image=False, next_kernel=None):
+def attention_block_bn_x3(x, Wq, Wk, Wv, logits_bn, attention_bn, Wo, bo, gamma, beta, num_heads, mask, mask_scale, image=False, next_kernel=None,
+                          grad_join=None):
     """logits_bn / attention_bn: (gamma, beta, moving_mean, moving_variance) of the two batch norms.  mask: the dropout KEEP mask
     (uint8 / bool [B, L, F]); image / next_kernel as ops.residual_layer_norm."""
     site = _site("a", next_kernel) if (image and LN_IMAGE and next_kernel is not None) else None
     return _AttnBlockBNX3.apply(x, Wq, Wk, Wv, *logits_bn, *attention_bn, Wo, bo, gamma, beta, int(num_heads), mask, float(mask_scale),
-                                bool(image) and LN_IMAGE, site)
+                                bool(image) and LN_IMAGE, site, grad_join)
 
 
 def qkv_attention_bn_ok(x, hidden, num_heads):

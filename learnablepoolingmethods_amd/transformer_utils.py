@@ -208,7 +208,8 @@ class TransformerEncoderMod(modules.BaseModule):
         self.multi_head_attention = MultiHeadAttentionBN(feature_size, hidden_size, num_heads, attention_dropout, is_train)
         self.ff_network = FeedForwardNetworkMod(feature_size, ff_filter_size, ff_relu_dropout, is_train, scope_id, final_size)
 
-    def forward(self, inputs, dropout_mask=None, dropout_rate=None, **unused_params):
+    def forward(self, inputs, dropout_mask=None, dropout_rate=None, grad_join=None, **unused_params):
+        """grad_join (ops.GradJoin): ``inputs`` has a second reader behind this encoder; the attention-half node accepts its gradient."""
         rate = (1.0 - self.attention_dropout) if dropout_rate is None else dropout_rate
         if (self.is_train and 0.0 < rate < 1.0 and ops.LN_DROPOUT_FUSED and inputs.is_cuda and inputs.dim() == 3
                 and inputs.shape[-1] in ops.LN_FEATURES):
@@ -239,7 +240,8 @@ class TransformerEncoderMod(modules.BaseModule):
                              and ops.ffn_mod_x3_ok(inputs, self.ff_network.filter_size, self.ff_network.final_size))
                 gamma, beta = layers.layer_norm_variables("LayerNorm", mha.feature_size, dev)
                 attention = ops.attention_block_bn_x3(inputs, wq, wk, wv, lbn, abn, wo, bo, gamma, beta, mha.num_heads, dropout_mask,
-                                                      1.0 / (1.0 - rate), image=image, next_kernel=self.ff_network.first_kernel())
+                                                      1.0 / (1.0 - rate), image=image, next_kernel=self.ff_network.first_kernel(),
+                                                      grad_join=grad_join)
                 return self.ff_network.forward(attention)
             attention, bias = self.multi_head_attention.forward(inputs, inputs, defer_bias=True)
             if bias is not None:

@@ -63,10 +63,13 @@ class NetVladAttenCluster(modules.BaseModule):
                 feature_size=self.feature_size, hidden_size=self.encoder_hidden_size, num_heads=self.num_heads,
                 attention_dropout=self.dropout_ratio, ff_filter_size=self.filter_size, ff_relu_dropout=0.1,
                 is_train=self.is_training, scope_id="encode", final_size=self.cluster_size)
+            # (the frames are read twice, by the encoder and by the aggregation below: their two gradients meet inside the encoder's
+            # backward instead of in an add pass of autograd's -- ops.GradJoin)
+            join = ops.GradJoin() if (self.is_training and inputs.is_cuda) else None
             cluster_similarities = encoder_block.forward(reshaped_input, dropout_mask=dropout_mask,
-                                                         dropout_rate=dropout_rate)          # [B,S,K] :1638
+                                                         dropout_rate=dropout_rate, grad_join=join)          # [B,S,K] :1638
         cluster_centres = vs.get_variable("cluster_centers", [self.feature_size, self.cluster_size],
                                           vs.random_normal_initializer(1 / math.sqrt(self.feature_size)),
                                           device=inputs.device)                                # :1641-1643
         # sum_n sims * (x - c), intra-L2, flatten, L2 (:1646-1658; App. C6/C7) -- HIP kernel K2
-        return ops.vlad_aggregate(cluster_similarities, inputs, cluster_centres, self.max_frames, lazy=lazy)
+        return ops.vlad_aggregate(cluster_similarities, inputs, cluster_centres, self.max_frames, lazy=lazy, grad_join=join)

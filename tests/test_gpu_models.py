@@ -585,6 +585,7 @@ def test_v2_attention_half_as_one_node_does_not_change_the_step():
     res = []
     for block in (True, False):
         blk0, ops.ATTN_BLOCK_BN = ops.ATTN_BLOCK_BN, block
+        puts0 = ops.GradJoin.puts
         torch.manual_seed(79)
         try:
             tr = Trainer(registry.get_model("NetVladV2"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=13,
@@ -594,11 +595,23 @@ def test_v2_attention_half_as_one_node_does_not_change_the_step():
             losses = [first] + [tr.step(x, nf, lab)["loss"].item() for _ in range(3)]
             torch.cuda.synchronize()
             res.append((losses, g1, tr.arena.param.clone()))
+            # both streams' frames are read by their encoder and by their aggregation: two joins per step with the node, none without
+            assert ops.GradJoin.puts - puts0 == (8 if block else 0)
         finally:
             ops.ATTN_BLOCK_BN = blk0
     (la, ga, pa), (lb, gb, pb) = res
     assert la[0] == lb[0], "the forward is the same kernels in the same order"
     assert rel_l2(ga, gb) < 2e-6
+    # ... and without ops.GradJoin (the aggregation's gradient of the frames back through autograd's add) the node alone
+    join0, ops.GRAD_JOIN = ops.GRAD_JOIN, False
+    torch.manual_seed(79)
+    try:
+        tr = Trainer(registry.get_model("NetVladV2"), vocab_size=50, batch_size=B, base_learning_rate=1e-3, device=dev, seed=13,
+                     model_kwargs=dict(iterations=MF, cluster_size=32, hidden_size=64))
+        assert tr.step(x, nf, lab)["loss"].item() == la[0]
+        assert rel_l2(tr.arena.grad, ga) < 2e-6 and rel_l2(tr.arena.grad, gb) < 2e-6
+    finally:
+        ops.GRAD_JOIN = join0
     for a, b in zip(la, lb):
         assert abs(a - b) <= 1e-4 * abs(b)
     assert rel_l2(pa, pb) < 5e-3
