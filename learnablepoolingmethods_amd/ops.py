@@ -1250,18 +1250,22 @@ class GradJoin:
     def __init__(self):
         self.accepted = False
         self.dx = None
+        self.taken = False
 
     def accept(self):
-        self.accepted, self.dx = True, None
+        self.accepted, self.dx, self.taken = True, None, False
 
     def put(self, dx):
+        if self.taken:
+            raise LpmError("GradJoin: the accepting node's backward ran BEFORE the gradient it was to take arrived -- the two readers are not "
+                           "ordered as the module that joined them assumed; this gradient would have been lost")
         if self.dx is not None:
             raise LpmError("GradJoin: a second gradient arrived before the first was taken (two backward passes over one forward?)")
         self.dx = dx
         GradJoin.puts += 1
 
     def take(self):
-        dx, self.dx = self.dx, None
+        dx, self.dx, self.taken = self.dx, None, True
         return dx
 
 

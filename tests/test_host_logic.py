@@ -323,3 +323,24 @@ def test_compute_copy_tracks_every_writer_of_its_master():
     assert torch.equal(cc.tensor(W), W.detach().to(torch.bfloat16)) and cc.refreshes == 3
     cc.invalidate()                                             # a write through raw pointers (the generic update): told explicitly
     assert cc.current(W) is None and torch.equal(cc.tensor(W), W.detach().to(torch.bfloat16)) and cc.refreshes == 4
+
+
+def test_grad_join_hands_one_gradient_over_once_and_refuses_the_wrong_order():
+    """ops.GradJoin (round 6): the aggregation's gradient of the frames travels to the encoder's node outside autograd.  It is taken exactly
+    once; a gradient that arrives after the taker ran (the two readers ordered the other way round) or on top of an untaken one raises
+    instead of being dropped; a join nobody accepted is inert."""
+    from learnablepoolingmethods_amd import ops
+    j = ops.GradJoin()
+    assert not j.accepted and j.take() is None
+    j = ops.GradJoin()
+    j.accept()
+    n0 = ops.GradJoin.puts
+    g = object()
+    j.put(g)
+    assert ops.GradJoin.puts == n0 + 1 and j.take() is g and j.take() is None
+    with pytest.raises(ops.LpmError, match="BEFORE"):
+        j.put(object())
+    j.accept()                      # a new forward pass re-arms it
+    j.put(g)
+    with pytest.raises(ops.LpmError, match="second gradient"):
+        j.put(g)
