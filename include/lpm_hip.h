@@ -477,6 +477,10 @@ size_t lpm_bn_bwd_workspace_bytes(int M, int K);
 int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var, const float* gamma,
                float eps, int M, int K, float* dl, float* dgamma, float* dbeta, void* workspace,
                size_t workspace_bytes, lpm_stream_t stream);
+/* ... where the normalised tensor is stored as bf16 [M, K] (BASELINE configs[4]'s logits; 16-byte aligned): read in place -- the same
+ * numbers as lpm_bn_bwd on its fp32 copy, without the copy (round 6: 62 us per cfg-5 step) */
+int lpm_bn_bwd_x16(const float* dlt, const void* logits_bf16, const float* mean, const float* var, const float* gamma, float eps, int M, int K,
+                   float* dl, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Split-bf16 operand preparation for the encoder's dense layers (tf.layers.dense at

@@ -138,6 +138,7 @@ SIGNATURES = {
     "lpm_bn_rows_fwd": (_i, [_f, _i, _i, _f, _f, _fl, _fl, _i, _f, _f, _f, _f, _f, _f, _s, _f]),
     "lpm_bn_bwd_workspace_bytes": (_s, [_i, _i]),
     "lpm_bn_bwd": (_i, [_f, _f, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _s, _f]),
+    "lpm_bn_bwd_x16": (_i, [_f, _f, _f, _f, _f, _fl, _i, _i, _f, _f, _f, _f, _s, _f]),
     "lpm_split_rows": (_i, [_f, _l, _l, _i, _f, _i, _i, _f, _f]),
     "lpm_split_weight": (_i, [_f, _i, _i, _f, _f, _f]),
     "lpm_split_rows_relu_bwd_workspace_bytes": (_s, [_l, _i]),

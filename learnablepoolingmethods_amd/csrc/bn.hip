@@ -46,6 +46,14 @@ __device__ __forceinline__ float4 bn_preact(float4 v, const float* __restrict__ 
     return v;
 }
 
+// four consecutive elements of the normalised tensor: float4 number i4 of an fp32 matrix, or the same four of a bf16 matrix (8 bytes; the
+// bf16-storage configuration keeps its logits that way: round 6 -- a .float() copy of the [38 400, 512] logits cost 62 us per step)
+__device__ __forceinline__ float4 bn_load4(const float* __restrict__ base, int64_t i4, int bf16) {
+    if (!bf16) return reinterpret_cast<const float4*>(base)[i4];
+    const uint2 w = reinterpret_cast<const uint2*>(base)[i4];
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+}
+
 // pass 1 of the BN backward: per-block column partials of dlt and dlt*Lhat.
 constexpr int BNB_ROWS = 64;
 // column chunks (gridDim.y) of the two statistics passes: one per 256 float4 column groups, at most 8; the per-block partial sums of a
@@ -62,7 +70,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ logits,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ var, float eps, int M,
-                                                             int K, float* __restrict__ partial, const float* __restrict__ pb, int relu) {
+                                                             int K, float* __restrict__ partial, const float* __restrict__ pb, int relu,
+                                                             int lbf16) {
     __shared__ float4 red[2][256];
     const int r0 = blockIdx.x * BNB_ROWS;
     const int r1 = min(M, r0 + BNB_ROWS);
@@ -83,19 +92,18 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
             q.z += d.z * ((l.z - mu.z) * rs.z); q.w += d.w * ((l.w - mu.w) * rs.w);
         };
         const float4* dp = reinterpret_cast<const float4*>(dlt) + c4;
-        const float4* lp = reinterpret_cast<const float4*>(logits) + c4;
         int r = r0 + rg;
         for (; r + 3 * RG < r1; r += 4 * RG) {
             float4 d[4], l[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 d[u] = dp[(int64_t)(r + u * RG) * K4];
-                l[u] = lp[(int64_t)(r + u * RG) * K4];
+                l[u] = bn_load4(logits, (int64_t)(r + u * RG) * K4 + c4, lbf16);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) add(d[u], l[u]);
         }
-        for (; r < r1; r += RG) add(dp[(int64_t)r * K4], lp[(int64_t)r * K4]);
+        for (; r < r1; r += RG) add(dp[(int64_t)r * K4], bn_load4(logits, (int64_t)r * K4 + c4, lbf16));
         if (RG > 1) {
             red[0][tid] = s;
             red[1][tid] = q;
@@ -223,7 +231,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float eps, int M, int K,
                                                            float* __restrict__ dl, const float* __restrict__ pb, int relu,
-                                                           float* __restrict__ dbpart, unsigned short* __restrict__ dl3, const OperandFmt fmt) {
+                                                           float* __restrict__ dbpart, unsigned short* __restrict__ dl3, const OperandFmt fmt,
+                                                           int lbf16) {
     float vmax = 0.f;
     // dl3 != null: the result leaves as the GRADIENT image [M][3K] = [hi | hi | lo] of the dense layer in front instead of as fp32
     // pb / relu: the normalised tensor was act(logits + pb); dl is then the gradient of the RAW logits (masked where the ReLU was off)
@@ -266,19 +275,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         else reinterpret_cast<float4*>(dl)[i] = o;
     };
     const float4* dp = reinterpret_cast<const float4*>(dlt);
-    const float4* lp = reinterpret_cast<const float4*>(logits);
     int64_t i = i0;
     for (; i + 3 * stride < total4; i += 4 * stride) {          // four grid strides' loads together
         float4 d[4], l[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             d[u] = dp[i + u * stride];
-            l[u] = lp[i + u * stride];
+            l[u] = bn_load4(logits, i + u * stride, lbf16);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) one(i + u * stride, d[u], l[u]);
     }
-    for (; i < total4; i += stride) one(i, dp[i], lp[i]);
+    for (; i < total4; i += stride) one(i, dp[i], bn_load4(logits, i, lbf16));
     if (dbpart && i0 < stride)            // (fixed: the thread kept columns 4 (i0 % K4) ..; threads beyond the data wrote nothing: zero sums)
         *reinterpret_cast<float4*>(dbpart + (i0 / K4) * K + (i0 % K4) * 4) = bsum;
     if (dl3) of_amax_commit(fmt.amax, vmax);
@@ -596,11 +604,18 @@ static int bn_bwd_grid(int M, int K) {
 }  // namespace lpm
 static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_bias, int pre_relu, const float* mean, const float* var,
                        const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                       size_t workspace_bytes, lpm_stream_t stream, void* dl3 = nullptr, const LpmOperandFormat* fmt = nullptr);
+                       size_t workspace_bytes, lpm_stream_t stream, void* dl3 = nullptr, const LpmOperandFormat* fmt = nullptr,
+                       int logits_bf16 = 0);
 extern "C" int lpm_bn_bwd(const float* dlt, const float* logits, const float* mean, const float* var,
                           const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta,
                           void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
     return bn_bwd_impl(dlt, logits, nullptr, 0, mean, var, gamma, eps, M, K, dl, dgamma, dbeta, nullptr, workspace, workspace_bytes, stream);
+}
+// ... of a tensor stored as bf16 (the bf16-storage configuration's logits): read in place, no fp32 copy (round 6)
+extern "C" int lpm_bn_bwd_x16(const float* dlt, const void* logits_bf16, const float* mean, const float* var, const float* gamma, float eps, int M,
+                              int K, float* dl, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    return bn_bwd_impl(dlt, (const float*)logits_bf16, nullptr, 0, mean, var, gamma, eps, M, K, dl, dgamma, dbeta, nullptr, workspace,
+                       workspace_bytes, stream, nullptr, nullptr, 1);
 }
 // backward of lpm_bn_rows_act_fwd: x = the RAW dense output it normalised as act(x + pre_bias); dl = the gradient of x (the ReLU mask
 // applied), dbias = its column sums.  0 from lpm_bn_act_bwd_supported: the thread layout cannot keep columns fixed for this shape.
@@ -648,7 +663,7 @@ extern "C" int lpm_bn_act_bwd_image_fmt(const float* dlt, const float* x, const 
 }
 static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_bias, int pre_relu, const float* mean, const float* var,
                        const float* gamma, float eps, int M, int K, float* dl, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                       size_t workspace_bytes, lpm_stream_t stream, void* dl3, const LpmOperandFormat* fmt) {
+                       size_t workspace_bytes, lpm_stream_t stream, void* dl3, const LpmOperandFormat* fmt, int logits_bf16) {
     using namespace lpm;
     LPM_REQUIRE(dlt && logits && mean && var && (dl || dl3) && dgamma && dbeta && workspace, LPM_ERR_BADARG,
                 "lpm_bn_bwd: null pointer");
@@ -659,12 +674,13 @@ static int bn_bwd_impl(const float* dlt, const float* logits, const float* pre_b
     hipStream_t s = (hipStream_t)stream;
     const int nblk = (M + BNB_ROWS - 1) / BNB_ROWS;
     float* partial = (float*)workspace;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, bn_col_chunks(K)), dim3(256), 0, s, dlt, logits, mean, var, eps, M, K, partial, pre_bias, pre_relu);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, bn_col_chunks(K)), dim3(256), 0, s, dlt, logits, mean, var, eps, M, K, partial, pre_bias, pre_relu,
+                       logits_bf16);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((K + 15) / 16), dim3(1024), 0, s, partial, nblk, K, dgamma, dbeta);
     const int grid = bn_bwd_grid(M, K);
     float* dbpart = dbias ? partial + (size_t)nblk * 2 * K : nullptr;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, dlt, logits, mean, var, gamma, dgamma, dbeta,
-                       eps, M, K, dl, pre_bias, pre_relu, dbpart, (unsigned short*)dl3, operand_fmt(fmt));
+                       eps, M, K, dl, pre_bias, pre_relu, dbpart, (unsigned short*)dl3, operand_fmt(fmt), logits_bf16);
     if (dbias) {
         const int rows = (int)((int64_t)grid * 256 / (K / 4));
         if (rows > 4 * BN_CS_SLICES) {

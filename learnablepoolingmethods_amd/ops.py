@@ -973,12 +973,16 @@ class _NetVLAD(torch.autograd.Function):
                                                            ptr(dcentres), ptr(g0), ptr(ws), wsb, st), "lpm_vlad_aggregate_bwd_tiles_ld")
         dgamma = dbeta = dbias = None
         if use_bn and is_training:
-            lf = logits.float()
             dgamma, dbeta = _empty((K,), W), _empty((K,), W)
             wsb2 = lib._lpm_bn_bwd_workspace_bytes(M, K)
             ws2 = torch.empty(wsb2 // 4, dtype=torch.float32, device=W.device)
-            lib.check(lib._lpm_bn_bwd(ptr(dlt), ptr(lf), ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, K, ptr(dlt), ptr(dgamma), ptr(dbeta),
-                                      ptr(ws2), wsb2, st), "lpm_bn_bwd")
+            if logits.dtype == torch.bfloat16 and logits.is_contiguous():          # read in place (no fp32 copy of the [B T, K] logits)
+                lib.check(lib._lpm_bn_bwd_x16(ptr(dlt), ptr(logits), ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, K, ptr(dlt), ptr(dgamma),
+                                              ptr(dbeta), ptr(ws2), wsb2, st), "lpm_bn_bwd_x16")
+            else:
+                lf = logits.float().contiguous()
+                lib.check(lib._lpm_bn_bwd(ptr(dlt), ptr(lf), ptr(mean), ptr(var), ptr(gamma), BN_EPS, M, K, ptr(dlt), ptr(dgamma), ptr(dbeta),
+                                          ptr(ws2), wsb2, st), "lpm_bn_bwd")
             dl = dlt
         elif use_bn:
             lhat = (logits.float() - mean) * torch.rsqrt(var + BN_EPS)

@@ -1,0 +1,28 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+from learnablepoolingmethods_amd import registry
+from learnablepoolingmethods_amd.train import Trainer
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
+wl = bench.WORKLOADS[cfg]
+bench.set_flags(wl)
+dev = torch.device("cuda:0")
+tr = Trainer(registry.get_model(wl.get("model", "NetVladV1")), vocab_size=bench.VOCAB, batch_size=wl["batch"], device=dev, seed=1234,
+             model_kwargs=wl["model_kwargs"], **bench.TRAIN)
+raw, nf, labels = bench.synthetic_batch(wl["batch"], dev, seed=0)
+for _ in range(5):
+    tr.step(raw, nf, labels)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+    tr.step(raw, nf, labels)
+    torch.cuda.synchronize()
+rows = []
+for e in prof.events():
+    if e.name in ("aten::add", "aten::add_", "aten::to", "aten::_to_copy", "aten::copy_", "aten::cat", "aten::mul", "aten::sum", "aten::contiguous", "aten::clone") and e.device_time_total > 5:
+        st = [f for f in (e.stack or []) if "learnablepoolingmethods_amd" in f or "bench" in f][:3]
+        rows.append((e.device_time_total, e.name, str(e.input_shapes)[:80], " <- ".join(s.split("/")[-1] for s in st)))
+rows.sort(reverse=True)
+for r in rows[:30]:
+    print(f"{r[0]:8.1f} us  {r[1]:18s} {r[2]:80s} {r[3]}")
