@@ -822,6 +822,13 @@ size_t lpm_clip_adam_scratch_bytes(int64_t total, int ntensors);
 int lpm_multi_tensor_clip_adam(float* param, const float* grad, float* m, float* v, const int64_t* offsets,
                                int ntensors, int64_t total, float clip_norm, float lr, float beta1, float beta2,
                                float eps, int64_t step, float* scratch, lpm_stream_t stream);
+/* ... with the analytic gradient of each variable's L2 penalty (slim.l2_regularizer on the MoE weights, video_level_models.py:84-100:
+ * part of the loss whose gradient utils.py:170-189 clips), l2coef[t] * param, added on the fly in the norm pass and in the update pass
+ * (round 6).  l2coef: device array [ntensors], 0 = none; NULL = lpm_multi_tensor_clip_adam.  Equals `grad += l2coef[t] * param` in front of
+ * the plain entry point without that pass over the arena. */
+int lpm_multi_tensor_clip_adam_l2(float* param, const float* grad, float* m, float* v, const int64_t* offsets, const float* l2coef,
+                                  int ntensors, int64_t total, float clip_norm, float lr, float beta1, float beta2, float eps,
+                                  int64_t step, float* scratch, lpm_stream_t stream);
 
 /* a14 + a15 for a variable whose gradient is dW [N1, N2] = X^T DY, X [R, N1], DY [R, N2], R = the batch over ALL towers (the SUM of
  * utils.combine_gradients, utils.py:192-213, is the product over the concatenated rows): the hidden projection's weight

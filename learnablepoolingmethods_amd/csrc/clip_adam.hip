@@ -12,15 +12,34 @@ namespace lpm {
 
 constexpr int CA_CHUNK = 4096;   // == LPM_ARENA_ALIGN
 
+// which variable owns the chunk that starts at `base`: binary search on the (chunk-aligned) offsets
+__device__ __forceinline__ int ca_owner(const int64_t* __restrict__ offsets, int ntensors, int64_t base) {
+    int lo = 0, hi = ntensors;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= base) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+// l2 (optional, [ntensors]): the analytic gradient of a variable's L2 penalty, coefficient * w (slim.l2_regularizer on the MoE weights,
+// video_level_models.py:84-100: part of the loss whose gradient is clipped), formed HERE and in ca_apply_kernel from the parameter both
+// passes can read, instead of by an add pass over the gradient arena before them (round 6: 68 us per cfg-5 step for two MoE matrices)
 __global__ __launch_bounds__(256) void ca_chunk_sumsq_kernel(const float* __restrict__ g, int64_t total,
-                                                             float* __restrict__ chunk_ss) {
+                                                             float* __restrict__ chunk_ss, const float* __restrict__ p,
+                                                             const int64_t* __restrict__ offsets, int ntensors,
+                                                             const float* __restrict__ l2) {
     const int64_t base = (int64_t)blockIdx.x * CA_CHUNK;
+    const float c = l2 ? l2[ca_owner(offsets, ntensors, base)] : 0.f;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < CA_CHUNK / (256 * 4); ++i) {
         const int64_t e = base + (int64_t)(i * 256 + threadIdx.x) * 4;
         if (e + 3 < total) {
-            const float4 v = *reinterpret_cast<const float4*>(g + e);
+            float4 v = *reinterpret_cast<const float4*>(g + e);
+            if (c != 0.f) {
+                const float4 w = *reinterpret_cast<const float4*>(p + e);
+                v.x = fmaf(c, w.x, v.x); v.y = fmaf(c, w.y, v.y); v.z = fmaf(c, w.z, v.z); v.w = fmaf(c, w.w, v.w);
+            }
             s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
         }
     }
@@ -64,15 +83,11 @@ __global__ __launch_bounds__(256) void ca_apply_kernel(float* __restrict__ p, co
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        const int64_t* __restrict__ offsets, int ntensors,
                                                        int64_t total, const float* __restrict__ factor, float lr_t,
-                                                       float b1, float b2, float eps, int nt) {
+                                                       float b1, float b2, float eps, int nt, const float* __restrict__ l2) {
     const int64_t base = (int64_t)blockIdx.x * CA_CHUNK;
-    // which variable owns this chunk: binary search on the (chunk-aligned) offsets
-    int lo = 0, hi = ntensors;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (offsets[mid] <= base) lo = mid; else hi = mid;
-    }
+    const int lo = ca_owner(offsets, ntensors, base);
     const float f = factor[lo];
+    const float c2 = l2 ? l2[lo] : 0.f;
 #pragma unroll
     for (int i = 0; i < CA_CHUNK / (256 * 4); ++i) {
         const int64_t e = base + (int64_t)(i * 256 + threadIdx.x) * 4;
@@ -92,6 +107,9 @@ __global__ __launch_bounds__(256) void ca_apply_kernel(float* __restrict__ p, co
                 gg = *reinterpret_cast<const float4*>(g + e);
                 mm = *reinterpret_cast<float4*>(m + e);
                 vv = *reinterpret_cast<float4*>(v + e);
+            }
+            if (c2 != 0.f) {                 // + the L2 penalty's gradient (the same fmaf as the norm pass)
+                gg.x = fmaf(c2, pp.x, gg.x); gg.y = fmaf(c2, pp.y, gg.y); gg.z = fmaf(c2, pp.z, gg.z); gg.w = fmaf(c2, pp.w, gg.w);
             }
 #define LPM_ADAM1(c) adam_element(gg.c * f, pp.c, mm.c, vv.c, lr_t, b1, b2, eps);
             LPM_ADAM1(x) LPM_ADAM1(y) LPM_ADAM1(z) LPM_ADAM1(w)
@@ -116,9 +134,24 @@ extern "C" size_t lpm_clip_adam_scratch_bytes(int64_t total, int ntensors) {
     return (size_t)(nchunk + ntensors) * sizeof(float);
 }
 
+static int clip_adam_impl(float* param, const float* grad, float* m, float* v, const int64_t* offsets, const float* l2coef, int ntensors,
+                          int64_t total, float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
+                          lpm_stream_t stream);
 extern "C" int lpm_multi_tensor_clip_adam(float* param, const float* grad, float* m, float* v, const int64_t* offsets,
                                           int ntensors, int64_t total, float clip_norm, float lr, float beta1,
                                           float beta2, float eps, int64_t step, float* scratch, lpm_stream_t stream) {
+    return clip_adam_impl(param, grad, m, v, offsets, nullptr, ntensors, total, clip_norm, lr, beta1, beta2, eps, step, scratch, stream);
+}
+// ... with the gradient of each variable's L2 penalty, l2coef[t] * w (device array [ntensors]; 0 = none), added on the fly in the norm
+// pass and in the update pass: what `grad += l2coef[t] * param` in front of lpm_multi_tensor_clip_adam computes, without that pass
+extern "C" int lpm_multi_tensor_clip_adam_l2(float* param, const float* grad, float* m, float* v, const int64_t* offsets, const float* l2coef,
+                                             int ntensors, int64_t total, float clip_norm, float lr, float beta1, float beta2, float eps,
+                                             int64_t step, float* scratch, lpm_stream_t stream) {
+    return clip_adam_impl(param, grad, m, v, offsets, l2coef, ntensors, total, clip_norm, lr, beta1, beta2, eps, step, scratch, stream);
+}
+static int clip_adam_impl(float* param, const float* grad, float* m, float* v, const int64_t* offsets, const float* l2coef, int ntensors,
+                          int64_t total, float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
+                          lpm_stream_t stream) {
     using namespace lpm;
     LPM_REQUIRE(param && grad && m && v && offsets && scratch, LPM_ERR_BADARG, "lpm_multi_tensor_clip_adam: null pointer");
     LPM_REQUIRE(ntensors > 0 && total > 0 && step >= 1, LPM_ERR_BADARG, "lpm_multi_tensor_clip_adam: bad sizes (step is 1-based)");
@@ -131,9 +164,10 @@ extern "C" int lpm_multi_tensor_clip_adam(float* param, const float* grad, float
     float* factor = scratch + nchunk;
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
     static const int adam_nt = [] { const char* e = getenv("LPM_ADAM_NT"); return (e && e[0] == '0') ? 0 : 1; }();
-    hipLaunchKernelGGL(ca_chunk_sumsq_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, grad, total, chunk_ss);
+    hipLaunchKernelGGL(ca_chunk_sumsq_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, grad, total, chunk_ss, (const float*)param, offsets, ntensors,
+                       l2coef);
     hipLaunchKernelGGL(ca_tensor_factor_kernel, dim3(ntensors), dim3(1024), 0, s, chunk_ss, offsets, clip_norm, factor);
     hipLaunchKernelGGL(ca_apply_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, param, grad, m, v, offsets, ntensors, total,
-                       factor, (float)lr_t, beta1, beta2, eps, adam_nt);
+                       factor, (float)lr_t, beta1, beta2, eps, adam_nt, l2coef);
     return check_launch("lpm_multi_tensor_clip_adam");
 }

@@ -100,6 +100,9 @@ FLAGS.define("hidden1_fold_input_gradient", False, "build extension, one tower w
              "default: the pass saves 60-165 us of the two kernels' 2.8 ms box to box and gives up the update stream's overlap with the rest of "
              "backward (~0.14 ms) -- cfg-5 5.431 -> 5.339 ms on one box, 5.275 -> 5.33 ms on another (profiles/r06_update_pass_fold.md).  "
              "LPM_FOLD_DX=0/1 overrides")
+FLAGS.define("fold_l2_into_update", True, "build extension, one tower on the GPU: the analytic gradient of the MoE weights' L2 penalties "
+             "(coefficient * w) is added inside the clip + Adam passes (lpm_multi_tensor_clip_adam_l2) instead of by an add pass over the "
+             "gradient arena in front of them.  False: the add pass (A/B; towers > 1 always add before the all-reduce)")
 FLAGS.define("direct_weight_gradients", True, "build extension: single-GPU training writes the encoders' dense-kernel gradients straight "
              "into the gradient arena from their producers (ops._dw_x3) instead of through autograd's .grad + a gather copy")
 FLAGS.define("hidden1_factored_max_towers", 4, "build extension: ... up to this many towers.  Both passes of the factored update multiply "

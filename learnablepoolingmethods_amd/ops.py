@@ -3489,13 +3489,22 @@ FactoredGradient._clip_adam_copy = _factored_clip_adam_copy
 
 
 def clip_adam_step(param, grad, m, v, offsets, ntensors, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8,
-                   scratch: Optional[torch.Tensor] = None):
+                   scratch: Optional[torch.Tensor] = None, l2: Optional[torch.Tensor] = None):
+    """l2 [ntensors] (device, fp32; optional): per-variable L2-penalty coefficients whose gradient, coefficient * w, the two passes add on
+    the fly (lpm_multi_tensor_clip_adam_l2) -- the caller then does NOT add it to ``grad`` itself."""
     lib = _capi.load()
     total = param.numel()
     if scratch is None:
         scratch = torch.empty(lib._lpm_clip_adam_scratch_bytes(total, ntensors) // 4, dtype=torch.float32, device=param.device)
     with _timed("clip_adam", (total, ntensors)):
-        lib.check(lib._lpm_multi_tensor_clip_adam(ptr(param), ptr(grad), ptr(m), ptr(v), ptr(offsets), ntensors, total,
-                                                  float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch),
-                                                  stream_ptr()), "lpm_multi_tensor_clip_adam")
+        if l2 is not None:
+            if l2.dtype != torch.float32 or l2.numel() != ntensors or not l2.is_contiguous():
+                raise LpmError("clip_adam_step: l2 must be a contiguous fp32 vector with one coefficient per variable")
+            lib.check(lib._lpm_multi_tensor_clip_adam_l2(ptr(param), ptr(grad), ptr(m), ptr(v), ptr(offsets), ptr(l2), ntensors, total,
+                                                         float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch),
+                                                         stream_ptr()), "lpm_multi_tensor_clip_adam_l2")
+        else:
+            lib.check(lib._lpm_multi_tensor_clip_adam(ptr(param), ptr(grad), ptr(m), ptr(v), ptr(offsets), ntensors, total,
+                                                      float(clip_norm), float(lr), beta1, beta2, eps, int(step), ptr(scratch),
+                                                      stream_ptr()), "lpm_multi_tensor_clip_adam")
     return scratch

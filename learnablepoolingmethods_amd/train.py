@@ -705,6 +705,26 @@ class Trainer:
                 raise RuntimeError("analytic L2 penalty on a variable the gather-mode arena does not gather")
             self.arena.l2[name] = self.arena.l2.get(name, 0.0) + self.reg_penalty * scale
         self._l2_regs = []
+        # One tower on the GPU: the penalties' gradients are formed inside the clip + Adam passes from the parameter they read anyway
+        # (lpm_multi_tensor_clip_adam_l2) instead of by add passes over the gradient arena (68 us per cfg-5 step for the MoE matrices).
+        # Towers > 1 keep the add: it has to be in the arena before the all-reduce leaves.
+        self._l2_fold = None
+        fold_l2 = FLAGS.fold_l2_into_update
+        if os.environ.get("LPM_L2_FOLD") in ("0", "1"):                # A/B
+            fold_l2 = os.environ["LPM_L2_FOLD"] == "1"
+        if (self.arena.l2 and fold_l2 and self.device.type == "cuda" and not self.sync.active and self.sharded is None
+                and not (self.factored is not None and self.arena.names[0] in self.arena.l2)):
+            key = tuple(sorted(self.arena.l2.items()))
+            if getattr(self, "_l2_key", None) != key:
+                vec = torch.zeros(len(self.arena.names), dtype=torch.float32)
+                for n, c in self.arena.l2.items():
+                    vec[self.arena.names.index(n)] = c
+                self._l2_vec, self._l2_key = vec.to(self.device), key
+            self._l2_fold = self._l2_vec
+            self._l2_folded = dict(self.arena.l2)      # (Trainer.gradient puts the penalty back for whoever asks for the raw gradient)
+            self.arena.l2 = {}               # (nothing left for ParameterArena.collect / gather_names to add)
+        else:
+            self._l2_folded = {}
         fg = self.factored
         if fg is not None:
             fg.clear()
@@ -738,6 +758,7 @@ class Trainer:
         lr = learning_rate(self.base_lr, self.global_step, model_input_raw.shape[0], self.num_towers,
                            self.lr_decay_examples, self.lr_decay)                               # :244-249
         self.global_step += 1
+        self._l2_lr = (lr, self.global_step)
         if self.sharded is not None:
             # route C: every other variable as usual, hidden1_weights on this rank's shard; its parameter all-gather stays in flight
             # until the next read of the variable (the projection of the next forward, a checkpoint, predict())
@@ -754,7 +775,8 @@ class Trainer:
             n1, k = a.offsets_host[1], a.views[a.names[0]].numel()
             if len(a.names) > 1:
                 self._tail_scratch = ops.clip_adam_step(a.param[n1:], a.grad[n1:], a.m[n1:], a.v[n1:], self._tail_offsets,
-                                                        len(a.names) - 1, self.clip, lr, self.global_step, scratch=self._tail_scratch)
+                                                        len(a.names) - 1, self.clip, lr, self.global_step, scratch=self._tail_scratch,
+                                                        l2=self._l2_fold[1:] if self._l2_fold is not None else None)
             early = self._early
             if early is not None and early["done"]:
                 assert early["lr"] == lr and early["step"] == self.global_step     # (the update ran inside backward with these)
@@ -767,7 +789,7 @@ class Trainer:
                 self.w16.invalidate()          # the generic update writes the master through raw pointers: the copy is rebuilt at its next use
             self.arena._scratch = ops.clip_adam_step(self.arena.param, self.arena.grad, self.arena.m, self.arena.v,
                                                      self.arena.offsets, len(self.arena.names), self.clip, lr,
-                                                     self.global_step, scratch=self.arena._scratch)  # :332-336
+                                                     self.global_step, scratch=self.arena._scratch, l2=self._l2_fold)  # :332-336
         self._join_update_stream()
         return {"loss": label_loss.detach(), "predictions": predictions.detach(), "learning_rate": lr,
                 "global_step": self.global_step}
@@ -834,7 +856,18 @@ class Trainer:
         if self.factored is not None and self.factored.pending and name == self.arena.names[0]:
             return self.factored.materialise().view(t.shape)
         a0, _ = self.arena.segment(name)
-        return self.arena.grad[a0:a0 + t.numel()].view(t.shape)
+        g = self.arena.grad[a0:a0 + t.numel()].view(t.shape)
+        coef = getattr(self, "_l2_folded", {}).get(name)
+        if coef:
+            # the L2 penalty's share, coefficient * w, was added inside the clip + Adam passes (FLAGS.fold_l2_into_update) from the weight
+            # BEFORE the update: w_old = w + lr_t m / (sqrt(v) + eps) with the moments the update left behind (exact to rounding)
+            b1, b2, eps = 0.9, 0.999, 1e-8
+            lr, step = self._l2_lr
+            lr_t = lr * math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
+            m = self.arena.m[a0:a0 + t.numel()].view(t.shape)
+            v = self.arena.v[a0:a0 + t.numel()].view(t.shape)
+            g = g + coef * (t.detach() + lr_t * m / (v.sqrt() + eps))
+        return g
 
     def _update_stream_for(self, fg):
         """The HIP stream hidden1_weights' early update runs on (FLAGS.hidden1_update_stream): it waits for everything queued so far on the

@@ -546,6 +546,50 @@ def test_clip_adam_matches_oracle():
         assert_close(M[o:o + p.numel()].reshape(p.shape), rm, tol=1e-5, what="adam m")
 
 
+def test_clip_adam_adds_the_l2_penalty_gradient_on_the_fly():
+    """lpm_multi_tensor_clip_adam_l2 (round 6): the gradient of a variable's L2 penalty, coefficient * w (slim.l2_regularizer on the MoE
+    weights, video_level_models.py:84-100; part of the loss whose gradient utils.py:170-189 clips), formed inside the norm pass and the
+    update pass -- against the fp64 oracle on grad + coefficient * w, and against the plain entry point behind an explicit add pass."""
+    from learnablepoolingmethods_amd import ops
+    from learnablepoolingmethods_amd.train import ARENA_ALIGN
+    dev = cuda()
+    g = torch.Generator().manual_seed(1)
+    shapes = [(700, 33), (5,), (9000,), (123, 7)]
+    scales = [3.0, 0.01, 1e-4, 1.0]
+    coefs = [0.0, 0.5, 30.0, 1e-2]                 # (the third variable's penalty decides whether it clips)
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    gs = [torch.randn(s, generator=g) * c for s, c in zip(shapes, scales)]
+    offs, cur = [], 0
+    for p in ps:
+        offs.append(cur)
+        cur += (p.numel() + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+    offs.append(cur)
+    P, G, M, V = (torch.zeros(cur, device=dev) for _ in range(4))
+    for p, gr, o in zip(ps, gs, offs):
+        P[o:o + p.numel()] = p.flatten().to(dev)
+        G[o:o + p.numel()] = gr.flatten().to(dev)
+    offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
+    l2 = torch.tensor(coefs, dtype=torch.float32, device=dev)
+    P2, M2, V2 = P.clone(), M.clone(), V.clone()
+    ref_p = [p.double() for p in ps]
+    ref_m = [torch.zeros_like(p).double() for p in ps]
+    ref_v = [torch.zeros_like(p).double() for p in ps]
+    for step in (1, 2, 3):
+        ops.clip_adam_step(P, G, M, V, offsets, len(ps), 1.0, 2e-4, step, l2=l2)
+        G2 = G.clone()
+        for c, p, o in zip(coefs, ps, offs):
+            G2[o:o + p.numel()].add_(P2[o:o + p.numel()], alpha=c)
+        ops.clip_adam_step(P2, G2, M2, V2, offsets, len(ps), 1.0, 2e-4, step)
+        cl = O.clip_gradient_norms({i: g_.double() + c * rp for i, (g_, c, rp) in enumerate(zip(gs, coefs, ref_p))}, 1.0)
+        for i in range(len(ps)):
+            ref_p[i], ref_m[i], ref_v[i] = O.adam_tf_update(ref_p[i], cl[i], ref_m[i], ref_v[i], 2e-4, step)
+    for p, rp, rm, o in zip(ps, ref_p, ref_m, offs):
+        assert_close(P[o:o + p.numel()].reshape(p.shape), rp, tol=1e-6, what="adam param (l2 on the fly)")
+        assert_close(M[o:o + p.numel()].reshape(p.shape), rm, tol=1e-5, what="adam m (l2 on the fly)")
+    assert_close(P, P2.double(), tol=1e-7, what="against the add pass + the plain entry point")
+    assert_close(M, M2.double(), tol=1e-6, what="m against the add pass + the plain entry point")
+
+
 @pytest.mark.parametrize("R,N1,N2,gscale", [(32, 1000, 64, 1.0), (80, 4096 + 96, 512, 1e-3), (128, 2048, 1024, 0.05), (160, 640, 128, 1.0)])
 def test_factored_clip_adam_matches_oracle(R, N1, N2, gscale):
     """lpm_factored_clip_adam: the hidden projection's weight update straight from the two factors of its gradient (dW = X^T DY is
