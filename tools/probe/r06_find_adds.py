@@ -20,7 +20,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 rows = []
 for e in prof.events():
-    if e.name in ("aten::add", "aten::add_", "aten::to", "aten::_to_copy", "aten::copy_", "aten::cat", "aten::mul", "aten::sum", "aten::contiguous", "aten::clone") and e.device_time_total > 5:
+    if e.name.startswith("aten::") and e.device_time_total > 4 and e.name not in ("aten::mm", "aten::addmm", "aten::matmul"):
         st = [f for f in (e.stack or []) if "learnablepoolingmethods_amd" in f or "bench" in f][:3]
         rows.append((e.device_time_total, e.name, str(e.input_shapes)[:80], " <- ".join(s.split("/")[-1] for s in st)))
 rows.sort(reverse=True)
