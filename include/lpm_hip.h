@@ -866,6 +866,11 @@ int lpm_factored_clip_adam_copy_dx(const void* xt, const void* dyt, const float*
                                    float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step, float* scratch,
                                    size_t scratch_bytes, lpm_stream_t stream);
 
+/* The keep mask of tf.layers.dropout (transformer_utils.py:450): mask[i] = 1 with probability keep_prob (16-bit resolution), 0 otherwise, from
+ * a counter-based hash of (seed, i) -- one store stream instead of torch's bernoulli_ (round 6).  n bytes, a multiple of 16; 16-byte aligned.
+ * The same (seed, n, keep_prob) gives the same mask.  The consumers are lpm_layer_norm_act_mask_image_fwd[_fmt] / lpm_layer_norm_act_mask_bwd[_fmt]. */
+int lpm_dropout_keep_mask(void* mask, int64_t n, float keep_prob, uint64_t seed, lpm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

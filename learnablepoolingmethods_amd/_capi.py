@@ -176,6 +176,7 @@ SIGNATURES = {
     "lpm_factored_fold_supported": (_i, [_i, _i, _i]),
     "lpm_factored_clip_adam": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _l, _f, _s, _f]),
     "lpm_multi_tensor_clip_adam": (_i, [_f, _f, _f, _f, _f, _i, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _f]),
+    "lpm_dropout_keep_mask": (_i, [_f, _l, _fl, C.c_uint64, _f]),
     "lpm_multi_tensor_clip_adam_l2": (_i, [_f, _f, _f, _f, _f, _f, _i, _l, _fl, _fl, _fl, _fl, _fl, _l, _f, _f]),
     "lpm_weight_pack": (_i, [_f, _i, _f]),
     "lpm_sum_splits": (_i, [_f, _i, _i, _i, _f, _f, _f, _i, _f]),          # (jobs: a HOST array of WeightPackJob)

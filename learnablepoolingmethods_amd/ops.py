@@ -3172,6 +3172,25 @@ class _QKVAttnBNX3(torch.autograd.Function):
         return (dx.view(B, L, F) if dx is not None else None), dWq, dWk, dWv, dgamma, dbeta, None, None, None
 
 
+DROPOUT_MASK_KERNEL = os.environ.get("LPM_DROPOUT_MASK_KERNEL", "1") != "0"       # "0": torch's bernoulli_ draws the keep masks (A/B)
+
+
+def dropout_keep_mask(shape, keep_prob, device):
+    """uint8 keep mask of tf.layers.dropout (1 = kept, probability keep_prob) for the layer norm that applies it (transformer_utils.py:450).
+    On the GPU one store-stream launch (lpm_dropout_keep_mask) seeded from torch's CPU generator -- torch.manual_seed makes runs repeatable;
+    elsewhere / switched off: torch's bernoulli_."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if DROPOUT_MASK_KERNEL and device.type == "cuda" and n % 16 == 0 and 0.0 < keep_prob <= 1.0:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) & ((1 << 63) - 1)
+        mask = torch.empty(tuple(shape), dtype=torch.uint8, device=device)
+        lib = _capi.load()
+        lib.check(lib._lpm_dropout_keep_mask(ptr(mask), n, float(keep_prob), seed, stream_ptr()), "lpm_dropout_keep_mask")
+        return mask
+    return torch.empty(tuple(shape), dtype=torch.uint8, device=device).bernoulli_(keep_prob)
+
+
 # LPM_ATTN_BLOCK_BN=0: MultiHeadAttentionBN + the encoder's first layer norm as separate autograd nodes (A/B)
 ATTN_BLOCK_BN = os.environ.get("LPM_ATTN_BLOCK_BN", "1") != "0"
 ATTN_BLOCK_BN_LN_IMAGE = os.environ.get("LPM_ATTN_BLOCK_LN_IMAGE", "1") != "0"      # "0": the masked gradient in fp32 + an operand-split pass (A/B)

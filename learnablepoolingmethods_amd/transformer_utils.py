@@ -233,7 +233,7 @@ class TransformerEncoderMod(modules.BaseModule):
                 abn = layers.bn_variables("attention_bn", mha.hidden_size, dev)
                 wo, bo = layers.dense_variables("output_transform", mha.hidden_size, mha.feature_size, True, dev)
                 if dropout_mask is None:
-                    dropout_mask = torch.empty((*inputs.shape[:-1], mha.feature_size), dtype=torch.uint8, device=dev).bernoulli_(1.0 - rate)
+                    dropout_mask = ops.dropout_keep_mask((*inputs.shape[:-1], mha.feature_size), 1.0 - rate, dev)
                 elif dropout_mask.dtype not in (torch.bool, torch.uint8):
                     dropout_mask = dropout_mask.ne(0)
                 image = bool(layers.use_split_gemm(inputs, rows, self.ff_network.filter_size)
@@ -246,7 +246,7 @@ class TransformerEncoderMod(modules.BaseModule):
             attention, bias = self.multi_head_attention.forward(inputs, inputs, defer_bias=True)
             if bias is not None:
                 if dropout_mask is None:
-                    dropout_mask = torch.empty(attention.shape, dtype=torch.uint8, device=attention.device).bernoulli_(1.0 - rate)
+                    dropout_mask = ops.dropout_keep_mask(attention.shape, 1.0 - rate, attention.device)
                 elif dropout_mask.dtype not in (torch.bool, torch.uint8):
                     dropout_mask = dropout_mask.ne(0)          # a KEEP mask handed in by a test / the parity step: non-zero = kept
                 image = bool(layers.use_split_gemm(attention, attention.numel() // attention.shape[-1], self.ff_network.filter_size)

@@ -1047,6 +1047,65 @@ def test_residual_layer_norm_with_a_dropout_between_dense_and_norm(B, L, F, relu
     assert_close(biasg.grad, bd.grad, tol=1e-4, what="layer_norm dbias")
 
 
+def test_dropout_keep_mask_is_a_repeatable_bernoulli_draw():
+    """lpm_dropout_keep_mask (round 6): the keep mask of tf.layers.dropout (transformer_utils.py:450, keep probability 0.1) as one launch
+    -- bytes are 0 / 1, the kept fraction is keep_prob to four standard deviations overall, per frame row and per feature column, a
+    neighbour's state says nothing about an element's, the same torch seed gives the same mask and another seed another one."""
+    from learnablepoolingmethods_amd import ops
+    dev = cuda()
+    B, L, F, p = 80, 300, 1024, 0.1
+    torch.manual_seed(5)
+    m1 = ops.dropout_keep_mask((B, L, F), p, dev)
+    m2 = ops.dropout_keep_mask((B, L, F), p, dev)
+    torch.manual_seed(5)
+    m1b = ops.dropout_keep_mask((B, L, F), p, dev)
+    assert m1.dtype == torch.uint8 and int(m1.max()) == 1 and int(m1.min()) == 0
+    assert torch.equal(m1, m1b) and not torch.equal(m1, m2)
+    k = m1.float()
+    n = k.numel()
+    sd = (p * (1 - p)) ** 0.5
+    assert abs(float(k.mean()) - p) < 4 * sd / n ** 0.5
+    assert float((k.mean(dim=2) - p).abs().max()) < 6 * sd / F ** 0.5                    # every frame row (24 000 of them: 6 sigma)
+    assert float((k.mean(dim=(0, 1)) - p).abs().max()) < 5 * sd / (B * L) ** 0.5          # every feature column
+    for a, b in ((k[..., 1:], k[..., :-1]), (k[:, 1:], k[:, :-1]), (m1.float(), m2.float())):
+        cov = float((a * b).mean()) - float(a.mean()) * float(b.mean())
+        assert abs(cov) < 5 * p * (1 - p) / a.numel() ** 0.5, "neighbouring elements / successive masks must be uncorrelated"
+    # other keep probabilities, 16-bit resolution
+    for q in (0.5, 0.9, 1.0):
+        assert abs(float(ops.dropout_keep_mask((64, 4096), q, dev).float().mean()) - q) < 4 * max((q * (1 - q)) ** 0.5, 1e-3) / (64 * 4096) ** 0.5 + 2e-5
+
+
+@pytest.mark.parametrize("B,L,F,fmt", [(3, 300, 1024, "fp16"), (2, 64, 128, "bf16x3"), (2, 300, 128, None)])
+def test_masked_layer_norm_backward_writes_the_gradient_image(B, L, F, fmt):
+    """lpm_layer_norm_act_mask_bwd_fmt (round 6): the gradient of the dense layer's raw output THROUGH the dropout mask leaves the layer
+    norm's backward as that layer's operand image (the V2 encoder's attention half as one node) -- bit for bit lpm_split_rows of the fp32
+    gradient the plain form returns, in the same operand format, with the same recorded max |x|; the residual's gradient with a second
+    gradient added on the way out (ops.GradJoin's share) is dz + extra."""
+    from learnablepoolingmethods_amd import _capi, ops
+    dev = cuda()
+    g = torch.Generator().manual_seed(B + L + F)
+    a, r, dy, extra = (torch.randn(B, L, F, generator=g).to(dev) for _ in range(4))
+    gamma, beta = (1 + 0.2 * torch.randn(F, generator=g)).to(dev), (0.1 * torch.randn(F, generator=g)).to(dev)
+    bias = (0.3 * torch.randn(F, generator=g)).to(dev)
+    keep = (torch.rand(B, L, F, generator=g) < 0.1).to(torch.uint8).to(dev)
+    ctx = ops._SubCtx()
+    ops._ResidualLayerNorm.forward(ctx, a, r, gamma, beta, bias, False, None, None, image=False, mask=keep, mask_scale=10.0, site=None)
+    plain = ops._ResidualLayerNorm.backward(ctx, dy)
+    da, dz = plain[0], plain[1]
+    amax_a = torch.zeros(_capi.LPM_OPERAND_AMAX_SUB * _capi.LPM_OPERAND_AMAX_STRIDE, device=dev)
+    amax_b = torch.zeros_like(amax_a)
+    mk = lambda amax: None if fmt is None else ops.OperandSite(fmt == "fp16", 2.0 ** 7, amax.data_ptr(), role="g")
+    want = ops._split_rows(da.reshape(B * L, F), grad=True, site=mk(amax_a))
+    got = ops._ResidualLayerNorm.backward(ctx, dy, dr_extra=extra, da_image=True, site=mk(amax_b))
+    assert got[0].dtype == want.dtype and tuple(got[0].shape) == tuple(want.shape)
+    assert torch.equal(got[0].view(torch.int16), want.view(torch.int16))
+    assert_close(got[1], (dz + extra).double(), tol=1e-6, what="residual gradient + the second gradient")
+    for i in (2, 3, 4):
+        assert torch.equal(got[i], plain[i])                # dgamma, dbeta, dbias: the same passes
+    if fmt is not None:
+        assert float(amax_b.max()) == float(amax_a.max()) == float(da.abs().max())
+
+
 @pytest.mark.parametrize("M,F,C,N", [(2400, 128, 512, 64), (24000, 1024, 4096, 256)])
 def test_ffn_mod_one_node(M, F, C, N):
     """FeedForwardNetworkMod up to its second dense layer, BN(relu(y W1 + b1)) W2 (transformer_utils.py:741-756), as ONE node
