@@ -112,6 +112,15 @@ int lpm_frame_apply(const float* raw, const int32_t* num_frames, int B, int max_
 int lpm_frame_apply_tiles(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
                           const float* scale, const float* shift, float* y, void* xt_video, int Dv, void* xt_audio, int Da,
                           lpm_stream_t stream);
+/* ... with the two column blocks as TWO contiguous matrices, y_video [B*S, Dv] and y_audio [B*S, Da] (round 6: NetVladV2, whose frame
+ * encoders and aggregations want whole rows -- a column slice of one [B*S, F] matrix cost a contiguous copy per stream, a second
+ * lpm_split_frames per stream and a concatenation of the two gradients), and lpm_frame_bn_bwd taking the gradient the same way. */
+int lpm_frame_apply_tiles_split(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S, const float* scale,
+                                const float* shift, float* y_video, float* y_audio, void* xt_video, int Dv, void* xt_audio, int Da,
+                                lpm_stream_t stream);
+int lpm_frame_bn_bwd_split(const float* dy_video, int64_t ldv, const float* dy_audio, int64_t lda, int Dv, const float* raw,
+                           const int32_t* num_frames, int B, int max_frames, int F, int S, const float* mean, const float* var, float eps,
+                           float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, lpm_stream_t stream);
 /* ... and the split-bf16 ROW tiles K1 reads (the layout of lpm_split_rows_tiles, lpm_row_tiles_bytes(B, S, D) each; xr_* may be
  * NULL), so that no pass over the fp32 matrix is needed between a3 and K1. */
 int lpm_frame_apply_tiles2(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,

@@ -46,8 +46,10 @@ SIGNATURES = {
     "lpm_frame_stats": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),
     "lpm_frame_apply": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f]),
     "lpm_frame_apply_tiles": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _i, _f]),
+    "lpm_frame_apply_tiles_split": (_i, [_f, _f, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _i, _f]),
     "lpm_frame_stats_nblk": (_i, [_i, _i]),
     "lpm_frame_bn_bwd": (_i, [_f, _l, _f, _f, _i, _i, _i, _i, _f, _f, _fl, _f, _f, _f, _s, _f]),
+    "lpm_frame_bn_bwd_split": (_i, [_f, _l, _f, _l, _i, _f, _f, _i, _i, _i, _i, _f, _f, _fl, _f, _f, _f, _s, _f]),
     "lpm_bn_fold": (_i, [_f, _i, _i, _l, _f, _f, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
     "lpm_assign_gemm_nblk": (_i, [_i]),
     "lpm_assign_gemm_fwd": (_i, [_f, _l, _f, _i, _i, _i, _i, _f, _f, _f]),

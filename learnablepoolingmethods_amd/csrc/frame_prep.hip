@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256) void frame_apply_tiles_kernel(const float* __r
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, float* __restrict__ y,
                                                                 uint4* __restrict__ xtv, int Dv,
-                                                                uint4* __restrict__ xta, int Da) {
+                                                                uint4* __restrict__ xta, int Da, float* __restrict__ y2) {
+    // y2 != null: the two column blocks leave as TWO contiguous matrices, y [B S, Dv] and y2 [B S, Da] (NetVladV2: each stream's encoder
+    // and aggregation want whole rows -- no strided slices, no contiguous copies of them)
     const int F4 = F / 4, NS = (S + 15) / 16;
     const int64_t total = (int64_t)B * NS * 2 * F4;
     for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
@@ -112,7 +114,10 @@ __global__ __launch_bounds__(256) void frame_apply_tiles_kernel(const float* __r
                 f = *reinterpret_cast<const float4*>(raw + ((int64_t)b * max_frames + idx) * F + c);
                 f.x = fmaf(f.x, sc.x, sh.x); f.y = fmaf(f.y, sc.y, sh.y);
                 f.z = fmaf(f.z, sc.z, sh.z); f.w = fmaf(f.w, sc.w, sh.w);
-                *reinterpret_cast<float4*>(y + ((int64_t)b * S + j) * F + c) = f;
+                const int64_t row = (int64_t)b * S + j;
+                if (!y2) *reinterpret_cast<float4*>(y + row * F + c) = f;
+                else if (c < Dv) *reinterpret_cast<float4*>(y + row * Dv + c) = f;
+                else *reinterpret_cast<float4*>(y2 + row * Da + (c - Dv)) = f;
             }
             v[0][e] = f.x; v[1][e] = f.y; v[2][e] = f.z; v[3][e] = f.w;
         }
@@ -141,7 +146,9 @@ __global__ __launch_bounds__(256) void frame_bn_bwd_partial_kernel(const float* 
                                                                    const float* __restrict__ raw,
                                                                    const int32_t* __restrict__ num_frames, int B,
                                                                    int max_frames, int F, int S, float step,
-                                                                   float* __restrict__ partial) {
+                                                                   float* __restrict__ partial, const float* __restrict__ dy2,
+                                                                   int64_t lddy2, int Dv) {
+    // dy2 != null: the gradient arrives as two matrices, columns [0, Dv) in dy and [Dv, F) in dy2 (lpm_frame_apply_tiles_split's outputs)
     const int r0 = blockIdx.x * FP_ROWS;
     const int rows = B * S;
     const int r1 = min(rows, r0 + FP_ROWS);
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void frame_bn_bwd_partial_kernel(const float* 
     for (int c = threadIdx.x; c < F; c += 256) {
         float s = 0.f, q = 0.f;
         for (int r = 0; r < r1 - r0; ++r) {
-            const float g = dy[(int64_t)(r0 + r) * lddy + c];
+            const float g = (dy2 && c >= Dv) ? dy2[(int64_t)(r0 + r) * lddy2 + (c - Dv)] : dy[(int64_t)(r0 + r) * lddy + c];
             s += g;
             q = fmaf(g, raw[base[r] + c], q);
         }
@@ -386,8 +393,25 @@ extern "C" int lpm_frame_apply_tiles(const float* raw, const int32_t* num_frames
     const int64_t total = (int64_t)B * ((S + 15) / 16) * 2 * (F / 4);
     const int64_t want = (total + 255) / 256;
     hipLaunchKernelGGL(frame_apply_tiles_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, raw,
-                       num_frames, B, max_frames, F, S, step, scale, shift, y, (uint4*)xt_video, Dv, (uint4*)xt_audio, Da);
+                       num_frames, B, max_frames, F, S, step, scale, shift, y, (uint4*)xt_video, Dv, (uint4*)xt_audio, Da, (float*)nullptr);
     return check_launch("lpm_frame_apply_tiles");
+}
+// ... with the two column blocks as two contiguous matrices y_video [B S, Dv] and y_audio [B S, Da] (round 6: NetVladV2)
+extern "C" int lpm_frame_apply_tiles_split(const float* raw, const int32_t* num_frames, int B, int max_frames, int F, int S,
+                                           const float* scale, const float* shift, float* y_video, float* y_audio, void* xt_video, int Dv,
+                                           void* xt_audio, int Da, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_FRAME_CHECK("lpm_frame_apply_tiles_split");
+    LPM_REQUIRE(y_video && y_audio && ((scale == nullptr) == (shift == nullptr)), LPM_ERR_BADARG, "lpm_frame_apply_tiles_split: bad pointers");
+    LPM_REQUIRE(Dv > 0 && Da > 0 && Dv + Da == F && Dv % 32 == 0 && Da % 32 == 0 && (((uintptr_t)y_video | (uintptr_t)y_audio) & 15) == 0,
+                LPM_ERR_UNSUPPORTED_SHAPE, "lpm_frame_apply_tiles_split: need Dv + Da == F, both multiples of 32, aligned outputs (F=%d Dv=%d Da=%d)",
+                F, Dv, Da);
+    const float step = 1.0f / (float)S;
+    const int64_t total = (int64_t)B * ((S + 15) / 16) * 2 * (F / 4);
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(frame_apply_tiles_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, raw,
+                       num_frames, B, max_frames, F, S, step, scale, shift, y_video, (uint4*)xt_video, Dv, (uint4*)xt_audio, Da, y_audio);
+    return check_launch("lpm_frame_apply_tiles_split");
 }
 
 // bf16 storage: see frame_apply_tiles_bf16_kernel.  y may be NULL (then the fp32 frames are not written at all); the tile buffers
@@ -443,10 +467,28 @@ extern "C" int lpm_frame_bn_bwd(const float* dy, int64_t lddy, const float* raw,
     const int nblk = fp_nblk(B, S);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(frame_bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, dy, lddy, raw, num_frames, B, max_frames, F, S,
-                       step, (float*)workspace);
+                       step, (float*)workspace, (const float*)nullptr, (int64_t)0, F);
     hipLaunchKernelGGL(frame_bn_bwd_reduce_kernel, dim3((F + 15) / 16), dim3(1024), 0, s, (const float*)workspace, nblk, F, mean,
                        var, eps, dgamma, dbeta);
     return check_launch("lpm_frame_bn_bwd");
+}
+// ... with the gradient as two matrices: dy_video [B S, Dv] (row stride ldv) and dy_audio [B S, F - Dv] (row stride lda)
+extern "C" int lpm_frame_bn_bwd_split(const float* dy_video, int64_t ldv, const float* dy_audio, int64_t lda, int Dv, const float* raw,
+                                      const int32_t* num_frames, int B, int max_frames, int F, int S, const float* mean, const float* var,
+                                      float eps, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, lpm_stream_t stream) {
+    using namespace lpm;
+    LPM_FRAME_CHECK("lpm_frame_bn_bwd_split");
+    LPM_REQUIRE(dy_video && dy_audio && mean && var && dgamma && dbeta && workspace && Dv > 0 && Dv < F && ldv >= Dv && lda >= F - Dv,
+                LPM_ERR_BADARG, "lpm_frame_bn_bwd_split: bad pointers / strides");
+    LPM_REQUIRE(workspace_bytes >= lpm_frame_stats_workspace_bytes(B, S, F), LPM_ERR_WORKSPACE, "lpm_frame_bn_bwd_split: workspace too small");
+    const float step = 1.0f / (float)S;
+    const int nblk = fp_nblk(B, S);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(frame_bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, dy_video, ldv, raw, num_frames, B, max_frames, F, S,
+                       step, (float*)workspace, dy_audio, lda, Dv);
+    hipLaunchKernelGGL(frame_bn_bwd_reduce_kernel, dim3((F + 15) / 16), dim3(1024), 0, s, (const float*)workspace, nblk, F, mean,
+                       var, eps, dgamma, dbeta);
+    return check_launch("lpm_frame_bn_bwd_split");
 }
 
 extern "C" int lpm_l2_normalize_rows(const float* x, int64_t rows, int F, float* y, lpm_stream_t stream) {

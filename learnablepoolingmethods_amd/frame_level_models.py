@@ -333,16 +333,26 @@ class NetVladV2(models.BaseModel):
         relu, gating, remove_diag = FLAGS.netvlad_relu, FLAGS.gating, FLAGS.gating_remove_diag
         dm = dropout_masks or {}
 
-        reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training)
-        vs.summary("input_bn", reshaped_input)
         max_frames, feature_size = iterations, model_input.shape[2]
         has_audio = feature_size > 1024
+        split = None
+        if (has_audio and add_batch_norm and vs.default_store().summaries is None and ops.frame_sample_bn_split_ok(model_input, 1024)):
+            # the two streams' blocks of the sampled, batch-normalised frames as two contiguous matrices straight from the frame-prep
+            # kernel (ops.frame_sample_bn_split): same values, same variables; no column slices, copies or gradient concatenation
+            bn = layers.bn_variables("input_bn", feature_size, model_input.device)
+            split = ops.frame_sample_bn_split(model_input, num_frames.reshape(-1), iterations, *bn, is_training, 1024)
+            reshaped_input = None
+        else:
+            reshaped_input = _sample_and_normalise(model_input, num_frames, iterations, add_batch_norm, is_training)
+            vs.summary("input_bn", reshaped_input)
 
         video_NetVLAD = video_pooling_modules.NetVladAttenCluster(1024, max_frames, cluster_size, add_batch_norm,
                                                                   is_training, "netvlad_rgb_scope")
         audio_NetVLAD = video_pooling_modules.NetVladAttenCluster(128, max_frames, cluster_size // 4, add_batch_norm,
                                                                   is_training, "netvlad_audio_scope")
-        if has_audio and reshaped_input.is_cuda and ops.V2_SPLIT_COLUMNS:
+        if split is not None:
+            rgb, audio = split
+        elif has_audio and reshaped_input.is_cuda and ops.V2_SPLIT_COLUMNS:
             # one contiguous copy per stream (the encoder and the aggregation both want whole rows); their gradients come back as ONE
             # concatenation instead of two zero-filled [M, 1152] buffers, two slice copies and an add
             # (the copies do not carry the views' shared-gradient slot -- ops._SplitColumns.backward then concatenates the two
@@ -356,7 +366,7 @@ class NetVladV2(models.BaseModel):
         # The video descriptor leaves its pooling LAZILY NORMALISED where the projection can take it that way: the un-normalised sums,
         # written once by the aggregation kernel, + one scale per (clip, cluster) -- no finalize pass, and no tf.concat either (the
         # projection reads the two streams' blocks where they are)
-        lazy_v = bool(FLAGS.netvlad_lazy_descriptor and reshaped_input.is_cuda and model_input.shape[0] <= 128 and hidden1_size % 512 == 0
+        lazy_v = bool(FLAGS.netvlad_lazy_descriptor and model_input.is_cuda and model_input.shape[0] <= 128 and hidden1_size % 512 == 0
                       and ops.vlad_aggregate_lazy_ok(max_frames, 1024, cluster_size))
         with vs.variable_scope("video_VLAD"):
             vlad_video = video_NetVLAD.forward(rgb, dropout_mask=dm.get("video"), dropout_rate=dropout_rate, lazy=lazy_v)   # :2437-2438

@@ -455,6 +455,71 @@ def frame_sample_bn(raw, num_frames, S, gamma=None, beta=None, moving_mean=None,
                                 bool(materialize))
 
 
+class _FrameSampleBNSplit(torch.autograd.Function):
+    """ops.frame_sample_bn with the rgb / audio column blocks as TWO contiguous matrices (round 6: NetVladV2 -- each stream's frame
+    encoder and aggregation take whole rows, so the column slices of one [B S, F] matrix cost a contiguous copy per stream, a second
+    frame-tile pass per stream because the copies were not the tensors the tiles were cached for, and a concatenation of the two gradients).
+    The same values bit for bit; the frame tiles written in the same pass are found for the two outputs (ops._cached_tiles)."""
+
+    @staticmethod
+    def forward(ctx, raw, num_frames, gamma, beta, moving_mean, moving_var, S, is_training, Dv):
+        lib = _capi.load()
+        raw = _f32(raw, "model_input").contiguous()
+        B, MF, F = raw.shape
+        Da = F - Dv
+        nf = num_frames.to(device=raw.device, dtype=torch.int32).contiguous()
+        if is_training:
+            nblk = lib._lpm_frame_stats_nblk(B, S)
+            partial = _empty((nblk, 2, F), raw)
+            lib.check(lib._lpm_frame_stats(ptr(raw), ptr(nf), B, MF, F, S, ptr(partial), stream_ptr()), "lpm_frame_stats")
+            mean, var, scale, shift = bn_fold(partial, nblk, F, B * S, gamma, beta, moving_mean, moving_var)
+        else:
+            scale, shift = folded_eval_affine(gamma, beta, moving_mean, moving_var)
+            scale, shift = scale.contiguous(), shift.contiguous()
+            mean, var = moving_mean.detach().clone(), moving_var.detach().clone()
+        yv, ya = _empty((B * S, Dv), raw), _empty((B * S, Da), raw)
+        xtv = torch.empty(lib._lpm_xt_bytes(B, S, Dv) // 4, dtype=torch.int32, device=raw.device)
+        xta = torch.empty(lib._lpm_xt_bytes(B, S, Da) // 4, dtype=torch.int32, device=raw.device)
+        lib.check(lib._lpm_frame_apply_tiles_split(ptr(raw), ptr(nf), B, MF, F, S, ptr(scale), ptr(shift), ptr(yv), ptr(ya), ptr(xtv), Dv,
+                                                   ptr(xta), Da, stream_ptr()), "lpm_frame_apply_tiles_split")
+        _XT_CACHE.clear()
+        _XT_CACHE.update(split=True, F=F, Dv=Dv, S=S, B=B, video=xtv, audio=xta, video_t=yv, audio_t=ya,
+                         video_ver=yv._version, audio_ver=ya._version)
+        ctx.S, ctx.Dv = S, Dv
+        ctx.save_for_backward(raw, nf, mean, var)
+        return yv, ya
+
+    @staticmethod
+    def backward(ctx, dv, da):
+        lib = _capi.load()
+        raw, nf, mean, var = ctx.saved_tensors
+        B, MF, F = raw.shape
+        Dv = ctx.Dv
+        M = B * ctx.S
+        dv = _rows(dv.contiguous(), "dy") if dv is not None else torch.zeros((M, Dv), dtype=torch.float32, device=raw.device)
+        da = _rows(da.contiguous(), "dy") if da is not None else torch.zeros((M, F - Dv), dtype=torch.float32, device=raw.device)
+        dgamma, dbeta = _empty((F,), raw), _empty((F,), raw)
+        wsb = lib._lpm_frame_stats_workspace_bytes(B, ctx.S, F)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=raw.device)
+        lib.check(lib._lpm_frame_bn_bwd_split(ptr(dv), dv.stride(0), ptr(da), da.stride(0), Dv, ptr(raw), ptr(nf), B, MF, F, ctx.S, ptr(mean),
+                                              ptr(var), BN_EPS, ptr(dgamma), ptr(dbeta), ptr(ws), wsb, stream_ptr()), "lpm_frame_bn_bwd_split")
+        return None, None, dgamma, dbeta, None, None, None, None, None
+
+
+FRAME_SPLIT = os.environ.get("LPM_FRAME_SPLIT", "1") != "0"      # "0": NetVladV2 slices one [B S, F] matrix (A/B)
+
+
+def frame_sample_bn_split_ok(raw, Dv):
+    return bool(FRAME_SPLIT and raw.is_cuda and raw.dim() == 3 and raw.dtype == torch.float32 and VLAD_PRECISION == "bf16x3"
+                and 0 < Dv < raw.shape[2] and Dv % 32 == 0 and (raw.shape[2] - Dv) % 32 == 0)
+
+
+def frame_sample_bn_split(raw, num_frames, S, gamma, beta, moving_mean, moving_var, is_training, Dv):
+    """-> (rgb [B*S, Dv], audio [B*S, F - Dv]): uniform frame sampling + input_bn (model_utils.py:101-122, frame_level_models.py:2265-2271)
+    with the two streams' blocks as separate contiguous matrices; gamma / beta receive ONE gradient each."""
+    return _FrameSampleBNSplit.apply(raw, num_frames, gamma, beta, moving_mean, moving_var, int(S), bool(is_training), int(Dv))
+
+
 # ----------------------------------------------------------------------------------------------
 # K1 + K2 (+K3): NetVLAD pooling
 # ----------------------------------------------------------------------------------------------
@@ -530,6 +595,15 @@ def _cached_tiles(x, B, T, D, rows=False, storage="f32"):
     tiles (K1's operand; bf16 storage only) instead of the frame tiles."""
     c = _XT_CACHE
     if not c or c["B"] != B or c["S"] != T or c.get("storage", "f32") != storage:
+        return None
+    if c.get("split"):                      # frame_sample_bn_split: two contiguous matrices, each with its own tiles
+        if rows:
+            return None
+        for which, Dw in (("video", c["Dv"]), ("audio", c["F"] - c["Dv"])):
+            t = c[which + "_t"]             # (held until the next frame_sample_bn: its memory cannot have been handed to anyone else)
+            if (D == Dw and x.data_ptr() == t.data_ptr() and tuple(x.shape) == tuple(t.shape) and x.is_contiguous()
+                    and t._version == c[which + "_ver"]):
+                return c[which]
         return None
     base = c["base"]()
     if base is None or x._base is not base or x.stride(0) != c["F"]:

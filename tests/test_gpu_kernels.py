@@ -485,6 +485,45 @@ def test_frame_sample_bn(B, MF, F, S):
     assert_close(mm, upd["input_bn/moving_mean"] * 0.001, tol=1e-4, what="moving_mean")
 
 
+@pytest.mark.parametrize("B,MF,S", [(3, 300, 300), (2, 90, 70), (5, 64, 64)])
+def test_frame_sample_bn_split_is_the_joint_form_in_two_matrices(B, MF, S):
+    """ops.frame_sample_bn_split (round 6; model_utils.py:101-122 + frame_level_models.py:2265-2271 for NetVladV2): the rgb / audio blocks
+    of the sampled, batch-normalised frames as two contiguous matrices -- bit for bit the column slices of the joint form, the same
+    moving statistics, the frame tiles of each found for it (and equal to lpm_split_frames of it), gamma / beta gradients bit for bit the
+    joint form's from the concatenated gradient."""
+    from learnablepoolingmethods_amd import _capi, ops
+    from learnablepoolingmethods_amd._capi import ptr, stream_ptr
+    dev = cuda()
+    F, Dv = 1152, 1024
+    x, nf, _ = O.make_synthetic_batch(B, MF, F, 10, seed=S)
+    g = torch.Generator().manual_seed(3)
+    gamma, beta = 1 + 0.2 * torch.randn(F, generator=g), 0.1 * torch.randn(F, generator=g)
+    dv, da = torch.randn(B * S, Dv, generator=g).to(dev), torch.randn(B * S, F - Dv, generator=g).to(dev)
+    res = []
+    for split in (False, True):
+        gg, bg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+        mm, mv = torch.zeros(F, device=dev), torch.ones(F, device=dev)
+        if split:
+            assert ops.frame_sample_bn_split_ok(x.to(dev), Dv)
+            yv, ya = ops.frame_sample_bn_split(x.to(dev), nf.to(dev), S, gg, bg, mm, mv, True, Dv)
+            assert yv.is_contiguous() and ya.is_contiguous()
+            lib = _capi.load()
+            for t, D in ((yv, Dv), (ya, F - Dv)):
+                got = ops._cached_tiles(t, B, S, D)
+                assert got is not None, "the tiles written with the matrices must be found for them"
+                want = torch.empty(lib._lpm_xt_bytes(B, S, D) // 4, dtype=torch.int32, device=dev)
+                lib.check(lib._lpm_split_frames(ptr(t), t.stride(0), B, S, D, ptr(want), stream_ptr()), "lpm_split_frames")
+                assert torch.equal(got, want)
+            torch.autograd.backward([yv, ya], [dv, da])
+        else:
+            y = ops.frame_sample_bn(x.to(dev), nf.to(dev), S, gg, bg, mm, mv, True)
+            yv, ya = y[:, :Dv], y[:, Dv:]
+            y.backward(torch.cat([dv, da], dim=1))
+        res.append((yv.detach().clone(), ya.detach().clone(), mm, mv, gg.grad.clone(), bg.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,MF,F,S", [(3, 300, 1152, 300), (2, 90, 1024, 70), (2, 64, 1152, 64)])
 def test_frame_sample_bn_tile_copies_are_the_split_of_its_output(B, MF, F, S, monkeypatch):
     """lpm_frame_apply_tiles2: the frame tiles (K2's operand) and row tiles (K1's operand) written with the fp32 matrix are, bit
